@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""Headline benchmark: MCTS simulations / second of AlphaZero self-play on 15x15 Gomoku,
+800 simulations per move, 512 lock-stepped games per GPU (BASELINE.json configs[3]:
+4096 games over 8 GPUs), random-init PolicyValueNet (torch.manual_seed(0)), fp32.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one move of every game on the GPU: n_playout simulation steps (select ->
+evaluate -> expand/backup for all games), pi from the root visits, a move drawn and applied,
+tree reuse; finished games are replaced by fresh ones so the batch stays full.  Games are
+independent, so N GPUs play N x 512 games with no collective in the timed region (weak
+scaling); rank 0 prints ONE JSON line.
+
+Also on the line:
+  roofline      for the dominant kernel region (the policy+value forward of the leaf batch,
+                the path's one dense contraction): algorithmic FLOPs F(S) = 188416*S + 8*S^2 +
+                128 per position x positions per launch / its average duration
+                from HIP events on the launch stream, against the fp32 matrix peak.
+  cpu_baseline  the oracle (Python restatement of the reference, batch-1 torch CPU forward,
+                one thread per process) timed on this host's cores on a bounded sample of
+                the same workload.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+BOARD, N_ROW, N_PLAYOUT, GAMES_PER_GPU, C_PUCT, TEMPERATURE = 15, 5, 800, 512, 5.0, 1.0
+PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_position(cells):
+    return 188416 * cells + 8 * cells * cells + 128
+
+
+def tree_bytes_per_sim(scanned, created, depth):
+    """12 B per scanned child, 16 B per created child, 24 B per backed-up node,
+    64 B of root bitboards."""
+    return 12.0 * scanned + 16.0 * created + 24.0 * (depth + 1.0) + 64.0
+
+
+# --------------------------------------------------------------------------- CPU baseline
+def cpu_worker(seconds, board, n_row, n_playout):
+    """One process of the CPU baseline: the oracle plays self-play moves of the same
+    configuration (fresh game, reference mode: one simulation at a time, batch-1 forward)."""
+    import numpy as np
+    import torch
+    torch.set_num_threads(1)
+    from oracle.evaluators import NetEvaluator
+    from oracle.gomoku_ref import RefGomoku
+    from oracle.mcts_ref import RefPlayer
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    torch.manual_seed(0)
+    net = PolicyValueNet(board)
+    weights = {k: v.detach().numpy() for k, v in net.state_dict().items()}
+    evaluator = NetEvaluator(weights, board)
+    np.random.seed(os.getpid() % 65536)
+    env = RefGomoku(board, n_row)
+    player = RefPlayer(evaluator, n_playout=n_playout, c_puct=C_PUCT, is_selfplay=True)
+    search = player.mcts
+    sims = 0
+    t0 = time.perf_counter()
+    deadline = t0 + seconds
+    with torch.no_grad():
+        while time.perf_counter() < deadline:
+            # simulations in chunks so the budget is respected on slow hosts
+            chunk = 50
+            for _ in range(0, n_playout, chunk):
+                for _ in range(chunk):
+                    search.playout(env.clone())
+                sims += chunk
+                if time.perf_counter() >= deadline:
+                    break
+            else:
+                acts = search.root.acts
+                visits = np.array([k.n for k in search.root.kids])
+                move = int(acts[int(np.argmax(visits + np.random.rand(len(acts))))])
+                search.update_with_move(move)
+                env.step(move)
+                if env.game_end_winner()[0]:
+                    env.reset()
+                    search.update_with_move(-1)
+    dt = time.perf_counter() - t0
+    print(json.dumps({'sims': sims, 'seconds': dt}))
+
+
+def run_cpu_baseline(seconds):
+    cores = os.cpu_count() or 1
+    env = dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1', HIP_VISIBLE_DEVICES='',
+               ROCR_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-worker', str(seconds)]
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, cwd=REPO)
+             for _ in range(cores)]
+    total, worst = 0, 0.0
+    for p in procs:
+        out, _ = p.communicate()
+        try:
+            rec = json.loads(out.decode().strip().splitlines()[-1])
+            total += rec['sims']
+            worst = max(worst, rec['seconds'])
+        except Exception:  # noqa: BLE001
+            pass
+    if worst <= 0:
+        return None
+    return {'value': round(total / worst, 1), 'unit': 'sims/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d processes x %.0f s of %dx%d Gomoku self-play at %d sims/move from the empty '
+                      'board, oracle/mcts_ref.py + batch-1 torch CPU forward, 1 thread each'
+                      % (cores, seconds, BOARD, BOARD, N_PLAYOUT)}
+
+
+# --------------------------------------------------------------------------- GPU run
+class TimedNet(object):
+    """NetEvaluator that brackets every forward with HIP events on the launch stream."""
+    needs_obs = True
+
+    def __init__(self, net, torch):
+        self.net, self.torch = net, torch
+        self.events = []
+        self.record = False
+
+    def __call__(self, eng):
+        t = self.torch
+        if self.record:
+            a, b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+            a.record()
+        with t.no_grad():
+            logp, value = self.net(eng.obs)
+        if self.record:
+            b.record()
+            self.events.append((a, b))
+        return logp.contiguous(), value.reshape(-1).contiguous()
+
+    def mean_ms(self):
+        if not self.events:
+            return None
+        return sum(a.elapsed_time(b) for a, b in self.events) / len(self.events)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=4)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--cpu-worker', type=float, default=None, help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--games', type=int, default=GAMES_PER_GPU, help='games per GPU')
+    ap.add_argument('--board', type=int, default=BOARD)
+    ap.add_argument('--playouts', type=int, default=N_PLAYOUT)
+    ap.add_argument('--evaluator', default='net', choices=['net', 'vlin'],
+                    help="'vlin' isolates the tree kernels (synthetic evaluator)")
+    ap.add_argument('--graph', type=int, default=0, help='simulation steps per hipGraph (0 = eager)')
+    args = ap.parse_args()
+    if args.cpu_worker is not None:
+        cpu_worker(args.cpu_worker, args.board, N_ROW if args.board >= 5 else args.board, args.playouts)
+        return
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+
+    # CPU baseline first (rank 0, N=1 only), before this process touches the GPU
+    cpu_baseline = None
+    if world == 1 and args.gpus == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(args.cpu_seconds)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from rlzero_amd.engine import MCTSEngine, SyntheticEvaluator
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    from rlzero_amd.selfplay import BatchedSelfPlay
+
+    torch.cuda.set_device(local_rank)
+    device = 'cuda:%d' % local_rank
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device(device))
+
+    board, n_row = args.board, (N_ROW if args.board >= 5 else args.board)
+    cells = board * board
+    G = args.games
+    eng = MCTSEngine(board, n_row, n_games=G, n_playout=args.playouts, c_puct=C_PUCT, device=device)
+    torch.manual_seed(0)  # identical weights on every rank
+    net = PolicyValueNet(board).to(device).eval()
+    evaluator = TimedNet(net, torch) if args.evaluator == 'net' else SyntheticEvaluator('vlin')
+    sp = BatchedSelfPlay(eng, evaluator, temperature=TEMPERATURE, seed=0,
+                         use_graph=args.graph > 0, sims_per_graph=max(args.graph, 1))
+    if args.graph > 0:
+        eng.reset_games()
+        eng.warm_graph(evaluator, args.graph)
+    # games rank, rank+world, ... ; ids beyond the first G refill finished slots
+    next_id = [rank + world * G]
+    sp._start(range(G), [rank + world * i for i in range(G)])
+    sp._set_active()
+    finished = [0]
+
+    def one_step():
+        done = sp.play_move()
+        finished[0] += len(done)
+        if done:
+            free = np.nonzero(sp.slot_game < 0)[0]
+            ids = [next_id[0] + world * i for i in range(len(free))]
+            next_id[0] += world * len(free)
+            sp._start(free, ids)
+            sp._set_active()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    if isinstance(evaluator, TimedNet):
+        evaluator.record = True
+    sims0, fin0 = sp.sims_done, finished[0]
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        counts = torch.tensor([sp.sims_done - sims0, finished[0] - fin0], dtype=torch.float64, device=device)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        total_sims, total_finished = float(counts[0].item()), float(counts[1].item())
+    else:
+        total_sims, total_finished = float(sp.sims_done - sims0), float(finished[0] - fin0)
+    stats = eng.check()
+
+    if rank == 0:
+        value = total_sims / elapsed
+        line = {
+            'metric': 'mcts_sims_per_sec', 'value': round(value, 1), 'unit': 'sims/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1000.0 * elapsed / max(args.steps, 1), 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32 net / f64 tree', 'data': 'synthetic (random-init net, torch.manual_seed(0); '
+            'games from the empty board)',
+            'config': {'workload': 'gomoku%dx%d_n%d_selfplay_%dsims_per_move_%dgames_per_gpu'
+                                   % (board, board, n_row, args.playouts, G),
+                       'games_total': G * world, 'c_puct': C_PUCT, 'temperature': TEMPERATURE,
+                       'evaluator': args.evaluator, 'score_mode': 'UCT_REF (bit-exact)',
+                       'sims_per_graph': args.graph, 'parallelism': 'games sharded, dp%d' % world},
+            'moves_per_sec': round(total_sims / args.playouts / elapsed, 2),
+            'games_finished_in_timed_region': int(total_finished),
+            'arena_slots_used_max': int(stats.max_slots_used),
+            'engine_hbm_bytes': int(stats.device_bytes),
+        }
+        if isinstance(evaluator, TimedNet) and evaluator.mean_ms():
+            ms = evaluator.mean_ms()
+            flops = flops_per_position(cells) * G
+            achieved = flops / (ms * 1e-3) / 1e12
+            line['roofline'] = {'bound': 'mfma', 'kernel': 'policy+value forward of %d leaves (torch/MIOpen)' % G,
+                                'achieved': round(achieved, 3), 'peak': PEAK_FP32_MATRIX_TFLOPS,
+                                'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
+                                'traffic': None, 'avg_launch_ms': round(ms, 4),
+                                'launches_timed': len(evaluator.events),
+                                'share_of_step_time': round(ms * len(evaluator.events) / (elapsed * 1e3), 3)}
+        else:
+            per_sim = tree_bytes_per_sim(365.5, 208.8, 1.74) if board == 15 else None
+            if per_sim:
+                achieved = value / world * per_sim / 1e9
+                line['roofline'] = {'bound': 'hbm', 'kernel': 'k_select + k_expand_backup (tree only)',
+                                    'achieved': round(achieved, 3), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                    'frac': round(achieved / PEAK_HBM_GBS, 6), 'traffic': None}
+        line['cpu_baseline'] = cpu_baseline
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

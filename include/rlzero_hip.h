@@ -1,0 +1,196 @@
+/*
+ * rlzero_hip.h -- C ABI of the MI355X (gfx950) AlphaZero self-play MCTS engine.
+ *
+ * This is the drop-in boundary for ONE path of jianzhnie/RLZero: the
+ * select -> expand -> evaluate -> backup loop of AlphaZero MCTS plus the Gomoku /
+ * TicTacToe board rules it steps through.  The reference is pure Python and has no FFI;
+ * each entry point below names the reference function(s) (file:line, relative to the
+ * reference repository) whose work it takes over for a whole batch of lock-stepped games.
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain C, no torch types.  `d_` pointers are DEVICE pointers (e.g. tensor.data_ptr()),
+ *    `h_` pointers are HOST pointers.  `stream` is a hipStream_t passed as void*.
+ *  - every function returns 0 (RZ_OK) or a negative RZ_ERR_* code; the message is
+ *    available from rz_last_error() (thread local).  No exception crosses the ABI.
+ *  - an engine is NOT thread safe: one host thread per engine (the reference is
+ *    single-threaded).  Launch functions enqueue on `stream` and do
+ *    not synchronise, allocate or free: they can be captured in a hipGraph.
+ *  - one tree per game, ONE simulation in flight per tree (the reference runs
+ *    simulations strictly sequentially, rlzero/mcts/alphazero_mcts.py:82-85); the
+ *    parallelism is across games.
+ *
+ * Boards: two bitboards per game, RZ_BOARD_WORDS u64 words per colour, bit `a` = move
+ * `a` = h*B + w (rlzero/games/gomoku/gomoku_env.py:227-234).  Layout of a board array:
+ * [n_games][2][RZ_BOARD_WORDS] (colour 0 = player id 0 = first player).
+ */
+#ifndef RLZERO_HIP_H
+#define RLZERO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RZ_ABI_VERSION 2
+#define RZ_MAX_BOARD_SIZE 16
+#define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
+
+enum {
+    RZ_OK = 0,
+    RZ_ERR_ARG = -1,      /* bad argument / config */
+    RZ_ERR_HIP = -2,      /* a HIP runtime call failed */
+    RZ_ERR_OOM = -3,      /* device allocation failed */
+    RZ_ERR_OVERFLOW = -4, /* a game ran out of arena slots / block-queue entries */
+    RZ_ERR_ILLEGAL = -5,  /* an illegal move was submitted (gomoku_env.py:51-53 asserts) */
+    RZ_ERR_INTERNAL = -6
+};
+
+enum { RZ_GAME_GOMOKU = 0 }; /* TicTacToe = Gomoku(board_size 3, n_in_row 3), tools/play.py:35 */
+
+enum {
+    RZ_SCORE_UCT_REF = 0, /* the reference's rule: W/N + c*sqrt(ln(Np)/N), +inf if unvisited
+                             (rlzero/mcts/node.py:41-42,75-88); bit-exact, fp64 */
+    RZ_SCORE_PUCT = 1     /* opt-in: Q + c*P*sqrt(Np)/(1+N) (node.py:105-117 is dead code in the
+                             reference and divides by zero at N=0; here Q=0 at N=0) */
+};
+
+enum { RZ_EVAL_V0 = 0, RZ_EVAL_VLIN = 1 }; /* synthetic evaluators, SURVEY.md Appendix B */
+
+/* per-game error bits reported by rz_get_stats */
+enum {
+    RZ_FLAG_ARENA_FULL = 1,
+    RZ_FLAG_BLOCKS_FULL = 2,
+    RZ_FLAG_ILLEGAL_MOVE = 4,
+    RZ_FLAG_LOGTAB = 8,
+    RZ_FLAG_INTERNAL = 16
+};
+
+typedef struct rz_engine rz_engine;
+
+typedef struct rz_config {
+    int32_t abi_version; /* RZ_ABI_VERSION */
+    int32_t game_kind;   /* RZ_GAME_GOMOKU */
+    int32_t board_size;  /* B <= RZ_MAX_BOARD_SIZE (GomokuEnv(board_size=), gomoku_env.py:19-31) */
+    int32_t n_in_row;    /* GomokuEnv(n_in_row=) */
+    int32_t n_games;     /* games searched in lock-step on this GPU */
+    int32_t n_playout;   /* simulations per move: sizes the arenas and the ln table
+                            (AlphaZeroPlayer(n_playout=), alphazero_mcts.py:112-130) */
+    int32_t score_mode;  /* RZ_SCORE_* */
+    int32_t add_noise;   /* reserved (Dirichlet noise only perturbs the stored prior, which
+                            RZ_SCORE_UCT_REF never reads; node.py:63-69) */
+    double c_puct;       /* AlphaZeroPlayer(c_puct=) */
+    double pool_factor;  /* arena slots per game = pool_factor*n_playout*B*B + B*B + 2;
+                            0 -> 2.0 */
+    int32_t device;      /* HIP device ordinal */
+    int32_t reserved;
+} rz_config;
+
+typedef struct rz_stats {
+    int32_t error_flags;     /* OR of RZ_FLAG_* over all games since the last clear */
+    int32_t first_bad_game;  /* lowest game index with a flag, or -1 */
+    int64_t arena_slots;     /* capacity per game per arena */
+    int64_t max_slots_used;  /* max over games of the current arena top */
+    int64_t max_blocks_used; /* max over games of expanded nodes in the current arena */
+    int64_t device_bytes;    /* bytes of HBM the engine allocated */
+    int64_t n_select_calls;  /* rz_select_step launches so far */
+} rz_stats;
+
+int rz_abi_version(void);
+const char *rz_last_error(void);
+
+/* Lifetime.  rz_create allocates every buffer up front (nothing is allocated later). */
+int rz_create(const rz_config *cfg, rz_engine **out);
+int rz_destroy(rz_engine *e);
+
+/* ln(n) table for n = 0 .. count-1 (entry 0 unused).  The engine fills it at creation
+ * with the host libm's log(), the function CPython's math.log() calls in
+ * rlzero/mcts/node.py:84-85; the device never evaluates a logarithm itself.  This entry
+ * replaces the table (e.g. with one produced by math.log on another host). */
+int rz_upload_log_table(rz_engine *e, const double *h_table, int64_t count);
+int rz_log_table_size(rz_engine *e, int64_t *count);
+
+/* Root positions.  Import boards for the games selected by d_mask (NULL = all games):
+ * what AlphaZeroPlayer.get_action reads from `game_env` (alphazero_mcts.py:136-146:
+ * states, current player, last_move).  reset_trees != 0 also discards those games'
+ * trees (AlphaZeroMCTS.update_with_move(-1), alphazero_mcts.py:96-103). */
+int rz_set_roots(rz_engine *e, const uint64_t *d_stones, const int32_t *d_to_move,
+                 const int32_t *d_last_move, const uint8_t *d_mask, int reset_trees,
+                 void *stream);
+int rz_get_roots(rz_engine *e, uint64_t *d_stones, int32_t *d_to_move, int32_t *d_last_move,
+                 void *stream);
+/* Games with active == 0 are skipped by select / expand_backup (finished games). */
+int rz_set_active(rz_engine *e, const uint8_t *d_active, void *stream);
+
+/* SELECT + STEP: for every active game walk from the root to a leaf
+ * (AlphaZeroMCTS._playout select loop, alphazero_mcts.py:48-54; TreeNode.select /
+ * uct_value, node.py:32-42,75-88), applying each chosen move to a private copy of the
+ * board (the reference's copy.deepcopy + GomokuEnv.step, alphazero_mcts.py:83,
+ * gomoku_env.py:49-70), then classify the leaf (GomokuEnv.game_end_winner,
+ * gomoku_env.py:196-203 -> has_a_winner :116-170).  If d_obs != NULL also writes the
+ * leaf's observation planes float32 [n_games][4][B][B] (GomokuEnv.current_state,
+ * gomoku_env.py:95-114) -- the input of the evaluator. */
+int rz_select_step(rz_engine *e, float *d_obs, void *stream);
+
+/* Observation planes of the current leaves / of the root positions (current_state). */
+int rz_encode_leaf_obs(rz_engine *e, float *d_obs, void *stream);
+int rz_encode_root_obs(rz_engine *e, float *d_obs, void *stream);
+
+/* Leaf positions for an evaluator that runs on the host (any policy_value_fn callable,
+ * alphazero_mcts.py:28-31,59).  d_terminal: 0 = not ended, 1 = tie, 2 = won. */
+int rz_get_leaves(rz_engine *e, uint64_t *d_stones, int32_t *d_to_move, int32_t *d_last_move,
+                  int32_t *d_terminal, void *stream);
+
+/* Synthetic evaluators of SURVEY.md Appendix B computed from the leaf bitboards:
+ * d_value float32 [n_games]; d_logp (nullable) float32 [n_games][B*B] = log(1/k) on
+ * empty cells, -inf elsewhere. */
+int rz_eval_synthetic(rz_engine *e, int kind, float *d_logp, float *d_value, void *stream);
+
+/* EXPAND + BACKUP: terminal rule and value (alphazero_mcts.py:60-68), TreeNode.expand
+ * (node.py:44-73; priors = exp(d_logp) on the leaf's legal moves as in
+ * AlphaZeroAgent.policy_value_fn, alphazero_agent.py:41-45; d_logp == NULL -> uniform),
+ * TreeNode.update_recursive(-leaf_value) (node.py:119-144).  d_value: leaf value from
+ * the evaluator, [n_games], float32 (the reference converts the fp32 net output to a
+ * Python float exactly, alphazero_agent.py:45) or float64 for host evaluators. */
+int rz_expand_backup(rz_engine *e, const float *d_logp, const float *d_value, void *stream);
+int rz_expand_backup_f64(rz_engine *e, const float *d_logp, const double *d_value, void *stream);
+
+/* Root statistics after the simulations (AlphaZeroMCTS.simulate, alphazero_mcts.py:88-90):
+ * visit count / W of the root child of every action, 0 for illegal or unvisited actions;
+ * [n_games][B*B].  rz_root_stats: N and W of the roots themselves, [n_games]. */
+int rz_root_visits(rz_engine *e, int32_t *d_visits, void *stream);
+int rz_root_wsum(rz_engine *e, double *d_w, void *stream);
+int rz_root_priors(rz_engine *e, float *d_p, void *stream);
+int rz_root_stats(rz_engine *e, int32_t *d_n, double *d_w, void *stream);
+
+/* Tree reuse: AlphaZeroMCTS.update_with_move (alphazero_mcts.py:96-103).  d_moves[g] >= 0:
+ * the subtree of that root child becomes the tree (statistics kept); -1: fresh tree
+ * (reset_player, alphazero_mcts.py:132-134); -2: leave the game untouched.  Must be called
+ * BEFORE rz_step_games for the same move (it ranks the move on the current root board). */
+int rz_advance_roots(rz_engine *e, const int32_t *d_moves, void *stream);
+
+/* GomokuEnv.step + game_end_winner on the root boards (gomoku_env.py:49-70,196-203):
+ * d_moves[g] < 0 = no move.  d_winner: player id or -1 (tie / not ended); d_ended 0/1. */
+int rz_step_games(rz_engine *e, const int32_t *d_moves, int32_t *d_winner, uint8_t *d_ended,
+                  void *stream);
+
+/* Synchronises `stream`-independent state: waits for the device, then reports flags. */
+int rz_get_stats(rz_engine *e, rz_stats *out);
+int rz_clear_errors(rz_engine *e);
+
+/* Inspection for parity tests: copies game `g`'s current arena to HOST arrays of
+ * max_slots entries (N, W, first-child index or -1, visited-children count, prior) and
+ * its used-slot count.  Synchronous. */
+int rz_copy_arena(rz_engine *e, int32_t game, int64_t max_slots, int32_t *h_n, double *h_w,
+                  int32_t *h_first_child, int32_t *h_n_visited, float *h_prior, int32_t *h_top);
+
+/* The scoring arithmetic alone, for bit-exactness tests against CPython:
+ * out[i] = w[i]/n[i] + c*sqrt(ln(np[i])/n[i]) with ln from the engine's table. */
+int rz_uct_scores(rz_engine *e, const double *d_w, const int32_t *d_n, const int32_t *d_np,
+                  double c_puct, double *d_out, int64_t count, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLZERO_HIP_H */

@@ -1,0 +1,104 @@
+"""ctypes binding of include/rlzero_hip.h (the C ABI of the HIP engine).
+
+There is deliberately NO fallback: if ``librlzero_hip.so`` is missing or a call fails the
+product raises.  Build it with ``python -m rlzero_amd._build``.
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p)
+
+ABI_VERSION = 2
+BOARD_WORDS = 4
+MAX_BOARD_SIZE = 16
+
+OK = 0
+SCORE_UCT_REF, SCORE_PUCT = 0, 1
+EVAL_V0, EVAL_VLIN = 0, 1
+FLAG_NAMES = {1: 'arena full', 2: 'block queue full', 4: 'illegal move', 8: 'ln table too short',
+              16: 'internal'}
+
+
+class RzConfig(Structure):
+    _fields_ = [('abi_version', c_int32), ('game_kind', c_int32), ('board_size', c_int32),
+                ('n_in_row', c_int32), ('n_games', c_int32), ('n_playout', c_int32),
+                ('score_mode', c_int32), ('add_noise', c_int32), ('c_puct', c_double),
+                ('pool_factor', c_double), ('device', c_int32), ('reserved', c_int32)]
+
+
+class RzStats(Structure):
+    _fields_ = [('error_flags', c_int32), ('first_bad_game', c_int32), ('arena_slots', c_int64),
+                ('max_slots_used', c_int64), ('max_blocks_used', c_int64),
+                ('device_bytes', c_int64), ('n_select_calls', c_int64)]
+
+
+class HipError(RuntimeError):
+    pass
+
+
+P = c_void_p  # device / host pointers and streams travel as integers
+
+_SIGNATURES = {
+    'rz_abi_version': (c_int, []),
+    'rz_last_error': (c_char_p, []),
+    'rz_create': (c_int, [POINTER(RzConfig), POINTER(c_void_p)]),
+    'rz_destroy': (c_int, [P]),
+    'rz_upload_log_table': (c_int, [P, P, c_int64]),
+    'rz_log_table_size': (c_int, [P, POINTER(c_int64)]),
+    'rz_set_roots': (c_int, [P, P, P, P, P, c_int, P]),
+    'rz_get_roots': (c_int, [P, P, P, P, P]),
+    'rz_set_active': (c_int, [P, P, P]),
+    'rz_select_step': (c_int, [P, P, P]),
+    'rz_encode_leaf_obs': (c_int, [P, P, P]),
+    'rz_encode_root_obs': (c_int, [P, P, P]),
+    'rz_get_leaves': (c_int, [P, P, P, P, P, P]),
+    'rz_eval_synthetic': (c_int, [P, c_int, P, P, P]),
+    'rz_expand_backup': (c_int, [P, P, P, P]),
+    'rz_expand_backup_f64': (c_int, [P, P, P, P]),
+    'rz_root_visits': (c_int, [P, P, P]),
+    'rz_root_wsum': (c_int, [P, P, P]),
+    'rz_root_priors': (c_int, [P, P, P]),
+    'rz_root_stats': (c_int, [P, P, P, P]),
+    'rz_advance_roots': (c_int, [P, P, P]),
+    'rz_step_games': (c_int, [P, P, P, P, P]),
+    'rz_get_stats': (c_int, [P, POINTER(RzStats)]),
+    'rz_clear_errors': (c_int, [P]),
+    'rz_copy_arena': (c_int, [P, c_int32, c_int64, P, P, P, P, P, P]),
+    'rz_uct_scores': (c_int, [P, P, P, P, c_double, P, c_int64, P]),
+}
+
+_lib = None
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'librlzero_hip.so')
+
+
+def load():
+    """Load the shared library (once) and declare every prototype of the header."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise HipError('%s is missing: the HIP extension is required (no CPU fallback). '
+                       'Build it with `python -m rlzero_amd._build`.' % path)
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = lib.rz_abi_version()
+    if got != ABI_VERSION:
+        raise HipError('librlzero_hip.so has ABI %d, binding expects %d: rebuild' % (got, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(rc, what=''):
+    if rc != OK:
+        msg = load().rz_last_error()
+        raise HipError('%s failed (%d): %s' % (what or 'rz call', rc, (msg or b'').decode()))

@@ -1,0 +1,11 @@
+"""Trainer API of the AlphaZero path.
+
+In the reference the AlphaZero trainer is the ``TrainPipeline`` class inside the script
+tools/train_alphazero.py:17-190 (``rlzero/algorithms`` only holds the unrelated DMC / CFR
+code).  The batched, multi-GPU self-play collector that replaces its sequential
+``collect_selfplay_data`` loop is ``rlzero_amd.selfplay``; it is re-exported here under the
+name BASELINE.json uses.
+"""
+from ..selfplay import BatchedSelfPlay, Trajectory, gather_trajectories, shard_game_ids
+
+__all__ = ['BatchedSelfPlay', 'Trajectory', 'gather_trajectories', 'shard_game_ids']

@@ -1,0 +1,1138 @@
+// rz_engine.hip -- MI355X (gfx950 / CDNA4) AlphaZero self-play MCTS engine.
+//
+// One 64-lane wavefront per game, one simulation in flight per tree (the reference runs
+// its simulations strictly sequentially, rlzero/mcts/alphazero_mcts.py:82-85, so this is
+// what bit-exact parity requires); the parallelism is across the lock-stepped games.
+//
+// Tree layout (struct of arrays in HBM, one arena pair per game):
+//   N  int32   visit count          (TreeNode.explore_count, rlzero/mcts/node.py:28)
+//   W  float64 total value          (TreeNode.total_reward,  node.py:29)
+//   P  float32 prior                (TreeNode.prior,         node.py:30)
+//   FC int32   index of the first child slot, -1 = not expanded (TreeNode._children)
+//   NV int32   number of children already visited
+// The children of a node are ONE contiguous block of k slots, k = number of empty cells
+// at that node, slot r = r-th legal move in ascending order (the reference's dict
+// insertion order, node.py:62-73).  The reference's selection rule gives an unvisited
+// child +inf and Python's max() keeps the first maximum (node.py:41-42,75-88), so the
+// visited children of every node are always a PREFIX of its block:
+// "first unvisited child" is slot NV, no scan; a scan (coalesced 4+8 B per child, fp64
+// score, first-index tie-break across the wave) happens only once all k are visited.
+// N/W/FC/NV of a slot are written the first time the slot is visited, so expansion only
+// reserves the block (bump allocator) and writes the k priors.
+//
+// Bit-exactness: fp64 throughout, this file is compiled with
+// -ffp-contract=off (q + c*u is two roundings in CPython), IEEE division and sqrt, and
+// ln(parent N) comes from a table filled by the HOST libm -- the function CPython's
+// math.log calls -- never from a device logarithm.
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "rlzero_hip.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kWords = RZ_BOARD_WORDS;
+
+struct Dev {
+    int S, B, n_row, n_games, score_mode;
+    int path_stride, qcap;
+    long long cap, logtab_n;
+    double c_puct;
+    int32_t *N;
+    double *W;
+    int32_t *FC;
+    int32_t *NV;
+    float *P;
+    int32_t *cur_arena, *top, *nblk;
+    uint64_t *root_stones;
+    int32_t *root_to_move, *root_last;
+    uint8_t *active;
+    int32_t *path, *leaf_node, *leaf_depth, *leaf_fresh, *leaf_term;
+    double *leaf_tval;
+    uint64_t *leaf_stones;
+    int32_t *leaf_to_move, *leaf_last;
+    int32_t *queue;
+    int32_t *err, *err_any;
+    const double *logtab;
+    uint64_t valid[kWords];
+};
+
+// ------------------------------------------------------------------ bitboard helpers
+__device__ __forceinline__ uint64_t word_of(const uint64_t *a, int j) {
+    uint64_t r = a[0];
+    r = (j == 1) ? a[1] : r;
+    r = (j == 2) ? a[2] : r;
+    r = (j == 3) ? a[3] : r;
+    return r;
+}
+__device__ __forceinline__ bool test_bit(const uint64_t *a, int c) {
+    return (word_of(a, c >> 6) >> (c & 63)) & 1ull;
+}
+__device__ __forceinline__ void set_bit(uint64_t *a, int c) {
+    const uint64_t m = 1ull << (c & 63);
+    const int j = c >> 6;
+    a[0] |= (j == 0) ? m : 0ull;
+    a[1] |= (j == 1) ? m : 0ull;
+    a[2] |= (j == 2) ? m : 0ull;
+    a[3] |= (j == 3) ? m : 0ull;
+}
+__device__ __forceinline__ int count_bits(const uint64_t *a) {
+    return __popcll(a[0]) + __popcll(a[1]) + __popcll(a[2]) + __popcll(a[3]);
+}
+
+// Rank of cell `a` among the empty cells (ascending) = its slot in a children block.
+__device__ __forceinline__ int rank_of_cell(const uint64_t *occ, const uint64_t *valid, int a) {
+    const int i = a >> 6;
+    const uint64_t below = (1ull << (a & 63)) - 1ull;
+    int r = 0;
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) {
+        const uint64_t e = ~occ[j] & valid[j];
+        r += (j < i) ? __popcll(e) : ((j == i) ? __popcll(e & below) : 0);
+    }
+    return r;
+}
+
+// r-th empty cell (ascending); lane l looks at bit l of each word.  Wave-uniform result.
+__device__ __forceinline__ int nth_empty_cell(const uint64_t *occ, const uint64_t *valid, int r,
+                                              int lane) {
+    const uint64_t below = (1ull << lane) - 1ull;
+    int before = 0, found = -1;
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) {
+        const uint64_t e = ~occ[j] & valid[j];
+        const bool mine = (e >> lane) & 1ull;
+        if (mine && before + __popcll(e & below) == r) found = 64 * j + lane;
+        before += __popcll(e);
+    }
+    const unsigned long long m = __ballot(found >= 0);
+    if (m == 0ull) return -1;
+    return __shfl(found, __ffsll((long long)m) - 1);
+}
+
+// n-in-row through `last` only: lane l < 4n tests the window of direction l/n that starts
+// l%n steps before `last`.  Equivalent to the reference's whole-board scan
+// (gomoku_env.py:136-168) when the position before `last` had no line.
+__device__ __forceinline__ bool line_through(const uint64_t *x, int last, int B, int n, int lane) {
+    bool hit = false;
+    if (lane < 4 * n) {
+        const int d = lane / n, t = lane - d * n;
+        const int stride = (d == 0) ? 1 : (d == 1) ? B : (d == 2) ? B + 1 : B - 1;
+        const int start = last - t * stride;
+        if (start >= 0) {
+            const int h = start / B, w = start - h * B;
+            const bool right = w <= B - n, down = h <= B - n, left = w >= n - 1;
+            const bool ok = (d == 0) ? right : (d == 1) ? down : (d == 2) ? (right && down)
+                                                                          : (left && down);
+            if (ok) {
+                hit = true;
+                for (int j = 0; j < n; ++j) hit = hit && test_bit(x, start + j * stride);
+            }
+        }
+    }
+    return __ballot(hit) != 0ull;
+}
+
+// Whole-board n-in-row scan of one colour (gomoku_env.py:136-168), lanes over start cells.
+__device__ __forceinline__ bool line_anywhere(const uint64_t *x, int S, int B, int n, int lane) {
+    bool hit = false;
+    for (int m = lane; m < S; m += kWave) {
+        if (!test_bit(x, m)) continue;
+        const int h = m / B, w = m - h * B;
+        const bool right = w <= B - n, down = h <= B - n, left = w >= n - 1;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int stride = (d == 0) ? 1 : (d == 1) ? B : (d == 2) ? B + 1 : B - 1;
+            const bool ok = (d == 0) ? right : (d == 1) ? down : (d == 2) ? (right && down)
+                                                                          : (left && down);
+            if (!ok) continue;
+            bool all = true;
+            for (int j = 1; j < n; ++j) all = all && test_bit(x, m + j * stride);
+            hit = hit || all;
+        }
+    }
+    return __ballot(hit) != 0ull;
+}
+
+// GomokuEnv.current_state (gomoku_env.py:95-114): 4 planes, [4][S] floats, coalesced.
+__device__ __forceinline__ void write_obs(float *out, const uint64_t *mine, const uint64_t *theirs,
+                                          int last, int nst, int S, int lane) {
+    const float colour = (nst & 1) ? 0.0f : 1.0f;
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) {
+        const int c = 64 * j + lane;
+        if (c < S) {
+            out[c] = (float)((mine[j] >> lane) & 1ull);
+            out[S + c] = (float)((theirs[j] >> lane) & 1ull);
+            out[2 * S + c] = (nst > 0 && c == last) ? 1.0f : 0.0f;
+            out[3 * S + c] = colour;
+        }
+    }
+}
+
+__device__ __forceinline__ void flag(const Dev &E, int g, int bits, int lane) {
+    if (lane == 0) {
+        atomicOr(&E.err[g], bits);
+        atomicOr(E.err_any, bits);
+    }
+}
+
+// node.py:83-87: exploration_score + c_puct * exploitation_score, each op rounded once.
+__device__ __forceinline__ double uct_ref(double w, int n, double ln_parent, double c) {
+    const double nd = (double)n;
+    const double q = w / nd;
+    const double u = sqrt(ln_parent / nd);
+    const double cu = c * u;
+    return q + cu;
+}
+
+// ------------------------------------------------------------------ SELECT + STEP
+__global__ __launch_bounds__(kWave) void k_select(Dev E, float *obs) {
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (!E.active[g]) return;
+    const int S = E.S, B = E.B;
+    const long long base = ((long long)g * 2 + E.cur_arena[g]) * E.cap;
+    int32_t *N = E.N + base;
+    double *W = E.W + base;
+    int32_t *FC = E.FC + base;
+    int32_t *NV = E.NV + base;
+
+    uint64_t st[2][kWords];
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) {
+        st[0][j] = E.root_stones[((long long)g * 2 + 0) * kWords + j];
+        st[1][j] = E.root_stones[((long long)g * 2 + 1) * kWords + j];
+    }
+    int to_move = E.root_to_move[g];
+    int last = E.root_last[g];
+    int nst = count_bits(st[0]) + count_bits(st[1]);
+
+    int32_t *path = E.path + (long long)g * E.path_stride;
+    int node = 0, depth = 0, fresh = 0;
+    if (lane == 0) path[0] = 0;
+
+    for (int it = 0; it <= S; ++it) {
+        const int fc = FC[node];
+        if (fc < 0) break;  // leaf: never expanded, or a terminal position
+        const int k = S - nst;
+        const int nv = NV[node];
+        int r;
+        if (nv < k) {
+            // some child still has N == 0 -> score +inf, first such child wins
+            r = nv;
+            fresh = 1;
+            if (lane == 0) NV[node] = nv + 1;
+        } else {
+            const int pn = N[node];
+            if (pn < 1 || pn >= E.logtab_n) {
+                flag(E, g, RZ_FLAG_LOGTAB, lane);
+                break;
+            }
+            const double lnp = E.logtab[pn];
+            double best = -INFINITY;
+            int besti = 0x7fffffff;
+            for (int r0 = lane; r0 < k; r0 += kWave) {
+                const double sc = uct_ref(W[fc + r0], N[fc + r0], lnp, E.c_puct);
+                if (sc > best) {
+                    best = sc;
+                    besti = r0;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double ob = __shfl_xor(best, off);
+                const int oi = __shfl_xor(besti, off);
+                if (ob > best || (ob == best && oi < besti)) {
+                    best = ob;
+                    besti = oi;
+                }
+            }
+            r = besti;
+            if (r >= k) {
+                flag(E, g, RZ_FLAG_INTERNAL, lane);
+                break;
+            }
+        }
+        uint64_t occ[kWords];
+#pragma unroll
+        for (int j = 0; j < kWords; ++j) occ[j] = st[0][j] | st[1][j];
+        const int a = nth_empty_cell(occ, E.valid, r, lane);
+        if (a < 0) {
+            flag(E, g, RZ_FLAG_INTERNAL, lane);
+            break;
+        }
+        if (to_move == 0) set_bit(st[0], a); else set_bit(st[1], a);
+        last = a;
+        to_move ^= 1;
+        nst += 1;
+        node = fc + r;
+        depth += 1;
+        if (lane == 0) path[depth] = node;
+        if (fresh) break;  // a first-visit child has no statistics and no children yet
+    }
+
+    // GomokuEnv.game_end_winner on the leaf (gomoku_env.py:196-203)
+    int term = 0;
+    double tval = 0.0;
+    {
+        int winner = -1;
+        if (depth == 0) {
+            if (line_anywhere(st[0], S, B, E.n_row, lane)) winner = 0;
+            else if (line_anywhere(st[1], S, B, E.n_row, lane)) winner = 1;
+        } else {
+            const int mover = to_move ^ 1;
+            if (line_through(mover == 0 ? st[0] : st[1], last, B, E.n_row, lane)) winner = mover;
+        }
+        if (winner >= 0) {
+            term = 2;
+            tval = (winner == to_move) ? 1.0 : -1.0;  // alphazero_mcts.py:66-68
+        } else if (nst == S) {
+            term = 1;
+            tval = 0.0;  // alphazero_mcts.py:64-65
+        }
+    }
+    if (lane == 0) {
+        E.leaf_node[g] = node;
+        E.leaf_depth[g] = depth;
+        E.leaf_fresh[g] = fresh;
+        E.leaf_term[g] = term;
+        E.leaf_tval[g] = tval;
+        E.leaf_to_move[g] = to_move;
+        E.leaf_last[g] = last;
+    }
+    if (lane < 2 * kWords) {
+        const int colour = lane / kWords, j = lane % kWords;
+        E.leaf_stones[((long long)g * 2 + colour) * kWords + j] = word_of(st[colour], j);
+    }
+    if (obs != nullptr)
+        write_obs(obs + (long long)g * 4 * S, to_move == 0 ? st[0] : st[1],
+                  to_move == 0 ? st[1] : st[0], last, nst, S, lane);
+}
+
+// ------------------------------------------------------------------ EXPAND + BACKUP
+template <typename VT>
+__global__ __launch_bounds__(kWave) void k_expand_backup(Dev E, const float *logp, const VT *value) {
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (!E.active[g]) return;
+    const int S = E.S;
+    const long long base = ((long long)g * 2 + E.cur_arena[g]) * E.cap;
+    int32_t *N = E.N + base;
+    double *W = E.W + base;
+    int32_t *FC = E.FC + base;
+    int32_t *NV = E.NV + base;
+    float *P = E.P + base;
+
+    const int leaf = E.leaf_node[g];
+    const int depth = E.leaf_depth[g];
+    const int fresh = E.leaf_fresh[g];
+    const int term = E.leaf_term[g];
+    // the reference evaluates terminal leaves too and discards the result (:59-68)
+    const double v = term ? E.leaf_tval[g] : (double)value[g];
+
+    if (!term) {
+        uint64_t occ[kWords];
+#pragma unroll
+        for (int j = 0; j < kWords; ++j)
+            occ[j] = E.leaf_stones[((long long)g * 2 + 0) * kWords + j] |
+                     E.leaf_stones[((long long)g * 2 + 1) * kWords + j];
+        const int k = S - count_bits(occ);
+        const int top = E.top[g];
+        const int nblk = E.nblk[g];
+        if ((long long)top + k > E.cap || nblk >= E.qcap) {
+            flag(E, g, (long long)top + k > E.cap ? RZ_FLAG_ARENA_FULL : RZ_FLAG_BLOCKS_FULL, lane);
+            if (lane == 0 && fresh) {
+                FC[leaf] = -1;
+                NV[leaf] = 0;
+            }
+        } else {
+            if (lane == 0) {
+                FC[leaf] = top;
+                NV[leaf] = 0;
+                E.top[g] = top + k;
+                E.nblk[g] = nblk + 1;
+            }
+            // TreeNode.expand: one child per legal move, prior from the policy head
+            const float uniform = 1.0f / (float)k;
+            const uint64_t below = (1ull << lane) - 1ull;
+            int before = 0;
+#pragma unroll
+            for (int j = 0; j < kWords; ++j) {
+                const uint64_t e = ~occ[j] & E.valid[j];
+                if ((e >> lane) & 1ull) {
+                    const int r = before + __popcll(e & below);
+                    const int c = 64 * j + lane;
+                    P[top + r] = logp ? expf(logp[(long long)g * S + c]) : uniform;
+                }
+                before += __popcll(e);
+            }
+        }
+    } else if (fresh && lane == 0) {
+        FC[leaf] = -1;
+        NV[leaf] = 0;
+    }
+
+    // TreeNode.update_recursive(-leaf_value): leaf gets -v, its parent +v, ... (node.py:135-144)
+    const int32_t *path = E.path + (long long)g * E.path_stride;
+    for (int d = lane; d <= depth; d += kWave) {
+        const int node = path[d];
+        const double x = ((depth - d) & 1) ? v : -v;
+        if (d == depth && fresh) {
+            N[node] = 1;
+            W[node] = 0.0 + x;  // int 0 + float in the reference (node.py:29,133)
+        } else {
+            N[node] += 1;
+            W[node] += x;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ synthetic evaluators
+__global__ __launch_bounds__(kWave) void k_eval_synth(Dev E, int kind, float *logp, float *value) {
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (!E.active[g]) return;
+    const int S = E.S;
+    uint64_t s0[kWords], s1[kWords];
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) {
+        s0[j] = E.leaf_stones[((long long)g * 2 + 0) * kWords + j];
+        s1[j] = E.leaf_stones[((long long)g * 2 + 1) * kWords + j];
+    }
+    int acc = 0, k = 0;
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) {
+        const int c = 64 * j + lane;
+        if (c < S) {
+            const int a = (int)((s0[j] >> lane) & 1ull), b = (int)((s1[j] >> lane) & 1ull);
+            acc += (c + 1) * (a + 3 * b);
+            k += 1 - a - b;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        acc += __shfl_xor(acc, off);
+        k += __shfl_xor(k, off);
+    }
+    if (lane == 0) {
+        float v = 0.0f;
+        if (kind == RZ_EVAL_VLIN) {
+            const int s = acc + 5 * E.leaf_to_move[g];
+            v = (float)((s % 17) - 8) / 8.0f;
+        }
+        value[g] = v;
+    }
+    if (logp != nullptr) {
+        const float lp = k > 0 ? logf(1.0f / (float)k) : 0.0f;
+#pragma unroll
+        for (int j = 0; j < kWords; ++j) {
+            const int c = 64 * j + lane;
+            if (c < S) {
+                const bool empty = !(((s0[j] | s1[j]) >> lane) & 1ull);
+                logp[(long long)g * S + c] = empty ? lp : -INFINITY;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ root read-out
+// what: 0 = visits (int32), 1 = W (double), 2 = prior (float)
+__global__ __launch_bounds__(kWave) void k_root_children(Dev E, int what, void *out) {
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int S = E.S;
+    const long long base = ((long long)g * 2 + E.cur_arena[g]) * E.cap;
+    uint64_t occ[kWords];
+#pragma unroll
+    for (int j = 0; j < kWords; ++j)
+        occ[j] = E.root_stones[((long long)g * 2 + 0) * kWords + j] |
+                 E.root_stones[((long long)g * 2 + 1) * kWords + j];
+    const int fc = E.FC[base];
+    const int nv = fc >= 0 ? E.NV[base] : 0;
+    const uint64_t below = (1ull << lane) - 1ull;
+    int before = 0;
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) {
+        const int c = 64 * j + lane;
+        const uint64_t e = ~occ[j] & E.valid[j];
+        if (c < S) {
+            const bool empty = (e >> lane) & 1ull;
+            const int r = before + __popcll(e & below);
+            const bool seen = empty && r < nv;
+            const long long o = (long long)g * S + c;
+            if (what == 0) ((int32_t *)out)[o] = seen ? E.N[base + fc + r] : 0;
+            else if (what == 1) ((double *)out)[o] = seen ? E.W[base + fc + r] : 0.0;
+            else ((float *)out)[o] = (empty && fc >= 0) ? E.P[base + fc + r] : 0.0f;
+        }
+        before += __popcll(e);
+    }
+}
+
+__global__ void k_root_stats(Dev E, int32_t *n, double *w) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.n_games) return;
+    const long long base = ((long long)g * 2 + E.cur_arena[g]) * E.cap;
+    n[g] = E.N[base];
+    w[g] = E.W[base];
+}
+
+// ------------------------------------------------------------------ tree reuse
+__device__ __forceinline__ void fresh_root(const Dev &E, int g, int arena, int lane) {
+    if (lane == 0) {
+        const long long base = ((long long)g * 2 + arena) * E.cap;
+        E.N[base] = 0;
+        E.W[base] = 0.0;
+        E.P[base] = 1.0f;
+        E.FC[base] = -1;
+        E.NV[base] = 0;
+        E.cur_arena[g] = arena;
+        E.top[g] = 1;
+        E.nblk[g] = 0;
+    }
+}
+
+// AlphaZeroMCTS.update_with_move (alphazero_mcts.py:96-103).  The kept subtree is copied
+// breadth-first into the game's other arena (blocks re-reserved at full width, only the
+// visited prefix copied), which also recycles every slot of the discarded siblings.
+__global__ __launch_bounds__(kWave) void k_advance(Dev E, const int32_t *moves) {
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int m = moves[g];
+    if (m == -2) return;
+    const int S = E.S;
+    const int src_arena = E.cur_arena[g], dst_arena = src_arena ^ 1;
+    const long long sb = ((long long)g * 2 + src_arena) * E.cap;
+    const long long db = ((long long)g * 2 + dst_arena) * E.cap;
+    if (m < 0 || m >= S) {
+        if (m != -1) flag(E, g, RZ_FLAG_ILLEGAL_MOVE, lane);
+        fresh_root(E, g, dst_arena, lane);
+        return;
+    }
+    uint64_t occ[kWords];
+#pragma unroll
+    for (int j = 0; j < kWords; ++j)
+        occ[j] = E.root_stones[((long long)g * 2 + 0) * kWords + j] |
+                 E.root_stones[((long long)g * 2 + 1) * kWords + j];
+    if (test_bit(occ, m)) {
+        flag(E, g, RZ_FLAG_ILLEGAL_MOVE, lane);
+        fresh_root(E, g, dst_arena, lane);
+        return;
+    }
+    const int root_fc = E.FC[sb];
+    const int rank = rank_of_cell(occ, E.valid, m);
+    if (root_fc < 0 || rank >= E.NV[sb]) {
+        // the chosen child was never visited: it is a TreeNode with N = 0 and no children
+        fresh_root(E, g, dst_arena, lane);
+        return;
+    }
+    const int nst_root = count_bits(occ);
+    const int src = root_fc + rank;
+    int32_t *queue = E.queue + (long long)g * E.qcap * 4;
+    int q_tail = 0;
+    const int src_fc = E.FC[sb + src];
+    if (lane == 0) {
+        E.N[db] = E.N[sb + src];
+        E.W[db] = E.W[sb + src];
+        E.P[db] = E.P[sb + src];
+        E.NV[db] = E.NV[sb + src];
+        E.FC[db] = -1;
+        if (src_fc >= 0) {
+            queue[0] = 0;
+            queue[1] = src_fc;
+            queue[2] = E.NV[sb + src];
+            queue[3] = 1;
+        }
+    }
+    if (src_fc >= 0) q_tail = 1;
+    __syncthreads();
+    int dtop = 1, nblk = 0;
+    bool full = false;
+    for (int q_head = 0; q_head < q_tail; ++q_head) {
+        const int dst = queue[4 * q_head + 0];
+        const int sfc = queue[4 * q_head + 1];
+        const int nv = queue[4 * q_head + 2];
+        const int dep = queue[4 * q_head + 3];
+        const int k = S - (nst_root + dep);
+        if ((long long)dtop + k > E.cap || nblk >= E.qcap) {
+            full = true;
+            break;
+        }
+        if (lane == 0) E.FC[db + dst] = dtop;
+        for (int r0 = 0; r0 < k; r0 += kWave) {
+            const int r = r0 + lane;
+            if (r < k) E.P[db + dtop + r] = E.P[sb + sfc + r];
+            int cfc = -1, cnv = 0;
+            if (r < nv) {
+                cfc = E.FC[sb + sfc + r];
+                cnv = E.NV[sb + sfc + r];
+                E.N[db + dtop + r] = E.N[sb + sfc + r];
+                E.W[db + dtop + r] = E.W[sb + sfc + r];
+                E.NV[db + dtop + r] = cnv;
+                E.FC[db + dtop + r] = -1;
+            }
+            const unsigned long long has = __ballot(cfc >= 0);
+            if (cfc >= 0) {
+                const int pos = q_tail + __popcll(has & ((1ull << lane) - 1ull));
+                if (pos < E.qcap) {
+                    queue[4 * pos + 0] = dtop + r;
+                    queue[4 * pos + 1] = cfc;
+                    queue[4 * pos + 2] = cnv;
+                    queue[4 * pos + 3] = dep + 1;
+                }
+            }
+            q_tail += __popcll(has);
+        }
+        if (q_tail > E.qcap) {
+            full = true;
+            break;
+        }
+        dtop += k;
+        nblk += 1;
+        __syncthreads();  // queue entries written by other lanes are read next iteration
+    }
+    if (full) {
+        flag(E, g, RZ_FLAG_BLOCKS_FULL, lane);
+        fresh_root(E, g, dst_arena, lane);
+        return;
+    }
+    if (lane == 0) {
+        E.cur_arena[g] = dst_arena;
+        E.top[g] = dtop;
+        E.nblk[g] = nblk;
+    }
+}
+
+// ------------------------------------------------------------------ game step
+__global__ __launch_bounds__(kWave) void k_step_games(Dev E, const int32_t *moves, int32_t *winner,
+                                                      uint8_t *ended) {
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int S = E.S;
+    uint64_t st[2][kWords];
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) {
+        st[0][j] = E.root_stones[((long long)g * 2 + 0) * kWords + j];
+        st[1][j] = E.root_stones[((long long)g * 2 + 1) * kWords + j];
+    }
+    const int m = moves[g];
+    int to_move = E.root_to_move[g];
+    if (m >= 0) {
+        uint64_t occ[kWords];
+#pragma unroll
+        for (int j = 0; j < kWords; ++j) occ[j] = st[0][j] | st[1][j];
+        if (m >= S || test_bit(occ, m)) {
+            flag(E, g, RZ_FLAG_ILLEGAL_MOVE, lane);
+        } else {
+            if (to_move == 0) set_bit(st[0], m); else set_bit(st[1], m);
+            to_move ^= 1;
+            if (lane == 0) {
+                E.root_to_move[g] = to_move;
+                E.root_last[g] = m;
+            }
+            if (lane < 2 * kWords) {
+                const int colour = lane / kWords, j = lane % kWords;
+                E.root_stones[((long long)g * 2 + colour) * kWords + j] = word_of(st[colour], j);
+            }
+        }
+    }
+    int who = -1;
+    if (line_anywhere(st[0], S, E.B, E.n_row, lane)) who = 0;
+    else if (line_anywhere(st[1], S, E.B, E.n_row, lane)) who = 1;
+    const bool over = who >= 0 || count_bits(st[0]) + count_bits(st[1]) == S;
+    if (lane == 0) {
+        if (winner) winner[g] = who;
+        if (ended) ended[g] = over ? 1 : 0;
+    }
+}
+
+__global__ void k_set_roots(Dev E, const uint64_t *stones, const int32_t *to_move,
+                            const int32_t *last_move, const uint8_t *mask, int reset_trees) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.n_games) return;
+    if (mask != nullptr && !mask[g]) return;
+    for (int j = 0; j < 2 * kWords; ++j) {
+        const uint64_t v = stones[(long long)g * 2 * kWords + j];
+        E.root_stones[(long long)g * 2 * kWords + j] = v & E.valid[j % kWords];
+    }
+    E.root_to_move[g] = to_move[g] & 1;
+    E.root_last[g] = last_move[g];
+    if (reset_trees) fresh_root(E, g, E.cur_arena[g], 0);
+}
+
+__global__ void k_get_roots(Dev E, uint64_t *stones, int32_t *to_move, int32_t *last_move) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.n_games) return;
+    for (int j = 0; j < 2 * kWords; ++j)
+        stones[(long long)g * 2 * kWords + j] = E.root_stones[(long long)g * 2 * kWords + j];
+    to_move[g] = E.root_to_move[g];
+    last_move[g] = E.root_last[g];
+}
+
+__global__ void k_get_leaves(Dev E, uint64_t *stones, int32_t *to_move, int32_t *last_move,
+                             int32_t *terminal) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.n_games) return;
+    for (int j = 0; j < 2 * kWords; ++j)
+        stones[(long long)g * 2 * kWords + j] = E.leaf_stones[(long long)g * 2 * kWords + j];
+    to_move[g] = E.leaf_to_move[g];
+    last_move[g] = E.leaf_last[g];
+    terminal[g] = E.leaf_term[g];
+}
+
+__global__ void k_set_active(Dev E, const uint8_t *active) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < E.n_games) E.active[g] = active ? (active[g] ? 1 : 0) : 1;
+}
+
+// which: 0 = leaf boards, 1 = root boards
+__global__ __launch_bounds__(kWave) void k_encode(Dev E, int which, float *obs) {
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint64_t *src = which == 0 ? E.leaf_stones : E.root_stones;
+    uint64_t st[2][kWords];
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) {
+        st[0][j] = src[((long long)g * 2 + 0) * kWords + j];
+        st[1][j] = src[((long long)g * 2 + 1) * kWords + j];
+    }
+    const int to_move = which == 0 ? E.leaf_to_move[g] : E.root_to_move[g];
+    const int last = which == 0 ? E.leaf_last[g] : E.root_last[g];
+    const int nst = count_bits(st[0]) + count_bits(st[1]);
+    write_obs(obs + (long long)g * 4 * E.S, to_move == 0 ? st[0] : st[1],
+              to_move == 0 ? st[1] : st[0], last, nst, E.S, lane);
+}
+
+__global__ void k_uct_scores(const double *w, const int32_t *n, const int32_t *np, double c,
+                             const double *logtab, long long logtab_n, double *out, long long count) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int pn = np[i];
+    if (pn == 0 || n[i] == 0 || pn >= logtab_n) {
+        out[i] = INFINITY;
+        return;
+    }
+    out[i] = uct_ref(w[i], n[i], logtab[pn], c);
+}
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define RZ_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t err__ = (call);                                                           \
+        if (err__ != hipSuccess)                                                             \
+            return fail(err__ == hipErrorOutOfMemory ? RZ_ERR_OOM : RZ_ERR_HIP, "%s failed: %s", \
+                        #call, hipGetErrorString(err__));                                    \
+    } while (0)
+
+}  // namespace
+
+struct rz_engine {
+    rz_config cfg;
+    Dev dev;
+    std::vector<void *> allocs;
+    long long bytes = 0;
+    long long n_select = 0;
+    double *d_logtab = nullptr;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(rz_engine *e, T **out, long long count) {
+    void *p = nullptr;
+    const size_t bytes = (size_t)count * sizeof(T);
+    hipError_t err = hipMalloc(&p, bytes ? bytes : 8);
+    if (err != hipSuccess)
+        return fail(RZ_ERR_OOM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(err));
+    e->allocs.push_back(p);
+    e->bytes += (long long)bytes;
+    *out = (T *)p;
+    return RZ_OK;
+}
+
+int check_engine(rz_engine *e) {
+    if (e == nullptr) return fail(RZ_ERR_ARG, "engine handle is NULL");
+    int cur = -1;
+    RZ_HIP(hipGetDevice(&cur));
+    if (cur != e->cfg.device) RZ_HIP(hipSetDevice(e->cfg.device));
+    return RZ_OK;
+}
+
+inline hipStream_t as_stream(void *s) { return (hipStream_t)s; }
+
+int launched(const char *what) {
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return fail(RZ_ERR_HIP, "launch of %s failed: %s", what, hipGetErrorString(err));
+    return RZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rz_abi_version(void) { return RZ_ABI_VERSION; }
+const char *rz_last_error(void) { return g_err; }
+
+int rz_create(const rz_config *cfg, rz_engine **out) {
+    if (cfg == nullptr || out == nullptr) return fail(RZ_ERR_ARG, "cfg/out is NULL");
+    *out = nullptr;
+    if (cfg->abi_version != RZ_ABI_VERSION)
+        return fail(RZ_ERR_ARG, "abi_version %d != library %d", cfg->abi_version, RZ_ABI_VERSION);
+    if (cfg->game_kind != RZ_GAME_GOMOKU) return fail(RZ_ERR_ARG, "unknown game_kind %d", cfg->game_kind);
+    if (cfg->board_size < 1 || cfg->board_size > RZ_MAX_BOARD_SIZE)
+        return fail(RZ_ERR_ARG, "board_size %d not in 1..%d", cfg->board_size, RZ_MAX_BOARD_SIZE);
+    if (cfg->n_in_row < 1 || cfg->n_in_row > cfg->board_size)
+        return fail(RZ_ERR_ARG, "n_in_row %d not in 1..board_size", cfg->n_in_row);
+    if (cfg->n_games < 1) return fail(RZ_ERR_ARG, "n_games must be >= 1");
+    if (cfg->n_playout < 1) return fail(RZ_ERR_ARG, "n_playout must be >= 1");
+    if (cfg->score_mode != RZ_SCORE_UCT_REF)
+        return fail(RZ_ERR_ARG, "score_mode %d is not available in this build", cfg->score_mode);
+    if (!(cfg->c_puct >= 0.0)) return fail(RZ_ERR_ARG, "c_puct must be >= 0");
+    int n_dev = 0;
+    RZ_HIP(hipGetDeviceCount(&n_dev));
+    if (cfg->device < 0 || cfg->device >= n_dev)
+        return fail(RZ_ERR_ARG, "device %d not in 0..%d", cfg->device, n_dev - 1);
+    RZ_HIP(hipSetDevice(cfg->device));
+
+    rz_engine *e = new (std::nothrow) rz_engine();
+    if (e == nullptr) return fail(RZ_ERR_OOM, "host allocation failed");
+    e->cfg = *cfg;
+    Dev &D = e->dev;
+    memset(&D, 0, sizeof(D));
+    const int S = cfg->board_size * cfg->board_size;
+    const double pf = cfg->pool_factor > 0.0 ? cfg->pool_factor : 2.0;
+    D.S = S;
+    D.B = cfg->board_size;
+    D.n_row = cfg->n_in_row;
+    D.n_games = cfg->n_games;
+    D.score_mode = cfg->score_mode;
+    D.c_puct = cfg->c_puct;
+    D.cap = (long long)(pf * (double)cfg->n_playout * (double)S) + S + 2;
+    D.qcap = (int)(pf * (double)cfg->n_playout) + 8;
+    D.path_stride = S + 2;
+    D.logtab_n = (long long)cfg->n_playout * (S + 1) + 2;
+    for (int j = 0; j < kWords; ++j) {
+        const int lo = 64 * j;
+        D.valid[j] = S >= lo + 64 ? ~0ull : (S > lo ? ((1ull << (S - lo)) - 1ull) : 0ull);
+    }
+    const long long G = cfg->n_games;
+    const long long slots = G * 2 * D.cap;
+    int rc = RZ_OK;
+#define RZ_ALLOC(field, count)                               \
+    if (rc == RZ_OK) rc = dev_alloc(e, &D.field, (count))
+    RZ_ALLOC(N, slots);
+    RZ_ALLOC(W, slots);
+    RZ_ALLOC(FC, slots);
+    RZ_ALLOC(NV, slots);
+    RZ_ALLOC(P, slots);
+    RZ_ALLOC(cur_arena, G);
+    RZ_ALLOC(top, G);
+    RZ_ALLOC(nblk, G);
+    RZ_ALLOC(root_stones, G * 2 * kWords);
+    RZ_ALLOC(root_to_move, G);
+    RZ_ALLOC(root_last, G);
+    RZ_ALLOC(active, G);
+    RZ_ALLOC(path, G * D.path_stride);
+    RZ_ALLOC(leaf_node, G);
+    RZ_ALLOC(leaf_depth, G);
+    RZ_ALLOC(leaf_fresh, G);
+    RZ_ALLOC(leaf_term, G);
+    RZ_ALLOC(leaf_tval, G);
+    RZ_ALLOC(leaf_stones, G * 2 * kWords);
+    RZ_ALLOC(leaf_to_move, G);
+    RZ_ALLOC(leaf_last, G);
+    RZ_ALLOC(queue, G * D.qcap * 4);
+    RZ_ALLOC(err, G);
+    RZ_ALLOC(err_any, 1);
+    if (rc == RZ_OK) rc = dev_alloc(e, &e->d_logtab, D.logtab_n);
+#undef RZ_ALLOC
+    if (rc != RZ_OK) {
+        rz_destroy(e);
+        return rc;
+    }
+    D.logtab = e->d_logtab;
+    // zero the small state; arenas need no initialisation beyond the root slot
+    hipError_t herr = hipSuccess;
+    auto zero = [&](void *p, size_t bytes) { if (herr == hipSuccess) herr = hipMemset(p, 0, bytes); };
+    zero(D.cur_arena, G * 4); zero(D.top, G * 4); zero(D.nblk, G * 4);
+    zero(D.root_stones, G * 2 * kWords * 8); zero(D.root_to_move, G * 4);
+    zero(D.leaf_node, G * 4); zero(D.leaf_depth, G * 4); zero(D.leaf_fresh, G * 4);
+    zero(D.leaf_term, G * 4); zero(D.leaf_tval, G * 8); zero(D.leaf_stones, G * 2 * kWords * 8);
+    zero(D.leaf_to_move, G * 4); zero(D.path, G * D.path_stride * 4);
+    zero(D.err, G * 4); zero(D.err_any, 4);
+    if (herr == hipSuccess) herr = hipMemset(D.root_last, 0xff, G * 4);  // -1
+    if (herr == hipSuccess) herr = hipMemset(D.leaf_last, 0xff, G * 4);
+    if (herr == hipSuccess) herr = hipMemset(D.active, 1, G);
+    if (herr != hipSuccess) {
+        rz_destroy(e);
+        return fail(RZ_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(herr));
+    }
+    {
+        std::vector<double> tab((size_t)D.logtab_n);
+        tab[0] = 0.0;
+        for (long long i = 1; i < D.logtab_n; ++i) tab[(size_t)i] = std::log((double)i);
+        herr = hipMemcpy(e->d_logtab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
+        if (herr != hipSuccess) {
+            rz_destroy(e);
+            return fail(RZ_ERR_HIP, "hipMemcpy(log table) failed: %s", hipGetErrorString(herr));
+        }
+    }
+    {   // fresh trees
+        std::vector<int32_t> mv((size_t)G, -1);
+        int32_t *d_mv = nullptr;
+        herr = hipMalloc((void **)&d_mv, G * 4);
+        if (herr == hipSuccess) herr = hipMemcpy(d_mv, mv.data(), G * 4, hipMemcpyHostToDevice);
+        if (herr == hipSuccess) {
+            k_advance<<<dim3((unsigned)G), dim3(kWave), 0, 0>>>(D, d_mv);
+            herr = hipDeviceSynchronize();
+        }
+        if (d_mv) (void)hipFree(d_mv);
+        if (herr != hipSuccess) {
+            rz_destroy(e);
+            return fail(RZ_ERR_HIP, "tree initialisation failed: %s", hipGetErrorString(herr));
+        }
+    }
+    *out = e;
+    return RZ_OK;
+}
+
+int rz_destroy(rz_engine *e) {
+    if (e == nullptr) return RZ_OK;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (void *p : e->allocs) (void)hipFree(p);
+    delete e;
+    return RZ_OK;
+}
+
+int rz_upload_log_table(rz_engine *e, const double *h_table, int64_t count) {
+    int rc = check_engine(e);
+    if (rc != RZ_OK) return rc;
+    if (h_table == nullptr || count < 2) return fail(RZ_ERR_ARG, "table is NULL or too short");
+    if (count > e->dev.logtab_n) count = e->dev.logtab_n;
+    RZ_HIP(hipDeviceSynchronize());
+    RZ_HIP(hipMemcpy(e->d_logtab, h_table, (size_t)count * sizeof(double), hipMemcpyHostToDevice));
+    return RZ_OK;
+}
+
+int rz_log_table_size(rz_engine *e, int64_t *count) {
+    if (e == nullptr || count == nullptr) return fail(RZ_ERR_ARG, "NULL argument");
+    *count = e->dev.logtab_n;
+    return RZ_OK;
+}
+
+#define RZ_ENTER(e)                      \
+    do {                                 \
+        int rc__ = check_engine(e);      \
+        if (rc__ != RZ_OK) return rc__;  \
+    } while (0)
+#define RZ_NEED(p)                                                       \
+    do {                                                                 \
+        if ((p) == nullptr) return fail(RZ_ERR_ARG, "%s is NULL", #p);   \
+    } while (0)
+
+static inline dim3 per_game(const rz_engine *e) { return dim3((unsigned)e->cfg.n_games); }
+static inline dim3 flat_grid(const rz_engine *e) { return dim3((unsigned)((e->cfg.n_games + 255) / 256)); }
+
+int rz_set_roots(rz_engine *e, const uint64_t *d_stones, const int32_t *d_to_move,
+                 const int32_t *d_last_move, const uint8_t *d_mask, int reset_trees, void *stream) {
+    RZ_ENTER(e);
+    RZ_NEED(d_stones); RZ_NEED(d_to_move); RZ_NEED(d_last_move);
+    k_set_roots<<<flat_grid(e), dim3(256), 0, as_stream(stream)>>>(e->dev, d_stones, d_to_move,
+                                                                   d_last_move, d_mask, reset_trees);
+    return launched("k_set_roots");
+}
+
+int rz_get_roots(rz_engine *e, uint64_t *d_stones, int32_t *d_to_move, int32_t *d_last_move,
+                 void *stream) {
+    RZ_ENTER(e);
+    RZ_NEED(d_stones); RZ_NEED(d_to_move); RZ_NEED(d_last_move);
+    k_get_roots<<<flat_grid(e), dim3(256), 0, as_stream(stream)>>>(e->dev, d_stones, d_to_move, d_last_move);
+    return launched("k_get_roots");
+}
+
+int rz_set_active(rz_engine *e, const uint8_t *d_active, void *stream) {
+    RZ_ENTER(e);
+    k_set_active<<<flat_grid(e), dim3(256), 0, as_stream(stream)>>>(e->dev, d_active);
+    return launched("k_set_active");
+}
+
+int rz_select_step(rz_engine *e, float *d_obs, void *stream) {
+    RZ_ENTER(e);
+    e->n_select += 1;
+    k_select<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_obs);
+    return launched("k_select");
+}
+
+int rz_encode_leaf_obs(rz_engine *e, float *d_obs, void *stream) {
+    RZ_ENTER(e);
+    RZ_NEED(d_obs);
+    k_encode<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, 0, d_obs);
+    return launched("k_encode");
+}
+
+int rz_encode_root_obs(rz_engine *e, float *d_obs, void *stream) {
+    RZ_ENTER(e);
+    RZ_NEED(d_obs);
+    k_encode<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, 1, d_obs);
+    return launched("k_encode");
+}
+
+int rz_get_leaves(rz_engine *e, uint64_t *d_stones, int32_t *d_to_move, int32_t *d_last_move,
+                  int32_t *d_terminal, void *stream) {
+    RZ_ENTER(e);
+    RZ_NEED(d_stones); RZ_NEED(d_to_move); RZ_NEED(d_last_move); RZ_NEED(d_terminal);
+    k_get_leaves<<<flat_grid(e), dim3(256), 0, as_stream(stream)>>>(e->dev, d_stones, d_to_move,
+                                                                    d_last_move, d_terminal);
+    return launched("k_get_leaves");
+}
+
+int rz_eval_synthetic(rz_engine *e, int kind, float *d_logp, float *d_value, void *stream) {
+    RZ_ENTER(e);
+    RZ_NEED(d_value);
+    if (kind != RZ_EVAL_V0 && kind != RZ_EVAL_VLIN) return fail(RZ_ERR_ARG, "unknown evaluator %d", kind);
+    k_eval_synth<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, kind, d_logp, d_value);
+    return launched("k_eval_synth");
+}
+
+int rz_expand_backup(rz_engine *e, const float *d_logp, const float *d_value, void *stream) {
+    RZ_ENTER(e);
+    RZ_NEED(d_value);
+    k_expand_backup<float><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_logp, d_value);
+    return launched("k_expand_backup");
+}
+
+int rz_expand_backup_f64(rz_engine *e, const float *d_logp, const double *d_value, void *stream) {
+    RZ_ENTER(e);
+    RZ_NEED(d_value);
+    k_expand_backup<double><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_logp, d_value);
+    return launched("k_expand_backup");
+}
+
+int rz_root_visits(rz_engine *e, int32_t *d_visits, void *stream) {
+    RZ_ENTER(e);
+    RZ_NEED(d_visits);
+    k_root_children<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, 0, d_visits);
+    return launched("k_root_children");
+}
+
+int rz_root_wsum(rz_engine *e, double *d_w, void *stream) {
+    RZ_ENTER(e);
+    RZ_NEED(d_w);
+    k_root_children<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, 1, d_w);
+    return launched("k_root_children");
+}
+
+int rz_root_priors(rz_engine *e, float *d_p, void *stream) {
+    RZ_ENTER(e);
+    RZ_NEED(d_p);
+    k_root_children<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, 2, d_p);
+    return launched("k_root_children");
+}
+
+int rz_root_stats(rz_engine *e, int32_t *d_n, double *d_w, void *stream) {
+    RZ_ENTER(e);
+    RZ_NEED(d_n); RZ_NEED(d_w);
+    k_root_stats<<<flat_grid(e), dim3(256), 0, as_stream(stream)>>>(e->dev, d_n, d_w);
+    return launched("k_root_stats");
+}
+
+int rz_advance_roots(rz_engine *e, const int32_t *d_moves, void *stream) {
+    RZ_ENTER(e);
+    RZ_NEED(d_moves);
+    k_advance<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_moves);
+    return launched("k_advance");
+}
+
+int rz_step_games(rz_engine *e, const int32_t *d_moves, int32_t *d_winner, uint8_t *d_ended, void *stream) {
+    RZ_ENTER(e);
+    RZ_NEED(d_moves);
+    k_step_games<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_moves, d_winner, d_ended);
+    return launched("k_step_games");
+}
+
+int rz_get_stats(rz_engine *e, rz_stats *out) {
+    RZ_ENTER(e);
+    RZ_NEED(out);
+    RZ_HIP(hipDeviceSynchronize());
+    const size_t G = (size_t)e->cfg.n_games;
+    std::vector<int32_t> err(G), top(G), nblk(G);
+    int32_t any = 0;
+    RZ_HIP(hipMemcpy(&any, e->dev.err_any, 4, hipMemcpyDeviceToHost));
+    RZ_HIP(hipMemcpy(err.data(), e->dev.err, G * 4, hipMemcpyDeviceToHost));
+    RZ_HIP(hipMemcpy(top.data(), e->dev.top, G * 4, hipMemcpyDeviceToHost));
+    RZ_HIP(hipMemcpy(nblk.data(), e->dev.nblk, G * 4, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof(*out));
+    out->error_flags = any;
+    out->first_bad_game = -1;
+    for (size_t g = 0; g < G; ++g) {
+        if (err[g] && out->first_bad_game < 0) out->first_bad_game = (int32_t)g;
+        if (top[g] > out->max_slots_used) out->max_slots_used = top[g];
+        if (nblk[g] > out->max_blocks_used) out->max_blocks_used = nblk[g];
+    }
+    out->arena_slots = e->dev.cap;
+    out->device_bytes = e->bytes;
+    out->n_select_calls = e->n_select;
+    return RZ_OK;
+}
+
+int rz_clear_errors(rz_engine *e) {
+    RZ_ENTER(e);
+    RZ_HIP(hipDeviceSynchronize());
+    RZ_HIP(hipMemset(e->dev.err, 0, (size_t)e->cfg.n_games * 4));
+    RZ_HIP(hipMemset(e->dev.err_any, 0, 4));
+    return RZ_OK;
+}
+
+int rz_copy_arena(rz_engine *e, int32_t game, int64_t max_slots, int32_t *h_n, double *h_w,
+                  int32_t *h_first_child, int32_t *h_n_visited, float *h_prior, int32_t *h_top) {
+    RZ_ENTER(e);
+    RZ_NEED(h_top);
+    if (game < 0 || game >= e->cfg.n_games) return fail(RZ_ERR_ARG, "game %d out of range", game);
+    RZ_HIP(hipDeviceSynchronize());
+    int32_t arena = 0, top = 0;
+    RZ_HIP(hipMemcpy(&arena, e->dev.cur_arena + game, 4, hipMemcpyDeviceToHost));
+    RZ_HIP(hipMemcpy(&top, e->dev.top + game, 4, hipMemcpyDeviceToHost));
+    *h_top = top;
+    long long n = top < max_slots ? top : max_slots;
+    if (n <= 0) return RZ_OK;
+    const long long base = ((long long)game * 2 + arena) * e->dev.cap;
+    if (h_n) RZ_HIP(hipMemcpy(h_n, e->dev.N + base, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (h_w) RZ_HIP(hipMemcpy(h_w, e->dev.W + base, (size_t)n * 8, hipMemcpyDeviceToHost));
+    if (h_first_child) RZ_HIP(hipMemcpy(h_first_child, e->dev.FC + base, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (h_n_visited) RZ_HIP(hipMemcpy(h_n_visited, e->dev.NV + base, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (h_prior) RZ_HIP(hipMemcpy(h_prior, e->dev.P + base, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return RZ_OK;
+}
+
+int rz_uct_scores(rz_engine *e, const double *d_w, const int32_t *d_n, const int32_t *d_np,
+                  double c_puct, double *d_out, int64_t count, void *stream) {
+    RZ_ENTER(e);
+    RZ_NEED(d_w); RZ_NEED(d_n); RZ_NEED(d_np); RZ_NEED(d_out);
+    if (count <= 0) return RZ_OK;
+    const unsigned blocks = (unsigned)((count + 255) / 256);
+    k_uct_scores<<<dim3(blocks), dim3(256), 0, as_stream(stream)>>>(d_w, d_n, d_np, c_puct, e->d_logtab,
+                                                                    e->dev.logtab_n, d_out, count);
+    return launched("k_uct_scores");
+}
+
+}  // extern "C"

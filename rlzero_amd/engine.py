@@ -1,0 +1,371 @@
+"""Host driver of the HIP MCTS engine: device buffers, the simulation loop, evaluators.
+
+PyTorch is used for device memory, streams and (for the evaluator) the network forward;
+the tree, the board rules and the observation encoding run in the hand-written HIP kernels
+of ``csrc/rz_engine.hip`` through the C ABI of ``include/rlzero_hip.h``.
+
+One simulation step of all games = what the reference does once per game in
+``AlphaZeroMCTS._playout`` (rlzero/mcts/alphazero_mcts.py:42-71):
+
+    rz_select_step      select loop + env.step + game_end_winner + current_state
+    evaluator           policy_value_fn on the batch of leaves
+    rz_expand_backup    expand / terminal value + update_recursive
+"""
+import ctypes
+
+import numpy as np
+
+from . import _hip
+from ._hip import HipError, check
+
+WORDS = _hip.BOARD_WORDS
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class SyntheticEvaluator(object):
+    """v0 / vlin of SURVEY.md Appendix B, computed on the device from the leaf bitboards."""
+    needs_obs = False
+
+    def __init__(self, kind):
+        self.kind = {'v0': _hip.EVAL_V0, 'vlin': _hip.EVAL_VLIN}[kind] if isinstance(kind, str) else kind
+
+    def __call__(self, eng):
+        check(eng.lib.rz_eval_synthetic(eng.handle, self.kind, _ptr(eng.logp), _ptr(eng.value),
+                                        eng.stream()), 'rz_eval_synthetic')
+        return eng.logp, eng.value
+
+
+class NetEvaluator(object):
+    """Batched forward of a policy-value module on the leaf observations
+    (AlphaZeroAgent.policy_value_fn, rlzero/games/gomoku/alphazero_agent.py:31-46, for the
+    whole batch at once).  ``net(obs[G,4,B,B]) -> (log_probs[G,S], value[G,1])``."""
+    needs_obs = True
+
+    def __init__(self, net):
+        self.net = net
+
+    def __call__(self, eng):
+        import torch
+        with torch.no_grad():
+            logp, value = self.net(eng.obs)
+        return logp.contiguous(), value.reshape(-1).contiguous()
+
+
+class HostEvaluator(object):
+    """Any ``policy_value_fn(env) -> (iterable[(action, prob)], value)`` callable
+    (alphazero_mcts.py:28-31,59), called once per leaf on a materialised env object.
+    Slow (one device round trip per simulation) but exact for arbitrary evaluators."""
+    needs_obs = False
+
+    def __init__(self, fn, make_env):
+        self.fn = fn
+        self.make_env = make_env  # (stones0:int, stones1:int, to_move, last_move) -> env
+        self.log = None           # optional list of (game, value)
+
+    def __call__(self, eng):
+        import torch
+        stones, to_move, last, term = eng.get_leaves()
+        active = eng.active_host
+        values = np.zeros(eng.n_games, dtype=np.float64)
+        logp = np.full((eng.n_games, eng.n_cells), -np.inf, dtype=np.float32)
+        for g in range(eng.n_games):
+            if not active[g]:
+                continue
+            env = self.make_env(bits_to_int(stones[g, 0]), bits_to_int(stones[g, 1]),
+                                int(to_move[g]), int(last[g]))
+            priors, value = self.fn(env)  # called on terminal leaves too (:59)
+            values[g] = value
+            for a, p in priors:
+                logp[g, int(a)] = np.log(np.float32(p)) if p > 0 else -np.inf
+            if self.log is not None:
+                self.log.append((g, float(value)))
+        eng.value64.copy_(torch.from_numpy(values))
+        eng.logp.copy_(torch.from_numpy(logp))
+        return eng.logp, eng.value64
+
+
+def bits_to_int(words):
+    out = 0
+    for j, w in enumerate(words):
+        out |= int(w) << (64 * j)
+    return out
+
+
+def int_to_bits(x):
+    return [(x >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(WORDS)]
+
+
+class MCTSEngine(object):
+    """``n_games`` independent trees searched in lock-step on one GPU."""
+
+    def __init__(self, board_size, n_in_row, n_games=1, n_playout=1000, c_puct=5.0,
+                 device='cuda:0', pool_factor=2.0):
+        import torch
+        self.lib = _hip.load()
+        self.torch = torch
+        dev = torch.device(device)
+        if dev.type != 'cuda' or not torch.cuda.is_available():
+            raise HipError('the MCTS engine needs an MI355X (device=%r, cuda available=%s); '
+                           'there is no CPU fallback' % (device, torch.cuda.is_available()))
+        self.device = torch.device('cuda', dev.index if dev.index is not None else torch.cuda.current_device())
+        self.board_size, self.n_in_row = int(board_size), int(n_in_row)
+        self.n_cells = self.board_size ** 2
+        self.n_games, self.n_playout, self.c_puct = int(n_games), int(n_playout), float(c_puct)
+        cfg = _hip.RzConfig(abi_version=_hip.ABI_VERSION, game_kind=0, board_size=self.board_size,
+                            n_in_row=self.n_in_row, n_games=self.n_games, n_playout=self.n_playout,
+                            score_mode=_hip.SCORE_UCT_REF, add_noise=0, c_puct=self.c_puct,
+                            pool_factor=float(pool_factor), device=self.device.index, reserved=0)
+        handle = ctypes.c_void_p()
+        check(self.lib.rz_create(ctypes.byref(cfg), ctypes.byref(handle)), 'rz_create')
+        self.handle = handle
+        G, S, B = self.n_games, self.n_cells, self.board_size
+        kw = dict(device=self.device)
+        self.obs = torch.zeros((G, 4, B, B), dtype=torch.float32, **kw)
+        self.logp = torch.zeros((G, S), dtype=torch.float32, **kw)
+        self.value = torch.zeros(G, dtype=torch.float32, **kw)
+        self.value64 = torch.zeros(G, dtype=torch.float64, **kw)
+        self.visits = torch.zeros((G, S), dtype=torch.int32, **kw)
+        self.wsum = torch.zeros((G, S), dtype=torch.float64, **kw)
+        self.priors = torch.zeros((G, S), dtype=torch.float32, **kw)
+        self.root_n = torch.zeros(G, dtype=torch.int32, **kw)
+        self.root_w = torch.zeros(G, dtype=torch.float64, **kw)
+        self.moves = torch.zeros(G, dtype=torch.int32, **kw)
+        self.winner = torch.zeros(G, dtype=torch.int32, **kw)
+        self.ended = torch.zeros(G, dtype=torch.uint8, **kw)
+        self.stones = torch.zeros((G, 2, WORDS), dtype=torch.int64, **kw)
+        self.to_move = torch.zeros(G, dtype=torch.int32, **kw)
+        self.last_move = torch.zeros(G, dtype=torch.int32, **kw)
+        self.terminal = torch.zeros(G, dtype=torch.int32, **kw)
+        self.mask = torch.zeros(G, dtype=torch.uint8, **kw)
+        self.active_dev = torch.ones(G, dtype=torch.uint8, **kw)
+        self.active_host = np.ones(G, dtype=np.uint8)
+        self._graphs = {}
+
+    # ------------------------------------------------------------------ plumbing
+    def stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self._graphs = {}
+            self.lib.rz_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stats(self):
+        out = _hip.RzStats()
+        check(self.lib.rz_get_stats(self.handle, ctypes.byref(out)), 'rz_get_stats')
+        return out
+
+    def check(self):
+        """Raise if any game overflowed its arena / received an illegal move."""
+        st = self.stats()
+        if st.error_flags:
+            names = [n for bit, n in _hip.FLAG_NAMES.items() if st.error_flags & bit]
+            raise HipError('engine error flags 0x%x (%s), first bad game %d, arena %d/%d slots' %
+                           (st.error_flags, ', '.join(names), st.first_bad_game,
+                            st.max_slots_used, st.arena_slots))
+        return st
+
+    # ------------------------------------------------------------------ roots
+    def set_roots(self, stones, to_move, last_move, mask=None, reset_trees=False):
+        """stones: uint64 [G,2,WORDS]; to_move / last_move: int [G]; mask: bool [G] or None."""
+        t = self.torch
+        self.stones.copy_(t.from_numpy(np.ascontiguousarray(stones, dtype=np.uint64).view(np.int64)))
+        self.to_move.copy_(t.from_numpy(np.ascontiguousarray(to_move, dtype=np.int32)))
+        self.last_move.copy_(t.from_numpy(np.ascontiguousarray(last_move, dtype=np.int32)))
+        mptr = None
+        if mask is not None:
+            self.mask.copy_(t.from_numpy(np.ascontiguousarray(mask, dtype=np.uint8)))
+            mptr = _ptr(self.mask)
+        check(self.lib.rz_set_roots(self.handle, _ptr(self.stones), _ptr(self.to_move),
+                                    _ptr(self.last_move), mptr, 1 if reset_trees else 0,
+                                    self.stream()), 'rz_set_roots')
+
+    def reset_games(self, mask=None):
+        """Empty boards, player 0 to move, fresh trees for the selected games."""
+        G = self.n_games
+        self.set_roots(np.zeros((G, 2, WORDS), np.uint64), np.zeros(G, np.int32),
+                       np.full(G, -1, np.int32), mask=mask, reset_trees=True)
+
+    def get_roots(self):
+        check(self.lib.rz_get_roots(self.handle, _ptr(self.stones), _ptr(self.to_move),
+                                    _ptr(self.last_move), self.stream()), 'rz_get_roots')
+        return (self.stones.cpu().numpy().view(np.uint64), self.to_move.cpu().numpy(),
+                self.last_move.cpu().numpy())
+
+    def set_active(self, active):
+        self.active_host = np.ascontiguousarray(active, dtype=np.uint8).copy()
+        self.active_dev.copy_(self.torch.from_numpy(self.active_host))
+        check(self.lib.rz_set_active(self.handle, _ptr(self.active_dev), self.stream()), 'rz_set_active')
+
+    def get_leaves(self):
+        check(self.lib.rz_get_leaves(self.handle, _ptr(self.stones), _ptr(self.to_move),
+                                     _ptr(self.last_move), _ptr(self.terminal), self.stream()),
+              'rz_get_leaves')
+        return (self.stones.cpu().numpy().view(np.uint64), self.to_move.cpu().numpy(),
+                self.last_move.cpu().numpy(), self.terminal.cpu().numpy())
+
+    def root_obs(self):
+        check(self.lib.rz_encode_root_obs(self.handle, _ptr(self.obs), self.stream()), 'rz_encode_root_obs')
+        return self.obs
+
+    # ------------------------------------------------------------------ the hot loop
+    def sim_step(self, evaluator):
+        """One simulation for every active game (enqueued, not synchronised)."""
+        obs = _ptr(self.obs) if getattr(evaluator, 'needs_obs', True) else None
+        check(self.lib.rz_select_step(self.handle, obs, self.stream()), 'rz_select_step')
+        logp, value = evaluator(self)
+        if value.dtype == self.torch.float64:
+            check(self.lib.rz_expand_backup_f64(self.handle, _ptr(logp), _ptr(value), self.stream()),
+                  'rz_expand_backup_f64')
+        else:
+            check(self.lib.rz_expand_backup(self.handle, _ptr(logp), _ptr(value), self.stream()),
+                  'rz_expand_backup')
+
+    def simulate(self, evaluator, n_sims=None, use_graph=False, sims_per_graph=8):
+        """Run ``n_sims`` (default n_playout) simulations in every active game.
+
+        use_graph: capture ``sims_per_graph`` simulation steps in one hipGraph
+        (torch.cuda.CUDAGraph around our launches + the net) and replay it, removing the
+        per-launch host cost; only for device-side evaluators."""
+        n = self.n_playout if n_sims is None else int(n_sims)
+        if not use_graph or isinstance(evaluator, HostEvaluator):
+            for _ in range(n):
+                self.sim_step(evaluator)
+            return
+        per = max(1, min(int(sims_per_graph), n))
+        graph = self._graph_for(evaluator, per)
+        full, rest = divmod(n, per)
+        for _ in range(full):
+            graph.replay()
+        for _ in range(rest):
+            self.sim_step(evaluator)
+
+    def _graph_for(self, evaluator, per):
+        key = (id(evaluator), per)
+        if key in self._graphs:
+            return self._graphs[key][0]
+        t = self.torch
+        # Capturing must not change the trees: simulate on a scratch copy is not possible
+        # (the tree IS the state), so capture happens on the real state and counts as `per`
+        # real simulations -- callers account for it through `warm_graph`.
+        raise HipError('call warm_graph(evaluator, sims_per_graph) before simulate(use_graph=True)')
+
+    def warm_graph(self, evaluator, per):
+        """Capture ``per`` simulation steps into a graph.  The capture itself does not
+        execute kernels; the (eager) warm-up step needed by MIOpen does, so this must be
+        called on throw-away tree state (e.g. before reset_games)."""
+        t = self.torch
+        key = (id(evaluator), per)
+        if key in self._graphs:
+            return self._graphs[key][0]
+        side = t.cuda.Stream(device=self.device)
+        side.wait_stream(t.cuda.current_stream(self.device))
+        with t.cuda.stream(side):
+            for _ in range(3):
+                self.sim_step(evaluator)
+        t.cuda.current_stream(self.device).wait_stream(side)
+        t.cuda.synchronize(self.device)
+        graph = t.cuda.CUDAGraph()
+        with t.cuda.graph(graph):
+            for _ in range(per):
+                self.sim_step(evaluator)
+        self._graphs[key] = (graph, evaluator)
+        return graph
+
+    # ------------------------------------------------------------------ read-out
+    def root_visits(self):
+        check(self.lib.rz_root_visits(self.handle, _ptr(self.visits), self.stream()), 'rz_root_visits')
+        return self.visits.cpu().numpy()
+
+    def root_wsum(self):
+        check(self.lib.rz_root_wsum(self.handle, _ptr(self.wsum), self.stream()), 'rz_root_wsum')
+        return self.wsum.cpu().numpy()
+
+    def root_priors(self):
+        check(self.lib.rz_root_priors(self.handle, _ptr(self.priors), self.stream()), 'rz_root_priors')
+        return self.priors.cpu().numpy()
+
+    def root_stats(self):
+        check(self.lib.rz_root_stats(self.handle, _ptr(self.root_n), _ptr(self.root_w), self.stream()),
+              'rz_root_stats')
+        return self.root_n.cpu().numpy(), self.root_w.cpu().numpy()
+
+    def advance(self, moves):
+        """update_with_move for every game: move >= 0 keep that subtree, -1 reset, -2 skip."""
+        self.moves.copy_(self.torch.from_numpy(np.ascontiguousarray(moves, dtype=np.int32)))
+        check(self.lib.rz_advance_roots(self.handle, _ptr(self.moves), self.stream()), 'rz_advance_roots')
+
+    def step(self, moves):
+        """env.step + game_end_winner on the root boards -> (winner[G], ended[G])."""
+        self.moves.copy_(self.torch.from_numpy(np.ascontiguousarray(moves, dtype=np.int32)))
+        check(self.lib.rz_step_games(self.handle, _ptr(self.moves), _ptr(self.winner),
+                                     _ptr(self.ended), self.stream()), 'rz_step_games')
+        return self.winner.cpu().numpy(), self.ended.cpu().numpy()
+
+    # ------------------------------------------------------------------ inspection
+    def arena(self, game=0):
+        cap = int(self.stats().arena_slots)
+        n = np.zeros(cap, np.int32)
+        w = np.zeros(cap, np.float64)
+        fc = np.zeros(cap, np.int32)
+        nv = np.zeros(cap, np.int32)
+        p = np.zeros(cap, np.float32)
+        top = ctypes.c_int32(0)
+
+        def hp(a):
+            return ctypes.c_void_p(a.ctypes.data)
+
+        check(self.lib.rz_copy_arena(self.handle, int(game), cap, hp(n), hp(w), hp(fc), hp(nv), hp(p),
+                                     ctypes.cast(ctypes.byref(top), ctypes.c_void_p)), 'rz_copy_arena')
+        k = top.value
+        return {'N': n[:k], 'W': w[:k], 'FC': fc[:k], 'NV': nv[:k], 'P': p[:k], 'top': k}
+
+    def tree_dump(self, game=0):
+        """{path of actions: (N, W)} over visited nodes (+ the root), like the oracle's."""
+        ar = self.arena(game)
+        stones, _, _ = self.get_roots()
+        occ0 = bits_to_int(stones[game, 0]) | bits_to_int(stones[game, 1])
+        out = {}
+        stack = [((), 0, occ0)]
+        while stack:
+            path, slot, occ = stack.pop()
+            out[path] = (int(ar['N'][slot]), float(ar['W'][slot]))
+            fc = int(ar['FC'][slot])
+            if fc < 0:
+                continue
+            empties = [c for c in range(self.n_cells) if not (occ >> c) & 1]
+            for r in range(int(ar['NV'][slot])):
+                a = empties[r]
+                stack.append((path + (a, ), fc + r, occ | (1 << a)))
+        return out
+
+    def uct_scores(self, w, n, n_parent, c_puct):
+        """The select arithmetic alone (for bit-exactness tests)."""
+        t = self.torch
+        dw = t.from_numpy(np.ascontiguousarray(w, np.float64)).to(self.device)
+        dn = t.from_numpy(np.ascontiguousarray(n, np.int32)).to(self.device)
+        dp = t.from_numpy(np.ascontiguousarray(n_parent, np.int32)).to(self.device)
+        out = t.empty_like(dw)
+        check(self.lib.rz_uct_scores(self.handle, _ptr(dw), _ptr(dn), _ptr(dp), float(c_puct),
+                                     _ptr(out), dw.numel(), self.stream()), 'rz_uct_scores')
+        return out.cpu().numpy()
+
+    def log_table_size(self):
+        n = ctypes.c_int64(0)
+        check(self.lib.rz_log_table_size(self.handle, ctypes.byref(n)), 'rz_log_table_size')
+        return n.value
+
+    def upload_log_table(self, table):
+        table = np.ascontiguousarray(table, dtype=np.float64)
+        check(self.lib.rz_upload_log_table(self.handle, ctypes.c_void_p(table.ctypes.data), table.size),
+              'rz_upload_log_table')

@@ -1,0 +1,7 @@
+from .base_env import BaseEnv, Error
+from .gomoku.game import GameControl
+from .gomoku.gomoku_env import GomokuEnv
+
+Game = BaseEnv  # BASELINE.json calls the env interface "rlzero.games.Game"
+
+__all__ = ['BaseEnv', 'GomokuEnv', 'GameControl', 'Game', 'Error']

@@ -1,0 +1,436 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the golden fixtures.
+
+Bit-exact: visit counts, W (fp64 bit patterns), moves, winners, z, observation planes.
+pi to 1e-12 (same numpy expression on identical integers).  Net outputs within the 1e-4
+fp32 tolerance BASELINE.json states.  Run on the GPU box: ``pytest -m gpu``.
+"""
+import hashlib
+import math
+
+import numpy as np
+import pytest
+from conftest import bits_of_planes, unhex
+
+from oracle import evaluators as ev
+from oracle.gomoku_ref import RefGomoku
+from oracle.mcts_ref import (RefPlayer, RefSearch, inverse_cdf_choice, self_play_game, tree_dump)
+
+pytestmark = pytest.mark.gpu
+
+EVALS = {'v0': ev.v0, 'vlin': ev.vlin}
+
+
+def _engine(*args, **kw):
+    from rlzero_amd.engine import MCTSEngine
+    return MCTSEngine(*args, **kw)
+
+
+def _stones_of(envs):
+    from rlzero_amd.engine import int_to_bits
+    return np.array([[int_to_bits(e.bitboards()[0]), int_to_bits(e.bitboards()[1])] for e in envs],
+                    dtype=np.uint64)
+
+
+def _set_roots(eng, envs, **kw):
+    eng.set_roots(_stones_of(envs), [e.current_player() for e in envs], [e.last_move for e in envs], **kw)
+
+
+def _hex_tree(dump):
+    return {p: (n, float(w).hex()) for p, (n, w) in dump.items()}
+
+
+# ------------------------------------------------------------------ arithmetic
+def test_uct_arithmetic_bit_exact():
+    """q + c*u on the device == CPython's two-rounding fp64 expression (node.py:83-87)."""
+    eng = _engine(15, 5, n_games=1, n_playout=800)
+    rs = np.random.RandomState(0)
+    count = 200000
+    n = rs.randint(1, 4000, size=count).astype(np.int32)
+    npar = np.maximum(n, rs.randint(1, eng.log_table_size() - 1, size=count)).astype(np.int32)
+    w = np.where(rs.rand(count) < 0.5, rs.randint(-8 * 4000, 8 * 4000, size=count) / 8.0,
+                 rs.standard_normal(count) * n)
+    w = np.clip(w, -n.astype(np.float64), n.astype(np.float64))
+    for c in (5.0, 0.5, 1.25, 0.0):
+        got = eng.uct_scores(w, n, npar, c)
+        want = np.array([wi / ni + c * math.sqrt(math.log(pi) / ni)
+                         for wi, ni, pi in zip(w.tolist(), n.tolist(), npar.tolist())])
+        assert got.view(np.uint64).tolist() == want.view(np.uint64).tolist()
+    # the table really is the host libm's log: re-uploading math.log changes nothing
+    base = eng.uct_scores(w, n, npar, 5.0)
+    eng.upload_log_table([0.0] + [math.log(i) for i in range(1, eng.log_table_size())])
+    assert (eng.uct_scores(w, n, npar, 5.0).view(np.uint64) == base.view(np.uint64)).all()
+    # unvisited child / parent -> +inf
+    assert np.isinf(eng.uct_scores([0.0, 1.0], [0, 3], [5, 0], 5.0)).all()
+    eng.close()
+
+
+# ------------------------------------------------------------------ rules
+@pytest.mark.parametrize('group', ['random', 'handmade'])
+def test_rules_on_device(g1, group):
+    """rz_step_games / rz_encode_root_obs vs every ply of the rules fixtures."""
+    by_board = {}
+    for case in g1[group]:
+        by_board.setdefault((case['B'], case['n']), []).append(case)
+    for (B, n), cases in by_board.items():
+        eng = _engine(B, n, n_games=len(cases), n_playout=4)
+        eng.reset_games()
+        for ply_i in range(max(len(c['plies']) for c in cases)):
+            moves = np.array([c['plies'][ply_i]['a'] if ply_i < len(c['plies']) else -1 for c in cases],
+                             dtype=np.int32)
+            winner, ended = eng.step(moves)
+            obs = eng.root_obs().cpu().numpy()
+            stones, to_move, last = eng.get_roots()
+            for g, c in enumerate(cases):
+                if ply_i >= len(c['plies']):
+                    continue
+                ply = c['plies'][ply_i]
+                assert bool(ended[g]) == ply['ended'] and int(winner[g]) == ply['winner'], (c.get('name'), ply_i)
+                assert bits_of_planes(obs[g]) == ply['obs']
+                assert int(to_move[g]) == ply['to_move'] and int(last[g]) == ply['last']
+        eng.check()
+        eng.close()
+
+
+def test_illegal_move_is_flagged():
+    from rlzero_amd._hip import HipError
+    eng = _engine(3, 3, n_games=2, n_playout=4)
+    eng.reset_games()
+    eng.step([4, 4])
+    eng.step([4, 0])
+    with pytest.raises(HipError):
+        eng.check()
+    eng.close()
+
+
+# ------------------------------------------------------------------ search (G2)
+def _check_case(eng, evaluator, rec, env):
+    from rlzero_amd.selfplay import visits_to_pi
+    eng.simulate(evaluator, rec['n_playout'])
+    visits, wsum = eng.root_visits()[0], eng.root_wsum()[0]
+    rn, rw = eng.root_stats()
+    eng.check()
+    assert int(rn[0]) == rec['root_N'] and float(rw[0]).hex() == rec['root_W']
+    acts = rec['acts']
+    assert env.leagel_actions() == acts
+    assert [int(visits[a]) for a in acts] == rec['N']
+    # unvisited children have W == int 0 in the reference -> '0x0.0p+0'
+    assert [float(wsum[a]).hex() for a in acts] == rec['W']
+    occupied = [a for a in range(eng.n_cells) if a not in acts]
+    assert not visits[occupied].any()
+    pi = visits_to_pi(visits[acts], rec['T'])
+    assert np.max(np.abs(pi - np.array([unhex(p) for p in rec['pi']]))) <= 1e-12
+    dump = _hex_tree(eng.tree_dump(0))
+    assert len(dump) == rec['n_nodes']
+    if 'tree' in rec:
+        assert dump == {tuple(p): (n, w) for p, n, w in rec['tree']}
+    else:
+        h = hashlib.sha1()
+        for path in sorted(dump, key=list):
+            h.update(repr((path, dump[path][0], dump[path][1])).encode())
+        assert h.hexdigest() == rec['tree_sha1']
+
+
+def test_search_synthetic_golden(g2):
+    from rlzero_amd.engine import SyntheticEvaluator
+    for rec in g2['cases']:
+        env = RefGomoku.from_moves(rec['B'], rec['n'], rec['pre'])
+        eng = _engine(rec['B'], rec['n'], n_games=1, n_playout=rec['n_playout'], c_puct=rec['c_puct'])
+        _set_roots(eng, [env], reset_trees=True)
+        _check_case(eng, SyntheticEvaluator(rec['eval']), rec, env)
+        eng.close()
+
+
+def test_search_host_callable_golden(g2):
+    """Same fixtures through the generic evaluator plug-in (a Python callable per leaf)."""
+    from rlzero_amd.engine import HostEvaluator
+    from rlzero_amd.games import GomokuEnv
+    for rec in g2['cases']:
+        if rec['n_playout'] > 400:
+            continue
+        B, n = rec['B'], rec['n']
+        env = RefGomoku.from_moves(B, n, rec['pre'])
+        eng = _engine(B, n, n_games=1, n_playout=rec['n_playout'], c_puct=rec['c_puct'])
+        _set_roots(eng, [env], reset_trees=True)
+        host = HostEvaluator(EVALS[rec['eval']],
+                             lambda s0, s1, tm, last, B=B, n=n: GomokuEnv.from_bitboards(B, n, s0, s1, tm, last))
+        _check_case(eng, host, rec, env)
+        eng.close()
+
+
+def test_search_batch_of_positions_vs_oracle():
+    """64 different 9x9 positions searched in lock-step == 64 independent oracle searches
+    (BASELINE config 2: 9x9, 200 sims, 64 games)."""
+    from rlzero_amd.engine import SyntheticEvaluator
+    rs = np.random.RandomState(99)
+    envs = []
+    while len(envs) < 64:
+        k = rs.randint(0, 40)
+        env = RefGomoku.from_moves(9, 5, [])
+        for m in rs.permutation(81)[:k]:
+            env.step(int(m))
+            if env.game_end_winner()[0]:
+                break
+        if not env.game_end_winner()[0]:
+            envs.append(env)
+    eng = _engine(9, 5, n_games=64, n_playout=200)
+    _set_roots(eng, envs, reset_trees=True)
+    eng.simulate(SyntheticEvaluator('vlin'), 200)
+    visits, wsum = eng.root_visits(), eng.root_wsum()
+    eng.check()
+    for g, env in enumerate(envs):
+        s = RefSearch(ev.vlin, 200, 5)
+        acts, _ = s.simulate(env, 1.0)
+        assert [int(visits[g, a]) for a in acts] == [k.n for k in s.root.kids]
+        assert [float(wsum[g, a]).hex() for a in acts] == [float(k.w).hex() for k in s.root.kids]
+        if g % 8 == 0:
+            assert _hex_tree(eng.tree_dump(g)) == _hex_tree(tree_dump(s.root))
+    eng.close()
+
+
+def test_full_size_known_answer_and_invariants():
+    """15x15, 800 sims (the metric's configuration): SURVEY.md Appendix B KAT 6 + the
+    size-independent invariants N(root) = n_playout, N(node) = 1 + sum N(children),
+    visited children form a prefix."""
+    from rlzero_amd.engine import SyntheticEvaluator
+    eng = _engine(15, 5, n_games=8, n_playout=800)
+    eng.reset_games()
+    eng.simulate(SyntheticEvaluator('vlin'), 800)
+    visits = eng.root_visits()
+    rn, rw = eng.root_stats()
+    eng.check()
+    assert (rn == 800).all() and (rw == -0.5).all()
+    for g in (0, 7):
+        assert hashlib.sha1(visits[g].astype(np.int32).tobytes()).hexdigest() == \
+            '238e277ad1bc97b96fb4cae3d6070abc24bb01c1'
+    ar = eng.arena(3)
+    expanded = np.nonzero(ar['FC'][:1] >= 0)[0]
+    assert len(expanded) == 1
+    # walk the tree: every expanded, visited node satisfies the sum rule
+    stack, checked = [0], 0
+    while stack:
+        slot = stack.pop()
+        fc = int(ar['FC'][slot])
+        if fc < 0:
+            continue
+        nv = int(ar['NV'][slot])
+        kids = ar['N'][fc:fc + nv]
+        assert (kids > 0).all() and int(ar['N'][slot]) == 1 + int(kids.sum())
+        checked += 1
+        stack.extend(range(fc, fc + nv))
+    assert checked > 200
+    eng.close()
+
+
+# ------------------------------------------------------------------ player / game loop (G3)
+class _Injected(object):
+
+    def __init__(self, us):
+        self.us = list(us)
+        self.real = np.random.choice
+
+    def __call__(self, acts, p=None):
+        cdf = np.cumsum(np.asarray(p, dtype=np.float64))
+        cdf /= cdf[-1]
+        return np.asarray(acts)[cdf.searchsorted(self.us.pop(0), side='right')]
+
+
+def test_selfplay_games_through_reference_api(g3):
+    """GameControl.start_self_play + AlphaZeroPlayer (this repo's, on the GPU) reproduce the
+    reference's games: moves, pi, winner, z, states, tree reuse."""
+    from rlzero_amd.games import GameControl, GomokuEnv
+    from rlzero_amd.mcts import AlphaZeroPlayer
+    for game in g3['selfplay']:
+        inj = _Injected([unhex(p['u']) for p in game['plies']])
+        np.random.choice = inj
+        try:
+            env = GomokuEnv(game['B'], game['n'])
+            player = AlphaZeroPlayer(EVALS[game['eval']], n_playout=game['n_playout'], c_puct=5,
+                                     is_selfplay=True)
+            roots = []
+            real = player.mcts.simulate
+
+            def spy(e, temperature=1e-3, _real=real, _roots=roots, _player=player):
+                acts, probs = _real(e, temperature)
+                eng = _player.mcts._engine
+                rn, rw = eng.root_stats()
+                _roots.append((int(rn[0]), float(rw[0]).hex(), eng.root_visits()[0], eng.root_wsum()[0]))
+                return acts, probs
+
+            player.mcts.simulate = spy
+            winner, data = GameControl(env).start_self_play(player, temperature=game['T'])
+            data = list(data)
+        finally:
+            np.random.choice = inj.real
+        assert winner == game['winner'] and list(env.states.keys()) == game['moves']
+        assert len(data) == len(game['plies']) and not inj.us
+        for (state, pi, z), root, ply in zip(data, roots, game['plies']):
+            assert root[0] == ply['root_N'] and root[1] == ply['root_W']
+            assert [int(root[2][a]) for a in ply['acts']] == ply['N']
+            assert [float(root[3][a]).hex() for a in ply['acts']] == ply['W']
+            assert bits_of_planes(state) == ply['obs'] and float(z) == ply['z']
+            assert np.max(np.abs(pi - np.array([unhex(p) for p in ply['pi_full']]))) <= 1e-12
+        view = player.mcts._root
+        assert [view.explore_count, len(view._children)] == game['root_after_reset']
+        player.mcts._engine.close()
+
+
+def test_two_player_games_through_reference_api(g3):
+    from rlzero_amd.games import GameControl, GomokuEnv
+    from rlzero_amd.mcts import AlphaZeroPlayer
+    for duel in g3['duels']:
+        inj = _Injected([unhex(u) for u in duel['u']])
+        np.random.choice = inj
+        try:
+            env = GomokuEnv(duel['B'], duel['n'])
+            p1 = AlphaZeroPlayer(ev.vlin, n_playout=duel['n_playout'][0], c_puct=5)
+            p2 = AlphaZeroPlayer(ev.v0, n_playout=duel['n_playout'][1], c_puct=5)
+            winner = GameControl(env).start_play(p1, p2, start_player=0, is_shown=0)
+        finally:
+            np.random.choice = inj.real
+        assert winner == duel['winner'] and list(env.states.keys()) == duel['moves'] and not inj.us
+        p1.mcts._engine.close()
+        p2.mcts._engine.close()
+
+
+def test_tree_view_matches_oracle_tree():
+    from rlzero_amd.games import GomokuEnv
+    from rlzero_amd.mcts.alphazero_mcts import AlphaZeroMCTS
+    env = GomokuEnv(6, 4)
+    env.reset()
+    for m in (14, 15, 20):
+        env.step(m)
+    mcts = AlphaZeroMCTS(ev.vlin, n_playout=150, c_puct=5)
+    acts, probs = mcts.simulate(env, 1.0)
+    s = RefSearch(ev.vlin, 150, 5)
+    s.simulate(RefGomoku.from_moves(6, 4, [14, 15, 20]), 1.0)
+    root = mcts._root
+    assert root.is_root() and not root.is_leaf() and root.explore_count == s.root.n
+    assert list(root._children) == list(s.root.acts) == list(acts)
+    for a, kid in zip(s.root.acts, s.root.kids):
+        view = root._children[a]
+        assert (view.explore_count, float(view.total_reward)) == (kid.n, float(kid.w))
+        assert abs(view.prior - kid.p) < 1e-6
+        assert len(view._children) == len(kid.kids)
+    assert env.states == {14: 0, 15: 1, 20: 0}  # the caller's env is untouched
+    mcts._engine.close()
+
+
+# ------------------------------------------------------------------ batched self-play
+def test_batched_selfplay_vs_oracle():
+    """BatchedSelfPlay (lock-step games, device evaluator, counter-based uniforms) gives, game
+    by game, the oracle's self-play game for the same uniforms; slots are refilled."""
+    from rlzero_amd.engine import SyntheticEvaluator
+    from rlzero_amd.selfplay import BatchedSelfPlay, move_uniform
+    eng = _engine(6, 4, n_games=8, n_playout=60)
+    sp = BatchedSelfPlay(eng, SyntheticEvaluator('vlin'), temperature=1.0, seed=5)
+    trajs = sp.run(range(20))
+    assert [t.game_id for t in trajs] == list(range(20))
+    for t in trajs[::3]:
+        us = move_uniform(5, np.full(64, t.game_id), np.arange(64))
+        player = RefPlayer(ev.vlin, 60, 5, is_selfplay=True, choice=inverse_cdf_choice(us))
+        winner, data, moves = self_play_game(RefGomoku(6, 4), player, temperature=1.0)
+        assert (winner, moves) == (t.winner, t.moves)
+        w2, data2 = t.as_reference_tuple()
+        for (s1, p1, z1), (s2, p2, z2) in zip(data, data2):
+            assert (s1 == s2).all() and np.max(np.abs(p1 - p2)) <= 1e-12 and z1 == z2
+    eng.close()
+
+
+# ------------------------------------------------------------------ real net
+def test_replay_recorded_leaf_values(g2net):
+    """Feeding the reference's recorded per-simulation leaf values (real net on CPU) through
+    the device tree rebuilds the reference's tree bit-for-bit."""
+    from rlzero_amd.engine import HostEvaluator
+    for rec in g2net['cases']:
+        B, n = rec['B'], rec['n']
+        values = iter([unhex(v) for _, v in rec['leaves']])
+        boards = iter([m for m, _ in rec['leaves']])
+
+        def replay(env, _values=values, _boards=boards):
+            assert sorted(env.states.keys()) == sorted(next(_boards))
+            legal = env.leagel_actions()
+            return [(a, 1.0 / max(len(legal), 1)) for a in legal], next(_values)
+
+        env = RefGomoku.from_moves(B, n, rec['pre'])
+        eng = _engine(B, n, n_games=1, n_playout=rec['n_playout'])
+        _set_roots(eng, [env], reset_trees=True)
+        host = HostEvaluator(replay, lambda s0, s1, tm, last, B=B, n=n: _make_env(B, n, s0, s1, tm, last))
+        rec = dict(rec, n_nodes=len(rec['tree']))
+        _check_case(eng, host, rec, env)
+        eng.close()
+
+
+def _make_env(B, n, s0, s1, tm, last):
+    from rlzero_amd.games import GomokuEnv
+    return GomokuEnv.from_bitboards(B, n, s0, s1, tm, last)
+
+
+def test_cpu_agent_through_host_path_vs_oracle():
+    """A CPU AlphaZeroAgent.policy_value_fn is an arbitrary callable for the engine: the
+    search must equal the oracle's search driven by the very same callable."""
+    import torch
+    torch.set_num_threads(1)
+    from rlzero_amd.games import GomokuEnv
+    from rlzero_amd.games.gomoku.alphazero_agent import AlphaZeroAgent
+    from rlzero_amd.mcts.alphazero_mcts import AlphaZeroMCTS
+    agent = AlphaZeroAgent(6, device='cpu')
+    agent.policy_value_net.load_state_dict({k: torch.from_numpy(v) for k, v in ev.numpy_weights(6, 101).items()})
+    env = GomokuEnv(6, 4)
+    env.reset()
+    for m in (14, 15, 20):
+        env.step(m)
+    with torch.no_grad():
+        mcts = AlphaZeroMCTS(agent.policy_value_fn, n_playout=120, c_puct=5)
+        acts, probs = mcts.simulate(env, 1.0)
+        s = RefSearch(agent.policy_value_fn, 120, 5)
+        acts2, probs2 = s.simulate(RefGomoku.from_moves(6, 4, [14, 15, 20]), 1.0)
+    assert list(acts) == list(acts2) and np.max(np.abs(probs - probs2)) <= 1e-12
+    assert _hex_tree(mcts._engine.tree_dump(0)) == _hex_tree(tree_dump(s.root))
+    mcts._engine.close()
+
+
+def test_net_on_gpu_vs_golden(g4):
+    """policy/value of PolicyValueNet on the MI355X vs the reference's CPU outputs: 1e-4."""
+    import torch
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    for B in (3, 6, 9, 15):
+        net = PolicyValueNet(B)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in ev.numpy_weights(B, int(g4['B%d_seed' % B])).items()})
+        net = net.to('cuda:0')
+        obs = torch.from_numpy(g4['B%d_obs' % B].astype(np.float32)).to('cuda:0')
+        with torch.no_grad():
+            logp, v = net(obs)
+        assert np.max(np.abs(logp.cpu().numpy() - g4['B%d_logp' % B])) <= 1e-4
+        assert np.max(np.abs(v.cpu().numpy() - g4['B%d_value' % B])) <= 1e-4
+
+
+def test_gpu_agent_fast_path_selfplay_game():
+    """AlphaZeroAgent on the GPU -> the batched device evaluator is used; a whole self-play
+    game runs through the reference API and satisfies the search invariants."""
+    import torch
+    from rlzero_amd.engine import NetEvaluator
+    from rlzero_amd.games import GameControl, GomokuEnv
+    from rlzero_amd.games.gomoku.alphazero_agent import AlphaZeroAgent
+    from rlzero_amd.mcts import AlphaZeroPlayer
+    torch.manual_seed(0)
+    np.random.seed(0)
+    agent = AlphaZeroAgent(6, device='cuda:0')
+    player = AlphaZeroPlayer(agent.policy_value_fn, n_playout=100, c_puct=5, is_selfplay=True)
+    env = GomokuEnv(6, 4)
+    winner, data = GameControl(env).start_self_play(player, temperature=1.0)
+    data = list(data)
+    assert isinstance(player.mcts._evaluator, NetEvaluator)
+    assert winner in (-1, 0, 1) and len(data) == len(env.states) >= 7
+    for state, pi, z in data:
+        assert abs(pi.sum() - 1.0) < 1e-9 and state.shape == (4, 6, 6)
+    # the net's value reaches the tree: leaf value of the first simulation = net(root obs)
+    env.reset()
+    mcts = player.mcts
+    mcts.n_playout = 1
+    mcts.update_with_move(-1)
+    mcts.simulate(env, 1.0)
+    rn, rw = mcts._engine.root_stats()
+    with torch.no_grad():
+        _, v = agent.policy_value_net(torch.from_numpy(env.current_state()[None]).float().to('cuda:0'))
+    assert int(rn[0]) == 1 and rw[0] == -float(v.item())
+    player.mcts._engine.close()

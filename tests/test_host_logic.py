@@ -1,0 +1,108 @@
+"""Host-side mirror of the reference interface (no GPU): GomokuEnv rules and observation
+against the golden fixtures, GameControl bookkeeping with a scripted player."""
+import copy
+
+import numpy as np
+import pytest
+from conftest import bits_of_planes
+
+from rlzero_amd.games import BaseEnv, Error, Game, GameControl, GomokuEnv
+from rlzero_amd.mcts import AlphaZeroPlayer, MCTSPlayer, Player
+
+
+def _replay(case):
+    env = GomokuEnv(case['B'], case['n'])
+    env.reset()
+    for ply in case['plies']:
+        obs, reward, win, _ = env.step(ply['a'])
+        ended, winner = env.game_end_winner()
+        won, who = env.has_a_winner()
+        assert (ended, winner, won, who) == (ply['ended'], ply['winner'], ply['won'], ply['who'])
+        assert win == ply['won']
+        if won:
+            assert reward == 1  # the mover wins
+        assert len(env.leagel_actions()) == ply['n_legal']
+        assert env.current_player() == ply['to_move'] and env.last_move == ply['last']
+        assert bits_of_planes(obs) == ply['obs']
+        assert bits_of_planes(env.current_state()) == ply['obs']
+        s0, s1 = env.bitboards()
+        twin = GomokuEnv.from_bitboards(case['B'], case['n'], s0, s1, env.current_player(), env.last_move)
+        assert bits_of_planes(twin.current_state()) == ply['obs']
+        assert twin.game_end_winner() == (ended, winner)
+        assert twin.leagel_actions() == env.leagel_actions() and twin.states == env.states
+
+
+def test_env_rules_random(g1):
+    for case in g1['random']:
+        _replay(case)
+
+
+def test_env_rules_handmade(g1):
+    for case in g1['handmade']:
+        _replay(case)
+
+
+def test_env_interface_and_errors():
+    assert Game is BaseEnv and MCTSPlayer is AlphaZeroPlayer
+    env = GomokuEnv(board_size=6, n_in_row=4)
+    obs = env.reset()
+    assert obs.shape == (4, 6, 6) and obs.dtype == np.float64
+    assert env.players == [0, 1] and env.last_move == -1 and env.states == {}
+    assert env.leagel_actions() == list(range(36)) and env.legal_actions(0) is env.leagel_actions()
+    with pytest.raises(AssertionError):
+        env.step(36)
+    env.step(7)
+    with pytest.raises(AssertionError):
+        env.step(7)
+    assert env.move_to_location(7) == [1, 1] and env.location_to_move([1, 1]) == 7
+    assert env.location_to_move([6, 0]) == -1 and env.location_to_move([1]) == -1
+    with pytest.raises(Error):
+        GomokuEnv(3, 5).reset()
+    with pytest.raises(Error):
+        env.reset(start_player_idx=2)
+    env.reset(start_player_idx=1)
+    assert env.current_player() == 1
+    twin = copy.deepcopy(env)
+    twin.step(0)
+    assert env.states == {} and twin.states == {0: 1}
+    assert env.clone().states == {}
+
+
+class Scripted(Player):
+
+    def __init__(self, moves):
+        super().__init__()
+        self.moves = list(moves)
+        self.resets = 0
+
+    def get_action(self, env, temperature=1e-3, return_prob=False):
+        move = self.moves.pop(0)
+        pi = np.zeros(env.board_size ** 2)
+        pi[move] = 1.0
+        return (move, pi) if return_prob else move
+
+    def reset_player(self):
+        self.resets += 1
+
+
+def test_game_control_self_play_bookkeeping():
+    game = GameControl(GomokuEnv(3, 3))
+    player = Scripted([0, 3, 1, 4, 2])  # player 0 wins with 0,1,2
+    winner, data = game.start_self_play(player, temperature=1.0)
+    data = list(data)
+    assert winner == 0 and player.resets == 1 and len(data) == 5
+    assert [z for _, _, z in data] == [1.0, -1.0, 1.0, -1.0, 1.0]
+    assert data[0][0].shape == (4, 3, 3) and data[0][0][3].all() and not data[1][0][3].any()
+    player = Scripted([0, 1, 2, 4, 3, 5, 7, 6, 8])
+    winner, data = game.start_self_play(player)
+    assert winner == -1 and [z for _, _, z in data] == [0.0] * 9
+
+
+def test_game_control_two_players():
+    game = GameControl(GomokuEnv(3, 3))
+    p1, p2 = Scripted([4, 0, 8]), Scripted([1, 2])
+    with pytest.raises(Error):
+        game.start_play(p1, p2, start_player=2, is_shown=0)
+    # 4,1,0,2,8 -> player 0 completes the diagonal 0,4,8
+    assert game.start_play(p1, p2, start_player=1, is_shown=0) == 0
+    assert p1.get_player_id() == 0 and p2.get_player_id() == 1

@@ -92,8 +92,24 @@ def cpu_worker(seconds, board, n_row, n_playout):
     print(json.dumps({'sims': sims, 'seconds': dt}))
 
 
-def run_cpu_baseline(seconds):
+def usable_cores():
+    """Cores this process may really use: min(visible, affinity, cgroup v2 cpu.max quota)."""
     cores = os.cpu_count() or 1
+    try:
+        cores = min(cores, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
+def run_cpu_baseline(seconds):
+    cores = usable_cores()
     env = dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1', HIP_VISIBLE_DEVICES='',
                ROCR_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
     cmd = [sys.executable, os.path.abspath(__file__), '--cpu-worker', str(seconds)]

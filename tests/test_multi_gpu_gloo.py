@@ -1,0 +1,87 @@
+"""N > 1 path on CPU: two gloo ranks shard the games by id, play them (the oracle stands in
+for the device search -- this test is about the sharding and the single gather, not the
+kernels), gather to rank 0, and the result equals the single-process run game for game."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import REPO
+
+
+def _play(game_ids, seed, sims):
+    """Trajectories for ``game_ids`` with the counter-based uniforms of rlzero_amd.selfplay."""
+    from oracle import evaluators as ev
+    from oracle.gomoku_ref import RefGomoku
+    from oracle.mcts_ref import RefPlayer, inverse_cdf_choice, self_play_game
+    from rlzero_amd.selfplay import Trajectory, move_uniform
+    out = []
+    for gid in game_ids:
+        us = move_uniform(seed, np.full(16, gid), np.arange(16))
+        player = RefPlayer(ev.vlin, sims, 5, is_selfplay=True, choice=inverse_cdf_choice(us))
+        winner, data, moves = self_play_game(RefGomoku(3, 3), player, temperature=1.0)
+        out.append(Trajectory(gid, 3, 3, moves, [pi for _, pi, _ in data], winner))
+    return out
+
+
+def _worker(rank, world, port, n_games, result_path):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import torch.distributed as dist
+    from rlzero_amd.selfplay import gather_trajectories, shard_game_ids
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    mine = shard_game_ids(n_games, rank, world)
+    assert mine == list(range(rank, n_games, world))
+    local = _play(mine, seed=3, sims=20)
+    merged = gather_trajectories(local, 3, 3, dst=0)
+    if rank == 0:
+        np.savez(result_path, ids=[t.game_id for t in merged], winners=[t.winner for t in merged],
+                 moves=np.concatenate([t.moves for t in merged]),
+                 pis=np.concatenate([t.pis for t in merged]))
+    else:
+        assert merged is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_selfplay_gather_equals_single_process(tmp_path):
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    n_games = 7  # ragged: rank 0 gets 4 games, rank 1 gets 3
+    result = str(tmp_path / 'merged.npz')
+    mp.spawn(_worker, args=(2, port, n_games, result), nprocs=2, join=True)
+    got = np.load(result)
+    single = _play(range(n_games), seed=3, sims=20)
+    assert got['ids'].tolist() == list(range(n_games))
+    assert got['winners'].tolist() == [t.winner for t in single]
+    assert got['moves'].tolist() == [m for t in single for m in t.moves]
+    assert np.array_equal(got['pis'], np.concatenate([t.pis for t in single]))
+
+
+def test_gather_without_process_group_is_identity():
+    from rlzero_amd.selfplay import gather_trajectories, pack_trajectories, unpack_trajectories
+    trajs = _play([2, 0, 1], seed=1, sims=10)
+    merged = gather_trajectories(trajs, 3, 3)
+    assert [t.game_id for t in merged] == [0, 1, 2]
+    back = unpack_trajectories(*pack_trajectories(merged, 9), 3, 3)
+    for a, b in zip(merged, back):
+        assert (a.game_id, a.moves, a.winner) == (b.game_id, b.moves, b.winner)
+        assert np.array_equal(a.pis, b.pis)
+    w, data = merged[0].as_reference_tuple()
+    assert w == merged[0].winner and len(data) == len(merged[0].moves)
+    assert data[0][0].shape == (4, 3, 3)
+
+
+def test_move_uniform_is_a_pure_function_of_seed_game_ply():
+    from rlzero_amd.selfplay import move_uniform
+    a = move_uniform(7, np.arange(1000), np.zeros(1000, dtype=np.int64))
+    b = move_uniform(7, np.arange(1000)[::-1], np.zeros(1000, dtype=np.int64))[::-1]
+    assert np.array_equal(a, b) and (a >= 0).all() and (a < 1).all()
+    assert abs(a.mean() - 0.5) < 0.05 and len(np.unique(a)) == 1000
+    assert move_uniform(7, 3, 4) != move_uniform(8, 3, 4) != move_uniform(7, 4, 3)

@@ -133,26 +133,26 @@ def run_cpu_baseline(seconds):
 
 
 # --------------------------------------------------------------------------- GPU run
-class TimedNet(object):
-    """NetEvaluator that brackets every forward with HIP events on the launch stream."""
+class TimedEvaluator(object):
+    """Brackets every evaluator call (the policy+value forward of the leaf batch) with HIP
+    events on the launch stream (torch's current stream is the stream our kernels use)."""
     needs_obs = True
 
-    def __init__(self, net, torch):
-        self.net, self.torch = net, torch
+    def __init__(self, inner, torch, label):
+        self.inner, self.torch, self.label = inner, torch, label
         self.events = []
         self.record = False
 
     def __call__(self, eng):
         t = self.torch
-        if self.record:
-            a, b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
-            a.record()
-        with t.no_grad():
-            logp, value = self.net(eng.obs)
-        if self.record:
-            b.record()
-            self.events.append((a, b))
-        return logp.contiguous(), value.reshape(-1).contiguous()
+        if not self.record:
+            return self.inner(eng)
+        a, b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+        a.record()
+        out = self.inner(eng)
+        b.record()
+        self.events.append((a, b))
+        return out
 
     def mean_ms(self):
         if not self.events:
@@ -171,8 +171,9 @@ def main():
     ap.add_argument('--games', type=int, default=GAMES_PER_GPU, help='games per GPU')
     ap.add_argument('--board', type=int, default=BOARD)
     ap.add_argument('--playouts', type=int, default=N_PLAYOUT)
-    ap.add_argument('--evaluator', default='net', choices=['net', 'vlin'],
-                    help="'vlin' isolates the tree kernels (synthetic evaluator)")
+    ap.add_argument('--evaluator', default='hipnet', choices=['hipnet', 'torchnet', 'vlin'],
+                    help="hipnet: hand-written fused fp32 MFMA forward (csrc/rz_net.hip); torchnet: "
+                         "PyTorch-ROCm/MIOpen; vlin: synthetic evaluator (isolates the tree kernels)")
     ap.add_argument('--graph', type=int, default=0, help='simulation steps per hipGraph (0 = eager)')
     args = ap.parse_args()
     if args.cpu_worker is not None:
@@ -191,7 +192,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from rlzero_amd.engine import MCTSEngine, SyntheticEvaluator
+    from rlzero_amd.engine import HipNetEvaluator, MCTSEngine, NetEvaluator, SyntheticEvaluator
     from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
     from rlzero_amd.selfplay import BatchedSelfPlay
 
@@ -207,7 +208,13 @@ def main():
     eng = MCTSEngine(board, n_row, n_games=G, n_playout=args.playouts, c_puct=C_PUCT, device=device)
     torch.manual_seed(0)  # identical weights on every rank
     net = PolicyValueNet(board).to(device).eval()
-    evaluator = TimedNet(net, torch) if args.evaluator == 'net' else SyntheticEvaluator('vlin')
+    if args.evaluator == 'hipnet':
+        evaluator = TimedEvaluator(HipNetEvaluator(net, board, device, max_boards=G), torch,
+                                   'k_trunk + k_heads (hand-written fp32 MFMA, csrc/rz_net.hip)')
+    elif args.evaluator == 'torchnet':
+        evaluator = TimedEvaluator(NetEvaluator(net), torch, 'torch/MIOpen forward (~14 kernels)')
+    else:
+        evaluator = SyntheticEvaluator('vlin')
     sp = BatchedSelfPlay(eng, evaluator, temperature=TEMPERATURE, seed=0,
                          use_graph=args.graph > 0, sims_per_graph=max(args.graph, 1))
     if args.graph > 0:
@@ -237,7 +244,7 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    if isinstance(evaluator, TimedNet):
+    if isinstance(evaluator, TimedEvaluator):
         evaluator.record = True
     sims0, fin0 = sp.sims_done, finished[0]
     fence()
@@ -276,11 +283,11 @@ def main():
             'arena_slots_used_max': int(stats.max_slots_used),
             'engine_hbm_bytes': int(stats.device_bytes),
         }
-        if isinstance(evaluator, TimedNet) and evaluator.mean_ms():
+        if isinstance(evaluator, TimedEvaluator) and evaluator.mean_ms():
             ms = evaluator.mean_ms()
             flops = flops_per_position(cells) * G
             achieved = flops / (ms * 1e-3) / 1e12
-            line['roofline'] = {'bound': 'mfma', 'kernel': 'policy+value forward of %d leaves (torch/MIOpen)' % G,
+            line['roofline'] = {'bound': 'mfma', 'kernel': 'policy+value forward of %d leaves: %s' % (G, evaluator.label),
                                 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MATRIX_TFLOPS,
                                 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
                                 'traffic': None, 'avg_launch_ms': round(ms, 4),

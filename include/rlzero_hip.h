@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 2
+#define RZ_ABI_VERSION 3
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 
@@ -189,6 +189,28 @@ int rz_copy_arena(rz_engine *e, int32_t game, int64_t max_slots, int32_t *h_n, d
  * out[i] = w[i]/n[i] + c*sqrt(ln(np[i])/n[i]) with ln from the engine's table. */
 int rz_uct_scores(rz_engine *e, const double *d_w, const int32_t *d_n, const int32_t *d_np,
                   double c_puct, double *d_out, int64_t count, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Policy-value network forward (the evaluator's dense contraction), hand-written fp32 MFMA.
+ * Replaces PolicyValueNet.forward (rlzero/games/gomoku/policy_value_net.py:34-52) for a batch
+ * of leaf observations: conv3x3 4->32->64->128 (+ReLU), conv1x1 heads, the three FC layers,
+ * log_softmax and tanh.  Exact fp32 arithmetic (no reduced precision).
+ *
+ * rz_net_load takes HOST pointers to the 16 tensors of PolicyValueNet.state_dict() in its
+ * order (conv1.weight, conv1.bias, conv2.*, conv3.*, act_conv1.*, act_fc1.*, val_conv1.*,
+ * val_fc1.*, val_fc2.*; policy_value_net.py:12-25), fp32, contiguous, torch layout.
+ * rz_net_reserve sizes the internal feature buffer (the launch path never allocates).
+ * rz_net_forward: d_obs float32 [n][4][B][B] -> d_logp [n][B*B] (log-probabilities),
+ * d_value [n].  rz_net_trunk exposes the first kernel alone: d_feat [n][6][B*B] = ReLU'd
+ * outputs of act_conv1 (4 planes) and val_conv1 (2 planes). */
+typedef struct rz_net rz_net;
+int rz_net_create(int32_t board_size, int32_t device, rz_net **out);
+int rz_net_destroy(rz_net *net);
+int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params);
+int rz_net_reserve(rz_net *net, int32_t max_boards);
+int rz_net_trunk(rz_net *net, const float *d_obs, int32_t n_boards, float *d_feat, void *stream);
+int rz_net_forward(rz_net *net, const float *d_obs, int32_t n_boards, float *d_logp,
+                   float *d_value, void *stream);
 
 #ifdef __cplusplus
 }

@@ -7,7 +7,7 @@ import ctypes
 import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p)
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
 
@@ -64,6 +64,12 @@ _SIGNATURES = {
     'rz_clear_errors': (c_int, [P]),
     'rz_copy_arena': (c_int, [P, c_int32, c_int64, P, P, P, P, P, P]),
     'rz_uct_scores': (c_int, [P, P, P, P, c_double, P, c_int64, P]),
+    'rz_net_create': (c_int, [c_int32, c_int32, POINTER(c_void_p)]),
+    'rz_net_destroy': (c_int, [P]),
+    'rz_net_load': (c_int, [P, POINTER(c_void_p), c_int32]),
+    'rz_net_reserve': (c_int, [P, c_int32]),
+    'rz_net_trunk': (c_int, [P, P, c_int32, P, P]),
+    'rz_net_forward': (c_int, [P, P, c_int32, P, P, P]),
 }
 
 _lib = None

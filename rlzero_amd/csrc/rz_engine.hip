@@ -745,6 +745,9 @@ int fail(int code, const char *fmt, ...) {
 
 }  // namespace
 
+// shared with rz_net.hip: set the thread-local message returned by rz_last_error()
+void rz_set_error(const char *msg) { snprintf(g_err, sizeof(g_err), "%s", msg ? msg : ""); }
+
 struct rz_engine {
     rz_config cfg;
     Dev dev;

@@ -54,6 +54,99 @@ class NetEvaluator(object):
         return logp.contiguous(), value.reshape(-1).contiguous()
 
 
+PARAM_ORDER = ('conv1.weight', 'conv1.bias', 'conv2.weight', 'conv2.bias', 'conv3.weight', 'conv3.bias',
+               'act_conv1.weight', 'act_conv1.bias', 'act_fc1.weight', 'act_fc1.bias',
+               'val_conv1.weight', 'val_conv1.bias', 'val_fc1.weight', 'val_fc1.bias',
+               'val_fc2.weight', 'val_fc2.bias')
+
+
+class HipNet(object):
+    """The hand-written fused fp32-MFMA forward (csrc/rz_net.hip) of a PolicyValueNet."""
+
+    def __init__(self, board_size, device='cuda:0', max_boards=512):
+        import torch
+        self.lib = _hip.load()
+        self.torch = torch
+        dev = torch.device(device)
+        if dev.type != 'cuda' or not torch.cuda.is_available():
+            raise HipError('HipNet needs an MI355X (device=%r); there is no CPU fallback' % (device, ))
+        self.device = torch.device('cuda', dev.index if dev.index is not None else torch.cuda.current_device())
+        self.board_size, self.n_cells = int(board_size), int(board_size) ** 2
+        handle = ctypes.c_void_p()
+        check(self.lib.rz_net_create(self.board_size, self.device.index, ctypes.byref(handle)), 'rz_net_create')
+        self.handle = handle
+        self.max_boards = 0
+        self._want = int(max_boards)
+
+    def load_state_dict(self, state_dict):
+        """Upload (and re-pack into MFMA fragment order) the 16 tensors of a
+        PolicyValueNet.state_dict(); call again after every optimiser step."""
+        arrays = []
+        for name in PARAM_ORDER:
+            t = state_dict[name]
+            a = t.detach().to('cpu', self.torch.float32).contiguous().numpy() if hasattr(t, 'detach') \
+                else np.ascontiguousarray(t, dtype=np.float32)
+            arrays.append(a)
+        ptrs = (ctypes.c_void_p * 16)(*[a.ctypes.data for a in arrays])
+        check(self.lib.rz_net_load(self.handle, ptrs, 16), 'rz_net_load')
+        self.reserve(max(self._want, self.max_boards))
+        return self
+
+    def reserve(self, max_boards):
+        check(self.lib.rz_net_reserve(self.handle, int(max_boards)), 'rz_net_reserve')
+        self.max_boards = max(self.max_boards, int(max_boards))
+
+    def forward(self, obs, logp=None, value=None):
+        """obs float32 [n,4,B,B] on the device -> (log_probs [n,S], value [n])."""
+        t = self.torch
+        n = obs.shape[0]
+        if n > self.max_boards:
+            self.reserve(n)
+        if logp is None:
+            logp = t.empty((n, self.n_cells), dtype=t.float32, device=self.device)
+        if value is None:
+            value = t.empty(n, dtype=t.float32, device=self.device)
+        st = ctypes.c_void_p(t.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.rz_net_forward(self.handle, _ptr(obs), n, _ptr(logp), _ptr(value), st), 'rz_net_forward')
+        return logp, value
+
+    def trunk(self, obs):
+        t = self.torch
+        n = obs.shape[0]
+        feat = t.empty((n, 6, self.n_cells), dtype=t.float32, device=self.device)
+        st = ctypes.c_void_p(t.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.rz_net_trunk(self.handle, _ptr(obs), n, _ptr(feat), st), 'rz_net_trunk')
+        return feat
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.rz_net_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class HipNetEvaluator(object):
+    """Evaluator running the leaf batch through HipNet (weights taken from a torch
+    PolicyValueNet; ``refresh()`` re-uploads them after training)."""
+    needs_obs = True
+
+    def __init__(self, net_module, board_size, device='cuda:0', max_boards=512):
+        self.module = net_module
+        self.hip = HipNet(board_size, device, max_boards)
+        self.refresh()
+
+    def refresh(self):
+        self.hip.load_state_dict(self.module.state_dict())
+
+    def __call__(self, eng):
+        return self.hip.forward(eng.obs, eng.logp, eng.value)
+
+
 class HostEvaluator(object):
     """Any ``policy_value_fn(env) -> (iterable[(action, prob)], value)`` callable
     (alphazero_mcts.py:28-31,59), called once per leaf on a materialised env object.

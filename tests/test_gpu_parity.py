@@ -434,3 +434,77 @@ def test_gpu_agent_fast_path_selfplay_game():
         _, v = agent.policy_value_net(torch.from_numpy(env.current_state()[None]).float().to('cuda:0'))
     assert int(rn[0]) == 1 and rw[0] == -float(v.item())
     player.mcts._engine.close()
+
+
+# ------------------------------------------------------------------ hand-written net forward
+def test_hip_net_vs_golden_and_torch(g4):
+    """csrc/rz_net.hip (fused fp32 MFMA forward) vs the reference's CPU outputs (1e-4, the
+    tolerance of BASELINE.json) and vs the torch module on the same GPU, all board sizes."""
+    import torch
+    from rlzero_amd.engine import HipNet
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    for B in (3, 6, 9, 15):
+        weights = ev.numpy_weights(B, int(g4['B%d_seed' % B]))
+        hip = HipNet(B, 'cuda:0', max_boards=16).load_state_dict(weights)
+        obs = torch.from_numpy(g4['B%d_obs' % B].astype(np.float32)).to('cuda:0')
+        logp, value = hip.forward(obs)
+        assert np.max(np.abs(logp.cpu().numpy() - g4['B%d_logp' % B])) <= 1e-4
+        assert np.max(np.abs(value.cpu().numpy()[:, None] - g4['B%d_value' % B])) <= 1e-4
+        assert abs(float(torch.exp(logp).sum(1).mean()) - 1.0) < 1e-5
+        # trunk features against torch fp64 on random (non 0/1) inputs
+        rs = np.random.RandomState(B)
+        x = torch.from_numpy(rs.standard_normal((37, 4, B, B)).astype(np.float32)).to('cuda:0')
+        lp64, v64 = ev.net_forward(weights, x.cpu().numpy(), dtype=torch.float64)
+        lp, v = hip.forward(x)
+        assert np.max(np.abs(lp.cpu().numpy() - lp64.numpy())) <= 1e-4
+        assert np.max(np.abs(v.cpu().numpy() - v64.numpy()[:, 0])) <= 1e-4
+        hip.close()
+    # A = I style layout check: an asymmetric single-tap kernel must shift, not transpose
+    B = 6
+    w = {k: np.zeros_like(v) for k, v in ev.numpy_weights(B, 1).items()}
+    w['conv1.weight'][5, 2, 0, 2] = 1.0   # out ch 5 <- in ch 2 shifted by (dy=-1, dx=+1)
+    w['conv2.weight'][7, 5, 1, 1] = 1.0
+    w['conv3.weight'][9, 7, 2, 0] = 1.0   # (dy=+1, dx=-1)
+    w['act_conv1.weight'][1, 9, 0, 0] = 1.0
+    hip = HipNet(B, 'cuda:0', max_boards=4).load_state_dict(w)
+    x = torch.rand((2, 4, B, B), device='cuda:0')
+    feat = hip.trunk(x).cpu().numpy().reshape(2, 6, B, B)
+    net = PolicyValueNet(B)
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    with torch.no_grad():
+        t = x.cpu()
+        for conv in (net.conv1, net.conv2, net.conv3):
+            t = torch.relu(conv(t))
+        want = torch.relu(net.act_conv1(t)).numpy()
+    assert np.max(np.abs(feat[:, :4] - want)) <= 1e-6 and np.abs(want).max() > 0.1
+    hip.close()
+
+
+def test_search_with_hip_net_equals_search_with_its_values():
+    """Tree built with the HIP net evaluator == oracle tree fed the very same fp32 values
+    (the net's value reaches the tree unchanged; a 512-game batch runs clean)."""
+    import torch
+    from rlzero_amd.engine import HipNetEvaluator
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    torch.manual_seed(0)
+    net = PolicyValueNet(6).to('cuda:0')
+    evaluator = HipNetEvaluator(net, 6, 'cuda:0', max_boards=8)
+    eng = _engine(6, 4, n_games=8, n_playout=80)
+    eng.reset_games()
+    eng.simulate(evaluator, 80)
+    eng.check()
+    rn, _ = eng.root_stats()
+    assert (rn == 80).all()
+    # game 0 from the empty board: recompute every leaf value with the same kernel, batch 1
+    values = {}
+
+    def pvf(env):
+        obs = torch.from_numpy(env.current_state()[None]).float().to('cuda:0')
+        logp, v = evaluator.hip.forward(obs)
+        legal = env.leagel_actions()
+        return [(a, 1.0 / len(legal)) for a in legal], float(v.item())
+
+    s = RefSearch(pvf, 80, 5)
+    s.simulate(RefGomoku(6, 4), 1.0)
+    assert _hex_tree(eng.tree_dump(0)) == _hex_tree(tree_dump(s.root))
+    eng.close()

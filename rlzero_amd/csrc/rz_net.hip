@@ -35,7 +35,7 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kRowW = 18;     // halo row width (x = -1 .. 16)
-constexpr int kRows = 18;     // halo rows (y = -1 .. 16)
+// halo rows: 18 (y = -1 .. 16), 18*18 = 324 floats per plane before padding
 constexpr int kPlane = 336;   // 18*18 = 324 padded so that 4 planes apart hit other banks
 constexpr int kPlanesIn = 4, kPlanesC1 = 32, kPlanesC2 = 64;
 constexpr int kLdsFloats = (kPlanesIn + kPlanesC1 + kPlanesC2) * kPlane;  // 33600 floats = 131.25 KiB
@@ -46,65 +46,96 @@ struct NetDev {
     const float *b1, *b2, *b3;   // conv biases
     const float *wh;             // [6][128]: act_conv1 (4 rows) then val_conv1 (2 rows)
     const float *bh;             // [6]
-    const float *fc_act_t;       // act_fc1.weight transposed: [4S][S]
-    const float *fc_act_b;       // [S]
-    const float *fc_val1_t;      // val_fc1.weight transposed: [2S][64]
+    const float *fc_act_t;       // act_fc1.weight transposed, zero padded: [4*steps_act][Npad]
+    const float *fc_act_b;       // [Npad]
+    const float *fc_val1_t;      // val_fc1.weight transposed, zero padded: [4*steps_val][64]
     const float *fc_val1_b;      // [64]
     const float *fc_val2_w;      // [64]
     const float *fc_val2_b;      // [1]
-    int B, S;
+    int B, S, Npad, steps_act, steps_val;  // steps_*: k-steps of 4, multiples of 4*kHeadU
 };
 
-// acc[m][t] += W(tile m) x in(rows 4*rg + t) over all input channels and taps.
-template <int CIN, int TM>
-__device__ __forceinline__ void conv_accumulate(const float *__restrict__ in,
-                                                const f32x4 *__restrict__ wp, int half, int rg,
-                                                int lane, f32x4 (&acc)[TM][4]) {
-    constexpr int kSteps = CIN / 4;
-    const int x = lane & 15, kq = lane >> 4;
-    // lane's channel within a group is kq; fragments are in[(4s+kq)][4rg + ro][x + dxi]
-    const float *base = in + kq * kPlane + (4 * rg) * kRowW + x;
-    const f32x4 *wbase = wp + (size_t)(half * TM) * kSteps * 3 * 64 + lane;
-#pragma unroll 1
-    for (int s = 0; s < kSteps; ++s) {
-        f32x4 a[TM][3];
+// Operand fragments of one input-channel group (4 channels x 9 taps) for a wave that owns TM
+// output-channel tiles and NR board rows: TM x 3 packed weight vectors and the (NR+2) x 3
+// distinct (row, dx) activation fragments that the 9 taps x NR rows reuse.
+template <int TM, int NR>
+struct Frags {
+    f32x4 a[TM][3];
+    float b[NR + 2][3];
+};
+
+template <int TM, int NR, int STEPS>
+__device__ __forceinline__ void load_frags(Frags<TM, NR> &f, const float *__restrict__ base,
+                                           const f32x4 *__restrict__ wbase, int s) {
 #pragma unroll
-        for (int m = 0; m < TM; ++m)
+    for (int m = 0; m < TM; ++m)
 #pragma unroll
-            for (int tg = 0; tg < 3; ++tg) a[m][tg] = wbase[((size_t)(m * kSteps + s) * 3 + tg) * 64];
-        float b[6][3];
-        const float *p = base + (4 * s) * kPlane;
+        for (int tg = 0; tg < 3; ++tg) f.a[m][tg] = wbase[((size_t)(m * STEPS + s) * 3 + tg) * 64];
+    const float *p = base + (4 * s) * kPlane;
 #pragma unroll
-        for (int ro = 0; ro < 6; ++ro)
+    for (int ro = 0; ro < NR + 2; ++ro)
 #pragma unroll
-            for (int dxi = 0; dxi < 3; ++dxi) b[ro][dxi] = p[ro * kRowW + dxi];
+        for (int dxi = 0; dxi < 3; ++dxi) f.b[ro][dxi] = p[ro * kRowW + dxi];
+}
+
+template <int TM, int NR>
+__device__ __forceinline__ void mfma_group(const Frags<TM, NR> &f, f32x4 (&acc)[TM][8]) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dyi = tap / 3, dxi = tap % 3;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dyi = tap / 3, dxi = tap % 3;
 #pragma unroll
-            for (int m = 0; m < TM; ++m) {
-                const float av = a[m][tap / 4][tap % 4];
+        for (int m = 0; m < TM; ++m) {
+            const float av = f.a[m][tap / 4][tap % 4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[t + dyi][dxi], acc[m][t], 0, 0, 0);
-            }
+            for (int t = 0; t < NR; ++t)
+                acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, f.b[t + dyi][dxi], acc[m][t], 0, 0, 0);
         }
     }
 }
 
+// acc[m][t] += W(tile tile0+m) x in(rows row0+t) over all CIN input channels and the 9 taps.
+// Software pipelined: the fragments of channel group s+1 are fetched (weights: 16-byte loads
+// from L2, activations: ds_read_b32) while the 9*TM*NR MFMAs of group s issue.
+template <int CIN, int TM, int NR>
+__device__ __forceinline__ void conv_accumulate(const float *__restrict__ in, const f32x4 *__restrict__ wp,
+                                                int tile0, int row0, int lane, f32x4 (&acc)[TM][8]) {
+    constexpr int kSteps = CIN / 4;
+    const int x = lane & 15, kq = lane >> 4;
+    const float *base = in + kq * kPlane + row0 * kRowW + x;  // in[(4s+kq)][row0 + ro][x + dxi]
+    const f32x4 *wbase = wp + (size_t)tile0 * kSteps * 3 * 64 + lane;
+    Frags<TM, NR> f0, f1;
+    load_frags<TM, NR, kSteps>(f0, base, wbase, 0);
+#pragma unroll 1
+    for (int s = 0; s < kSteps; s += 2) {
+        load_frags<TM, NR, kSteps>(f1, base, wbase, s + 1 < kSteps ? s + 1 : kSteps - 1);
+        mfma_group<TM, NR>(f0, acc);
+        if (s + 1 < kSteps) {
+            load_frags<TM, NR, kSteps>(f0, base, wbase, s + 2 < kSteps ? s + 2 : kSteps - 1);
+            mfma_group<TM, NR>(f1, acc);
+        }
+    }
+}
+
+template <int CIN, int TM>
+__device__ __forceinline__ void conv_rows(const float *__restrict__ in, const f32x4 *__restrict__ wp, int tile0,
+                                          int row0, int n_rows, int lane, f32x4 (&acc)[TM][8]) {
+    if (n_rows == 7) conv_accumulate<CIN, TM, 7>(in, wp, tile0, row0, lane, acc);
+    else conv_accumulate<CIN, TM, 8>(in, wp, tile0, row0, lane, acc);
+}
+
 // out[cout][y+1][x+1] = relu(acc + bias[cout]) for the lane's 4 channels of every tile/row.
 template <int TM>
-__device__ __forceinline__ void store_relu(float *__restrict__ out, const float *__restrict__ bias,
-                                           int half, int rg, int lane, int B, const f32x4 (&acc)[TM][4]) {
+__device__ __forceinline__ void store_relu(float *__restrict__ out, const float *__restrict__ bias, int tile0,
+                                           int row0, int lane, int B, const f32x4 (&acc)[TM][8]) {
     const int x = lane & 15, q = lane >> 4;
     if (x >= B) return;
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
-        const int c0 = (half * TM + m) * 16 + 4 * q;
+        const int c0 = (tile0 + m) * 16 + 4 * q;
         const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + c0);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int y = 4 * rg + t;
+        for (int t = 0; t < 8; ++t) {
+            const int y = row0 + t;
             if (y >= B) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -114,13 +145,16 @@ __device__ __forceinline__ void store_relu(float *__restrict__ out, const float 
 }
 
 template <int TM>
-__device__ __forceinline__ void zero_acc(f32x4 (&acc)[TM][4]) {
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[TM][8]) {
 #pragma unroll
     for (int m = 0; m < TM; ++m)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 8; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
+// Wave w = 4*rh + q4: output-channel quarter q4 (the two waves of a quarter share a SIMD, waves
+// are dealt to SIMDs cyclically) and row half rh (rows 0-7 / 8-15; on a 15x15 board the second
+// half computes 7 rows, so every SIMD carries exactly 15 row-units of each layer).
 __global__ __launch_bounds__(kTrunkThreads) void k_trunk(NetDev nd, const float *__restrict__ obs,
                                                          float *__restrict__ feat, int n_boards) {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
@@ -128,10 +162,13 @@ __global__ __launch_bounds__(kTrunkThreads) void k_trunk(NetDev nd, const float 
     float *c1 = in0 + kPlanesIn * kPlane;
     float *c2 = c1 + kPlanesC1 * kPlane;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int half = wave & 1, rg = wave >> 1;
+    const int q4 = wave & 3, rh = wave >> 2;
     const int B = nd.B, S = nd.S;
     const int board = blockIdx.x;
     if (board >= n_boards) return;
+    const int row0 = 8 * rh;
+    const int n_rows = (B - row0 == 7) ? 7 : 8;
+    const bool busy = row0 < B;  // a wave whose rows are all outside the board only hits barriers
 
     // zero the halo planes (interiors are overwritten below), then stage the observation
     {
@@ -147,46 +184,41 @@ __global__ __launch_bounds__(kTrunkThreads) void k_trunk(NetDev nd, const float 
         }
     }
     __syncthreads();
-    const bool busy = 4 * rg < B;  // waves whose rows are all outside the board only hit barriers
 
-    {   // conv1: 4 -> 32 (one 16-channel tile per half)
-        f32x4 acc[1][4];
+    if (busy && q4 < 2) {   // conv1: 4 -> 32 = two 16-channel tiles
+        f32x4 acc[1][8];
         zero_acc<1>(acc);
-        if (busy) {
-            conv_accumulate<4, 1>(in0, nd.w1, half, rg, lane, acc);
-            store_relu<1>(c1, nd.b1, half, rg, lane, B, acc);
-        }
+        conv_rows<4, 1>(in0, nd.w1, q4, row0, n_rows, lane, acc);
+        store_relu<1>(c1, nd.b1, q4, row0, lane, B, acc);
     }
     __syncthreads();
-    {   // conv2: 32 -> 64
-        f32x4 acc[2][4];
-        zero_acc<2>(acc);
-        if (busy) {
-            conv_accumulate<32, 2>(c1, nd.w2, half, rg, lane, acc);
-            store_relu<2>(c2, nd.b2, half, rg, lane, B, acc);
-        }
+    if (busy) {   // conv2: 32 -> 64 = one tile per quarter
+        f32x4 acc[1][8];
+        zero_acc<1>(acc);
+        conv_rows<32, 1>(c1, nd.w2, q4, row0, n_rows, lane, acc);
+        store_relu<1>(c2, nd.b2, q4, row0, lane, B, acc);
     }
     __syncthreads();
-    // conv3: 64 -> 128, kept in registers and fed to the two 1x1 head convolutions
-    float part[4][6];
+    // conv3: 64 -> 128 (two tiles per quarter), kept in registers and fed to the 1x1 head convs
+    float part[8][6];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int o = 0; o < 6; ++o) part[t][o] = 0.0f;
     if (busy) {
-        f32x4 acc[4][4];
-        zero_acc<4>(acc);
-        conv_accumulate<64, 4>(c2, nd.w3, half, rg, lane, acc);
+        f32x4 acc[2][8];
+        zero_acc<2>(acc);
+        conv_rows<64, 2>(c2, nd.w3, 2 * q4, row0, n_rows, lane, acc);
         const int q = lane >> 4;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const int c0 = (half * 4 + m) * 16 + 4 * q;
+        for (int m = 0; m < 2; ++m) {
+            const int c0 = (2 * q4 + m) * 16 + 4 * q;
             const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b3 + c0);
             f32x4 wv[6];
 #pragma unroll
             for (int o = 0; o < 6; ++o) wv[o] = *reinterpret_cast<const f32x4 *>(nd.wh + o * 128 + c0);
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 8; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float h = fmaxf(acc[m][t][j] + bv[j], 0.0f);
@@ -195,9 +227,9 @@ __global__ __launch_bounds__(kTrunkThreads) void k_trunk(NetDev nd, const float 
                 }
         }
     }
-    // sum over the 4 channel quarters held by lanes x, x+16, x+32, x+48
+    // sum over the 4 channel sub-groups held by lanes x, x+16, x+32, x+48
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 8; ++t)
 #pragma unroll
         for (int o = 0; o < 6; ++o) {
             float v = part[t][o];
@@ -205,113 +237,127 @@ __global__ __launch_bounds__(kTrunkThreads) void k_trunk(NetDev nd, const float 
             v += __shfl_xor(v, 32);
             part[t][o] = v;
         }
-    // c1 is free now: partial[half][o][y][x]
+    // c1 is free now: partial[q4][o][y][x]
     float *partial = c1;
     if (lane < 16) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 8; ++t)
 #pragma unroll
-            for (int o = 0; o < 6; ++o)
-                partial[((half * 6 + o) * 16 + (4 * rg + t)) * 16 + lane] = part[t][o];
+            for (int o = 0; o < 6; ++o) partial[((q4 * 6 + o) * 16 + (row0 + t)) * 16 + lane] = part[t][o];
     }
     __syncthreads();
     {
         float *dst = feat + (size_t)board * 6 * S;
         for (int i = tid; i < 6 * S; i += kTrunkThreads) {
             const int o = i / S, r = i - o * S, y = r / B, x = r - y * B;
-            const float v = partial[((0 * 6 + o) * 16 + y) * 16 + x] + partial[((1 * 6 + o) * 16 + y) * 16 + x] +
-                            nd.bh[o];
+            float v = nd.bh[o];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v += partial[((k * 6 + o) * 16 + y) * 16 + x];
             dst[i] = fmaxf(v, 0.0f);
         }
     }
 }
 
 // ------------------------------------------------------------------ heads (FC layers)
-// One workgroup per kHeadBoards boards; thread j < S accumulates logit j of every board of the
-// tile (weights transposed to [k][j] so a wave reads contiguous rows and reuses each weight
-// kHeadBoards times); threads then do log_softmax through LDS; the value head uses the first
-// 64 threads.  feat: [n][6S] (policy features 4S then value features 2S).
-constexpr int kHeadBoards = 8;
-constexpr int kHeadThreads = 256;
+// k_heads_gemm: the two first FC layers as ONE fp32-MFMA GEMM over (tile of 16 boards) x (tile of
+// 16 outputs): M = boards, N = outputs (S policy logits padded to a multiple of 16, then the 64
+// hidden units of the value head), K = 4S (policy) / 2S (value).  One workgroup per
+// (board tile, output tile); its 4 waves split K, each streaming its slice of the features and
+// of the transposed, zero-padded weights from L2 with a 16-step register prefetch (no LDS
+// staging -> many workgroups per CU hide the latency of the short dependent MFMA chains), then
+// the 4 partial tiles are summed through LDS.  k_heads_finish: log_softmax / fc2 + tanh.
+constexpr int kHeadU = 16;  // k-steps per prefetch group
 
-__global__ __launch_bounds__(kHeadThreads) void k_heads(NetDev nd, const float *__restrict__ feat,
-                                                        float *__restrict__ logp, float *__restrict__ value,
-                                                        int n_boards) {
-    __shared__ float sfeat[kHeadBoards][6 * 256];
-    __shared__ float sred[kHeadBoards][kHeadThreads];
-    __shared__ float shid[kHeadBoards][64];
-    const int tid = threadIdx.x;
+__global__ __launch_bounds__(256) void k_heads_gemm(NetDev nd, const float *__restrict__ feat,
+                                                    float *__restrict__ raw, float *__restrict__ hid,
+                                                    int n_boards) {
+    __shared__ float part[4][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int S = nd.S;
-    const int b0 = blockIdx.x * kHeadBoards;
-    for (int i = tid; i < kHeadBoards * 6 * S; i += kHeadThreads) {
-        const int bb = i / (6 * S), r = i - bb * 6 * S;
-        sfeat[bb][r] = (b0 + bb < n_boards) ? feat[(size_t)(b0 + bb) * 6 * S + r] : 0.0f;
+    const int b0 = blockIdx.x * 16;
+    const int n_act_tiles = nd.Npad / 16;
+    const int ot = blockIdx.y;
+    const bool is_act = ot < n_act_tiles;
+    const int n = lane & 15, kq = lane >> 4;
+    const int steps = (is_act ? nd.steps_act : nd.steps_val) / 4;  // per wave
+    const int ldw = is_act ? nd.Npad : 64;
+    const int s_first = wave * steps;
+    const float *w = (is_act ? nd.fc_act_t + 16 * ot : nd.fc_val1_t + 16 * (ot - n_act_tiles)) +
+                     (size_t)(4 * s_first + kq) * ldw + n;
+    int brow = b0 + n;  // A row = board (lane & 15)
+    if (brow >= n_boards) brow = n_boards - 1;
+    const float *a = feat + (size_t)brow * 6 * S + (is_act ? 0 : 4 * S) + 4 * s_first + kq;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float acur[kHeadU], bcur[kHeadU], anxt[kHeadU], bnxt[kHeadU];
+#pragma unroll
+    for (int u = 0; u < kHeadU; ++u) {
+        acur[u] = a[4 * u];
+        bcur[u] = w[(size_t)(4 * u) * ldw];
     }
-    __syncthreads();
-    float logit[kHeadBoards];
+    for (int s0 = 0; s0 < steps; s0 += kHeadU) {
+        const int sn = (s0 + kHeadU < steps) ? s0 + kHeadU : s0;  // last group re-reads itself
 #pragma unroll
-    for (int bb = 0; bb < kHeadBoards; ++bb) logit[bb] = 0.0f;
-    if (tid < S) {
-        const float *w = nd.fc_act_t + tid;
-        for (int k = 0; k < 4 * S; ++k) {
-            const float wv = w[(size_t)k * S];
-#pragma unroll
-            for (int bb = 0; bb < kHeadBoards; ++bb) logit[bb] = fmaf(sfeat[bb][k], wv, logit[bb]);
+        for (int u = 0; u < kHeadU; ++u) {
+            anxt[u] = a[4 * (sn + u)];
+            bnxt[u] = w[(size_t)(4 * (sn + u)) * ldw];
         }
-        const float bias = nd.fc_act_b[tid];
 #pragma unroll
-        for (int bb = 0; bb < kHeadBoards; ++bb) logit[bb] += bias;
-    }
-    // log_softmax over j < S per board
+        for (int u = 0; u < kHeadU; ++u)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[u], bcur[u], acc, 0, 0, 0);
 #pragma unroll
-    for (int bb = 0; bb < kHeadBoards; ++bb) sred[bb][tid] = tid < S ? logit[bb] : -INFINITY;
-    __syncthreads();
-    for (int off = kHeadThreads / 2; off >= 1; off >>= 1) {
-        if (tid < off)
-#pragma unroll
-            for (int bb = 0; bb < kHeadBoards; ++bb) sred[bb][tid] = fmaxf(sred[bb][tid], sred[bb][tid + off]);
-        __syncthreads();
-    }
-    float mx[kHeadBoards];
-#pragma unroll
-    for (int bb = 0; bb < kHeadBoards; ++bb) mx[bb] = sred[bb][0];
-    __syncthreads();
-#pragma unroll
-    for (int bb = 0; bb < kHeadBoards; ++bb) sred[bb][tid] = tid < S ? expf(logit[bb] - mx[bb]) : 0.0f;
-    __syncthreads();
-    for (int off = kHeadThreads / 2; off >= 1; off >>= 1) {
-        if (tid < off)
-#pragma unroll
-            for (int bb = 0; bb < kHeadBoards; ++bb) sred[bb][tid] += sred[bb][tid + off];
-        __syncthreads();
-    }
-    if (tid < S) {
-#pragma unroll
-        for (int bb = 0; bb < kHeadBoards; ++bb)
-            if (b0 + bb < n_boards)
-                logp[(size_t)(b0 + bb) * S + tid] = logit[bb] - mx[bb] - logf(sred[bb][0]);
-    }
-    // value head: fc(2S -> 64) relu, fc(64 -> 1), tanh
-    if (tid < 64) {
-        float h[kHeadBoards];
-#pragma unroll
-        for (int bb = 0; bb < kHeadBoards; ++bb) h[bb] = 0.0f;
-        const float *w = nd.fc_val1_t + tid;
-        for (int k = 0; k < 2 * S; ++k) {
-            const float wv = w[(size_t)k * 64];
-#pragma unroll
-            for (int bb = 0; bb < kHeadBoards; ++bb) h[bb] = fmaf(sfeat[bb][4 * S + k], wv, h[bb]);
+        for (int u = 0; u < kHeadU; ++u) {
+            acur[u] = anxt[u];
+            bcur[u] = bnxt[u];
         }
-        const float bias = nd.fc_val1_b[tid], w2 = nd.fc_val2_w[tid];
+    }
 #pragma unroll
-        for (int bb = 0; bb < kHeadBoards; ++bb) shid[bb][tid] = fmaxf(h[bb] + bias, 0.0f) * w2;
-    }
+    for (int j = 0; j < 4; ++j) part[wave][j][lane] = acc[j];
     __syncthreads();
-    if (tid < kHeadBoards && b0 + tid < n_boards) {
-        float s = 0.0f;
-        for (int k = 0; k < 64; ++k) s += shid[tid][k];
-        value[b0 + tid] = tanhf(s + nd.fc_val2_b[0]);
+    if (wave != 0) return;
+    // D: column = output (lane & 15), rows = boards 4*(lane >> 4) + j
+    const int col = 16 * (is_act ? ot : ot - n_act_tiles) + n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int b = b0 + 4 * kq + j;
+        if (b >= n_boards) continue;
+        const float v = part[0][j][lane] + part[1][j][lane] + part[2][j][lane] + part[3][j][lane];
+        if (is_act) raw[(size_t)b * nd.Npad + col] = v + nd.fc_act_b[col];
+        else hid[(size_t)b * 64 + col] = fmaxf(v + nd.fc_val1_b[col], 0.0f);
     }
+}
+
+__global__ __launch_bounds__(64) void k_heads_finish(NetDev nd, const float *__restrict__ raw,
+                                                     const float *__restrict__ hid, float *__restrict__ logp,
+                                                     float *__restrict__ value, int n_boards) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= n_boards) return;
+    const int S = nd.S;
+    const float *r = raw + (size_t)b * nd.Npad;
+    float v[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = lane + 64 * i;
+        v[i] = j < S ? r[j] : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sum += (lane + 64 * i < S) ? expf(v[i] - mx) : 0.0f;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    const float lse = mx + logf(sum);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int j = lane + 64 * i;
+        if (j < S) logp[(size_t)b * S + j] = v[i] - lse;
+    }
+    float h = hid[(size_t)b * 64 + lane] * nd.fc_val2_w[lane];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) h += __shfl_xor(h, off);
+    if (lane == 0) value[b] = tanhf(h + nd.fc_val2_b[0]);
 }
 
 }  // namespace
@@ -321,7 +367,7 @@ struct rz_net {
     bool loaded = false;
     NetDev dev;
     std::vector<void *> allocs;
-    float *d_feat = nullptr;
+    float *d_feat = nullptr, *d_raw = nullptr, *d_hid = nullptr;
     long long feat_boards = 0;
 };
 
@@ -383,6 +429,12 @@ int rz_net_create(int32_t board_size, int32_t device, rz_net **out) {
     memset(&net->dev, 0, sizeof(net->dev));
     net->dev.B = board_size;
     net->dev.S = board_size * board_size;
+    {
+        NetDev &D = net->dev;
+        D.Npad = (D.S + 15) / 16 * 16;
+        D.steps_act = (4 * D.S + 16 * kHeadU - 1) / (16 * kHeadU) * (4 * kHeadU);
+        D.steps_val = (2 * D.S + 16 * kHeadU - 1) / (16 * kHeadU) * (4 * kHeadU);
+    }
     *out = net;
     return RZ_OK;
 }
@@ -393,6 +445,8 @@ int rz_net_destroy(rz_net *net) {
     (void)hipDeviceSynchronize();
     for (void *p : net->allocs) (void)hipFree(p);
     if (net->d_feat) (void)hipFree(net->d_feat);
+    if (net->d_raw) (void)hipFree(net->d_raw);
+    if (net->d_hid) (void)hipFree(net->d_hid);
     delete net;
     return RZ_OK;
 }
@@ -431,14 +485,16 @@ int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params) {
         if (rc == RZ_OK) rc = net_upload(net, bh, &D.bh);
     }
     {
-        std::vector<float> t((size_t)4 * S * S);
-        for (int j = 0; j < S; ++j)
-            for (int k = 0; k < 4 * S; ++k) t[(size_t)k * S + j] = h_params[8][(size_t)j * 4 * S + k];
+        std::vector<float> t((size_t)4 * D.steps_act * D.Npad, 0.0f), bias((size_t)D.Npad, 0.0f);
+        for (int j = 0; j < S; ++j) {
+            bias[j] = h_params[9][j];
+            for (int k = 0; k < 4 * S; ++k) t[(size_t)k * D.Npad + j] = h_params[8][(size_t)j * 4 * S + k];
+        }
         if (rc == RZ_OK) rc = net_upload(net, t, &D.fc_act_t);
-        up_f(h_params[9], S, &D.fc_act_b);
+        if (rc == RZ_OK) rc = net_upload(net, bias, &D.fc_act_b);
     }
     {
-        std::vector<float> t((size_t)2 * S * 64);
+        std::vector<float> t((size_t)4 * D.steps_val * 64, 0.0f);
         for (int j = 0; j < 64; ++j)
             for (int k = 0; k < 2 * S; ++k) t[(size_t)k * 64 + j] = h_params[12][(size_t)j * 2 * S + k];
         if (rc == RZ_OK) rc = net_upload(net, t, &D.fc_val1_t);
@@ -466,10 +522,17 @@ int rz_net_reserve(rz_net *net, int32_t max_boards) {
     if (max_boards <= net->feat_boards) return RZ_OK;
     (void)hipDeviceSynchronize();
     if (net->d_feat) (void)hipFree(net->d_feat);
-    net->d_feat = nullptr;
+    if (net->d_raw) (void)hipFree(net->d_raw);
+    if (net->d_hid) (void)hipFree(net->d_hid);
+    net->d_feat = net->d_raw = net->d_hid = nullptr;
     net->feat_boards = 0;
-    if (hipMalloc((void **)&net->d_feat, (size_t)max_boards * 6 * net->dev.S * sizeof(float)) != hipSuccess)
-        return net_fail(RZ_ERR_OOM, "hipMalloc failed (feature buffer)");
+    if (hipMalloc((void **)&net->d_feat, ((size_t)max_boards * 6 * net->dev.S + 4096) * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&net->d_raw, (size_t)max_boards * net->dev.Npad * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&net->d_hid, (size_t)max_boards * 64 * sizeof(float)) != hipSuccess)
+        return net_fail(RZ_ERR_OOM, "hipMalloc failed (feature buffers)");
+    // the zero-padded K tail of the last board reads into the slack: it must hold finite values
+    if (hipMemset(net->d_feat, 0, ((size_t)max_boards * 6 * net->dev.S + 4096) * sizeof(float)) != hipSuccess)
+        return net_fail(RZ_ERR_HIP, "hipMemset failed (feature buffer)");
     net->feat_boards = max_boards;
     return RZ_OK;
 }
@@ -492,8 +555,9 @@ int rz_net_forward(rz_net *net, const float *d_obs, int32_t n_boards, float *d_l
     if (n_boards > net->feat_boards)
         return net_fail(RZ_ERR_ARG, "batch larger than rz_net_reserve()d (no allocation on the launch path)");
     k_trunk<<<dim3((unsigned)n_boards), dim3(kTrunkThreads), 0, (hipStream_t)stream>>>(net->dev, d_obs, net->d_feat, n_boards);
-    const unsigned blocks = (unsigned)((n_boards + kHeadBoards - 1) / kHeadBoards);
-    k_heads<<<dim3(blocks), dim3(kHeadThreads), 0, (hipStream_t)stream>>>(net->dev, net->d_feat, d_logp, d_value, n_boards);
+    const dim3 grid((unsigned)((n_boards + 15) / 16), (unsigned)(net->dev.Npad / 16 + 4));
+    k_heads_gemm<<<grid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, net->d_feat, net->d_raw, net->d_hid, n_boards);
+    k_heads_finish<<<dim3((unsigned)n_boards), dim3(64), 0, (hipStream_t)stream>>>(net->dev, net->d_raw, net->d_hid, d_logp, d_value, n_boards);
     if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_trunk/k_heads failed");
     return RZ_OK;
 }

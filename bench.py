@@ -41,10 +41,28 @@ def flops_per_position(cells):
     return 188416 * cells + 8 * cells * cells + 128
 
 
+def trunk_flops_per_position(cells):
+    """conv1 + conv2 + conv3 + the two 1x1 head convolutions: 2*(9*(4*32 + 32*64 + 64*128) + 128*6) per cell."""
+    return 188160 * cells
+
+
 def tree_bytes_per_sim(scanned, created, depth):
     """12 B per scanned child, 16 B per created child, 24 B per backed-up node,
     64 B of root bitboards."""
     return 12.0 * scanned + 16.0 * created + 24.0 * (depth + 1.0) + 64.0
+
+
+def pmc_traffic(kernel, workload, lanes):
+    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes (separate
+    FETCH_SIZE / WRITE_SIZE runs, gfx950 read correction applied; profiles/r01/pmc_traffic.json).
+    None when no counter run exists for this workload / launch geometry."""
+    try:
+        rec = json.load(open(os.path.join(REPO, 'profiles', 'r01', 'pmc_traffic.json')))
+        if rec['workload'] != workload or lanes != 1:
+            return None
+        return rec['kernels'][kernel]['traffic_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 # --------------------------------------------------------------------------- CPU baseline
@@ -148,9 +166,16 @@ class TimedEvaluator(object):
         if not self.record:
             return self.inner(eng)
         a, b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
-        a.record()
-        out = self.inner(eng)
-        b.record()
+        hip = getattr(self.inner, 'hip', None)
+        if hip is not None:  # bracket the dominant kernel (k_trunk) alone
+            a.record()
+            hip.trunk_internal(eng.obs)
+            b.record()
+            out = hip.heads(eng.obs.shape[0], eng.logp, eng.value)
+        else:
+            a.record()
+            out = self.inner(eng)
+            b.record()
         self.events.append((a, b))
         return out
 
@@ -174,7 +199,10 @@ def main():
     ap.add_argument('--evaluator', default='hipnet', choices=['hipnet', 'torchnet', 'vlin'],
                     help="hipnet: hand-written fused fp32 MFMA forward (csrc/rz_net.hip); torchnet: "
                          "PyTorch-ROCm/MIOpen; vlin: synthetic evaluator (isolates the tree kernels)")
-    ap.add_argument('--graph', type=int, default=0, help='simulation steps per hipGraph (0 = eager)')
+    ap.add_argument('--graph', type=int, default=8, help='simulation steps per hipGraph (0 = eager)')
+    ap.add_argument('--lanes', type=int, default=1,
+                    help='half-batches on separate HIP streams (tree kernels of one lane run beside '
+                         'the network kernel of the other)')
     args = ap.parse_args()
     if args.cpu_worker is not None:
         cpu_worker(args.cpu_worker, args.board, N_ROW if args.board >= 5 else args.board, args.playouts)
@@ -205,21 +233,31 @@ def main():
     board, n_row = args.board, (N_ROW if args.board >= 5 else args.board)
     cells = board * board
     G = args.games
-    eng = MCTSEngine(board, n_row, n_games=G, n_playout=args.playouts, c_puct=C_PUCT, device=device)
+    lanes = max(1, min(args.lanes, G))
+    per_lane = [G // lanes + (1 if i < G % lanes else 0) for i in range(lanes)]
     torch.manual_seed(0)  # identical weights on every rank
     net = PolicyValueNet(board).to(device).eval()
-    if args.evaluator == 'hipnet':
-        evaluator = TimedEvaluator(HipNetEvaluator(net, board, device, max_boards=G), torch,
-                                   'k_trunk + k_heads (hand-written fp32 MFMA, csrc/rz_net.hip)')
-    elif args.evaluator == 'torchnet':
-        evaluator = TimedEvaluator(NetEvaluator(net), torch, 'torch/MIOpen forward (~14 kernels)')
-    else:
-        evaluator = SyntheticEvaluator('vlin')
-    sp = BatchedSelfPlay(eng, evaluator, temperature=TEMPERATURE, seed=0,
-                         use_graph=args.graph > 0, sims_per_graph=max(args.graph, 1))
+    engines, evaluators = [], []
+    for g_lane in per_lane:
+        eng = MCTSEngine(board, n_row, n_games=g_lane, n_playout=args.playouts, c_puct=C_PUCT, device=device)
+        if args.evaluator == 'hipnet':
+            ev = TimedEvaluator(HipNetEvaluator(net, board, device, max_boards=g_lane), torch,
+                                'k_trunk (hand-written fused fp32-MFMA conv trunk, csrc/rz_net.hip)')
+        elif args.evaluator == 'torchnet':
+            ev = TimedEvaluator(NetEvaluator(net), torch, 'torch/MIOpen forward (~14 kernels)')
+        else:
+            ev = SyntheticEvaluator('vlin')
+        engines.append(eng)
+        evaluators.append(ev)
+    evaluator = evaluators[0]
+    sp = BatchedSelfPlay(engines, evaluators, temperature=TEMPERATURE, seed=0,
+                         use_graph=args.graph > 0, sims_per_graph=max(args.graph, 1), eager_every=10)
     if args.graph > 0:
-        eng.reset_games()
-        eng.warm_graph(evaluator, args.graph)
+        for lane in sp.lanes:
+            with torch.cuda.stream(lane.stream):
+                lane.eng.reset_games()
+                lane.eng.warm_graph(lane.evaluator, args.graph)
+        torch.cuda.synchronize()
     # games rank, rank+world, ... ; ids beyond the first G refill finished slots
     next_id = [rank + world * G]
     sp._start(range(G), [rank + world * i for i in range(G)])
@@ -234,7 +272,7 @@ def main():
             ids = [next_id[0] + world * i for i in range(len(free))]
             next_id[0] += world * len(free)
             sp._start(free, ids)
-            sp._set_active()
+            sp.retire_finished()
 
     def fence():
         torch.cuda.synchronize()
@@ -244,8 +282,9 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
-    if isinstance(evaluator, TimedEvaluator):
-        evaluator.record = True
+    for ev in evaluators:
+        if isinstance(ev, TimedEvaluator):
+            ev.record = True
     sims0, fin0 = sp.sims_done, finished[0]
     fence()
     t0 = time.perf_counter()
@@ -262,7 +301,9 @@ def main():
         total_sims, total_finished = float(counts[0].item()), float(counts[1].item())
     else:
         total_sims, total_finished = float(sp.sims_done - sims0), float(finished[0] - fin0)
-    stats = eng.check()
+    all_stats = sp.check()
+    stats = max(all_stats, key=lambda st: st.max_slots_used)
+    hbm_bytes = sum(st.device_bytes for st in all_stats)
 
     if rank == 0:
         value = total_sims / elapsed
@@ -277,22 +318,28 @@ def main():
                                    % (board, board, n_row, args.playouts, G),
                        'games_total': G * world, 'c_puct': C_PUCT, 'temperature': TEMPERATURE,
                        'evaluator': args.evaluator, 'score_mode': 'UCT_REF (bit-exact)',
-                       'sims_per_graph': args.graph, 'parallelism': 'games sharded, dp%d' % world},
+                       'sims_per_graph': args.graph, 'lanes': lanes, 'parallelism': 'games sharded, dp%d' % world},
             'moves_per_sec': round(total_sims / args.playouts / elapsed, 2),
             'games_finished_in_timed_region': int(total_finished),
             'arena_slots_used_max': int(stats.max_slots_used),
-            'engine_hbm_bytes': int(stats.device_bytes),
+            'engine_hbm_bytes': int(hbm_bytes),
         }
         if isinstance(evaluator, TimedEvaluator) and evaluator.mean_ms():
-            ms = evaluator.mean_ms()
-            flops = flops_per_position(cells) * G
+            # one launch = the forward of one lane's leaves; durations from HIP events on that
+            # lane's stream (with lanes > 1 they include time the launch waited for the CUs)
+            n_ev = sum(len(ev.events) for ev in evaluators)
+            ms = sum(ev.mean_ms() * len(ev.events) for ev in evaluators) / n_ev
+            boards_per_launch = G / float(lanes)
+            per_pos = trunk_flops_per_position(cells) if args.evaluator == 'hipnet' else flops_per_position(cells)
+            flops = per_pos * boards_per_launch
             achieved = flops / (ms * 1e-3) / 1e12
-            line['roofline'] = {'bound': 'mfma', 'kernel': 'policy+value forward of %d leaves: %s' % (G, evaluator.label),
+            line['roofline'] = {'bound': 'mfma',
+                                'kernel': '%s, %d leaves per launch' % (evaluator.label, boards_per_launch),
                                 'achieved': round(achieved, 3), 'peak': PEAK_FP32_MATRIX_TFLOPS,
                                 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
-                                'traffic': None, 'avg_launch_ms': round(ms, 4),
-                                'launches_timed': len(evaluator.events),
-                                'share_of_step_time': round(ms * len(evaluator.events) / (elapsed * 1e3), 3)}
+                                'traffic': pmc_traffic('k_trunk', line['config']['workload'], lanes),
+                                'avg_launch_ms': round(ms, 4), 'launches_timed': n_ev,
+                                'share_of_step_time': round(ms * (total_sims / world / G) / (elapsed * 1e3), 3)}
         else:
             per_sim = tree_bytes_per_sim(365.5, 208.8, 1.74) if board == 15 else None
             if per_sim:
@@ -302,7 +349,8 @@ def main():
                                     'frac': round(achieved / PEAK_HBM_GBS, 6), 'traffic': None}
         line['cpu_baseline'] = cpu_baseline
         print(json.dumps(line), flush=True)
-    eng.close()
+    for eng in engines:
+        eng.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 3
+#define RZ_ABI_VERSION 5
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 
@@ -156,6 +156,11 @@ int rz_eval_synthetic(rz_engine *e, int kind, float *d_logp, float *d_value, voi
 int rz_expand_backup(rz_engine *e, const float *d_logp, const float *d_value, void *stream);
 int rz_expand_backup_f64(rz_engine *e, const float *d_logp, const double *d_value, void *stream);
 
+/* rz_expand_backup of the pending leaves followed by rz_select_step of the next simulation in
+ * ONE launch (two consecutive iterations of the reference's loop, alphazero_mcts.py:82-85,
+ * share a kernel boundary).  Same arguments as the two calls it replaces. */
+int rz_tree_step(rz_engine *e, const float *d_logp, const float *d_value, float *d_obs, void *stream);
+
 /* Root statistics after the simulations (AlphaZeroMCTS.simulate, alphazero_mcts.py:88-90):
  * visit count / W of the root child of every action, 0 for illegal or unvisited actions;
  * [n_games][B*B].  rz_root_stats: N and W of the roots themselves, [n_games]. */
@@ -202,13 +207,17 @@ int rz_uct_scores(rz_engine *e, const double *d_w, const int32_t *d_n, const int
  * rz_net_reserve sizes the internal feature buffer (the launch path never allocates).
  * rz_net_forward: d_obs float32 [n][4][B][B] -> d_logp [n][B*B] (log-probabilities),
  * d_value [n].  rz_net_trunk exposes the first kernel alone: d_feat [n][6][B*B] = ReLU'd
- * outputs of act_conv1 (4 planes) and val_conv1 (2 planes). */
+ * outputs of act_conv1 (4 planes) and val_conv1 (2 planes); d_feat == NULL writes the
+ * internal buffer that rz_net_heads (the FC layers + log_softmax + tanh) reads, so
+ * rz_net_trunk(.., NULL, ..) + rz_net_heads == rz_net_forward (lets a caller time the
+ * dominant kernel by itself). */
 typedef struct rz_net rz_net;
 int rz_net_create(int32_t board_size, int32_t device, rz_net **out);
 int rz_net_destroy(rz_net *net);
 int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params);
 int rz_net_reserve(rz_net *net, int32_t max_boards);
 int rz_net_trunk(rz_net *net, const float *d_obs, int32_t n_boards, float *d_feat, void *stream);
+int rz_net_heads(rz_net *net, int32_t n_boards, float *d_logp, float *d_value, void *stream);
 int rz_net_forward(rz_net *net, const float *d_obs, int32_t n_boards, float *d_logp,
                    float *d_value, void *stream);
 

@@ -7,7 +7,7 @@ import ctypes
 import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p)
 
-ABI_VERSION = 3
+ABI_VERSION = 5
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
 
@@ -54,6 +54,7 @@ _SIGNATURES = {
     'rz_eval_synthetic': (c_int, [P, c_int, P, P, P]),
     'rz_expand_backup': (c_int, [P, P, P, P]),
     'rz_expand_backup_f64': (c_int, [P, P, P, P]),
+    'rz_tree_step': (c_int, [P, P, P, P, P]),
     'rz_root_visits': (c_int, [P, P, P]),
     'rz_root_wsum': (c_int, [P, P, P]),
     'rz_root_priors': (c_int, [P, P, P]),
@@ -69,6 +70,7 @@ _SIGNATURES = {
     'rz_net_load': (c_int, [P, POINTER(c_void_p), c_int32]),
     'rz_net_reserve': (c_int, [P, c_int32]),
     'rz_net_trunk': (c_int, [P, P, c_int32, P, P]),
+    'rz_net_heads': (c_int, [P, c_int32, P, P, P]),
     'rz_net_forward': (c_int, [P, P, c_int32, P, P, P]),
 }
 

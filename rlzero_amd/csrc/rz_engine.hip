@@ -197,9 +197,7 @@ __device__ __forceinline__ double uct_ref(double w, int n, double ln_parent, dou
 }
 
 // ------------------------------------------------------------------ SELECT + STEP
-__global__ __launch_bounds__(kWave) void k_select(Dev E, float *obs) {
-    const int g = blockIdx.x;
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int lane) {
     if (!E.active[g]) return;
     const int S = E.S, B = E.B;
     const long long base = ((long long)g * 2 + E.cur_arena[g]) * E.cap;
@@ -322,9 +320,8 @@ __global__ __launch_bounds__(kWave) void k_select(Dev E, float *obs) {
 
 // ------------------------------------------------------------------ EXPAND + BACKUP
 template <typename VT>
-__global__ __launch_bounds__(kWave) void k_expand_backup(Dev E, const float *logp, const VT *value) {
-    const int g = blockIdx.x;
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void expand_backup_body(const Dev &E, const float *logp, const VT *value, int g,
+                                                   int lane) {
     if (!E.active[g]) return;
     const int S = E.S;
     const long long base = ((long long)g * 2 + E.cur_arena[g]) * E.cap;
@@ -396,6 +393,28 @@ __global__ __launch_bounds__(kWave) void k_expand_backup(Dev E, const float *log
             W[node] += x;
         }
     }
+}
+
+__global__ __launch_bounds__(kWave) void k_select(Dev E, float *obs) {
+    __builtin_amdgcn_s_setprio(3);  // latency-bound: issue ahead of a co-resident MFMA kernel
+    select_body(E, obs, blockIdx.x, threadIdx.x);
+}
+
+template <typename VT>
+__global__ __launch_bounds__(kWave) void k_expand_backup(Dev E, const float *logp, const VT *value) {
+    __builtin_amdgcn_s_setprio(3);
+    expand_backup_body<VT>(E, logp, value, blockIdx.x, threadIdx.x);
+}
+
+// EXPAND + BACKUP of simulation s and SELECT + STEP of simulation s+1 in one launch (same
+// wave, same game): saves a kernel boundary per simulation.  The barrier makes the tree
+// updates of the first half visible to the loads of the second.
+template <typename VT>
+__global__ __launch_bounds__(kWave) void k_tree_step(Dev E, const float *logp, const VT *value, float *obs) {
+    __builtin_amdgcn_s_setprio(3);
+    expand_backup_body<VT>(E, logp, value, blockIdx.x, threadIdx.x);
+    __syncthreads();
+    select_body(E, obs, blockIdx.x, threadIdx.x);
 }
 
 // ------------------------------------------------------------------ synthetic evaluators
@@ -1029,6 +1048,14 @@ int rz_expand_backup_f64(rz_engine *e, const float *d_logp, const double *d_valu
     RZ_NEED(d_value);
     k_expand_backup<double><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_logp, d_value);
     return launched("k_expand_backup");
+}
+
+int rz_tree_step(rz_engine *e, const float *d_logp, const float *d_value, float *d_obs, void *stream) {
+    RZ_ENTER(e);
+    RZ_NEED(d_value);
+    e->n_select += 1;
+    k_tree_step<float><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_logp, d_value, d_obs);
+    return launched("k_tree_step");
 }
 
 int rz_root_visits(rz_engine *e, int32_t *d_visits, void *stream) {

@@ -5,18 +5,19 @@
 // 15x15 position, MFMA-bound).  Exact fp32: v_mfma_f32_16x16x4_f32 is a k-ordered fmaf
 // chain, no reduced precision anywhere (tolerance vs the reference's CPU output: 1e-4).
 //
-// Kernel A (k_trunk): ONE workgroup (8 waves) per board.  The board's activations never
-// leave the CU: input planes, conv1 output (32 ch) and conv2 output (64 ch) live in LDS as
-// halo-padded planes [channel][18 rows][18 cols] (plane stride 336 floats = 16 mod 32 banks);
-// conv3's 128 channels stay in the MFMA accumulators and are consumed by the two 1x1 head
-// convolutions in registers.  Implicit GEMM per layer with M = output channels (A = weights,
-// pre-packed on the host in fragment order, streamed from L2 as 16-byte loads), N = the 16
-// columns of one board row (B = one ds_read_b32 per lane from the halo planes), K = (input
-// channel group of 4, tap).  Wave w owns output-channel half (w & 1) and rows 4*(w>>1)..+3,
-// i.e. TM x 4 accumulator tiles; the 18 distinct (row offset, dx) fragments of a channel
-// group are read once and reused by all 9 taps x 4 rows.
-// Kernel B (k_heads): the three fully connected layers, log_softmax and tanh for a tile of
-// boards per workgroup.
+// k_trunk: ONE workgroup (8 waves) per board.  The board's activations never leave the CU:
+// input planes, conv1 output (32 ch) and conv2 output (64 ch) live in LDS as halo-padded
+// planes [channel][18 rows][18 cols] (plane stride 336 floats = 16 mod 32 banks: the 4 channel
+// sub-groups of a fragment read hit disjoint banks); conv3's 128 channels stay in the MFMA
+// accumulators and are consumed by the two 1x1 head convolutions in registers.  Implicit GEMM
+// per layer: M = output channels (A = weights, pre-packed on the host in fragment order,
+// streamed from L2 with 16-byte loads), N = the 16 columns of one board row (B = ds_read_b32
+// from the halo planes), K = (group of 4 input channels, tap).  Wave w = 4*rh + q4 owns
+// output-channel quarter q4 and row half rh (8 + 7 rows on a 15x15 board; the two waves of a
+// quarter share a SIMD, so every SIMD carries 15 row-units: no padded row is computed).  Per
+// channel group the (NR+2) x 3 distinct (row, dx) fragments are read once and reused by the
+// 9 taps x NR rows; the next group's fragments are in flight under this group's MFMAs.
+// k_heads_gemm + k_heads_finish: the three fully connected layers, log_softmax and tanh.
 
 #include <hip/hip_runtime.h>
 
@@ -106,12 +107,18 @@ __device__ __forceinline__ void conv_accumulate(const float *__restrict__ in, co
     Frags<TM, NR> f0, f1;
     load_frags<TM, NR, kSteps>(f0, base, wbase, 0);
 #pragma unroll 1
+    // sched_barrier(0) pins "issue every load of the next group, THEN the MFMAs of this one":
+    // left alone, hipcc sinks each load next to its first use and the MFMAs wait on it.
     for (int s = 0; s < kSteps; s += 2) {
         load_frags<TM, NR, kSteps>(f1, base, wbase, s + 1 < kSteps ? s + 1 : kSteps - 1);
+        __builtin_amdgcn_sched_barrier(0);
         mfma_group<TM, NR>(f0, acc);
-        if (s + 1 < kSteps) {
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (kSteps > 1) {  // kSteps is 1 (conv1) or even
             load_frags<TM, NR, kSteps>(f0, base, wbase, s + 2 < kSteps ? s + 2 : kSteps - 1);
+            __builtin_amdgcn_sched_barrier(0);
             mfma_group<TM, NR>(f1, acc);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -272,6 +279,7 @@ __global__ __launch_bounds__(256) void k_heads_gemm(NetDev nd, const float *__re
                                                     float *__restrict__ raw, float *__restrict__ hid,
                                                     int n_boards) {
     __shared__ float part[4][4][64];
+    __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int S = nd.S;
     const int b0 = blockIdx.x * 16;
@@ -329,6 +337,7 @@ __global__ __launch_bounds__(256) void k_heads_gemm(NetDev nd, const float *__re
 __global__ __launch_bounds__(64) void k_heads_finish(NetDev nd, const float *__restrict__ raw,
                                                      const float *__restrict__ hid, float *__restrict__ logp,
                                                      float *__restrict__ value, int n_boards) {
+    __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= n_boards) return;
     const int S = nd.S;
@@ -537,14 +546,37 @@ int rz_net_reserve(rz_net *net, int32_t max_boards) {
     return RZ_OK;
 }
 
+static int launch_heads(rz_net *net, const float *d_feat, int32_t n_boards, float *d_logp, float *d_value,
+                        void *stream) {
+    const dim3 grid((unsigned)((n_boards + 15) / 16), (unsigned)(net->dev.Npad / 16 + 4));
+    k_heads_gemm<<<grid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_feat, net->d_raw, net->d_hid, n_boards);
+    k_heads_finish<<<dim3((unsigned)n_boards), dim3(64), 0, (hipStream_t)stream>>>(net->dev, net->d_raw, net->d_hid,
+                                                                                  d_logp, d_value, n_boards);
+    if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_heads_* failed");
+    return RZ_OK;
+}
+
 int rz_net_trunk(rz_net *net, const float *d_obs, int32_t n_boards, float *d_feat, void *stream) {
     int rc = net_ready(net, n_boards);
     if (rc != RZ_OK) return rc;
-    if (!d_obs || !d_feat) return net_fail(RZ_ERR_ARG, "NULL device pointer");
+    if (!d_obs) return net_fail(RZ_ERR_ARG, "NULL device pointer");
     if (n_boards == 0) return RZ_OK;
+    if (!d_feat) {  // internal feature buffer (the input of rz_net_heads)
+        if (n_boards > net->feat_boards) return net_fail(RZ_ERR_ARG, "batch larger than rz_net_reserve()d");
+        d_feat = net->d_feat;
+    }
     k_trunk<<<dim3((unsigned)n_boards), dim3(kTrunkThreads), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
     if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_trunk failed");
     return RZ_OK;
+}
+
+int rz_net_heads(rz_net *net, int32_t n_boards, float *d_logp, float *d_value, void *stream) {
+    int rc = net_ready(net, n_boards);
+    if (rc != RZ_OK) return rc;
+    if (!d_logp || !d_value) return net_fail(RZ_ERR_ARG, "NULL device pointer");
+    if (n_boards == 0) return RZ_OK;
+    if (n_boards > net->feat_boards) return net_fail(RZ_ERR_ARG, "batch larger than rz_net_reserve()d");
+    return launch_heads(net, net->d_feat, n_boards, d_logp, d_value, stream);
 }
 
 int rz_net_forward(rz_net *net, const float *d_obs, int32_t n_boards, float *d_logp, float *d_value, void *stream) {
@@ -555,11 +587,8 @@ int rz_net_forward(rz_net *net, const float *d_obs, int32_t n_boards, float *d_l
     if (n_boards > net->feat_boards)
         return net_fail(RZ_ERR_ARG, "batch larger than rz_net_reserve()d (no allocation on the launch path)");
     k_trunk<<<dim3((unsigned)n_boards), dim3(kTrunkThreads), 0, (hipStream_t)stream>>>(net->dev, d_obs, net->d_feat, n_boards);
-    const dim3 grid((unsigned)((n_boards + 15) / 16), (unsigned)(net->dev.Npad / 16 + 4));
-    k_heads_gemm<<<grid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, net->d_feat, net->d_raw, net->d_hid, n_boards);
-    k_heads_finish<<<dim3((unsigned)n_boards), dim3(64), 0, (hipStream_t)stream>>>(net->dev, net->d_raw, net->d_hid, d_logp, d_value, n_boards);
-    if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_trunk/k_heads failed");
-    return RZ_OK;
+    if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_trunk failed");
+    return launch_heads(net, net->d_feat, n_boards, d_logp, d_value, stream);
 }
 
 }  // extern "C"

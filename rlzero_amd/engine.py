@@ -110,6 +110,20 @@ class HipNet(object):
         check(self.lib.rz_net_forward(self.handle, _ptr(obs), n, _ptr(logp), _ptr(value), st), 'rz_net_forward')
         return logp, value
 
+    def _stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def trunk_internal(self, obs):
+        """k_trunk alone into the internal feature buffer (pair with ``heads``)."""
+        n = obs.shape[0]
+        if n > self.max_boards:
+            self.reserve(n)
+        check(self.lib.rz_net_trunk(self.handle, _ptr(obs), n, None, self._stream()), 'rz_net_trunk')
+
+    def heads(self, n, logp, value):
+        check(self.lib.rz_net_heads(self.handle, int(n), _ptr(logp), _ptr(value), self._stream()), 'rz_net_heads')
+        return logp, value
+
     def trunk(self, obs):
         t = self.torch
         n = obs.shape[0]
@@ -324,54 +338,64 @@ class MCTSEngine(object):
             check(self.lib.rz_expand_backup(self.handle, _ptr(logp), _ptr(value), self.stream()),
                   'rz_expand_backup')
 
-    def simulate(self, evaluator, n_sims=None, use_graph=False, sims_per_graph=8):
-        """Run ``n_sims`` (default n_playout) simulations in every active game.
-
-        use_graph: capture ``sims_per_graph`` simulation steps in one hipGraph
-        (torch.cuda.CUDAGraph around our launches + the net) and replay it, removing the
-        per-launch host cost; only for device-side evaluators."""
-        n = self.n_playout if n_sims is None else int(n_sims)
-        if not use_graph or isinstance(evaluator, HostEvaluator):
+    def sim_chunk(self, evaluator, n):
+        """``n`` simulations of every active game: select, (evaluate, expand+backup+select) x
+        (n-1), evaluate, expand+backup -- consecutive simulations share one tree launch."""
+        if n <= 0:
+            return
+        if isinstance(evaluator, HostEvaluator):
             for _ in range(n):
                 self.sim_step(evaluator)
             return
+        lib, h = self.lib, self.handle
+        obs = _ptr(self.obs) if getattr(evaluator, 'needs_obs', True) else None
+        check(lib.rz_select_step(h, obs, self.stream()), 'rz_select_step')
+        for i in range(n):
+            logp, value = evaluator(self)
+            if value.dtype != self.torch.float32:
+                raise HipError('device evaluators must return float32 values')
+            if i + 1 < n:
+                check(lib.rz_tree_step(h, _ptr(logp), _ptr(value), obs, self.stream()), 'rz_tree_step')
+            else:
+                check(lib.rz_expand_backup(h, _ptr(logp), _ptr(value), self.stream()), 'rz_expand_backup')
+
+    def simulate(self, evaluator, n_sims=None, use_graph=False, sims_per_graph=8):
+        """Run ``n_sims`` (default n_playout) simulations in every active game.
+
+        use_graph: replay a hipGraph holding ``sims_per_graph`` simulations (captured by
+        ``warm_graph``) instead of launching kernel by kernel; device-side evaluators only."""
+        n = self.n_playout if n_sims is None else int(n_sims)
+        if not use_graph or isinstance(evaluator, HostEvaluator):
+            self.sim_chunk(evaluator, n)
+            return
         per = max(1, min(int(sims_per_graph), n))
-        graph = self._graph_for(evaluator, per)
+        key = (id(evaluator), per)
+        if key not in self._graphs:
+            raise HipError('call warm_graph(evaluator, %d) before simulate(use_graph=True)' % per)
+        graph = self._graphs[key][0]
         full, rest = divmod(n, per)
         for _ in range(full):
             graph.replay()
-        for _ in range(rest):
-            self.sim_step(evaluator)
-
-    def _graph_for(self, evaluator, per):
-        key = (id(evaluator), per)
-        if key in self._graphs:
-            return self._graphs[key][0]
-        t = self.torch
-        # Capturing must not change the trees: simulate on a scratch copy is not possible
-        # (the tree IS the state), so capture happens on the real state and counts as `per`
-        # real simulations -- callers account for it through `warm_graph`.
-        raise HipError('call warm_graph(evaluator, sims_per_graph) before simulate(use_graph=True)')
+        self.sim_chunk(evaluator, rest)
 
     def warm_graph(self, evaluator, per):
-        """Capture ``per`` simulation steps into a graph.  The capture itself does not
-        execute kernels; the (eager) warm-up step needed by MIOpen does, so this must be
-        called on throw-away tree state (e.g. before reset_games)."""
+        """Capture ``per`` simulations into a hipGraph (torch.cuda.CUDAGraph around our launches
+        and the evaluator).  Capturing executes nothing, but the eager warm-up does run 3
+        simulations, so call this on throw-away tree state (before reset_games)."""
         t = self.torch
         key = (id(evaluator), per)
         if key in self._graphs:
             return self._graphs[key][0]
+        cur = t.cuda.current_stream(self.device)
         side = t.cuda.Stream(device=self.device)
-        side.wait_stream(t.cuda.current_stream(self.device))
+        side.wait_stream(cur)
         with t.cuda.stream(side):
-            for _ in range(3):
-                self.sim_step(evaluator)
-        t.cuda.current_stream(self.device).wait_stream(side)
+            self.sim_chunk(evaluator, 3)
+        cur.wait_stream(side)
         t.cuda.synchronize(self.device)
         graph = t.cuda.CUDAGraph()
         with t.cuda.graph(graph):
-            for _ in range(per):
-                self.sim_step(evaluator)
+            self.sim_chunk(evaluator, per)
         self._graphs[key] = (graph, evaluator)
         return graph
 

@@ -91,18 +91,46 @@ class Trajectory(object):
         return self.winner, list(zip(self.states(), list(self.pis), self.z()))
 
 
-class BatchedSelfPlay(object):
-    """Plays ``len(game_ids)`` games on ``engine`` (slots are refilled as games end)."""
+class _Lane(object):
+    """One engine + its evaluator + the HIP stream its kernels are enqueued on."""
 
-    def __init__(self, engine, evaluator, temperature=1.0, seed=0, use_graph=False,
-                 sims_per_graph=8):
-        self.eng = engine
-        self.evaluator = evaluator
+    def __init__(self, engine, evaluator, stream, offset):
+        self.eng, self.evaluator, self.stream, self.offset = engine, evaluator, stream, offset
+        self.slots = slice(offset, offset + engine.n_games)
+
+
+class BatchedSelfPlay(object):
+    """Plays games on one GPU; slots are refilled as games end.
+
+    ``engine`` / ``evaluator`` may be lists of equal length: each (engine, evaluator) pair is a
+    *lane* with its own HIP stream, and the simulation steps of the lanes are enqueued
+    alternately.  While the network kernel of one lane owns the CUs' LDS, the latency-bound tree
+    kernels of the other lane run beside it (they use no LDS), so the halves ping-pong and the
+    tree work is hidden under the dense contraction.  Results do not depend on the lane split:
+    games are independent and their uniforms are keyed by game id."""
+
+    def __init__(self, engine, evaluator, temperature=1.0, seed=0, use_graph=False, sims_per_graph=8,
+                 eager_every=0):
+        engines = list(engine) if isinstance(engine, (list, tuple)) else [engine]
+        evaluators = list(evaluator) if isinstance(evaluator, (list, tuple)) else [evaluator]
+        assert len(engines) == len(evaluators) >= 1
+        torch = engines[0].torch
+        self.torch = torch
+        self.lanes, offset = [], 0
+        for i, (eng, ev) in enumerate(zip(engines, evaluators)):
+            stream = torch.cuda.current_stream(eng.device) if len(engines) == 1 else \
+                torch.cuda.Stream(device=eng.device)
+            self.lanes.append(_Lane(eng, ev, stream, offset))
+            offset += eng.n_games
+        self.eng = engines[0]  # geometry (board size, n_playout) is common to all lanes
+        self.evaluator = evaluators[0]
+        self.n_slots = offset
         self.temperature = float(temperature)
         self.seed = int(seed)
         self.use_graph = use_graph
         self.sims_per_graph = sims_per_graph
-        G = engine.n_games
+        self.eager_every = int(eager_every)  # with graphs: every k-th chunk runs eagerly (timing samples)
+        G = self.n_slots
         self.slot_game = np.full(G, -1, dtype=np.int64)
         self.slot_ply = np.zeros(G, dtype=np.int64)
         self.slot_occ = [0] * G
@@ -111,9 +139,12 @@ class BatchedSelfPlay(object):
         self.sims_done = 0
         self.moves_done = 0
 
+    def _on(self, lane):
+        return self.torch.cuda.stream(lane.stream)
+
     # -- slot management -----------------------------------------------------------
     def _start(self, slots, game_ids):
-        mask = np.zeros(self.eng.n_games, dtype=np.uint8)
+        mask = np.zeros(self.n_slots, dtype=np.uint8)
         for s, g in zip(slots, game_ids):
             mask[s] = 1
             self.slot_game[s] = g
@@ -121,10 +152,41 @@ class BatchedSelfPlay(object):
             self.slot_occ[s] = 0
             self.slot_moves[s] = []
             self.slot_pis[s] = []
-        self.eng.reset_games(mask=mask)
+        for lane in self.lanes:
+            if mask[lane.slots].any():
+                with self._on(lane):
+                    lane.eng.reset_games(mask=mask[lane.slots])
 
     def _set_active(self):
-        self.eng.set_active((self.slot_game >= 0).astype(np.uint8))
+        active = (self.slot_game >= 0).astype(np.uint8)
+        for lane in self.lanes:
+            with self._on(lane):
+                lane.eng.set_active(active[lane.slots])
+
+    def _simulate(self):
+        n = self.eng.n_playout
+        if self.use_graph:
+            per = max(1, int(self.sims_per_graph))
+            full, n = divmod(n, per)
+            for c in range(full):
+                eager = self.eager_every > 0 and c % self.eager_every == 0
+                for lane in self.lanes:
+                    with self._on(lane):
+                        if eager:
+                            lane.eng.sim_chunk(lane.evaluator, per)
+                        else:
+                            lane.eng.simulate(lane.evaluator, per, use_graph=True, sims_per_graph=per)
+        if n and len(self.lanes) == 1:
+            lane = self.lanes[0]
+            with self._on(lane):
+                lane.eng.sim_chunk(lane.evaluator, n)
+        elif n:
+            # interleave the lanes in chunks so that their kernels alternate on the device
+            chunk = 8
+            for c0 in range(0, n, chunk):
+                for lane in self.lanes:
+                    with self._on(lane):
+                        lane.eng.sim_chunk(lane.evaluator, min(chunk, n - c0))
 
     # -- one move for every running game ----------------------------------------------
     def play_move(self):
@@ -133,11 +195,13 @@ class BatchedSelfPlay(object):
         eng = self.eng
         S = eng.n_cells
         running = np.nonzero(self.slot_game >= 0)[0]
-        eng.simulate(self.evaluator, eng.n_playout, use_graph=self.use_graph,
-                     sims_per_graph=self.sims_per_graph)
-        visits = eng.root_visits()
+        self._simulate()
+        visits = np.zeros((self.n_slots, S), dtype=np.int32)
+        for lane in self.lanes:
+            with self._on(lane):
+                visits[lane.slots] = lane.eng.root_visits()
         self.sims_done += eng.n_playout * len(running)
-        moves = np.full(eng.n_games, -2, dtype=np.int32)
+        moves = np.full(self.n_slots, -2, dtype=np.int32)
         us = move_uniform(self.seed, self.slot_game[running], self.slot_ply[running])
         for s, u in zip(running, us):
             occ = self.slot_occ[s]
@@ -151,9 +215,13 @@ class BatchedSelfPlay(object):
             self.slot_moves[s].append(move)
             self.slot_occ[s] = occ | (1 << move)
             self.slot_ply[s] += 1
-        eng.advance(moves)  # tree reuse (update_with_move), before the boards change
+        winner = np.zeros(self.n_slots, dtype=np.int32)
+        ended = np.zeros(self.n_slots, dtype=np.uint8)
         step_moves = np.where(moves >= 0, moves, -1).astype(np.int32)
-        winner, ended = eng.step(step_moves)
+        for lane in self.lanes:
+            with self._on(lane):
+                lane.eng.advance(moves[lane.slots])  # tree reuse, before the boards change
+                winner[lane.slots], ended[lane.slots] = lane.eng.step(step_moves[lane.slots])
         self.moves_done += len(running)
         done = []
         for s in running:
@@ -163,10 +231,22 @@ class BatchedSelfPlay(object):
                 self.slot_game[s] = -1
         return done
 
+    def retire_finished(self):
+        """reset_player(): discard the trees of idle slots (game.py:128) and mask them out."""
+        idle = np.full(self.n_slots, -2, dtype=np.int32)
+        idle[np.nonzero(self.slot_game < 0)[0]] = -1
+        for lane in self.lanes:
+            with self._on(lane):
+                lane.eng.advance(idle[lane.slots])
+        self._set_active()
+
+    def check(self):
+        return [lane.eng.check() for lane in self.lanes]
+
     def run(self, game_ids, max_moves=None):
         """Play all ``game_ids`` to the end; returns trajectories sorted by game id."""
         pending = list(game_ids)
-        G = self.eng.n_games
+        G = self.n_slots
         first = pending[:G]
         pending = pending[G:]
         self._start(range(len(first)), first)
@@ -183,14 +263,10 @@ class BatchedSelfPlay(object):
                 pending = pending[len(take):]
                 self._start(free[:len(take)], take)
             if done:
-                # reset_player(): the trees of finished games are discarded (game.py:128)
-                idle = np.full(G, -2, dtype=np.int32)
-                idle[np.nonzero(self.slot_game < 0)[0]] = -1
-                self.eng.advance(idle)
-                self._set_active()
+                self.retire_finished()
             if max_moves is not None and n_moves >= max_moves:
                 break
-        self.eng.check()
+        self.check()
         return sorted(out, key=lambda t: t.game_id)
 
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 5
+#define RZ_ABI_VERSION 6
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 
@@ -146,6 +146,15 @@ int rz_get_leaves(rz_engine *e, uint64_t *d_stones, int32_t *d_to_move, int32_t 
  * d_value float32 [n_games]; d_logp (nullable) float32 [n_games][B*B] = log(1/k) on
  * empty cells, -inf elsewhere. */
 int rz_eval_synthetic(rz_engine *e, int kind, float *d_logp, float *d_value, void *stream);
+
+/* Random-rollout evaluator of the pure-MCTS opponent: RolloutMCTS._evaluate
+ * (rlzero/mcts/rollout_mcts.py:49-74, rollout_policy :96-100) from every leaf, on bitboards.
+ * Move of ply p = the floor(u*k)-th legal move, u from splitmix64(seed, game, sim_index, p)
+ * (the reference draws k uniforms from numpy's global stream and takes the arg-max: also a
+ * uniform choice).  d_value float32 [n_games] follows the reference's perspective rule (:68-72).
+ * Pair with rz_expand_backup(e, NULL, d_value): uniform priors (rollout_mcts.py:102-108). */
+int rz_eval_rollout(rz_engine *e, uint64_t seed, uint32_t sim_index, int32_t n_limit, float *d_value,
+                    void *stream);
 
 /* EXPAND + BACKUP: terminal rule and value (alphazero_mcts.py:60-68), TreeNode.expand
  * (node.py:44-73; priors = exp(d_logp) on the leaf's legal moves as in

@@ -5,9 +5,10 @@ product raises.  Build it with ``python -m rlzero_amd._build``.
 """
 import ctypes
 import os
-from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_void_p)
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64,
+                    c_void_p)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
 
@@ -52,6 +53,7 @@ _SIGNATURES = {
     'rz_encode_root_obs': (c_int, [P, P, P]),
     'rz_get_leaves': (c_int, [P, P, P, P, P, P]),
     'rz_eval_synthetic': (c_int, [P, c_int, P, P, P]),
+    'rz_eval_rollout': (c_int, [P, c_uint64, c_uint32, c_int32, P, P]),
     'rz_expand_backup': (c_int, [P, P, P, P]),
     'rz_expand_backup_f64': (c_int, [P, P, P, P]),
     'rz_tree_step': (c_int, [P, P, P, P, P]),

@@ -465,6 +465,65 @@ __global__ __launch_bounds__(kWave) void k_eval_synth(Dev E, int kind, float *lo
     }
 }
 
+// ------------------------------------------------------------------ random rollouts
+// RolloutMCTS._evaluate (rlzero/mcts/rollout_mcts.py:49-74): from the leaf play uniformly random
+// legal moves (the reference takes the arg-max of k fresh uniforms, :99-100 = a uniform choice)
+// until the game ends or n_limit plies, then value = 0 on a tie / limit, else +1 if the winner
+// is the player to move AFTER the rollout else -1 (the reference's perspective quirk, :68-72:
+// the winner has just moved, so a decisive rollout always yields -1).  The move index of ply p
+// is floor(u * k) with u = the high 32 bits of splitmix64(seed, game, sim, ply) -- reproducible
+// on the host (rlzero_amd.mcts.rollout_mcts.rollout_pick) so parity tests can drive the oracle
+// with the very same choices.
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(kWave) void k_eval_rollout(Dev E, uint64_t seed, uint32_t sim, int n_limit,
+                                                        float *value) {
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (!E.active[g]) return;
+    const int S = E.S, B = E.B;
+    uint64_t st[2][kWords];
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) {
+        st[0][j] = E.leaf_stones[((long long)g * 2 + 0) * kWords + j];
+        st[1][j] = E.leaf_stones[((long long)g * 2 + 1) * kWords + j];
+    }
+    int to_move = E.leaf_to_move[g];
+    int nst = count_bits(st[0]) + count_bits(st[1]);
+    int term = E.leaf_term[g];  // 0 running, 1 tie, 2 won by the player who just moved
+    int winner = term == 2 ? (to_move ^ 1) : -1;
+    const uint64_t key = mix64(mix64(seed ^ (uint64_t)g) ^ (uint64_t)sim);
+    for (int ply = 0; ply < n_limit && term == 0; ++ply) {
+        const int k = S - nst;
+        const uint32_t u = (uint32_t)(mix64(key ^ (uint64_t)ply) >> 32);
+        const int r = (int)(((uint64_t)u * (uint64_t)k) >> 32);
+        uint64_t occ[kWords];
+#pragma unroll
+        for (int j = 0; j < kWords; ++j) occ[j] = st[0][j] | st[1][j];
+        const int a = nth_empty_cell(occ, E.valid, r, lane);
+        if (a < 0) {
+            flag(E, g, RZ_FLAG_INTERNAL, lane);
+            break;
+        }
+        if (to_move == 0) set_bit(st[0], a); else set_bit(st[1], a);
+        nst += 1;
+        if (line_through(to_move == 0 ? st[0] : st[1], a, B, E.n_row, lane)) {
+            term = 2;
+            winner = to_move;
+        } else if (nst == S) {
+            term = 1;
+        }
+        to_move ^= 1;
+    }
+    if (lane == 0) value[g] = (winner < 0) ? 0.0f : (winner == to_move ? 1.0f : -1.0f);
+}
+
 // ------------------------------------------------------------------ root read-out
 // what: 0 = visits (int32), 1 = W (double), 2 = prior (float)
 __global__ __launch_bounds__(kWave) void k_root_children(Dev E, int what, void *out) {
@@ -1034,6 +1093,15 @@ int rz_eval_synthetic(rz_engine *e, int kind, float *d_logp, float *d_value, voi
     if (kind != RZ_EVAL_V0 && kind != RZ_EVAL_VLIN) return fail(RZ_ERR_ARG, "unknown evaluator %d", kind);
     k_eval_synth<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, kind, d_logp, d_value);
     return launched("k_eval_synth");
+}
+
+int rz_eval_rollout(rz_engine *e, uint64_t seed, uint32_t sim_index, int32_t n_limit, float *d_value,
+                    void *stream) {
+    RZ_ENTER(e);
+    RZ_NEED(d_value);
+    if (n_limit < 0) return fail(RZ_ERR_ARG, "n_limit must be >= 0");
+    k_eval_rollout<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, seed, sim_index, n_limit, d_value);
+    return launched("k_eval_rollout");
 }
 
 int rz_expand_backup(rz_engine *e, const float *d_logp, const float *d_value, void *stream) {

@@ -38,6 +38,23 @@ class SyntheticEvaluator(object):
         return eng.logp, eng.value
 
 
+class RolloutEvaluator(object):
+    """Leaf value from a uniformly random play-out on the device (RolloutMCTS._evaluate,
+    rlzero/mcts/rollout_mcts.py:49-74); priors are uniform (None -> rz_expand_backup fills 1/k)."""
+    needs_obs = False
+
+    def __init__(self, seed=0, n_limit=1000):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.n_limit = int(n_limit)
+        self.sim_index = 0
+
+    def __call__(self, eng):
+        check(eng.lib.rz_eval_rollout(eng.handle, self.seed, self.sim_index & 0xFFFFFFFF, self.n_limit,
+                                      _ptr(eng.value), eng.stream()), 'rz_eval_rollout')
+        self.sim_index += 1
+        return None, eng.value
+
+
 class NetEvaluator(object):
     """Batched forward of a policy-value module on the leaf observations
     (AlphaZeroAgent.policy_value_fn, rlzero/games/gomoku/alphazero_agent.py:31-46, for the
@@ -154,8 +171,18 @@ class HipNetEvaluator(object):
         self.hip = HipNet(board_size, device, max_boards)
         self.refresh()
 
+    def _fingerprint(self):
+        # in-place optimiser steps bump Tensor._version; load_state_dict / .to() change data_ptr
+        return tuple((p.data_ptr(), p._version) for p in self.module.parameters())
+
     def refresh(self):
         self.hip.load_state_dict(self.module.state_dict())
+        self._seen = self._fingerprint()
+
+    def refresh_if_changed(self):
+        """Re-upload the weights if the torch module was trained / reloaded since the last upload."""
+        if self._fingerprint() != self._seen:
+            self.refresh()
 
     def __call__(self, eng):
         return self.hip.forward(eng.obs, eng.logp, eng.value)

@@ -16,7 +16,7 @@ import os
 
 import numpy as np
 
-from ..engine import HostEvaluator, MCTSEngine, NetEvaluator, bits_to_int, int_to_bits
+from ..engine import (HipNetEvaluator, HostEvaluator, MCTSEngine, NetEvaluator, bits_to_int, int_to_bits)
 from .player import Player
 
 
@@ -99,7 +99,11 @@ class AlphaZeroMCTS(object):
         eng = MCTSEngine(size, n_row, n_games=1, n_playout=self.n_playout, c_puct=self._c_puct,
                          device=device)
         if fast:
-            self._evaluator = NetEvaluator(net)
+            from ..games.gomoku.policy_value_net import PolicyValueNet
+            # the reference architecture runs on the hand-written fused kernels (csrc/rz_net.hip);
+            # any other nn.Module with the same call signature goes through PyTorch-ROCm
+            self._evaluator = HipNetEvaluator(net, size, eng.device, max_boards=1) \
+                if type(net) is PolicyValueNet else NetEvaluator(net)
         else:
             from ..games.gomoku.gomoku_env import GomokuEnv
             self._evaluator = HostEvaluator(
@@ -122,6 +126,8 @@ class AlphaZeroMCTS(object):
         """All ``n_playout`` simulations, then (actions, probabilities) of the root
         children: softmax(1/T * log(N + 1e-10)) (alphazero_mcts.py:73-94)."""
         eng = self._import_root(game_env)
+        if isinstance(self._evaluator, HipNetEvaluator):
+            self._evaluator.refresh_if_changed()  # the learner may have stepped since the last move
         eng.simulate(self._evaluator, self.n_playout)
         visits = eng.root_visits()[0]
         eng.check()

@@ -69,3 +69,8 @@ def bits_of_planes(obs):
         assert set(np.unique(flat)) <= {0.0, 1.0}
         out.append(hex(sum(1 << i for i, v in enumerate(flat) if v == 1.0)))
     return out
+
+
+@pytest.fixture(scope='session')
+def g6():
+    return load_golden_json('g6_rollout.json')

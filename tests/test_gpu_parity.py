@@ -408,7 +408,7 @@ def test_gpu_agent_fast_path_selfplay_game():
     """AlphaZeroAgent on the GPU -> the batched device evaluator is used; a whole self-play
     game runs through the reference API and satisfies the search invariants."""
     import torch
-    from rlzero_amd.engine import NetEvaluator
+    from rlzero_amd.engine import HipNetEvaluator
     from rlzero_amd.games import GameControl, GomokuEnv
     from rlzero_amd.games.gomoku.alphazero_agent import AlphaZeroAgent
     from rlzero_amd.mcts import AlphaZeroPlayer
@@ -419,7 +419,7 @@ def test_gpu_agent_fast_path_selfplay_game():
     env = GomokuEnv(6, 4)
     winner, data = GameControl(env).start_self_play(player, temperature=1.0)
     data = list(data)
-    assert isinstance(player.mcts._evaluator, NetEvaluator)
+    assert isinstance(player.mcts._evaluator, HipNetEvaluator)
     assert winner in (-1, 0, 1) and len(data) == len(env.states) >= 7
     for state, pi, z in data:
         assert abs(pi.sum() - 1.0) < 1e-9 and state.shape == (4, 6, 6)
@@ -432,7 +432,17 @@ def test_gpu_agent_fast_path_selfplay_game():
     rn, rw = mcts._engine.root_stats()
     with torch.no_grad():
         _, v = agent.policy_value_net(torch.from_numpy(env.current_state()[None]).float().to('cuda:0'))
-    assert int(rn[0]) == 1 and rw[0] == -float(v.item())
+    assert int(rn[0]) == 1 and abs(rw[0] + float(v.item())) <= 1e-5
+    # a training step changes the weights: the next search must see them
+    states = [s for s, _, _ in data][:8]
+    pis = [p for _, p, _ in data][:8]
+    agent.learn(states, pis, [1.0] * len(states))
+    mcts.update_with_move(-1)
+    mcts.simulate(env, 1.0)
+    _, rw2 = mcts._engine.root_stats()
+    with torch.no_grad():
+        _, v2 = agent.policy_value_net(torch.from_numpy(env.current_state()[None]).float().to('cuda:0'))
+    assert abs(rw2[0] + float(v2.item())) <= 1e-5 and abs(float(v2.item()) - float(v.item())) > 1e-6
     player.mcts._engine.close()
 
 
@@ -508,3 +518,66 @@ def test_search_with_hip_net_equals_search_with_its_values():
     s.simulate(RefGomoku(6, 4), 1.0)
     assert _hex_tree(eng.tree_dump(0)) == _hex_tree(tree_dump(s.root))
     eng.close()
+
+
+# ------------------------------------------------------------------ pure-MCTS opponent
+def _device_stream_rand(seed, search):
+    """rand(k) for the oracle that reproduces the device play-out's choices: a one-hot whose
+    arg-max is rollout_pick(seed, game 0, sim, ply, k)."""
+    from rlzero_amd.mcts.rollout_mcts import rollout_pick
+    state = {'sim': -1, 'ply': 0}
+
+    def rand(k):
+        if search.sim_index != state['sim']:
+            state['sim'], state['ply'] = search.sim_index, 0
+        out = np.zeros(k)
+        out[rollout_pick(seed, 0, state['sim'], state['ply'], k)] = 1.0
+        state['ply'] += 1
+        return out
+
+    return rand
+
+
+def test_rollout_search_vs_oracle():
+    """Device random play-outs (k_eval_rollout) + the shared tree == the oracle's RolloutMCTS
+    driven by the same per-(sim, ply) choices: identical trees and chosen moves."""
+    from oracle.rollout_ref import RefRolloutSearch
+    from rlzero_amd.games import GomokuEnv
+    from rlzero_amd.mcts.rollout_mcts import RolloutMCTS
+    for B, n, pre, sims, seed in ((3, 3, [], 60, 5), (3, 3, [4, 0, 2], 150, 6), (6, 4, [14, 15, 20, 21, 8], 200, 7),
+                                  (9, 5, [40, 41, 31], 120, 8), (15, 5, [112, 113], 100, 9),
+                                  (3, 3, [0, 1, 2, 4, 3, 5, 7], 30, 10)):
+        env = GomokuEnv(B, n)
+        env.reset()
+        for m in pre:
+            env.step(m)
+        mcts = RolloutMCTS(n_playout=sims, c_puct=5)
+        mcts.seed = seed
+        move = mcts.simulate(env)
+        ref = RefRolloutSearch(sims, 5)
+        ref.rand = _device_stream_rand(seed, ref)
+        want = ref.simulate(RefGomoku.from_moves(B, n, pre))
+        assert move == want
+        assert _hex_tree(mcts._engine.tree_dump(0)) == _hex_tree(tree_dump(ref.root))
+        mcts._engine.close()
+
+
+def test_rollout_player_game_through_reference_api():
+    """policy_evaluate's pairing (tools/train_alphazero.py:139-163): AlphaZeroPlayer vs
+    RolloutPlayer through GameControl.start_play runs to the end and is reproducible."""
+    from rlzero_amd.games import GameControl, GomokuEnv
+    from rlzero_amd.mcts import AlphaZeroPlayer
+    from rlzero_amd.mcts.rollout_mcts import RolloutPlayer
+    results = []
+    for _ in range(2):
+        np.random.seed(123)
+        env = GomokuEnv(6, 4)
+        az = AlphaZeroPlayer(ev.vlin, n_playout=60, c_puct=5)
+        pure = RolloutPlayer(n_playout=80, c_puct=5)
+        winner = GameControl(env).start_play(az, pure, start_player=0, is_shown=0)
+        results.append((winner, list(env.states.keys())))
+        assert winner in (-1, 0, 1) and env.game_end_winner()[0]
+        assert pure.mcts._root.explore_count == 0  # tree reset after every move
+        az.mcts._engine.close()
+        pure.mcts._engine.close()
+    assert results[0] == results[1]

@@ -224,11 +224,18 @@ def main():
     from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
     from rlzero_amd.selfplay import BatchedSelfPlay
 
+    # test hooks: run several ranks on ONE GPU with gloo (the multi-rank code path on a 1-GPU box)
+    if os.environ.get('RZ_BENCH_SINGLE_DEVICE') == '1':
+        local_rank = 0
+    backend = os.environ.get('RZ_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local_rank)
     device = 'cuda:%d' % local_rank
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device(device))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
 
     board, n_row = args.board, (N_ROW if args.board >= 5 else args.board)
     cells = board * board

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 6
+#define RZ_ABI_VERSION 7
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 
@@ -52,8 +52,9 @@ enum { RZ_GAME_GOMOKU = 0 }; /* TicTacToe = Gomoku(board_size 3, n_in_row 3), to
 enum {
     RZ_SCORE_UCT_REF = 0, /* the reference's rule: W/N + c*sqrt(ln(Np)/N), +inf if unvisited
                              (rlzero/mcts/node.py:41-42,75-88); bit-exact, fp64 */
-    RZ_SCORE_PUCT = 1     /* opt-in: Q + c*P*sqrt(Np)/(1+N) (node.py:105-117 is dead code in the
-                             reference and divides by zero at N=0; here Q=0 at N=0) */
+    RZ_SCORE_PUCT = 1     /* opt-in: Q + c*(P*sqrt(Np)/(N+1)) (node.py:105-117 is dead code in the
+                             reference and divides by zero at N=0; here Q=0 at N=0); fp64, every
+                             child initialised at expansion */
 };
 
 enum { RZ_EVAL_V0 = 0, RZ_EVAL_VLIN = 1 }; /* synthetic evaluators, SURVEY.md Appendix B */
@@ -78,13 +79,16 @@ typedef struct rz_config {
     int32_t n_playout;   /* simulations per move: sizes the arenas and the ln table
                             (AlphaZeroPlayer(n_playout=), alphazero_mcts.py:112-130) */
     int32_t score_mode;  /* RZ_SCORE_* */
-    int32_t add_noise;   /* reserved (Dirichlet noise only perturbs the stored prior, which
-                            RZ_SCORE_UCT_REF never reads; node.py:63-69) */
+    int32_t add_noise;   /* != 0: priors are mixed 0.75/0.25 with Dirichlet(0.3) noise at every expanded
+                            node (node.py:63-69; is_selfplay in alphazero_mcts.py:124-129).  Drawn on the
+                            device from a counter-based stream (noise_seed, game, expansion #): same
+                            distribution as numpy's, not its global stream.  RZ_SCORE_UCT_REF never reads
+                            the prior, so the noise cannot change its search. */
     double c_puct;       /* AlphaZeroPlayer(c_puct=) */
     double pool_factor;  /* arena slots per game = pool_factor*n_playout*B*B + B*B + 2;
                             0 -> 2.0 */
     int32_t device;      /* HIP device ordinal */
-    int32_t reserved;
+    int32_t noise_seed;  /* seed of the Dirichlet stream */
 } rz_config;
 
 typedef struct rz_stats {
@@ -164,6 +168,9 @@ int rz_eval_rollout(rz_engine *e, uint64_t seed, uint32_t sim_index, int32_t n_l
  * Python float exactly, alphazero_agent.py:45) or float64 for host evaluators. */
 int rz_expand_backup(rz_engine *e, const float *d_logp, const float *d_value, void *stream);
 int rz_expand_backup_f64(rz_engine *e, const float *d_logp, const double *d_value, void *stream);
+/* same, but d_probs float32 [n_games][B*B] holds the evaluator's probabilities themselves (a host
+ * policy_value_fn returns (action, prob) pairs, alphazero_mcts.py:28-31): stored unchanged. */
+int rz_expand_backup_probs(rz_engine *e, const float *d_probs, const double *d_value, void *stream);
 
 /* rz_expand_backup of the pending leaves followed by rz_select_step of the next simulation in
  * ONE launch (two consecutive iterations of the reference's loop, alphazero_mcts.py:82-85,

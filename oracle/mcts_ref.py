@@ -48,13 +48,23 @@ def uct_score(parent_n, child_n, child_w, c_puct):
     return q + c_puct * u
 
 
-def select_child(node, c_puct):
+def puct_score(parent_n, child_n, child_w, child_p, c_puct):
+    """node.py:105-117 (dead code in the reference) with Q = 0 at N = 0 instead of its division
+    by zero: exploration_score + c_puct * (prior * sqrt(parent N) / (N + 1)).  The opt-in
+    RZ_SCORE_PUCT mode of the engine; parity for it is pinned by this restatement only."""
+    q = child_w / child_n if child_n > 0 else 0.0
+    u = float(child_p) * math.sqrt(parent_n) / (child_n + 1)
+    return q + c_puct * u
+
+
+def select_child(node, c_puct, score_mode='uct_ref'):
     """node.py:32-42 -- Python max(): the first maximal child wins."""
     if not node.kids:
         raise ValueError('Node has no children.')
     best_i, best_s = 0, None
     for i, kid in enumerate(node.kids):
-        s = uct_score(node.n, kid.n, kid.w, c_puct)
+        s = uct_score(node.n, kid.n, kid.w, c_puct) if score_mode == 'uct_ref' else \
+            puct_score(node.n, kid.n, kid.w, kid.p, c_puct)
         if best_s is None or s > best_s:
             best_i, best_s = i, s
     return node.acts[best_i], node.kids[best_i]
@@ -88,7 +98,8 @@ def softmax(x):
 class RefSearch(object):
     """alphazero_mcts.py:17-103."""
 
-    def __init__(self, policy_value_fn, n_playout=1000, c_puct=5):
+    def __init__(self, policy_value_fn, n_playout=1000, c_puct=5, score_mode='uct_ref'):
+        self.score_mode = score_mode
         self.root = RefNode(None, 1.0)
         self.policy_value_fn = policy_value_fn
         self.n_playout = n_playout
@@ -100,7 +111,7 @@ class RefSearch(object):
         node = self.root
         path = []
         while node.kids:
-            action, node = select_child(node, self.c_puct)
+            action, node = select_child(node, self.c_puct, self.score_mode)
             env.step(action)
             path.append(action)
         action_priors, leaf_value = self.policy_value_fn(env)  # always called (:59)

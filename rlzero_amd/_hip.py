@@ -8,7 +8,7 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64,
                     c_void_p)
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
 
@@ -23,7 +23,7 @@ class RzConfig(Structure):
     _fields_ = [('abi_version', c_int32), ('game_kind', c_int32), ('board_size', c_int32),
                 ('n_in_row', c_int32), ('n_games', c_int32), ('n_playout', c_int32),
                 ('score_mode', c_int32), ('add_noise', c_int32), ('c_puct', c_double),
-                ('pool_factor', c_double), ('device', c_int32), ('reserved', c_int32)]
+                ('pool_factor', c_double), ('device', c_int32), ('noise_seed', c_int32)]
 
 
 class RzStats(Structure):
@@ -56,6 +56,7 @@ _SIGNATURES = {
     'rz_eval_rollout': (c_int, [P, c_uint64, c_uint32, c_int32, P, P]),
     'rz_expand_backup': (c_int, [P, P, P, P]),
     'rz_expand_backup_f64': (c_int, [P, P, P, P]),
+    'rz_expand_backup_probs': (c_int, [P, P, P, P]),
     'rz_tree_step': (c_int, [P, P, P, P, P]),
     'rz_root_visits': (c_int, [P, P, P]),
     'rz_root_wsum': (c_int, [P, P, P]),

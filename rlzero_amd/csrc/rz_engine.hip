@@ -64,6 +64,9 @@ struct Dev {
     int32_t *queue;
     int32_t *err, *err_any;
     const double *logtab;
+    int32_t *noise_ctr;
+    uint64_t noise_seed;
+    int add_noise;
     uint64_t valid[kWords];
 };
 
@@ -196,6 +199,46 @@ __device__ __forceinline__ double uct_ref(double w, int n, double ln_parent, dou
     return q + cu;
 }
 
+// Opt-in PUCT (node.py:105-117 with Q = 0 at N = 0 instead of the reference's division by zero):
+// exploration_score + c_puct * (prior * sqrt(parent N) / (N + 1)), evaluated in this order in fp64.
+__device__ __forceinline__ double puct(double w, int n, float prior, double sqrt_parent, double c) {
+    const double q = n > 0 ? w / (double)n : 0.0;
+    const double u = ((double)prior * sqrt_parent) / (double)(n + 1);
+    const double cu = c * u;
+    return q + cu;
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// One Gamma(0.3, 1) sample (the marginal of numpy's dirichlet(0.3 * ones(k)), node.py:65) from a
+// counter-based stream: Marsaglia-Tsang for shape 1.3, boosted by U^(1/0.3).
+__device__ __forceinline__ float gamma03(uint64_t key) {
+    const float d = 1.3f - 1.0f / 3.0f, c = 0.33903103f;  // 1 / sqrt(9 d)
+    float g = d;
+    for (int t = 0; t < 8; ++t) {
+        const uint64_t h1 = mix64(key + 3ull * t), h2 = mix64(key + 3ull * t + 1), h3 = mix64(key + 3ull * t + 2);
+        const float u1 = (float)((h1 >> 40) + 1ull) * (1.0f / 16777216.0f);
+        const float u2 = (float)(h2 >> 40) * (1.0f / 16777216.0f);
+        const float u3 = (float)((h3 >> 40) + 1ull) * (1.0f / 16777216.0f);
+        const float x = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);
+        float v = 1.0f + c * x;
+        if (v <= 0.0f) continue;
+        v = v * v * v;
+        if (logf(u3) < 0.5f * x * x + d - d * v + d * logf(v)) {
+            g = d * v;
+            break;
+        }
+    }
+    const float ub = (float)((mix64(key + 31ull) >> 40) + 1ull) * (1.0f / 16777216.0f);
+    return g * powf(ub, 1.0f / 0.3f);
+}
+
 // ------------------------------------------------------------------ SELECT + STEP
 __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int lane) {
     if (!E.active[g]) return;
@@ -205,6 +248,8 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
     double *W = E.W + base;
     int32_t *FC = E.FC + base;
     int32_t *NV = E.NV + base;
+    const float *P = E.P + base;
+    const bool use_puct = E.score_mode == RZ_SCORE_PUCT;
 
     uint64_t st[2][kWords];
 #pragma unroll
@@ -226,7 +271,33 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
         const int k = S - nst;
         const int nv = NV[node];
         int r;
-        if (nv < k) {
+        if (use_puct) {
+            // every child was initialised at expansion (N = 0, W = 0, prior): scan all k
+            const double sq = sqrt((double)N[node]);
+            double best = -INFINITY;
+            int besti = 0x7fffffff;
+            for (int r0 = lane; r0 < k; r0 += kWave) {
+                const double sc = puct(W[fc + r0], N[fc + r0], P[fc + r0], sq, E.c_puct);
+                if (sc > best) {
+                    best = sc;
+                    besti = r0;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double ob = __shfl_xor(best, off);
+                const int oi = __shfl_xor(besti, off);
+                if (ob > best || (ob == best && oi < besti)) {
+                    best = ob;
+                    besti = oi;
+                }
+            }
+            r = besti;
+            if (r >= k) {
+                flag(E, g, RZ_FLAG_INTERNAL, lane);
+                break;
+            }
+        } else if (nv < k) {
             // some child still has N == 0 -> score +inf, first such child wins
             r = nv;
             fresh = 1;
@@ -319,7 +390,9 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
 }
 
 // ------------------------------------------------------------------ EXPAND + BACKUP
-template <typename VT>
+// PROBS: `logp` already holds probabilities (host evaluators hand over the callable's exact
+// numbers); otherwise log-probabilities from the network (prior = exp, alphazero_agent.py:44).
+template <typename VT, bool PROBS = false>
 __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *logp, const VT *value, int g,
                                                    int lane) {
     if (!E.active[g]) return;
@@ -354,15 +427,36 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
                 NV[leaf] = 0;
             }
         } else {
+            const bool dense = E.score_mode == RZ_SCORE_PUCT;
             if (lane == 0) {
                 FC[leaf] = top;
-                NV[leaf] = 0;
+                NV[leaf] = dense ? k : 0;  // PUCT: all k children are initialised below
                 E.top[g] = top + k;
                 E.nblk[g] = nblk + 1;
             }
-            // TreeNode.expand: one child per legal move, prior from the policy head
+            // TreeNode.expand: one child per legal move, prior from the policy head; in self-play
+            // mixed with Dirichlet(0.3) noise at EVERY expanded node (node.py:63-69)
             const float uniform = 1.0f / (float)k;
             const uint64_t below = (1ull << lane) - 1ull;
+            float noise[kWords] = {0.f, 0.f, 0.f, 0.f};
+            float noise_sum = 1.0f;
+            if (E.add_noise) {
+                const int ctr = E.noise_ctr[g];
+                const uint64_t key = mix64(mix64(E.noise_seed ^ ((uint64_t)g << 20)) ^ (uint64_t)ctr);
+                float local = 0.0f;
+#pragma unroll
+                for (int j = 0; j < kWords; ++j) {
+                    const uint64_t e = ~occ[j] & E.valid[j];
+                    if ((e >> lane) & 1ull) {
+                        noise[j] = gamma03(mix64(key ^ (uint64_t)(64 * j + lane)) );
+                        local += noise[j];
+                    }
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) local += __shfl_xor(local, off);
+                noise_sum = local > 0.0f ? local : 1.0f;
+                if (lane == 0) E.noise_ctr[g] = ctr + 1;
+            }
             int before = 0;
 #pragma unroll
             for (int j = 0; j < kWords; ++j) {
@@ -370,7 +464,16 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
                 if ((e >> lane) & 1ull) {
                     const int r = before + __popcll(e & below);
                     const int c = 64 * j + lane;
-                    P[top + r] = logp ? expf(logp[(long long)g * S + c]) : uniform;
+                    float prior = uniform;
+                    if (logp) prior = PROBS ? logp[(long long)g * S + c] : expf(logp[(long long)g * S + c]);
+                    if (E.add_noise) prior = 0.75f * prior + 0.25f * (noise[j] / noise_sum);
+                    P[top + r] = prior;
+                    if (dense) {
+                        N[top + r] = 0;
+                        W[top + r] = 0.0;
+                        FC[top + r] = -1;
+                        NV[top + r] = 0;
+                    }
                 }
                 before += __popcll(e);
             }
@@ -400,10 +503,10 @@ __global__ __launch_bounds__(kWave) void k_select(Dev E, float *obs) {
     select_body(E, obs, blockIdx.x, threadIdx.x);
 }
 
-template <typename VT>
+template <typename VT, bool PROBS = false>
 __global__ __launch_bounds__(kWave) void k_expand_backup(Dev E, const float *logp, const VT *value) {
     __builtin_amdgcn_s_setprio(3);
-    expand_backup_body<VT>(E, logp, value, blockIdx.x, threadIdx.x);
+    expand_backup_body<VT, PROBS>(E, logp, value, blockIdx.x, threadIdx.x);
 }
 
 // EXPAND + BACKUP of simulation s and SELECT + STEP of simulation s+1 in one launch (same
@@ -474,14 +577,6 @@ __global__ __launch_bounds__(kWave) void k_eval_synth(Dev E, int kind, float *lo
 // is floor(u * k) with u = the high 32 bits of splitmix64(seed, game, sim, ply) -- reproducible
 // on the host (rlzero_amd.mcts.rollout_mcts.rollout_pick) so parity tests can drive the oracle
 // with the very same choices.
-__device__ __forceinline__ uint64_t mix64(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ull;
-    uint64_t z = x;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
 __global__ __launch_bounds__(kWave) void k_eval_rollout(Dev E, uint64_t seed, uint32_t sim, int n_limit,
                                                         float *value) {
     const int g = blockIdx.x;
@@ -885,8 +980,8 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
         return fail(RZ_ERR_ARG, "n_in_row %d not in 1..board_size", cfg->n_in_row);
     if (cfg->n_games < 1) return fail(RZ_ERR_ARG, "n_games must be >= 1");
     if (cfg->n_playout < 1) return fail(RZ_ERR_ARG, "n_playout must be >= 1");
-    if (cfg->score_mode != RZ_SCORE_UCT_REF)
-        return fail(RZ_ERR_ARG, "score_mode %d is not available in this build", cfg->score_mode);
+    if (cfg->score_mode != RZ_SCORE_UCT_REF && cfg->score_mode != RZ_SCORE_PUCT)
+        return fail(RZ_ERR_ARG, "unknown score_mode %d", cfg->score_mode);
     if (!(cfg->c_puct >= 0.0)) return fail(RZ_ERR_ARG, "c_puct must be >= 0");
     int n_dev = 0;
     RZ_HIP(hipGetDeviceCount(&n_dev));
@@ -906,6 +1001,8 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     D.n_row = cfg->n_in_row;
     D.n_games = cfg->n_games;
     D.score_mode = cfg->score_mode;
+    D.add_noise = cfg->add_noise ? 1 : 0;
+    D.noise_seed = (uint64_t)(uint32_t)cfg->noise_seed;
     D.c_puct = cfg->c_puct;
     D.cap = (long long)(pf * (double)cfg->n_playout * (double)S) + S + 2;
     D.qcap = (int)(pf * (double)cfg->n_playout) + 8;
@@ -944,6 +1041,7 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     RZ_ALLOC(queue, G * D.qcap * 4);
     RZ_ALLOC(err, G);
     RZ_ALLOC(err_any, 1);
+    RZ_ALLOC(noise_ctr, G);
     if (rc == RZ_OK) rc = dev_alloc(e, &e->d_logtab, D.logtab_n);
 #undef RZ_ALLOC
     if (rc != RZ_OK) {
@@ -959,7 +1057,7 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     zero(D.leaf_node, G * 4); zero(D.leaf_depth, G * 4); zero(D.leaf_fresh, G * 4);
     zero(D.leaf_term, G * 4); zero(D.leaf_tval, G * 8); zero(D.leaf_stones, G * 2 * kWords * 8);
     zero(D.leaf_to_move, G * 4); zero(D.path, G * D.path_stride * 4);
-    zero(D.err, G * 4); zero(D.err_any, 4);
+    zero(D.err, G * 4); zero(D.err_any, 4); zero(D.noise_ctr, G * 4);
     if (herr == hipSuccess) herr = hipMemset(D.root_last, 0xff, G * 4);  // -1
     if (herr == hipSuccess) herr = hipMemset(D.leaf_last, 0xff, G * 4);
     if (herr == hipSuccess) herr = hipMemset(D.active, 1, G);
@@ -1124,6 +1222,13 @@ int rz_tree_step(rz_engine *e, const float *d_logp, const float *d_value, float 
     e->n_select += 1;
     k_tree_step<float><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_logp, d_value, d_obs);
     return launched("k_tree_step");
+}
+
+int rz_expand_backup_probs(rz_engine *e, const float *d_probs, const double *d_value, void *stream) {
+    RZ_ENTER(e);
+    RZ_NEED(d_value);
+    k_expand_backup<double, true><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_probs, d_value);
+    return launched("k_expand_backup");
 }
 
 int rz_root_visits(rz_engine *e, int32_t *d_visits, void *stream) {

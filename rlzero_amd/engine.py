@@ -193,6 +193,7 @@ class HostEvaluator(object):
     (alphazero_mcts.py:28-31,59), called once per leaf on a materialised env object.
     Slow (one device round trip per simulation) but exact for arbitrary evaluators."""
     needs_obs = False
+    returns_probs = True  # the callable's probabilities are stored unchanged (TreeNode.prior)
 
     def __init__(self, fn, make_env):
         self.fn = fn
@@ -204,7 +205,7 @@ class HostEvaluator(object):
         stones, to_move, last, term = eng.get_leaves()
         active = eng.active_host
         values = np.zeros(eng.n_games, dtype=np.float64)
-        logp = np.full((eng.n_games, eng.n_cells), -np.inf, dtype=np.float32)
+        probs = np.zeros((eng.n_games, eng.n_cells), dtype=np.float32)
         for g in range(eng.n_games):
             if not active[g]:
                 continue
@@ -213,11 +214,11 @@ class HostEvaluator(object):
             priors, value = self.fn(env)  # called on terminal leaves too (:59)
             values[g] = value
             for a, p in priors:
-                logp[g, int(a)] = np.log(np.float32(p)) if p > 0 else -np.inf
+                probs[g, int(a)] = p
             if self.log is not None:
                 self.log.append((g, float(value)))
         eng.value64.copy_(torch.from_numpy(values))
-        eng.logp.copy_(torch.from_numpy(logp))
+        eng.logp.copy_(torch.from_numpy(probs))
         return eng.logp, eng.value64
 
 
@@ -236,7 +237,7 @@ class MCTSEngine(object):
     """``n_games`` independent trees searched in lock-step on one GPU."""
 
     def __init__(self, board_size, n_in_row, n_games=1, n_playout=1000, c_puct=5.0,
-                 device='cuda:0', pool_factor=2.0):
+                 device='cuda:0', pool_factor=2.0, score_mode='uct_ref', add_noise=False, noise_seed=0):
         import torch
         self.lib = _hip.load()
         self.torch = torch
@@ -248,10 +249,14 @@ class MCTSEngine(object):
         self.board_size, self.n_in_row = int(board_size), int(n_in_row)
         self.n_cells = self.board_size ** 2
         self.n_games, self.n_playout, self.c_puct = int(n_games), int(n_playout), float(c_puct)
+        self.score_mode = {'uct_ref': _hip.SCORE_UCT_REF, 'puct': _hip.SCORE_PUCT}[score_mode] \
+            if isinstance(score_mode, str) else int(score_mode)
+        self.add_noise = bool(add_noise)
         cfg = _hip.RzConfig(abi_version=_hip.ABI_VERSION, game_kind=0, board_size=self.board_size,
                             n_in_row=self.n_in_row, n_games=self.n_games, n_playout=self.n_playout,
-                            score_mode=_hip.SCORE_UCT_REF, add_noise=0, c_puct=self.c_puct,
-                            pool_factor=float(pool_factor), device=self.device.index, reserved=0)
+                            score_mode=self.score_mode, add_noise=1 if add_noise else 0, c_puct=self.c_puct,
+                            pool_factor=float(pool_factor), device=self.device.index,
+                            noise_seed=int(noise_seed) & 0x7FFFFFFF)
         handle = ctypes.c_void_p()
         check(self.lib.rz_create(ctypes.byref(cfg), ctypes.byref(handle)), 'rz_create')
         self.handle = handle
@@ -358,7 +363,10 @@ class MCTSEngine(object):
         obs = _ptr(self.obs) if getattr(evaluator, 'needs_obs', True) else None
         check(self.lib.rz_select_step(self.handle, obs, self.stream()), 'rz_select_step')
         logp, value = evaluator(self)
-        if value.dtype == self.torch.float64:
+        if getattr(evaluator, 'returns_probs', False):
+            check(self.lib.rz_expand_backup_probs(self.handle, _ptr(logp), _ptr(value), self.stream()),
+                  'rz_expand_backup_probs')
+        elif value.dtype == self.torch.float64:
             check(self.lib.rz_expand_backup_f64(self.handle, _ptr(logp), _ptr(value), self.stream()),
                   'rz_expand_backup_f64')
         else:
@@ -489,8 +497,9 @@ class MCTSEngine(object):
                 continue
             empties = [c for c in range(self.n_cells) if not (occ >> c) & 1]
             for r in range(int(ar['NV'][slot])):
-                a = empties[r]
-                stack.append((path + (a, ), fc + r, occ | (1 << a)))
+                if int(ar['N'][fc + r]) > 0:  # PUCT initialises every child; only visited ones count
+                    a = empties[r]
+                    stack.append((path + (a, ), fc + r, occ | (1 << a)))
         return out
 
     def uct_scores(self, w, n, n_parent, c_puct):

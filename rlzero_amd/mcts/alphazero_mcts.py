@@ -69,11 +69,12 @@ class AlphaZeroMCTS(object):
     """Monte Carlo tree search guided by a policy-value function."""
 
     def __init__(self, policy_value_fn, n_playout: int = 1000, c_puct: float = 5,
-                 add_noise: bool = False, device=None) -> None:
+                 add_noise: bool = False, device=None, score_mode: str = 'uct_ref') -> None:
+        self.score_mode = score_mode  # 'uct_ref' = the reference's rule (parity); 'puct' = opt-in
         self.policy_value_fn = policy_value_fn
         self.n_playout = n_playout
         self._c_puct = c_puct
-        self.add_noise = add_noise  # see DESIGN.md: the prior (and its noise) is never read by UCT
+        self.add_noise = add_noise  # Dirichlet noise on the stored priors (never read by 'uct_ref')
         self._device = device
         self._engine = None
         self._evaluator = None
@@ -97,7 +98,8 @@ class AlphaZeroMCTS(object):
             getattr(self.policy_value_fn, '__func__', None) is getattr(type(agent), 'policy_value_fn', None)
         device = self._device or (agent_dev if fast else os.environ.get('RLZERO_DEVICE', 'cuda:0'))
         eng = MCTSEngine(size, n_row, n_games=1, n_playout=self.n_playout, c_puct=self._c_puct,
-                         device=device)
+                         device=device, score_mode=self.score_mode, add_noise=self.add_noise,
+                         noise_seed=int(np.random.randint(0, 2 ** 31 - 1)) if self.add_noise else 0)
         if fast:
             from ..games.gomoku.policy_value_net import PolicyValueNet
             # the reference architecture runs on the hand-written fused kernels (csrc/rz_net.hip);
@@ -174,12 +176,12 @@ class AlphaZeroPlayer(Player):
 
     def __init__(self, policy_value_fn, n_playout: int = 1000, c_puct: float = 5,
                  is_selfplay: bool = False, player_id: int = 0, player_name: str = '',
-                 device=None) -> None:
+                 device=None, score_mode: str = 'uct_ref') -> None:
         super().__init__(player_id, player_name)
         self.is_selfplay = is_selfplay
         self.add_noise = is_selfplay
         self.mcts = AlphaZeroMCTS(policy_value_fn, n_playout=n_playout, c_puct=c_puct,
-                                  add_noise=self.add_noise, device=device)
+                                  add_noise=self.add_noise, device=device, score_mode=score_mode)
 
     def reset_player(self):
         self.mcts.update_with_move(-1)

@@ -581,3 +581,81 @@ def test_rollout_player_game_through_reference_api():
         az.mcts._engine.close()
         pure.mcts._engine.close()
     assert results[0] == results[1]
+
+
+# ------------------------------------------------------------------ opt-in PUCT mode, noise
+def _skewed(env):
+    """Evaluator with non-uniform float32 priors (exactly the numbers the engine stores) and the
+    vlin value."""
+    legal = env.leagel_actions()
+    raw = np.array([1 + (7 * a + 3) % 5 for a in legal], dtype=np.float32)
+    probs = raw / np.float32(raw.sum())
+    return list(zip(legal, probs)), ev.vlin_value(env.states, env.current_player())
+
+
+def test_puct_mode_vs_oracle():
+    """RZ_SCORE_PUCT (every child initialised, prior-weighted exploration, fp64, first maximum)
+    against the oracle's restatement of node.py:105-117; tree reuse included."""
+    from rlzero_amd.engine import HostEvaluator
+    for B, n, pre, sims, c in ((3, 3, [], 80, 5.0), (6, 4, [14, 15, 20], 300, 5.0), (6, 4, [], 250, 1.5),
+                               (9, 5, [40, 41, 31, 49], 300, 3.0)):
+        env = RefGomoku.from_moves(B, n, pre)
+        eng = _engine(B, n, n_games=1, n_playout=sims, c_puct=c, score_mode='puct')
+        _set_roots(eng, [env], reset_trees=True)
+        host = HostEvaluator(_skewed, lambda s0, s1, tm, last, B=B, n=n: _make_env(B, n, s0, s1, tm, last))
+        eng.simulate(host, sims)
+        eng.check()
+        s = RefSearch(_skewed, sims, c, score_mode='puct')
+        acts, _ = s.simulate(env, 1.0)
+        visits, wsum, pri = eng.root_visits()[0], eng.root_wsum()[0], eng.root_priors()[0]
+        assert [int(visits[a]) for a in acts] == [k.n for k in s.root.kids]
+        assert [float(wsum[a]).hex() for a in acts] == [float(k.w).hex() for k in s.root.kids]
+        assert [float(pri[a]) for a in acts] == [float(k.p) for k in s.root.kids]
+        assert _hex_tree(eng.tree_dump(0)) == _hex_tree(tree_dump(s.root))
+        assert max(k.n for k in s.root.kids) > 2 * min(k.n for k in s.root.kids)  # priors matter here
+        # keep the most visited child's subtree and search again (update_with_move)
+        best = acts[int(np.argmax([k.n for k in s.root.kids]))]
+        eng.advance([best])
+        eng.step([best])
+        s.update_with_move(best)
+        env.step(best)
+        if not env.game_end_winner()[0]:
+            eng.simulate(host, sims)
+            s.simulate(env, 1.0)
+            assert _hex_tree(eng.tree_dump(0)) == _hex_tree(tree_dump(s.root))
+        eng.check()
+        eng.close()
+
+
+def test_dirichlet_noise_on_priors():
+    """add_noise: stored prior = 0.75 p + 0.25 eta, eta ~ Dirichlet(0.3) over the legal moves
+    (node.py:63-69).  The device stream is not numpy's: check the distribution's moments, that it
+    sums to one, is reproducible for a seed, and that UCT_REF search results do not depend on it."""
+    from rlzero_amd.engine import SyntheticEvaluator
+    G, sims = 256, 30
+    eng = _engine(9, 5, n_games=G, n_playout=sims, add_noise=True, noise_seed=11)
+    eng.reset_games()
+    eng.simulate(SyntheticEvaluator('v0'), sims)
+    pri = eng.root_priors().astype(np.float64)
+    vis = eng.root_visits()
+    eng.check()
+    k = 81
+    eta = (pri - 0.75 / k) / 0.25
+    assert np.allclose(pri.sum(1), 1.0, atol=1e-5) and (eta > -1e-6).all()
+    assert abs(eta.mean() - 1.0 / k) < 1e-6
+    want_var = (1.0 / k) * (1 - 1.0 / k) / (0.3 * k + 1)  # Dirichlet(alpha) marginal variance
+    assert 0.8 * want_var < eta.var() < 1.25 * want_var
+    # sparse like Dirichlet(0.3): most of the mass sits on few moves
+    top = np.sort(eta, axis=1)[:, -8:].sum(1).mean()
+    assert 0.35 < top < 0.75
+    eng2 = _engine(9, 5, n_games=G, n_playout=sims, add_noise=True, noise_seed=11)
+    eng2.reset_games()
+    eng2.simulate(SyntheticEvaluator('v0'), sims)
+    assert np.array_equal(eng2.root_priors(), eng.root_priors())
+    eng3 = _engine(9, 5, n_games=G, n_playout=sims)
+    eng3.reset_games()
+    eng3.simulate(SyntheticEvaluator('v0'), sims)
+    assert np.array_equal(eng3.root_visits(), vis)  # the reference's selection never reads the prior
+    assert not np.array_equal(eng3.root_priors(), eng.root_priors())
+    for e in (eng, eng2, eng3):
+        e.close()

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 7
+#define RZ_ABI_VERSION 9
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 
@@ -47,7 +47,13 @@ enum {
     RZ_ERR_INTERNAL = -6
 };
 
-enum { RZ_GAME_GOMOKU = 0 }; /* TicTacToe = Gomoku(board_size 3, n_in_row 3), tools/play.py:35 */
+enum {
+    RZ_GAME_GOMOKU = 0,  /* TicTacToe = Gomoku(board_size 3, n_in_row 3), tools/play.py:35; action = cell */
+    RZ_GAME_CONNECT4 = 1 /* no implementation in the reference (docs/open-spiel_alphazero.md:58 only names
+                            it): build-defined.  board_height x board_width (default 6 x 7), n_in_row
+                            (default 4), action = column, stones drop to the lowest empty cell, cell =
+                            row*width + column with row 0 at the bottom; same planes / search / API */
+};
 
 enum {
     RZ_SCORE_UCT_REF = 0, /* the reference's rule: W/N + c*sqrt(ln(Np)/N), +inf if unvisited
@@ -89,6 +95,8 @@ typedef struct rz_config {
                             0 -> 2.0 */
     int32_t device;      /* HIP device ordinal */
     int32_t noise_seed;  /* seed of the Dirichlet stream */
+    int32_t board_height; /* RZ_GAME_CONNECT4 only (0 -> 6) */
+    int32_t board_width;  /* RZ_GAME_CONNECT4 only (0 -> 7) */
 } rz_config;
 
 typedef struct rz_stats {
@@ -107,6 +115,9 @@ const char *rz_last_error(void);
 /* Lifetime.  rz_create allocates every buffer up front (nothing is allocated later). */
 int rz_create(const rz_config *cfg, rz_engine **out);
 int rz_destroy(rz_engine *e);
+/* Board rows, columns and size A of the action space (Gomoku: A = cells; Connect4: A = columns).
+ * Every per-action array of this ABI (d_logp, d_probs, d_visits, d_w, d_p) is [n_games][A]. */
+int rz_geometry(rz_engine *e, int32_t *height, int32_t *width, int32_t *n_actions);
 
 /* ln(n) table for n = 0 .. count-1 (entry 0 unused).  The engine fills it at creation
  * with the host libm's log(), the function CPython's math.log() calls in
@@ -221,14 +232,16 @@ int rz_uct_scores(rz_engine *e, const double *d_w, const int32_t *d_n, const int
  * order (conv1.weight, conv1.bias, conv2.*, conv3.*, act_conv1.*, act_fc1.*, val_conv1.*,
  * val_fc1.*, val_fc2.*; policy_value_net.py:12-25), fp32, contiguous, torch layout.
  * rz_net_reserve sizes the internal feature buffer (the launch path never allocates).
- * rz_net_forward: d_obs float32 [n][4][B][B] -> d_logp [n][B*B] (log-probabilities),
+ * The board is height x width (<= 16 x 16) and the policy head has n_actions outputs (Gomoku:
+ * height = width = B, n_actions = B*B; Connect4: 6 x 7, 7).
+ * rz_net_forward: d_obs float32 [n][4][H][W] -> d_logp [n][n_actions] (log-probabilities),
  * d_value [n].  rz_net_trunk exposes the first kernel alone: d_feat [n][6][B*B] = ReLU'd
  * outputs of act_conv1 (4 planes) and val_conv1 (2 planes); d_feat == NULL writes the
  * internal buffer that rz_net_heads (the FC layers + log_softmax + tanh) reads, so
  * rz_net_trunk(.., NULL, ..) + rz_net_heads == rz_net_forward (lets a caller time the
  * dominant kernel by itself). */
 typedef struct rz_net rz_net;
-int rz_net_create(int32_t board_size, int32_t device, rz_net **out);
+int rz_net_create(int32_t height, int32_t width, int32_t n_actions, int32_t device, rz_net **out);
 int rz_net_destroy(rz_net *net);
 int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params);
 int rz_net_reserve(rz_net *net, int32_t max_boards);

@@ -162,7 +162,7 @@ class RefPlayer(object):
         self.mcts.update_with_move(-1)
 
     def get_action(self, env, temperature=1e-3, return_prob=False):
-        size = env.board_size * env.board_size
+        size = getattr(env, 'n_actions', None) or env.board_size * env.board_size
         move_probs = np.zeros(size)
         if not env.leagel_actions():
             print('WARNING: the board is full')

@@ -8,12 +8,13 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64,
                     c_void_p)
 
-ABI_VERSION = 7
+ABI_VERSION = 9
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
 
 OK = 0
 SCORE_UCT_REF, SCORE_PUCT = 0, 1
+GAME_GOMOKU, GAME_CONNECT4 = 0, 1
 EVAL_V0, EVAL_VLIN = 0, 1
 FLAG_NAMES = {1: 'arena full', 2: 'block queue full', 4: 'illegal move', 8: 'ln table too short',
               16: 'internal'}
@@ -23,7 +24,8 @@ class RzConfig(Structure):
     _fields_ = [('abi_version', c_int32), ('game_kind', c_int32), ('board_size', c_int32),
                 ('n_in_row', c_int32), ('n_games', c_int32), ('n_playout', c_int32),
                 ('score_mode', c_int32), ('add_noise', c_int32), ('c_puct', c_double),
-                ('pool_factor', c_double), ('device', c_int32), ('noise_seed', c_int32)]
+                ('pool_factor', c_double), ('device', c_int32), ('noise_seed', c_int32),
+                ('board_height', c_int32), ('board_width', c_int32)]
 
 
 class RzStats(Structure):
@@ -43,6 +45,7 @@ _SIGNATURES = {
     'rz_last_error': (c_char_p, []),
     'rz_create': (c_int, [POINTER(RzConfig), POINTER(c_void_p)]),
     'rz_destroy': (c_int, [P]),
+    'rz_geometry': (c_int, [P, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
     'rz_upload_log_table': (c_int, [P, P, c_int64]),
     'rz_log_table_size': (c_int, [P, POINTER(c_int64)]),
     'rz_set_roots': (c_int, [P, P, P, P, P, c_int, P]),
@@ -68,7 +71,7 @@ _SIGNATURES = {
     'rz_clear_errors': (c_int, [P]),
     'rz_copy_arena': (c_int, [P, c_int32, c_int64, P, P, P, P, P, P]),
     'rz_uct_scores': (c_int, [P, P, P, P, c_double, P, c_int64, P]),
-    'rz_net_create': (c_int, [c_int32, c_int32, POINTER(c_void_p)]),
+    'rz_net_create': (c_int, [c_int32, c_int32, c_int32, c_int32, POINTER(c_void_p)]),
     'rz_net_destroy': (c_int, [P]),
     'rz_net_load': (c_int, [P, POINTER(c_void_p), c_int32]),
     'rz_net_reserve': (c_int, [P, c_int32]),

@@ -6,6 +6,6 @@ code).  The batched, multi-GPU self-play collector that replaces its sequential
 ``collect_selfplay_data`` loop is ``rlzero_amd.selfplay``; it is re-exported here under the
 name BASELINE.json uses.
 """
-from ..selfplay import BatchedSelfPlay, Trajectory, gather_trajectories, shard_game_ids
+from ..selfplay import (BatchedSelfPlay, Trajectory, broadcast_weights, gather_trajectories, shard_game_ids)
 
-__all__ = ['BatchedSelfPlay', 'Trajectory', 'gather_trajectories', 'shard_game_ids']
+__all__ = ['BatchedSelfPlay', 'Trajectory', 'gather_trajectories', 'shard_game_ids', 'broadcast_weights']

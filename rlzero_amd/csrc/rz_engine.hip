@@ -4,21 +4,28 @@
 // its simulations strictly sequentially, rlzero/mcts/alphazero_mcts.py:82-85, so this is
 // what bit-exact parity requires); the parallelism is across the lock-stepped games.
 //
-// Tree layout (struct of arrays in HBM, one arena pair per game):
-//   N  int32   visit count          (TreeNode.explore_count, rlzero/mcts/node.py:28)
-//   W  float64 total value          (TreeNode.total_reward,  node.py:29)
-//   P  float32 prior                (TreeNode.prior,         node.py:30)
-//   FC int32   index of the first child slot, -1 = not expanded (TreeNode._children)
-//   NV int32   number of children already visited
-// The children of a node are ONE contiguous block of k slots, k = number of empty cells
-// at that node, slot r = r-th legal move in ascending order (the reference's dict
-// insertion order, node.py:62-73).  The reference's selection rule gives an unvisited
-// child +inf and Python's max() keeps the first maximum (node.py:41-42,75-88), so the
-// visited children of every node are always a PREFIX of its block:
-// "first unvisited child" is slot NV, no scan; a scan (coalesced 4+8 B per child, fp64
-// score, first-index tie-break across the wave) happens only once all k are visited.
-// N/W/FC/NV of a slot are written the first time the slot is visited, so expansion only
-// reserves the block (bump allocator) and writes the k priors.
+// Tree layout (struct of arrays in HBM, one arena pair per game), per node slot:
+//   M  int4    {N  visit count            (TreeNode.explore_count, rlzero/mcts/node.py:28),
+//               FC index of the first child slot, -1 = not expanded (TreeNode._children),
+//               NV number of children already visited,
+//               K  size of the children block = legal moves at this node}
+//              -- ONE 16-byte record, so a level of the descent costs one load;
+//   Wsum float64 total value              (TreeNode.total_reward,  node.py:29)
+//   P    float32 prior                    (TreeNode.prior,         node.py:30)
+// The children of a node are ONE contiguous block of K slots, slot r = r-th legal move in
+// ascending order (the reference's dict insertion order, node.py:62-73).  The reference's
+// selection rule gives an unvisited child +inf and Python's max() keeps the first maximum
+// (node.py:41-42,75-88), so the visited children of every node are always a PREFIX of its
+// block: "first unvisited child" is slot NV, no scan; a scan (coalesced,
+// fp64 score, first-index tie-break across the wave) happens only once all K are visited.
+// A slot's record is written the first time the slot is visited, so expansion only
+// reserves the block (bump allocator) and writes the K priors.  (The opt-in PUCT mode
+// initialises all K children at expansion and always scans.)
+//
+// Boards: two bitboards per game (4 x u64 per colour), cell = h*BW + w.  Gomoku / TicTacToe:
+// action = cell (rlzero/games/gomoku/gomoku_env.py:227-234).  Connect4 (no reference
+// implementation: build-defined, docs/open-spiel_alphazero.md:58 only mentions it): action =
+// column, the stone drops to the lowest empty cell, row 0 is the bottom row.
 //
 // Bit-exactness: fp64 throughout, this file is compiled with
 // -ffp-contract=off (q + c*u is two roundings in CPython), IEEE division and sqrt, and
@@ -44,14 +51,12 @@ constexpr int kWave = 64;
 constexpr int kWords = RZ_BOARD_WORDS;
 
 struct Dev {
-    int S, B, n_row, n_games, score_mode;
+    int kind, BH, BW, S, A, n_row, n_games, score_mode;
     int path_stride, qcap;
     long long cap, logtab_n;
     double c_puct;
-    int32_t *N;
-    double *W;
-    int32_t *FC;
-    int32_t *NV;
+    int4 *M;
+    double *Wsum;
     float *P;
     int32_t *cur_arena, *top, *nblk;
     uint64_t *root_stones;
@@ -69,6 +74,11 @@ struct Dev {
     int add_noise;
     uint64_t valid[kWords];
 };
+
+// field accessors of the packed node record (4-byte accesses into the int4)
+__device__ __forceinline__ int32_t *m_n(int4 *M, int i) { return reinterpret_cast<int32_t *>(M + i) + 0; }
+__device__ __forceinline__ int32_t *m_fc(int4 *M, int i) { return reinterpret_cast<int32_t *>(M + i) + 1; }
+__device__ __forceinline__ int32_t *m_nv(int4 *M, int i) { return reinterpret_cast<int32_t *>(M + i) + 2; }
 
 // ------------------------------------------------------------------ bitboard helpers
 __device__ __forceinline__ uint64_t word_of(const uint64_t *a, int j) {
@@ -92,49 +102,123 @@ __device__ __forceinline__ void set_bit(uint64_t *a, int c) {
 __device__ __forceinline__ int count_bits(const uint64_t *a) {
     return __popcll(a[0]) + __popcll(a[1]) + __popcll(a[2]) + __popcll(a[3]);
 }
-
-// Rank of cell `a` among the empty cells (ascending) = its slot in a children block.
-__device__ __forceinline__ int rank_of_cell(const uint64_t *occ, const uint64_t *valid, int a) {
-    const int i = a >> 6;
-    const uint64_t below = (1ull << (a & 63)) - 1ull;
-    int r = 0;
+__device__ __forceinline__ void load_board(const uint64_t *src, int g, uint64_t (&st)[2][kWords]) {
 #pragma unroll
     for (int j = 0; j < kWords; ++j) {
-        const uint64_t e = ~occ[j] & valid[j];
-        r += (j < i) ? __popcll(e) : ((j == i) ? __popcll(e & below) : 0);
+        st[0][j] = src[((long long)g * 2 + 0) * kWords + j];
+        st[1][j] = src[((long long)g * 2 + 1) * kWords + j];
     }
-    return r;
+}
+__device__ __forceinline__ void store_board(uint64_t *dst, int g, const uint64_t (&st)[2][kWords], int lane) {
+    if (lane < 2 * kWords) {
+        const int colour = lane / kWords, j = lane % kWords;
+        dst[((long long)g * 2 + colour) * kWords + j] = colour == 0 ? word_of(st[0], j) : word_of(st[1], j);
+    }
 }
 
-// r-th empty cell (ascending); lane l looks at bit l of each word.  Wave-uniform result.
-__device__ __forceinline__ int nth_empty_cell(const uint64_t *occ, const uint64_t *valid, int r,
-                                              int lane) {
+// ------------------------------------------------------------------ legal moves
+// Wave-uniform description of the legal actions of a position.  Gomoku: every empty cell.
+// Connect4: every column whose top cell is empty; lane c < BW keeps the column's height.
+struct Legal {
+    int k;                     // number of legal actions
+    unsigned long long cols;   // Connect4: bit c = column c playable
+    int height;                // Connect4: stones in column `lane` (per lane)
+};
+
+__device__ __forceinline__ Legal legal_of(const Dev &E, const uint64_t *occ, int lane) {
+    Legal L;
+    L.cols = 0ull;
+    L.height = 0;
+    if (E.kind == RZ_GAME_CONNECT4) {
+        int h = 0;
+        if (lane < E.BW)
+            for (int y = 0; y < E.BH; ++y) h += test_bit(occ, y * E.BW + lane) ? 1 : 0;
+        L.height = h;
+        L.cols = __ballot(lane < E.BW && h < E.BH);
+        L.k = __popcll(L.cols);
+    } else {
+        L.k = E.S - count_bits(occ);
+    }
+    return L;
+}
+
+// r-th legal action in ascending order -> (action, cell it occupies).  Wave-uniform.
+__device__ __forceinline__ bool nth_legal(const Dev &E, const uint64_t *occ, const Legal &L, int r, int lane,
+                                          int &action, int &cell) {
+    if (E.kind == RZ_GAME_CONNECT4) {
+        const bool mine = (L.cols >> lane) & 1ull;
+        const bool hit = mine && __popcll(L.cols & ((1ull << lane) - 1ull)) == r;
+        const unsigned long long m = __ballot(hit);
+        if (m == 0ull) return false;
+        action = __ffsll((long long)m) - 1;
+        cell = __shfl(L.height, action) * E.BW + action;
+        return true;
+    }
     const uint64_t below = (1ull << lane) - 1ull;
     int before = 0, found = -1;
 #pragma unroll
     for (int j = 0; j < kWords; ++j) {
-        const uint64_t e = ~occ[j] & valid[j];
+        const uint64_t e = ~occ[j] & E.valid[j];
         const bool mine = (e >> lane) & 1ull;
         if (mine && before + __popcll(e & below) == r) found = 64 * j + lane;
         before += __popcll(e);
     }
     const unsigned long long m = __ballot(found >= 0);
-    if (m == 0ull) return -1;
-    return __shfl(found, __ffsll((long long)m) - 1);
+    if (m == 0ull) return false;
+    action = cell = __shfl(found, __ffsll((long long)m) - 1);
+    return true;
+}
+
+// action -> (legal?, rank among the legal actions, cell).  Wave-uniform.
+__device__ __forceinline__ bool locate_action(const Dev &E, const uint64_t *occ, const Legal &L, int a,
+                                              int &rank, int &cell) {
+    if (a < 0 || a >= E.A) return false;
+    if (E.kind == RZ_GAME_CONNECT4) {
+        if (!((L.cols >> a) & 1ull)) return false;
+        rank = __popcll(L.cols & ((1ull << a) - 1ull));
+        cell = __shfl(L.height, a) * E.BW + a;
+        return true;
+    }
+    if (test_bit(occ, a)) return false;
+    const int i = a >> 6;
+    const uint64_t below = (1ull << (a & 63)) - 1ull;
+    int r = 0;
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) {
+        const uint64_t e = ~occ[j] & E.valid[j];
+        r += (j < i) ? __popcll(e) : ((j == i) ? __popcll(e & below) : 0);
+    }
+    rank = r;
+    cell = a;
+    return true;
+}
+
+// Per-lane view of "my" legal action for scatter/gather over the action space: lane handles
+// action 64*j + lane (j < kWords; Connect4 only j == 0).  Returns rank or -1.
+__device__ __forceinline__ int lane_action_rank(const Dev &E, const uint64_t *occ, const Legal &L, int j,
+                                                int lane, int &before) {
+    if (E.kind == RZ_GAME_CONNECT4) {
+        if (j != 0 || !((L.cols >> lane) & 1ull)) return -1;
+        return __popcll(L.cols & ((1ull << lane) - 1ull));
+    }
+    const uint64_t e = ~occ[j] & E.valid[j];
+    const int r = ((e >> lane) & 1ull) ? before + __popcll(e & ((1ull << lane) - 1ull)) : -1;
+    before += __popcll(e);
+    return r;
 }
 
 // n-in-row through `last` only: lane l < 4n tests the window of direction l/n that starts
 // l%n steps before `last`.  Equivalent to the reference's whole-board scan
 // (gomoku_env.py:136-168) when the position before `last` had no line.
-__device__ __forceinline__ bool line_through(const uint64_t *x, int last, int B, int n, int lane) {
+__device__ __forceinline__ bool line_through(const uint64_t *x, int last, int BH, int BW, int n, int lane) {
     bool hit = false;
     if (lane < 4 * n) {
         const int d = lane / n, t = lane - d * n;
-        const int stride = (d == 0) ? 1 : (d == 1) ? B : (d == 2) ? B + 1 : B - 1;
+        const int stride = (d == 0) ? 1 : (d == 1) ? BW : (d == 2) ? BW + 1 : BW - 1;
         const int start = last - t * stride;
         if (start >= 0) {
-            const int h = start / B, w = start - h * B;
-            const bool right = w <= B - n, down = h <= B - n, left = w >= n - 1;
+            const int h = start / BW, w = start - h * BW;
+            const bool right = w <= BW - n, down = h <= BH - n, left = w >= n - 1;
             const bool ok = (d == 0) ? right : (d == 1) ? down : (d == 2) ? (right && down)
                                                                           : (left && down);
             if (ok) {
@@ -147,15 +231,15 @@ __device__ __forceinline__ bool line_through(const uint64_t *x, int last, int B,
 }
 
 // Whole-board n-in-row scan of one colour (gomoku_env.py:136-168), lanes over start cells.
-__device__ __forceinline__ bool line_anywhere(const uint64_t *x, int S, int B, int n, int lane) {
+__device__ __forceinline__ bool line_anywhere(const uint64_t *x, int S, int BH, int BW, int n, int lane) {
     bool hit = false;
     for (int m = lane; m < S; m += kWave) {
         if (!test_bit(x, m)) continue;
-        const int h = m / B, w = m - h * B;
-        const bool right = w <= B - n, down = h <= B - n, left = w >= n - 1;
+        const int h = m / BW, w = m - h * BW;
+        const bool right = w <= BW - n, down = h <= BH - n, left = w >= n - 1;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const int stride = (d == 0) ? 1 : (d == 1) ? B : (d == 2) ? B + 1 : B - 1;
+            const int stride = (d == 0) ? 1 : (d == 1) ? BW : (d == 2) ? BW + 1 : BW - 1;
             const bool ok = (d == 0) ? right : (d == 1) ? down : (d == 2) ? (right && down)
                                                                           : (left && down);
             if (!ok) continue;
@@ -239,24 +323,32 @@ __device__ __forceinline__ float gamma03(uint64_t key) {
     return g * powf(ub, 1.0f / 0.3f);
 }
 
+// wave arg-max of (score, index) with the LOWEST index winning ties (Python's max keeps the first)
+__device__ __forceinline__ int wave_first_max(double best, int besti) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ob = __shfl_xor(best, off);
+        const int oi = __shfl_xor(besti, off);
+        if (ob > best || (ob == best && oi < besti)) {
+            best = ob;
+            besti = oi;
+        }
+    }
+    return besti;
+}
+
 // ------------------------------------------------------------------ SELECT + STEP
 __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int lane) {
     if (!E.active[g]) return;
-    const int S = E.S, B = E.B;
+    const int S = E.S;
     const long long base = ((long long)g * 2 + E.cur_arena[g]) * E.cap;
-    int32_t *N = E.N + base;
-    double *W = E.W + base;
-    int32_t *FC = E.FC + base;
-    int32_t *NV = E.NV + base;
+    int4 *M = E.M + base;
+    const double *Wsum = E.Wsum + base;
     const float *P = E.P + base;
     const bool use_puct = E.score_mode == RZ_SCORE_PUCT;
 
     uint64_t st[2][kWords];
-#pragma unroll
-    for (int j = 0; j < kWords; ++j) {
-        st[0][j] = E.root_stones[((long long)g * 2 + 0) * kWords + j];
-        st[1][j] = E.root_stones[((long long)g * 2 + 1) * kWords + j];
-    }
+    load_board(E.root_stones, g, st);
     int to_move = E.root_to_move[g];
     int last = E.root_last[g];
     int nst = count_bits(st[0]) + count_bits(st[1]);
@@ -266,44 +358,31 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
     if (lane == 0) path[0] = 0;
 
     for (int it = 0; it <= S; ++it) {
-        const int fc = FC[node];
+        const int4 m = M[node];  // {N, FC, NV, K}: one load per level
+        const int fc = m.y;
         if (fc < 0) break;  // leaf: never expanded, or a terminal position
-        const int k = S - nst;
-        const int nv = NV[node];
+        const int k = m.w;
         int r;
         if (use_puct) {
             // every child was initialised at expansion (N = 0, W = 0, prior): scan all k
-            const double sq = sqrt((double)N[node]);
+            const double sq = sqrt((double)m.x);
             double best = -INFINITY;
             int besti = 0x7fffffff;
             for (int r0 = lane; r0 < k; r0 += kWave) {
-                const double sc = puct(W[fc + r0], N[fc + r0], P[fc + r0], sq, E.c_puct);
+                const double sc = puct(Wsum[fc + r0], *m_n(M, fc + r0), P[fc + r0], sq, E.c_puct);
                 if (sc > best) {
                     best = sc;
                     besti = r0;
                 }
             }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const double ob = __shfl_xor(best, off);
-                const int oi = __shfl_xor(besti, off);
-                if (ob > best || (ob == best && oi < besti)) {
-                    best = ob;
-                    besti = oi;
-                }
-            }
-            r = besti;
-            if (r >= k) {
-                flag(E, g, RZ_FLAG_INTERNAL, lane);
-                break;
-            }
-        } else if (nv < k) {
+            r = wave_first_max(best, besti);
+        } else if (m.z < k) {
             // some child still has N == 0 -> score +inf, first such child wins
-            r = nv;
+            r = m.z;
             fresh = 1;
-            if (lane == 0) NV[node] = nv + 1;
+            if (lane == 0) *m_nv(M, node) = m.z + 1;
         } else {
-            const int pn = N[node];
+            const int pn = m.x;
             if (pn < 1 || pn >= E.logtab_n) {
                 flag(E, g, RZ_FLAG_LOGTAB, lane);
                 break;
@@ -312,37 +391,29 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
             double best = -INFINITY;
             int besti = 0x7fffffff;
             for (int r0 = lane; r0 < k; r0 += kWave) {
-                const double sc = uct_ref(W[fc + r0], N[fc + r0], lnp, E.c_puct);
+                const double sc = uct_ref(Wsum[fc + r0], *m_n(M, fc + r0), lnp, E.c_puct);
                 if (sc > best) {
                     best = sc;
                     besti = r0;
                 }
             }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const double ob = __shfl_xor(best, off);
-                const int oi = __shfl_xor(besti, off);
-                if (ob > best || (ob == best && oi < besti)) {
-                    best = ob;
-                    besti = oi;
-                }
-            }
-            r = besti;
-            if (r >= k) {
-                flag(E, g, RZ_FLAG_INTERNAL, lane);
-                break;
-            }
+            r = wave_first_max(best, besti);
+        }
+        if (r >= k) {
+            flag(E, g, RZ_FLAG_INTERNAL, lane);
+            break;
         }
         uint64_t occ[kWords];
 #pragma unroll
         for (int j = 0; j < kWords; ++j) occ[j] = st[0][j] | st[1][j];
-        const int a = nth_empty_cell(occ, E.valid, r, lane);
-        if (a < 0) {
+        const Legal L = legal_of(E, occ, lane);
+        int action, cell;
+        if (!nth_legal(E, occ, L, r, lane, action, cell)) {
             flag(E, g, RZ_FLAG_INTERNAL, lane);
             break;
         }
-        if (to_move == 0) set_bit(st[0], a); else set_bit(st[1], a);
-        last = a;
+        if (to_move == 0) set_bit(st[0], cell); else set_bit(st[1], cell);
+        last = cell;
         to_move ^= 1;
         nst += 1;
         node = fc + r;
@@ -351,17 +422,17 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
         if (fresh) break;  // a first-visit child has no statistics and no children yet
     }
 
-    // GomokuEnv.game_end_winner on the leaf (gomoku_env.py:196-203)
+    // game_end_winner on the leaf (gomoku_env.py:196-203)
     int term = 0;
     double tval = 0.0;
     {
         int winner = -1;
         if (depth == 0) {
-            if (line_anywhere(st[0], S, B, E.n_row, lane)) winner = 0;
-            else if (line_anywhere(st[1], S, B, E.n_row, lane)) winner = 1;
+            if (line_anywhere(st[0], S, E.BH, E.BW, E.n_row, lane)) winner = 0;
+            else if (line_anywhere(st[1], S, E.BH, E.BW, E.n_row, lane)) winner = 1;
         } else {
             const int mover = to_move ^ 1;
-            if (line_through(mover == 0 ? st[0] : st[1], last, B, E.n_row, lane)) winner = mover;
+            if (line_through(mover == 0 ? st[0] : st[1], last, E.BH, E.BW, E.n_row, lane)) winner = mover;
         }
         if (winner >= 0) {
             term = 2;
@@ -380,10 +451,7 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
         E.leaf_to_move[g] = to_move;
         E.leaf_last[g] = last;
     }
-    if (lane < 2 * kWords) {
-        const int colour = lane / kWords, j = lane % kWords;
-        E.leaf_stones[((long long)g * 2 + colour) * kWords + j] = word_of(st[colour], j);
-    }
+    store_board(E.leaf_stones, g, st, lane);
     if (obs != nullptr)
         write_obs(obs + (long long)g * 4 * S, to_move == 0 ? st[0] : st[1],
                   to_move == 0 ? st[1] : st[0], last, nst, S, lane);
@@ -392,52 +460,51 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
 // ------------------------------------------------------------------ EXPAND + BACKUP
 // PROBS: `logp` already holds probabilities (host evaluators hand over the callable's exact
 // numbers); otherwise log-probabilities from the network (prior = exp, alphazero_agent.py:44).
+// Policy arrays are indexed by ACTION: [n_games][A].
 template <typename VT, bool PROBS = false>
 __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *logp, const VT *value, int g,
                                                    int lane) {
     if (!E.active[g]) return;
-    const int S = E.S;
     const long long base = ((long long)g * 2 + E.cur_arena[g]) * E.cap;
-    int32_t *N = E.N + base;
-    double *W = E.W + base;
-    int32_t *FC = E.FC + base;
-    int32_t *NV = E.NV + base;
+    int4 *M = E.M + base;
+    double *Wsum = E.Wsum + base;
     float *P = E.P + base;
 
-    const int leaf = E.leaf_node[g];
     const int depth = E.leaf_depth[g];
     const int fresh = E.leaf_fresh[g];
     const int term = E.leaf_term[g];
     // the reference evaluates terminal leaves too and discards the result (:59-68)
     const double v = term ? E.leaf_tval[g] : (double)value[g];
+    const int32_t *path = E.path + (long long)g * E.path_stride;
 
+    int new_fc = -1, new_nv = 0, new_k = 0;
     if (!term) {
-        uint64_t occ[kWords];
+        uint64_t st[2][kWords], occ[kWords];
+        load_board(E.leaf_stones, g, st);
 #pragma unroll
-        for (int j = 0; j < kWords; ++j)
-            occ[j] = E.leaf_stones[((long long)g * 2 + 0) * kWords + j] |
-                     E.leaf_stones[((long long)g * 2 + 1) * kWords + j];
-        const int k = S - count_bits(occ);
+        for (int j = 0; j < kWords; ++j) occ[j] = st[0][j] | st[1][j];
+        const Legal L = legal_of(E, occ, lane);
+        const int k = L.k;
         const int top = E.top[g];
         const int nblk = E.nblk[g];
         if ((long long)top + k > E.cap || nblk >= E.qcap) {
             flag(E, g, (long long)top + k > E.cap ? RZ_FLAG_ARENA_FULL : RZ_FLAG_BLOCKS_FULL, lane);
-            if (lane == 0 && fresh) {
-                FC[leaf] = -1;
-                NV[leaf] = 0;
-            }
         } else {
             const bool dense = E.score_mode == RZ_SCORE_PUCT;
+            new_fc = top;
+            new_nv = dense ? k : 0;  // PUCT: all k children are initialised below
+            new_k = k;
             if (lane == 0) {
-                FC[leaf] = top;
-                NV[leaf] = dense ? k : 0;  // PUCT: all k children are initialised below
                 E.top[g] = top + k;
                 E.nblk[g] = nblk + 1;
             }
             // TreeNode.expand: one child per legal move, prior from the policy head; in self-play
             // mixed with Dirichlet(0.3) noise at EVERY expanded node (node.py:63-69)
             const float uniform = 1.0f / (float)k;
-            const uint64_t below = (1ull << lane) - 1ull;
+            int ranks[kWords];
+            int before = 0;
+#pragma unroll
+            for (int j = 0; j < kWords; ++j) ranks[j] = lane_action_rank(E, occ, L, j, lane, before);
             float noise[kWords] = {0.f, 0.f, 0.f, 0.f};
             float noise_sum = 1.0f;
             if (E.add_noise) {
@@ -445,55 +512,52 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
                 const uint64_t key = mix64(mix64(E.noise_seed ^ ((uint64_t)g << 20)) ^ (uint64_t)ctr);
                 float local = 0.0f;
 #pragma unroll
-                for (int j = 0; j < kWords; ++j) {
-                    const uint64_t e = ~occ[j] & E.valid[j];
-                    if ((e >> lane) & 1ull) {
-                        noise[j] = gamma03(mix64(key ^ (uint64_t)(64 * j + lane)) );
+                for (int j = 0; j < kWords; ++j)
+                    if (ranks[j] >= 0) {
+                        noise[j] = gamma03(mix64(key ^ (uint64_t)(64 * j + lane)));
                         local += noise[j];
                     }
-                }
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) local += __shfl_xor(local, off);
                 noise_sum = local > 0.0f ? local : 1.0f;
                 if (lane == 0) E.noise_ctr[g] = ctr + 1;
             }
-            int before = 0;
 #pragma unroll
             for (int j = 0; j < kWords; ++j) {
-                const uint64_t e = ~occ[j] & E.valid[j];
-                if ((e >> lane) & 1ull) {
-                    const int r = before + __popcll(e & below);
-                    const int c = 64 * j + lane;
-                    float prior = uniform;
-                    if (logp) prior = PROBS ? logp[(long long)g * S + c] : expf(logp[(long long)g * S + c]);
-                    if (E.add_noise) prior = 0.75f * prior + 0.25f * (noise[j] / noise_sum);
-                    P[top + r] = prior;
-                    if (dense) {
-                        N[top + r] = 0;
-                        W[top + r] = 0.0;
-                        FC[top + r] = -1;
-                        NV[top + r] = 0;
-                    }
+                const int r = ranks[j];
+                if (r < 0) continue;
+                const int a = 64 * j + lane;
+                float prior = uniform;
+                if (logp) prior = PROBS ? logp[(long long)g * E.A + a] : expf(logp[(long long)g * E.A + a]);
+                if (E.add_noise) prior = 0.75f * prior + 0.25f * (noise[j] / noise_sum);
+                P[top + r] = prior;
+                if (dense) {
+                    M[top + r] = make_int4(0, -1, 0, 0);
+                    Wsum[top + r] = 0.0;
                 }
-                before += __popcll(e);
             }
         }
-    } else if (fresh && lane == 0) {
-        FC[leaf] = -1;
-        NV[leaf] = 0;
     }
 
     // TreeNode.update_recursive(-leaf_value): leaf gets -v, its parent +v, ... (node.py:135-144)
-    const int32_t *path = E.path + (long long)g * E.path_stride;
     for (int d = lane; d <= depth; d += kWave) {
         const int node = path[d];
         const double x = ((depth - d) & 1) ? v : -v;
-        if (d == depth && fresh) {
-            N[node] = 1;
-            W[node] = 0.0 + x;  // int 0 + float in the reference (node.py:29,133)
+        if (d == depth) {
+            // the leaf: first-visit slots get their whole record here; an old leaf that is now
+            // expanded gets its child block
+            if (fresh) {
+                M[node] = make_int4(1, new_fc, new_nv, new_k);
+                Wsum[node] = 0.0 + x;  // int 0 + float in the reference (node.py:29,133)
+            } else {
+                const int4 m = M[node];
+                M[node] = (new_fc >= 0) ? make_int4(m.x + 1, new_fc, new_nv, new_k)
+                                        : make_int4(m.x + 1, m.y, m.z, m.w);
+                Wsum[node] += x;
+            }
         } else {
-            N[node] += 1;
-            W[node] += x;
+            *m_n(M, node) += 1;
+            Wsum[node] += x;
         }
     }
 }
@@ -526,27 +590,19 @@ __global__ __launch_bounds__(kWave) void k_eval_synth(Dev E, int kind, float *lo
     const int lane = threadIdx.x;
     if (!E.active[g]) return;
     const int S = E.S;
-    uint64_t s0[kWords], s1[kWords];
-#pragma unroll
-    for (int j = 0; j < kWords; ++j) {
-        s0[j] = E.leaf_stones[((long long)g * 2 + 0) * kWords + j];
-        s1[j] = E.leaf_stones[((long long)g * 2 + 1) * kWords + j];
-    }
-    int acc = 0, k = 0;
+    uint64_t st[2][kWords];
+    load_board(E.leaf_stones, g, st);
+    int acc = 0;
 #pragma unroll
     for (int j = 0; j < kWords; ++j) {
         const int c = 64 * j + lane;
         if (c < S) {
-            const int a = (int)((s0[j] >> lane) & 1ull), b = (int)((s1[j] >> lane) & 1ull);
+            const int a = (int)((st[0][j] >> lane) & 1ull), b = (int)((st[1][j] >> lane) & 1ull);
             acc += (c + 1) * (a + 3 * b);
-            k += 1 - a - b;
         }
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        acc += __shfl_xor(acc, off);
-        k += __shfl_xor(k, off);
-    }
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
     if (lane == 0) {
         float v = 0.0f;
         if (kind == RZ_EVAL_VLIN) {
@@ -556,14 +612,17 @@ __global__ __launch_bounds__(kWave) void k_eval_synth(Dev E, int kind, float *lo
         value[g] = v;
     }
     if (logp != nullptr) {
-        const float lp = k > 0 ? logf(1.0f / (float)k) : 0.0f;
+        uint64_t occ[kWords];
+#pragma unroll
+        for (int j = 0; j < kWords; ++j) occ[j] = st[0][j] | st[1][j];
+        const Legal L = legal_of(E, occ, lane);
+        const float lp = L.k > 0 ? logf(1.0f / (float)L.k) : 0.0f;
+        int before = 0;
 #pragma unroll
         for (int j = 0; j < kWords; ++j) {
-            const int c = 64 * j + lane;
-            if (c < S) {
-                const bool empty = !(((s0[j] | s1[j]) >> lane) & 1ull);
-                logp[(long long)g * S + c] = empty ? lp : -INFINITY;
-            }
+            const int r = lane_action_rank(E, occ, L, j, lane, before);
+            const int a = 64 * j + lane;
+            if (a < E.A) logp[(long long)g * E.A + a] = r >= 0 ? lp : -INFINITY;
         }
     }
 }
@@ -575,40 +634,36 @@ __global__ __launch_bounds__(kWave) void k_eval_synth(Dev E, int kind, float *lo
 // is the player to move AFTER the rollout else -1 (the reference's perspective quirk, :68-72:
 // the winner has just moved, so a decisive rollout always yields -1).  The move index of ply p
 // is floor(u * k) with u = the high 32 bits of splitmix64(seed, game, sim, ply) -- reproducible
-// on the host (rlzero_amd.mcts.rollout_mcts.rollout_pick) so parity tests can drive the oracle
+// on the host (rlzero_amd.mcts.rollout_mcts.rollout_pick) so parity tests can drive the checker
 // with the very same choices.
 __global__ __launch_bounds__(kWave) void k_eval_rollout(Dev E, uint64_t seed, uint32_t sim, int n_limit,
                                                         float *value) {
     const int g = blockIdx.x;
     const int lane = threadIdx.x;
     if (!E.active[g]) return;
-    const int S = E.S, B = E.B;
+    const int S = E.S;
     uint64_t st[2][kWords];
-#pragma unroll
-    for (int j = 0; j < kWords; ++j) {
-        st[0][j] = E.leaf_stones[((long long)g * 2 + 0) * kWords + j];
-        st[1][j] = E.leaf_stones[((long long)g * 2 + 1) * kWords + j];
-    }
+    load_board(E.leaf_stones, g, st);
     int to_move = E.leaf_to_move[g];
     int nst = count_bits(st[0]) + count_bits(st[1]);
     int term = E.leaf_term[g];  // 0 running, 1 tie, 2 won by the player who just moved
     int winner = term == 2 ? (to_move ^ 1) : -1;
     const uint64_t key = mix64(mix64(seed ^ (uint64_t)g) ^ (uint64_t)sim);
     for (int ply = 0; ply < n_limit && term == 0; ++ply) {
-        const int k = S - nst;
-        const uint32_t u = (uint32_t)(mix64(key ^ (uint64_t)ply) >> 32);
-        const int r = (int)(((uint64_t)u * (uint64_t)k) >> 32);
         uint64_t occ[kWords];
 #pragma unroll
         for (int j = 0; j < kWords; ++j) occ[j] = st[0][j] | st[1][j];
-        const int a = nth_empty_cell(occ, E.valid, r, lane);
-        if (a < 0) {
+        const Legal L = legal_of(E, occ, lane);
+        const uint32_t u = (uint32_t)(mix64(key ^ (uint64_t)ply) >> 32);
+        const int r = (int)(((uint64_t)u * (uint64_t)L.k) >> 32);
+        int action, cell;
+        if (!nth_legal(E, occ, L, r, lane, action, cell)) {
             flag(E, g, RZ_FLAG_INTERNAL, lane);
             break;
         }
-        if (to_move == 0) set_bit(st[0], a); else set_bit(st[1], a);
+        if (to_move == 0) set_bit(st[0], cell); else set_bit(st[1], cell);
         nst += 1;
-        if (line_through(to_move == 0 ? st[0] : st[1], a, B, E.n_row, lane)) {
+        if (line_through(to_move == 0 ? st[0] : st[1], cell, E.BH, E.BW, E.n_row, lane)) {
             term = 2;
             winner = to_move;
         } else if (nst == S) {
@@ -620,35 +675,30 @@ __global__ __launch_bounds__(kWave) void k_eval_rollout(Dev E, uint64_t seed, ui
 }
 
 // ------------------------------------------------------------------ root read-out
-// what: 0 = visits (int32), 1 = W (double), 2 = prior (float)
+// what: 0 = visits (int32), 1 = W (double), 2 = prior (float); output [n_games][A] by action
 __global__ __launch_bounds__(kWave) void k_root_children(Dev E, int what, void *out) {
     const int g = blockIdx.x;
     const int lane = threadIdx.x;
-    const int S = E.S;
     const long long base = ((long long)g * 2 + E.cur_arena[g]) * E.cap;
-    uint64_t occ[kWords];
+    uint64_t st[2][kWords], occ[kWords];
+    load_board(E.root_stones, g, st);
 #pragma unroll
-    for (int j = 0; j < kWords; ++j)
-        occ[j] = E.root_stones[((long long)g * 2 + 0) * kWords + j] |
-                 E.root_stones[((long long)g * 2 + 1) * kWords + j];
-    const int fc = E.FC[base];
-    const int nv = fc >= 0 ? E.NV[base] : 0;
-    const uint64_t below = (1ull << lane) - 1ull;
+    for (int j = 0; j < kWords; ++j) occ[j] = st[0][j] | st[1][j];
+    const Legal L = legal_of(E, occ, lane);
+    const int4 m = E.M[base];
+    const int fc = m.y;
+    const int nv = fc >= 0 ? m.z : 0;
     int before = 0;
 #pragma unroll
     for (int j = 0; j < kWords; ++j) {
-        const int c = 64 * j + lane;
-        const uint64_t e = ~occ[j] & E.valid[j];
-        if (c < S) {
-            const bool empty = (e >> lane) & 1ull;
-            const int r = before + __popcll(e & below);
-            const bool seen = empty && r < nv;
-            const long long o = (long long)g * S + c;
-            if (what == 0) ((int32_t *)out)[o] = seen ? E.N[base + fc + r] : 0;
-            else if (what == 1) ((double *)out)[o] = seen ? E.W[base + fc + r] : 0.0;
-            else ((float *)out)[o] = (empty && fc >= 0) ? E.P[base + fc + r] : 0.0f;
-        }
-        before += __popcll(e);
+        const int r = lane_action_rank(E, occ, L, j, lane, before);
+        const int a = 64 * j + lane;
+        if (a >= E.A) continue;
+        const bool seen = r >= 0 && r < nv;
+        const long long o = (long long)g * E.A + a;
+        if (what == 0) ((int32_t *)out)[o] = seen ? E.M[base + fc + r].x : 0;
+        else if (what == 1) ((double *)out)[o] = seen ? E.Wsum[base + fc + r] : 0.0;
+        else ((float *)out)[o] = (r >= 0 && fc >= 0) ? E.P[base + fc + r] : 0.0f;
     }
 }
 
@@ -656,19 +706,17 @@ __global__ void k_root_stats(Dev E, int32_t *n, double *w) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= E.n_games) return;
     const long long base = ((long long)g * 2 + E.cur_arena[g]) * E.cap;
-    n[g] = E.N[base];
-    w[g] = E.W[base];
+    n[g] = E.M[base].x;
+    w[g] = E.Wsum[base];
 }
 
 // ------------------------------------------------------------------ tree reuse
 __device__ __forceinline__ void fresh_root(const Dev &E, int g, int arena, int lane) {
     if (lane == 0) {
         const long long base = ((long long)g * 2 + arena) * E.cap;
-        E.N[base] = 0;
-        E.W[base] = 0.0;
+        E.M[base] = make_int4(0, -1, 0, 0);
+        E.Wsum[base] = 0.0;
         E.P[base] = 1.0f;
-        E.FC[base] = -1;
-        E.NV[base] = 0;
         E.cur_arena[g] = arena;
         E.top[g] = 1;
         E.nblk[g] = 0;
@@ -681,53 +729,49 @@ __device__ __forceinline__ void fresh_root(const Dev &E, int g, int arena, int l
 __global__ __launch_bounds__(kWave) void k_advance(Dev E, const int32_t *moves) {
     const int g = blockIdx.x;
     const int lane = threadIdx.x;
-    const int m = moves[g];
-    if (m == -2) return;
-    const int S = E.S;
+    const int mv = moves[g];
+    if (mv == -2) return;
     const int src_arena = E.cur_arena[g], dst_arena = src_arena ^ 1;
     const long long sb = ((long long)g * 2 + src_arena) * E.cap;
     const long long db = ((long long)g * 2 + dst_arena) * E.cap;
-    if (m < 0 || m >= S) {
-        if (m != -1) flag(E, g, RZ_FLAG_ILLEGAL_MOVE, lane);
+    if (mv < 0) {
+        if (mv != -1) flag(E, g, RZ_FLAG_ILLEGAL_MOVE, lane);
         fresh_root(E, g, dst_arena, lane);
         return;
     }
-    uint64_t occ[kWords];
+    uint64_t st[2][kWords], occ[kWords];
+    load_board(E.root_stones, g, st);
 #pragma unroll
-    for (int j = 0; j < kWords; ++j)
-        occ[j] = E.root_stones[((long long)g * 2 + 0) * kWords + j] |
-                 E.root_stones[((long long)g * 2 + 1) * kWords + j];
-    if (test_bit(occ, m)) {
+    for (int j = 0; j < kWords; ++j) occ[j] = st[0][j] | st[1][j];
+    const Legal L = legal_of(E, occ, lane);
+    int rank = 0, cell = 0;
+    if (!locate_action(E, occ, L, mv, rank, cell)) {
         flag(E, g, RZ_FLAG_ILLEGAL_MOVE, lane);
         fresh_root(E, g, dst_arena, lane);
         return;
     }
-    const int root_fc = E.FC[sb];
-    const int rank = rank_of_cell(occ, E.valid, m);
-    if (root_fc < 0 || rank >= E.NV[sb]) {
+    const int4 root = E.M[sb];
+    if (root.y < 0 || rank >= root.z) {
         // the chosen child was never visited: it is a TreeNode with N = 0 and no children
         fresh_root(E, g, dst_arena, lane);
         return;
     }
-    const int nst_root = count_bits(occ);
-    const int src = root_fc + rank;
+    const int src = root.y + rank;
+    const int4 sm = E.M[sb + src];
     int32_t *queue = E.queue + (long long)g * E.qcap * 4;
     int q_tail = 0;
-    const int src_fc = E.FC[sb + src];
     if (lane == 0) {
-        E.N[db] = E.N[sb + src];
-        E.W[db] = E.W[sb + src];
+        E.M[db] = make_int4(sm.x, -1, sm.z, sm.w);
+        E.Wsum[db] = E.Wsum[sb + src];
         E.P[db] = E.P[sb + src];
-        E.NV[db] = E.NV[sb + src];
-        E.FC[db] = -1;
-        if (src_fc >= 0) {
+        if (sm.y >= 0) {
             queue[0] = 0;
-            queue[1] = src_fc;
-            queue[2] = E.NV[sb + src];
-            queue[3] = 1;
+            queue[1] = sm.y;
+            queue[2] = sm.z;
+            queue[3] = sm.w;
         }
     }
-    if (src_fc >= 0) q_tail = 1;
+    if (sm.y >= 0) q_tail = 1;
     __syncthreads();
     int dtop = 1, nblk = 0;
     bool full = false;
@@ -735,24 +779,22 @@ __global__ __launch_bounds__(kWave) void k_advance(Dev E, const int32_t *moves) 
         const int dst = queue[4 * q_head + 0];
         const int sfc = queue[4 * q_head + 1];
         const int nv = queue[4 * q_head + 2];
-        const int dep = queue[4 * q_head + 3];
-        const int k = S - (nst_root + dep);
+        const int k = queue[4 * q_head + 3];
         if ((long long)dtop + k > E.cap || nblk >= E.qcap) {
             full = true;
             break;
         }
-        if (lane == 0) E.FC[db + dst] = dtop;
+        if (lane == 0) *m_fc(E.M + db, dst) = dtop;
         for (int r0 = 0; r0 < k; r0 += kWave) {
             const int r = r0 + lane;
             if (r < k) E.P[db + dtop + r] = E.P[sb + sfc + r];
-            int cfc = -1, cnv = 0;
+            int cfc = -1;
+            int4 cm = make_int4(0, -1, 0, 0);
             if (r < nv) {
-                cfc = E.FC[sb + sfc + r];
-                cnv = E.NV[sb + sfc + r];
-                E.N[db + dtop + r] = E.N[sb + sfc + r];
-                E.W[db + dtop + r] = E.W[sb + sfc + r];
-                E.NV[db + dtop + r] = cnv;
-                E.FC[db + dtop + r] = -1;
+                cm = E.M[sb + sfc + r];
+                cfc = cm.y;
+                E.M[db + dtop + r] = make_int4(cm.x, -1, cm.z, cm.w);
+                E.Wsum[db + dtop + r] = E.Wsum[sb + sfc + r];
             }
             const unsigned long long has = __ballot(cfc >= 0);
             if (cfc >= 0) {
@@ -760,8 +802,8 @@ __global__ __launch_bounds__(kWave) void k_advance(Dev E, const int32_t *moves) 
                 if (pos < E.qcap) {
                     queue[4 * pos + 0] = dtop + r;
                     queue[4 * pos + 1] = cfc;
-                    queue[4 * pos + 2] = cnv;
-                    queue[4 * pos + 3] = dep + 1;
+                    queue[4 * pos + 2] = cm.z;
+                    queue[4 * pos + 3] = cm.w;
                 }
             }
             q_tail += __popcll(has);
@@ -793,35 +835,30 @@ __global__ __launch_bounds__(kWave) void k_step_games(Dev E, const int32_t *move
     const int lane = threadIdx.x;
     const int S = E.S;
     uint64_t st[2][kWords];
-#pragma unroll
-    for (int j = 0; j < kWords; ++j) {
-        st[0][j] = E.root_stones[((long long)g * 2 + 0) * kWords + j];
-        st[1][j] = E.root_stones[((long long)g * 2 + 1) * kWords + j];
-    }
-    const int m = moves[g];
+    load_board(E.root_stones, g, st);
+    const int mv = moves[g];
     int to_move = E.root_to_move[g];
-    if (m >= 0) {
+    if (mv >= 0) {
         uint64_t occ[kWords];
 #pragma unroll
         for (int j = 0; j < kWords; ++j) occ[j] = st[0][j] | st[1][j];
-        if (m >= S || test_bit(occ, m)) {
+        const Legal L = legal_of(E, occ, lane);
+        int rank = 0, cell = 0;
+        if (!locate_action(E, occ, L, mv, rank, cell)) {
             flag(E, g, RZ_FLAG_ILLEGAL_MOVE, lane);
         } else {
-            if (to_move == 0) set_bit(st[0], m); else set_bit(st[1], m);
+            if (to_move == 0) set_bit(st[0], cell); else set_bit(st[1], cell);
             to_move ^= 1;
             if (lane == 0) {
                 E.root_to_move[g] = to_move;
-                E.root_last[g] = m;
+                E.root_last[g] = cell;
             }
-            if (lane < 2 * kWords) {
-                const int colour = lane / kWords, j = lane % kWords;
-                E.root_stones[((long long)g * 2 + colour) * kWords + j] = word_of(st[colour], j);
-            }
+            store_board(E.root_stones, g, st, lane);
         }
     }
     int who = -1;
-    if (line_anywhere(st[0], S, E.B, E.n_row, lane)) who = 0;
-    else if (line_anywhere(st[1], S, E.B, E.n_row, lane)) who = 1;
+    if (line_anywhere(st[0], S, E.BH, E.BW, E.n_row, lane)) who = 0;
+    else if (line_anywhere(st[1], S, E.BH, E.BW, E.n_row, lane)) who = 1;
     const bool over = who >= 0 || count_bits(st[0]) + count_bits(st[1]) == S;
     if (lane == 0) {
         if (winner) winner[g] = who;
@@ -872,13 +909,8 @@ __global__ void k_set_active(Dev E, const uint8_t *active) {
 __global__ __launch_bounds__(kWave) void k_encode(Dev E, int which, float *obs) {
     const int g = blockIdx.x;
     const int lane = threadIdx.x;
-    const uint64_t *src = which == 0 ? E.leaf_stones : E.root_stones;
     uint64_t st[2][kWords];
-#pragma unroll
-    for (int j = 0; j < kWords; ++j) {
-        st[0][j] = src[((long long)g * 2 + 0) * kWords + j];
-        st[1][j] = src[((long long)g * 2 + 1) * kWords + j];
-    }
+    load_board(which == 0 ? E.leaf_stones : E.root_stones, g, st);
     const int to_move = which == 0 ? E.leaf_to_move[g] : E.root_to_move[g];
     const int last = which == 0 ? E.leaf_last[g] : E.root_last[g];
     const int nst = count_bits(st[0]) + count_bits(st[1]);
@@ -973,11 +1005,23 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     *out = nullptr;
     if (cfg->abi_version != RZ_ABI_VERSION)
         return fail(RZ_ERR_ARG, "abi_version %d != library %d", cfg->abi_version, RZ_ABI_VERSION);
-    if (cfg->game_kind != RZ_GAME_GOMOKU) return fail(RZ_ERR_ARG, "unknown game_kind %d", cfg->game_kind);
-    if (cfg->board_size < 1 || cfg->board_size > RZ_MAX_BOARD_SIZE)
-        return fail(RZ_ERR_ARG, "board_size %d not in 1..%d", cfg->board_size, RZ_MAX_BOARD_SIZE);
-    if (cfg->n_in_row < 1 || cfg->n_in_row > cfg->board_size)
-        return fail(RZ_ERR_ARG, "n_in_row %d not in 1..board_size", cfg->n_in_row);
+    int BH, BW, A, n_row = cfg->n_in_row;
+    if (cfg->game_kind == RZ_GAME_GOMOKU) {
+        if (cfg->board_size < 1 || cfg->board_size > RZ_MAX_BOARD_SIZE)
+            return fail(RZ_ERR_ARG, "board_size %d not in 1..%d", cfg->board_size, RZ_MAX_BOARD_SIZE);
+        BH = BW = cfg->board_size;
+        A = BH * BW;
+    } else if (cfg->game_kind == RZ_GAME_CONNECT4) {
+        BH = cfg->board_height > 0 ? cfg->board_height : 6;
+        BW = cfg->board_width > 0 ? cfg->board_width : 7;
+        if (n_row == 0) n_row = 4;
+        if (BH > RZ_MAX_BOARD_SIZE || BW > RZ_MAX_BOARD_SIZE)
+            return fail(RZ_ERR_ARG, "board %dx%d exceeds %d", BH, BW, RZ_MAX_BOARD_SIZE);
+        A = BW;
+    } else {
+        return fail(RZ_ERR_ARG, "unknown game_kind %d", cfg->game_kind);
+    }
+    if (n_row < 1 || (n_row > BH && n_row > BW)) return fail(RZ_ERR_ARG, "n_in_row %d does not fit the board", n_row);
     if (cfg->n_games < 1) return fail(RZ_ERR_ARG, "n_games must be >= 1");
     if (cfg->n_playout < 1) return fail(RZ_ERR_ARG, "n_playout must be >= 1");
     if (cfg->score_mode != RZ_SCORE_UCT_REF && cfg->score_mode != RZ_SCORE_PUCT)
@@ -994,17 +1038,20 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     e->cfg = *cfg;
     Dev &D = e->dev;
     memset(&D, 0, sizeof(D));
-    const int S = cfg->board_size * cfg->board_size;
+    const int S = BH * BW;
     const double pf = cfg->pool_factor > 0.0 ? cfg->pool_factor : 2.0;
+    D.kind = cfg->game_kind;
+    D.BH = BH;
+    D.BW = BW;
     D.S = S;
-    D.B = cfg->board_size;
-    D.n_row = cfg->n_in_row;
+    D.A = A;
+    D.n_row = n_row;
     D.n_games = cfg->n_games;
     D.score_mode = cfg->score_mode;
     D.add_noise = cfg->add_noise ? 1 : 0;
     D.noise_seed = (uint64_t)(uint32_t)cfg->noise_seed;
     D.c_puct = cfg->c_puct;
-    D.cap = (long long)(pf * (double)cfg->n_playout * (double)S) + S + 2;
+    D.cap = (long long)(pf * (double)cfg->n_playout * (double)A) + A + 2;
     D.qcap = (int)(pf * (double)cfg->n_playout) + 8;
     D.path_stride = S + 2;
     D.logtab_n = (long long)cfg->n_playout * (S + 1) + 2;
@@ -1017,10 +1064,8 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     int rc = RZ_OK;
 #define RZ_ALLOC(field, count)                               \
     if (rc == RZ_OK) rc = dev_alloc(e, &D.field, (count))
-    RZ_ALLOC(N, slots);
-    RZ_ALLOC(W, slots);
-    RZ_ALLOC(FC, slots);
-    RZ_ALLOC(NV, slots);
+    RZ_ALLOC(M, slots);
+    RZ_ALLOC(Wsum, slots);
     RZ_ALLOC(P, slots);
     RZ_ALLOC(cur_arena, G);
     RZ_ALLOC(top, G);
@@ -1100,6 +1145,14 @@ int rz_destroy(rz_engine *e) {
     (void)hipDeviceSynchronize();
     for (void *p : e->allocs) (void)hipFree(p);
     delete e;
+    return RZ_OK;
+}
+
+int rz_geometry(rz_engine *e, int32_t *height, int32_t *width, int32_t *n_actions) {
+    if (e == nullptr) return fail(RZ_ERR_ARG, "engine handle is NULL");
+    if (height) *height = e->dev.BH;
+    if (width) *width = e->dev.BW;
+    if (n_actions) *n_actions = e->dev.A;
     return RZ_OK;
 }
 
@@ -1216,19 +1269,19 @@ int rz_expand_backup_f64(rz_engine *e, const float *d_logp, const double *d_valu
     return launched("k_expand_backup");
 }
 
+int rz_expand_backup_probs(rz_engine *e, const float *d_probs, const double *d_value, void *stream) {
+    RZ_ENTER(e);
+    RZ_NEED(d_value);
+    k_expand_backup<double, true><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_probs, d_value);
+    return launched("k_expand_backup");
+}
+
 int rz_tree_step(rz_engine *e, const float *d_logp, const float *d_value, float *d_obs, void *stream) {
     RZ_ENTER(e);
     RZ_NEED(d_value);
     e->n_select += 1;
     k_tree_step<float><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_logp, d_value, d_obs);
     return launched("k_tree_step");
-}
-
-int rz_expand_backup_probs(rz_engine *e, const float *d_probs, const double *d_value, void *stream) {
-    RZ_ENTER(e);
-    RZ_NEED(d_value);
-    k_expand_backup<double, true><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_probs, d_value);
-    return launched("k_expand_backup");
 }
 
 int rz_root_visits(rz_engine *e, int32_t *d_visits, void *stream) {
@@ -1319,10 +1372,16 @@ int rz_copy_arena(rz_engine *e, int32_t game, int64_t max_slots, int32_t *h_n, d
     long long n = top < max_slots ? top : max_slots;
     if (n <= 0) return RZ_OK;
     const long long base = ((long long)game * 2 + arena) * e->dev.cap;
-    if (h_n) RZ_HIP(hipMemcpy(h_n, e->dev.N + base, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (h_w) RZ_HIP(hipMemcpy(h_w, e->dev.W + base, (size_t)n * 8, hipMemcpyDeviceToHost));
-    if (h_first_child) RZ_HIP(hipMemcpy(h_first_child, e->dev.FC + base, (size_t)n * 4, hipMemcpyDeviceToHost));
-    if (h_n_visited) RZ_HIP(hipMemcpy(h_n_visited, e->dev.NV + base, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (h_n || h_first_child || h_n_visited) {
+        std::vector<int4> meta((size_t)n);
+        RZ_HIP(hipMemcpy(meta.data(), e->dev.M + base, (size_t)n * sizeof(int4), hipMemcpyDeviceToHost));
+        for (long long i = 0; i < n; ++i) {
+            if (h_n) h_n[i] = meta[(size_t)i].x;
+            if (h_first_child) h_first_child[i] = meta[(size_t)i].y;
+            if (h_n_visited) h_n_visited[i] = meta[(size_t)i].z;
+        }
+    }
+    if (h_w) RZ_HIP(hipMemcpy(h_w, e->dev.Wsum + base, (size_t)n * 8, hipMemcpyDeviceToHost));
     if (h_prior) RZ_HIP(hipMemcpy(h_prior, e->dev.P + base, (size_t)n * 4, hipMemcpyDeviceToHost));
     return RZ_OK;
 }

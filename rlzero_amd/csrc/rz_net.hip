@@ -53,7 +53,7 @@ struct NetDev {
     const float *fc_val1_b;      // [64]
     const float *fc_val2_w;      // [64]
     const float *fc_val2_b;      // [1]
-    int B, S, Npad, steps_act, steps_val;  // steps_*: k-steps of 4, multiples of 4*kHeadU
+    int BH, BW, S, A, Npad, steps_act, steps_val;  // A policy outputs; steps_*: k-steps of 4, multiples of 4*kHeadU
 };
 
 // Operand fragments of one input-channel group (4 channels x 9 taps) for a wave that owns TM
@@ -133,9 +133,9 @@ __device__ __forceinline__ void conv_rows(const float *__restrict__ in, const f3
 // out[cout][y+1][x+1] = relu(acc + bias[cout]) for the lane's 4 channels of every tile/row.
 template <int TM>
 __device__ __forceinline__ void store_relu(float *__restrict__ out, const float *__restrict__ bias, int tile0,
-                                           int row0, int lane, int B, const f32x4 (&acc)[TM][8]) {
+                                           int row0, int lane, int BH, int BW, const f32x4 (&acc)[TM][8]) {
     const int x = lane & 15, q = lane >> 4;
-    if (x >= B) return;
+    if (x >= BW) return;
 #pragma unroll
     for (int m = 0; m < TM; ++m) {
         const int c0 = (tile0 + m) * 16 + 4 * q;
@@ -143,7 +143,7 @@ __device__ __forceinline__ void store_relu(float *__restrict__ out, const float 
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int y = row0 + t;
-            if (y >= B) continue;
+            if (y >= BH) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 out[(c0 + j) * kPlane + (y + 1) * kRowW + (x + 1)] = fmaxf(acc[m][t][j] + bv[j], 0.0f);
@@ -170,12 +170,12 @@ __global__ __launch_bounds__(kTrunkThreads) void k_trunk(NetDev nd, const float 
     float *c2 = c1 + kPlanesC1 * kPlane;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q4 = wave & 3, rh = wave >> 2;
-    const int B = nd.B, S = nd.S;
+    const int BH = nd.BH, BW = nd.BW, S = nd.S;
     const int board = blockIdx.x;
     if (board >= n_boards) return;
     const int row0 = 8 * rh;
-    const int n_rows = (B - row0 == 7) ? 7 : 8;
-    const bool busy = row0 < B;  // a wave whose rows are all outside the board only hits barriers
+    const int n_rows = (BH - row0 == 7) ? 7 : 8;
+    const bool busy = row0 < BH;  // a wave whose rows are all outside the board only hits barriers
 
     // zero the halo planes (interiors are overwritten below), then stage the observation
     {
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kTrunkThreads) void k_trunk(NetDev nd, const float 
     {
         const float *src = obs + (size_t)board * 4 * S;
         for (int i = tid; i < 4 * S; i += kTrunkThreads) {
-            const int c = i / S, r = i - c * S, y = r / B, x = r - y * B;
+            const int c = i / S, r = i - c * S, y = r / BW, x = r - y * BW;
             in0[c * kPlane + (y + 1) * kRowW + (x + 1)] = src[i];
         }
     }
@@ -196,14 +196,14 @@ __global__ __launch_bounds__(kTrunkThreads) void k_trunk(NetDev nd, const float 
         f32x4 acc[1][8];
         zero_acc<1>(acc);
         conv_rows<4, 1>(in0, nd.w1, q4, row0, n_rows, lane, acc);
-        store_relu<1>(c1, nd.b1, q4, row0, lane, B, acc);
+        store_relu<1>(c1, nd.b1, q4, row0, lane, BH, BW, acc);
     }
     __syncthreads();
     if (busy) {   // conv2: 32 -> 64 = one tile per quarter
         f32x4 acc[1][8];
         zero_acc<1>(acc);
         conv_rows<32, 1>(c1, nd.w2, q4, row0, n_rows, lane, acc);
-        store_relu<1>(c2, nd.b2, q4, row0, lane, B, acc);
+        store_relu<1>(c2, nd.b2, q4, row0, lane, BH, BW, acc);
     }
     __syncthreads();
     // conv3: 64 -> 128 (two tiles per quarter), kept in registers and fed to the 1x1 head convs
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kTrunkThreads) void k_trunk(NetDev nd, const float 
     {
         float *dst = feat + (size_t)board * 6 * S;
         for (int i = tid; i < 6 * S; i += kTrunkThreads) {
-            const int o = i / S, r = i - o * S, y = r / B, x = r - y * B;
+            const int o = i / S, r = i - o * S, y = r / BW, x = r - y * BW;
             float v = nd.bh[o];
 #pragma unroll
             for (int k = 0; k < 4; ++k) v += partial[((k * 6 + o) * 16 + y) * 16 + x];
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(64) void k_heads_finish(NetDev nd, const float *__r
     __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= n_boards) return;
-    const int S = nd.S;
+    const int S = nd.A;  // number of policy outputs
     const float *r = raw + (size_t)b * nd.Npad;
     float v[4];
     float mx = -INFINITY;
@@ -424,23 +424,28 @@ std::vector<f32x4> pack_conv(const float *w, int cout, int cin) {
 
 extern "C" {
 
-int rz_net_create(int32_t board_size, int32_t device, rz_net **out) {
+int rz_net_create(int32_t height, int32_t width, int32_t n_actions, int32_t device, rz_net **out) {
     if (out == nullptr) return net_fail(RZ_ERR_ARG, "out is NULL");
     *out = nullptr;
-    if (board_size < 1 || board_size > RZ_MAX_BOARD_SIZE) return net_fail(RZ_ERR_ARG, "board_size out of range");
+    if (height < 1 || height > RZ_MAX_BOARD_SIZE || width < 1 || width > RZ_MAX_BOARD_SIZE)
+        return net_fail(RZ_ERR_ARG, "board dimensions out of range");
+    if (n_actions < 1 || n_actions > RZ_MAX_BOARD_SIZE * RZ_MAX_BOARD_SIZE)
+        return net_fail(RZ_ERR_ARG, "n_actions out of range");
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || device < 0 || device >= n_dev)
         return net_fail(RZ_ERR_ARG, "bad device ordinal");
     rz_net *net = new (std::nothrow) rz_net();
     if (!net) return net_fail(RZ_ERR_OOM, "host allocation failed");
-    net->board_size = board_size;
+    net->board_size = height;
     net->device = device;
     memset(&net->dev, 0, sizeof(net->dev));
-    net->dev.B = board_size;
-    net->dev.S = board_size * board_size;
+    net->dev.BH = height;
+    net->dev.BW = width;
+    net->dev.S = height * width;
+    net->dev.A = n_actions;
     {
         NetDev &D = net->dev;
-        D.Npad = (D.S + 15) / 16 * 16;
+        D.Npad = (D.A + 15) / 16 * 16;
         D.steps_act = (4 * D.S + 16 * kHeadU - 1) / (16 * kHeadU) * (4 * kHeadU);
         D.steps_val = (2 * D.S + 16 * kHeadU - 1) / (16 * kHeadU) * (4 * kHeadU);
     }
@@ -495,7 +500,7 @@ int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params) {
     }
     {
         std::vector<float> t((size_t)4 * D.steps_act * D.Npad, 0.0f), bias((size_t)D.Npad, 0.0f);
-        for (int j = 0; j < S; ++j) {
+        for (int j = 0; j < D.A; ++j) {
             bias[j] = h_params[9][j];
             for (int k = 0; k < 4 * S; ++k) t[(size_t)k * D.Npad + j] = h_params[8][(size_t)j * 4 * S + k];
         }

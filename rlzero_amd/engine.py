@@ -88,9 +88,15 @@ class HipNet(object):
         if dev.type != 'cuda' or not torch.cuda.is_available():
             raise HipError('HipNet needs an MI355X (device=%r); there is no CPU fallback' % (device, ))
         self.device = torch.device('cuda', dev.index if dev.index is not None else torch.cuda.current_device())
-        self.board_size, self.n_cells = int(board_size), int(board_size) ** 2
+        if isinstance(board_size, (tuple, list)):  # (rows, cols, n_actions), e.g. Connect4 (6, 7, 7)
+            self.rows, self.cols, self.n_actions = (int(v) for v in board_size)
+        else:
+            self.rows = self.cols = int(board_size)
+            self.n_actions = self.rows * self.cols
+        self.board_size, self.n_cells = board_size, self.rows * self.cols
         handle = ctypes.c_void_p()
-        check(self.lib.rz_net_create(self.board_size, self.device.index, ctypes.byref(handle)), 'rz_net_create')
+        check(self.lib.rz_net_create(self.rows, self.cols, self.n_actions, self.device.index,
+                                     ctypes.byref(handle)), 'rz_net_create')
         self.handle = handle
         self.max_boards = 0
         self._want = int(max_boards)
@@ -120,7 +126,7 @@ class HipNet(object):
         if n > self.max_boards:
             self.reserve(n)
         if logp is None:
-            logp = t.empty((n, self.n_cells), dtype=t.float32, device=self.device)
+            logp = t.empty((n, self.n_actions), dtype=t.float32, device=self.device)
         if value is None:
             value = t.empty(n, dtype=t.float32, device=self.device)
         st = ctypes.c_void_p(t.cuda.current_stream(self.device).cuda_stream)
@@ -205,7 +211,7 @@ class HostEvaluator(object):
         stones, to_move, last, term = eng.get_leaves()
         active = eng.active_host
         values = np.zeros(eng.n_games, dtype=np.float64)
-        probs = np.zeros((eng.n_games, eng.n_cells), dtype=np.float32)
+        probs = np.zeros((eng.n_games, eng.n_actions), dtype=np.float32)
         for g in range(eng.n_games):
             if not active[g]:
                 continue
@@ -237,7 +243,9 @@ class MCTSEngine(object):
     """``n_games`` independent trees searched in lock-step on one GPU."""
 
     def __init__(self, board_size, n_in_row, n_games=1, n_playout=1000, c_puct=5.0,
-                 device='cuda:0', pool_factor=2.0, score_mode='uct_ref', add_noise=False, noise_seed=0):
+                 device='cuda:0', pool_factor=2.0, score_mode='uct_ref', add_noise=False, noise_seed=0,
+                 game='gomoku'):
+        """``board_size``: int B (Gomoku / TicTacToe, B x B) or (rows, cols) for ``game='connect4'``."""
         import torch
         self.lib = _hip.load()
         self.torch = torch
@@ -246,23 +254,33 @@ class MCTSEngine(object):
             raise HipError('the MCTS engine needs an MI355X (device=%r, cuda available=%s); '
                            'there is no CPU fallback' % (device, torch.cuda.is_available()))
         self.device = torch.device('cuda', dev.index if dev.index is not None else torch.cuda.current_device())
-        self.board_size, self.n_in_row = int(board_size), int(n_in_row)
-        self.n_cells = self.board_size ** 2
+        self.game = game
+        if game == 'connect4':
+            rows, cols = (6, 7) if board_size is None else (int(board_size[0]), int(board_size[1]))
+            self.board_size = (rows, cols)
+        else:
+            rows = cols = int(board_size)
+            self.board_size = rows
+        self.rows, self.cols, self.n_in_row = rows, cols, int(n_in_row)
+        self.n_cells = rows * cols
+        self.n_actions = cols if game == 'connect4' else self.n_cells
         self.n_games, self.n_playout, self.c_puct = int(n_games), int(n_playout), float(c_puct)
         self.score_mode = {'uct_ref': _hip.SCORE_UCT_REF, 'puct': _hip.SCORE_PUCT}[score_mode] \
             if isinstance(score_mode, str) else int(score_mode)
         self.add_noise = bool(add_noise)
-        cfg = _hip.RzConfig(abi_version=_hip.ABI_VERSION, game_kind=0, board_size=self.board_size,
+        cfg = _hip.RzConfig(abi_version=_hip.ABI_VERSION,
+                            game_kind=_hip.GAME_CONNECT4 if game == 'connect4' else _hip.GAME_GOMOKU,
+                            board_size=rows if game != 'connect4' else 0,
                             n_in_row=self.n_in_row, n_games=self.n_games, n_playout=self.n_playout,
                             score_mode=self.score_mode, add_noise=1 if add_noise else 0, c_puct=self.c_puct,
                             pool_factor=float(pool_factor), device=self.device.index,
-                            noise_seed=int(noise_seed) & 0x7FFFFFFF)
+                            noise_seed=int(noise_seed) & 0x7FFFFFFF, board_height=rows, board_width=cols)
         handle = ctypes.c_void_p()
         check(self.lib.rz_create(ctypes.byref(cfg), ctypes.byref(handle)), 'rz_create')
         self.handle = handle
-        G, S, B = self.n_games, self.n_cells, self.board_size
+        G, S = self.n_games, self.n_actions
         kw = dict(device=self.device)
-        self.obs = torch.zeros((G, 4, B, B), dtype=torch.float32, **kw)
+        self.obs = torch.zeros((G, 4, rows, cols), dtype=torch.float32, **kw)
         self.logp = torch.zeros((G, S), dtype=torch.float32, **kw)
         self.value = torch.zeros(G, dtype=torch.float32, **kw)
         self.value64 = torch.zeros(G, dtype=torch.float64, **kw)
@@ -495,12 +513,30 @@ class MCTSEngine(object):
             fc = int(ar['FC'][slot])
             if fc < 0:
                 continue
-            empties = [c for c in range(self.n_cells) if not (occ >> c) & 1]
+            legal = self.legal_actions(occ)
             for r in range(int(ar['NV'][slot])):
                 if int(ar['N'][fc + r]) > 0:  # PUCT initialises every child; only visited ones count
-                    a = empties[r]
-                    stack.append((path + (a, ), fc + r, occ | (1 << a)))
+                    a = legal[r]
+                    stack.append((path + (a, ), fc + r, occ | (1 << self.cell_of_action(occ, a))))
         return out
+
+    # ------------------------------------------------------------------ rules helpers (host)
+    def legal_actions(self, occ):
+        """Ascending legal actions of a position given its occupancy bitboard (Python int)."""
+        if self.game == 'connect4':
+            top = (self.rows - 1) * self.cols
+            return [c for c in range(self.cols) if not (occ >> (top + c)) & 1]
+        return [c for c in range(self.n_cells) if not (occ >> c) & 1]
+
+    def cell_of_action(self, occ, action):
+        """Cell a move occupies: the cell itself (Gomoku) or the lowest empty cell of the column."""
+        if self.game != 'connect4':
+            return int(action)
+        for row in range(self.rows):
+            cell = row * self.cols + int(action)
+            if not (occ >> cell) & 1:
+                return cell
+        raise ValueError('column %d is full' % action)
 
     def uct_scores(self, w, n, n_parent, c_puct):
         """The select arithmetic alone (for bit-exactness tests)."""

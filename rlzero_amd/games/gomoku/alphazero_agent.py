@@ -19,10 +19,11 @@ from .policy_value_net import PolicyValueNet
 class AlphaZeroAgent(object):
 
     def __init__(self, board_size: int, learning_rate: float = 0.001, weight_decay: float = 1e-4,
-                 device: str = 'cpu') -> None:
+                 device: str = 'cpu', board_width: int = None, n_actions: int = None) -> None:
         self.board_size = board_size
+        self.board_width = board_width if board_width is not None else board_size
         self.device = device
-        self.policy_value_net = PolicyValueNet(board_size).to(device)
+        self.policy_value_net = PolicyValueNet(board_size, board_width, n_actions).to(device)
         self.optimizer = optim.Adam(self.policy_value_net.parameters(), lr=learning_rate,
                                     weight_decay=weight_decay)
 
@@ -34,8 +35,7 @@ class AlphaZeroAgent(object):
         probabilities are exp(log_softmax) over ALL cells indexed by the legal ones (not
         renormalised), value is a Python float (alphazero_agent.py:31-46)."""
         legal = game_env.leagel_actions()
-        size = self.board_size
-        obs = np.ascontiguousarray(game_env.current_state().reshape(-1, 4, size, size))
+        obs = np.ascontiguousarray(game_env.current_state().reshape(-1, 4, self.board_size, self.board_width))
         log_probs, value = self.policy_value_net(torch.from_numpy(obs).float().to(self.device))
         probs = np.exp(log_probs.detach().cpu().numpy().flatten())
         return zip(legal, probs[legal]), value.item()

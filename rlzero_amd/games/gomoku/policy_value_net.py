@@ -12,16 +12,21 @@ import torch.nn.functional as F
 
 class PolicyValueNet(nn.Module):
 
-    def __init__(self, board_size: int) -> None:
+    def __init__(self, board_size: int, board_width: int = None, n_actions: int = None) -> None:
+        """``PolicyValueNet(B)`` is the reference's square network.  ``board_width`` / ``n_actions``
+        (extensions, e.g. Connect4: PolicyValueNet(6, 7, 7)) make the board board_size x board_width
+        with n_actions policy outputs; the layers and their names are unchanged."""
         super().__init__()
         self.board_size = board_size
-        cells = board_size * board_size
+        self.board_width = board_width if board_width is not None else board_size
+        cells = board_size * self.board_width
+        self.n_actions = n_actions if n_actions is not None else cells
         # creation order = the reference's, so a seeded default init gives equal weights
         self.conv1 = nn.Conv2d(4, 32, kernel_size=3, padding=1)
         self.conv2 = nn.Conv2d(32, 64, kernel_size=3, padding=1)
         self.conv3 = nn.Conv2d(64, 128, kernel_size=3, padding=1)
         self.act_conv1 = nn.Conv2d(128, 4, kernel_size=1)
-        self.act_fc1 = nn.Linear(4 * cells, cells)
+        self.act_fc1 = nn.Linear(4 * cells, self.n_actions)
         self.val_conv1 = nn.Conv2d(128, 2, kernel_size=1)
         self.val_fc1 = nn.Linear(2 * cells, 64)
         self.val_fc2 = nn.Linear(64, 1)

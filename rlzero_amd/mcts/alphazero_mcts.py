@@ -84,8 +84,9 @@ class AlphaZeroMCTS(object):
     # ------------------------------------------------------------------ engine binding
     def _bind(self, game_env):
         size, n_row = game_env.board_size, game_env.n_in_row
+        kind = getattr(game_env, 'game_kind', 'gomoku')
         eng = self._engine
-        if eng is not None and (eng.board_size, eng.n_in_row) == (size, n_row) and \
+        if eng is not None and (eng.game, eng.board_size, eng.n_in_row) == (kind, size, n_row) and \
                 eng.n_playout >= self.n_playout and eng.c_puct == float(self._c_puct):
             return eng
         if eng is not None:
@@ -93,24 +94,29 @@ class AlphaZeroMCTS(object):
         agent = getattr(self.policy_value_fn, '__self__', None)
         net = getattr(agent, 'policy_value_net', None)
         agent_dev = str(getattr(agent, 'device', 'cpu'))
-        fast = net is not None and getattr(agent, 'board_size', None) == size and \
+        rows, cols = (size, size) if kind == 'gomoku' else size
+        fast = net is not None and (getattr(agent, 'board_size', None), getattr(agent, 'board_width', rows)) == \
+            (rows, cols) and \
             agent_dev.startswith('cuda') and \
             getattr(self.policy_value_fn, '__func__', None) is getattr(type(agent), 'policy_value_fn', None)
         device = self._device or (agent_dev if fast else os.environ.get('RLZERO_DEVICE', 'cuda:0'))
         eng = MCTSEngine(size, n_row, n_games=1, n_playout=self.n_playout, c_puct=self._c_puct,
-                         device=device, score_mode=self.score_mode, add_noise=self.add_noise,
+                         device=device, score_mode=self.score_mode, add_noise=self.add_noise, game=kind,
                          noise_seed=int(np.random.randint(0, 2 ** 31 - 1)) if self.add_noise else 0)
         if fast:
             from ..games.gomoku.policy_value_net import PolicyValueNet
             # the reference architecture runs on the hand-written fused kernels (csrc/rz_net.hip);
             # any other nn.Module with the same call signature goes through PyTorch-ROCm
-            self._evaluator = HipNetEvaluator(net, size, eng.device, max_boards=1) \
+            self._evaluator = HipNetEvaluator(net, (rows, cols, eng.n_actions), eng.device, max_boards=1) \
                 if type(net) is PolicyValueNet else NetEvaluator(net)
         else:
+            from ..games.connect4.connect4_env import Connect4Env
             from ..games.gomoku.gomoku_env import GomokuEnv
-            self._evaluator = HostEvaluator(
-                lambda env: self.policy_value_fn(env),
-                lambda s0, s1, to_move, last: GomokuEnv.from_bitboards(size, n_row, s0, s1, to_move, last))
+            if kind == 'connect4':
+                make = lambda s0, s1, to_move, last: Connect4Env.from_bitboards(rows, cols, n_row, s0, s1, to_move, last)  # noqa: E731
+            else:
+                make = lambda s0, s1, to_move, last: GomokuEnv.from_bitboards(size, n_row, s0, s1, to_move, last)  # noqa: E731
+            self._evaluator = HostEvaluator(lambda env: self.policy_value_fn(env), make)
         self._engine = eng
         return eng
 
@@ -118,7 +124,7 @@ class AlphaZeroMCTS(object):
         eng = self._bind(game_env)
         s0, s1 = _bitboards_of(game_env)
         stones = np.array([[int_to_bits(s0), int_to_bits(s1)]], dtype=np.uint64)
-        eng.set_roots(stones, [game_env.current_player()], [game_env.last_move])
+        eng.set_roots(stones, [game_env.current_player()], [getattr(game_env, 'last_cell', game_env.last_move)])
         self._root_occ = s0 | s1
         self._legal = tuple(game_env.leagel_actions())
         return eng
@@ -188,7 +194,7 @@ class AlphaZeroPlayer(Player):
 
     def get_action(self, game_env, temperature: float = 1e-3, return_prob: bool = False):
         sensible_moves = game_env.leagel_actions()
-        move_probs = np.zeros(game_env.board_size * game_env.board_size)
+        move_probs = np.zeros(getattr(game_env, 'n_actions', None) or game_env.board_size * game_env.board_size)
         if len(sensible_moves) == 0:
             print('WARNING: the board is full')
             return None

@@ -49,14 +49,15 @@ class RolloutMCTS(object):
 
     def _bind(self, game_env):
         size, n_row = game_env.board_size, game_env.n_in_row
+        kind = getattr(game_env, 'game_kind', 'gomoku')
         eng = self._engine
-        if eng is not None and (eng.board_size, eng.n_in_row) == (size, n_row) and \
+        if eng is not None and (eng.game, eng.board_size, eng.n_in_row) == (kind, size, n_row) and \
                 eng.n_playout >= self.n_playout and eng.c_puct == float(self._c_puct):
             return eng
         if eng is not None:
             eng.close()
         self._engine = MCTSEngine(size, n_row, n_games=1, n_playout=self.n_playout, c_puct=self._c_puct,
-                                  device=self._device or os.environ.get('RLZERO_DEVICE', 'cuda:0'))
+                                  device=self._device or os.environ.get('RLZERO_DEVICE', 'cuda:0'), game=kind)
         return self._engine
 
     def simulate(self, game_env, temperature: float = 0.001):
@@ -64,7 +65,7 @@ class RolloutMCTS(object):
         eng = self._bind(game_env)
         s0, s1 = _bitboards_of(game_env)
         eng.set_roots(np.array([[int_to_bits(s0), int_to_bits(s1)]], dtype=np.uint64),
-                      [game_env.current_player()], [game_env.last_move])
+                      [game_env.current_player()], [getattr(game_env, 'last_cell', game_env.last_move)])
         self._legal = tuple(game_env.leagel_actions())
         seed = self.seed if self.seed is not None else int(np.random.randint(0, 2 ** 31 - 1))
         self.evaluator = RolloutEvaluator(seed, self.n_limit)

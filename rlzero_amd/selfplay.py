@@ -193,7 +193,7 @@ class BatchedSelfPlay(object):
         """n_playout simulations, then pick / apply one move per game.  Returns the list of
         trajectories of the games that ended with this move."""
         eng = self.eng
-        S = eng.n_cells
+        S = eng.n_actions
         running = np.nonzero(self.slot_game >= 0)[0]
         self._simulate()
         visits = np.zeros((self.n_slots, S), dtype=np.int32)
@@ -205,7 +205,7 @@ class BatchedSelfPlay(object):
         us = move_uniform(self.seed, self.slot_game[running], self.slot_ply[running])
         for s, u in zip(running, us):
             occ = self.slot_occ[s]
-            acts = np.array([c for c in range(S) if not (occ >> c) & 1])
+            acts = np.array(eng.legal_actions(occ))
             probs = visits_to_pi(visits[s, acts], self.temperature)
             pi = np.zeros(S)
             pi[acts] = probs
@@ -213,7 +213,7 @@ class BatchedSelfPlay(object):
             moves[s] = move
             self.slot_pis[s].append(pi)
             self.slot_moves[s].append(move)
-            self.slot_occ[s] = occ | (1 << move)
+            self.slot_occ[s] = occ | (1 << eng.cell_of_action(occ, move))
             self.slot_ply[s] += 1
         winner = np.zeros(self.n_slots, dtype=np.int32)
         ended = np.zeros(self.n_slots, dtype=np.uint8)
@@ -328,3 +328,24 @@ def gather_trajectories(trajs, board_size, n_in_row, dst=0, group=None):
         merged.extend(unpack_trajectories(recvs[0][r][:n_g].cpu().numpy(), recvs[1][r][:n_p].cpu().numpy(),
                                           recvs[2][r][:n_p].cpu().numpy(), board_size, n_in_row))
     return sorted(merged, key=lambda t: t.game_id)
+
+
+def broadcast_weights(module, src=0, group=None):
+    """After ``policy_update`` on rank ``src``: one broadcast of the flattened parameters
+    (1.3 MB at 15x15) so every rank's self-play uses the same network.  RCCL when the process
+    group backend is nccl; identity without a process group."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return module
+    params = [p.data for p in module.parameters()]
+    flat = torch.cat([p.reshape(-1) for p in params])
+    if dist.get_backend(group) == 'nccl' and not flat.is_cuda:
+        flat = flat.cuda()
+    dist.broadcast(flat, src=src, group=group)
+    at = 0
+    for p in params:
+        n = p.numel()
+        p.copy_(flat[at:at + n].reshape(p.shape).to(p.device))
+        at += n
+    return module

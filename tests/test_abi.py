@@ -23,7 +23,7 @@ def lib_path():
 def test_library_exports_every_declared_symbol(lib_path):
     lib = ctypes.CDLL(lib_path)
     names = _declared()
-    assert len(names) >= 26
+    assert len(names) >= 36
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
 
@@ -39,8 +39,8 @@ def test_binding_covers_the_header(lib_path):
 
 def test_config_struct_layout_matches_header():
     from rlzero_amd import _hip
-    # 8 int32, 2 doubles, 2 int32 -> 56 bytes, doubles 8-aligned at offset 32
-    assert ctypes.sizeof(_hip.RzConfig) == 56
+    # 8 int32, 2 doubles, 4 int32 -> 64 bytes, doubles 8-aligned at offset 32
+    assert ctypes.sizeof(_hip.RzConfig) == 64
     assert _hip.RzConfig.c_puct.offset == 32 and _hip.RzConfig.device.offset == 48
     assert ctypes.sizeof(_hip.RzStats) == 48
 

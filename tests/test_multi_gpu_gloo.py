@@ -45,6 +45,17 @@ def _worker(rank, world, port, n_games, result_path):
                  pis=np.concatenate([t.pis for t in merged]))
     else:
         assert merged is None
+    # weights broadcast (after policy_update on rank 0): every rank ends with rank 0's parameters
+    import torch
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    from rlzero_amd.selfplay import broadcast_weights
+    torch.manual_seed(100 + rank)
+    net = PolicyValueNet(3)
+    broadcast_weights(net, src=0)
+    torch.manual_seed(100)
+    want = PolicyValueNet(3)
+    for a, b in zip(net.parameters(), want.parameters()):
+        assert torch.equal(a, b)
     dist.barrier()
     dist.destroy_process_group()
 

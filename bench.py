@@ -195,6 +195,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--games', type=int, default=GAMES_PER_GPU, help='games per GPU')
     ap.add_argument('--board', type=int, default=BOARD)
+    ap.add_argument('--game', default='gomoku', choices=['gomoku', 'connect4'],
+                    help='connect4: 6x7, 4 in a row, 7 column actions (BASELINE config 3; pair with '
+                         '--playouts 400 --games 512)')
     ap.add_argument('--playouts', type=int, default=N_PLAYOUT)
     ap.add_argument('--evaluator', default='hipnet', choices=['hipnet', 'torchnet', 'vlin'],
                     help="hipnet: hand-written fused fp32 MFMA forward (csrc/rz_net.hip); torchnet: "
@@ -239,16 +242,20 @@ def main():
 
     board, n_row = args.board, (N_ROW if args.board >= 5 else args.board)
     cells = board * board
+    if args.game == 'connect4':
+        board, n_row, cells = (6, 7), 4, 42
     G = args.games
     lanes = max(1, min(args.lanes, G))
     per_lane = [G // lanes + (1 if i < G % lanes else 0) for i in range(lanes)]
     torch.manual_seed(0)  # identical weights on every rank
-    net = PolicyValueNet(board).to(device).eval()
+    net = (PolicyValueNet(6, 7, 7) if args.game == 'connect4' else PolicyValueNet(board)).to(device).eval()
+    net_shape = (6, 7, 7) if args.game == 'connect4' else board
     engines, evaluators = [], []
     for g_lane in per_lane:
-        eng = MCTSEngine(board, n_row, n_games=g_lane, n_playout=args.playouts, c_puct=C_PUCT, device=device)
+        eng = MCTSEngine(board, n_row, n_games=g_lane, n_playout=args.playouts, c_puct=C_PUCT, device=device,
+                         game=args.game)
         if args.evaluator == 'hipnet':
-            ev = TimedEvaluator(HipNetEvaluator(net, board, device, max_boards=g_lane), torch,
+            ev = TimedEvaluator(HipNetEvaluator(net, net_shape, device, max_boards=g_lane), torch,
                                 'k_trunk (hand-written fused fp32-MFMA conv trunk, csrc/rz_net.hip)')
         elif args.evaluator == 'torchnet':
             ev = TimedEvaluator(NetEvaluator(net), torch, 'torch/MIOpen forward (~14 kernels)')
@@ -321,8 +328,9 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32 net / f64 tree', 'data': 'synthetic (random-init net, torch.manual_seed(0); '
             'games from the empty board)',
-            'config': {'workload': 'gomoku%dx%d_n%d_selfplay_%dsims_per_move_%dgames_per_gpu'
-                                   % (board, board, n_row, args.playouts, G),
+            'config': {'workload': ('connect4_6x7_n4_selfplay_%dsims_per_move_%dgames_per_gpu' % (args.playouts, G))
+                       if args.game == 'connect4' else
+                       'gomoku%dx%d_n%d_selfplay_%dsims_per_move_%dgames_per_gpu' % (board, board, n_row, args.playouts, G),
                        'games_total': G * world, 'c_puct': C_PUCT, 'temperature': TEMPERATURE,
                        'evaluator': args.evaluator, 'score_mode': 'UCT_REF (bit-exact)',
                        'sims_per_graph': args.graph, 'lanes': lanes, 'parallelism': 'games sharded, dp%d' % world},
@@ -348,7 +356,7 @@ def main():
                                 'avg_launch_ms': round(ms, 4), 'launches_timed': n_ev,
                                 'share_of_step_time': round(ms * (total_sims / world / G) / (elapsed * 1e3), 3)}
         else:
-            per_sim = tree_bytes_per_sim(365.5, 208.8, 1.74) if board == 15 else None
+            per_sim = tree_bytes_per_sim(365.5, 208.8, 1.74) if board == 15 else None  # SURVEY.md 8d, C4
             if per_sim:
                 achieved = value / world * per_sim / 1e9
                 line['roofline'] = {'bound': 'hbm', 'kernel': 'k_select + k_expand_backup (tree only)',

@@ -61,12 +61,23 @@ def shard_game_ids(n_games_total, rank, world_size):
 class Trajectory(object):
     """One finished game: what start_self_play returns, in compact form."""
 
-    def __init__(self, game_id, board_size, n_in_row, moves, pis, winner):
+    def __init__(self, game_id, board_size, n_in_row, moves, pis, winner, game='gomoku'):
         self.game_id = int(game_id)
-        self.board_size, self.n_in_row = int(board_size), int(n_in_row)
+        self.game = game
+        self.board_size, self.n_in_row = board_size, int(n_in_row)
         self.moves = [int(m) for m in moves]
-        self.pis = np.asarray(pis, dtype=np.float64).reshape(len(self.moves), board_size * board_size)
+        pis = np.asarray(pis, dtype=np.float64)
+        self.pis = pis.reshape(len(self.moves), -1) if len(self.moves) else pis.reshape(0, 0)
         self.winner = int(winner)
+
+    def _env(self):
+        if self.game == 'connect4':
+            from .games.connect4.connect4_env import Connect4Env
+            return Connect4Env(self.board_size[0], self.board_size[1], self.n_in_row)
+        from .games.gomoku.gomoku_env import GomokuEnv
+        env = GomokuEnv(self.board_size, self.n_in_row)
+        env.reset()
+        return env
 
     def z(self):
         """+1 for the plies of the winner, -1 for the loser's, 0 on a tie (game.py:121-126)."""
@@ -76,10 +87,8 @@ class Trajectory(object):
         return np.where(movers == self.winner, 1.0, -1.0)
 
     def states(self):
-        """Observation planes before every move (GomokuEnv.current_state)."""
-        from .games.gomoku.gomoku_env import GomokuEnv
-        env = GomokuEnv(self.board_size, self.n_in_row)
-        env.reset()
+        """Observation planes before every move (current_state)."""
+        env = self._env()
         out = []
         for m in self.moves:
             out.append(env.current_state())
@@ -227,7 +236,7 @@ class BatchedSelfPlay(object):
         for s in running:
             if ended[s]:
                 done.append(Trajectory(self.slot_game[s], eng.board_size, eng.n_in_row,
-                                       self.slot_moves[s], self.slot_pis[s], winner[s]))
+                                       self.slot_moves[s], self.slot_pis[s], winner[s], game=eng.game))
                 self.slot_game[s] = -1
         return done
 
@@ -279,22 +288,23 @@ def pack_trajectories(trajs, n_cells):
     return header, moves, pis.reshape(-1, n_cells)
 
 
-def unpack_trajectories(header, moves, pis, board_size, n_in_row):
+def unpack_trajectories(header, moves, pis, board_size, n_in_row, game='gomoku'):
     out, at = [], 0
     for gid, plies, winner, _ in header:
         plies = int(plies)
-        out.append(Trajectory(gid, board_size, n_in_row, moves[at:at + plies], pis[at:at + plies], winner))
+        out.append(Trajectory(gid, board_size, n_in_row, moves[at:at + plies], pis[at:at + plies], winner,
+                              game=game))
         at += plies
     return out
 
 
-def gather_trajectories(trajs, board_size, n_in_row, dst=0, group=None):
+def gather_trajectories(trajs, board_size, n_in_row, dst=0, group=None, game='gomoku'):
     """The one exchange of the path: every rank sends its finished trajectories to ``dst``
     (one size all_gather + one padded gather per array).  Returns the merged, game-id-sorted
     list on ``dst`` and None elsewhere.  Without an initialised process group: identity."""
     import torch
     import torch.distributed as dist
-    n_cells = board_size * board_size
+    n_cells = board_size[1] if game == 'connect4' else board_size * board_size  # width of a pi row
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return sorted(trajs, key=lambda t: t.game_id)
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -326,7 +336,7 @@ def gather_trajectories(trajs, board_size, n_in_row, dst=0, group=None):
     for r in range(world):
         n_g, n_p = int(all_sizes[r, 0]), int(all_sizes[r, 1])
         merged.extend(unpack_trajectories(recvs[0][r][:n_g].cpu().numpy(), recvs[1][r][:n_p].cpu().numpy(),
-                                          recvs[2][r][:n_p].cpu().numpy(), board_size, n_in_row))
+                                          recvs[2][r][:n_p].cpu().numpy(), board_size, n_in_row, game=game))
     return sorted(merged, key=lambda t: t.game_id)
 
 

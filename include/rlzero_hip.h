@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 9
+#define RZ_ABI_VERSION 10
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 
@@ -241,6 +241,12 @@ int rz_uct_scores(rz_engine *e, const double *d_w, const int32_t *d_n, const int
  * rz_net_trunk(.., NULL, ..) + rz_net_heads == rz_net_forward (lets a caller time the
  * dominant kernel by itself). */
 typedef struct rz_net rz_net;
+enum {
+    RZ_NET_DIRECT = 0,   /* conv2/conv3 as direct implicit GEMM: bit-for-bit a k-ordered fp32 fmaf chain */
+    RZ_NET_WINOGRAD = 1  /* default: conv2/conv3 as Winograd F(2x2,3x3) on the fp32 MFMA path (2.25x fewer
+                            multiply-adds; fp32 throughout, differs from DIRECT by re-association only) */
+};
+int rz_net_set_algo(rz_net *net, int32_t algo);
 int rz_net_create(int32_t height, int32_t width, int32_t n_actions, int32_t device, rz_net **out);
 int rz_net_destroy(rz_net *net);
 int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params);

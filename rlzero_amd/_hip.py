@@ -8,13 +8,14 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64,
                     c_void_p)
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
 
 OK = 0
 SCORE_UCT_REF, SCORE_PUCT = 0, 1
 GAME_GOMOKU, GAME_CONNECT4 = 0, 1
+NET_DIRECT, NET_WINOGRAD = 0, 1
 EVAL_V0, EVAL_VLIN = 0, 1
 FLAG_NAMES = {1: 'arena full', 2: 'block queue full', 4: 'illegal move', 8: 'ln table too short',
               16: 'internal'}
@@ -73,6 +74,7 @@ _SIGNATURES = {
     'rz_uct_scores': (c_int, [P, P, P, P, c_double, P, c_int64, P]),
     'rz_net_create': (c_int, [c_int32, c_int32, c_int32, c_int32, POINTER(c_void_p)]),
     'rz_net_destroy': (c_int, [P]),
+    'rz_net_set_algo': (c_int, [P, c_int32]),
     'rz_net_load': (c_int, [P, POINTER(c_void_p), c_int32]),
     'rz_net_reserve': (c_int, [P, c_int32]),
     'rz_net_trunk': (c_int, [P, P, c_int32, P, P]),

@@ -44,6 +44,7 @@ constexpr int kTrunkThreads = 512;
 
 struct NetDev {
     const f32x4 *w1, *w2, *w3;   // packed [tile][cin_step][3][64 lanes] x 4 taps
+    const f32x4 *u2, *u3;        // Winograd-domain weights of conv2 / conv3: [tile][i'][cin_step][64 lanes] x 4 j'
     const float *b1, *b2, *b3;   // conv biases
     const float *wh;             // [6][128]: act_conv1 (4 rows) then val_conv1 (2 rows)
     const float *bh;             // [6]
@@ -159,9 +160,153 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[TM][8]) {
         for (int t = 0; t < 8; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
+// ------------------------------------------------------------------ Winograd F(2x2, 3x3)
+// conv2 / conv3 in the Winograd domain: Y = A^T [ (G g G^T) . (B^T d B) ] A per 2x2 output tile,
+// i.e. 16 element-wise products per (cout, cin) instead of 36 multiply-adds: 2.25x fewer MFMAs.
+//   * U = G g G^T is precomputed on the host (fp64, rounded once) and packed in fragment order;
+//   * V = B^T d B is formed ON THE FLY from the halo planes in LDS: one pass handles the 4
+//     components (i', j' = 0..3) of one transform row i', which need only 2 rows x 4 columns of
+//     the 4x4 input patch (4 ds_read_b64) and 8 additions per lane and channel group;
+//   * the MFMA N dimension is 16 tiles = 2 tile rows x 8 tile columns, so a wave's 8 board rows
+//     x 16 columns are two N-tiles; K = input channels only;
+//   * the output transform A^T M A is linear in M, so after each pass the 4 accumulators of a
+//     (cout tile, N-tile) are folded into the 4 output values of the tile with coefficients
+//     0 / +1 / -1 -- all 16 components of a (cout, tile) live in the same lane, no data movement.
+// fp32 throughout; differs from the direct kernel only by Winograd's re-association
+// (|error| ~1e-6 relative, far inside the 1e-4 tolerance; both paths are tested).
+template <int TM, int IP, int STEPS>
+__device__ __forceinline__ void wino_load_a(f32x4 (&a)[TM], const f32x4 *__restrict__ ubase, int s) {
+#pragma unroll
+    for (int m = 0; m < TM; ++m) a[m] = ubase[((size_t)(m * 4 + IP) * STEPS + s) * 64];
+}
+
+// the 2 patch rows x 4 columns this pass needs, for both N-tiles
+template <int IP>
+__device__ __forceinline__ void wino_load_d(float (&d)[2][2][4], const float *__restrict__ base, int s) {
+    constexpr int r0 = (IP == 0) ? 0 : (IP == 1) ? 1 : (IP == 2) ? 2 : 1;
+    constexpr int r1 = (IP == 0) ? 2 : (IP == 1) ? 2 : (IP == 2) ? 1 : 3;
+    const float *p = base + (4 * s) * kPlane;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const float *q = p + nt * 4 * kRowW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            d[nt][0][j] = q[r0 * kRowW + j];
+            d[nt][1][j] = q[r1 * kRowW + j];
+        }
+    }
+}
+
+template <int IP>
+__device__ __forceinline__ void wino_transform(const float (&d)[2][2][4], float (&v)[2][4]) {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        float t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = (IP == 1) ? d[nt][0][j] + d[nt][1][j] : d[nt][0][j] - d[nt][1][j];
+        v[nt][0] = t[0] - t[2];
+        v[nt][1] = t[1] + t[2];
+        v[nt][2] = t[2] - t[1];
+        v[nt][3] = t[1] - t[3];
+    }
+}
+
+template <int TM>
+__device__ __forceinline__ void wino_mfma(const f32x4 (&a)[TM], const float (&v)[2][4], f32x4 (&acc)[TM][2][4]) {
+#pragma unroll
+    for (int jp = 0; jp < 4; ++jp)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                acc[m][nt][jp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][jp], v[nt][jp], acc[m][nt][jp], 0, 0, 0);
+}
+
+// One transform row i' = IP.  Per channel group: transform the patch rows fetched during the
+// previous group (their registers die here), issue the next group's loads, then the MFMAs.
+template <int CIN, int TM, int IP>
+__device__ __forceinline__ void wino_pass(const float *__restrict__ base, const f32x4 *__restrict__ ubase,
+                                          f32x4 (&Y)[TM][2][4]) {
+    constexpr int kSteps = CIN / 4;
+    f32x4 acc[TM][2][4];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp) acc[m][nt][jp] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 a0[TM], a1[TM];
+    float d[2][2][4], v[2][4];
+    wino_load_a<TM, IP, kSteps>(a0, ubase, 0);
+    wino_load_d<IP>(d, base, 0);
+#pragma unroll 1
+    for (int s = 0; s < kSteps; s += 2) {
+        wino_transform<IP>(d, v);
+        __builtin_amdgcn_sched_barrier(0);
+        wino_load_a<TM, IP, kSteps>(a1, ubase, s + 1);
+        wino_load_d<IP>(d, base, s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        wino_mfma<TM>(a0, v, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        wino_transform<IP>(d, v);
+        __builtin_amdgcn_sched_barrier(0);
+        wino_load_a<TM, IP, kSteps>(a0, ubase, s + 2 < kSteps ? s + 2 : kSteps - 1);
+        wino_load_d<IP>(d, base, s + 2 < kSteps ? s + 2 : kSteps - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        wino_mfma<TM>(a1, v, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // fold this transform row into the 2x2 outputs: Y[a][b] += At[a][i'] * sum_j' At[b][j'] M[i'][j']
+    constexpr float c0 = (IP < 3) ? 1.0f : 0.0f;                       // At[0][i'] = 1 1 1 0
+    constexpr float c1 = (IP == 0) ? 0.0f : (IP == 1) ? 1.0f : -1.0f;  // At[1][i'] = 0 1 -1 -1
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const f32x4 yb0 = acc[m][nt][0] + acc[m][nt][1] + acc[m][nt][2];
+            const f32x4 yb1 = acc[m][nt][1] - acc[m][nt][2] - acc[m][nt][3];
+            if (c0 != 0.0f) {
+                Y[m][nt][0] += yb0;
+                Y[m][nt][1] += yb1;
+            }
+            if (c1 > 0.0f) {
+                Y[m][nt][2] += yb0;
+                Y[m][nt][3] += yb1;
+            } else if (c1 < 0.0f) {
+                Y[m][nt][2] -= yb0;
+                Y[m][nt][3] -= yb1;
+            }
+        }
+    // keep the fold here: without it hipcc overlaps this pass's accumulators with the next pass's
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Y[m][nt][a*2+b] = conv output (no bias) of cout tile tile0+m at rows 8rh + 4nt + 2(lane>>3 & 1) + a,
+// columns 2(lane & 7) + b, for the lane's 4 channels.
+template <int CIN, int TM>
+__device__ __forceinline__ void wino_conv(const float *__restrict__ in, const f32x4 *__restrict__ up, int tile0,
+                                          int rh, int lane, f32x4 (&Y)[TM][2][4]) {
+    constexpr int kSteps = CIN / 4;
+    const int n = lane & 15, kq = lane >> 4;
+    const int ty = n >> 3, tx = n & 7;
+    const float *base = in + kq * kPlane + (8 * rh + 2 * ty) * kRowW + 2 * tx;
+    const f32x4 *ubase = up + (size_t)tile0 * 4 * kSteps * 64 + lane;
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) Y[m][nt][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+    wino_pass<CIN, TM, 0>(base, ubase, Y);
+    wino_pass<CIN, TM, 1>(base, ubase, Y);
+    wino_pass<CIN, TM, 2>(base, ubase, Y);
+    wino_pass<CIN, TM, 3>(base, ubase, Y);
+}
+
 // Wave w = 4*rh + q4: output-channel quarter q4 (the two waves of a quarter share a SIMD, waves
 // are dealt to SIMDs cyclically) and row half rh (rows 0-7 / 8-15; on a 15x15 board the second
 // half computes 7 rows, so every SIMD carries exactly 15 row-units of each layer).
+template <bool WINO>
 __global__ __launch_bounds__(kTrunkThreads) void k_trunk(NetDev nd, const float *__restrict__ obs,
                                                          float *__restrict__ feat, int n_boards) {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
@@ -200,39 +345,89 @@ __global__ __launch_bounds__(kTrunkThreads) void k_trunk(NetDev nd, const float 
     }
     __syncthreads();
     if (busy) {   // conv2: 32 -> 64 = one tile per quarter
-        f32x4 acc[1][8];
-        zero_acc<1>(acc);
-        conv_rows<32, 1>(c1, nd.w2, q4, row0, n_rows, lane, acc);
-        store_relu<1>(c2, nd.b2, q4, row0, lane, BH, BW, acc);
+        if constexpr (WINO) {
+            f32x4 Y[1][2][4];
+            wino_conv<32, 1>(c1, nd.u2, q4, rh, lane, Y);
+            const int n = lane & 15, q = lane >> 4, ty = n >> 3, tx = n & 7;
+            const int c0 = q4 * 16 + 4 * q;
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b2 + c0);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int ab = 0; ab < 4; ++ab) {
+                    const int y = 8 * rh + 4 * nt + 2 * ty + (ab >> 1), x = 2 * tx + (ab & 1);
+                    if (y < BH && x < BW) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            c2[(c0 + j) * kPlane + (y + 1) * kRowW + (x + 1)] = fmaxf(Y[0][nt][ab][j] + bv[j], 0.0f);
+                    }
+                }
+        } else {
+            f32x4 acc[1][8];
+            zero_acc<1>(acc);
+            conv_rows<32, 1>(c1, nd.w2, q4, row0, n_rows, lane, acc);
+            store_relu<1>(c2, nd.b2, q4, row0, lane, BH, BW, acc);
+        }
     }
     __syncthreads();
     // conv3: 64 -> 128 (two tiles per quarter), kept in registers and fed to the 1x1 head convs
     float part[8][6];
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int o = 0; o < 6; ++o) part[t][o] = 0.0f;
     if (busy) {
-        f32x4 acc[2][8];
-        zero_acc<2>(acc);
-        conv_rows<64, 2>(c2, nd.w3, 2 * q4, row0, n_rows, lane, acc);
         const int q = lane >> 4;
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int c0 = (2 * q4 + m) * 16 + 4 * q;
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b3 + c0);
-            f32x4 wv[6];
-#pragma unroll
-            for (int o = 0; o < 6; ++o) wv[o] = *reinterpret_cast<const f32x4 *>(nd.wh + o * 128 + c0);
+        if constexpr (WINO) {
+            f32x4 Y[2][2][4];
+            wino_conv<64, 2>(c2, nd.u3, 2 * q4, rh, lane, Y);
 #pragma unroll
             for (int t = 0; t < 8; ++t)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float h = fmaxf(acc[m][t][j] + bv[j], 0.0f);
+                for (int o = 0; o < 6; ++o) part[t][o] = 0.0f;
 #pragma unroll
-                    for (int o = 0; o < 6; ++o) part[t][o] = fmaf(wv[o][j], h, part[t][o]);
-                }
+            for (int m = 0; m < 2; ++m) {
+                const int c0 = (2 * q4 + m) * 16 + 4 * q;
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b3 + c0);
+                f32x4 wv[6];
+#pragma unroll
+                for (int o = 0; o < 6; ++o) wv[o] = *reinterpret_cast<const f32x4 *>(nd.wh + o * 128 + c0);
+#pragma unroll
+                for (int t = 0; t < 8; ++t)  // t = nt*4 + a*2 + b
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float h = fmaxf(Y[m][t >> 2][t & 3][j] + bv[j], 0.0f);
+#pragma unroll
+                        for (int o = 0; o < 6; ++o) part[t][o] = fmaf(wv[o][j], h, part[t][o]);
+                    }
+            }
+        } else {
+            f32x4 acc[2][8];
+            zero_acc<2>(acc);
+            conv_rows<64, 2>(c2, nd.w3, 2 * q4, row0, n_rows, lane, acc);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int o = 0; o < 6; ++o) part[t][o] = 0.0f;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int c0 = (2 * q4 + m) * 16 + 4 * q;
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b3 + c0);
+                f32x4 wv[6];
+#pragma unroll
+                for (int o = 0; o < 6; ++o) wv[o] = *reinterpret_cast<const f32x4 *>(nd.wh + o * 128 + c0);
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float h = fmaxf(acc[m][t][j] + bv[j], 0.0f);
+#pragma unroll
+                        for (int o = 0; o < 6; ++o) part[t][o] = fmaf(wv[o][j], h, part[t][o]);
+                    }
+            }
         }
+    }
+    else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int o = 0; o < 6; ++o) part[t][o] = 0.0f;
     }
     // sum over the 4 channel sub-groups held by lanes x, x+16, x+32, x+48
 #pragma unroll
@@ -248,9 +443,13 @@ __global__ __launch_bounds__(kTrunkThreads) void k_trunk(NetDev nd, const float 
     float *partial = c1;
     if (lane < 16) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < 8; ++t) {
+            // direct: t = row within the half, lane = column; Winograd: t = (N-tile, a, b), lane = tile
+            const int y = WINO ? 8 * rh + 4 * (t >> 2) + 2 * (lane >> 3) + ((t >> 1) & 1) : row0 + t;
+            const int x = WINO ? 2 * (lane & 7) + (t & 1) : lane;
 #pragma unroll
-            for (int o = 0; o < 6; ++o) partial[((q4 * 6 + o) * 16 + (row0 + t)) * 16 + lane] = part[t][o];
+            for (int o = 0; o < 6; ++o) partial[((q4 * 6 + o) * 16 + y) * 16 + x] = part[t][o];
+        }
     }
     __syncthreads();
     {
@@ -374,6 +573,7 @@ __global__ __launch_bounds__(64) void k_heads_finish(NetDev nd, const float *__r
 struct rz_net {
     int board_size = 0, device = 0;
     bool loaded = false;
+    int algo = RZ_NET_WINOGRAD;
     NetDev dev;
     std::vector<void *> allocs;
     float *d_feat = nullptr, *d_raw = nullptr, *d_hid = nullptr;
@@ -417,6 +617,32 @@ std::vector<f32x4> pack_conv(const float *w, int cout, int cin) {
                     }
                     out[(((size_t)t * steps + s) * 3 + tg) * 64 + lane] = v;
                 }
+    return out;
+}
+
+// U = G g G^T of every (cout, cin) 3x3 kernel, packed [tile][i'][cin_step][lane] x 4 (j'): lane =
+// kq*16 + m holds U[16*tile + m][4*step + kq][i'][0..3].  Computed in fp64, rounded once.
+std::vector<f32x4> pack_wino(const float *w, int cout, int cin) {
+    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int tiles = cout / 16, steps = cin / 4;
+    std::vector<f32x4> out((size_t)tiles * 4 * steps * 64);
+    for (int t = 0; t < tiles; ++t)
+        for (int s = 0; s < steps; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int m = lane & 15, kq = lane >> 4;
+                const float *g = w + ((size_t)(16 * t + m) * cin + (4 * s + kq)) * 9;
+                double tmp[4][3], U[4][4];
+                for (int i = 0; i < 4; ++i)
+                    for (int c = 0; c < 3; ++c)
+                        tmp[i][c] = G[i][0] * g[0 * 3 + c] + G[i][1] * g[1 * 3 + c] + G[i][2] * g[2 * 3 + c];
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 4; ++j) U[i][j] = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
+                for (int ip = 0; ip < 4; ++ip) {
+                    f32x4 v;
+                    for (int jp = 0; jp < 4; ++jp) v[jp] = (float)U[ip][jp];
+                    out[(((size_t)t * 4 + ip) * steps + s) * 64 + lane] = v;
+                }
+            }
     return out;
 }
 
@@ -488,6 +714,8 @@ int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params) {
     up_vec4(pack_conv(h_params[2], 64, 32), &D.w2);
     up_f(h_params[3], 64, &D.b2);
     up_vec4(pack_conv(h_params[4], 128, 64), &D.w3);
+    up_vec4(pack_wino(h_params[2], 64, 32), &D.u2);
+    up_vec4(pack_wino(h_params[4], 128, 64), &D.u3);
     up_f(h_params[5], 128, &D.b3);
     {
         std::vector<float> wh(6 * 128), bh(6);
@@ -551,6 +779,14 @@ int rz_net_reserve(rz_net *net, int32_t max_boards) {
     return RZ_OK;
 }
 
+static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t n_boards, void *stream) {
+    const dim3 grid((unsigned)n_boards), block(kTrunkThreads);
+    if (net->algo == RZ_NET_WINOGRAD)
+        k_trunk<true><<<grid, block, 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
+    else
+        k_trunk<false><<<grid, block, 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
+}
+
 static int launch_heads(rz_net *net, const float *d_feat, int32_t n_boards, float *d_logp, float *d_value,
                         void *stream) {
     const dim3 grid((unsigned)((n_boards + 15) / 16), (unsigned)(net->dev.Npad / 16 + 4));
@@ -570,8 +806,15 @@ int rz_net_trunk(rz_net *net, const float *d_obs, int32_t n_boards, float *d_fea
         if (n_boards > net->feat_boards) return net_fail(RZ_ERR_ARG, "batch larger than rz_net_reserve()d");
         d_feat = net->d_feat;
     }
-    k_trunk<<<dim3((unsigned)n_boards), dim3(kTrunkThreads), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
+    launch_trunk(net, d_obs, d_feat, n_boards, stream);
     if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_trunk failed");
+    return RZ_OK;
+}
+
+int rz_net_set_algo(rz_net *net, int32_t algo) {
+    if (!net) return net_fail(RZ_ERR_ARG, "net handle is NULL");
+    if (algo != RZ_NET_DIRECT && algo != RZ_NET_WINOGRAD) return net_fail(RZ_ERR_ARG, "unknown algorithm");
+    net->algo = algo;
     return RZ_OK;
 }
 
@@ -591,7 +834,7 @@ int rz_net_forward(rz_net *net, const float *d_obs, int32_t n_boards, float *d_l
     if (n_boards == 0) return RZ_OK;
     if (n_boards > net->feat_boards)
         return net_fail(RZ_ERR_ARG, "batch larger than rz_net_reserve()d (no allocation on the launch path)");
-    k_trunk<<<dim3((unsigned)n_boards), dim3(kTrunkThreads), 0, (hipStream_t)stream>>>(net->dev, d_obs, net->d_feat, n_boards);
+    launch_trunk(net, d_obs, net->d_feat, n_boards, stream);
     if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_trunk failed");
     return launch_heads(net, net->d_feat, n_boards, d_logp, d_value, stream);
 }

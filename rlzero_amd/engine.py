@@ -101,6 +101,12 @@ class HipNet(object):
         self.max_boards = 0
         self._want = int(max_boards)
 
+    def set_algo(self, algo):
+        """'winograd' (default) or 'direct' for conv2 / conv3 (both fp32 MFMA)."""
+        code = {'direct': _hip.NET_DIRECT, 'winograd': _hip.NET_WINOGRAD}[algo]
+        check(self.lib.rz_net_set_algo(self.handle, code), 'rz_net_set_algo')
+        return self
+
     def load_state_dict(self, state_dict):
         """Upload (and re-pack into MFMA fragment order) the 16 tensors of a
         PolicyValueNet.state_dict(); call again after every optimiser step."""

@@ -453,9 +453,9 @@ def test_hip_net_vs_golden_and_torch(g4):
     import torch
     from rlzero_amd.engine import HipNet
     from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
-    for B in (3, 6, 9, 15):
+    for B, algo in [(b, a) for b in (3, 6, 9, 15) for a in ('winograd', 'direct')]:
         weights = ev.numpy_weights(B, int(g4['B%d_seed' % B]))
-        hip = HipNet(B, 'cuda:0', max_boards=16).load_state_dict(weights)
+        hip = HipNet(B, 'cuda:0', max_boards=16).load_state_dict(weights).set_algo(algo)
         obs = torch.from_numpy(g4['B%d_obs' % B].astype(np.float32)).to('cuda:0')
         logp, value = hip.forward(obs)
         assert np.max(np.abs(logp.cpu().numpy() - g4['B%d_logp' % B])) <= 1e-4
@@ -479,6 +479,8 @@ def test_hip_net_vs_golden_and_torch(g4):
     hip = HipNet(B, 'cuda:0', max_boards=4).load_state_dict(w)
     x = torch.rand((2, 4, B, B), device='cuda:0')
     feat = hip.trunk(x).cpu().numpy().reshape(2, 6, B, B)
+    feat_direct = hip.set_algo('direct').trunk(x).cpu().numpy().reshape(2, 6, B, B)
+    assert np.max(np.abs(feat - feat_direct)) <= 1e-5
     net = PolicyValueNet(B)
     net.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
     with torch.no_grad():

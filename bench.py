@@ -203,6 +203,7 @@ def main():
                     help="hipnet: hand-written fused fp32 MFMA forward (csrc/rz_net.hip); torchnet: "
                          "PyTorch-ROCm/MIOpen; vlin: synthetic evaluator (isolates the tree kernels)")
     ap.add_argument('--graph', type=int, default=8, help='simulation steps per hipGraph (0 = eager)')
+    ap.add_argument('--net-algo', default='winograd', choices=['winograd', 'winograd4w', 'direct'])
     ap.add_argument('--lanes', type=int, default=1,
                     help='half-batches on separate HIP streams (tree kernels of one lane run beside '
                          'the network kernel of the other)')
@@ -255,7 +256,9 @@ def main():
         eng = MCTSEngine(board, n_row, n_games=g_lane, n_playout=args.playouts, c_puct=C_PUCT, device=device,
                          game=args.game)
         if args.evaluator == 'hipnet':
-            ev = TimedEvaluator(HipNetEvaluator(net, net_shape, device, max_boards=g_lane), torch,
+            hip_ev = HipNetEvaluator(net, net_shape, device, max_boards=g_lane)
+            hip_ev.hip.set_algo(args.net_algo)
+            ev = TimedEvaluator(hip_ev, torch,
                                 'k_trunk (hand-written fused fp32-MFMA conv trunk, csrc/rz_net.hip)')
         elif args.evaluator == 'torchnet':
             ev = TimedEvaluator(NetEvaluator(net), torch, 'torch/MIOpen forward (~14 kernels)')

@@ -243,8 +243,10 @@ int rz_uct_scores(rz_engine *e, const double *d_w, const int32_t *d_n, const int
 typedef struct rz_net rz_net;
 enum {
     RZ_NET_DIRECT = 0,   /* conv2/conv3 as direct implicit GEMM: bit-for-bit a k-ordered fp32 fmaf chain */
-    RZ_NET_WINOGRAD = 1  /* default: conv2/conv3 as Winograd F(2x2,3x3) on the fp32 MFMA path (2.25x fewer
-                            multiply-adds; fp32 throughout, differs from DIRECT by re-association only) */
+    RZ_NET_WINOGRAD = 1, /* default: conv2/conv3 as Winograd F(2x2,3x3) on the fp32 MFMA path (2.25x fewer
+                            multiply-adds; fp32 throughout, differs from DIRECT by re-association only);
+                            8 waves per board, two per SIMD */
+    RZ_NET_WINOGRAD_4W = 2 /* same arithmetic, 4 waves per board (one per SIMD, whole register file) */
 };
 int rz_net_set_algo(rz_net *net, int32_t algo);
 int rz_net_create(int32_t height, int32_t width, int32_t n_actions, int32_t device, rz_net **out);

@@ -37,9 +37,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kRowW = 18;     // halo row width (x = -1 .. 16)
 // halo rows: 18 (y = -1 .. 16), 18*18 = 324 floats per plane before padding
-constexpr int kPlane = 336;   // 18*18 = 324 padded so that 4 planes apart hit other banks
-constexpr int kPlanesIn = 4, kPlanesC1 = 32, kPlanesC2 = 64;
-constexpr int kLdsFloats = (kPlanesIn + kPlanesC1 + kPlanesC2) * kPlane;  // 33600 floats = 131.25 KiB
+// plane stride (floats): 18*18 = 324 padded.  Direct kernel: 336 = 16 mod 32, so the 4 channel
+// sub-groups of a fragment read hit disjoint banks.  Winograd kernel: 337 (odd) -- see wino_conv.
+constexpr int kPlaneDirect = 336, kPlaneWino = 337;
+constexpr int kPlanesIn = 4, kPlanesC1 = 32, kPlanesC2 = 64, kPlanes = kPlanesIn + kPlanesC1 + kPlanesC2;
 constexpr int kTrunkThreads = 512;
 
 struct NetDev {
@@ -66,14 +67,14 @@ struct Frags {
     float b[NR + 2][3];
 };
 
-template <int TM, int NR, int STEPS>
+template <int PL, int TM, int NR, int STEPS>
 __device__ __forceinline__ void load_frags(Frags<TM, NR> &f, const float *__restrict__ base,
                                            const f32x4 *__restrict__ wbase, int s) {
 #pragma unroll
     for (int m = 0; m < TM; ++m)
 #pragma unroll
         for (int tg = 0; tg < 3; ++tg) f.a[m][tg] = wbase[((size_t)(m * STEPS + s) * 3 + tg) * 64];
-    const float *p = base + (4 * s) * kPlane;
+    const float *p = base + (4 * s) * PL;
 #pragma unroll
     for (int ro = 0; ro < NR + 2; ++ro)
 #pragma unroll
@@ -98,25 +99,25 @@ __device__ __forceinline__ void mfma_group(const Frags<TM, NR> &f, f32x4 (&acc)[
 // acc[m][t] += W(tile tile0+m) x in(rows row0+t) over all CIN input channels and the 9 taps.
 // Software pipelined: the fragments of channel group s+1 are fetched (weights: 16-byte loads
 // from L2, activations: ds_read_b32) while the 9*TM*NR MFMAs of group s issue.
-template <int CIN, int TM, int NR>
+template <int PL, int CIN, int TM, int NR>
 __device__ __forceinline__ void conv_accumulate(const float *__restrict__ in, const f32x4 *__restrict__ wp,
                                                 int tile0, int row0, int lane, f32x4 (&acc)[TM][8]) {
     constexpr int kSteps = CIN / 4;
     const int x = lane & 15, kq = lane >> 4;
-    const float *base = in + kq * kPlane + row0 * kRowW + x;  // in[(4s+kq)][row0 + ro][x + dxi]
+    const float *base = in + kq * PL + row0 * kRowW + x;  // in[(4s+kq)][row0 + ro][x + dxi]
     const f32x4 *wbase = wp + (size_t)tile0 * kSteps * 3 * 64 + lane;
     Frags<TM, NR> f0, f1;
-    load_frags<TM, NR, kSteps>(f0, base, wbase, 0);
+    load_frags<PL, TM, NR, kSteps>(f0, base, wbase, 0);
 #pragma unroll 1
     // sched_barrier(0) pins "issue every load of the next group, THEN the MFMAs of this one":
     // left alone, hipcc sinks each load next to its first use and the MFMAs wait on it.
     for (int s = 0; s < kSteps; s += 2) {
-        load_frags<TM, NR, kSteps>(f1, base, wbase, s + 1 < kSteps ? s + 1 : kSteps - 1);
+        load_frags<PL, TM, NR, kSteps>(f1, base, wbase, s + 1 < kSteps ? s + 1 : kSteps - 1);
         __builtin_amdgcn_sched_barrier(0);
         mfma_group<TM, NR>(f0, acc);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (kSteps > 1) {  // kSteps is 1 (conv1) or even
-            load_frags<TM, NR, kSteps>(f0, base, wbase, s + 2 < kSteps ? s + 2 : kSteps - 1);
+            load_frags<PL, TM, NR, kSteps>(f0, base, wbase, s + 2 < kSteps ? s + 2 : kSteps - 1);
             __builtin_amdgcn_sched_barrier(0);
             mfma_group<TM, NR>(f1, acc);
             __builtin_amdgcn_sched_barrier(0);
@@ -124,15 +125,15 @@ __device__ __forceinline__ void conv_accumulate(const float *__restrict__ in, co
     }
 }
 
-template <int CIN, int TM>
+template <int PL, int CIN, int TM>
 __device__ __forceinline__ void conv_rows(const float *__restrict__ in, const f32x4 *__restrict__ wp, int tile0,
                                           int row0, int n_rows, int lane, f32x4 (&acc)[TM][8]) {
-    if (n_rows == 7) conv_accumulate<CIN, TM, 7>(in, wp, tile0, row0, lane, acc);
-    else conv_accumulate<CIN, TM, 8>(in, wp, tile0, row0, lane, acc);
+    if (n_rows == 7) conv_accumulate<PL, CIN, TM, 7>(in, wp, tile0, row0, lane, acc);
+    else conv_accumulate<PL, CIN, TM, 8>(in, wp, tile0, row0, lane, acc);
 }
 
 // out[cout][y+1][x+1] = relu(acc + bias[cout]) for the lane's 4 channels of every tile/row.
-template <int TM>
+template <int PL, int TM>
 __device__ __forceinline__ void store_relu(float *__restrict__ out, const float *__restrict__ bias, int tile0,
                                            int row0, int lane, int BH, int BW, const f32x4 (&acc)[TM][8]) {
     const int x = lane & 15, q = lane >> 4;
@@ -147,7 +148,7 @@ __device__ __forceinline__ void store_relu(float *__restrict__ out, const float 
             if (y >= BH) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                out[(c0 + j) * kPlane + (y + 1) * kRowW + (x + 1)] = fmaxf(acc[m][t][j] + bv[j], 0.0f);
+                out[(c0 + j) * PL + (y + 1) * kRowW + (x + 1)] = fmaxf(acc[m][t][j] + bv[j], 0.0f);
         }
     }
 }
@@ -166,29 +167,31 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[TM][8]) {
 //   * U = G g G^T is precomputed on the host (fp64, rounded once) and packed in fragment order;
 //   * V = B^T d B is formed ON THE FLY from the halo planes in LDS: one pass handles the 4
 //     components (i', j' = 0..3) of one transform row i', which need only 2 rows x 4 columns of
-//     the 4x4 input patch (4 ds_read_b64) and 8 additions per lane and channel group;
-//   * the MFMA N dimension is 16 tiles = 2 tile rows x 8 tile columns, so a wave's 8 board rows
-//     x 16 columns are two N-tiles; K = input channels only;
+//     the 4x4 input patch and 8 additions per lane, N-tile and channel group;
+//   * the MFMA N dimension is 16 tiles = tile rows {r, r+4} x 8 tile columns; K = input channels.
+//     With the odd plane stride the 32 lanes of a ds_read half-wave (8 tile columns: banks 0,2..14;
+//     tile row +4 = 8 board rows = 144 floats: +16; channel sub-group +1 plane: odd banks) hit 32
+//     different banks -- the naive {r, r+1} pairing is 2-way conflicted on every read;
 //   * the output transform A^T M A is linear in M, so after each pass the 4 accumulators of a
 //     (cout tile, N-tile) are folded into the 4 output values of the tile with coefficients
-//     0 / +1 / -1 -- all 16 components of a (cout, tile) live in the same lane, no data movement.
+//     0 / +1 / -1 -- all 16 components of a (cout, tile) live in the same lane, no data movement;
+//   * FOUR waves per workgroup, one per SIMD, each with the whole 512-register file: a wave owns
+//     TM output-channel tiles x 2 N-tiles, so one transformed fragment feeds 4*TM MFMAs (with one
+//     tile per wave the loop was VALU-issue bound: in-kernel stamps);
+//   * the packed U vectors are one contiguous stream over (pass, channel group) and are
+//     prefetched 3 groups ahead through a 4-slot register ring that runs across the passes.
 // fp32 throughout; differs from the direct kernel only by Winograd's re-association
 // (|error| ~1e-6 relative, far inside the 1e-4 tolerance; both paths are tested).
-template <int TM, int IP, int STEPS>
-__device__ __forceinline__ void wino_load_a(f32x4 (&a)[TM], const f32x4 *__restrict__ ubase, int s) {
-#pragma unroll
-    for (int m = 0; m < TM; ++m) a[m] = ubase[((size_t)(m * 4 + IP) * STEPS + s) * 64];
-}
 
-// the 2 patch rows x 4 columns this pass needs, for both N-tiles
-template <int IP>
+// the 2 patch rows x 4 columns pass IP needs, for both N-tiles of the wave
+template <int PL, int IP>
 __device__ __forceinline__ void wino_load_d(float (&d)[2][2][4], const float *__restrict__ base, int s) {
     constexpr int r0 = (IP == 0) ? 0 : (IP == 1) ? 1 : (IP == 2) ? 2 : 1;
     constexpr int r1 = (IP == 0) ? 2 : (IP == 1) ? 2 : (IP == 2) ? 1 : 3;
-    const float *p = base + (4 * s) * kPlane;
+    const float *p = base + (4 * s) * PL;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        const float *q = p + nt * 4 * kRowW;
+        const float *q = p + nt * 2 * kRowW;  // N-tile nt starts one tile row (2 board rows) lower
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             d[nt][0][j] = q[r0 * kRowW + j];
@@ -211,23 +214,14 @@ __device__ __forceinline__ void wino_transform(const float (&d)[2][2][4], float 
     }
 }
 
-template <int TM>
-__device__ __forceinline__ void wino_mfma(const f32x4 (&a)[TM], const float (&v)[2][4], f32x4 (&acc)[TM][2][4]) {
-#pragma unroll
-    for (int jp = 0; jp < 4; ++jp)
-#pragma unroll
-        for (int m = 0; m < TM; ++m)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-                acc[m][nt][jp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][jp], v[nt][jp], acc[m][nt][jp], 0, 0, 0);
-}
-
-// One transform row i' = IP.  Per channel group: transform the patch rows fetched during the
-// previous group (their registers die here), issue the next group's loads, then the MFMAs.
-template <int CIN, int TM, int IP>
+// One transform row i' = IP for the wave's TM output-channel tiles.  Per channel group: transform
+// the patch rows fetched during the previous group (their registers die here), issue the loads
+// of the coming groups (U three groups ahead, possibly already the next pass's), then 8*TM MFMAs.
+template <int PL, int CIN, int TM, int IP>
 __device__ __forceinline__ void wino_pass(const float *__restrict__ base, const f32x4 *__restrict__ ubase,
-                                          f32x4 (&Y)[TM][2][4]) {
-    constexpr int kSteps = CIN / 4;
+                                          f32x4 (&a)[4][TM], float (&d)[2][2][4], f32x4 (&Y)[TM][2][4]) {
+    constexpr int kSteps = CIN / 4;  // 8 or 16: a multiple of the ring size
+    constexpr int kT = 4 * kSteps;   // U vectors per tile: index t = IP*kSteps + s
     f32x4 acc[TM][2][4];
 #pragma unroll
     for (int m = 0; m < TM; ++m)
@@ -235,26 +229,33 @@ __device__ __forceinline__ void wino_pass(const float *__restrict__ base, const 
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int jp = 0; jp < 4; ++jp) acc[m][nt][jp] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 a0[TM], a1[TM];
-    float d[2][2][4], v[2][4];
-    wino_load_a<TM, IP, kSteps>(a0, ubase, 0);
-    wino_load_d<IP>(d, base, 0);
+    float v[2][4];
 #pragma unroll 1
-    for (int s = 0; s < kSteps; s += 2) {
-        wino_transform<IP>(d, v);
-        __builtin_amdgcn_sched_barrier(0);
-        wino_load_a<TM, IP, kSteps>(a1, ubase, s + 1);
-        wino_load_d<IP>(d, base, s + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        wino_mfma<TM>(a0, v, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        wino_transform<IP>(d, v);
-        __builtin_amdgcn_sched_barrier(0);
-        wino_load_a<TM, IP, kSteps>(a0, ubase, s + 2 < kSteps ? s + 2 : kSteps - 1);
-        wino_load_d<IP>(d, base, s + 2 < kSteps ? s + 2 : kSteps - 1);
-        __builtin_amdgcn_sched_barrier(0);
-        wino_mfma<TM>(a1, v, acc);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int s0 = 0; s0 < kSteps; s0 += 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int s = s0 + r;
+            wino_transform<IP>(d, v);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const int t3 = IP * kSteps + s + 3;
+                const int tn = t3 < kT ? t3 : kT - 1;
+#pragma unroll
+                for (int m = 0; m < TM; ++m) a[(r + 3) & 3][m] = ubase[((size_t)m * kT + tn) * 64];
+            }
+            if (r < 3 || s + 1 < kSteps) wino_load_d<PL, IP>(d, base, s + 1);
+            else if (IP < 3) wino_load_d<PL, (IP < 3 ? IP + 1 : 3)>(d, base, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jp = 0; jp < 4; ++jp)
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+                        acc[m][nt][jp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][m][jp], v[nt][jp],
+                                                                              acc[m][nt][jp], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     // fold this transform row into the 2x2 outputs: Y[a][b] += At[a][i'] * sum_j' At[b][j'] M[i'][j']
     constexpr float c0 = (IP < 3) ? 1.0f : 0.0f;                       // At[0][i'] = 1 1 1 0
@@ -277,42 +278,197 @@ __device__ __forceinline__ void wino_pass(const float *__restrict__ base, const 
                 Y[m][nt][3] -= yb1;
             }
         }
-    // keep the fold here: without it hipcc overlaps this pass's accumulators with the next pass's
+    // Materialise Y HERE.  Without this the optimiser sinks the fold to Y's final use and keeps the
+    // accumulators of all four passes alive at once (register demand grew by one set per pass).
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) asm volatile("" : "+v"(Y[m][nt][o]));
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// Y[m][nt][a*2+b] = conv output (no bias) of cout tile tile0+m at rows 8rh + 4nt + 2(lane>>3 & 1) + a,
-// columns 2(lane & 7) + b, for the lane's 4 channels.
-template <int CIN, int TM>
+// Wave geometry of the Winograd path: lane -> tile (column tx = lane & 7, row selector ty =
+// (lane >> 3) & 1); board half h: the wave's N-tile nt covers tile rows 2h + nt + 4*ty.
+__device__ __forceinline__ int wino_row(int h, int nt, int lane, int a) {
+    return 2 * (2 * h + nt + 4 * ((lane >> 3) & 1)) + a;  // board row of output (a) of the lane's tile
+}
+
+// Y[m][nt][a*2+b] = conv output (no bias) of output-channel tile tile0+m at board rows
+// wino_row(h, nt, lane, a), columns 2*(lane & 7) + b, for the lane's 4 channels.
+template <int PL, int CIN, int TM>
 __device__ __forceinline__ void wino_conv(const float *__restrict__ in, const f32x4 *__restrict__ up, int tile0,
-                                          int rh, int lane, f32x4 (&Y)[TM][2][4]) {
-    constexpr int kSteps = CIN / 4;
-    const int n = lane & 15, kq = lane >> 4;
-    const int ty = n >> 3, tx = n & 7;
-    const float *base = in + kq * kPlane + (8 * rh + 2 * ty) * kRowW + 2 * tx;
-    const f32x4 *ubase = up + (size_t)tile0 * 4 * kSteps * 64 + lane;
+                                          int h, int lane, f32x4 (&Y)[TM][2][4]) {
+    constexpr int kSteps = CIN / 4, kT = 4 * kSteps;
+    const int kq = lane >> 4, ty = (lane >> 3) & 1, tx = lane & 7;
+    // top-left of the 4x4 patch of N-tile 0 in halo coordinates: row 2*(2h + 4ty), column 2tx
+    const float *base = in + kq * PL + (4 * h + 8 * ty) * kRowW + 2 * tx;
+    const f32x4 *ubase = up + (size_t)tile0 * kT * 64 + lane;
 #pragma unroll
     for (int m = 0; m < TM; ++m)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int o = 0; o < 4; ++o) Y[m][nt][o] = f32x4{0.f, 0.f, 0.f, 0.f};
-    wino_pass<CIN, TM, 0>(base, ubase, Y);
-    wino_pass<CIN, TM, 1>(base, ubase, Y);
-    wino_pass<CIN, TM, 2>(base, ubase, Y);
-    wino_pass<CIN, TM, 3>(base, ubase, Y);
+    f32x4 a[4][TM];
+    float d[2][2][4];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int m = 0; m < TM; ++m) a[t][m] = ubase[((size_t)m * kT + t) * 64];
+    wino_load_d<PL, 0>(d, base, 0);
+    wino_pass<PL, CIN, TM, 0>(base, ubase, a, d, Y);
+    wino_pass<PL, CIN, TM, 1>(base, ubase, a, d, Y);
+    wino_pass<PL, CIN, TM, 2>(base, ubase, a, d, Y);
+    wino_pass<PL, CIN, TM, 3>(base, ubase, a, d, Y);
 }
 
-// Wave w = 4*rh + q4: output-channel quarter q4 (the two waves of a quarter share a SIMD, waves
-// are dealt to SIMDs cyclically) and row half rh (rows 0-7 / 8-15; on a 15x15 board the second
-// half computes 7 rows, so every SIMD carries exactly 15 row-units of each layer).
-template <bool WINO>
-__global__ __launch_bounds__(kTrunkThreads) void k_trunk(NetDev nd, const float *__restrict__ obs,
+// Sum `vals` over the 4 lanes {n, n+16, n+32, n+48} as a reduce-scatter with the gfx950 lane-swap
+// instructions (no LDS traffic): afterwards every lane holds 12 of the 48 sums,
+// out[i] = sum over the 4 lanes of vals[(q & 1) * 24 + (q >> 1) * 12 + i], q = lane >> 4.
+__device__ __forceinline__ void reduce_scatter_48(const float (&vals)[48], float (&out)[12]) {
+    float r1[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(vals[i]), __float_as_uint(vals[24 + i]),
+                                                         false, false);
+        r1[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(r1[i]), __float_as_uint(r1[12 + i]),
+                                                         false, false);
+        out[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+}
+
+// Winograd trunk: CG channel groups x 2 board halves = 2*CG waves; wave w = CG*h + cg owns output
+// channels [cg*128/CG, (cg+1)*128/CG) of conv3 (64/CG of conv2) and the board half h.
+// CG = 4: 8 waves, two per SIMD -- while one wave transforms / loads, its partner issues MFMAs.
+// CG = 2: 4 waves, one per SIMD with the whole register file (more MFMAs per transformed fragment,
+// but nothing fills the matrix pipe during the wave's own transform / load block).
+template <int CG>
+__global__ __launch_bounds__(128 * CG) void k_trunk_wino(NetDev nd, const float *__restrict__ obs,
                                                          float *__restrict__ feat, int n_boards) {
+    constexpr int PL = kPlaneWino;
+    constexpr int kLdsFloats = kPlanes * PL;
+    constexpr int kThreads = 128 * CG;
+    constexpr int TM2 = 4 / CG, TM3 = 8 / CG;
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     float *in0 = lds;
-    float *c1 = in0 + kPlanesIn * kPlane;
-    float *c2 = c1 + kPlanesC1 * kPlane;
+    float *c1 = in0 + kPlanesIn * PL;
+    float *c2 = c1 + kPlanesC1 * PL;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = wave % CG, h = wave / CG;
+    const int BH = nd.BH, BW = nd.BW, S = nd.S;
+    const int board = blockIdx.x;
+    if (board >= n_boards) return;
+    {
+        f32x4 *z = reinterpret_cast<f32x4 *>(lds);
+        for (int i = tid; i < kLdsFloats / 4; i += kThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    {
+        const float *src = obs + (size_t)board * 4 * S;
+        for (int i = tid; i < 4 * S; i += kThreads) {
+            const int c = i / S, r = i - c * S, y = r / BW, x = r - y * BW;
+            in0[c * PL + (y + 1) * kRowW + (x + 1)] = src[i];
+        }
+    }
+    __syncthreads();
+    {   // conv1: 4 -> 32 direct (1 % of the work): the first two channel groups take one tile each
+        const int row0 = 8 * h;
+        if (cg < 2 && row0 < BH) {
+            f32x4 acc[1][8];
+            zero_acc<1>(acc);
+            conv_rows<PL, 4, 1>(in0, nd.w1, cg, row0, (BH - row0 == 7) ? 7 : 8, lane, acc);
+            store_relu<PL, 1>(c1, nd.b1, cg, row0, lane, BH, BW, acc);
+        }
+    }
+    __syncthreads();
+    const int q = lane >> 4, tx = lane & 7;
+    {   // conv2: 32 -> 64
+        f32x4 Y[TM2][2][4];
+        wino_conv<PL, 32, TM2>(c1, nd.u2, TM2 * cg, h, lane, Y);
+#pragma unroll
+        for (int m = 0; m < TM2; ++m) {
+            const int c0 = (TM2 * cg + m) * 16 + 4 * q;
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b2 + c0);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int ab = 0; ab < 4; ++ab) {
+                    const int y = wino_row(h, nt, lane, ab >> 1), x = 2 * tx + (ab & 1);
+                    if (y < BH && x < BW) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            c2[(c0 + j) * PL + (y + 1) * kRowW + (x + 1)] = fmaxf(Y[m][nt][ab][j] + bv[j], 0.0f);
+                    }
+                }
+        }
+    }
+    __syncthreads();
+    float *partial = c1;  // [cg][o][y][x]: c1 is free now
+    {   // conv3: 64 -> 128; the ReLU'd output goes straight from the registers into the two 1x1
+        // head convolutions
+        float vals[48];  // index t*6 + o, t = nt*4 + a*2 + b
+#pragma unroll
+        for (int i = 0; i < 48; ++i) vals[i] = 0.0f;
+        {
+            f32x4 Y[TM3][2][4];
+            wino_conv<PL, 64, TM3>(c2, nd.u3, TM3 * cg, h, lane, Y);
+#pragma unroll
+            for (int m = 0; m < TM3; ++m) {
+                const int c0 = (TM3 * cg + m) * 16 + 4 * q;
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b3 + c0);
+                f32x4 wv[6];
+#pragma unroll
+                for (int o = 0; o < 6; ++o) wv[o] = *reinterpret_cast<const f32x4 *>(nd.wh + o * 128 + c0);
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float hv = fmaxf(Y[m][t >> 2][t & 3][j] + bv[j], 0.0f);
+#pragma unroll
+                        for (int o = 0; o < 6; ++o) vals[t * 6 + o] = fmaf(wv[o][j], hv, vals[t * 6 + o]);
+                    }
+            }
+        }
+        float sums[12];
+        reduce_scatter_48(vals, sums);
+        const int off = (q & 1) * 24 + (q >> 1) * 12;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int vi = off + i, t = vi / 6, o = vi - 6 * t;
+            const int y = wino_row(h, t >> 2, lane, (t >> 1) & 1), x = 2 * tx + (t & 1);
+            partial[((cg * 6 + o) * 16 + y) * 16 + x] = sums[i];
+        }
+    }
+    __syncthreads();
+    {
+        float *dst = feat + (size_t)board * 6 * S;
+        for (int i = tid; i < 6 * S; i += kThreads) {
+            const int o = i / S, r = i - o * S, y = r / BW, x = r - y * BW;
+            float v = nd.bh[o];
+#pragma unroll
+            for (int k = 0; k < CG; ++k) v += partial[((k * 6 + o) * 16 + y) * 16 + x];
+            dst[i] = fmaxf(v, 0.0f);
+        }
+    }
+}
+
+// Direct path: wave w = 4*rh + q4 owns output-channel quarter q4 (the two waves of a quarter share
+// a SIMD, waves are dealt to SIMDs cyclically) and row half rh (rows 0-7 / 8-15; on a 15x15 board
+// the second half computes 7 rows, so every SIMD carries exactly 15 row-units of each layer).
+__global__ __launch_bounds__(kTrunkThreads) void k_trunk(NetDev nd, const float *__restrict__ obs,
+                                                         float *__restrict__ feat, int n_boards) {
+    constexpr int PL = kPlaneDirect;
+    constexpr int kLdsFloats = kPlanes * PL;  // 131.25 KiB
+    __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+    float *in0 = lds;
+    float *c1 = in0 + kPlanesIn * PL;
+    float *c2 = c1 + kPlanesC1 * PL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q4 = wave & 3, rh = wave >> 2;
     const int BH = nd.BH, BW = nd.BW, S = nd.S;
@@ -332,7 +488,7 @@ __global__ __launch_bounds__(kTrunkThreads) void k_trunk(NetDev nd, const float 
         const float *src = obs + (size_t)board * 4 * S;
         for (int i = tid; i < 4 * S; i += kTrunkThreads) {
             const int c = i / S, r = i - c * S, y = r / BW, x = r - y * BW;
-            in0[c * kPlane + (y + 1) * kRowW + (x + 1)] = src[i];
+            in0[c * PL + (y + 1) * kRowW + (x + 1)] = src[i];
         }
     }
     __syncthreads();
@@ -340,94 +496,44 @@ __global__ __launch_bounds__(kTrunkThreads) void k_trunk(NetDev nd, const float 
     if (busy && q4 < 2) {   // conv1: 4 -> 32 = two 16-channel tiles
         f32x4 acc[1][8];
         zero_acc<1>(acc);
-        conv_rows<4, 1>(in0, nd.w1, q4, row0, n_rows, lane, acc);
-        store_relu<1>(c1, nd.b1, q4, row0, lane, BH, BW, acc);
+        conv_rows<PL, 4, 1>(in0, nd.w1, q4, row0, n_rows, lane, acc);
+        store_relu<PL, 1>(c1, nd.b1, q4, row0, lane, BH, BW, acc);
     }
     __syncthreads();
     if (busy) {   // conv2: 32 -> 64 = one tile per quarter
-        if constexpr (WINO) {
-            f32x4 Y[1][2][4];
-            wino_conv<32, 1>(c1, nd.u2, q4, rh, lane, Y);
-            const int n = lane & 15, q = lane >> 4, ty = n >> 3, tx = n & 7;
-            const int c0 = q4 * 16 + 4 * q;
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b2 + c0);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int ab = 0; ab < 4; ++ab) {
-                    const int y = 8 * rh + 4 * nt + 2 * ty + (ab >> 1), x = 2 * tx + (ab & 1);
-                    if (y < BH && x < BW) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            c2[(c0 + j) * kPlane + (y + 1) * kRowW + (x + 1)] = fmaxf(Y[0][nt][ab][j] + bv[j], 0.0f);
-                    }
-                }
-        } else {
-            f32x4 acc[1][8];
-            zero_acc<1>(acc);
-            conv_rows<32, 1>(c1, nd.w2, q4, row0, n_rows, lane, acc);
-            store_relu<1>(c2, nd.b2, q4, row0, lane, BH, BW, acc);
-        }
+        f32x4 acc[1][8];
+        zero_acc<1>(acc);
+        conv_rows<PL, 32, 1>(c1, nd.w2, q4, row0, n_rows, lane, acc);
+        store_relu<PL, 1>(c2, nd.b2, q4, row0, lane, BH, BW, acc);
     }
     __syncthreads();
     // conv3: 64 -> 128 (two tiles per quarter), kept in registers and fed to the 1x1 head convs
     float part[8][6];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int o = 0; o < 6; ++o) part[t][o] = 0.0f;
     if (busy) {
         const int q = lane >> 4;
-        if constexpr (WINO) {
-            f32x4 Y[2][2][4];
-            wino_conv<64, 2>(c2, nd.u3, 2 * q4, rh, lane, Y);
+        f32x4 acc[2][8];
+        zero_acc<2>(acc);
+        conv_rows<PL, 64, 2>(c2, nd.w3, 2 * q4, row0, n_rows, lane, acc);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int c0 = (2 * q4 + m) * 16 + 4 * q;
+            const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b3 + c0);
+            f32x4 wv[6];
+#pragma unroll
+            for (int o = 0; o < 6; ++o) wv[o] = *reinterpret_cast<const f32x4 *>(nd.wh + o * 128 + c0);
 #pragma unroll
             for (int t = 0; t < 8; ++t)
 #pragma unroll
-                for (int o = 0; o < 6; ++o) part[t][o] = 0.0f;
+                for (int j = 0; j < 4; ++j) {
+                    const float hv = fmaxf(acc[m][t][j] + bv[j], 0.0f);
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int c0 = (2 * q4 + m) * 16 + 4 * q;
-                const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b3 + c0);
-                f32x4 wv[6];
-#pragma unroll
-                for (int o = 0; o < 6; ++o) wv[o] = *reinterpret_cast<const f32x4 *>(nd.wh + o * 128 + c0);
-#pragma unroll
-                for (int t = 0; t < 8; ++t)  // t = nt*4 + a*2 + b
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float h = fmaxf(Y[m][t >> 2][t & 3][j] + bv[j], 0.0f);
-#pragma unroll
-                        for (int o = 0; o < 6; ++o) part[t][o] = fmaf(wv[o][j], h, part[t][o]);
-                    }
-            }
-        } else {
-            f32x4 acc[2][8];
-            zero_acc<2>(acc);
-            conv_rows<64, 2>(c2, nd.w3, 2 * q4, row0, n_rows, lane, acc);
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-#pragma unroll
-                for (int o = 0; o < 6; ++o) part[t][o] = 0.0f;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int c0 = (2 * q4 + m) * 16 + 4 * q;
-                const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b3 + c0);
-                f32x4 wv[6];
-#pragma unroll
-                for (int o = 0; o < 6; ++o) wv[o] = *reinterpret_cast<const f32x4 *>(nd.wh + o * 128 + c0);
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float h = fmaxf(acc[m][t][j] + bv[j], 0.0f);
-#pragma unroll
-                        for (int o = 0; o < 6; ++o) part[t][o] = fmaf(wv[o][j], h, part[t][o]);
-                    }
-            }
+                    for (int o = 0; o < 6; ++o) part[t][o] = fmaf(wv[o][j], hv, part[t][o]);
+                }
         }
-    }
-    else {
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-            for (int o = 0; o < 6; ++o) part[t][o] = 0.0f;
     }
     // sum over the 4 channel sub-groups held by lanes x, x+16, x+32, x+48
 #pragma unroll
@@ -439,17 +545,12 @@ __global__ __launch_bounds__(kTrunkThreads) void k_trunk(NetDev nd, const float 
             v += __shfl_xor(v, 32);
             part[t][o] = v;
         }
-    // c1 is free now: partial[q4][o][y][x]
-    float *partial = c1;
+    float *partial = c1;  // [q4][o][y][x]: c1 is free now
     if (lane < 16) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            // direct: t = row within the half, lane = column; Winograd: t = (N-tile, a, b), lane = tile
-            const int y = WINO ? 8 * rh + 4 * (t >> 2) + 2 * (lane >> 3) + ((t >> 1) & 1) : row0 + t;
-            const int x = WINO ? 2 * (lane & 7) + (t & 1) : lane;
+        for (int t = 0; t < 8; ++t)
 #pragma unroll
-            for (int o = 0; o < 6; ++o) partial[((q4 * 6 + o) * 16 + y) * 16 + x] = part[t][o];
-        }
+            for (int o = 0; o < 6; ++o) partial[((q4 * 6 + o) * 16 + (row0 + t)) * 16 + lane] = part[t][o];
     }
     __syncthreads();
     {
@@ -780,11 +881,13 @@ int rz_net_reserve(rz_net *net, int32_t max_boards) {
 }
 
 static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t n_boards, void *stream) {
-    const dim3 grid((unsigned)n_boards), block(kTrunkThreads);
+    const dim3 grid((unsigned)n_boards);
     if (net->algo == RZ_NET_WINOGRAD)
-        k_trunk<true><<<grid, block, 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
+        k_trunk_wino<4><<<grid, dim3(512), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
+    else if (net->algo == RZ_NET_WINOGRAD_4W)
+        k_trunk_wino<2><<<grid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
     else
-        k_trunk<false><<<grid, block, 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
+        k_trunk<<<grid, dim3(kTrunkThreads), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
 }
 
 static int launch_heads(rz_net *net, const float *d_feat, int32_t n_boards, float *d_logp, float *d_value,
@@ -813,7 +916,8 @@ int rz_net_trunk(rz_net *net, const float *d_obs, int32_t n_boards, float *d_fea
 
 int rz_net_set_algo(rz_net *net, int32_t algo) {
     if (!net) return net_fail(RZ_ERR_ARG, "net handle is NULL");
-    if (algo != RZ_NET_DIRECT && algo != RZ_NET_WINOGRAD) return net_fail(RZ_ERR_ARG, "unknown algorithm");
+    if (algo != RZ_NET_DIRECT && algo != RZ_NET_WINOGRAD && algo != RZ_NET_WINOGRAD_4W)
+        return net_fail(RZ_ERR_ARG, "unknown algorithm");
     net->algo = algo;
     return RZ_OK;
 }

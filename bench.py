@@ -46,6 +46,15 @@ def trunk_flops_per_position(cells):
     return 188160 * cells
 
 
+def executed_flop_ratio(args, cells):
+    """MFMA flops executed / algorithmic trunk flops.  Direct: rows x 16 columns tiles.  Winograd
+    (15x15): conv2 2048 + conv3 8192 + conv1 270 MFMAs of 2048 flops per board; the 1x1 heads are VALU."""
+    if args.evaluator != 'hipnet' or args.game != 'gomoku' or args.board != 15:
+        return 1.0
+    mfmas = {'winograd': 10510, 'winograd4w': 10510, 'direct': 21870}[args.net_algo]
+    return mfmas * 2048.0 / trunk_flops_per_position(cells)
+
+
 def tree_bytes_per_sim(scanned, created, depth):
     """12 B per scanned child, 16 B per created child, 24 B per backed-up node,
     64 B of root bitboards."""
@@ -259,7 +268,9 @@ def main():
             hip_ev = HipNetEvaluator(net, net_shape, device, max_boards=g_lane)
             hip_ev.hip.set_algo(args.net_algo)
             ev = TimedEvaluator(hip_ev, torch,
-                                'k_trunk (hand-written fused fp32-MFMA conv trunk, csrc/rz_net.hip)')
+                                {'winograd': 'k_trunk_wino<4> (hand-written fused fp32-MFMA conv trunk, Winograd F(2x2,3x3), csrc/rz_net.hip)',
+                                 'winograd4w': 'k_trunk_wino<2> (same, 4 waves per board)',
+                                 'direct': 'k_trunk (hand-written fused fp32-MFMA conv trunk, direct, csrc/rz_net.hip)'}[args.net_algo])
         elif args.evaluator == 'torchnet':
             ev = TimedEvaluator(NetEvaluator(net), torch, 'torch/MIOpen forward (~14 kernels)')
         else:
@@ -357,6 +368,11 @@ def main():
                                 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
                                 'traffic': pmc_traffic('k_trunk', line['config']['workload'], lanes),
                                 'avg_launch_ms': round(ms, 4), 'launches_timed': n_ev,
+                                'note': 'achieved = ALGORITHMIC flops (direct convolution, SURVEY.md 8d) / time; '
+                                        'mfma_executed_frac = flops the MFMA pipe really executed / time / peak '
+                                        '(Winograd executes 2.09x fewer)',
+                                'mfma_executed_frac': round(achieved / PEAK_FP32_MATRIX_TFLOPS *
+                                                            executed_flop_ratio(args, cells), 4),
                                 'share_of_step_time': round(ms * (total_sims / world / G) / (elapsed * 1e3), 3)}
         else:
             per_sim = tree_bytes_per_sim(365.5, 208.8, 1.74) if board == 15 else None

@@ -55,6 +55,7 @@ struct NetDev {
     const float *fc_val1_b;      // [64]
     const float *fc_val2_w;      // [64]
     const float *fc_val2_b;      // [1]
+    int feat_nb4;  // 0: features as [board][6S]; else 4*padded_boards: features as [k/4][board][4]
     int BH, BW, S, A, Npad, steps_act, steps_val;  // A policy outputs; steps_*: k-steps of 4, multiples of 4*kHeadU
 };
 
@@ -453,7 +454,8 @@ __global__ __launch_bounds__(128 * CG) void k_trunk_wino(NetDev nd, const float 
             float v = nd.bh[o];
 #pragma unroll
             for (int k = 0; k < CG; ++k) v += partial[((k * 6 + o) * 16 + y) * 16 + x];
-            dst[i] = fmaxf(v, 0.0f);
+            if (nd.feat_nb4) feat[(size_t)(i >> 2) * nd.feat_nb4 + board * 4 + (i & 3)] = fmaxf(v, 0.0f);
+            else dst[i] = fmaxf(v, 0.0f);
         }
     }
 }
@@ -560,7 +562,8 @@ __global__ __launch_bounds__(kTrunkThreads) void k_trunk(NetDev nd, const float 
             float v = nd.bh[o];
 #pragma unroll
             for (int k = 0; k < 4; ++k) v += partial[((k * 6 + o) * 16 + y) * 16 + x];
-            dst[i] = fmaxf(v, 0.0f);
+            if (nd.feat_nb4) feat[(size_t)(i >> 2) * nd.feat_nb4 + board * 4 + (i & 3)] = fmaxf(v, 0.0f);
+            else dst[i] = fmaxf(v, 0.0f);
         }
     }
 }
@@ -592,21 +595,22 @@ __global__ __launch_bounds__(256) void k_heads_gemm(NetDev nd, const float *__re
     const int s_first = wave * steps;
     const float *w = (is_act ? nd.fc_act_t + 16 * ot : nd.fc_val1_t + 16 * (ot - n_act_tiles)) +
                      (size_t)(4 * s_first + kq) * ldw + n;
-    int brow = b0 + n;  // A row = board (lane & 15)
-    if (brow >= n_boards) brow = n_boards - 1;
-    const float *a = feat + (size_t)brow * 6 * S + (is_act ? 0 : 4 * S) + 4 * s_first + kq;
+    // A row = board (lane & 15); features are stored [k/4][board][4], so the 64 lanes of one load
+    // (16 boards x 4 consecutive k) read 256 contiguous bytes.  Rows of padded boards are zero.
+    const size_t nb4 = (size_t)nd.feat_nb4;
+    const float *a = feat + ((size_t)(is_act ? 0 : S) + s_first) * nb4 + (size_t)(b0 + n) * 4 + kq;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float acur[kHeadU], bcur[kHeadU], anxt[kHeadU], bnxt[kHeadU];
 #pragma unroll
     for (int u = 0; u < kHeadU; ++u) {
-        acur[u] = a[4 * u];
+        acur[u] = a[(size_t)u * nb4];
         bcur[u] = w[(size_t)(4 * u) * ldw];
     }
     for (int s0 = 0; s0 < steps; s0 += kHeadU) {
         const int sn = (s0 + kHeadU < steps) ? s0 + kHeadU : s0;  // last group re-reads itself
 #pragma unroll
         for (int u = 0; u < kHeadU; ++u) {
-            anxt[u] = a[4 * (sn + u)];
+            anxt[u] = a[(size_t)(sn + u) * nb4];
             bnxt[u] = w[(size_t)(4 * (sn + u)) * ldw];
         }
 #pragma unroll
@@ -679,6 +683,7 @@ struct rz_net {
     std::vector<void *> allocs;
     float *d_feat = nullptr, *d_raw = nullptr, *d_hid = nullptr;
     long long feat_boards = 0;
+    size_t feat_floats = 0;
 };
 
 namespace {
@@ -869,12 +874,16 @@ int rz_net_reserve(rz_net *net, int32_t max_boards) {
     if (net->d_hid) (void)hipFree(net->d_hid);
     net->d_feat = net->d_raw = net->d_hid = nullptr;
     net->feat_boards = 0;
-    if (hipMalloc((void **)&net->d_feat, ((size_t)max_boards * 6 * net->dev.S + 4096) * sizeof(float)) != hipSuccess ||
+    // internal features: [k/4][padded boards][4]; rows cover the zero-padded K range of both heads
+    const size_t pad_boards = ((size_t)max_boards + 15) / 16 * 16;
+    const size_t feat_rows = (size_t)net->dev.S + (size_t)net->dev.steps_val + 1;
+    net->feat_floats = feat_rows * pad_boards * 4;
+    if (hipMalloc((void **)&net->d_feat, net->feat_floats * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&net->d_raw, (size_t)max_boards * net->dev.Npad * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&net->d_hid, (size_t)max_boards * 64 * sizeof(float)) != hipSuccess)
         return net_fail(RZ_ERR_OOM, "hipMalloc failed (feature buffers)");
-    // the zero-padded K tail of the last board reads into the slack: it must hold finite values
-    if (hipMemset(net->d_feat, 0, ((size_t)max_boards * 6 * net->dev.S + 4096) * sizeof(float)) != hipSuccess)
+    // padded boards and the K tail must read as finite values (they meet zero weights)
+    if (hipMemset(net->d_feat, 0, net->feat_floats * sizeof(float)) != hipSuccess)
         return net_fail(RZ_ERR_HIP, "hipMemset failed (feature buffer)");
     net->feat_boards = max_boards;
     return RZ_OK;
@@ -882,6 +891,8 @@ int rz_net_reserve(rz_net *net, int32_t max_boards) {
 
 static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t n_boards, void *stream) {
     const dim3 grid((unsigned)n_boards);
+    // the internal buffer uses the GEMM-friendly layout, a caller's buffer the natural one
+    net->dev.feat_nb4 = (d_feat == net->d_feat) ? 4 * ((n_boards + 15) / 16 * 16) : 0;
     if (net->algo == RZ_NET_WINOGRAD)
         k_trunk_wino<4><<<grid, dim3(512), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
     else if (net->algo == RZ_NET_WINOGRAD_4W)
@@ -892,6 +903,7 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
 
 static int launch_heads(rz_net *net, const float *d_feat, int32_t n_boards, float *d_logp, float *d_value,
                         void *stream) {
+    net->dev.feat_nb4 = 4 * ((n_boards + 15) / 16 * 16);
     const dim3 grid((unsigned)((n_boards + 15) / 16), (unsigned)(net->dev.Npad / 16 + 4));
     k_heads_gemm<<<grid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_feat, net->d_raw, net->d_hid, n_boards);
     k_heads_finish<<<dim3((unsigned)n_boards), dim3(64), 0, (hipStream_t)stream>>>(net->dev, net->d_raw, net->d_hid,

@@ -188,6 +188,23 @@ class TimedEvaluator(object):
         self.events.append((a, b))
         return out
 
+    @property
+    def fused_heads(self):
+        return getattr(self.inner, 'fused_heads', False)
+
+    def raw_heads(self, eng):
+        """Fused route (the tree kernel finishes the heads): k_trunk bracketed when recording."""
+        if not self.record:
+            return self.inner.raw_heads(eng)
+        t = self.torch
+        a, b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+        hip = self.inner.hip
+        a.record()
+        hip.trunk_internal(eng.obs)
+        b.record()
+        self.events.append((a, b))
+        return hip.heads_gemm(eng.obs.shape[0])
+
     def mean_ms(self):
         if not self.events:
             return None

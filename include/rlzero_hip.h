@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 10
+#define RZ_ABI_VERSION 11
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 
@@ -188,6 +188,16 @@ int rz_expand_backup_probs(rz_engine *e, const float *d_probs, const double *d_v
  * share a kernel boundary).  Same arguments as the two calls it replaces. */
 int rz_tree_step(rz_engine *e, const float *d_logp, const float *d_value, float *d_obs, void *stream);
 
+/* The same two entry points fed with the evaluator's UN-NORMALISED head outputs: policy logits
+ * d_raw [n_games][ld] (ld >= A) and the value head's hidden layer d_hid [n_games][64] with its last
+ * weights d_w2 [64], d_b2 [1]; log_softmax and tanh(hid . w2 + b2) are finished inside the tree
+ * kernel (same wave per game), saving the separate rz_net_heads finishing launch.  Pair with
+ * rz_net_trunk(.., NULL, ..) + rz_net_heads_gemm.  Bit-identical to the un-fused route. */
+int rz_expand_backup_raw(rz_engine *e, const float *d_raw, int32_t ld, const float *d_hid, const float *d_w2,
+                         const float *d_b2, void *stream);
+int rz_tree_step_raw(rz_engine *e, const float *d_raw, int32_t ld, const float *d_hid, const float *d_w2,
+                     const float *d_b2, float *d_obs, void *stream);
+
 /* Root statistics after the simulations (AlphaZeroMCTS.simulate, alphazero_mcts.py:88-90):
  * visit count / W of the root child of every action, 0 for illegal or unvisited actions;
  * [n_games][B*B].  rz_root_stats: N and W of the roots themselves, [n_games]. */
@@ -255,6 +265,10 @@ int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params);
 int rz_net_reserve(rz_net *net, int32_t max_boards);
 int rz_net_trunk(rz_net *net, const float *d_obs, int32_t n_boards, float *d_feat, void *stream);
 int rz_net_heads(rz_net *net, int32_t n_boards, float *d_logp, float *d_value, void *stream);
+/* only the FC GEMM of the heads on the internal features; returns the device pointers that
+ * rz_tree_step_raw / rz_expand_backup_raw consume (valid until the next rz_net_reserve / load) */
+int rz_net_heads_gemm(rz_net *net, int32_t n_boards, const float **d_raw, int32_t *ld, const float **d_hid,
+                      const float **d_w2, const float **d_b2, void *stream);
 int rz_net_forward(rz_net *net, const float *d_obs, int32_t n_boards, float *d_logp,
                    float *d_value, void *stream);
 

@@ -8,7 +8,7 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64,
                     c_void_p)
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
 
@@ -62,6 +62,8 @@ _SIGNATURES = {
     'rz_expand_backup_f64': (c_int, [P, P, P, P]),
     'rz_expand_backup_probs': (c_int, [P, P, P, P]),
     'rz_tree_step': (c_int, [P, P, P, P, P]),
+    'rz_expand_backup_raw': (c_int, [P, P, c_int32, P, P, P, P]),
+    'rz_tree_step_raw': (c_int, [P, P, c_int32, P, P, P, P, P]),
     'rz_root_visits': (c_int, [P, P, P]),
     'rz_root_wsum': (c_int, [P, P, P]),
     'rz_root_priors': (c_int, [P, P, P]),
@@ -79,6 +81,8 @@ _SIGNATURES = {
     'rz_net_reserve': (c_int, [P, c_int32]),
     'rz_net_trunk': (c_int, [P, P, c_int32, P, P]),
     'rz_net_heads': (c_int, [P, c_int32, P, P, P]),
+    'rz_net_heads_gemm': (c_int, [P, c_int32, POINTER(c_void_p), POINTER(c_int32), POINTER(c_void_p),
+                                  POINTER(c_void_p), POINTER(c_void_p), P]),
     'rz_net_forward': (c_int, [P, P, c_int32, P, P, P]),
 }
 

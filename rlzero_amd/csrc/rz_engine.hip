@@ -457,14 +457,49 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
                   to_move == 0 ? st[1] : st[0], last, nst, S, lane);
 }
 
+// Un-normalised outputs of the evaluator's last GEMM, finished inside the tree kernel (same wave
+// per game): log_softmax over the A policy logits and value = tanh(hid . w2 + b2).  This is the
+// work of k_heads_finish (rz_net.hip), operation for operation, so both routes give identical bits.
+struct RawHeads {
+    const float *raw;  // [n_games][ld] policy logits
+    int ld;
+    const float *hid;  // [n_games][64] ReLU'd hidden layer of the value head
+    const float *w2;   // [64]
+    const float *b2;   // [1]
+};
+
 // ------------------------------------------------------------------ EXPAND + BACKUP
 // PROBS: `logp` already holds probabilities (host evaluators hand over the callable's exact
 // numbers); otherwise log-probabilities from the network (prior = exp, alphazero_agent.py:44).
 // Policy arrays are indexed by ACTION: [n_games][A].
-template <typename VT, bool PROBS = false>
+template <typename VT, bool PROBS = false, bool RAW = false>
 __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *logp, const VT *value, int g,
-                                                   int lane) {
+                                                   int lane, RawHeads rh = RawHeads()) {
     if (!E.active[g]) return;
+    float lse = 0.0f, raw_value = 0.0f;
+    if (RAW) {
+        const float *r = rh.raw + (size_t)g * rh.ld;
+        float x[kWords];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < kWords; ++i) {
+            const int j = lane + 64 * i;
+            x[i] = j < E.A ? r[j] : -INFINITY;
+            mx = fmaxf(mx, x[i]);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < kWords; ++i) sum += (lane + 64 * i < E.A) ? expf(x[i] - mx) : 0.0f;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+        lse = mx + logf(sum);
+        float h = rh.hid[(size_t)g * 64 + lane] * rh.w2[lane];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) h += __shfl_xor(h, off);
+        raw_value = tanhf(h + rh.b2[0]);
+    }
     const long long base = ((long long)g * 2 + E.cur_arena[g]) * E.cap;
     int4 *M = E.M + base;
     double *Wsum = E.Wsum + base;
@@ -474,7 +509,7 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
     const int fresh = E.leaf_fresh[g];
     const int term = E.leaf_term[g];
     // the reference evaluates terminal leaves too and discards the result (:59-68)
-    const double v = term ? E.leaf_tval[g] : (double)value[g];
+    const double v = term ? E.leaf_tval[g] : (RAW ? (double)raw_value : (double)value[g]);
     const int32_t *path = E.path + (long long)g * E.path_stride;
 
     int new_fc = -1, new_nv = 0, new_k = 0;
@@ -528,7 +563,8 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
                 if (r < 0) continue;
                 const int a = 64 * j + lane;
                 float prior = uniform;
-                if (logp) prior = PROBS ? logp[(long long)g * E.A + a] : expf(logp[(long long)g * E.A + a]);
+                if (RAW) prior = expf(rh.raw[(size_t)g * rh.ld + a] - lse);  // = exp(log_softmax)
+                else if (logp) prior = PROBS ? logp[(long long)g * E.A + a] : expf(logp[(long long)g * E.A + a]);
                 if (E.add_noise) prior = 0.75f * prior + 0.25f * (noise[j] / noise_sum);
                 P[top + r] = prior;
                 if (dense) {
@@ -571,6 +607,18 @@ template <typename VT, bool PROBS = false>
 __global__ __launch_bounds__(kWave) void k_expand_backup(Dev E, const float *logp, const VT *value) {
     __builtin_amdgcn_s_setprio(3);
     expand_backup_body<VT, PROBS>(E, logp, value, blockIdx.x, threadIdx.x);
+}
+
+__global__ __launch_bounds__(kWave) void k_expand_backup_raw(Dev E, RawHeads rh) {
+    __builtin_amdgcn_s_setprio(3);
+    expand_backup_body<float, false, true>(E, nullptr, nullptr, blockIdx.x, threadIdx.x, rh);
+}
+
+__global__ __launch_bounds__(kWave) void k_tree_step_raw(Dev E, RawHeads rh, float *obs) {
+    __builtin_amdgcn_s_setprio(3);
+    expand_backup_body<float, false, true>(E, nullptr, nullptr, blockIdx.x, threadIdx.x, rh);
+    __syncthreads();
+    select_body(E, obs, blockIdx.x, threadIdx.x);
 }
 
 // EXPAND + BACKUP of simulation s and SELECT + STEP of simulation s+1 in one launch (same
@@ -1282,6 +1330,34 @@ int rz_tree_step(rz_engine *e, const float *d_logp, const float *d_value, float 
     e->n_select += 1;
     k_tree_step<float><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_logp, d_value, d_obs);
     return launched("k_tree_step");
+}
+
+static int raw_heads_ok(rz_engine *e, const float *d_raw, int32_t ld, const float *d_hid, const float *d_w2,
+                        const float *d_b2) {
+    if (!d_raw || !d_hid || !d_w2 || !d_b2) return fail(RZ_ERR_ARG, "NULL device pointer");
+    if (ld < e->dev.A) return fail(RZ_ERR_ARG, "ld %d < n_actions %d", ld, e->dev.A);
+    return RZ_OK;
+}
+
+int rz_expand_backup_raw(rz_engine *e, const float *d_raw, int32_t ld, const float *d_hid, const float *d_w2,
+                         const float *d_b2, void *stream) {
+    RZ_ENTER(e);
+    int rc = raw_heads_ok(e, d_raw, ld, d_hid, d_w2, d_b2);
+    if (rc != RZ_OK) return rc;
+    const RawHeads rh = {d_raw, ld, d_hid, d_w2, d_b2};
+    k_expand_backup_raw<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, rh);
+    return launched("k_expand_backup_raw");
+}
+
+int rz_tree_step_raw(rz_engine *e, const float *d_raw, int32_t ld, const float *d_hid, const float *d_w2,
+                     const float *d_b2, float *d_obs, void *stream) {
+    RZ_ENTER(e);
+    int rc = raw_heads_ok(e, d_raw, ld, d_hid, d_w2, d_b2);
+    if (rc != RZ_OK) return rc;
+    e->n_select += 1;
+    const RawHeads rh = {d_raw, ld, d_hid, d_w2, d_b2};
+    k_tree_step_raw<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, rh, d_obs);
+    return launched("k_tree_step_raw");
 }
 
 int rz_root_visits(rz_engine *e, int32_t *d_visits, void *stream) {

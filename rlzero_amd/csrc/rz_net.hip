@@ -934,6 +934,25 @@ int rz_net_set_algo(rz_net *net, int32_t algo) {
     return RZ_OK;
 }
 
+int rz_net_heads_gemm(rz_net *net, int32_t n_boards, const float **d_raw, int32_t *ld, const float **d_hid,
+                      const float **d_w2, const float **d_b2, void *stream) {
+    int rc = net_ready(net, n_boards);
+    if (rc != RZ_OK) return rc;
+    if (!d_raw || !ld || !d_hid || !d_w2 || !d_b2) return net_fail(RZ_ERR_ARG, "NULL output pointer");
+    if (n_boards > net->feat_boards) return net_fail(RZ_ERR_ARG, "batch larger than rz_net_reserve()d");
+    *d_raw = net->d_raw;
+    *ld = net->dev.Npad;
+    *d_hid = net->d_hid;
+    *d_w2 = net->dev.fc_val2_w;
+    *d_b2 = net->dev.fc_val2_b;
+    if (n_boards == 0) return RZ_OK;
+    net->dev.feat_nb4 = 4 * ((n_boards + 15) / 16 * 16);
+    const dim3 grid((unsigned)((n_boards + 15) / 16), (unsigned)(net->dev.Npad / 16 + 4));
+    k_heads_gemm<<<grid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, net->d_feat, net->d_raw, net->d_hid, n_boards);
+    if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_heads_gemm failed");
+    return RZ_OK;
+}
+
 int rz_net_heads(rz_net *net, int32_t n_boards, float *d_logp, float *d_value, void *stream) {
     int rc = net_ready(net, n_boards);
     if (rc != RZ_OK) return rc;

@@ -149,6 +149,15 @@ class HipNet(object):
             self.reserve(n)
         check(self.lib.rz_net_trunk(self.handle, _ptr(obs), n, None, self._stream()), 'rz_net_trunk')
 
+    def heads_gemm(self, n):
+        """Only the FC GEMM on the internal features -> (raw ptr, ld, hid ptr, w2 ptr, b2 ptr) for
+        the tree kernels that finish log_softmax / tanh themselves."""
+        raw, hid, w2, b2 = (ctypes.c_void_p() for _ in range(4))
+        ld = ctypes.c_int32(0)
+        check(self.lib.rz_net_heads_gemm(self.handle, int(n), ctypes.byref(raw), ctypes.byref(ld), ctypes.byref(hid),
+                                         ctypes.byref(w2), ctypes.byref(b2), self._stream()), 'rz_net_heads_gemm')
+        return raw, ld.value, hid, w2, b2
+
     def heads(self, n, logp, value):
         check(self.lib.rz_net_heads(self.handle, int(n), _ptr(logp), _ptr(value), self._stream()), 'rz_net_heads')
         return logp, value
@@ -175,8 +184,14 @@ class HipNet(object):
 
 class HipNetEvaluator(object):
     """Evaluator running the leaf batch through HipNet (weights taken from a torch
-    PolicyValueNet; ``refresh()`` re-uploads them after training)."""
+    PolicyValueNet; ``refresh()`` re-uploads them after training).  ``fused_heads``: the engine
+    lets the tree kernel finish log_softmax / tanh (one launch less per simulation)."""
     needs_obs = True
+    fused_heads = True
+
+    def raw_heads(self, eng):
+        self.hip.trunk_internal(eng.obs)
+        return self.hip.heads_gemm(eng.obs.shape[0])
 
     def __init__(self, net_module, board_size, device='cuda:0', max_boards=512):
         self.module = net_module
@@ -409,6 +424,14 @@ class MCTSEngine(object):
         lib, h = self.lib, self.handle
         obs = _ptr(self.obs) if getattr(evaluator, 'needs_obs', True) else None
         check(lib.rz_select_step(h, obs, self.stream()), 'rz_select_step')
+        if getattr(evaluator, 'fused_heads', False):
+            for i in range(n):
+                raw, ld, hid, w2, b2 = evaluator.raw_heads(self)
+                if i + 1 < n:
+                    check(lib.rz_tree_step_raw(h, raw, ld, hid, w2, b2, obs, self.stream()), 'rz_tree_step_raw')
+                else:
+                    check(lib.rz_expand_backup_raw(h, raw, ld, hid, w2, b2, self.stream()), 'rz_expand_backup_raw')
+            return
         for i in range(n):
             logp, value = evaluator(self)
             if value.dtype != self.torch.float32:

@@ -136,7 +136,8 @@ __device__ __forceinline__ void conv_rows(const float *__restrict__ in, const f3
 // out[cout][y+1][x+1] = relu(acc + bias[cout]) for the lane's 4 channels of every tile/row.
 template <int PL, int TM>
 __device__ __forceinline__ void store_relu(float *__restrict__ out, const float *__restrict__ bias, int tile0,
-                                           int row0, int lane, int BH, int BW, const f32x4 (&acc)[TM][8]) {
+                                           int row0, int lane, int BH, int BW, const f32x4 (&acc)[TM][8],
+                                           int n_rows = 8) {
     const int x = lane & 15, q = lane >> 4;
     if (x >= BW) return;
 #pragma unroll
@@ -146,7 +147,7 @@ __device__ __forceinline__ void store_relu(float *__restrict__ out, const float 
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int y = row0 + t;
-            if (y >= BH) continue;
+            if (y >= BH || t >= n_rows) continue;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 out[(c0 + j) * PL + (y + 1) * kRowW + (x + 1)] = fmaxf(acc[m][t][j] + bv[j], 0.0f);
@@ -356,20 +357,28 @@ __global__ __launch_bounds__(128 * CG) void k_trunk_wino(NetDev nd, const float 
     constexpr int kLdsFloats = kPlanes * PL;
     constexpr int kThreads = 128 * CG;
     constexpr int TM2 = 4 / CG, TM3 = 8 / CG;
-    __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+    constexpr int kPartialFloats = CG * 6 * 256;
+    __shared__ __attribute__((aligned(16))) float lds[kLdsFloats + kPartialFloats];  // 155.6 KiB at CG = 4
     float *in0 = lds;
     float *c1 = in0 + kPlanesIn * PL;
     float *c2 = c1 + kPlanesC1 * PL;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cg = wave % CG, h = wave / CG;
+    float *partial = c2 + kPlanesC2 * PL;  // [cg][o][y][x] head partial sums; outside the zero-haloed planes
+    const int tid0 = threadIdx.x;
     const int BH = nd.BH, BW = nd.BW, S = nd.S;
-    const int board = blockIdx.x;
-    if (board >= n_boards) return;
+    // Persistent workgroup: the halo / padding cells are zeroed ONCE (stores below are masked to the
+    // board, so they stay zero), every interior cell is rewritten for each board.
     {
         f32x4 *z = reinterpret_cast<f32x4 *>(lds);
-        for (int i = tid; i < kLdsFloats / 4; i += kThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = tid0; i < kLdsFloats / 4; i += kThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    __syncthreads();
+    for (int board = blockIdx.x; board < n_boards; board += gridDim.x) {
+    // The thread id is laundered per board so that no lane-dependent address is hoisted out of the
+    // board loop and kept live across it (that costs ~50 spilled VGPRs).
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave % CG, h = wave / CG;
+    __syncthreads();  // first pass: the zero fill is complete before the staging writes
     {
         const float *src = obs + (size_t)board * 4 * S;
         for (int i = tid; i < 4 * S; i += kThreads) {
@@ -378,13 +387,16 @@ __global__ __launch_bounds__(128 * CG) void k_trunk_wino(NetDev nd, const float 
         }
     }
     __syncthreads();
-    {   // conv1: 4 -> 32 direct (1 % of the work): the first two channel groups take one tile each
-        const int row0 = 8 * h;
-        if (cg < 2 && row0 < BH) {
+    {   // conv1: 4 -> 32 direct (1 % of the work): 2 tiles x (2 or 4) row groups over all waves
+        constexpr int kRowsPer = (CG == 4) ? 4 : 8;
+        const int tile = cg & 1;
+        const int row0 = (CG == 4) ? 4 * (2 * h + (cg >> 1)) : 8 * h;
+        if (row0 < BH) {
             f32x4 acc[1][8];
             zero_acc<1>(acc);
-            conv_rows<PL, 4, 1>(in0, nd.w1, cg, row0, (BH - row0 == 7) ? 7 : 8, lane, acc);
-            store_relu<PL, 1>(c1, nd.b1, cg, row0, lane, BH, BW, acc);
+            if (kRowsPer == 4) conv_accumulate<PL, 4, 1, 4>(in0, nd.w1, tile, row0, lane, acc);
+            else conv_rows<PL, 4, 1>(in0, nd.w1, tile, row0, (BH - row0 == 7) ? 7 : 8, lane, acc);
+            store_relu<PL, 1>(c1, nd.b1, tile, row0, lane, BH, BW, acc, kRowsPer);
         }
     }
     __syncthreads();
@@ -410,7 +422,6 @@ __global__ __launch_bounds__(128 * CG) void k_trunk_wino(NetDev nd, const float 
         }
     }
     __syncthreads();
-    float *partial = c1;  // [cg][o][y][x]: c1 is free now
     {   // conv3: 64 -> 128; the ReLU'd output goes straight from the registers into the two 1x1
         // head convolutions
         float vals[48];  // index t*6 + o, t = nt*4 + a*2 + b
@@ -458,6 +469,7 @@ __global__ __launch_bounds__(128 * CG) void k_trunk_wino(NetDev nd, const float 
             else dst[i] = fmaxf(v, 0.0f);
         }
     }
+    }  // boards
 }
 
 // Direct path: wave w = 4*rh + q4 owns output-channel quarter q4 (the two waves of a quarter share
@@ -679,6 +691,7 @@ struct rz_net {
     int board_size = 0, device = 0;
     bool loaded = false;
     int algo = RZ_NET_WINOGRAD;
+    int n_cus = 256;
     NetDev dev;
     std::vector<void *> allocs;
     float *d_feat = nullptr, *d_raw = nullptr, *d_hid = nullptr;
@@ -770,6 +783,11 @@ int rz_net_create(int32_t height, int32_t width, int32_t n_actions, int32_t devi
     if (!net) return net_fail(RZ_ERR_OOM, "host allocation failed");
     net->board_size = height;
     net->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            net->n_cus = prop.multiProcessorCount;
+    }
     memset(&net->dev, 0, sizeof(net->dev));
     net->dev.BH = height;
     net->dev.BW = width;
@@ -893,10 +911,12 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
     const dim3 grid((unsigned)n_boards);
     // the internal buffer uses the GEMM-friendly layout, a caller's buffer the natural one
     net->dev.feat_nb4 = (d_feat == net->d_feat) ? 4 * ((n_boards + 15) / 16 * 16) : 0;
+    // Winograd kernels are persistent: one workgroup per CU (LDS bound) loops over its boards
+    const dim3 pgrid((unsigned)(n_boards < net->n_cus ? n_boards : net->n_cus));
     if (net->algo == RZ_NET_WINOGRAD)
-        k_trunk_wino<4><<<grid, dim3(512), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
+        k_trunk_wino<4><<<pgrid, dim3(512), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
     else if (net->algo == RZ_NET_WINOGRAD_4W)
-        k_trunk_wino<2><<<grid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
+        k_trunk_wino<2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
     else
         k_trunk<<<grid, dim3(kTrunkThreads), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
 }

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 11
+#define RZ_ABI_VERSION 12
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 
@@ -102,7 +102,8 @@ typedef struct rz_config {
 typedef struct rz_stats {
     int32_t error_flags;     /* OR of RZ_FLAG_* over all games since the last clear */
     int32_t first_bad_game;  /* lowest game index with a flag, or -1 */
-    int64_t arena_slots;     /* capacity per game per arena */
+    int64_t arena_slots;     /* node-record capacity per game per arena */
+    int64_t prior_floats;    /* prior-block capacity (floats) per game per arena */
     int64_t max_slots_used;  /* max over games of the current arena top */
     int64_t max_blocks_used; /* max over games of expanded nodes in the current arena */
     int64_t device_bytes;    /* bytes of HBM the engine allocated */
@@ -221,11 +222,15 @@ int rz_step_games(rz_engine *e, const int32_t *d_moves, int32_t *d_winner, uint8
 int rz_get_stats(rz_engine *e, rz_stats *out);
 int rz_clear_errors(rz_engine *e);
 
-/* Inspection for parity tests: copies game `g`'s current arena to HOST arrays of
- * max_slots entries (N, W, first-child index or -1, visited-children count, prior) and
- * its used-slot count.  Synchronous. */
+/* Inspection for parity tests: copies game `g`'s current arena to HOST arrays of max_slots
+ * entries -- per node record: N, W, slot of the first child record (-1 = none yet), number of
+ * visited children (= child records in use), number of children K (0 = not expanded), offset of
+ * the node's block of K child priors -- plus the root's own prior and the used-slot count.
+ * rz_copy_priors copies the prior arena those offsets index.  Synchronous. */
 int rz_copy_arena(rz_engine *e, int32_t game, int64_t max_slots, int32_t *h_n, double *h_w,
-                  int32_t *h_first_child, int32_t *h_n_visited, float *h_prior, int32_t *h_top);
+                  int32_t *h_first_child, int32_t *h_n_visited, int32_t *h_n_children,
+                  int32_t *h_prior_block, float *h_root_prior, int32_t *h_top);
+int rz_copy_priors(rz_engine *e, int32_t game, int64_t max_floats, float *h_priors, int32_t *h_count);
 
 /* The scoring arithmetic alone, for bit-exactness tests against CPython:
  * out[i] = w[i]/n[i] + c*sqrt(ln(np[i])/n[i]) with ln from the engine's table. */

@@ -8,7 +8,7 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64,
                     c_void_p)
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
 
@@ -31,7 +31,7 @@ class RzConfig(Structure):
 
 class RzStats(Structure):
     _fields_ = [('error_flags', c_int32), ('first_bad_game', c_int32), ('arena_slots', c_int64),
-                ('max_slots_used', c_int64), ('max_blocks_used', c_int64),
+                ('prior_floats', c_int64), ('max_slots_used', c_int64), ('max_blocks_used', c_int64),
                 ('device_bytes', c_int64), ('n_select_calls', c_int64)]
 
 
@@ -72,7 +72,8 @@ _SIGNATURES = {
     'rz_step_games': (c_int, [P, P, P, P, P]),
     'rz_get_stats': (c_int, [P, POINTER(RzStats)]),
     'rz_clear_errors': (c_int, [P]),
-    'rz_copy_arena': (c_int, [P, c_int32, c_int64, P, P, P, P, P, P]),
+    'rz_copy_arena': (c_int, [P, c_int32, c_int64, P, P, P, P, P, P, P, P]),
+    'rz_copy_priors': (c_int, [P, c_int32, c_int64, P, P]),
     'rz_uct_scores': (c_int, [P, P, P, P, c_double, P, c_int64, P]),
     'rz_net_create': (c_int, [c_int32, c_int32, c_int32, c_int32, POINTER(c_void_p)]),
     'rz_net_destroy': (c_int, [P]),

@@ -4,23 +4,29 @@
 // its simulations strictly sequentially, rlzero/mcts/alphazero_mcts.py:82-85, so this is
 // what bit-exact parity requires); the parallelism is across the lock-stepped games.
 //
-// Tree layout (struct of arrays in HBM, one arena pair per game), per node slot:
-//   M  int4    {N  visit count            (TreeNode.explore_count, rlzero/mcts/node.py:28),
-//               FC index of the first child slot, -1 = not expanded (TreeNode._children),
-//               NV number of children already visited,
-//               K  size of the children block = legal moves at this node}
-//              -- ONE 16-byte record, so a level of the descent costs one load;
-//   Wsum float64 total value              (TreeNode.total_reward,  node.py:29)
-//   P    float32 prior                    (TreeNode.prior,         node.py:30)
-// The children of a node are ONE contiguous block of K slots, slot r = r-th legal move in
-// ascending order (the reference's dict insertion order, node.py:62-73).  The reference's
-// selection rule gives an unvisited child +inf and Python's max() keeps the first maximum
-// (node.py:41-42,75-88), so the visited children of every node are always a PREFIX of its
-// block: "first unvisited child" is slot NV, no scan; a scan (coalesced,
-// fp64 score, first-index tie-break across the wave) happens only once all K are visited.
-// A slot's record is written the first time the slot is visited, so expansion only
-// reserves the block (bump allocator) and writes the K priors.  (The opt-in PUCT mode
-// initialises all K children at expansion and always scans.)
+// Tree layout (HBM, one arena pair per game).  A node is ONE 32-byte record (two int4):
+//   lo = {N   visit count                        (TreeNode.explore_count, rlzero/mcts/node.py:28),
+//         FC  slot of the first child record, -1 = no child record yet,
+//         NV  number of children already visited,
+//         K | cap << 16:  K = legal moves at this node = len(TreeNode._children), 0 = not expanded;
+//                         cap = child records reserved at FC}
+//   hi = {Wsum float64 total value               (TreeNode.total_reward, node.py:29),
+//         PB  offset of the node's block of K child priors (TreeNode.prior of each child, node.py:30),
+//         the node's own prior (float bits; maintained for roots and for dense blocks)}
+// so a level of the descent costs one 32-byte load per lane, all from one cache line.
+// The reference's selection rule gives an unvisited child +inf and Python's max() keeps the first
+// maximum (node.py:41-42,75-88), so the visited children of every node are always a PREFIX of its
+// children in ascending action order: "first unvisited child" is child NV, no scan;
+// a scan (coalesced, fp64 score, first-index tie-break across the wave) happens only once all K are
+// visited.  Only VISITED children need a record, so the child records of a node are a contiguous
+// vector [FC, FC + cap) that grows on demand (4, 8, 16 ... K: the wave copies the visited prefix to a
+// new block at the top of the arena; the old block is reclaimed by the next re-root compaction).
+// An 800-simulation search then touches ~1.5 k records (~50 KB per game, cache resident) instead of
+// one K-slot block per expansion (~5 MB per game): the tree step is latency bound, and that
+// latency is dominated by address translation and cache misses, not by instruction count.
+// The K priors of an expanded node are written once, to a bump-allocated block of the separate
+// prior arena (the reference's rule never reads them; the opt-in PUCT rule does).  PUCT mode
+// reserves and initialises all K child records at expansion (cap = K) and always scans.
 //
 // Boards: two bitboards per game (4 x u64 per colour), cell = h*BW + w.  Gomoku / TicTacToe:
 // action = cell (rlzero/games/gomoku/gomoku_env.py:227-234).  Connect4 (no reference
@@ -53,12 +59,11 @@ constexpr int kWords = RZ_BOARD_WORDS;
 struct Dev {
     int kind, BH, BW, S, A, n_row, n_games, score_mode;
     int path_stride, qcap;
-    long long cap, logtab_n;
+    long long cap, pcap, logtab_n;  // record slots / prior floats per arena
     double c_puct;
-    int4 *M;
-    double *Wsum;
-    float *P;
-    int32_t *cur_arena, *top, *nblk;
+    int4 *R;   // node records, two int4 per slot
+    float *P;  // prior blocks
+    int32_t *cur_arena, *top, *ptop, *nblk;
     uint64_t *root_stones;
     int32_t *root_to_move, *root_last;
     uint8_t *active;
@@ -75,10 +80,24 @@ struct Dev {
     uint64_t valid[kWords];
 };
 
-// field accessors of the packed node record (4-byte accesses into the int4)
-__device__ __forceinline__ int32_t *m_n(int4 *M, int i) { return reinterpret_cast<int32_t *>(M + i) + 0; }
-__device__ __forceinline__ int32_t *m_fc(int4 *M, int i) { return reinterpret_cast<int32_t *>(M + i) + 1; }
-__device__ __forceinline__ int32_t *m_nv(int4 *M, int i) { return reinterpret_cast<int32_t *>(M + i) + 2; }
+// the packed node record
+constexpr int kFirstCap = 4;  // child records reserved at a node's first visited child
+__device__ __forceinline__ int rec_k(const int4 &lo) { return lo.w & 0xffff; }
+__device__ __forceinline__ int rec_cap(const int4 &lo) { return (int)((unsigned)lo.w >> 16); }
+__device__ __forceinline__ int pack_kc(int k, int cap) { return k | (cap << 16); }
+__device__ __forceinline__ double rec_w(const int4 &hi) { return __hiloint2double(hi.y, hi.x); }
+__device__ __forceinline__ int4 make_hi(double w, int pb, float prior) {
+    return make_int4(__double2loint(w), __double2hiint(w), pb, __float_as_int(prior));
+}
+__device__ __forceinline__ int4 *arena_records(const Dev &E, int g, int arena) {
+    return E.R + 2 * (((long long)g * 2 + arena) * E.cap);
+}
+__device__ __forceinline__ float *arena_priors(const Dev &E, int g, int arena) {
+    return E.P + ((long long)g * 2 + arena) * E.pcap;
+}
+__device__ __forceinline__ int32_t *rec_n(int4 *R, int slot) { return reinterpret_cast<int32_t *>(R + 2 * slot); }
+__device__ __forceinline__ double *rec_wsum(int4 *R, int slot) { return reinterpret_cast<double *>(R + 2 * slot + 1); }
+__device__ __forceinline__ int32_t *rec_pb(int4 *R, int slot) { return reinterpret_cast<int32_t *>(R + 2 * slot + 1) + 2; }
 
 // ------------------------------------------------------------------ bitboard helpers
 __device__ __forceinline__ uint64_t word_of(const uint64_t *a, int j) {
@@ -338,14 +357,62 @@ __device__ __forceinline__ int wave_first_max(double best, int besti) {
 }
 
 // ------------------------------------------------------------------ SELECT + STEP
+// Score every child of a fully visited (or dense) node, lane r0 = lane + 64 j takes child r0, and
+// return the first maximum; the winner's record is broadcast so the descent needs no reload.
+template <bool PUCT>
+__device__ __forceinline__ int scan_children(const Dev &E, const int4 *R, const float *P, const int4 &lo,
+                                             const int4 &hi, double parent_term, int lane, int4 &clo, int4 &chi) {
+    const int k = rec_k(lo), fc = lo.y, pb = hi.z;
+    int4 klo[kWords], khi[kWords];
+    double best = -INFINITY;
+    int besti = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) {
+        const int r0 = lane + 64 * j;
+        klo[j] = make_int4(0, -1, 0, 0);
+        khi[j] = make_int4(0, 0, -1, 0);
+        if (r0 < k) {
+            klo[j] = R[2 * (fc + r0)];
+            khi[j] = R[2 * (fc + r0) + 1];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) {
+        const int r0 = lane + 64 * j;
+        if (r0 < k) {
+            const double sc = PUCT ? puct(rec_w(khi[j]), klo[j].x, P[pb + r0], parent_term, E.c_puct)
+                                   : uct_ref(rec_w(khi[j]), klo[j].x, parent_term, E.c_puct);
+            if (sc > best) {
+                best = sc;
+                besti = r0;
+            }
+        }
+    }
+    const int r = __builtin_amdgcn_readfirstlane(wave_first_max(best, besti));
+    if (r >= k) return r;
+    const int j = r >> 6, l = r & 63;
+    int4 a = klo[0], b = khi[0];
+#pragma unroll
+    for (int t = 1; t < kWords; ++t) {
+        a = (j == t) ? klo[t] : a;
+        b = (j == t) ? khi[t] : b;
+    }
+    clo = make_int4(__builtin_amdgcn_readlane(a.x, l), __builtin_amdgcn_readlane(a.y, l),
+                    __builtin_amdgcn_readlane(a.z, l), __builtin_amdgcn_readlane(a.w, l));
+    chi = make_int4(__builtin_amdgcn_readlane(b.x, l), __builtin_amdgcn_readlane(b.y, l),
+                    __builtin_amdgcn_readlane(b.z, l), __builtin_amdgcn_readlane(b.w, l));
+    return r;
+}
+
 __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int lane) {
     if (!E.active[g]) return;
     const int S = E.S;
-    const long long base = ((long long)g * 2 + E.cur_arena[g]) * E.cap;
-    int4 *M = E.M + base;
-    const double *Wsum = E.Wsum + base;
-    const float *P = E.P + base;
+    const int arena = E.cur_arena[g];
+    int4 *R = arena_records(E, g, arena);
+    const float *P = arena_priors(E, g, arena);
     const bool use_puct = E.score_mode == RZ_SCORE_PUCT;
+    const int top0 = E.top[g];
+    int top = top0;
 
     uint64_t st[2][kWords];
     load_board(E.root_stones, g, st);
@@ -357,47 +424,47 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
     int node = 0, depth = 0, fresh = 0;
     if (lane == 0) path[0] = 0;
 
+    int4 lo = R[0], hi = R[1];  // the record of `node`: loaded for the root, broadcast by the scans below
     for (int it = 0; it <= S; ++it) {
-        const int4 m = M[node];  // {N, FC, NV, K}: one load per level
-        const int fc = m.y;
-        if (fc < 0) break;  // leaf: never expanded, or a terminal position
-        const int k = m.w;
+        const int k = rec_k(lo);
+        if (k == 0) break;  // leaf: never expanded, or a terminal position
+        int fc = lo.y;
         int r;
+        int4 clo = make_int4(0, -1, 0, 0), chi = make_int4(0, 0, -1, 0);
         if (use_puct) {
-            // every child was initialised at expansion (N = 0, W = 0, prior): scan all k
-            const double sq = sqrt((double)m.x);
-            double best = -INFINITY;
-            int besti = 0x7fffffff;
-            for (int r0 = lane; r0 < k; r0 += kWave) {
-                const double sc = puct(Wsum[fc + r0], *m_n(M, fc + r0), P[fc + r0], sq, E.c_puct);
-                if (sc > best) {
-                    best = sc;
-                    besti = r0;
+            // every child was initialised at expansion (N = 0, W = 0): scan all k
+            r = scan_children<true>(E, R, P, lo, hi, sqrt((double)lo.x), lane, clo, chi);
+        } else if (lo.z < k) {
+            // some child still has N == 0 -> score +inf, first such child wins; its record is
+            // written by the backup of this simulation, here only the slot is reserved
+            const int nv = lo.z;
+            int cap = rec_cap(lo);
+            if (nv == cap) {
+                const int ncap = cap == 0 ? (k < kFirstCap ? k : kFirstCap) : (2 * cap < k ? 2 * cap : k);
+                if ((long long)top + ncap > E.cap) {
+                    flag(E, g, RZ_FLAG_ARENA_FULL, lane);
+                    fresh = 2;  // stop at this (expanded) node; the backup must not expand it again
+                    break;
                 }
+                for (int i = lane; i < nv; i += kWave) {
+                    const int4 a = R[2 * (fc + i)], b = R[2 * (fc + i) + 1];
+                    R[2 * (top + i)] = a;
+                    R[2 * (top + i) + 1] = b;
+                }
+                fc = top;
+                top += ncap;
+                cap = ncap;
             }
-            r = wave_first_max(best, besti);
-        } else if (m.z < k) {
-            // some child still has N == 0 -> score +inf, first such child wins
-            r = m.z;
+            r = nv;
             fresh = 1;
-            if (lane == 0) *m_nv(M, node) = m.z + 1;
+            if (lane == 0) R[2 * node] = make_int4(lo.x, fc, nv + 1, pack_kc(k, cap));
         } else {
-            const int pn = m.x;
+            const int pn = lo.x;
             if (pn < 1 || pn >= E.logtab_n) {
                 flag(E, g, RZ_FLAG_LOGTAB, lane);
                 break;
             }
-            const double lnp = E.logtab[pn];
-            double best = -INFINITY;
-            int besti = 0x7fffffff;
-            for (int r0 = lane; r0 < k; r0 += kWave) {
-                const double sc = uct_ref(Wsum[fc + r0], *m_n(M, fc + r0), lnp, E.c_puct);
-                if (sc > best) {
-                    best = sc;
-                    besti = r0;
-                }
-            }
-            r = wave_first_max(best, besti);
+            r = scan_children<false>(E, R, P, lo, hi, E.logtab[pn], lane, clo, chi);
         }
         if (r >= k) {
             flag(E, g, RZ_FLAG_INTERNAL, lane);
@@ -420,7 +487,10 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
         depth += 1;
         if (lane == 0) path[depth] = node;
         if (fresh) break;  // a first-visit child has no statistics and no children yet
+        lo = clo;
+        hi = chi;
     }
+    if (lane == 0 && top != top0) E.top[g] = top;
 
     // game_end_winner on the leaf (gomoku_env.py:196-203)
     int term = 0;
@@ -500,10 +570,9 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
         for (int off = 32; off >= 1; off >>= 1) h += __shfl_xor(h, off);
         raw_value = tanhf(h + rh.b2[0]);
     }
-    const long long base = ((long long)g * 2 + E.cur_arena[g]) * E.cap;
-    int4 *M = E.M + base;
-    double *Wsum = E.Wsum + base;
-    float *P = E.P + base;
+    const int arena = E.cur_arena[g];
+    int4 *R = arena_records(E, g, arena);
+    float *P = arena_priors(E, g, arena);
 
     const int depth = E.leaf_depth[g];
     const int fresh = E.leaf_fresh[g];
@@ -512,26 +581,34 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
     const double v = term ? E.leaf_tval[g] : (RAW ? (double)raw_value : (double)value[g]);
     const int32_t *path = E.path + (long long)g * E.path_stride;
 
-    int new_fc = -1, new_nv = 0, new_k = 0;
-    if (!term) {
+    int new_fc = -1, new_nv = 0, new_k = 0, new_cap = 0, new_pb = -1;
+    if (!term && fresh != 2) {
         uint64_t st[2][kWords], occ[kWords];
         load_board(E.leaf_stones, g, st);
 #pragma unroll
         for (int j = 0; j < kWords; ++j) occ[j] = st[0][j] | st[1][j];
         const Legal L = legal_of(E, occ, lane);
         const int k = L.k;
-        const int top = E.top[g];
+        const bool dense = E.score_mode == RZ_SCORE_PUCT;
+        const int ptop = E.ptop[g];
         const int nblk = E.nblk[g];
-        if ((long long)top + k > E.cap || nblk >= E.qcap) {
-            flag(E, g, (long long)top + k > E.cap ? RZ_FLAG_ARENA_FULL : RZ_FLAG_BLOCKS_FULL, lane);
+        const int top = dense ? E.top[g] : 0;
+        if ((long long)ptop + k > E.pcap || nblk >= E.qcap) {
+            flag(E, g, RZ_FLAG_BLOCKS_FULL, lane);
+        } else if (dense && (long long)top + k > E.cap) {
+            flag(E, g, RZ_FLAG_ARENA_FULL, lane);
         } else {
-            const bool dense = E.score_mode == RZ_SCORE_PUCT;
-            new_fc = top;
-            new_nv = dense ? k : 0;  // PUCT: all k children are initialised below
+            new_pb = ptop;
             new_k = k;
+            if (dense) {  // PUCT: all k child records are reserved and initialised below
+                new_fc = top;
+                new_nv = k;
+                new_cap = k;
+            }
             if (lane == 0) {
-                E.top[g] = top + k;
+                E.ptop[g] = ptop + k;
                 E.nblk[g] = nblk + 1;
+                if (dense) E.top[g] = top + k;
             }
             // TreeNode.expand: one child per legal move, prior from the policy head; in self-play
             // mixed with Dirichlet(0.3) noise at EVERY expanded node (node.py:63-69)
@@ -566,10 +643,10 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
                 if (RAW) prior = expf(rh.raw[(size_t)g * rh.ld + a] - lse);  // = exp(log_softmax)
                 else if (logp) prior = PROBS ? logp[(long long)g * E.A + a] : expf(logp[(long long)g * E.A + a]);
                 if (E.add_noise) prior = 0.75f * prior + 0.25f * (noise[j] / noise_sum);
-                P[top + r] = prior;
+                P[ptop + r] = prior;
                 if (dense) {
-                    M[top + r] = make_int4(0, -1, 0, 0);
-                    Wsum[top + r] = 0.0;
+                    R[2 * (top + r)] = make_int4(0, -1, 0, 0);
+                    R[2 * (top + r) + 1] = make_hi(0.0, -1, prior);
                 }
             }
         }
@@ -580,20 +657,21 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
         const int node = path[d];
         const double x = ((depth - d) & 1) ? v : -v;
         if (d == depth) {
-            // the leaf: first-visit slots get their whole record here; an old leaf that is now
-            // expanded gets its child block
-            if (fresh) {
-                M[node] = make_int4(1, new_fc, new_nv, new_k);
-                Wsum[node] = 0.0 + x;  // int 0 + float in the reference (node.py:29,133)
+            // the leaf: a first-visit slot gets its whole record here; an old leaf that is now
+            // expanded gets its prior block (and, dense, its child block)
+            if (fresh == 1) {
+                R[2 * node] = make_int4(1, new_fc, new_nv, pack_kc(new_k, new_cap));
+                R[2 * node + 1] = make_hi(0.0 + x, new_pb, 0.0f);  // int 0 + float in the reference (node.py:29,133)
             } else {
-                const int4 m = M[node];
-                M[node] = (new_fc >= 0) ? make_int4(m.x + 1, new_fc, new_nv, new_k)
-                                        : make_int4(m.x + 1, m.y, m.z, m.w);
-                Wsum[node] += x;
+                const int4 m = R[2 * node];
+                R[2 * node] = (new_k > 0) ? make_int4(m.x + 1, new_fc, new_nv, pack_kc(new_k, new_cap))
+                                          : make_int4(m.x + 1, m.y, m.z, m.w);
+                *rec_wsum(R, node) += x;
+                if (new_k > 0) *rec_pb(R, node) = new_pb;
             }
         } else {
-            *m_n(M, node) += 1;
-            Wsum[node] += x;
+            *rec_n(R, node) += 1;
+            *rec_wsum(R, node) += x;
         }
     }
 }
@@ -727,15 +805,18 @@ __global__ __launch_bounds__(kWave) void k_eval_rollout(Dev E, uint64_t seed, ui
 __global__ __launch_bounds__(kWave) void k_root_children(Dev E, int what, void *out) {
     const int g = blockIdx.x;
     const int lane = threadIdx.x;
-    const long long base = ((long long)g * 2 + E.cur_arena[g]) * E.cap;
+    const int arena = E.cur_arena[g];
+    const int4 *R = arena_records(E, g, arena);
+    const float *P = arena_priors(E, g, arena);
     uint64_t st[2][kWords], occ[kWords];
     load_board(E.root_stones, g, st);
 #pragma unroll
     for (int j = 0; j < kWords; ++j) occ[j] = st[0][j] | st[1][j];
     const Legal L = legal_of(E, occ, lane);
-    const int4 m = E.M[base];
-    const int fc = m.y;
-    const int nv = fc >= 0 ? m.z : 0;
+    const int4 lo = R[0], hi = R[1];
+    const bool expanded = rec_k(lo) > 0;
+    const int fc = lo.y;
+    const int nv = expanded ? lo.z : 0;
     int before = 0;
 #pragma unroll
     for (int j = 0; j < kWords; ++j) {
@@ -744,44 +825,49 @@ __global__ __launch_bounds__(kWave) void k_root_children(Dev E, int what, void *
         if (a >= E.A) continue;
         const bool seen = r >= 0 && r < nv;
         const long long o = (long long)g * E.A + a;
-        if (what == 0) ((int32_t *)out)[o] = seen ? E.M[base + fc + r].x : 0;
-        else if (what == 1) ((double *)out)[o] = seen ? E.Wsum[base + fc + r] : 0.0;
-        else ((float *)out)[o] = (r >= 0 && fc >= 0) ? E.P[base + fc + r] : 0.0f;
+        if (what == 0) ((int32_t *)out)[o] = seen ? R[2 * (fc + r)].x : 0;
+        else if (what == 1) ((double *)out)[o] = seen ? rec_w(R[2 * (fc + r) + 1]) : 0.0;
+        else ((float *)out)[o] = (r >= 0 && expanded) ? P[hi.z + r] : 0.0f;
     }
 }
 
 __global__ void k_root_stats(Dev E, int32_t *n, double *w) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= E.n_games) return;
-    const long long base = ((long long)g * 2 + E.cur_arena[g]) * E.cap;
-    n[g] = E.M[base].x;
-    w[g] = E.Wsum[base];
+    const int4 *R = arena_records(E, g, E.cur_arena[g]);
+    n[g] = R[0].x;
+    w[g] = rec_w(R[1]);
 }
 
 // ------------------------------------------------------------------ tree reuse
 __device__ __forceinline__ void fresh_root(const Dev &E, int g, int arena, int lane) {
     if (lane == 0) {
-        const long long base = ((long long)g * 2 + arena) * E.cap;
-        E.M[base] = make_int4(0, -1, 0, 0);
-        E.Wsum[base] = 0.0;
-        E.P[base] = 1.0f;
+        int4 *R = arena_records(E, g, arena);
+        R[0] = make_int4(0, -1, 0, 0);
+        R[1] = make_hi(0.0, -1, 1.0f);  // TreeNode(None, 1.0), alphazero_mcts.py:35,103
         E.cur_arena[g] = arena;
         E.top[g] = 1;
+        E.ptop[g] = 0;
         E.nblk[g] = 0;
     }
 }
 
 // AlphaZeroMCTS.update_with_move (alphazero_mcts.py:96-103).  The kept subtree is copied
-// breadth-first into the game's other arena (blocks re-reserved at full width, only the
-// visited prefix copied), which also recycles every slot of the discarded siblings.
+// breadth-first into the game's other arena (per expanded node: its prior block, and the visited
+// prefix of its child records into a block of the same capacity), which also recycles the slots
+// of the discarded siblings and of every outgrown child block.  A copied record keeps its SOURCE
+// first-child / prior-block offsets until the node itself is taken from the queue, so the queue
+// holds destination slots only.
 __global__ __launch_bounds__(kWave) void k_advance(Dev E, const int32_t *moves) {
     const int g = blockIdx.x;
     const int lane = threadIdx.x;
     const int mv = moves[g];
     if (mv == -2) return;
     const int src_arena = E.cur_arena[g], dst_arena = src_arena ^ 1;
-    const long long sb = ((long long)g * 2 + src_arena) * E.cap;
-    const long long db = ((long long)g * 2 + dst_arena) * E.cap;
+    const int4 *Rs = arena_records(E, g, src_arena);
+    int4 *Rd = arena_records(E, g, dst_arena);
+    const float *Ps = arena_priors(E, g, src_arena);
+    float *Pd = arena_priors(E, g, dst_arena);
     if (mv < 0) {
         if (mv != -1) flag(E, g, RZ_FLAG_ILLEGAL_MOVE, lane);
         fresh_root(E, g, dst_arena, lane);
@@ -798,61 +884,47 @@ __global__ __launch_bounds__(kWave) void k_advance(Dev E, const int32_t *moves) 
         fresh_root(E, g, dst_arena, lane);
         return;
     }
-    const int4 root = E.M[sb];
-    if (root.y < 0 || rank >= root.z) {
+    const int4 rlo = Rs[0], rhi = Rs[1];
+    if (rec_k(rlo) == 0 || rank >= rlo.z) {
         // the chosen child was never visited: it is a TreeNode with N = 0 and no children
         fresh_root(E, g, dst_arena, lane);
         return;
     }
-    const int src = root.y + rank;
-    const int4 sm = E.M[sb + src];
-    int32_t *queue = E.queue + (long long)g * E.qcap * 4;
-    int q_tail = 0;
+    const int src = rlo.y + rank;
+    const int4 slo = Rs[2 * src], shi = Rs[2 * src + 1];
+    const float prior = Ps[rhi.z + rank];
+    int32_t *queue = E.queue + (long long)g * E.qcap;
     if (lane == 0) {
-        E.M[db] = make_int4(sm.x, -1, sm.z, sm.w);
-        E.Wsum[db] = E.Wsum[sb + src];
-        E.P[db] = E.P[sb + src];
-        if (sm.y >= 0) {
-            queue[0] = 0;
-            queue[1] = sm.y;
-            queue[2] = sm.z;
-            queue[3] = sm.w;
-        }
+        Rd[0] = slo;
+        Rd[1] = make_int4(shi.x, shi.y, shi.z, __float_as_int(prior));
+        queue[0] = 0;
     }
-    if (sm.y >= 0) q_tail = 1;
+    int q_tail = rec_k(slo) > 0 ? 1 : 0;
     __syncthreads();
-    int dtop = 1, nblk = 0;
+    int dtop = 1, dptop = 0, nblk = 0;
     bool full = false;
     for (int q_head = 0; q_head < q_tail; ++q_head) {
-        const int dst = queue[4 * q_head + 0];
-        const int sfc = queue[4 * q_head + 1];
-        const int nv = queue[4 * q_head + 2];
-        const int k = queue[4 * q_head + 3];
-        if ((long long)dtop + k > E.cap || nblk >= E.qcap) {
+        const int dst = queue[q_head];
+        const int4 lo = Rd[2 * dst], hi = Rd[2 * dst + 1];
+        const int k = rec_k(lo), cap = rec_cap(lo), nv = lo.z, sfc = lo.y, spb = hi.z;
+        if ((long long)dptop + k > E.pcap || (long long)dtop + cap > E.cap || nblk >= E.qcap) {
             full = true;
             break;
         }
-        if (lane == 0) *m_fc(E.M + db, dst) = dtop;
-        for (int r0 = 0; r0 < k; r0 += kWave) {
+        for (int r = lane; r < k; r += kWave) Pd[dptop + r] = Ps[spb + r];
+        for (int r0 = 0; r0 < nv; r0 += kWave) {
             const int r = r0 + lane;
-            if (r < k) E.P[db + dtop + r] = E.P[sb + sfc + r];
-            int cfc = -1;
-            int4 cm = make_int4(0, -1, 0, 0);
+            bool expanded = false;
             if (r < nv) {
-                cm = E.M[sb + sfc + r];
-                cfc = cm.y;
-                E.M[db + dtop + r] = make_int4(cm.x, -1, cm.z, cm.w);
-                E.Wsum[db + dtop + r] = E.Wsum[sb + sfc + r];
+                const int4 a = Rs[2 * (sfc + r)], b = Rs[2 * (sfc + r) + 1];
+                Rd[2 * (dtop + r)] = a;
+                Rd[2 * (dtop + r) + 1] = b;
+                expanded = rec_k(a) > 0;
             }
-            const unsigned long long has = __ballot(cfc >= 0);
-            if (cfc >= 0) {
+            const unsigned long long has = __ballot(expanded);
+            if (expanded) {
                 const int pos = q_tail + __popcll(has & ((1ull << lane) - 1ull));
-                if (pos < E.qcap) {
-                    queue[4 * pos + 0] = dtop + r;
-                    queue[4 * pos + 1] = cfc;
-                    queue[4 * pos + 2] = cm.z;
-                    queue[4 * pos + 3] = cm.w;
-                }
+                if (pos < E.qcap) queue[pos] = dtop + r;
             }
             q_tail += __popcll(has);
         }
@@ -860,9 +932,14 @@ __global__ __launch_bounds__(kWave) void k_advance(Dev E, const int32_t *moves) 
             full = true;
             break;
         }
-        dtop += k;
+        if (lane == 0) {
+            Rd[2 * dst] = make_int4(lo.x, cap > 0 ? dtop : -1, nv, lo.w);
+            *rec_pb(Rd, dst) = dptop;
+        }
+        dtop += cap;
+        dptop += k;
         nblk += 1;
-        __syncthreads();  // queue entries written by other lanes are read next iteration
+        __syncthreads();  // records and queue entries written by other lanes are read next iteration
     }
     if (full) {
         flag(E, g, RZ_FLAG_BLOCKS_FULL, lane);
@@ -872,6 +949,7 @@ __global__ __launch_bounds__(kWave) void k_advance(Dev E, const int32_t *moves) 
     if (lane == 0) {
         E.cur_arena[g] = dst_arena;
         E.top[g] = dtop;
+        E.ptop[g] = dptop;
         E.nblk[g] = nblk;
     }
 }
@@ -1099,8 +1177,14 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     D.add_noise = cfg->add_noise ? 1 : 0;
     D.noise_seed = (uint64_t)(uint32_t)cfg->noise_seed;
     D.c_puct = cfg->c_puct;
-    D.cap = (long long)(pf * (double)cfg->n_playout * (double)A) + A + 2;
-    D.qcap = (int)(pf * (double)cfg->n_playout) + 8;
+    // qcap expanded nodes (= prior blocks) per arena: this move's n_playout plus a carried subtree of
+    // up to pf * n_playout.  Record slots: dense (PUCT) = one K-block per expansion; otherwise only
+    // visited nodes hold records, at most ~3 slots per simulation with the doubling child vectors
+    // (typically ~2), so 16 per expansion leaves a wide margin.
+    D.qcap = (int)((pf + 1.0) * (double)cfg->n_playout) + 8;
+    D.pcap = (long long)D.qcap * A;
+    D.cap = cfg->score_mode == RZ_SCORE_PUCT ? (long long)D.qcap * A + 2
+                                             : (long long)D.qcap * 16 + 2 * A + 64;
     D.path_stride = S + 2;
     D.logtab_n = (long long)cfg->n_playout * (S + 1) + 2;
     for (int j = 0; j < kWords; ++j) {
@@ -1109,14 +1193,19 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     }
     const long long G = cfg->n_games;
     const long long slots = G * 2 * D.cap;
+    if (D.cap >= (1ll << 30) || D.pcap >= (1ll << 31))
+    {
+        delete e;
+        return fail(RZ_ERR_ARG, "n_playout %d is too large for 32-bit slot indices", cfg->n_playout);
+    }
     int rc = RZ_OK;
 #define RZ_ALLOC(field, count)                               \
     if (rc == RZ_OK) rc = dev_alloc(e, &D.field, (count))
-    RZ_ALLOC(M, slots);
-    RZ_ALLOC(Wsum, slots);
-    RZ_ALLOC(P, slots);
+    RZ_ALLOC(R, slots * 2);
+    RZ_ALLOC(P, G * 2 * D.pcap);
     RZ_ALLOC(cur_arena, G);
     RZ_ALLOC(top, G);
+    RZ_ALLOC(ptop, G);
     RZ_ALLOC(nblk, G);
     RZ_ALLOC(root_stones, G * 2 * kWords);
     RZ_ALLOC(root_to_move, G);
@@ -1131,7 +1220,7 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     RZ_ALLOC(leaf_stones, G * 2 * kWords);
     RZ_ALLOC(leaf_to_move, G);
     RZ_ALLOC(leaf_last, G);
-    RZ_ALLOC(queue, G * D.qcap * 4);
+    RZ_ALLOC(queue, G * D.qcap);
     RZ_ALLOC(err, G);
     RZ_ALLOC(err_any, 1);
     RZ_ALLOC(noise_ctr, G);
@@ -1145,7 +1234,7 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     // zero the small state; arenas need no initialisation beyond the root slot
     hipError_t herr = hipSuccess;
     auto zero = [&](void *p, size_t bytes) { if (herr == hipSuccess) herr = hipMemset(p, 0, bytes); };
-    zero(D.cur_arena, G * 4); zero(D.top, G * 4); zero(D.nblk, G * 4);
+    zero(D.cur_arena, G * 4); zero(D.top, G * 4); zero(D.ptop, G * 4); zero(D.nblk, G * 4);
     zero(D.root_stones, G * 2 * kWords * 8); zero(D.root_to_move, G * 4);
     zero(D.leaf_node, G * 4); zero(D.leaf_depth, G * 4); zero(D.leaf_fresh, G * 4);
     zero(D.leaf_term, G * 4); zero(D.leaf_tval, G * 8); zero(D.leaf_stones, G * 2 * kWords * 8);
@@ -1422,6 +1511,7 @@ int rz_get_stats(rz_engine *e, rz_stats *out) {
         if (nblk[g] > out->max_blocks_used) out->max_blocks_used = nblk[g];
     }
     out->arena_slots = e->dev.cap;
+    out->prior_floats = e->dev.pcap;
     out->device_bytes = e->bytes;
     out->n_select_calls = e->n_select;
     return RZ_OK;
@@ -1436,7 +1526,8 @@ int rz_clear_errors(rz_engine *e) {
 }
 
 int rz_copy_arena(rz_engine *e, int32_t game, int64_t max_slots, int32_t *h_n, double *h_w,
-                  int32_t *h_first_child, int32_t *h_n_visited, float *h_prior, int32_t *h_top) {
+                  int32_t *h_first_child, int32_t *h_n_visited, int32_t *h_n_children,
+                  int32_t *h_prior_block, float *h_root_prior, int32_t *h_top) {
     RZ_ENTER(e);
     RZ_NEED(h_top);
     if (game < 0 || game >= e->cfg.n_games) return fail(RZ_ERR_ARG, "game %d out of range", game);
@@ -1448,17 +1539,34 @@ int rz_copy_arena(rz_engine *e, int32_t game, int64_t max_slots, int32_t *h_n, d
     long long n = top < max_slots ? top : max_slots;
     if (n <= 0) return RZ_OK;
     const long long base = ((long long)game * 2 + arena) * e->dev.cap;
-    if (h_n || h_first_child || h_n_visited) {
-        std::vector<int4> meta((size_t)n);
-        RZ_HIP(hipMemcpy(meta.data(), e->dev.M + base, (size_t)n * sizeof(int4), hipMemcpyDeviceToHost));
-        for (long long i = 0; i < n; ++i) {
-            if (h_n) h_n[i] = meta[(size_t)i].x;
-            if (h_first_child) h_first_child[i] = meta[(size_t)i].y;
-            if (h_n_visited) h_n_visited[i] = meta[(size_t)i].z;
-        }
+    std::vector<int4> rec((size_t)n * 2);
+    RZ_HIP(hipMemcpy(rec.data(), e->dev.R + 2 * base, (size_t)n * 2 * sizeof(int4), hipMemcpyDeviceToHost));
+    for (long long i = 0; i < n; ++i) {
+        const int4 lo = rec[(size_t)(2 * i)], hi = rec[(size_t)(2 * i + 1)];
+        if (h_n) h_n[i] = lo.x;
+        if (h_first_child) h_first_child[i] = lo.y;
+        if (h_n_visited) h_n_visited[i] = lo.z;
+        if (h_n_children) h_n_children[i] = lo.w & 0xffff;
+        if (h_prior_block) h_prior_block[i] = hi.z;
+        if (h_w) memcpy(&h_w[i], &hi.x, 8);
     }
-    if (h_w) RZ_HIP(hipMemcpy(h_w, e->dev.Wsum + base, (size_t)n * 8, hipMemcpyDeviceToHost));
-    if (h_prior) RZ_HIP(hipMemcpy(h_prior, e->dev.P + base, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (h_root_prior) memcpy(h_root_prior, &rec[1].w, 4);
+    return RZ_OK;
+}
+
+int rz_copy_priors(rz_engine *e, int32_t game, int64_t max_floats, float *h_priors, int32_t *h_count) {
+    RZ_ENTER(e);
+    RZ_NEED(h_count);
+    if (game < 0 || game >= e->cfg.n_games) return fail(RZ_ERR_ARG, "game %d out of range", game);
+    RZ_HIP(hipDeviceSynchronize());
+    int32_t arena = 0, ptop = 0;
+    RZ_HIP(hipMemcpy(&arena, e->dev.cur_arena + game, 4, hipMemcpyDeviceToHost));
+    RZ_HIP(hipMemcpy(&ptop, e->dev.ptop + game, 4, hipMemcpyDeviceToHost));
+    *h_count = ptop;
+    const long long n = ptop < max_floats ? ptop : max_floats;
+    if (n <= 0 || h_priors == nullptr) return RZ_OK;
+    RZ_HIP(hipMemcpy(h_priors, e->dev.P + ((long long)game * 2 + arena) * e->dev.pcap, (size_t)n * 4,
+                     hipMemcpyDeviceToHost));
     return RZ_OK;
 }
 

@@ -513,21 +513,34 @@ class MCTSEngine(object):
 
     # ------------------------------------------------------------------ inspection
     def arena(self, game=0):
-        cap = int(self.stats().arena_slots)
+        """Host snapshot of one game's tree.  Per node record (slot): N, W, FC (slot of the first child
+        record, -1 = none yet), NV (visited children = child records in use), K (children, 0 = not
+        expanded), PB (offset into PRI of the node's K child priors); the visited child r < NV of a node
+        is slot FC + r and the prior of ANY child r < K is PRI[PB + r]."""
+        st = self.stats()
+        cap = int(st.arena_slots)
         n = np.zeros(cap, np.int32)
         w = np.zeros(cap, np.float64)
         fc = np.zeros(cap, np.int32)
         nv = np.zeros(cap, np.int32)
-        p = np.zeros(cap, np.float32)
-        top = ctypes.c_int32(0)
+        kk = np.zeros(cap, np.int32)
+        pb = np.zeros(cap, np.int32)
+        pri = np.zeros(int(st.prior_floats), np.float32)
+        root_prior = ctypes.c_float(1.0)
+        top, ptop = ctypes.c_int32(0), ctypes.c_int32(0)
 
         def hp(a):
             return ctypes.c_void_p(a.ctypes.data)
 
-        check(self.lib.rz_copy_arena(self.handle, int(game), cap, hp(n), hp(w), hp(fc), hp(nv), hp(p),
-                                     ctypes.cast(ctypes.byref(top), ctypes.c_void_p)), 'rz_copy_arena')
+        def ref(x):
+            return ctypes.cast(ctypes.byref(x), ctypes.c_void_p)
+
+        check(self.lib.rz_copy_arena(self.handle, int(game), cap, hp(n), hp(w), hp(fc), hp(nv), hp(kk), hp(pb),
+                                     ref(root_prior), ref(top)), 'rz_copy_arena')
+        check(self.lib.rz_copy_priors(self.handle, int(game), pri.size, hp(pri), ref(ptop)), 'rz_copy_priors')
         k = top.value
-        return {'N': n[:k], 'W': w[:k], 'FC': fc[:k], 'NV': nv[:k], 'P': p[:k], 'top': k}
+        return {'N': n[:k], 'W': w[:k], 'FC': fc[:k], 'NV': nv[:k], 'K': kk[:k], 'PB': pb[:k],
+                'PRI': pri[:ptop.value], 'root_prior': float(root_prior.value), 'top': k}
 
     def tree_dump(self, game=0):
         """{path of actions: (N, W)} over visited nodes (+ the root), like the oracle's."""
@@ -539,11 +552,12 @@ class MCTSEngine(object):
         while stack:
             path, slot, occ = stack.pop()
             out[path] = (int(ar['N'][slot]), float(ar['W'][slot]))
-            fc = int(ar['FC'][slot])
-            if fc < 0:
+            nv = int(ar['NV'][slot])
+            if int(ar['K'][slot]) == 0 or nv == 0:
                 continue
+            fc = int(ar['FC'][slot])
             legal = self.legal_actions(occ)
-            for r in range(int(ar['NV'][slot])):
+            for r in range(nv):
                 if int(ar['N'][fc + r]) > 0:  # PUCT initialises every child; only visited ones count
                     a = legal[r]
                     stack.append((path + (a, ), fc + r, occ | (1 << self.cell_of_action(occ, a))))

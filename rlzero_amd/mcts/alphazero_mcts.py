@@ -43,13 +43,14 @@ class TreeNodeView(object):
         if self._kids is None:
             self._kids = {}
             snap = self._snap
-            fc = int(snap['FC'][self._slot]) if self._visited or self._parent is None else -1
-            if fc >= 0:
-                nv = int(snap['NV'][self._slot])
+            k = int(snap['K'][self._slot]) if self._visited or self._parent is None else 0
+            if k > 0:
+                fc, nv, pb = int(snap['FC'][self._slot]), int(snap['NV'][self._slot]), int(snap['PB'][self._slot])
                 empties = [c for c in range(snap['cells']) if not (self._occ >> c) & 1]
                 for r, a in enumerate(empties):
-                    self._kids[a] = TreeNodeView(snap, fc + r, self._occ | (1 << a), self,
-                                                 float(snap['P'][fc + r]), visited=r < nv)
+                    seen = r < nv  # only visited children hold a record
+                    self._kids[a] = TreeNodeView(snap, fc + r if seen else 0, self._occ | (1 << a), self,
+                                                 float(snap['PRI'][pb + r]), visited=seen)
         return self._kids
 
     children = _children
@@ -157,12 +158,13 @@ class AlphaZeroMCTS(object):
     @property
     def _root(self):
         if self._engine is None:
-            return TreeNodeView({'N': [0], 'W': [0], 'FC': [-1], 'NV': [0], 'P': [1.0], 'cells': 0}, 0, 0)
+            return TreeNodeView({'N': [0], 'W': [0], 'FC': [-1], 'NV': [0], 'K': [0], 'PB': [-1], 'PRI': [],
+                                 'cells': 0}, 0, 0)
         snap = self._engine.arena(0)
         snap['cells'] = self._engine.n_cells
         stones, _, _ = self._engine.get_roots()
         occ = bits_to_int(stones[0, 0]) | bits_to_int(stones[0, 1])
-        return TreeNodeView(snap, 0, occ, None, float(snap['P'][0]))
+        return TreeNodeView(snap, 0, occ, None, snap['root_prior'])
 
     def __str__(self):
         return 'AlphaZeroMCTS'

@@ -94,7 +94,8 @@ class RolloutMCTS(object):
     @property
     def _root(self):
         if self._engine is None:
-            return TreeNodeView({'N': [0], 'W': [0], 'FC': [-1], 'NV': [0], 'P': [1.0], 'cells': 0}, 0, 0)
+            return TreeNodeView({'N': [0], 'W': [0], 'FC': [-1], 'NV': [0], 'K': [0], 'PB': [-1], 'PRI': [],
+                                 'cells': 0}, 0, 0)
         from ..engine import bits_to_int
         snap = self._engine.arena(0)
         snap['cells'] = self._engine.n_cells

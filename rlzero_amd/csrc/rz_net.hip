@@ -49,14 +49,17 @@ struct NetDev {
     const float *b1, *b2, *b3;   // conv biases
     const float *wh;             // [6][128]: act_conv1 (4 rows) then val_conv1 (2 rows)
     const float *bh;             // [6]
-    const float *fc_act_t;       // act_fc1.weight transposed, zero padded: [4*steps_act][Npad]
+    const float *fc_act_w;       // act_fc1.weight [out][in], zero padded to [Npad][16*groups_act]
     const float *fc_act_b;       // [Npad]
-    const float *fc_val1_t;      // val_fc1.weight transposed, zero padded: [4*steps_val][64]
+    const float *fc_val1_w;      // val_fc1.weight [out][in], zero padded to [64][16*groups_val]
     const float *fc_val1_b;      // [64]
     const float *fc_val2_w;      // [64]
     const float *fc_val2_b;      // [1]
-    int feat_nb4;  // 0: features as [board][6S]; else 4*padded_boards: features as [k/4][board][4]
-    int BH, BW, S, A, Npad, steps_act, steps_val;  // A policy outputs; steps_*: k-steps of 4, multiples of 4*kHeadU
+    // head features of a board: policy inputs at [0, 4S), value inputs at [feat_val_off, +2S) of a row of
+    // feat_ld floats.  A caller's buffer is the natural [board][6S]; the internal one pads both ranges
+    // to multiples of 16 (zero filled) so the FC GEMM reads aligned 16-byte fragments.
+    int feat_ld, feat_val_off;
+    int BH, BW, S, A, Npad, groups_act, groups_val;  // A policy outputs (Npad: padded to 32); groups_*: K / 16
 };
 
 // Operand fragments of one input-channel group (4 channels x 9 taps) for a wave that owns TM
@@ -459,14 +462,13 @@ __global__ __launch_bounds__(128 * CG) void k_trunk_wino(NetDev nd, const float 
     }
     __syncthreads();
     {
-        float *dst = feat + (size_t)board * 6 * S;
+        float *dst = feat + (size_t)board * nd.feat_ld;
         for (int i = tid; i < 6 * S; i += kThreads) {
             const int o = i / S, r = i - o * S, y = r / BW, x = r - y * BW;
             float v = nd.bh[o];
 #pragma unroll
             for (int k = 0; k < CG; ++k) v += partial[((k * 6 + o) * 16 + y) * 16 + x];
-            if (nd.feat_nb4) feat[(size_t)(i >> 2) * nd.feat_nb4 + board * 4 + (i & 3)] = fmaxf(v, 0.0f);
-            else dst[i] = fmaxf(v, 0.0f);
+            dst[i < 4 * S ? i : i - 4 * S + nd.feat_val_off] = fmaxf(v, 0.0f);
         }
     }
     }  // boards
@@ -568,85 +570,107 @@ __global__ __launch_bounds__(kTrunkThreads) void k_trunk(NetDev nd, const float 
     }
     __syncthreads();
     {
-        float *dst = feat + (size_t)board * 6 * S;
+        float *dst = feat + (size_t)board * nd.feat_ld;
         for (int i = tid; i < 6 * S; i += kTrunkThreads) {
             const int o = i / S, r = i - o * S, y = r / BW, x = r - y * BW;
             float v = nd.bh[o];
 #pragma unroll
             for (int k = 0; k < 4; ++k) v += partial[((k * 6 + o) * 16 + y) * 16 + x];
-            if (nd.feat_nb4) feat[(size_t)(i >> 2) * nd.feat_nb4 + board * 4 + (i & 3)] = fmaxf(v, 0.0f);
-            else dst[i] = fmaxf(v, 0.0f);
+            dst[i < 4 * S ? i : i - 4 * S + nd.feat_val_off] = fmaxf(v, 0.0f);
         }
     }
 }
 
 // ------------------------------------------------------------------ heads (FC layers)
-// k_heads_gemm: the two first FC layers as ONE fp32-MFMA GEMM over (tile of 16 boards) x (tile of
-// 16 outputs): M = boards, N = outputs (S policy logits padded to a multiple of 16, then the 64
-// hidden units of the value head), K = 4S (policy) / 2S (value).  One workgroup per
-// (board tile, output tile); its 4 waves split K, each streaming its slice of the features and
-// of the transposed, zero-padded weights from L2 with a 16-step register prefetch (no LDS
-// staging -> many workgroups per CU hide the latency of the short dependent MFMA chains), then
-// the 4 partial tiles are summed through LDS.  k_heads_finish: log_softmax / fc2 + tanh.
-constexpr int kHeadU = 16;  // k-steps per prefetch group
+// k_heads_gemm: the two first FC layers as ONE fp32-MFMA GEMM: M = boards, N = outputs (policy
+// logits padded to a multiple of 32, then the 64 hidden units of the value head), K = 4S (policy) /
+// 2S (value), both padded to multiples of 16.  One workgroup per (32 boards) x (32 outputs); its 4
+// waves split K and each accumulates the whole 2 x 2 block of 16 x 16 tiles over its slice, so a
+// fragment pair feeds four independent MFMA chains.  Operands stream straight from L2 in their
+// natural row-major layouts: lane (row r, quarter q) loads 16 bytes = k 16g + 4q .. + 3 of its row,
+// the 4 values being the lane's operand of the 4 MFMA steps of group g (the order in which K is
+// consumed is free as long as both operands agree).  A ring of kHeadDepth groups is kept in flight.
+// The 4 partial blocks are summed through LDS.  k_heads_finish: log_softmax / fc2 + tanh.
+constexpr int kHeadDepth = 4;
 
 __global__ __launch_bounds__(256) void k_heads_gemm(NetDev nd, const float *__restrict__ feat,
                                                     float *__restrict__ raw, float *__restrict__ hid,
                                                     int n_boards) {
-    __shared__ float part[4][4][64];
+    __shared__ f32x4 part[4][4][64];
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int S = nd.S;
-    const int b0 = blockIdx.x * 16;
-    const int n_act_tiles = nd.Npad / 16;
+    const int b0 = blockIdx.x * 32;
+    const int n_act_tiles = nd.Npad / 32;
     const int ot = blockIdx.y;
     const bool is_act = ot < n_act_tiles;
-    const int n = lane & 15, kq = lane >> 4;
-    const int steps = (is_act ? nd.steps_act : nd.steps_val) / 4;  // per wave
-    const int ldw = is_act ? nd.Npad : 64;
-    const int s_first = wave * steps;
-    const float *w = (is_act ? nd.fc_act_t + 16 * ot : nd.fc_val1_t + 16 * (ot - n_act_tiles)) +
-                     (size_t)(4 * s_first + kq) * ldw + n;
-    // A row = board (lane & 15); features are stored [k/4][board][4], so the 64 lanes of one load
-    // (16 boards x 4 consecutive k) read 256 contiguous bytes.  Rows of padded boards are zero.
-    const size_t nb4 = (size_t)nd.feat_nb4;
-    const float *a = feat + ((size_t)(is_act ? 0 : S) + s_first) * nb4 + (size_t)(b0 + n) * 4 + kq;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    float acur[kHeadU], bcur[kHeadU], anxt[kHeadU], bnxt[kHeadU];
+    const int m = lane & 15, kq = lane >> 4;
+    const int groups = is_act ? nd.groups_act : nd.groups_val;
+    const int g0 = wave * groups / 4, g1 = (wave + 1) * groups / 4;
+    const size_t ldw = (size_t)16 * groups, lda = (size_t)nd.feat_ld;
+    const int n0 = 32 * (is_act ? ot : ot - n_act_tiles);
+    const float *w = (is_act ? nd.fc_act_w : nd.fc_val1_w) + (size_t)(n0 + m) * ldw + 4 * kq;
+    const float *a = feat + (size_t)(b0 + m) * lda + (is_act ? 0 : nd.feat_val_off) + 4 * kq;
+    f32x4 acc[2][2];
 #pragma unroll
-    for (int u = 0; u < kHeadU; ++u) {
-        acur[u] = a[(size_t)u * nb4];
-        bcur[u] = w[(size_t)(4 * u) * ldw];
-    }
-    for (int s0 = 0; s0 < steps; s0 += kHeadU) {
-        const int sn = (s0 + kHeadU < steps) ? s0 + kHeadU : s0;  // last group re-reads itself
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int u = 0; u < kHeadU; ++u) {
-            anxt[u] = a[(size_t)(sn + u) * nb4];
-            bnxt[u] = w[(size_t)(4 * (sn + u)) * ldw];
-        }
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 ra[kHeadDepth][2], rw[kHeadDepth][2];
 #pragma unroll
-        for (int u = 0; u < kHeadU; ++u)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[u], bcur[u], acc, 0, 0, 0);
+    for (int d = 0; d < kHeadDepth; ++d) {
+        const int g = g0 + d;
 #pragma unroll
-        for (int u = 0; u < kHeadU; ++u) {
-            acur[u] = anxt[u];
-            bcur[u] = bnxt[u];
+        for (int i = 0; i < 2; ++i) {
+            ra[d][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            rw[d][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (g < g1) {
+                ra[d][i] = *reinterpret_cast<const f32x4 *>(a + (size_t)(16 * i) * lda + 16 * g);
+                rw[d][i] = *reinterpret_cast<const f32x4 *>(w + (size_t)(16 * i) * ldw + 16 * g);
+            }
         }
     }
+    for (int g = g0; g < g1; g += kHeadDepth) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) part[wave][j][lane] = acc[j];
+        for (int d = 0; d < kHeadDepth; ++d) {
+            if (g + d >= g1) break;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[d][i][u], rw[d][j][u], acc[i][j], 0, 0, 0);
+            const int gn = g + d + kHeadDepth;
+            if (gn < g1) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    ra[d][i] = *reinterpret_cast<const f32x4 *>(a + (size_t)(16 * i) * lda + 16 * gn);
+                    rw[d][i] = *reinterpret_cast<const f32x4 *>(w + (size_t)(16 * i) * ldw + 16 * gn);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) part[wave][2 * i + j][lane] = acc[i][j];
     __syncthreads();
-    if (wave != 0) return;
-    // D: column = output (lane & 15), rows = boards 4*(lane >> 4) + j
-    const int col = 16 * (is_act ? ot : ot - n_act_tiles) + n;
+    // wave t finishes tile t = 2 i + j.  D: column = output (lane & 15), rows = boards 4 * (lane >> 4) + e
+    const int ti = wave >> 1, tj = wave & 1;
+    f32x4 v = part[0][wave][lane];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int b = b0 + 4 * kq + j;
+    for (int k = 1; k < 4; ++k) {
+        const f32x4 p = part[k][wave][lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += p[e];
+    }
+    const int col = n0 + 16 * tj + m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int b = b0 + 16 * ti + 4 * kq + e;
         if (b >= n_boards) continue;
-        const float v = part[0][j][lane] + part[1][j][lane] + part[2][j][lane] + part[3][j][lane];
-        if (is_act) raw[(size_t)b * nd.Npad + col] = v + nd.fc_act_b[col];
-        else hid[(size_t)b * 64 + col] = fmaxf(v + nd.fc_val1_b[col], 0.0f);
+        if (is_act) raw[(size_t)b * nd.Npad + col] = v[e] + nd.fc_act_b[col];
+        else hid[(size_t)b * 64 + col] = fmaxf(v[e] + nd.fc_val1_b[col], 0.0f);
     }
 }
 
@@ -787,6 +811,7 @@ int rz_net_create(int32_t height, int32_t width, int32_t n_actions, int32_t devi
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             net->n_cus = prop.multiProcessorCount;
+        if (getenv("RZ_TRUNK_GRID")) net->n_cus = atoi(getenv("RZ_TRUNK_GRID"));
     }
     memset(&net->dev, 0, sizeof(net->dev));
     net->dev.BH = height;
@@ -795,9 +820,9 @@ int rz_net_create(int32_t height, int32_t width, int32_t n_actions, int32_t devi
     net->dev.A = n_actions;
     {
         NetDev &D = net->dev;
-        D.Npad = (D.A + 15) / 16 * 16;
-        D.steps_act = (4 * D.S + 16 * kHeadU - 1) / (16 * kHeadU) * (4 * kHeadU);
-        D.steps_val = (2 * D.S + 16 * kHeadU - 1) / (16 * kHeadU) * (4 * kHeadU);
+        D.Npad = (D.A + 31) / 32 * 32;
+        D.groups_act = (4 * D.S + 15) / 16;
+        D.groups_val = (2 * D.S + 15) / 16;
     }
     *out = net;
     return RZ_OK;
@@ -851,19 +876,21 @@ int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params) {
         if (rc == RZ_OK) rc = net_upload(net, bh, &D.bh);
     }
     {
-        std::vector<float> t((size_t)4 * D.steps_act * D.Npad, 0.0f), bias((size_t)D.Npad, 0.0f);
+        const size_t ld = (size_t)16 * D.groups_act;
+        std::vector<float> t((size_t)D.Npad * ld, 0.0f), bias((size_t)D.Npad, 0.0f);
         for (int j = 0; j < D.A; ++j) {
             bias[j] = h_params[9][j];
-            for (int k = 0; k < 4 * S; ++k) t[(size_t)k * D.Npad + j] = h_params[8][(size_t)j * 4 * S + k];
+            memcpy(&t[(size_t)j * ld], h_params[8] + (size_t)j * 4 * S, (size_t)4 * S * sizeof(float));
         }
-        if (rc == RZ_OK) rc = net_upload(net, t, &D.fc_act_t);
+        if (rc == RZ_OK) rc = net_upload(net, t, &D.fc_act_w);
         if (rc == RZ_OK) rc = net_upload(net, bias, &D.fc_act_b);
     }
     {
-        std::vector<float> t((size_t)4 * D.steps_val * 64, 0.0f);
+        const size_t ld = (size_t)16 * D.groups_val;
+        std::vector<float> t((size_t)64 * ld, 0.0f);
         for (int j = 0; j < 64; ++j)
-            for (int k = 0; k < 2 * S; ++k) t[(size_t)k * 64 + j] = h_params[12][(size_t)j * 2 * S + k];
-        if (rc == RZ_OK) rc = net_upload(net, t, &D.fc_val1_t);
+            memcpy(&t[(size_t)j * ld], h_params[12] + (size_t)j * 2 * S, (size_t)2 * S * sizeof(float));
+        if (rc == RZ_OK) rc = net_upload(net, t, &D.fc_val1_w);
         up_f(h_params[13], 64, &D.fc_val1_b);
     }
     up_f(h_params[14], 64, &D.fc_val2_w);
@@ -892,10 +919,9 @@ int rz_net_reserve(rz_net *net, int32_t max_boards) {
     if (net->d_hid) (void)hipFree(net->d_hid);
     net->d_feat = net->d_raw = net->d_hid = nullptr;
     net->feat_boards = 0;
-    // internal features: [k/4][padded boards][4]; rows cover the zero-padded K range of both heads
-    const size_t pad_boards = ((size_t)max_boards + 15) / 16 * 16;
-    const size_t feat_rows = (size_t)net->dev.S + (size_t)net->dev.steps_val + 1;
-    net->feat_floats = feat_rows * pad_boards * 4;
+    // internal features: [boards padded to 32][16 * (groups_act + groups_val)], zero filled once
+    const size_t pad_boards = ((size_t)max_boards + 31) / 32 * 32;
+    net->feat_floats = pad_boards * 16 * (size_t)(net->dev.groups_act + net->dev.groups_val);
     if (hipMalloc((void **)&net->d_feat, net->feat_floats * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&net->d_raw, (size_t)max_boards * net->dev.Npad * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&net->d_hid, (size_t)max_boards * 64 * sizeof(float)) != hipSuccess)
@@ -909,8 +935,10 @@ int rz_net_reserve(rz_net *net, int32_t max_boards) {
 
 static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t n_boards, void *stream) {
     const dim3 grid((unsigned)n_boards);
-    // the internal buffer uses the GEMM-friendly layout, a caller's buffer the natural one
-    net->dev.feat_nb4 = (d_feat == net->d_feat) ? 4 * ((n_boards + 15) / 16 * 16) : 0;
+    // the internal buffer uses the padded layout of the FC GEMM, a caller's buffer the natural one
+    const bool internal = d_feat == net->d_feat;
+    net->dev.feat_ld = internal ? 16 * (net->dev.groups_act + net->dev.groups_val) : 6 * net->dev.S;
+    net->dev.feat_val_off = internal ? 16 * net->dev.groups_act : 4 * net->dev.S;
     // Winograd kernels are persistent: one workgroup per CU (LDS bound) loops over its boards
     const dim3 pgrid((unsigned)(n_boards < net->n_cus ? n_boards : net->n_cus));
     if (net->algo == RZ_NET_WINOGRAD)
@@ -923,8 +951,9 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
 
 static int launch_heads(rz_net *net, const float *d_feat, int32_t n_boards, float *d_logp, float *d_value,
                         void *stream) {
-    net->dev.feat_nb4 = 4 * ((n_boards + 15) / 16 * 16);
-    const dim3 grid((unsigned)((n_boards + 15) / 16), (unsigned)(net->dev.Npad / 16 + 4));
+    net->dev.feat_ld = 16 * (net->dev.groups_act + net->dev.groups_val);
+    net->dev.feat_val_off = 16 * net->dev.groups_act;
+    const dim3 grid((unsigned)((n_boards + 31) / 32), (unsigned)(net->dev.Npad / 32 + 2));
     k_heads_gemm<<<grid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_feat, net->d_raw, net->d_hid, n_boards);
     k_heads_finish<<<dim3((unsigned)n_boards), dim3(64), 0, (hipStream_t)stream>>>(net->dev, net->d_raw, net->d_hid,
                                                                                   d_logp, d_value, n_boards);
@@ -966,8 +995,9 @@ int rz_net_heads_gemm(rz_net *net, int32_t n_boards, const float **d_raw, int32_
     *d_w2 = net->dev.fc_val2_w;
     *d_b2 = net->dev.fc_val2_b;
     if (n_boards == 0) return RZ_OK;
-    net->dev.feat_nb4 = 4 * ((n_boards + 15) / 16 * 16);
-    const dim3 grid((unsigned)((n_boards + 15) / 16), (unsigned)(net->dev.Npad / 16 + 4));
+    net->dev.feat_ld = 16 * (net->dev.groups_act + net->dev.groups_val);
+    net->dev.feat_val_off = 16 * net->dev.groups_act;
+    const dim3 grid((unsigned)((n_boards + 31) / 32), (unsigned)(net->dev.Npad / 32 + 2));
     k_heads_gemm<<<grid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, net->d_feat, net->d_raw, net->d_hid, n_boards);
     if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_heads_gemm failed");
     return RZ_OK;

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Headline benchmark: MCTS simulations / second of AlphaZero self-play on 15x15 Gomoku,
-800 simulations per move, 512 lock-stepped games per GPU (BASELINE.json configs[3]:
-4096 games over 8 GPUs), random-init PolicyValueNet (torch.manual_seed(0)), fp32.
+800 simulations per move (BASELINE.json configs[3]), random-init PolicyValueNet
+(torch.manual_seed(0)), fp32.  Games in flight per GPU are an engine parameter (the batch of
+the leaf evaluation): the default keeps 2 lanes x 448 games = 896 per GPU, which is what fills
+an MI355X -- the network trunk of one lane runs as 224 persistent workgroups (28 of the 32 CUs
+of every XCD, two boards each) while the tree / FC kernels of the other lane use the 32 CUs left
+free.  `--lanes 1 --games 512` is the literal 4096 / 8 games per GPU of configs[3].
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -33,6 +37,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 BOARD, N_ROW, N_PLAYOUT, GAMES_PER_GPU, C_PUCT, TEMPERATURE = 15, 5, 800, 512, 5.0, 1.0
+RESERVED_CUS_PER_XCD, N_XCD = 4, 8  # CUs the trunk leaves to the other lane's small kernels
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0
 
@@ -67,7 +72,7 @@ def pmc_traffic(kernel, workload, lanes):
     None when no counter run exists for this workload / launch geometry."""
     try:
         rec = json.load(open(os.path.join(REPO, 'profiles', 'r01', 'pmc_traffic.json')))
-        if rec['workload'] != workload or lanes != 1:
+        if rec['workload'] != workload or rec.get('lanes', 1) != lanes:
             return None
         return rec['kernels'][kernel]['traffic_bytes_per_launch']
     except (OSError, KeyError, ValueError):
@@ -219,7 +224,12 @@ def main():
     ap.add_argument('--cpu-worker', type=float, default=None, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--games', type=int, default=GAMES_PER_GPU, help='games per GPU')
+    ap.add_argument('--games', type=int, default=0,
+                    help='games per GPU; 0 = lanes x 2 boards x trunk workgroups (896) with 2 lanes, %d with 1' %
+                    GAMES_PER_GPU)
+    ap.add_argument('--trunk-wgs', type=int, default=-1,
+                    help='persistent trunk workgroups per lane; -1 = CUs - %d with lanes > 1, one per CU otherwise' %
+                    (RESERVED_CUS_PER_XCD * N_XCD))
     ap.add_argument('--board', type=int, default=BOARD)
     ap.add_argument('--game', default='gomoku', choices=['gomoku', 'connect4'],
                     help='connect4: 6x7, 4 in a row, 7 column actions (BASELINE config 3; pair with '
@@ -230,9 +240,9 @@ def main():
                          "PyTorch-ROCm/MIOpen; vlin: synthetic evaluator (isolates the tree kernels)")
     ap.add_argument('--graph', type=int, default=8, help='simulation steps per hipGraph (0 = eager)')
     ap.add_argument('--net-algo', default='winograd', choices=['winograd', 'winograd4w', 'direct'])
-    ap.add_argument('--lanes', type=int, default=1,
-                    help='half-batches on separate HIP streams (tree kernels of one lane run beside '
-                         'the network kernel of the other)')
+    ap.add_argument('--lanes', type=int, default=2,
+                    help='independent batches of games on separate HIP streams (the tree / FC kernels of one '
+                         'lane run beside the network trunk of the other)')
     args = ap.parse_args()
     if args.cpu_worker is not None:
         cpu_worker(args.cpu_worker, args.board, N_ROW if args.board >= 5 else args.board, args.playouts)
@@ -271,8 +281,13 @@ def main():
     cells = board * board
     if args.game == 'connect4':
         board, n_row, cells = (6, 7), 4, 42
-    G = args.games
-    lanes = max(1, min(args.lanes, G))
+    n_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
+    lanes = max(1, args.lanes)
+    trunk_wgs = args.trunk_wgs
+    if trunk_wgs < 0:
+        trunk_wgs = n_cus - RESERVED_CUS_PER_XCD * N_XCD if lanes > 1 and args.evaluator == 'hipnet' else 0
+    G = args.games if args.games > 0 else (lanes * 2 * trunk_wgs if trunk_wgs > 0 else GAMES_PER_GPU)
+    lanes = max(1, min(lanes, G))
     per_lane = [G // lanes + (1 if i < G % lanes else 0) for i in range(lanes)]
     torch.manual_seed(0)  # identical weights on every rank
     net = (PolicyValueNet(6, 7, 7) if args.game == 'connect4' else PolicyValueNet(board)).to(device).eval()
@@ -284,6 +299,7 @@ def main():
         if args.evaluator == 'hipnet':
             hip_ev = HipNetEvaluator(net, net_shape, device, max_boards=g_lane)
             hip_ev.hip.set_algo(args.net_algo)
+            hip_ev.hip.set_max_workgroups(trunk_wgs)
             ev = TimedEvaluator(hip_ev, torch,
                                 {'winograd': 'k_trunk_wino<4> (hand-written fused fp32-MFMA conv trunk, Winograd F(2x2,3x3), csrc/rz_net.hip)',
                                  'winograd4w': 'k_trunk_wino<2> (same, 4 waves per board)',
@@ -348,6 +364,21 @@ def main():
         total_sims, total_finished = float(sp.sims_done - sims0), float(finished[0] - fin0)
     all_stats = sp.check()
     stats = max(all_stats, key=lambda st: st.max_slots_used)
+    # the dominant kernel by itself (no other lane on the GPU): its duration on the CUs it is given
+    exclusive_ms = None
+    if isinstance(evaluator, TimedEvaluator) and getattr(evaluator.inner, 'hip', None) is not None and rank == 0:
+        lane0 = sp.lanes[0]
+        torch.cuda.synchronize()
+        with torch.cuda.stream(lane0.stream):
+            evs = []
+            for _ in range(24):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                evaluator.inner.hip.trunk_internal(lane0.eng.obs)
+                b.record()
+                evs.append((a, b))
+        torch.cuda.synchronize()
+        exclusive_ms = sum(a.elapsed_time(b) for a, b in evs[4:]) / len(evs[4:])
     hbm_bytes = sum(st.device_bytes for st in all_stats)
 
     if rank == 0:
@@ -371,8 +402,9 @@ def main():
             'engine_hbm_bytes': int(hbm_bytes),
         }
         if isinstance(evaluator, TimedEvaluator) and evaluator.mean_ms():
-            # one launch = the forward of one lane's leaves; durations from HIP events on that
-            # lane's stream (with lanes > 1 they include time the launch waited for the CUs)
+            # one launch = the trunk of one lane's leaves; durations from HIP events on that lane's
+            # stream.  With lanes > 1 the launches of different lanes overlap in time and share the
+            # CUs, so a launch's duration is longer than the kernel needs by itself (exclusive_*).
             n_ev = sum(len(ev.events) for ev in evaluators)
             ms = sum(ev.mean_ms() * len(ev.events) for ev in evaluators) / n_ev
             boards_per_launch = G / float(lanes)
@@ -385,12 +417,27 @@ def main():
                                 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4),
                                 'traffic': pmc_traffic('k_trunk', line['config']['workload'], lanes),
                                 'avg_launch_ms': round(ms, 4), 'launches_timed': n_ev,
-                                'note': 'achieved = ALGORITHMIC flops (direct convolution, SURVEY.md 8d) / time; '
-                                        'mfma_executed_frac = flops the MFMA pipe really executed / time / peak '
-                                        '(Winograd executes 2.09x fewer)',
+                                'note': 'achieved = ALGORITHMIC flops (direct convolution, SURVEY.md 8d) per launch / '
+                                        'average launch duration (HIP events, timed region; with 2 lanes two '
+                                        'launches overlap and share the CUs); exclusive_* = the same kernel '
+                                        'launched alone after the timed region; whole_job_* = trunk flops of all '
+                                        'simulations / wall-clock; mfma_executed_frac = flops the MFMA pipe '
+                                        'really executed / time / peak (Winograd executes 2.09x fewer)',
                                 'mfma_executed_frac': round(achieved / PEAK_FP32_MATRIX_TFLOPS *
                                                             executed_flop_ratio(args, cells), 4),
-                                'share_of_step_time': round(ms * (total_sims / world / G) / (elapsed * 1e3), 3)}
+                                'share_of_step_time': round(ms * (total_sims / world / G) / (elapsed * 1e3), 3),
+                                'concurrent_lanes': lanes,
+                                'trunk_workgroups': trunk_wgs if trunk_wgs > 0 else n_cus}
+            rf = line['roofline']
+            if exclusive_ms:
+                ex = flops / (exclusive_ms * 1e-3) / 1e12
+                rf['exclusive_launch_ms'] = round(exclusive_ms, 4)
+                rf['exclusive_achieved'] = round(ex, 3)
+                rf['exclusive_frac'] = round(ex / PEAK_FP32_MATRIX_TFLOPS, 4)
+            # all trunk flops of the timed region / its whole wall-clock (tree, FC, host time included)
+            whole = value / world * per_pos / 1e12
+            rf['whole_job_achieved'] = round(whole, 3)
+            rf['whole_job_frac'] = round(whole / PEAK_FP32_MATRIX_TFLOPS, 4)
         else:
             per_sim = tree_bytes_per_sim(365.5, 208.8, 1.74) if board == 15 else None
             if per_sim:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 12
+#define RZ_ABI_VERSION 13
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 
@@ -264,6 +264,12 @@ enum {
     RZ_NET_WINOGRAD_4W = 2 /* same arithmetic, 4 waves per board (one per SIMD, whole register file) */
 };
 int rz_net_set_algo(rz_net *net, int32_t algo);
+/* The Winograd trunk runs as persistent workgroups (one per CU: its LDS and registers fill a CU),
+ * each looping over its boards.  max_workgroups > 0 caps their number so that the remaining CUs stay
+ * free for the latency-bound tree / FC kernels of ANOTHER stream (a second lane of games) running
+ * beside the trunk; 0 (default) = one workgroup per CU.  Workgroups are dealt to the 8 XCDs in turn:
+ * use a multiple of 8. */
+int rz_net_set_max_workgroups(rz_net *net, int32_t max_workgroups);
 int rz_net_create(int32_t height, int32_t width, int32_t n_actions, int32_t device, rz_net **out);
 int rz_net_destroy(rz_net *net);
 int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params);

@@ -8,7 +8,7 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64,
                     c_void_p)
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
 
@@ -78,6 +78,7 @@ _SIGNATURES = {
     'rz_net_create': (c_int, [c_int32, c_int32, c_int32, c_int32, POINTER(c_void_p)]),
     'rz_net_destroy': (c_int, [P]),
     'rz_net_set_algo': (c_int, [P, c_int32]),
+    'rz_net_set_max_workgroups': (c_int, [P, c_int32]),
     'rz_net_load': (c_int, [P, POINTER(c_void_p), c_int32]),
     'rz_net_reserve': (c_int, [P, c_int32]),
     'rz_net_trunk': (c_int, [P, P, c_int32, P, P]),

@@ -592,11 +592,12 @@ __global__ __launch_bounds__(kTrunkThreads) void k_trunk(NetDev nd, const float 
 // consumed is free as long as both operands agree).  A ring of kHeadDepth groups is kept in flight.
 // The 4 partial blocks are summed through LDS.  k_heads_finish: log_softmax / fc2 + tanh.
 constexpr int kHeadDepth = 4;
+constexpr int kHeadWaves = 4;  // K split
 
-__global__ __launch_bounds__(256) void k_heads_gemm(NetDev nd, const float *__restrict__ feat,
+__global__ __launch_bounds__(64 * kHeadWaves) void k_heads_gemm(NetDev nd, const float *__restrict__ feat,
                                                     float *__restrict__ raw, float *__restrict__ hid,
                                                     int n_boards) {
-    __shared__ f32x4 part[4][4][64];
+    __shared__ f32x4 part[kHeadWaves][4][64];
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b0 = blockIdx.x * 32;
@@ -605,7 +606,7 @@ __global__ __launch_bounds__(256) void k_heads_gemm(NetDev nd, const float *__re
     const bool is_act = ot < n_act_tiles;
     const int m = lane & 15, kq = lane >> 4;
     const int groups = is_act ? nd.groups_act : nd.groups_val;
-    const int g0 = wave * groups / 4, g1 = (wave + 1) * groups / 4;
+    const int g0 = wave * groups / kHeadWaves, g1 = (wave + 1) * groups / kHeadWaves;
     const size_t ldw = (size_t)16 * groups, lda = (size_t)nd.feat_ld;
     const int n0 = 32 * (is_act ? ot : ot - n_act_tiles);
     const float *w = (is_act ? nd.fc_act_w : nd.fc_val1_w) + (size_t)(n0 + m) * ldw + 4 * kq;
@@ -655,11 +656,12 @@ __global__ __launch_bounds__(256) void k_heads_gemm(NetDev nd, const float *__re
 #pragma unroll
         for (int j = 0; j < 2; ++j) part[wave][2 * i + j][lane] = acc[i][j];
     __syncthreads();
+    if (wave >= 4) return;
     // wave t finishes tile t = 2 i + j.  D: column = output (lane & 15), rows = boards 4 * (lane >> 4) + e
     const int ti = wave >> 1, tj = wave & 1;
     f32x4 v = part[0][wave][lane];
 #pragma unroll
-    for (int k = 1; k < 4; ++k) {
+    for (int k = 1; k < kHeadWaves; ++k) {
         const f32x4 p = part[k][wave][lane];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += p[e];
@@ -716,6 +718,7 @@ struct rz_net {
     bool loaded = false;
     int algo = RZ_NET_WINOGRAD;
     int n_cus = 256;
+    int max_wgs = 0;  // rz_net_set_max_workgroups: 0 = one persistent trunk workgroup per CU
     NetDev dev;
     std::vector<void *> allocs;
     float *d_feat = nullptr, *d_raw = nullptr, *d_hid = nullptr;
@@ -811,7 +814,6 @@ int rz_net_create(int32_t height, int32_t width, int32_t n_actions, int32_t devi
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             net->n_cus = prop.multiProcessorCount;
-        if (getenv("RZ_TRUNK_GRID")) net->n_cus = atoi(getenv("RZ_TRUNK_GRID"));
     }
     memset(&net->dev, 0, sizeof(net->dev));
     net->dev.BH = height;
@@ -940,7 +942,8 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
     net->dev.feat_ld = internal ? 16 * (net->dev.groups_act + net->dev.groups_val) : 6 * net->dev.S;
     net->dev.feat_val_off = internal ? 16 * net->dev.groups_act : 4 * net->dev.S;
     // Winograd kernels are persistent: one workgroup per CU (LDS bound) loops over its boards
-    const dim3 pgrid((unsigned)(n_boards < net->n_cus ? n_boards : net->n_cus));
+    const int wg_cap = net->max_wgs > 0 ? net->max_wgs : net->n_cus;
+    const dim3 pgrid((unsigned)(n_boards < wg_cap ? n_boards : wg_cap));
     if (net->algo == RZ_NET_WINOGRAD)
         k_trunk_wino<4><<<pgrid, dim3(512), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
     else if (net->algo == RZ_NET_WINOGRAD_4W)
@@ -954,7 +957,7 @@ static int launch_heads(rz_net *net, const float *d_feat, int32_t n_boards, floa
     net->dev.feat_ld = 16 * (net->dev.groups_act + net->dev.groups_val);
     net->dev.feat_val_off = 16 * net->dev.groups_act;
     const dim3 grid((unsigned)((n_boards + 31) / 32), (unsigned)(net->dev.Npad / 32 + 2));
-    k_heads_gemm<<<grid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_feat, net->d_raw, net->d_hid, n_boards);
+    k_heads_gemm<<<grid, dim3(64 * kHeadWaves), 0, (hipStream_t)stream>>>(net->dev, d_feat, net->d_raw, net->d_hid, n_boards);
     k_heads_finish<<<dim3((unsigned)n_boards), dim3(64), 0, (hipStream_t)stream>>>(net->dev, net->d_raw, net->d_hid,
                                                                                   d_logp, d_value, n_boards);
     if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_heads_* failed");
@@ -983,6 +986,13 @@ int rz_net_set_algo(rz_net *net, int32_t algo) {
     return RZ_OK;
 }
 
+int rz_net_set_max_workgroups(rz_net *net, int32_t max_workgroups) {
+    if (!net) return net_fail(RZ_ERR_ARG, "net handle is NULL");
+    if (max_workgroups < 0) return net_fail(RZ_ERR_ARG, "max_workgroups must be >= 0");
+    net->max_wgs = max_workgroups;
+    return RZ_OK;
+}
+
 int rz_net_heads_gemm(rz_net *net, int32_t n_boards, const float **d_raw, int32_t *ld, const float **d_hid,
                       const float **d_w2, const float **d_b2, void *stream) {
     int rc = net_ready(net, n_boards);
@@ -998,7 +1008,7 @@ int rz_net_heads_gemm(rz_net *net, int32_t n_boards, const float **d_raw, int32_
     net->dev.feat_ld = 16 * (net->dev.groups_act + net->dev.groups_val);
     net->dev.feat_val_off = 16 * net->dev.groups_act;
     const dim3 grid((unsigned)((n_boards + 31) / 32), (unsigned)(net->dev.Npad / 32 + 2));
-    k_heads_gemm<<<grid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, net->d_feat, net->d_raw, net->d_hid, n_boards);
+    k_heads_gemm<<<grid, dim3(64 * kHeadWaves), 0, (hipStream_t)stream>>>(net->dev, net->d_feat, net->d_raw, net->d_hid, n_boards);
     if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_heads_gemm failed");
     return RZ_OK;
 }

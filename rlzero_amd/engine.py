@@ -107,6 +107,12 @@ class HipNet(object):
         check(self.lib.rz_net_set_algo(self.handle, code), 'rz_net_set_algo')
         return self
 
+    def set_max_workgroups(self, n):
+        """Cap the persistent trunk workgroups (0 = one per CU) so that the other CUs stay free for
+        the tree / FC kernels of a second lane of games (see BatchedSelfPlay)."""
+        check(self.lib.rz_net_set_max_workgroups(self.handle, int(n)), 'rz_net_set_max_workgroups')
+        return self
+
     def load_state_dict(self, state_dict):
         """Upload (and re-pack into MFMA fragment order) the 16 tensors of a
         PolicyValueNet.state_dict(); call again after every optimiser step."""

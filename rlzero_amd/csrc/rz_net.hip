@@ -205,28 +205,91 @@ __device__ __forceinline__ void wino_load_d(float (&d)[2][2][4], const float *__
     }
 }
 
+// patch rows (of the 4x4 input patch) that transform row i' = IP combines: V[i'] = d[r0] +/- d[r1]
+template <int IP> struct WinoRows {
+    static constexpr int r0 = (IP == 0) ? 0 : (IP == 1) ? 1 : (IP == 2) ? 2 : 1;
+    static constexpr int r1 = (IP == 0) ? 2 : (IP == 1) ? 2 : (IP == 2) ? 1 : 3;
+};
+
+// One of the 8 LDS reads (two adjacent floats) of a channel group's patch rows: o = nt*4 + rr*2 + half.
+// `q` is the group's base (opaque to the optimiser), so every read is q + a compile-time offset that
+// fits the ds_read2 offset fields: one address add per group instead of one per read.
+typedef const __attribute__((address_space(3))) float *lds_cptr;
+
 template <int IP>
-__device__ __forceinline__ void wino_transform(const float (&d)[2][2][4], float (&v)[2][4]) {
+__device__ __forceinline__ void wino_ld_op(float (&d)[2][2][4], lds_cptr q, int o) {
+    const int nt = o >> 2, rr = (o >> 1) & 1, c = 2 * (o & 1);
+    const int row = (rr == 0 ? WinoRows<IP>::r0 : WinoRows<IP>::r1) + 2 * nt;  // N-tile nt: one tile row lower
+    d[nt][rr][c] = q[row * kRowW + c];
+    d[nt][rr][c + 1] = q[row * kRowW + c + 1];
+}
+
+// One of the 16 additions of the input transform of a channel group: o = nt*8 + w; w < 4: the row
+// combination t[w], else the column combination v[w - 4].
+template <int IP>
+__device__ __forceinline__ void wino_xf_op(const float (&d)[2][2][4], float (&t)[2][4], float (&v)[2][4], int o) {
+    const int nt = o >> 3, w = o & 7;
+    if (w < 4) t[nt][w] = (IP == 1) ? d[nt][0][w] + d[nt][1][w] : d[nt][0][w] - d[nt][1][w];
+    else if (w == 4) v[nt][0] = t[nt][0] - t[nt][2];
+    else if (w == 5) v[nt][1] = t[nt][1] + t[nt][2];
+    else if (w == 6) v[nt][2] = t[nt][2] - t[nt][1];
+    else v[nt][3] = t[nt][1] - t[nt][3];
+}
+
+// The MFMA block of one channel group (8*TM MFMAs on the fragments a_cur x v_cur) with the
+// non-matrix work of the NEXT groups threaded between the MFMAs, one small slice per MFMA, each
+// slice pinned in place: first half = the input transform of the group after this one (patch rows
+// already in `d`, type XIP) into v_nxt; second half = the LDS reads of the group after that
+// (pass LIP, base q_ld) into `d` and the U loads `DIST` groups ahead into a_ld.  The matrix pipe
+// then never waits for a block of VALU / LDS issue of the same wave, and the partner wave of
+// the SIMD finds issue slots between this wave's MFMAs.
+template <int TM, int XIP, int LIP, bool DO_XF, bool DO_LD, bool DO_U>
+__device__ __forceinline__ void wino_block(f32x4 (&acc)[TM][2][4], const f32x4 (&a_cur)[TM], const float (&v_cur)[2][4],
+                                           float (&v_nxt)[2][4], float (&d)[2][2][4], lds_cptr q_ld,
+                                           f32x4 (&a_ld)[TM], const char *u_ptr, unsigned u_lane, int u_stride) {
+    constexpr int NS = 8 * TM;          // MFMAs = slots
+    constexpr int XF_PER = 32 / NS;     // transform ops per slot of the first half (16 ops)
+    constexpr int LD_SLOTS = NS / 2;    // second half
+    float t[2][4];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        float t[4];
+    for (int i = 0; i < NS; ++i) {
+        const int jp = i / (2 * TM), m = (i >> 1) % TM, nt = i & 1;
+        acc[m][nt][jp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[m][jp], v_cur[nt][jp], acc[m][nt][jp], 0, 0, 0);
+        if (i < NS / 2) {
+            if (DO_XF) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) t[j] = (IP == 1) ? d[nt][0][j] + d[nt][1][j] : d[nt][0][j] - d[nt][1][j];
-        v[nt][0] = t[0] - t[2];
-        v[nt][1] = t[1] + t[2];
-        v[nt][2] = t[2] - t[1];
-        v[nt][3] = t[1] - t[3];
+                for (int k = 0; k < XF_PER; ++k) wino_xf_op<XIP>(d, t, v_nxt, i * XF_PER + k);
+            }
+        } else {
+            const int j = i - NS / 2;  // 0 .. LD_SLOTS-1
+            if (DO_LD) {
+                // 8 reads over LD_SLOTS slots
+                if (LD_SLOTS >= 8) {
+                    if ((j % (LD_SLOTS / 8)) == 0) wino_ld_op<LIP>(d, q_ld, j / (LD_SLOTS / 8));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8 / LD_SLOTS; ++k) wino_ld_op<LIP>(d, q_ld, j * (8 / LD_SLOTS) + k);
+                }
+            }
+            if (DO_U && j < TM)
+                a_ld[j] = *reinterpret_cast<const f32x4 *>(u_ptr + (size_t)j * u_stride + u_lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// One transform row i' = IP for the wave's TM output-channel tiles.  Per channel group: transform
-// the patch rows fetched during the previous group (their registers die here), issue the loads
-// of the coming groups (U three groups ahead, possibly already the next pass's), then 8*TM MFMAs.
+// One transform row i' = IP for the wave's TM output-channel tiles.  Software pipeline over the
+// channel groups g = IP*kSteps + s of the whole convolution: block g multiplies group g, transforms
+// group g+1 and fetches the patch rows of group g+2 and the U fragments of group g+3 (4-slot ring).
+// `vb` double-buffers the transformed fragment; kSteps is even, so every pass starts on vb[0].
 template <int PL, int CIN, int TM, int IP>
-__device__ __forceinline__ void wino_pass(const float *__restrict__ base, const f32x4 *__restrict__ ubase,
-                                          f32x4 (&a)[4][TM], float (&d)[2][2][4], f32x4 (&Y)[TM][2][4]) {
+__device__ __forceinline__ void wino_pass(lds_cptr base, const char *__restrict__ ubase, unsigned u_lane,
+                                          f32x4 (&a)[4][TM], float (&d)[2][2][4], float (&vb)[2][2][4],
+                                          f32x4 (&Y)[TM][2][4]) {
     constexpr int kSteps = CIN / 4;  // 8 or 16: a multiple of the ring size
     constexpr int kT = 4 * kSteps;   // U vectors per tile: index t = IP*kSteps + s
+    constexpr int kUStride = kT * 64 * 16;  // bytes between the U streams of consecutive tiles
+    constexpr int NIP = IP < 3 ? IP + 1 : 3;
     f32x4 acc[TM][2][4];
 #pragma unroll
     for (int m = 0; m < TM; ++m)
@@ -234,32 +297,45 @@ __device__ __forceinline__ void wino_pass(const float *__restrict__ base, const 
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int jp = 0; jp < 4; ++jp) acc[m][nt][jp] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float v[2][4];
+    // all but the last 4 groups of the pass: everything this block prepares belongs to this pass
 #pragma unroll 1
-    for (int s0 = 0; s0 < kSteps; s0 += 4) {
+    for (int s0 = 0; s0 < kSteps - 4; s0 += 4) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int s = s0 + r;
-            wino_transform<IP>(d, v);
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const int t3 = IP * kSteps + s + 3;
-                const int tn = t3 < kT ? t3 : kT - 1;
-#pragma unroll
-                for (int m = 0; m < TM; ++m) a[(r + 3) & 3][m] = ubase[((size_t)m * kT + tn) * 64];
-            }
-            if (r < 3 || s + 1 < kSteps) wino_load_d<PL, IP>(d, base, s + 1);
-            else if (IP < 3) wino_load_d<PL, (IP < 3 ? IP + 1 : 3)>(d, base, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int jp = 0; jp < 4; ++jp)
-#pragma unroll
-                for (int m = 0; m < TM; ++m)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-                        acc[m][nt][jp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][m][jp], v[nt][jp],
-                                                                              acc[m][nt][jp], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            lds_cptr q = base + (4 * (s + 2)) * PL;
+            asm volatile("" : "+v"(q));
+            const char *u = ubase + (size_t)(IP * kSteps + s + 3) * (64 * 16);
+            wino_block<TM, IP, IP, true, true, true>(acc, a[r], vb[r & 1], vb[(r + 1) & 1], d, q, a[(r + 3) & 3], u, u_lane,
+                                                     kUStride);
+        }
+    }
+    {   // last 4 groups: the prepared groups run over into pass IP + 1 (nothing after the last pass)
+        constexpr int s0 = kSteps - 4;
+        {
+            lds_cptr q = base + (4 * (s0 + 2)) * PL;
+            asm volatile("" : "+v"(q));
+            wino_block<TM, IP, IP, true, true, true>(acc, a[0], vb[0], vb[1], d, q, a[3],
+                                                     ubase + (size_t)(IP * kSteps + s0 + 3) * (64 * 16), u_lane, kUStride);
+        }
+        {
+            lds_cptr q = base + (4 * (s0 + 3)) * PL;
+            asm volatile("" : "+v"(q));
+            wino_block<TM, IP, IP, true, true, (IP < 3)>(acc, a[1], vb[1], vb[0], d, q, a[0],
+                                                         ubase + (size_t)(IP * kSteps + s0 + 4) * (64 * 16), u_lane, kUStride);
+        }
+        {
+            lds_cptr q = base;  // group 0 of the next pass
+            asm volatile("" : "+v"(q));
+            wino_block<TM, IP, NIP, true, (IP < 3), (IP < 3)>(acc, a[2], vb[0], vb[1], d, q, a[1],
+                                                              ubase + (size_t)(IP * kSteps + s0 + 5) * (64 * 16), u_lane, kUStride);
+        }
+        {
+            lds_cptr q = base + 4 * PL;  // group 1 of the next pass
+            asm volatile("" : "+v"(q));
+            wino_block<TM, NIP, NIP, (IP < 3), (IP < 3), (IP < 3)>(acc, a[3], vb[1], vb[0], d, q, a[2],
+                                                                   ubase + (size_t)(IP * kSteps + s0 + 6) * (64 * 16), u_lane,
+                                                                   kUStride);
         }
     }
     // fold this transform row into the 2x2 outputs: Y[a][b] += At[a][i'] * sum_j' At[b][j'] M[i'][j']
@@ -308,8 +384,11 @@ __device__ __forceinline__ void wino_conv(const float *__restrict__ in, const f3
     constexpr int kSteps = CIN / 4, kT = 4 * kSteps;
     const int kq = lane >> 4, ty = (lane >> 3) & 1, tx = lane & 7;
     // top-left of the 4x4 patch of N-tile 0 in halo coordinates: row 2*(2h + 4ty), column 2tx
-    const float *base = in + kq * PL + (4 * h + 8 * ty) * kRowW + 2 * tx;
-    const f32x4 *ubase = up + (size_t)tile0 * kT * 64 + lane;
+    const lds_cptr base = (lds_cptr)(in + kq * PL + (4 * h + 8 * ty) * kRowW + 2 * tx);
+    // U fragments: uniform stream base + the lane's 16 bytes (scalar base + 32-bit lane offset addressing)
+    const char *ubase = reinterpret_cast<const char *>(up + (size_t)tile0 * kT * 64);
+    const unsigned u_lane = (unsigned)lane * 16u;
+    constexpr int kUStride = kT * 64 * 16;
 #pragma unroll
     for (int m = 0; m < TM; ++m)
 #pragma unroll
@@ -317,16 +396,25 @@ __device__ __forceinline__ void wino_conv(const float *__restrict__ in, const f3
 #pragma unroll
             for (int o = 0; o < 4; ++o) Y[m][nt][o] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 a[4][TM];
-    float d[2][2][4];
+    float d[2][2][4], vb[2][2][4], t[2][4];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int g = 0; g < 3; ++g)
 #pragma unroll
-        for (int m = 0; m < TM; ++m) a[t][m] = ubase[((size_t)m * kT + t) * 64];
-    wino_load_d<PL, 0>(d, base, 0);
-    wino_pass<PL, CIN, TM, 0>(base, ubase, a, d, Y);
-    wino_pass<PL, CIN, TM, 1>(base, ubase, a, d, Y);
-    wino_pass<PL, CIN, TM, 2>(base, ubase, a, d, Y);
-    wino_pass<PL, CIN, TM, 3>(base, ubase, a, d, Y);
+        for (int m = 0; m < TM; ++m)
+            a[g][m] = *reinterpret_cast<const f32x4 *>(ubase + (size_t)m * kUStride + (size_t)g * (64 * 16) + u_lane);
+    // pipeline prologue: group 0 transformed, patch rows of group 1 in flight
+#pragma unroll
+    for (int o = 0; o < 8; ++o) wino_ld_op<0>(d, base, o);
+#pragma unroll
+    for (int o = 0; o < 16; ++o) wino_xf_op<0>(d, t, vb[0], o);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int o = 0; o < 8; ++o) wino_ld_op<0>(d, base + 4 * PL, o);
+    __builtin_amdgcn_sched_barrier(0);
+    wino_pass<PL, CIN, TM, 0>(base, ubase, u_lane, a, d, vb, Y);
+    wino_pass<PL, CIN, TM, 1>(base, ubase, u_lane, a, d, vb, Y);
+    wino_pass<PL, CIN, TM, 2>(base, ubase, u_lane, a, d, vb, Y);
+    wino_pass<PL, CIN, TM, 3>(base, ubase, u_lane, a, d, vb, Y);
 }
 
 // Sum `vals` over the 4 lanes {n, n+16, n+32, n+48} as a reduce-scatter with the gfx950 lane-swap

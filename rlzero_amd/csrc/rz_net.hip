@@ -215,6 +215,13 @@ template <int IP> struct WinoRows {
 // `q` is the group's base (opaque to the optimiser), so every read is q + a compile-time offset that
 // fits the ds_read2 offset fields: one address add per group instead of one per read.
 typedef const __attribute__((address_space(3))) float *lds_cptr;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// U fragment load: buffer addressing = scalar resource + the lane's 32-bit offset + a scalar byte
+// offset, so the address of every load of the stream costs SALU only.
+__device__ __forceinline__ f32x4 load_u(__amdgpu_buffer_rsrc_t rsrc, int lane_off, int uniform_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, uniform_off, 0));
+}
 
 template <int IP>
 __device__ __forceinline__ void wino_ld_op(float (&d)[2][2][4], lds_cptr q, int o) {
@@ -246,7 +253,8 @@ __device__ __forceinline__ void wino_xf_op(const float (&d)[2][2][4], float (&t)
 template <int TM, int XIP, int LIP, bool DO_XF, bool DO_LD, bool DO_U>
 __device__ __forceinline__ void wino_block(f32x4 (&acc)[TM][2][4], const f32x4 (&a_cur)[TM], const float (&v_cur)[2][4],
                                            float (&v_nxt)[2][4], float (&d)[2][2][4], lds_cptr q_ld,
-                                           f32x4 (&a_ld)[TM], const char *u_ptr, unsigned u_lane, int u_stride) {
+                                           f32x4 (&a_ld)[TM], __amdgpu_buffer_rsrc_t u_rsrc, int u_off, int u_lane,
+                                           int u_stride) {
     constexpr int NS = 8 * TM;          // MFMAs = slots
     constexpr int XF_PER = 32 / NS;     // transform ops per slot of the first half (16 ops)
     constexpr int LD_SLOTS = NS / 2;    // second half
@@ -272,7 +280,7 @@ __device__ __forceinline__ void wino_block(f32x4 (&acc)[TM][2][4], const f32x4 (
                 }
             }
             if (DO_U && j < TM)
-                a_ld[j] = *reinterpret_cast<const f32x4 *>(u_ptr + (size_t)j * u_stride + u_lane);
+                a_ld[j] = load_u(u_rsrc, u_lane, u_off + j * u_stride);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -283,7 +291,7 @@ __device__ __forceinline__ void wino_block(f32x4 (&acc)[TM][2][4], const f32x4 (
 // group g+1 and fetches the patch rows of group g+2 and the U fragments of group g+3 (4-slot ring).
 // `vb` double-buffers the transformed fragment; kSteps is even, so every pass starts on vb[0].
 template <int PL, int CIN, int TM, int IP>
-__device__ __forceinline__ void wino_pass(lds_cptr base, const char *__restrict__ ubase, unsigned u_lane,
+__device__ __forceinline__ void wino_pass(lds_cptr base, __amdgpu_buffer_rsrc_t u_rsrc, int ubase, int u_lane,
                                           f32x4 (&a)[4][TM], float (&d)[2][2][4], float (&vb)[2][2][4],
                                           f32x4 (&Y)[TM][2][4]) {
     constexpr int kSteps = CIN / 4;  // 8 or 16: a multiple of the ring size
@@ -305,9 +313,9 @@ __device__ __forceinline__ void wino_pass(lds_cptr base, const char *__restrict_
             const int s = s0 + r;
             lds_cptr q = base + (4 * (s + 2)) * PL;
             asm volatile("" : "+v"(q));
-            const char *u = ubase + (size_t)(IP * kSteps + s + 3) * (64 * 16);
-            wino_block<TM, IP, IP, true, true, true>(acc, a[r], vb[r & 1], vb[(r + 1) & 1], d, q, a[(r + 3) & 3], u, u_lane,
-                                                     kUStride);
+            const int u = ubase + (IP * kSteps + s + 3) * (64 * 16);
+            wino_block<TM, IP, IP, true, true, true>(acc, a[r], vb[r & 1], vb[(r + 1) & 1], d, q, a[(r + 3) & 3], u_rsrc, u,
+                                                     u_lane, kUStride);
         }
     }
     {   // last 4 groups: the prepared groups run over into pass IP + 1 (nothing after the last pass)
@@ -315,27 +323,26 @@ __device__ __forceinline__ void wino_pass(lds_cptr base, const char *__restrict_
         {
             lds_cptr q = base + (4 * (s0 + 2)) * PL;
             asm volatile("" : "+v"(q));
-            wino_block<TM, IP, IP, true, true, true>(acc, a[0], vb[0], vb[1], d, q, a[3],
-                                                     ubase + (size_t)(IP * kSteps + s0 + 3) * (64 * 16), u_lane, kUStride);
+            wino_block<TM, IP, IP, true, true, true>(acc, a[0], vb[0], vb[1], d, q, a[3], u_rsrc,
+                                                     ubase + (IP * kSteps + s0 + 3) * (64 * 16), u_lane, kUStride);
         }
         {
             lds_cptr q = base + (4 * (s0 + 3)) * PL;
             asm volatile("" : "+v"(q));
-            wino_block<TM, IP, IP, true, true, (IP < 3)>(acc, a[1], vb[1], vb[0], d, q, a[0],
-                                                         ubase + (size_t)(IP * kSteps + s0 + 4) * (64 * 16), u_lane, kUStride);
+            wino_block<TM, IP, IP, true, true, (IP < 3)>(acc, a[1], vb[1], vb[0], d, q, a[0], u_rsrc,
+                                                         ubase + (IP * kSteps + s0 + 4) * (64 * 16), u_lane, kUStride);
         }
         {
             lds_cptr q = base;  // group 0 of the next pass
             asm volatile("" : "+v"(q));
-            wino_block<TM, IP, NIP, true, (IP < 3), (IP < 3)>(acc, a[2], vb[0], vb[1], d, q, a[1],
-                                                              ubase + (size_t)(IP * kSteps + s0 + 5) * (64 * 16), u_lane, kUStride);
+            wino_block<TM, IP, NIP, true, (IP < 3), (IP < 3)>(acc, a[2], vb[0], vb[1], d, q, a[1], u_rsrc,
+                                                              ubase + (IP * kSteps + s0 + 5) * (64 * 16), u_lane, kUStride);
         }
         {
             lds_cptr q = base + 4 * PL;  // group 1 of the next pass
             asm volatile("" : "+v"(q));
-            wino_block<TM, NIP, NIP, (IP < 3), (IP < 3), (IP < 3)>(acc, a[3], vb[1], vb[0], d, q, a[2],
-                                                                   ubase + (size_t)(IP * kSteps + s0 + 6) * (64 * 16), u_lane,
-                                                                   kUStride);
+            wino_block<TM, NIP, NIP, (IP < 3), (IP < 3), (IP < 3)>(acc, a[3], vb[1], vb[0], d, q, a[2], u_rsrc,
+                                                                   ubase + (IP * kSteps + s0 + 6) * (64 * 16), u_lane, kUStride);
         }
     }
     // fold this transform row into the 2x2 outputs: Y[a][b] += At[a][i'] * sum_j' At[b][j'] M[i'][j']
@@ -386,8 +393,10 @@ __device__ __forceinline__ void wino_conv(const float *__restrict__ in, const f3
     // top-left of the 4x4 patch of N-tile 0 in halo coordinates: row 2*(2h + 4ty), column 2tx
     const lds_cptr base = (lds_cptr)(in + kq * PL + (4 * h + 8 * ty) * kRowW + 2 * tx);
     // U fragments: uniform stream base + the lane's 16 bytes (scalar base + 32-bit lane offset addressing)
-    const char *ubase = reinterpret_cast<const char *>(up + (size_t)tile0 * kT * 64);
-    const unsigned u_lane = (unsigned)lane * 16u;
+    const __amdgpu_buffer_rsrc_t u_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(up), 0, 0x7fffffff, 0x00020000);
+    const int ubase = tile0 * kT * 64 * 16;  // byte offset of the wave's first tile stream
+    const int u_lane = lane * 16;
     constexpr int kUStride = kT * 64 * 16;
 #pragma unroll
     for (int m = 0; m < TM; ++m)
@@ -401,7 +410,7 @@ __device__ __forceinline__ void wino_conv(const float *__restrict__ in, const f3
     for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int m = 0; m < TM; ++m)
-            a[g][m] = *reinterpret_cast<const f32x4 *>(ubase + (size_t)m * kUStride + (size_t)g * (64 * 16) + u_lane);
+            a[g][m] = load_u(u_rsrc, u_lane, ubase + m * kUStride + g * (64 * 16));
     // pipeline prologue: group 0 transformed, patch rows of group 1 in flight
 #pragma unroll
     for (int o = 0; o < 8; ++o) wino_ld_op<0>(d, base, o);
@@ -411,10 +420,10 @@ __device__ __forceinline__ void wino_conv(const float *__restrict__ in, const f3
 #pragma unroll
     for (int o = 0; o < 8; ++o) wino_ld_op<0>(d, base + 4 * PL, o);
     __builtin_amdgcn_sched_barrier(0);
-    wino_pass<PL, CIN, TM, 0>(base, ubase, u_lane, a, d, vb, Y);
-    wino_pass<PL, CIN, TM, 1>(base, ubase, u_lane, a, d, vb, Y);
-    wino_pass<PL, CIN, TM, 2>(base, ubase, u_lane, a, d, vb, Y);
-    wino_pass<PL, CIN, TM, 3>(base, ubase, u_lane, a, d, vb, Y);
+    wino_pass<PL, CIN, TM, 0>(base, u_rsrc, ubase, u_lane, a, d, vb, Y);
+    wino_pass<PL, CIN, TM, 1>(base, u_rsrc, ubase, u_lane, a, d, vb, Y);
+    wino_pass<PL, CIN, TM, 2>(base, u_rsrc, ubase, u_lane, a, d, vb, Y);
+    wino_pass<PL, CIN, TM, 3>(base, u_rsrc, ubase, u_lane, a, d, vb, Y);
 }
 
 // Sum `vals` over the 4 lanes {n, n+16, n+32, n+48} as a reduce-scatter with the gfx950 lane-swap

@@ -1,0 +1,39 @@
+#!/bin/bash
+# Collects the measurements kept under profiles/<round>/ on a GPU box (run from the repository root):
+#   bash profiles/collect.sh r01
+# Output goes to gpurun_out/<round>/ (scratch); copy what is to be kept into profiles/<round>/.
+# rocprofv3 is always given the program itself after `--` and counters get their own passes.
+set -u
+ROUND=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$ROUND
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+
+# 1. the default bench line (with the CPU baseline) and the literal 4096/8 games-per-GPU configuration
+python3 "$ROOT/bench.py" > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+python3 "$ROOT/bench.py" --no-cpu-baseline --lanes 1 --games 512 > "$OUT/bench_1lane_512games.json" 2>> "$OUT/bench_default.err"
+
+# 2. per-kernel times of the same default command (hipGraph replays: rocprofv3 attributes the time a
+#    dependent node waits to the node) and of an eager run (true durations)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_default" -o s -- \
+    python3 "$ROOT/bench.py" --no-cpu-baseline > "$OUT/bench_under_rocprof.json" 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager" -o s -- \
+    python3 "$ROOT/bench.py" --no-cpu-baseline --graph 0 --steps 2 > "$OUT/bench_eager_under_rocprof.json" 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_1lane" -o s -- \
+    python3 "$ROOT/bench.py" --no-cpu-baseline --graph 0 --steps 2 --lanes 1 --games 512 \
+    > "$OUT/bench_eager_1lane_under_rocprof.json" 2> /dev/null
+
+# 3. HBM traffic counters, one pass each (short eager run of the default geometry)
+for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_$c" -o p -- \
+        python3 "$ROOT/bench.py" --no-cpu-baseline --steps 1 --warmup 0 --playouts 40 --graph 0 \
+        > /dev/null 2> /dev/null
+done
+
+# 4. the other single-GPU configurations of BASELINE.json (parity-test cases, recorded for reference)
+python3 "$ROOT/bench.py" --no-cpu-baseline --lanes 1 --board 3 --playouts 25 --games 1 > "$OUT/bench_c1_ttt.json" 2> /dev/null
+python3 "$ROOT/bench.py" --no-cpu-baseline --lanes 1 --board 9 --playouts 200 --games 64 > "$OUT/bench_c2_9x9.json" 2> /dev/null
+python3 "$ROOT/bench.py" --no-cpu-baseline --lanes 1 --game connect4 --playouts 400 --games 512 > "$OUT/bench_c3_connect4.json" 2> /dev/null
+
+cd "$ROOT" && python3 profiles/summarise.py "$OUT"

@@ -180,30 +180,14 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[TM][8]) {
 //   * the output transform A^T M A is linear in M, so after each pass the 4 accumulators of a
 //     (cout tile, N-tile) are folded into the 4 output values of the tile with coefficients
 //     0 / +1 / -1 -- all 16 components of a (cout, tile) live in the same lane, no data movement;
-//   * FOUR waves per workgroup, one per SIMD, each with the whole 512-register file: a wave owns
-//     TM output-channel tiles x 2 N-tiles, so one transformed fragment feeds 4*TM MFMAs (with one
-//     tile per wave the loop was VALU-issue bound: in-kernel stamps);
-//   * the packed U vectors are one contiguous stream over (pass, channel group) and are
-//     prefetched 3 groups ahead through a 4-slot register ring that runs across the passes.
+//   * a wave owns TM output-channel tiles x 2 N-tiles (one board half), so one transformed fragment
+//     feeds 4*TM MFMAs; 8 waves (two per SIMD, TM = 2 for conv3) beat 4 waves with TM = 4;
+//   * the packed U vectors are one contiguous stream over (pass, channel group), fetched with
+//     buffer loads 3 groups ahead through a 4-slot register ring that runs across the passes;
+//   * software pipeline over the channel groups: the input transform, the LDS reads and the U loads
+//     of the coming groups are threaded between the MFMAs of the current one (wino_block).
 // fp32 throughout; differs from the direct kernel only by Winograd's re-association
 // (|error| ~1e-6 relative, far inside the 1e-4 tolerance; both paths are tested).
-
-// the 2 patch rows x 4 columns pass IP needs, for both N-tiles of the wave
-template <int PL, int IP>
-__device__ __forceinline__ void wino_load_d(float (&d)[2][2][4], const float *__restrict__ base, int s) {
-    constexpr int r0 = (IP == 0) ? 0 : (IP == 1) ? 1 : (IP == 2) ? 2 : 1;
-    constexpr int r1 = (IP == 0) ? 2 : (IP == 1) ? 2 : (IP == 2) ? 1 : 3;
-    const float *p = base + (4 * s) * PL;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const float *q = p + nt * 2 * kRowW;  // N-tile nt starts one tile row (2 board rows) lower
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            d[nt][0][j] = q[r0 * kRowW + j];
-            d[nt][1][j] = q[r1 * kRowW + j];
-        }
-    }
-}
 
 // patch rows (of the 4x4 input patch) that transform row i' = IP combines: V[i'] = d[r0] +/- d[r1]
 template <int IP> struct WinoRows {

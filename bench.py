@@ -313,12 +313,7 @@ def main():
     evaluator = evaluators[0]
     sp = BatchedSelfPlay(engines, evaluators, temperature=TEMPERATURE, seed=0,
                          use_graph=args.graph > 0, sims_per_graph=max(args.graph, 1), eager_every=10)
-    if args.graph > 0:
-        for lane in sp.lanes:
-            with torch.cuda.stream(lane.stream):
-                lane.eng.reset_games()
-                lane.eng.warm_graph(lane.evaluator, args.graph)
-        torch.cuda.synchronize()
+    sp.warm_graphs()
     # games rank, rank+world, ... ; ids beyond the first G refill finished slots
     next_id = [rank + world * G]
     sp._start(range(G), [rank + world * i for i in range(G)])

@@ -272,6 +272,8 @@ int rz_net_set_algo(rz_net *net, int32_t algo);
 int rz_net_set_max_workgroups(rz_net *net, int32_t max_workgroups);
 int rz_net_create(int32_t height, int32_t width, int32_t n_actions, int32_t device, rz_net **out);
 int rz_net_destroy(rz_net *net);
+/* Uploads (and re-packs) the 16 tensors of PolicyValueNet.state_dict().  Later calls reuse the device
+ * buffers of the first one, so launches captured in a hipGraph stay valid across weight updates. */
 int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params);
 int rz_net_reserve(rz_net *net, int32_t max_boards);
 int rz_net_trunk(rz_net *net, const float *d_obs, int32_t n_boards, float *d_feat, void *stream);

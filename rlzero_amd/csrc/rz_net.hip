@@ -802,6 +802,8 @@ struct rz_net {
     int max_wgs = 0;  // rz_net_set_max_workgroups: 0 = one persistent trunk workgroup per CU
     NetDev dev;
     std::vector<void *> allocs;
+    std::vector<size_t> alloc_bytes;
+    size_t upload_cursor = 0;
     float *d_feat = nullptr, *d_raw = nullptr, *d_hid = nullptr;
     long long feat_boards = 0;
     size_t feat_floats = 0;
@@ -816,11 +818,21 @@ int net_fail(int code, const char *msg, const char *detail = "") {
     return code;
 }
 
+// Parameter buffers are allocated by the first rz_net_load and REUSED by later ones (same shapes, same
+// order), so device pointers captured in hipGraphs stay valid across weight updates.
 template <typename T>
 int net_upload(rz_net *net, const std::vector<T> &host, const T **out) {
     void *p = nullptr;
-    if (hipMalloc(&p, host.size() * sizeof(T)) != hipSuccess) return net_fail(RZ_ERR_OOM, "hipMalloc failed (net)");
-    net->allocs.push_back(p);
+    const size_t bytes = host.size() * sizeof(T);
+    if (net->upload_cursor < net->allocs.size()) {
+        if (net->alloc_bytes[net->upload_cursor] != bytes) return net_fail(RZ_ERR_ARG, "parameter size changed between loads");
+        p = net->allocs[net->upload_cursor];
+    } else {
+        if (hipMalloc(&p, bytes) != hipSuccess) return net_fail(RZ_ERR_OOM, "hipMalloc failed (net)");
+        net->allocs.push_back(p);
+        net->alloc_bytes.push_back(bytes);
+    }
+    net->upload_cursor += 1;
     if (hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
         return net_fail(RZ_ERR_HIP, "hipMemcpy failed (net)");
     *out = (const T *)p;
@@ -930,8 +942,7 @@ int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params) {
         if (!h_params[i]) return net_fail(RZ_ERR_ARG, "a parameter pointer is NULL");
     if (hipSetDevice(net->device) != hipSuccess) return net_fail(RZ_ERR_HIP, "hipSetDevice failed");
     (void)hipDeviceSynchronize();
-    for (void *p : net->allocs) (void)hipFree(p);
-    net->allocs.clear();
+    net->upload_cursor = 0;
     const int S = net->dev.S;
     NetDev &D = net->dev;
     int rc = RZ_OK;

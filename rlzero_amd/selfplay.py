@@ -100,6 +100,25 @@ class Trajectory(object):
         return self.winner, list(zip(self.states(), list(self.pis), self.z()))
 
 
+RESERVED_CUS_PER_XCD, N_XCD = 4, 8  # CUs a lane's trunk leaves to the other lane's tree / FC kernels
+
+
+def plan_lanes(n_games, n_cus=256):
+    """-> (lanes, trunk_workgroups) for ``n_games`` games in flight on a GPU with ``n_cus`` CUs.
+
+    One lane: the trunk takes ceil(G / CUs) board rounds (~60 us each on 15x15) and then the GPU idles
+    through the lane's FC + tree kernels and three kernel boundaries (~40 us).  Two lanes: each trunk is
+    capped at CUs - 32 persistent workgroups (4 CUs per XCD stay free), the two trunks alternate and the
+    small kernels of one lane hide under the trunk of the other.  The cheaper estimate wins; 0 workgroups
+    means "one per CU" (no cap)."""
+    capped = n_cus - RESERVED_CUS_PER_XCD * N_XCD
+    if capped <= 0 or n_games < 2:
+        return 1, 0
+    one = -(-n_games // n_cus) * 60.0 + 40.0
+    two = 2.0 * -(-((n_games + 1) // 2) // capped) * 60.0 + 5.0
+    return (2, capped) if two < one else (1, 0)
+
+
 class _Lane(object):
     """One engine + its evaluator + the HIP stream its kernels are enqueued on."""
 
@@ -147,6 +166,60 @@ class BatchedSelfPlay(object):
         self.slot_pis = [[] for _ in range(G)]
         self.sims_done = 0
         self.moves_done = 0
+
+    @classmethod
+    def for_network(cls, net_module, board, n_in_row, n_games, n_playout, c_puct=5.0, device='cuda:0',
+                    game='gomoku', net_shape=None, lanes=None, trunk_workgroups=None, temperature=1.0, seed=0,
+                    use_graph=True, sims_per_graph=8, eager_every=0, **engine_kw):
+        """Self-play of ``n_games`` games in flight with the hand-written evaluator of ``net_module`` (a
+        PolicyValueNet): builds the lanes (engine + HipNetEvaluator each) as plan_lanes() recommends, unless
+        ``lanes`` / ``trunk_workgroups`` are given."""
+        import torch
+        from .engine import HipNetEvaluator, MCTSEngine
+        dev = torch.device(device)
+        n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        auto_lanes, auto_wgs = plan_lanes(n_games, n_cus)
+        if lanes is None:
+            lanes, wgs = auto_lanes, auto_wgs
+        else:
+            wgs = (n_cus - RESERVED_CUS_PER_XCD * N_XCD) if lanes > 1 else 0
+        if trunk_workgroups is not None:
+            wgs = trunk_workgroups
+        lanes = max(1, min(int(lanes), n_games))
+        per_lane = [n_games // lanes + (1 if i < n_games % lanes else 0) for i in range(lanes)]
+        engines, evaluators = [], []
+        for g_lane in per_lane:
+            engines.append(MCTSEngine(board, n_in_row, n_games=g_lane, n_playout=n_playout, c_puct=c_puct,
+                                      device=str(device), game=game, **engine_kw))
+            ev = HipNetEvaluator(net_module, net_shape if net_shape is not None else board, str(device),
+                                 max_boards=g_lane)
+            ev.hip.set_max_workgroups(max(0, int(wgs)))
+            evaluators.append(ev)
+        sp = cls(engines if lanes > 1 else engines[0], evaluators if lanes > 1 else evaluators[0],
+                 temperature=temperature, seed=seed, use_graph=use_graph, sims_per_graph=sims_per_graph,
+                 eager_every=eager_every)
+        sp.trunk_workgroups = int(wgs)
+        sp.warm_graphs()
+        return sp
+
+    def warm_graphs(self):
+        """Capture the simulation-chunk hipGraph of every lane (before any game is started: the capture
+        runs the chunk once).  Weight updates keep the graphs valid: rz_net_load reuses its device buffers."""
+        if not self.use_graph:
+            return
+        per = max(1, int(self.sims_per_graph))
+        for lane in self.lanes:
+            with self._on(lane):
+                lane.eng.reset_games()
+                lane.eng.warm_graph(lane.evaluator, per)
+        self.torch.cuda.synchronize()
+
+    def refresh_weights(self):
+        """Re-upload the network weights of every lane if the torch module changed (after a learner step)."""
+        for lane in self.lanes:
+            refresh = getattr(lane.evaluator, 'refresh_if_changed', None)
+            if refresh is not None:
+                refresh()
 
     def _on(self, lane):
         return self.torch.cuda.stream(lane.stream)

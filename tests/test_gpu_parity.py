@@ -336,6 +336,38 @@ def test_batched_selfplay_vs_oracle():
     eng.close()
 
 
+def test_two_capped_lanes_with_graphs_equal_one_eager_lane():
+    """Lanes, hipGraph replay and the persistent-workgroup cap of the trunk are scheduling only: games are
+    keyed by id, so 2 lanes x 6 games (graphs, trunk capped at 8 workgroups) give the very trajectories of 1
+    lane x 12 games run kernel by kernel -- also after a weight update, which the captured graphs survive."""
+    import torch
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    from rlzero_amd.selfplay import BatchedSelfPlay
+    torch.manual_seed(3)
+    net = PolicyValueNet(6).to('cuda:0').eval()
+    kw = dict(board=6, n_in_row=4, n_games=12, n_playout=40, c_puct=5.0, device='cuda:0', temperature=1.0, seed=11)
+    one = BatchedSelfPlay.for_network(net, lanes=1, use_graph=False, **kw)
+    two = BatchedSelfPlay.for_network(net, lanes=2, trunk_workgroups=8, use_graph=True, sims_per_graph=8, **kw)
+    assert len(two.lanes) == 2 and two.trunk_workgroups == 8
+
+    def same(a, b):
+        assert [t.game_id for t in a] == [t.game_id for t in b]
+        for x, y in zip(a, b):
+            assert (x.winner, x.moves) == (y.winner, y.moves)
+            assert np.array_equal(np.asarray(x.pis), np.asarray(y.pis))
+
+    same(one.run(range(30)), two.run(range(30)))
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.mul_(1.25)
+    one.refresh_weights()
+    two.refresh_weights()
+    a, b = one.run(range(30, 54)), two.run(range(30, 54))
+    same(a, b)
+    for lane in one.lanes + two.lanes:
+        lane.eng.close()
+
+
 # ------------------------------------------------------------------ real net
 def test_replay_recorded_leaf_values(g2net):
     """Feeding the reference's recorded per-simulation leaf values (real net on CPU) through

@@ -92,16 +92,13 @@ class TrainPipeline:
 
     def _collect_batched(self, n_games):
         from rlzero.algorithms import BatchedSelfPlay
-        from rlzero_amd.engine import HipNetEvaluator, MCTSEngine
         if self._batched is None:
-            in_flight = self.selfplay_games_in_flight
-            engine = MCTSEngine(self.board_size, self.n_in_row, n_games=in_flight, n_playout=self.n_playout,
-                                c_puct=self.c_puct, device=str(self.device))
-            evaluator = HipNetEvaluator(self.alphazero_agent.policy_value_net, self.board_size,
-                                        str(self.device), max_boards=in_flight)
-            self._batched = BatchedSelfPlay(engine, evaluator, temperature=self.temperature,
-                                            seed=random.getrandbits(31))
-        self._batched.evaluator.refresh_if_changed()
+            # one or two lanes of games, whichever fills the GPU better (selfplay.plan_lanes)
+            self._batched = BatchedSelfPlay.for_network(
+                self.alphazero_agent.policy_value_net, self.board_size, self.n_in_row,
+                n_games=self.selfplay_games_in_flight, n_playout=self.n_playout, c_puct=self.c_puct,
+                device=str(self.device), temperature=self.temperature, seed=random.getrandbits(31))
+        self._batched.refresh_weights()
         ids = range(self._next_game_id, self._next_game_id + n_games)
         self._next_game_id += n_games
         return [t.as_reference_tuple() for t in self._batched.run(ids)]

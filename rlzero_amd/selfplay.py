@@ -54,6 +54,36 @@ def draw_move(acts, probs, u):
     return int(acts[int(cdf.searchsorted(u, side='right'))])
 
 
+def batch_pi_and_moves(visits, legal, temperature, uniforms):
+    """visits_to_pi + draw_move for many games at once: visits int [R, A], legal bool [R, A], uniforms [R]
+    -> (pi float64 [R, A] with zeros at illegal actions, chosen action int [R]).
+
+    Bit-identical to the per-game expressions above (which are the reference's, alphazero_mcts.py:10-14,
+    91-92,148): log / exp / divide are elementwise; the maximum is exact; the normalising sum is taken over
+    each game's COMPRESSED legal entries, grouped by their count, because numpy's pairwise summation depends on
+    the array length; cumsum is sequential and adding the zeros of illegal actions changes nothing, so the
+    first index with cdf > u on the full row is searchsorted(u, 'right') on the compressed one."""
+    visits = np.asarray(visits)
+    legal = np.asarray(legal, dtype=bool)
+    R, A = visits.shape
+    x = 1.0 / temperature * np.log(visits + 1e-10)
+    mx = np.where(legal, x, -np.inf).max(axis=1)
+    e = np.exp(np.where(legal, x - mx[:, None], -np.inf))  # exp(-inf) = 0 at illegal actions
+    k = legal.sum(axis=1)
+    order = np.argsort(~legal, axis=1, kind='stable')  # legal actions first, ascending
+    comp = np.take_along_axis(e, order, axis=1)
+    sums = np.ones(R)
+    for kk in np.unique(k):
+        if kk > 0:
+            rows = np.nonzero(k == kk)[0]
+            sums[rows] = np.ascontiguousarray(comp[rows, :kk]).sum(axis=1)
+    pi = e / sums[:, None]
+    cdf = np.cumsum(pi, axis=1)
+    cdf /= cdf[:, -1:]
+    moves = (cdf > np.asarray(uniforms, dtype=np.float64)[:, None]).argmax(axis=1)
+    return pi, moves.astype(np.int64)
+
+
 def shard_game_ids(n_games_total, rank, world_size):
     return list(range(rank, n_games_total, world_size))
 
@@ -161,7 +191,7 @@ class BatchedSelfPlay(object):
         G = self.n_slots
         self.slot_game = np.full(G, -1, dtype=np.int64)
         self.slot_ply = np.zeros(G, dtype=np.int64)
-        self.slot_occ = [0] * G
+        self.cell_taken = np.zeros((G, self.eng.n_cells), dtype=bool)  # host mirror of the root boards
         self.slot_moves = [[] for _ in range(G)]
         self.slot_pis = [[] for _ in range(G)]
         self.sims_done = 0
@@ -231,7 +261,7 @@ class BatchedSelfPlay(object):
             mask[s] = 1
             self.slot_game[s] = g
             self.slot_ply[s] = 0
-            self.slot_occ[s] = 0
+            self.cell_taken[s] = False
             self.slot_moves[s] = []
             self.slot_pis[s] = []
         for lane in self.lanes:
@@ -284,19 +314,22 @@ class BatchedSelfPlay(object):
                 visits[lane.slots] = lane.eng.root_visits()
         self.sims_done += eng.n_playout * len(running)
         moves = np.full(self.n_slots, -2, dtype=np.int32)
-        us = move_uniform(self.seed, self.slot_game[running], self.slot_ply[running])
-        for s, u in zip(running, us):
-            occ = self.slot_occ[s]
-            acts = np.array(eng.legal_actions(occ))
-            probs = visits_to_pi(visits[s, acts], self.temperature)
-            pi = np.zeros(S)
-            pi[acts] = probs
-            move = draw_move(acts, probs, u)
-            moves[s] = move
-            self.slot_pis[s].append(pi)
-            self.slot_moves[s].append(move)
-            self.slot_occ[s] = occ | (1 << eng.cell_of_action(occ, move))
-            self.slot_ply[s] += 1
+        if len(running):
+            us = move_uniform(self.seed, self.slot_game[running], self.slot_ply[running])
+            taken = self.cell_taken[running]
+            if eng.game == 'connect4':  # action = column, legal while its top cell is empty; the stone drops
+                legal = ~taken[:, (eng.rows - 1) * eng.cols:]
+                heights = taken.reshape(len(running), eng.rows, eng.cols).sum(axis=1)
+            else:
+                legal = ~taken
+            pis, chosen = batch_pi_and_moves(visits[running], legal, self.temperature, us)
+            cells = heights[np.arange(len(running)), chosen] * eng.cols + chosen if eng.game == 'connect4' else chosen
+            moves[running] = chosen
+            self.cell_taken[running, cells] = True
+            self.slot_ply[running] += 1
+            for i, s_ in enumerate(running):
+                self.slot_pis[s_].append(pis[i])
+                self.slot_moves[s_].append(int(chosen[i]))
         winner = np.zeros(self.n_slots, dtype=np.int32)
         ended = np.zeros(self.n_slots, dtype=np.uint8)
         step_moves = np.where(moves >= 0, moves, -1).astype(np.int32)

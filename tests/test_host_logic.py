@@ -115,3 +115,24 @@ def test_plan_lanes():
     assert plan_lanes(1) == (1, 0) and plan_lanes(256) == (1, 0) and plan_lanes(512) == (1, 0)
     assert plan_lanes(448) == (2, 224) and plan_lanes(896) == (2, 224)
     assert plan_lanes(100, n_cus=32) == (1, 0)  # nothing left to reserve
+
+
+def test_batched_pi_and_moves_bit_identical_to_per_game_expressions():
+    """The vectorised host step of BatchedSelfPlay reproduces, bit for bit, the reference's per-game numpy
+    expressions (softmax of log visits over the legal moves, numpy's inverse-CDF choice)."""
+    from rlzero_amd.selfplay import batch_pi_and_moves, draw_move, visits_to_pi
+    rng = np.random.default_rng(0)
+    for temperature in (1.0, 1e-3, 0.5):
+        for _ in range(6):
+            R, A = 48, 225
+            legal = rng.random((R, A)) < rng.random((R, 1))
+            legal[:, 0] |= ~legal.any(axis=1)
+            visits = (rng.integers(0, 50, size=(R, A)) * (rng.random((R, A)) < 0.6) * legal).astype(np.int32)
+            us = rng.random(R)
+            pi, mv = batch_pi_and_moves(visits, legal, temperature, us)
+            for r in range(R):
+                acts = np.nonzero(legal[r])[0]
+                p = visits_to_pi(visits[r, acts], temperature)
+                full = np.zeros(A)
+                full[acts] = p
+                assert np.array_equal(full, pi[r]) and draw_move(acts, p, us[r]) == mv[r]

@@ -234,7 +234,7 @@ __device__ __forceinline__ void wino_xf_op(const float (&d)[2][2][4], float (&t)
 // (pass LIP, base q_ld) into `d` and the U loads `DIST` groups ahead into a_ld.  The matrix pipe
 // then never waits for a block of VALU / LDS issue of the same wave, and the partner wave of
 // the SIMD finds issue slots between this wave's MFMAs.
-template <int TM, int XIP, int LIP, bool DO_XF, bool DO_LD, bool DO_U>
+template <int TM, int XIP, int LIP, bool DO_XF, bool DO_LD, bool DO_U, bool ZERO_C = false>
 __device__ __forceinline__ void wino_block(f32x4 (&acc)[TM][2][4], const f32x4 (&a_cur)[TM], const float (&v_cur)[2][4],
                                            float (&v_nxt)[2][4], float (&d)[2][2][4], lds_cptr q_ld,
                                            f32x4 (&a_ld)[TM], __amdgpu_buffer_rsrc_t u_rsrc, int u_off, int u_lane,
@@ -246,7 +246,9 @@ __device__ __forceinline__ void wino_block(f32x4 (&acc)[TM][2][4], const f32x4 (
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const int jp = i / (2 * TM), m = (i >> 1) % TM, nt = i & 1;
-        acc[m][nt][jp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[m][jp], v_cur[nt][jp], acc[m][nt][jp], 0, 0, 0);
+        // ZERO_C (first group of a pass): C is the inline constant 0, the accumulators need no clearing
+        acc[m][nt][jp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[m][jp], v_cur[nt][jp],
+                                                              ZERO_C ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[m][nt][jp], 0, 0, 0);
         if (i < NS / 2) {
             if (DO_XF) {
 #pragma unroll
@@ -282,16 +284,23 @@ __device__ __forceinline__ void wino_pass(lds_cptr base, __amdgpu_buffer_rsrc_t 
     constexpr int kT = 4 * kSteps;   // U vectors per tile: index t = IP*kSteps + s
     constexpr int kUStride = kT * 64 * 16;  // bytes between the U streams of consecutive tiles
     constexpr int NIP = IP < 3 ? IP + 1 : 3;
-    f32x4 acc[TM][2][4];
+    f32x4 acc[TM][2][4];  // first written by the ZERO_C block below
+    // all but the last 4 groups of the pass: everything these blocks prepare belongs to this pass.  The
+    // first 4 are peeled (kSteps >= 8): their first block starts the accumulators from C = 0.
 #pragma unroll
-    for (int m = 0; m < TM; ++m)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int jp = 0; jp < 4; ++jp) acc[m][nt][jp] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // all but the last 4 groups of the pass: everything this block prepares belongs to this pass
+    for (int r = 0; r < 4; ++r) {
+        lds_cptr q = base + (4 * (r + 2)) * PL;
+        asm volatile("" : "+v"(q));
+        const int u = ubase + (IP * kSteps + r + 3) * (64 * 16);
+        if (r == 0)
+            wino_block<TM, IP, IP, true, true, true, true>(acc, a[r], vb[r & 1], vb[(r + 1) & 1], d, q, a[(r + 3) & 3], u_rsrc,
+                                                           u, u_lane, kUStride);
+        else
+            wino_block<TM, IP, IP, true, true, true>(acc, a[r], vb[r & 1], vb[(r + 1) & 1], d, q, a[(r + 3) & 3], u_rsrc, u,
+                                                     u_lane, kUStride);
+    }
 #pragma unroll 1
-    for (int s0 = 0; s0 < kSteps - 4; s0 += 4) {
+    for (int s0 = 4; s0 < kSteps - 4; s0 += 4) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int s = s0 + r;
@@ -338,13 +347,17 @@ __device__ __forceinline__ void wino_pass(lds_cptr base, __amdgpu_buffer_rsrc_t 
         for (int nt = 0; nt < 2; ++nt) {
             const f32x4 yb0 = acc[m][nt][0] + acc[m][nt][1] + acc[m][nt][2];
             const f32x4 yb1 = acc[m][nt][1] - acc[m][nt][2] - acc[m][nt][3];
-            if (c0 != 0.0f) {
+            // Y is first written here: rows 0, 1 by pass 0, rows 2, 3 by pass 1 (no clearing, no add)
+            if (IP == 0) {
+                Y[m][nt][0] = yb0;
+                Y[m][nt][1] = yb1;
+            } else if (c0 != 0.0f) {
                 Y[m][nt][0] += yb0;
                 Y[m][nt][1] += yb1;
             }
-            if (c1 > 0.0f) {
-                Y[m][nt][2] += yb0;
-                Y[m][nt][3] += yb1;
+            if (IP == 1) {
+                Y[m][nt][2] = yb0;
+                Y[m][nt][3] = yb1;
             } else if (c1 < 0.0f) {
                 Y[m][nt][2] -= yb0;
                 Y[m][nt][3] -= yb1;
@@ -357,7 +370,7 @@ __device__ __forceinline__ void wino_pass(lds_cptr base, __amdgpu_buffer_rsrc_t 
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int o = 0; o < 4; ++o) asm volatile("" : "+v"(Y[m][nt][o]));
+            for (int o = 0; o < (IP == 0 ? 2 : 4); ++o) asm volatile("" : "+v"(Y[m][nt][o]));
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -382,12 +395,6 @@ __device__ __forceinline__ void wino_conv(const float *__restrict__ in, const f3
     const int ubase = tile0 * kT * 64 * 16;  // byte offset of the wave's first tile stream
     const int u_lane = lane * 16;
     constexpr int kUStride = kT * 64 * 16;
-#pragma unroll
-    for (int m = 0; m < TM; ++m)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int o = 0; o < 4; ++o) Y[m][nt][o] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 a[4][TM];
     float d[2][2][4], vb[2][2][4], t[2][4];
 #pragma unroll

@@ -462,6 +462,34 @@ __global__ __launch_bounds__(128 * CG) void k_trunk_wino(NetDev nd, const float 
         f32x4 *z = reinterpret_cast<f32x4 *>(lds);
         for (int i = tid0; i < kLdsFloats / 4; i += kThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // Observation planes of a board: fetched into registers one board AHEAD (right after conv1 has
+    // consumed the current ones), written into the input planes after conv2 -- the global-memory
+    // latency hides under conv2 and a board starts with its input already staged.
+    constexpr int kObsPer = (4 * RZ_MAX_BOARD_SIZE * RZ_MAX_BOARD_SIZE + kThreads - 1) / kThreads;
+    float ob[kObsPer];
+    auto load_obs = [&](int board, int tid) {
+        const float *src = obs + (size_t)board * 4 * S;
+#pragma unroll
+        for (int k = 0; k < kObsPer; ++k) {
+            const int i = tid + k * kThreads;
+            ob[k] = i < 4 * S ? src[i] : 0.0f;
+        }
+    };
+    auto store_obs = [&](int tid) {
+#pragma unroll
+        for (int k = 0; k < kObsPer; ++k) {
+            const int i = tid + k * kThreads;
+            if (i < 4 * S) {
+                const int c = i / S, r = i - c * S, y = r / BW, x = r - y * BW;
+                in0[c * PL + (y + 1) * kRowW + (x + 1)] = ob[k];
+            }
+        }
+    };
+    __syncthreads();  // the zero fill is complete before the staging writes
+    if ((int)blockIdx.x < n_boards) {
+        load_obs(blockIdx.x, tid0);
+        store_obs(tid0);
+    }
     for (int board = blockIdx.x; board < n_boards; board += gridDim.x) {
     // The thread id is laundered per board so that no lane-dependent address is hoisted out of the
     // board loop and kept live across it (that costs ~50 spilled VGPRs).
@@ -469,15 +497,8 @@ __global__ __launch_bounds__(128 * CG) void k_trunk_wino(NetDev nd, const float 
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cg = wave % CG, h = wave / CG;
-    __syncthreads();  // first pass: the zero fill is complete before the staging writes
-    {
-        const float *src = obs + (size_t)board * 4 * S;
-        for (int i = tid; i < 4 * S; i += kThreads) {
-            const int c = i / S, r = i - c * S, y = r / BW, x = r - y * BW;
-            in0[c * PL + (y + 1) * kRowW + (x + 1)] = src[i];
-        }
-    }
-    __syncthreads();
+    const int next_board = board + (int)gridDim.x;
+    __syncthreads();  // the input planes are staged (and the previous board's epilogue is done)
     {   // conv1: 4 -> 32 direct (1 % of the work): 2 tiles x (2 or 4) row groups over all waves
         constexpr int kRowsPer = (CG == 4) ? 4 : 8;
         const int tile = cg & 1;
@@ -491,6 +512,7 @@ __global__ __launch_bounds__(128 * CG) void k_trunk_wino(NetDev nd, const float 
         }
     }
     __syncthreads();
+    if (next_board < n_boards) load_obs(next_board, tid);
     const int q = lane >> 4, tx = lane & 7;
     {   // conv2: 32 -> 64
         f32x4 Y[TM2][2][4];
@@ -512,6 +534,7 @@ __global__ __launch_bounds__(128 * CG) void k_trunk_wino(NetDev nd, const float 
                 }
         }
     }
+    if (next_board < n_boards) store_obs(tid);  // conv1 of this board is done with the input planes
     __syncthreads();
     {   // conv3: 64 -> 128; the ReLU'd output goes straight from the registers into the two 1x1
         // head convolutions

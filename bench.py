@@ -216,6 +216,57 @@ class TimedEvaluator(object):
         return sum(a.elapsed_time(b) for a, b in self.events) / len(self.events)
 
 
+def run_muzero(args, rank, world, device, dist):
+    """BASELINE.json configs[4]: MuZero on CartPole-v1, 50 simulations per move (random-init model).  A step =
+    one move of every environment: initial inference, n simulations (HIP tree kernels + recurrent inference on
+    the batch), action sampling, environment step."""
+    import torch
+    from rlzero_amd.muzero import CartPoleBatch, MuZeroNet, MuZeroSelfPlay
+    G = args.games if args.games > 0 else 4096
+    n_sims = args.playouts if args.playouts != N_PLAYOUT else 50
+    torch.manual_seed(0)
+    net = MuZeroNet().to(device).eval()
+    sp = MuZeroSelfPlay(net, CartPoleBatch(G, device, seed=rank), n_sims=n_sims, seed=rank)
+    for _ in range(args.warmup):
+        sp.play_move()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    sims0 = sp.sims_done
+    t0 = time.perf_counter()
+    finished = 0
+    for _ in range(args.steps):
+        finished += len(sp.play_move())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    total = float(sp.sims_done - sims0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([total], dtype=torch.float64, device=device)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        total = float(c.item())
+    sp.tree.check()
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'mcts_sims_per_sec', 'value': round(total / elapsed, 1), 'unit': 'sims/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000.0 * elapsed / max(args.steps, 1), 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 model / f64 tree',
+            'data': 'synthetic (random-init MuZero MLPs, torch.manual_seed(0); CartPole-v1 restatement)',
+            'config': {'workload': 'muzero_cartpole_v1_%dsims_per_move_%denvs_per_gpu' % (n_sims, G),
+                       'games_total': G * world, 'discount': 0.997, 'parallelism': 'environments sharded, dp%d' % world},
+            'episodes_finished_in_timed_region': finished, 'tree_hbm_bytes': int(sp.tree.device_bytes),
+            'roofline': None, 'cpu_baseline': None}), flush=True)
+    sp.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -231,9 +282,10 @@ def main():
                     help='persistent trunk workgroups per lane; -1 = CUs - %d with lanes > 1, one per CU otherwise' %
                     (RESERVED_CUS_PER_XCD * N_XCD))
     ap.add_argument('--board', type=int, default=BOARD)
-    ap.add_argument('--game', default='gomoku', choices=['gomoku', 'connect4'],
+    ap.add_argument('--game', default='gomoku', choices=['gomoku', 'connect4', 'muzero'],
                     help='connect4: 6x7, 4 in a row, 7 column actions (BASELINE config 3; pair with '
-                         '--playouts 400 --games 512)')
+                         '--playouts 400 --games 512); muzero: learned-dynamics MCTS on CartPole-v1 (BASELINE config 5; '
+                         'pair with --playouts 50 --games 4096)')
     ap.add_argument('--playouts', type=int, default=N_PLAYOUT)
     ap.add_argument('--evaluator', default='hipnet', choices=['hipnet', 'torchnet', 'vlin'],
                     help="hipnet: hand-written fused fp32 MFMA forward (csrc/rz_net.hip); torchnet: "
@@ -277,6 +329,9 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    if args.game == 'muzero':
+        run_muzero(args, rank, world, device, dist)
+        return
     board, n_row = args.board, (N_ROW if args.board >= 5 else args.board)
     cells = board * board
     if args.game == 'connect4':

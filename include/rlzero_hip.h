@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 13
+#define RZ_ABI_VERSION 14
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 
@@ -284,6 +284,51 @@ int rz_net_heads_gemm(rz_net *net, int32_t n_boards, const float **d_raw, int32_
                       const float **d_w2, const float **d_b2, void *stream);
 int rz_net_forward(rz_net *net, const float *d_obs, int32_t n_boards, float *d_logp,
                    float *d_value, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * MuZero search tree (BASELINE.json configs[4]).  The reference only names
+ * MuZero (README.md:3, rlzero/algorithms/rl_args.py:21-24); the algorithm is the published
+ * pseudocode of arXiv:1911.08265v2 (run_mcts, select_child, ucb_score, expand_node, backpropagate,
+ * MinMaxStats), single-player form.  The learned model stays with the caller: per simulation
+ *   rz_mz_select         -> (parent slot, action, leaf slot) per game; the caller gathers the parents'
+ *                           hidden states, runs dynamics + prediction on the batch, keeps the new
+ *                           hidden state of game g at slot leaf[g];
+ *   rz_mz_expand_backup  <- reward, policy PROBABILITIES [n_games][n_actions] (softmax evaluated by the
+ *                           network head in fp32), value; expands the leaf and backs the value up with
+ *                           the discount, updating the game's min-max statistics.
+ * rz_mz_init_roots starts a search (expand_node(root, initial inference) + add_exploration_noise with
+ * caller-supplied Dirichlet samples, fresh MinMaxStats).  d_mask (optional, [n_games] bytes): games with
+ * 0 are left untouched.  Slots: root = 0; the children of a node are consecutive slots. */
+typedef struct rz_muzero rz_muzero;
+typedef struct rz_mz_config {
+    int32_t abi_version; /* RZ_ABI_VERSION */
+    int32_t n_games;
+    int32_t n_actions;   /* 1..64 */
+    int32_t n_sims;      /* simulations per search (sizes the tree: 1 + n_actions * (n_sims + 1) slots) */
+    double discount;     /* 0.997 */
+    double pb_c_base;    /* 19652 */
+    double pb_c_init;    /* 1.25 */
+    int32_t device;
+    int32_t reserved;
+} rz_mz_config;
+
+int rz_mz_create(const rz_mz_config *cfg, rz_muzero **out);
+int rz_mz_destroy(rz_muzero *e);
+/* log((n + pb_c_base + 1) / pb_c_base) for n = 0 .. n_sims + 1, filled at creation by the host libm;
+ * this entry replaces it (e.g. with math.log's values from another host). */
+int rz_mz_upload_log_table(rz_muzero *e, const double *h_table, int64_t count);
+int rz_mz_init_roots(rz_muzero *e, const float *d_probs, const double *d_noise, double noise_frac,
+                     const uint8_t *d_mask, void *stream);
+int rz_mz_select(rz_muzero *e, int32_t *d_parent, int32_t *d_action, int32_t *d_leaf, const uint8_t *d_mask,
+                 void *stream);
+int rz_mz_expand_backup(rz_muzero *e, const float *d_reward, const float *d_probs, const float *d_value,
+                        const uint8_t *d_mask, void *stream);
+/* what: 0 = visit counts (int32), 1 = value sums, 2 = rewards, 3 = priors (float64) of the root's children,
+ * [n_games][n_actions] */
+int rz_mz_root_children(rz_muzero *e, int32_t what, void *d_out, void *stream);
+int rz_mz_root_stats(rz_muzero *e, int32_t *d_n, double *d_value_sum, double *d_vmin, double *d_vmax, void *stream);
+int rz_mz_geometry(rz_muzero *e, int32_t *slots_per_game, int64_t *device_bytes);
+int rz_mz_error_flags(rz_muzero *e, int32_t *flags);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64,
                     c_void_p)
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
 
@@ -33,6 +33,12 @@ class RzStats(Structure):
     _fields_ = [('error_flags', c_int32), ('first_bad_game', c_int32), ('arena_slots', c_int64),
                 ('prior_floats', c_int64), ('max_slots_used', c_int64), ('max_blocks_used', c_int64),
                 ('device_bytes', c_int64), ('n_select_calls', c_int64)]
+
+
+class RzMzConfig(Structure):
+    _fields_ = [('abi_version', c_int32), ('n_games', c_int32), ('n_actions', c_int32), ('n_sims', c_int32),
+                ('discount', c_double), ('pb_c_base', c_double), ('pb_c_init', c_double),
+                ('device', c_int32), ('reserved', c_int32)]
 
 
 class HipError(RuntimeError):
@@ -86,6 +92,16 @@ _SIGNATURES = {
     'rz_net_heads_gemm': (c_int, [P, c_int32, POINTER(c_void_p), POINTER(c_int32), POINTER(c_void_p),
                                   POINTER(c_void_p), POINTER(c_void_p), P]),
     'rz_net_forward': (c_int, [P, P, c_int32, P, P, P]),
+    'rz_mz_create': (c_int, [POINTER(RzMzConfig), POINTER(c_void_p)]),
+    'rz_mz_destroy': (c_int, [P]),
+    'rz_mz_upload_log_table': (c_int, [P, P, c_int64]),
+    'rz_mz_init_roots': (c_int, [P, P, P, c_double, P, P]),
+    'rz_mz_select': (c_int, [P, P, P, P, P, P]),
+    'rz_mz_expand_backup': (c_int, [P, P, P, P, P, P]),
+    'rz_mz_root_children': (c_int, [P, c_int32, P, P]),
+    'rz_mz_root_stats': (c_int, [P, P, P, P, P, P]),
+    'rz_mz_geometry': (c_int, [P, POINTER(c_int32), POINTER(c_int64)]),
+    'rz_mz_error_flags': (c_int, [P, POINTER(c_int32)]),
 }
 
 _lib = None

@@ -1,0 +1,208 @@
+"""Batched MuZero self-play: many CartPole environments in lock-step on one GPU.
+
+Per move (arXiv:1911.08265v2 appendix: ``play_game`` / ``run_mcts`` / ``select_action``):
+  observation -> initial inference (representation + prediction) -> roots expanded with Dirichlet noise
+  -> ``n_sims`` x [ rz_mz_select -> gather the parents' hidden states -> recurrent inference on the whole
+     batch -> store the leaves' hidden states -> rz_mz_expand_backup ]
+  -> action ~ visit counts ^ (1 / T) -> environment step -> the step goes to the episode's trajectory.
+Everything between the observation and the chosen action stays on the device; the tree statistics live
+in the HIP kernels, the small MLPs of the model run on PyTorch-ROCm (rocBLAS GEMMs)."""
+import numpy as np
+
+
+class Episode(object):
+    """One finished (or running) episode: observations, actions, rewards, search policies, root values."""
+
+    def __init__(self):
+        self.obs, self.actions, self.rewards, self.policies, self.root_values = [], [], [], [], []
+
+    def __len__(self):
+        return len(self.actions)
+
+
+class ReplayBuffer(object):
+    """Finished episodes + the target construction of the MuZero learner (``make_target``): K unrolled
+    steps, n-step value targets bootstrapped from the stored root values."""
+
+    def __init__(self, capacity=2000, unroll_steps=5, td_steps=10, discount=0.997, seed=0):
+        self.capacity, self.K, self.td_steps, self.discount = capacity, unroll_steps, td_steps, discount
+        self.episodes = []
+        self.rng = np.random.RandomState(seed)
+
+    def add(self, episode):
+        if len(episode) == 0:
+            return
+        self.episodes.append(episode)
+        if len(self.episodes) > self.capacity:
+            self.episodes.pop(0)
+
+    def __len__(self):
+        return len(self.episodes)
+
+    def _value_target(self, ep, t):
+        boot = t + self.td_steps
+        value = ep.root_values[boot] * self.discount ** self.td_steps if boot < len(ep.root_values) else 0.0
+        for i, r in enumerate(ep.rewards[t:boot]):
+            value += r * self.discount ** i
+        return value
+
+    def sample(self, batch_size, n_actions):
+        """-> obs [b, obs_dim], actions [b, K], target value [b, K+1], target reward [b, K+1], target policy
+        [b, K+1, A], mask [b, K+1] (0 past the end of the episode: no policy loss there)."""
+        K = self.K
+        eps = [self.episodes[i] for i in self.rng.randint(len(self.episodes), size=batch_size)]
+        pos = [self.rng.randint(len(ep)) for ep in eps]
+        obs = np.stack([ep.obs[t] for ep, t in zip(eps, pos)]).astype(np.float32)
+        actions = np.zeros((batch_size, K), dtype=np.int64)
+        tv = np.zeros((batch_size, K + 1), dtype=np.float32)
+        tr = np.zeros((batch_size, K + 1), dtype=np.float32)
+        tp = np.full((batch_size, K + 1, n_actions), 1.0 / n_actions, dtype=np.float32)
+        mask = np.zeros((batch_size, K + 1), dtype=np.float32)
+        for b, (ep, t) in enumerate(zip(eps, pos)):
+            for k in range(K + 1):
+                i = t + k
+                if i < len(ep):
+                    tv[b, k] = self._value_target(ep, i)
+                    tp[b, k] = ep.policies[i]
+                    mask[b, k] = 1.0
+                if k > 0:
+                    if i - 1 < len(ep):
+                        actions[b, k - 1] = ep.actions[i - 1]
+                        tr[b, k] = ep.rewards[i - 1]
+                    else:
+                        actions[b, k - 1] = self.rng.randint(n_actions)  # past the end: random action, zero targets
+        return obs, actions, tv, tr, tp, mask
+
+
+class MuZeroSelfPlay(object):
+
+    def __init__(self, net, env, n_sims=50, discount=0.997, temperature=1.0, root_dirichlet_alpha=0.25,
+                 root_exploration_fraction=0.25, seed=0, pb_c_base=19652.0, pb_c_init=1.25, use_graph=True):
+        import torch
+        from .tree import MuZeroTree
+        self.torch = torch
+        self.net, self.env = net, env
+        self.device = env.device
+        self.n_envs, self.n_actions = env.n_envs, env.n_actions
+        self.n_sims, self.discount, self.temperature = int(n_sims), float(discount), float(temperature)
+        self.alpha, self.noise_frac = float(root_dirichlet_alpha), float(root_exploration_fraction)
+        self.tree = MuZeroTree(self.n_envs, self.n_actions, self.n_sims, discount, pb_c_base, pb_c_init,
+                               device=str(self.device))
+        self.hidden = torch.zeros((self.n_envs, self.tree.slots_per_game, net.hidden), dtype=torch.float32,
+                                  device=self.device)
+        self.rows = torch.arange(self.n_envs, device=self.device)
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(seed))
+        self.running = [Episode() for _ in range(self.n_envs)]
+        self.sims_done = 0
+        self.moves_done = 0
+        self.obs = env.observe()
+        # One simulation (select -> gather -> recurrent inference -> scatter -> expand + backup) is a fixed
+        # sequence of ~15 small launches with static shapes: captured once as a hipGraph and replayed n_sims
+        # times per move.  Captured before any search (the capture runs the step on the still empty trees;
+        # every search starts by re-initialising its roots).  Weight updates are in place: the graph stays valid.
+        self._graph = None
+        if use_graph:
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(3):
+                    self._sim_step()
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            torch.cuda.synchronize(self.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(graph):
+                self._sim_step()
+            self._graph = graph
+
+    def _sim_step(self):
+        t = self.torch
+        parent, action, leaf = self.tree.select()
+        state = self.hidden[self.rows, parent.long()]
+        nxt, reward, logits, value = self.net.recurrent_inference(state, action.long())
+        self.hidden[self.rows, leaf.long()] = nxt
+        probs = t.softmax(logits, dim=1).contiguous()
+        reward, value = reward.contiguous(), value.contiguous()
+        self.tree.expand_backup(reward, probs, value)
+        return parent, action, leaf, reward, probs, value
+
+    def close(self):
+        self.tree.close()
+
+    # ------------------------------------------------------------------ search
+    def search(self, obs, add_noise=True, record=None):
+        """One MuZero search per environment from the observations ``obs`` [n, obs_dim].
+        -> (visit counts int32 [n, A], root value float64 [n]).  ``record`` (list): receives per simulation
+        (parent, action, leaf, reward, probs, value) tensors -- parity tests replay them through their CPython restatement."""
+        t = self.torch
+        tree, net = self.tree, self.net
+        with t.no_grad():
+            s0, logits, _ = net.initial_inference(obs)
+            probs = t.softmax(logits, dim=1).contiguous()
+            self.hidden[:, 0] = s0
+            noise = None
+            if add_noise and self.noise_frac > 0:
+                conc = t.full((self.n_envs, self.n_actions), self.alpha, dtype=t.float64, device=self.device)
+                g = t._standard_gamma(conc, generator=self.gen)
+                noise = (g / g.sum(dim=1, keepdim=True)).contiguous()
+            tree.init_roots(probs, noise, self.noise_frac)
+            if record is not None:
+                record.append(('root', probs.clone(), None if noise is None else noise.clone()))
+            for _ in range(self.n_sims):
+                if self._graph is not None and record is None:
+                    self._graph.replay()
+                    continue
+                out = self._sim_step()
+                if record is not None:
+                    record.append(tuple(x.clone() for x in out))
+            visits = tree.root_visits().clone()
+            n, vsum, _, _ = tree.root_stats()
+            root_value = vsum / n.clamp_min(1).to(t.float64)
+        self.sims_done += self.n_sims * self.n_envs
+        return visits, root_value
+
+    def select_actions(self, visits):
+        """pseudocode ``select_action``: sample from visit counts ^ (1 / temperature) (arg-max at T = 0)."""
+        t = self.torch
+        if self.temperature <= 0:
+            return visits.argmax(dim=1)
+        w = visits.to(t.float64) ** (1.0 / self.temperature)
+        return t.multinomial(w / w.sum(dim=1, keepdim=True), 1, generator=self.gen).squeeze(1)
+
+    # ------------------------------------------------------------------ game loop
+    def play_move(self):
+        """One move of every environment; returns the episodes that ended with it."""
+        t = self.torch
+        obs = self.obs
+        visits, root_value = self.search(obs)
+        actions = self.select_actions(visits)
+        nxt_obs, reward, terminated, truncated = self.env.step(actions)
+        obs_h = obs.cpu().numpy()
+        act_h = actions.cpu().numpy()
+        rew_h = reward.cpu().numpy()
+        vis_h = visits.cpu().numpy().astype(np.float64)
+        val_h = root_value.cpu().numpy()
+        done_h = (terminated | truncated).cpu().numpy()
+        pol_h = vis_h / vis_h.sum(axis=1, keepdims=True)
+        finished = []
+        for i in range(self.n_envs):
+            ep = self.running[i]
+            ep.obs.append(obs_h[i])
+            ep.actions.append(int(act_h[i]))
+            ep.rewards.append(float(rew_h[i]))
+            ep.policies.append(pol_h[i].astype(np.float32))
+            ep.root_values.append(float(val_h[i]))
+            if done_h[i]:
+                finished.append(ep)
+                self.running[i] = Episode()
+        self.obs = nxt_obs
+        self.moves_done += self.n_envs
+        return finished
+
+    def collect(self, n_moves):
+        """``n_moves`` moves of every environment -> list of finished episodes."""
+        out = []
+        for _ in range(n_moves):
+            out.extend(self.play_move())
+        self.tree.check()
+        return out

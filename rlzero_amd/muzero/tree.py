@@ -1,0 +1,100 @@
+"""ctypes binding of the MuZero search tree kernels (include/rlzero_hip.h, rz_mz_*)."""
+import ctypes
+
+import numpy as np
+
+from .. import _hip
+from ..engine import _ptr, check
+
+
+class MuZeroTree(object):
+    """Search trees of ``n_games`` environments on one GPU (one thread per tree).  The learned model is the
+    caller's: see ``MuZeroSelfPlay.search`` for the simulation loop."""
+
+    def __init__(self, n_games, n_actions, n_sims, discount=0.997, pb_c_base=19652.0, pb_c_init=1.25,
+                 device='cuda:0'):
+        import torch
+        self.torch = torch
+        self.lib = _hip.load()
+        self.device = torch.device(device)
+        if self.device.type != 'cuda' or not torch.cuda.is_available():
+            raise _hip.HipError('MuZeroTree needs an MI355X (device=%r): there is no CPU path' % (device, ))
+        self.n_games, self.n_actions, self.n_sims = int(n_games), int(n_actions), int(n_sims)
+        self.discount = float(discount)
+        cfg = _hip.RzMzConfig(_hip.ABI_VERSION, self.n_games, self.n_actions, self.n_sims, self.discount,
+                              float(pb_c_base), float(pb_c_init), self.device.index or 0, 0)
+        self.handle = ctypes.c_void_p()
+        check(self.lib.rz_mz_create(ctypes.byref(cfg), ctypes.byref(self.handle)), 'rz_mz_create')
+        slots, nbytes = ctypes.c_int32(0), ctypes.c_int64(0)
+        check(self.lib.rz_mz_geometry(self.handle, ctypes.byref(slots), ctypes.byref(nbytes)), 'rz_mz_geometry')
+        self.slots_per_game, self.device_bytes = slots.value, nbytes.value
+        kw = dict(device=self.device)
+        G, A = self.n_games, self.n_actions
+        self.parent = torch.zeros(G, dtype=torch.int32, **kw)
+        self.action = torch.zeros(G, dtype=torch.int32, **kw)
+        self.leaf = torch.zeros(G, dtype=torch.int32, **kw)
+        self.visits = torch.zeros((G, A), dtype=torch.int32, **kw)
+        self.child_f64 = torch.zeros((G, A), dtype=torch.float64, **kw)
+        self.root_n = torch.zeros(G, dtype=torch.int32, **kw)
+        self.root_sum = torch.zeros(G, dtype=torch.float64, **kw)
+        self.vmin = torch.zeros(G, dtype=torch.float64, **kw)
+        self.vmax = torch.zeros(G, dtype=torch.float64, **kw)
+        # the very table CPython's math.log gives on this host
+        import math
+        tab = np.array([math.log((n + pb_c_base + 1) / pb_c_base) for n in range(self.n_sims + 2)], dtype=np.float64)
+        check(self.lib.rz_mz_upload_log_table(self.handle, ctypes.c_void_p(tab.ctypes.data), tab.size),
+              'rz_mz_upload_log_table')
+
+    def stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if self.handle:
+            self.lib.rz_mz_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _mask(self, mask):
+        return _ptr(mask) if mask is not None else None
+
+    def init_roots(self, probs, noise=None, noise_frac=0.25, mask=None):
+        """probs float32 [G, A] (device); noise float64 [G, A] Dirichlet samples or None; mask uint8 [G]."""
+        check(self.lib.rz_mz_init_roots(self.handle, _ptr(probs), _ptr(noise) if noise is not None else None,
+                                        float(noise_frac), self._mask(mask), self.stream()), 'rz_mz_init_roots')
+
+    def select(self, mask=None):
+        check(self.lib.rz_mz_select(self.handle, _ptr(self.parent), _ptr(self.action), _ptr(self.leaf),
+                                    self._mask(mask), self.stream()), 'rz_mz_select')
+        return self.parent, self.action, self.leaf
+
+    def expand_backup(self, reward, probs, value, mask=None):
+        check(self.lib.rz_mz_expand_backup(self.handle, _ptr(reward), _ptr(probs), _ptr(value), self._mask(mask),
+                                           self.stream()), 'rz_mz_expand_backup')
+
+    def root_visits(self):
+        check(self.lib.rz_mz_root_children(self.handle, 0, _ptr(self.visits), self.stream()), 'rz_mz_root_children')
+        return self.visits
+
+    def root_children(self, what):
+        """'value_sum' | 'reward' | 'prior' of the root's children, float64 [G, A]."""
+        code = {'value_sum': 1, 'reward': 2, 'prior': 3}[what]
+        check(self.lib.rz_mz_root_children(self.handle, code, _ptr(self.child_f64), self.stream()),
+              'rz_mz_root_children')
+        return self.child_f64.clone()
+
+    def root_stats(self):
+        """-> (N, value_sum, min, max) of the roots / their MinMaxStats."""
+        check(self.lib.rz_mz_root_stats(self.handle, _ptr(self.root_n), _ptr(self.root_sum), _ptr(self.vmin),
+                                        _ptr(self.vmax), self.stream()), 'rz_mz_root_stats')
+        return self.root_n, self.root_sum, self.vmin, self.vmax
+
+    def check(self):
+        flags = ctypes.c_int32(0)
+        check(self.lib.rz_mz_error_flags(self.handle, ctypes.byref(flags)), 'rz_mz_error_flags')
+        if flags.value:
+            raise _hip.HipError('MuZero tree error flags 0x%x (tree arena full)' % flags.value)

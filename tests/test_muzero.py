@@ -1,0 +1,217 @@
+"""MuZero (BASELINE configs[4]).  The reference has no MuZero to pin against: the CPU
+tests check the restatement of the published pseudocode / the Gymnasium CartPole equations against hand-computed
+known answers and invariants; the GPU tests compare the HIP tree kernels with that restatement bit for bit
+(the oracle is fed the very network outputs the device used) and the batched environment with the scalar one."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import muzero_ref as ref
+
+
+# ------------------------------------------------------------------ oracle (CPU)
+def test_cartpole_first_step_known_answer():
+    """From rest at the origin, push right: the textbook numbers of the Barto-Sutton-Anderson cart-pole."""
+    env = ref.RefCartPole()
+    env.reset((0.0, 0.0, 0.0, 0.0))
+    state, reward, terminated, truncated = env.step(1)
+    temp = 10.0 / 1.1
+    thetaacc = -temp / (0.5 * (4.0 / 3.0 - 0.1 / 1.1))
+    xacc = temp - 0.05 * thetaacc / 1.1
+    assert state == (0.0, 0.02 * xacc, 0.0, 0.02 * thetaacc)
+    assert abs(state[1] - 0.19512195) < 1e-8 and abs(state[3] + 0.29268293) < 1e-8
+    assert reward == 1.0 and not terminated and not truncated
+    # constant push to the right: the pole falls left past 12 degrees within a dozen steps
+    for n in range(2, 200):
+        state, reward, terminated, truncated = env.step(1)
+        if terminated:
+            break
+    assert terminated and 5 < n < 20 and state[2] < -ref.RefCartPole.theta_threshold_radians
+    env.reset((0.0, 0.0, 0.0, 0.0))
+    for n in range(1, 501):  # alternating pushes keep it up; the time limit truncates at 500
+        state, reward, terminated, truncated = env.step(n % 2)
+        if terminated or truncated:
+            break
+    assert n == 500 and truncated or terminated
+
+
+def _toy_model(hidden, action, path):
+    """A deterministic stand-in for the learned model: everything depends on the action path only."""
+    h = hash(path) % 1000 / 1000.0
+    p0 = 0.2 + 0.6 * ((len(path) * 7 + sum(path)) % 5) / 4.0
+    return path, 1.0 if sum(path) % 3 else 0.5, (p0, 1.0 - p0), 10.0 * h - 3.0
+
+
+def test_muzero_search_invariants_and_tie_break():
+    cfg = ref.MuZeroConfig(num_simulations=50)
+    root = ref.Node(0)
+    ref.expand_node(root, (), 0.0, (0.5, 0.5))
+    log = []
+    stats = ref.run_mcts(cfg, root, _toy_model, log=log)
+    assert log[0] == (1, )  # sqrt(0) makes every first score 0: max() over (score, action) takes the larger action
+    assert root.visit_count == 50 and sum(c.visit_count for c in root.children) == 50
+    dump = ref.tree_dump(root)
+    assert sum(1 for p, (n, _, _, _) in dump.items() if n > 0) == 51  # root + one new node per simulation
+    for path, (n, vsum, reward, prior) in dump.items():
+        node = root
+        for a in path:
+            node = node.children[a]
+        if node.expanded():
+            assert node.visit_count == 1 + sum(c.visit_count for c in node.children) - (1 if not path else 0)
+    assert stats.minimum <= root.value() <= stats.maximum
+    # value recursion at the root: value_sum accumulates reward + discount * value along each path
+    assert math.isfinite(root.value_sum) and stats.maximum > stats.minimum
+
+
+def test_min_max_normalisation_matches_pseudocode():
+    s = ref.MinMaxStats()
+    assert s.normalize(3.0) == 3.0  # no range yet: value unchanged
+    s.update(1.0)
+    assert s.normalize(3.0) == 3.0  # max == min
+    s.update(5.0)
+    assert s.normalize(3.0) == 0.5 and s.normalize(1.0) == 0.0 and s.normalize(5.0) == 1.0
+
+
+def test_initial_states_and_replay_targets():
+    from rlzero_amd.muzero.cartpole import initial_states
+    from rlzero_amd.muzero.selfplay import Episode, ReplayBuffer
+    a = initial_states(3, np.arange(64), np.zeros(64, dtype=np.int64))
+    b = initial_states(3, np.arange(32, 64), np.zeros(32, dtype=np.int64))
+    assert a.shape == (64, 4) and (a >= -0.05).all() and (a < 0.05).all() and np.array_equal(a[32:], b)
+    assert not np.array_equal(a, initial_states(3, np.arange(64), np.ones(64, dtype=np.int64)))
+    ep = Episode()
+    for t in range(6):
+        ep.obs.append(np.full(4, t, dtype=np.float32))
+        ep.actions.append(t % 2)
+        ep.rewards.append(1.0)
+        ep.policies.append(np.array([0.25, 0.75], dtype=np.float32))
+        ep.root_values.append(float(10 + t))
+    buf = ReplayBuffer(unroll_steps=2, td_steps=3, discount=0.5, seed=0)
+    buf.add(ep)
+    assert buf._value_target(ep, 0) == 1 + 0.5 + 0.25 + 13 * 0.125      # 3 rewards + bootstrap from root value 3
+    assert buf._value_target(ep, 4) == 1 + 0.5                           # runs off the end: no bootstrap
+    obs, actions, tv, tr, tp, mask = buf.sample(16, 2)
+    assert obs.shape == (16, 4) and actions.shape == (16, 2) and tv.shape == tr.shape == mask.shape == (16, 3)
+    for b_ in range(16):
+        t = int(obs[b_, 0])
+        for k in range(3):
+            inside = t + k < 6
+            assert mask[b_, k] == (1.0 if inside else 0.0)
+            assert tv[b_, k] == (np.float32(buf._value_target(ep, t + k)) if inside else 0.0)
+            if k > 0:
+                assert tr[b_, k] == (1.0 if t + k - 1 < 6 else 0.0)
+                if t + k - 1 < 6:
+                    assert actions[b_, k - 1] == (t + k - 1) % 2
+
+
+# ------------------------------------------------------------------ HIP tree kernels vs the oracle
+def _hexf(x):
+    return float(x).hex()
+
+
+@pytest.mark.gpu
+def test_muzero_tree_kernels_bit_exact_vs_pseudocode():
+    import torch
+    from rlzero_amd.muzero import CartPoleBatch, MuZeroNet, MuZeroSelfPlay
+    torch.manual_seed(1)
+    net = MuZeroNet().to('cuda:0').eval()
+    env = CartPoleBatch(48, 'cuda:0', seed=2)
+    sp = MuZeroSelfPlay(net, env, n_sims=50, seed=5)
+    for trial in range(2):
+        record = []
+        visits, root_value = sp.search(env.observe(), add_noise=True, record=record)
+        tree = sp.tree
+        n, vsum, vmin, vmax = (x.cpu().numpy().copy() for x in tree.root_stats())
+        child_sum = tree.root_children('value_sum').cpu().numpy()
+        child_rew = tree.root_children('reward').cpu().numpy()
+        child_pri = tree.root_children('prior').cpu().numpy()
+        visits = visits.cpu().numpy()
+        _, probs0, noise = record[0]
+        sims = [tuple(x.cpu().numpy() for x in r) for r in record[1:]]
+        probs0, noise = probs0.cpu().numpy(), noise.cpu().numpy()
+        cfg = ref.MuZeroConfig(num_simulations=50)
+        for g in range(0, 48, 5):
+            outputs = {}
+            root = ref.Node(0)
+            ref.expand_node(root, None, 0.0, [float(p) for p in probs0[g]])
+            ref.add_exploration_noise(cfg, root, [float(x) for x in noise[g]])
+            step = [0]
+
+            def model(hidden, action, path, g=g, step=step):
+                parent, act, leaf, reward, probs, value = sims[step[0]]
+                assert act[g] == action  # the device took the same edge in the same simulation
+                step[0] += 1
+                return None, float(reward[g]), [float(p) for p in probs[g]], float(value[g])
+
+            stats = ref.run_mcts(cfg, root, model)
+            assert root.visit_count == n[g] == 50 and _hexf(root.value_sum) == _hexf(vsum[g])
+            assert _hexf(stats.minimum) == _hexf(vmin[g]) and _hexf(stats.maximum) == _hexf(vmax[g])
+            for a, child in enumerate(root.children):
+                assert child.visit_count == visits[g, a]
+                assert _hexf(child.value_sum) == _hexf(child_sum[g, a])
+                assert _hexf(child.reward) == _hexf(child_rew[g, a]) and _hexf(child.prior) == _hexf(child_pri[g, a])
+            assert _hexf(root.value()) == _hexf(root_value[g].item())
+        env.step(torch.from_numpy(visits.argmax(axis=1)).to('cuda:0'))
+    # the hipGraph replay of the simulation step (the production path) gives the eager path's trees
+    obs = env.observe()
+    v_graph, rv_graph = sp.search(obs, add_noise=False)
+    v_graph, rv_graph = v_graph.clone(), rv_graph.clone()
+    v_eager, rv_eager = sp.search(obs, add_noise=False, record=[])
+    assert sp._graph is not None and torch.equal(v_graph, v_eager) and torch.equal(rv_graph, rv_eager)
+    sp.tree.check()
+    sp.close()
+
+
+@pytest.mark.gpu
+def test_cartpole_batch_vs_scalar_restatement():
+    import torch
+    from rlzero_amd.muzero.cartpole import CartPoleBatch, initial_states
+    env = CartPoleBatch(32, 'cuda:0', seed=9)
+    init = initial_states(9, np.arange(32), np.zeros(32, dtype=np.int64))
+    assert np.array_equal(env.state.cpu().numpy(), init)
+    refs = [ref.RefCartPole() for _ in range(32)]
+    for r, s in zip(refs, init):
+        r.reset(s)
+    rng = np.random.RandomState(0)
+    alive = np.ones(32, dtype=bool)
+    for t in range(120):
+        actions = rng.randint(2, size=32)
+        before = env.state.cpu().numpy().copy()
+        obs, reward, terminated, truncated = env.step(torch.from_numpy(actions).to('cuda:0'))
+        terminated = terminated.cpu().numpy()
+        for i in range(32):
+            if not alive[i]:
+                continue
+            state, rew, term, trunc = refs[i].step(int(actions[i]))
+            assert term == bool(terminated[i])
+            if term:
+                alive[i] = False  # the batch auto-resets; the scalar twin stops here
+                assert np.array_equal(env.state[i].cpu().numpy(), initial_states(9, [i], [1])[0])
+            else:
+                assert np.max(np.abs(env.state[i].cpu().numpy() - np.array(state))) < 1e-9
+        assert (reward.cpu().numpy() == 1.0).all() and before.shape == (32, 4)
+    assert (~alive).sum() > 10  # random play drops the pole quickly
+
+
+@pytest.mark.gpu
+def test_muzero_selfplay_and_learner_smoke():
+    import torch
+    from rlzero_amd.muzero import CartPoleBatch, MuZeroAgent, MuZeroSelfPlay, ReplayBuffer
+    torch.manual_seed(0)
+    agent = MuZeroAgent(device='cuda:0')
+    env = CartPoleBatch(64, 'cuda:0', seed=1)
+    sp = MuZeroSelfPlay(agent.net, env, n_sims=20, seed=3)
+    buf = ReplayBuffer(unroll_steps=5, td_steps=10, seed=0)
+    for ep in sp.collect(40):
+        buf.add(ep)
+    assert len(buf) > 20 and sp.sims_done == 64 * 40 * 20
+    lengths = [len(ep) for ep in buf.episodes]
+    assert min(lengths) >= 7 and max(lengths) <= 500
+    first = None
+    for it in range(30):
+        loss, lv, lr_, lp = agent.learn(buf.sample(128, 2))
+        assert math.isfinite(loss)
+        first = first if first is not None else loss
+    assert loss < first  # the model fits its own replay data
+    sp.close()

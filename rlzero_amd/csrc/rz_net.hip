@@ -382,9 +382,23 @@ __device__ __forceinline__ int wino_row(int h, int nt, int lane, int a) {
 
 // Y[m][nt][a*2+b] = conv output (no bias) of output-channel tile tile0+m at board rows
 // wino_row(h, nt, lane, a), columns 2*(lane & 7) + b, for the lane's 4 channels.
+// The first three U groups of a convolution, fetched EARLY (before the barrier that publishes the
+// layer's input planes): the weight stream does not depend on the activations.
+template <int CIN, int TM>
+__device__ __forceinline__ void wino_preload_u(const f32x4 *__restrict__ up, int tile0, int lane, f32x4 (&a)[4][TM]) {
+    constexpr int kT = CIN, kUStride = kT * 64 * 16;  // kT = 4 * (CIN / 4)
+    const __amdgpu_buffer_rsrc_t u_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(up), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+            a[g][m] = load_u(u_rsrc, lane * 16, tile0 * kT * 64 * 16 + m * kUStride + g * (64 * 16));
+}
+
 template <int PL, int CIN, int TM>
 __device__ __forceinline__ void wino_conv(const float *__restrict__ in, const f32x4 *__restrict__ up, int tile0,
-                                          int h, int lane, f32x4 (&Y)[TM][2][4]) {
+                                          int h, int lane, f32x4 (&a)[4][TM], f32x4 (&Y)[TM][2][4]) {
     constexpr int kSteps = CIN / 4, kT = 4 * kSteps;
     const int kq = lane >> 4, ty = (lane >> 3) & 1, tx = lane & 7;
     // top-left of the 4x4 patch of N-tile 0 in halo coordinates: row 2*(2h + 4ty), column 2tx
@@ -394,15 +408,8 @@ __device__ __forceinline__ void wino_conv(const float *__restrict__ in, const f3
         __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(up), 0, 0x7fffffff, 0x00020000);
     const int ubase = tile0 * kT * 64 * 16;  // byte offset of the wave's first tile stream
     const int u_lane = lane * 16;
-    constexpr int kUStride = kT * 64 * 16;
-    f32x4 a[4][TM];
     float d[2][2][4], vb[2][2][4], t[2][4];
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int m = 0; m < TM; ++m)
-            a[g][m] = load_u(u_rsrc, u_lane, ubase + m * kUStride + g * (64 * 16));
-    // pipeline prologue: group 0 transformed, patch rows of group 1 in flight
+    // pipeline prologue (`a` already holds the U fragments of groups 0..2: wino_preload_u): group 0 transformed, patch rows of group 1 in flight
 #pragma unroll
     for (int o = 0; o < 8; ++o) wino_ld_op<0>(d, base, o);
 #pragma unroll
@@ -490,6 +497,10 @@ __global__ __launch_bounds__(128 * CG) void k_trunk_wino(NetDev nd, const float 
         load_obs(blockIdx.x, tid0);
         store_obs(tid0);
     }
+    __syncthreads();  // the first board's input planes are staged
+    // Barriers per board: after conv1, after conv2 (which also publishes the NEXT board's input planes) and
+    // after conv3; none at the top of the loop -- every buffer a board writes was last read before one of the
+    // previous board's barriers.
     for (int board = blockIdx.x; board < n_boards; board += gridDim.x) {
     // The thread id is laundered per board so that no lane-dependent address is hoisted out of the
     // board loop and kept live across it (that costs ~50 spilled VGPRs).
@@ -498,7 +509,8 @@ __global__ __launch_bounds__(128 * CG) void k_trunk_wino(NetDev nd, const float 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cg = wave % CG, h = wave / CG;
     const int next_board = board + (int)gridDim.x;
-    __syncthreads();  // the input planes are staged (and the previous board's epilogue is done)
+    f32x4 a2[4][TM2];
+    wino_preload_u<32, TM2>(nd.u2, TM2 * cg, lane, a2);  // lands while conv1 runs
     {   // conv1: 4 -> 32 direct (1 % of the work): 2 tiles x (2 or 4) row groups over all waves
         constexpr int kRowsPer = (CG == 4) ? 4 : 8;
         const int tile = cg & 1;
@@ -514,9 +526,11 @@ __global__ __launch_bounds__(128 * CG) void k_trunk_wino(NetDev nd, const float 
     __syncthreads();
     if (next_board < n_boards) load_obs(next_board, tid);
     const int q = lane >> 4, tx = lane & 7;
+    f32x4 a3[4][TM3];
     {   // conv2: 32 -> 64
         f32x4 Y[TM2][2][4];
-        wino_conv<PL, 32, TM2>(c1, nd.u2, TM2 * cg, h, lane, Y);
+        wino_conv<PL, 32, TM2>(c1, nd.u2, TM2 * cg, h, lane, a2, Y);
+        wino_preload_u<64, TM3>(nd.u3, TM3 * cg, lane, a3);  // lands under the store below and the barrier
 #pragma unroll
         for (int m = 0; m < TM2; ++m) {
             const int c0 = (TM2 * cg + m) * 16 + 4 * q;
@@ -543,7 +557,7 @@ __global__ __launch_bounds__(128 * CG) void k_trunk_wino(NetDev nd, const float 
         for (int i = 0; i < 48; ++i) vals[i] = 0.0f;
         {
             f32x4 Y[TM3][2][4];
-            wino_conv<PL, 64, TM3>(c2, nd.u3, TM3 * cg, h, lane, Y);
+            wino_conv<PL, 64, TM3>(c2, nd.u3, TM3 * cg, h, lane, a3, Y);
 #pragma unroll
             for (int m = 0; m < TM3; ++m) {
                 const int c0 = (TM3 * cg + m) * 16 + 4 * q;

@@ -258,11 +258,13 @@ __device__ __forceinline__ void wino_block(f32x4 (&acc)[TM][2][4], const f32x4 (
             const int j = i - NS / 2;  // 0 .. LD_SLOTS-1
             if (DO_LD) {
                 // 8 reads over LD_SLOTS slots
+                constexpr int kEvery = LD_SLOTS >= 8 ? LD_SLOTS / 8 : 1;
                 if (LD_SLOTS >= 8) {
-                    if ((j % (LD_SLOTS / 8)) == 0) wino_ld_op<LIP>(d, q_ld, j / (LD_SLOTS / 8));
+                    if ((j % kEvery) == 0) wino_ld_op<LIP>(d, q_ld, j / kEvery);
                 } else {
+                    constexpr int kPer = LD_SLOTS < 8 ? 8 / LD_SLOTS : 1;
 #pragma unroll
-                    for (int k = 0; k < 8 / LD_SLOTS; ++k) wino_ld_op<LIP>(d, q_ld, j * (8 / LD_SLOTS) + k);
+                    for (int k = 0; k < kPer; ++k) wino_ld_op<LIP>(d, q_ld, j * kPer + k);
                 }
             }
             if (DO_U && j < TM)

@@ -35,5 +35,6 @@ done
 python3 "$ROOT/bench.py" --no-cpu-baseline --lanes 1 --board 3 --playouts 25 --games 1 > "$OUT/bench_c1_ttt.json" 2> /dev/null
 python3 "$ROOT/bench.py" --no-cpu-baseline --lanes 1 --board 9 --playouts 200 --games 64 > "$OUT/bench_c2_9x9.json" 2> /dev/null
 python3 "$ROOT/bench.py" --no-cpu-baseline --lanes 1 --game connect4 --playouts 400 --games 512 > "$OUT/bench_c3_connect4.json" 2> /dev/null
+python3 "$ROOT/bench.py" --game muzero --steps 8 --warmup 2 > "$OUT/bench_c5_muzero_cartpole.json" 2> /dev/null
 
 cd "$ROOT" && python3 profiles/summarise.py "$OUT"

@@ -37,7 +37,7 @@ def main(out):
     os.makedirs(keep, exist_ok=True)
     for name in ('bench_default.json', 'bench_1lane_512games.json', 'bench_under_rocprof.json',
                  'bench_eager_under_rocprof.json', 'bench_eager_1lane_under_rocprof.json',
-                 'bench_c1_ttt.json', 'bench_c2_9x9.json', 'bench_c3_connect4.json'):
+                 'bench_c1_ttt.json', 'bench_c2_9x9.json', 'bench_c3_connect4.json', 'bench_c5_muzero_cartpole.json'):
         src = os.path.join(out, name)
         if os.path.exists(src) and os.path.getsize(src):
             shutil.copy(src, os.path.join(keep, name))

@@ -95,6 +95,10 @@ class CartPoleBatch(object):
         reward = t.ones(self.n_envs, dtype=t.float32, device=self.device)
         done = (terminated | truncated).cpu().numpy()
         if done.any():
-            self.episode[done] += 1
-            self.set_states(initial_states(self.seed, np.arange(self.n_envs), self.episode), mask=done)
+            idx = np.nonzero(done)[0]
+            self.episode[idx] += 1
+            new = t.from_numpy(initial_states(self.seed, idx, self.episode[idx])).to(self.device)
+            where = t.from_numpy(idx).to(self.device)
+            self.state[where] = new
+            self.steps[where] = 0
         return self.observe(), reward, terminated, truncated

@@ -93,7 +93,11 @@ class MuZeroSelfPlay(object):
         self.rows = torch.arange(self.n_envs, device=self.device)
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(int(seed))
-        self.running = [Episode() for _ in range(self.n_envs)]
+        # step history as per-step arrays over all environments; an episode is cut out of it when it ends
+        self._hist = []                                       # [(obs, action, reward, policy, root value)]
+        self._hist_t0 = 0                                     # global step index of _hist[0]
+        self._t = 0                                           # global step index of the next move
+        self._ep_start = np.zeros(self.n_envs, dtype=np.int64)
         self.sims_done = 0
         self.moves_done = 0
         self.obs = env.observe()
@@ -177,24 +181,27 @@ class MuZeroSelfPlay(object):
         visits, root_value = self.search(obs)
         actions = self.select_actions(visits)
         nxt_obs, reward, terminated, truncated = self.env.step(actions)
-        obs_h = obs.cpu().numpy()
-        act_h = actions.cpu().numpy()
-        rew_h = reward.cpu().numpy()
         vis_h = visits.cpu().numpy().astype(np.float64)
-        val_h = root_value.cpu().numpy()
         done_h = (terminated | truncated).cpu().numpy()
-        pol_h = vis_h / vis_h.sum(axis=1, keepdims=True)
+        self._hist.append((obs.cpu().numpy(), actions.cpu().numpy(), reward.cpu().numpy(),
+                           (vis_h / vis_h.sum(axis=1, keepdims=True)).astype(np.float32), root_value.cpu().numpy()))
+        self._t += 1
         finished = []
-        for i in range(self.n_envs):
-            ep = self.running[i]
-            ep.obs.append(obs_h[i])
-            ep.actions.append(int(act_h[i]))
-            ep.rewards.append(float(rew_h[i]))
-            ep.policies.append(pol_h[i].astype(np.float32))
-            ep.root_values.append(float(val_h[i]))
-            if done_h[i]:
-                finished.append(ep)
-                self.running[i] = Episode()
+        for i in np.nonzero(done_h)[0]:
+            ep = Episode()
+            for t_ in range(int(self._ep_start[i]) - self._hist_t0, self._t - self._hist_t0):
+                o, a_, r, p_, v = self._hist[t_]
+                ep.obs.append(o[i])
+                ep.actions.append(int(a_[i]))
+                ep.rewards.append(float(r[i]))
+                ep.policies.append(p_[i])
+                ep.root_values.append(float(v[i]))
+            finished.append(ep)
+            self._ep_start[i] = self._t
+        drop = int(self._ep_start.min()) - self._hist_t0  # steps no running episode refers to any more
+        if drop > 0:
+            del self._hist[:drop]
+            self._hist_t0 += drop
         self.obs = nxt_obs
         self.moves_done += self.n_envs
         return finished

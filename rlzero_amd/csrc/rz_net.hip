@@ -1105,8 +1105,8 @@ static int launch_heads(rz_net *net, const float *d_feat, int32_t n_boards, floa
 int rz_net_trunk(rz_net *net, const float *d_obs, int32_t n_boards, float *d_feat, void *stream) {
     int rc = net_ready(net, n_boards);
     if (rc != RZ_OK) return rc;
+    if (n_boards == 0) return RZ_OK;  // an empty batch is a no-op (its tensors have no storage)
     if (!d_obs) return net_fail(RZ_ERR_ARG, "NULL device pointer");
-    if (n_boards == 0) return RZ_OK;
     if (!d_feat) {  // internal feature buffer (the input of rz_net_heads)
         if (n_boards > net->feat_boards) return net_fail(RZ_ERR_ARG, "batch larger than rz_net_reserve()d");
         d_feat = net->d_feat;
@@ -1154,8 +1154,8 @@ int rz_net_heads_gemm(rz_net *net, int32_t n_boards, const float **d_raw, int32_
 int rz_net_heads(rz_net *net, int32_t n_boards, float *d_logp, float *d_value, void *stream) {
     int rc = net_ready(net, n_boards);
     if (rc != RZ_OK) return rc;
-    if (!d_logp || !d_value) return net_fail(RZ_ERR_ARG, "NULL device pointer");
     if (n_boards == 0) return RZ_OK;
+    if (!d_logp || !d_value) return net_fail(RZ_ERR_ARG, "NULL device pointer");
     if (n_boards > net->feat_boards) return net_fail(RZ_ERR_ARG, "batch larger than rz_net_reserve()d");
     return launch_heads(net, net->d_feat, n_boards, d_logp, d_value, stream);
 }
@@ -1163,8 +1163,8 @@ int rz_net_heads(rz_net *net, int32_t n_boards, float *d_logp, float *d_value, v
 int rz_net_forward(rz_net *net, const float *d_obs, int32_t n_boards, float *d_logp, float *d_value, void *stream) {
     int rc = net_ready(net, n_boards);
     if (rc != RZ_OK) return rc;
-    if (!d_obs || !d_logp || !d_value) return net_fail(RZ_ERR_ARG, "NULL device pointer");
     if (n_boards == 0) return RZ_OK;
+    if (!d_obs || !d_logp || !d_value) return net_fail(RZ_ERR_ARG, "NULL device pointer");
     if (n_boards > net->feat_boards)
         return net_fail(RZ_ERR_ARG, "batch larger than rz_net_reserve()d (no allocation on the launch path)");
     launch_trunk(net, d_obs, net->d_feat, n_boards, stream);

@@ -187,6 +187,61 @@ def test_search_batch_of_positions_vs_oracle():
     eng.close()
 
 
+def test_edge_cases_max_board_single_game_near_full_board_empty_batch():
+    """Edges of the domain: the largest board the ABI admits (16x16, 4 bitboard words all in use), one game
+    per engine, a board with a single empty cell (every simulation ends in a terminal leaf or the last
+    move), a search longer than a child vector's first capacities (growth 4 -> 8 -> ... -> K), and the
+    evaluator on an empty batch."""
+    import torch
+    from rlzero_amd.engine import HipNet, SyntheticEvaluator
+    # 16 x 16, n = 5, one game: 600 simulations from the empty board visit all 256 children (vector grown to K)
+    eng = _engine(16, 5, n_games=1, n_playout=600)
+    eng.reset_games()
+    eng.simulate(SyntheticEvaluator('vlin'), 600)
+    eng.check()
+    s = RefSearch(ev.vlin, 600, 5)
+    s.simulate(RefGomoku(16, 5), 1.0)
+    assert _hex_tree(eng.tree_dump(0)) == _hex_tree(tree_dump(s.root))
+    assert int(eng.root_visits()[0].sum()) == 599 and (eng.root_visits()[0] > 0).all()  # N(root) = 1 + sum
+    eng.close()
+    # a 6x6 board (n = 4) filled without a winner except for the last 1 / 2 cells: colour = (column pair + row)
+    # parity gives runs of at most 2 in every direction
+    cells = [r * 6 + c for r in range(6) for c in range(6)]
+    a_cells = [c for c in cells if ((c % 6) // 2 + c // 6) % 2 == 0]
+    b_cells = [c for c in cells if ((c % 6) // 2 + c // 6) % 2 == 1]
+    for keep in (1, 2):
+        seq = []
+        for x, y in zip(a_cells, b_cells):
+            seq += [x, y]
+        seq = seq[:36 - keep]
+        env = RefGomoku.from_moves(6, 4, seq)
+        assert not env.game_end_winner()[0] and len(env.leagel_actions()) == keep
+        eng = _engine(6, 4, n_games=2, n_playout=40)
+        _set_roots(eng, [env, env], reset_trees=True)
+        eng.simulate(SyntheticEvaluator('vlin'), 40)
+        eng.check()
+        ref = RefSearch(ev.vlin, 40, 5)
+        ref.simulate(env, 1.0)
+        for g in (0, 1):
+            assert _hex_tree(eng.tree_dump(g)) == _hex_tree(tree_dump(ref.root))
+        eng.close()
+    # evaluator: empty batch is a no-op, a 1-board batch and a ragged 33-board batch agree row by row
+    torch.manual_seed(4)
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    net = PolicyValueNet(16)
+    hip = HipNet(16, 'cuda:0', max_boards=64).load_state_dict(net.state_dict())
+    x = (torch.rand((33, 4, 16, 16), device='cuda:0') > 0.5).float()
+    lp0, v0 = hip.forward(x[:0])
+    assert lp0.shape[0] == 0 and v0.shape[0] == 0
+    lp, v = hip.forward(x)
+    lp1, v1 = hip.forward(x[7:8])
+    assert torch.equal(lp1[0], lp[7]) and torch.equal(v1[0], v[7])
+    with torch.no_grad():
+        want_lp, want_v = net(x.cpu())
+    assert float((lp.cpu() - want_lp).abs().max()) <= 1e-4 and float((v.cpu() - want_v[:, 0]).abs().max()) <= 1e-4
+    hip.close()
+
+
 def test_full_size_known_answer_and_invariants():
     """15x15, 800 sims (the metric's configuration): SURVEY.md Appendix B KAT 6 + the
     size-independent invariants N(root) = n_playout, N(node) = 1 + sum N(children),

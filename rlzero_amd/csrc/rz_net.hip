@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "rlzero_hip.h"
@@ -46,6 +47,7 @@ constexpr int kTrunkThreads = 512;
 struct NetDev {
     const f32x4 *w1, *w2, *w3;   // packed [tile][cin_step][3][64 lanes] x 4 taps
     const f32x4 *u2, *u3;        // Winograd-domain weights of conv2 / conv3: [tile][i'][cin_step][64 lanes] x 4 j'
+    const f32x4 *u2f, *u3f;      // F(4x4,3x3): [tile][pass][cin_step][3][64 lanes] x 4 components (pack_wino_f4)
     const float *b1, *b2, *b3;   // conv biases
     const float *wh;             // [6][128]: act_conv1 (4 rows) then val_conv1 (2 rows)
     const float *bh;             // [6]
@@ -484,15 +486,30 @@ __global__ __launch_bounds__(128 * CG) void k_trunk_wino(NetDev nd, const float 
             ob[k] = i < 4 * S ? src[i] : 0.0f;
         }
     };
-    auto store_obs = [&](int tid) {
+    // element tid + k*kThreads of a board's observation planes / head features -> where it lives in LDS /
+    // in the feature row: the same for every board, so the integer divisions are done once per thread
+    int obs_off[kObsPer];
 #pragma unroll
-        for (int k = 0; k < kObsPer; ++k) {
-            const int i = tid + k * kThreads;
-            if (i < 4 * S) {
-                const int c = i / S, r = i - c * S, y = r / BW, x = r - y * BW;
-                in0[c * PL + (y + 1) * kRowW + (x + 1)] = ob[k];
-            }
-        }
+    for (int k = 0; k < kObsPer; ++k) {
+        const int i = tid0 + k * kThreads;
+        const int c = i / S, r = i - c * S, y = r / BW, x = r - y * BW;
+        obs_off[k] = i < 4 * S ? c * PL + (y + 1) * kRowW + (x + 1) : -1;
+    }
+    constexpr int kFeatPer = (6 * RZ_MAX_BOARD_SIZE * RZ_MAX_BOARD_SIZE + kThreads - 1) / kThreads;
+    int feat_src[kFeatPer], feat_dst[kFeatPer];
+    float feat_bias[kFeatPer];
+#pragma unroll
+    for (int k = 0; k < kFeatPer; ++k) {
+        const int i = tid0 + k * kThreads;
+        const int o = i / S, r = i - o * S, y = r / BW, x = r - y * BW;
+        feat_src[k] = (o * 16 + y) * 16 + x;
+        feat_dst[k] = i < 6 * S ? (i < 4 * S ? i : i - 4 * S + nd.feat_val_off) : -1;
+        feat_bias[k] = i < 6 * S ? nd.bh[o] : 0.0f;
+    }
+    auto store_obs = [&](int) {
+#pragma unroll
+        for (int k = 0; k < kObsPer; ++k)
+            if (obs_off[k] >= 0) in0[obs_off[k]] = ob[k];
     };
     __syncthreads();  // the zero fill is complete before the staging writes
     if ((int)blockIdx.x < n_boards) {
@@ -590,12 +607,443 @@ __global__ __launch_bounds__(128 * CG) void k_trunk_wino(NetDev nd, const float 
     __syncthreads();
     {
         float *dst = feat + (size_t)board * nd.feat_ld;
-        for (int i = tid; i < 6 * S; i += kThreads) {
-            const int o = i / S, r = i - o * S, y = r / BW, x = r - y * BW;
-            float v = nd.bh[o];
 #pragma unroll
-            for (int k = 0; k < CG; ++k) v += partial[((k * 6 + o) * 16 + y) * 16 + x];
-            dst[i < 4 * S ? i : i - 4 * S + nd.feat_val_off] = fmaxf(v, 0.0f);
+        for (int k = 0; k < kFeatPer; ++k) {
+            if (feat_dst[k] < 0) continue;
+            float v = feat_bias[k];
+#pragma unroll
+            for (int g = 0; g < CG; ++g) v += partial[g * 6 * 256 + feat_src[k]];
+            dst[feat_dst[k]] = fmaxf(v, 0.0f);
+        }
+    }
+    }  // boards
+}
+
+// =====================================================================================================
+// Winograd F(4x4,3x3) trunk (RZ_NET_WINOGRAD_F4): 36 element-wise products per 4x4 output tile instead of
+// 144 multiply-adds -- 4x fewer MFMAs than the direct form, 1.78x fewer than F(2x2,3x3).  fp32
+// throughout; the larger transform constants cost about one decimal digit (|error| ~1e-6 on the conv3
+// activations against fp64, ~5e-7 on the log-probabilities: tests/test_gpu_parity.py).
+//   * the MFMA N dimension is the WHOLE board: 16 tiles of 4x4 outputs (lane & 15 = 4*ty + tx); K = input
+//     channels (4 per step, lane >> 4); M = 16 output channels;
+//   * 4 waves per workgroup, one per SIMD (up to 512 registers): a wave owns TM output-channel tiles (conv3: 2,
+//     conv2: 1) and ALL 36 components, taken in 3 passes over the channel groups, two transform rows (12
+//     components) per pass -- {1,2}, {3,4}, {0,5} -- so 12*TM accumulators are live, and each pass folds
+//     its rows into the 4x4 outputs (the output transform A^T M A is linear in M);
+//   * per channel group a lane reads its 6x6 input patch rows from the halo planes (4 rows for the
+//     first two passes, 6 for the last), forms the 12 transformed values (row stage then column stage,
+//     52..64 fused multiply-adds) and issues 12*TM MFMAs against U fragments streamed from L2 with buffer
+//     loads; the software pipeline of wino_block is kept: the transform of group g+1, the LDS reads of
+//     g+2 and the U loads of g+3 are threaded between the MFMAs of group g.
+namespace f4 {
+
+// Everything below is indexed by template parameters and expanded with fold expressions (not loops the
+// unroller may decline to unroll: the op lists are long), so every register-array index is a constant.
+
+template <int P> struct Pass {  // pass P handles transform rows i' = a, b
+    static constexpr int a = (P == 0) ? 1 : (P == 1) ? 3 : 0;
+    static constexpr int b = (P == 0) ? 2 : (P == 1) ? 4 : 5;
+    static constexpr int first = (P == 2) ? 0 : 1;   // patch rows it reads: 1..4, or all six for rows 0 / 5
+    static constexpr int count = (P == 2) ? 6 : 4;
+    static constexpr int n_ld = 3 * count;           // ds_read2 per group
+    static constexpr int row_ops = (P == 0) ? 6 : 4; // row-stage instructions per patch column
+    static constexpr int n_xf = 6 * row_ops + 28;    // transform instructions per group
+};
+
+// LDS read O of a group of pass P: patch row first + O / 3, column pair O % 3
+template <int P, int O>
+__device__ __forceinline__ void ld_op(float (&d)[6][6], lds_cptr q) {
+    constexpr int row = Pass<P>::first + O / 3, c = 2 * (O % 3);
+    d[row][c] = q[row * kRowW + c];
+    d[row][c + 1] = q[row * kRowW + c + 1];
+}
+
+// Transform instruction O of a group of pass P, every case ONE add / fused multiply-add.  Row stage
+// (t = rows a, b of B^T d, column by column), then the column stage of the two rows (v = t B),
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1].
+template <int P, int O>
+__device__ __forceinline__ void xf_op(const float (&d)[6][6], float (&w)[4], float (&t)[2][6], float (&u)[8],
+                                      float (&v)[2][6]) {
+    constexpr int kRowOps = Pass<P>::row_ops;
+    if constexpr (O < 6 * kRowOps) {
+        constexpr int c = O / kRowOps, k = O % kRowOps;
+        if constexpr (P == 0) {  // rows 1, 2: -4 (d1 + d2) + (d3 + d4) ; 4 (d1 - d2) - (d3 - d4)
+            if constexpr (k == 0) w[0] = d[1][c] + d[2][c];
+            else if constexpr (k == 1) w[1] = d[3][c] + d[4][c];
+            else if constexpr (k == 2) w[2] = d[1][c] - d[2][c];
+            else if constexpr (k == 3) w[3] = d[3][c] - d[4][c];
+            else if constexpr (k == 4) t[0][c] = fmaf(-4.0f, w[0], w[1]);
+            else t[1][c] = fmaf(4.0f, w[2], -w[3]);
+        } else if constexpr (P == 1) {  // rows 3, 4: +-2 (d3 - d1) + (d4 - d2)
+            if constexpr (k == 0) w[0] = d[3][c] - d[1][c];
+            else if constexpr (k == 1) w[1] = d[4][c] - d[2][c];
+            else if constexpr (k == 2) t[0][c] = fmaf(2.0f, w[0], w[1]);
+            else t[1][c] = fmaf(-2.0f, w[0], w[1]);
+        } else {  // rows 0, 5: 4 d0 - 5 d2 + d4 ; 4 d1 - 5 d3 + d5
+            if constexpr (k == 0) w[0] = fmaf(-5.0f, d[2][c], d[4][c]);
+            else if constexpr (k == 1) t[0][c] = fmaf(4.0f, d[0][c], w[0]);
+            else if constexpr (k == 2) w[1] = fmaf(-5.0f, d[3][c], d[5][c]);
+            else t[1][c] = fmaf(4.0f, d[1][c], w[1]);
+        }
+    } else {
+        constexpr int oc = O - 6 * kRowOps, rr = oc / 14, k = oc % 14;
+        const float (&x)[6] = t[rr];
+        if constexpr (k == 0) u[0] = x[1] + x[2];
+        else if constexpr (k == 1) u[1] = x[3] + x[4];
+        else if constexpr (k == 2) u[2] = x[1] - x[2];
+        else if constexpr (k == 3) u[3] = x[3] - x[4];
+        else if constexpr (k == 4) v[rr][1] = fmaf(-4.0f, u[0], u[1]);
+        else if constexpr (k == 5) v[rr][2] = fmaf(4.0f, u[2], -u[3]);
+        else if constexpr (k == 6) u[4] = x[3] - x[1];
+        else if constexpr (k == 7) u[5] = x[4] - x[2];
+        else if constexpr (k == 8) v[rr][3] = fmaf(2.0f, u[4], u[5]);
+        else if constexpr (k == 9) v[rr][4] = fmaf(-2.0f, u[4], u[5]);
+        else if constexpr (k == 10) u[6] = fmaf(-5.0f, x[2], x[4]);
+        else if constexpr (k == 11) v[rr][0] = fmaf(4.0f, x[0], u[6]);
+        else if constexpr (k == 12) u[7] = fmaf(-5.0f, x[3], x[5]);
+        else v[rr][5] = fmaf(4.0f, x[1], u[7]);
+    }
+}
+template <int P, int BASE, int... Os>
+__device__ __forceinline__ void xf_ops(std::integer_sequence<int, Os...>, const float (&d)[6][6], float (&w)[4],
+                                       float (&t)[2][6], float (&u)[8], float (&v)[2][6]) {
+    (xf_op<P, BASE + Os>(d, w, t, u, v), ...);
+}
+template <int P, int BASE, int... Os>
+__device__ __forceinline__ void ld_ops(std::integer_sequence<int, Os...>, float (&d)[6][6], lds_cptr q) {
+    (ld_op<P, BASE + Os>(d, q), ...);
+}
+
+// Slot I of the MFMA block of one channel group: MFMA I (component k = I / TM = rr*6 + j', tile m = I % TM) and its
+// slice of the next groups' work: first two thirds of the slots = transform of the next group (pass XP) into
+// v_nxt, last third = LDS reads of the group after it (pass LP) into d and the U loads two groups ahead.
+template <int TM, int XP, int LP, int I>
+__device__ __forceinline__ void slot(f32x4 (&acc)[TM][12], const f32x4 (&a_cur)[TM][3], const float (&v_cur)[2][6],
+                                     float (&v_nxt)[2][6], float (&d)[6][6], float (&w)[4], float (&t)[2][6],
+                                     float (&u)[8], lds_cptr q_ld, f32x4 (&a_ld)[TM][3], __amdgpu_buffer_rsrc_t u_rsrc,
+                                     int u_off, int u_lane, int u_stride) {
+    constexpr int NS = 12 * TM, XF_SLOTS = 2 * NS / 3, LD_SLOTS = NS / 3;
+    constexpr int kXf = Pass<XP>::n_xf, kLd = Pass<LP>::n_ld;
+    constexpr int XF_PER = (kXf + XF_SLOTS - 1) / XF_SLOTS, LD_PER = (kLd + LD_SLOTS - 1) / LD_SLOTS;
+    constexpr int k = I / TM, m = I % TM;
+    // In-place accumulation on accumulation registers, written as inline assembly: with more than 256
+    // registers per wave the compiler otherwise stages every accumulator through a[0:3] and copies it to
+    // and from ordinary registers around each MFMA (8 extra instructions per MFMA).  No hazard handling is
+    // lost: consecutive MFMAs use different accumulators (the same one recurs 12*TM MFMAs later) and the
+    // operands were produced at least a third of a block earlier; the fold waits explicitly.
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0"
+                 : "+a"(acc[m][k])
+                 : "v"(a_cur[m][k >> 2][k & 3]), "v"(v_cur[k / 6][k % 6]));
+    if constexpr (I < XF_SLOTS) {
+        constexpr int lo = I * XF_PER, hi = (lo + XF_PER < kXf) ? lo + XF_PER : kXf;
+        if constexpr (hi > lo) xf_ops<XP, lo>(std::make_integer_sequence<int, hi - lo>{}, d, w, t, u, v_nxt);
+    } else {
+        constexpr int j = I - XF_SLOTS;
+        constexpr int lo = j * LD_PER, hi = (lo + LD_PER < kLd) ? lo + LD_PER : kLd;
+        if constexpr (hi > lo) ld_ops<LP, lo>(std::make_integer_sequence<int, hi - lo>{}, d, q_ld);
+        if constexpr (j < 3) {
+#pragma unroll
+            for (int m2 = 0; m2 < TM; ++m2) a_ld[m2][j] = load_u(u_rsrc, u_lane, u_off + m2 * u_stride + j * 1024);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int TM, int XP, int LP, int... Is>
+__device__ __forceinline__ void block(std::integer_sequence<int, Is...>, f32x4 (&acc)[TM][12], const f32x4 (&a_cur)[TM][3],
+                                      const float (&v_cur)[2][6], float (&v_nxt)[2][6], float (&d)[6][6], lds_cptr q_ld,
+                                      f32x4 (&a_ld)[TM][3], __amdgpu_buffer_rsrc_t u_rsrc, int u_off, int u_lane,
+                                      int u_stride) {
+    float w[4], t[2][6], u[8];
+    (slot<TM, XP, LP, Is>(acc, a_cur, v_cur, v_nxt, d, w, t, u, q_ld, a_ld, u_rsrc, u_off, u_lane, u_stride), ...);
+}
+
+// output transform of one transform row: w[q] = sum_j' A^T[q][j'] M[j'],  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0;
+// 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+__device__ __forceinline__ void out_row(const f32x4 *M, f32x4 (&w)[4]) {
+    const f32x4 s12 = M[1] + M[2], d12 = M[1] - M[2], s34 = M[3] + M[4], d34 = M[3] - M[4];
+    w[0] = M[0] + s12 + s34;
+    w[1] = d12 + 2.0f * d34;
+    w[2] = s12 + 4.0f * s34;
+    w[3] = d12 + 8.0f * d34 + M[5];
+}
+
+template <int CIN, int TM>
+__device__ __forceinline__ void preload_u(const f32x4 *__restrict__ up, int tile0, int lane, f32x4 (&a)[4][TM][3]) {
+    constexpr int kSteps = CIN / 4, kG = 3 * 1024, kUStride = 3 * kSteps * kG;
+    const __amdgpu_buffer_rsrc_t u_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(up), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                a[g][m][j] = load_u(u_rsrc, lane * 16, tile0 * kUStride + m * kUStride + g * kG + j * 1024);
+}
+
+// One pass (transform rows Pass<P>::a, b) over the kSteps channel groups.  Linear group index g = P*kSteps + s;
+// block g multiplies group g, transforms g+1, reads the patch of g+2 and loads the U fragments of g+2 -- at the end
+// of the pass those belong to pass P+1 (after the last pass the indices are clamped: fetched again, unused).
+template <int PL, int CIN, int TM, int P>
+__device__ __forceinline__ void pass(lds_cptr base, __amdgpu_buffer_rsrc_t u_rsrc, int ubase, int u_lane,
+                                     f32x4 (&a)[4][TM][3], float (&d)[6][6], float (&vb)[2][2][6], f32x4 (&Y)[TM][16]) {
+    constexpr int kSteps = CIN / 4, kGroups = 3 * kSteps, kG = 3 * 1024, kUStride = 3 * kSteps * kG;
+    constexpr int NP = P < 2 ? P + 1 : 2;
+    constexpr auto seq = std::make_integer_sequence<int, 12 * TM>{};
+    f32x4 acc[TM][12];
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) acc[m][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the compiler cannot see that the assembly below is an MFMA reading these registers as its C operand:
+    // ALL clearing writes are forced to precede this point (every accumulator is an operand) and the required
+    // distance to the first MFMA is kept by hand
+    if constexpr (TM == 1) asm volatile("s_nop 15" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[0][4]), "+a"(acc[0][5]), "+a"(acc[0][6]), "+a"(acc[0][7]), "+a"(acc[0][8]), "+a"(acc[0][9]), "+a"(acc[0][10]), "+a"(acc[0][11]));
+    else asm volatile("s_nop 15" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[0][4]), "+a"(acc[0][5]), "+a"(acc[0][6]), "+a"(acc[0][7]), "+a"(acc[0][8]), "+a"(acc[0][9]), "+a"(acc[0][10]), "+a"(acc[0][11]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[1][3]), "+a"(acc[1][4]), "+a"(acc[1][5]), "+a"(acc[1][6]), "+a"(acc[1][7]), "+a"(acc[1][8]), "+a"(acc[1][9]), "+a"(acc[1][10]), "+a"(acc[1][11]));
+    auto patch = [&](int g2) {  // LDS base of group g2's patch, opaque so that the reads use immediate offsets
+        lds_cptr q = base + (4 * (g2 % kSteps)) * PL;
+        asm volatile("" : "+v"(q));
+        return q;
+    };
+#pragma unroll 1
+    for (int s0 = 0; s0 < kSteps - 4; s0 += 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int g2 = P * kSteps + s0 + r + 2;
+            block<TM, P, P>(seq, acc, a[r], vb[r & 1], vb[(r + 1) & 1], d, patch(g2), a[(r + 2) & 3], u_rsrc, ubase + g2 * kG,
+                            u_lane, kUStride);
+        }
+    }
+    {   // last four groups of the pass
+        constexpr int g0 = P * kSteps + kSteps - 4;
+        constexpr int c2 = (g0 + 4 < kGroups) ? g0 + 4 : kGroups - 1, c3 = (g0 + 5 < kGroups) ? g0 + 5 : kGroups - 1;
+        block<TM, P, P>(seq, acc, a[0], vb[0], vb[1], d, patch(g0 + 2), a[2], u_rsrc, ubase + (g0 + 2) * kG, u_lane, kUStride);
+        block<TM, P, P>(seq, acc, a[1], vb[1], vb[0], d, patch(g0 + 3), a[3], u_rsrc, ubase + (g0 + 3) * kG, u_lane, kUStride);
+        block<TM, P, NP>(seq, acc, a[2], vb[0], vb[1], d, patch(c2), a[0], u_rsrc, ubase + c2 * kG, u_lane, kUStride);
+        block<TM, NP, NP>(seq, acc, a[3], vb[1], vb[0], d, patch(c3), a[1], u_rsrc, ubase + c3 * kG, u_lane, kUStride);
+    }
+    // the last MFMAs (8 passes = 32 cycles) must have left the matrix pipe before the fold reads them
+    // (every accumulator is an operand, so no read of one can be moved above the wait)
+    if constexpr (TM == 1) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[0][4]), "+a"(acc[0][5]), "+a"(acc[0][6]), "+a"(acc[0][7]), "+a"(acc[0][8]), "+a"(acc[0][9]), "+a"(acc[0][10]), "+a"(acc[0][11]));
+    else asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[0][4]), "+a"(acc[0][5]), "+a"(acc[0][6]), "+a"(acc[0][7]), "+a"(acc[0][8]), "+a"(acc[0][9]), "+a"(acc[0][10]), "+a"(acc[0][11]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]), "+a"(acc[1][3]), "+a"(acc[1][4]), "+a"(acc[1][5]), "+a"(acc[1][6]), "+a"(acc[1][7]), "+a"(acc[1][8]), "+a"(acc[1][9]), "+a"(acc[1][10]), "+a"(acc[1][11]));
+    // fold: Y[p][q] (+)= A^T[p][i'] w_i'[q]; columns of A^T: i'=1: 1 1 1 1, 2: 1 -1 1 -1, 3: 1 2 4 8,
+    // 4: 1 -2 4 -8, 0: 1 0 0 0, 5: 0 0 0 1.  Pass 0 writes Y for the first time.
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        f32x4 wa[4], wb[4];
+        out_row(&acc[m][0], wa);
+        out_row(&acc[m][6], wb);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if constexpr (P == 0) {
+                const f32x4 sum = wa[q] + wb[q], dif = wa[q] - wb[q];
+                Y[m][0 + q] = sum;
+                Y[m][4 + q] = dif;
+                Y[m][8 + q] = sum;
+                Y[m][12 + q] = dif;
+            } else if constexpr (P == 1) {
+                const f32x4 sum = wa[q] + wb[q], dif = wa[q] - wb[q];
+                Y[m][0 + q] += sum;
+                Y[m][4 + q] += 2.0f * dif;
+                Y[m][8 + q] += 4.0f * sum;
+                Y[m][12 + q] += 8.0f * dif;
+            } else {
+                Y[m][0 + q] += wa[q];
+                Y[m][12 + q] += wb[q];
+            }
+        }
+    }
+}
+
+// Y[m][p*4 + q] = conv output (no bias) of output-channel tile tile0 + m at board row 4*ty + p, column 4*tx + q
+// (ty = (lane >> 2) & 3, tx = lane & 3) for the lane's 4 channels.
+template <int PL, int CIN, int TM>
+__device__ __forceinline__ void conv(const float *__restrict__ in, const f32x4 *__restrict__ up, int tile0, int lane,
+                                     f32x4 (&a)[4][TM][3], f32x4 (&Y)[TM][16]) {
+    constexpr int kSteps = CIN / 4, kG = 3 * 1024, kUStride = 3 * kSteps * kG;
+    const int kq = lane >> 4, ty = (lane >> 2) & 3, tx = lane & 3;
+    // top-left of the lane's 6x6 patch in halo coordinates: row 4*ty, column 4*tx, plane kq of the group
+    const lds_cptr base = (lds_cptr)(in + kq * PL + (4 * ty) * kRowW + 4 * tx);
+    const __amdgpu_buffer_rsrc_t u_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(up), 0, 0x7fffffff, 0x00020000);
+    const int ubase = tile0 * kUStride, u_lane = lane * 16;
+    float d[6][6], vb[2][2][6];
+    {   // pipeline prologue: group 0 transformed, patch rows of group 1 in flight
+        float w[4], t[2][6], u[8];
+        ld_ops<0, 0>(std::make_integer_sequence<int, Pass<0>::n_ld>{}, d, base);
+        xf_ops<0, 0>(std::make_integer_sequence<int, Pass<0>::n_xf>{}, d, w, t, u, vb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        ld_ops<0, 0>(std::make_integer_sequence<int, Pass<0>::n_ld>{}, d, base + 4 * PL);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    pass<PL, CIN, TM, 0>(base, u_rsrc, ubase, u_lane, a, d, vb, Y);
+    pass<PL, CIN, TM, 1>(base, u_rsrc, ubase, u_lane, a, d, vb, Y);
+    pass<PL, CIN, TM, 2>(base, u_rsrc, ubase, u_lane, a, d, vb, Y);
+}
+
+// Sum `vals` over the 4 lanes {n, n+16, n+32, n+48}: every lane ends with 24 of the 96 sums,
+// out[i] = sum of vals[(q & 1) * 48 + (q >> 1) * 24 + i], q = lane >> 4.
+__device__ __forceinline__ void reduce_scatter_96(const float (&vals)[96], float (&out)[24]) {
+    float r1[48];
+#pragma unroll
+    for (int i = 0; i < 48; ++i) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(vals[i]), __float_as_uint(vals[48 + i]),
+                                                         false, false);
+        r1[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(r1[i]), __float_as_uint(r1[24 + i]),
+                                                         false, false);
+        out[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+}
+
+}  // namespace f4
+
+// 4 waves, one per SIMD: wave w owns output-channel tiles {2w, 2w+1} of conv3 and tile w of conv2 for the whole
+// board.  Persistent workgroups, LDS layout, conv1, observation prefetch and the feature epilogue as in
+// k_trunk_wino.
+__global__ __launch_bounds__(256) void k_trunk_wino_f4(NetDev nd, const float *__restrict__ obs,
+                                                       float *__restrict__ feat, int n_boards) {
+    constexpr int PL = kPlaneWino;
+    constexpr int kLdsFloats = kPlanes * PL;
+    constexpr int kThreads = 256;
+    constexpr int kPartialFloats = 4 * 6 * 256;
+    __shared__ __attribute__((aligned(16))) float lds[kLdsFloats + kPartialFloats];
+    float *in0 = lds;
+    float *c1 = in0 + kPlanesIn * PL;
+    float *c2 = c1 + kPlanesC1 * PL;
+    float *partial = c2 + kPlanesC2 * PL;  // [wave][o][y][x]
+    const int tid0 = threadIdx.x;
+    const int BH = nd.BH, BW = nd.BW, S = nd.S;
+    {
+        f32x4 *z = reinterpret_cast<f32x4 *>(lds);
+        for (int i = tid0; i < kLdsFloats / 4; i += kThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    constexpr int kObsPer = (4 * RZ_MAX_BOARD_SIZE * RZ_MAX_BOARD_SIZE + kThreads - 1) / kThreads;
+    float ob[kObsPer];
+    auto load_obs = [&](int board, int tid) {
+        const float *src = obs + (size_t)board * 4 * S;
+#pragma unroll
+        for (int k = 0; k < kObsPer; ++k) {
+            const int i = tid + k * kThreads;
+            ob[k] = i < 4 * S ? src[i] : 0.0f;
+        }
+    };
+    // element tid + k*kThreads of a board's observation planes / head features -> where it lives in LDS /
+    // in the feature row: the same for every board, so the integer divisions are done once per thread
+    int obs_off[kObsPer];
+#pragma unroll
+    for (int k = 0; k < kObsPer; ++k) {
+        const int i = tid0 + k * kThreads;
+        const int c = i / S, r = i - c * S, y = r / BW, x = r - y * BW;
+        obs_off[k] = i < 4 * S ? c * PL + (y + 1) * kRowW + (x + 1) : -1;
+    }
+    constexpr int kFeatPer = (6 * RZ_MAX_BOARD_SIZE * RZ_MAX_BOARD_SIZE + kThreads - 1) / kThreads;
+    int feat_src[kFeatPer], feat_dst[kFeatPer];
+    float feat_bias[kFeatPer];
+#pragma unroll
+    for (int k = 0; k < kFeatPer; ++k) {
+        const int i = tid0 + k * kThreads;
+        const int o = i / S, r = i - o * S, y = r / BW, x = r - y * BW;
+        feat_src[k] = (o * 16 + y) * 16 + x;
+        feat_dst[k] = i < 6 * S ? (i < 4 * S ? i : i - 4 * S + nd.feat_val_off) : -1;
+        feat_bias[k] = i < 6 * S ? nd.bh[o] : 0.0f;
+    }
+    auto store_obs = [&](int) {
+#pragma unroll
+        for (int k = 0; k < kObsPer; ++k)
+            if (obs_off[k] >= 0) in0[obs_off[k]] = ob[k];
+    };
+    __syncthreads();
+    if ((int)blockIdx.x < n_boards) {
+        load_obs(blockIdx.x, tid0);
+        store_obs(tid0);
+    }
+    __syncthreads();
+    for (int board = blockIdx.x; board < n_boards; board += gridDim.x) {
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int next_board = board + (int)gridDim.x;
+    {   // conv1: 4 -> 32 direct: output tile (wave & 1), board rows 8 * (wave >> 1) ..
+        const int tile = wave & 1, row0 = 8 * (wave >> 1);
+        if (row0 < BH) {
+            f32x4 acc[1][8];
+            zero_acc<1>(acc);
+            conv_rows<PL, 4, 1>(in0, nd.w1, tile, row0, (BH - row0 == 7) ? 7 : 8, lane, acc);
+            store_relu<PL, 1>(c1, nd.b1, tile, row0, lane, BH, BW, acc, 8);
+        }
+    }
+    __syncthreads();
+    if (next_board < n_boards) load_obs(next_board, tid);
+    const int q = lane >> 4, ty = (lane >> 2) & 3, tx = lane & 3;
+    {   // conv2: 32 -> 64, one output-channel tile per wave
+        f32x4 a2[4][1][3];
+        f32x4 Y[1][16];
+        f4::preload_u<32, 1>(nd.u2f, wave, lane, a2);
+        f4::conv<PL, 32, 1>(c1, nd.u2f, wave, lane, a2, Y);
+        const int c0 = wave * 16 + 4 * q;
+        const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b2 + c0);
+#pragma unroll
+        for (int pq = 0; pq < 16; ++pq) {
+            const int y = 4 * ty + (pq >> 2), x = 4 * tx + (pq & 3);
+            if (y < BH && x < BW) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    c2[(c0 + j) * PL + (y + 1) * kRowW + (x + 1)] = fmaxf(Y[0][pq][j] + bv[j], 0.0f);
+            }
+        }
+    }
+    if (next_board < n_boards) store_obs(tid);
+    __syncthreads();
+    {   // conv3: 64 -> 128, two tiles per wave; the ReLU'd output feeds the two 1x1 head convolutions
+        float vals[96];  // index pos*6 + o, pos = p*4 + q
+#pragma unroll
+        for (int i = 0; i < 96; ++i) vals[i] = 0.0f;
+        {
+            f32x4 a3[4][2][3];
+            f32x4 Y[2][16];
+            f4::preload_u<64, 2>(nd.u3f, 2 * wave, lane, a3);
+            f4::conv<PL, 64, 2>(c2, nd.u3f, 2 * wave, lane, a3, Y);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int c0 = (2 * wave + m) * 16 + 4 * q;
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b3 + c0);
+                f32x4 wv[6];
+#pragma unroll
+                for (int o = 0; o < 6; ++o) wv[o] = *reinterpret_cast<const f32x4 *>(nd.wh + o * 128 + c0);
+#pragma unroll
+                for (int pq = 0; pq < 16; ++pq)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float hv = fmaxf(Y[m][pq][j] + bv[j], 0.0f);
+#pragma unroll
+                        for (int o = 0; o < 6; ++o) vals[pq * 6 + o] = fmaf(wv[o][j], hv, vals[pq * 6 + o]);
+                    }
+            }
+        }
+        float sums[24];
+        f4::reduce_scatter_96(vals, sums);
+        const int off = (q & 1) * 48 + (q >> 1) * 24;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            const int vi = off + i, pq = vi / 6, o = vi - 6 * pq;
+            const int y = 4 * ty + (pq >> 2), x = 4 * tx + (pq & 3);
+            partial[((wave * 6 + o) * 16 + y) * 16 + x] = sums[i];
+        }
+    }
+    __syncthreads();
+    {
+        float *dst = feat + (size_t)board * nd.feat_ld;
+#pragma unroll
+        for (int k = 0; k < kFeatPer; ++k) {
+            if (feat_dst[k] < 0) continue;
+            float v = feat_bias[k];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v += partial[g * 6 * 256 + feat_src[k]];
+            dst[feat_dst[k]] = fmaxf(v, 0.0f);
         }
     }
     }  // boards
@@ -931,6 +1379,39 @@ std::vector<f32x4> pack_wino(const float *w, int cout, int cin) {
     return out;
 }
 
+// U = G g G^T for F(4x4,3x3) (G: 6x3), packed [tile][pass][cin_step][3][64 lanes] x 4: lane = kq*16 + m
+// holds components k = 4*j + e (j = 0..2) of pass p for U[16*tile + m][4*step + kq], component k =
+// (transform row i' = rows[p][k / 6], column j' = k % 6).  fp64, rounded once.
+std::vector<f32x4> pack_wino_f4(const float *w, int cout, int cin) {
+    static const double G[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6},  {0, 0, 1}};
+    static const int rows[3][2] = {{1, 2}, {3, 4}, {0, 5}};
+    const int tiles = cout / 16, steps = cin / 4;
+    std::vector<f32x4> out((size_t)tiles * 3 * steps * 3 * 64);
+    for (int t = 0; t < tiles; ++t)
+        for (int s = 0; s < steps; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int m = lane & 15, kq = lane >> 4;
+                const float *g = w + ((size_t)(16 * t + m) * cin + (4 * s + kq)) * 9;
+                double tmp[6][3], U[6][6];
+                for (int i = 0; i < 6; ++i)
+                    for (int c = 0; c < 3; ++c)
+                        tmp[i][c] = G[i][0] * g[0 * 3 + c] + G[i][1] * g[1 * 3 + c] + G[i][2] * g[2 * 3 + c];
+                for (int i = 0; i < 6; ++i)
+                    for (int j = 0; j < 6; ++j) U[i][j] = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
+                for (int p = 0; p < 3; ++p)
+                    for (int j = 0; j < 3; ++j) {
+                        f32x4 v;
+                        for (int e = 0; e < 4; ++e) {
+                            const int k = 4 * j + e;
+                            v[e] = (float)U[rows[p][k / 6]][k % 6];
+                        }
+                        out[((((size_t)t * 3 + p) * steps + s) * 3 + j) * 64 + lane] = v;
+                    }
+            }
+    return out;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1005,6 +1486,8 @@ int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params) {
     up_vec4(pack_conv(h_params[4], 128, 64), &D.w3);
     up_vec4(pack_wino(h_params[2], 64, 32), &D.u2);
     up_vec4(pack_wino(h_params[4], 128, 64), &D.u3);
+    up_vec4(pack_wino_f4(h_params[2], 64, 32), &D.u2f);
+    up_vec4(pack_wino_f4(h_params[4], 128, 64), &D.u3f);
     up_f(h_params[5], 128, &D.b3);
     {
         std::vector<float> wh(6 * 128), bh(6);
@@ -1086,6 +1569,8 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
         k_trunk_wino<4><<<pgrid, dim3(512), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
     else if (net->algo == RZ_NET_WINOGRAD_4W)
         k_trunk_wino<2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
+    else if (net->algo == RZ_NET_WINOGRAD_F4)
+        k_trunk_wino_f4<<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
     else
         k_trunk<<<grid, dim3(kTrunkThreads), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
 }
@@ -1118,7 +1603,7 @@ int rz_net_trunk(rz_net *net, const float *d_obs, int32_t n_boards, float *d_fea
 
 int rz_net_set_algo(rz_net *net, int32_t algo) {
     if (!net) return net_fail(RZ_ERR_ARG, "net handle is NULL");
-    if (algo != RZ_NET_DIRECT && algo != RZ_NET_WINOGRAD && algo != RZ_NET_WINOGRAD_4W)
+    if (algo != RZ_NET_DIRECT && algo != RZ_NET_WINOGRAD && algo != RZ_NET_WINOGRAD_4W && algo != RZ_NET_WINOGRAD_F4)
         return net_fail(RZ_ERR_ARG, "unknown algorithm");
     net->algo = algo;
     return RZ_OK;

@@ -103,7 +103,8 @@ class HipNet(object):
 
     def set_algo(self, algo):
         """'winograd' (default) or 'direct' for conv2 / conv3 (both fp32 MFMA)."""
-        code = {'direct': _hip.NET_DIRECT, 'winograd': _hip.NET_WINOGRAD, 'winograd4w': _hip.NET_WINOGRAD_4W}[algo]
+        code = {'direct': _hip.NET_DIRECT, 'winograd': _hip.NET_WINOGRAD, 'winograd4w': _hip.NET_WINOGRAD_4W,
+                'winograd_f4': _hip.NET_WINOGRAD_F4}[algo]
         check(self.lib.rz_net_set_algo(self.handle, code), 'rz_net_set_algo')
         return self
 

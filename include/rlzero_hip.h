@@ -258,11 +258,11 @@ int rz_uct_scores(rz_engine *e, const double *d_w, const int32_t *d_n, const int
 typedef struct rz_net rz_net;
 enum {
     RZ_NET_DIRECT = 0,   /* conv2/conv3 as direct implicit GEMM: bit-for-bit a k-ordered fp32 fmaf chain */
-    RZ_NET_WINOGRAD = 1, /* default: conv2/conv3 as Winograd F(2x2,3x3) on the fp32 MFMA path (2.25x fewer
+    RZ_NET_WINOGRAD = 1, /* conv2/conv3 as Winograd F(2x2,3x3) on the fp32 MFMA path (2.25x fewer
                             multiply-adds; fp32 throughout, differs from DIRECT by re-association only);
                             8 waves per board, two per SIMD */
     RZ_NET_WINOGRAD_4W = 2, /* same arithmetic, 4 waves per board (one per SIMD, whole register file) */
-    RZ_NET_WINOGRAD_F4 = 3  /* conv2/conv3 as Winograd F(4x4,3x3): 4x fewer multiply-adds than DIRECT; fp32
+    RZ_NET_WINOGRAD_F4 = 3  /* default: conv2/conv3 as Winograd F(4x4,3x3): 4x fewer multiply-adds than DIRECT; fp32
                                throughout, ~1e-6 absolute on the activations (one digit more than F(2x2,3x3)) */
 };
 int rz_net_set_algo(rz_net *net, int32_t algo);

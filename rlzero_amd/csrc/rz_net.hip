@@ -1291,7 +1291,7 @@ __global__ __launch_bounds__(64) void k_heads_finish(NetDev nd, const float *__r
 struct rz_net {
     int board_size = 0, device = 0;
     bool loaded = false;
-    int algo = RZ_NET_WINOGRAD;
+    int algo = RZ_NET_WINOGRAD_F4;
     int n_cus = 256;
     int max_wgs = 0;  // rz_net_set_max_workgroups: 0 = one persistent trunk workgroup per CU
     NetDev dev;

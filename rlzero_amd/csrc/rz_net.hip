@@ -35,6 +35,7 @@ void rz_set_error(const char *msg);  // rz_engine.hip
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kRowW = 18;     // halo row width (x = -1 .. 16)
 // halo rows: 18 (y = -1 .. 16), 18*18 = 324 floats per plane before padding
@@ -646,8 +647,8 @@ template <int P> struct Pass {  // pass P handles transform rows i' = a, b
     static constexpr int first = (P == 2) ? 0 : 1;   // patch rows it reads: 1..4, or all six for rows 0 / 5
     static constexpr int count = (P == 2) ? 6 : 4;
     static constexpr int n_ld = 3 * count;           // ds_read2 per group
-    static constexpr int row_ops = (P == 0) ? 6 : 4; // row-stage instructions per patch column
-    static constexpr int n_xf = 6 * row_ops + 28;    // transform instructions per group
+    static constexpr int row_ops = (P == 2) ? 4 : 3; // row-stage instructions per patch column
+    static constexpr int n_xf = 6 * row_ops + 14;    // transform instructions per group (packed: 2 floats each)
 };
 
 // LDS read O of a group of pass P: patch row first + O / 3, column pair O % 3
@@ -658,55 +659,53 @@ __device__ __forceinline__ void ld_op(float (&d)[6][6], lds_cptr q) {
     d[row][c + 1] = q[row * kRowW + c + 1];
 }
 
-// Transform instruction O of a group of pass P, every case ONE add / fused multiply-add.  Row stage
-// (t = rows a, b of B^T d, column by column), then the column stage of the two rows (v = t B),
+// Transform instruction O of a group of pass P; every case is ONE instruction, most of them PACKED fp32
+// (v_pk_add_f32 / v_pk_fma_f32 on register pairs, with half selects / negations as operand modifiers):
+// the two transform rows a, b of the pass go through identical arithmetic, so the pair (row a, row b) is
+// the natural vector.  Row stage, column by column: t[c] = (rows a, b of B^T d)[c]; then the column stage
+// v[j'] = (t B)[j'] on those pairs,
 //   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1].
 template <int P, int O>
-__device__ __forceinline__ void xf_op(const float (&d)[6][6], float (&w)[4], float (&t)[2][6], float (&u)[8],
-                                      float (&v)[2][6]) {
+__device__ __forceinline__ void xf_op(const float (&d)[6][6], f32x2 (&w)[2], f32x2 (&t)[6], f32x2 (&u)[8], f32x2 (&v)[6]) {
     constexpr int kRowOps = Pass<P>::row_ops;
     if constexpr (O < 6 * kRowOps) {
         constexpr int c = O / kRowOps, k = O % kRowOps;
         if constexpr (P == 0) {  // rows 1, 2: -4 (d1 + d2) + (d3 + d4) ; 4 (d1 - d2) - (d3 - d4)
-            if constexpr (k == 0) w[0] = d[1][c] + d[2][c];
-            else if constexpr (k == 1) w[1] = d[3][c] + d[4][c];
-            else if constexpr (k == 2) w[2] = d[1][c] - d[2][c];
-            else if constexpr (k == 3) w[3] = d[3][c] - d[4][c];
-            else if constexpr (k == 4) t[0][c] = fmaf(-4.0f, w[0], w[1]);
-            else t[1][c] = fmaf(4.0f, w[2], -w[3]);
+            if constexpr (k == 0) w[0] = f32x2{d[1][c], d[1][c]} + f32x2{d[2][c], -d[2][c]};
+            else if constexpr (k == 1) w[1] = f32x2{d[4][c], d[4][c]} + f32x2{d[3][c], -d[3][c]};
+            else t[c] = __builtin_elementwise_fma(f32x2{-4.0f, 4.0f}, w[0], w[1]);
         } else if constexpr (P == 1) {  // rows 3, 4: +-2 (d3 - d1) + (d4 - d2)
-            if constexpr (k == 0) w[0] = d[3][c] - d[1][c];
-            else if constexpr (k == 1) w[1] = d[4][c] - d[2][c];
-            else if constexpr (k == 2) t[0][c] = fmaf(2.0f, w[0], w[1]);
-            else t[1][c] = fmaf(-2.0f, w[0], w[1]);
+            if constexpr (k == 0) w[0].x = d[3][c] - d[1][c];
+            else if constexpr (k == 1) w[0].y = d[4][c] - d[2][c];
+            else t[c] = __builtin_elementwise_fma(f32x2{2.0f, -2.0f}, f32x2{w[0].x, w[0].x}, f32x2{w[0].y, w[0].y});
         } else {  // rows 0, 5: 4 d0 - 5 d2 + d4 ; 4 d1 - 5 d3 + d5
-            if constexpr (k == 0) w[0] = fmaf(-5.0f, d[2][c], d[4][c]);
-            else if constexpr (k == 1) t[0][c] = fmaf(4.0f, d[0][c], w[0]);
-            else if constexpr (k == 2) w[1] = fmaf(-5.0f, d[3][c], d[5][c]);
-            else t[1][c] = fmaf(4.0f, d[1][c], w[1]);
+            if constexpr (k == 0) w[0].x = fmaf(-5.0f, d[2][c], d[4][c]);
+            else if constexpr (k == 1) t[c].x = fmaf(4.0f, d[0][c], w[0].x);
+            else if constexpr (k == 2) w[0].y = fmaf(-5.0f, d[3][c], d[5][c]);
+            else t[c].y = fmaf(4.0f, d[1][c], w[0].y);
         }
     } else {
-        constexpr int oc = O - 6 * kRowOps, rr = oc / 14, k = oc % 14;
-        const float (&x)[6] = t[rr];
-        if constexpr (k == 0) u[0] = x[1] + x[2];
-        else if constexpr (k == 1) u[1] = x[3] + x[4];
-        else if constexpr (k == 2) u[2] = x[1] - x[2];
-        else if constexpr (k == 3) u[3] = x[3] - x[4];
-        else if constexpr (k == 4) v[rr][1] = fmaf(-4.0f, u[0], u[1]);
-        else if constexpr (k == 5) v[rr][2] = fmaf(4.0f, u[2], -u[3]);
-        else if constexpr (k == 6) u[4] = x[3] - x[1];
-        else if constexpr (k == 7) u[5] = x[4] - x[2];
-        else if constexpr (k == 8) v[rr][3] = fmaf(2.0f, u[4], u[5]);
-        else if constexpr (k == 9) v[rr][4] = fmaf(-2.0f, u[4], u[5]);
-        else if constexpr (k == 10) u[6] = fmaf(-5.0f, x[2], x[4]);
-        else if constexpr (k == 11) v[rr][0] = fmaf(4.0f, x[0], u[6]);
-        else if constexpr (k == 12) u[7] = fmaf(-5.0f, x[3], x[5]);
-        else v[rr][5] = fmaf(4.0f, x[1], u[7]);
+        constexpr int k = O - 6 * kRowOps;
+        const f32x2 c4 = {4.0f, 4.0f}, c2 = {2.0f, 2.0f}, c5 = {-5.0f, -5.0f};
+        if constexpr (k == 0) u[0] = t[1] + t[2];
+        else if constexpr (k == 1) u[1] = t[3] + t[4];
+        else if constexpr (k == 2) u[2] = t[1] - t[2];
+        else if constexpr (k == 3) u[3] = t[3] - t[4];
+        else if constexpr (k == 4) v[1] = __builtin_elementwise_fma(-c4, u[0], u[1]);
+        else if constexpr (k == 5) v[2] = __builtin_elementwise_fma(c4, u[2], -u[3]);
+        else if constexpr (k == 6) u[4] = t[3] - t[1];
+        else if constexpr (k == 7) u[5] = t[4] - t[2];
+        else if constexpr (k == 8) v[3] = __builtin_elementwise_fma(c2, u[4], u[5]);
+        else if constexpr (k == 9) v[4] = __builtin_elementwise_fma(-c2, u[4], u[5]);
+        else if constexpr (k == 10) u[6] = __builtin_elementwise_fma(c5, t[2], t[4]);
+        else if constexpr (k == 11) v[0] = __builtin_elementwise_fma(c4, t[0], u[6]);
+        else if constexpr (k == 12) u[7] = __builtin_elementwise_fma(c5, t[3], t[5]);
+        else v[5] = __builtin_elementwise_fma(c4, t[1], u[7]);
     }
 }
 template <int P, int BASE, int... Os>
-__device__ __forceinline__ void xf_ops(std::integer_sequence<int, Os...>, const float (&d)[6][6], float (&w)[4],
-                                       float (&t)[2][6], float (&u)[8], float (&v)[2][6]) {
+__device__ __forceinline__ void xf_ops(std::integer_sequence<int, Os...>, const float (&d)[6][6], f32x2 (&w)[2],
+                                       f32x2 (&t)[6], f32x2 (&u)[8], f32x2 (&v)[6]) {
     (xf_op<P, BASE + Os>(d, w, t, u, v), ...);
 }
 template <int P, int BASE, int... Os>
@@ -718,9 +717,9 @@ __device__ __forceinline__ void ld_ops(std::integer_sequence<int, Os...>, float 
 // slice of the next groups' work: first two thirds of the slots = transform of the next group (pass XP) into
 // v_nxt, last third = LDS reads of the group after it (pass LP) into d and the U loads two groups ahead.
 template <int TM, int XP, int LP, int I>
-__device__ __forceinline__ void slot(f32x4 (&acc)[TM][12], const f32x4 (&a_cur)[TM][3], const float (&v_cur)[2][6],
-                                     float (&v_nxt)[2][6], float (&d)[6][6], float (&w)[4], float (&t)[2][6],
-                                     float (&u)[8], lds_cptr q_ld, f32x4 (&a_ld)[TM][3], __amdgpu_buffer_rsrc_t u_rsrc,
+__device__ __forceinline__ void slot(f32x4 (&acc)[TM][12], const f32x4 (&a_cur)[TM][3], const f32x2 (&v_cur)[6],
+                                     f32x2 (&v_nxt)[6], float (&d)[6][6], f32x2 (&w)[2], f32x2 (&t)[6],
+                                     f32x2 (&u)[8], lds_cptr q_ld, f32x4 (&a_ld)[TM][3], __amdgpu_buffer_rsrc_t u_rsrc,
                                      int u_off, int u_lane, int u_stride) {
     constexpr int NS = 12 * TM, XF_SLOTS = 2 * NS / 3, LD_SLOTS = NS / 3;
     constexpr int kXf = Pass<XP>::n_xf, kLd = Pass<LP>::n_ld;
@@ -733,7 +732,7 @@ __device__ __forceinline__ void slot(f32x4 (&acc)[TM][12], const f32x4 (&a_cur)[
     // operands were produced at least a third of a block earlier; the fold waits explicitly.
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0"
                  : "+a"(acc[m][k])
-                 : "v"(a_cur[m][k >> 2][k & 3]), "v"(v_cur[k / 6][k % 6]));
+                 : "v"(a_cur[m][k >> 2][k & 3]), "v"(v_cur[k % 6][k / 6]));
     if constexpr (I < XF_SLOTS) {
         constexpr int lo = I * XF_PER, hi = (lo + XF_PER < kXf) ? lo + XF_PER : kXf;
         if constexpr (hi > lo) xf_ops<XP, lo>(std::make_integer_sequence<int, hi - lo>{}, d, w, t, u, v_nxt);
@@ -750,10 +749,10 @@ __device__ __forceinline__ void slot(f32x4 (&acc)[TM][12], const f32x4 (&a_cur)[
 }
 template <int TM, int XP, int LP, int... Is>
 __device__ __forceinline__ void block(std::integer_sequence<int, Is...>, f32x4 (&acc)[TM][12], const f32x4 (&a_cur)[TM][3],
-                                      const float (&v_cur)[2][6], float (&v_nxt)[2][6], float (&d)[6][6], lds_cptr q_ld,
+                                      const f32x2 (&v_cur)[6], f32x2 (&v_nxt)[6], float (&d)[6][6], lds_cptr q_ld,
                                       f32x4 (&a_ld)[TM][3], __amdgpu_buffer_rsrc_t u_rsrc, int u_off, int u_lane,
                                       int u_stride) {
-    float w[4], t[2][6], u[8];
+    f32x2 w[2], t[6], u[8];
     (slot<TM, XP, LP, Is>(acc, a_cur, v_cur, v_nxt, d, w, t, u, q_ld, a_ld, u_rsrc, u_off, u_lane, u_stride), ...);
 }
 
@@ -786,7 +785,7 @@ __device__ __forceinline__ void preload_u(const f32x4 *__restrict__ up, int tile
 // of the pass those belong to pass P+1 (after the last pass the indices are clamped: fetched again, unused).
 template <int PL, int CIN, int TM, int P>
 __device__ __forceinline__ void pass(lds_cptr base, __amdgpu_buffer_rsrc_t u_rsrc, int ubase, int u_lane,
-                                     f32x4 (&a)[4][TM][3], float (&d)[6][6], float (&vb)[2][2][6], f32x4 (&Y)[TM][16]) {
+                                     f32x4 (&a)[4][TM][3], float (&d)[6][6], f32x2 (&vb)[2][6], f32x4 (&Y)[TM][16]) {
     constexpr int kSteps = CIN / 4, kGroups = 3 * kSteps, kG = 3 * 1024, kUStride = 3 * kSteps * kG;
     constexpr int NP = P < 2 ? P + 1 : 2;
     constexpr auto seq = std::make_integer_sequence<int, 12 * TM>{};
@@ -867,9 +866,10 @@ __device__ __forceinline__ void conv(const float *__restrict__ in, const f32x4 *
     const __amdgpu_buffer_rsrc_t u_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(up), 0, 0x7fffffff, 0x00020000);
     const int ubase = tile0 * kUStride, u_lane = lane * 16;
-    float d[6][6], vb[2][2][6];
+    float d[6][6];
+    f32x2 vb[2][6];  // transformed fragment, double buffered: vb[.][j'] = (row a, row b) of column j'
     {   // pipeline prologue: group 0 transformed, patch rows of group 1 in flight
-        float w[4], t[2][6], u[8];
+        f32x2 w[2], t[6], u[8];
         ld_ops<0, 0>(std::make_integer_sequence<int, Pass<0>::n_ld>{}, d, base);
         xf_ops<0, 0>(std::make_integer_sequence<int, Pass<0>::n_xf>{}, d, w, t, u, vb[0]);
         __builtin_amdgcn_sched_barrier(0);

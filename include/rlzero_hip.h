@@ -262,8 +262,10 @@ enum {
                             multiply-adds; fp32 throughout, differs from DIRECT by re-association only);
                             8 waves per board, two per SIMD */
     RZ_NET_WINOGRAD_4W = 2, /* same arithmetic, 4 waves per board (one per SIMD, whole register file) */
-    RZ_NET_WINOGRAD_F4 = 3  /* default: conv2/conv3 as Winograd F(4x4,3x3): 4x fewer multiply-adds than DIRECT; fp32
-                               throughout, ~1e-6 absolute on the activations (one digit more than F(2x2,3x3)) */
+    RZ_NET_WINOGRAD_F4 = 3,  /* default: conv2/conv3 as Winograd F(4x4,3x3): 4x fewer multiply-adds than DIRECT; fp32
+                                throughout, ~1e-6 absolute on the activations (one digit more than F(2x2,3x3));
+                                4 waves per board, two output-channel tiles each, one per SIMD */
+    RZ_NET_WINOGRAD_F4_8W = 4 /* same arithmetic, 8 waves per board with one tile each (two per SIMD; slower) */
 };
 int rz_net_set_algo(rz_net *net, int32_t algo);
 /* The Winograd trunk runs as persistent workgroups (one per CU: its LDS and registers fill a CU),

@@ -15,7 +15,7 @@ MAX_BOARD_SIZE = 16
 OK = 0
 SCORE_UCT_REF, SCORE_PUCT = 0, 1
 GAME_GOMOKU, GAME_CONNECT4 = 0, 1
-NET_DIRECT, NET_WINOGRAD, NET_WINOGRAD_4W, NET_WINOGRAD_F4 = 0, 1, 2, 3
+NET_DIRECT, NET_WINOGRAD, NET_WINOGRAD_4W, NET_WINOGRAD_F4, NET_WINOGRAD_F4_8W = 0, 1, 2, 3, 4
 EVAL_V0, EVAL_VLIN = 0, 1
 FLAG_NAMES = {1: 'arena full', 2: 'block queue full', 4: 'illegal move', 8: 'ln table too short',
               16: 'internal'}

@@ -714,14 +714,16 @@ __device__ __forceinline__ void ld_ops(std::integer_sequence<int, Os...>, float 
 }
 
 // Slot I of the MFMA block of one channel group: MFMA I (component k = I / TM = rr*6 + j', tile m = I % TM) and its
-// slice of the next groups' work: first two thirds of the slots = transform of the next group (pass XP) into
-// v_nxt, last third = LDS reads of the group after it (pass LP) into d and the U loads two groups ahead.
+// slice of the next groups' work: first third of the slots = LDS reads of the group two ahead (pass LP) into
+// d_ld and the U loads two groups ahead; the other two thirds = transform of the next group (pass XP), whose
+// patch rows d_xf were fetched during the PREVIOUS block (the patch buffer is double buffered: with one wave
+// per SIMD nothing else covers the LDS latency), into v_nxt.
 template <int TM, int XP, int LP, int I>
 __device__ __forceinline__ void slot(f32x4 (&acc)[TM][12], const f32x4 (&a_cur)[TM][3], const f32x2 (&v_cur)[6],
-                                     f32x2 (&v_nxt)[6], float (&d)[6][6], f32x2 (&w)[2], f32x2 (&t)[6],
-                                     f32x2 (&u)[8], lds_cptr q_ld, f32x4 (&a_ld)[TM][3], __amdgpu_buffer_rsrc_t u_rsrc,
-                                     int u_off, int u_lane, int u_stride) {
-    constexpr int NS = 12 * TM, XF_SLOTS = 2 * NS / 3, LD_SLOTS = NS / 3;
+                                     f32x2 (&v_nxt)[6], const float (&d_xf)[6][6], float (&d_ld)[6][6], f32x2 (&w)[2],
+                                     f32x2 (&t)[6], f32x2 (&u)[8], lds_cptr q_ld, f32x4 (&a_ld)[TM][3],
+                                     __amdgpu_buffer_rsrc_t u_rsrc, int u_off, int u_lane, int u_stride) {
+    constexpr int NS = 12 * TM, LD_SLOTS = NS / 3, XF_SLOTS = NS - LD_SLOTS;
     constexpr int kXf = Pass<XP>::n_xf, kLd = Pass<LP>::n_ld;
     constexpr int XF_PER = (kXf + XF_SLOTS - 1) / XF_SLOTS, LD_PER = (kLd + LD_SLOTS - 1) / LD_SLOTS;
     constexpr int k = I / TM, m = I % TM;
@@ -729,31 +731,31 @@ __device__ __forceinline__ void slot(f32x4 (&acc)[TM][12], const f32x4 (&a_cur)[
     // registers per wave the compiler otherwise stages every accumulator through a[0:3] and copies it to
     // and from ordinary registers around each MFMA (8 extra instructions per MFMA).  No hazard handling is
     // lost: consecutive MFMAs use different accumulators (the same one recurs 12*TM MFMAs later) and the
-    // operands were produced at least a third of a block earlier; the fold waits explicitly.
+    // operands were produced in the previous block; the fold waits explicitly.
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0"
                  : "+a"(acc[m][k])
                  : "v"(a_cur[m][k >> 2][k & 3]), "v"(v_cur[k % 6][k / 6]));
-    if constexpr (I < XF_SLOTS) {
-        constexpr int lo = I * XF_PER, hi = (lo + XF_PER < kXf) ? lo + XF_PER : kXf;
-        if constexpr (hi > lo) xf_ops<XP, lo>(std::make_integer_sequence<int, hi - lo>{}, d, w, t, u, v_nxt);
-    } else {
-        constexpr int j = I - XF_SLOTS;
-        constexpr int lo = j * LD_PER, hi = (lo + LD_PER < kLd) ? lo + LD_PER : kLd;
-        if constexpr (hi > lo) ld_ops<LP, lo>(std::make_integer_sequence<int, hi - lo>{}, d, q_ld);
-        if constexpr (j < 3) {
+    if constexpr (I < LD_SLOTS) {
+        constexpr int lo = I * LD_PER, hi = (lo + LD_PER < kLd) ? lo + LD_PER : kLd;
+        if constexpr (hi > lo) ld_ops<LP, lo>(std::make_integer_sequence<int, hi - lo>{}, d_ld, q_ld);
+        if constexpr (I < 3) {
 #pragma unroll
-            for (int m2 = 0; m2 < TM; ++m2) a_ld[m2][j] = load_u(u_rsrc, u_lane, u_off + m2 * u_stride + j * 1024);
+            for (int m2 = 0; m2 < TM; ++m2) a_ld[m2][I] = load_u(u_rsrc, u_lane, u_off + m2 * u_stride + I * 1024);
         }
+    } else {
+        constexpr int j = I - LD_SLOTS;
+        constexpr int lo = j * XF_PER, hi = (lo + XF_PER < kXf) ? lo + XF_PER : kXf;
+        if constexpr (hi > lo) xf_ops<XP, lo>(std::make_integer_sequence<int, hi - lo>{}, d_xf, w, t, u, v_nxt);
     }
     __builtin_amdgcn_sched_barrier(0);
 }
 template <int TM, int XP, int LP, int... Is>
 __device__ __forceinline__ void block(std::integer_sequence<int, Is...>, f32x4 (&acc)[TM][12], const f32x4 (&a_cur)[TM][3],
-                                      const f32x2 (&v_cur)[6], f32x2 (&v_nxt)[6], float (&d)[6][6], lds_cptr q_ld,
-                                      f32x4 (&a_ld)[TM][3], __amdgpu_buffer_rsrc_t u_rsrc, int u_off, int u_lane,
-                                      int u_stride) {
+                                      const f32x2 (&v_cur)[6], f32x2 (&v_nxt)[6], const float (&d_xf)[6][6],
+                                      float (&d_ld)[6][6], lds_cptr q_ld, f32x4 (&a_ld)[TM][3],
+                                      __amdgpu_buffer_rsrc_t u_rsrc, int u_off, int u_lane, int u_stride) {
     f32x2 w[2], t[6], u[8];
-    (slot<TM, XP, LP, Is>(acc, a_cur, v_cur, v_nxt, d, w, t, u, q_ld, a_ld, u_rsrc, u_off, u_lane, u_stride), ...);
+    (slot<TM, XP, LP, Is>(acc, a_cur, v_cur, v_nxt, d_xf, d_ld, w, t, u, q_ld, a_ld, u_rsrc, u_off, u_lane, u_stride), ...);
 }
 
 // output transform of one transform row: w[q] = sum_j' A^T[q][j'] M[j'],  A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0;
@@ -785,7 +787,7 @@ __device__ __forceinline__ void preload_u(const f32x4 *__restrict__ up, int tile
 // of the pass those belong to pass P+1 (after the last pass the indices are clamped: fetched again, unused).
 template <int PL, int CIN, int TM, int P>
 __device__ __forceinline__ void pass(lds_cptr base, __amdgpu_buffer_rsrc_t u_rsrc, int ubase, int u_lane,
-                                     f32x4 (&a)[4][TM][3], float (&d)[6][6], f32x2 (&vb)[2][6], f32x4 (&Y)[TM][16]) {
+                                     f32x4 (&a)[4][TM][3], float (&d)[2][6][6], f32x2 (&vb)[2][6], f32x4 (&Y)[TM][16]) {
     constexpr int kSteps = CIN / 4, kGroups = 3 * kSteps, kG = 3 * 1024, kUStride = 3 * kSteps * kG;
     constexpr int NP = P < 2 ? P + 1 : 2;
     constexpr auto seq = std::make_integer_sequence<int, 12 * TM>{};
@@ -809,17 +811,19 @@ __device__ __forceinline__ void pass(lds_cptr base, __amdgpu_buffer_rsrc_t u_rsr
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int g2 = P * kSteps + s0 + r + 2;
-            block<TM, P, P>(seq, acc, a[r], vb[r & 1], vb[(r + 1) & 1], d, patch(g2), a[(r + 2) & 3], u_rsrc, ubase + g2 * kG,
-                            u_lane, kUStride);
+            block<TM, P, P>(seq, acc, a[r], vb[r & 1], vb[(r + 1) & 1], d[(r + 1) & 1], d[r & 1], patch(g2), a[(r + 2) & 3],
+                            u_rsrc, ubase + g2 * kG, u_lane, kUStride);
         }
     }
     {   // last four groups of the pass
         constexpr int g0 = P * kSteps + kSteps - 4;
         constexpr int c2 = (g0 + 4 < kGroups) ? g0 + 4 : kGroups - 1, c3 = (g0 + 5 < kGroups) ? g0 + 5 : kGroups - 1;
-        block<TM, P, P>(seq, acc, a[0], vb[0], vb[1], d, patch(g0 + 2), a[2], u_rsrc, ubase + (g0 + 2) * kG, u_lane, kUStride);
-        block<TM, P, P>(seq, acc, a[1], vb[1], vb[0], d, patch(g0 + 3), a[3], u_rsrc, ubase + (g0 + 3) * kG, u_lane, kUStride);
-        block<TM, P, NP>(seq, acc, a[2], vb[0], vb[1], d, patch(c2), a[0], u_rsrc, ubase + c2 * kG, u_lane, kUStride);
-        block<TM, NP, NP>(seq, acc, a[3], vb[1], vb[0], d, patch(c3), a[1], u_rsrc, ubase + c3 * kG, u_lane, kUStride);
+        block<TM, P, P>(seq, acc, a[0], vb[0], vb[1], d[1], d[0], patch(g0 + 2), a[2], u_rsrc, ubase + (g0 + 2) * kG, u_lane,
+                        kUStride);
+        block<TM, P, P>(seq, acc, a[1], vb[1], vb[0], d[0], d[1], patch(g0 + 3), a[3], u_rsrc, ubase + (g0 + 3) * kG, u_lane,
+                        kUStride);
+        block<TM, P, NP>(seq, acc, a[2], vb[0], vb[1], d[1], d[0], patch(c2), a[0], u_rsrc, ubase + c2 * kG, u_lane, kUStride);
+        block<TM, NP, NP>(seq, acc, a[3], vb[1], vb[0], d[0], d[1], patch(c3), a[1], u_rsrc, ubase + c3 * kG, u_lane, kUStride);
     }
     // the last MFMAs (8 passes = 32 cycles) must have left the matrix pipe before the fold reads them
     // (every accumulator is an operand, so no read of one can be moved above the wait)
@@ -866,14 +870,13 @@ __device__ __forceinline__ void conv(const float *__restrict__ in, const f32x4 *
     const __amdgpu_buffer_rsrc_t u_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(up), 0, 0x7fffffff, 0x00020000);
     const int ubase = tile0 * kUStride, u_lane = lane * 16;
-    float d[6][6];
-    f32x2 vb[2][6];  // transformed fragment, double buffered: vb[.][j'] = (row a, row b) of column j'
+    float d[2][6][6];  // patch rows, double buffered: a group's rows are read one block before they are transformed
+    f32x2 vb[2][6];    // transformed fragment, double buffered: vb[.][j'] = (row a, row b) of column j'
     {   // pipeline prologue: group 0 transformed, patch rows of group 1 in flight
         f32x2 w[2], t[6], u[8];
-        ld_ops<0, 0>(std::make_integer_sequence<int, Pass<0>::n_ld>{}, d, base);
-        xf_ops<0, 0>(std::make_integer_sequence<int, Pass<0>::n_xf>{}, d, w, t, u, vb[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        ld_ops<0, 0>(std::make_integer_sequence<int, Pass<0>::n_ld>{}, d, base + 4 * PL);
+        ld_ops<0, 0>(std::make_integer_sequence<int, Pass<0>::n_ld>{}, d[0], base);
+        ld_ops<0, 0>(std::make_integer_sequence<int, Pass<0>::n_ld>{}, d[1], base + 4 * PL);
+        xf_ops<0, 0>(std::make_integer_sequence<int, Pass<0>::n_xf>{}, d[0], w, t, u, vb[0]);
         __builtin_amdgcn_sched_barrier(0);
     }
     pass<PL, CIN, TM, 0>(base, u_rsrc, ubase, u_lane, a, d, vb, Y);
@@ -901,14 +904,22 @@ __device__ __forceinline__ void reduce_scatter_96(const float (&vals)[96], float
 
 }  // namespace f4
 
-// 4 waves, one per SIMD: wave w owns output-channel tiles {2w, 2w+1} of conv3 and tile w of conv2 for the whole
-// board.  Persistent workgroups, LDS layout, conv1, observation prefetch and the feature epilogue as in
-// k_trunk_wino.
-__global__ __launch_bounds__(256) void k_trunk_wino_f4(NetDev nd, const float *__restrict__ obs,
-                                                       float *__restrict__ feat, int n_boards) {
+// W waves per workgroup: wave w owns the 8 / W output-channel tiles {w*8/W ..} of conv3 for the whole board;
+// conv2 (4 tiles) runs on waves 0..3.
+//   W = 4 (default): two tiles per wave, one wave per SIMD with up to 512 registers.  A wave does not overlap
+//     its own MFMAs with its own vector work (measured: time = MFMA + VALU), so the transform is exposed --
+//     but it is done once per SIMD.
+//   W = 8: one tile per wave, two waves per SIMD (<= 256 registers each, spills) that do overlap -- but every
+//     wave forms the transformed input of the whole board itself, and the doubled vector work makes it 40 %
+//     slower than W = 4 (kept selectable as RZ_NET_WINOGRAD_F4_8W).
+// Persistent workgroups, LDS layout, conv1, observation prefetch and the feature epilogue as in k_trunk_wino.
+template <int W>
+__global__ __launch_bounds__(64 * W) void k_trunk_wino_f4(NetDev nd, const float *__restrict__ obs,
+                                                          float *__restrict__ feat, int n_boards) {
     constexpr int PL = kPlaneWino;
     constexpr int kLdsFloats = kPlanes * PL;
-    constexpr int kThreads = 256;
+    constexpr int kThreads = 64 * W;
+    constexpr int TM3 = 8 / W;
     constexpr int kPartialFloats = 4 * 6 * 256;
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats + kPartialFloats];
     float *in0 = lds;
@@ -967,19 +978,21 @@ __global__ __launch_bounds__(256) void k_trunk_wino_f4(NetDev nd, const float *_
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int next_board = board + (int)gridDim.x;
-    {   // conv1: 4 -> 32 direct: output tile (wave & 1), board rows 8 * (wave >> 1) ..
-        const int tile = wave & 1, row0 = 8 * (wave >> 1);
+    {   // conv1: 4 -> 32 direct: output tile (wave & 1), board rows (32 / W) * (wave >> 1) ..
+        constexpr int kRowsPer = 32 / W;
+        const int tile = wave & 1, row0 = kRowsPer * (wave >> 1);
         if (row0 < BH) {
             f32x4 acc[1][8];
             zero_acc<1>(acc);
-            conv_rows<PL, 4, 1>(in0, nd.w1, tile, row0, (BH - row0 == 7) ? 7 : 8, lane, acc);
-            store_relu<PL, 1>(c1, nd.b1, tile, row0, lane, BH, BW, acc, 8);
+            if (kRowsPer == 4) conv_accumulate<PL, 4, 1, 4>(in0, nd.w1, tile, row0, lane, acc);
+            else conv_rows<PL, 4, 1>(in0, nd.w1, tile, row0, (BH - row0 == 7) ? 7 : 8, lane, acc);
+            store_relu<PL, 1>(c1, nd.b1, tile, row0, lane, BH, BW, acc, kRowsPer);
         }
     }
     __syncthreads();
     if (next_board < n_boards) load_obs(next_board, tid);
     const int q = lane >> 4, ty = (lane >> 2) & 3, tx = lane & 3;
-    {   // conv2: 32 -> 64, one output-channel tile per wave
+    if (wave < 4) {  // conv2: 32 -> 64, one output-channel tile per wave (waves 0..3)
         f32x4 a2[4][1][3];
         f32x4 Y[1][16];
         f4::preload_u<32, 1>(nd.u2f, wave, lane, a2);
@@ -998,18 +1011,18 @@ __global__ __launch_bounds__(256) void k_trunk_wino_f4(NetDev nd, const float *_
     }
     if (next_board < n_boards) store_obs(tid);
     __syncthreads();
-    {   // conv3: 64 -> 128, two tiles per wave; the ReLU'd output feeds the two 1x1 head convolutions
+    {   // conv3: 64 -> 128, TM3 tiles per wave; the ReLU'd output feeds the two 1x1 head convolutions
         float vals[96];  // index pos*6 + o, pos = p*4 + q
 #pragma unroll
         for (int i = 0; i < 96; ++i) vals[i] = 0.0f;
         {
-            f32x4 a3[4][2][3];
-            f32x4 Y[2][16];
-            f4::preload_u<64, 2>(nd.u3f, 2 * wave, lane, a3);
-            f4::conv<PL, 64, 2>(c2, nd.u3f, 2 * wave, lane, a3, Y);
+            f32x4 a3[4][TM3][3];
+            f32x4 Y[TM3][16];
+            f4::preload_u<64, TM3>(nd.u3f, TM3 * wave, lane, a3);
+            f4::conv<PL, 64, TM3>(c2, nd.u3f, TM3 * wave, lane, a3, Y);
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const int c0 = (2 * wave + m) * 16 + 4 * q;
+            for (int m = 0; m < TM3; ++m) {
+                const int c0 = (TM3 * wave + m) * 16 + 4 * q;
                 const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b3 + c0);
                 f32x4 wv[6];
 #pragma unroll
@@ -1026,12 +1039,27 @@ __global__ __launch_bounds__(256) void k_trunk_wino_f4(NetDev nd, const float *_
         }
         float sums[24];
         f4::reduce_scatter_96(vals, sums);
+        // partial sums of the waves: [wave & 3][o][y][x]; with 8 waves, wave w + 4 stores first and wave w adds
+        // its own on top (fixed order: the result does not depend on timing)
         const int off = (q & 1) * 48 + (q >> 1) * 24;
+        if (W == 4 || wave >= 4) {
 #pragma unroll
-        for (int i = 0; i < 24; ++i) {
-            const int vi = off + i, pq = vi / 6, o = vi - 6 * pq;
-            const int y = 4 * ty + (pq >> 2), x = 4 * tx + (pq & 3);
-            partial[((wave * 6 + o) * 16 + y) * 16 + x] = sums[i];
+            for (int i = 0; i < 24; ++i) {
+                const int vi = off + i, pq = vi / 6, o = vi - 6 * pq;
+                const int y = 4 * ty + (pq >> 2), x = 4 * tx + (pq & 3);
+                partial[(((wave & 3) * 6 + o) * 16 + y) * 16 + x] = sums[i];
+            }
+        }
+        if (W == 8) {
+            __syncthreads();
+            if (wave < 4) {
+#pragma unroll
+                for (int i = 0; i < 24; ++i) {
+                    const int vi = off + i, pq = vi / 6, o = vi - 6 * pq;
+                    const int y = 4 * ty + (pq >> 2), x = 4 * tx + (pq & 3);
+                    partial[((wave * 6 + o) * 16 + y) * 16 + x] += sums[i];
+                }
+            }
         }
     }
     __syncthreads();
@@ -1570,7 +1598,9 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
     else if (net->algo == RZ_NET_WINOGRAD_4W)
         k_trunk_wino<2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
     else if (net->algo == RZ_NET_WINOGRAD_F4)
-        k_trunk_wino_f4<<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
+        k_trunk_wino_f4<4><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
+    else if (net->algo == RZ_NET_WINOGRAD_F4_8W)
+        k_trunk_wino_f4<8><<<pgrid, dim3(512), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
     else
         k_trunk<<<grid, dim3(kTrunkThreads), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
 }
@@ -1603,7 +1633,7 @@ int rz_net_trunk(rz_net *net, const float *d_obs, int32_t n_boards, float *d_fea
 
 int rz_net_set_algo(rz_net *net, int32_t algo) {
     if (!net) return net_fail(RZ_ERR_ARG, "net handle is NULL");
-    if (algo != RZ_NET_DIRECT && algo != RZ_NET_WINOGRAD && algo != RZ_NET_WINOGRAD_4W && algo != RZ_NET_WINOGRAD_F4)
+    if (algo < RZ_NET_DIRECT || algo > RZ_NET_WINOGRAD_F4_8W)
         return net_fail(RZ_ERR_ARG, "unknown algorithm");
     net->algo = algo;
     return RZ_OK;

@@ -105,7 +105,7 @@ class HipNet(object):
         """conv2 / conv3 algorithm, all fp32 MFMA: 'winograd_f4' (default, F(4x4,3x3)), 'winograd' /
         'winograd4w' (F(2x2,3x3), 8 / 4 waves per board) or 'direct' (bit-for-bit a k-ordered fmaf chain)."""
         code = {'direct': _hip.NET_DIRECT, 'winograd': _hip.NET_WINOGRAD, 'winograd4w': _hip.NET_WINOGRAD_4W,
-                'winograd_f4': _hip.NET_WINOGRAD_F4}[algo]
+                'winograd_f4': _hip.NET_WINOGRAD_F4, 'winograd_f4_8w': _hip.NET_WINOGRAD_F4_8W}[algo]
         check(self.lib.rz_net_set_algo(self.handle, code), 'rz_net_set_algo')
         return self
 

@@ -540,7 +540,7 @@ def test_hip_net_vs_golden_and_torch(g4):
     import torch
     from rlzero_amd.engine import HipNet
     from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
-    for B, algo in [(b, a) for b in (3, 6, 9, 15) for a in ('winograd', 'winograd4w', 'winograd_f4', 'direct')]:
+    for B, algo in [(b, a) for b in (3, 6, 9, 15) for a in ('winograd', 'winograd4w', 'winograd_f4', 'winograd_f4_8w', 'direct')]:
         weights = ev.numpy_weights(B, int(g4['B%d_seed' % B]))
         hip = HipNet(B, 'cuda:0', max_boards=16).load_state_dict(weights).set_algo(algo)
         obs = torch.from_numpy(g4['B%d_obs' % B].astype(np.float32)).to('cuda:0')

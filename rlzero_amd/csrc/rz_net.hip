@@ -5,19 +5,19 @@
 // 15x15 position, MFMA-bound).  Exact fp32: v_mfma_f32_16x16x4_f32 is a k-ordered fmaf
 // chain, no reduced precision anywhere (tolerance vs the reference's CPU output: 1e-4).
 //
-// k_trunk: ONE workgroup (8 waves) per board.  The board's activations never leave the CU:
-// input planes, conv1 output (32 ch) and conv2 output (64 ch) live in LDS as halo-padded
-// planes [channel][18 rows][18 cols] (plane stride 336 floats = 16 mod 32 banks: the 4 channel
-// sub-groups of a fragment read hit disjoint banks); conv3's 128 channels stay in the MFMA
-// accumulators and are consumed by the two 1x1 head convolutions in registers.  Implicit GEMM
-// per layer: M = output channels (A = weights, pre-packed on the host in fragment order,
-// streamed from L2 with 16-byte loads), N = the 16 columns of one board row (B = ds_read_b32
-// from the halo planes), K = (group of 4 input channels, tap).  Wave w = 4*rh + q4 owns
-// output-channel quarter q4 and row half rh (8 + 7 rows on a 15x15 board; the two waves of a
-// quarter share a SIMD, so every SIMD carries 15 row-units: no padded row is computed).  Per
-// channel group the (NR+2) x 3 distinct (row, dx) fragments are read once and reused by the
-// 9 taps x NR rows; the next group's fragments are in flight under this group's MFMAs.
-// k_heads_gemm + k_heads_finish: the three fully connected layers, log_softmax and tanh.
+// Kernels (one workgroup owns a board; its activations never leave the CU: input planes, conv1 output (32 ch)
+// and conv2 output (64 ch) live in LDS as halo-padded planes [channel][18 rows][18 cols]; conv3's 128 channels
+// stay in registers and are consumed by the two 1x1 head convolutions there):
+//   k_trunk_wino_f4<4> (default)  conv2 / conv3 as Winograd F(4x4,3x3), persistent workgroups, 4 waves
+//   k_trunk_wino_f4<8>            same arithmetic, 8 waves
+//   k_trunk_wino<4> / <2>         Winograd F(2x2,3x3), 8 / 4 waves
+//   k_trunk                       direct implicit GEMM (bit-for-bit a k-ordered fmaf chain): M = output channels
+//                                 (A = weights, pre-packed on the host in fragment order, streamed from L2), N =
+//                                 the 16 columns of a board row (B = ds_read_b32 from the halo planes), K =
+//                                 (group of 4 input channels, tap); wave w = 4*rh + q4 owns channel quarter q4
+//                                 and row half rh
+//   k_heads_gemm, k_heads_finish  the fully connected layers (32 x 32 output blocks), log_softmax and tanh
+// Every kernel and its design notes are described where it is defined.
 
 #include <hip/hip_runtime.h>
 

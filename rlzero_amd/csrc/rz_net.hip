@@ -1012,12 +1012,13 @@ __global__ __launch_bounds__(64 * W) void k_trunk_wino_f4(NetDev nd, const float
     if (next_board < n_boards) store_obs(tid);
     __syncthreads();
     {   // conv3: 64 -> 128, TM3 tiles per wave; the ReLU'd output feeds the two 1x1 head convolutions
-        float vals[96];  // index pos*6 + o, pos = p*4 + q
+        // head partial sums, packed in pairs of outputs (o, o+1): index pos*3 + o/2, pos = p*4 + q
+        f32x2 vals2[48];
 #pragma unroll
-        for (int i = 0; i < 96; ++i) vals[i] = 0.0f;
+        for (int i = 0; i < 48; ++i) vals2[i] = f32x2{0.0f, 0.0f};
         {
-            f32x4 a3[4][TM3][3];
             f32x4 Y[TM3][16];
+            f32x4 a3[4][TM3][3];
             f4::preload_u<64, TM3>(nd.u3f, TM3 * wave, lane, a3);
             f4::conv<PL, 64, TM3>(c2, nd.u3f, TM3 * wave, lane, a3, Y);
 #pragma unroll
@@ -1033,10 +1034,15 @@ __global__ __launch_bounds__(64 * W) void k_trunk_wino_f4(NetDev nd, const float
                     for (int j = 0; j < 4; ++j) {
                         const float hv = fmaxf(Y[m][pq][j] + bv[j], 0.0f);
 #pragma unroll
-                        for (int o = 0; o < 6; ++o) vals[pq * 6 + o] = fmaf(wv[o][j], hv, vals[pq * 6 + o]);
+                        for (int o2 = 0; o2 < 3; ++o2)  // one v_pk_fma_f32 per pair of head outputs
+                            vals2[pq * 3 + o2] = __builtin_elementwise_fma(f32x2{wv[2 * o2][j], wv[2 * o2 + 1][j]},
+                                                                           f32x2{hv, hv}, vals2[pq * 3 + o2]);
                     }
             }
         }
+        float vals[96];
+#pragma unroll
+        for (int i = 0; i < 96; ++i) vals[i] = vals2[i >> 1][i & 1];
         float sums[24];
         f4::reduce_scatter_96(vals, sums);
         // partial sums of the waves: [wave & 3][o][y][x]; with 8 waves, wave w + 4 stores first and wave w adds

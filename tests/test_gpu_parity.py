@@ -585,6 +585,39 @@ def test_hip_net_vs_golden_and_torch(g4):
     hip.close()
 
 
+def test_trunk_is_deterministic_under_load():
+    """The default trunk accumulates with an inline-assembly MFMA whose register hazards are kept by hand
+    (DESIGN.md section 7): a violated hazard would be timing dependent, so 60 launches of a full 512-board batch,
+    alone and beside a second stream that keeps the small kernels busy, must give bit-identical features that
+    also agree with the direct kernel."""
+    import torch
+    from rlzero_amd.engine import HipNet
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    torch.manual_seed(11)
+    net = PolicyValueNet(15)
+    hip = HipNet(15, 'cuda:0', max_boards=512).load_state_dict(net.state_dict())
+    x = (torch.rand((512, 4, 15, 15), device='cuda:0') > 0.5).float()
+    ref = hip.set_algo('direct').trunk(x).clone()
+    for algo, caps in (('winograd_f4', (0, 224)), ('winograd', (0, ))):
+        hip.set_algo(algo)
+        first = None
+        side = torch.cuda.Stream()
+        busy = torch.rand((2048, 2048), device='cuda:0')
+        for it in range(60):
+            hip.set_max_workgroups(caps[it % len(caps)])
+            if it % 3 == 0:
+                with torch.cuda.stream(side):
+                    busy = (busy @ busy).clamp_(-1, 1)
+            out = hip.trunk(x)
+            if first is None:
+                first = out.clone()
+                assert float((first - ref).abs().max()) < 5e-6
+            else:
+                assert torch.equal(out, first)
+        torch.cuda.synchronize()
+    hip.close()
+
+
 def test_search_with_hip_net_equals_search_with_its_values():
     """Tree built with the HIP net evaluator == oracle tree fed the very same fp32 values
     (the net's value reaches the tree unchanged; a 512-game batch runs clean)."""

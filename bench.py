@@ -56,7 +56,8 @@ def executed_flop_ratio(args, cells):
     (15x15): conv2 2048 + conv3 8192 + conv1 270 MFMAs of 2048 flops per board; the 1x1 heads are VALU."""
     if args.evaluator != 'hipnet' or args.game != 'gomoku' or args.board != 15:
         return 1.0
-    mfmas = {'winograd': 10510, 'winograd4w': 10510, 'winograd_f4': 6030, 'winograd_f4_8w': 6030, 'direct': 21870}[args.net_algo]
+    mfmas = {'winograd': 10510, 'winograd4w': 10510, 'winograd_f4': 6030, 'winograd_f4_8w': 6030, 'direct': 21870,
+             'split_f16': 4320 * 16 + 270}[args.net_algo]
     return mfmas * 2048.0 / trunk_flops_per_position(cells)
 
 
@@ -291,7 +292,7 @@ def main():
                     help="hipnet: hand-written fused fp32 MFMA forward (csrc/rz_net.hip); torchnet: "
                          "PyTorch-ROCm/MIOpen; vlin: synthetic evaluator (isolates the tree kernels)")
     ap.add_argument('--graph', type=int, default=8, help='simulation steps per hipGraph (0 = eager)')
-    ap.add_argument('--net-algo', default='winograd_f4', choices=['winograd', 'winograd4w', 'winograd_f4', 'winograd_f4_8w', 'direct'])
+    ap.add_argument('--net-algo', default='winograd_f4', choices=['winograd', 'winograd4w', 'winograd_f4', 'winograd_f4_8w', 'direct', 'split_f16'])
     ap.add_argument('--lanes', type=int, default=2,
                     help='independent batches of games on separate HIP streams (the tree / FC kernels of one '
                          'lane run beside the network trunk of the other)')
@@ -360,6 +361,7 @@ def main():
                                  'winograd4w': 'k_trunk_wino<2> (same, 4 waves per board)',
                                  'winograd_f4_8w': 'k_trunk_wino_f4<8> (same, 8 waves per board)',
                                  'winograd_f4': 'k_trunk_wino_f4<4> (hand-written fused fp32-MFMA conv trunk, Winograd F(4x4,3x3), csrc/rz_net.hip)',
+                                 'split_f16': 'k_trunk_split (hand-written fused conv trunk: direct convolution on the f16 matrix pipe, f32 operands as hi + lo f16 pairs, f32 accumulation, csrc/rz_net.hip)',
                                  'direct': 'k_trunk (hand-written fused fp32-MFMA conv trunk, direct, csrc/rz_net.hip)'}[args.net_algo])
         elif args.evaluator == 'torchnet':
             ev = TimedEvaluator(NetEvaluator(net), torch, 'torch/MIOpen forward (~14 kernels)')

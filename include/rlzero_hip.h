@@ -265,8 +265,15 @@ enum {
     RZ_NET_WINOGRAD_F4 = 3,  /* default: conv2/conv3 as Winograd F(4x4,3x3): 4x fewer multiply-adds than DIRECT; fp32
                                 throughout, ~1e-6 absolute on the activations (one digit more than F(2x2,3x3));
                                 4 waves per board, two output-channel tiles each, one per SIMD */
-    RZ_NET_WINOGRAD_F4_8W = 4 /* same arithmetic, 8 waves per board with one tile each (two per SIMD; slower) */
+    RZ_NET_WINOGRAD_F4_8W = 4, /* same arithmetic, 8 waves per board with one tile each (two per SIMD; slower) */
+    RZ_NET_SPLIT_F16 = 5 /* conv2/conv3 as direct convolutions on the f16 matrix pipe with every f32 operand carried
+                            as hi + lo (two f16 values, 22 significant bits) and every product as hi*hi + hi*lo +
+                            lo*hi accumulated in f32: within a few 1e-7 (relative) of the f32 kernels.  Scaled
+                            activations must stay below 65504 / 16: a larger one sets RZ_NET_FLAG_F16_RANGE */
 };
+/* rz_net_error_flags: sticky bits set by the kernels since creation / the last call (synchronises the device) */
+enum { RZ_NET_FLAG_F16_RANGE = 1 };
+int rz_net_error_flags(rz_net *net, uint32_t *h_flags);
 int rz_net_set_algo(rz_net *net, int32_t algo);
 /* The Winograd trunk runs as persistent workgroups (one per CU: its LDS and registers fill a CU),
  * each looping over its boards.  max_workgroups > 0 caps their number so that the remaining CUs stay

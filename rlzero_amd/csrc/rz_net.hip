@@ -49,6 +49,8 @@ struct NetDev {
     const f32x4 *w1, *w2, *w3;   // packed [tile][cin_step][3][64 lanes] x 4 taps
     const f32x4 *u2, *u3;        // Winograd-domain weights of conv2 / conv3: [tile][i'][cin_step][64 lanes] x 4 j'
     const f32x4 *u2f, *u3f;      // F(4x4,3x3): [tile][pass][cin_step][3][64 lanes] x 4 components (pack_wino_f4)
+    const f32x4 *s2, *s3;        // split f16 weights: [32-channel tile][tap][16-channel chunk][hi | lo][64 lanes] x 8 f16
+    float s2_inv, s3_inv;        // 1 / (activation scale * weight scale) of conv2 / conv3 (pack_split)
     const float *b1, *b2, *b3;   // conv biases
     const float *wh;             // [6][128]: act_conv1 (4 rows) then val_conv1 (2 rows)
     const float *bh;             // [6]
@@ -1083,6 +1085,317 @@ __global__ __launch_bounds__(64 * W) void k_trunk_wino_f4(NetDev nd, const float
     }  // boards
 }
 
+// ------------------------------------------------------------------ split-operand direct convolution
+// conv2 / conv3 as DIRECT 3x3 convolutions on the f16 matrix pipe (v_mfma_f32_32x32x16_f16: 16x the rate of
+// the f32-input MFMA, which runs at the vector rate and does not overlap with vector work at all -- DESIGN.md
+// section 5), with every f32 operand carried as an unevaluated sum of two f16 values:
+//     x * s = hi + lo,  hi = f16(x * s),  lo = f16(x * s - hi)           (s: a power of two, see below)
+// and every product formed as hi*hi + hi*lo + lo*hi on three MFMAs that accumulate in f32.  hi + lo holds 22
+// significant bits of x and the dropped lo*lo term is below 2^-22 of the product, so the result is within a
+// few 1e-7 (relative) of the f32 kernels -- the level of their own accumulation rounding (measured in
+// tests/test_gpu_parity.py; the tolerance of the path is 1e-4).  Scales keep the lo halves out of f16's
+// subnormal range: activations are stored times kActScale = 16 (exact range up to 4094, an overflow raises
+// RZ_NET_FLAG_F16_RANGE), the weights of a layer times the power of two that brings their largest magnitude
+// into [2^13, 2^14); the accumulator is rescaled (exactly) in the epilogue.
+//   * LDS: conv1's and conv2's outputs as [piece][18 rows][18 cols][channels + 8] f16, channels innermost, so
+//     the B fragment of a lane (8 consecutive input channels of one position) is ONE ds_read_b128; position
+//     strides of 80 / 144 bytes spread the 8 lanes of an LDS cycle over all 64 banks.  150.5 KB + 12 KB of
+//     head partial sums.
+//   * MFMA tile: M = 32 output channels, N = 32 positions = two board rows x 16 columns, K = 16 input channels
+//     of one tap.  A wave owns 2 M-tiles x TN N-tiles (conv2: TN = 2, all four waves on different rows; conv3:
+//     TN = 4, wave = (channel half, board half)), so one K-step is 6*TN MFMAs on 4 weight fragments (buffer
+//     loads from L2, packed on the host in fragment order, two steps ahead) and 2*TN activation fragments (one
+//     step ahead); one load is pinned behind each of the first MFMAs of the step.
+//   * conv1 (4 -> 32, 2 % of the work) stays on the exact f32 path of the other kernels and writes its output
+//     as hi / lo pieces; conv3's output feeds the two 1x1 head convolutions from registers in f32.
+namespace sp {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef const __attribute__((address_space(3))) f16x8 *lds_frag;
+
+constexpr float kActScale = 16.0f;
+constexpr int kGridPos = 18 * 18;
+template <int CIN> struct Geo {
+    static constexpr int pos_bytes = (CIN + 8) * 2;          // 80 / 144
+    static constexpr int piece_bytes = kGridPos * pos_bytes;  // 25 920 / 46 656
+    static constexpr int chunks = CIN / 16, steps = 9 * chunks;
+};
+constexpr int kC1Bytes = 2 * Geo<32>::piece_bytes, kC2Bytes = 2 * Geo<64>::piece_bytes;
+constexpr int kInFloats = kPlanesIn * kPlaneWino;
+constexpr int kPartialFloats = 2 * 6 * 256;
+constexpr int kLdsBytes = kInFloats * 4 + kC1Bytes + kC2Bytes + kPartialFloats * 4;
+static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+static_assert((kInFloats * 4) % 16 == 0, "piece alignment");
+
+__device__ __forceinline__ f16x8 load_w(__amdgpu_buffer_rsrc_t rsrc, int lane_off, int uniform_off) {
+    return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, uniform_off, 0));
+}
+
+// x (already scaled) -> hi, lo
+__device__ __forceinline__ void split4(const float (&z)[4], f16x4 &hi, f16x4 &lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        hi[j] = (_Float16)z[j];
+        lo[j] = (_Float16)(z[j] - (float)hi[j]);
+    }
+}
+
+// slot I of K-step S: MFMA I of the step plus (behind the first MFMAs) one load of a coming step
+template <int CIN, int TN, int S, int I>
+__device__ __forceinline__ void slot(f32x16 (&acc)[2][TN], f16x8 (&a)[3][2][2], f16x8 (&b)[2][TN][2], lds_frag q0,
+                                     lds_frag q1, __amdgpu_buffer_rsrc_t w_rsrc, int w_base, int w_lane) {
+    using G = Geo<CIN>;
+    constexpr int combo = I / (2 * TN), m = (I / TN) % 2, n = I % TN;
+    constexpr int pa = combo == 2 ? 1 : 0, pb = combo == 1 ? 1 : 0;
+    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[S % 3][m][pa], b[S % 2][n][pb], acc[m][n], 0, 0, 0);
+    if constexpr (I < 2 * TN) {
+        if constexpr (S + 1 < G::steps) {
+            constexpr int s1 = S + 1, tap = s1 / G::chunks, c = s1 % G::chunks, nn = I / 2, piece = I % 2;
+            constexpr int off = ((2 * nn + tap / 3) * kRowW + tap % 3) * G::pos_bytes + c * 32;
+            static_assert(off % 16 == 0 && off < 65536, "ds_read_b128 immediate");
+            b[s1 % 2][nn][piece] = (piece ? q1 : q0)[off / 16];
+        }
+    } else if constexpr (I < 2 * TN + 4) {
+        if constexpr (S + 2 < G::steps) {
+            constexpr int s2 = S + 2, j = I - 2 * TN, mm = j / 2, piece = j % 2;
+            a[s2 % 3][mm][piece] = load_w(w_rsrc, w_lane, w_base + ((mm * G::steps + s2) * 2 + piece) * 1024);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int CIN, int TN, int S, int... Is>
+__device__ __forceinline__ void step(std::integer_sequence<int, Is...>, f32x16 (&acc)[2][TN], f16x8 (&a)[3][2][2],
+                                     f16x8 (&b)[2][TN][2], lds_frag q0, lds_frag q1, __amdgpu_buffer_rsrc_t w_rsrc,
+                                     int w_base, int w_lane) {
+    (slot<CIN, TN, S, Is>(acc, a, b, q0, q1, w_rsrc, w_base, w_lane), ...);
+}
+
+template <int CIN, int TN, int... Ss>
+__device__ __forceinline__ void steps(std::integer_sequence<int, Ss...>, f32x16 (&acc)[2][TN], f16x8 (&a)[3][2][2],
+                                      f16x8 (&b)[2][TN][2], lds_frag q0, lds_frag q1, __amdgpu_buffer_rsrc_t w_rsrc,
+                                      int w_base, int w_lane) {
+    (step<CIN, TN, Ss>(std::make_integer_sequence<int, 6 * TN>{}, acc, a, b, q0, q1, w_rsrc, w_base, w_lane), ...);
+}
+
+// acc[m][n] = sum over taps and input channels for M-tiles mt0, mt0 + 1 and N-tiles nt0 .. nt0 + TN - 1
+// (`in` = piece 0 of the layer's input in LDS).
+template <int CIN, int TN>
+__device__ __forceinline__ void conv(const char *in, const void *wts, int mt0, int nt0, int lane,
+                                     f32x16 (&acc)[2][TN]) {
+    using G = Geo<CIN>;
+    const int n = lane & 31, h = lane >> 5;
+    // halo position (row 2*nt0 + (n >> 4), column n & 15) = the top-left tap of output (2*nt0 + (n >> 4), n & 15)
+    const int lane_byte = ((2 * nt0 + (n >> 4)) * kRowW + (n & 15)) * G::pos_bytes + h * 16;
+    const lds_frag q0 = (lds_frag)(in + lane_byte), q1 = (lds_frag)(in + lane_byte + G::piece_bytes);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(wts), 0, 0x7fffffff, 0x00020000);
+    const int w_base = mt0 * G::steps * 2048, w_lane = lane * 16;
+    f16x8 a[3][2][2], b[2][TN][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) a[s][m][p] = load_w(w_rsrc, w_lane, w_base + ((m * G::steps + s) * 2 + p) * 1024);
+#pragma unroll
+    for (int nn = 0; nn < TN; ++nn) {
+        b[0][nn][0] = q0[(2 * nn * kRowW * G::pos_bytes) / 16];
+        b[0][nn][1] = q1[(2 * nn * kRowW * G::pos_bytes) / 16];
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int nn = 0; nn < TN; ++nn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.0f;
+    __builtin_amdgcn_sched_barrier(0);
+    steps<CIN, TN>(std::make_integer_sequence<int, G::steps>{}, acc, a, b, q0, q1, w_rsrc, w_base, w_lane);
+}
+
+}  // namespace sp
+
+__global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__restrict__ obs,
+                                                     float *__restrict__ feat, int n_boards,
+                                                     unsigned *__restrict__ flags) {
+    constexpr int PL = kPlaneWino;
+    constexpr int kThreads = 256;
+    __shared__ __attribute__((aligned(16))) char lds_raw[sp::kLdsBytes];
+    float *in0 = reinterpret_cast<float *>(lds_raw);
+    char *c1 = lds_raw + sp::kInFloats * 4;   // conv1 output, pieces hi | lo
+    char *c2 = c1 + sp::kC1Bytes;             // conv2 output, pieces hi | lo
+    float *partial = reinterpret_cast<float *>(c2 + sp::kC2Bytes);  // [channel half][o][y][x]
+    const int tid0 = threadIdx.x;
+    const int BH = nd.BH, BW = nd.BW, S = nd.S;
+    {
+        f32x4 *z = reinterpret_cast<f32x4 *>(lds_raw);
+        for (int i = tid0; i < sp::kLdsBytes / 16; i += kThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    constexpr int kObsPer = (4 * RZ_MAX_BOARD_SIZE * RZ_MAX_BOARD_SIZE + kThreads - 1) / kThreads;
+    float ob[kObsPer];
+    auto load_obs = [&](int board, int tid) {
+        const float *src = obs + (size_t)board * 4 * S;
+#pragma unroll
+        for (int k = 0; k < kObsPer; ++k) {
+            const int i = tid + k * kThreads;
+            ob[k] = i < 4 * S ? src[i] : 0.0f;
+        }
+    };
+    int obs_off[kObsPer];
+#pragma unroll
+    for (int k = 0; k < kObsPer; ++k) {
+        const int i = tid0 + k * kThreads;
+        const int c = i / S, r = i - c * S, y = r / BW, x = r - y * BW;
+        obs_off[k] = i < 4 * S ? c * PL + (y + 1) * kRowW + (x + 1) : -1;
+    }
+    constexpr int kFeatPer = (6 * RZ_MAX_BOARD_SIZE * RZ_MAX_BOARD_SIZE + kThreads - 1) / kThreads;
+    int feat_src[kFeatPer], feat_dst[kFeatPer];
+    float feat_bias[kFeatPer];
+#pragma unroll
+    for (int k = 0; k < kFeatPer; ++k) {
+        const int i = tid0 + k * kThreads;
+        const int o = i / S, r = i - o * S, y = r / BW, x = r - y * BW;
+        feat_src[k] = (o * 16 + y) * 16 + x;
+        feat_dst[k] = i < 6 * S ? (i < 4 * S ? i : i - 4 * S + nd.feat_val_off) : -1;
+        feat_bias[k] = i < 6 * S ? nd.bh[o] : 0.0f;
+    }
+    auto store_obs = [&](int) {
+#pragma unroll
+        for (int k = 0; k < kObsPer; ++k)
+            if (obs_off[k] >= 0) in0[obs_off[k]] = ob[k];
+    };
+    __syncthreads();
+    if ((int)blockIdx.x < n_boards) {
+        load_obs(blockIdx.x, tid0);
+        store_obs(tid0);
+    }
+    __syncthreads();
+    float zmax = 0.0f;  // largest scaled activation this thread stored
+    for (int board = blockIdx.x; board < n_boards; board += gridDim.x) {
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int next_board = board + (int)gridDim.x;
+    {   // conv1: 4 -> 32, exact f32 MFMA: output tile (wave & 1), board rows 8 * (wave >> 1) ..
+        const int tile = wave & 1, row0 = 8 * (wave >> 1);
+        if (row0 < BH) {
+            f32x4 acc[1][8];
+            zero_acc<1>(acc);
+            conv_rows<PL, 4, 1>(in0, nd.w1, tile, row0, (BH - row0 == 7) ? 7 : 8, lane, acc);
+            const int x = lane & 15, q = lane >> 4, c0 = tile * 16 + 4 * q;
+            if (x < BW) {
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b1 + c0);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int y = row0 + t;
+                    if (y >= BH) continue;
+                    float z[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        z[j] = fmaxf(acc[0][t][j] + bv[j], 0.0f) * sp::kActScale;
+                        zmax = fmaxf(zmax, z[j]);
+                    }
+                    sp::f16x4 hi, lo;
+                    sp::split4(z, hi, lo);
+                    char *dst = c1 + ((y + 1) * kRowW + (x + 1)) * sp::Geo<32>::pos_bytes + c0 * 2;
+                    *reinterpret_cast<sp::f16x4 *>(dst) = hi;
+                    *reinterpret_cast<sp::f16x4 *>(dst + sp::Geo<32>::piece_bytes) = lo;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (next_board < n_boards) load_obs(next_board, tid);
+    const int n = lane & 31, h = lane >> 5;
+    {   // conv2: 32 -> 64: both M-tiles, N-tiles 2*wave, 2*wave + 1 (board rows 4*wave .. 4*wave + 3)
+        sp::f32x16 acc[2][2];
+        sp::conv<32, 2>(c1, nd.s2, 0, 2 * wave, lane, acc);
+        const int x = n & 15;
+        const float k2 = nd.s2_inv * sp::kActScale;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = m * 32 + 8 * g + 4 * h;
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b2 + c0);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int y = 4 * wave + 2 * t + (n >> 4);
+                    float z[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) z[j] = fmaxf(fmaf(acc[m][t][4 * g + j], k2, bv[j] * sp::kActScale), 0.0f);
+                    if (y < BH && x < BW) {
+                        zmax = fmaxf(fmaxf(zmax, fmaxf(z[0], z[1])), fmaxf(z[2], z[3]));
+                        sp::f16x4 hi, lo;
+                        sp::split4(z, hi, lo);
+                        char *dst = c2 + ((y + 1) * kRowW + (x + 1)) * sp::Geo<64>::pos_bytes + c0 * 2;
+                        *reinterpret_cast<sp::f16x4 *>(dst) = hi;
+                        *reinterpret_cast<sp::f16x4 *>(dst + sp::Geo<64>::piece_bytes) = lo;
+                    }
+                }
+            }
+    }
+    if (next_board < n_boards) store_obs(tid);
+    __syncthreads();
+    {   // conv3: 64 -> 128: wave = (channel half mp, board half nh); its ReLU'd output feeds the 1x1 head convs
+        const int mp = wave & 1, nh = wave >> 1;
+        f32x2 vals2[4][3];  // [position][pair of head outputs]
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int o2 = 0; o2 < 3; ++o2) vals2[t][o2] = f32x2{0.0f, 0.0f};
+        {
+            sp::f32x16 acc[2][4];
+            sp::conv<64, 4>(c2, nd.s3, 2 * mp, 4 * nh, lane, acc);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int c0 = (2 * mp + m) * 32 + 8 * g + 4 * h;
+                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b3 + c0);
+                    f32x4 wv[6];
+#pragma unroll
+                    for (int o = 0; o < 6; ++o) wv[o] = *reinterpret_cast<const f32x4 *>(nd.wh + o * 128 + c0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float hv = fmaxf(fmaf(acc[m][t][4 * g + j], nd.s3_inv, bv[j]), 0.0f);
+#pragma unroll
+                            for (int o2 = 0; o2 < 3; ++o2)
+                                vals2[t][o2] = __builtin_elementwise_fma(f32x2{wv[2 * o2][j], wv[2 * o2 + 1][j]},
+                                                                         f32x2{hv, hv}, vals2[t][o2]);
+                        }
+                }
+        }
+        // the two lane halves hold different channels of the same positions
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int o = 0; o < 6; ++o) {
+                float v = vals2[t][o >> 1][o & 1];
+                v += __shfl_xor(v, 32);
+                if (h == 0) {
+                    const int y = 8 * nh + 2 * t + (n >> 4);
+                    partial[((mp * 6 + o) * 16 + y) * 16 + (n & 15)] = v;
+                }
+            }
+    }
+    __syncthreads();
+    {
+        float *dst = feat + (size_t)board * nd.feat_ld;
+#pragma unroll
+        for (int k = 0; k < kFeatPer; ++k) {
+            if (feat_dst[k] < 0) continue;
+            const float v = feat_bias[k] + partial[feat_src[k]] + partial[6 * 256 + feat_src[k]];
+            dst[feat_dst[k]] = fmaxf(v, 0.0f);
+        }
+    }
+    }  // boards
+    if (!(zmax <= 65504.0f)) atomicOr(flags, (unsigned)RZ_NET_FLAG_F16_RANGE);
+}
+
 // Direct path: wave w = 4*rh + q4 owns output-channel quarter q4 (the two waves of a quarter share
 // a SIMD, waves are dealt to SIMDs cyclically) and row half rh (rows 0-7 / 8-15; on a 15x15 board
 // the second half computes 7 rows, so every SIMD carries exactly 15 row-units of each layer).
@@ -1333,6 +1646,7 @@ struct rz_net {
     std::vector<size_t> alloc_bytes;
     size_t upload_cursor = 0;
     float *d_feat = nullptr, *d_raw = nullptr, *d_hid = nullptr;
+    unsigned *d_flags = nullptr;
     long long feat_boards = 0;
     size_t feat_floats = 0;
 };
@@ -1446,6 +1760,39 @@ std::vector<f32x4> pack_wino_f4(const float *w, int cout, int cin) {
     return out;
 }
 
+// Split f16 weights (k_trunk_split): w * scale = hi + lo with scale = the power of two that brings the
+// largest |w| of the layer into [2^13, 2^14).  Packed [tile of 32 cout][step = tap * chunks + chunk][piece][lane]
+// x 8 f16: lane = h*32 + r holds W[32*tile + r][16*chunk + 8*h + j][tap], j = 0..7 (the A fragment of
+// v_mfma_f32_32x32x16_f16).
+std::vector<f32x4> pack_split(const float *w, int cout, int cin, float *scale_out) {
+    float wmax = 0.0f;
+    for (size_t i = 0; i < (size_t)cout * cin * 9; ++i) wmax = std::fmax(wmax, std::fabs(w[i]));
+    int e = 0;
+    if (wmax > 0.0f && std::isfinite(wmax)) {
+        (void)std::frexp(wmax, &e);  // wmax = f * 2^e, f in [0.5, 1)
+        e = 14 - e;                  // wmax * 2^e in [2^13, 2^14)
+    }
+    const float scale = std::ldexp(1.0f, e);
+    *scale_out = scale;
+    const int tiles = cout / 32, chunks = cin / 16, steps = 9 * chunks;
+    std::vector<f32x4> out((size_t)tiles * steps * 2 * 64);
+    _Float16 *o = reinterpret_cast<_Float16 *>(out.data());
+    for (int t = 0; t < tiles; ++t)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int c = 0; c < chunks; ++c)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int r = lane & 31, h = lane >> 5, s = tap * chunks + c;
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = w[((size_t)(32 * t + r) * cin + (16 * c + 8 * h + j)) * 9 + tap] * scale;
+                        const _Float16 hi = (_Float16)v;
+                        const _Float16 lo = (_Float16)(v - (float)hi);
+                        o[((((size_t)t * steps + s) * 2 + 0) * 64 + lane) * 8 + j] = hi;
+                        o[((((size_t)t * steps + s) * 2 + 1) * 64 + lane) * 8 + j] = lo;
+                    }
+                }
+    return out;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1468,6 +1815,11 @@ int rz_net_create(int32_t height, int32_t width, int32_t n_actions, int32_t devi
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             net->n_cus = prop.multiProcessorCount;
+    }
+    if (hipSetDevice(device) != hipSuccess || hipMalloc((void **)&net->d_flags, sizeof(unsigned)) != hipSuccess ||
+        hipMemset(net->d_flags, 0, sizeof(unsigned)) != hipSuccess) {
+        delete net;
+        return net_fail(RZ_ERR_OOM, "hipMalloc failed (net flags)");
     }
     memset(&net->dev, 0, sizeof(net->dev));
     net->dev.BH = height;
@@ -1492,7 +1844,20 @@ int rz_net_destroy(rz_net *net) {
     if (net->d_feat) (void)hipFree(net->d_feat);
     if (net->d_raw) (void)hipFree(net->d_raw);
     if (net->d_hid) (void)hipFree(net->d_hid);
+    if (net->d_flags) (void)hipFree(net->d_flags);
     delete net;
+    return RZ_OK;
+}
+
+int rz_net_error_flags(rz_net *net, uint32_t *h_flags) {
+    if (!net || !h_flags) return net_fail(RZ_ERR_ARG, "NULL argument");
+    if (hipSetDevice(net->device) != hipSuccess) return net_fail(RZ_ERR_HIP, "hipSetDevice failed");
+    unsigned v = 0;
+    if (hipMemcpy(&v, net->d_flags, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess)
+        return net_fail(RZ_ERR_HIP, "hipMemcpy failed (net flags)");
+    if (v != 0 && hipMemset(net->d_flags, 0, sizeof(unsigned)) != hipSuccess)
+        return net_fail(RZ_ERR_HIP, "hipMemset failed (net flags)");
+    *h_flags = v;
     return RZ_OK;
 }
 
@@ -1522,6 +1887,13 @@ int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params) {
     up_vec4(pack_wino(h_params[4], 128, 64), &D.u3);
     up_vec4(pack_wino_f4(h_params[2], 64, 32), &D.u2f);
     up_vec4(pack_wino_f4(h_params[4], 128, 64), &D.u3f);
+    {
+        float sw2 = 1.0f, sw3 = 1.0f;
+        up_vec4(pack_split(h_params[2], 64, 32, &sw2), &D.s2);
+        up_vec4(pack_split(h_params[4], 128, 64, &sw3), &D.s3);
+        D.s2_inv = 1.0f / (sp::kActScale * sw2);
+        D.s3_inv = 1.0f / (sp::kActScale * sw3);
+    }
     up_f(h_params[5], 128, &D.b3);
     {
         std::vector<float> wh(6 * 128), bh(6);
@@ -1607,6 +1979,8 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
         k_trunk_wino_f4<4><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
     else if (net->algo == RZ_NET_WINOGRAD_F4_8W)
         k_trunk_wino_f4<8><<<pgrid, dim3(512), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
+    else if (net->algo == RZ_NET_SPLIT_F16)
+        k_trunk_split<<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards, net->d_flags);
     else
         k_trunk<<<grid, dim3(kTrunkThreads), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
 }
@@ -1639,7 +2013,7 @@ int rz_net_trunk(rz_net *net, const float *d_obs, int32_t n_boards, float *d_fea
 
 int rz_net_set_algo(rz_net *net, int32_t algo) {
     if (!net) return net_fail(RZ_ERR_ARG, "net handle is NULL");
-    if (algo < RZ_NET_DIRECT || algo > RZ_NET_WINOGRAD_F4_8W)
+    if (algo < RZ_NET_DIRECT || algo > RZ_NET_SPLIT_F16)
         return net_fail(RZ_ERR_ARG, "unknown algorithm");
     net->algo = algo;
     return RZ_OK;

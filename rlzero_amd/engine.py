@@ -105,8 +105,18 @@ class HipNet(object):
         """conv2 / conv3 algorithm, all fp32 MFMA: 'winograd_f4' (default, F(4x4,3x3)), 'winograd' /
         'winograd4w' (F(2x2,3x3), 8 / 4 waves per board) or 'direct' (bit-for-bit a k-ordered fmaf chain)."""
         code = {'direct': _hip.NET_DIRECT, 'winograd': _hip.NET_WINOGRAD, 'winograd4w': _hip.NET_WINOGRAD_4W,
-                'winograd_f4': _hip.NET_WINOGRAD_F4, 'winograd_f4_8w': _hip.NET_WINOGRAD_F4_8W}[algo]
+                'winograd_f4': _hip.NET_WINOGRAD_F4, 'winograd_f4_8w': _hip.NET_WINOGRAD_F4_8W,
+                'split_f16': _hip.NET_SPLIT_F16}[algo]
         check(self.lib.rz_net_set_algo(self.handle, code), 'rz_net_set_algo')
+        return self
+
+    def check_flags(self):
+        """Raise if a kernel reported a condition since the last call (synchronises): 'split_f16' needs every
+        activation of conv1 / conv2 below 65504 / 16."""
+        flags = ctypes.c_uint32(0)
+        check(self.lib.rz_net_error_flags(self.handle, ctypes.byref(flags)), 'rz_net_error_flags')
+        if flags.value & _hip.NET_FLAG_F16_RANGE:
+            raise HipError("an activation left the range of the split-f16 trunk (>= 4094): use set_algo('winograd_f4')")
         return self
 
     def set_max_workgroups(self, n):

@@ -540,7 +540,7 @@ def test_hip_net_vs_golden_and_torch(g4):
     import torch
     from rlzero_amd.engine import HipNet
     from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
-    for B, algo in [(b, a) for b in (3, 6, 9, 15) for a in ('winograd', 'winograd4w', 'winograd_f4', 'winograd_f4_8w', 'direct')]:
+    for B, algo in [(b, a) for b in (3, 6, 9, 15) for a in ('winograd', 'winograd4w', 'winograd_f4', 'winograd_f4_8w', 'direct', 'split_f16')]:
         weights = ev.numpy_weights(B, int(g4['B%d_seed' % B]))
         hip = HipNet(B, 'cuda:0', max_boards=16).load_state_dict(weights).set_algo(algo)
         obs = torch.from_numpy(g4['B%d_obs' % B].astype(np.float32)).to('cuda:0')
@@ -598,7 +598,7 @@ def test_trunk_is_deterministic_under_load():
     hip = HipNet(15, 'cuda:0', max_boards=512).load_state_dict(net.state_dict())
     x = (torch.rand((512, 4, 15, 15), device='cuda:0') > 0.5).float()
     ref = hip.set_algo('direct').trunk(x).clone()
-    for algo, caps in (('winograd_f4', (0, 224)), ('winograd', (0, ))):
+    for algo, caps in (('split_f16', (0, 224)), ('winograd_f4', (0, 224)), ('winograd', (0, ))):
         hip.set_algo(algo)
         first = None
         side = torch.cuda.Stream()
@@ -615,6 +615,52 @@ def test_trunk_is_deterministic_under_load():
             else:
                 assert torch.equal(out, first)
         torch.cuda.synchronize()
+    hip.close()
+
+
+def test_split_f16_trunk_is_as_accurate_as_the_f32_trunk_and_flags_its_range():
+    """RZ_NET_SPLIT_F16 (f32 operands carried as hi + lo f16 pairs on the f16 matrix pipe, f32 accumulation):
+    its error against an fp64 evaluation of the same weights is at the level of the exact-f32 direct kernel
+    (and below the Winograd kernels'), on unit-scale and on 30x larger weights; an activation beyond the
+    range of the scaled f16 pieces is reported, not silently wrong."""
+    import torch
+    from rlzero_amd.engine import HipError, HipNet
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    for B, gain in ((15, 1.0), (15, 30.0), (9, 0.03), (16, 1.0)):
+        torch.manual_seed(5)
+        net = PolicyValueNet(B)
+        with torch.no_grad():
+            net.conv2.weight.mul_(gain)
+            net.conv3.weight.mul_(gain)
+        weights = {k: v.detach().numpy() for k, v in net.state_dict().items()}
+        hip = HipNet(B, 'cuda:0', max_boards=32).load_state_dict(weights)
+        x = (torch.rand((24, 4, B, B), device='cuda:0') < 0.4).float()
+        net64 = PolicyValueNet(B).double()
+        net64.load_state_dict({k: torch.from_numpy(v).double() for k, v in weights.items()})
+        with torch.no_grad():
+            h = x.cpu().double()
+            for conv in (net64.conv1, net64.conv2, net64.conv3):
+                h = torch.relu(conv(h))
+            ref = torch.cat([torch.relu(net64.act_conv1(h)).flatten(1), torch.relu(net64.val_conv1(h)).flatten(1)], 1).numpy()
+        err = {}
+        for algo in ('direct', 'winograd_f4', 'split_f16'):
+            out = hip.set_algo(algo).trunk(x).cpu().numpy().reshape(ref.shape)
+            err[algo] = float(np.abs(out - ref).max()) / float(np.abs(ref).max())
+        hip.check_flags()
+        assert err['split_f16'] <= 1e-6, err
+        assert err['split_f16'] <= 2.0 * err['direct'] + 1e-7, err
+        assert err['split_f16'] <= err['winograd_f4'] + 1e-7, err
+        hip.close()
+    # out of range: conv1 outputs of ~1e4 (x 16 > 65504)
+    torch.manual_seed(5)
+    net = PolicyValueNet(6)
+    with torch.no_grad():
+        net.conv1.weight.mul_(1e5)
+    hip = HipNet(6, 'cuda:0', max_boards=8).load_state_dict(net.state_dict()).set_algo('split_f16')
+    hip.trunk((torch.rand((4, 4, 6, 6), device='cuda:0') < 0.5).float())
+    with pytest.raises(HipError):
+        hip.check_flags()
+    hip.check_flags()  # the flag is cleared by the report
     hip.close()
 
 

@@ -53,6 +53,7 @@ struct NetDev {
     float s2_inv, s3_inv;        // 1 / (activation scale * weight scale) of conv2 / conv3 (pack_split)
     const float *b1, *b2, *b3;   // conv biases
     const float *wh;             // [6][128]: act_conv1 (4 rows) then val_conv1 (2 rows)
+    const float *whp;            // the same, [128][6] (k_trunk_split)
     const float *bh;             // [6]
     const float *fc_act_w;       // act_fc1.weight [out][in], zero padded to [Npad][16*groups_act]
     const float *fc_act_b;       // [Npad]
@@ -1124,8 +1125,8 @@ template <int CIN> struct Geo {
 };
 constexpr int kC1Bytes = 2 * Geo<32>::piece_bytes, kC2Bytes = 2 * Geo<64>::piece_bytes;
 constexpr int kInFloats = kPlanesIn * kPlaneWino;
-constexpr int kPartialFloats = 2 * 6 * 256;
-constexpr int kLdsBytes = kInFloats * 4 + kC1Bytes + kC2Bytes + kPartialFloats * 4;
+constexpr int kHeadFloats = 128 * 7;  // head weights [128][6] + conv3 biases [128]
+constexpr int kLdsBytes = kInFloats * 4 + kC1Bytes + kC2Bytes + kHeadFloats * 4;
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 static_assert((kInFloats * 4) % 16 == 0, "piece alignment");
 
@@ -1143,11 +1144,11 @@ __device__ __forceinline__ void split4(const float (&z)[4], f16x4 &hi, f16x4 &lo
 }
 
 // slot I of K-step S: MFMA I of the step plus (behind the first MFMAs) one load of a coming step
-template <int CIN, int TN, int S, int I>
-__device__ __forceinline__ void slot(f32x16 (&acc)[2][TN], f16x8 (&a)[3][2][2], f16x8 (&b)[2][TN][2], lds_frag q0,
+template <int CIN, int TM, int TN, int S, int I>
+__device__ __forceinline__ void slot(f32x16 (&acc)[TM][TN], f16x8 (&a)[3][TM][2], f16x8 (&b)[2][TN][2], lds_frag q0,
                                      lds_frag q1, __amdgpu_buffer_rsrc_t w_rsrc, int w_base, int w_lane) {
     using G = Geo<CIN>;
-    constexpr int combo = I / (2 * TN), m = (I / TN) % 2, n = I % TN;
+    constexpr int combo = I / (TM * TN), m = (I / TN) % TM, n = I % TN;
     constexpr int pa = combo == 2 ? 1 : 0, pb = combo == 1 ? 1 : 0;
     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[S % 3][m][pa], b[S % 2][n][pb], acc[m][n], 0, 0, 0);
     if constexpr (I < 2 * TN) {
@@ -1157,7 +1158,7 @@ __device__ __forceinline__ void slot(f32x16 (&acc)[2][TN], f16x8 (&a)[3][2][2], 
             static_assert(off % 16 == 0 && off < 65536, "ds_read_b128 immediate");
             b[s1 % 2][nn][piece] = (piece ? q1 : q0)[off / 16];
         }
-    } else if constexpr (I < 2 * TN + 4) {
+    } else if constexpr (I < 2 * TN + 2 * TM) {
         if constexpr (S + 2 < G::steps) {
             constexpr int s2 = S + 2, j = I - 2 * TN, mm = j / 2, piece = j % 2;
             a[s2 % 3][mm][piece] = load_w(w_rsrc, w_lane, w_base + ((mm * G::steps + s2) * 2 + piece) * 1024);
@@ -1166,56 +1167,66 @@ __device__ __forceinline__ void slot(f32x16 (&acc)[2][TN], f16x8 (&a)[3][2][2], 
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int CIN, int TN, int S, int... Is>
-__device__ __forceinline__ void step(std::integer_sequence<int, Is...>, f32x16 (&acc)[2][TN], f16x8 (&a)[3][2][2],
+template <int CIN, int TM, int TN, int S, int... Is>
+__device__ __forceinline__ void step(std::integer_sequence<int, Is...>, f32x16 (&acc)[TM][TN], f16x8 (&a)[3][TM][2],
                                      f16x8 (&b)[2][TN][2], lds_frag q0, lds_frag q1, __amdgpu_buffer_rsrc_t w_rsrc,
                                      int w_base, int w_lane) {
-    (slot<CIN, TN, S, Is>(acc, a, b, q0, q1, w_rsrc, w_base, w_lane), ...);
+    (slot<CIN, TM, TN, S, Is>(acc, a, b, q0, q1, w_rsrc, w_base, w_lane), ...);
 }
 
-template <int CIN, int TN, int... Ss>
-__device__ __forceinline__ void steps(std::integer_sequence<int, Ss...>, f32x16 (&acc)[2][TN], f16x8 (&a)[3][2][2],
+template <int CIN, int TM, int TN, int... Ss>
+__device__ __forceinline__ void steps(std::integer_sequence<int, Ss...>, f32x16 (&acc)[TM][TN], f16x8 (&a)[3][TM][2],
                                       f16x8 (&b)[2][TN][2], lds_frag q0, lds_frag q1, __amdgpu_buffer_rsrc_t w_rsrc,
                                       int w_base, int w_lane) {
-    (step<CIN, TN, Ss>(std::make_integer_sequence<int, 6 * TN>{}, acc, a, b, q0, q1, w_rsrc, w_base, w_lane), ...);
+    (step<CIN, TM, TN, Ss>(std::make_integer_sequence<int, 3 * TM * TN>{}, acc, a, b, q0, q1, w_rsrc, w_base, w_lane), ...);
 }
 
-// acc[m][n] = sum over taps and input channels for M-tiles mt0, mt0 + 1 and N-tiles nt0 .. nt0 + TN - 1
-// (`in` = piece 0 of the layer's input in LDS).
-template <int CIN, int TN>
-__device__ __forceinline__ void conv(const char *in, const void *wts, int mt0, int nt0, int lane,
-                                     f32x16 (&acc)[2][TN]) {
+// The weight fragments of K-steps 0 and 1 (M-tiles 0 .. TM-1): no dependence on LDS, so a layer's first
+// fragments are requested while the previous layer is still being reduced.
+template <int CIN, int TM>
+__device__ __forceinline__ void preload_w(f16x8 (&a)[3][TM][2], const void *wts, int lane) {
+    using G = Geo<CIN>;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(wts), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) a[s][m][p] = load_w(w_rsrc, lane * 16, ((m * G::steps + s) * 2 + p) * 1024);
+}
+
+// acc[m][n] = sum over taps and input channels for M-tiles 0 .. TM-1 (all output channels of the layer) and
+// N-tiles nt0 .. nt0 + TN - 1 (`in` = piece 0 of the layer's input in LDS, `a` primed by preload_w).
+template <int CIN, int TM, int TN>
+__device__ __forceinline__ void conv(const char *in, const void *wts, int nt0, int lane, f16x8 (&a)[3][TM][2],
+                                     f32x16 (&acc)[TM][TN]) {
     using G = Geo<CIN>;
     const int n = lane & 31, h = lane >> 5;
     // halo position (row 2*nt0 + (n >> 4), column n & 15) = the top-left tap of output (2*nt0 + (n >> 4), n & 15)
     const int lane_byte = ((2 * nt0 + (n >> 4)) * kRowW + (n & 15)) * G::pos_bytes + h * 16;
     const lds_frag q0 = (lds_frag)(in + lane_byte), q1 = (lds_frag)(in + lane_byte + G::piece_bytes);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(wts), 0, 0x7fffffff, 0x00020000);
-    const int w_base = mt0 * G::steps * 2048, w_lane = lane * 16;
-    f16x8 a[3][2][2], b[2][TN][2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) a[s][m][p] = load_w(w_rsrc, w_lane, w_base + ((m * G::steps + s) * 2 + p) * 1024);
+    f16x8 b[2][TN][2];
 #pragma unroll
     for (int nn = 0; nn < TN; ++nn) {
         b[0][nn][0] = q0[(2 * nn * kRowW * G::pos_bytes) / 16];
         b[0][nn][1] = q1[(2 * nn * kRowW * G::pos_bytes) / 16];
     }
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < TM; ++m)
 #pragma unroll
         for (int nn = 0; nn < TN; ++nn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.0f;
     __builtin_amdgcn_sched_barrier(0);
-    steps<CIN, TN>(std::make_integer_sequence<int, G::steps>{}, acc, a, b, q0, q1, w_rsrc, w_base, w_lane);
+    steps<CIN, TM, TN>(std::make_integer_sequence<int, G::steps>{}, acc, a, b, q0, q1, w_rsrc, 0, lane * 16);
 }
 
 }  // namespace sp
 
+// Wave w owns board rows 4w .. 4w+3 (N-tiles 2w, 2w+1) and ALL output channels of conv2 and of conv3, so the
+// 1x1 head convolutions see every channel of a position in one wave (two lane halves, one shuffle) and the head
+// features go from registers to memory: two barriers per board.
 __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__restrict__ obs,
                                                      float *__restrict__ feat, int n_boards,
                                                      unsigned *__restrict__ flags) {
@@ -1225,7 +1236,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     float *in0 = reinterpret_cast<float *>(lds_raw);
     char *c1 = lds_raw + sp::kInFloats * 4;   // conv1 output, pieces hi | lo
     char *c2 = c1 + sp::kC1Bytes;             // conv2 output, pieces hi | lo
-    float *partial = reinterpret_cast<float *>(c2 + sp::kC2Bytes);  // [channel half][o][y][x]
+    float *hw = reinterpret_cast<float *>(c2 + sp::kC2Bytes);  // head weights [128][6], then conv3 biases [128]
     const int tid0 = threadIdx.x;
     const int BH = nd.BH, BW = nd.BW, S = nd.S;
     {
@@ -1249,23 +1260,13 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         const int c = i / S, r = i - c * S, y = r / BW, x = r - y * BW;
         obs_off[k] = i < 4 * S ? c * PL + (y + 1) * kRowW + (x + 1) : -1;
     }
-    constexpr int kFeatPer = (6 * RZ_MAX_BOARD_SIZE * RZ_MAX_BOARD_SIZE + kThreads - 1) / kThreads;
-    int feat_src[kFeatPer], feat_dst[kFeatPer];
-    float feat_bias[kFeatPer];
-#pragma unroll
-    for (int k = 0; k < kFeatPer; ++k) {
-        const int i = tid0 + k * kThreads;
-        const int o = i / S, r = i - o * S, y = r / BW, x = r - y * BW;
-        feat_src[k] = (o * 16 + y) * 16 + x;
-        feat_dst[k] = i < 6 * S ? (i < 4 * S ? i : i - 4 * S + nd.feat_val_off) : -1;
-        feat_bias[k] = i < 6 * S ? nd.bh[o] : 0.0f;
-    }
     auto store_obs = [&](int) {
 #pragma unroll
         for (int k = 0; k < kObsPer; ++k)
             if (obs_off[k] >= 0) in0[obs_off[k]] = ob[k];
     };
     __syncthreads();
+    for (int i = tid0; i < 128 * 7; i += kThreads) hw[i] = i < 768 ? nd.whp[i] : nd.b3[i - 768];
     if ((int)blockIdx.x < n_boards) {
         load_obs(blockIdx.x, tid0);
         store_obs(tid0);
@@ -1277,6 +1278,8 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int next_board = board + (int)gridDim.x;
+    sp::f16x8 a2[3][2][2];
+    sp::preload_w<32, 2>(a2, nd.s2, lane);
     {   // conv1: 4 -> 32, exact f32 MFMA: output tile (wave & 1), board rows 8 * (wave >> 1) ..
         const int tile = wave & 1, row0 = 8 * (wave >> 1);
         if (row0 < BH) {
@@ -1307,24 +1310,30 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     }
     __syncthreads();
     if (next_board < n_boards) load_obs(next_board, tid);
-    const int n = lane & 31, h = lane >> 5;
-    {   // conv2: 32 -> 64: both M-tiles, N-tiles 2*wave, 2*wave + 1 (board rows 4*wave .. 4*wave + 3)
+    const int n = lane & 31, h = lane >> 5, x = n & 15;
+    sp::f16x8 a3[3][4][2];
+    {   // conv2: 32 -> 64
         sp::f32x16 acc[2][2];
-        sp::conv<32, 2>(c1, nd.s2, 0, 2 * wave, lane, acc);
-        const int x = n & 15;
+        f32x4 bias2[2][4];  // fetched before the MFMA loop
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias2[m][g] = *reinterpret_cast<const f32x4 *>(nd.b2 + m * 32 + 8 * g + 4 * h) * sp::kActScale;
+        sp::conv<32, 2, 2>(c1, nd.s2, 2 * wave, lane, a2, acc);
+        sp::preload_w<64, 4>(a3, nd.s3, lane);
         const float k2 = nd.s2_inv * sp::kActScale;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int c0 = m * 32 + 8 * g + 4 * h;
-                const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b2 + c0);
+                const f32x4 bv = bias2[m][g];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const int y = 4 * wave + 2 * t + (n >> 4);
                     float z[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) z[j] = fmaxf(fmaf(acc[m][t][4 * g + j], k2, bv[j] * sp::kActScale), 0.0f);
+                    for (int j = 0; j < 4; ++j) z[j] = fmaxf(fmaf(acc[m][t][4 * g + j], k2, bv[j]), 0.0f);
                     if (y < BH && x < BW) {
                         zmax = fmaxf(fmaxf(zmax, fmaxf(z[0], z[1])), fmaxf(z[2], z[3]));
                         sp::f16x4 hi, lo;
@@ -1338,58 +1347,59 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     }
     if (next_board < n_boards) store_obs(tid);
     __syncthreads();
-    {   // conv3: 64 -> 128: wave = (channel half mp, board half nh); its ReLU'd output feeds the 1x1 head convs
-        const int mp = wave & 1, nh = wave >> 1;
-        f32x2 vals2[4][3];  // [position][pair of head outputs]
+    {   // conv3: 64 -> 128; its ReLU'd output feeds the two 1x1 head convolutions from registers
+        f32x2 vals2[2][3];  // [position][pair of head outputs]
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int o2 = 0; o2 < 3; ++o2) vals2[t][o2] = f32x2{0.0f, 0.0f};
         {
-            sp::f32x16 acc[2][4];
-            sp::conv<64, 4>(c2, nd.s3, 2 * mp, 4 * nh, lane, acc);
+            sp::f32x16 acc[4][2];
+            sp::conv<64, 4, 2>(c2, nd.s3, 2 * wave, lane, a3, acc);
+            // per (m, g): the lane's channels c0 .. c0+3 = 32*m + 8*g + 4*h ..: 24 head weights [j][output] and 4
+            // biases from LDS, fetched one group ahead (the fences keep hipcc from hoisting all 16 groups' reads)
+            f32x4 w[2][7];
+            auto load_group = [&](int mg, f32x4 (&dstw)[7]) {
+                const int c0 = (mg >> 2) * 32 + 8 * (mg & 3) + 4 * h;
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+                for (int i = 0; i < 6; ++i) dstw[i] = *reinterpret_cast<const f32x4 *>(hw + c0 * 6 + 4 * i);
+                dstw[6] = *reinterpret_cast<const f32x4 *>(hw + 768 + c0);
+            };
+            load_group(0, w[0]);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int c0 = (2 * mp + m) * 32 + 8 * g + 4 * h;
-                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b3 + c0);
-                    f32x4 wv[6];
+            for (int mg = 0; mg < 16; ++mg) {
+                const int m = mg >> 2, g = mg & 3;
+                if (mg + 1 < 16) load_group(mg + 1, w[(mg + 1) & 1]);
+                const f32x4(&wc)[7] = w[mg & 1];
 #pragma unroll
-                    for (int o = 0; o < 6; ++o) wv[o] = *reinterpret_cast<const f32x4 *>(nd.wh + o * 128 + c0);
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
+                    for (int j = 0; j < 4; ++j) {
+                        const float hv = fmaxf(fmaf(acc[m][t][4 * g + j], nd.s3_inv, wc[6][j]), 0.0f);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float hv = fmaxf(fmaf(acc[m][t][4 * g + j], nd.s3_inv, bv[j]), 0.0f);
-#pragma unroll
-                            for (int o2 = 0; o2 < 3; ++o2)
-                                vals2[t][o2] = __builtin_elementwise_fma(f32x2{wv[2 * o2][j], wv[2 * o2 + 1][j]},
-                                                                         f32x2{hv, hv}, vals2[t][o2]);
+                        for (int o2 = 0; o2 < 3; ++o2) {
+                            const int e = 6 * j + 2 * o2;  // float index of (channel j, outputs 2*o2, 2*o2 + 1)
+                            vals2[t][o2] = __builtin_elementwise_fma(f32x2{wc[e >> 2][e & 3], wc[e >> 2][(e & 3) + 1]},
+                                                                     f32x2{hv, hv}, vals2[t][o2]);
                         }
-                }
-        }
-        // the two lane halves hold different channels of the same positions
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int o = 0; o < 6; ++o) {
-                float v = vals2[t][o >> 1][o & 1];
-                v += __shfl_xor(v, 32);
-                if (h == 0) {
-                    const int y = 8 * nh + 2 * t + (n >> 4);
-                    partial[((mp * 6 + o) * 16 + y) * 16 + (n & 15)] = v;
-                }
+                    }
+                // pin the partial sums here: their only use is the guarded store below, and hipcc otherwise sinks
+                // the whole chains of multiply-adds into that block (every weight and activation kept alive)
+                asm volatile("" : "+v"(vals2[0][0]), "+v"(vals2[0][1]), "+v"(vals2[0][2]), "+v"(vals2[1][0]),
+                             "+v"(vals2[1][1]), "+v"(vals2[1][2]));
+                __builtin_amdgcn_sched_barrier(0);
             }
-    }
-    __syncthreads();
-    {
+        }
+        // the two lane halves hold different channels of the same two positions: lane half h stores position h
         float *dst = feat + (size_t)board * nd.feat_ld;
+        const int y = 4 * wave + 2 * h + (n >> 4);
 #pragma unroll
-        for (int k = 0; k < kFeatPer; ++k) {
-            if (feat_dst[k] < 0) continue;
-            const float v = feat_bias[k] + partial[feat_src[k]] + partial[6 * 256 + feat_src[k]];
-            dst[feat_dst[k]] = fmaxf(v, 0.0f);
+        for (int o = 0; o < 6; ++o) {
+            float v0 = vals2[0][o >> 1][o & 1], v1 = vals2[1][o >> 1][o & 1];
+            v0 += __shfl_xor(v0, 32);
+            v1 += __shfl_xor(v1, 32);
+            const float v = fmaxf((h ? v1 : v0) + nd.bh[o], 0.0f);
+            if (y < BH && x < BW) dst[(o < 4 ? o * S : nd.feat_val_off + (o - 4) * S) + y * BW + x] = v;
         }
     }
     }  // boards
@@ -1902,6 +1912,10 @@ int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params) {
         memcpy(bh.data(), h_params[7], 4 * sizeof(float));
         memcpy(bh.data() + 4, h_params[11], 2 * sizeof(float));
         if (rc == RZ_OK) rc = net_upload(net, wh, &D.wh);
+        std::vector<float> whp(128 * 6);
+        for (int c = 0; c < 128; ++c)
+            for (int o = 0; o < 6; ++o) whp[c * 6 + o] = wh[o * 128 + c];
+        if (rc == RZ_OK) rc = net_upload(net, whp, &D.whp);
         if (rc == RZ_OK) rc = net_upload(net, bh, &D.bh);
     }
     {

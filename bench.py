@@ -38,6 +38,7 @@ if REPO not in sys.path:
 
 BOARD, N_ROW, N_PLAYOUT, GAMES_PER_GPU, C_PUCT, TEMPERATURE = 15, 5, 800, 512, 5.0, 1.0
 RESERVED_CUS_PER_XCD, N_XCD = 4, 8  # CUs the trunk leaves to the other lane's small kernels
+BOARDS_PER_WORKGROUP = 3  # boards per persistent trunk workgroup and step at the default batch
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0
 
@@ -277,8 +278,8 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=15.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--games', type=int, default=0,
-                    help='games per GPU; 0 = lanes x 2 boards x trunk workgroups (896) with 2 lanes, %d with 1' %
-                    GAMES_PER_GPU)
+                    help='games per GPU; 0 = lanes x %d boards x trunk workgroups (1344) with 2 lanes, %d with 1' %
+                    (BOARDS_PER_WORKGROUP, GAMES_PER_GPU))
     ap.add_argument('--trunk-wgs', type=int, default=-1,
                     help='persistent trunk workgroups per lane; -1 = CUs - %d with lanes > 1, one per CU otherwise' %
                     (RESERVED_CUS_PER_XCD * N_XCD))
@@ -292,7 +293,7 @@ def main():
                     help="hipnet: hand-written fused fp32 MFMA forward (csrc/rz_net.hip); torchnet: "
                          "PyTorch-ROCm/MIOpen; vlin: synthetic evaluator (isolates the tree kernels)")
     ap.add_argument('--graph', type=int, default=8, help='simulation steps per hipGraph (0 = eager)')
-    ap.add_argument('--net-algo', default='winograd_f4', choices=['winograd', 'winograd4w', 'winograd_f4', 'winograd_f4_8w', 'direct', 'split_f16'])
+    ap.add_argument('--net-algo', default='split_f16', choices=['winograd', 'winograd4w', 'winograd_f4', 'winograd_f4_8w', 'direct', 'split_f16'])
     ap.add_argument('--lanes', type=int, default=2,
                     help='independent batches of games on separate HIP streams (the tree / FC kernels of one '
                          'lane run beside the network trunk of the other)')
@@ -342,7 +343,7 @@ def main():
     trunk_wgs = args.trunk_wgs
     if trunk_wgs < 0:
         trunk_wgs = n_cus - RESERVED_CUS_PER_XCD * N_XCD if lanes > 1 and args.evaluator == 'hipnet' else 0
-    G = args.games if args.games > 0 else (lanes * 2 * trunk_wgs if trunk_wgs > 0 else GAMES_PER_GPU)
+    G = args.games if args.games > 0 else (lanes * BOARDS_PER_WORKGROUP * trunk_wgs if trunk_wgs > 0 else GAMES_PER_GPU)
     lanes = max(1, min(lanes, G))
     per_lane = [G // lanes + (1 if i < G % lanes else 0) for i in range(lanes)]
     torch.manual_seed(0)  # identical weights on every rank

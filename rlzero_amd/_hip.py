@@ -8,7 +8,7 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64,
                     c_void_p)
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
 

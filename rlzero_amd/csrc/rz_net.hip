@@ -50,7 +50,8 @@ struct NetDev {
     const f32x4 *u2, *u3;        // Winograd-domain weights of conv2 / conv3: [tile][i'][cin_step][64 lanes] x 4 j'
     const f32x4 *u2f, *u3f;      // F(4x4,3x3): [tile][pass][cin_step][3][64 lanes] x 4 components (pack_wino_f4)
     const f32x4 *s2, *s3;        // split f16 weights: [32-channel tile][tap][16-channel chunk][hi | lo][64 lanes] x 8 f16
-    float s2_inv, s3_inv;        // 1 / (activation scale * weight scale) of conv2 / conv3 (pack_split)
+    const float *s_inv;          // [2] in device memory (a captured launch must see a reload's values):
+                                 // 1 / (activation scale * weight scale) of conv2, conv3 (pack_split)
     const float *b1, *b2, *b3;   // conv biases
     const float *wh;             // [6][128]: act_conv1 (4 rows) then val_conv1 (2 rows)
     const float *whp;            // the same, [128][6] (k_trunk_split)
@@ -1321,7 +1322,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
             for (int g = 0; g < 4; ++g) bias2[m][g] = *reinterpret_cast<const f32x4 *>(nd.b2 + m * 32 + 8 * g + 4 * h) * sp::kActScale;
         sp::conv<32, 2, 2>(c1, nd.s2, 2 * wave, lane, a2, acc);
         sp::preload_w<64, 4>(a3, nd.s3, lane);
-        const float k2 = nd.s2_inv * sp::kActScale;
+        const float k2 = nd.s_inv[0] * sp::kActScale;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1355,6 +1356,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
             for (int o2 = 0; o2 < 3; ++o2) vals2[t][o2] = f32x2{0.0f, 0.0f};
         {
             sp::f32x16 acc[4][2];
+            const float k3 = nd.s_inv[1];
             sp::conv<64, 4, 2>(c2, nd.s3, 2 * wave, lane, a3, acc);
             // per (m, g): the lane's channels c0 .. c0+3 = 32*m + 8*g + 4*h ..: 24 head weights [j][output] and 4
             // biases from LDS, fetched one group ahead (the fences keep hipcc from hoisting all 16 groups' reads)
@@ -1375,7 +1377,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float hv = fmaxf(fmaf(acc[m][t][4 * g + j], nd.s3_inv, wc[6][j]), 0.0f);
+                        const float hv = fmaxf(fmaf(acc[m][t][4 * g + j], k3, wc[6][j]), 0.0f);
 #pragma unroll
                         for (int o2 = 0; o2 < 3; ++o2) {
                             const int e = 6 * j + 2 * o2;  // float index of (channel j, outputs 2*o2, 2*o2 + 1)
@@ -1648,7 +1650,7 @@ __global__ __launch_bounds__(64) void k_heads_finish(NetDev nd, const float *__r
 struct rz_net {
     int board_size = 0, device = 0;
     bool loaded = false;
-    int algo = RZ_NET_WINOGRAD_F4;
+    int algo = RZ_NET_SPLIT_F16;
     int n_cus = 256;
     int max_wgs = 0;  // rz_net_set_max_workgroups: 0 = one persistent trunk workgroup per CU
     NetDev dev;
@@ -1901,8 +1903,7 @@ int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params) {
         float sw2 = 1.0f, sw3 = 1.0f;
         up_vec4(pack_split(h_params[2], 64, 32, &sw2), &D.s2);
         up_vec4(pack_split(h_params[4], 128, 64, &sw3), &D.s3);
-        D.s2_inv = 1.0f / (sp::kActScale * sw2);
-        D.s3_inv = 1.0f / (sp::kActScale * sw3);
+        up_f(std::vector<float>{1.0f / (sp::kActScale * sw2), 1.0f / (sp::kActScale * sw3)}.data(), 2, &D.s_inv);
     }
     up_f(h_params[5], 128, &D.b3);
     {

@@ -102,8 +102,10 @@ class HipNet(object):
         self._want = int(max_boards)
 
     def set_algo(self, algo):
-        """conv2 / conv3 algorithm, all fp32 MFMA: 'winograd_f4' (default, F(4x4,3x3)), 'winograd' /
-        'winograd4w' (F(2x2,3x3), 8 / 4 waves per board) or 'direct' (bit-for-bit a k-ordered fmaf chain)."""
+        """conv2 / conv3 algorithm: 'split_f16' (default: direct convolution on the f16 matrix pipe, every f32
+        operand carried as a hi + lo pair of f16 values, f32 accumulation -- as accurate as 'direct'), or on the
+        f32-input MFMA: 'winograd_f4' (F(4x4,3x3)), 'winograd' / 'winograd4w' (F(2x2,3x3), 8 / 4 waves per
+        board), 'direct' (bit-for-bit a k-ordered fmaf chain)."""
         code = {'direct': _hip.NET_DIRECT, 'winograd': _hip.NET_WINOGRAD, 'winograd4w': _hip.NET_WINOGRAD_4W,
                 'winograd_f4': _hip.NET_WINOGRAD_F4, 'winograd_f4_8w': _hip.NET_WINOGRAD_F4_8W,
                 'split_f16': _hip.NET_SPLIT_F16}[algo]

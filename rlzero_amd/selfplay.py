@@ -131,21 +131,22 @@ class Trajectory(object):
 
 
 RESERVED_CUS_PER_XCD, N_XCD = 4, 8  # CUs a lane's trunk leaves to the other lane's tree / FC kernels
+BOARDS_PER_WORKGROUP = 3  # boards a persistent trunk workgroup takes per step at the tuned batch (bench.py default)
 
 
 def plan_lanes(n_games, n_cus=256):
     """-> (lanes, trunk_workgroups) for ``n_games`` games in flight on a GPU with ``n_cus`` CUs.
 
-    One lane: the trunk takes ceil(G / CUs) board rounds (~60 us each on 15x15) and then the GPU idles
-    through the lane's FC + tree kernels and three kernel boundaries (~40 us).  Two lanes: each trunk is
+    One lane: the trunk takes ceil(G / CUs) board rounds (~27 us each on 15x15) and then the GPU idles
+    through the lane's FC + tree kernels and three kernel boundaries (~45 us).  Two lanes: each trunk is
     capped at CUs - 32 persistent workgroups (4 CUs per XCD stay free), the two trunks alternate and the
     small kernels of one lane hide under the trunk of the other.  The cheaper estimate wins; 0 workgroups
     means "one per CU" (no cap)."""
     capped = n_cus - RESERVED_CUS_PER_XCD * N_XCD
     if capped <= 0 or n_games < 2:
         return 1, 0
-    one = -(-n_games // n_cus) * 60.0 + 40.0
-    two = 2.0 * -(-((n_games + 1) // 2) // capped) * 60.0 + 5.0
+    one = -(-n_games // n_cus) * 27.0 + 45.0
+    two = 2.0 * -(-((n_games + 1) // 2) // capped) * 27.0 + 5.0
     return (2, capped) if two < one else (1, 0)
 
 
@@ -312,6 +313,8 @@ class BatchedSelfPlay(object):
         for lane in self.lanes:
             with self._on(lane):
                 visits[lane.slots] = lane.eng.root_visits()
+                if hasattr(getattr(lane.evaluator, 'hip', None), 'check_flags'):
+                    lane.evaluator.hip.check_flags()  # the split-f16 trunk reports activations out of its range
         self.sims_done += eng.n_playout * len(running)
         moves = np.full(self.n_slots, -2, dtype=np.int32)
         if len(running):

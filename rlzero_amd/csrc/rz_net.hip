@@ -49,9 +49,10 @@ struct NetDev {
     const f32x4 *w1, *w2, *w3;   // packed [tile][cin_step][3][64 lanes] x 4 taps
     const f32x4 *u2, *u3;        // Winograd-domain weights of conv2 / conv3: [tile][i'][cin_step][64 lanes] x 4 j'
     const f32x4 *u2f, *u3f;      // F(4x4,3x3): [tile][pass][cin_step][3][64 lanes] x 4 components (pack_wino_f4)
+    const f32x4 *s1;             // conv1 for k_trunk_split: [kernel row][hi | lo][64 lanes] x 8 f16 (pack_split1)
     const f32x4 *s2, *s3;        // split f16 weights: [32-channel tile][tap][16-channel chunk][hi | lo][64 lanes] x 8 f16
-    const float *s_inv;          // [2] in device memory (a captured launch must see a reload's values):
-                                 // 1 / (activation scale * weight scale) of conv2, conv3 (pack_split)
+    const float *s_inv;          // [3] in device memory (a captured launch must see a reload's values):
+                                 // 1 / (activation scale * weight scale) of conv2, conv3; 1 / weight scale of conv1
     const float *b1, *b2, *b3;   // conv biases
     const float *wh;             // [6][128]: act_conv1 (4 rows) then val_conv1 (2 rows)
     const float *whp;            // the same, [128][6] (k_trunk_split)
@@ -1125,11 +1126,14 @@ template <int CIN> struct Geo {
     static constexpr int chunks = CIN / 16, steps = 9 * chunks;
 };
 constexpr int kC1Bytes = 2 * Geo<32>::piece_bytes, kC2Bytes = 2 * Geo<64>::piece_bytes;
-constexpr int kInFloats = kPlanesIn * kPlaneWino;
+// observation planes: [hi | lo][18 rows][20 cols][4 planes] f16 -- the 4 planes of a position are 8 contiguous bytes,
+// so the 16 K-values of conv1's step "kernel row ky" (4 columns x 4 planes, the 4th column meeting zero weights)
+// are two 16-byte runs
+constexpr int kInCols = 20, kInPieceBytes = 18 * kInCols * 8, kInBytes = 2 * kInPieceBytes;
 constexpr int kHeadFloats = 128 * 7;  // head weights [128][6] + conv3 biases [128]
-constexpr int kLdsBytes = kInFloats * 4 + kC1Bytes + kC2Bytes + kHeadFloats * 4;
+constexpr int kLdsBytes = kInBytes + kC1Bytes + kC2Bytes + kHeadFloats * 4;
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
-static_assert((kInFloats * 4) % 16 == 0, "piece alignment");
+static_assert(kInBytes % 16 == 0, "piece alignment");
 
 __device__ __forceinline__ f16x8 load_w(__amdgpu_buffer_rsrc_t rsrc, int lane_off, int uniform_off) {
     return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, uniform_off, 0));
@@ -1231,11 +1235,10 @@ __device__ __forceinline__ void conv(const char *in, const void *wts, int nt0, i
 __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__restrict__ obs,
                                                      float *__restrict__ feat, int n_boards,
                                                      unsigned *__restrict__ flags) {
-    constexpr int PL = kPlaneWino;
     constexpr int kThreads = 256;
     __shared__ __attribute__((aligned(16))) char lds_raw[sp::kLdsBytes];
-    float *in0 = reinterpret_cast<float *>(lds_raw);
-    char *c1 = lds_raw + sp::kInFloats * 4;   // conv1 output, pieces hi | lo
+    char *in0 = lds_raw;                      // observation planes, pieces hi | lo
+    char *c1 = lds_raw + sp::kInBytes;        // conv1 output, pieces hi | lo
     char *c2 = c1 + sp::kC1Bytes;             // conv2 output, pieces hi | lo
     float *hw = reinterpret_cast<float *>(c2 + sp::kC2Bytes);  // head weights [128][6], then conv3 biases [128]
     const int tid0 = threadIdx.x;
@@ -1244,6 +1247,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         f32x4 *z = reinterpret_cast<f32x4 *>(lds_raw);
         for (int i = tid0; i < sp::kLdsBytes / 16; i += kThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    float zmax = 0.0f;  // largest scaled value this thread stored as f16 pieces
     constexpr int kObsPer = (4 * RZ_MAX_BOARD_SIZE * RZ_MAX_BOARD_SIZE + kThreads - 1) / kThreads;
     float ob[kObsPer];
     auto load_obs = [&](int board, int tid) {
@@ -1259,21 +1263,39 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     for (int k = 0; k < kObsPer; ++k) {
         const int i = tid0 + k * kThreads;
         const int c = i / S, r = i - c * S, y = r / BW, x = r - y * BW;
-        obs_off[k] = i < 4 * S ? c * PL + (y + 1) * kRowW + (x + 1) : -1;
+        obs_off[k] = i < 4 * S ? ((y + 1) * sp::kInCols + (x + 1)) * 8 + c * 2 : -1;
     }
     auto store_obs = [&](int) {
 #pragma unroll
         for (int k = 0; k < kObsPer; ++k)
-            if (obs_off[k] >= 0) in0[obs_off[k]] = ob[k];
+            if (obs_off[k] >= 0) {
+                const float z = ob[k] * sp::kActScale;
+                const _Float16 hi = (_Float16)z;
+                zmax = fmaxf(zmax, fabsf(z));
+                *reinterpret_cast<_Float16 *>(in0 + obs_off[k]) = hi;
+                *reinterpret_cast<_Float16 *>(in0 + sp::kInPieceBytes + obs_off[k]) = (_Float16)(z - (float)hi);
+            }
     };
     __syncthreads();
     for (int i = tid0; i < 128 * 7; i += kThreads) hw[i] = i < 768 ? nd.whp[i] : nd.b3[i - 768];
+    // conv1's weights (3 kernel rows x hi / lo, 6 KB per workgroup) and biases stay in registers for all boards
+    sp::f16x8 a1[3][2];
+    f32x4 bias1[4];
+    {
+        const int lane0 = tid0 & 63;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int p_ = 0; p_ < 2; ++p_) a1[ky][p_] = __builtin_bit_cast(sp::f16x8, nd.s1[(ky * 2 + p_) * 64 + lane0]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias1[g] = *reinterpret_cast<const f32x4 *>(nd.b1 + 8 * g + 4 * (lane0 >> 5)) * sp::kActScale;
+    }
+    const float k1 = nd.s_inv[2];
     if ((int)blockIdx.x < n_boards) {
         load_obs(blockIdx.x, tid0);
         store_obs(tid0);
     }
     __syncthreads();
-    float zmax = 0.0f;  // largest scaled activation this thread stored
     for (int board = blockIdx.x; board < n_boards; board += gridDim.x) {
     int tid = tid0;
     asm volatile("" : "+v"(tid));
@@ -1281,28 +1303,46 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     const int next_board = board + (int)gridDim.x;
     sp::f16x8 a2[3][2][2];
     sp::preload_w<32, 2>(a2, nd.s2, lane);
-    {   // conv1: 4 -> 32, exact f32 MFMA: output tile (wave & 1), board rows 8 * (wave >> 1) ..
-        const int tile = wave & 1, row0 = 8 * (wave >> 1);
-        if (row0 < BH) {
-            f32x4 acc[1][8];
-            zero_acc<1>(acc);
-            conv_rows<PL, 4, 1>(in0, nd.w1, tile, row0, (BH - row0 == 7) ? 7 : 8, lane, acc);
-            const int x = lane & 15, q = lane >> 4, c0 = tile * 16 + 4 * q;
-            if (x < BW) {
-                const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b1 + c0);
+    const int n = lane & 31, h = lane >> 5, x = n & 15;
+    if (4 * wave < BH) {   // conv1: 4 -> 32 (one M-tile), N-tiles 2*wave, 2*wave + 1; K-step = kernel row ky
+        typedef const __attribute__((address_space(3))) sp::f16x4 *lds_half;
+        const lds_half q = (lds_half)(in0 + ((4 * wave + (n >> 4)) * sp::kInCols + x + 2 * h) * 8);
+        sp::f16x8 b1[3][2][2];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const int y = row0 + t;
-                    if (y >= BH) continue;
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int p_ = 0; p_ < 2; ++p_) {
+                    const int o = ((2 * t + ky) * sp::kInCols * 8 + p_ * sp::kInPieceBytes) / 8;
+                    const sp::f16x4 lo4 = q[o], hi4 = q[o + 1];
+                    b1[ky][t][p_] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+        sp::f32x16 acc1[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[t][r] = 0.0f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int combo = 0; combo < 3; ++combo)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ky][combo == 2], b1[ky][t][combo == 1], acc1[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int y = 4 * wave + 2 * t + (n >> 4);
+            if (y < BH && x < BW) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
                     float z[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        z[j] = fmaxf(acc[0][t][j] + bv[j], 0.0f) * sp::kActScale;
-                        zmax = fmaxf(zmax, z[j]);
-                    }
+                    for (int j = 0; j < 4; ++j) z[j] = fmaxf(fmaf(acc1[t][4 * g + j], k1, bias1[g][j]), 0.0f);
+                    zmax = fmaxf(fmaxf(zmax, fmaxf(z[0], z[1])), fmaxf(z[2], z[3]));
                     sp::f16x4 hi, lo;
                     sp::split4(z, hi, lo);
-                    char *dst = c1 + ((y + 1) * kRowW + (x + 1)) * sp::Geo<32>::pos_bytes + c0 * 2;
+                    char *dst = c1 + ((y + 1) * kRowW + (x + 1)) * sp::Geo<32>::pos_bytes + (8 * g + 4 * h) * 2;
                     *reinterpret_cast<sp::f16x4 *>(dst) = hi;
                     *reinterpret_cast<sp::f16x4 *>(dst + sp::Geo<32>::piece_bytes) = lo;
                 }
@@ -1311,7 +1351,6 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     }
     __syncthreads();
     if (next_board < n_boards) load_obs(next_board, tid);
-    const int n = lane & 31, h = lane >> 5, x = n & 15;
     sp::f16x8 a3[3][4][2];
     {   // conv2: 32 -> 64
         sp::f32x16 acc[2][2];
@@ -1805,6 +1844,34 @@ std::vector<f32x4> pack_split(const float *w, int cout, int cin, float *scale_ou
     return out;
 }
 
+// conv1 (32 x 4 x 3 x 3) for k_trunk_split: K-step = kernel row ky, k = 4 * kx + plane for kx = 0..3 (kx = 3: zero
+// padding); lane = h*32 + r holds k = 8*h .. 8*h + 7 of output channel r.  [ky][hi | lo][lane] x 8 f16.
+std::vector<f32x4> pack_split1(const float *w, float *scale_out) {
+    float wmax = 0.0f;
+    for (int i = 0; i < 32 * 4 * 9; ++i) wmax = std::fmax(wmax, std::fabs(w[i]));
+    int e = 0;
+    if (wmax > 0.0f && std::isfinite(wmax)) {
+        (void)std::frexp(wmax, &e);
+        e = 14 - e;
+    }
+    const float scale = std::ldexp(1.0f, e);
+    *scale_out = scale;
+    std::vector<f32x4> out((size_t)3 * 2 * 64);
+    _Float16 *o = reinterpret_cast<_Float16 *>(out.data());
+    for (int ky = 0; ky < 3; ++ky)
+        for (int lane = 0; lane < 64; ++lane) {
+            const int r = lane & 31, h = lane >> 5;
+            for (int j = 0; j < 8; ++j) {
+                const int kx = 2 * h + (j >> 2), c = j & 3;
+                const float v = kx < 3 ? w[((r * 4 + c) * 3 + ky) * 3 + kx] * scale : 0.0f;
+                const _Float16 hi = (_Float16)v;
+                o[(((size_t)ky * 2 + 0) * 64 + lane) * 8 + j] = hi;
+                o[(((size_t)ky * 2 + 1) * 64 + lane) * 8 + j] = (_Float16)(v - (float)hi);
+            }
+        }
+    return out;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1903,7 +1970,9 @@ int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params) {
         float sw2 = 1.0f, sw3 = 1.0f;
         up_vec4(pack_split(h_params[2], 64, 32, &sw2), &D.s2);
         up_vec4(pack_split(h_params[4], 128, 64, &sw3), &D.s3);
-        up_f(std::vector<float>{1.0f / (sp::kActScale * sw2), 1.0f / (sp::kActScale * sw3)}.data(), 2, &D.s_inv);
+        float sw1 = 1.0f;
+        up_vec4(pack_split1(h_params[0], &sw1), &D.s1);
+        up_f(std::vector<float>{1.0f / (sp::kActScale * sw2), 1.0f / (sp::kActScale * sw3), 1.0f / sw1}.data(), 3, &D.s_inv);
     }
     up_f(h_params[5], 128, &D.b3);
     {

@@ -238,10 +238,13 @@ int rz_uct_scores(rz_engine *e, const double *d_w, const int32_t *d_n, const int
                   double c_puct, double *d_out, int64_t count, void *stream);
 
 /* ---------------------------------------------------------------------------------------
- * Policy-value network forward (the evaluator's dense contraction), hand-written fp32 MFMA.
+ * Policy-value network forward (the evaluator's dense contraction), hand-written MFMA kernels.
  * Replaces PolicyValueNet.forward (rlzero/games/gomoku/policy_value_net.py:34-52) for a batch
  * of leaf observations: conv3x3 4->32->64->128 (+ReLU), conv1x1 heads, the three FC layers,
- * log_softmax and tanh.  Exact fp32 arithmetic (no reduced precision).
+ * log_softmax and tanh.  f32 results: the default trunk (RZ_NET_SPLIT_F16) carries every f32 operand of
+ * conv1..conv3 as a pair of f16 values on the f16 matrix pipe and accumulates in f32 (error against fp64
+ * at the level of the exact-f32 kernel, 1e-7 relative); the other algorithms and the FC layers use the
+ * f32-input MFMA.
  *
  * rz_net_load takes HOST pointers to the 16 tensors of PolicyValueNet.state_dict() in its
  * order (conv1.weight, conv1.bias, conv2.*, conv3.*, act_conv1.*, act_fc1.*, val_conv1.*,
@@ -262,11 +265,11 @@ enum {
                             multiply-adds; fp32 throughout, differs from DIRECT by re-association only);
                             8 waves per board, two per SIMD */
     RZ_NET_WINOGRAD_4W = 2, /* same arithmetic, 4 waves per board (one per SIMD, whole register file) */
-    RZ_NET_WINOGRAD_F4 = 3,  /* default: conv2/conv3 as Winograd F(4x4,3x3): 4x fewer multiply-adds than DIRECT; fp32
+    RZ_NET_WINOGRAD_F4 = 3,  /* conv2/conv3 as Winograd F(4x4,3x3): 4x fewer multiply-adds than DIRECT; fp32
                                 throughout, ~1e-6 absolute on the activations (one digit more than F(2x2,3x3));
                                 4 waves per board, two output-channel tiles each, one per SIMD */
     RZ_NET_WINOGRAD_F4_8W = 4, /* same arithmetic, 8 waves per board with one tile each (two per SIMD; slower) */
-    RZ_NET_SPLIT_F16 = 5 /* conv2/conv3 as direct convolutions on the f16 matrix pipe with every f32 operand carried
+    RZ_NET_SPLIT_F16 = 5 /* default: conv1..conv3 as direct convolutions on the f16 matrix pipe with every f32 operand carried
                             as hi + lo (two f16 values, 22 significant bits) and every product as hi*hi + hi*lo +
                             lo*hi accumulated in f32: within a few 1e-7 (relative) of the f32 kernels.  Scaled
                             activations must stay below 65504 / 16: a larger one sets RZ_NET_FLAG_F16_RANGE */

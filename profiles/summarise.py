@@ -17,7 +17,7 @@ import os
 import shutil
 import sys
 
-KERNELS = {'k_trunk': 'k_trunk_wino', 'k_tree_step': 'k_tree_step_raw', 'k_heads_gemm': 'k_heads_gemm'}
+KERNELS = {'k_trunk': 'k_trunk', 'k_tree_step': 'k_tree_step_raw', 'k_heads_gemm': 'k_heads_gemm'}
 
 
 def per_kernel(csv_path, counter):
@@ -35,7 +35,9 @@ def per_kernel(csv_path, counter):
 def main(out):
     keep = os.path.join(out, 'keep')
     os.makedirs(keep, exist_ok=True)
-    for name in ('bench_default.json', 'bench_1lane_512games.json', 'bench_under_rocprof.json',
+    for name in ('bench_default.json', 'bench_1lane_512games.json', 'bench_2lanes_896games.json', 'bench_f32_winograd_f4.json',
+                 'microbench_f32_mfma_overlap.txt', 'microbench_f16_mfma_rate.txt', 'microbench_f16_mfma_fillers.txt',
+                 'bench_under_rocprof.json',
                  'bench_eager_under_rocprof.json', 'bench_eager_1lane_under_rocprof.json',
                  'bench_c1_ttt.json', 'bench_c2_9x9.json', 'bench_c3_connect4.json', 'bench_c5_muzero_cartpole.json'):
         src = os.path.join(out, name)

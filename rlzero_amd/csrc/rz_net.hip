@@ -1,14 +1,18 @@
-// rz_net.hip -- fused fp32 forward of the AlphaZero policy-value network on MI355X (gfx950).
+// rz_net.hip -- fused forward of the AlphaZero policy-value network on MI355X (gfx950), f32 results.
 //
 // Replaces PolicyValueNet.forward (rlzero/games/gomoku/policy_value_net.py:34-52) for the
 // batch of MCTS leaves: the one dense contraction of the path (42.8 MFLOP per
-// 15x15 position, MFMA-bound).  Exact fp32: v_mfma_f32_16x16x4_f32 is a k-ordered fmaf
-// chain, no reduced precision anywhere (tolerance vs the reference's CPU output: 1e-4).
+// 15x15 position, MFMA-bound).  The default trunk carries f32 operands as hi + lo f16 pairs on the f16 matrix
+// pipe (three MFMAs per product, f32 accumulation: as accurate as the exact-f32 kernel); the other trunks and
+// the FC layers use v_mfma_f32_16x16x4_f32, a k-ordered fmaf chain (tolerance vs the reference's CPU output: 1e-4).
 //
 // Kernels (one workgroup owns a board; its activations never leave the CU: input planes, conv1 output (32 ch)
 // and conv2 output (64 ch) live in LDS as halo-padded planes [channel][18 rows][18 cols]; conv3's 128 channels
 // stay in registers and are consumed by the two 1x1 head convolutions there):
-//   k_trunk_wino_f4<4> (default)  conv2 / conv3 as Winograd F(4x4,3x3), persistent workgroups, 4 waves
+//   k_trunk_split (default)       conv1..conv3 as direct convolutions on v_mfma_f32_32x32x16_f16, every f32 operand
+//                                 a hi + lo pair of f16 values; persistent workgroups, 4 waves (f16 layouts in LDS:
+//                                 see the kernel)
+//   k_trunk_wino_f4<4>            conv2 / conv3 as Winograd F(4x4,3x3), persistent workgroups, 4 waves
 //   k_trunk_wino_f4<8>            same arithmetic, 8 waves
 //   k_trunk_wino<4> / <2>         Winograd F(2x2,3x3), 8 / 4 waves
 //   k_trunk                       direct implicit GEMM (bit-for-bit a k-ordered fmaf chain): M = output channels
@@ -1089,7 +1093,7 @@ __global__ __launch_bounds__(64 * W) void k_trunk_wino_f4(NetDev nd, const float
 }
 
 // ------------------------------------------------------------------ split-operand direct convolution
-// conv2 / conv3 as DIRECT 3x3 convolutions on the f16 matrix pipe (v_mfma_f32_32x32x16_f16: 16x the rate of
+// conv1 .. conv3 as DIRECT 3x3 convolutions on the f16 matrix pipe (v_mfma_f32_32x32x16_f16: 16x the rate of
 // the f32-input MFMA, which runs at the vector rate and does not overlap with vector work at all -- DESIGN.md
 // section 5), with every f32 operand carried as an unevaluated sum of two f16 values:
 //     x * s = hi + lo,  hi = f16(x * s),  lo = f16(x * s - hi)           (s: a power of two, see below)
@@ -1102,15 +1106,17 @@ __global__ __launch_bounds__(64 * W) void k_trunk_wino_f4(NetDev nd, const float
 // into [2^13, 2^14); the accumulator is rescaled (exactly) in the epilogue.
 //   * LDS: conv1's and conv2's outputs as [piece][18 rows][18 cols][channels + 8] f16, channels innermost, so
 //     the B fragment of a lane (8 consecutive input channels of one position) is ONE ds_read_b128; position
-//     strides of 80 / 144 bytes spread the 8 lanes of an LDS cycle over all 64 banks.  150.5 KB + 12 KB of
-//     head partial sums.
+//     strides of 80 / 144 bytes spread the 8 lanes of an LDS cycle over all 64 banks.  147.4 KB + 3.5 KB of
+//     head weights and conv3 biases, staged once per persistent workgroup.
 //   * MFMA tile: M = 32 output channels, N = 32 positions = two board rows x 16 columns, K = 16 input channels
-//     of one tap.  A wave owns 2 M-tiles x TN N-tiles (conv2: TN = 2, all four waves on different rows; conv3:
-//     TN = 4, wave = (channel half, board half)), so one K-step is 6*TN MFMAs on 4 weight fragments (buffer
-//     loads from L2, packed on the host in fragment order, two steps ahead) and 2*TN activation fragments (one
-//     step ahead); one load is pinned behind each of the first MFMAs of the step.
-//   * conv1 (4 -> 32, 2 % of the work) stays on the exact f32 path of the other kernels and writes its output
-//     as hi / lo pieces; conv3's output feeds the two 1x1 head convolutions from registers in f32.
+//     of one tap.  Wave w owns board rows 4w .. 4w+3 (2 N-tiles) and ALL M-tiles of a layer (conv2: 2, conv3:
+//     4), so one K-step is 6*TM MFMAs on 2*TM weight fragments (buffer loads from L2, packed on the host in
+//     fragment order, two steps ahead) and 4 activation fragments (one step ahead); one load is pinned behind
+//     each of the first MFMAs of the step.  The chip is at its power limit in these loops (DESIGN.md section
+//     5): what counts is the amount of work, not where it is placed.
+//   * conv1 (4 -> 32): the observation planes live in LDS as [piece][position][4 planes] f16, K-step = one kernel
+//     row (4 columns x 4 planes, the 4th column meeting zero weights), its 6 weight fragments and biases stay in
+//     registers across boards; conv3's output feeds the two 1x1 head convolutions from registers in f32.
 namespace sp {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
-"""Headline benchmark: MCTS simulations / second of AlphaZero self-play on 15x15 Gomoku,
-800 simulations per move (BASELINE.json configs[3]), random-init PolicyValueNet
-(torch.manual_seed(0)), fp32.  Games in flight per GPU are an engine parameter (the batch of
-the leaf evaluation): the default keeps 2 lanes x 448 games = 896 per GPU, which is what fills
-an MI355X -- the network trunk of one lane runs as 224 persistent workgroups (28 of the 32 CUs
-of every XCD, two boards each) while the tree / FC kernels of the other lane use the 32 CUs left
-free.  `--lanes 1 --games 512` is the literal 4096 / 8 games per GPU of configs[3].
+"""Headline benchmark: MCTS simulations / second (and self-play games / second) of AlphaZero self-play on
+15x15 Gomoku, 800 simulations per move (BASELINE.json configs[3]), random-init PolicyValueNet
+(torch.manual_seed(0)), fp32.  Games in flight per GPU are an engine parameter (the batch of the leaf
+evaluation): the default keeps 2 lanes x 672 games = 1344 per GPU, which is what fills an MI355X -- the
+network trunk of one lane runs as 224 persistent workgroups (28 of the 32 CUs of every XCD, three boards
+each) while the tree / FC kernels of the other lane use the 32 CUs left free.  `--lanes 1 --games 512` is
+the literal 4096 / 8 games per GPU of configs[3]; at N = 1 the default run measures it too (`literal_config`).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -13,7 +13,7 @@ free.  `--lanes 1 --games 512` is the literal 4096 / 8 games per GPU of configs[
 A "step" is one move of every game on the GPU: n_playout simulation steps (select ->
 evaluate -> expand/backup for all games), pi from the root visits, a move drawn and applied,
 tree reuse; finished games are replaced by fresh ones so the batch stays full.  Games are
-independent, so N GPUs play N x 512 games with no collective in the timed region (weak
+independent, so N GPUs play N x 1344 games with no collective in the timed region (weak
 scaling); rank 0 prints ONE JSON line.
 
 Also on the line:
@@ -21,6 +21,8 @@ Also on the line:
                 the path's one dense contraction): algorithmic FLOPs F(S) = 188416*S + 8*S^2 +
                 128 per position x positions per launch / its average duration
                 from HIP events on the launch stream, against the fp32 matrix peak.
+  selfplay      after the timed steps the first-generation games are played to their end (slots refilled):
+                games/s = moves/s of that leg / mean plies per game.
   cpu_baseline  the oracle (Python restatement of the reference, batch-1 torch CPU forward,
                 one thread per process) timed on this host's cores on a bounded sample of
                 the same workload.
@@ -181,6 +183,24 @@ def run_cpu_baseline(seconds):
                       % (cores, seconds, BOARD, BOARD, N_PLAYOUT)}
 
 
+def run_literal_config(args):
+    """`bench.py --lanes 1 --games 512` as a child process -> the fields of its line worth keeping, or None."""
+    cmd = [sys.executable, os.path.abspath(__file__), '--lanes', '1', '--games', str(GAMES_PER_GPU), '--steps',
+           str(args.steps), '--warmup', str(args.warmup), '--net-algo', args.net_algo, '--graph', str(args.graph),
+           '--no-cpu-baseline', '--no-games-leg', '--no-literal-config']
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=REPO, timeout=600).stdout
+        rec = json.loads(out.decode().strip().splitlines()[-1])
+        rf = rec.get('roofline') or {}
+        return {'workload': rec['config']['workload'], 'lanes': 1, 'value': rec['value'], 'unit': rec['unit'],
+                'ms_per_step': rec['ms_per_step'], 'roofline_frac': rf.get('frac'),
+                'roofline_avg_launch_ms': rf.get('avg_launch_ms'),
+                'note': 'same engine, one lane of %d games in flight = 4096 games / 8 GPUs (BASELINE.json configs[3]); '
+                        'measured by a child process before the main run' % GAMES_PER_GPU}
+    except Exception:  # noqa: BLE001
+        return None
+
+
 # --------------------------------------------------------------------------- GPU run
 class TimedEvaluator(object):
     """Brackets every evaluator call (the policy+value forward of the leaf batch) with HIP
@@ -233,7 +253,7 @@ class TimedEvaluator(object):
         return sum(a.elapsed_time(b) for a, b in self.events) / len(self.events)
 
 
-def run_muzero(args, rank, world, device, dist):
+def run_muzero(args, rank, world, device, dist, red_device):
     """BASELINE.json configs[4]: MuZero on CartPole-v1, 50 simulations per move (random-init model).  A step =
     one move of every environment: initial inference, n simulations (HIP tree kernels + recurrent inference on
     the batch), action sampling, environment step."""
@@ -262,10 +282,10 @@ def run_muzero(args, rank, world, device, dist):
     elapsed = time.perf_counter() - t0
     total = float(sp.sims_done - sims0)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([total], dtype=torch.float64, device=device)
+        c = torch.tensor([total], dtype=torch.float64, device=red_device)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         total = float(c.item())
     sp.tree.check()
@@ -309,6 +329,12 @@ def main():
                          "PyTorch-ROCm/MIOpen; vlin: synthetic evaluator (isolates the tree kernels)")
     ap.add_argument('--graph', type=int, default=8, help='simulation steps per hipGraph (0 = eager)')
     ap.add_argument('--net-algo', default='split_f16', choices=['winograd', 'winograd4w', 'winograd_f4', 'winograd_f4_8w', 'direct', 'split_f16'])
+    ap.add_argument('--no-games-leg', action='store_true',
+                    help='skip the self-play games/s leg (after the timed steps the games of the first generation '
+                         'are played to their end, slots refilled, to measure moves/s over whole games and the mean '
+                         'game length)')
+    ap.add_argument('--no-literal-config', action='store_true',
+                    help='skip the extra N=1 measurement of the literal configs[3] share: 1 lane x %d games' % GAMES_PER_GPU)
     ap.add_argument('--lanes', type=int, default=2,
                     help='independent batches of games on separate HIP streams (the tree / FC kernels of one '
                          'lane run beside the network trunk of the other)')
@@ -326,6 +352,13 @@ def main():
     if world == 1 and args.gpus == 1 and not args.no_cpu_baseline:
         cpu_baseline = run_cpu_baseline(args.cpu_seconds)
 
+    # the literal share of configs[3] (4096 games / 8 GPUs = 512 per GPU, one lane) in a child process of its
+    # own, also before this process touches the GPU (a process that has initialised the GPU starts no program)
+    literal = None
+    if (world == 1 and args.gpus == 1 and not args.no_literal_config and args.game == 'gomoku' and args.games == 0
+            and args.board == BOARD and args.playouts == N_PLAYOUT and args.evaluator == 'hipnet'):
+        literal = run_literal_config(args)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -339,6 +372,7 @@ def main():
     backend = os.environ.get('RZ_BENCH_BACKEND', 'nccl')
     torch.cuda.set_device(local_rank)
     device = 'cuda:%d' % local_rank
+    red_device = device if backend == 'nccl' else 'cpu'  # where the MAX / SUM reductions of the result live
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
@@ -347,7 +381,7 @@ def main():
             dist.init_process_group(backend)
 
     if args.game == 'muzero':
-        run_muzero(args, rank, world, device, dist)
+        run_muzero(args, rank, world, device, dist, red_device)
         return
     board, n_row = args.board, (N_ROW if args.board >= 5 else args.board)
     cells = board * board
@@ -394,10 +428,12 @@ def main():
     sp._start(range(G), [rank + world * i for i in range(G)])
     sp._set_active()
     finished = [0]
+    first_gen_plies = []  # lengths of the finished games among the G games this rank started with
 
     def one_step():
         done = sp.play_move()
         finished[0] += len(done)
+        first_gen_plies.extend(len(t.moves) for t in done if t.game_id < world * G)
         if done:
             free = np.nonzero(sp.slot_game < 0)[0]
             ids = [next_id[0] + world * i for i in range(len(free))]
@@ -424,10 +460,10 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        counts = torch.tensor([sp.sims_done - sims0, finished[0] - fin0], dtype=torch.float64, device=device)
+        counts = torch.tensor([sp.sims_done - sims0, finished[0] - fin0], dtype=torch.float64, device=red_device)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
         total_sims, total_finished = float(counts[0].item()), float(counts[1].item())
     else:
@@ -451,6 +487,39 @@ def main():
         exclusive_ms = sum(a.elapsed_time(b) for a, b in evs[4:]) / len(evs[4:])
     hbm_bytes = sum(st.device_bytes for st in all_stats)
 
+    # self-play games / second (the second half of BASELINE.json's metric): keep playing, slots refilled, until
+    # every game of the first generation has ended (a game ends within S plies), so the mean game length is
+    # unbiased; steady-state games/s = moves/s over this leg / mean plies per game.
+    selfplay = None
+    if not args.no_games_leg:
+        for ev in evaluators:
+            if isinstance(ev, TimedEvaluator):
+                ev.record = False
+        fence()
+        m0, t1 = sp.moves_done, time.perf_counter()
+        guard = 0
+        while len(first_gen_plies) < G and guard <= cells + 1:
+            one_step()
+            guard += 1
+        fence()
+        leg = time.perf_counter() - t1
+        acc = [float(sp.moves_done - m0), float(sum(first_gen_plies)), float(len(first_gen_plies))]
+        if world > 1:
+            t = torch.tensor([leg], dtype=torch.float64, device=red_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            leg = float(t.item())
+            c = torch.tensor(acc, dtype=torch.float64, device=red_device)
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            acc = [float(v) for v in c.tolist()]
+        sp.check()
+        if acc[2] > 0 and leg > 0:
+            mean_plies = acc[1] / acc[2]
+            selfplay = {'games_per_sec': round(acc[0] / leg / mean_plies, 2), 'mean_plies_per_game': round(mean_plies, 2),
+                        'games_sampled': int(acc[2]), 'moves_per_sec': round(acc[0] / leg, 2),
+                        'leg_seconds': round(leg, 2),
+                        'note': 'after the timed steps: all first-generation games played to their end with finished '
+                                'slots refilled; games/s = moves/s of this leg / mean plies of those games'}
+
     if rank == 0:
         value = total_sims / elapsed
         line = {
@@ -469,6 +538,8 @@ def main():
                        'sims_per_graph': args.graph, 'lanes': lanes, 'parallelism': 'games sharded, dp%d' % world},
             'moves_per_sec': round(total_sims / args.playouts / elapsed, 2),
             'games_finished_in_timed_region': int(total_finished),
+            'selfplay_games_per_sec': selfplay['games_per_sec'] if selfplay else None,
+            'selfplay': selfplay,
             'arena_slots_used_max': int(stats.max_slots_used),
             'engine_hbm_bytes': int(hbm_bytes),
         }
@@ -517,6 +588,7 @@ def main():
                 line['roofline'] = {'bound': 'hbm', 'kernel': 'k_select + k_expand_backup (tree only)',
                                     'achieved': round(achieved, 3), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                     'frac': round(achieved / PEAK_HBM_GBS, 6), 'traffic': None}
+        line['literal_config'] = literal
         line['cpu_baseline'] = cpu_baseline
         print(json.dumps(line), flush=True)
     for eng in engines:

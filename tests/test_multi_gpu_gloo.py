@@ -96,3 +96,30 @@ def test_move_uniform_is_a_pure_function_of_seed_game_ply():
     assert np.array_equal(a, b) and (a >= 0).all() and (a < 1).all()
     assert abs(a.mean() - 0.5) < 0.05 and len(np.unique(a)) == 1000
     assert move_uniform(7, 3, 4) != move_uniform(8, 3, 4) != move_uniform(7, 4, 3)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 path (RANK / WORLD_SIZE from the launcher, barriers around the timed region, MAX over
+    ranks of the time, SUM of the work, one JSON line from rank 0) rehearsed on a 1-GPU box: the two ranks share
+    cuda:0 and rendezvous over gloo (RCCL refuses two ranks on one device)."""
+    import json
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RZ_BENCH_SINGLE_DEVICE='1', RZ_BENCH_BACKEND='gloo')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2',
+           '--warmup', '1', '--board', '9', '--playouts', '40', '--games', '32']
+    out = subprocess.run(cmd, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['steps'] == 2 and rec['scaling'] == 'weak'
+    assert rec['config']['games_total'] == 64
+    # 2 ranks x 32 games x 2 moves x 40 simulations in the timed region
+    assert abs(rec['value'] * rec['ms_per_step'] * 2 / 1000.0 - 2 * 32 * 2 * 40) < 1.0
+    assert rec['cpu_baseline'] is None and rec['literal_config'] is None
+    assert rec['selfplay']['games_sampled'] == 64 and rec['selfplay_games_per_sec'] > 0

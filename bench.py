@@ -45,6 +45,7 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 PEAK_F16_MATRIX_TFLOPS = 2500.0  # dense f16 / bf16 MFMA, same table
 SPLIT_MFMAS_PER_PRODUCT = 3      # split_f16: hi*hi + hi*lo + lo*hi
 PEAK_HBM_GBS = 8000.0
+GATHER_SAMPLE_GAMES = 256  # N > 1: finished games per rank sent to rank 0 by the trajectory gather (outside the timed region)
 
 
 def flops_per_position(cells):
@@ -186,7 +187,7 @@ def run_cpu_baseline(seconds):
 def run_literal_config(args):
     """`bench.py --lanes 1 --games 512` as a child process -> the fields of its line worth keeping, or None."""
     cmd = [sys.executable, os.path.abspath(__file__), '--lanes', '1', '--games', str(GAMES_PER_GPU), '--steps',
-           str(args.steps), '--warmup', str(args.warmup), '--net-algo', args.net_algo, '--graph', str(args.graph),
+           str(args.steps), '--warmup', str(args.warmup), '--net-algo', args.net_algo, '--heads-algo', args.heads_algo, '--graph', str(args.graph),
            '--no-cpu-baseline', '--no-games-leg', '--no-literal-config']
     try:
         out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=REPO, timeout=600).stdout
@@ -335,6 +336,8 @@ def main():
                          'game length)')
     ap.add_argument('--no-literal-config', action='store_true',
                     help='skip the extra N=1 measurement of the literal configs[3] share: 1 lane x %d games' % GAMES_PER_GPU)
+    ap.add_argument('--heads-algo', default='auto', choices=['auto', 'f32', 'split32', 'split64'],
+                    help='GEMM of the first FC layers (rz_net_set_heads_algo)')
     ap.add_argument('--lanes', type=int, default=2,
                     help='independent batches of games on separate HIP streams (the tree / FC kernels of one '
                          'lane run beside the network trunk of the other)')
@@ -405,6 +408,7 @@ def main():
         if args.evaluator == 'hipnet':
             hip_ev = HipNetEvaluator(net, net_shape, device, max_boards=g_lane)
             hip_ev.hip.set_algo(args.net_algo)
+            hip_ev.hip.set_heads_algo(args.heads_algo)
             hip_ev.hip.set_max_workgroups(trunk_wgs)
             ev = TimedEvaluator(hip_ev, torch,
                                 {'winograd': 'k_trunk_wino<4> (hand-written fused fp32-MFMA conv trunk, Winograd F(2x2,3x3), csrc/rz_net.hip)',
@@ -429,11 +433,14 @@ def main():
     sp._set_active()
     finished = [0]
     first_gen_plies = []  # lengths of the finished games among the G games this rank started with
+    gather_sample = []    # N > 1: finished trajectories for the one exchange of the path (after the timed region)
 
     def one_step():
         done = sp.play_move()
         finished[0] += len(done)
         first_gen_plies.extend(len(t.moves) for t in done if t.game_id < world * G)
+        if world > 1 and len(gather_sample) < GATHER_SAMPLE_GAMES:
+            gather_sample.extend(done[:GATHER_SAMPLE_GAMES - len(gather_sample)])
         if done:
             free = np.nonzero(sp.slot_game < 0)[0]
             ids = [next_id[0] + world * i for i in range(len(free))]
@@ -520,6 +527,23 @@ def main():
                         'note': 'after the timed steps: all first-generation games played to their end with finished '
                                 'slots refilled; games/s = moves/s of this leg / mean plies of those games'}
 
+    # N > 1: the path's single exchange, a gather of finished trajectories to rank 0 (RCCL over xGMI when the
+    # process group is nccl), exercised on a bounded sample outside the timed region
+    gather = None
+    if world > 1 and not args.no_games_leg:
+        from rlzero_amd.selfplay import gather_trajectories
+        fence()
+        t2 = time.perf_counter()
+        merged = gather_trajectories(gather_sample, board, n_row, dst=0, game=args.game)
+        fence()
+        dt = time.perf_counter() - t2
+        if rank == 0:
+            plies = sum(len(t.moves) for t in merged)
+            gather = {'ranks': world, 'games': len(merged), 'plies': plies, 'backend': dist.get_backend(),
+                      'payload_bytes': int(32 * len(merged) + plies * 8 * (1 + merged[0].pis.shape[1])) if merged else 0,
+                      'ms': round(1000.0 * dt, 2),
+                      'unique_game_ids': len({t.game_id for t in merged}) == len(merged)}
+
     if rank == 0:
         value = total_sims / elapsed
         line = {
@@ -540,6 +564,7 @@ def main():
             'games_finished_in_timed_region': int(total_finished),
             'selfplay_games_per_sec': selfplay['games_per_sec'] if selfplay else None,
             'selfplay': selfplay,
+            'trajectory_gather': gather,
             'arena_slots_used_max': int(stats.max_slots_used),
             'engine_hbm_bytes': int(hbm_bytes),
         }

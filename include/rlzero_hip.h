@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 15
+#define RZ_ABI_VERSION 16
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 
@@ -243,8 +243,8 @@ int rz_uct_scores(rz_engine *e, const double *d_w, const int32_t *d_n, const int
  * of leaf observations: conv3x3 4->32->64->128 (+ReLU), conv1x1 heads, the three FC layers,
  * log_softmax and tanh.  f32 results: the default trunk (RZ_NET_SPLIT_F16) carries every f32 operand of
  * conv1..conv3 as a pair of f16 values on the f16 matrix pipe and accumulates in f32 (error against fp64
- * at the level of the exact-f32 kernel, 1e-7 relative); the other algorithms and the FC layers use the
- * f32-input MFMA.
+ * at the level of the exact-f32 kernel, 1e-7 relative) and the FC GEMM that follows it does the same
+ * (rz_net_set_heads_algo); the other algorithms use the f32-input MFMA.
  *
  * rz_net_load takes HOST pointers to the 16 tensors of PolicyValueNet.state_dict() in its
  * order (conv1.weight, conv1.bias, conv2.*, conv3.*, act_conv1.*, act_fc1.*, val_conv1.*,
@@ -284,6 +284,15 @@ int rz_net_set_algo(rz_net *net, int32_t algo);
  * beside the trunk; 0 (default) = one workgroup per CU.  Workgroups are dealt to the 8 XCDs in turn:
  * use a multiple of 8. */
 int rz_net_set_max_workgroups(rz_net *net, int32_t max_workgroups);
+/* The first FC layers of the two heads (act_fc1, val_fc1; policy_value_net.py:43,48) as one GEMM over the leaf batch.
+ * RZ_NET_HEADS_F32: the f32-input MFMA GEMM (32 x 32 output blocks, many small workgroups).  RZ_NET_HEADS_SPLIT_32 /
+ * _64: on the f16 matrix pipe with hi + lo f16 operand pairs (k_heads_split, the arithmetic of RZ_NET_SPLIT_F16), 32 /
+ * 64 boards per workgroup; needs the f16 feature pieces that the RZ_NET_SPLIT_F16 trunk writes beside the f32
+ * features of the internal buffer, and falls back to F32 when the last trunk was another one.
+ * RZ_NET_HEADS_AUTO (default): SPLIT_64 when the trunk is capped by rz_net_set_max_workgroups (the GEMM then has
+ * only the few CUs the trunk leaves free, where the f32-input MFMA rate is the limit), F32 otherwise. */
+enum { RZ_NET_HEADS_AUTO = 0, RZ_NET_HEADS_F32 = 1, RZ_NET_HEADS_SPLIT_32 = 2, RZ_NET_HEADS_SPLIT_64 = 3 };
+int rz_net_set_heads_algo(rz_net *net, int32_t heads_algo);
 int rz_net_create(int32_t height, int32_t width, int32_t n_actions, int32_t device, rz_net **out);
 int rz_net_destroy(rz_net *net);
 /* Uploads (and re-packs) the 16 tensors of PolicyValueNet.state_dict().  Later calls reuse the device

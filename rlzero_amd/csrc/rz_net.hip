@@ -55,8 +55,10 @@ struct NetDev {
     const f32x4 *u2f, *u3f;      // F(4x4,3x3): [tile][pass][cin_step][3][64 lanes] x 4 components (pack_wino_f4)
     const f32x4 *s1;             // conv1 for k_trunk_split: [kernel row][hi | lo][64 lanes] x 8 f16 (pack_split1)
     const f32x4 *s2, *s3;        // split f16 weights: [32-channel tile][tap][16-channel chunk][hi | lo][64 lanes] x 8 f16
-    const float *s_inv;          // [3] in device memory (a captured launch must see a reload's values):
-                                 // 1 / (activation scale * weight scale) of conv2, conv3; 1 / weight scale of conv1
+    const float *s_inv;          // [5] in device memory (a captured launch must see a reload's values):
+                                 // 1 / (activation scale * weight scale) of conv2, conv3; 1 / weight scale of conv1;
+                                 // 1 / (activation scale * weight scale) of act_fc1, val_fc1 (k_heads_split)
+    const f32x4 *fs_act, *fs_val;  // split f16 FC weights: [32-output tile][K-step of 16][hi | lo][64 lanes] x 8 f16
     const float *b1, *b2, *b3;   // conv biases
     const float *wh;             // [6][128]: act_conv1 (4 rows) then val_conv1 (2 rows)
     const float *whp;            // the same, [128][6] (k_trunk_split)
@@ -1239,8 +1241,8 @@ __device__ __forceinline__ void conv(const char *in, const void *wts, int nt0, i
 // 1x1 head convolutions see every channel of a position in one wave (two lane halves, one shuffle) and the head
 // features go from registers to memory: two barriers per board.
 __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__restrict__ obs,
-                                                     float *__restrict__ feat, int n_boards,
-                                                     unsigned *__restrict__ flags) {
+                                                     float *__restrict__ feat, _Float16 *__restrict__ feat16,
+                                                     int n_boards, unsigned *__restrict__ flags) {
     constexpr int kThreads = 256;
     __shared__ __attribute__((aligned(16))) char lds_raw[sp::kLdsBytes];
     char *in0 = lds_raw;                      // observation planes, pieces hi | lo
@@ -1440,13 +1442,29 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         // the two lane halves hold different channels of the same two positions: lane half h stores position h
         float *dst = feat + (size_t)board * nd.feat_ld;
         const int y = 4 * wave + 2 * h + (n >> 4);
+        // the same features as hi + lo f16 pieces in the A-fragment order of k_heads_split:
+        // [32-board tile][K-step][hi | lo][lane = 32 * (k / 8 % 2) + board % 32][k % 8]
+        _Float16 *dst16 = feat16 ? feat16 + ((size_t)(board >> 5) * (nd.groups_act + nd.groups_val) * 1024 + (board & 31) * 8)
+                                 : nullptr;
 #pragma unroll
         for (int o = 0; o < 6; ++o) {
             float v0 = vals2[0][o >> 1][o & 1], v1 = vals2[1][o >> 1][o & 1];
             v0 += __shfl_xor(v0, 32);
             v1 += __shfl_xor(v1, 32);
             const float v = fmaxf((h ? v1 : v0) + nd.bh[o], 0.0f);
-            if (y < BH && x < BW) dst[(o < 4 ? o * S : nd.feat_val_off + (o - 4) * S) + y * BW + x] = v;
+            if (y < BH && x < BW) {
+                dst[(o < 4 ? o * S : nd.feat_val_off + (o - 4) * S) + y * BW + x] = v;
+                if (dst16) {
+                    const int k = (o < 4 ? o : o - 4) * S + y * BW + x;
+                    const int step = (o < 4 ? 0 : nd.groups_act) + (k >> 4);
+                    const float z = v * sp::kActScale;
+                    const _Float16 zh = (_Float16)z;
+                    zmax = fmaxf(zmax, z);
+                    _Float16 *q = dst16 + (size_t)step * 1024 + ((k >> 3) & 1) * 256 + (k & 7);
+                    q[0] = zh;
+                    q[512] = (_Float16)(z - (float)zh);
+                }
+            }
         }
     }
     }  // boards
@@ -1655,6 +1673,164 @@ __global__ __launch_bounds__(64 * kHeadWaves) void k_heads_gemm(NetDev nd, const
     }
 }
 
+// k_heads_split: the same two FC layers on the f16 matrix pipe, operands as hi + lo f16 pairs (three
+// v_mfma_f32_32x32x16_f16 per product, f32 accumulation -- the arithmetic of k_trunk_split, which also writes the
+// features as f16 pieces in A-fragment order; weights packed by pack_split_fc).  M = boards, N = outputs, so a
+// lane's accumulator registers are boards of ONE output column and the stores of a tile row are 128 contiguous
+// bytes.  One workgroup = TM 32-board tiles x one half of the policy outputs (4 N-tiles) + one of the two value
+// N-tiles; its 4 waves split K (policy: 4S/16 steps, value: 2S/16) and every wave carries the whole TM x 4 block,
+// so each fragment it loads (1 KB, one 16-byte load per lane, fully coalesced) feeds 3*4 or 3*TM MFMAs -- the
+// loads stay below the ~64 B/clk a CU's vector memory path delivers.  A ring of kFsDepth K-steps is in flight.
+// The partial blocks are summed through LDS (policy first, then the value tile in the same memory).
+constexpr int kFsDepth = 3;
+
+template <int TM, int TN>
+struct FsFrags {
+    sp::f16x8 a[TM][2], b[TN][2];
+};
+
+template <int TM, int TN>
+__device__ __forceinline__ void fs_load(FsFrags<TM, TN> &f, const f32x4 *__restrict__ fa, const f32x4 *__restrict__ fb,
+                                        int steps_a, int steps_b, int step_a, int step_b, const bool (&nv)[TN], int lane) {
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            f.a[m][p] = __builtin_bit_cast(sp::f16x8, fa[(((size_t)m * steps_a + step_a) * 2 + p) * 64 + lane]);
+#pragma unroll
+    for (int n = 0; n < TN; ++n)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            if (nv[n]) f.b[n][p] = __builtin_bit_cast(sp::f16x8, fb[(((size_t)n * steps_b + step_b) * 2 + p) * 64 + lane]);
+}
+
+// acc[m][n] += sum over K-steps [k0, k1) of A-tile m (features) x B-tile n (weights); fa -> step 0 of the first
+// A tile (tiles steps_a K-steps apart), fb likewise for the weights
+template <int TM, int TN>
+__device__ __forceinline__ void fs_gemm(sp::f32x16 (&acc)[TM][TN], const f32x4 *__restrict__ fa, const f32x4 *__restrict__ fb,
+                                        int steps_a, int steps_b, int a_step0, int k0, int k1, const bool (&nv)[TN], int lane) {
+    FsFrags<TM, TN> ring[kFsDepth];
+#pragma unroll
+    for (int d = 0; d < kFsDepth; ++d) {
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) ring[d].a[m][p] = sp::f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int n = 0; n < TN; ++n)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) ring[d].b[n][p] = sp::f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (k0 + d < k1) fs_load<TM, TN>(ring[d], fa, fb, steps_a, steps_b, a_step0 + k0 + d, k0 + d, nv, lane);
+    }
+    for (int k = k0; k < k1; k += kFsDepth) {
+#pragma unroll
+        for (int d = 0; d < kFsDepth; ++d) {
+            if (k + d >= k1) break;
+#pragma unroll
+            for (int combo = 0; combo < 3; ++combo)
+#pragma unroll
+                for (int m = 0; m < TM; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        if (nv[n])
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[d].a[m][combo == 2], ring[d].b[n][combo == 1],
+                                                                              acc[m][n], 0, 0, 0);
+            const int kn = k + d + kFsDepth;
+            if (kn < k1) fs_load<TM, TN>(ring[d], fa, fb, steps_a, steps_b, a_step0 + kn, kn, nv, lane);
+        }
+    }
+}
+
+template <int TM>
+__global__ __launch_bounds__(256) void k_heads_split(NetDev nd, const f32x4 *__restrict__ feat16,
+                                                     float *__restrict__ raw, float *__restrict__ hid, int n_boards) {
+    constexpr int TN = 4;
+    __shared__ sp::f32x16 part[4][TM * TN][64];  // [K quarter][tile][lane]: 16 KB per tile row
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt0 = blockIdx.x * TM, half = blockIdx.y;
+    const int steps_all = nd.groups_act + nd.groups_val;
+    const int n_act_tiles = nd.Npad / 32;
+    const f32x4 *fa = feat16 + (size_t)mt0 * steps_all * 128;  // 128 f32x4 = one K-step (hi | lo) of one tile
+    const int col = lane & 31, h = lane >> 5;
+    {   // policy outputs 128 * half .. + 127
+        bool nv[TN];
+#pragma unroll
+        for (int n = 0; n < TN; ++n) nv[n] = TN * half + n < n_act_tiles;
+        if (nv[0]) {
+            sp::f32x16 acc[TM][TN];
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+            const int K = nd.groups_act, k0 = wave * K / 4, k1 = (wave + 1) * K / 4;
+            fs_gemm<TM, TN>(acc, fa, nd.fs_act + (size_t)TN * half * K * 128, steps_all, K, 0, k0, k1, nv, lane);
+#pragma unroll
+            for (int m = 0; m < TM; ++m)
+#pragma unroll
+                for (int n = 0; n < TN; ++n) part[wave][m * TN + n][lane] = acc[m][n];
+        }
+        __syncthreads();
+        if (nv[0]) {
+            const float scale = nd.s_inv[3];
+            // wave w finishes tiles w, w + 4, ...: D column = output (lane & 31), rows = boards 8g + 4h + j
+#pragma unroll
+            for (int t = wave; t < TM * TN; t += 4) {
+                const int m = t / TN, n = t % TN;
+                if (TN * half + n >= n_act_tiles) continue;
+                sp::f32x16 v = part[0][t][lane];
+#pragma unroll
+                for (int q = 1; q < 4; ++q) {
+                    const sp::f32x16 pq = part[q][t][lane];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] += pq[r];
+                }
+                const int c = 32 * (TN * half + n) + col;
+                const float bias = nd.fc_act_b[c];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int b = 32 * (mt0 + m) + 8 * (r >> 2) + 4 * h + (r & 3);
+                    if (b < n_boards) raw[(size_t)b * nd.Npad + c] = fmaf(v[r], scale, bias);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    {   // value head: hidden units 32 * half .. + 31
+        bool nv[1] = {true};
+        sp::f32x16 acc[TM][1];
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][0][r] = 0.0f;
+        const int K = nd.groups_val, k0 = wave * K / 4, k1 = (wave + 1) * K / 4;
+        fs_gemm<TM, 1>(acc, fa, nd.fs_val + (size_t)half * K * 128, steps_all, K, nd.groups_act, k0, k1, nv, lane);
+#pragma unroll
+        for (int m = 0; m < TM; ++m) part[wave][m][lane] = acc[m][0];
+        __syncthreads();
+        if (wave < TM) {
+            const int m = wave;
+            sp::f32x16 v = part[0][m][lane];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) {
+                const sp::f32x16 pq = part[q][m][lane];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += pq[r];
+            }
+            const float scale = nd.s_inv[4];
+            const int c = 32 * half + col;
+            const float bias = nd.fc_val1_b[c];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int b = 32 * (mt0 + m) + 8 * (r >> 2) + 4 * h + (r & 3);
+                if (b < n_boards) hid[(size_t)b * 64 + c] = fmaxf(fmaf(v[r], scale, bias), 0.0f);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void k_heads_finish(NetDev nd, const float *__restrict__ raw,
                                                      const float *__restrict__ hid, float *__restrict__ logp,
                                                      float *__restrict__ value, int n_boards) {
@@ -1703,6 +1879,9 @@ struct rz_net {
     std::vector<size_t> alloc_bytes;
     size_t upload_cursor = 0;
     float *d_feat = nullptr, *d_raw = nullptr, *d_hid = nullptr;
+    _Float16 *d_feat16 = nullptr;  // the features as hi + lo f16 pieces in fragment order (k_trunk_split -> k_heads_split)
+    bool feat16_valid = false;     // the last trunk launch into the internal buffer wrote d_feat16 too
+    int heads_algo = RZ_NET_HEADS_AUTO;
     unsigned *d_flags = nullptr;
     long long feat_boards = 0;
     size_t feat_floats = 0;
@@ -1878,6 +2057,36 @@ std::vector<f32x4> pack_split1(const float *w, float *scale_out) {
     return out;
 }
 
+// FC weights for k_heads_split: w [n_out][k_in] row-major * scale = hi + lo (scale as in pack_split), packed
+// [32-output tile][K-step][hi | lo][lane] x 8 f16: lane = h*32 + c holds W[32*tile + c][16*step + 8*h + j], the B
+// fragment of v_mfma_f32_32x32x16_f16; zero beyond n_out / k_in.
+std::vector<f32x4> pack_split_fc(const float *w, int n_out, int k_in, int tiles, int steps, float *scale_out) {
+    float wmax = 0.0f;
+    for (size_t i = 0; i < (size_t)n_out * k_in; ++i) wmax = std::fmax(wmax, std::fabs(w[i]));
+    int e = 0;
+    if (wmax > 0.0f && std::isfinite(wmax)) {
+        (void)std::frexp(wmax, &e);
+        e = 14 - e;
+    }
+    const float scale = std::ldexp(1.0f, e);
+    *scale_out = scale;
+    std::vector<f32x4> out((size_t)tiles * steps * 2 * 64, f32x4{0.f, 0.f, 0.f, 0.f});
+    _Float16 *o = reinterpret_cast<_Float16 *>(out.data());
+    for (int t = 0; t < tiles; ++t)
+        for (int st = 0; st < steps; ++st)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int c = lane & 31, h = lane >> 5, row = 32 * t + c;
+                for (int j = 0; j < 8; ++j) {
+                    const int k = 16 * st + 8 * h + j;
+                    const float v = (row < n_out && k < k_in) ? w[(size_t)row * k_in + k] * scale : 0.0f;
+                    const _Float16 hi = (_Float16)v;
+                    o[((((size_t)t * steps + st) * 2 + 0) * 64 + lane) * 8 + j] = hi;
+                    o[((((size_t)t * steps + st) * 2 + 1) * 64 + lane) * 8 + j] = (_Float16)(v - (float)hi);
+                }
+            }
+    return out;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1927,6 +2136,7 @@ int rz_net_destroy(rz_net *net) {
     (void)hipDeviceSynchronize();
     for (void *p : net->allocs) (void)hipFree(p);
     if (net->d_feat) (void)hipFree(net->d_feat);
+    if (net->d_feat16) (void)hipFree(net->d_feat16);
     if (net->d_raw) (void)hipFree(net->d_raw);
     if (net->d_hid) (void)hipFree(net->d_hid);
     if (net->d_flags) (void)hipFree(net->d_flags);
@@ -1978,7 +2188,11 @@ int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params) {
         up_vec4(pack_split(h_params[4], 128, 64, &sw3), &D.s3);
         float sw1 = 1.0f;
         up_vec4(pack_split1(h_params[0], &sw1), &D.s1);
-        up_f(std::vector<float>{1.0f / (sp::kActScale * sw2), 1.0f / (sp::kActScale * sw3), 1.0f / sw1}.data(), 3, &D.s_inv);
+        float sfa = 1.0f, sfv = 1.0f;
+        up_vec4(pack_split_fc(h_params[8], D.A, 4 * S, D.Npad / 32, D.groups_act, &sfa), &D.fs_act);
+        up_vec4(pack_split_fc(h_params[12], 64, 2 * S, 2, D.groups_val, &sfv), &D.fs_val);
+        up_f(std::vector<float>{1.0f / (sp::kActScale * sw2), 1.0f / (sp::kActScale * sw3), 1.0f / sw1,
+                                1.0f / (sp::kActScale * sfa), 1.0f / (sp::kActScale * sfv)}.data(), 5, &D.s_inv);
     }
     up_f(h_params[5], 128, &D.b3);
     {
@@ -2034,9 +2248,12 @@ int rz_net_reserve(rz_net *net, int32_t max_boards) {
     if (max_boards <= net->feat_boards) return RZ_OK;
     (void)hipDeviceSynchronize();
     if (net->d_feat) (void)hipFree(net->d_feat);
+    if (net->d_feat16) (void)hipFree(net->d_feat16);
     if (net->d_raw) (void)hipFree(net->d_raw);
     if (net->d_hid) (void)hipFree(net->d_hid);
     net->d_feat = net->d_raw = net->d_hid = nullptr;
+    net->d_feat16 = nullptr;
+    net->feat16_valid = false;
     net->feat_boards = 0;
     // internal features: [boards padded to 32][16 * (groups_act + groups_val)], zero filled once
     const size_t pad_boards = ((size_t)max_boards + 31) / 32 * 32;
@@ -2048,6 +2265,13 @@ int rz_net_reserve(rz_net *net, int32_t max_boards) {
     // padded boards and the K tail must read as finite values (they meet zero weights)
     if (hipMemset(net->d_feat, 0, net->feat_floats * sizeof(float)) != hipSuccess)
         return net_fail(RZ_ERR_HIP, "hipMemset failed (feature buffer)");
+    {   // f16 pieces: [boards padded to 64][K-steps][hi | lo][16 x f16]; the K tail and padded boards stay zero
+        const size_t bytes = (((size_t)max_boards + 63) / 64 * 64) * (size_t)(net->dev.groups_act + net->dev.groups_val) * 64;
+        if (hipMalloc((void **)&net->d_feat16, bytes) != hipSuccess)
+            return net_fail(RZ_ERR_OOM, "hipMalloc failed (f16 feature buffer)");
+        if (hipMemset(net->d_feat16, 0, bytes) != hipSuccess)
+            return net_fail(RZ_ERR_HIP, "hipMemset failed (f16 feature buffer)");
+    }
     net->feat_boards = max_boards;
     return RZ_OK;
 }
@@ -2056,6 +2280,7 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
     const dim3 grid((unsigned)n_boards);
     // the internal buffer uses the padded layout of the FC GEMM, a caller's buffer the natural one
     const bool internal = d_feat == net->d_feat;
+    if (internal) net->feat16_valid = net->algo == RZ_NET_SPLIT_F16;
     net->dev.feat_ld = internal ? 16 * (net->dev.groups_act + net->dev.groups_val) : 6 * net->dev.S;
     net->dev.feat_val_off = internal ? 16 * net->dev.groups_act : 4 * net->dev.S;
     // Winograd kernels are persistent: one workgroup per CU (LDS bound) loops over its boards
@@ -2070,17 +2295,39 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
     else if (net->algo == RZ_NET_WINOGRAD_F4_8W)
         k_trunk_wino_f4<8><<<pgrid, dim3(512), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
     else if (net->algo == RZ_NET_SPLIT_F16)
-        k_trunk_split<<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards, net->d_flags);
+        k_trunk_split<<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, internal ? net->d_feat16 : nullptr,
+                                                                    n_boards, net->d_flags);
     else
         k_trunk<<<grid, dim3(kTrunkThreads), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
 }
 
-static int launch_heads(rz_net *net, const float *d_feat, int32_t n_boards, float *d_logp, float *d_value,
-                        void *stream) {
+// The FC GEMM of the heads on the internal features -> net->d_raw (policy logits) / net->d_hid (value hidden layer).
+static void launch_heads_gemm(rz_net *net, const float *d_feat, int32_t n_boards, void *stream) {
     net->dev.feat_ld = 16 * (net->dev.groups_act + net->dev.groups_val);
     net->dev.feat_val_off = 16 * net->dev.groups_act;
-    const dim3 grid((unsigned)((n_boards + 31) / 32), (unsigned)(net->dev.Npad / 32 + 2));
-    k_heads_gemm<<<grid, dim3(64 * kHeadWaves), 0, (hipStream_t)stream>>>(net->dev, d_feat, net->d_raw, net->d_hid, n_boards);
+    int algo = net->heads_algo;
+    // measured (profiles/r01/sweep_heads.txt): beside a capped trunk the GEMM has 32 CUs, where the f32-input MFMA is
+    // the limit and the f16 pipe wins; alone on 256 CUs the f32 kernel's 160 small workgroups hide the load latency
+    // that the 16 .. 42 workgroups of k_heads_split expose
+    if (algo == RZ_NET_HEADS_AUTO) algo = net->max_wgs > 0 ? RZ_NET_HEADS_SPLIT_64 : RZ_NET_HEADS_F32;
+    if (d_feat != net->d_feat || !net->feat16_valid) algo = RZ_NET_HEADS_F32;
+    if (algo == RZ_NET_HEADS_SPLIT_64) {
+        const dim3 grid((unsigned)((n_boards + 63) / 64), 2);  // y: policy half + value tile
+        k_heads_split<2><<<grid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, reinterpret_cast<const f32x4 *>(net->d_feat16),
+                                                                      net->d_raw, net->d_hid, n_boards);
+    } else if (algo == RZ_NET_HEADS_SPLIT_32) {
+        const dim3 grid((unsigned)((n_boards + 31) / 32), 2);
+        k_heads_split<1><<<grid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, reinterpret_cast<const f32x4 *>(net->d_feat16),
+                                                                      net->d_raw, net->d_hid, n_boards);
+    } else {
+        const dim3 grid((unsigned)((n_boards + 31) / 32), (unsigned)(net->dev.Npad / 32 + 2));
+        k_heads_gemm<<<grid, dim3(64 * kHeadWaves), 0, (hipStream_t)stream>>>(net->dev, d_feat, net->d_raw, net->d_hid, n_boards);
+    }
+}
+
+static int launch_heads(rz_net *net, const float *d_feat, int32_t n_boards, float *d_logp, float *d_value,
+                        void *stream) {
+    launch_heads_gemm(net, d_feat, n_boards, stream);
     k_heads_finish<<<dim3((unsigned)n_boards), dim3(64), 0, (hipStream_t)stream>>>(net->dev, net->d_raw, net->d_hid,
                                                                                   d_logp, d_value, n_boards);
     if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_heads_* failed");
@@ -2109,6 +2356,13 @@ int rz_net_set_algo(rz_net *net, int32_t algo) {
     return RZ_OK;
 }
 
+int rz_net_set_heads_algo(rz_net *net, int32_t heads_algo) {
+    if (!net) return net_fail(RZ_ERR_ARG, "net handle is NULL");
+    if (heads_algo < RZ_NET_HEADS_AUTO || heads_algo > RZ_NET_HEADS_SPLIT_64) return net_fail(RZ_ERR_ARG, "unknown heads algorithm");
+    net->heads_algo = heads_algo;
+    return RZ_OK;
+}
+
 int rz_net_set_max_workgroups(rz_net *net, int32_t max_workgroups) {
     if (!net) return net_fail(RZ_ERR_ARG, "net handle is NULL");
     if (max_workgroups < 0) return net_fail(RZ_ERR_ARG, "max_workgroups must be >= 0");
@@ -2128,10 +2382,7 @@ int rz_net_heads_gemm(rz_net *net, int32_t n_boards, const float **d_raw, int32_
     *d_w2 = net->dev.fc_val2_w;
     *d_b2 = net->dev.fc_val2_b;
     if (n_boards == 0) return RZ_OK;
-    net->dev.feat_ld = 16 * (net->dev.groups_act + net->dev.groups_val);
-    net->dev.feat_val_off = 16 * net->dev.groups_act;
-    const dim3 grid((unsigned)((n_boards + 31) / 32), (unsigned)(net->dev.Npad / 32 + 2));
-    k_heads_gemm<<<grid, dim3(64 * kHeadWaves), 0, (hipStream_t)stream>>>(net->dev, net->d_feat, net->d_raw, net->d_hid, n_boards);
+    launch_heads_gemm(net, net->d_feat, n_boards, stream);
     if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_heads_gemm failed");
     return RZ_OK;
 }

@@ -121,6 +121,15 @@ class HipNet(object):
             raise HipError("an activation left the range of the split-f16 trunk (>= 4094): use set_algo('winograd_f4')")
         return self
 
+    def set_heads_algo(self, algo):
+        """GEMM of the first FC layers: 'f32' (f32-input MFMA), 'split32' / 'split64' (f16 matrix pipe with hi + lo
+        operand pairs after the 'split_f16' trunk, 32 / 64 boards per workgroup), 'auto' (default: 'split64' beside
+        a capped trunk, 'f32' otherwise)."""
+        code = {'auto': _hip.NET_HEADS_AUTO, 'f32': _hip.NET_HEADS_F32, 'split32': _hip.NET_HEADS_SPLIT_32,
+                'split64': _hip.NET_HEADS_SPLIT_64}[algo]
+        check(self.lib.rz_net_set_heads_algo(self.handle, code), 'rz_net_set_heads_algo')
+        return self
+
     def set_max_workgroups(self, n):
         """Cap the persistent trunk workgroups (0 = one per CU) so that the other CUs stay free for
         the tree / FC kernels of a second lane of games (see BatchedSelfPlay)."""

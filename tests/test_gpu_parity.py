@@ -664,6 +664,50 @@ def test_split_f16_trunk_is_as_accurate_as_the_f32_trunk_and_flags_its_range():
     hip.close()
 
 
+def test_split_f16_heads_gemm_equals_the_f32_gemm():
+    """k_heads_split (the FC GEMM on the f16 matrix pipe, hi + lo operand pairs, fed by the f16 feature pieces the
+    split-f16 trunk writes) against the f32-input MFMA GEMM and an fp64 evaluation: ragged batches (partial 32- and
+    64-board tiles), every board shape (1 .. 8 policy output tiles), both workgroup shapes bit-identical."""
+    import torch
+    from rlzero_amd.engine import HipNet
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    for shape, batches in ((15, (1, 33, 100, 672)), (16, (65, )), (9, (64, 70)), (3, (5, )), ((6, 7, 7), (47, ))):
+        torch.manual_seed(3)
+        net = PolicyValueNet(*shape) if isinstance(shape, tuple) else PolicyValueNet(shape)
+        with torch.no_grad():  # away from the tiny default initialisation: logits of order 1
+            net.act_fc1.weight.mul_(8.0)
+            net.val_fc1.weight.mul_(8.0)
+        hip = HipNet(shape, 'cuda:0', max_boards=max(batches)).load_state_dict(net.state_dict())
+        net64 = (PolicyValueNet(*shape) if isinstance(shape, tuple) else PolicyValueNet(shape)).double()
+        net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+        rows, cols = (shape[0], shape[1]) if isinstance(shape, tuple) else (shape, shape)
+        for n in batches:
+            x = (torch.rand((n, 4, rows, cols), device='cuda:0') < 0.4).float()
+            out = {}
+            for algo in ('f32', 'split32', 'split64', 'auto'):
+                lp, v = hip.set_heads_algo(algo).forward(x)
+                out[algo] = (lp.clone(), v.clone())
+            lp, v = hip.set_max_workgroups(8).forward(x)  # 'auto' beside a capped trunk: the f16 pipe
+            out['auto_capped'] = (lp.clone(), v.clone())
+            hip.set_max_workgroups(0)
+            hip.check_flags()
+            with torch.no_grad():
+                lp64, v64 = net64(x.cpu().double())
+            for algo in ('f32', 'split32'):
+                assert float((out[algo][0].cpu().double() - lp64).abs().max()) <= 2e-5, (shape, n, algo)
+                assert float((out[algo][1].cpu().double() - v64[:, 0]).abs().max()) <= 2e-6, (shape, n, algo)
+            assert float((out['f32'][0] - out['split32'][0]).abs().max()) <= 1e-5
+            assert float((out['f32'][1] - out['split32'][1]).abs().max()) <= 2e-6
+            for algo in ('split64', 'auto_capped'):
+                assert torch.equal(out[algo][0], out['split32'][0]) and torch.equal(out[algo][1], out['split32'][1])
+            assert torch.equal(out['auto'][0], out['f32'][0]) and torch.equal(out['auto'][1], out['f32'][1])
+        # after another trunk the f16 pieces are stale: the GEMM must take the f32 features
+        lp_d, v_d = hip.set_algo('direct').set_heads_algo('split64').forward(x)
+        lp_f, v_f = hip.set_heads_algo('f32').forward(x)
+        assert torch.equal(lp_d, lp_f) and torch.equal(v_d, v_f)
+        hip.close()
+
+
 def test_search_with_hip_net_equals_search_with_its_values():
     """Tree built with the HIP net evaluator == oracle tree fed the very same fp32 values
     (the net's value reaches the tree unchanged; a 512-game batch runs clean)."""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turns the raw rocprofv3 output of profiles/collect.sh into the small files kept under
 profiles/<round>/: per-kernel statistics (CSV as rocprofv3 wrote them) and pmc_traffic.json
-(HBM bytes per launch of the three kernels of a simulation step).
+(HBM bytes per launch of the three kernels of a simulation step; the FC GEMM is k_heads_split beside a capped trunk, k_heads_gemm otherwise).
 
     python3 profiles/summarise.py gpurun_out/r01
 
@@ -17,7 +17,7 @@ import os
 import shutil
 import sys
 
-KERNELS = {'k_trunk': 'k_trunk', 'k_tree_step': 'k_tree_step_raw', 'k_heads_gemm': 'k_heads_gemm'}
+KERNELS = {'k_trunk': 'k_trunk', 'k_tree_step': 'k_tree_step_raw', 'k_heads_gemm': 'k_heads_gemm', 'k_heads_split': 'k_heads_split'}
 
 
 def per_kernel(csv_path, counter):
@@ -37,7 +37,7 @@ def main(out):
     os.makedirs(keep, exist_ok=True)
     for name in ('bench_default.json', 'bench_1lane_512games.json', 'bench_2lanes_896games.json', 'bench_f32_winograd_f4.json',
                  'microbench_f32_mfma_overlap.txt', 'microbench_f16_mfma_rate.txt', 'microbench_f16_mfma_fillers.txt',
-                 'bench_under_rocprof.json',
+                 'bench_under_rocprof.json', 'sweep_games.txt', 'sweep_heads.txt',
                  'bench_eager_under_rocprof.json', 'bench_eager_1lane_under_rocprof.json',
                  'bench_c1_ttt.json', 'bench_c2_9x9.json', 'bench_c3_connect4.json', 'bench_c5_muzero_cartpole.json'):
         src = os.path.join(out, name)

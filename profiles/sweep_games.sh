@@ -1,6 +1,6 @@
 mkdir -p gpurun_out/s3
 for g in 1344 1792 2240 2688; do
-  python bench.py --no-cpu-baseline --games $g > gpurun_out/s3/g$g.json 2> gpurun_out/s3/g$g.err
+  python bench.py --no-cpu-baseline --no-games-leg --no-literal-config --games $g > gpurun_out/s3/g$g.json 2> gpurun_out/s3/g$g.err
   python - <<PY
 import json
 r=json.load(open('gpurun_out/s3/g$g.json'))
@@ -9,7 +9,7 @@ PY
 done
 for w in 232 240; do
   g=$((w*2*4))
-  python bench.py --no-cpu-baseline --games $g --trunk-wgs $w > gpurun_out/s3/w${w}_g$g.json 2> gpurun_out/s3/w${w}_g$g.err
+  python bench.py --no-cpu-baseline --no-games-leg --no-literal-config --games $g --trunk-wgs $w > gpurun_out/s3/w${w}_g$g.json 2> gpurun_out/s3/w${w}_g$g.err
   python - <<PY
 import json
 r=json.load(open('gpurun_out/s3/w${w}_g$g.json'))

@@ -1677,136 +1677,136 @@ __global__ __launch_bounds__(64 * kHeadWaves) void k_heads_gemm(NetDev nd, const
 // v_mfma_f32_32x32x16_f16 per product, f32 accumulation -- the arithmetic of k_trunk_split, which also writes the
 // features as f16 pieces in A-fragment order; weights packed by pack_split_fc).  M = boards, N = outputs, so a
 // lane's accumulator registers are boards of ONE output column and the stores of a tile row are 128 contiguous
-// bytes.  One workgroup = TM 32-board tiles x one half of the policy outputs (4 N-tiles) + one of the two value
-// N-tiles; its 4 waves split K (policy: 4S/16 steps, value: 2S/16) and every wave carries the whole TM x 4 block,
-// so each fragment it loads (1 KB, one 16-byte load per lane, fully coalesced) feeds 3*4 or 3*TM MFMAs -- the
-// loads stay below the ~64 B/clk a CU's vector memory path delivers.  A ring of kFsDepth K-steps is in flight.
-// The partial blocks are summed through LDS (policy first, then the value tile in the same memory).
-constexpr int kFsDepth = 3;
-
+// bytes.  A workgroup = TM 32-board tiles x TN policy N-tiles (group blockIdx.y) or x one of the two value N-tiles;
+// its 4 waves split K into quarters (policy: 4S/16 steps, value: 2S/16) and every wave carries the whole block, so
+// a fragment it loads (1 KB, one 16-byte load per lane, fully coalesced) feeds 3*TN or 3*TM MFMAs; DEPTH K-steps
+// are in flight per wave.  The four partial blocks are summed through LDS in wave order.  The K quarters and the
+// order of the sums do not depend on the shape, so every instantiation gives the same bits:
+//   <2, 4, 3, true>   64 boards x half of the policy outputs AND one value tile per workgroup (policy first, then
+//                     the value tile in the same LDS): 22 workgroups for 672 boards -- for the 32 CUs a capped
+//                     trunk leaves free; the loads stay below the ~64 B/clk of a CU's vector memory path
+//   <1, 2, 5, false>  32 boards x 2 policy tiles, the value tiles in workgroups of their own: 96 small workgroups
+//                     for 512 boards, deep prefetch -- for the whole chip (the kernel is load-latency bound)
 template <int TM, int TN>
 struct FsFrags {
     sp::f16x8 a[TM][2], b[TN][2];
 };
 
+// Fragments of K-step `step` (A: TM feature tiles, steps_a K-steps apart; B: TN weight tiles at fb[n]).  Every load
+// is unconditional -- a load under a branch makes hipcc wait for ALL outstanding loads (vmcnt(0)) before each use,
+// which serialises the ring: a step past the end of the wave's K range re-reads the last feature step against the
+// all-zero weight fragment `zero` (pack_split_fc appends one), and so does an N-tile past the last output tile.
 template <int TM, int TN>
-__device__ __forceinline__ void fs_load(FsFrags<TM, TN> &f, const f32x4 *__restrict__ fa, const f32x4 *__restrict__ fb,
-                                        int steps_a, int steps_b, int step_a, int step_b, const bool (&nv)[TN], int lane) {
+__device__ __forceinline__ void fs_load(FsFrags<TM, TN> &f, const f32x4 *__restrict__ fa, const f32x4 *const (&fb)[TN],
+                                        const f32x4 *__restrict__ zero, int steps_a, int a_step0, int step, int k1, int lane) {
+    const bool live = step < k1;
+    const int sa = a_step0 + (live ? step : k1 - 1);
 #pragma unroll
     for (int m = 0; m < TM; ++m)
 #pragma unroll
         for (int p = 0; p < 2; ++p)
-            f.a[m][p] = __builtin_bit_cast(sp::f16x8, fa[(((size_t)m * steps_a + step_a) * 2 + p) * 64 + lane]);
+            f.a[m][p] = __builtin_bit_cast(sp::f16x8, fa[(((size_t)m * steps_a + sa) * 2 + p) * 64 + lane]);
 #pragma unroll
-    for (int n = 0; n < TN; ++n)
+    for (int n = 0; n < TN; ++n) {
+        // (a tile that does not exist has fb[n] == zero: every step of it reads the one zero fragment)
+        const f32x4 *src = live && fb[n] != zero ? fb[n] + (size_t)step * 128 : zero;
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
-            if (nv[n]) f.b[n][p] = __builtin_bit_cast(sp::f16x8, fb[(((size_t)n * steps_b + step_b) * 2 + p) * 64 + lane]);
+        for (int p = 0; p < 2; ++p) f.b[n][p] = __builtin_bit_cast(sp::f16x8, src[p * 64 + lane]);
+    }
 }
 
-// acc[m][n] += sum over K-steps [k0, k1) of A-tile m (features) x B-tile n (weights); fa -> step 0 of the first
-// A tile (tiles steps_a K-steps apart), fb likewise for the weights
-template <int TM, int TN>
-__device__ __forceinline__ void fs_gemm(sp::f32x16 (&acc)[TM][TN], const f32x4 *__restrict__ fa, const f32x4 *__restrict__ fb,
-                                        int steps_a, int steps_b, int a_step0, int k0, int k1, const bool (&nv)[TN], int lane) {
-    FsFrags<TM, TN> ring[kFsDepth];
+// acc[m][n] += sum over K-steps [k0, k1) of A-tile m (features) x B-tile n (weights, fb[n] -> its step 0, or the zero
+// fragment for a tile that does not exist)
+template <int TM, int TN, int DEPTH>
+__device__ __forceinline__ void fs_gemm(sp::f32x16 (&acc)[TM][TN], const f32x4 *__restrict__ fa, const f32x4 *const (&fb)[TN],
+                                        const f32x4 *__restrict__ zero, int steps_a, int a_step0, int k0, int k1, int lane) {
+    if (k0 >= k1) return;
+    FsFrags<TM, TN> ring[DEPTH];
 #pragma unroll
-    for (int d = 0; d < kFsDepth; ++d) {
+    for (int d = 0; d < DEPTH; ++d) fs_load<TM, TN>(ring[d], fa, fb, zero, steps_a, a_step0, k0 + d, k1, lane);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int k = k0; k < k1; k += DEPTH) {
 #pragma unroll
-        for (int m = 0; m < TM; ++m)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) ring[d].a[m][p] = sp::f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int n = 0; n < TN; ++n)
-#pragma unroll
-            for (int p = 0; p < 2; ++p) ring[d].b[n][p] = sp::f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (k0 + d < k1) fs_load<TM, TN>(ring[d], fa, fb, steps_a, steps_b, a_step0 + k0 + d, k0 + d, nv, lane);
-    }
-    for (int k = k0; k < k1; k += kFsDepth) {
-#pragma unroll
-        for (int d = 0; d < kFsDepth; ++d) {
-            if (k + d >= k1) break;
+        for (int d = 0; d < DEPTH; ++d) {
 #pragma unroll
             for (int combo = 0; combo < 3; ++combo)
 #pragma unroll
                 for (int m = 0; m < TM; ++m)
 #pragma unroll
                     for (int n = 0; n < TN; ++n)
-                        if (nv[n])
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[d].a[m][combo == 2], ring[d].b[n][combo == 1],
-                                                                              acc[m][n], 0, 0, 0);
-            const int kn = k + d + kFsDepth;
-            if (kn < k1) fs_load<TM, TN>(ring[d], fa, fb, steps_a, steps_b, a_step0 + kn, kn, nv, lane);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[d].a[m][combo == 2], ring[d].b[n][combo == 1],
+                                                                          acc[m][n], 0, 0, 0);
+            fs_load<TM, TN>(ring[d], fa, fb, zero, steps_a, a_step0, k + d + DEPTH, k1, lane);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
-template <int TM>
+template <int TM, int TN, int DEPTH, bool VAL_FUSED>
 __global__ __launch_bounds__(256) void k_heads_split(NetDev nd, const f32x4 *__restrict__ feat16,
                                                      float *__restrict__ raw, float *__restrict__ hid, int n_boards) {
-    constexpr int TN = 4;
-    __shared__ sp::f32x16 part[4][TM * TN][64];  // [K quarter][tile][lane]: 16 KB per tile row
+    __shared__ sp::f32x16 part[4][TM * TN][64];  // [K quarter][tile][lane]
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mt0 = blockIdx.x * TM, half = blockIdx.y;
+    const int mt0 = blockIdx.x * TM;
     const int steps_all = nd.groups_act + nd.groups_val;
-    const int n_act_tiles = nd.Npad / 32;
+    const int n_act_tiles = nd.Npad / 32, n_groups = (n_act_tiles + TN - 1) / TN;
     const f32x4 *fa = feat16 + (size_t)mt0 * steps_all * 128;  // 128 f32x4 = one K-step (hi | lo) of one tile
+    const f32x4 *zero = nd.fs_act + (size_t)n_act_tiles * nd.groups_act * 128;  // one all-zero K-step behind the weights
     const int col = lane & 31, h = lane >> 5;
-    {   // policy outputs 128 * half .. + 127
-        bool nv[TN];
+    const int group = blockIdx.y;                                       // policy outputs 32 * TN * group ..
+    const int vtile = VAL_FUSED ? (int)blockIdx.y : (int)blockIdx.y - n_groups;  // value hidden units 32 * vtile ..
+    if (group < n_groups) {
+        const f32x4 *fb[TN];
 #pragma unroll
-        for (int n = 0; n < TN; ++n) nv[n] = TN * half + n < n_act_tiles;
-        if (nv[0]) {
-            sp::f32x16 acc[TM][TN];
+        for (int n = 0; n < TN; ++n)
+            fb[n] = TN * group + n < n_act_tiles ? nd.fs_act + (size_t)(TN * group + n) * nd.groups_act * 128 : zero;
+        sp::f32x16 acc[TM][TN];
 #pragma unroll
-            for (int m = 0; m < TM; ++m)
+        for (int m = 0; m < TM; ++m)
 #pragma unroll
-                for (int n = 0; n < TN; ++n)
+            for (int n = 0; n < TN; ++n)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-            const int K = nd.groups_act, k0 = wave * K / 4, k1 = (wave + 1) * K / 4;
-            fs_gemm<TM, TN>(acc, fa, nd.fs_act + (size_t)TN * half * K * 128, steps_all, K, 0, k0, k1, nv, lane);
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+        const int K = nd.groups_act, k0 = wave * K / 4, k1 = (wave + 1) * K / 4;
+        fs_gemm<TM, TN, DEPTH>(acc, fa, fb, zero, steps_all, 0, k0, k1, lane);
 #pragma unroll
-            for (int m = 0; m < TM; ++m)
+        for (int m = 0; m < TM; ++m)
 #pragma unroll
-                for (int n = 0; n < TN; ++n) part[wave][m * TN + n][lane] = acc[m][n];
-        }
+            for (int n = 0; n < TN; ++n) part[wave][m * TN + n][lane] = acc[m][n];
         __syncthreads();
-        if (nv[0]) {
-            const float scale = nd.s_inv[3];
-            // wave w finishes tiles w, w + 4, ...: D column = output (lane & 31), rows = boards 8g + 4h + j
+        const float scale = nd.s_inv[3];
+        // wave w finishes tiles w, w + 4, ...: D column = output (lane & 31), rows = boards 8g + 4h + j
 #pragma unroll
-            for (int t = wave; t < TM * TN; t += 4) {
-                const int m = t / TN, n = t % TN;
-                if (TN * half + n >= n_act_tiles) continue;
-                sp::f32x16 v = part[0][t][lane];
+        for (int t = wave; t < TM * TN; t += 4) {
+            const int m = t / TN, n = t % TN;
+            if (TN * group + n >= n_act_tiles) continue;
+            sp::f32x16 v = part[0][t][lane];
 #pragma unroll
-                for (int q = 1; q < 4; ++q) {
-                    const sp::f32x16 pq = part[q][t][lane];
+            for (int q = 1; q < 4; ++q) {
+                const sp::f32x16 pq = part[q][t][lane];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] += pq[r];
-                }
-                const int c = 32 * (TN * half + n) + col;
-                const float bias = nd.fc_act_b[c];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int b = 32 * (mt0 + m) + 8 * (r >> 2) + 4 * h + (r & 3);
-                    if (b < n_boards) raw[(size_t)b * nd.Npad + c] = fmaf(v[r], scale, bias);
-                }
+                for (int r = 0; r < 16; ++r) v[r] += pq[r];
             }
+            const int c = 32 * (TN * group + n) + col;
+            const float bias = nd.fc_act_b[c];
+            // raw / hid have rows for whole 64-board tiles (rz_net_reserve): the stores need no bounds test -- under a
+            // branch each one would wait for the previous store to be acknowledged (vmcnt(0) per basic block)
+            float *dst = raw + (size_t)(32 * (mt0 + m) + 4 * h) * nd.Npad + c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(size_t)(8 * (r >> 2) + (r & 3)) * nd.Npad] = fmaf(v[r], scale, bias);
         }
-        __syncthreads();
+        if (VAL_FUSED) __syncthreads();
     }
-    {   // value head: hidden units 32 * half .. + 31
-        bool nv[1] = {true};
+    if (vtile >= 0 && vtile < 2) {
+        const f32x4 *fb[1] = {nd.fs_val + (size_t)vtile * nd.groups_val * 128};
         sp::f32x16 acc[TM][1];
 #pragma unroll
         for (int m = 0; m < TM; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][0][r] = 0.0f;
         const int K = nd.groups_val, k0 = wave * K / 4, k1 = (wave + 1) * K / 4;
-        fs_gemm<TM, 1>(acc, fa, nd.fs_val + (size_t)half * K * 128, steps_all, K, nd.groups_act, k0, k1, nv, lane);
+        fs_gemm<TM, 1, DEPTH>(acc, fa, fb, zero, steps_all, nd.groups_act, k0, k1, lane);
 #pragma unroll
         for (int m = 0; m < TM; ++m) part[wave][m][lane] = acc[m][0];
         __syncthreads();
@@ -1820,13 +1820,11 @@ __global__ __launch_bounds__(256) void k_heads_split(NetDev nd, const f32x4 *__r
                 for (int r = 0; r < 16; ++r) v[r] += pq[r];
             }
             const float scale = nd.s_inv[4];
-            const int c = 32 * half + col;
+            const int c = 32 * vtile + col;
             const float bias = nd.fc_val1_b[c];
+            float *dst = hid + (size_t)(32 * (mt0 + m) + 4 * h) * 64 + c;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int b = 32 * (mt0 + m) + 8 * (r >> 2) + 4 * h + (r & 3);
-                if (b < n_boards) hid[(size_t)b * 64 + c] = fmaxf(fmaf(v[r], scale, bias), 0.0f);
-            }
+            for (int r = 0; r < 16; ++r) dst[(8 * (r >> 2) + (r & 3)) * 64] = fmaxf(fmaf(v[r], scale, bias), 0.0f);
         }
     }
 }
@@ -2070,7 +2068,7 @@ std::vector<f32x4> pack_split_fc(const float *w, int n_out, int k_in, int tiles,
     }
     const float scale = std::ldexp(1.0f, e);
     *scale_out = scale;
-    std::vector<f32x4> out((size_t)tiles * steps * 2 * 64, f32x4{0.f, 0.f, 0.f, 0.f});
+    std::vector<f32x4> out(((size_t)tiles * steps + 1) * 2 * 64, f32x4{0.f, 0.f, 0.f, 0.f});  // + one all-zero K-step
     _Float16 *o = reinterpret_cast<_Float16 *>(out.data());
     for (int t = 0; t < tiles; ++t)
         for (int st = 0; st < steps; ++st)
@@ -2259,8 +2257,8 @@ int rz_net_reserve(rz_net *net, int32_t max_boards) {
     const size_t pad_boards = ((size_t)max_boards + 31) / 32 * 32;
     net->feat_floats = pad_boards * 16 * (size_t)(net->dev.groups_act + net->dev.groups_val);
     if (hipMalloc((void **)&net->d_feat, net->feat_floats * sizeof(float)) != hipSuccess ||
-        hipMalloc((void **)&net->d_raw, (size_t)max_boards * net->dev.Npad * sizeof(float)) != hipSuccess ||
-        hipMalloc((void **)&net->d_hid, (size_t)max_boards * 64 * sizeof(float)) != hipSuccess)
+        hipMalloc((void **)&net->d_raw, (((size_t)max_boards + 63) / 64 * 64) * net->dev.Npad * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&net->d_hid, (((size_t)max_boards + 63) / 64 * 64) * 64 * sizeof(float)) != hipSuccess)
         return net_fail(RZ_ERR_OOM, "hipMalloc failed (feature buffers)");
     // padded boards and the K tail must read as finite values (they meet zero weights)
     if (hipMemset(net->d_feat, 0, net->feat_floats * sizeof(float)) != hipSuccess)
@@ -2306,19 +2304,20 @@ static void launch_heads_gemm(rz_net *net, const float *d_feat, int32_t n_boards
     net->dev.feat_ld = 16 * (net->dev.groups_act + net->dev.groups_val);
     net->dev.feat_val_off = 16 * net->dev.groups_act;
     int algo = net->heads_algo;
-    // measured (profiles/r01/sweep_heads.txt): beside a capped trunk the GEMM has 32 CUs, where the f32-input MFMA is
-    // the limit and the f16 pipe wins; alone on 256 CUs the f32 kernel's 160 small workgroups hide the load latency
-    // that the 16 .. 42 workgroups of k_heads_split expose
-    if (algo == RZ_NET_HEADS_AUTO) algo = net->max_wgs > 0 ? RZ_NET_HEADS_SPLIT_64 : RZ_NET_HEADS_F32;
+    // after the split-f16 trunk: the f16 pipe.  Beside a capped trunk the GEMM has 32 CUs (64-board workgroups keep
+    // the loads of a CU below its vector memory rate), alone it has the chip (many small workgroups hide the load
+    // latency); both shapes give the same bits (profiles/r01/sweep_heads.txt)
+    if (algo == RZ_NET_HEADS_AUTO) algo = net->max_wgs > 0 ? RZ_NET_HEADS_SPLIT_64 : RZ_NET_HEADS_SPLIT_32;
     if (d_feat != net->d_feat || !net->feat16_valid) algo = RZ_NET_HEADS_F32;
+    const f32x4 *f16 = reinterpret_cast<const f32x4 *>(net->d_feat16);
+    const int n_act_tiles = net->dev.Npad / 32;
     if (algo == RZ_NET_HEADS_SPLIT_64) {
-        const dim3 grid((unsigned)((n_boards + 63) / 64), 2);  // y: policy half + value tile
-        k_heads_split<2><<<grid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, reinterpret_cast<const f32x4 *>(net->d_feat16),
-                                                                      net->d_raw, net->d_hid, n_boards);
+        // y = policy half (4 N-tiles) + value tile y: both halves exist even when the second has no policy tile
+        const dim3 grid((unsigned)((n_boards + 63) / 64), 2);
+        k_heads_split<2, 4, 3, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, f16, net->d_raw, net->d_hid, n_boards);
     } else if (algo == RZ_NET_HEADS_SPLIT_32) {
-        const dim3 grid((unsigned)((n_boards + 31) / 32), 2);
-        k_heads_split<1><<<grid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, reinterpret_cast<const f32x4 *>(net->d_feat16),
-                                                                      net->d_raw, net->d_hid, n_boards);
+        const dim3 grid((unsigned)((n_boards + 31) / 32), (unsigned)((n_act_tiles + 1) / 2 + 2));
+        k_heads_split<1, 2, 5, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, f16, net->d_raw, net->d_hid, n_boards);
     } else {
         const dim3 grid((unsigned)((n_boards + 31) / 32), (unsigned)(net->dev.Npad / 32 + 2));
         k_heads_gemm<<<grid, dim3(64 * kHeadWaves), 0, (hipStream_t)stream>>>(net->dev, d_feat, net->d_raw, net->d_hid, n_boards);

@@ -687,7 +687,7 @@ def test_split_f16_heads_gemm_equals_the_f32_gemm():
             for algo in ('f32', 'split32', 'split64', 'auto'):
                 lp, v = hip.set_heads_algo(algo).forward(x)
                 out[algo] = (lp.clone(), v.clone())
-            lp, v = hip.set_max_workgroups(8).forward(x)  # 'auto' beside a capped trunk: the f16 pipe
+            lp, v = hip.set_max_workgroups(8).forward(x)  # 'auto' beside a capped trunk: 64-board workgroups
             out['auto_capped'] = (lp.clone(), v.clone())
             hip.set_max_workgroups(0)
             hip.check_flags()
@@ -698,9 +698,8 @@ def test_split_f16_heads_gemm_equals_the_f32_gemm():
                 assert float((out[algo][1].cpu().double() - v64[:, 0]).abs().max()) <= 2e-6, (shape, n, algo)
             assert float((out['f32'][0] - out['split32'][0]).abs().max()) <= 1e-5
             assert float((out['f32'][1] - out['split32'][1]).abs().max()) <= 2e-6
-            for algo in ('split64', 'auto_capped'):
+            for algo in ('split64', 'auto', 'auto_capped'):  # the workgroup shape is scheduling only: same bits
                 assert torch.equal(out[algo][0], out['split32'][0]) and torch.equal(out[algo][1], out['split32'][1])
-            assert torch.equal(out['auto'][0], out['f32'][0]) and torch.equal(out['auto'][1], out['f32'][1])
         # after another trunk the f16 pieces are stale: the GEMM must take the f32 features
         lp_d, v_d = hip.set_algo('direct').set_heads_algo('split64').forward(x)
         lp_f, v_f = hip.set_heads_algo('f32').forward(x)

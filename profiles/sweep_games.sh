@@ -1,3 +1,5 @@
+# Games per GPU (2 lanes, trunk on 224 CUs) and trunk workgroups x 4 boards (run from the repository root on a GPU box).
+echo '# games_per_gpu  sims/s  ms_per_move  trunk_launch_ms(union of the lanes)  trunk_launch_ms(alone); last rows: trunk_workgroups games ...'
 mkdir -p gpurun_out/s3
 for g in 1344 1792 2240 2688; do
   python bench.py --no-cpu-baseline --no-games-leg --no-literal-config --games $g > gpurun_out/s3/g$g.json 2> gpurun_out/s3/g$g.err

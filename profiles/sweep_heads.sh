@@ -2,6 +2,7 @@
 # trunk launch ms (union of the lanes' event intervals / launches), per-stream average, the trunk alone, roofline frac.
 # l1 = 1 lane x 512 games, l2 = 2 lanes x 672 games (trunk capped at 224 workgroups).
 mkdir -p gpurun_out/s5
+echo '# run  sims/s  ms_per_move  trunk_ms(union of the lanes)  trunk_ms(per stream)  trunk_ms(alone)  roofline_frac   (l1 = 1 lane x 512 games, l2 = 2 lanes x 672 games, trunk capped at 224 workgroups)'
 run() { name=$1; shift; python bench.py --no-cpu-baseline --no-games-leg --no-literal-config "$@" > gpurun_out/s5/$name.json 2> gpurun_out/s5/$name.err; python - <<PY
 import json
 try:

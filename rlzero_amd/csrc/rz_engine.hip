@@ -547,9 +547,9 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
                                                    int lane, RawHeads rh = RawHeads()) {
     if (!E.active[g]) return;
     float lse = 0.0f, raw_value = 0.0f;
+    float x[kWords] = {0.f, 0.f, 0.f, 0.f};  // RAW: the lane's policy logits, kept for the priors below
     if (RAW) {
         const float *r = rh.raw + (size_t)g * rh.ld;
-        float x[kWords];
         float mx = -INFINITY;
 #pragma unroll
         for (int i = 0; i < kWords; ++i) {
@@ -640,7 +640,9 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
                 if (r < 0) continue;
                 const int a = 64 * j + lane;
                 float prior = uniform;
-                if (RAW) prior = expf(rh.raw[(size_t)g * rh.ld + a] - lse);  // = exp(log_softmax)
+                // = exp(log_softmax); the logit is the one loaded above (a second load here would sit between the
+                // prior stores, and its s_waitcnt vmcnt(0) also waits for the stores before it)
+                if (RAW) prior = expf(x[j] - lse);
                 else if (logp) prior = PROBS ? logp[(long long)g * E.A + a] : expf(logp[(long long)g * E.A + a]);
                 if (E.add_noise) prior = 0.75f * prior + 0.25f * (noise[j] / noise_sum);
                 P[ptop + r] = prior;

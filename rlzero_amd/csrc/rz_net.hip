@@ -1138,7 +1138,7 @@ constexpr int kC1Bytes = 2 * Geo<32>::piece_bytes, kC2Bytes = 2 * Geo<64>::piece
 // so the 16 K-values of conv1's step "kernel row ky" (4 columns x 4 planes, the 4th column meeting zero weights)
 // are two 16-byte runs
 constexpr int kInCols = 20, kInPieceBytes = 18 * kInCols * 8, kInBytes = 2 * kInPieceBytes;
-constexpr int kHeadFloats = 128 * 7;  // head weights [128][6] + conv3 biases [128]
+constexpr int kHeadFloats = 128 * 7 + 8;  // head weights [128][6] + conv3 biases [128] + head biases [6] (+ 2 pad)
 constexpr int kLdsBytes = kInBytes + kC1Bytes + kC2Bytes + kHeadFloats * 4;
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 static_assert(kInBytes % 16 == 0, "piece alignment");
@@ -1286,6 +1286,9 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     };
     __syncthreads();
     for (int i = tid0; i < 128 * 7; i += kThreads) hw[i] = i < 768 ? nd.whp[i] : nd.b3[i - 768];
+    // the 6 head biases too: a global load in the epilogue would sit between the feature stores, and its
+    // s_waitcnt vmcnt(0) also waits for the stores before it -- six store round trips per board
+    if (tid0 < 8) hw[128 * 7 + tid0] = tid0 < 6 ? nd.bh[tid0] : 0.0f;
     // conv1's weights (3 kernel rows x hi / lo, 6 KB per workgroup) and biases stay in registers for all boards
     sp::f16x8 a1[3][2];
     f32x4 bias1[4];
@@ -1298,7 +1301,8 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
 #pragma unroll
         for (int g = 0; g < 4; ++g) bias1[g] = *reinterpret_cast<const f32x4 *>(nd.b1 + 8 * g + 4 * (lane0 >> 5)) * sp::kActScale;
     }
-    const float k1 = nd.s_inv[2];
+    // the three rescaling factors once per workgroup (a load placed behind a layer's MFMA loop is exposed in full)
+    const float k1 = nd.s_inv[2], k2 = nd.s_inv[0] * sp::kActScale, k3 = nd.s_inv[1];
     if ((int)blockIdx.x < n_boards) {
         load_obs(blockIdx.x, tid0);
         store_obs(tid0);
@@ -1369,7 +1373,6 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
             for (int g = 0; g < 4; ++g) bias2[m][g] = *reinterpret_cast<const f32x4 *>(nd.b2 + m * 32 + 8 * g + 4 * h) * sp::kActScale;
         sp::conv<32, 2, 2>(c1, nd.s2, 2 * wave, lane, a2, acc);
         sp::preload_w<64, 4>(a3, nd.s3, lane);
-        const float k2 = nd.s_inv[0] * sp::kActScale;
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1403,7 +1406,6 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
             for (int o2 = 0; o2 < 3; ++o2) vals2[t][o2] = f32x2{0.0f, 0.0f};
         {
             sp::f32x16 acc[4][2];
-            const float k3 = nd.s_inv[1];
             sp::conv<64, 4, 2>(c2, nd.s3, 2 * wave, lane, a3, acc);
             // per (m, g): the lane's channels c0 .. c0+3 = 32*m + 8*g + 4*h ..: 24 head weights [j][output] and 4
             // biases from LDS, fetched one group ahead (the fences keep hipcc from hoisting all 16 groups' reads)
@@ -1451,7 +1453,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
             float v0 = vals2[0][o >> 1][o & 1], v1 = vals2[1][o >> 1][o & 1];
             v0 += __shfl_xor(v0, 32);
             v1 += __shfl_xor(v1, 32);
-            const float v = fmaxf((h ? v1 : v0) + nd.bh[o], 0.0f);
+            const float v = fmaxf((h ? v1 : v0) + hw[128 * 7 + o], 0.0f);
             if (y < BH && x < BW) {
                 dst[(o < 4 ? o * S : nd.feat_val_off + (o - 4) * S) + y * BW + x] = v;
                 if (dst16) {

@@ -405,19 +405,21 @@ __device__ __forceinline__ int scan_children(const Dev &E, const int4 *R, const 
 }
 
 __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int lane) {
-    if (!E.active[g]) return;
-    const int S = E.S;
+    // every load that does not depend on another one is issued before `active` is tested: a kernel of dependent
+    // round trips (an inactive game's slots exist, reading them is harmless)
     const int arena = E.cur_arena[g];
+    const int top0 = E.top[g];
+    int to_move = E.root_to_move[g];
+    int last = E.root_last[g];
+    const bool act = E.active[g] != 0;
+    const int S = E.S;
+    uint64_t st[2][kWords];
+    load_board(E.root_stones, g, st);
+    if (!act) return;
     int4 *R = arena_records(E, g, arena);
     const float *P = arena_priors(E, g, arena);
     const bool use_puct = E.score_mode == RZ_SCORE_PUCT;
-    const int top0 = E.top[g];
     int top = top0;
-
-    uint64_t st[2][kWords];
-    load_board(E.root_stones, g, st);
-    int to_move = E.root_to_move[g];
-    int last = E.root_last[g];
     int nst = count_bits(st[0]) + count_bits(st[1]);
 
     int32_t *path = E.path + (long long)g * E.path_stride;
@@ -545,11 +547,26 @@ struct RawHeads {
 template <typename VT, bool PROBS = false, bool RAW = false>
 __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *logp, const VT *value, int g,
                                                    int lane, RawHeads rh = RawHeads()) {
-    if (!E.active[g]) return;
+    // loads first, the test of `active` after them (see select_body)
+    const bool act = E.active[g] != 0;
+    const int arena = E.cur_arena[g];
+    const int depth = E.leaf_depth[g];
+    const int fresh = E.leaf_fresh[g];
+    const int term = E.leaf_term[g];
+    const double leaf_tval = E.leaf_tval[g];
+    const int ptop = E.ptop[g];
+    const int nblk = E.nblk[g];
+    const int top_now = E.top[g];
+    const int noise_ctr = E.noise_ctr[g];
+    const int32_t *path = E.path + (long long)g * E.path_stride;
+    const int path_lane = path[lane < E.path_stride ? lane : 0];  // the node of path level `lane` (if that level exists)
+    uint64_t st[2][kWords];
+    load_board(E.leaf_stones, g, st);
     float lse = 0.0f, raw_value = 0.0f;
     float x[kWords] = {0.f, 0.f, 0.f, 0.f};  // RAW: the lane's policy logits, kept for the priors below
     if (RAW) {
         const float *r = rh.raw + (size_t)g * rh.ld;
+        const float hid = rh.hid[(size_t)g * 64 + lane], w2 = rh.w2[lane], b2 = rh.b2[0];
         float mx = -INFINITY;
 #pragma unroll
         for (int i = 0; i < kWords; ++i) {
@@ -565,34 +582,27 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
         lse = mx + logf(sum);
-        float h = rh.hid[(size_t)g * 64 + lane] * rh.w2[lane];
+        float h = hid * w2;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) h += __shfl_xor(h, off);
-        raw_value = tanhf(h + rh.b2[0]);
+        raw_value = tanhf(h + b2);
     }
-    const int arena = E.cur_arena[g];
+    if (!act) return;
     int4 *R = arena_records(E, g, arena);
     float *P = arena_priors(E, g, arena);
 
-    const int depth = E.leaf_depth[g];
-    const int fresh = E.leaf_fresh[g];
-    const int term = E.leaf_term[g];
     // the reference evaluates terminal leaves too and discards the result (:59-68)
-    const double v = term ? E.leaf_tval[g] : (RAW ? (double)raw_value : (double)value[g]);
-    const int32_t *path = E.path + (long long)g * E.path_stride;
+    const double v = term ? leaf_tval : (RAW ? (double)raw_value : (double)value[g]);
 
     int new_fc = -1, new_nv = 0, new_k = 0, new_cap = 0, new_pb = -1;
     if (!term && fresh != 2) {
-        uint64_t st[2][kWords], occ[kWords];
-        load_board(E.leaf_stones, g, st);
+        uint64_t occ[kWords];
 #pragma unroll
         for (int j = 0; j < kWords; ++j) occ[j] = st[0][j] | st[1][j];
         const Legal L = legal_of(E, occ, lane);
         const int k = L.k;
         const bool dense = E.score_mode == RZ_SCORE_PUCT;
-        const int ptop = E.ptop[g];
-        const int nblk = E.nblk[g];
-        const int top = dense ? E.top[g] : 0;
+        const int top = dense ? top_now : 0;
         if ((long long)ptop + k > E.pcap || nblk >= E.qcap) {
             flag(E, g, RZ_FLAG_BLOCKS_FULL, lane);
         } else if (dense && (long long)top + k > E.cap) {
@@ -620,7 +630,7 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
             float noise[kWords] = {0.f, 0.f, 0.f, 0.f};
             float noise_sum = 1.0f;
             if (E.add_noise) {
-                const int ctr = E.noise_ctr[g];
+                const int ctr = noise_ctr;
                 const uint64_t key = mix64(mix64(E.noise_seed ^ ((uint64_t)g << 20)) ^ (uint64_t)ctr);
                 float local = 0.0f;
 #pragma unroll
@@ -656,7 +666,7 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
 
     // TreeNode.update_recursive(-leaf_value): leaf gets -v, its parent +v, ... (node.py:135-144)
     for (int d = lane; d <= depth; d += kWave) {
-        const int node = path[d];
+        const int node = d == lane ? path_lane : path[d];
         const double x = ((depth - d) & 1) ? v : -v;
         if (d == depth) {
             // the leaf: a first-visit slot gets its whole record here; an old leaf that is now

@@ -1239,7 +1239,9 @@ __device__ __forceinline__ void conv(const char *in, const void *wts, int nt0, i
 
 // Wave w owns board rows 4w .. 4w+3 (N-tiles 2w, 2w+1) and ALL output channels of conv2 and of conv3, so the
 // 1x1 head convolutions see every channel of a position in one wave (two lane halves, one shuffle) and the head
-// features go from registers to memory: two barriers per board.
+// features go from registers to memory: two barriers per board.  TN = N-tiles per wave: 2 for boards of up to 16
+// rows; boards of up to 8 rows (6x6, Connect4's 6x7, 8x8) take TN = 1 -- wave w owns rows 2w, 2w+1 -- and half the MFMAs.
+template <int TN>
 __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__restrict__ obs,
                                                      float *__restrict__ feat, _Float16 *__restrict__ feat16,
                                                      int n_boards, unsigned *__restrict__ flags) {
@@ -1316,23 +1318,23 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     sp::f16x8 a2[3][2][2];
     sp::preload_w<32, 2>(a2, nd.s2, lane);
     const int n = lane & 31, h = lane >> 5, x = n & 15;
-    if (4 * wave < BH) {   // conv1: 4 -> 32 (one M-tile), N-tiles 2*wave, 2*wave + 1; K-step = kernel row ky
+    if (2 * TN * wave < BH) {   // conv1: 4 -> 32 (one M-tile), N-tiles TN*wave ..; K-step = kernel row ky
         typedef const __attribute__((address_space(3))) sp::f16x4 *lds_half;
-        const lds_half q = (lds_half)(in0 + ((4 * wave + (n >> 4)) * sp::kInCols + x + 2 * h) * 8);
-        sp::f16x8 b1[3][2][2];
+        const lds_half q = (lds_half)(in0 + ((2 * TN * wave + (n >> 4)) * sp::kInCols + x + 2 * h) * 8);
+        sp::f16x8 b1[3][TN][2];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < TN; ++t)
 #pragma unroll
                 for (int p_ = 0; p_ < 2; ++p_) {
                     const int o = ((2 * t + ky) * sp::kInCols * 8 + p_ * sp::kInPieceBytes) / 8;
                     const sp::f16x4 lo4 = q[o], hi4 = q[o + 1];
                     b1[ky][t][p_] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
-        sp::f32x16 acc1[2];
+        sp::f32x16 acc1[TN];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < TN; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[t][r] = 0.0f;
 #pragma unroll
@@ -1340,11 +1342,11 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
 #pragma unroll
             for (int combo = 0; combo < 3; ++combo)
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < TN; ++t)
                     acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ky][combo == 2], b1[ky][t][combo == 1], acc1[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int y = 4 * wave + 2 * t + (n >> 4);
+        for (int t = 0; t < TN; ++t) {
+            const int y = 2 * TN * wave + 2 * t + (n >> 4);
             if (y < BH && x < BW) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -1365,13 +1367,13 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     if (next_board < n_boards) load_obs(next_board, tid);
     sp::f16x8 a3[3][4][2];
     {   // conv2: 32 -> 64
-        sp::f32x16 acc[2][2];
+        sp::f32x16 acc[2][TN];
         f32x4 bias2[2][4];  // fetched before the MFMA loop
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int g = 0; g < 4; ++g) bias2[m][g] = *reinterpret_cast<const f32x4 *>(nd.b2 + m * 32 + 8 * g + 4 * h) * sp::kActScale;
-        sp::conv<32, 2, 2>(c1, nd.s2, 2 * wave, lane, a2, acc);
+        sp::conv<32, 2, TN>(c1, nd.s2, TN * wave, lane, a2, acc);
         sp::preload_w<64, 4>(a3, nd.s3, lane);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -1380,8 +1382,8 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
                 const int c0 = m * 32 + 8 * g + 4 * h;
                 const f32x4 bv = bias2[m][g];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const int y = 4 * wave + 2 * t + (n >> 4);
+                for (int t = 0; t < TN; ++t) {
+                    const int y = 2 * TN * wave + 2 * t + (n >> 4);
                     float z[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) z[j] = fmaxf(fmaf(acc[m][t][4 * g + j], k2, bv[j]), 0.0f);
@@ -1399,14 +1401,14 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     if (next_board < n_boards) store_obs(tid);
     __syncthreads();
     {   // conv3: 64 -> 128; its ReLU'd output feeds the two 1x1 head convolutions from registers
-        f32x2 vals2[2][3];  // [position][pair of head outputs]
+        f32x2 vals2[TN][3];  // [position][pair of head outputs]
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < TN; ++t)
 #pragma unroll
             for (int o2 = 0; o2 < 3; ++o2) vals2[t][o2] = f32x2{0.0f, 0.0f};
         {
-            sp::f32x16 acc[4][2];
-            sp::conv<64, 4, 2>(c2, nd.s3, 2 * wave, lane, a3, acc);
+            sp::f32x16 acc[4][TN];
+            sp::conv<64, 4, TN>(c2, nd.s3, TN * wave, lane, a3, acc);
             // per (m, g): the lane's channels c0 .. c0+3 = 32*m + 8*g + 4*h ..: 24 head weights [j][output] and 4
             // biases from LDS, fetched one group ahead (the fences keep hipcc from hoisting all 16 groups' reads)
             f32x4 w[2][7];
@@ -1423,7 +1425,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
                 if (mg + 1 < 16) load_group(mg + 1, w[(mg + 1) & 1]);
                 const f32x4(&wc)[7] = w[mg & 1];
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < TN; ++t)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float hv = fmaxf(fmaf(acc[m][t][4 * g + j], k3, wc[6][j]), 0.0f);
@@ -1436,25 +1438,30 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
                     }
                 // pin the partial sums here: their only use is the guarded store below, and hipcc otherwise sinks
                 // the whole chains of multiply-adds into that block (every weight and activation kept alive)
-                asm volatile("" : "+v"(vals2[0][0]), "+v"(vals2[0][1]), "+v"(vals2[0][2]), "+v"(vals2[1][0]),
-                             "+v"(vals2[1][1]), "+v"(vals2[1][2]));
+                if constexpr (TN == 2)
+                    asm volatile("" : "+v"(vals2[0][0]), "+v"(vals2[0][1]), "+v"(vals2[0][2]), "+v"(vals2[TN - 1][0]),
+                                 "+v"(vals2[TN - 1][1]), "+v"(vals2[TN - 1][2]));
+                else
+                    asm volatile("" : "+v"(vals2[0][0]), "+v"(vals2[0][1]), "+v"(vals2[0][2]));
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // the two lane halves hold different channels of the same two positions: lane half h stores position h
+        // the two lane halves hold different channels of the same TN positions: with TN = 2 lane half h stores
+        // position h, with TN = 1 half 0 stores the one position
         float *dst = feat + (size_t)board * nd.feat_ld;
-        const int y = 4 * wave + 2 * h + (n >> 4);
+        const int y = TN == 2 ? 4 * wave + 2 * h + (n >> 4) : 2 * wave + (n >> 4);
+        const bool mine = TN == 2 || h == 0;
         // the same features as hi + lo f16 pieces in the A-fragment order of k_heads_split:
         // [32-board tile][K-step][hi | lo][lane = 32 * (k / 8 % 2) + board % 32][k % 8]
         _Float16 *dst16 = feat16 ? feat16 + ((size_t)(board >> 5) * (nd.groups_act + nd.groups_val) * 1024 + (board & 31) * 8)
                                  : nullptr;
 #pragma unroll
         for (int o = 0; o < 6; ++o) {
-            float v0 = vals2[0][o >> 1][o & 1], v1 = vals2[1][o >> 1][o & 1];
+            float v0 = vals2[0][o >> 1][o & 1], v1 = vals2[TN - 1][o >> 1][o & 1];
             v0 += __shfl_xor(v0, 32);
-            v1 += __shfl_xor(v1, 32);
-            const float v = fmaxf((h ? v1 : v0) + hw[128 * 7 + o], 0.0f);
-            if (y < BH && x < BW) {
+            if (TN == 2) v1 += __shfl_xor(v1, 32);
+            const float v = fmaxf(((TN == 2 && h) ? v1 : v0) + hw[128 * 7 + o], 0.0f);
+            if (mine && y < BH && x < BW) {
                 dst[(o < 4 ? o * S : nd.feat_val_off + (o - 4) * S) + y * BW + x] = v;
                 if (dst16) {
                     const int k = (o < 4 ? o : o - 4) * S + y * BW + x;
@@ -2295,8 +2302,13 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
     else if (net->algo == RZ_NET_WINOGRAD_F4_8W)
         k_trunk_wino_f4<8><<<pgrid, dim3(512), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
     else if (net->algo == RZ_NET_SPLIT_F16)
-        k_trunk_split<<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, internal ? net->d_feat16 : nullptr,
-                                                                    n_boards, net->d_flags);
+    {
+        _Float16 *f16 = internal ? net->d_feat16 : nullptr;
+        if (net->dev.BH <= 8)  // rows 2w, 2w+1 per wave: half the N-tiles
+            k_trunk_split<1><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, f16, n_boards, net->d_flags);
+        else
+            k_trunk_split<2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, f16, n_boards, net->d_flags);
+    }
     else
         k_trunk<<<grid, dim3(kTrunkThreads), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
 }

@@ -19,8 +19,10 @@ scaling); rank 0 prints ONE JSON line.
 Also on the line:
   roofline      for the dominant kernel region (the policy+value forward of the leaf batch,
                 the path's one dense contraction): algorithmic FLOPs F(S) = 188416*S + 8*S^2 +
-                128 per position x positions per launch / its average duration
-                from HIP events on the launch stream, against the fp32 matrix peak.
+                128 per position (the trunk kernel alone: 188160*S) x positions per launch /
+                its average duration from HIP events on the launch streams (two lanes: the union of their
+                intervals / launches), against the peak of the pipe it runs on: the f16 MFMA peak / 3 for the
+                default trunk (three f16 MFMAs per f32 product), the f32-input MFMA peak for the others.
   selfplay      after the timed steps the first-generation games are played to their end (slots refilled):
                 games/s = moves/s of that leg / mean plies per game.
   cpu_baseline  the oracle (Python restatement of the reference, batch-1 torch CPU forward,

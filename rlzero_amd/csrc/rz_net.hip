@@ -3,15 +3,16 @@
 // Replaces PolicyValueNet.forward (rlzero/games/gomoku/policy_value_net.py:34-52) for the
 // batch of MCTS leaves: the one dense contraction of the path (42.8 MFLOP per
 // 15x15 position, MFMA-bound).  The default trunk carries f32 operands as hi + lo f16 pairs on the f16 matrix
-// pipe (three MFMAs per product, f32 accumulation: as accurate as the exact-f32 kernel); the other trunks and
-// the FC layers use v_mfma_f32_16x16x4_f32, a k-ordered fmaf chain (tolerance vs the reference's CPU output: 1e-4).
+// pipe (three MFMAs per product, f32 accumulation: as accurate as the exact-f32 kernel) and so does the FC GEMM
+// behind it; the other trunks and their FC GEMM use v_mfma_f32_16x16x4_f32, a k-ordered fmaf chain (tolerance vs
+// the reference's CPU output: 1e-4).
 //
 // Kernels (one workgroup owns a board; its activations never leave the CU: input planes, conv1 output (32 ch)
 // and conv2 output (64 ch) live in LDS as halo-padded planes [channel][18 rows][18 cols]; conv3's 128 channels
 // stay in registers and are consumed by the two 1x1 head convolutions there):
-//   k_trunk_split (default)       conv1..conv3 as direct convolutions on v_mfma_f32_32x32x16_f16, every f32 operand
+//   k_trunk_split<TN> (default)   conv1..conv3 as direct convolutions on v_mfma_f32_32x32x16_f16, every f32 operand
 //                                 a hi + lo pair of f16 values; persistent workgroups, 4 waves (f16 layouts in LDS:
-//                                 see the kernel)
+//                                 see the kernel); TN = 2 row-pair tiles per wave, 1 for boards of up to 8 rows
 //   k_trunk_wino_f4<4>            conv2 / conv3 as Winograd F(4x4,3x3), persistent workgroups, 4 waves
 //   k_trunk_wino_f4<8>            same arithmetic, 8 waves
 //   k_trunk_wino<4> / <2>         Winograd F(2x2,3x3), 8 / 4 waves
@@ -20,7 +21,9 @@
 //                                 the 16 columns of a board row (B = ds_read_b32 from the halo planes), K =
 //                                 (group of 4 input channels, tap); wave w = 4*rh + q4 owns channel quarter q4
 //                                 and row half rh
-//   k_heads_gemm, k_heads_finish  the fully connected layers (32 x 32 output blocks), log_softmax and tanh
+//   k_heads_split                 the first FC layers of both heads on the f16 pipe (hi + lo pairs), fed by the f16
+//                                 feature pieces k_trunk_split writes in MFMA fragment order (default behind it)
+//   k_heads_gemm, k_heads_finish  the same layers on the f32-input MFMA (32 x 32 output blocks); log_softmax and tanh
 // Every kernel and its design notes are described where it is defined.
 
 #include <hip/hip_runtime.h>

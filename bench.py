@@ -206,7 +206,7 @@ def run_cpu_baseline(seconds):
 def run_literal_config(args):
     """`bench.py --lanes 1 --games 512` as a child process -> the fields of its line worth keeping, or None."""
     cmd = [sys.executable, os.path.abspath(__file__), '--lanes', '1', '--games', str(GAMES_PER_GPU), '--steps',
-           str(args.steps), '--warmup', str(args.warmup), '--net-algo', args.net_algo, '--heads-algo', args.heads_algo, '--graph', str(args.graph),
+           str(args.steps), '--warmup', str(args.warmup), '--net-algo', args.net_algo, '--heads-algo', args.heads_algo, '--graph', str(args.graph), '--noise', str(args.noise),
            '--no-cpu-baseline', '--no-games-leg', '--no-literal-config']
     try:
         out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=REPO, timeout=600).stdout
@@ -357,6 +357,10 @@ def main():
                     help='skip the extra N=1 measurement of the literal configs[3] share: 1 lane x %d games' % GAMES_PER_GPU)
     ap.add_argument('--heads-algo', default='auto', choices=['auto', 'f32', 'split32', 'split64'],
                     help='GEMM of the first FC layers (rz_net_set_heads_algo)')
+    ap.add_argument('--noise', type=int, default=1,
+                    help='Dirichlet(0.3) noise mixed into the priors of EVERY expanded node, as the reference does in '
+                         'self-play (node.py:63-69, alphazero_mcts.py:124-129); under its UCT rule the priors are never '
+                         'read, so this is work with no effect on the moves -- kept because the reference does it')
     ap.add_argument('--lanes', type=int, default=2,
                     help='independent batches of games on separate HIP streams (the tree / FC kernels of one '
                          'lane run beside the network trunk of the other)')
@@ -423,7 +427,7 @@ def main():
     engines, evaluators = [], []
     for g_lane in per_lane:
         eng = MCTSEngine(board, n_row, n_games=g_lane, n_playout=args.playouts, c_puct=C_PUCT, device=device,
-                         game=args.game)
+                         game=args.game, add_noise=bool(args.noise), noise_seed=1000 * rank + len(engines))
         if args.evaluator == 'hipnet':
             hip_ev = HipNetEvaluator(net, net_shape, device, max_boards=g_lane)
             hip_ev.hip.set_algo(args.net_algo)
@@ -578,6 +582,7 @@ def main():
                        'gomoku%dx%d_n%d_selfplay_%dsims_per_move_%dgames_per_gpu' % (board, board, n_row, args.playouts, G),
                        'games_total': G * world, 'c_puct': C_PUCT, 'temperature': TEMPERATURE,
                        'evaluator': args.evaluator, 'score_mode': 'UCT_REF (bit-exact)',
+                       'dirichlet_noise_at_every_expansion': bool(args.noise),
                        'sims_per_graph': args.graph, 'lanes': lanes, 'parallelism': 'games sharded, dp%d' % world},
             'moves_per_sec': round(total_sims / args.playouts / elapsed, 2),
             'games_finished_in_timed_region': int(total_finished),

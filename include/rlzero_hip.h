@@ -287,10 +287,12 @@ int rz_net_set_max_workgroups(rz_net *net, int32_t max_workgroups);
 /* The first FC layers of the two heads (act_fc1, val_fc1; policy_value_net.py:43,48) as one GEMM over the leaf batch.
  * RZ_NET_HEADS_F32: the f32-input MFMA GEMM (32 x 32 output blocks, many small workgroups).  RZ_NET_HEADS_SPLIT_32 /
  * _64: on the f16 matrix pipe with hi + lo f16 operand pairs (k_heads_split, the arithmetic of RZ_NET_SPLIT_F16), 32 /
- * 64 boards per workgroup; needs the f16 feature pieces that the RZ_NET_SPLIT_F16 trunk writes beside the f32
- * features of the internal buffer, and falls back to F32 when the last trunk was another one.
- * RZ_NET_HEADS_AUTO (default): SPLIT_64 when the trunk is capped by rz_net_set_max_workgroups (the GEMM then has
- * only the few CUs the trunk leaves free, where the f32-input MFMA rate is the limit), F32 otherwise. */
+ * 64 boards per workgroup; needs the f16 feature pieces that the RZ_NET_SPLIT_F16 trunk writes into the internal
+ * buffer, and falls back to F32 when the last trunk was another one.
+ * RZ_NET_HEADS_AUTO (default): after the RZ_NET_SPLIT_F16 trunk SPLIT_64 when the trunk is capped by
+ * rz_net_set_max_workgroups (the GEMM then has only the few CUs the trunk leaves free) and SPLIT_32 otherwise -- both
+ * give the same bits; F32 after the other trunks.  Choose before the trunk is launched: into the internal buffer the
+ * RZ_NET_SPLIT_F16 trunk writes only what the chosen GEMM reads (F32 chosen later runs SPLIT on the pieces present). */
 enum { RZ_NET_HEADS_AUTO = 0, RZ_NET_HEADS_F32 = 1, RZ_NET_HEADS_SPLIT_32 = 2, RZ_NET_HEADS_SPLIT_64 = 3 };
 int rz_net_set_heads_algo(rz_net *net, int32_t heads_algo);
 int rz_net_create(int32_t height, int32_t width, int32_t n_actions, int32_t device, rz_net **out);

@@ -320,26 +320,30 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 }
 
 // One Gamma(0.3, 1) sample (the marginal of numpy's dirichlet(0.3 * ones(k)), node.py:65) from a
-// counter-based stream: Marsaglia-Tsang for shape 1.3, boosted by U^(1/0.3).
+// counter-based stream: Marsaglia-Tsang for shape 1.3, boosted by U^(1/0.3).  The sample is noise: its
+// transcendentals are the hardware ones (v_log_f32 / v_exp_f32 / v_cos_f32 / v_sqrt_f32, ~1 ulp) -- with the
+// correctly rounded library routines four samples per lane cost the tree step 6 us per expansion, with these 1 us.
 __device__ __forceinline__ float gamma03(uint64_t key) {
     const float d = 1.3f - 1.0f / 3.0f, c = 0.33903103f;  // 1 / sqrt(9 d)
+    const float kLn2 = 0.69314718f, k2m24 = 1.0f / 16777216.0f;
     float g = d;
     for (int t = 0; t < 8; ++t) {
-        const uint64_t h1 = mix64(key + 3ull * t), h2 = mix64(key + 3ull * t + 1), h3 = mix64(key + 3ull * t + 2);
-        const float u1 = (float)((h1 >> 40) + 1ull) * (1.0f / 16777216.0f);
-        const float u2 = (float)(h2 >> 40) * (1.0f / 16777216.0f);
-        const float u3 = (float)((h3 >> 40) + 1ull) * (1.0f / 16777216.0f);
-        const float x = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);
+        const uint64_t h1 = mix64(key + 2ull * t), h2 = mix64(key + 2ull * t + 1);
+        const float u1 = (float)((uint32_t)(h1 >> 40) + 1u) * k2m24;        // (0, 1]
+        const float u2 = (float)((uint32_t)(h1 >> 16) & 0xffffffu) * k2m24;  // [0, 1): a turn of the cosine
+        const float u3 = (float)((uint32_t)(h2 >> 40) + 1u) * k2m24;        // (0, 1]
+        // Box-Muller: sqrt(-2 ln u1) cos(2 pi u2); v_cos_f32 takes its argument in turns
+        const float x = __builtin_amdgcn_sqrtf(-2.0f * kLn2 * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
         float v = 1.0f + c * x;
         if (v <= 0.0f) continue;
         v = v * v * v;
-        if (logf(u3) < 0.5f * x * x + d - d * v + d * logf(v)) {
+        if (kLn2 * __builtin_amdgcn_logf(u3) < 0.5f * x * x + d - d * v + d * kLn2 * __builtin_amdgcn_logf(v)) {
             g = d * v;
             break;
         }
     }
-    const float ub = (float)((mix64(key + 31ull) >> 40) + 1ull) * (1.0f / 16777216.0f);
-    return g * powf(ub, 1.0f / 0.3f);
+    const float ub = (float)((uint32_t)(mix64(key + 31ull) >> 40) + 1u) * k2m24;
+    return g * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(ub) * (1.0f / 0.3f));  // ub^(1/0.3)
 }
 
 // wave arg-max of (score, index) with the LOWEST index winning ties (Python's max keeps the first)

@@ -61,7 +61,7 @@ struct NetDev {
     const float *s_inv;          // [5] in device memory (a captured launch must see a reload's values):
                                  // 1 / (activation scale * weight scale) of conv2, conv3; 1 / weight scale of conv1;
                                  // 1 / (activation scale * weight scale) of act_fc1, val_fc1 (k_heads_split)
-    const f32x4 *fs_act, *fs_val;  // split f16 FC weights: [32-output tile][K-step of 16][hi | lo][64 lanes] x 8 f16
+    const f32x4 *fs_act, *fs_val;  // split f16 FC weights: [32-output tile][K-step of 16][hi | lo][64 lanes] x 8 f16 (+ a zero step)
     const float *b1, *b2, *b3;   // conv biases
     const float *wh;             // [6][128]: act_conv1 (4 rows) then val_conv1 (2 rows)
     const float *whp;            // the same, [128][6] (k_trunk_split)
@@ -1451,12 +1451,13 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         }
         // the two lane halves hold different channels of the same TN positions: with TN = 2 lane half h stores
         // position h, with TN = 1 half 0 stores the one position
-        float *dst = feat + (size_t)board * nd.feat_ld;
+        float *dst = feat ? feat + (size_t)board * nd.feat_ld : nullptr;  // null: only the f16 pieces are wanted
         const int y = TN == 2 ? 4 * wave + 2 * h + (n >> 4) : 2 * wave + (n >> 4);
         const bool mine = TN == 2 || h == 0;
-        // the same features as hi + lo f16 pieces in the A-fragment order of k_heads_split:
-        // [32-board tile][K-step][hi | lo][lane = 32 * (k / 8 % 2) + board % 32][k % 8]
-        _Float16 *dst16 = feat16 ? feat16 + ((size_t)(board >> 5) * (nd.groups_act + nd.groups_val) * 1024 + (board & 31) * 8)
+        // the same features as hi + lo f16 pieces for the A fragments of k_heads_split:
+        // [32-board tile][K-step][hi | lo][board % 32][k % 16] -- the 16 values of a board and K-step are one 32-byte
+        // sector (written whole by neighbouring lanes of this wave), a wave of the GEMM reads the 1 KB of a piece
+        _Float16 *dst16 = feat16 ? feat16 + ((size_t)(board >> 5) * (nd.groups_act + nd.groups_val) * 1024 + (board & 31) * 16)
                                  : nullptr;
 #pragma unroll
         for (int o = 0; o < 6; ++o) {
@@ -1465,14 +1466,14 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
             if (TN == 2) v1 += __shfl_xor(v1, 32);
             const float v = fmaxf(((TN == 2 && h) ? v1 : v0) + hw[128 * 7 + o], 0.0f);
             if (mine && y < BH && x < BW) {
-                dst[(o < 4 ? o * S : nd.feat_val_off + (o - 4) * S) + y * BW + x] = v;
+                if (dst) dst[(o < 4 ? o * S : nd.feat_val_off + (o - 4) * S) + y * BW + x] = v;
                 if (dst16) {
                     const int k = (o < 4 ? o : o - 4) * S + y * BW + x;
                     const int step = (o < 4 ? 0 : nd.groups_act) + (k >> 4);
                     const float z = v * sp::kActScale;
                     const _Float16 zh = (_Float16)z;
                     zmax = fmaxf(zmax, z);
-                    _Float16 *q = dst16 + (size_t)step * 1024 + ((k >> 3) & 1) * 256 + (k & 7);
+                    _Float16 *q = dst16 + (size_t)step * 1024 + (k & 15);
                     q[0] = zh;
                     q[512] = (_Float16)(z - (float)zh);
                 }
@@ -1713,11 +1714,12 @@ __device__ __forceinline__ void fs_load(FsFrags<TM, TN> &f, const f32x4 *__restr
                                         const f32x4 *__restrict__ zero, int steps_a, int a_step0, int step, int k1, int lane) {
     const bool live = step < k1;
     const int sa = a_step0 + (live ? step : k1 - 1);
+    const int lane_a = ((lane & 31) << 1) | (lane >> 5);  // features: [board % 32][k / 8 % 2] x 8 f16 (k_trunk_split)
 #pragma unroll
     for (int m = 0; m < TM; ++m)
 #pragma unroll
         for (int p = 0; p < 2; ++p)
-            f.a[m][p] = __builtin_bit_cast(sp::f16x8, fa[(((size_t)m * steps_a + sa) * 2 + p) * 64 + lane]);
+            f.a[m][p] = __builtin_bit_cast(sp::f16x8, fa[(((size_t)m * steps_a + sa) * 2 + p) * 64 + lane_a]);
 #pragma unroll
     for (int n = 0; n < TN; ++n) {
         // (a tile that does not exist has fb[n] == zero: every step of it reads the one zero fragment)
@@ -1890,7 +1892,8 @@ struct rz_net {
     size_t upload_cursor = 0;
     float *d_feat = nullptr, *d_raw = nullptr, *d_hid = nullptr;
     _Float16 *d_feat16 = nullptr;  // the features as hi + lo f16 pieces in fragment order (k_trunk_split -> k_heads_split)
-    bool feat16_valid = false;     // the last trunk launch into the internal buffer wrote d_feat16 too
+    bool feat16_valid = false;     // the last trunk launch into the internal buffer wrote d_feat16
+    bool feat32_valid = false;     // ... wrote d_feat (the split-f16 trunk skips it when the GEMM reads the f16 pieces)
     int heads_algo = RZ_NET_HEADS_AUTO;
     unsigned *d_flags = nullptr;
     long long feat_boards = 0;
@@ -2263,7 +2266,7 @@ int rz_net_reserve(rz_net *net, int32_t max_boards) {
     if (net->d_hid) (void)hipFree(net->d_hid);
     net->d_feat = net->d_raw = net->d_hid = nullptr;
     net->d_feat16 = nullptr;
-    net->feat16_valid = false;
+    net->feat16_valid = net->feat32_valid = false;
     net->feat_boards = 0;
     // internal features: [boards padded to 32][16 * (groups_act + groups_val)], zero filled once
     const size_t pad_boards = ((size_t)max_boards + 31) / 32 * 32;
@@ -2290,7 +2293,14 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
     const dim3 grid((unsigned)n_boards);
     // the internal buffer uses the padded layout of the FC GEMM, a caller's buffer the natural one
     const bool internal = d_feat == net->d_feat;
-    if (internal) net->feat16_valid = net->algo == RZ_NET_SPLIT_F16;
+    // the split-f16 trunk writes what the FC GEMM behind it reads: the f16 pieces, and the f32 features only for a
+    // caller's buffer or when the f32 GEMM is forced
+    const bool split = net->algo == RZ_NET_SPLIT_F16;
+    const bool want_f32 = !split || !internal || net->heads_algo == RZ_NET_HEADS_F32;
+    if (internal) {
+        net->feat16_valid = split;
+        net->feat32_valid = want_f32;
+    }
     net->dev.feat_ld = internal ? 16 * (net->dev.groups_act + net->dev.groups_val) : 6 * net->dev.S;
     net->dev.feat_val_off = internal ? 16 * net->dev.groups_act : 4 * net->dev.S;
     // Winograd kernels are persistent: one workgroup per CU (LDS bound) loops over its boards
@@ -2307,10 +2317,11 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
     else if (net->algo == RZ_NET_SPLIT_F16)
     {
         _Float16 *f16 = internal ? net->d_feat16 : nullptr;
+        float *f32 = want_f32 ? d_feat : nullptr;
         if (net->dev.BH <= 8)  // rows 2w, 2w+1 per wave: half the N-tiles
-            k_trunk_split<1><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, f16, n_boards, net->d_flags);
+            k_trunk_split<1><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, f32, f16, n_boards, net->d_flags);
         else
-            k_trunk_split<2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, f16, n_boards, net->d_flags);
+            k_trunk_split<2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, f32, f16, n_boards, net->d_flags);
     }
     else
         k_trunk<<<grid, dim3(kTrunkThreads), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
@@ -2326,6 +2337,8 @@ static void launch_heads_gemm(rz_net *net, const float *d_feat, int32_t n_boards
     // latency); both shapes give the same bits (profiles/r01/sweep_heads.txt)
     if (algo == RZ_NET_HEADS_AUTO) algo = net->max_wgs > 0 ? RZ_NET_HEADS_SPLIT_64 : RZ_NET_HEADS_SPLIT_32;
     if (d_feat != net->d_feat || !net->feat16_valid) algo = RZ_NET_HEADS_F32;
+    else if (algo == RZ_NET_HEADS_F32 && !net->feat32_valid)  // F32 chosen after a trunk that wrote only the f16 pieces
+        algo = net->max_wgs > 0 ? RZ_NET_HEADS_SPLIT_64 : RZ_NET_HEADS_SPLIT_32;
     const f32x4 *f16 = reinterpret_cast<const f32x4 *>(net->d_feat16);
     const int n_act_tiles = net->dev.Npad / 32;
     if (algo == RZ_NET_HEADS_SPLIT_64) {

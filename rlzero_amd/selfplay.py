@@ -201,10 +201,11 @@ class BatchedSelfPlay(object):
     @classmethod
     def for_network(cls, net_module, board, n_in_row, n_games, n_playout, c_puct=5.0, device='cuda:0',
                     game='gomoku', net_shape=None, lanes=None, trunk_workgroups=None, temperature=1.0, seed=0,
-                    use_graph=True, sims_per_graph=8, eager_every=0, **engine_kw):
+                    use_graph=True, sims_per_graph=8, eager_every=0, add_noise=True, **engine_kw):
         """Self-play of ``n_games`` games in flight with the hand-written evaluator of ``net_module`` (a
         PolicyValueNet): builds the lanes (engine + HipNetEvaluator each) as plan_lanes() recommends, unless
-        ``lanes`` / ``trunk_workgroups`` are given."""
+        ``lanes`` / ``trunk_workgroups`` are given.  ``add_noise``: Dirichlet noise on the priors of every expanded
+        node, what ``AlphaZeroPlayer(is_selfplay=True)`` does (alphazero_mcts.py:124-129, node.py:63-69)."""
         import torch
         from .engine import HipNetEvaluator, MCTSEngine
         dev = torch.device(device)
@@ -221,7 +222,8 @@ class BatchedSelfPlay(object):
         engines, evaluators = [], []
         for g_lane in per_lane:
             engines.append(MCTSEngine(board, n_in_row, n_games=g_lane, n_playout=n_playout, c_puct=c_puct,
-                                      device=str(device), game=game, **engine_kw))
+                                      device=str(device), game=game, add_noise=add_noise,
+                                      noise_seed=(int(seed) * 7919 + len(engines)) & 0x7fffffff, **engine_kw))
             ev = HipNetEvaluator(net_module, net_shape if net_shape is not None else board, str(device),
                                  max_boards=g_lane)
             ev.hip.set_max_workgroups(max(0, int(wgs)))

@@ -700,6 +700,12 @@ def test_split_f16_heads_gemm_equals_the_f32_gemm():
             assert float((out['f32'][1] - out['split32'][1]).abs().max()) <= 2e-6
             for algo in ('split64', 'auto', 'auto_capped'):  # the workgroup shape is scheduling only: same bits
                 assert torch.equal(out[algo][0], out['split32'][0]) and torch.equal(out[algo][1], out['split32'][1])
+        # the split trunk wrote only the f16 pieces (GEMM 'auto'): a GEMM forced to f32 afterwards runs on them
+        hip.set_heads_algo('auto').trunk_internal(x)
+        lp_late = torch.empty_like(out['split32'][0])
+        v_late = torch.empty_like(out['split32'][1])
+        hip.set_heads_algo('f32').heads(x.shape[0], lp_late, v_late)
+        assert torch.equal(lp_late, out['split32'][0]) and torch.equal(v_late, out['split32'][1])
         # after another trunk the f16 pieces are stale: the GEMM must take the f32 features
         lp_d, v_d = hip.set_algo('direct').set_heads_algo('split64').forward(x)
         lp_f, v_f = hip.set_heads_algo('f32').forward(x)

@@ -52,3 +52,10 @@ if [ -z "${SKIP_MICRO:-}" ]; then
 fi
 
 cd "$ROOT" && python3 profiles/summarise.py "$OUT"
+
+# 6. the default line once more, now that this run's counters are in place (bench.py reports roofline.traffic from
+#    profiles/<round>/pmc_traffic.json)
+if [ -f "$OUT/keep/pmc_traffic.json" ]; then
+    cp "$OUT/keep/pmc_traffic.json" "$ROOT/profiles/r01/pmc_traffic.json"
+    python3 "$ROOT/bench.py" > "$OUT/keep/bench_default.json" 2>> "$OUT/bench_default.err"
+fi

@@ -557,10 +557,16 @@ def main():
         from rlzero_amd.selfplay import gather_trajectories
         fence()
         t2 = time.perf_counter()
-        merged = gather_trajectories(gather_sample, board, n_row, dst=0, game=args.game)
+        try:
+            merged = gather_trajectories(gather_sample, board, n_row, dst=0, game=args.game)
+            gather_error = None
+        except Exception as exc:  # noqa: BLE001 -- the measured line must still be printed
+            merged, gather_error = [], '%s: %s' % (type(exc).__name__, exc)
         fence()
         dt = time.perf_counter() - t2
-        if rank == 0:
+        if rank == 0 and gather_error:
+            gather = {'ranks': world, 'error': gather_error[:300]}
+        elif rank == 0:
             plies = sum(len(t.moves) for t in merged)
             gather = {'ranks': world, 'games': len(merged), 'plies': plies, 'backend': dist.get_backend(),
                       'payload_bytes': int(32 * len(merged) + plies * 8 * (1 + merged[0].pis.shape[1])) if merged else 0,

@@ -273,7 +273,7 @@ class TimedEvaluator(object):
         return sum(a.elapsed_time(b) for a, b in self.events) / len(self.events)
 
 
-def run_muzero(args, rank, world, device, dist, red_device):
+def run_muzero(args, rank, world, device, dist, red_device, use_dist=False):
     """BASELINE.json configs[4]: MuZero on CartPole-v1, 50 simulations per move (random-init model).  A step =
     one move of every environment: initial inference, n simulations (HIP tree kernels + recurrent inference on
     the batch), action sampling, environment step."""
@@ -287,7 +287,7 @@ def run_muzero(args, rank, world, device, dist, red_device):
     for _ in range(args.warmup):
         sp.play_move()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     sims0 = sp.sims_done
@@ -296,12 +296,12 @@ def run_muzero(args, rank, world, device, dist, red_device):
     for _ in range(args.steps):
         finished += len(sp.play_move())
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     total = float(sp.sims_done - sims0)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -320,7 +320,7 @@ def run_muzero(args, rank, world, device, dist, red_device):
             'episodes_finished_in_timed_region': finished, 'tree_hbm_bytes': int(sp.tree.device_bytes),
             'roofline': None, 'cpu_baseline': None}), flush=True)
     sp.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -396,10 +396,13 @@ def main():
     if os.environ.get('RZ_BENCH_SINGLE_DEVICE') == '1':
         local_rank = 0
     backend = os.environ.get('RZ_BENCH_BACKEND', 'nccl')
+    # RZ_BENCH_FORCE_DIST=1: initialise the process group and run every collective of the N > 1 path even at world
+    # size 1 -- exercises the RCCL calls (barrier, MAX / SUM all_reduce, all_gather + gather of trajectories) on a 1-GPU box
+    use_dist = world > 1 or os.environ.get('RZ_BENCH_FORCE_DIST') == '1'
     torch.cuda.set_device(local_rank)
     device = 'cuda:%d' % local_rank
     red_device = device if backend == 'nccl' else 'cpu'  # where the MAX / SUM reductions of the result live
-    if world > 1:
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device(device))
@@ -407,7 +410,7 @@ def main():
             dist.init_process_group(backend)
 
     if args.game == 'muzero':
-        run_muzero(args, rank, world, device, dist, red_device)
+        run_muzero(args, rank, world, device, dist, red_device, use_dist)
         return
     board, n_row = args.board, (N_ROW if args.board >= 5 else args.board)
     cells = board * board
@@ -462,7 +465,7 @@ def main():
         done = sp.play_move()
         finished[0] += len(done)
         first_gen_plies.extend(len(t.moves) for t in done if t.game_id < world * G)
-        if world > 1 and len(gather_sample) < GATHER_SAMPLE_GAMES:
+        if use_dist and len(gather_sample) < GATHER_SAMPLE_GAMES:
             gather_sample.extend(done[:GATHER_SAMPLE_GAMES - len(gather_sample)])
         if done:
             free = np.nonzero(sp.slot_game < 0)[0]
@@ -473,7 +476,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -489,7 +492,7 @@ def main():
         one_step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -534,7 +537,7 @@ def main():
         fence()
         leg = time.perf_counter() - t1
         acc = [float(sp.moves_done - m0), float(sum(first_gen_plies)), float(len(first_gen_plies))]
-        if world > 1:
+        if use_dist:
             t = torch.tensor([leg], dtype=torch.float64, device=red_device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             leg = float(t.item())
@@ -553,7 +556,7 @@ def main():
     # N > 1: the path's single exchange, a gather of finished trajectories to rank 0 (RCCL over xGMI when the
     # process group is nccl), exercised on a bounded sample outside the timed region
     gather = None
-    if world > 1 and not args.no_games_leg:
+    if use_dist and not args.no_games_leg:
         from rlzero_amd.selfplay import gather_trajectories
         fence()
         t2 = time.perf_counter()
@@ -658,7 +661,7 @@ def main():
         print(json.dumps(line), flush=True)
     for eng in engines:
         eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

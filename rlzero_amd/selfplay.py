@@ -416,9 +416,9 @@ def gather_trajectories(trajs, board_size, n_in_row, dst=0, group=None, game='go
     import torch
     import torch.distributed as dist
     n_cells = board_size[1] if game == 'connect4' else board_size * board_size  # width of a pi row
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return sorted(trajs, key=lambda t: t.game_id)
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)  # a group of one runs the same collectives
     on_gpu = dist.get_backend(group) == 'nccl'
     device = torch.device('cuda', torch.cuda.current_device()) if on_gpu else torch.device('cpu')
     header, moves, pis = pack_trajectories(trajs, n_cells)

@@ -125,3 +125,26 @@ def test_bench_two_ranks_on_one_gpu():
     assert rec['selfplay']['games_sampled'] == 64 and rec['selfplay_games_per_sec'] > 0
     tg = rec['trajectory_gather']  # the one exchange of the path, here over gloo
     assert tg['ranks'] == 2 and tg['games'] >= 64 and tg['unique_game_ids'] and tg['plies'] >= 64 * 9
+
+
+@pytest.mark.gpu
+def test_bench_collectives_on_rccl_with_one_rank():
+    """The RCCL side of the N > 1 bench path on a 1-GPU box: one rank, process group 'nccl', every collective of the
+    path forced to run (barrier, MAX / SUM all_reduce of float64, all_gather of sizes, gather of trajectories)."""
+    import json
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RZ_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '2',
+           '--warmup', '1', '--board', '9', '--playouts', '40', '--games', '32', '--no-cpu-baseline',
+           '--no-literal-config']
+    out = subprocess.run(cmd, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    rec = json.loads([ln for ln in out.stdout.decode().splitlines() if ln.startswith('{')][-1])
+    tg = rec['trajectory_gather']
+    assert tg.get('error') is None and tg['backend'] == 'nccl' and tg['ranks'] == 1
+    assert tg['games'] >= 32 and tg['unique_game_ids'] and tg['payload_bytes'] > 0
+    assert rec['selfplay']['games_sampled'] == 32

@@ -230,6 +230,7 @@ class TimedEvaluator(object):
     def __init__(self, inner, torch, label):
         self.inner, self.torch, self.label = inner, torch, label
         self.events = []
+        self.fc_events, self.tree_events, self.last_c = [], [], None
         self.record = False
 
     def __call__(self, eng):
@@ -250,22 +251,35 @@ class TimedEvaluator(object):
         self.events.append((a, b))
         return out
 
+    def begin_chunk(self):
+        """engine.sim_chunk starts a chunk of eager simulations: the previous chunk's last event pairs with nothing."""
+        self.last_c = None
+
     @property
     def fused_heads(self):
         return getattr(self.inner, 'fused_heads', False)
 
     def raw_heads(self, eng):
-        """Fused route (the tree kernel finishes the heads): k_trunk bracketed when recording."""
+        """Fused route (the tree kernel finishes the heads): k_trunk bracketed when recording; a third event behind
+        the FC GEMM brackets that kernel and, with the first event of the NEXT simulation of the same eager chunk,
+        the tree step launched in between (same stream)."""
         if not self.record:
+            self.last_c = None
             return self.inner.raw_heads(eng)
         t = self.torch
-        a, b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+        a, b, c = (t.cuda.Event(enable_timing=True) for _ in range(3))
         hip = self.inner.hip
         a.record()
+        if getattr(self, 'last_c', None) is not None:
+            self.tree_events.append((self.last_c, a))
         hip.trunk_internal(eng.obs)
         b.record()
         self.events.append((a, b))
-        return hip.heads_gemm(eng.obs.shape[0])
+        out = hip.heads_gemm(eng.obs.shape[0])
+        c.record()
+        self.fc_events.append((b, c))
+        self.last_c = c
+        return out
 
     def mean_ms(self):
         if not self.events:
@@ -645,6 +659,27 @@ def main():
                 rf['exclusive_launch_ms'] = round(exclusive_ms, 4)
                 rf['exclusive_achieved'] = round(ex, 3)
                 rf['exclusive_frac'] = round(ex / peak, 4)
+            # the two small kernels of a simulation step, bracketed the same way (per stream: beside a capped trunk
+            # they share 32 CUs with nothing but each other)
+            fc = [x.elapsed_time(y) for ev in evaluators for x, y in ev.fc_events]
+            tr = [x.elapsed_time(y) for ev in evaluators for x, y in ev.tree_events]
+            if fc and tr:
+                fc_ms, tr_ms = sum(fc) / len(fc), sum(tr) / len(tr)
+                per_sim = tree_bytes_per_sim(365.5, 208.8, 1.74) if (args.game == 'gomoku' and board == 15) else None
+                line['small_kernels'] = {'heads_gemm_ms': round(fc_ms, 4), 'tree_step_ms': round(tr_ms, 4),
+                                         'launches_timed': len(tr)}
+                if per_sim:
+                    gbs = per_sim * boards_per_launch / (tr_ms * 1e-3) / 1e9
+                    line['roofline_tree'] = {
+                        'bound': 'hbm', 'kernel': 'k_tree_step_raw (expand + backup of one simulation, select of the next), '
+                                                  '%d games per launch' % boards_per_launch,
+                        'achieved': round(gbs, 2), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 5),
+                        'traffic': pmc_traffic('k_tree_step', line['config']['workload'], lanes),
+                        'avg_launch_ms': round(tr_ms, 4),
+                        'note': 'achieved = the ALGORITHMIC tree bytes of the reference\'s dense formulation (SURVEY.md 8d: 12 B per '
+                                'scanned child, 16 B per created child, 24 B per backed-up node, 64 B of root boards = 7.86 KB per '
+                                'simulation at 15x15) x games per launch / average launch duration (HIP events); the kernel is a '
+                                'chain of dependent loads per game (latency bound, one wave per game), not a streaming kernel'}
             # all trunk flops of the timed region / its whole wall-clock (tree, FC, host time included)
             whole = value / world * per_pos / 1e12
             rf['whole_job_achieved'] = round(whole, 3)

@@ -451,6 +451,9 @@ class MCTSEngine(object):
                 self.sim_step(evaluator)
             return
         lib, h = self.lib, self.handle
+        begin = getattr(evaluator, 'begin_chunk', None)  # optional evaluator hook (bench.py's timing wrapper)
+        if begin is not None:
+            begin()
         obs = _ptr(self.obs) if getattr(evaluator, 'needs_obs', True) else None
         check(lib.rz_select_step(h, obs, self.stream()), 'rz_select_step')
         if getattr(evaluator, 'fused_heads', False):

@@ -650,7 +650,9 @@ def main():
                                         'really executed / time / the peak of that pipe (split_f16: 3.35x the algorithmic '
                                         'flops on the f16 pipe; Winograd F(2x2,3x3) 2.09x fewer, F(4x4,3x3) 3.65x fewer on the f32 pipe)',
                                 'mfma_executed_frac': round(achieved / pipe_peak * executed_flop_ratio(args, cells), 4),
-                                'share_of_step_time': round(ms * (total_sims / world / G) / (elapsed * 1e3), 3),
+                                # trunk launches of all lanes x the duration charged to one / wall-clock (the eager samples
+                                # run a little slower than the graph replays they stand for, so a trunk-bound run reads ~1)
+                                'share_of_step_time': round(ms * lanes * (total_sims / world / G) / (elapsed * 1e3), 3),
                                 'concurrent_lanes': lanes,
                                 'trunk_workgroups': trunk_wgs if trunk_wgs > 0 else n_cus}
             rf = line['roofline']

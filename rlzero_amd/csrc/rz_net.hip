@@ -77,6 +77,10 @@ struct NetDev {
     // to multiples of 16 (zero filled) so the FC GEMM reads aligned 16-byte fragments.
     int feat_ld, feat_val_off;
     int BH, BW, S, A, Npad, groups_act, groups_val;  // A policy outputs (Npad: padded to 32); groups_*: K / 16
+    // k_trunk_split: an N-tile (32 MFMA columns) = tile_rows board rows x tile_cols columns, position n of a tile =
+    // (n / tile_cols, n % tile_cols) with n / tile_cols = (n * tile_rcp) >> 16; (2, 16) for boards that need 5 .. 8
+    // tiles, (32 / width, width) when 4 tiles of that shape cover the board (9x9: 3 x 9, Connect4: 4 x 7)
+    int tile_rows, tile_cols, tile_rcp;
 };
 
 // Operand fragments of one input-channel group (4 channels x 9 taps) for a wave that owns TM
@@ -1213,13 +1217,15 @@ __device__ __forceinline__ void preload_w(f16x8 (&a)[3][TM][2], const void *wts,
 
 // acc[m][n] = sum over taps and input channels for M-tiles 0 .. TM-1 (all output channels of the layer) and
 // N-tiles nt0 .. nt0 + TN - 1 (`in` = piece 0 of the layer's input in LDS, `a` primed by preload_w).
+// The lane's MFMA column is the position (row0 + ry, x) of the wave's first N-tile; a further tile of the wave (TN = 2
+// only) lies two rows below.
 template <int CIN, int TM, int TN>
-__device__ __forceinline__ void conv(const char *in, const void *wts, int nt0, int lane, f16x8 (&a)[3][TM][2],
-                                     f32x16 (&acc)[TM][TN]) {
+__device__ __forceinline__ void conv(const char *in, const void *wts, int row0, int ry, int x, int lane,
+                                     f16x8 (&a)[3][TM][2], f32x16 (&acc)[TM][TN]) {
     using G = Geo<CIN>;
-    const int n = lane & 31, h = lane >> 5;
-    // halo position (row 2*nt0 + (n >> 4), column n & 15) = the top-left tap of output (2*nt0 + (n >> 4), n & 15)
-    const int lane_byte = ((2 * nt0 + (n >> 4)) * kRowW + (n & 15)) * G::pos_bytes + h * 16;
+    const int h = lane >> 5;
+    // halo position (row0 + ry, x) = the top-left tap of output (row0 + ry, x)
+    const int lane_byte = ((row0 + ry) * kRowW + x) * G::pos_bytes + h * 16;
     const lds_frag q0 = (lds_frag)(in + lane_byte), q1 = (lds_frag)(in + lane_byte + G::piece_bytes);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(wts), 0, 0x7fffffff, 0x00020000);
     f16x8 b[2][TN][2];
@@ -1242,8 +1248,10 @@ __device__ __forceinline__ void conv(const char *in, const void *wts, int nt0, i
 
 // Wave w owns board rows 4w .. 4w+3 (N-tiles 2w, 2w+1) and ALL output channels of conv2 and of conv3, so the
 // 1x1 head convolutions see every channel of a position in one wave (two lane halves, one shuffle) and the head
-// features go from registers to memory: two barriers per board.  TN = N-tiles per wave: 2 for boards of up to 16
-// rows; boards of up to 8 rows (6x6, Connect4's 6x7, 8x8) take TN = 1 -- wave w owns rows 2w, 2w+1 -- and half the MFMAs.
+// features go from registers to memory: two barriers per board.  TN = N-tiles per wave: 2 (tiles of 2 rows x 16
+// columns) in general; when four tiles of 32 / width rows x width columns cover the board (9x9: 3 x 9, 10x10: 3 x 10,
+// 8x8: 4 x 8, Connect4: 4 x 7, 6x6: 5 x 6) a wave owns ONE such tile (TN = 1) and issues half the MFMAs or fewer; a
+// wave whose rows lie below the board skips its MFMA loops.
 template <int TN>
 __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__restrict__ obs,
                                                      float *__restrict__ feat, _Float16 *__restrict__ feat16,
@@ -1320,10 +1328,20 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     const int next_board = board + (int)gridDim.x;
     sp::f16x8 a2[3][2][2];
     sp::preload_w<32, 2>(a2, nd.s2, lane);
-    const int n = lane & 31, h = lane >> 5, x = n & 15;
-    if (2 * TN * wave < BH) {   // conv1: 4 -> 32 (one M-tile), N-tiles TN*wave ..; K-step = kernel row ky
+    // the lane's column of an N-tile: position (ry, x) of a tile of RT rows (TN = 2: always 2 x 16); a lane past the
+    // tile's positions computes position (0, 0) again and stores nothing
+    const int RT = TN == 2 ? 2 : nd.tile_rows, CT = TN == 2 ? 16 : nd.tile_cols;
+    const int n = lane & 31, h = lane >> 5;
+    const int ry_raw = TN == 2 ? n >> 4 : (n * nd.tile_rcp) >> 16;
+    const bool col_ok = ry_raw < RT;
+    const int ry = col_ok ? ry_raw : 0, x = col_ok ? n - ry_raw * CT : 0;
+    const int row0 = RT * TN * wave;       // first board row of this wave
+    // a wave below the board skips its MFMA loops (it still meets the barriers); with TN = 2 its rows stay inside the
+    // halo grid and it computes them unconditionally (a branch around the loops costs the accumulators their registers)
+    const bool busy = row0 < BH;
+    if (busy) {   // conv1: 4 -> 32 (one M-tile), N-tiles TN*wave ..; K-step = kernel row ky
         typedef const __attribute__((address_space(3))) sp::f16x4 *lds_half;
-        const lds_half q = (lds_half)(in0 + ((2 * TN * wave + (n >> 4)) * sp::kInCols + x + 2 * h) * 8);
+        const lds_half q = (lds_half)(in0 + ((row0 + ry) * sp::kInCols + x + 2 * h) * 8);
         sp::f16x8 b1[3][TN][2];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -1349,8 +1367,8 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
                     acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ky][combo == 2], b1[ky][t][combo == 1], acc1[t], 0, 0, 0);
 #pragma unroll
         for (int t = 0; t < TN; ++t) {
-            const int y = 2 * TN * wave + 2 * t + (n >> 4);
-            if (y < BH && x < BW) {
+            const int y = row0 + 2 * t + ry;
+            if (col_ok && y < BH && x < BW) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float z[4];
@@ -1376,7 +1394,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int g = 0; g < 4; ++g) bias2[m][g] = *reinterpret_cast<const f32x4 *>(nd.b2 + m * 32 + 8 * g + 4 * h) * sp::kActScale;
-        sp::conv<32, 2, TN>(c1, nd.s2, TN * wave, lane, a2, acc);
+        if (TN == 2 || busy) sp::conv<32, 2, TN>(c1, nd.s2, row0, ry, x, lane, a2, acc);
         sp::preload_w<64, 4>(a3, nd.s3, lane);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -1386,11 +1404,11 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
                 const f32x4 bv = bias2[m][g];
 #pragma unroll
                 for (int t = 0; t < TN; ++t) {
-                    const int y = 2 * TN * wave + 2 * t + (n >> 4);
+                    const int y = row0 + 2 * t + ry;
                     float z[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) z[j] = fmaxf(fmaf(acc[m][t][4 * g + j], k2, bv[j]), 0.0f);
-                    if (y < BH && x < BW) {
+                    if (busy && col_ok && y < BH && x < BW) {
                         zmax = fmaxf(fmaxf(zmax, fmaxf(z[0], z[1])), fmaxf(z[2], z[3]));
                         sp::f16x4 hi, lo;
                         sp::split4(z, hi, lo);
@@ -1411,7 +1429,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
             for (int o2 = 0; o2 < 3; ++o2) vals2[t][o2] = f32x2{0.0f, 0.0f};
         {
             sp::f32x16 acc[4][TN];
-            sp::conv<64, 4, TN>(c2, nd.s3, TN * wave, lane, a3, acc);
+            if (TN == 2 || busy) sp::conv<64, 4, TN>(c2, nd.s3, row0, ry, x, lane, a3, acc);
             // per (m, g): the lane's channels c0 .. c0+3 = 32*m + 8*g + 4*h ..: 24 head weights [j][output] and 4
             // biases from LDS, fetched one group ahead (the fences keep hipcc from hoisting all 16 groups' reads)
             f32x4 w[2][7];
@@ -1452,8 +1470,8 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         // the two lane halves hold different channels of the same TN positions: with TN = 2 lane half h stores
         // position h, with TN = 1 half 0 stores the one position
         float *dst = feat ? feat + (size_t)board * nd.feat_ld : nullptr;  // null: only the f16 pieces are wanted
-        const int y = TN == 2 ? 4 * wave + 2 * h + (n >> 4) : 2 * wave + (n >> 4);
-        const bool mine = TN == 2 || h == 0;
+        const int y = row0 + (TN == 2 ? 2 * h : 0) + ry;
+        const bool mine = busy && col_ok && (TN == 2 || h == 0);
         // the same features as hi + lo f16 pieces for the A fragments of k_heads_split:
         // [32-board tile][K-step][hi | lo][board % 32][k % 16] -- the 16 values of a board and K-step are one 32-byte
         // sector (written whole by neighbouring lanes of this wave), a wave of the GEMM reads the 1 KB of a piece
@@ -2138,6 +2156,16 @@ int rz_net_create(int32_t height, int32_t width, int32_t n_actions, int32_t devi
         D.Npad = (D.A + 31) / 32 * 32;
         D.groups_act = (4 * D.S + 15) / 16;
         D.groups_val = (2 * D.S + 15) / 16;
+        // N-tile geometry of k_trunk_split: rows x width tiles if four of them cover the board, else 2 x 16
+        const int rows = 32 / D.BW < 16 ? 32 / D.BW : 16;  // rows + 2 halo rows stay inside the 18-row grid
+        if (rows >= 1 && (D.BH + rows - 1) / rows <= 4) {
+            D.tile_rows = rows;
+            D.tile_cols = D.BW;
+        } else {
+            D.tile_rows = 2;
+            D.tile_cols = 16;
+        }
+        D.tile_rcp = (65536 + D.tile_cols - 1) / D.tile_cols;  // (n * rcp) >> 16 == n / cols for n < 32
     }
     *out = net;
     return RZ_OK;
@@ -2318,7 +2346,7 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
     {
         _Float16 *f16 = internal ? net->d_feat16 : nullptr;
         float *f32 = want_f32 ? d_feat : nullptr;
-        if (net->dev.BH <= 8)  // rows 2w, 2w+1 per wave: half the N-tiles
+        if ((net->dev.BH + net->dev.tile_rows - 1) / net->dev.tile_rows <= 4)  // four tiles cover the board: one per wave
             k_trunk_split<1><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, f32, f16, n_boards, net->d_flags);
         else
             k_trunk_split<2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, f32, f16, n_boards, net->d_flags);

@@ -661,6 +661,10 @@ def main():
                 rf['exclusive_launch_ms'] = round(exclusive_ms, 4)
                 rf['exclusive_achieved'] = round(ex, 3)
                 rf['exclusive_frac'] = round(ex / peak, 4)
+                if ms > 1.3 * exclusive_ms:
+                    # short kernels (small boards): in the eager samples the GPU drains its queue faster than Python
+                    # refills it, and the interval between a launch's two events then contains the host's enqueue gap
+                    rf['eager_samples_host_bound'] = True
             # the two small kernels of a simulation step, bracketed the same way (per stream: beside a capped trunk
             # they share 32 CUs with nothing but each other)
             fc = [x.elapsed_time(y) for ev in evaluators for x, y in ev.fc_events]

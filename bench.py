@@ -61,13 +61,11 @@ def trunk_flops_per_position(cells):
 
 def executed_flop_ratio(args, cells):
     """Flops the matrix pipe executes / algorithmic trunk flops (15x15).  f32-MFMA kernels: MFMAs of 2048 flops
-    per board -- direct 21870 (rows x 16 columns tiles), Winograd F(2x2,3x3) 10510, F(4x4,3x3) 6030, the 1x1
-    heads on the VALU.  split_f16: 4320 f16 MFMAs of 32768 flops (3 per product, 32-position tiles on 2 x 15
+    per board -- direct 21870 (rows x 16 columns tiles), Winograd F(4x4,3x3) 6030, the 1x1 heads on the VALU.  split_f16: 4320 f16 MFMAs of 32768 flops (3 per product, 32-position tiles on 2 x 15
     columns) + conv1's 270 f32 MFMAs."""
     if args.evaluator != 'hipnet' or args.game != 'gomoku' or args.board != 15:
         return 1.0
-    mfmas = {'winograd': 10510, 'winograd4w': 10510, 'winograd_f4': 6030, 'winograd_f4_8w': 6030, 'direct': 21870,
-             'split_f16': 4320 * 16 + 270}[args.net_algo]
+    mfmas = {'winograd_f4': 6030, 'direct': 21870, 'split_f16': 4320 * 16 + 270}[args.net_algo]
     return mfmas * 2048.0 / trunk_flops_per_position(cells)
 
 
@@ -119,48 +117,89 @@ def pmc_traffic(kernel, workload, lanes):
 
 
 # --------------------------------------------------------------------------- CPU baseline
-def cpu_worker(seconds, board, n_row, n_playout):
-    """One process of the CPU baseline: the oracle plays self-play moves of the same
-    configuration (fresh game, reference mode: one simulation at a time, batch-1 forward)."""
+def cpu_worker(seconds, game, board, n_playout):
+    """One process of the CPU baseline: the oracle plays self-play moves of the same configuration in reference
+    mode -- one simulation at a time, batch-1 torch CPU forward, moves drawn the way the reference draws them
+    (softmax(log(N + 1e-10) / T) over the root visits, numpy.random.choice; alphazero_mcts.py:88-92,148)."""
     import numpy as np
     import torch
     torch.set_num_threads(1)
+    np.random.seed(os.getpid() % 65536)
+    if game == 'muzero':
+        return cpu_worker_muzero(seconds, n_playout)
     from oracle.evaluators import NetEvaluator
-    from oracle.gomoku_ref import RefGomoku
-    from oracle.mcts_ref import RefPlayer
+    from oracle.mcts_ref import RefSearch, softmax
     from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
     torch.manual_seed(0)
-    net = PolicyValueNet(board)
+    if game == 'connect4':
+        from oracle.connect4_ref import RefConnect4
+        net, env, shape = PolicyValueNet(6, 7, 7), RefConnect4(6, 7, 4), (6, 7)
+    else:
+        from oracle.gomoku_ref import RefGomoku
+        net, env, shape = PolicyValueNet(board), RefGomoku(board, N_ROW if board >= 5 else board), board
     weights = {k: v.detach().numpy() for k, v in net.state_dict().items()}
-    evaluator = NetEvaluator(weights, board)
-    np.random.seed(os.getpid() % 65536)
-    env = RefGomoku(board, n_row)
-    player = RefPlayer(evaluator, n_playout=n_playout, c_puct=C_PUCT, is_selfplay=True)
-    search = player.mcts
+    search = RefSearch(NetEvaluator(weights, shape), n_playout, C_PUCT)
     sims = 0
     t0 = time.perf_counter()
     deadline = t0 + seconds
+    chunk = min(50, n_playout)
     with torch.no_grad():
         while time.perf_counter() < deadline:
-            # simulations in chunks so the budget is respected on slow hosts
-            chunk = 50
-            for _ in range(0, n_playout, chunk):
-                for _ in range(chunk):
+            done = 0
+            while done < n_playout and time.perf_counter() < deadline:  # in chunks: the budget holds on slow hosts
+                m = min(chunk, n_playout - done)
+                for _ in range(m):
                     search.playout(env.clone())
-                sims += chunk
-                if time.perf_counter() >= deadline:
-                    break
-            else:
-                acts = search.root.acts
-                visits = np.array([k.n for k in search.root.kids])
-                move = int(acts[int(np.argmax(visits + np.random.rand(len(acts))))])
-                search.update_with_move(move)
-                env.step(move)
-                if env.game_end_winner()[0]:
-                    env.reset()
-                    search.update_with_move(-1)
-    dt = time.perf_counter() - t0
-    print(json.dumps({'sims': sims, 'seconds': dt}))
+                done += m
+                sims += m
+            if done < n_playout:
+                break
+            acts = search.root.acts
+            visits = np.array([k.n for k in search.root.kids])
+            probs = softmax(1.0 / TEMPERATURE * np.log(visits + 1e-10))
+            move = int(np.random.choice(acts, p=probs))
+            search.update_with_move(move)
+            env.step(move)
+            if env.game_end_winner()[0]:
+                env.reset()
+                search.update_with_move(-1)
+    print(json.dumps({'sims': sims, 'seconds': time.perf_counter() - t0}))
+
+
+def cpu_worker_muzero(seconds, n_sims):
+    """configs[4] on the CPU: the restated MuZero pseudocode (oracle/muzero_ref.py) on a scalar CartPole-v1 with the
+    same random-init MLPs evaluated at batch 1 on torch CPU."""
+    import numpy as np
+    import torch
+    from oracle import muzero_ref as mz
+    from rlzero_amd.muzero import MuZeroNet
+    torch.manual_seed(0)
+    net = MuZeroNet().eval()
+    cfg = mz.MuZeroConfig(num_simulations=n_sims)
+
+    def recurrent(hidden, action, path):
+        nxt, reward, logits, value = net.recurrent_inference(hidden, torch.tensor([action]))
+        return nxt, float(reward), torch.softmax(logits, dim=1)[0].tolist(), float(value)
+
+    env = mz.RefCartPole()
+    rs = np.random.RandomState(os.getpid() % 65536)
+    state = env.reset(rs.uniform(-0.05, 0.05, 4))
+    sims, t0 = 0, time.perf_counter()
+    deadline = t0 + seconds
+    with torch.no_grad():
+        while time.perf_counter() < deadline:
+            root = mz.Node(0)
+            s0, logits, _ = net.initial_inference(torch.tensor([state], dtype=torch.float32))
+            mz.expand_node(root, s0, 0.0, torch.softmax(logits, dim=1)[0].tolist())
+            mz.add_exploration_noise(cfg, root, rs.dirichlet([cfg.root_dirichlet_alpha] * 2))
+            mz.run_mcts(cfg, root, recurrent)
+            sims += n_sims
+            visits = np.array([c.visit_count for c in root.children], dtype=np.float64)
+            action = int(rs.choice(2, p=visits / visits.sum()))
+            state, _, terminated, truncated = env.step(action)
+            if terminated or truncated:
+                state = env.reset(rs.uniform(-0.05, 0.05, 4))
+    print(json.dumps({'sims': sims, 'seconds': time.perf_counter() - t0}))
 
 
 def usable_cores():
@@ -179,11 +218,12 @@ def usable_cores():
     return cores
 
 
-def run_cpu_baseline(seconds):
+def run_cpu_baseline(seconds, game='gomoku', board=BOARD, n_playout=N_PLAYOUT):
     cores = usable_cores()
     env = dict(os.environ, OMP_NUM_THREADS='1', MKL_NUM_THREADS='1', HIP_VISIBLE_DEVICES='',
                ROCR_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='')
-    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-worker', str(seconds)]
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-worker', str(seconds), '--game', game, '--board', str(board),
+           '--playouts', str(n_playout)]
     procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, cwd=REPO)
              for _ in range(cores)]
     total, worst = 0, 0.0
@@ -197,28 +237,84 @@ def run_cpu_baseline(seconds):
             pass
     if worst <= 0:
         return None
+    what = {'gomoku': '%dx%d Gomoku self-play' % (board, board), 'connect4': '6x7 Connect4 self-play',
+            'muzero': 'MuZero CartPole-v1 episodes'}[game]
     return {'value': round(total / worst, 1), 'unit': 'sims/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d processes x %.0f s of %dx%d Gomoku self-play at %d sims/move from the empty '
-                      'board, oracle/mcts_ref.py + batch-1 torch CPU forward, 1 thread each'
-                      % (cores, seconds, BOARD, BOARD, N_PLAYOUT)}
+            'per_process': round(total / worst / cores, 1),
+            'sample': '%d processes x %.0f s of %s at %d sims/move from the start position, oracle (%s) + batch-1 '
+                      'torch CPU forward, 1 thread each, moves sampled like the reference (numpy.random.choice on '
+                      'softmax(log N)); the port runs ~2x the reference\'s own 376-444 sims/s/thread at 15x15 '
+                      '(BASELINE.md section 2): it is the faster of the two CPU paths'
+                      % (cores, seconds, what, n_playout, 'oracle/muzero_ref.py' if game == 'muzero' else 'oracle/mcts_ref.py')}
+
+
+def child_line(flags, timeout=900):
+    """Run `bench.py <flags>` as a child process (this process has not touched the GPU) -> its JSON line or None."""
+    cmd = [sys.executable, os.path.abspath(__file__)] + [str(f) for f in flags]
+    try:
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=REPO, timeout=timeout).stdout
+        return json.loads([ln for ln in out.decode().splitlines() if ln.startswith('{')][-1])
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def run_literal_config(args):
     """`bench.py --lanes 1 --games 512` as a child process -> the fields of its line worth keeping, or None."""
-    cmd = [sys.executable, os.path.abspath(__file__), '--lanes', '1', '--games', str(GAMES_PER_GPU), '--steps',
-           str(args.steps), '--warmup', str(args.warmup), '--net-algo', args.net_algo, '--heads-algo', args.heads_algo, '--graph', str(args.graph), '--noise', str(args.noise),
-           '--no-cpu-baseline', '--no-games-leg', '--no-literal-config']
-    try:
-        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, cwd=REPO, timeout=600).stdout
-        rec = json.loads(out.decode().strip().splitlines()[-1])
-        rf = rec.get('roofline') or {}
-        return {'workload': rec['config']['workload'], 'lanes': 1, 'value': rec['value'], 'unit': rec['unit'],
-                'ms_per_step': rec['ms_per_step'], 'roofline_frac': rf.get('frac'),
-                'roofline_avg_launch_ms': rf.get('avg_launch_ms'),
-                'note': 'same engine, one lane of %d games in flight = 4096 games / 8 GPUs (BASELINE.json configs[3]); '
-                        'measured by a child process before the main run' % GAMES_PER_GPU}
-    except Exception:  # noqa: BLE001
+    rec = child_line(['--lanes', 1, '--games', GAMES_PER_GPU, '--steps', args.steps, '--warmup', args.warmup,
+                      '--net-algo', args.net_algo, '--heads-algo', args.heads_algo, '--graph', args.graph, '--noise',
+                      args.noise, '--no-cpu-baseline', '--no-games-leg', '--no-literal-config', '--no-configs'], 600)
+    if rec is None:
         return None
+    rf = rec.get('roofline') or {}
+    return {'workload': rec['config']['workload'], 'lanes': 1, 'value': rec['value'], 'unit': rec['unit'],
+            'ms_per_step': rec['ms_per_step'], 'roofline_frac': rf.get('frac'),
+            'roofline_avg_launch_ms': rf.get('avg_launch_ms'),
+            'note': 'same engine, one lane of %d games in flight = 4096 games / 8 GPUs (BASELINE.json configs[3]); '
+                    'measured by a child process before the main run' % GAMES_PER_GPU}
+
+
+# the other configurations of BASELINE.json, each measured by a child process of the default N = 1 run
+CONFIG_LEGS = (
+    ('C1', 'configs[0] TicTacToe, 25 sims/move, 1 game', ['--board', 3, '--playouts', 25, '--games', 1, '--lanes', 1, '--steps', 9], 5.0),
+    ('C2', 'configs[1] 9x9 Gomoku, 200 sims/move, 64 games', ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 8], 12.0),
+    ('C3', 'configs[2] Connect4, 400 sims/move, 512 games', ['--game', 'connect4', '--playouts', 400, '--games', 512, '--lanes', 1, '--steps', 6], 12.0),
+    ('C5', 'configs[4] MuZero CartPole-v1, 50 sims/move, 4096 environments', ['--game', 'muzero', '--playouts', 50, '--games', 4096, '--steps', 8], 12.0),
+)
+
+
+def run_config_legs(args):
+    out = {}
+    for key, title, flags, cpu_s in CONFIG_LEGS:
+        rec = child_line(flags + ['--warmup', 2, '--cpu-seconds', cpu_s * args.cpu_seconds / 60.0, '--no-games-leg',
+                                  '--no-literal-config', '--no-configs'] + (['--no-cpu-baseline'] if args.no_cpu_baseline else []), 600)
+        if rec is None:
+            out[key] = {'config': title, 'error': 'the child process printed no line'}
+            continue
+        rf = rec.get('roofline')
+        if rf:
+            rf = {k: rf[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms',
+                                     'exclusive_frac', 'eager_samples_host_bound', 'note') if k in rf}
+        out[key] = {'config': title, 'workload': rec['config']['workload'], 'value': rec['value'], 'unit': rec['unit'],
+                    'ms_per_step': rec['ms_per_step'], 'steps': rec['steps'], 'roofline': rf,
+                    'cpu_baseline': rec.get('cpu_baseline')}
+        for extra in ('multi_sim',):
+            if extra in rec.get('config', {}):
+                out[key][extra] = rec['config'][extra]
+    return out
+
+
+def launch_ranks(n):
+    """Run this very command line under `python -m torch.distributed.run --nproc-per-node n` as a CHILD process
+    (this process has not initialised the GPU and never will), pass its stdout / stderr through and return its exit
+    code: non-zero if any rank failed."""
+    import socket
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env, cwd=REPO).returncode
 
 
 # --------------------------------------------------------------------------- GPU run
@@ -287,7 +383,11 @@ class TimedEvaluator(object):
         return sum(a.elapsed_time(b) for a, b in self.events) / len(self.events)
 
 
-def run_muzero(args, rank, world, device, dist, red_device, use_dist=False):
+MZ_FLOPS_PER_SIM = 2 * (66 * 64 + 3 * 64 * 64 + 64 + 2 * 64 + 64)  # recurrent inference: dyn1, dyn2, rew1, pre1, rew2, pol, val
+MZ_BYTES_PER_SIM = 2 * 256 + 40 * 4 + 3 * 4 + 2 * 4 + 8  # hidden state read + written (64 f32), ~4 tree nodes x 40 B, indices, policy, reward / value
+
+
+def run_muzero(args, rank, world, device, dist, red_device, use_dist=False, cpu_baseline=None):
     """BASELINE.json configs[4]: MuZero on CartPole-v1, 50 simulations per move (random-init model).  A step =
     one move of every environment: initial inference, n simulations (HIP tree kernels + recurrent inference on
     the batch), action sampling, environment step."""
@@ -305,6 +405,7 @@ def run_muzero(args, rank, world, device, dist, red_device, use_dist=False):
         dist.barrier()
     torch.cuda.synchronize()
     sims0 = sp.sims_done
+    sp.sim_events = []  # HIP events around every simulation step (one hipGraph replay) of the timed region
     t0 = time.perf_counter()
     finished = 0
     for _ in range(args.steps):
@@ -324,6 +425,21 @@ def run_muzero(args, rank, world, device, dist, red_device, use_dist=False):
         total = float(c.item())
     sp.tree.check()
     if rank == 0:
+        roofline = None
+        if sp.sim_events:
+            ms = sum(a.elapsed_time(b) for a, b in sp.sim_events) / len(sp.sim_events)
+            gbs = MZ_BYTES_PER_SIM * G / (ms * 1e-3) / 1e9
+            tf = MZ_FLOPS_PER_SIM * G / (ms * 1e-3) / 1e12
+            roofline = {'bound': 'hbm', 'kernel': sp.sim_step_label + ', %d environments per launch' % G,
+                        'achieved': round(gbs, 2), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 5),
+                        'traffic': None, 'avg_launch_ms': round(ms, 4), 'launches_timed': len(sp.sim_events),
+                        'flops_achieved_tflops': round(tf, 3), 'flops_frac_of_f32_mfma_peak': round(tf / PEAK_FP32_MATRIX_TFLOPS, 5),
+                        'note': 'one simulation step of all environments (select -> recurrent inference -> expand + backup), '
+                                'HIP events on the launch stream; algorithmic bytes per simulation = %d (hidden state in + out, '
+                                'tree nodes on the path, network heads), algorithmic flops = %d (the 7 dense layers of the '
+                                'recurrent inference): arithmetic intensity 45 flop/B is above the ridge only nominally -- at '
+                                '4096 environments the step is bound by launch / dependent latency, not by either roof'
+                                % (MZ_BYTES_PER_SIM, MZ_FLOPS_PER_SIM)}
         print(json.dumps({
             'metric': 'mcts_sims_per_sec', 'value': round(total / elapsed, 1), 'unit': 'sims/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000.0 * elapsed / max(args.steps, 1), 3),
@@ -332,7 +448,7 @@ def run_muzero(args, rank, world, device, dist, red_device, use_dist=False):
             'config': {'workload': 'muzero_cartpole_v1_%dsims_per_move_%denvs_per_gpu' % (n_sims, G),
                        'games_total': G * world, 'discount': 0.997, 'parallelism': 'environments sharded, dp%d' % world},
             'episodes_finished_in_timed_region': finished, 'tree_hbm_bytes': int(sp.tree.device_bytes),
-            'roofline': None, 'cpu_baseline': None}), flush=True)
+            'roofline': roofline, 'cpu_baseline': cpu_baseline}), flush=True)
     sp.close()
     if use_dist:
         dist.destroy_process_group()
@@ -344,7 +460,11 @@ def main():
     ap.add_argument('--steps', type=int, default=4)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--cpu-worker', type=float, default=None, help=argparse.SUPPRESS)
-    ap.add_argument('--cpu-seconds', type=float, default=15.0)
+    ap.add_argument('--cpu-seconds', type=float, default=60.0,
+                    help='wall-clock budget of the CPU baseline of the main workload (SURVEY.md 8d: >= 60 s); the '
+                         'baselines of the `configs` legs get 5-12 s each, scaled with this value')
+    ap.add_argument('--no-configs', action='store_true',
+                    help='skip the child-process legs for the other BASELINE.json configurations (C1, C2, C3, C5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--games', type=int, default=0,
                     help='games per GPU; 0 = lanes x %d boards x trunk workgroups (1344) with 2 lanes, %d with 1' %
@@ -362,7 +482,7 @@ def main():
                     help="hipnet: hand-written fused fp32 MFMA forward (csrc/rz_net.hip); torchnet: "
                          "PyTorch-ROCm/MIOpen; vlin: synthetic evaluator (isolates the tree kernels)")
     ap.add_argument('--graph', type=int, default=8, help='simulation steps per hipGraph (0 = eager)')
-    ap.add_argument('--net-algo', default='split_f16', choices=['winograd', 'winograd4w', 'winograd_f4', 'winograd_f4_8w', 'direct', 'split_f16'])
+    ap.add_argument('--net-algo', default='split_f16', choices=['winograd_f4', 'direct', 'split_f16'])
     ap.add_argument('--no-games-leg', action='store_true',
                     help='skip the self-play games/s leg (after the timed steps the games of the first generation '
                          'are played to their end, slots refilled, to measure moves/s over whole games and the mean '
@@ -375,13 +495,21 @@ def main():
                     help='Dirichlet(0.3) noise mixed into the priors of EVERY expanded node, as the reference does in '
                          'self-play (node.py:63-69, alphazero_mcts.py:124-129); under its UCT rule the priors are never '
                          'read, so this is work with no effect on the moves -- kept because the reference does it')
+    ap.add_argument('--dump-trajectories', default='',
+                    help='rank 0 writes the finished games it holds after the run (N > 1: the gathered ones) as JSON '
+                         '{game id: moves, winner, first pi}: a game must not depend on the number of ranks')
     ap.add_argument('--lanes', type=int, default=2,
                     help='independent batches of games on separate HIP streams (the tree / FC kernels of one '
                          'lane run beside the network trunk of the other)')
     args = ap.parse_args()
     if args.cpu_worker is not None:
-        cpu_worker(args.cpu_worker, args.board, N_ROW if args.board >= 5 else args.board, args.playouts)
+        cpu_worker(args.cpu_worker, args.game, args.board, args.playouts)
         return
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks as children (one process per GPU,
+    # torch.distributed.run) BEFORE anything touches the GPU, relay rank 0's line, exit with their code
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -389,8 +517,10 @@ def main():
 
     # CPU baseline first (rank 0, N=1 only), before this process touches the GPU
     cpu_baseline = None
+    default_config = (args.game == 'gomoku' and args.board == BOARD and args.playouts == N_PLAYOUT)
     if world == 1 and args.gpus == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(args.cpu_seconds)
+        playouts = 50 if (args.game == 'muzero' and args.playouts == N_PLAYOUT) else args.playouts
+        cpu_baseline = run_cpu_baseline(args.cpu_seconds, args.game, args.board, playouts)
 
     # the literal share of configs[3] (4096 games / 8 GPUs = 512 per GPU, one lane) in a child process of its
     # own, also before this process touches the GPU (a process that has initialised the GPU starts no program)
@@ -398,6 +528,12 @@ def main():
     if (world == 1 and args.gpus == 1 and not args.no_literal_config and args.game == 'gomoku' and args.games == 0
             and args.board == BOARD and args.playouts == N_PLAYOUT and args.evaluator == 'hipnet'):
         literal = run_literal_config(args)
+    # ... and the other configurations of BASELINE.json (C1, C2, C3, C5), each a child process with its own
+    # roofline and CPU baseline: reported under `configs` of the default N = 1 line
+    config_legs = None
+    if (world == 1 and args.gpus == 1 and not args.no_configs and default_config and args.games == 0
+            and args.evaluator == 'hipnet'):
+        config_legs = run_config_legs(args)
 
     import numpy as np
     import torch
@@ -424,7 +560,7 @@ def main():
             dist.init_process_group(backend)
 
     if args.game == 'muzero':
-        run_muzero(args, rank, world, device, dist, red_device, use_dist)
+        run_muzero(args, rank, world, device, dist, red_device, use_dist, cpu_baseline)
         return
     board, n_row = args.board, (N_ROW if args.board >= 5 else args.board)
     cells = board * board
@@ -451,10 +587,7 @@ def main():
             hip_ev.hip.set_heads_algo(args.heads_algo)
             hip_ev.hip.set_max_workgroups(trunk_wgs)
             ev = TimedEvaluator(hip_ev, torch,
-                                {'winograd': 'k_trunk_wino<4> (hand-written fused fp32-MFMA conv trunk, Winograd F(2x2,3x3), csrc/rz_net.hip)',
-                                 'winograd4w': 'k_trunk_wino<2> (same, 4 waves per board)',
-                                 'winograd_f4_8w': 'k_trunk_wino_f4<8> (same, 8 waves per board)',
-                                 'winograd_f4': 'k_trunk_wino_f4<4> (hand-written fused fp32-MFMA conv trunk, Winograd F(4x4,3x3), csrc/rz_net.hip)',
+                                {'winograd_f4': 'k_trunk_wino_f4<4> (hand-written fused fp32-MFMA conv trunk, Winograd F(4x4,3x3), csrc/rz_net.hip)',
                                  'split_f16': 'k_trunk_split (hand-written fused conv trunk: direct convolution on the f16 matrix pipe, f32 operands as hi + lo f16 pairs, f32 accumulation, csrc/rz_net.hip)',
                                  'direct': 'k_trunk (hand-written fused fp32-MFMA conv trunk, direct, csrc/rz_net.hip)'}[args.net_algo])
         elif args.evaluator == 'torchnet':
@@ -479,7 +612,7 @@ def main():
         done = sp.play_move()
         finished[0] += len(done)
         first_gen_plies.extend(len(t.moves) for t in done if t.game_id < world * G)
-        if use_dist and len(gather_sample) < GATHER_SAMPLE_GAMES:
+        if (use_dist or args.dump_trajectories) and len(gather_sample) < GATHER_SAMPLE_GAMES:
             gather_sample.extend(done[:GATHER_SAMPLE_GAMES - len(gather_sample)])
         if done:
             free = np.nonzero(sp.slot_game < 0)[0]
@@ -570,14 +703,17 @@ def main():
     # N > 1: the path's single exchange, a gather of finished trajectories to rank 0 (RCCL over xGMI when the
     # process group is nccl), exercised on a bounded sample outside the timed region
     gather = None
+    merged = sorted(gather_sample, key=lambda t: t.game_id)
     if use_dist and not args.no_games_leg:
         from rlzero_amd.selfplay import gather_trajectories
         fence()
         t2 = time.perf_counter()
         try:
-            merged = gather_trajectories(gather_sample, board, n_row, dst=0, game=args.game)
+            # a local failure inside is agreed on by all ranks within the collectives (selfplay.gather_trajectories):
+            # every rank raises together, nobody stays blocked, and the measured line is still printed
+            merged = gather_trajectories(gather_sample, board, n_row, dst=0, game=args.game) or []
             gather_error = None
-        except Exception as exc:  # noqa: BLE001 -- the measured line must still be printed
+        except Exception as exc:  # noqa: BLE001
             merged, gather_error = [], '%s: %s' % (type(exc).__name__, exc)
         fence()
         dt = time.perf_counter() - t2
@@ -590,6 +726,12 @@ def main():
                       'ms': round(1000.0 * dt, 2),
                       'unique_game_ids': len({t.game_id for t in merged}) == len(merged)}
 
+    if rank == 0 and args.dump_trajectories:
+        # the finished games rank 0 holds (N > 1: gathered from all ranks), for world-size-invariance checks
+        with open(args.dump_trajectories, 'w') as f:
+            json.dump({str(t.game_id): {'moves': t.moves, 'winner': t.winner,
+                                        'pi_hex': [float(x).hex() for x in t.pis[0]] if len(t.moves) else []}
+                       for t in merged}, f)
     if rank == 0:
         value = total_sims / elapsed
         line = {
@@ -648,7 +790,7 @@ def main():
                                         'per dispatch); exclusive_* = the same kernel launched alone after the timed region; whole_job_* = trunk flops of all '
                                         'simulations / wall-clock; mfma_executed_frac = flops the matrix pipe '
                                         'really executed / time / the peak of that pipe (split_f16: 3.35x the algorithmic '
-                                        'flops on the f16 pipe; Winograd F(2x2,3x3) 2.09x fewer, F(4x4,3x3) 3.65x fewer on the f32 pipe)',
+                                        'flops on the f16 pipe; Winograd F(4x4,3x3) 3.65x fewer on the f32 pipe)',
                                 'mfma_executed_frac': round(achieved / pipe_peak * executed_flop_ratio(args, cells), 4),
                                 # trunk launches of all lanes x the duration charged to one / wall-clock (the eager samples
                                 # run a little slower than the graph replays they stand for, so a trunk-bound run reads ~1)
@@ -698,6 +840,7 @@ def main():
                                     'achieved': round(achieved, 3), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                     'frac': round(achieved / PEAK_HBM_GBS, 6), 'traffic': None}
         line['literal_config'] = literal
+        line['configs'] = config_legs
         line['cpu_baseline'] = cpu_baseline
         print(json.dumps(line), flush=True)
     for eng in engines:

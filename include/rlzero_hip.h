@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 16
+#define RZ_ABI_VERSION 17
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 
@@ -71,7 +71,10 @@ enum {
     RZ_FLAG_BLOCKS_FULL = 2,
     RZ_FLAG_ILLEGAL_MOVE = 4,
     RZ_FLAG_LOGTAB = 8,
-    RZ_FLAG_INTERNAL = 16
+    RZ_FLAG_INTERNAL = 16,
+    RZ_FLAG_REUSE_DROPPED = 32 /* NOT an error: rz_advance_roots found the kept subtree larger than pool_factor * n_playout
+                                  expanded nodes and restarted that game's search from a fresh root (the reference's tree
+                                  is unbounded, alphazero_mcts.py:96-103); counted in rz_stats.reuse_dropped */
 };
 
 typedef struct rz_engine rz_engine;
@@ -108,6 +111,7 @@ typedef struct rz_stats {
     int64_t max_blocks_used; /* max over games of expanded nodes in the current arena */
     int64_t device_bytes;    /* bytes of HBM the engine allocated */
     int64_t n_select_calls;  /* rz_select_step launches so far */
+    int64_t reuse_dropped;   /* kept subtrees dropped by rz_advance_roots since the last clear (RZ_FLAG_REUSE_DROPPED) */
 } rz_stats;
 
 int rz_abi_version(void);
@@ -260,20 +264,21 @@ int rz_uct_scores(rz_engine *e, const double *d_w, const int32_t *d_n, const int
  * dominant kernel by itself). */
 typedef struct rz_net rz_net;
 enum {
-    RZ_NET_DIRECT = 0,   /* conv2/conv3 as direct implicit GEMM: bit-for-bit a k-ordered fp32 fmaf chain */
-    RZ_NET_WINOGRAD = 1, /* conv2/conv3 as Winograd F(2x2,3x3) on the fp32 MFMA path (2.25x fewer
-                            multiply-adds; fp32 throughout, differs from DIRECT by re-association only);
-                            8 waves per board, two per SIMD */
-    RZ_NET_WINOGRAD_4W = 2, /* same arithmetic, 4 waves per board (one per SIMD, whole register file) */
-    RZ_NET_WINOGRAD_F4 = 3,  /* conv2/conv3 as Winograd F(4x4,3x3): 4x fewer multiply-adds than DIRECT; fp32
-                                throughout, ~1e-6 absolute on the activations (one digit more than F(2x2,3x3));
-                                4 waves per board, two output-channel tiles each, one per SIMD */
-    RZ_NET_WINOGRAD_F4_8W = 4, /* same arithmetic, 8 waves per board with one tile each (two per SIMD; slower) */
-    RZ_NET_SPLIT_F16 = 5 /* default: conv1..conv3 as direct convolutions on the f16 matrix pipe with every f32 operand carried
-                            as hi + lo (two f16 values, 22 significant bits) and every product as hi*hi + hi*lo +
-                            lo*hi accumulated in f32: within a few 1e-7 (relative) of the f32 kernels.  Scaled
-                            activations must stay below 65504 / 16: a larger one sets RZ_NET_FLAG_F16_RANGE */
+    RZ_NET_DIRECT = 0,      /* conv2/conv3 as direct implicit GEMM on the f32-input MFMA: bit-for-bit a k-ordered fp32 fmaf
+                               chain (the exact reference arithmetic; also what a net without finite activation bounds runs on) */
+    RZ_NET_WINOGRAD_F4 = 1, /* conv2/conv3 as Winograd F(4x4,3x3) on the f32-input MFMA: 4x fewer multiply-adds than
+                               DIRECT; fp32 throughout, ~1e-6 relative from DIRECT */
+    RZ_NET_SPLIT_F16 = 2    /* default: conv1..conv3 as direct convolutions on the f16 matrix pipe with every f32 operand carried
+                               as a hi + lo pair of f16 values (three MFMAs per product, f32 accumulation): as accurate as
+                               DIRECT (1e-7 relative against fp64).  The f16 pieces of a layer's activations are stored times a
+                               power of two that rz_net_load derives from bounds on the activations (observation planes in
+                               [0, 1]), so weights of any scale stay in range on MCTS leaves; only inputs beyond [0, 1]
+                               can overflow, which sets RZ_NET_FLAG_F16_RANGE */
 };
+/* rz_net_range_info: h_info8 = {bound on conv1's, conv2's activations and on the head features for inputs in [0, 1];
+ * the three activation scales chosen from them; 1.0 if the bounds are finite (0.0: RZ_NET_SPLIT_F16 runs RZ_NET_DIRECT
+ * instead for this net); 0} -- valid after rz_net_load. */
+int rz_net_range_info(rz_net *net, float *h_info8);
 /* rz_net_error_flags: sticky bits set by the kernels since creation / the last call (synchronises the device) */
 enum { RZ_NET_FLAG_F16_RANGE = 1 };
 int rz_net_error_flags(rz_net *net, uint32_t *h_flags);

@@ -106,7 +106,8 @@ class NetEvaluator(object):
     def __call__(self, env):
         import torch
         legal = env.leagel_actions()
-        obs = env.current_state().reshape(-1, 4, self.board_size, self.board_size)
+        rows, cols = self.board_size if isinstance(self.board_size, (tuple, list)) else (self.board_size, self.board_size)
+        obs = env.current_state().reshape(-1, 4, rows, cols)
         with torch.no_grad():
             logp, v = net_forward(self.weights, np.ascontiguousarray(obs))
         probs = np.exp(logp.numpy().flatten())

@@ -8,19 +8,20 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64,
                     c_void_p)
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
 
 OK = 0
 SCORE_UCT_REF, SCORE_PUCT = 0, 1
 GAME_GOMOKU, GAME_CONNECT4 = 0, 1
-NET_DIRECT, NET_WINOGRAD, NET_WINOGRAD_4W, NET_WINOGRAD_F4, NET_WINOGRAD_F4_8W, NET_SPLIT_F16 = 0, 1, 2, 3, 4, 5
+NET_DIRECT, NET_WINOGRAD_F4, NET_SPLIT_F16 = 0, 1, 2
 NET_FLAG_F16_RANGE = 1
 NET_HEADS_AUTO, NET_HEADS_F32, NET_HEADS_SPLIT_32, NET_HEADS_SPLIT_64 = 0, 1, 2, 3
 EVAL_V0, EVAL_VLIN = 0, 1
 FLAG_NAMES = {1: 'arena full', 2: 'block queue full', 4: 'illegal move', 8: 'ln table too short',
               16: 'internal'}
+FLAG_REUSE_DROPPED = 32  # not an error: a kept subtree exceeded the arena's carry limit and was dropped (counted)
 
 
 class RzConfig(Structure):
@@ -34,7 +35,7 @@ class RzConfig(Structure):
 class RzStats(Structure):
     _fields_ = [('error_flags', c_int32), ('first_bad_game', c_int32), ('arena_slots', c_int64),
                 ('prior_floats', c_int64), ('max_slots_used', c_int64), ('max_blocks_used', c_int64),
-                ('device_bytes', c_int64), ('n_select_calls', c_int64)]
+                ('device_bytes', c_int64), ('n_select_calls', c_int64), ('reuse_dropped', c_int64)]
 
 
 class RzMzConfig(Structure):
@@ -89,6 +90,7 @@ _SIGNATURES = {
     'rz_net_set_max_workgroups': (c_int, [P, c_int32]),
     'rz_net_set_heads_algo': (c_int, [P, c_int32]),
     'rz_net_error_flags': (c_int, [P, POINTER(ctypes.c_uint32)]),
+    'rz_net_range_info': (c_int, [P, POINTER(ctypes.c_float)]),
     'rz_net_load': (c_int, [P, POINTER(c_void_p), c_int32]),
     'rz_net_reserve': (c_int, [P, c_int32]),
     'rz_net_trunk': (c_int, [P, P, c_int32, P, P]),

@@ -57,7 +57,7 @@ constexpr int kWave = 64;
 constexpr int kWords = RZ_BOARD_WORDS;
 
 struct Dev {
-    int kind, BH, BW, S, A, n_row, n_games, score_mode;
+    int kind, BH, BW, S, A, n_row, n_games, score_mode, n_playout;
     int path_stride, qcap;
     long long cap, pcap, logtab_n;  // record slots / prior floats per arena
     double c_puct;
@@ -72,7 +72,7 @@ struct Dev {
     uint64_t *leaf_stones;
     int32_t *leaf_to_move, *leaf_last;
     int32_t *queue;
-    int32_t *err, *err_any;
+    int32_t *err, *err_any, *reuse_drops;
     const double *logtab;
     int32_t *noise_ctr;
     uint64_t noise_seed;
@@ -923,7 +923,9 @@ __global__ __launch_bounds__(kWave) void k_advance(Dev E, const int32_t *moves) 
         const int dst = queue[q_head];
         const int4 lo = Rd[2 * dst], hi = Rd[2 * dst + 1];
         const int k = rec_k(lo), cap = rec_cap(lo), nv = lo.z, sfc = lo.y, spb = hi.z;
-        if ((long long)dptop + k > E.pcap || (long long)dtop + cap > E.cap || nblk >= E.qcap) {
+        // the carried subtree must leave room for the n_playout expansions of the coming search
+        if ((long long)dptop + k > E.pcap - (long long)(E.n_playout + 1) * E.A ||
+            (long long)dtop + cap > E.cap - (long long)(E.n_playout + 1) * 8 - 2 * E.A || nblk >= E.qcap - E.n_playout - 1) {
             full = true;
             break;
         }
@@ -958,7 +960,14 @@ __global__ __launch_bounds__(kWave) void k_advance(Dev E, const int32_t *moves) 
         __syncthreads();  // records and queue entries written by other lanes are read next iteration
     }
     if (full) {
-        flag(E, g, RZ_FLAG_BLOCKS_FULL, lane);
+        // The reference's tree is unbounded; here the kept subtree is limited to pool_factor * n_playout expanded
+        // nodes.  A larger one is DROPPED (the search restarts from a fresh root, like update_with_move(-1)):
+        // a deviation from the reference that is counted (rz_stats.reuse_dropped) and flagged per game with the
+        // non-fatal RZ_FLAG_REUSE_DROPPED, never silent and never fatal for the rest of the batch.
+        if (lane == 0) {
+            atomicOr(&E.err[g], RZ_FLAG_REUSE_DROPPED);
+            atomicAdd(E.reuse_drops, 1);
+        }
         fresh_root(E, g, dst_arena, lane);
         return;
     }
@@ -1189,6 +1198,7 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     D.A = A;
     D.n_row = n_row;
     D.n_games = cfg->n_games;
+    D.n_playout = cfg->n_playout;
     D.score_mode = cfg->score_mode;
     D.add_noise = cfg->add_noise ? 1 : 0;
     D.noise_seed = (uint64_t)(uint32_t)cfg->noise_seed;
@@ -1239,6 +1249,7 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     RZ_ALLOC(queue, G * D.qcap);
     RZ_ALLOC(err, G);
     RZ_ALLOC(err_any, 1);
+    RZ_ALLOC(reuse_drops, 1);
     RZ_ALLOC(noise_ctr, G);
     if (rc == RZ_OK) rc = dev_alloc(e, &e->d_logtab, D.logtab_n);
 #undef RZ_ALLOC
@@ -1255,7 +1266,7 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     zero(D.leaf_node, G * 4); zero(D.leaf_depth, G * 4); zero(D.leaf_fresh, G * 4);
     zero(D.leaf_term, G * 4); zero(D.leaf_tval, G * 8); zero(D.leaf_stones, G * 2 * kWords * 8);
     zero(D.leaf_to_move, G * 4); zero(D.path, G * D.path_stride * 4);
-    zero(D.err, G * 4); zero(D.err_any, 4); zero(D.noise_ctr, G * 4);
+    zero(D.err, G * 4); zero(D.err_any, 4); zero(D.reuse_drops, 4); zero(D.noise_ctr, G * 4);
     if (herr == hipSuccess) herr = hipMemset(D.root_last, 0xff, G * 4);  // -1
     if (herr == hipSuccess) herr = hipMemset(D.leaf_last, 0xff, G * 4);
     if (herr == hipSuccess) herr = hipMemset(D.active, 1, G);
@@ -1513,8 +1524,9 @@ int rz_get_stats(rz_engine *e, rz_stats *out) {
     RZ_HIP(hipDeviceSynchronize());
     const size_t G = (size_t)e->cfg.n_games;
     std::vector<int32_t> err(G), top(G), nblk(G);
-    int32_t any = 0;
+    int32_t any = 0, drops = 0;
     RZ_HIP(hipMemcpy(&any, e->dev.err_any, 4, hipMemcpyDeviceToHost));
+    RZ_HIP(hipMemcpy(&drops, e->dev.reuse_drops, 4, hipMemcpyDeviceToHost));
     RZ_HIP(hipMemcpy(err.data(), e->dev.err, G * 4, hipMemcpyDeviceToHost));
     RZ_HIP(hipMemcpy(top.data(), e->dev.top, G * 4, hipMemcpyDeviceToHost));
     RZ_HIP(hipMemcpy(nblk.data(), e->dev.nblk, G * 4, hipMemcpyDeviceToHost));
@@ -1522,7 +1534,7 @@ int rz_get_stats(rz_engine *e, rz_stats *out) {
     out->error_flags = any;
     out->first_bad_game = -1;
     for (size_t g = 0; g < G; ++g) {
-        if (err[g] && out->first_bad_game < 0) out->first_bad_game = (int32_t)g;
+        if ((err[g] & ~RZ_FLAG_REUSE_DROPPED) && out->first_bad_game < 0) out->first_bad_game = (int32_t)g;
         if (top[g] > out->max_slots_used) out->max_slots_used = top[g];
         if (nblk[g] > out->max_blocks_used) out->max_blocks_used = nblk[g];
     }
@@ -1530,6 +1542,7 @@ int rz_get_stats(rz_engine *e, rz_stats *out) {
     out->prior_floats = e->dev.pcap;
     out->device_bytes = e->bytes;
     out->n_select_calls = e->n_select;
+    out->reuse_dropped = drops;
     return RZ_OK;
 }
 
@@ -1538,6 +1551,7 @@ int rz_clear_errors(rz_engine *e) {
     RZ_HIP(hipDeviceSynchronize());
     RZ_HIP(hipMemset(e->dev.err, 0, (size_t)e->cfg.n_games * 4));
     RZ_HIP(hipMemset(e->dev.err_any, 0, 4));
+    RZ_HIP(hipMemset(e->dev.reuse_drops, 0, 4));
     return RZ_OK;
 }
 

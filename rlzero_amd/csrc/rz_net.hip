@@ -13,9 +13,7 @@
 //   k_trunk_split<TN> (default)   conv1..conv3 as direct convolutions on v_mfma_f32_32x32x16_f16, every f32 operand
 //                                 a hi + lo pair of f16 values; persistent workgroups, 4 waves (f16 layouts in LDS:
 //                                 see the kernel); TN = 2 row-pair tiles per wave, 1 for boards of up to 8 rows
-//   k_trunk_wino_f4<4>            conv2 / conv3 as Winograd F(4x4,3x3), persistent workgroups, 4 waves
-//   k_trunk_wino_f4<8>            same arithmetic, 8 waves
-//   k_trunk_wino<4> / <2>         Winograd F(2x2,3x3), 8 / 4 waves
+//   k_trunk_wino_f4<4>            conv2 / conv3 as Winograd F(4x4,3x3) on the f32-input MFMA, persistent workgroups, 4 waves
 //   k_trunk                       direct implicit GEMM (bit-for-bit a k-ordered fmaf chain): M = output channels
 //                                 (A = weights, pre-packed on the host in fragment order, streamed from L2), N =
 //                                 the 16 columns of a board row (B = ds_read_b32 from the halo planes), K =
@@ -54,13 +52,14 @@ constexpr int kTrunkThreads = 512;
 
 struct NetDev {
     const f32x4 *w1, *w2, *w3;   // packed [tile][cin_step][3][64 lanes] x 4 taps
-    const f32x4 *u2, *u3;        // Winograd-domain weights of conv2 / conv3: [tile][i'][cin_step][64 lanes] x 4 j'
     const f32x4 *u2f, *u3f;      // F(4x4,3x3): [tile][pass][cin_step][3][64 lanes] x 4 components (pack_wino_f4)
     const f32x4 *s1;             // conv1 for k_trunk_split: [kernel row][hi | lo][64 lanes] x 8 f16 (pack_split1)
     const f32x4 *s2, *s3;        // split f16 weights: [32-channel tile][tap][16-channel chunk][hi | lo][64 lanes] x 8 f16
-    const float *s_inv;          // [5] in device memory (a captured launch must see a reload's values):
-                                 // 1 / (activation scale * weight scale) of conv2, conv3; 1 / weight scale of conv1;
-                                 // 1 / (activation scale * weight scale) of act_fc1, val_fc1 (k_heads_split)
+    const float *s_inv;          // [8] in device memory (a captured launch must see a reload's values), with a1, a2, a3 =
+                                 // the activation scales of conv1's / conv2's outputs and of the head features (powers of
+                                 // two from rz_net_load's activation bounds), sw* the weight scales:
+                                 // [0] a2 / (a1 sw2), [1] 1 / (a2 sw3), [2] a1 / (16 sw1), [3] 1 / (a3 sw_act_fc1),
+                                 // [4] 1 / (a3 sw_val_fc1), [5] a1, [6] a2, [7] a3
     const f32x4 *fs_act, *fs_val;  // split f16 FC weights: [32-output tile][K-step of 16][hi | lo][64 lanes] x 8 f16 (+ a zero step)
     const float *b1, *b2, *b3;   // conv biases
     const float *wh;             // [6][128]: act_conv1 (4 rows) then val_conv1 (2 rows)
@@ -187,38 +186,7 @@ __device__ __forceinline__ void zero_acc(f32x4 (&acc)[TM][8]) {
         for (int t = 0; t < 8; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// ------------------------------------------------------------------ Winograd F(2x2, 3x3)
-// conv2 / conv3 in the Winograd domain: Y = A^T [ (G g G^T) . (B^T d B) ] A per 2x2 output tile,
-// i.e. 16 element-wise products per (cout, cin) instead of 36 multiply-adds: 2.25x fewer MFMAs.
-//   * U = G g G^T is precomputed on the host (fp64, rounded once) and packed in fragment order;
-//   * V = B^T d B is formed ON THE FLY from the halo planes in LDS: one pass handles the 4
-//     components (i', j' = 0..3) of one transform row i', which need only 2 rows x 4 columns of
-//     the 4x4 input patch and 8 additions per lane, N-tile and channel group;
-//   * the MFMA N dimension is 16 tiles = tile rows {r, r+4} x 8 tile columns; K = input channels.
-//     With the odd plane stride the 32 lanes of a ds_read half-wave (8 tile columns: banks 0,2..14;
-//     tile row +4 = 8 board rows = 144 floats: +16; channel sub-group +1 plane: odd banks) hit 32
-//     different banks -- the naive {r, r+1} pairing is 2-way conflicted on every read;
-//   * the output transform A^T M A is linear in M, so after each pass the 4 accumulators of a
-//     (cout tile, N-tile) are folded into the 4 output values of the tile with coefficients
-//     0 / +1 / -1 -- all 16 components of a (cout, tile) live in the same lane, no data movement;
-//   * a wave owns TM output-channel tiles x 2 N-tiles (one board half), so one transformed fragment
-//     feeds 4*TM MFMAs; 8 waves (two per SIMD, TM = 2 for conv3) beat 4 waves with TM = 4;
-//   * the packed U vectors are one contiguous stream over (pass, channel group), fetched with
-//     buffer loads 3 groups ahead through a 4-slot register ring that runs across the passes;
-//   * software pipeline over the channel groups: the input transform, the LDS reads and the U loads
-//     of the coming groups are threaded between the MFMAs of the current one (wino_block).
-// fp32 throughout; differs from the direct kernel only by Winograd's re-association
-// (|error| ~1e-6 relative, far inside the 1e-4 tolerance; both paths are tested).
-
-// patch rows (of the 4x4 input patch) that transform row i' = IP combines: V[i'] = d[r0] +/- d[r1]
-template <int IP> struct WinoRows {
-    static constexpr int r0 = (IP == 0) ? 0 : (IP == 1) ? 1 : (IP == 2) ? 2 : 1;
-    static constexpr int r1 = (IP == 0) ? 2 : (IP == 1) ? 2 : (IP == 2) ? 1 : 3;
-};
-
-// One of the 8 LDS reads (two adjacent floats) of a channel group's patch rows: o = nt*4 + rr*2 + half.
-// `q` is the group's base (opaque to the optimiser), so every read is q + a compile-time offset that
-// fits the ds_read2 offset fields: one address add per group instead of one per read.
+// helpers shared by the Winograd F(4x4,3x3) trunk
 typedef const __attribute__((address_space(3))) float *lds_cptr;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
@@ -226,416 +194,6 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // offset, so the address of every load of the stream costs SALU only.
 __device__ __forceinline__ f32x4 load_u(__amdgpu_buffer_rsrc_t rsrc, int lane_off, int uniform_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, uniform_off, 0));
-}
-
-template <int IP>
-__device__ __forceinline__ void wino_ld_op(float (&d)[2][2][4], lds_cptr q, int o) {
-    const int nt = o >> 2, rr = (o >> 1) & 1, c = 2 * (o & 1);
-    const int row = (rr == 0 ? WinoRows<IP>::r0 : WinoRows<IP>::r1) + 2 * nt;  // N-tile nt: one tile row lower
-    d[nt][rr][c] = q[row * kRowW + c];
-    d[nt][rr][c + 1] = q[row * kRowW + c + 1];
-}
-
-// One of the 16 additions of the input transform of a channel group: o = nt*8 + w; w < 4: the row
-// combination t[w], else the column combination v[w - 4].
-template <int IP>
-__device__ __forceinline__ void wino_xf_op(const float (&d)[2][2][4], float (&t)[2][4], float (&v)[2][4], int o) {
-    const int nt = o >> 3, w = o & 7;
-    if (w < 4) t[nt][w] = (IP == 1) ? d[nt][0][w] + d[nt][1][w] : d[nt][0][w] - d[nt][1][w];
-    else if (w == 4) v[nt][0] = t[nt][0] - t[nt][2];
-    else if (w == 5) v[nt][1] = t[nt][1] + t[nt][2];
-    else if (w == 6) v[nt][2] = t[nt][2] - t[nt][1];
-    else v[nt][3] = t[nt][1] - t[nt][3];
-}
-
-// The MFMA block of one channel group (8*TM MFMAs on the fragments a_cur x v_cur) with the
-// non-matrix work of the NEXT groups threaded between the MFMAs, one small slice per MFMA, each
-// slice pinned in place: first half = the input transform of the group after this one (patch rows
-// already in `d`, type XIP) into v_nxt; second half = the LDS reads of the group after that
-// (pass LIP, base q_ld) into `d` and the U loads `DIST` groups ahead into a_ld.  The matrix pipe
-// then never waits for a block of VALU / LDS issue of the same wave, and the partner wave of
-// the SIMD finds issue slots between this wave's MFMAs.
-template <int TM, int XIP, int LIP, bool DO_XF, bool DO_LD, bool DO_U, bool ZERO_C = false>
-__device__ __forceinline__ void wino_block(f32x4 (&acc)[TM][2][4], const f32x4 (&a_cur)[TM], const float (&v_cur)[2][4],
-                                           float (&v_nxt)[2][4], float (&d)[2][2][4], lds_cptr q_ld,
-                                           f32x4 (&a_ld)[TM], __amdgpu_buffer_rsrc_t u_rsrc, int u_off, int u_lane,
-                                           int u_stride) {
-    constexpr int NS = 8 * TM;          // MFMAs = slots
-    constexpr int XF_PER = 32 / NS;     // transform ops per slot of the first half (16 ops)
-    constexpr int LD_SLOTS = NS / 2;    // second half
-    float t[2][4];
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const int jp = i / (2 * TM), m = (i >> 1) % TM, nt = i & 1;
-        // ZERO_C (first group of a pass): C is the inline constant 0, the accumulators need no clearing
-        acc[m][nt][jp] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[m][jp], v_cur[nt][jp],
-                                                              ZERO_C ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[m][nt][jp], 0, 0, 0);
-        if (i < NS / 2) {
-            if (DO_XF) {
-#pragma unroll
-                for (int k = 0; k < XF_PER; ++k) wino_xf_op<XIP>(d, t, v_nxt, i * XF_PER + k);
-            }
-        } else {
-            const int j = i - NS / 2;  // 0 .. LD_SLOTS-1
-            if (DO_LD) {
-                // 8 reads over LD_SLOTS slots
-                constexpr int kEvery = LD_SLOTS >= 8 ? LD_SLOTS / 8 : 1;
-                if (LD_SLOTS >= 8) {
-                    if ((j % kEvery) == 0) wino_ld_op<LIP>(d, q_ld, j / kEvery);
-                } else {
-                    constexpr int kPer = LD_SLOTS < 8 ? 8 / LD_SLOTS : 1;
-#pragma unroll
-                    for (int k = 0; k < kPer; ++k) wino_ld_op<LIP>(d, q_ld, j * kPer + k);
-                }
-            }
-            if (DO_U && j < TM)
-                a_ld[j] = load_u(u_rsrc, u_lane, u_off + j * u_stride);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// One transform row i' = IP for the wave's TM output-channel tiles.  Software pipeline over the
-// channel groups g = IP*kSteps + s of the whole convolution: block g multiplies group g, transforms
-// group g+1 and fetches the patch rows of group g+2 and the U fragments of group g+3 (4-slot ring).
-// `vb` double-buffers the transformed fragment; kSteps is even, so every pass starts on vb[0].
-template <int PL, int CIN, int TM, int IP>
-__device__ __forceinline__ void wino_pass(lds_cptr base, __amdgpu_buffer_rsrc_t u_rsrc, int ubase, int u_lane,
-                                          f32x4 (&a)[4][TM], float (&d)[2][2][4], float (&vb)[2][2][4],
-                                          f32x4 (&Y)[TM][2][4]) {
-    constexpr int kSteps = CIN / 4;  // 8 or 16: a multiple of the ring size
-    constexpr int kT = 4 * kSteps;   // U vectors per tile: index t = IP*kSteps + s
-    constexpr int kUStride = kT * 64 * 16;  // bytes between the U streams of consecutive tiles
-    constexpr int NIP = IP < 3 ? IP + 1 : 3;
-    f32x4 acc[TM][2][4];  // first written by the ZERO_C block below
-    // all but the last 4 groups of the pass: everything these blocks prepare belongs to this pass.  The
-    // first 4 are peeled (kSteps >= 8): their first block starts the accumulators from C = 0.
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        lds_cptr q = base + (4 * (r + 2)) * PL;
-        asm volatile("" : "+v"(q));
-        const int u = ubase + (IP * kSteps + r + 3) * (64 * 16);
-        if (r == 0)
-            wino_block<TM, IP, IP, true, true, true, true>(acc, a[r], vb[r & 1], vb[(r + 1) & 1], d, q, a[(r + 3) & 3], u_rsrc,
-                                                           u, u_lane, kUStride);
-        else
-            wino_block<TM, IP, IP, true, true, true>(acc, a[r], vb[r & 1], vb[(r + 1) & 1], d, q, a[(r + 3) & 3], u_rsrc, u,
-                                                     u_lane, kUStride);
-    }
-#pragma unroll 1
-    for (int s0 = 4; s0 < kSteps - 4; s0 += 4) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int s = s0 + r;
-            lds_cptr q = base + (4 * (s + 2)) * PL;
-            asm volatile("" : "+v"(q));
-            const int u = ubase + (IP * kSteps + s + 3) * (64 * 16);
-            wino_block<TM, IP, IP, true, true, true>(acc, a[r], vb[r & 1], vb[(r + 1) & 1], d, q, a[(r + 3) & 3], u_rsrc, u,
-                                                     u_lane, kUStride);
-        }
-    }
-    {   // last 4 groups: the prepared groups run over into pass IP + 1 (nothing after the last pass)
-        constexpr int s0 = kSteps - 4;
-        {
-            lds_cptr q = base + (4 * (s0 + 2)) * PL;
-            asm volatile("" : "+v"(q));
-            wino_block<TM, IP, IP, true, true, true>(acc, a[0], vb[0], vb[1], d, q, a[3], u_rsrc,
-                                                     ubase + (IP * kSteps + s0 + 3) * (64 * 16), u_lane, kUStride);
-        }
-        {
-            lds_cptr q = base + (4 * (s0 + 3)) * PL;
-            asm volatile("" : "+v"(q));
-            wino_block<TM, IP, IP, true, true, (IP < 3)>(acc, a[1], vb[1], vb[0], d, q, a[0], u_rsrc,
-                                                         ubase + (IP * kSteps + s0 + 4) * (64 * 16), u_lane, kUStride);
-        }
-        {
-            lds_cptr q = base;  // group 0 of the next pass
-            asm volatile("" : "+v"(q));
-            wino_block<TM, IP, NIP, true, (IP < 3), (IP < 3)>(acc, a[2], vb[0], vb[1], d, q, a[1], u_rsrc,
-                                                              ubase + (IP * kSteps + s0 + 5) * (64 * 16), u_lane, kUStride);
-        }
-        {
-            lds_cptr q = base + 4 * PL;  // group 1 of the next pass
-            asm volatile("" : "+v"(q));
-            wino_block<TM, NIP, NIP, (IP < 3), (IP < 3), (IP < 3)>(acc, a[3], vb[1], vb[0], d, q, a[2], u_rsrc,
-                                                                   ubase + (IP * kSteps + s0 + 6) * (64 * 16), u_lane, kUStride);
-        }
-    }
-    // fold this transform row into the 2x2 outputs: Y[a][b] += At[a][i'] * sum_j' At[b][j'] M[i'][j']
-    constexpr float c0 = (IP < 3) ? 1.0f : 0.0f;                       // At[0][i'] = 1 1 1 0
-    constexpr float c1 = (IP == 0) ? 0.0f : (IP == 1) ? 1.0f : -1.0f;  // At[1][i'] = 0 1 -1 -1
-#pragma unroll
-    for (int m = 0; m < TM; ++m)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const f32x4 yb0 = acc[m][nt][0] + acc[m][nt][1] + acc[m][nt][2];
-            const f32x4 yb1 = acc[m][nt][1] - acc[m][nt][2] - acc[m][nt][3];
-            // Y is first written here: rows 0, 1 by pass 0, rows 2, 3 by pass 1 (no clearing, no add)
-            if (IP == 0) {
-                Y[m][nt][0] = yb0;
-                Y[m][nt][1] = yb1;
-            } else if (c0 != 0.0f) {
-                Y[m][nt][0] += yb0;
-                Y[m][nt][1] += yb1;
-            }
-            if (IP == 1) {
-                Y[m][nt][2] = yb0;
-                Y[m][nt][3] = yb1;
-            } else if (c1 < 0.0f) {
-                Y[m][nt][2] -= yb0;
-                Y[m][nt][3] -= yb1;
-            }
-        }
-    // Materialise Y HERE.  Without this the optimiser sinks the fold to Y's final use and keeps the
-    // accumulators of all four passes alive at once (register demand grew by one set per pass).
-#pragma unroll
-    for (int m = 0; m < TM; ++m)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int o = 0; o < (IP == 0 ? 2 : 4); ++o) asm volatile("" : "+v"(Y[m][nt][o]));
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// Wave geometry of the Winograd path: lane -> tile (column tx = lane & 7, row selector ty =
-// (lane >> 3) & 1); board half h: the wave's N-tile nt covers tile rows 2h + nt + 4*ty.
-__device__ __forceinline__ int wino_row(int h, int nt, int lane, int a) {
-    return 2 * (2 * h + nt + 4 * ((lane >> 3) & 1)) + a;  // board row of output (a) of the lane's tile
-}
-
-// Y[m][nt][a*2+b] = conv output (no bias) of output-channel tile tile0+m at board rows
-// wino_row(h, nt, lane, a), columns 2*(lane & 7) + b, for the lane's 4 channels.
-// The first three U groups of a convolution, fetched EARLY (before the barrier that publishes the
-// layer's input planes): the weight stream does not depend on the activations.
-template <int CIN, int TM>
-__device__ __forceinline__ void wino_preload_u(const f32x4 *__restrict__ up, int tile0, int lane, f32x4 (&a)[4][TM]) {
-    constexpr int kT = CIN, kUStride = kT * 64 * 16;  // kT = 4 * (CIN / 4)
-    const __amdgpu_buffer_rsrc_t u_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(up), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int m = 0; m < TM; ++m)
-            a[g][m] = load_u(u_rsrc, lane * 16, tile0 * kT * 64 * 16 + m * kUStride + g * (64 * 16));
-}
-
-template <int PL, int CIN, int TM>
-__device__ __forceinline__ void wino_conv(const float *__restrict__ in, const f32x4 *__restrict__ up, int tile0,
-                                          int h, int lane, f32x4 (&a)[4][TM], f32x4 (&Y)[TM][2][4]) {
-    constexpr int kSteps = CIN / 4, kT = 4 * kSteps;
-    const int kq = lane >> 4, ty = (lane >> 3) & 1, tx = lane & 7;
-    // top-left of the 4x4 patch of N-tile 0 in halo coordinates: row 2*(2h + 4ty), column 2tx
-    const lds_cptr base = (lds_cptr)(in + kq * PL + (4 * h + 8 * ty) * kRowW + 2 * tx);
-    // U fragments: uniform stream base + the lane's 16 bytes (scalar base + 32-bit lane offset addressing)
-    const __amdgpu_buffer_rsrc_t u_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4 *>(up), 0, 0x7fffffff, 0x00020000);
-    const int ubase = tile0 * kT * 64 * 16;  // byte offset of the wave's first tile stream
-    const int u_lane = lane * 16;
-    float d[2][2][4], vb[2][2][4], t[2][4];
-    // pipeline prologue (`a` already holds the U fragments of groups 0..2: wino_preload_u): group 0 transformed, patch rows of group 1 in flight
-#pragma unroll
-    for (int o = 0; o < 8; ++o) wino_ld_op<0>(d, base, o);
-#pragma unroll
-    for (int o = 0; o < 16; ++o) wino_xf_op<0>(d, t, vb[0], o);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int o = 0; o < 8; ++o) wino_ld_op<0>(d, base + 4 * PL, o);
-    __builtin_amdgcn_sched_barrier(0);
-    wino_pass<PL, CIN, TM, 0>(base, u_rsrc, ubase, u_lane, a, d, vb, Y);
-    wino_pass<PL, CIN, TM, 1>(base, u_rsrc, ubase, u_lane, a, d, vb, Y);
-    wino_pass<PL, CIN, TM, 2>(base, u_rsrc, ubase, u_lane, a, d, vb, Y);
-    wino_pass<PL, CIN, TM, 3>(base, u_rsrc, ubase, u_lane, a, d, vb, Y);
-}
-
-// Sum `vals` over the 4 lanes {n, n+16, n+32, n+48} as a reduce-scatter with the gfx950 lane-swap
-// instructions (no LDS traffic): afterwards every lane holds 12 of the 48 sums,
-// out[i] = sum over the 4 lanes of vals[(q & 1) * 24 + (q >> 1) * 12 + i], q = lane >> 4.
-__device__ __forceinline__ void reduce_scatter_48(const float (&vals)[48], float (&out)[12]) {
-    float r1[24];
-#pragma unroll
-    for (int i = 0; i < 24; ++i) {
-        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(vals[i]), __float_as_uint(vals[24 + i]),
-                                                         false, false);
-        r1[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    }
-#pragma unroll
-    for (int i = 0; i < 12; ++i) {
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(r1[i]), __float_as_uint(r1[12 + i]),
-                                                         false, false);
-        out[i] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-    }
-}
-
-// Winograd trunk: CG channel groups x 2 board halves = 2*CG waves; wave w = CG*h + cg owns output
-// channels [cg*128/CG, (cg+1)*128/CG) of conv3 (64/CG of conv2) and the board half h.
-// CG = 4: 8 waves, two per SIMD -- while one wave transforms / loads, its partner issues MFMAs.
-// CG = 2: 4 waves, one per SIMD with the whole register file (more MFMAs per transformed fragment,
-// but nothing fills the matrix pipe during the wave's own transform / load block).
-template <int CG>
-__global__ __launch_bounds__(128 * CG) void k_trunk_wino(NetDev nd, const float *__restrict__ obs,
-                                                         float *__restrict__ feat, int n_boards) {
-    constexpr int PL = kPlaneWino;
-    constexpr int kLdsFloats = kPlanes * PL;
-    constexpr int kThreads = 128 * CG;
-    constexpr int TM2 = 4 / CG, TM3 = 8 / CG;
-    constexpr int kPartialFloats = CG * 6 * 256;
-    __shared__ __attribute__((aligned(16))) float lds[kLdsFloats + kPartialFloats];  // 155.6 KiB at CG = 4
-    float *in0 = lds;
-    float *c1 = in0 + kPlanesIn * PL;
-    float *c2 = c1 + kPlanesC1 * PL;
-    float *partial = c2 + kPlanesC2 * PL;  // [cg][o][y][x] head partial sums; outside the zero-haloed planes
-    const int tid0 = threadIdx.x;
-    const int BH = nd.BH, BW = nd.BW, S = nd.S;
-    // Persistent workgroup: the halo / padding cells are zeroed ONCE (stores below are masked to the
-    // board, so they stay zero), every interior cell is rewritten for each board.
-    {
-        f32x4 *z = reinterpret_cast<f32x4 *>(lds);
-        for (int i = tid0; i < kLdsFloats / 4; i += kThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    // Observation planes of a board: fetched into registers one board AHEAD (right after conv1 has
-    // consumed the current ones), written into the input planes after conv2 -- the global-memory
-    // latency hides under conv2 and a board starts with its input already staged.
-    constexpr int kObsPer = (4 * RZ_MAX_BOARD_SIZE * RZ_MAX_BOARD_SIZE + kThreads - 1) / kThreads;
-    float ob[kObsPer];
-    auto load_obs = [&](int board, int tid) {
-        const float *src = obs + (size_t)board * 4 * S;
-#pragma unroll
-        for (int k = 0; k < kObsPer; ++k) {
-            const int i = tid + k * kThreads;
-            ob[k] = i < 4 * S ? src[i] : 0.0f;
-        }
-    };
-    // element tid + k*kThreads of a board's observation planes / head features -> where it lives in LDS /
-    // in the feature row: the same for every board, so the integer divisions are done once per thread
-    int obs_off[kObsPer];
-#pragma unroll
-    for (int k = 0; k < kObsPer; ++k) {
-        const int i = tid0 + k * kThreads;
-        const int c = i / S, r = i - c * S, y = r / BW, x = r - y * BW;
-        obs_off[k] = i < 4 * S ? c * PL + (y + 1) * kRowW + (x + 1) : -1;
-    }
-    constexpr int kFeatPer = (6 * RZ_MAX_BOARD_SIZE * RZ_MAX_BOARD_SIZE + kThreads - 1) / kThreads;
-    int feat_src[kFeatPer], feat_dst[kFeatPer];
-    float feat_bias[kFeatPer];
-#pragma unroll
-    for (int k = 0; k < kFeatPer; ++k) {
-        const int i = tid0 + k * kThreads;
-        const int o = i / S, r = i - o * S, y = r / BW, x = r - y * BW;
-        feat_src[k] = (o * 16 + y) * 16 + x;
-        feat_dst[k] = i < 6 * S ? (i < 4 * S ? i : i - 4 * S + nd.feat_val_off) : -1;
-        feat_bias[k] = i < 6 * S ? nd.bh[o] : 0.0f;
-    }
-    auto store_obs = [&](int) {
-#pragma unroll
-        for (int k = 0; k < kObsPer; ++k)
-            if (obs_off[k] >= 0) in0[obs_off[k]] = ob[k];
-    };
-    __syncthreads();  // the zero fill is complete before the staging writes
-    if ((int)blockIdx.x < n_boards) {
-        load_obs(blockIdx.x, tid0);
-        store_obs(tid0);
-    }
-    __syncthreads();  // the first board's input planes are staged
-    // Barriers per board: after conv1, after conv2 (which also publishes the NEXT board's input planes) and
-    // after conv3; none at the top of the loop -- every buffer a board writes was last read before one of the
-    // previous board's barriers.
-    for (int board = blockIdx.x; board < n_boards; board += gridDim.x) {
-    // The thread id is laundered per board so that no lane-dependent address is hoisted out of the
-    // board loop and kept live across it (that costs ~50 spilled VGPRs).
-    int tid = tid0;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cg = wave % CG, h = wave / CG;
-    const int next_board = board + (int)gridDim.x;
-    f32x4 a2[4][TM2];
-    wino_preload_u<32, TM2>(nd.u2, TM2 * cg, lane, a2);  // lands while conv1 runs
-    {   // conv1: 4 -> 32 direct (1 % of the work): 2 tiles x (2 or 4) row groups over all waves
-        constexpr int kRowsPer = (CG == 4) ? 4 : 8;
-        const int tile = cg & 1;
-        const int row0 = (CG == 4) ? 4 * (2 * h + (cg >> 1)) : 8 * h;
-        if (row0 < BH) {
-            f32x4 acc[1][8];
-            zero_acc<1>(acc);
-            if (kRowsPer == 4) conv_accumulate<PL, 4, 1, 4>(in0, nd.w1, tile, row0, lane, acc);
-            else conv_rows<PL, 4, 1>(in0, nd.w1, tile, row0, (BH - row0 == 7) ? 7 : 8, lane, acc);
-            store_relu<PL, 1>(c1, nd.b1, tile, row0, lane, BH, BW, acc, kRowsPer);
-        }
-    }
-    __syncthreads();
-    if (next_board < n_boards) load_obs(next_board, tid);
-    const int q = lane >> 4, tx = lane & 7;
-    f32x4 a3[4][TM3];
-    {   // conv2: 32 -> 64
-        f32x4 Y[TM2][2][4];
-        wino_conv<PL, 32, TM2>(c1, nd.u2, TM2 * cg, h, lane, a2, Y);
-        wino_preload_u<64, TM3>(nd.u3, TM3 * cg, lane, a3);  // lands under the store below and the barrier
-#pragma unroll
-        for (int m = 0; m < TM2; ++m) {
-            const int c0 = (TM2 * cg + m) * 16 + 4 * q;
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b2 + c0);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int ab = 0; ab < 4; ++ab) {
-                    const int y = wino_row(h, nt, lane, ab >> 1), x = 2 * tx + (ab & 1);
-                    if (y < BH && x < BW) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            c2[(c0 + j) * PL + (y + 1) * kRowW + (x + 1)] = fmaxf(Y[m][nt][ab][j] + bv[j], 0.0f);
-                    }
-                }
-        }
-    }
-    if (next_board < n_boards) store_obs(tid);  // conv1 of this board is done with the input planes
-    __syncthreads();
-    {   // conv3: 64 -> 128; the ReLU'd output goes straight from the registers into the two 1x1
-        // head convolutions
-        float vals[48];  // index t*6 + o, t = nt*4 + a*2 + b
-#pragma unroll
-        for (int i = 0; i < 48; ++i) vals[i] = 0.0f;
-        {
-            f32x4 Y[TM3][2][4];
-            wino_conv<PL, 64, TM3>(c2, nd.u3, TM3 * cg, h, lane, a3, Y);
-#pragma unroll
-            for (int m = 0; m < TM3; ++m) {
-                const int c0 = (TM3 * cg + m) * 16 + 4 * q;
-                const f32x4 bv = *reinterpret_cast<const f32x4 *>(nd.b3 + c0);
-                f32x4 wv[6];
-#pragma unroll
-                for (int o = 0; o < 6; ++o) wv[o] = *reinterpret_cast<const f32x4 *>(nd.wh + o * 128 + c0);
-#pragma unroll
-                for (int t = 0; t < 8; ++t)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float hv = fmaxf(Y[m][t >> 2][t & 3][j] + bv[j], 0.0f);
-#pragma unroll
-                        for (int o = 0; o < 6; ++o) vals[t * 6 + o] = fmaf(wv[o][j], hv, vals[t * 6 + o]);
-                    }
-            }
-        }
-        float sums[12];
-        reduce_scatter_48(vals, sums);
-        const int off = (q & 1) * 24 + (q >> 1) * 12;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const int vi = off + i, t = vi / 6, o = vi - 6 * t;
-            const int y = wino_row(h, t >> 2, lane, (t >> 1) & 1), x = 2 * tx + (t & 1);
-            partial[((cg * 6 + o) * 16 + y) * 16 + x] = sums[i];
-        }
-    }
-    __syncthreads();
-    {
-        float *dst = feat + (size_t)board * nd.feat_ld;
-#pragma unroll
-        for (int k = 0; k < kFeatPer; ++k) {
-            if (feat_dst[k] < 0) continue;
-            float v = feat_bias[k];
-#pragma unroll
-            for (int g = 0; g < CG; ++g) v += partial[g * 6 * 256 + feat_src[k]];
-            dst[feat_dst[k]] = fmaxf(v, 0.0f);
-        }
-    }
-    }  // boards
 }
 
 // =====================================================================================================
@@ -1110,9 +668,12 @@ __global__ __launch_bounds__(64 * W) void k_trunk_wino_f4(NetDev nd, const float
 // significant bits of x and the dropped lo*lo term is below 2^-22 of the product, so the result is within a
 // few 1e-7 (relative) of the f32 kernels -- the level of their own accumulation rounding (measured in
 // tests/test_gpu_parity.py; the tolerance of the path is 1e-4).  Scales keep the lo halves out of f16's
-// subnormal range: activations are stored times kActScale = 16 (exact range up to 4094, an overflow raises
-// RZ_NET_FLAG_F16_RANGE), the weights of a layer times the power of two that brings their largest magnitude
-// into [2^13, 2^14); the accumulator is rescaled (exactly) in the epilogue.
+// subnormal range: the activations of a layer are stored times a power of two <= 16 that rz_net_load derives from a
+// bound on that layer's activations (bias + positive weights x input bounds, observation planes in [0, 1]), so a
+// network of ANY weight scale stays inside the f16 range on the 0 / 1 planes of the MCTS leaves -- no fallback is
+// needed for trained weights (inputs beyond [0, 1] through rz_net_trunk / rz_net_forward can still overflow: that
+// raises RZ_NET_FLAG_F16_RANGE); the weights of a layer are stored times the power of two that brings their
+// largest magnitude into [2^13, 2^14); the accumulator is rescaled (exactly) in the epilogue.
 //   * LDS: conv1's and conv2's outputs as [piece][18 rows][18 cols][channels + 8] f16, channels innermost, so
 //     the B fragment of a lane (8 consecutive input channels of one position) is ONE ds_read_b128; position
 //     strides of 80 / 144 bytes spread the 8 lanes of an LDS cycle over all 64 banks.  147.4 KB + 3.5 KB of
@@ -1133,7 +694,8 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef const __attribute__((address_space(3))) f16x8 *lds_frag;
 
-constexpr float kActScale = 16.0f;
+constexpr float kObsScale = 16.0f;  // observation planes (0 / 1) are stored times 16
+constexpr float kMaxActScale = 16.0f, kF16Room = 60000.0f;  // activation scales: powers of two <= 16 that keep bound * scale < 60000
 constexpr int kGridPos = 18 * 18;
 template <int CIN> struct Geo {
     static constexpr int pos_bytes = (CIN + 8) * 2;          // 80 / 144
@@ -1290,7 +852,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
 #pragma unroll
         for (int k = 0; k < kObsPer; ++k)
             if (obs_off[k] >= 0) {
-                const float z = ob[k] * sp::kActScale;
+                const float z = ob[k] * sp::kObsScale;
                 const _Float16 hi = (_Float16)z;
                 zmax = fmaxf(zmax, fabsf(z));
                 *reinterpret_cast<_Float16 *>(in0 + obs_off[k]) = hi;
@@ -1302,6 +864,10 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     // the 6 head biases too: a global load in the epilogue would sit between the feature stores, and its
     // s_waitcnt vmcnt(0) also waits for the stores before it -- six store round trips per board
     if (tid0 < 8) hw[128 * 7 + tid0] = tid0 < 6 ? nd.bh[tid0] : 0.0f;
+    // the rescaling factors and the activation scales of the layers (powers of two chosen by rz_net_load from
+    // bounds on the activations) once per workgroup: a load placed behind a layer's MFMA loop is exposed in full
+    const float k1 = nd.s_inv[2], k2 = nd.s_inv[0], k3 = nd.s_inv[1];
+    const float act1 = nd.s_inv[5], act2 = nd.s_inv[6], act3 = nd.s_inv[7];
     // conv1's weights (3 kernel rows x hi / lo, 6 KB per workgroup) and biases stay in registers for all boards
     sp::f16x8 a1[3][2];
     f32x4 bias1[4];
@@ -1312,10 +878,8 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
 #pragma unroll
             for (int p_ = 0; p_ < 2; ++p_) a1[ky][p_] = __builtin_bit_cast(sp::f16x8, nd.s1[(ky * 2 + p_) * 64 + lane0]);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bias1[g] = *reinterpret_cast<const f32x4 *>(nd.b1 + 8 * g + 4 * (lane0 >> 5)) * sp::kActScale;
+        for (int g = 0; g < 4; ++g) bias1[g] = *reinterpret_cast<const f32x4 *>(nd.b1 + 8 * g + 4 * (lane0 >> 5)) * act1;
     }
-    // the three rescaling factors once per workgroup (a load placed behind a layer's MFMA loop is exposed in full)
-    const float k1 = nd.s_inv[2], k2 = nd.s_inv[0] * sp::kActScale, k3 = nd.s_inv[1];
     if ((int)blockIdx.x < n_boards) {
         load_obs(blockIdx.x, tid0);
         store_obs(tid0);
@@ -1393,7 +957,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bias2[m][g] = *reinterpret_cast<const f32x4 *>(nd.b2 + m * 32 + 8 * g + 4 * h) * sp::kActScale;
+            for (int g = 0; g < 4; ++g) bias2[m][g] = *reinterpret_cast<const f32x4 *>(nd.b2 + m * 32 + 8 * g + 4 * h) * act2;
         if (TN == 2 || busy) sp::conv<32, 2, TN>(c1, nd.s2, row0, ry, x, lane, a2, acc);
         sp::preload_w<64, 4>(a3, nd.s3, lane);
 #pragma unroll
@@ -1488,7 +1052,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
                 if (dst16) {
                     const int k = (o < 4 ? o : o - 4) * S + y * BW + x;
                     const int step = (o < 4 ? 0 : nd.groups_act) + (k >> 4);
-                    const float z = v * sp::kActScale;
+                    const float z = v * act3;
                     const _Float16 zh = (_Float16)z;
                     zmax = fmaxf(zmax, z);
                     _Float16 *q = dst16 + (size_t)step * 1024 + (k & 15);
@@ -1901,6 +1465,8 @@ __global__ __launch_bounds__(64) void k_heads_finish(NetDev nd, const float *__r
 struct rz_net {
     int board_size = 0, device = 0;
     bool loaded = false;
+    bool split_ok = true;        // rz_net_load found finite activation bounds: the split-f16 trunk cannot overflow
+    float range_info[8] = {0};   // rz_net_range_info
     int algo = RZ_NET_SPLIT_F16;
     int n_cus = 256;
     int max_wgs = 0;  // rz_net_set_max_workgroups: 0 = one persistent trunk workgroup per CU
@@ -1965,32 +1531,6 @@ std::vector<f32x4> pack_conv(const float *w, int cout, int cin) {
                     }
                     out[(((size_t)t * steps + s) * 3 + tg) * 64 + lane] = v;
                 }
-    return out;
-}
-
-// U = G g G^T of every (cout, cin) 3x3 kernel, packed [tile][i'][cin_step][lane] x 4 (j'): lane =
-// kq*16 + m holds U[16*tile + m][4*step + kq][i'][0..3].  Computed in fp64, rounded once.
-std::vector<f32x4> pack_wino(const float *w, int cout, int cin) {
-    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
-    const int tiles = cout / 16, steps = cin / 4;
-    std::vector<f32x4> out((size_t)tiles * 4 * steps * 64);
-    for (int t = 0; t < tiles; ++t)
-        for (int s = 0; s < steps; ++s)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int m = lane & 15, kq = lane >> 4;
-                const float *g = w + ((size_t)(16 * t + m) * cin + (4 * s + kq)) * 9;
-                double tmp[4][3], U[4][4];
-                for (int i = 0; i < 4; ++i)
-                    for (int c = 0; c < 3; ++c)
-                        tmp[i][c] = G[i][0] * g[0 * 3 + c] + G[i][1] * g[1 * 3 + c] + G[i][2] * g[2 * 3 + c];
-                for (int i = 0; i < 4; ++i)
-                    for (int j = 0; j < 4; ++j) U[i][j] = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
-                for (int ip = 0; ip < 4; ++ip) {
-                    f32x4 v;
-                    for (int jp = 0; jp < 4; ++jp) v[jp] = (float)U[ip][jp];
-                    out[(((size_t)t * 4 + ip) * steps + s) * 64 + lane] = v;
-                }
-            }
     return out;
 }
 
@@ -2219,8 +1759,6 @@ int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params) {
     up_vec4(pack_conv(h_params[2], 64, 32), &D.w2);
     up_f(h_params[3], 64, &D.b2);
     up_vec4(pack_conv(h_params[4], 128, 64), &D.w3);
-    up_vec4(pack_wino(h_params[2], 64, 32), &D.u2);
-    up_vec4(pack_wino(h_params[4], 128, 64), &D.u3);
     up_vec4(pack_wino_f4(h_params[2], 64, 32), &D.u2f);
     up_vec4(pack_wino_f4(h_params[4], 128, 64), &D.u3f);
     {
@@ -2232,8 +1770,47 @@ int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params) {
         float sfa = 1.0f, sfv = 1.0f;
         up_vec4(pack_split_fc(h_params[8], D.A, 4 * S, D.Npad / 32, D.groups_act, &sfa), &D.fs_act);
         up_vec4(pack_split_fc(h_params[12], 64, 2 * S, 2, D.groups_val, &sfv), &D.fs_val);
-        up_f(std::vector<float>{1.0f / (sp::kActScale * sw2), 1.0f / (sp::kActScale * sw3), 1.0f / sw1,
-                                1.0f / (sp::kActScale * sfa), 1.0f / (sp::kActScale * sfv)}.data(), 5, &D.s_inv);
+        // Activation bounds for observation planes in [0, 1] (the MCTS leaves: 0 / 1): a ReLU output is at most its
+        // bias plus the positive weights times the bounds of their inputs.  Each layer's f16 pieces are stored times
+        // the largest power of two <= 16 that keeps bound * scale below 60000, so NO activation of such an input can
+        // leave the f16 range (the pieces of a value of size z carry an absolute error of max(2^-22 z, 2^-25): a
+        // bound 1000x above the real activations still leaves the error below f32 rounding).  Without finite
+        // bounds (inf / nan weights) the net runs on the exact-f32 direct trunk instead.
+        double b1v[32], b2v[64], b3v[128], bfv[6];
+        auto layer_bound = [](const float *w, const float *bias, int cout, int cin, int taps, const double *in, double *out) {
+            double top = 0.0;
+            for (int c = 0; c < cout; ++c) {
+                double acc = bias[c] > 0.0f ? (double)bias[c] : 0.0;
+                for (int i = 0; i < cin; ++i)
+                    for (int t = 0; t < taps; ++t) {
+                        const double wv = w[((size_t)c * cin + i) * taps + t];
+                        if (wv > 0.0) acc += wv * (in ? in[i] : 1.0);
+                        else if (!(wv <= 0.0)) acc = INFINITY;  // nan
+                    }
+                out[c] = acc;
+                top = std::fmax(top, acc);
+                if (!(acc >= 0.0)) top = INFINITY;
+            }
+            return top;
+        };
+        const double t1 = layer_bound(h_params[0], h_params[1], 32, 4, 9, nullptr, b1v);
+        const double t2 = layer_bound(h_params[2], h_params[3], 64, 32, 9, b1v, b2v);
+        (void)layer_bound(h_params[4], h_params[5], 128, 64, 9, b2v, b3v);
+        double tf = layer_bound(h_params[6], h_params[7], 4, 128, 1, b3v, bfv);
+        tf = std::fmax(tf, layer_bound(h_params[10], h_params[11], 2, 128, 1, b3v, bfv + 4));
+        auto act_scale = [](double bound) {
+            if (!(bound * sp::kMaxActScale >= sp::kF16Room)) return sp::kMaxActScale;  // also bound == 0
+            int e = 0;
+            (void)std::frexp(sp::kF16Room / bound, &e);   // kF16Room / bound = f * 2^e, f in [0.5, 1)
+            return std::ldexp(1.0f, e - 1);                // the largest power of two <= kF16Room / bound
+        };
+        net->split_ok = std::isfinite(t1) && std::isfinite(t2) && std::isfinite(tf) && t1 < 1e30 && t2 < 1e30 && tf < 1e30;
+        const float a1 = net->split_ok ? act_scale(t1) : sp::kMaxActScale, a2 = net->split_ok ? act_scale(t2) : sp::kMaxActScale,
+                    a3 = net->split_ok ? act_scale(tf) : sp::kMaxActScale;
+        const float info[8] = {(float)t1, (float)t2, (float)tf, a1, a2, a3, net->split_ok ? 1.0f : 0.0f, 0.0f};
+        memcpy(net->range_info, info, sizeof(info));
+        up_f(std::vector<float>{a2 / (a1 * sw2), 1.0f / (a2 * sw3), a1 / (sp::kObsScale * sw1),
+                                1.0f / (a3 * sfa), 1.0f / (a3 * sfv), a1, a2, a3}.data(), 8, &D.s_inv);
     }
     up_f(h_params[5], 128, &D.b3);
     {
@@ -2323,7 +1900,9 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
     const bool internal = d_feat == net->d_feat;
     // the split-f16 trunk writes what the FC GEMM behind it reads: the f16 pieces, and the f32 features only for a
     // caller's buffer or when the f32 GEMM is forced
-    const bool split = net->algo == RZ_NET_SPLIT_F16;
+    // a net whose weights give no finite activation bound (rz_net_load) never runs on the f16 pipe
+    const int algo = (net->algo == RZ_NET_SPLIT_F16 && !net->split_ok) ? RZ_NET_DIRECT : net->algo;
+    const bool split = algo == RZ_NET_SPLIT_F16;
     const bool want_f32 = !split || !internal || net->heads_algo == RZ_NET_HEADS_F32;
     if (internal) {
         net->feat16_valid = split;
@@ -2334,15 +1913,9 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
     // Winograd kernels are persistent: one workgroup per CU (LDS bound) loops over its boards
     const int wg_cap = net->max_wgs > 0 ? net->max_wgs : net->n_cus;
     const dim3 pgrid((unsigned)(n_boards < wg_cap ? n_boards : wg_cap));
-    if (net->algo == RZ_NET_WINOGRAD)
-        k_trunk_wino<4><<<pgrid, dim3(512), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
-    else if (net->algo == RZ_NET_WINOGRAD_4W)
-        k_trunk_wino<2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
-    else if (net->algo == RZ_NET_WINOGRAD_F4)
+    if (algo == RZ_NET_WINOGRAD_F4)
         k_trunk_wino_f4<4><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
-    else if (net->algo == RZ_NET_WINOGRAD_F4_8W)
-        k_trunk_wino_f4<8><<<pgrid, dim3(512), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
-    else if (net->algo == RZ_NET_SPLIT_F16)
+    else if (algo == RZ_NET_SPLIT_F16)
     {
         _Float16 *f16 = internal ? net->d_feat16 : nullptr;
         float *f32 = want_f32 ? d_feat : nullptr;
@@ -2407,9 +1980,16 @@ int rz_net_trunk(rz_net *net, const float *d_obs, int32_t n_boards, float *d_fea
 
 int rz_net_set_algo(rz_net *net, int32_t algo) {
     if (!net) return net_fail(RZ_ERR_ARG, "net handle is NULL");
-    if (algo < RZ_NET_DIRECT || algo > RZ_NET_SPLIT_F16)
+    if (algo != RZ_NET_DIRECT && algo != RZ_NET_WINOGRAD_F4 && algo != RZ_NET_SPLIT_F16)
         return net_fail(RZ_ERR_ARG, "unknown algorithm");
     net->algo = algo;
+    return RZ_OK;
+}
+
+int rz_net_range_info(rz_net *net, float *h_info8) {
+    if (!net || !h_info8) return net_fail(RZ_ERR_ARG, "NULL argument");
+    if (!net->loaded) return net_fail(RZ_ERR_ARG, "rz_net_load has not been called");
+    memcpy(h_info8, net->range_info, sizeof(net->range_info));
     return RZ_OK;
 }
 

@@ -104,27 +104,34 @@ class HipNet(object):
     def set_algo(self, algo):
         """conv2 / conv3 algorithm: 'split_f16' (default: direct convolution on the f16 matrix pipe, every f32
         operand carried as a hi + lo pair of f16 values, f32 accumulation -- as accurate as 'direct'), or on the
-        f32-input MFMA: 'winograd_f4' (F(4x4,3x3)), 'winograd' / 'winograd4w' (F(2x2,3x3), 8 / 4 waves per
-        board), 'direct' (bit-for-bit a k-ordered fmaf chain)."""
-        code = {'direct': _hip.NET_DIRECT, 'winograd': _hip.NET_WINOGRAD, 'winograd4w': _hip.NET_WINOGRAD_4W,
-                'winograd_f4': _hip.NET_WINOGRAD_F4, 'winograd_f4_8w': _hip.NET_WINOGRAD_F4_8W,
-                'split_f16': _hip.NET_SPLIT_F16}[algo]
+        f32-input MFMA: 'winograd_f4' (F(4x4,3x3)) or 'direct' (bit-for-bit a k-ordered fmaf chain)."""
+        code = {'direct': _hip.NET_DIRECT, 'winograd_f4': _hip.NET_WINOGRAD_F4, 'split_f16': _hip.NET_SPLIT_F16}[algo]
         check(self.lib.rz_net_set_algo(self.handle, code), 'rz_net_set_algo')
         return self
 
+    def range_info(self):
+        """What rz_net_load derived from the weights for the split-f16 trunk: bounds on the activations of conv1 /
+        conv2 / the head features for observation planes in [0, 1], the power-of-two scales their f16 pieces are
+        stored with (bound x scale < 60000: no overflow is possible on MCTS leaves, whatever the weights), and
+        whether the bounds are finite (otherwise 'split_f16' runs the 'direct' kernel for this net)."""
+        out = (ctypes.c_float * 8)()
+        check(self.lib.rz_net_range_info(self.handle, out), 'rz_net_range_info')
+        return {'bounds': (out[0], out[1], out[2]), 'scales': (out[3], out[4], out[5]), 'split_ok': bool(out[6])}
+
     def check_flags(self):
-        """Raise if a kernel reported a condition since the last call (synchronises): 'split_f16' needs every
-        activation of conv1 / conv2 below 65504 / 16."""
+        """Raise if a kernel reported a condition since the last call (synchronises).  The split-f16 trunk cannot
+        overflow on observation planes in [0, 1] (see range_info); an input beyond that range can."""
         flags = ctypes.c_uint32(0)
         check(self.lib.rz_net_error_flags(self.handle, ctypes.byref(flags)), 'rz_net_error_flags')
         if flags.value & _hip.NET_FLAG_F16_RANGE:
-            raise HipError("an activation left the range of the split-f16 trunk (>= 4094): use set_algo('winograd_f4')")
+            raise HipError("an input outside [0, 1] drove an activation out of the range of the split-f16 trunk: "
+                           "use set_algo('direct') for such inputs")
         return self
 
     def set_heads_algo(self, algo):
         """GEMM of the first FC layers: 'f32' (f32-input MFMA), 'split32' / 'split64' (f16 matrix pipe with hi + lo
-        operand pairs after the 'split_f16' trunk, 32 / 64 boards per workgroup), 'auto' (default: 'split64' beside
-        a capped trunk, 'f32' otherwise)."""
+        operand pairs after the 'split_f16' trunk, 32 / 64 boards per workgroup), 'auto' (default after the
+        'split_f16' trunk: 'split64' beside a capped trunk, 'split32' otherwise; 'f32' after the f32 trunks)."""
         code = {'auto': _hip.NET_HEADS_AUTO, 'f32': _hip.NET_HEADS_F32, 'split32': _hip.NET_HEADS_SPLIT_32,
                 'split64': _hip.NET_HEADS_SPLIT_64}[algo]
         check(self.lib.rz_net_set_heads_algo(self.handle, code), 'rz_net_set_heads_algo')
@@ -373,9 +380,12 @@ class MCTSEngine(object):
         return out
 
     def check(self):
-        """Raise if any game overflowed its arena / received an illegal move."""
+        """Raise if any game overflowed its arena / received an illegal move.  Returns the statistics;
+        ``reuse_dropped`` counts kept subtrees that exceeded the carry limit (pool_factor * n_playout expanded
+        nodes) and were replaced by a fresh root -- a counted deviation from the reference's unbounded tree, not
+        an error."""
         st = self.stats()
-        if st.error_flags:
+        if st.error_flags & ~_hip.FLAG_REUSE_DROPPED:
             names = [n for bit, n in _hip.FLAG_NAMES.items() if st.error_flags & bit]
             raise HipError('engine error flags 0x%x (%s), first bad game %d, arena %d/%d slots' %
                            (st.error_flags, ', '.join(names), st.first_bad_game,

@@ -140,6 +140,8 @@ class AlphaZeroMCTS(object):
         eng.simulate(self._evaluator, self.n_playout)
         visits = eng.root_visits()[0]
         eng.check()
+        if isinstance(self._evaluator, HipNetEvaluator):
+            self._evaluator.hip.check_flags()  # root_visits() has synchronised: one 4-byte read
         acts = self._legal
         counts = np.array([int(visits[a]) for a in acts])
         act_probs = softmax(1.0 / temperature * np.log(counts + 1e-10))

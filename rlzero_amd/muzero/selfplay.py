@@ -106,6 +106,8 @@ class MuZeroSelfPlay(object):
         # times per move.  Captured before any search (the capture runs the step on the still empty trees;
         # every search starts by re-initialising its roots).  Weight updates are in place: the graph stays valid.
         self._graph = None
+        self.sim_events = None
+        self.sim_step_label = 'MuZero simulation step (k_mz_select + torch recurrent inference + k_mz_expand_backup, one hipGraph)'
         if use_graph:
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
@@ -154,6 +156,13 @@ class MuZeroSelfPlay(object):
                 record.append(('root', probs.clone(), None if noise is None else noise.clone()))
             for _ in range(self.n_sims):
                 if self._graph is not None and record is None:
+                    if self.sim_events is not None:  # bench.py: HIP events around the step, on the launch stream
+                        a, b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+                        a.record()
+                        self._graph.replay()
+                        b.record()
+                        self.sim_events.append((a, b))
+                        continue
                     self._graph.replay()
                     continue
                 out = self._sim_step()

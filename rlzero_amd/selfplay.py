@@ -179,6 +179,8 @@ class BatchedSelfPlay(object):
         for i, (eng, ev) in enumerate(zip(engines, evaluators)):
             stream = torch.cuda.current_stream(eng.device) if len(engines) == 1 else \
                 torch.cuda.Stream(device=eng.device)
+            # the engine's buffers were initialised on the current stream: order the lane's stream behind it
+            stream.wait_stream(torch.cuda.current_stream(eng.device))
             self.lanes.append(_Lane(eng, ev, stream, offset))
             offset += eng.n_games
         self.eng = engines[0]  # geometry (board size, n_playout) is common to all lanes
@@ -421,11 +423,23 @@ def gather_trajectories(trajs, board_size, n_in_row, dst=0, group=None, game='go
     rank, world = dist.get_rank(group), dist.get_world_size(group)  # a group of one runs the same collectives
     on_gpu = dist.get_backend(group) == 'nccl'
     device = torch.device('cuda', torch.cuda.current_device()) if on_gpu else torch.device('cpu')
-    header, moves, pis = pack_trajectories(trajs, n_cells)
-    sizes = torch.tensor([header.shape[0], moves.shape[0]], dtype=torch.int64, device=device)
+    # Host-side work that can fail locally (packing, buffer allocation) is kept out of the collectives, and the
+    # ranks agree on its success inside them: a rank that failed still takes part in every collective up to the
+    # agreement and then ALL ranks raise, so no peer is left blocked in a gather.
+    local_error = None
+    try:
+        header, moves, pis = pack_trajectories(trajs, n_cells)
+    except Exception as exc:  # noqa: BLE001
+        local_error = exc
+        header, moves, pis = np.zeros((0, 4), np.int64), np.zeros(0, np.int64), np.zeros((0, n_cells))
+    sizes = torch.tensor([header.shape[0], moves.shape[0], 0 if local_error is None else 1], dtype=torch.int64,
+                         device=device)
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
     dist.all_gather(all_sizes, sizes, group=group)
     all_sizes = torch.stack(all_sizes).cpu().numpy()
+    if all_sizes[:, 2].any():
+        raise RuntimeError('gather_trajectories: packing failed on rank(s) %s%s' % (
+            np.nonzero(all_sizes[:, 2])[0].tolist(), '' if local_error is None else ' (here: %r)' % (local_error, )))
     max_games, max_plies = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
 
     def padded(arr, rows, dtype):
@@ -434,11 +448,22 @@ def gather_trajectories(trajs, board_size, n_in_row, dst=0, group=None, game='go
             buf[:arr.shape[0]] = torch.from_numpy(arr).to(device)
         return buf
 
-    sends = (padded(header, max_games, torch.int64), padded(moves, max_plies, torch.int64),
-             padded(pis, max_plies, torch.float64))
+    sends, buckets = None, None
+    try:
+        sends = (padded(header, max_games, torch.int64), padded(moves, max_plies, torch.int64),
+                 padded(pis, max_plies, torch.float64))
+        if rank == dst:
+            buckets = [[torch.zeros_like(buf) for _ in range(world)] for buf in sends]
+    except Exception as exc:  # noqa: BLE001 -- e.g. out of memory for the padded buffers
+        local_error = exc
+    bad = torch.tensor([0 if local_error is None else 1], dtype=torch.int64, device=device)
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+    if int(bad.item()):
+        raise RuntimeError('gather_trajectories: buffer allocation failed on some rank%s' % (
+            '' if local_error is None else ' (here: %r)' % (local_error, )))
     recvs = []
-    for buf in sends:
-        bucket = [torch.zeros_like(buf) for _ in range(world)] if rank == dst else None
+    for i, buf in enumerate(sends):
+        bucket = buckets[i] if rank == dst else None
         dist.gather(buf, gather_list=bucket, dst=dst, group=group)
         recvs.append(bucket)
     if rank != dst:

@@ -18,6 +18,25 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def pytest_collection_modifyitems(config, items):
+    """gpu-marked tests need an MI355X and the built extension: skipped elsewhere, so a plain `pytest` is green on a
+    CPU host (the driver's GPU tier selects them with -m gpu on a GPU box, where they run)."""
+    reason = None
+    try:
+        import torch
+        if not torch.cuda.is_available():
+            reason = 'no GPU in this container (run on the GPU box: pytest -m gpu)'
+    except Exception as exc:  # noqa: BLE001
+        reason = 'torch unavailable: %r' % (exc, )
+    if reason is None and not os.path.exists(os.path.join(REPO, 'rlzero_amd', 'librlzero_hip.so')):
+        reason = 'rlzero_amd/librlzero_hip.so is not built (python -m rlzero_amd._build)'
+    if reason:
+        skip = pytest.mark.skip(reason=reason)
+        for item in items:
+            if 'gpu' in item.keywords:
+                item.add_marker(skip)
+
+
 def load_golden_json(name):
     with gzip.open(os.path.join(GOLDEN, name + '.gz'), 'rb') as f:
         return json.loads(f.read().decode())

@@ -42,7 +42,7 @@ def test_config_struct_layout_matches_header():
     # 8 int32, 2 doubles, 4 int32 -> 64 bytes, doubles 8-aligned at offset 32
     assert ctypes.sizeof(_hip.RzConfig) == 64
     assert _hip.RzConfig.c_puct.offset == 32 and _hip.RzConfig.device.offset == 48
-    assert ctypes.sizeof(_hip.RzStats) == 56
+    assert ctypes.sizeof(_hip.RzStats) == 64
 
 
 def test_product_fails_loudly_without_gpu():

@@ -276,6 +276,82 @@ def test_full_size_known_answer_and_invariants():
     eng.close()
 
 
+def _sum_rule(eng, game):
+    """N(node) = 1 + sum N(children) over every expanded node of the game's tree; returns (#checked, N(root))."""
+    ar = eng.arena(game)
+    stack, checked = [0], 0
+    while stack:
+        slot = stack.pop()
+        fc, nv = int(ar['FC'][slot]), int(ar['NV'][slot])
+        if int(ar['K'][slot]) == 0 or fc < 0:
+            continue
+        kids = ar['N'][fc:fc + nv]
+        assert (kids > 0).all() and int(ar['N'][slot]) == 1 + int(kids.sum())
+        checked += 1
+        stack.extend(range(fc, fc + nv))
+    return checked, int(ar['N'][0])
+
+
+@pytest.mark.parametrize('config', ['C4_gomoku15_800sims_512games', 'C3_connect4_400sims_512games'])
+def test_full_size_batches_of_the_baseline_configs(config):
+    """BASELINE.json configs[3] (its 512-games-per-GPU share) and configs[2] at FULL size through the production path
+    (BatchedSelfPlay.for_network: hand-written net, hipGraphs, Dirichlet noise, tree reuse, slots refilled): the arena
+    sizing at the configured batch is tested, not only benchmarked.  Size-independent properties: N(root) = n_playout
+    after the first move, N(root) = carried + n_playout afterwards, the sum rule on sampled trees, pi from exact
+    visit counts, no overflow flag, no dropped subtree, arena use below capacity."""
+    import torch
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    from rlzero_amd.selfplay import BatchedSelfPlay
+    torch.manual_seed(0)
+    if config.startswith('C4'):
+        net, kw, sims, moves = PolicyValueNet(15).to('cuda:0'), dict(board=15, n_in_row=5), 800, 6
+    else:
+        net = PolicyValueNet(6, 7, 7).to('cuda:0')
+        kw, sims, moves = dict(board=(6, 7), n_in_row=4, game='connect4', net_shape=(6, 7, 7)), 400, 42
+    G = 512
+    sp = BatchedSelfPlay.for_network(net, n_games=G, n_playout=sims, lanes=1, seed=5, **kw)
+    eng = sp.eng
+    sp._start(range(G), range(G))
+    sp._set_active()
+    carried = np.zeros(G, dtype=np.int64)
+    finished, worst_slots, worst_blocks = [], 0, 0
+    for ply in range(moves):
+        running = sp.slot_game >= 0
+        if not running.any():
+            break
+        # what play_move() does, with the roots inspected between the search and the move
+        sp._simulate()
+        rn, _ = eng.root_stats()
+        visits = eng.root_visits()
+        assert (rn[running] == carried[running] + sims).all(), ply
+        assert (visits.sum(axis=1)[running] == rn[running] - 1).all()  # N(root) = 1 + sum over its children
+        for g in np.nonzero(running)[0][:3]:
+            checked, n_root = _sum_rule(eng, int(g))
+            assert n_root == rn[g] and checked >= 1
+        # ... then the move itself, through the production code
+        sp._simulate = lambda: None
+        done = sp.play_move()
+        del sp._simulate
+        st = eng.check()
+        assert st.reuse_dropped == 0
+        worst_slots, worst_blocks = max(worst_slots, st.max_slots_used), max(worst_blocks, st.max_blocks_used)
+        rn2, _ = eng.root_stats()
+        carried = rn2.astype(np.int64)
+        assert (carried[running] <= rn[running] - 1).all()  # the kept child's visits
+        finished.extend(done)
+        if done:
+            sp.retire_finished()
+            carried[sp.slot_game < 0] = 0
+    st = eng.check()
+    assert worst_slots < st.arena_slots and worst_blocks < st.arena_slots // 16
+    for t in finished:
+        assert abs(t.pis.sum(axis=1) - 1.0).max() < 1e-9 and t.winner in (-1, 0, 1)
+    if config.startswith('C3'):
+        assert len(finished) == G  # every Connect4 game ends within 42 plies
+    for lane in sp.lanes:
+        lane.eng.close()
+
+
 # ------------------------------------------------------------------ player / game loop (G3)
 class _Injected(object):
 
@@ -540,7 +616,7 @@ def test_hip_net_vs_golden_and_torch(g4):
     import torch
     from rlzero_amd.engine import HipNet
     from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
-    for B, algo in [(b, a) for b in (3, 6, 9, 15) for a in ('winograd', 'winograd4w', 'winograd_f4', 'winograd_f4_8w', 'direct', 'split_f16')]:
+    for B, algo in [(b, a) for b in (3, 6, 9, 15) for a in ('winograd_f4', 'direct', 'split_f16')]:
         weights = ev.numpy_weights(B, int(g4['B%d_seed' % B]))
         hip = HipNet(B, 'cuda:0', max_boards=16).load_state_dict(weights).set_algo(algo)
         obs = torch.from_numpy(g4['B%d_obs' % B].astype(np.float32)).to('cuda:0')
@@ -598,7 +674,7 @@ def test_trunk_is_deterministic_under_load():
     hip = HipNet(15, 'cuda:0', max_boards=512).load_state_dict(net.state_dict())
     x = (torch.rand((512, 4, 15, 15), device='cuda:0') > 0.5).float()
     ref = hip.set_algo('direct').trunk(x).clone()
-    for algo, caps in (('split_f16', (0, 224)), ('winograd_f4', (0, 224)), ('winograd', (0, ))):
+    for algo, caps in (('split_f16', (0, 224)), ('winograd_f4', (0, 224))):
         hip.set_algo(algo)
         first = None
         side = torch.cuda.Stream()
@@ -651,17 +727,85 @@ def test_split_f16_trunk_is_as_accurate_as_the_f32_trunk_and_flags_its_range():
         assert err['split_f16'] <= 2.0 * err['direct'] + 1e-7, err
         assert err['split_f16'] <= err['winograd_f4'] + 1e-7, err
         hip.close()
-    # out of range: conv1 outputs of ~1e4 (x 16 > 65504)
+    # weights of ANY scale stay in range on 0 / 1 planes: the activation scales follow the bounds rz_net_load derives.
+    # conv1 x 1e5 (activations ~1e5: 16x that is far beyond f16), conv2 x 1e-5 brings the rest back to order 1
     torch.manual_seed(5)
     net = PolicyValueNet(6)
     with torch.no_grad():
         net.conv1.weight.mul_(1e5)
+        net.conv1.bias.mul_(1e5)
+        net.conv2.weight.mul_(1e-5)
     hip = HipNet(6, 'cuda:0', max_boards=8).load_state_dict(net.state_dict()).set_algo('split_f16')
-    hip.trunk((torch.rand((4, 4, 6, 6), device='cuda:0') < 0.5).float())
+    info = hip.range_info()
+    assert info['split_ok'] and info['scales'][0] < 1.0 and info['bounds'][0] * info['scales'][0] < 60000.0
+    assert info['scales'][1] == 16.0 and info['bounds'][0] > 1e4
+    x = (torch.rand((4, 4, 6, 6), device='cuda:0') < 0.5).float()
+    lp, v = hip.forward(x)
+    hip.check_flags()
+    with torch.no_grad():
+        lp64, v64 = net.double()(x.cpu().double())
+    assert float((lp.cpu().double() - lp64).abs().max()) <= 1e-4 and float((v.cpu().double() - v64[:, 0]).abs().max()) <= 1e-4
+    lp_d, v_d = hip.set_algo('direct').forward(x)
+    assert float((lp - lp_d).abs().max()) <= 2e-5  # the exact-f32 kernel is no closer to fp64 than the split one
+    assert float((lp_d.cpu().double() - lp64).abs().max()) <= 1e-4
+    # an input far outside [0, 1] is what can still overflow: reported, not silently wrong
+    hip.set_algo('split_f16').trunk(1e6 * x)
     with pytest.raises(HipError):
         hip.check_flags()
     hip.check_flags()  # the flag is cleared by the report
     hip.close()
+    # weights without finite bounds: the net runs on the exact-f32 direct kernel (no f16 piece is ever formed)
+    net = PolicyValueNet(6)
+    with torch.no_grad():
+        net.conv2.weight[3, 2, 1, 1] = float('inf')
+    hip = HipNet(6, 'cuda:0', max_boards=8).load_state_dict(net.state_dict())
+    assert not hip.range_info()['split_ok']
+    a = hip.trunk(x).clone()
+    b = hip.set_algo('direct').trunk(x)
+    assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
+    hip.check_flags()
+    hip.close()
+
+
+def test_scaled_up_weights_through_the_reference_api():
+    """A net whose conv1 activations are far outside the f16 range (weights x 1e5, the next layer x 1e-5) played
+    through AlphaZeroPlayer / GameControl on the default split-f16 trunk: no exception, and the priors / value
+    that reach the tree agree with the torch module to the 1e-4 of the contract (alphazero_agent.py:31-46)."""
+    import torch
+    from rlzero_amd.engine import HipNetEvaluator
+    from rlzero_amd.games import GameControl, GomokuEnv
+    from rlzero_amd.games.gomoku.alphazero_agent import AlphaZeroAgent
+    from rlzero_amd.mcts import AlphaZeroPlayer
+    torch.manual_seed(2)
+    np.random.seed(2)
+    agent = AlphaZeroAgent(6, device='cuda:0')
+    with torch.no_grad():
+        agent.policy_value_net.conv1.weight.mul_(1e5)
+        agent.policy_value_net.conv1.bias.mul_(1e5)
+        agent.policy_value_net.conv2.weight.mul_(1e-5)
+    player = AlphaZeroPlayer(agent.policy_value_fn, n_playout=60, c_puct=5, is_selfplay=True)
+    env = GomokuEnv(6, 4)
+    winner, data = GameControl(env).start_self_play(player, temperature=1.0)
+    assert isinstance(player.mcts._evaluator, HipNetEvaluator) and winner in (-1, 0, 1)
+    assert player.mcts._evaluator.hip.range_info()['scales'][0] < 1.0
+    # one expansion of a mid-game root: stored priors and backed-up value vs the torch module in fp64
+    env.reset()
+    for m in (14, 15, 20):
+        env.step(m)
+    mcts = player.mcts
+    mcts.add_noise = False
+    mcts._engine.close()
+    mcts._engine = None
+    mcts.n_playout = 1
+    mcts.simulate(env, 1.0)
+    pri = mcts._engine.root_priors()[0]
+    _, rw = mcts._engine.root_stats()
+    with torch.no_grad():
+        lp64, v64 = agent.policy_value_net.double()(torch.from_numpy(env.current_state()[None]).double().to('cuda:0'))
+    legal = env.leagel_actions()
+    assert np.max(np.abs(np.log(pri[legal].astype(np.float64)) - lp64.cpu().numpy()[0][legal])) <= 1e-4
+    assert abs(rw[0] + float(v64.item())) <= 1e-4
+    mcts._engine.close()
 
 
 def test_split_f16_heads_gemm_equals_the_f32_gemm():
@@ -741,6 +885,113 @@ def test_search_with_hip_net_equals_search_with_its_values():
     s.simulate(RefGomoku(6, 4), 1.0)
     assert _hex_tree(eng.tree_dump(0)) == _hex_tree(tree_dump(s.root))
     eng.close()
+
+
+class _UnfusedHipNet(object):
+    """The same HipNet through the un-fused route: rz_net_forward (trunk + GEMM + k_heads_finish) writes log-probabilities
+    and values, rz_expand_backup / rz_tree_step take exp() of them."""
+    needs_obs = True
+
+    def __init__(self, hip):
+        self.hip = hip
+
+    def __call__(self, eng):
+        return self.hip.forward(eng.obs, eng.logp, eng.value)
+
+
+def test_fused_route_priors_vs_golden_and_unfused(g4):
+    """The production route (k_trunk_split -> k_heads_split -> k_tree_step_raw finishing log_softmax / tanh itself):
+    the priors it stores and the value it backs up for G4's position (after move 0), against the reference's
+    policy_value_fn output (alphazero_agent.py:41-45; 1e-4) and bit-for-bit against the un-fused rz_net_heads route;
+    all trunk algorithms, all board sizes; and on a batch of random mid-game positions the two routes agree bit-for-bit."""
+    import torch
+    from rlzero_amd.engine import HipNetEvaluator
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    for B in (3, 6, 9, 15):
+        n = 3 if B == 3 else (4 if B == 6 else 5)
+        net = PolicyValueNet(B)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in ev.numpy_weights(B, int(g4['B%d_seed' % B])).items()})
+        evaluator = HipNetEvaluator(net, B, 'cuda:0', max_boards=16)
+        acts = [int(a) for a in g4['B%d_pvf_acts' % B]]
+        want_p, want_v = g4['B%d_pvf_probs' % B].astype(np.float64), float(g4['B%d_pvf_value' % B])
+        rs = np.random.RandomState(B)
+        envs = [RefGomoku.from_moves(B, n, [0])]
+        while len(envs) < 16:  # random non-terminal mid-game positions
+            e = RefGomoku(B, n)
+            for m in rs.permutation(B * B)[:rs.randint(0, B * B - 1)]:
+                e.step(int(m))
+                if e.game_end_winner()[0]:
+                    break
+            if not e.game_end_winner()[0]:
+                envs.append(e)
+        for algo in ('split_f16', 'winograd_f4', 'direct'):
+            evaluator.hip.set_algo(algo)
+            got = {}
+            for route, evl in (('fused', evaluator), ('unfused', _UnfusedHipNet(evaluator.hip))):
+                eng = _engine(B, n, n_games=len(envs), n_playout=4)
+                _set_roots(eng, envs, reset_trees=True)
+                eng.sim_chunk(evl, 1)  # the first simulation expands every root
+                pri = eng.root_priors()
+                rn, rw = eng.root_stats()
+                eng.check()
+                assert (rn == 1).all()
+                got[route] = (pri.copy(), rw.copy())
+                eng.close()
+            pri, rw = got['fused']
+            assert np.max(np.abs(pri[0][acts].astype(np.float64) - want_p)) <= 1e-4, (B, algo)
+            assert np.max(np.abs(np.log(pri[0][acts].astype(np.float64)) - np.log(want_p))) <= 1e-4, (B, algo)
+            assert abs(-rw[0] - want_v) <= 1e-4, (B, algo)
+            occupied = [a for a in range(B * B) if a not in acts]
+            assert not pri[0][occupied].any()
+            for g, e in enumerate(envs):  # priors exist for the legal moves only: the legal share of the softmax
+                illegal = sorted(set(range(B * B)) - set(e.leagel_actions()))
+                assert not pri[g][illegal].any() and 0.0 < pri[g].astype(np.float64).sum() <= 1.0 + 1e-5
+            assert np.array_equal(got['fused'][0].view(np.uint32), got['unfused'][0].view(np.uint32)), (B, algo)
+            assert np.array_equal(got['fused'][1].view(np.uint64), got['unfused'][1].view(np.uint64)), (B, algo)
+        evaluator.hip.close()
+
+
+def test_puct_search_with_hip_net_vs_oracle():
+    """Opt-in PUCT driven by the production evaluator (priors written by k_tree_step_raw are READ by this rule):
+    the engine's tree == the oracle's PUCT restatement fed, leaf by leaf, the priors and value the device produces
+    for that position (a one-game engine expanding that position as its root: the evaluation of a board does not
+    depend on the batch it is in)."""
+    import torch
+    from rlzero_amd.engine import HipNetEvaluator
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    for B, n, pre, sims, c in ((6, 4, [14, 15, 20], 120, 5.0), (9, 5, [40, 41], 100, 2.0)):
+        torch.manual_seed(4)
+        net = PolicyValueNet(B)
+        with torch.no_grad():  # away from the near-uniform initial policy
+            net.act_fc1.weight.mul_(20.0)
+        net = net.to('cuda:0')
+        evaluator = HipNetEvaluator(net, B, 'cuda:0', max_boards=8)
+        probe = _engine(B, n, n_games=1, n_playout=2)
+
+        def pvf(env, probe=probe, evaluator=evaluator):
+            _set_roots(probe, [env], reset_trees=True)
+            probe.sim_chunk(evaluator, 1)
+            pri = probe.root_priors()[0]
+            _, rw = probe.root_stats()
+            legal = env.leagel_actions()
+            return [(a, pri[a]) for a in legal], -float(rw[0])
+
+        env = RefGomoku.from_moves(B, n, pre)
+        eng = _engine(B, n, n_games=3, n_playout=sims, c_puct=c, score_mode='puct')
+        _set_roots(eng, [env, RefGomoku(B, n), env], reset_trees=True)
+        eng.simulate(evaluator, sims)
+        eng.check()
+        s = RefSearch(pvf, sims, c, score_mode='puct')
+        acts, _ = s.simulate(env, 1.0)
+        for g in (0, 2):
+            visits, pri = eng.root_visits()[g], eng.root_priors()[g]
+            assert [int(visits[a]) for a in acts] == [k.n for k in s.root.kids]
+            assert [float(pri[a]) for a in acts] == [float(k.p) for k in s.root.kids]
+            assert _hex_tree(eng.tree_dump(g)) == _hex_tree(tree_dump(s.root))
+        assert max(k.n for k in s.root.kids) > 3 * max(1, min(k.n for k in s.root.kids))  # the priors shape the search
+        eng.close()
+        probe.close()
+        evaluator.hip.close()
 
 
 # ------------------------------------------------------------------ pure-MCTS opponent

@@ -99,19 +99,22 @@ def test_move_uniform_is_a_pure_function_of_seed_game_ply():
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_on_one_gpu():
-    """bench.py's N > 1 path (RANK / WORLD_SIZE from the launcher, barriers around the timed region, MAX over
-    ranks of the time, SUM of the work, one JSON line from rank 0) rehearsed on a 1-GPU box: the two ranks share
-    cuda:0 and rendezvous over gloo (RCCL refuses two ranks on one device)."""
+def test_bench_two_ranks_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 2` with NO external launcher: bench.py starts its two ranks itself (children of a
+    process that never touches the GPU), the N > 1 path (barriers around the timed region, MAX over ranks of the
+    time, SUM of the work, the trajectory gather, one JSON line from rank 0) runs on a 1-GPU box -- the two ranks
+    share cuda:0 and rendezvous over gloo (RCCL refuses two ranks on one device) -- and every game's trajectory
+    equals the one the same game id gets in a single-rank run (world-size invariance)."""
     import json
     import subprocess
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        port = s.getsockname()[1]
     env = dict(os.environ, RZ_BENCH_SINGLE_DEVICE='1', RZ_BENCH_BACKEND='gloo')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-           '127.0.0.1', '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '2',
-           '--warmup', '1', '--board', '9', '--playouts', '40', '--games', '32']
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    dump2, dump1 = str(tmp_path / 'two.json'), str(tmp_path / 'one.json')
+    common = ['--steps', '2', '--warmup', '1', '--board', '9', '--playouts', '40', '--no-cpu-baseline',
+              '--no-literal-config', '--no-configs']
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--games', '32', '--dump-trajectories',
+           dump2] + common
     out = subprocess.run(cmd, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith('{')]
@@ -125,6 +128,21 @@ def test_bench_two_ranks_on_one_gpu():
     assert rec['selfplay']['games_sampled'] == 64 and rec['selfplay_games_per_sec'] > 0
     tg = rec['trajectory_gather']  # the one exchange of the path, here over gloo
     assert tg['ranks'] == 2 and tg['games'] >= 64 and tg['unique_game_ids'] and tg['plies'] >= 64 * 9
+    assert tg['backend'] == 'gloo'
+    # the same 64 game ids on ONE rank (one lane of 64 games instead of two ranks x two lanes of 16)
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--games', '64', '--lanes', '1',
+           '--dump-trajectories', dump1] + common
+    out = subprocess.run(cmd, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    two, one = json.load(open(dump2)), json.load(open(dump1))
+    first_generation = [str(g) for g in range(64)]
+    assert all(g in two and g in one for g in first_generation)
+    for g in sorted(set(two) & set(one), key=int):
+        assert two[g] == one[g], 'game %s depends on the number of ranks' % g
+    # a rank that fails makes the self-launched run fail (non-zero exit, no line)
+    bad = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--games', '8', '--board', '99']
+                         + common[:4], env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert bad.returncode != 0 and not [ln for ln in bad.stdout.decode().splitlines() if ln.startswith('{')]
 
 
 @pytest.mark.gpu
@@ -140,7 +158,7 @@ def test_bench_collectives_on_rccl_with_one_rank():
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
            '127.0.0.1', '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '2',
            '--warmup', '1', '--board', '9', '--playouts', '40', '--games', '32', '--no-cpu-baseline',
-           '--no-literal-config']
+           '--no-literal-config', '--no-configs']
     out = subprocess.run(cmd, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     rec = json.loads([ln for ln in out.stdout.decode().splitlines() if ln.startswith('{')][-1])

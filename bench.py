@@ -405,7 +405,7 @@ def run_muzero(args, rank, world, device, dist, red_device, use_dist=False, cpu_
         dist.barrier()
     torch.cuda.synchronize()
     sims0 = sp.sims_done
-    sp.sim_events = []  # HIP events around every simulation step (one hipGraph replay) of the timed region
+    sp.sim_events = []  # HIP events around every 8th simulation step (one hipGraph replay) of the timed region
     t0 = time.perf_counter()
     finished = 0
     for _ in range(args.steps):
@@ -498,6 +498,9 @@ def main():
     ap.add_argument('--dump-trajectories', default='',
                     help='rank 0 writes the finished games it holds after the run (N > 1: the gathered ones) as JSON '
                          '{game id: moves, winner, first pi}: a game must not depend on the number of ranks')
+    ap.add_argument('--in-flight', type=int, default=1,
+                    help='K > 1: opt-in virtual-loss mode, K simulations of every tree share one evaluator batch (NOT the '
+                         'reference\'s sequential search: results differ from it; for batches too small to fill the GPU)')
     ap.add_argument('--lanes', type=int, default=2,
                     help='independent batches of games on separate HIP streams (the tree / FC kernels of one '
                          'lane run beside the network trunk of the other)')
@@ -580,9 +583,10 @@ def main():
     engines, evaluators = [], []
     for g_lane in per_lane:
         eng = MCTSEngine(board, n_row, n_games=g_lane, n_playout=args.playouts, c_puct=C_PUCT, device=device,
-                         game=args.game, add_noise=bool(args.noise), noise_seed=1000 * rank + len(engines))
+                         game=args.game, add_noise=bool(args.noise), noise_seed=1000 * rank + len(engines),
+                         sims_in_flight=args.in_flight)
         if args.evaluator == 'hipnet':
-            hip_ev = HipNetEvaluator(net, net_shape, device, max_boards=g_lane)
+            hip_ev = HipNetEvaluator(net, net_shape, device, max_boards=eng.n_leaves)
             hip_ev.hip.set_algo(args.net_algo)
             hip_ev.hip.set_heads_algo(args.heads_algo)
             hip_ev.hip.set_max_workgroups(trunk_wgs)
@@ -746,7 +750,11 @@ def main():
                        if args.game == 'connect4' else
                        'gomoku%dx%d_n%d_selfplay_%dsims_per_move_%dgames_per_gpu' % (board, board, n_row, args.playouts, G),
                        'games_total': G * world, 'c_puct': C_PUCT, 'temperature': TEMPERATURE,
-                       'evaluator': args.evaluator, 'score_mode': 'UCT_REF (bit-exact)',
+                       'evaluator': args.evaluator,
+                       'score_mode': 'UCT_REF (bit-exact)' if args.in_flight <= 1 else
+                       'UCT_REF rule with %d simulations in flight per tree and virtual loss (opt-in, NOT the reference\'s '
+                       'sequential search)' % args.in_flight,
+                       'multi_sim': {'sims_in_flight': max(1, args.in_flight)},
                        'dirichlet_noise_at_every_expansion': bool(args.noise),
                        'sims_per_graph': args.graph, 'lanes': lanes, 'parallelism': 'games sharded, dp%d' % world},
             'moves_per_sec': round(total_sims / args.playouts / elapsed, 2),
@@ -769,7 +777,7 @@ def main():
             # the time during which AT LEAST ONE trunk launch is in flight (union of the event intervals of all
             # lanes on one clock) / number of launches; with one lane this is the plain average.
             ms = union_ms([iv for ev in evaluators for iv in ev.events]) / n_ev if lanes > 1 else per_stream_ms
-            boards_per_launch = G / float(lanes)
+            boards_per_launch = G / float(lanes) * max(1, args.in_flight)
             per_pos = trunk_flops_per_position(cells) if args.evaluator == 'hipnet' else flops_per_position(cells)
             flops = per_pos * boards_per_launch
             achieved = flops / (ms * 1e-3) / 1e12
@@ -794,7 +802,7 @@ def main():
                                 'mfma_executed_frac': round(achieved / pipe_peak * executed_flop_ratio(args, cells), 4),
                                 # trunk launches of all lanes x the duration charged to one / wall-clock (the eager samples
                                 # run a little slower than the graph replays they stand for, so a trunk-bound run reads ~1)
-                                'share_of_step_time': round(ms * lanes * (total_sims / world / G) / (elapsed * 1e3), 3),
+                                'share_of_step_time': round(ms * lanes * (total_sims / world / G / max(1, args.in_flight)) / (elapsed * 1e3), 3),
                                 'concurrent_lanes': lanes,
                                 'trunk_workgroups': trunk_wgs if trunk_wgs > 0 else n_cus}
             rf = line['roofline']

@@ -36,6 +36,7 @@ extern "C" {
 #define RZ_ABI_VERSION 17
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
+#define RZ_MAX_IN_FLIGHT 32 /* rz_config.sims_in_flight */
 
 enum {
     RZ_OK = 0,
@@ -100,6 +101,13 @@ typedef struct rz_config {
     int32_t noise_seed;  /* seed of the Dirichlet stream */
     int32_t board_height; /* RZ_GAME_CONNECT4 only (0 -> 6) */
     int32_t board_width;  /* RZ_GAME_CONNECT4 only (0 -> 7) */
+    int32_t sims_in_flight; /* 0 / 1 (default): ONE simulation in flight per tree, the reference's sequential search
+                               (alphazero_mcts.py:82-85) -- the only mode the parity tests use.  K > 1 (opt-in, NOT
+                               the reference's algorithm): K simulations of a tree share one evaluator batch; every node
+                               of a selected path carries a virtual loss (N += 1, W -= 1) until its backup.  Leaf
+                               arrays of this ABI (d_obs, d_logp, d_value, d_raw, d_hid) then have n_games * K rows,
+                               row = game * K + slot.  Device evaluators only. */
+    int32_t reserved;
 } rz_config;
 
 typedef struct rz_stats {
@@ -152,6 +160,10 @@ int rz_set_active(rz_engine *e, const uint8_t *d_active, void *stream);
  * leaf's observation planes float32 [n_games][4][B][B] (GomokuEnv.current_state,
  * gomoku_env.py:95-114) -- the input of the evaluator. */
 int rz_select_step(rz_engine *e, float *d_obs, void *stream);
+/* sims_in_flight > 1 only: how many of the K slots the NEXT launches back up (rz_expand_backup*, rz_tree_step*) and
+ * select (rz_select_step, rz_tree_step*); default K, K.  A search of n simulations is ceil(n / K) steps, the last one
+ * with the remainder, so that N(root) grows by exactly n. */
+int rz_set_in_flight(rz_engine *e, int32_t k_backup, int32_t k_select);
 
 /* Observation planes of the current leaves / of the root positions (current_state). */
 int rz_encode_leaf_obs(rz_engine *e, float *d_obs, void *stream);

@@ -11,6 +11,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_in
 ABI_VERSION = 17
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
+MAX_IN_FLIGHT = 32
 
 OK = 0
 SCORE_UCT_REF, SCORE_PUCT = 0, 1
@@ -29,7 +30,8 @@ class RzConfig(Structure):
                 ('n_in_row', c_int32), ('n_games', c_int32), ('n_playout', c_int32),
                 ('score_mode', c_int32), ('add_noise', c_int32), ('c_puct', c_double),
                 ('pool_factor', c_double), ('device', c_int32), ('noise_seed', c_int32),
-                ('board_height', c_int32), ('board_width', c_int32)]
+                ('board_height', c_int32), ('board_width', c_int32),
+                ('sims_in_flight', c_int32), ('reserved', c_int32)]
 
 
 class RzStats(Structure):
@@ -62,6 +64,7 @@ _SIGNATURES = {
     'rz_get_roots': (c_int, [P, P, P, P, P]),
     'rz_set_active': (c_int, [P, P, P]),
     'rz_select_step': (c_int, [P, P, P]),
+    'rz_set_in_flight': (c_int, [P, c_int32, c_int32]),
     'rz_encode_leaf_obs': (c_int, [P, P, P]),
     'rz_encode_root_obs': (c_int, [P, P, P]),
     'rz_get_leaves': (c_int, [P, P, P, P, P, P]),

@@ -58,6 +58,7 @@ constexpr int kWords = RZ_BOARD_WORDS;
 
 struct Dev {
     int kind, BH, BW, S, A, n_row, n_games, score_mode, n_playout;
+    int K;  // simulations in flight per tree (1 = the reference's sequential search; > 1: opt-in virtual-loss mode)
     int path_stride, qcap;
     long long cap, pcap, logtab_n;  // record slots / prior floats per arena
     double c_puct;
@@ -408,7 +409,16 @@ __device__ __forceinline__ int scan_children(const Dev &E, const int4 *R, const 
     return r;
 }
 
-__device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int lane) {
+// VL = false: the reference's search, ONE simulation in flight per tree (bit-exact).  VL = true (opt-in, E.K > 1,
+// never used by a parity test): slot j of K simulations in flight; the slots of a game are selected one after the
+// other by the game's wave, and every node on a selected path -- the leaf included -- gets a VIRTUAL LOSS (N += 1,
+// W -= 1: "one more visit, lost") that steers the following slots elsewhere until the backup of the slot replaces it
+// by the real value.  A first-visit child gets a placeholder record (N = 1, W = -1) at once, so the prefix invariant
+// and the scans hold while its evaluation is pending; two slots may end in the same unexpanded leaf (both are
+// evaluated, the first backup expands it).  Per-leaf state is indexed by g * K + j.
+template <bool VL>
+__device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int lane, int j = 0) {
+    const int gk = VL ? g * E.K + j : g;
     // every load that does not depend on another one is issued before `active` is tested: a kernel of dependent
     // round trips (an inactive game's slots exist, reading them is harmless)
     const int arena = E.cur_arena[g];
@@ -426,7 +436,7 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
     int top = top0;
     int nst = count_bits(st[0]) + count_bits(st[1]);
 
-    int32_t *path = E.path + (long long)g * E.path_stride;
+    int32_t *path = E.path + (long long)gk * E.path_stride;
     int node = 0, depth = 0, fresh = 0;
     if (lane == 0) path[0] = 0;
 
@@ -463,7 +473,14 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
             }
             r = nv;
             fresh = 1;
-            if (lane == 0) R[2 * node] = make_int4(lo.x, fc, nv + 1, pack_kc(k, cap));
+            if (lane == 0) {
+                R[2 * node] = make_int4(lo.x + (VL ? 1 : 0), fc, nv + 1, pack_kc(k, cap));
+                if (VL) {
+                    *rec_wsum(R, node) = rec_w(hi) - 1.0;
+                    R[2 * (fc + r)] = make_int4(1, -1, 0, 0);          // placeholder of the pending child:
+                    R[2 * (fc + r) + 1] = make_hi(-1.0, -1, 0.0f);     // visited once, lost
+                }
+            }
         } else {
             const int pn = lo.x;
             if (pn < 1 || pn >= E.logtab_n) {
@@ -475,6 +492,10 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
         if (r >= k) {
             flag(E, g, RZ_FLAG_INTERNAL, lane);
             break;
+        }
+        if (VL && !fresh && lane == 0) {  // virtual loss on an inner node of the path
+            *rec_n(R, node) = lo.x + 1;
+            *rec_wsum(R, node) = rec_w(hi) - 1.0;
         }
         uint64_t occ[kWords];
 #pragma unroll
@@ -497,6 +518,10 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
         hi = chi;
     }
     if (lane == 0 && top != top0) E.top[g] = top;
+    if (VL && fresh == 0 && lane == 0) {  // the path ends in an existing leaf (unexpanded or terminal): virtual loss on it
+        *rec_n(R, node) = lo.x + 1;
+        *rec_wsum(R, node) = rec_w(hi) - 1.0;
+    }
 
     // game_end_winner on the leaf (gomoku_env.py:196-203)
     int term = 0;
@@ -519,17 +544,17 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
         }
     }
     if (lane == 0) {
-        E.leaf_node[g] = node;
-        E.leaf_depth[g] = depth;
-        E.leaf_fresh[g] = fresh;
-        E.leaf_term[g] = term;
-        E.leaf_tval[g] = tval;
-        E.leaf_to_move[g] = to_move;
-        E.leaf_last[g] = last;
+        E.leaf_node[gk] = node;
+        E.leaf_depth[gk] = depth;
+        E.leaf_fresh[gk] = fresh;
+        E.leaf_term[gk] = term;
+        E.leaf_tval[gk] = tval;
+        E.leaf_to_move[gk] = to_move;
+        E.leaf_last[gk] = last;
     }
-    store_board(E.leaf_stones, g, st, lane);
+    store_board(E.leaf_stones, gk, st, lane);
     if (obs != nullptr)
-        write_obs(obs + (long long)g * 4 * S, to_move == 0 ? st[0] : st[1],
+        write_obs(obs + (long long)gk * 4 * S, to_move == 0 ? st[0] : st[1],
                   to_move == 0 ? st[1] : st[0], last, nst, S, lane);
 }
 
@@ -548,29 +573,34 @@ struct RawHeads {
 // PROBS: `logp` already holds probabilities (host evaluators hand over the callable's exact
 // numbers); otherwise log-probabilities from the network (prior = exp, alphazero_agent.py:44).
 // Policy arrays are indexed by ACTION: [n_games][A].
-template <typename VT, bool PROBS = false, bool RAW = false>
+// VL (see select_body): the backup of slot j of a game with K simulations in flight.  Every node of the path already
+// counts this visit (N += 1 at selection) and carries its virtual loss, so the backup adds x + 1 to W and leaves N
+// alone; whether the leaf is expanded is decided from its CURRENT record (an earlier slot of the same step may have
+// expanded it already).
+template <typename VT, bool PROBS = false, bool RAW = false, bool VL = false>
 __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *logp, const VT *value, int g,
-                                                   int lane, RawHeads rh = RawHeads()) {
+                                                   int lane, RawHeads rh = RawHeads(), int j = 0) {
+    const int gk = VL ? g * E.K + j : g;
     // loads first, the test of `active` after them (see select_body)
     const bool act = E.active[g] != 0;
     const int arena = E.cur_arena[g];
-    const int depth = E.leaf_depth[g];
-    const int fresh = E.leaf_fresh[g];
-    const int term = E.leaf_term[g];
-    const double leaf_tval = E.leaf_tval[g];
+    const int depth = E.leaf_depth[gk];
+    const int fresh = E.leaf_fresh[gk];
+    const int term = E.leaf_term[gk];
+    const double leaf_tval = E.leaf_tval[gk];
     const int ptop = E.ptop[g];
     const int nblk = E.nblk[g];
     const int top_now = E.top[g];
     const int noise_ctr = E.noise_ctr[g];
-    const int32_t *path = E.path + (long long)g * E.path_stride;
+    const int32_t *path = E.path + (long long)gk * E.path_stride;
     const int path_lane = path[lane < E.path_stride ? lane : 0];  // the node of path level `lane` (if that level exists)
     uint64_t st[2][kWords];
-    load_board(E.leaf_stones, g, st);
+    load_board(E.leaf_stones, gk, st);
     float lse = 0.0f, raw_value = 0.0f;
     float x[kWords] = {0.f, 0.f, 0.f, 0.f};  // RAW: the lane's policy logits, kept for the priors below
     if (RAW) {
-        const float *r = rh.raw + (size_t)g * rh.ld;
-        const float hid = rh.hid[(size_t)g * 64 + lane], w2 = rh.w2[lane], b2 = rh.b2[0];
+        const float *r = rh.raw + (size_t)gk * rh.ld;
+        const float hid = rh.hid[(size_t)gk * 64 + lane], w2 = rh.w2[lane], b2 = rh.b2[0];
         float mx = -INFINITY;
 #pragma unroll
         for (int i = 0; i < kWords; ++i) {
@@ -596,10 +626,15 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
     float *P = arena_priors(E, g, arena);
 
     // the reference evaluates terminal leaves too and discards the result (:59-68)
-    const double v = term ? leaf_tval : (RAW ? (double)raw_value : (double)value[g]);
+    const double v = term ? leaf_tval : (RAW ? (double)raw_value : (double)value[gk]);
 
     int new_fc = -1, new_nv = 0, new_k = 0, new_cap = 0, new_pb = -1;
-    if (!term && fresh != 2) {
+    bool expand_now = !term && fresh != 2;
+    if (VL && expand_now) {  // pending in several slots: only the first backup expands the leaf
+        const int leaf = __shfl(path_lane, depth < kWave ? depth : 0);
+        expand_now = rec_k(R[2 * (depth < kWave ? leaf : path[depth])]) == 0;
+    }
+    if (expand_now) {
         uint64_t occ[kWords];
 #pragma unroll
         for (int j = 0; j < kWords; ++j) occ[j] = st[0][j] | st[1][j];
@@ -657,7 +692,7 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
                 // = exp(log_softmax); the logit is the one loaded above (a second load here would sit between the
                 // prior stores, and its s_waitcnt vmcnt(0) also waits for the stores before it)
                 if (RAW) prior = expf(x[j] - lse);
-                else if (logp) prior = PROBS ? logp[(long long)g * E.A + a] : expf(logp[(long long)g * E.A + a]);
+                else if (logp) prior = PROBS ? logp[(long long)gk * E.A + a] : expf(logp[(long long)gk * E.A + a]);
                 if (E.add_noise) prior = 0.75f * prior + 0.25f * (noise[j] / noise_sum);
                 P[ptop + r] = prior;
                 if (dense) {
@@ -672,7 +707,15 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
     for (int d = lane; d <= depth; d += kWave) {
         const int node = d == lane ? path_lane : path[d];
         const double x = ((depth - d) & 1) ? v : -v;
-        if (d == depth) {
+        if (VL) {
+            // N was counted at selection; W trades the virtual loss for the value; a leaf expanded now gets its blocks
+            if (d == depth && new_k > 0) {
+                const int4 m = R[2 * node];
+                R[2 * node] = make_int4(m.x, new_fc, new_nv, pack_kc(new_k, new_cap));
+                *rec_pb(R, node) = new_pb;
+            }
+            *rec_wsum(R, node) += x + 1.0;
+        } else if (d == depth) {
             // the leaf: a first-visit slot gets its whole record here; an old leaf that is now
             // expanded gets its prior block (and, dense, its child block)
             if (fresh == 1) {
@@ -694,7 +737,7 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
 
 __global__ __launch_bounds__(kWave) void k_select(Dev E, float *obs) {
     __builtin_amdgcn_s_setprio(3);  // latency-bound: issue ahead of a co-resident MFMA kernel
-    select_body(E, obs, blockIdx.x, threadIdx.x);
+    select_body<false>(E, obs, blockIdx.x, threadIdx.x);
 }
 
 template <typename VT, bool PROBS = false>
@@ -712,7 +755,7 @@ __global__ __launch_bounds__(kWave) void k_tree_step_raw(Dev E, RawHeads rh, flo
     __builtin_amdgcn_s_setprio(3);
     expand_backup_body<float, false, true>(E, nullptr, nullptr, blockIdx.x, threadIdx.x, rh);
     __syncthreads();
-    select_body(E, obs, blockIdx.x, threadIdx.x);
+    select_body<false>(E, obs, blockIdx.x, threadIdx.x);
 }
 
 // EXPAND + BACKUP of simulation s and SELECT + STEP of simulation s+1 in one launch (same
@@ -723,14 +766,33 @@ __global__ __launch_bounds__(kWave) void k_tree_step(Dev E, const float *logp, c
     __builtin_amdgcn_s_setprio(3);
     expand_backup_body<VT>(E, logp, value, blockIdx.x, threadIdx.x);
     __syncthreads();
-    select_body(E, obs, blockIdx.x, threadIdx.x);
+    select_body<false>(E, obs, blockIdx.x, threadIdx.x);
+}
+
+// K simulations in flight (opt-in): the game's wave backs up the kb pending slots of the previous step one after
+// the other, then selects ks new ones; the barrier between two slots orders the tree updates of one before the loads
+// of the next (same wave: s_waitcnt + s_barrier).  kb = 0 / ks = 0 give the select-only / backup-only launches.
+template <bool RAW>
+__global__ __launch_bounds__(kWave) void k_tree_step_vl(Dev E, const float *logp, const float *value, RawHeads rh,
+                                                        float *obs, int kb, int ks) {
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll 1
+    for (int j = 0; j < kb; ++j) {
+        expand_backup_body<float, false, RAW, true>(E, logp, value, blockIdx.x, threadIdx.x, rh, j);
+        __syncthreads();
+    }
+#pragma unroll 1
+    for (int j = 0; j < ks; ++j) {
+        select_body<true>(E, obs, blockIdx.x, threadIdx.x, j);
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------ synthetic evaluators
 __global__ __launch_bounds__(kWave) void k_eval_synth(Dev E, int kind, float *logp, float *value) {
-    const int g = blockIdx.x;
+    const int g = blockIdx.x;  // leaf index: game * K + slot (K = 1: the game)
     const int lane = threadIdx.x;
-    if (!E.active[g]) return;
+    if (!E.active[g / E.K]) return;
     const int S = E.S;
     uint64_t st[2][kWords];
     load_board(E.leaf_stones, g, st);
@@ -780,9 +842,9 @@ __global__ __launch_bounds__(kWave) void k_eval_synth(Dev E, int kind, float *lo
 // with the very same choices.
 __global__ __launch_bounds__(kWave) void k_eval_rollout(Dev E, uint64_t seed, uint32_t sim, int n_limit,
                                                         float *value) {
-    const int g = blockIdx.x;
+    const int g = blockIdx.x;  // leaf index: game * K + slot (K = 1: the game)
     const int lane = threadIdx.x;
-    if (!E.active[g]) return;
+    if (!E.active[g / E.K]) return;
     const int S = E.S;
     uint64_t st[2][kWords];
     load_board(E.leaf_stones, g, st);
@@ -1058,7 +1120,7 @@ __global__ void k_set_active(Dev E, const uint8_t *active) {
 
 // which: 0 = leaf boards, 1 = root boards
 __global__ __launch_bounds__(kWave) void k_encode(Dev E, int which, float *obs) {
-    const int g = blockIdx.x;
+    const int g = blockIdx.x;  // which == 0: leaf index (game * K + slot); which == 1: game
     const int lane = threadIdx.x;
     uint64_t st[2][kWords];
     load_board(which == 0 ? E.leaf_stones : E.root_stones, g, st);
@@ -1110,6 +1172,7 @@ struct rz_engine {
     std::vector<void *> allocs;
     long long bytes = 0;
     long long n_select = 0;
+    int kb = 1, ks = 1;  // rz_set_in_flight: slots the next launches back up / select (sims_in_flight > 1 only)
     double *d_logtab = nullptr;
 };
 
@@ -1178,6 +1241,8 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     if (cfg->score_mode != RZ_SCORE_UCT_REF && cfg->score_mode != RZ_SCORE_PUCT)
         return fail(RZ_ERR_ARG, "unknown score_mode %d", cfg->score_mode);
     if (!(cfg->c_puct >= 0.0)) return fail(RZ_ERR_ARG, "c_puct must be >= 0");
+    if (cfg->sims_in_flight < 0 || cfg->sims_in_flight > RZ_MAX_IN_FLIGHT)
+        return fail(RZ_ERR_ARG, "sims_in_flight %d not in 0..%d", cfg->sims_in_flight, RZ_MAX_IN_FLIGHT);
     int n_dev = 0;
     RZ_HIP(hipGetDeviceCount(&n_dev));
     if (cfg->device < 0 || cfg->device >= n_dev)
@@ -1199,6 +1264,8 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     D.n_row = n_row;
     D.n_games = cfg->n_games;
     D.n_playout = cfg->n_playout;
+    D.K = cfg->sims_in_flight > 1 ? cfg->sims_in_flight : 1;
+    e->kb = e->ks = D.K;
     D.score_mode = cfg->score_mode;
     D.add_noise = cfg->add_noise ? 1 : 0;
     D.noise_seed = (uint64_t)(uint32_t)cfg->noise_seed;
@@ -1217,7 +1284,7 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
         const int lo = 64 * j;
         D.valid[j] = S >= lo + 64 ? ~0ull : (S > lo ? ((1ull << (S - lo)) - 1ull) : 0ull);
     }
-    const long long G = cfg->n_games;
+    const long long G = cfg->n_games, GL = G * D.K;  // games, leaves in flight
     const long long slots = G * 2 * D.cap;
     if (D.cap >= (1ll << 30) || D.pcap >= (1ll << 31))
     {
@@ -1237,15 +1304,15 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     RZ_ALLOC(root_to_move, G);
     RZ_ALLOC(root_last, G);
     RZ_ALLOC(active, G);
-    RZ_ALLOC(path, G * D.path_stride);
-    RZ_ALLOC(leaf_node, G);
-    RZ_ALLOC(leaf_depth, G);
-    RZ_ALLOC(leaf_fresh, G);
-    RZ_ALLOC(leaf_term, G);
-    RZ_ALLOC(leaf_tval, G);
-    RZ_ALLOC(leaf_stones, G * 2 * kWords);
-    RZ_ALLOC(leaf_to_move, G);
-    RZ_ALLOC(leaf_last, G);
+    RZ_ALLOC(path, GL * D.path_stride);
+    RZ_ALLOC(leaf_node, GL);
+    RZ_ALLOC(leaf_depth, GL);
+    RZ_ALLOC(leaf_fresh, GL);
+    RZ_ALLOC(leaf_term, GL);
+    RZ_ALLOC(leaf_tval, GL);
+    RZ_ALLOC(leaf_stones, GL * 2 * kWords);
+    RZ_ALLOC(leaf_to_move, GL);
+    RZ_ALLOC(leaf_last, GL);
     RZ_ALLOC(queue, G * D.qcap);
     RZ_ALLOC(err, G);
     RZ_ALLOC(err_any, 1);
@@ -1263,12 +1330,12 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     auto zero = [&](void *p, size_t bytes) { if (herr == hipSuccess) herr = hipMemset(p, 0, bytes); };
     zero(D.cur_arena, G * 4); zero(D.top, G * 4); zero(D.ptop, G * 4); zero(D.nblk, G * 4);
     zero(D.root_stones, G * 2 * kWords * 8); zero(D.root_to_move, G * 4);
-    zero(D.leaf_node, G * 4); zero(D.leaf_depth, G * 4); zero(D.leaf_fresh, G * 4);
-    zero(D.leaf_term, G * 4); zero(D.leaf_tval, G * 8); zero(D.leaf_stones, G * 2 * kWords * 8);
-    zero(D.leaf_to_move, G * 4); zero(D.path, G * D.path_stride * 4);
+    zero(D.leaf_node, GL * 4); zero(D.leaf_depth, GL * 4); zero(D.leaf_fresh, GL * 4);
+    zero(D.leaf_term, GL * 4); zero(D.leaf_tval, GL * 8); zero(D.leaf_stones, GL * 2 * kWords * 8);
+    zero(D.leaf_to_move, GL * 4); zero(D.path, GL * D.path_stride * 4);
     zero(D.err, G * 4); zero(D.err_any, 4); zero(D.reuse_drops, 4); zero(D.noise_ctr, G * 4);
     if (herr == hipSuccess) herr = hipMemset(D.root_last, 0xff, G * 4);  // -1
-    if (herr == hipSuccess) herr = hipMemset(D.leaf_last, 0xff, G * 4);
+    if (herr == hipSuccess) herr = hipMemset(D.leaf_last, 0xff, GL * 4);
     if (herr == hipSuccess) herr = hipMemset(D.active, 1, G);
     if (herr != hipSuccess) {
         rz_destroy(e);
@@ -1347,6 +1414,7 @@ int rz_log_table_size(rz_engine *e, int64_t *count) {
     } while (0)
 
 static inline dim3 per_game(const rz_engine *e) { return dim3((unsigned)e->cfg.n_games); }
+static inline dim3 per_leaf(const rz_engine *e) { return dim3((unsigned)(e->cfg.n_games * e->dev.K)); }
 static inline dim3 flat_grid(const rz_engine *e) { return dim3((unsigned)((e->cfg.n_games + 255) / 256)); }
 
 int rz_set_roots(rz_engine *e, const uint64_t *d_stones, const int32_t *d_to_move,
@@ -1372,9 +1440,22 @@ int rz_set_active(rz_engine *e, const uint8_t *d_active, void *stream) {
     return launched("k_set_active");
 }
 
+int rz_set_in_flight(rz_engine *e, int32_t k_backup, int32_t k_select) {
+    if (e == nullptr) return fail(RZ_ERR_ARG, "engine handle is NULL");
+    if (k_backup < 0 || k_backup > e->dev.K || k_select < 0 || k_select > e->dev.K)
+        return fail(RZ_ERR_ARG, "in-flight counts (%d, %d) not in 0..%d", k_backup, k_select, e->dev.K);
+    e->kb = k_backup;
+    e->ks = k_select;
+    return RZ_OK;
+}
+
 int rz_select_step(rz_engine *e, float *d_obs, void *stream) {
     RZ_ENTER(e);
     e->n_select += 1;
+    if (e->dev.K > 1) {
+        k_tree_step_vl<false><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, nullptr, nullptr, RawHeads(), d_obs, 0, e->ks);
+        return launched("k_tree_step_vl");
+    }
     k_select<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_obs);
     return launched("k_select");
 }
@@ -1382,7 +1463,7 @@ int rz_select_step(rz_engine *e, float *d_obs, void *stream) {
 int rz_encode_leaf_obs(rz_engine *e, float *d_obs, void *stream) {
     RZ_ENTER(e);
     RZ_NEED(d_obs);
-    k_encode<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, 0, d_obs);
+    k_encode<<<per_leaf(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, 0, d_obs);
     return launched("k_encode");
 }
 
@@ -1397,6 +1478,7 @@ int rz_get_leaves(rz_engine *e, uint64_t *d_stones, int32_t *d_to_move, int32_t 
                   int32_t *d_terminal, void *stream) {
     RZ_ENTER(e);
     RZ_NEED(d_stones); RZ_NEED(d_to_move); RZ_NEED(d_last_move); RZ_NEED(d_terminal);
+    if (e->dev.K > 1) return fail(RZ_ERR_ARG, "rz_get_leaves serves host evaluators: not available with sims_in_flight > 1");
     k_get_leaves<<<flat_grid(e), dim3(256), 0, as_stream(stream)>>>(e->dev, d_stones, d_to_move,
                                                                     d_last_move, d_terminal);
     return launched("k_get_leaves");
@@ -1406,7 +1488,7 @@ int rz_eval_synthetic(rz_engine *e, int kind, float *d_logp, float *d_value, voi
     RZ_ENTER(e);
     RZ_NEED(d_value);
     if (kind != RZ_EVAL_V0 && kind != RZ_EVAL_VLIN) return fail(RZ_ERR_ARG, "unknown evaluator %d", kind);
-    k_eval_synth<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, kind, d_logp, d_value);
+    k_eval_synth<<<per_leaf(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, kind, d_logp, d_value);
     return launched("k_eval_synth");
 }
 
@@ -1415,13 +1497,17 @@ int rz_eval_rollout(rz_engine *e, uint64_t seed, uint32_t sim_index, int32_t n_l
     RZ_ENTER(e);
     RZ_NEED(d_value);
     if (n_limit < 0) return fail(RZ_ERR_ARG, "n_limit must be >= 0");
-    k_eval_rollout<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, seed, sim_index, n_limit, d_value);
+    k_eval_rollout<<<per_leaf(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, seed, sim_index, n_limit, d_value);
     return launched("k_eval_rollout");
 }
 
 int rz_expand_backup(rz_engine *e, const float *d_logp, const float *d_value, void *stream) {
     RZ_ENTER(e);
     RZ_NEED(d_value);
+    if (e->dev.K > 1) {
+        k_tree_step_vl<false><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_logp, d_value, RawHeads(), nullptr, e->kb, 0);
+        return launched("k_tree_step_vl");
+    }
     k_expand_backup<float><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_logp, d_value);
     return launched("k_expand_backup");
 }
@@ -1429,6 +1515,7 @@ int rz_expand_backup(rz_engine *e, const float *d_logp, const float *d_value, vo
 int rz_expand_backup_f64(rz_engine *e, const float *d_logp, const double *d_value, void *stream) {
     RZ_ENTER(e);
     RZ_NEED(d_value);
+    if (e->dev.K > 1) return fail(RZ_ERR_ARG, "host evaluators are not available with sims_in_flight > 1");
     k_expand_backup<double><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_logp, d_value);
     return launched("k_expand_backup");
 }
@@ -1436,6 +1523,7 @@ int rz_expand_backup_f64(rz_engine *e, const float *d_logp, const double *d_valu
 int rz_expand_backup_probs(rz_engine *e, const float *d_probs, const double *d_value, void *stream) {
     RZ_ENTER(e);
     RZ_NEED(d_value);
+    if (e->dev.K > 1) return fail(RZ_ERR_ARG, "host evaluators are not available with sims_in_flight > 1");
     k_expand_backup<double, true><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_probs, d_value);
     return launched("k_expand_backup");
 }
@@ -1444,6 +1532,10 @@ int rz_tree_step(rz_engine *e, const float *d_logp, const float *d_value, float 
     RZ_ENTER(e);
     RZ_NEED(d_value);
     e->n_select += 1;
+    if (e->dev.K > 1) {
+        k_tree_step_vl<false><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_logp, d_value, RawHeads(), d_obs, e->kb, e->ks);
+        return launched("k_tree_step_vl");
+    }
     k_tree_step<float><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_logp, d_value, d_obs);
     return launched("k_tree_step");
 }
@@ -1461,6 +1553,10 @@ int rz_expand_backup_raw(rz_engine *e, const float *d_raw, int32_t ld, const flo
     int rc = raw_heads_ok(e, d_raw, ld, d_hid, d_w2, d_b2);
     if (rc != RZ_OK) return rc;
     const RawHeads rh = {d_raw, ld, d_hid, d_w2, d_b2};
+    if (e->dev.K > 1) {
+        k_tree_step_vl<true><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, nullptr, nullptr, rh, nullptr, e->kb, 0);
+        return launched("k_tree_step_vl");
+    }
     k_expand_backup_raw<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, rh);
     return launched("k_expand_backup_raw");
 }
@@ -1472,6 +1568,10 @@ int rz_tree_step_raw(rz_engine *e, const float *d_raw, int32_t ld, const float *
     if (rc != RZ_OK) return rc;
     e->n_select += 1;
     const RawHeads rh = {d_raw, ld, d_hid, d_w2, d_b2};
+    if (e->dev.K > 1) {
+        k_tree_step_vl<true><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, nullptr, nullptr, rh, d_obs, e->kb, e->ks);
+        return launched("k_tree_step_vl");
+    }
     k_tree_step_raw<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, rh, d_obs);
     return launched("k_tree_step_raw");
 }

@@ -301,8 +301,14 @@ class MCTSEngine(object):
 
     def __init__(self, board_size, n_in_row, n_games=1, n_playout=1000, c_puct=5.0,
                  device='cuda:0', pool_factor=2.0, score_mode='uct_ref', add_noise=False, noise_seed=0,
-                 game='gomoku'):
-        """``board_size``: int B (Gomoku / TicTacToe, B x B) or (rows, cols) for ``game='connect4'``."""
+                 game='gomoku', sims_in_flight=1):
+        """``board_size``: int B (Gomoku / TicTacToe, B x B) or (rows, cols) for ``game='connect4'``.
+
+        ``sims_in_flight`` = K > 1 (opt-in, NOT the reference's algorithm, never used by a parity test): K
+        simulations of every tree share one evaluator batch of ``n_games * K`` leaves; the nodes of a selected path
+        carry a virtual loss (N += 1, W -= 1) until their backup.  The reference runs its simulations strictly one
+        after the other (alphazero_mcts.py:82-85): results differ from it as soon as K > 1.  Device evaluators
+        only."""
         import torch
         self.lib = _hip.load()
         self.torch = torch
@@ -325,22 +331,25 @@ class MCTSEngine(object):
         self.score_mode = {'uct_ref': _hip.SCORE_UCT_REF, 'puct': _hip.SCORE_PUCT}[score_mode] \
             if isinstance(score_mode, str) else int(score_mode)
         self.add_noise = bool(add_noise)
+        self.sims_in_flight = max(1, int(sims_in_flight))
+        self.n_leaves = self.n_games * self.sims_in_flight  # rows of obs / logp / value
         cfg = _hip.RzConfig(abi_version=_hip.ABI_VERSION,
                             game_kind=_hip.GAME_CONNECT4 if game == 'connect4' else _hip.GAME_GOMOKU,
                             board_size=rows if game != 'connect4' else 0,
                             n_in_row=self.n_in_row, n_games=self.n_games, n_playout=self.n_playout,
                             score_mode=self.score_mode, add_noise=1 if add_noise else 0, c_puct=self.c_puct,
                             pool_factor=float(pool_factor), device=self.device.index,
-                            noise_seed=int(noise_seed) & 0x7FFFFFFF, board_height=rows, board_width=cols)
+                            noise_seed=int(noise_seed) & 0x7FFFFFFF, board_height=rows, board_width=cols,
+                            sims_in_flight=self.sims_in_flight, reserved=0)
         handle = ctypes.c_void_p()
         check(self.lib.rz_create(ctypes.byref(cfg), ctypes.byref(handle)), 'rz_create')
         self.handle = handle
-        G, S = self.n_games, self.n_actions
+        G, S, GL = self.n_games, self.n_actions, self.n_leaves
         kw = dict(device=self.device)
-        self.obs = torch.zeros((G, 4, rows, cols), dtype=torch.float32, **kw)
-        self.logp = torch.zeros((G, S), dtype=torch.float32, **kw)
-        self.value = torch.zeros(G, dtype=torch.float32, **kw)
-        self.value64 = torch.zeros(G, dtype=torch.float64, **kw)
+        self.obs = torch.zeros((GL, 4, rows, cols), dtype=torch.float32, **kw)
+        self.logp = torch.zeros((GL, S), dtype=torch.float32, **kw)
+        self.value = torch.zeros(GL, dtype=torch.float32, **kw)
+        self.value64 = torch.zeros(GL, dtype=torch.float64, **kw)
         self.visits = torch.zeros((G, S), dtype=torch.int32, **kw)
         self.wsum = torch.zeros((G, S), dtype=torch.float64, **kw)
         self.priors = torch.zeros((G, S), dtype=torch.float32, **kw)
@@ -438,6 +447,8 @@ class MCTSEngine(object):
     # ------------------------------------------------------------------ the hot loop
     def sim_step(self, evaluator):
         """One simulation for every active game (enqueued, not synchronised)."""
+        if self.sims_in_flight > 1:
+            return self.sim_chunk(evaluator, 1)
         obs = _ptr(self.obs) if getattr(evaluator, 'needs_obs', True) else None
         check(self.lib.rz_select_step(self.handle, obs, self.stream()), 'rz_select_step')
         logp, value = evaluator(self)
@@ -451,12 +462,19 @@ class MCTSEngine(object):
             check(self.lib.rz_expand_backup(self.handle, _ptr(logp), _ptr(value), self.stream()),
                   'rz_expand_backup')
 
+    def _in_flight(self, k_backup, k_select):
+        check(self.lib.rz_set_in_flight(self.handle, int(k_backup), int(k_select)), 'rz_set_in_flight')
+
     def sim_chunk(self, evaluator, n):
         """``n`` simulations of every active game: select, (evaluate, expand+backup+select) x
-        (n-1), evaluate, expand+backup -- consecutive simulations share one tree launch."""
+        (n-1), evaluate, expand+backup -- consecutive simulations share one tree launch.
+        With ``sims_in_flight`` = K > 1: ceil(n / K) steps of K simulations each (the last one with the remainder)."""
         if n <= 0:
             return
+        K = self.sims_in_flight
         if isinstance(evaluator, HostEvaluator):
+            if K > 1:
+                raise HipError('host evaluators are not available with sims_in_flight > 1')
             for _ in range(n):
                 self.sim_step(evaluator)
             return
@@ -465,23 +483,38 @@ class MCTSEngine(object):
         if begin is not None:
             begin()
         obs = _ptr(self.obs) if getattr(evaluator, 'needs_obs', True) else None
+        steps = -(-n // K)
+        counts = [min(K, n - i * K) for i in range(steps)] + [0]  # slots in flight in step i
+        if K > 1:
+            self._in_flight(0, counts[0])
         check(lib.rz_select_step(h, obs, self.stream()), 'rz_select_step')
-        if getattr(evaluator, 'fused_heads', False):
-            for i in range(n):
+        fused = getattr(evaluator, 'fused_heads', False)
+        for i in range(steps):
+            if K > 1 and (i == 0 or counts[i + 1] != K or counts[i] != K):
+                self._in_flight(counts[i], counts[i + 1])
+            if fused:
                 raw, ld, hid, w2, b2 = evaluator.raw_heads(self)
-                if i + 1 < n:
+                if i + 1 < steps:
                     check(lib.rz_tree_step_raw(h, raw, ld, hid, w2, b2, obs, self.stream()), 'rz_tree_step_raw')
                 else:
                     check(lib.rz_expand_backup_raw(h, raw, ld, hid, w2, b2, self.stream()), 'rz_expand_backup_raw')
-            return
-        for i in range(n):
+                continue
             logp, value = evaluator(self)
             if value.dtype != self.torch.float32:
                 raise HipError('device evaluators must return float32 values')
-            if i + 1 < n:
+            if i + 1 < steps:
                 check(lib.rz_tree_step(h, _ptr(logp), _ptr(value), obs, self.stream()), 'rz_tree_step')
             else:
                 check(lib.rz_expand_backup(h, _ptr(logp), _ptr(value), self.stream()), 'rz_expand_backup')
+        if K > 1:
+            self._in_flight(K, K)
+
+    def graph_chunk(self, sims_per_graph):
+        """Simulations a captured chunk holds: ``sims_per_graph``, rounded to whole steps of K simulations when K
+        simulations are in flight."""
+        per = max(1, int(sims_per_graph))
+        K = self.sims_in_flight
+        return per if K == 1 else max(K, per - per % K)
 
     def simulate(self, evaluator, n_sims=None, use_graph=False, sims_per_graph=8):
         """Run ``n_sims`` (default n_playout) simulations in every active game.
@@ -492,7 +525,10 @@ class MCTSEngine(object):
         if not use_graph or isinstance(evaluator, HostEvaluator):
             self.sim_chunk(evaluator, n)
             return
-        per = max(1, min(int(sims_per_graph), n))
+        per = self.graph_chunk(sims_per_graph)
+        if per > n:
+            self.sim_chunk(evaluator, n)
+            return
         key = (id(evaluator), per)
         if key not in self._graphs:
             raise HipError('call warm_graph(evaluator, %d) before simulate(use_graph=True)' % per)
@@ -507,6 +543,7 @@ class MCTSEngine(object):
         and the evaluator).  Capturing executes nothing, but the eager warm-up does run 3
         simulations, so call this on throw-away tree state (before reset_games)."""
         t = self.torch
+        per = self.graph_chunk(per)
         key = (id(evaluator), per)
         if key in self._graphs:
             return self._graphs[key][0]
@@ -514,7 +551,7 @@ class MCTSEngine(object):
         side = t.cuda.Stream(device=self.device)
         side.wait_stream(cur)
         with t.cuda.stream(side):
-            self.sim_chunk(evaluator, 3)
+            self.sim_chunk(evaluator, 3 * self.sims_in_flight)
         cur.wait_stream(side)
         t.cuda.synchronize(self.device)
         graph = t.cuda.CUDAGraph()

@@ -70,8 +70,10 @@ class AlphaZeroMCTS(object):
     """Monte Carlo tree search guided by a policy-value function."""
 
     def __init__(self, policy_value_fn, n_playout: int = 1000, c_puct: float = 5,
-                 add_noise: bool = False, device=None, score_mode: str = 'uct_ref') -> None:
+                 add_noise: bool = False, device=None, score_mode: str = 'uct_ref', sims_in_flight: int = 1) -> None:
         self.score_mode = score_mode  # 'uct_ref' = the reference's rule (parity); 'puct' = opt-in
+        # opt-in, NOT the reference's algorithm: K > 1 simulations of the tree share one evaluator batch (virtual loss)
+        self.sims_in_flight = max(1, int(sims_in_flight))
         self.policy_value_fn = policy_value_fn
         self.n_playout = n_playout
         self._c_puct = c_puct
@@ -88,7 +90,8 @@ class AlphaZeroMCTS(object):
         kind = getattr(game_env, 'game_kind', 'gomoku')
         eng = self._engine
         if eng is not None and (eng.game, eng.board_size, eng.n_in_row) == (kind, size, n_row) and \
-                eng.n_playout >= self.n_playout and eng.c_puct == float(self._c_puct):
+                eng.n_playout >= self.n_playout and eng.c_puct == float(self._c_puct) and \
+                getattr(self, '_bound_k', 1) == self.sims_in_flight:
             return eng
         if eng is not None:
             eng.close()
@@ -103,12 +106,13 @@ class AlphaZeroMCTS(object):
         device = self._device or (agent_dev if fast else os.environ.get('RLZERO_DEVICE', 'cuda:0'))
         eng = MCTSEngine(size, n_row, n_games=1, n_playout=self.n_playout, c_puct=self._c_puct,
                          device=device, score_mode=self.score_mode, add_noise=self.add_noise, game=kind,
+                         sims_in_flight=self.sims_in_flight if fast else 1,
                          noise_seed=int(np.random.randint(0, 2 ** 31 - 1)) if self.add_noise else 0)
         if fast:
             from ..games.gomoku.policy_value_net import PolicyValueNet
             # the reference architecture runs on the hand-written fused kernels (csrc/rz_net.hip);
             # any other nn.Module with the same call signature goes through PyTorch-ROCm
-            self._evaluator = HipNetEvaluator(net, (rows, cols, eng.n_actions), eng.device, max_boards=1) \
+            self._evaluator = HipNetEvaluator(net, (rows, cols, eng.n_actions), eng.device, max_boards=eng.n_leaves) \
                 if type(net) is PolicyValueNet else NetEvaluator(net)
         else:
             from ..games.connect4.connect4_env import Connect4Env
@@ -119,6 +123,7 @@ class AlphaZeroMCTS(object):
                 make = lambda s0, s1, to_move, last: GomokuEnv.from_bitboards(size, n_row, s0, s1, to_move, last)  # noqa: E731
             self._evaluator = HostEvaluator(lambda env: self.policy_value_fn(env), make)
         self._engine = eng
+        self._bound_k = self.sims_in_flight
         return eng
 
     def _import_root(self, game_env):
@@ -186,12 +191,13 @@ class AlphaZeroPlayer(Player):
 
     def __init__(self, policy_value_fn, n_playout: int = 1000, c_puct: float = 5,
                  is_selfplay: bool = False, player_id: int = 0, player_name: str = '',
-                 device=None, score_mode: str = 'uct_ref') -> None:
+                 device=None, score_mode: str = 'uct_ref', sims_in_flight: int = 1) -> None:
         super().__init__(player_id, player_name)
         self.is_selfplay = is_selfplay
         self.add_noise = is_selfplay
         self.mcts = AlphaZeroMCTS(policy_value_fn, n_playout=n_playout, c_puct=c_puct,
-                                  add_noise=self.add_noise, device=device, score_mode=score_mode)
+                                  add_noise=self.add_noise, device=device, score_mode=score_mode,
+                                  sims_in_flight=sims_in_flight)
 
     def reset_player(self):
         self.mcts.update_with_move(-1)

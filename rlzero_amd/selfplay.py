@@ -203,16 +203,19 @@ class BatchedSelfPlay(object):
     @classmethod
     def for_network(cls, net_module, board, n_in_row, n_games, n_playout, c_puct=5.0, device='cuda:0',
                     game='gomoku', net_shape=None, lanes=None, trunk_workgroups=None, temperature=1.0, seed=0,
-                    use_graph=True, sims_per_graph=8, eager_every=0, add_noise=True, **engine_kw):
+                    use_graph=True, sims_per_graph=8, eager_every=0, add_noise=True, sims_in_flight=1, **engine_kw):
         """Self-play of ``n_games`` games in flight with the hand-written evaluator of ``net_module`` (a
         PolicyValueNet): builds the lanes (engine + HipNetEvaluator each) as plan_lanes() recommends, unless
         ``lanes`` / ``trunk_workgroups`` are given.  ``add_noise``: Dirichlet noise on the priors of every expanded
-        node, what ``AlphaZeroPlayer(is_selfplay=True)`` does (alphazero_mcts.py:124-129, node.py:63-69)."""
+        node, what ``AlphaZeroPlayer(is_selfplay=True)`` does (alphazero_mcts.py:124-129, node.py:63-69).
+        ``sims_in_flight`` = K > 1: the opt-in virtual-loss mode (MCTSEngine), for batches too small to fill the GPU
+        with one leaf per game; the evaluator batch of a lane is then its games x K."""
         import torch
         from .engine import HipNetEvaluator, MCTSEngine
         dev = torch.device(device)
         n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        auto_lanes, auto_wgs = plan_lanes(n_games, n_cus)
+        K = max(1, int(sims_in_flight))
+        auto_lanes, auto_wgs = plan_lanes(n_games * K, n_cus)
         if lanes is None:
             lanes, wgs = auto_lanes, auto_wgs
         else:
@@ -224,10 +227,10 @@ class BatchedSelfPlay(object):
         engines, evaluators = [], []
         for g_lane in per_lane:
             engines.append(MCTSEngine(board, n_in_row, n_games=g_lane, n_playout=n_playout, c_puct=c_puct,
-                                      device=str(device), game=game, add_noise=add_noise,
+                                      device=str(device), game=game, add_noise=add_noise, sims_in_flight=K,
                                       noise_seed=(int(seed) * 7919 + len(engines)) & 0x7fffffff, **engine_kw))
             ev = HipNetEvaluator(net_module, net_shape if net_shape is not None else board, str(device),
-                                 max_boards=g_lane)
+                                 max_boards=g_lane * K)
             ev.hip.set_max_workgroups(max(0, int(wgs)))
             evaluators.append(ev)
         sp = cls(engines if lanes > 1 else engines[0], evaluators if lanes > 1 else evaluators[0],
@@ -242,7 +245,7 @@ class BatchedSelfPlay(object):
         runs the chunk once).  Weight updates keep the graphs valid: rz_net_load reuses its device buffers."""
         if not self.use_graph:
             return
-        per = max(1, int(self.sims_per_graph))
+        per = self.eng.graph_chunk(self.sims_per_graph)
         for lane in self.lanes:
             with self._on(lane):
                 lane.eng.reset_games()
@@ -283,7 +286,7 @@ class BatchedSelfPlay(object):
     def _simulate(self):
         n = self.eng.n_playout
         if self.use_graph:
-            per = max(1, int(self.sims_per_graph))
+            per = self.eng.graph_chunk(self.sims_per_graph)
             full, n = divmod(n, per)
             for c in range(full):
                 eager = self.eager_every > 0 and c % self.eager_every == 0
@@ -299,7 +302,7 @@ class BatchedSelfPlay(object):
                 lane.eng.sim_chunk(lane.evaluator, n)
         elif n:
             # interleave the lanes in chunks so that their kernels alternate on the device
-            chunk = 8
+            chunk = self.eng.graph_chunk(8)
             for c0 in range(0, n, chunk):
                 for lane in self.lanes:
                     with self._on(lane):

@@ -39,8 +39,8 @@ def test_binding_covers_the_header(lib_path):
 
 def test_config_struct_layout_matches_header():
     from rlzero_amd import _hip
-    # 8 int32, 2 doubles, 4 int32 -> 64 bytes, doubles 8-aligned at offset 32
-    assert ctypes.sizeof(_hip.RzConfig) == 64
+    # 8 int32, 2 doubles, 6 int32 -> 72 bytes, doubles 8-aligned at offset 32
+    assert ctypes.sizeof(_hip.RzConfig) == 72
     assert _hip.RzConfig.c_puct.offset == 32 and _hip.RzConfig.device.offset == 48
     assert ctypes.sizeof(_hip.RzStats) == 64
 

@@ -467,6 +467,23 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
                     R[2 * (top + i)] = a;
                     R[2 * (top + i) + 1] = b;
                 }
+                if (VL) {
+                    // the paths of the slots selected earlier in this step are still pending and hold slot indices:
+                    // entries inside the block that has just moved follow it
+                    for (int jj = 0; jj < j; ++jj) {
+                        const int gj = g * E.K + jj;
+                        int32_t *pj = E.path + (long long)gj * E.path_stride;
+                        const int dj = E.leaf_depth[gj];
+                        for (int d = lane; d <= dj; d += kWave) {
+                            const int q = pj[d];
+                            if (q >= fc && q < fc + nv) pj[d] = q - fc + top;
+                        }
+                        if (lane == 0) {
+                            const int q = E.leaf_node[gj];
+                            if (q >= fc && q < fc + nv) E.leaf_node[gj] = q - fc + top;
+                        }
+                    }
+                }
                 fc = top;
                 top += ncap;
                 cap = ncap;

@@ -93,3 +93,8 @@ def bits_of_planes(obs):
 @pytest.fixture(scope='session')
 def g6():
     return load_golden_json('g6_rollout.json')
+
+
+@pytest.fixture(scope='session')
+def g7():
+    return load_golden_json('g7_train.json')

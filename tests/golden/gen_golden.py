@@ -12,6 +12,10 @@ not travel to the GPU box, so its outputs are committed here as data:
   g2_netleaf.json.gz a search driven by the real net on CPU: per-simulation leaf values
   g4_net.npz       PolicyValueNet outputs for deterministic numpy weights
   g5_equi.npz      TrainPipeline.get_equi_data for one asymmetric sample
+  g7_train.json.gz  the reference's TrainPipeline.run() (tools/train_alphazero.py) for 4 batches at 50 playouts: per batch
+                   episode_len, buffer length, the moves of the game, and every number policy_update prints
+                   (kl, lr_multiplier, loss, entropy, explained variances); search driven by vlin + injected uniforms
+                   (exactly reproducible data), learner = the reference's AlphaZeroAgent.learn on numpy_weights
   g6_rollout.json.gz pure-MCTS opponent (RolloutMCTS / RolloutPlayer) with np.random.rand drawn from a
                    recorded private stream: root statistics, chosen moves, a full duel
 
@@ -475,6 +479,63 @@ def gen_g6():
     return {'cases': cases, 'duel': duel}
 
 
+def gen_g7():
+    """TrainPipeline.run() of the reference, 4 batches.  The self-play search is driven by the exactly representable
+    vlin evaluator with injected move uniforms, so the collected (state, pi, z) data are reproducible bit for bit on
+    any host; the learner is the reference's own (AlphaZeroAgent.learn on CPU, deterministic numpy weights), so
+    loss / entropy / kl pin policy_update + learn (train_alphazero.py:92-137, alphazero_agent.py:59-86)."""
+    import contextlib
+    import io
+    import random
+    import tempfile
+    spec = importlib.util.spec_from_file_location('ref_train7', '/root/reference/tools/train_alphazero.py')
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    seed, wseed, n_playout, batches = 70, 71, 50, 4
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    random.seed(seed)
+    cwd = os.getcwd()
+    inj = InjectedChoice(seed)
+    records = []
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        np.random.choice = inj
+        try:
+            pipe = mod.TrainPipeline()
+            pipe.n_playout = n_playout
+            pipe.game_batch_num = batches
+            load_numpy_weights(pipe.alphazero_agent, pipe.board_size, wseed)
+            pipe.mcts_player = AlphaZeroPlayer(vlin, n_playout=n_playout, c_puct=pipe.c_puct, is_selfplay=True)
+            real_collect, real_update = pipe.collect_selfplay_data, pipe.policy_update
+
+            def collect(n_games=1):
+                real_collect(n_games)
+                records.append({'episode_len': int(pipe.episode_len), 'buffer_len': len(pipe.data_buffer),
+                                'moves': [int(m) for m in pipe.board.states.keys()], 'u_used': len(inj.used)})
+
+            def update():
+                loss, entropy = real_update()
+                records[-1].update({'loss': hexf(loss), 'entropy': hexf(entropy),
+                                    'lr_multiplier': hexf(pipe.lr_multiplier)})
+                return loss, entropy
+
+            pipe.collect_selfplay_data, pipe.policy_update = collect, update
+            out = io.StringIO()
+            with contextlib.redirect_stdout(out):
+                pipe.run()
+        finally:
+            np.random.choice = inj.real
+            os.chdir(cwd)
+    sd = pipe.alphazero_agent.policy_value_net.state_dict()
+    return {'seed': seed, 'weight_seed': wseed, 'B': pipe.board_size, 'n': pipe.n_in_row, 'n_playout': n_playout,
+            'c_puct': pipe.c_puct, 'temperature': pipe.temperature, 'batch_size': pipe.batch_size, 'epochs': pipe.epochs,
+            'buffer_size': pipe.buffer_size, 'batches': records, 'u': [hexf(u) for u in inj.used],
+            'stdout': out.getvalue().splitlines(),
+            'final_weights_abs_sum': {k: hexf(float(v.double().abs().sum())) for k, v in sd.items()},
+            'final_conv1_head': [hexf(float(x)) for x in sd['conv1.weight'].flatten()[:8]]}
+
+
 def write_json(name, obj):
     path = os.path.join(HERE, name + '.gz')
     with gzip.GzipFile(path, 'wb', mtime=0) as f:  # mtime=0: reproducible bytes
@@ -489,6 +550,7 @@ def main():
     write_json('g3_games.json', gen_g3())
     write_json('g2_netleaf.json', gen_netleaf())
     write_json('g6_rollout.json', gen_g6())
+    write_json('g7_train.json', gen_g7())
     np.savez_compressed(os.path.join(HERE, 'g4_net.npz'), **gen_g4())
     np.savez_compressed(os.path.join(HERE, 'g5_equi.npz'), **gen_g5())
     for name in ('g4_net.npz', 'g5_equi.npz'):

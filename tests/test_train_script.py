@@ -38,6 +38,127 @@ def test_reference_import_lines_and_names():
         assert callable(getattr(mod.TrainPipeline, name))
 
 
+def _numbers(line):
+    """'kl:0.00087,lr_multiplier:1.500,loss:4.55,...' -> {name: float}"""
+    return {k: float(v) for k, v in (item.split(':') for item in line.split(','))}
+
+
+def _run_g7(mod, g7, pipe, capsys, tol):
+    """pipe.run() of this repository's twin against the reference's captured run: same episode_len / buffer
+    length per batch, same log lines, every number policy_update prints within ``tol``."""
+    import random
+    import torch
+    from conftest import unhex
+    from oracle.evaluators import numpy_weights
+    torch.manual_seed(g7['seed'])
+    np.random.seed(g7['seed'])
+    random.seed(g7['seed'])
+    pipe.alphazero_agent.policy_value_net.load_state_dict(
+        {k: torch.from_numpy(v) for k, v in numpy_weights(g7['B'], g7['weight_seed']).items()})
+    losses = []
+    real_update = pipe.policy_update
+    pipe.policy_update = lambda: losses.append(real_update()) or losses[-1]
+    seen = []
+    real_collect = pipe.collect_selfplay_data
+
+    def collect(n_games=1):
+        real_collect(n_games)
+        seen.append((pipe.episode_len, len(pipe.data_buffer)))
+
+    pipe.collect_selfplay_data = collect
+    capsys.readouterr()
+    pipe.run()
+    out = capsys.readouterr().out.splitlines()
+    want = g7['stdout']
+    assert seen == [(b['episode_len'], b['buffer_len']) for b in g7['batches']]
+    assert len(out) == len(want)
+    for got_line, want_line in zip(out, want):
+        if want_line.startswith('batch i:'):
+            assert got_line == want_line
+        else:
+            a, b = _numbers(got_line), _numbers(want_line)
+            assert list(a) == list(b)
+            printed = {'kl': 1e-5, 'lr_multiplier': 0.0, 'explained_var_old': 1e-3, 'explained_var_new': 1e-3}
+            for k in a:  # loss / entropy are printed in full; the others rounded to 5 / 3 decimals
+                assert abs(a[k] - b[k]) <= 10 * tol + printed.get(k, 0.0), (k, a[k], b[k])
+    for (loss, entropy), b in zip(losses, g7['batches']):
+        assert abs(loss - unhex(b['loss'])) <= tol and abs(entropy - unhex(b['entropy'])) <= tol
+    assert pipe.lr_multiplier == unhex(g7['batches'][-1]['lr_multiplier'])
+    sd = pipe.alphazero_agent.policy_value_net.state_dict()
+    for k, v in g7['final_weights_abs_sum'].items():
+        assert abs(float(sd[k].double().abs().sum()) - unhex(v)) <= 100 * tol * max(1.0, unhex(v)), k
+
+
+def test_training_run_matches_the_reference_on_cpu(g7, capsys, monkeypatch, tmp_path):
+    """The reference's 4-batch TrainPipeline.run() (tests/golden/g7_train.json.gz, captured from the reference itself)
+    against this repository's trainer twin + AlphaZeroAgent.learn on the CPU.  The games come from the oracle driven
+    by the fixture's uniforms (the same vlin search the reference ran; the HIP search is compared with it in the gpu
+    twin of this test), everything behind them -- get_equi_data, the deque, random.sample, policy_update, learn, the
+    log lines -- is the product's code: loss / entropy to 1e-5 (train_alphazero.py:92-137,170; alphazero_agent.py:59-86)."""
+    import torch
+    from conftest import unhex
+    from oracle import evaluators as ev
+    from oracle.gomoku_ref import RefGomoku
+    from oracle.mcts_ref import RefPlayer, inverse_cdf_choice, self_play_game
+    torch.set_num_threads(1)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(torch.cuda, 'is_available', lambda: False)  # the trainer picks its device from this
+    mod = _load()
+    pipe = mod.TrainPipeline(board_size=g7['B'], n_in_row=g7['n'], n_playout=g7['n_playout'],
+                             game_batch_num=len(g7['batches']), check_freq=50)
+    choice = inverse_cdf_choice([unhex(u) for u in g7['u']])
+    moves_seen = []
+
+    def oracle_self_play(player, temperature=1e-3):
+        ref_player = RefPlayer(ev.vlin, g7['n_playout'], g7['c_puct'], is_selfplay=True, choice=choice)
+        winner, data, moves = self_play_game(RefGomoku(g7['B'], g7['n']), ref_player, temperature=temperature)
+        moves_seen.append(moves)
+        return winner, data
+
+    pipe.game.start_self_play = oracle_self_play
+    _run_g7(mod, g7, pipe, capsys, 1e-5)
+    assert moves_seen == [b['moves'] for b in g7['batches']]
+    assert len(choice.used) == len(g7['u'])
+
+
+@pytest.mark.gpu
+def test_training_run_matches_the_reference_on_gpu(g7, capsys, monkeypatch, tmp_path):
+    """The same captured reference run against the WHOLE product on the MI355X: self-play through
+    GameControl.start_self_play / AlphaZeroPlayer on the HIP engine (vlin as a host policy_value_fn, the reference's
+    np.random.choice fed the fixture's uniforms), learner on the GPU: identical games and buffer, loss / entropy within
+    1e-4 of the reference's CPU numbers (20 Adam steps on another device's convolution kernels)."""
+    from conftest import unhex
+    from oracle import evaluators as ev
+    from rlzero.mcts.alphazero_mcts import AlphaZeroPlayer
+    monkeypatch.chdir(tmp_path)
+    mod = _load()
+    pipe = mod.TrainPipeline(board_size=g7['B'], n_in_row=g7['n'], n_playout=g7['n_playout'],
+                             game_batch_num=len(g7['batches']), check_freq=50)
+    assert str(pipe.device).startswith('cuda')
+    pipe.mcts_player = AlphaZeroPlayer(ev.vlin, n_playout=g7['n_playout'], c_puct=g7['c_puct'], is_selfplay=True)
+    us = iter([unhex(u) for u in g7['u']])
+
+    def choice(acts, p=None):
+        cdf = np.cumsum(np.asarray(p, dtype=np.float64))
+        cdf /= cdf[-1]
+        return np.asarray(acts)[cdf.searchsorted(next(us), side='right')]
+
+    monkeypatch.setattr(np.random, 'choice', choice)
+    games = []
+    real = pipe.game.start_self_play
+
+    def spy(player, temperature=1e-3):
+        winner, data = real(player, temperature=temperature)
+        games.append([int(m) for m in pipe.board.states.keys()])
+        return winner, data
+
+    pipe.game.start_self_play = spy
+    _run_g7(mod, g7, pipe, capsys, 1e-4)
+    assert games == [b['moves'] for b in g7['batches']]
+    assert next(us, None) is None
+    pipe.mcts_player.mcts._engine.close()
+
+
 @pytest.mark.gpu
 def test_train_pipeline_runs_on_gpu(tmp_path, capsys, monkeypatch):
     """Two batches of the reference flow and one batched collection: data flows from the GPU

@@ -489,7 +489,7 @@ def main():
                          'game length)')
     ap.add_argument('--no-literal-config', action='store_true',
                     help='skip the extra N=1 measurement of the literal configs[3] share: 1 lane x %d games' % GAMES_PER_GPU)
-    ap.add_argument('--heads-algo', default='auto', choices=['auto', 'f32', 'split32', 'split64'],
+    ap.add_argument('--heads-algo', default='auto', choices=['auto', 'f32', 'split32', 'split64', 'parts'],
                     help='GEMM of the first FC layers (rz_net_set_heads_algo)')
     ap.add_argument('--noise', type=int, default=1,
                     help='Dirichlet(0.3) noise mixed into the priors of EVERY expanded node, as the reference does in '

@@ -205,15 +205,33 @@ int rz_expand_backup_probs(rz_engine *e, const float *d_probs, const double *d_v
  * share a kernel boundary).  Same arguments as the two calls it replaces. */
 int rz_tree_step(rz_engine *e, const float *d_logp, const float *d_value, float *d_obs, void *stream);
 
-/* The same two entry points fed with the evaluator's UN-NORMALISED head outputs: policy logits
- * d_raw [n_games][ld] (ld >= A) and the value head's hidden layer d_hid [n_games][64] with its last
- * weights d_w2 [64], d_b2 [1]; log_softmax and tanh(hid . w2 + b2) are finished inside the tree
- * kernel (same wave per game), saving the separate rz_net_heads finishing launch.  Pair with
+/* The evaluator's UN-NORMALISED head outputs, as rz_net_heads_gemm leaves them: policy logits raw [rows][ld] (ld >= A)
+ * and the value head's hidden layer hid [rows][64] with its last weights w2 [64], b2 [1].  n_parts == 1: raw / hid are
+ * final (bias added, hid ReLU'd).  n_parts == 4 (RZ_NET_HEADS_SPLIT_PARTS): raw / hid hold the four K-quarter partial
+ * sums of the FC GEMM, part q at raw + q * raw_part_stride / hid + q * hid_part_stride (floats), and the consumer
+ * finishes logit = ((p0 + p1) + p2) + p3 -> fmaf(sum, *act_scale, act_bias[a]), hidden unit = relu(fmaf(sum,
+ * *val_scale, val_bias[u])) -- the very operations, in the very order, of the GEMM kernels that reduce the parts
+ * themselves, so every route gives the same bits. */
+typedef struct rz_raw_heads {
+    const float *raw;
+    const float *hid;
+    const float *w2;
+    const float *b2;
+    const float *act_scale; /* [1], n_parts == 4 only */
+    const float *act_bias;  /* [ld] */
+    const float *val_scale; /* [1] */
+    const float *val_bias;  /* [64] */
+    int64_t raw_part_stride;
+    int64_t hid_part_stride;
+    int32_t ld;
+    int32_t n_parts;
+} rz_raw_heads;
+
+/* rz_expand_backup / rz_tree_step fed with those outputs: log_softmax and tanh(hid . w2 + b2) are finished inside the
+ * tree kernel (same wave per game), saving the separate rz_net_heads finishing launch.  Pair with
  * rz_net_trunk(.., NULL, ..) + rz_net_heads_gemm.  Bit-identical to the un-fused route. */
-int rz_expand_backup_raw(rz_engine *e, const float *d_raw, int32_t ld, const float *d_hid, const float *d_w2,
-                         const float *d_b2, void *stream);
-int rz_tree_step_raw(rz_engine *e, const float *d_raw, int32_t ld, const float *d_hid, const float *d_w2,
-                     const float *d_b2, float *d_obs, void *stream);
+int rz_expand_backup_raw(rz_engine *e, const rz_raw_heads *heads, void *stream);
+int rz_tree_step_raw(rz_engine *e, const rz_raw_heads *heads, float *d_obs, void *stream);
 
 /* Root statistics after the simulations (AlphaZeroMCTS.simulate, alphazero_mcts.py:88-90):
  * visit count / W of the root child of every action, 0 for illegal or unvisited actions;
@@ -308,9 +326,13 @@ int rz_net_set_max_workgroups(rz_net *net, int32_t max_workgroups);
  * buffer, and falls back to F32 when the last trunk was another one.
  * RZ_NET_HEADS_AUTO (default): after the RZ_NET_SPLIT_F16 trunk SPLIT_64 when the trunk is capped by
  * rz_net_set_max_workgroups (the GEMM then has only the few CUs the trunk leaves free) and SPLIT_32 otherwise -- both
- * give the same bits; F32 after the other trunks.  Choose before the trunk is launched: into the internal buffer the
+ * give the same bits; F32 after the other trunks.  RZ_NET_HEADS_SPLIT_PARTS: the same arithmetic with NO reduction inside
+ * the GEMM -- one single-wave workgroup per (32 boards x 32 outputs x K quarter), no LDS, few registers, so its waves fit on
+ * a CU beside a resident trunk workgroup of another lane; the four partial sums are added by the consumer (the tree kernel
+ * of the fused route, k_heads_finish otherwise; see rz_raw_heads) in the order the other shapes use: same bits again.
+ * Choose before the trunk is launched: into the internal buffer the
  * RZ_NET_SPLIT_F16 trunk writes only what the chosen GEMM reads (F32 chosen later runs SPLIT on the pieces present). */
-enum { RZ_NET_HEADS_AUTO = 0, RZ_NET_HEADS_F32 = 1, RZ_NET_HEADS_SPLIT_32 = 2, RZ_NET_HEADS_SPLIT_64 = 3 };
+enum { RZ_NET_HEADS_AUTO = 0, RZ_NET_HEADS_F32 = 1, RZ_NET_HEADS_SPLIT_32 = 2, RZ_NET_HEADS_SPLIT_64 = 3, RZ_NET_HEADS_SPLIT_PARTS = 4 };
 int rz_net_set_heads_algo(rz_net *net, int32_t heads_algo);
 int rz_net_create(int32_t height, int32_t width, int32_t n_actions, int32_t device, rz_net **out);
 int rz_net_destroy(rz_net *net);
@@ -322,8 +344,7 @@ int rz_net_trunk(rz_net *net, const float *d_obs, int32_t n_boards, float *d_fea
 int rz_net_heads(rz_net *net, int32_t n_boards, float *d_logp, float *d_value, void *stream);
 /* only the FC GEMM of the heads on the internal features; returns the device pointers that
  * rz_tree_step_raw / rz_expand_backup_raw consume (valid until the next rz_net_reserve / load) */
-int rz_net_heads_gemm(rz_net *net, int32_t n_boards, const float **d_raw, int32_t *ld, const float **d_hid,
-                      const float **d_w2, const float **d_b2, void *stream);
+int rz_net_heads_gemm(rz_net *net, int32_t n_boards, rz_raw_heads *out, void *stream);
 int rz_net_forward(rz_net *net, const float *d_obs, int32_t n_boards, float *d_logp,
                    float *d_value, void *stream);
 

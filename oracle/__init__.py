@@ -5,8 +5,7 @@ only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may import it, and there only as the checker / the timed CPU baseline.
 ``rlzero_amd`` never imports this package.
 
-What it is: a from-scratch restatement, in plain Python (+ a C twin under
-``oracle/c`` for full-size cases), of the algorithm the reference implements in
+What it is: a from-scratch restatement, in plain Python, of the algorithm the reference implements in
 
 * ``rlzero/mcts/node.py``            (tree node, UCT select, expand, backup)
 * ``rlzero/mcts/alphazero_mcts.py``  (playout, simulate, player, tree reuse)

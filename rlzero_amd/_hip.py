@@ -18,7 +18,7 @@ SCORE_UCT_REF, SCORE_PUCT = 0, 1
 GAME_GOMOKU, GAME_CONNECT4 = 0, 1
 NET_DIRECT, NET_WINOGRAD_F4, NET_SPLIT_F16 = 0, 1, 2
 NET_FLAG_F16_RANGE = 1
-NET_HEADS_AUTO, NET_HEADS_F32, NET_HEADS_SPLIT_32, NET_HEADS_SPLIT_64 = 0, 1, 2, 3
+NET_HEADS_AUTO, NET_HEADS_F32, NET_HEADS_SPLIT_32, NET_HEADS_SPLIT_64, NET_HEADS_SPLIT_PARTS = 0, 1, 2, 3, 4
 EVAL_V0, EVAL_VLIN = 0, 1
 FLAG_NAMES = {1: 'arena full', 2: 'block queue full', 4: 'illegal move', 8: 'ln table too short',
               16: 'internal'}
@@ -44,6 +44,13 @@ class RzMzConfig(Structure):
     _fields_ = [('abi_version', c_int32), ('n_games', c_int32), ('n_actions', c_int32), ('n_sims', c_int32),
                 ('discount', c_double), ('pb_c_base', c_double), ('pb_c_init', c_double),
                 ('device', c_int32), ('reserved', c_int32)]
+
+
+class RzRawHeads(Structure):
+    """rz_raw_heads: the FC GEMM's outputs as the tree kernels consume them (device pointers)."""
+    _fields_ = [('raw', c_void_p), ('hid', c_void_p), ('w2', c_void_p), ('b2', c_void_p), ('act_scale', c_void_p),
+                ('act_bias', c_void_p), ('val_scale', c_void_p), ('val_bias', c_void_p), ('raw_part_stride', c_int64),
+                ('hid_part_stride', c_int64), ('ld', c_int32), ('n_parts', c_int32)]
 
 
 class HipError(RuntimeError):
@@ -74,8 +81,8 @@ _SIGNATURES = {
     'rz_expand_backup_f64': (c_int, [P, P, P, P]),
     'rz_expand_backup_probs': (c_int, [P, P, P, P]),
     'rz_tree_step': (c_int, [P, P, P, P, P]),
-    'rz_expand_backup_raw': (c_int, [P, P, c_int32, P, P, P, P]),
-    'rz_tree_step_raw': (c_int, [P, P, c_int32, P, P, P, P, P]),
+    'rz_expand_backup_raw': (c_int, [P, POINTER(RzRawHeads), P]),
+    'rz_tree_step_raw': (c_int, [P, POINTER(RzRawHeads), P, P]),
     'rz_root_visits': (c_int, [P, P, P]),
     'rz_root_wsum': (c_int, [P, P, P]),
     'rz_root_priors': (c_int, [P, P, P]),
@@ -98,8 +105,7 @@ _SIGNATURES = {
     'rz_net_reserve': (c_int, [P, c_int32]),
     'rz_net_trunk': (c_int, [P, P, c_int32, P, P]),
     'rz_net_heads': (c_int, [P, c_int32, P, P, P]),
-    'rz_net_heads_gemm': (c_int, [P, c_int32, POINTER(c_void_p), POINTER(c_int32), POINTER(c_void_p),
-                                  POINTER(c_void_p), POINTER(c_void_p), P]),
+    'rz_net_heads_gemm': (c_int, [P, c_int32, POINTER(RzRawHeads), P]),
     'rz_net_forward': (c_int, [P, P, c_int32, P, P, P]),
     'rz_mz_create': (c_int, [POINTER(RzMzConfig), POINTER(c_void_p)]),
     'rz_mz_destroy': (c_int, [P]),

@@ -101,12 +101,13 @@ __device__ __forceinline__ double *rec_wsum(int4 *R, int slot) { return reinterp
 __device__ __forceinline__ int32_t *rec_pb(int4 *R, int slot) { return reinterpret_cast<int32_t *>(R + 2 * slot + 1) + 2; }
 
 // ------------------------------------------------------------------ bitboard helpers
+// a[j] for a lane-dependent j, as pure ALU on the four VALUES (masks, no selects of array elements): hipcc turns a
+// chain of `j == i ? a[i] : r` into ONE load with a selected address, which pins the whole board array in scratch
+// memory (a memory round trip inside the dependent chain of the tree kernels; 106 scratch instructions before)
 __device__ __forceinline__ uint64_t word_of(const uint64_t *a, int j) {
-    uint64_t r = a[0];
-    r = (j == 1) ? a[1] : r;
-    r = (j == 2) ? a[2] : r;
-    r = (j == 3) ? a[3] : r;
-    return r;
+    const uint64_t m0 = j == 0 ? ~0ull : 0ull, m1 = j == 1 ? ~0ull : 0ull, m2 = j == 2 ? ~0ull : 0ull,
+                   m3 = j == 3 ? ~0ull : 0ull;
+    return (a[0] & m0) | (a[1] & m1) | (a[2] & m2) | (a[3] & m3);
 }
 __device__ __forceinline__ bool test_bit(const uint64_t *a, int c) {
     return (word_of(a, c >> 6) >> (c & 63)) & 1ull;
@@ -368,44 +369,42 @@ template <bool PUCT>
 __device__ __forceinline__ int scan_children(const Dev &E, const int4 *R, const float *P, const int4 &lo,
                                              const int4 &hi, double parent_term, int lane, int4 &clo, int4 &chi) {
     const int k = rec_k(lo), fc = lo.y, pb = hi.z;
-    int4 klo[kWords], khi[kWords];
+    // the lane's (up to) four children r0 = lane + 64 j: all loads first, then the scores; the lane keeps the RECORD
+    // of its best child in registers (no array survives the loop: an array of records selected by a run-time index
+    // ends up in scratch memory), and the wave's winner is the best child of the lane that owns it
+    int4 l0 = make_int4(0, -1, 0, 0), l1 = l0, l2 = l0, l3 = l0;
+    int4 h0 = make_int4(0, 0, -1, 0), h1 = h0, h2 = h0, h3 = h0;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+    if (lane < k) { l0 = R[2 * (fc + lane)]; h0 = R[2 * (fc + lane) + 1]; if (PUCT) p0 = P[pb + lane]; }
+    if (lane + 64 < k) { l1 = R[2 * (fc + lane + 64)]; h1 = R[2 * (fc + lane + 64) + 1]; if (PUCT) p1 = P[pb + lane + 64]; }
+    if (lane + 128 < k) { l2 = R[2 * (fc + lane + 128)]; h2 = R[2 * (fc + lane + 128) + 1]; if (PUCT) p2 = P[pb + lane + 128]; }
+    if (lane + 192 < k) { l3 = R[2 * (fc + lane + 192)]; h3 = R[2 * (fc + lane + 192) + 1]; if (PUCT) p3 = P[pb + lane + 192]; }
     double best = -INFINITY;
     int besti = 0x7fffffff;
-#pragma unroll
-    for (int j = 0; j < kWords; ++j) {
-        const int r0 = lane + 64 * j;
-        klo[j] = make_int4(0, -1, 0, 0);
-        khi[j] = make_int4(0, 0, -1, 0);
+    int4 blo = l0, bhi = h0;
+    auto consider = [&](const int4 &cl, const int4 &ch, float prior, int r0) {
         if (r0 < k) {
-            klo[j] = R[2 * (fc + r0)];
-            khi[j] = R[2 * (fc + r0) + 1];
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < kWords; ++j) {
-        const int r0 = lane + 64 * j;
-        if (r0 < k) {
-            const double sc = PUCT ? puct(rec_w(khi[j]), klo[j].x, P[pb + r0], parent_term, E.c_puct)
-                                   : uct_ref(rec_w(khi[j]), klo[j].x, parent_term, E.c_puct);
+            const double sc = PUCT ? puct(rec_w(ch), cl.x, prior, parent_term, E.c_puct)
+                                   : uct_ref(rec_w(ch), cl.x, parent_term, E.c_puct);
             if (sc > best) {
                 best = sc;
                 besti = r0;
+                blo = cl;
+                bhi = ch;
             }
         }
-    }
+    };
+    consider(l0, h0, p0, lane);
+    consider(l1, h1, p1, lane + 64);
+    consider(l2, h2, p2, lane + 128);
+    consider(l3, h3, p3, lane + 192);
     const int r = __builtin_amdgcn_readfirstlane(wave_first_max(best, besti));
     if (r >= k) return r;
-    const int j = r >> 6, l = r & 63;
-    int4 a = klo[0], b = khi[0];
-#pragma unroll
-    for (int t = 1; t < kWords; ++t) {
-        a = (j == t) ? klo[t] : a;
-        b = (j == t) ? khi[t] : b;
-    }
-    clo = make_int4(__builtin_amdgcn_readlane(a.x, l), __builtin_amdgcn_readlane(a.y, l),
-                    __builtin_amdgcn_readlane(a.z, l), __builtin_amdgcn_readlane(a.w, l));
-    chi = make_int4(__builtin_amdgcn_readlane(b.x, l), __builtin_amdgcn_readlane(b.y, l),
-                    __builtin_amdgcn_readlane(b.z, l), __builtin_amdgcn_readlane(b.w, l));
+    const int l = r & 63;
+    clo = make_int4(__builtin_amdgcn_readlane(blo.x, l), __builtin_amdgcn_readlane(blo.y, l),
+                    __builtin_amdgcn_readlane(blo.z, l), __builtin_amdgcn_readlane(blo.w, l));
+    chi = make_int4(__builtin_amdgcn_readlane(bhi.x, l), __builtin_amdgcn_readlane(bhi.y, l),
+                    __builtin_amdgcn_readlane(bhi.z, l), __builtin_amdgcn_readlane(bhi.w, l));
     return r;
 }
 
@@ -575,16 +574,12 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
                   to_move == 0 ? st[1] : st[0], last, nst, S, lane);
 }
 
-// Un-normalised outputs of the evaluator's last GEMM, finished inside the tree kernel (same wave
-// per game): log_softmax over the A policy logits and value = tanh(hid . w2 + b2).  This is the
-// work of k_heads_finish (rz_net.hip), operation for operation, so both routes give identical bits.
-struct RawHeads {
-    const float *raw;  // [n_games][ld] policy logits
-    int ld;
-    const float *hid;  // [n_games][64] ReLU'd hidden layer of the value head
-    const float *w2;   // [64]
-    const float *b2;   // [1]
-};
+// Un-normalised outputs of the evaluator's last GEMM (rz_raw_heads, include/rlzero_hip.h), finished inside the tree
+// kernel (same wave per game): with n_parts == 4 the sum of the four K-quarter partial sums of the FC GEMM + scale +
+// bias (and ReLU for the value head's hidden units) -- the operations of k_heads_split's epilogue, in its order --
+// then log_softmax over the A policy logits and value = tanh(hid . w2 + b2), the work of k_heads_finish
+// (rz_net.hip), operation for operation, so every route gives identical bits.
+typedef rz_raw_heads RawHeads;
 
 // ------------------------------------------------------------------ EXPAND + BACKUP
 // PROBS: `logp` already holds probabilities (host evaluators hand over the callable's exact
@@ -617,13 +612,37 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
     float x[kWords] = {0.f, 0.f, 0.f, 0.f};  // RAW: the lane's policy logits, kept for the priors below
     if (RAW) {
         const float *r = rh.raw + (size_t)gk * rh.ld;
-        const float hid = rh.hid[(size_t)gk * 64 + lane], w2 = rh.w2[lane], b2 = rh.b2[0];
+        const float *hp = rh.hid + (size_t)gk * 64 + lane;
+        const float w2 = rh.w2[lane], b2 = rh.b2[0];
+        float hid = hp[0];
         float mx = -INFINITY;
+        if (rh.n_parts == 4) {
+            const long long rs = rh.raw_part_stride, hs = rh.hid_part_stride;
+            const float act_scale = rh.act_scale[0], val_scale = rh.val_scale[0];
+            float part[kWords][4], bias[kWords];
 #pragma unroll
-        for (int i = 0; i < kWords; ++i) {
-            const int j = lane + 64 * i;
-            x[i] = j < E.A ? r[j] : -INFINITY;
-            mx = fmaxf(mx, x[i]);
+            for (int i = 0; i < kWords; ++i) {
+                const int j = lane + 64 * i;
+                const bool in = j < E.A;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) part[i][q] = in ? r[j + q * rs] : 0.0f;
+                bias[i] = in ? rh.act_bias[j] : 0.0f;
+            }
+            const float h1 = hp[hs], h2 = hp[2 * hs], h3 = hp[3 * hs], hb = rh.val_bias[lane];
+#pragma unroll
+            for (int i = 0; i < kWords; ++i) {
+                const float sum4 = ((part[i][0] + part[i][1]) + part[i][2]) + part[i][3];
+                x[i] = lane + 64 * i < E.A ? fmaf(sum4, act_scale, bias[i]) : -INFINITY;
+                mx = fmaxf(mx, x[i]);
+            }
+            hid = fmaxf(fmaf(((hid + h1) + h2) + h3, val_scale, hb), 0.0f);
+        } else {
+#pragma unroll
+            for (int i = 0; i < kWords; ++i) {
+                const int j = lane + 64 * i;
+                x[i] = j < E.A ? r[j] : -INFINITY;
+                mx = fmaxf(mx, x[i]);
+            }
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
@@ -1557,19 +1576,20 @@ int rz_tree_step(rz_engine *e, const float *d_logp, const float *d_value, float 
     return launched("k_tree_step");
 }
 
-static int raw_heads_ok(rz_engine *e, const float *d_raw, int32_t ld, const float *d_hid, const float *d_w2,
-                        const float *d_b2) {
-    if (!d_raw || !d_hid || !d_w2 || !d_b2) return fail(RZ_ERR_ARG, "NULL device pointer");
-    if (ld < e->dev.A) return fail(RZ_ERR_ARG, "ld %d < n_actions %d", ld, e->dev.A);
+static int raw_heads_ok(rz_engine *e, const rz_raw_heads *h) {
+    if (!h || !h->raw || !h->hid || !h->w2 || !h->b2) return fail(RZ_ERR_ARG, "NULL device pointer");
+    if (h->ld < e->dev.A) return fail(RZ_ERR_ARG, "ld %d < n_actions %d", h->ld, e->dev.A);
+    if (h->n_parts != 1 && h->n_parts != 4) return fail(RZ_ERR_ARG, "n_parts %d is neither 1 nor 4", h->n_parts);
+    if (h->n_parts == 4 && (!h->act_scale || !h->act_bias || !h->val_scale || !h->val_bias))
+        return fail(RZ_ERR_ARG, "partial sums need their scales and biases");
     return RZ_OK;
 }
 
-int rz_expand_backup_raw(rz_engine *e, const float *d_raw, int32_t ld, const float *d_hid, const float *d_w2,
-                         const float *d_b2, void *stream) {
+int rz_expand_backup_raw(rz_engine *e, const rz_raw_heads *heads, void *stream) {
     RZ_ENTER(e);
-    int rc = raw_heads_ok(e, d_raw, ld, d_hid, d_w2, d_b2);
+    int rc = raw_heads_ok(e, heads);
     if (rc != RZ_OK) return rc;
-    const RawHeads rh = {d_raw, ld, d_hid, d_w2, d_b2};
+    const RawHeads rh = *heads;
     if (e->dev.K > 1) {
         k_tree_step_vl<true><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, nullptr, nullptr, rh, nullptr, e->kb, 0);
         return launched("k_tree_step_vl");
@@ -1578,13 +1598,12 @@ int rz_expand_backup_raw(rz_engine *e, const float *d_raw, int32_t ld, const flo
     return launched("k_expand_backup_raw");
 }
 
-int rz_tree_step_raw(rz_engine *e, const float *d_raw, int32_t ld, const float *d_hid, const float *d_w2,
-                     const float *d_b2, float *d_obs, void *stream) {
+int rz_tree_step_raw(rz_engine *e, const rz_raw_heads *heads, float *d_obs, void *stream) {
     RZ_ENTER(e);
-    int rc = raw_heads_ok(e, d_raw, ld, d_hid, d_w2, d_b2);
+    int rc = raw_heads_ok(e, heads);
     if (rc != RZ_OK) return rc;
     e->n_select += 1;
-    const RawHeads rh = {d_raw, ld, d_hid, d_w2, d_b2};
+    const RawHeads rh = *heads;
     if (e->dev.K > 1) {
         k_tree_step_vl<true><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, nullptr, nullptr, rh, d_obs, e->kb, e->ks);
         return launched("k_tree_step_vl");

@@ -1425,20 +1425,63 @@ __global__ __launch_bounds__(256) void k_heads_split(NetDev nd, const f32x4 *__r
     }
 }
 
+// k_heads_part: the arithmetic of k_heads_split with the reduction left to the consumer.  One single-wave workgroup
+// per (32-board tile, 32-output tile, K quarter): no LDS, no barrier, ~170 registers -- a wave fits on a SIMD beside a
+// wave of a resident k_trunk_split workgroup (344 registers of 512, 151 KB of LDS), so with two lanes of games this
+// GEMM runs UNDER the other lane's trunk on all CUs instead of waiting for it (or for CUs reserved for it).  Part q of
+// tile (m, n) goes to raw + q * raw_stride (policy) / hid + q * hid_stride (value) un-scaled; the consumer adds the four
+// parts in the order k_heads_split does, ((p0 + p1) + p2) + p3, then fmaf(sum, scale, bias): the same bits.
+// blockIdx = (board tile, output tile: policy tiles then the two value tiles, K quarter).
+template <int DEPTH>
+__global__ __launch_bounds__(64) void k_heads_part(NetDev nd, const f32x4 *__restrict__ feat16, float *__restrict__ raw,
+                                                   float *__restrict__ hid, long long raw_stride, long long hid_stride) {
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x;
+    const int mt = blockIdx.x, q = blockIdx.z;
+    const int steps_all = nd.groups_act + nd.groups_val;
+    const int n_act_tiles = nd.Npad / 32;
+    const f32x4 *fa = feat16 + (size_t)mt * steps_all * 128;
+    const f32x4 *zero = nd.fs_act + (size_t)n_act_tiles * nd.groups_act * 128;
+    const int col = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.y;
+    const bool is_act = tile < n_act_tiles;
+    const int vtile = tile - n_act_tiles;
+    const f32x4 *fb[1] = {is_act ? nd.fs_act + (size_t)tile * nd.groups_act * 128 : nd.fs_val + (size_t)vtile * nd.groups_val * 128};
+    sp::f32x16 acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.0f;
+    const int K = is_act ? nd.groups_act : nd.groups_val, k0 = q * K / 4, k1 = (q + 1) * K / 4;
+    fs_gemm<1, 1, DEPTH>(acc, fa, fb, zero, steps_all, is_act ? 0 : nd.groups_act, k0, k1, lane);
+    // rows for whole 64-board tiles exist in every part (rz_net_reserve): unconditional stores
+    float *dst = is_act ? raw + (size_t)q * raw_stride + (size_t)(32 * mt + 4 * h) * nd.Npad + 32 * tile + col
+                        : hid + (size_t)q * hid_stride + (size_t)(32 * mt + 4 * h) * 64 + 32 * vtile + col;
+    const size_t ld = is_act ? (size_t)nd.Npad : (size_t)64;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[(size_t)(8 * (r >> 2) + (r & 3)) * ld] = acc[0][0][r];
+}
+
 __global__ __launch_bounds__(64) void k_heads_finish(NetDev nd, const float *__restrict__ raw,
                                                      const float *__restrict__ hid, float *__restrict__ logp,
-                                                     float *__restrict__ value, int n_boards) {
+                                                     float *__restrict__ value, int n_boards, int n_parts,
+                                                     long long raw_stride, long long hid_stride) {
     __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.x, lane = threadIdx.x;
     if (b >= n_boards) return;
     const int S = nd.A;  // number of policy outputs
     const float *r = raw + (size_t)b * nd.Npad;
+    const float act_scale = nd.s_inv[3], val_scale = nd.s_inv[4];
     float v[4];
     float mx = -INFINITY;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int j = lane + 64 * i;
-        v[i] = j < S ? r[j] : -INFINITY;
+        v[i] = -INFINITY;
+        if (j < S) {
+            if (n_parts == 4)  // k_heads_part left the four K-quarter sums: finish them as k_heads_split does
+                v[i] = fmaf(((r[j] + r[j + raw_stride]) + r[j + 2 * raw_stride]) + r[j + 3 * raw_stride], act_scale, nd.fc_act_b[j]);
+            else
+                v[i] = r[j];
+        }
         mx = fmaxf(mx, v[i]);
     }
 #pragma unroll
@@ -1454,7 +1497,11 @@ __global__ __launch_bounds__(64) void k_heads_finish(NetDev nd, const float *__r
         const int j = lane + 64 * i;
         if (j < S) logp[(size_t)b * S + j] = v[i] - lse;
     }
-    float h = hid[(size_t)b * 64 + lane] * nd.fc_val2_w[lane];
+    const float *hp = hid + (size_t)b * 64 + lane;
+    float hv = hp[0];
+    if (n_parts == 4)
+        hv = fmaxf(fmaf(((hp[0] + hp[hid_stride]) + hp[2 * hid_stride]) + hp[3 * hid_stride], val_scale, nd.fc_val1_b[lane]), 0.0f);
+    float h = hv * nd.fc_val2_w[lane];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) h += __shfl_xor(h, off);
     if (lane == 0) value[b] = tanhf(h + nd.fc_val2_b[0]);
@@ -1479,6 +1526,8 @@ struct rz_net {
     bool feat16_valid = false;     // the last trunk launch into the internal buffer wrote d_feat16
     bool feat32_valid = false;     // ... wrote d_feat (the split-f16 trunk skips it when the GEMM reads the f16 pieces)
     int heads_algo = RZ_NET_HEADS_AUTO;
+    int raw_parts = 1;           // what the last launch_heads_gemm left in d_raw / d_hid: 1 = final, 4 = K-quarter sums
+    size_t raw_part_floats = 0, hid_part_floats = 0;  // stride between the parts
     unsigned *d_flags = nullptr;
     long long feat_boards = 0;
     size_t feat_floats = 0;
@@ -1877,8 +1926,8 @@ int rz_net_reserve(rz_net *net, int32_t max_boards) {
     const size_t pad_boards = ((size_t)max_boards + 31) / 32 * 32;
     net->feat_floats = pad_boards * 16 * (size_t)(net->dev.groups_act + net->dev.groups_val);
     if (hipMalloc((void **)&net->d_feat, net->feat_floats * sizeof(float)) != hipSuccess ||
-        hipMalloc((void **)&net->d_raw, (((size_t)max_boards + 63) / 64 * 64) * net->dev.Npad * sizeof(float)) != hipSuccess ||
-        hipMalloc((void **)&net->d_hid, (((size_t)max_boards + 63) / 64 * 64) * 64 * sizeof(float)) != hipSuccess)
+        hipMalloc((void **)&net->d_raw, 4 * (((size_t)max_boards + 63) / 64 * 64) * net->dev.Npad * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&net->d_hid, 4 * (((size_t)max_boards + 63) / 64 * 64) * 64 * sizeof(float)) != hipSuccess)
         return net_fail(RZ_ERR_OOM, "hipMalloc failed (feature buffers)");
     // padded boards and the K tail must read as finite values (they meet zero weights)
     if (hipMemset(net->d_feat, 0, net->feat_floats * sizeof(float)) != hipSuccess)
@@ -1890,6 +1939,8 @@ int rz_net_reserve(rz_net *net, int32_t max_boards) {
         if (hipMemset(net->d_feat16, 0, bytes) != hipSuccess)
             return net_fail(RZ_ERR_HIP, "hipMemset failed (f16 feature buffer)");
     }
+    net->raw_part_floats = (((size_t)max_boards + 63) / 64 * 64) * net->dev.Npad;  // room for four K-quarter parts
+    net->hid_part_floats = (((size_t)max_boards + 63) / 64 * 64) * 64;
     net->feat_boards = max_boards;
     return RZ_OK;
 }
@@ -1942,7 +1993,13 @@ static void launch_heads_gemm(rz_net *net, const float *d_feat, int32_t n_boards
         algo = net->max_wgs > 0 ? RZ_NET_HEADS_SPLIT_64 : RZ_NET_HEADS_SPLIT_32;
     const f32x4 *f16 = reinterpret_cast<const f32x4 *>(net->d_feat16);
     const int n_act_tiles = net->dev.Npad / 32;
-    if (algo == RZ_NET_HEADS_SPLIT_64) {
+    net->raw_parts = 1;
+    if (algo == RZ_NET_HEADS_SPLIT_PARTS) {
+        net->raw_parts = 4;
+        const dim3 grid((unsigned)((n_boards + 31) / 32), (unsigned)(n_act_tiles + 2), 4);
+        k_heads_part<5><<<grid, dim3(64), 0, (hipStream_t)stream>>>(net->dev, f16, net->d_raw, net->d_hid,
+                                                                     (long long)net->raw_part_floats, (long long)net->hid_part_floats);
+    } else if (algo == RZ_NET_HEADS_SPLIT_64) {
         // y = policy half (4 N-tiles) + value tile y: both halves exist even when the second has no policy tile
         const dim3 grid((unsigned)((n_boards + 63) / 64), 2);
         k_heads_split<2, 4, 3, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, f16, net->d_raw, net->d_hid, n_boards);
@@ -1958,8 +2015,9 @@ static void launch_heads_gemm(rz_net *net, const float *d_feat, int32_t n_boards
 static int launch_heads(rz_net *net, const float *d_feat, int32_t n_boards, float *d_logp, float *d_value,
                         void *stream) {
     launch_heads_gemm(net, d_feat, n_boards, stream);
-    k_heads_finish<<<dim3((unsigned)n_boards), dim3(64), 0, (hipStream_t)stream>>>(net->dev, net->d_raw, net->d_hid,
-                                                                                  d_logp, d_value, n_boards);
+    k_heads_finish<<<dim3((unsigned)n_boards), dim3(64), 0, (hipStream_t)stream>>>(
+        net->dev, net->d_raw, net->d_hid, d_logp, d_value, n_boards, net->raw_parts, (long long)net->raw_part_floats,
+        (long long)net->hid_part_floats);
     if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_heads_* failed");
     return RZ_OK;
 }
@@ -1995,7 +2053,7 @@ int rz_net_range_info(rz_net *net, float *h_info8) {
 
 int rz_net_set_heads_algo(rz_net *net, int32_t heads_algo) {
     if (!net) return net_fail(RZ_ERR_ARG, "net handle is NULL");
-    if (heads_algo < RZ_NET_HEADS_AUTO || heads_algo > RZ_NET_HEADS_SPLIT_64) return net_fail(RZ_ERR_ARG, "unknown heads algorithm");
+    if (heads_algo < RZ_NET_HEADS_AUTO || heads_algo > RZ_NET_HEADS_SPLIT_PARTS) return net_fail(RZ_ERR_ARG, "unknown heads algorithm");
     net->heads_algo = heads_algo;
     return RZ_OK;
 }
@@ -2007,20 +2065,28 @@ int rz_net_set_max_workgroups(rz_net *net, int32_t max_workgroups) {
     return RZ_OK;
 }
 
-int rz_net_heads_gemm(rz_net *net, int32_t n_boards, const float **d_raw, int32_t *ld, const float **d_hid,
-                      const float **d_w2, const float **d_b2, void *stream) {
+int rz_net_heads_gemm(rz_net *net, int32_t n_boards, rz_raw_heads *out, void *stream) {
     int rc = net_ready(net, n_boards);
     if (rc != RZ_OK) return rc;
-    if (!d_raw || !ld || !d_hid || !d_w2 || !d_b2) return net_fail(RZ_ERR_ARG, "NULL output pointer");
+    if (!out) return net_fail(RZ_ERR_ARG, "NULL output pointer");
     if (n_boards > net->feat_boards) return net_fail(RZ_ERR_ARG, "batch larger than rz_net_reserve()d");
-    *d_raw = net->d_raw;
-    *ld = net->dev.Npad;
-    *d_hid = net->d_hid;
-    *d_w2 = net->dev.fc_val2_w;
-    *d_b2 = net->dev.fc_val2_b;
-    if (n_boards == 0) return RZ_OK;
-    launch_heads_gemm(net, net->d_feat, n_boards, stream);
-    if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_heads_gemm failed");
+    if (n_boards > 0) {
+        launch_heads_gemm(net, net->d_feat, n_boards, stream);
+        if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_heads_gemm failed");
+    }
+    memset(out, 0, sizeof(*out));
+    out->raw = net->d_raw;
+    out->hid = net->d_hid;
+    out->w2 = net->dev.fc_val2_w;
+    out->b2 = net->dev.fc_val2_b;
+    out->act_scale = net->dev.s_inv + 3;
+    out->act_bias = net->dev.fc_act_b;
+    out->val_scale = net->dev.s_inv + 4;
+    out->val_bias = net->dev.fc_val1_b;
+    out->raw_part_stride = (int64_t)net->raw_part_floats;
+    out->hid_part_stride = (int64_t)net->hid_part_floats;
+    out->ld = net->dev.Npad;
+    out->n_parts = n_boards > 0 ? net->raw_parts : 1;
     return RZ_OK;
 }
 

@@ -133,7 +133,7 @@ class HipNet(object):
         operand pairs after the 'split_f16' trunk, 32 / 64 boards per workgroup), 'auto' (default after the
         'split_f16' trunk: 'split64' beside a capped trunk, 'split32' otherwise; 'f32' after the f32 trunks)."""
         code = {'auto': _hip.NET_HEADS_AUTO, 'f32': _hip.NET_HEADS_F32, 'split32': _hip.NET_HEADS_SPLIT_32,
-                'split64': _hip.NET_HEADS_SPLIT_64}[algo]
+                'split64': _hip.NET_HEADS_SPLIT_64, 'parts': _hip.NET_HEADS_SPLIT_PARTS}[algo]
         check(self.lib.rz_net_set_heads_algo(self.handle, code), 'rz_net_set_heads_algo')
         return self
 
@@ -186,13 +186,12 @@ class HipNet(object):
         check(self.lib.rz_net_trunk(self.handle, _ptr(obs), n, None, self._stream()), 'rz_net_trunk')
 
     def heads_gemm(self, n):
-        """Only the FC GEMM on the internal features -> (raw ptr, ld, hid ptr, w2 ptr, b2 ptr) for
-        the tree kernels that finish log_softmax / tanh themselves."""
-        raw, hid, w2, b2 = (ctypes.c_void_p() for _ in range(4))
-        ld = ctypes.c_int32(0)
-        check(self.lib.rz_net_heads_gemm(self.handle, int(n), ctypes.byref(raw), ctypes.byref(ld), ctypes.byref(hid),
-                                         ctypes.byref(w2), ctypes.byref(b2), self._stream()), 'rz_net_heads_gemm')
-        return raw, ld.value, hid, w2, b2
+        """Only the FC GEMM on the internal features -> the rz_raw_heads record (device pointers to the raw policy
+        logits / value hidden layer, or to their four K-quarter partial sums with 'parts') for the tree kernels that
+        finish the heads themselves."""
+        out = _hip.RzRawHeads()
+        check(self.lib.rz_net_heads_gemm(self.handle, int(n), ctypes.byref(out), self._stream()), 'rz_net_heads_gemm')
+        return out
 
     def heads(self, n, logp, value):
         check(self.lib.rz_net_heads(self.handle, int(n), _ptr(logp), _ptr(value), self._stream()), 'rz_net_heads')
@@ -493,11 +492,11 @@ class MCTSEngine(object):
             if K > 1 and (i == 0 or counts[i + 1] != K or counts[i] != K):
                 self._in_flight(counts[i], counts[i + 1])
             if fused:
-                raw, ld, hid, w2, b2 = evaluator.raw_heads(self)
+                heads = evaluator.raw_heads(self)
                 if i + 1 < steps:
-                    check(lib.rz_tree_step_raw(h, raw, ld, hid, w2, b2, obs, self.stream()), 'rz_tree_step_raw')
+                    check(lib.rz_tree_step_raw(h, ctypes.byref(heads), obs, self.stream()), 'rz_tree_step_raw')
                 else:
-                    check(lib.rz_expand_backup_raw(h, raw, ld, hid, w2, b2, self.stream()), 'rz_expand_backup_raw')
+                    check(lib.rz_expand_backup_raw(h, ctypes.byref(heads), self.stream()), 'rz_expand_backup_raw')
                 continue
             logp, value = evaluator(self)
             if value.dtype != self.torch.float32:

@@ -828,7 +828,7 @@ def test_split_f16_heads_gemm_equals_the_f32_gemm():
         for n in batches:
             x = (torch.rand((n, 4, rows, cols), device='cuda:0') < 0.4).float()
             out = {}
-            for algo in ('f32', 'split32', 'split64', 'auto'):
+            for algo in ('f32', 'split32', 'split64', 'parts', 'auto'):
                 lp, v = hip.set_heads_algo(algo).forward(x)
                 out[algo] = (lp.clone(), v.clone())
             lp, v = hip.set_max_workgroups(8).forward(x)  # 'auto' beside a capped trunk: 64-board workgroups
@@ -842,7 +842,7 @@ def test_split_f16_heads_gemm_equals_the_f32_gemm():
                 assert float((out[algo][1].cpu().double() - v64[:, 0]).abs().max()) <= 2e-6, (shape, n, algo)
             assert float((out['f32'][0] - out['split32'][0]).abs().max()) <= 1e-5
             assert float((out['f32'][1] - out['split32'][1]).abs().max()) <= 2e-6
-            for algo in ('split64', 'auto', 'auto_capped'):  # the workgroup shape is scheduling only: same bits
+            for algo in ('split64', 'parts', 'auto', 'auto_capped'):  # the workgroup shape / who adds the K quarters is scheduling only: same bits
                 assert torch.equal(out[algo][0], out['split32'][0]) and torch.equal(out[algo][1], out['split32'][1])
         # the split trunk wrote only the f16 pieces (GEMM 'auto'): a GEMM forced to f32 afterwards runs on them
         hip.set_heads_algo('auto').trunk_internal(x)
@@ -924,8 +924,8 @@ def test_fused_route_priors_vs_golden_and_unfused(g4):
                     break
             if not e.game_end_winner()[0]:
                 envs.append(e)
-        for algo in ('split_f16', 'winograd_f4', 'direct'):
-            evaluator.hip.set_algo(algo)
+        for algo, heads in (('split_f16', 'auto'), ('split_f16', 'parts'), ('winograd_f4', 'auto'), ('direct', 'auto')):
+            evaluator.hip.set_algo(algo).set_heads_algo(heads)
             got = {}
             for route, evl in (('fused', evaluator), ('unfused', _UnfusedHipNet(evaluator.hip))):
                 eng = _engine(B, n, n_games=len(envs), n_playout=4)
@@ -948,6 +948,12 @@ def test_fused_route_priors_vs_golden_and_unfused(g4):
                 assert not pri[g][illegal].any() and 0.0 < pri[g].astype(np.float64).sum() <= 1.0 + 1e-5
             assert np.array_equal(got['fused'][0].view(np.uint32), got['unfused'][0].view(np.uint32)), (B, algo)
             assert np.array_equal(got['fused'][1].view(np.uint64), got['unfused'][1].view(np.uint64)), (B, algo)
+            if algo == 'split_f16':  # the tree kernel adding the GEMM's four K-quarter sums itself: the same bits
+                if heads == 'auto':
+                    reference_bits = (got['fused'][0].copy(), got['fused'][1].copy())
+                else:
+                    assert np.array_equal(got['fused'][0].view(np.uint32), reference_bits[0].view(np.uint32))
+                    assert np.array_equal(got['fused'][1].view(np.uint64), reference_bits[1].view(np.uint64))
         evaluator.hip.close()
 
 

@@ -179,6 +179,8 @@ def test_train_pipeline_runs_on_gpu(tmp_path, capsys, monkeypatch):
     # batched collection: 8 games in flight feed the same buffer format
     pipe2 = mod.TrainPipeline(board_size=6, n_in_row=4, n_playout=30, game_batch_num=1, check_freq=50,
                               selfplay_games_in_flight=8)
+    assert pipe2.buffer_size == 8 * 36 * 8 and pipe.buffer_size == 1000  # one round of the batched mode / the reference's
+    assert mod.TrainPipeline(selfplay_games_in_flight=8, buffer_size=1000).data_buffer.maxlen == 1000
     pipe2.collect_selfplay_data(8)
     state, prob, z = pipe2.data_buffer[0]
     assert state.shape == (4, 6, 6) and prob.shape == (36, ) and z in (-1.0, 0.0, 1.0)

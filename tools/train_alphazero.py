@@ -50,7 +50,12 @@ def _symmetries(planes, pi_grid):
 class TrainPipeline:
 
     def __init__(self, board_size=6, n_in_row=4, n_playout=400, game_batch_num=64, check_freq=50,
-                 selfplay_games_in_flight=0):
+                 selfplay_games_in_flight=0, buffer_size=None):
+        """``buffer_size``: length of the replay deque.  None = the reference's 1000 (train_alphazero.py:32) in the
+        reference flow; in the batched mode (``selfplay_games_in_flight > 0``) None sizes it to hold ONE collection
+        round (games in flight x board cells x 8 symmetries) -- a documented deviation: with the reference's 1000 a
+        256-game round (~200 k augmented samples) would keep its last 1000 samples and drop > 99 % of what the GPU
+        produced.  Pass 1000 to get the reference's number in either mode."""
         # board and game
         self.board_size = board_size
         self.n_in_row = n_in_row
@@ -62,7 +67,10 @@ class TrainPipeline:
         self.temperature = 1.0
         self.n_playout = n_playout
         self.c_puct = 5
-        self.buffer_size = 1000
+        if buffer_size is None:
+            buffer_size = 1000 if selfplay_games_in_flight <= 0 else \
+                max(1000, selfplay_games_in_flight * board_size * board_size * 8)
+        self.buffer_size = int(buffer_size)
         self.batch_size = 32
         self.data_buffer = deque(maxlen=self.buffer_size)
         self.play_batch_size = 1

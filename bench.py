@@ -259,24 +259,30 @@ def child_line(flags, timeout=900):
 
 
 def run_literal_config(args):
-    """`bench.py --lanes 1 --games 512` as a child process -> the fields of its line worth keeping, or None."""
-    rec = child_line(['--lanes', 1, '--games', GAMES_PER_GPU, '--steps', args.steps, '--warmup', args.warmup,
-                      '--net-algo', args.net_algo, '--heads-algo', args.heads_algo, '--graph', args.graph, '--noise',
+    """The literal share of configs[3], 512 games in flight, as a child process with the lane layout plan_lanes() picks
+    for that batch (two lanes of 256 games, un-capped trunks, 'parts' FC GEMM) -> the fields of its line worth keeping."""
+    rec = child_line(['--lanes', 2, '--games', GAMES_PER_GPU, '--trunk-wgs', 0, '--heads-algo', 'parts', '--steps', args.steps,
+                      '--warmup', args.warmup, '--net-algo', args.net_algo, '--graph', args.graph, '--noise',
                       args.noise, '--no-cpu-baseline', '--no-games-leg', '--no-literal-config', '--no-configs'], 600)
     if rec is None:
         return None
     rf = rec.get('roofline') or {}
-    return {'workload': rec['config']['workload'], 'lanes': 1, 'value': rec['value'], 'unit': rec['unit'],
+    return {'workload': rec['config']['workload'], 'lanes': 2, 'value': rec['value'], 'unit': rec['unit'],
             'ms_per_step': rec['ms_per_step'], 'roofline_frac': rf.get('frac'),
-            'roofline_avg_launch_ms': rf.get('avg_launch_ms'),
-            'note': 'same engine, one lane of %d games in flight = 4096 games / 8 GPUs (BASELINE.json configs[3]); '
-                    'measured by a child process before the main run' % GAMES_PER_GPU}
+            'roofline_avg_launch_ms': rf.get('avg_launch_ms'), 'roofline_exclusive_frac': rf.get('exclusive_frac'),
+            'note': 'same engine, %d games in flight = 4096 games / 8 GPUs (BASELINE.json configs[3]) as two lanes of 256 '
+                    'with un-capped trunks and the FC GEMM / tree step co-resident with the other lane\'s trunk '
+                    '(selfplay.plan_lanes); measured by a child process before the main run; one lane of 512: '
+                    '--lanes 1 --games 512' % GAMES_PER_GPU}
 
 
 # the other configurations of BASELINE.json, each measured by a child process of the default N = 1 run
 CONFIG_LEGS = (
     ('C1', 'configs[0] TicTacToe, 25 sims/move, 1 game', ['--board', 3, '--playouts', 25, '--games', 1, '--lanes', 1, '--steps', 9], 5.0),
     ('C2', 'configs[1] 9x9 Gomoku, 200 sims/move, 64 games', ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 8], 12.0),
+    ('C2_16_in_flight', 'configs[1] with the opt-in virtual-loss mode: 16 simulations in flight per tree (NOT the reference\'s '
+     'sequential search; leaf batches of 1024 instead of 64)',
+     ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 8, '--in-flight', 16, '--no-cpu-baseline'], 0.0),
     ('C3', 'configs[2] Connect4, 400 sims/move, 512 games', ['--game', 'connect4', '--playouts', 400, '--games', 512, '--lanes', 1, '--steps', 6], 12.0),
     ('C5', 'configs[4] MuZero CartPole-v1, 50 sims/move, 4096 environments', ['--game', 'muzero', '--playouts', 50, '--games', 4096, '--steps', 8], 12.0),
 )
@@ -285,7 +291,7 @@ CONFIG_LEGS = (
 def run_config_legs(args):
     out = {}
     for key, title, flags, cpu_s in CONFIG_LEGS:
-        rec = child_line(flags + ['--warmup', 2, '--cpu-seconds', cpu_s * args.cpu_seconds / 60.0, '--no-games-leg',
+        rec = child_line(flags + ['--warmup', 2, '--cpu-seconds', max(1.0, cpu_s * args.cpu_seconds / 60.0), '--no-games-leg',
                                   '--no-literal-config', '--no-configs'] + (['--no-cpu-baseline'] if args.no_cpu_baseline else []), 600)
         if rec is None:
             out[key] = {'config': title, 'error': 'the child process printed no line'}
@@ -321,7 +327,17 @@ def launch_ranks(n):
 class TimedEvaluator(object):
     """Brackets every evaluator call (the policy+value forward of the leaf batch) with HIP
     events on the launch stream (torch's current stream is the stream our kernels use)."""
-    needs_obs = True
+
+    @property
+    def needs_obs(self):
+        return getattr(self.inner, 'needs_obs', True)
+
+    def _trunk(self, eng):
+        hip = self.inner.hip
+        if self.needs_obs:
+            hip.trunk_internal(eng.obs)
+        else:
+            hip.trunk_leaves(eng)  # the leaf bitboards, no float planes
 
     def __init__(self, inner, torch, label):
         self.inner, self.torch, self.label = inner, torch, label
@@ -339,7 +355,7 @@ class TimedEvaluator(object):
             a.record()
             hip.trunk_internal(eng.obs)
             b.record()
-            out = hip.heads(eng.obs.shape[0], eng.logp, eng.value)
+            out = hip.heads(eng.obs.shape[0], eng.logp, eng.value)  # (the un-fused route reads float planes)
         else:
             a.record()
             out = self.inner(eng)
@@ -368,7 +384,7 @@ class TimedEvaluator(object):
         a.record()
         if getattr(self, 'last_c', None) is not None:
             self.tree_events.append((self.last_c, a))
-        hip.trunk_internal(eng.obs)
+        self._trunk(eng)
         b.record()
         self.events.append((a, b))
         out = hip.heads_gemm(eng.obs.shape[0])
@@ -664,7 +680,7 @@ def main():
             for _ in range(24):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-                evaluator.inner.hip.trunk_internal(lane0.eng.obs)
+                evaluator._trunk(lane0.eng)
                 b.record()
                 evs.append((a, b))
         torch.cuda.synchronize()

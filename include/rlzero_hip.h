@@ -36,7 +36,7 @@ extern "C" {
 #define RZ_ABI_VERSION 17
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
-#define RZ_MAX_IN_FLIGHT 32 /* rz_config.sims_in_flight */
+#define RZ_MAX_IN_FLIGHT 16 /* rz_config.sims_in_flight */
 
 enum {
     RZ_OK = 0,
@@ -107,7 +107,9 @@ typedef struct rz_config {
                                of a selected path carries a virtual loss (N += 1, W -= 1) until its backup.  Leaf
                                arrays of this ABI (d_obs, d_logp, d_value, d_raw, d_hid) then have n_games * K rows,
                                row = game * K + slot.  Device evaluators only. */
-    int32_t reserved;
+    int32_t in_flight_impl; /* sims_in_flight > 1: 0 = the level-synchronous kernel (a workgroup of K waves per game: child
+                               records of all slots' nodes staged per level, slots walked in slot order), 1 = its sequential
+                               restatement (one wave, one slot after the other); same trees, bit for bit */
 } rz_config;
 
 typedef struct rz_stats {
@@ -164,6 +166,11 @@ int rz_select_step(rz_engine *e, float *d_obs, void *stream);
  * select (rz_select_step, rz_tree_step*); default K, K.  A search of n simulations is ceil(n / K) steps, the last one
  * with the remainder, so that N(root) grows by exactly n. */
 int rz_set_in_flight(rz_engine *e, int32_t k_backup, int32_t k_select);
+
+/* Device pointers to the engine's leaf arrays, valid for its lifetime: stones uint64 [n_games * K][2][4], side to move and
+ * last cell int32 [n_games * K] of the leaves of the last rz_select_step / rz_tree_step (row = game * K + slot).  An
+ * evaluator that reads positions (rz_net_trunk_leaves) needs no observation planes: pass d_obs = NULL to the select calls. */
+int rz_leaf_buffers(rz_engine *e, const uint64_t **d_stones, const int32_t **d_to_move, const int32_t **d_last_cell);
 
 /* Observation planes of the current leaves / of the root positions (current_state). */
 int rz_encode_leaf_obs(rz_engine *e, float *d_obs, void *stream);
@@ -341,6 +348,13 @@ int rz_net_destroy(rz_net *net);
 int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params);
 int rz_net_reserve(rz_net *net, int32_t max_boards);
 int rz_net_trunk(rz_net *net, const float *d_obs, int32_t n_boards, float *d_feat, void *stream);
+/* The RZ_NET_SPLIT_F16 trunk fed with the leaf POSITIONS instead of their float planes: d_stones uint64 [n][2][4]
+ * (colour 0 / colour 1 bitboards, bit = cell), d_to_move, d_last_cell int32 [n] -- the engine's own leaf arrays
+ * (rz_leaf_buffers).  The kernel builds the four planes of GomokuEnv.current_state (gomoku_env.py:95-114) itself; into
+ * the internal feature buffer only (pair with rz_net_heads_gemm / rz_net_heads).  Same bits as rz_net_trunk on the planes
+ * rz_select_step would have written. */
+int rz_net_trunk_leaves(rz_net *net, const uint64_t *d_stones, const int32_t *d_to_move, const int32_t *d_last_cell,
+                        int32_t n_boards, void *stream);
 int rz_net_heads(rz_net *net, int32_t n_boards, float *d_logp, float *d_value, void *stream);
 /* only the FC GEMM of the heads on the internal features; returns the device pointers that
  * rz_tree_step_raw / rz_expand_backup_raw consume (valid until the next rz_net_reserve / load) */

@@ -11,7 +11,7 @@ from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_in
 ABI_VERSION = 17
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
-MAX_IN_FLIGHT = 32
+MAX_IN_FLIGHT = 16
 
 OK = 0
 SCORE_UCT_REF, SCORE_PUCT = 0, 1
@@ -31,7 +31,7 @@ class RzConfig(Structure):
                 ('score_mode', c_int32), ('add_noise', c_int32), ('c_puct', c_double),
                 ('pool_factor', c_double), ('device', c_int32), ('noise_seed', c_int32),
                 ('board_height', c_int32), ('board_width', c_int32),
-                ('sims_in_flight', c_int32), ('reserved', c_int32)]
+                ('sims_in_flight', c_int32), ('in_flight_impl', c_int32)]
 
 
 class RzStats(Structure):
@@ -72,6 +72,7 @@ _SIGNATURES = {
     'rz_set_active': (c_int, [P, P, P]),
     'rz_select_step': (c_int, [P, P, P]),
     'rz_set_in_flight': (c_int, [P, c_int32, c_int32]),
+    'rz_leaf_buffers': (c_int, [P, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),
     'rz_encode_leaf_obs': (c_int, [P, P, P]),
     'rz_encode_root_obs': (c_int, [P, P, P]),
     'rz_get_leaves': (c_int, [P, P, P, P, P, P]),
@@ -104,6 +105,7 @@ _SIGNATURES = {
     'rz_net_load': (c_int, [P, POINTER(c_void_p), c_int32]),
     'rz_net_reserve': (c_int, [P, c_int32]),
     'rz_net_trunk': (c_int, [P, P, c_int32, P, P]),
+    'rz_net_trunk_leaves': (c_int, [P, P, P, P, c_int32, P]),
     'rz_net_heads': (c_int, [P, c_int32, P, P, P]),
     'rz_net_heads_gemm': (c_int, [P, c_int32, POINTER(RzRawHeads), P]),
     'rz_net_forward': (c_int, [P, P, c_int32, P, P, P]),

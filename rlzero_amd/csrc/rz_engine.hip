@@ -824,6 +824,505 @@ __global__ __launch_bounds__(kWave) void k_tree_step_vl(Dev E, const float *logp
     }
 }
 
+// ------------------------------------------------------------------ K simulations in flight, level-synchronous
+// The production kernel of the opt-in virtual-loss mode (k_tree_step_vl above is its sequential restatement: one
+// wave, one slot after the other, kept selectable for the tests that compare the two tree for tree).  A game is a
+// workgroup of K waves.  Every step of the sequential rule "slot j sees the virtual losses of slots 0 .. j-1" that does
+// not depend on an earlier slot is done for all slots at once:
+//   * BACKUP of the kb pending leaves: wave j finishes the heads of leaf j (log_softmax, tanh), draws its noise and
+//     writes its prior block at an offset taken from a prefix sum over the slots (bump allocator in slot order); then
+//     wave 0 trades every virtual loss for the value: W(node) += x + 1 for all (slot, level) pairs with fire-and-forget
+//     f64 atomics issued in slot order (same wave, same address: applied in program order), N untouched.
+//   * SELECT of ks new leaves, level by level: at level L the slots sit in at most K distinct nodes; wave j stages the
+//     child records of slot j's node in LDS (all nodes of a level in ONE memory round trip instead of one per slot and
+//     level), then wave 0 walks the slots IN SLOT ORDER: scores from LDS, first maximum, virtual loss into the staged
+//     record at once (the next slot at the same node sees it), the slot's own view of the chosen child -- N, W as they
+//     were BEFORE its own virtual loss, i.e. with those of the earlier slots only -- goes along to the next level.
+//     This is the sequential rule exactly: what slot j sees at a node are the losses of the slots before it, and
+//     those were all placed at the same level earlier in the same pass.  A moved child block is written back from the
+//     staged copy, so nothing has to be patched.
+//   * the tails (terminal test, duplicate-leaf test, leaf arrays, observation planes) again one wave per slot.
+struct MlSlot {
+    uint64_t st[2][kWords];  // board of the slot's path so far
+    int4 lo, hi;             // the slot's VIEW of its current node: record with the virtual losses of earlier slots only
+    int4 xlo;                // owner slot only: the node's structure fields (y FC, z NV, w K | cap) as they evolve in a pass
+    int node, rank, owner, depth, fresh, active, to_move, last, nst, moved, pad0, pad1;
+};
+
+__host__ __device__ inline int ml_prior_bytes(int K, int A, bool puct) { return puct ? ((K * A * 4 + 15) / 16) * 16 : 0; }
+__host__ __device__ inline int ml_lds_bytes(int K, int A, bool puct) {
+    return K * (int)sizeof(MlSlot) + K * A * 32 + ml_prior_bytes(K, A, puct) + 64 + K * 16;
+}
+
+template <bool RAW>
+__global__ void k_tree_step_ml(Dev E, const float *logp, const float *value, RawHeads rh, float *obs, int kb, int ks) {
+    extern __shared__ __attribute__((aligned(16))) char ml_lds[];
+    const int g = blockIdx.x, K = E.K, A = E.A, S = E.S;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool puct_mode = E.score_mode == RZ_SCORE_PUCT;
+    MlSlot *SL = reinterpret_cast<MlSlot *>(ml_lds);
+    int4 *stage = reinterpret_cast<int4 *>(ml_lds + K * sizeof(MlSlot));          // [K][A][2]
+    float *stage_p = reinterpret_cast<float *>(stage + (size_t)K * A * 2);          // [K][A] (PUCT)
+    int *misc = reinterpret_cast<int *>(reinterpret_cast<char *>(stage_p) + ml_prior_bytes(K, A, puct_mode));  // [0] any slot active
+    double *bval = reinterpret_cast<double *>(misc + 16);                            // [K] leaf values
+    int *bdepth = reinterpret_cast<int *>(bval + K);                                 // [K]
+    int *bexp = bdepth + K;                                                          // [K] children of an expanded leaf, else 0
+    if (!E.active[g]) return;  // the whole workgroup: before any barrier
+    const int arena = E.cur_arena[g];
+    int4 *R = arena_records(E, g, arena);
+    float *P = arena_priors(E, g, arena);
+
+    // ------------------------------------------------------------- BACKUP of the pending leaves
+    if (kb > 0) {
+        const int j = w, gk = g * K + j;
+        const bool mine = j < kb;
+        const int ptop0 = E.ptop[g], nblk0 = E.nblk[g], ctr0 = E.noise_ctr[g], top0 = E.top[g];  // before anyone moves them
+        int depth = 0, fresh = 0, term = 0, leaf = 0, k = 0;
+        double v = 0.0;
+        float lse = 0.0f;
+        float x[kWords] = {0.f, 0.f, 0.f, 0.f};
+        uint64_t st[2][kWords] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, occ[kWords] = {0, 0, 0, 0};
+        Legal L;
+        L.k = 0; L.cols = 0ull; L.height = 0;
+        bool expand = false;
+        if (mine) {
+            depth = E.leaf_depth[gk];
+            fresh = E.leaf_fresh[gk];
+            term = E.leaf_term[gk];
+            leaf = E.leaf_node[gk];
+            const double tval = E.leaf_tval[gk];
+            load_board(E.leaf_stones, gk, st);
+            float val = 0.0f;
+            if (RAW) {  // the heads of leaf j, as in expand_backup_body
+                const float *r = rh.raw + (size_t)gk * rh.ld;
+                const float *hp = rh.hid + (size_t)gk * 64 + lane;
+                const float w2 = rh.w2[lane], b2 = rh.b2[0];
+                float hid = hp[0], mx = -INFINITY;
+                if (rh.n_parts == 4) {
+                    const long long rs = rh.raw_part_stride, hs = rh.hid_part_stride;
+                    const float act_scale = rh.act_scale[0], val_scale = rh.val_scale[0];
+#pragma unroll
+                    for (int i = 0; i < kWords; ++i) {
+                        const int a = lane + 64 * i;
+                        const bool in = a < A;
+                        const float q0 = in ? r[a] : 0.f, q1 = in ? r[a + rs] : 0.f, q2 = in ? r[a + 2 * rs] : 0.f,
+                                    q3 = in ? r[a + 3 * rs] : 0.f, bias = in ? rh.act_bias[a] : 0.f;
+                        x[i] = in ? fmaf(((q0 + q1) + q2) + q3, act_scale, bias) : -INFINITY;
+                        mx = fmaxf(mx, x[i]);
+                    }
+                    hid = fmaxf(fmaf(((hid + hp[hs]) + hp[2 * hs]) + hp[3 * hs], val_scale, rh.val_bias[lane]), 0.0f);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < kWords; ++i) {
+                        const int a = lane + 64 * i;
+                        x[i] = a < A ? r[a] : -INFINITY;
+                        mx = fmaxf(mx, x[i]);
+                    }
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+                float sum = 0.0f;
+#pragma unroll
+                for (int i = 0; i < kWords; ++i) sum += (lane + 64 * i < A) ? expf(x[i] - mx) : 0.0f;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+                lse = mx + logf(sum);
+                float h = hid * w2;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) h += __shfl_xor(h, off);
+                val = tanhf(h + b2);
+            } else {
+                val = value[gk];
+            }
+            v = term ? tval : (double)val;
+            expand = !term && fresh != 2 && fresh != 3;
+#pragma unroll
+            for (int i = 0; i < kWords; ++i) occ[i] = st[0][i] | st[1][i];
+            L = legal_of(E, occ, lane);
+            k = L.k;
+        }
+        if (lane == 0 && j < K) {
+            bexp[j] = (mine && expand) ? k : 0;
+            bval[j] = v;
+            bdepth[j] = mine ? depth : -1;
+        }
+        __syncthreads();
+        // bump allocation in slot order: offsets = prefix sums over the slots before j
+        int before_k = 0, before_n = 0, total_k = 0, total_n = 0;
+        for (int i = 0; i < kb; ++i) {
+            const int ki = bexp[i];
+            if (i < j) { before_k += ki; before_n += ki > 0 ? 1 : 0; }
+            total_k += ki;
+            total_n += ki > 0 ? 1 : 0;
+        }
+        if (w == 0 && lane == 0) {
+            if ((long long)ptop0 + total_k > E.pcap || nblk0 + total_n > E.qcap) {
+                atomicOr(&E.err[g], RZ_FLAG_BLOCKS_FULL);
+                atomicOr(E.err_any, RZ_FLAG_BLOCKS_FULL);
+            } else if (puct_mode && (long long)top0 + total_k > E.cap) {
+                atomicOr(&E.err[g], RZ_FLAG_ARENA_FULL);
+                atomicOr(E.err_any, RZ_FLAG_ARENA_FULL);
+            } else {
+                E.ptop[g] = ptop0 + total_k;
+                E.nblk[g] = nblk0 + total_n;
+                if (E.add_noise) E.noise_ctr[g] = ctr0 + total_n;
+                if (puct_mode) E.top[g] = top0 + total_k;
+            }
+        }
+        const bool fits = (long long)ptop0 + total_k <= E.pcap && nblk0 + total_n <= E.qcap &&
+                          (!puct_mode || (long long)top0 + total_k <= E.cap);
+        if (mine && expand && fits) {
+            const int pb = ptop0 + before_k, ctop = top0 + before_k;
+            const float uniform = 1.0f / (float)k;
+            int ranks[kWords];
+            int before = 0;
+#pragma unroll
+            for (int i = 0; i < kWords; ++i) ranks[i] = lane_action_rank(E, occ, L, i, lane, before);
+            float noise[kWords] = {0.f, 0.f, 0.f, 0.f};
+            float noise_sum = 1.0f;
+            if (E.add_noise) {
+                const uint64_t key = mix64(mix64(E.noise_seed ^ ((uint64_t)g << 20)) ^ (uint64_t)(ctr0 + before_n));
+                float local = 0.0f;
+#pragma unroll
+                for (int i = 0; i < kWords; ++i)
+                    if (ranks[i] >= 0) {
+                        noise[i] = gamma03(mix64(key ^ (uint64_t)(64 * i + lane)));
+                        local += noise[i];
+                    }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) local += __shfl_xor(local, off);
+                noise_sum = local > 0.0f ? local : 1.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < kWords; ++i) {
+                const int r = ranks[i];
+                if (r < 0) continue;
+                const int a = 64 * i + lane;
+                float prior = uniform;
+                if (RAW) prior = expf(x[i] - lse);
+                else if (logp) prior = expf(logp[(long long)gk * A + a]);
+                if (E.add_noise) prior = 0.75f * prior + 0.25f * (noise[i] / noise_sum);
+                P[pb + r] = prior;
+                if (puct_mode) {
+                    R[2 * (ctop + r)] = make_int4(0, -1, 0, 0);
+                    R[2 * (ctop + r) + 1] = make_hi(0.0, -1, prior);
+                }
+            }
+            if (lane == 0) {  // the leaf's record: its blocks (N and W stay: counted at selection / traded below)
+                int32_t *f = reinterpret_cast<int32_t *>(R + 2 * leaf);
+                f[1] = puct_mode ? ctop : -1;
+                f[2] = puct_mode ? k : 0;
+                f[3] = pack_kc(k, puct_mode ? k : 0);
+                *rec_pb(R, leaf) = pb;
+            }
+        }
+        __syncthreads();
+        if (w == 0) {
+            // W(node) += x + 1 for every (slot, level) pair, slot after slot: fire-and-forget atomics of ONE wave.  The
+            // path entries of all slots are fetched first (one round trip), then the atomics go out in slot order.
+            int pnode[RZ_MAX_IN_FLIGHT];
+#pragma unroll
+            for (int i = 0; i < RZ_MAX_IN_FLIGHT; ++i) {
+                pnode[i] = 0;
+                if (i < kb) {
+                    const int di = bdepth[i];
+                    if (lane <= di) pnode[i] = E.path[(long long)(g * K + i) * E.path_stride + lane];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < RZ_MAX_IN_FLIGHT; ++i) {
+                if (i < kb) {
+                    const int di = bdepth[i];
+                    const double vi = bval[i];
+                    if (lane <= di) unsafeAtomicAdd(rec_wsum(R, pnode[i]), (((di - lane) & 1) ? vi : -vi) + 1.0);
+                    if (di >= kWave) {  // (paths longer than a wave: the rest, level by level)
+                        const int32_t *path = E.path + (long long)(g * K + i) * E.path_stride;
+                        for (int d = lane + kWave; d <= di; d += kWave)
+                            unsafeAtomicAdd(rec_wsum(R, path[d]), (((di - d) & 1) ? vi : -vi) + 1.0);
+                    }
+                }
+            }
+        }
+        // the selection below must read what the stores and atomics above wrote
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    if (ks <= 0) return;
+
+    // ------------------------------------------------------------- SELECT, level by level
+    int top = E.top[g];
+    const int top_at_start = top;
+    {
+        const int4 lo0 = R[0], hi0 = R[1];
+        uint64_t st0[2][kWords];
+        load_board(E.root_stones, g, st0);
+        const int to_move0 = E.root_to_move[g], last0 = E.root_last[g];
+        const int j = w;
+        if (j < ks) {
+            double wv = rec_w(hi0);
+            for (int i = 0; i < j; ++i) wv = wv - 1.0;  // the root as slot j sees it: the slots before it have passed
+            if (lane < 2 * kWords) SL[j].st[lane / kWords][lane % kWords] = word_of(st0[lane / kWords], lane % kWords);
+            if (lane == 0) {
+                SL[j].lo = make_int4(lo0.x + j, lo0.y, lo0.z, lo0.w);
+                SL[j].hi = make_hi(wv, hi0.z, __int_as_float(hi0.w));
+                SL[j].xlo = lo0;
+                SL[j].node = 0;
+                SL[j].rank = -1;
+                SL[j].owner = 0;
+                SL[j].depth = 0;
+                SL[j].fresh = 0;
+                SL[j].active = 1;
+                SL[j].to_move = to_move0;
+                SL[j].last = last0;
+                SL[j].nst = count_bits(st0[0]) + count_bits(st0[1]);
+                SL[j].moved = 0;
+                E.path[(long long)(g * K + j) * E.path_stride] = 0;
+            }
+        }
+        if (w == 0 && lane == 0) {
+            misc[0] = 1;
+            double wv = rec_w(hi0);
+            for (int i = 0; i < ks; ++i) wv = wv - 1.0;
+            *rec_n(R, 0) = lo0.x + ks;  // the root carries the virtual loss of every slot
+            *rec_wsum(R, 0) = wv;
+        }
+    }
+    for (int pass = 0; pass <= S + 1; ++pass) {
+        __syncthreads();
+        if (misc[0] == 0) break;
+        // phase A: wave j stages the child records of its slot's node (once per distinct node: the owner does it)
+        if (w < ks) {
+            const int j = w;
+            if (SL[j].active && SL[j].owner == j) {
+                const int4 xlo = SL[j].xlo;
+                const int k = rec_k(xlo), fc = xlo.y, n_load = puct_mode ? k : xlo.z, pb = SL[j].hi.z;
+                int4 *dst = stage + (size_t)j * A * 2;
+                for (int i = lane; i < n_load; i += kWave) {
+                    dst[2 * i] = R[2 * (fc + i)];
+                    dst[2 * i + 1] = R[2 * (fc + i) + 1];
+                    if (puct_mode) stage_p[(size_t)j * A + i] = P[pb + i];
+                }
+            }
+        }
+        __syncthreads();
+        if (w != 0) continue;
+        // phase B: wave 0 walks the slots in slot order
+        for (int j = 0; j < ks; ++j) {
+            if (!SL[j].active) continue;
+            const int o = SL[j].owner;
+            const int4 xlo = SL[o].xlo;
+            const int4 vlo = SL[j].lo;
+            const int k = rec_k(xlo);
+            if (k == 0) {  // the path ends in an existing leaf (its virtual loss came with the choice of it)
+                if (lane == 0) SL[j].active = 0;
+                continue;
+            }
+            int fc = xlo.y, cap = rec_cap(xlo);
+            const int nv = xlo.z;
+            int4 *stg = stage + (size_t)o * A * 2;
+            int r;
+            int4 clo, chi;
+            bool fresh = false;
+            if (!puct_mode && nv < k) {
+                if (nv == cap) {  // the child vector grows: new block at the arena top, written from the staged copy below
+                    const int ncap = cap == 0 ? (k < kFirstCap ? k : kFirstCap) : (2 * cap < k ? 2 * cap : k);
+                    if ((long long)top + ncap > E.cap) {
+                        flag(E, g, RZ_FLAG_ARENA_FULL, lane);
+                        if (lane == 0) { SL[j].fresh = 2; SL[j].active = 0; }
+                        continue;
+                    }
+                    fc = top;
+                    top += ncap;
+                    cap = ncap;
+                    if (lane == 0) SL[o].moved = 1;
+                }
+                r = nv;
+                fresh = true;
+                clo = make_int4(1, -1, 0, 0);          // the pending child: visited once, lost
+                chi = make_hi(-1.0, -1, 0.0f);
+                if (lane == 0) {
+                    stg[2 * r] = clo;
+                    stg[2 * r + 1] = chi;
+                    SL[o].xlo = make_int4(xlo.x, fc, nv + 1, pack_kc(k, cap));
+                }
+            } else {
+                const int pn = vlo.x;
+                if (!puct_mode && (pn < 1 || pn >= E.logtab_n)) {
+                    flag(E, g, RZ_FLAG_LOGTAB, lane);
+                    if (lane == 0) { SL[j].fresh = 2; SL[j].active = 0; }
+                    continue;
+                }
+                const double parent_term = puct_mode ? sqrt((double)pn) : E.logtab[pn];
+                double best = -INFINITY;
+                int besti = 0x7fffffff;
+#pragma unroll
+                for (int i = 0; i < kWords; ++i) {
+                    const int r0 = lane + 64 * i;
+                    if (r0 < k) {
+                        const int4 cl = stg[2 * r0], ch = stg[2 * r0 + 1];
+                        const double sc = puct_mode ? puct(rec_w(ch), cl.x, stage_p[(size_t)o * A + r0], parent_term, E.c_puct)
+                                                    : uct_ref(rec_w(ch), cl.x, parent_term, E.c_puct);
+                        if (sc > best) {
+                            best = sc;
+                            besti = r0;
+                        }
+                    }
+                }
+                r = __builtin_amdgcn_readfirstlane(wave_first_max(best, besti));
+                if (r >= k) {
+                    flag(E, g, RZ_FLAG_INTERNAL, lane);
+                    if (lane == 0) { SL[j].fresh = 2; SL[j].active = 0; }
+                    continue;
+                }
+                clo = stg[2 * r];   // the child as THIS slot sees it: before its own virtual loss
+                chi = stg[2 * r + 1];
+                if (lane == 0) {
+                    stg[2 * r] = make_int4(clo.x + 1, clo.y, clo.z, clo.w);
+                    stg[2 * r + 1] = make_hi(rec_w(chi) - 1.0, chi.z, __int_as_float(chi.w));
+                }
+            }
+            // the move on the slot's board
+            uint64_t st[2][kWords], occ[kWords];
+#pragma unroll
+            for (int i = 0; i < kWords; ++i) {
+                st[0][i] = SL[j].st[0][i];
+                st[1][i] = SL[j].st[1][i];
+                occ[i] = st[0][i] | st[1][i];
+            }
+            const Legal L = legal_of(E, occ, lane);
+            int action, cell;
+            if (!nth_legal(E, occ, L, r, lane, action, cell)) {
+                flag(E, g, RZ_FLAG_INTERNAL, lane);
+                if (lane == 0) { SL[j].fresh = 2; SL[j].active = 0; }
+                continue;
+            }
+            if (lane == 0) {
+                const int tm = SL[j].to_move;
+                SL[j].st[tm][cell >> 6] |= 1ull << (cell & 63);
+                SL[j].to_move = tm ^ 1;
+                SL[j].last = cell;
+                SL[j].nst += 1;
+                SL[j].depth += 1;
+                SL[j].rank = r;
+                SL[j].lo = clo;
+                SL[j].hi = chi;
+                if (fresh) {
+                    SL[j].fresh = 1;
+                    SL[j].active = 0;
+                }
+            }
+        }
+        // phase C: write back what the pass changed, resolve the slots' new nodes, owners of the next pass
+        for (int o = 0; o < ks; ++o) {
+            if (SL[o].owner != o || SL[o].rank < -1) continue;
+            const int4 xlo = SL[o].xlo;
+            const int X = SL[o].node;
+            bool touched = false;
+            for (int j = o; j < ks; ++j) touched = touched || (SL[j].owner == o && SL[j].rank >= 0);
+            if (!touched) continue;
+            if (lane == 0) {  // the structure fields of the node (its N / W were written when it was chosen)
+                int32_t *f = reinterpret_cast<int32_t *>(R + 2 * X);
+                f[1] = xlo.y;
+                f[2] = xlo.z;
+                f[3] = xlo.w;
+            }
+            const int4 *stg = stage + (size_t)o * A * 2;
+            if (SL[o].moved) {
+                for (int i = lane; i < xlo.z; i += kWave) {
+                    R[2 * (xlo.y + i)] = stg[2 * i];
+                    R[2 * (xlo.y + i) + 1] = stg[2 * i + 1];
+                }
+            }
+        }
+        int any = 0;
+        if (lane < ks) {
+            const int j = lane;
+            const int rk = SL[j].rank;
+            if (rk >= 0) {
+                const int o = SL[j].owner;
+                const int4 xlo = SL[o].xlo;
+                const int node = xlo.y + rk;
+                if (!SL[o].moved) {  // (a moved block was written whole, above)
+                    const int4 *stg = stage + (size_t)o * A * 2;
+                    R[2 * node] = stg[2 * rk];
+                    R[2 * node + 1] = stg[2 * rk + 1];
+                }
+                E.path[(long long)(g * K + j) * E.path_stride + SL[j].depth] = node;
+                SL[j].node = node;
+            }
+        }
+        // (every lane < ks has read its owner's record before any of them is overwritten)
+        __builtin_amdgcn_wave_barrier();
+        int node_l = 0, act_l = 0;
+        if (lane < ks) {
+            const int j = lane;
+            if (SL[j].rank >= 0) {
+                SL[j].xlo = SL[j].lo;
+                SL[j].rank = -1;
+            }
+            SL[j].moved = 0;
+            node_l = SL[j].node;
+            act_l = SL[j].active;
+        }
+        int owner_l = lane;
+        for (int i = ks - 1; i >= 0; --i) {
+            const int ni = __shfl(node_l, i), ai = __shfl(act_l, i);
+            if (ai && ni == node_l && i <= lane) owner_l = i;
+        }
+        if (lane < ks) SL[lane].owner = owner_l;
+        any = __ballot(lane < ks && act_l) != 0ull ? 1 : 0;
+        if (lane == 0) misc[0] = any;
+    }
+    __syncthreads();
+    if (w == 0 && lane == 0 && top != top_at_start) E.top[g] = top;
+
+    // ------------------------------------------------------------- tails: one wave per slot
+    if (w < ks) {
+        const int j = w, gk = g * K + j;
+        uint64_t st[2][kWords];
+#pragma unroll
+        for (int i = 0; i < kWords; ++i) {
+            st[0][i] = SL[j].st[0][i];
+            st[1][i] = SL[j].st[1][i];
+        }
+        const int to_move = SL[j].to_move, last = SL[j].last, nst = SL[j].nst, depth = SL[j].depth, node = SL[j].node;
+        int fresh = SL[j].fresh;
+        int term = 0;
+        double tval = 0.0;
+        int winner = -1;
+        if (depth == 0) {
+            if (line_anywhere(st[0], S, E.BH, E.BW, E.n_row, lane)) winner = 0;
+            else if (line_anywhere(st[1], S, E.BH, E.BW, E.n_row, lane)) winner = 1;
+        } else {
+            const int mover = to_move ^ 1;
+            if (line_through(mover == 0 ? st[0] : st[1], last, E.BH, E.BW, E.n_row, lane)) winner = mover;
+        }
+        if (winner >= 0) {
+            term = 2;
+            tval = (winner == to_move) ? 1.0 : -1.0;
+        } else if (nst == S) {
+            term = 1;
+        }
+        if (fresh == 0 && term == 0)  // an unexpanded leaf an earlier slot of this step ends in too: that one expands it
+            for (int i = 0; i < j; ++i)
+                if (SL[i].node == node) fresh = 3;
+        if (lane == 0) {
+            E.leaf_node[gk] = node;
+            E.leaf_depth[gk] = depth;
+            E.leaf_fresh[gk] = fresh;
+            E.leaf_term[gk] = term;
+            E.leaf_tval[gk] = tval;
+            E.leaf_to_move[gk] = to_move;
+            E.leaf_last[gk] = last;
+        }
+        store_board(E.leaf_stones, gk, st, lane);
+        if (obs != nullptr)
+            write_obs(obs + (long long)gk * 4 * S, to_move == 0 ? st[0] : st[1], to_move == 0 ? st[1] : st[0], last, nst, S,
+                      lane);
+    }
+}
+
 // ------------------------------------------------------------------ synthetic evaluators
 __global__ __launch_bounds__(kWave) void k_eval_synth(Dev E, int kind, float *logp, float *value) {
     const int g = blockIdx.x;  // leaf index: game * K + slot (K = 1: the game)
@@ -1209,6 +1708,8 @@ struct rz_engine {
     long long bytes = 0;
     long long n_select = 0;
     int kb = 1, ks = 1;  // rz_set_in_flight: slots the next launches back up / select (sims_in_flight > 1 only)
+    bool ml = false;     // sims_in_flight > 1: the level-synchronous kernel (default) instead of the sequential restatement
+    int ml_lds = 0;
     double *d_logtab = nullptr;
 };
 
@@ -1279,6 +1780,7 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     if (!(cfg->c_puct >= 0.0)) return fail(RZ_ERR_ARG, "c_puct must be >= 0");
     if (cfg->sims_in_flight < 0 || cfg->sims_in_flight > RZ_MAX_IN_FLIGHT)
         return fail(RZ_ERR_ARG, "sims_in_flight %d not in 0..%d", cfg->sims_in_flight, RZ_MAX_IN_FLIGHT);
+    if (cfg->in_flight_impl != 0 && cfg->in_flight_impl != 1) return fail(RZ_ERR_ARG, "unknown in_flight_impl %d", cfg->in_flight_impl);
     int n_dev = 0;
     RZ_HIP(hipGetDeviceCount(&n_dev));
     if (cfg->device < 0 || cfg->device >= n_dev)
@@ -1302,6 +1804,21 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     D.n_playout = cfg->n_playout;
     D.K = cfg->sims_in_flight > 1 ? cfg->sims_in_flight : 1;
     e->kb = e->ks = D.K;
+    e->ml = D.K > 1 && cfg->in_flight_impl == 0;
+    if (e->ml) {
+        e->ml_lds = ml_lds_bytes(D.K, A, cfg->score_mode == RZ_SCORE_PUCT);
+        if (e->ml_lds > 160 * 1024) {
+            const int need = e->ml_lds;
+            delete e;
+            return fail(RZ_ERR_ARG, "sims_in_flight %d x %d actions needs %d bytes of LDS (> 160 KB)", cfg->sims_in_flight, A, need);
+        }
+        hipError_t a1 = hipFuncSetAttribute((const void *)k_tree_step_ml<true>, hipFuncAttributeMaxDynamicSharedMemorySize, e->ml_lds);
+        hipError_t a2 = hipFuncSetAttribute((const void *)k_tree_step_ml<false>, hipFuncAttributeMaxDynamicSharedMemorySize, e->ml_lds);
+        if (a1 != hipSuccess || a2 != hipSuccess) {
+            delete e;
+            return fail(RZ_ERR_HIP, "hipFuncSetAttribute(dynamic LDS %d bytes) failed", e->ml_lds);
+        }
+    }
     D.score_mode = cfg->score_mode;
     D.add_noise = cfg->add_noise ? 1 : 0;
     D.noise_seed = (uint64_t)(uint32_t)cfg->noise_seed;
@@ -1489,11 +2006,20 @@ int rz_select_step(rz_engine *e, float *d_obs, void *stream) {
     RZ_ENTER(e);
     e->n_select += 1;
     if (e->dev.K > 1) {
-        k_tree_step_vl<false><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, nullptr, nullptr, RawHeads(), d_obs, 0, e->ks);
+        if (e->ml) k_tree_step_ml<false><<<per_game(e), dim3(kWave * e->dev.K), e->ml_lds, as_stream(stream)>>>(e->dev, nullptr, nullptr, RawHeads(), d_obs, 0, e->ks);
+        else k_tree_step_vl<false><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, nullptr, nullptr, RawHeads(), d_obs, 0, e->ks);
         return launched("k_tree_step_vl");
     }
     k_select<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_obs);
     return launched("k_select");
+}
+
+int rz_leaf_buffers(rz_engine *e, const uint64_t **d_stones, const int32_t **d_to_move, const int32_t **d_last_cell) {
+    if (e == nullptr || !d_stones || !d_to_move || !d_last_cell) return fail(RZ_ERR_ARG, "NULL argument");
+    *d_stones = e->dev.leaf_stones;
+    *d_to_move = e->dev.leaf_to_move;
+    *d_last_cell = e->dev.leaf_last;
+    return RZ_OK;
 }
 
 int rz_encode_leaf_obs(rz_engine *e, float *d_obs, void *stream) {
@@ -1541,7 +2067,8 @@ int rz_expand_backup(rz_engine *e, const float *d_logp, const float *d_value, vo
     RZ_ENTER(e);
     RZ_NEED(d_value);
     if (e->dev.K > 1) {
-        k_tree_step_vl<false><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_logp, d_value, RawHeads(), nullptr, e->kb, 0);
+        if (e->ml) k_tree_step_ml<false><<<per_game(e), dim3(kWave * e->dev.K), e->ml_lds, as_stream(stream)>>>(e->dev, d_logp, d_value, RawHeads(), nullptr, e->kb, 0);
+        else k_tree_step_vl<false><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_logp, d_value, RawHeads(), nullptr, e->kb, 0);
         return launched("k_tree_step_vl");
     }
     k_expand_backup<float><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_logp, d_value);
@@ -1569,7 +2096,8 @@ int rz_tree_step(rz_engine *e, const float *d_logp, const float *d_value, float 
     RZ_NEED(d_value);
     e->n_select += 1;
     if (e->dev.K > 1) {
-        k_tree_step_vl<false><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_logp, d_value, RawHeads(), d_obs, e->kb, e->ks);
+        if (e->ml) k_tree_step_ml<false><<<per_game(e), dim3(kWave * e->dev.K), e->ml_lds, as_stream(stream)>>>(e->dev, d_logp, d_value, RawHeads(), d_obs, e->kb, e->ks);
+        else k_tree_step_vl<false><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_logp, d_value, RawHeads(), d_obs, e->kb, e->ks);
         return launched("k_tree_step_vl");
     }
     k_tree_step<float><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_logp, d_value, d_obs);
@@ -1591,7 +2119,8 @@ int rz_expand_backup_raw(rz_engine *e, const rz_raw_heads *heads, void *stream) 
     if (rc != RZ_OK) return rc;
     const RawHeads rh = *heads;
     if (e->dev.K > 1) {
-        k_tree_step_vl<true><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, nullptr, nullptr, rh, nullptr, e->kb, 0);
+        if (e->ml) k_tree_step_ml<true><<<per_game(e), dim3(kWave * e->dev.K), e->ml_lds, as_stream(stream)>>>(e->dev, nullptr, nullptr, rh, nullptr, e->kb, 0);
+        else k_tree_step_vl<true><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, nullptr, nullptr, rh, nullptr, e->kb, 0);
         return launched("k_tree_step_vl");
     }
     k_expand_backup_raw<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, rh);
@@ -1605,7 +2134,8 @@ int rz_tree_step_raw(rz_engine *e, const rz_raw_heads *heads, float *d_obs, void
     e->n_select += 1;
     const RawHeads rh = *heads;
     if (e->dev.K > 1) {
-        k_tree_step_vl<true><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, nullptr, nullptr, rh, d_obs, e->kb, e->ks);
+        if (e->ml) k_tree_step_ml<true><<<per_game(e), dim3(kWave * e->dev.K), e->ml_lds, as_stream(stream)>>>(e->dev, nullptr, nullptr, rh, d_obs, e->kb, e->ks);
+        else k_tree_step_vl<true><<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, nullptr, nullptr, rh, d_obs, e->kb, e->ks);
         return launched("k_tree_step_vl");
     }
     k_tree_step_raw<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, rh, d_obs);

@@ -814,8 +814,19 @@ __device__ __forceinline__ void conv(const char *in, const void *wts, int row0, 
 // columns) in general; when four tiles of 32 / width rows x width columns cover the board (9x9: 3 x 9, 10x10: 3 x 10,
 // 8x8: 4 x 8, Connect4: 4 x 7, 6x6: 5 x 6) a wave owns ONE such tile (TN = 1) and issues half the MFMAs or fewer; a
 // wave whose rows lie below the board skips its MFMA loops.
+// The leaf positions themselves (rz_net_trunk_leaves): bitboards [board][2 colours][4 words], side to move and last
+// cell, exactly what the tree kernels keep per leaf.  The trunk then builds the four observation planes of
+// GomokuEnv.current_state (gomoku_env.py:95-114) itself -- thread t = cell t: stones of the side to move, of the other
+// side, the last move (if any stone is on the board), ones if the stone count is even -- so the tree kernel need not
+// write, and this kernel need not read, 16 S bytes of 0.0 / 1.0 floats per leaf.
+struct LeafBits {
+    const uint64_t *stones;
+    const int32_t *to_move;
+    const int32_t *last;
+};
+
 template <int TN>
-__global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__restrict__ obs,
+__global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__restrict__ obs, LeafBits leaves,
                                                      float *__restrict__ feat, _Float16 *__restrict__ feat16,
                                                      int n_boards, unsigned *__restrict__ flags) {
     constexpr int kThreads = 256;
@@ -848,7 +859,36 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         const int c = i / S, r = i - c * S, y = r / BW, x = r - y * BW;
         obs_off[k] = i < 4 * S ? ((y + 1) * sp::kInCols + (x + 1)) * 8 + c * 2 : -1;
     }
+    const bool from_bits = leaves.stones != nullptr;
+    // bit mode: thread t owns cell t (S <= 256 = threads); its 4 plane values as f16 (x 16: exact, the lo piece is 0)
+    const int cell_y = tid0 / BW, cell_x = tid0 - cell_y * BW;
+    const int cell_off = tid0 < S ? ((cell_y + 1) * sp::kInCols + (cell_x + 1)) * 8 : -1;
+    sp::f16x4 cell_planes = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+    auto load_bits = [&](int board, int tid) {
+        const uint64_t *sb = leaves.stones + (size_t)board * 8;
+        const int tm = leaves.to_move[board], lc = leaves.last[board];
+        int nst = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) nst += __popcll(sb[q]);  // (uniform address: scalar loads)
+        const int word = (tid >> 6) & 3, bit = tid & 63;
+        const uint64_t w0 = sb[word], w1 = sb[4 + word];
+        const bool s0 = (w0 >> bit) & 1ull, s1 = (w1 >> bit) & 1ull;
+        const bool mine = tm == 0 ? s0 : s1, theirs = tm == 0 ? s1 : s0;
+        const _Float16 one = (_Float16)sp::kObsScale, zero = (_Float16)0.0f;
+        cell_planes[0] = mine ? one : zero;
+        cell_planes[1] = theirs ? one : zero;
+        cell_planes[2] = (nst > 0 && tid == lc) ? one : zero;
+        cell_planes[3] = (nst & 1) ? zero : one;
+    };
     auto store_obs = [&](int) {
+        if (from_bits) {
+            if (cell_off >= 0) {
+                *reinterpret_cast<sp::f16x4 *>(in0 + cell_off) = cell_planes;
+                *reinterpret_cast<sp::f16x4 *>(in0 + sp::kInPieceBytes + cell_off) =
+                    sp::f16x4{(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < kObsPer; ++k)
             if (obs_off[k] >= 0) {
@@ -881,7 +921,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         for (int g = 0; g < 4; ++g) bias1[g] = *reinterpret_cast<const f32x4 *>(nd.b1 + 8 * g + 4 * (lane0 >> 5)) * act1;
     }
     if ((int)blockIdx.x < n_boards) {
-        load_obs(blockIdx.x, tid0);
+        if (from_bits) load_bits(blockIdx.x, tid0); else load_obs(blockIdx.x, tid0);
         store_obs(tid0);
     }
     __syncthreads();
@@ -949,7 +989,9 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         }
     }
     __syncthreads();
-    if (next_board < n_boards) load_obs(next_board, tid);
+    if (next_board < n_boards) {
+        if (from_bits) load_bits(next_board, tid); else load_obs(next_board, tid);
+    }
     sp::f16x8 a3[3][4][2];
     {   // conv2: 32 -> 64
         sp::f32x16 acc[2][TN];
@@ -1945,7 +1987,8 @@ int rz_net_reserve(rz_net *net, int32_t max_boards) {
     return RZ_OK;
 }
 
-static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t n_boards, void *stream) {
+static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t n_boards, void *stream,
+                         LeafBits leaves = LeafBits{nullptr, nullptr, nullptr}) {
     const dim3 grid((unsigned)n_boards);
     // the internal buffer uses the padded layout of the FC GEMM, a caller's buffer the natural one
     const bool internal = d_feat == net->d_feat;
@@ -1971,9 +2014,9 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
         _Float16 *f16 = internal ? net->d_feat16 : nullptr;
         float *f32 = want_f32 ? d_feat : nullptr;
         if ((net->dev.BH + net->dev.tile_rows - 1) / net->dev.tile_rows <= 4)  // four tiles cover the board: one per wave
-            k_trunk_split<1><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, f32, f16, n_boards, net->d_flags);
+            k_trunk_split<1><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
         else
-            k_trunk_split<2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, f32, f16, n_boards, net->d_flags);
+            k_trunk_split<2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
     }
     else
         k_trunk<<<grid, dim3(kTrunkThreads), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
@@ -2033,6 +2076,20 @@ int rz_net_trunk(rz_net *net, const float *d_obs, int32_t n_boards, float *d_fea
     }
     launch_trunk(net, d_obs, d_feat, n_boards, stream);
     if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_trunk failed");
+    return RZ_OK;
+}
+
+int rz_net_trunk_leaves(rz_net *net, const uint64_t *d_stones, const int32_t *d_to_move, const int32_t *d_last_cell,
+                        int32_t n_boards, void *stream) {
+    int rc = net_ready(net, n_boards);
+    if (rc != RZ_OK) return rc;
+    if (n_boards == 0) return RZ_OK;
+    if (!d_stones || !d_to_move || !d_last_cell) return net_fail(RZ_ERR_ARG, "NULL device pointer");
+    if (n_boards > net->feat_boards) return net_fail(RZ_ERR_ARG, "batch larger than rz_net_reserve()d");
+    if (net->algo != RZ_NET_SPLIT_F16 || !net->split_ok)
+        return net_fail(RZ_ERR_ARG, "rz_net_trunk_leaves needs the RZ_NET_SPLIT_F16 trunk (the others read float planes: rz_net_trunk)");
+    launch_trunk(net, nullptr, net->d_feat, n_boards, stream, LeafBits{d_stones, d_to_move, d_last_cell});
+    if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_trunk_split failed");
     return RZ_OK;
 }
 

@@ -107,7 +107,21 @@ class HipNet(object):
         f32-input MFMA: 'winograd_f4' (F(4x4,3x3)) or 'direct' (bit-for-bit a k-ordered fmaf chain)."""
         code = {'direct': _hip.NET_DIRECT, 'winograd_f4': _hip.NET_WINOGRAD_F4, 'split_f16': _hip.NET_SPLIT_F16}[algo]
         check(self.lib.rz_net_set_algo(self.handle, code), 'rz_net_set_algo')
+        self.algo = algo
         return self
+
+    def reads_positions(self):
+        """True when the trunk can be fed the engine's leaf bitboards (rz_net_trunk_leaves): the 'split_f16' trunk of a
+        net with finite activation bounds.  The tree kernels then write no observation planes at all."""
+        return getattr(self, 'algo', 'split_f16') == 'split_f16' and getattr(self, '_split_ok', True)
+
+    def trunk_leaves(self, eng):
+        """The trunk on the engine's current leaves, read as bitboards (no float planes), into the internal buffer."""
+        n = eng.n_leaves
+        if n > self.max_boards:
+            self.reserve(n)
+        stones, to_move, last = eng.leaf_buffers()
+        check(self.lib.rz_net_trunk_leaves(self.handle, stones, to_move, last, n, self._stream()), 'rz_net_trunk_leaves')
 
     def range_info(self):
         """What rz_net_load derived from the weights for the split-f16 trunk: bounds on the activations of conv1 /
@@ -155,6 +169,7 @@ class HipNet(object):
         ptrs = (ctypes.c_void_p * 16)(*[a.ctypes.data for a in arrays])
         check(self.lib.rz_net_load(self.handle, ptrs, 16), 'rz_net_load')
         self.reserve(max(self._want, self.max_boards))
+        self._split_ok = self.range_info()['split_ok']
         return self
 
     def reserve(self, max_boards):
@@ -220,16 +235,25 @@ class HipNet(object):
 class HipNetEvaluator(object):
     """Evaluator running the leaf batch through HipNet (weights taken from a torch
     PolicyValueNet; ``refresh()`` re-uploads them after training).  ``fused_heads``: the engine
-    lets the tree kernel finish log_softmax / tanh (one launch less per simulation)."""
-    needs_obs = True
+    lets the tree kernel finish log_softmax / tanh (one launch less per simulation).  On that route the default
+    trunk reads the leaf POSITIONS (the engine's bitboards) and ``needs_obs`` is False: no observation planes are
+    written or read; the f32 trunks and the un-fused ``__call__`` route take the float planes."""
     fused_heads = True
 
-    def raw_heads(self, eng):
-        self.hip.trunk_internal(eng.obs)
-        return self.hip.heads_gemm(eng.obs.shape[0])
+    @property
+    def needs_obs(self):
+        return not (self.use_positions and self.hip.reads_positions())
 
-    def __init__(self, net_module, board_size, device='cuda:0', max_boards=512):
+    def raw_heads(self, eng):
+        if not self.needs_obs:
+            self.hip.trunk_leaves(eng)
+        else:
+            self.hip.trunk_internal(eng.obs)
+        return self.hip.heads_gemm(eng.n_leaves)
+
+    def __init__(self, net_module, board_size, device='cuda:0', max_boards=512, use_positions=True):
         self.module = net_module
+        self.use_positions = bool(use_positions)
         self.hip = HipNet(board_size, device, max_boards)
         self.refresh()
 
@@ -247,6 +271,8 @@ class HipNetEvaluator(object):
             self.refresh()
 
     def __call__(self, eng):
+        if not self.needs_obs:  # the select kernels were told to write no planes: encode them for this un-fused call
+            check(eng.lib.rz_encode_leaf_obs(eng.handle, _ptr(eng.obs), eng.stream()), 'rz_encode_leaf_obs')
         return self.hip.forward(eng.obs, eng.logp, eng.value)
 
 
@@ -300,14 +326,15 @@ class MCTSEngine(object):
 
     def __init__(self, board_size, n_in_row, n_games=1, n_playout=1000, c_puct=5.0,
                  device='cuda:0', pool_factor=2.0, score_mode='uct_ref', add_noise=False, noise_seed=0,
-                 game='gomoku', sims_in_flight=1):
+                 game='gomoku', sims_in_flight=1, in_flight_impl='level_sync'):
         """``board_size``: int B (Gomoku / TicTacToe, B x B) or (rows, cols) for ``game='connect4'``.
 
         ``sims_in_flight`` = K > 1 (opt-in, NOT the reference's algorithm, never used by a parity test): K
         simulations of every tree share one evaluator batch of ``n_games * K`` leaves; the nodes of a selected path
         carry a virtual loss (N += 1, W -= 1) until their backup.  The reference runs its simulations strictly one
         after the other (alphazero_mcts.py:82-85): results differ from it as soon as K > 1.  Device evaluators
-        only."""
+        only.  ``in_flight_impl``: 'level_sync' (the production kernel: a workgroup of K waves per game) or 'sequential'
+        (its one-wave restatement, slower; the two build the same trees bit for bit)."""
         import torch
         self.lib = _hip.load()
         self.torch = torch
@@ -339,7 +366,8 @@ class MCTSEngine(object):
                             score_mode=self.score_mode, add_noise=1 if add_noise else 0, c_puct=self.c_puct,
                             pool_factor=float(pool_factor), device=self.device.index,
                             noise_seed=int(noise_seed) & 0x7FFFFFFF, board_height=rows, board_width=cols,
-                            sims_in_flight=self.sims_in_flight, reserved=0)
+                            sims_in_flight=self.sims_in_flight,
+                            in_flight_impl={'level_sync': 0, 'sequential': 1}[in_flight_impl])
         handle = ctypes.c_void_p()
         check(self.lib.rz_create(ctypes.byref(cfg), ctypes.byref(handle)), 'rz_create')
         self.handle = handle
@@ -438,6 +466,14 @@ class MCTSEngine(object):
               'rz_get_leaves')
         return (self.stones.cpu().numpy().view(np.uint64), self.to_move.cpu().numpy(),
                 self.last_move.cpu().numpy(), self.terminal.cpu().numpy())
+
+    def leaf_buffers(self):
+        """Device pointers (stones, to_move, last cell) of the engine's leaf arrays, [n_leaves] rows."""
+        if getattr(self, '_leaf_ptrs', None) is None:
+            a, b, c = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+            check(self.lib.rz_leaf_buffers(self.handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)), 'rz_leaf_buffers')
+            self._leaf_ptrs = (a, b, c)
+        return self._leaf_ptrs
 
     def root_obs(self):
         check(self.lib.rz_encode_root_obs(self.handle, _ptr(self.obs), self.stream()), 'rz_encode_root_obs')

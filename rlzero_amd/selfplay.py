@@ -135,19 +135,26 @@ BOARDS_PER_WORKGROUP = 3  # boards a persistent trunk workgroup takes per step a
 
 
 def plan_lanes(n_games, n_cus=256):
-    """-> (lanes, trunk_workgroups) for ``n_games`` games in flight on a GPU with ``n_cus`` CUs.
+    """-> (lanes, trunk_workgroups, heads_algo) for ``n_games`` leaves per simulation step on a GPU with ``n_cus`` CUs
+    (measured on MI355X, profiles/r02/lane_sweeps.txt; a trunk round = one board per workgroup, ~27-30 us at 15x15).
 
-    One lane: the trunk takes ceil(G / CUs) board rounds (~27 us each on 15x15) and then the GPU idles
-    through the lane's FC + tree kernels and three kernel boundaries (~45 us).  Two lanes: each trunk is
-    capped at CUs - 32 persistent workgroups (4 CUs per XCD stay free), the two trunks alternate and the
-    small kernels of one lane hide under the trunk of the other.  The cheaper estimate wins; 0 workgroups
-    means "one per CU" (no cap)."""
+    * a lane's batch fits ONE round of CUs - 32 workgroups, or is large (>= 2 boards per workgroup): TWO lanes, each
+      trunk capped at CUs - 32 persistent
+      workgroups (4 CUs per XCD stay free), the FC GEMM ('split64') and the tree step of one lane run at full speed
+      on the free CUs under the other lane's trunk;
+    * in between (e.g. the 512 games per GPU of BASELINE.json configs[3]: 256 per lane): TWO lanes with
+      UN-capped trunks (a lane's batch is one round on all CUs) and the 'parts' FC GEMM, whose single-wave workgroups
+      need no LDS and fit on a CU beside a resident trunk workgroup, like the tree step's waves (they run slower
+      there -- the trunk saturates the issue slots -- but hidden): +7 % over one lane at 512 games;
+    * up to one round: one lane, nothing to overlap with.
+    0 workgroups means "one per CU" (no cap)."""
     capped = n_cus - RESERVED_CUS_PER_XCD * N_XCD
-    if capped <= 0 or n_games < 2:
-        return 1, 0
-    one = -(-n_games // n_cus) * 27.0 + 45.0
-    two = 2.0 * -(-((n_games + 1) // 2) // capped) * 27.0 + 5.0
-    return (2, capped) if two < one else (1, 0)
+    if capped <= 0 or n_games <= n_cus:
+        return 1, 0, 'auto'
+    per_lane = (n_games + 1) // 2
+    if per_lane <= capped or per_lane >= 2 * capped:  # one round of the capped trunk, or >= two boards per workgroup
+        return 2, capped, 'auto'
+    return 2, 0, 'parts'
 
 
 class _Lane(object):
@@ -215,11 +222,11 @@ class BatchedSelfPlay(object):
         dev = torch.device(device)
         n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         K = max(1, int(sims_in_flight))
-        auto_lanes, auto_wgs = plan_lanes(n_games * K, n_cus)
+        auto_lanes, auto_wgs, heads_algo = plan_lanes(n_games * K, n_cus)
         if lanes is None:
             lanes, wgs = auto_lanes, auto_wgs
         else:
-            wgs = (n_cus - RESERVED_CUS_PER_XCD * N_XCD) if lanes > 1 else 0
+            wgs, heads_algo = ((n_cus - RESERVED_CUS_PER_XCD * N_XCD) if lanes > 1 else 0), 'auto'
         if trunk_workgroups is not None:
             wgs = trunk_workgroups
         lanes = max(1, min(int(lanes), n_games))
@@ -232,6 +239,7 @@ class BatchedSelfPlay(object):
             ev = HipNetEvaluator(net_module, net_shape if net_shape is not None else board, str(device),
                                  max_boards=g_lane * K)
             ev.hip.set_max_workgroups(max(0, int(wgs)))
+            ev.hip.set_heads_algo(heads_algo)
             evaluators.append(ev)
         sp = cls(engines if lanes > 1 else engines[0], evaluators if lanes > 1 else evaluators[0],
                  temperature=temperature, seed=seed, use_graph=use_graph, sims_per_graph=sims_per_graph,

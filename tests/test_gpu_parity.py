@@ -927,7 +927,10 @@ def test_fused_route_priors_vs_golden_and_unfused(g4):
         for algo, heads in (('split_f16', 'auto'), ('split_f16', 'parts'), ('winograd_f4', 'auto'), ('direct', 'auto')):
             evaluator.hip.set_algo(algo).set_heads_algo(heads)
             got = {}
-            for route, evl in (('fused', evaluator), ('unfused', _UnfusedHipNet(evaluator.hip))):
+            planes = HipNetEvaluator.__new__(HipNetEvaluator)  # the same HipNet, fed float planes instead of positions
+            planes.module, planes.hip, planes.use_positions = evaluator.module, evaluator.hip, False
+            assert planes.needs_obs and evaluator.needs_obs == (algo != 'split_f16')
+            for route, evl in (('fused', evaluator), ('fused_planes', planes), ('unfused', _UnfusedHipNet(evaluator.hip))):
                 eng = _engine(B, n, n_games=len(envs), n_playout=4)
                 _set_roots(eng, envs, reset_trees=True)
                 eng.sim_chunk(evl, 1)  # the first simulation expands every root
@@ -948,6 +951,9 @@ def test_fused_route_priors_vs_golden_and_unfused(g4):
                 assert not pri[g][illegal].any() and 0.0 < pri[g].astype(np.float64).sum() <= 1.0 + 1e-5
             assert np.array_equal(got['fused'][0].view(np.uint32), got['unfused'][0].view(np.uint32)), (B, algo)
             assert np.array_equal(got['fused'][1].view(np.uint64), got['unfused'][1].view(np.uint64)), (B, algo)
+            # the trunk reading the leaf bitboards == the trunk reading the float planes the tree kernel writes
+            assert np.array_equal(got['fused'][0].view(np.uint32), got['fused_planes'][0].view(np.uint32)), (B, algo)
+            assert np.array_equal(got['fused'][1].view(np.uint64), got['fused_planes'][1].view(np.uint64)), (B, algo)
             if algo == 'split_f16':  # the tree kernel adding the GEMM's four K-quarter sums itself: the same bits
                 if heads == 'auto':
                     reference_bits = (got['fused'][0].copy(), got['fused'][1].copy())

@@ -113,9 +113,10 @@ def test_plan_lanes():
     """One lane while the trunk fits a board round or two lanes would need an extra round; two capped lanes
     (4 CUs per XCD left to the other lane's small kernels) otherwise."""
     from rlzero_amd.selfplay import plan_lanes
-    assert plan_lanes(1) == (1, 0) and plan_lanes(512) == (1, 0)
-    assert plan_lanes(448) == (2, 224) and plan_lanes(896) == (2, 224) and plan_lanes(1344) == (2, 224)
-    assert plan_lanes(100, n_cus=32) == (1, 0)  # nothing left to reserve
+    assert plan_lanes(1) == (1, 0, 'auto') and plan_lanes(256) == (1, 0, 'auto')
+    assert plan_lanes(448) == (2, 224, 'auto') and plan_lanes(896) == (2, 224, 'auto') and plan_lanes(1344) == (2, 224, 'auto')
+    assert plan_lanes(512) == (2, 0, 'parts')  # configs[3]'s share: un-capped trunks, small kernels co-resident
+    assert plan_lanes(100, n_cus=32) == (1, 0, 'auto')  # nothing left to reserve
 
 
 def test_batched_pi_and_moves_bit_identical_to_per_game_expressions():

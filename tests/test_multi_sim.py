@@ -41,13 +41,14 @@ def _check_tree(eng, game, env0, sims_expected):
     return collisions
 
 
-@pytest.mark.parametrize('K', [2, 5, 8])
-def test_visit_and_value_conservation(K):
+@pytest.mark.parametrize('impl', ['level_sync', 'sequential'])
+@pytest.mark.parametrize('K', [2, 5, 8, 16])
+def test_visit_and_value_conservation(K, impl):
     from rlzero_amd.engine import MCTSEngine, SyntheticEvaluator, int_to_bits
     cases = [(6, 4, [], 203), (9, 5, [40, 41, 31], 160), (3, 3, [4, 0], 57)]
     for B, n, pre, sims in cases:
         envs = [RefGomoku.from_moves(B, n, pre), RefGomoku(B, n)]
-        eng = MCTSEngine(B, n, n_games=2, n_playout=sims, sims_in_flight=K, device='cuda:0')
+        eng = MCTSEngine(B, n, n_games=2, n_playout=sims, sims_in_flight=K, in_flight_impl=impl, device='cuda:0')
         stones = np.array([[int_to_bits(e.bitboards()[0]), int_to_bits(e.bitboards()[1])] for e in envs], dtype=np.uint64)
         eng.set_roots(stones, [e.current_player() for e in envs], [e.last_move for e in envs], reset_trees=True)
         eng.simulate(SyntheticEvaluator('vlin'), sims)
@@ -73,11 +74,61 @@ def test_visit_and_value_conservation(K):
         eng.close()
 
 
-def test_one_slot_in_use_is_the_sequential_search():
+def _dump_bits(eng, g):
+    return {p: (n, float(w).hex()) for p, (n, w) in eng.tree_dump(g).items()}
+
+
+@pytest.mark.parametrize('mode', ['uct_ref', 'puct'])
+def test_level_synchronous_kernel_equals_its_sequential_restatement(mode):
+    """The production kernel of the mode (a workgroup of K waves per game, slots walked level by level) against the
+    one-wave kernel that selects and backs up one slot after the other: identical trees, bit for bit -- with the
+    synthetic evaluator and with the hand-written net (un-fused and fused routes), over several moves with tree reuse,
+    Dirichlet noise on, ragged last steps (n_playout not a multiple of K)."""
+    import torch
+    from rlzero_amd.engine import HipNetEvaluator, MCTSEngine, SyntheticEvaluator
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    torch.manual_seed(3)
+    net = PolicyValueNet(9)
+    with torch.no_grad():
+        net.act_fc1.weight.mul_(10.0)
+    net = net.to('cuda:0')
+    for evaluator_kind, B, n, G, K, sims in (('vlin', 6, 4, 5, 7, 150), ('net', 9, 5, 6, 8, 123), ('vlin', 15, 5, 3, 16, 200),
+                                             ('net', 9, 5, 4, 3, 64)):
+        engines = [MCTSEngine(B, n, n_games=G, n_playout=sims, sims_in_flight=K, in_flight_impl=impl, score_mode=mode,
+                              add_noise=True, noise_seed=9, device='cuda:0') for impl in ('level_sync', 'sequential')]
+        if evaluator_kind == 'net':
+            net_b = net if B == 9 else None
+            evaluators = [HipNetEvaluator(net_b, B, 'cuda:0', max_boards=G * K) for _ in engines]
+        else:
+            evaluators = [SyntheticEvaluator('vlin') for _ in engines]
+        for eng in engines:
+            eng.reset_games()
+        for move in range(4):
+            for eng, evl in zip(engines, evaluators):
+                eng.simulate(evl, sims)
+                eng.check()
+            va, vb = engines[0].root_visits(), engines[1].root_visits()
+            assert np.array_equal(va, vb), (evaluator_kind, move)
+            assert np.array_equal(engines[0].root_wsum().view(np.uint64), engines[1].root_wsum().view(np.uint64))
+            assert np.array_equal(engines[0].root_priors().view(np.uint32), engines[1].root_priors().view(np.uint32))
+            for g in range(G):
+                assert _dump_bits(engines[0], g) == _dump_bits(engines[1], g), (evaluator_kind, move, g)
+            moves = [int(np.argmax(va[g])) for g in range(G)]
+            for eng in engines:
+                eng.advance(moves)
+                _, ended = eng.step(moves)
+            if ended.any():
+                break
+        for eng in engines:
+            eng.close()
+
+
+@pytest.mark.parametrize('impl', ['level_sync', 'sequential'])
+def test_one_slot_in_use_is_the_sequential_search(impl):
     """sims_in_flight = 4 but every step told to use ONE slot: no other simulation is pending when a path is
     selected, so the tree must equal the oracle's (the virtual loss is put on and taken off exactly: multiples of 1/8)."""
     from rlzero_amd.engine import MCTSEngine, SyntheticEvaluator
-    eng = MCTSEngine(6, 4, n_games=1, n_playout=150, sims_in_flight=4, device='cuda:0')
+    eng = MCTSEngine(6, 4, n_games=1, n_playout=150, sims_in_flight=4, in_flight_impl=impl, device='cuda:0')
     eng.reset_games()
     evaluator = SyntheticEvaluator('vlin')
     for _ in range(150):

@@ -105,15 +105,17 @@ def union_ms(intervals):
 
 def pmc_traffic(kernel, workload, lanes):
     """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes (separate
-    FETCH_SIZE / WRITE_SIZE runs, gfx950 read correction applied; profiles/r01/pmc_traffic.json).
+    FETCH_SIZE / WRITE_SIZE runs, gfx950 read correction applied; profiles/r02/pmc_traffic.json).
     None when no counter run exists for this workload / launch geometry."""
-    try:
-        rec = json.load(open(os.path.join(REPO, 'profiles', 'r01', 'pmc_traffic.json')))
-        if rec['workload'] != workload or rec.get('lanes', 1) != lanes:
-            return None
-        return rec['kernels'][kernel]['traffic_bytes_per_launch']
-    except (OSError, KeyError, ValueError):
-        return None
+    for rnd in ('r02', 'r01'):  # the newest committed counter run that matches this launch geometry
+        try:
+            rec = json.load(open(os.path.join(REPO, 'profiles', rnd, 'pmc_traffic.json')))
+            if rec['workload'] != workload or rec.get('lanes', 1) != lanes:
+                continue
+            return rec['kernels'][kernel]['traffic_bytes_per_launch']
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 # --------------------------------------------------------------------------- CPU baseline

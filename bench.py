@@ -262,20 +262,20 @@ def child_line(flags, timeout=900):
 
 def run_literal_config(args):
     """The literal share of configs[3], 512 games in flight, as a child process with the lane layout plan_lanes() picks
-    for that batch (two lanes of 256 games, un-capped trunks, 'parts' FC GEMM) -> the fields of its line worth keeping."""
-    rec = child_line(['--lanes', 2, '--games', GAMES_PER_GPU, '--trunk-wgs', 0, '--heads-algo', 'parts', '--steps', args.steps,
-                      '--warmup', args.warmup, '--net-algo', args.net_algo, '--graph', args.graph, '--noise',
+    for that batch (one lane: two rounds of its trunk on all CUs) -> the fields of its line worth keeping."""
+    rec = child_line(['--lanes', 1, '--games', GAMES_PER_GPU, '--steps', args.steps, '--warmup', args.warmup,
+                      '--net-algo', args.net_algo, '--heads-algo', args.heads_algo, '--graph', args.graph, '--noise',
                       args.noise, '--no-cpu-baseline', '--no-games-leg', '--no-literal-config', '--no-configs'], 600)
     if rec is None:
         return None
     rf = rec.get('roofline') or {}
-    return {'workload': rec['config']['workload'], 'lanes': 2, 'value': rec['value'], 'unit': rec['unit'],
+    return {'workload': rec['config']['workload'], 'lanes': 1, 'value': rec['value'], 'unit': rec['unit'],
             'ms_per_step': rec['ms_per_step'], 'roofline_frac': rf.get('frac'),
-            'roofline_avg_launch_ms': rf.get('avg_launch_ms'), 'roofline_exclusive_frac': rf.get('exclusive_frac'),
-            'note': 'same engine, %d games in flight = 4096 games / 8 GPUs (BASELINE.json configs[3]) as two lanes of 256 '
-                    'with un-capped trunks and the FC GEMM / tree step co-resident with the other lane\'s trunk '
-                    '(selfplay.plan_lanes); measured by a child process before the main run; one lane of 512: '
-                    '--lanes 1 --games 512' % GAMES_PER_GPU}
+            'roofline_avg_launch_ms': rf.get('avg_launch_ms'),
+            'note': 'same engine, one lane of %d games in flight = 4096 games / 8 GPUs (BASELINE.json configs[3]); '
+                    'measured by a child process before the main run (two lanes of 256 with un-capped trunks and the '
+                    'co-resident FC GEMM: --lanes 2 --games 512 --trunk-wgs 0 --heads-algo parts, -5 %% .. +7 %% '
+                    'depending on the box, profiles/r02/lane_sweeps.txt)' % GAMES_PER_GPU}
 
 
 # the other configurations of BASELINE.json, each measured by a child process of the default N = 1 run
@@ -286,7 +286,7 @@ CONFIG_LEGS = (
      'sequential search; leaf batches of 1024 instead of 64)',
      ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 8, '--in-flight', 16, '--no-cpu-baseline'], 0.0),
     ('C3', 'configs[2] Connect4, 400 sims/move, 512 games', ['--game', 'connect4', '--playouts', 400, '--games', 512, '--lanes', 1, '--steps', 6], 12.0),
-    ('C5', 'configs[4] MuZero CartPole-v1, 50 sims/move, 4096 environments', ['--game', 'muzero', '--playouts', 50, '--games', 4096, '--steps', 8], 12.0),
+    ('C5', 'configs[4] MuZero CartPole-v1, 50 sims/move, 4096 environments', ['--game', 'muzero', '--playouts', 50, '--games', 4096, '--steps', 16], 12.0),
 )
 
 

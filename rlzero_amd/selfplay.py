@@ -138,23 +138,22 @@ def plan_lanes(n_games, n_cus=256):
     """-> (lanes, trunk_workgroups, heads_algo) for ``n_games`` leaves per simulation step on a GPU with ``n_cus`` CUs
     (measured on MI355X, profiles/r02/lane_sweeps.txt; a trunk round = one board per workgroup, ~27-30 us at 15x15).
 
-    * a lane's batch fits ONE round of CUs - 32 workgroups, or is large (>= 2 boards per workgroup): TWO lanes, each
-      trunk capped at CUs - 32 persistent
-      workgroups (4 CUs per XCD stay free), the FC GEMM ('split64') and the tree step of one lane run at full speed
-      on the free CUs under the other lane's trunk;
-    * in between (e.g. the 512 games per GPU of BASELINE.json configs[3]: 256 per lane): TWO lanes with
-      UN-capped trunks (a lane's batch is one round on all CUs) and the 'parts' FC GEMM, whose single-wave workgroups
-      need no LDS and fit on a CU beside a resident trunk workgroup, like the tree step's waves (they run slower
-      there -- the trunk saturates the issue slots -- but hidden): +7 % over one lane at 512 games;
-    * up to one round: one lane, nothing to overlap with.
+    * a lane's half of the batch fits ONE round of CUs - 32 workgroups, or is large (>= 2 boards per workgroup): TWO
+      lanes, each trunk capped at CUs - 32 persistent workgroups (4 CUs per XCD stay free): the FC GEMM ('split64')
+      and the tree step of one lane run at full speed on the free CUs under the other lane's trunk;
+    * in between (e.g. the 512 games per GPU of BASELINE.json configs[3]) and up to one round: ONE lane.  Two lanes of
+      256 with un-capped trunks and the LDS-free 'parts' FC GEMM -- whose waves, like the tree step's, fit on a CU beside
+      a resident trunk workgroup -- were measured at -5 % .. +7 % against one lane depending on the box: beside the
+      trunk, which saturates the issue slots of its SIMDs, the tree step takes 70-115 us instead of 12-15.  Selectable
+      (lanes=2, trunk_workgroups=0, heads algo 'parts'), not the default.
     0 workgroups means "one per CU" (no cap)."""
     capped = n_cus - RESERVED_CUS_PER_XCD * N_XCD
     if capped <= 0 or n_games <= n_cus:
         return 1, 0, 'auto'
     per_lane = (n_games + 1) // 2
-    if per_lane <= capped or per_lane >= 2 * capped:  # one round of the capped trunk, or >= two boards per workgroup
+    if per_lane <= capped or per_lane >= 2 * capped:
         return 2, capped, 'auto'
-    return 2, 0, 'parts'
+    return 1, 0, 'auto'
 
 
 class _Lane(object):

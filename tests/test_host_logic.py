@@ -115,7 +115,7 @@ def test_plan_lanes():
     from rlzero_amd.selfplay import plan_lanes
     assert plan_lanes(1) == (1, 0, 'auto') and plan_lanes(256) == (1, 0, 'auto')
     assert plan_lanes(448) == (2, 224, 'auto') and plan_lanes(896) == (2, 224, 'auto') and plan_lanes(1344) == (2, 224, 'auto')
-    assert plan_lanes(512) == (2, 0, 'parts')  # configs[3]'s share: un-capped trunks, small kernels co-resident
+    assert plan_lanes(512) == (1, 0, 'auto')  # configs[3]'s share: two rounds of one lane's trunk on all CUs
     assert plan_lanes(100, n_cus=32) == (1, 0, 'auto')  # nothing left to reserve
 
 

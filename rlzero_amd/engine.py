@@ -544,12 +544,22 @@ class MCTSEngine(object):
         if K > 1:
             self._in_flight(K, K)
 
+    def _whole_steps(self, n_sims):
+        """``n_sims`` rounded down to whole steps of K simulations (at least one step)."""
+        K = self.sims_in_flight
+        return max(K, int(n_sims) - int(n_sims) % K)
+
     def graph_chunk(self, sims_per_graph):
-        """Simulations a captured chunk holds: ``sims_per_graph``, rounded to whole steps of K simulations when K
-        simulations are in flight."""
+        """Simulations a captured chunk holds.  One simulation in flight: ``sims_per_graph``.  K in flight: whole
+        steps of K simulations -- as many as ``sims_per_graph`` STEPS, lowered to a divisor of the full steps of a
+        search (n_playout // K) so that only the ragged last step is left to eager launches."""
         per = max(1, int(sims_per_graph))
         K = self.sims_in_flight
-        return per if K == 1 else max(K, per - per % K)
+        if K == 1:
+            return per
+        full = max(1, self.n_playout // K)
+        steps = max(s for s in range(1, min(per, full) + 1) if full % s == 0)
+        return K * steps
 
     def simulate(self, evaluator, n_sims=None, use_graph=False, sims_per_graph=8):
         """Run ``n_sims`` (default n_playout) simulations in every active game.
@@ -560,7 +570,7 @@ class MCTSEngine(object):
         if not use_graph or isinstance(evaluator, HostEvaluator):
             self.sim_chunk(evaluator, n)
             return
-        per = self.graph_chunk(sims_per_graph)
+        per = self._whole_steps(sims_per_graph)
         if per > n:
             self.sim_chunk(evaluator, n)
             return
@@ -578,7 +588,7 @@ class MCTSEngine(object):
         and the evaluator).  Capturing executes nothing, but the eager warm-up does run 3
         simulations, so call this on throw-away tree state (before reset_games)."""
         t = self.torch
-        per = self.graph_chunk(per)
+        per = self._whole_steps(per)
         key = (id(evaluator), per)
         if key in self._graphs:
             return self._graphs[key][0]

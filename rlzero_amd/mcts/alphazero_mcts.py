@@ -124,6 +124,14 @@ class AlphaZeroMCTS(object):
             self._evaluator = HostEvaluator(lambda env: self.policy_value_fn(env), make)
         self._engine = eng
         self._bound_k = self.sims_in_flight
+        # device evaluators: the simulation loop is replayed from a hipGraph of 8 simulations (three launches each) --
+        # one game per launch is bound by launch latency, not by the kernels.  Captured now, on the still empty tree.
+        self._graph_sims = 0
+        if not isinstance(self._evaluator, HostEvaluator) and os.environ.get('RLZERO_NO_GRAPH') != '1':
+            eng.reset_games()
+            self._graph_sims = eng.graph_chunk(8)
+            eng.warm_graph(self._evaluator, self._graph_sims)
+            eng.reset_games()
         return eng
 
     def _import_root(self, game_env):
@@ -142,7 +150,7 @@ class AlphaZeroMCTS(object):
         eng = self._import_root(game_env)
         if isinstance(self._evaluator, HipNetEvaluator):
             self._evaluator.refresh_if_changed()  # the learner may have stepped since the last move
-        eng.simulate(self._evaluator, self.n_playout)
+        eng.simulate(self._evaluator, self.n_playout, use_graph=self._graph_sims > 0, sims_per_graph=max(self._graph_sims, 1))
         visits = eng.root_visits()[0]
         eng.check()
         if isinstance(self._evaluator, HipNetEvaluator):

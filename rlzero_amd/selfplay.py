@@ -295,7 +295,9 @@ class BatchedSelfPlay(object):
         if self.use_graph:
             per = self.eng.graph_chunk(self.sims_per_graph)
             full, n = divmod(n, per)
-            for c in range(full):
+            for _ in range(full):
+                # timing samples: every k-th chunk of the run (counted across moves) is launched eagerly
+                c = self._chunks_done = getattr(self, '_chunks_done', -1) + 1
                 eager = self.eager_every > 0 and c % self.eager_every == 0
                 for lane in self.lanes:
                     with self._on(lane):

@@ -415,7 +415,7 @@ def run_muzero(args, rank, world, device, dist, red_device, use_dist=False, cpu_
     n_sims = args.playouts if args.playouts != N_PLAYOUT else 50
     torch.manual_seed(0)
     net = MuZeroNet().to(device).eval()
-    sp = MuZeroSelfPlay(net, CartPoleBatch(G, device, seed=rank), n_sims=n_sims, seed=rank)
+    sp = MuZeroSelfPlay(net, CartPoleBatch(G, device, seed=rank), n_sims=n_sims, seed=rank, fused=bool(args.mz_fused))
     for _ in range(args.warmup):
         sp.play_move()
     torch.cuda.synchronize()
@@ -424,6 +424,8 @@ def run_muzero(args, rank, world, device, dist, red_device, use_dist=False, cpu_
     torch.cuda.synchronize()
     sims0 = sp.sims_done
     sp.sim_events = []  # HIP events around every 8th simulation step (one hipGraph replay) of the timed region
+    if sp.fused:
+        sp.search_events = []  # ... or around every fused search launch (all simulations of a move)
     t0 = time.perf_counter()
     finished = 0
     for _ in range(args.steps):
@@ -444,20 +446,34 @@ def run_muzero(args, rank, world, device, dist, red_device, use_dist=False, cpu_
     sp.tree.check()
     if rank == 0:
         roofline = None
-        if sp.sim_events:
-            ms = sum(a.elapsed_time(b) for a, b in sp.sim_events) / len(sp.sim_events)
-            gbs = MZ_BYTES_PER_SIM * G / (ms * 1e-3) / 1e9
-            tf = MZ_FLOPS_PER_SIM * G / (ms * 1e-3) / 1e12
-            roofline = {'bound': 'hbm', 'kernel': sp.sim_step_label + ', %d environments per launch' % G,
-                        'achieved': round(gbs, 2), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 5),
-                        'traffic': None, 'avg_launch_ms': round(ms, 4), 'launches_timed': len(sp.sim_events),
-                        'flops_achieved_tflops': round(tf, 3), 'flops_frac_of_f32_mfma_peak': round(tf / PEAK_FP32_MATRIX_TFLOPS, 5),
-                        'note': 'one simulation step of all environments (select -> recurrent inference -> expand + backup), '
-                                'HIP events on the launch stream; algorithmic bytes per simulation = %d (hidden state in + out, '
-                                'tree nodes on the path, network heads), algorithmic flops = %d (the 7 dense layers of the '
-                                'recurrent inference): arithmetic intensity 45 flop/B is above the ridge only nominally -- at '
-                                '4096 environments the step is bound by launch / dependent latency, not by either roof'
-                                % (MZ_BYTES_PER_SIM, MZ_FLOPS_PER_SIM)}
+        events = sp.search_events if sp.fused else sp.sim_events
+        per_launch = G * (n_sims if sp.fused else 1)  # simulations one launch carries
+        if events:
+            ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
+            gbs = MZ_BYTES_PER_SIM * per_launch / (ms * 1e-3) / 1e9
+            tf = MZ_FLOPS_PER_SIM * per_launch / (ms * 1e-3) / 1e12
+            if sp.fused:
+                # fp32 FMAs on the vector pipe (no MFMA: a 64 x 64 layer per 64 games; vector fp32 peak = the f32 matrix peak)
+                roofline = {'bound': 'mfma', 'kernel': sp.sim_step_label + ', %d environments per launch' % G,
+                            'achieved': round(tf, 3), 'peak': PEAK_FP32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
+                            'frac': round(tf / PEAK_FP32_MATRIX_TFLOPS, 5), 'traffic': None, 'avg_launch_ms': round(ms, 4),
+                            'launches_timed': len(events), 'hbm_achieved_gbs': round(gbs, 2),
+                            'note': 'achieved = algorithmic flops of the recurrent inference (%d per simulation: its 7 dense '
+                                    'layers) x %d simulations x %d environments per launch / launch duration (HIP events), against '
+                                    'the fp32 peak (vector fp32 = f32-input MFMA = 157.3 TFLOP/s); %d of the 256 CUs hold a '
+                                    'workgroup (64 environments each), and wave 0 of each walks its 64 trees between the layers'
+                                    % (MZ_FLOPS_PER_SIM, n_sims, G, (G + 63) // 64)}
+            else:
+                roofline = {'bound': 'hbm', 'kernel': sp.sim_step_label + ', %d environments per launch' % G,
+                            'achieved': round(gbs, 2), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 5),
+                            'traffic': None, 'avg_launch_ms': round(ms, 4), 'launches_timed': len(events),
+                            'flops_achieved_tflops': round(tf, 3), 'flops_frac_of_f32_mfma_peak': round(tf / PEAK_FP32_MATRIX_TFLOPS, 5),
+                            'note': 'one simulation step of all environments (select -> recurrent inference -> expand + backup), '
+                                    'HIP events on the launch stream; algorithmic bytes per simulation = %d (hidden state in + out, '
+                                    'tree nodes on the path, network heads), algorithmic flops = %d (the 7 dense layers of the '
+                                    'recurrent inference): arithmetic intensity 45 flop/B is above the ridge only nominally -- at '
+                                    '4096 environments the step is bound by launch / dependent latency, not by either roof'
+                                    % (MZ_BYTES_PER_SIM, MZ_FLOPS_PER_SIM)}
         print(json.dumps({
             'metric': 'mcts_sims_per_sec', 'value': round(total / elapsed, 1), 'unit': 'sims/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000.0 * elapsed / max(args.steps, 1), 3),
@@ -516,6 +532,9 @@ def main():
     ap.add_argument('--dump-trajectories', default='',
                     help='rank 0 writes the finished games it holds after the run (N > 1: the gathered ones) as JSON '
                          '{game id: moves, winner, first pi}: a game must not depend on the number of ranks')
+    ap.add_argument('--mz-fused', type=int, default=1,
+                    help='--game muzero: 1 = the whole search of a move in one kernel launch (k_mz_search), 0 = one hipGraph '
+                         'of tree kernels + PyTorch-ROCm layers per simulation')
     ap.add_argument('--in-flight', type=int, default=1,
                     help='K > 1: opt-in virtual-loss mode, K simulations of every tree share one evaluator batch (NOT the '
                          'reference\'s sequential search: results differ from it; for batches too small to fill the GPU)')

@@ -402,6 +402,18 @@ int rz_mz_expand_backup(rz_muzero *e, const float *d_reward, const float *d_prob
                         const uint8_t *d_mask, void *stream);
 /* what: 0 = visit counts (int32), 1 = value sums, 2 = rewards, 3 = priors (float64) of the root's children,
  * [n_games][n_actions] */
+/* The search in ONE launch (k_mz_search): the model of rlzero_amd/muzero/network.py -- dynamics g(s, a) -> (r, s'),
+ * prediction f(s) -> (p, v), hidden size 64, <= 8 actions -- evaluated inside the kernel, a workgroup keeping 64 games and
+ * the weights in LDS for all n_sims simulations.  rz_mz_load_model takes HOST pointers to 14 fp32 tensors in torch layout
+ * ([out][in]): dyn1.weight [64][64 + A], dyn1.bias, dyn2.weight, dyn2.bias, rew1.weight, rew1.bias, rew2.weight [1][64],
+ * rew2.bias, pre1.weight, pre1.bias, pol.weight [A][64], pol.bias, val.weight [1][64], val.bias; call again after every
+ * optimiser step.  rz_mz_search: d_hidden float32 [n_games][slots_per_game][64] with slot 0 = the root's state from the
+ * initial inference (rz_mz_init_roots first); runs n_sims simulations of every game.  The six trace arrays (all or none):
+ * per simulation and game what the kernel selected and what its network returned, [n_sims][n_games] (probs:
+ * x n_actions) -- the parity tests feed them to the CPython restatement of the pseudocode. */
+int rz_mz_load_model(rz_muzero *e, const float *const *h_params, int32_t n_params, int32_t hidden);
+int rz_mz_search(rz_muzero *e, float *d_hidden, int32_t n_sims, int32_t *d_trace_parent, int32_t *d_trace_action,
+                 int32_t *d_trace_leaf, float *d_trace_reward, float *d_trace_probs, float *d_trace_value, void *stream);
 int rz_mz_root_children(rz_muzero *e, int32_t what, void *d_out, void *stream);
 int rz_mz_root_stats(rz_muzero *e, int32_t *d_n, double *d_value_sum, double *d_vmin, double *d_vmax, void *stream);
 int rz_mz_geometry(rz_muzero *e, int32_t *slots_per_game, int64_t *device_bytes);

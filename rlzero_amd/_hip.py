@@ -115,6 +115,8 @@ _SIGNATURES = {
     'rz_mz_init_roots': (c_int, [P, P, P, c_double, P, P]),
     'rz_mz_select': (c_int, [P, P, P, P, P, P]),
     'rz_mz_expand_backup': (c_int, [P, P, P, P, P, P]),
+    'rz_mz_load_model': (c_int, [P, POINTER(c_void_p), c_int32, c_int32]),
+    'rz_mz_search': (c_int, [P, P, c_int32, P, P, P, P, P, P, P]),
     'rz_mz_root_children': (c_int, [P, c_int32, P, P]),
     'rz_mz_root_stats': (c_int, [P, P, P, P, P, P]),
     'rz_mz_geometry': (c_int, [P, POINTER(c_int32), POINTER(c_int64)]),

@@ -16,6 +16,13 @@ class Episode(object):
     def __init__(self):
         self.obs, self.actions, self.rewards, self.policies, self.root_values = [], [], [], [], []
 
+    @classmethod
+    def from_arrays(cls, obs, actions, rewards, policies, root_values):
+        """An episode cut out of the self-play history in one go: numpy arrays with the step as first axis."""
+        ep = cls()
+        ep.obs, ep.actions, ep.rewards, ep.policies, ep.root_values = obs, actions, rewards, policies, root_values
+        return ep
+
     def __len__(self):
         return len(self.actions)
 
@@ -77,7 +84,11 @@ class ReplayBuffer(object):
 class MuZeroSelfPlay(object):
 
     def __init__(self, net, env, n_sims=50, discount=0.997, temperature=1.0, root_dirichlet_alpha=0.25,
-                 root_exploration_fraction=0.25, seed=0, pb_c_base=19652.0, pb_c_init=1.25, use_graph=True):
+                 root_exploration_fraction=0.25, seed=0, pb_c_base=19652.0, pb_c_init=1.25, use_graph=True, fused=None):
+        """``fused``: run the whole search of a move in ONE kernel launch (csrc/rz_muzero.hip k_mz_search: the model is
+        evaluated inside the kernel, weights and 64 games per workgroup resident in LDS); None = whenever the model fits
+        it (hidden size 64, <= 8 actions).  Otherwise one hipGraph of ~15 launches per simulation (tree kernels +
+        PyTorch-ROCm layers)."""
         import torch
         from .tree import MuZeroTree
         self.torch = torch
@@ -93,9 +104,15 @@ class MuZeroSelfPlay(object):
         self.rows = torch.arange(self.n_envs, device=self.device)
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(int(seed))
-        # step history as per-step arrays over all environments; an episode is cut out of it when it ends
-        self._hist = []                                       # [(obs, action, reward, policy, root value)]
-        self._hist_t0 = 0                                     # global step index of _hist[0]
+        # step history: rings [step % HIST][environment] on the host; an episode is cut out of them (one fancy index per
+        # field) when it ends.  CartPole-v1 truncates at 500 steps, so 512 steps of history always cover an episode.
+        self.HIST = max(512, int(getattr(env, 'max_episode_steps', 500)) + 12)
+        G, A = self.n_envs, self.n_actions
+        self._h_obs = np.zeros((self.HIST, G, net.obs_dim), dtype=np.float32)
+        self._h_act = np.zeros((self.HIST, G), dtype=np.int64)
+        self._h_rew = np.zeros((self.HIST, G), dtype=np.float64)
+        self._h_pol = np.zeros((self.HIST, G, A), dtype=np.float32)
+        self._h_val = np.zeros((self.HIST, G), dtype=np.float64)
         self._t = 0                                           # global step index of the next move
         self._ep_start = np.zeros(self.n_envs, dtype=np.int64)
         self.sims_done = 0
@@ -105,9 +122,17 @@ class MuZeroSelfPlay(object):
         # sequence of ~15 small launches with static shapes: captured once as a hipGraph and replayed n_sims
         # times per move.  Captured before any search (the capture runs the step on the still empty trees;
         # every search starts by re-initialising its roots).  Weight updates are in place: the graph stays valid.
+        self.fused = (net.hidden == 64 and self.n_actions <= 8) if fused is None else bool(fused)
+        self._model_seen = None
+        if self.fused:
+            use_graph = False
+            self._refresh_model()
+        self.search_events = None  # bench.py: HIP events around the fused search launches
         self._graph = None
         self.sim_events = None
-        self.sim_step_label = 'MuZero simulation step (k_mz_select + torch recurrent inference + k_mz_expand_backup, one hipGraph)'
+        self.sim_step_label = ('k_mz_search (the whole %d-simulation search of a move in one launch: select, recurrent '
+                               'inference on LDS-resident weights, expand + backup)' % self.n_sims) if self.fused else \
+            'MuZero simulation step (k_mz_select + torch recurrent inference + k_mz_expand_backup, one hipGraph)'
         if use_graph:
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
@@ -120,6 +145,13 @@ class MuZeroSelfPlay(object):
             with torch.no_grad(), torch.cuda.graph(graph):
                 self._sim_step()
             self._graph = graph
+
+    def _refresh_model(self):
+        """(Re-)upload the model's weights for the fused search if the torch module changed (a learner step)."""
+        seen = tuple((p.data_ptr(), p._version) for p in self.net.parameters())
+        if seen != self._model_seen:
+            self.tree.load_model(self.net)
+            self._model_seen = seen
 
     def _sim_step(self):
         t = self.torch
@@ -154,7 +186,20 @@ class MuZeroSelfPlay(object):
             tree.init_roots(probs, noise, self.noise_frac)
             if record is not None:
                 record.append(('root', probs.clone(), None if noise is None else noise.clone()))
-            for i_sim in range(self.n_sims):
+            if self.fused:
+                self._refresh_model()
+                ev = None
+                if self.search_events is not None:
+                    ev = (t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True))
+                    ev[0].record()
+                trace = tree.search_fused(self.hidden, self.n_sims, trace=record is not None)
+                if ev is not None:
+                    ev[1].record()
+                    self.search_events.append(ev)
+                if record is not None:
+                    for i_sim in range(self.n_sims):
+                        record.append(tuple(trace[k][i_sim].clone() for k in ('parent', 'action', 'leaf', 'reward', 'probs', 'value')))
+            for i_sim in range(0 if self.fused else self.n_sims):
                 if self._graph is not None and record is None:
                     if self.sim_events is not None and i_sim % 8 == 3:  # bench.py: HIP events around a sample of the steps, on the launch stream
                         a, b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
@@ -190,27 +235,33 @@ class MuZeroSelfPlay(object):
         visits, root_value = self.search(obs)
         actions = self.select_actions(visits)
         nxt_obs, reward, terminated, truncated = self.env.step(actions)
-        vis_h = visits.cpu().numpy().astype(np.float64)
-        done_h = (terminated | truncated).cpu().numpy()
-        self._hist.append((obs.cpu().numpy(), actions.cpu().numpy(), reward.cpu().numpy(),
-                           (vis_h / vis_h.sum(axis=1, keepdims=True)).astype(np.float32), root_value.cpu().numpy()))
+        # everything the host keeps of this move in ONE device-to-host copy: [obs | action | reward | visits | root value | done]
+        D, A = obs.shape[1], self.n_actions
+        packed = t.cat((obs.to(t.float64), actions.to(t.float64)[:, None], reward.to(t.float64)[:, None],
+                        visits.to(t.float64), root_value.to(t.float64)[:, None],
+                        (terminated | truncated).to(t.float64)[:, None]), dim=1).cpu().numpy()
+        slot = self._t % self.HIST
+        self._h_obs[slot] = packed[:, :D]
+        self._h_act[slot] = packed[:, D].astype(np.int64)
+        self._h_rew[slot] = packed[:, D + 1]
+        vis = packed[:, D + 2:D + 2 + A]
+        self._h_pol[slot] = (vis / vis.sum(axis=1, keepdims=True)).astype(np.float32)
+        self._h_val[slot] = packed[:, D + 2 + A]
+        done_h = packed[:, D + 3 + A] != 0.0
         self._t += 1
         finished = []
-        for i in np.nonzero(done_h)[0]:
-            ep = Episode()
-            for t_ in range(int(self._ep_start[i]) - self._hist_t0, self._t - self._hist_t0):
-                o, a_, r, p_, v = self._hist[t_]
-                ep.obs.append(o[i])
-                ep.actions.append(int(a_[i]))
-                ep.rewards.append(float(r[i]))
-                ep.policies.append(p_[i])
-                ep.root_values.append(float(v[i]))
-            finished.append(ep)
-            self._ep_start[i] = self._t
-        drop = int(self._ep_start.min()) - self._hist_t0  # steps no running episode refers to any more
-        if drop > 0:
-            del self._hist[:drop]
-            self._hist_t0 += drop
+        ended = np.nonzero(done_h)[0]
+        if len(ended):
+            # all episodes that ended with this move in ONE gather per field, then split by length
+            lengths = self._t - self._ep_start[ended]
+            env_idx = np.repeat(ended, lengths)
+            first = np.repeat(self._ep_start[ended], lengths)
+            within = np.arange(int(lengths.sum())) - np.repeat(np.cumsum(lengths) - lengths, lengths)
+            step_idx = (first + within) % self.HIST
+            cuts = np.cumsum(lengths)[:-1]
+            fields = [np.split(h[step_idx, env_idx], cuts) for h in (self._h_obs, self._h_act, self._h_rew, self._h_pol, self._h_val)]
+            finished = [Episode.from_arrays(*parts) for parts in zip(*fields)]
+            self._ep_start[ended] = self._t
         self.obs = nxt_obs
         self.moves_done += self.n_envs
         return finished

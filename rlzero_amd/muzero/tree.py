@@ -45,6 +45,34 @@ class MuZeroTree(object):
         check(self.lib.rz_mz_upload_log_table(self.handle, ctypes.c_void_p(tab.ctypes.data), tab.size),
               'rz_mz_upload_log_table')
 
+    MODEL_PARAMS = ('dyn1.weight', 'dyn1.bias', 'dyn2.weight', 'dyn2.bias', 'rew1.weight', 'rew1.bias', 'rew2.weight',
+                    'rew2.bias', 'pre1.weight', 'pre1.bias', 'pol.weight', 'pol.bias', 'val.weight', 'val.bias')
+
+    def load_model(self, net):
+        """Upload the dynamics / reward / prediction layers of a MuZeroNet (hidden size 64) for ``search_fused``; call
+        again after every optimiser step."""
+        sd = net.state_dict()
+        arrays = [sd[name].detach().to('cpu', self.torch.float32).contiguous().numpy() for name in self.MODEL_PARAMS]
+        ptrs = (ctypes.c_void_p * 14)(*[a.ctypes.data for a in arrays])
+        check(self.lib.rz_mz_load_model(self.handle, ptrs, 14, int(net.hidden)), 'rz_mz_load_model')
+
+    def search_fused(self, hidden, n_sims, trace=False):
+        """All ``n_sims`` simulations of every game in ONE launch (k_mz_search; init_roots and the root's hidden state
+        in ``hidden[:, 0]`` first).  ``trace``: returns per simulation what the kernel selected and its network outputs:
+        dict of tensors parent / action / leaf int32 [n_sims, G], reward / value float32 [n_sims, G], probs [n_sims, G, A]."""
+        t = self.torch
+        out = None
+        args = [None] * 6
+        if trace:
+            kw = dict(device=self.device)
+            G, A = self.n_games, self.n_actions
+            out = {'parent': t.zeros((n_sims, G), dtype=t.int32, **kw), 'action': t.zeros((n_sims, G), dtype=t.int32, **kw),
+                   'leaf': t.zeros((n_sims, G), dtype=t.int32, **kw), 'reward': t.zeros((n_sims, G), dtype=t.float32, **kw),
+                   'probs': t.zeros((n_sims, G, A), dtype=t.float32, **kw), 'value': t.zeros((n_sims, G), dtype=t.float32, **kw)}
+            args = [_ptr(out[k]) for k in ('parent', 'action', 'leaf', 'reward', 'probs', 'value')]
+        check(self.lib.rz_mz_search(self.handle, _ptr(hidden), int(n_sims), *args, self.stream()), 'rz_mz_search')
+        return out
+
     def stream(self):
         return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
 

@@ -111,13 +111,18 @@ def _hexf(x):
 
 
 @pytest.mark.gpu
-def test_muzero_tree_kernels_bit_exact_vs_pseudocode():
+@pytest.mark.parametrize('fused', [True, False])
+def test_muzero_tree_kernels_bit_exact_vs_pseudocode(fused):
+    """Both routes -- the whole search in one launch (k_mz_search, the model evaluated inside the kernel) and the
+    step-by-step route (tree kernels + PyTorch layers) -- against the CPython restatement of the pseudocode fed the network
+    outputs the device used: identical trees, statistic for statistic."""
     import torch
     from rlzero_amd.muzero import CartPoleBatch, MuZeroNet, MuZeroSelfPlay
     torch.manual_seed(1)
     net = MuZeroNet().to('cuda:0').eval()
     env = CartPoleBatch(48, 'cuda:0', seed=2)
-    sp = MuZeroSelfPlay(net, env, n_sims=50, seed=5)
+    sp = MuZeroSelfPlay(net, env, n_sims=50, seed=5, fused=fused)
+    assert sp.fused == fused
     for trial in range(2):
         record = []
         visits, root_value = sp.search(env.observe(), add_noise=True, record=record)
@@ -153,12 +158,47 @@ def test_muzero_tree_kernels_bit_exact_vs_pseudocode():
                 assert _hexf(child.reward) == _hexf(child_rew[g, a]) and _hexf(child.prior) == _hexf(child_pri[g, a])
             assert _hexf(root.value()) == _hexf(root_value[g].item())
         env.step(torch.from_numpy(visits.argmax(axis=1)).to('cuda:0'))
-    # the hipGraph replay of the simulation step (the production path) gives the eager path's trees
+    # the production path (fused: no trace arrays; else the hipGraph replay of the simulation step) gives the traced path's trees
     obs = env.observe()
     v_graph, rv_graph = sp.search(obs, add_noise=False)
     v_graph, rv_graph = v_graph.clone(), rv_graph.clone()
     v_eager, rv_eager = sp.search(obs, add_noise=False, record=[])
-    assert sp._graph is not None and torch.equal(v_graph, v_eager) and torch.equal(rv_graph, rv_eager)
+    assert (sp._graph is not None) != fused and torch.equal(v_graph, v_eager) and torch.equal(rv_graph, rv_eager)
+    sp.tree.check()
+    sp.close()
+
+
+@pytest.mark.gpu
+def test_fused_search_network_matches_the_torch_model():
+    """The recurrent inference k_mz_search evaluates inside the kernel (dynamics, reward head, min-max scaled next state,
+    prediction with softmax) against MuZeroNet.recurrent_inference on the same (parent state, action), simulation by
+    simulation: 1e-5 on reward / value / probabilities and on the hidden state stored for the leaf; ragged batch (not a
+    multiple of 64 games), weights re-uploaded after they change."""
+    import torch
+    from rlzero_amd.muzero import CartPoleBatch, MuZeroNet, MuZeroSelfPlay
+    torch.manual_seed(4)
+    net = MuZeroNet().to('cuda:0').eval()
+    env = CartPoleBatch(100, 'cuda:0', seed=3)
+    sp = MuZeroSelfPlay(net, env, n_sims=30, seed=1)
+    assert sp.fused
+    for round_ in range(2):
+        record = []
+        sp.search(env.observe(), add_noise=True, record=record)
+        hidden = sp.hidden.clone()
+        rows = torch.arange(100, device='cuda:0')
+        worst = 0.0
+        with torch.no_grad():
+            for parent, action, leaf, reward, probs, value in record[1:]:
+                nxt, r, logits, v = net.recurrent_inference(hidden[rows, parent.long()], action.long())
+                worst = max(worst, float((r - reward).abs().max()), float((v - value).abs().max()),
+                            float((torch.softmax(logits, dim=1) - probs).abs().max()),
+                            float((nxt - hidden[rows, leaf.long()]).abs().max()))
+        assert worst <= 1e-5, worst
+        n, _, _, _ = sp.tree.root_stats()
+        assert (n == 30).all()
+        with torch.no_grad():  # a "learner step": the next search must see the new weights
+            for p in net.parameters():
+                p.add_(0.01 * torch.randn_like(p))
     sp.tree.check()
     sp.close()
 

@@ -835,7 +835,7 @@ __global__ __launch_bounds__(kWave) void k_tree_step_vl(Dev E, const float *logp
 //     f64 atomics issued in slot order (same wave, same address: applied in program order), N untouched.
 //   * SELECT of ks new leaves, level by level: at level L the slots sit in at most K distinct nodes; wave j stages the
 //     child records of slot j's node in LDS (all nodes of a level in ONE memory round trip instead of one per slot and
-//     level), then wave 0 walks the slots IN SLOT ORDER: scores from LDS, first maximum, virtual loss into the staged
+//     level), then the slots of a node are walked IN SLOT ORDER by one wave (the groups of different nodes side by side): scores from LDS, first maximum, virtual loss into the staged
 //     record at once (the next slot at the same node sees it), the slot's own view of the chosen child -- N, W as they
 //     were BEFORE its own virtual loss, i.e. with those of the earlier slots only -- goes along to the next level.
 //     This is the sequential rule exactly: what slot j sees at a node are the losses of the slots before it, and
@@ -1106,11 +1106,12 @@ __global__ void k_tree_step_ml(Dev E, const float *logp, const float *value, Raw
             }
         }
         __syncthreads();
-        if (w != 0) continue;
-        // phase B: wave 0 walks the slots in slot order
-        for (int j = 0; j < ks; ++j) {
-            if (!SL[j].active) continue;
-            const int o = SL[j].owner;
+        // phase B: the owner's wave walks the slots of ITS node in slot order (slots at different nodes do not see each
+        // other within a level: the groups run side by side; at the root all slots are one group)
+        if (w < ks && SL[w].active && SL[w].owner == w)
+        for (int j = w; j < ks; ++j) {
+            if (!SL[j].active || SL[j].owner != w) continue;
+            const int o = w;
             const int4 xlo = SL[o].xlo;
             const int4 vlo = SL[j].lo;
             const int k = rec_k(xlo);
@@ -1125,16 +1126,9 @@ __global__ void k_tree_step_ml(Dev E, const float *logp, const float *value, Raw
             int4 clo, chi;
             bool fresh = false;
             if (!puct_mode && nv < k) {
-                if (nv == cap) {  // the child vector grows: new block at the arena top, written from the staged copy below
-                    const int ncap = cap == 0 ? (k < kFirstCap ? k : kFirstCap) : (2 * cap < k ? 2 * cap : k);
-                    if ((long long)top + ncap > E.cap) {
-                        flag(E, g, RZ_FLAG_ARENA_FULL, lane);
-                        if (lane == 0) { SL[j].fresh = 2; SL[j].active = 0; }
-                        continue;
-                    }
-                    fc = top;
-                    top += ncap;
-                    cap = ncap;
+                if (nv == cap) {  // the child vector grows: its new block is allocated in phase C (in owner order, whatever the
+                                  // groups' timing) and written from the staged copy
+                    cap = cap == 0 ? (k < kFirstCap ? k : kFirstCap) : (2 * cap < k ? 2 * cap : k);
                     if (lane == 0) SL[o].moved = 1;
                 }
                 r = nv;
@@ -1213,7 +1207,21 @@ __global__ void k_tree_step_ml(Dev E, const float *logp, const float *value, Raw
                 }
             }
         }
-        // phase C: write back what the pass changed, resolve the slots' new nodes, owners of the next pass
+        __syncthreads();
+        if (w != 0) continue;
+        // phase C (wave 0): new blocks for the child vectors that grew, write back what the pass changed, resolve the slots'
+        // new nodes, owners of the next pass
+        for (int o = 0; o < ks; ++o) {
+            if (SL[o].owner != o || !SL[o].moved) continue;
+            const int4 xlo = SL[o].xlo;
+            const int need = rec_cap(xlo);
+            if ((long long)top + need > E.cap) {
+                flag(E, g, RZ_FLAG_ARENA_FULL, lane);
+                continue;
+            }
+            if (lane == 0) SL[o].xlo = make_int4(xlo.x, top, xlo.z, xlo.w);
+            top += need;
+        }
         for (int o = 0; o < ks; ++o) {
             if (SL[o].owner != o || SL[o].rank < -1) continue;
             const int4 xlo = SL[o].xlo;

@@ -179,6 +179,28 @@ def test_batched_selfplay_with_the_net_and_graphs():
             lane.eng.close()
 
 
+def test_whole_games_with_sims_in_flight():
+    """BatchedSelfPlay.run() to the end of every game (slots refilled) with 4 simulations in flight: trajectories are
+    complete and consistent, no arena flag, no dropped subtree."""
+    import torch
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    from rlzero_amd.selfplay import BatchedSelfPlay
+    torch.manual_seed(2)
+    net = PolicyValueNet(6).to('cuda:0')
+    sp = BatchedSelfPlay.for_network(net, board=6, n_in_row=4, n_games=16, n_playout=60, seed=4, sims_in_flight=4)
+    trajs = sp.run(range(40))
+    assert [t.game_id for t in trajs] == list(range(40))
+    for t in trajs:
+        assert 7 <= len(t.moves) <= 36 and len(set(t.moves)) == len(t.moves) and t.winner in (-1, 0, 1)
+        assert abs(t.pis.sum(axis=1) - 1.0).max() < 1e-9
+        w, data = t.as_reference_tuple()
+        assert len(list(data)) == len(t.moves)
+    for st in sp.check():
+        assert st.reuse_dropped == 0
+    for lane in sp.lanes:
+        lane.eng.close()
+
+
 def test_reference_api_player_with_sims_in_flight():
     """configs[0] (TicTacToe, 25 simulations) through AlphaZeroPlayer with 5 simulations in flight: whole games end,
     pi is a distribution over the legal moves and N(root) = 25 after a fresh search."""

@@ -263,7 +263,8 @@ def child_line(flags, timeout=900):
 def run_literal_config(args):
     """The literal share of configs[3], 512 games in flight, as a child process with the lane layout plan_lanes() picks
     for that batch (one lane: two rounds of its trunk on all CUs) -> the fields of its line worth keeping."""
-    rec = child_line(['--lanes', 1, '--games', GAMES_PER_GPU, '--steps', args.steps, '--warmup', args.warmup,
+    # (a few more warm-up moves than the main run: the GPU has idled through the CPU baseline before this child starts)
+    rec = child_line(['--lanes', 1, '--games', GAMES_PER_GPU, '--steps', args.steps, '--warmup', max(args.warmup, 4),
                       '--net-algo', args.net_algo, '--heads-algo', args.heads_algo, '--graph', args.graph, '--noise',
                       args.noise, '--no-cpu-baseline', '--no-games-leg', '--no-literal-config', '--no-configs'], 600)
     if rec is None:
@@ -279,21 +280,22 @@ def run_literal_config(args):
 
 
 # the other configurations of BASELINE.json, each measured by a child process of the default N = 1 run
-CONFIG_LEGS = (
-    ('C1', 'configs[0] TicTacToe, 25 sims/move, 1 game', ['--board', 3, '--playouts', 25, '--games', 1, '--lanes', 1, '--steps', 9], 5.0),
-    ('C2', 'configs[1] 9x9 Gomoku, 200 sims/move, 64 games', ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 8], 12.0),
+CONFIG_LEGS = (  # (key, title, flags, seconds of CPU baseline at --cpu-seconds 60); warm-up moves sized to ~0.3 s of GPU work:
+    # a leg starts on a GPU that has idled through its own CPU baseline
+    ('C1', 'configs[0] TicTacToe, 25 sims/move, 1 game', ['--board', 3, '--playouts', 25, '--games', 1, '--lanes', 1, '--steps', 9, '--warmup', 200], 5.0),
+    ('C2', 'configs[1] 9x9 Gomoku, 200 sims/move, 64 games', ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 8, '--warmup', 40], 12.0),
     ('C2_16_in_flight', 'configs[1] with the opt-in virtual-loss mode: 16 simulations in flight per tree (NOT the reference\'s '
      'sequential search; leaf batches of 1024 instead of 64)',
-     ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 8, '--in-flight', 16, '--no-cpu-baseline'], 0.0),
-    ('C3', 'configs[2] Connect4, 400 sims/move, 512 games', ['--game', 'connect4', '--playouts', 400, '--games', 512, '--lanes', 1, '--steps', 6], 12.0),
-    ('C5', 'configs[4] MuZero CartPole-v1, 50 sims/move, 4096 environments', ['--game', 'muzero', '--playouts', 50, '--games', 4096, '--steps', 16], 12.0),
+     ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 8, '--warmup', 100, '--in-flight', 16, '--no-cpu-baseline'], 0.0),
+    ('C3', 'configs[2] Connect4, 400 sims/move, 512 games', ['--game', 'connect4', '--playouts', 400, '--games', 512, '--lanes', 1, '--steps', 6, '--warmup', 12], 12.0),
+    ('C5', 'configs[4] MuZero CartPole-v1, 50 sims/move, 4096 environments', ['--game', 'muzero', '--playouts', 50, '--games', 4096, '--steps', 16, '--warmup', 80], 12.0),
 )
 
 
 def run_config_legs(args):
     out = {}
     for key, title, flags, cpu_s in CONFIG_LEGS:
-        rec = child_line(flags + ['--warmup', 2, '--cpu-seconds', max(1.0, cpu_s * args.cpu_seconds / 60.0), '--no-games-leg',
+        rec = child_line(flags + ['--cpu-seconds', max(1.0, cpu_s * args.cpu_seconds / 60.0), '--no-games-leg',
                                   '--no-literal-config', '--no-configs'] + (['--no-cpu-baseline'] if args.no_cpu_baseline else []), 600)
         if rec is None:
             out[key] = {'config': title, 'error': 'the child process printed no line'}

@@ -321,19 +321,31 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     return z ^ (z >> 31);
 }
 
+// 32-bit integer hash (two multiplies, three xor-shifts): the uniforms of the noise come from a counter hashed with it
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
 // One Gamma(0.3, 1) sample (the marginal of numpy's dirichlet(0.3 * ones(k)), node.py:65) from a
 // counter-based stream: Marsaglia-Tsang for shape 1.3, boosted by U^(1/0.3).  The sample is noise: its
-// transcendentals are the hardware ones (v_log_f32 / v_exp_f32 / v_cos_f32 / v_sqrt_f32, ~1 ulp) -- with the
-// correctly rounded library routines four samples per lane cost the tree step 6 us per expansion, with these 1 us.
-__device__ __forceinline__ float gamma03(uint64_t key) {
+// transcendentals are the hardware ones (v_log_f32 / v_exp_f32 / v_cos_f32 / v_sqrt_f32, ~1 ulp) and its uniforms
+// 24-bit fractions of a 32-bit hash of (key, draw index) -- the whole sample is ~60 instructions per rejection round
+// (the 64-bit mixer of the first version cost ~150: a third of the instructions of an expansion, which counts double
+// when the tree step shares a SIMD with a trunk wave).  `key` = 32 bits derived per (seed, game, expansion, child).
+__device__ __forceinline__ float gamma03(uint32_t key) {
     const float d = 1.3f - 1.0f / 3.0f, c = 0.33903103f;  // 1 / sqrt(9 d)
     const float kLn2 = 0.69314718f, k2m24 = 1.0f / 16777216.0f;
     float g = d;
     for (int t = 0; t < 8; ++t) {
-        const uint64_t h1 = mix64(key + 2ull * t), h2 = mix64(key + 2ull * t + 1);
-        const float u1 = (float)((uint32_t)(h1 >> 40) + 1u) * k2m24;        // (0, 1]
-        const float u2 = (float)((uint32_t)(h1 >> 16) & 0xffffffu) * k2m24;  // [0, 1): a turn of the cosine
-        const float u3 = (float)((uint32_t)(h2 >> 40) + 1u) * k2m24;        // (0, 1]
+        const uint32_t h1 = hash32(key + 3u * t), h2 = hash32(key + 3u * t + 1u), h3 = hash32(key + 3u * t + 2u);
+        const float u1 = (float)((h1 >> 8) + 1u) * k2m24;   // (0, 1]
+        const float u2 = (float)(h2 >> 8) * k2m24;           // [0, 1): a turn of the cosine
+        const float u3 = (float)((h3 >> 8) + 1u) * k2m24;   // (0, 1]
         // Box-Muller: sqrt(-2 ln u1) cos(2 pi u2); v_cos_f32 takes its argument in turns
         const float x = __builtin_amdgcn_sqrtf(-2.0f * kLn2 * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
         float v = 1.0f + c * x;
@@ -344,7 +356,7 @@ __device__ __forceinline__ float gamma03(uint64_t key) {
             break;
         }
     }
-    const float ub = (float)((uint32_t)(mix64(key + 31ull) >> 40) + 1u) * k2m24;
+    const float ub = (float)((hash32(key + 0x5bd1e995u) >> 8) + 1u) * k2m24;
     return g * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(ub) * (1.0f / 0.3f));  // ub^(1/0.3)
 }
 
@@ -711,7 +723,7 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
 #pragma unroll
                 for (int j = 0; j < kWords; ++j)
                     if (ranks[j] >= 0) {
-                        noise[j] = gamma03(mix64(key ^ (uint64_t)(64 * j + lane)));
+                        noise[j] = gamma03(hash32((uint32_t)key ^ (uint32_t)(key >> 32)) + 0x9E3779B9u * (uint32_t)(64 * j + lane + 1));
                         local += noise[j];
                     }
 #pragma unroll
@@ -986,7 +998,7 @@ __global__ void k_tree_step_ml(Dev E, const float *logp, const float *value, Raw
 #pragma unroll
                 for (int i = 0; i < kWords; ++i)
                     if (ranks[i] >= 0) {
-                        noise[i] = gamma03(mix64(key ^ (uint64_t)(64 * i + lane)));
+                        noise[i] = gamma03(hash32((uint32_t)key ^ (uint32_t)(key >> 32)) + 0x9E3779B9u * (uint32_t)(64 * i + lane + 1));
                         local += noise[i];
                     }
 #pragma unroll

@@ -2,10 +2,11 @@
 """Headline benchmark: MCTS simulations / second (and self-play games / second) of AlphaZero self-play on
 15x15 Gomoku, 800 simulations per move (BASELINE.json configs[3]), random-init PolicyValueNet
 (torch.manual_seed(0)), fp32.  Games in flight per GPU are an engine parameter (the batch of the leaf
-evaluation): the default keeps 2 lanes x 672 games = 1344 per GPU, which is what fills an MI355X -- the
-network trunk of one lane runs as 224 persistent workgroups (28 of the 32 CUs of every XCD, three boards
-each) while the tree / FC kernels of the other lane use the 32 CUs left free.  `--lanes 1 --games 512` is
-the literal 4096 / 8 games per GPU of configs[3]; at N = 1 the default run measures it too (`literal_config`).
+evaluation): the default keeps 2 lanes x 768 games = 1536 per GPU, which is what fills an MI355X -- the
+network trunk of one lane runs as 256 persistent workgroups (one per CU, three boards each) while the tree / FC
+kernels of the other lane run beside it on the same CUs (their waves fit next to a resident trunk workgroup).
+`--games 512` is the literal 4096 / 8 games per GPU of configs[3]; at N = 1 the default run measures it too
+(`literal_config`); `--trunk-wgs 224 --games 1344` is the capped layout of round 1.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -13,7 +14,7 @@ the literal 4096 / 8 games per GPU of configs[3]; at N = 1 the default run measu
 A "step" is one move of every game on the GPU: n_playout simulation steps (select ->
 evaluate -> expand/backup for all games), pi from the root visits, a move drawn and applied,
 tree reuse; finished games are replaced by fresh ones so the batch stays full.  Games are
-independent, so N GPUs play N x 1344 games with no collective in the timed region (weak
+independent, so N GPUs play N x 1536 games with no collective in the timed region (weak
 scaling); rank 0 prints ONE JSON line.
 
 Also on the line:
@@ -41,7 +42,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 BOARD, N_ROW, N_PLAYOUT, GAMES_PER_GPU, C_PUCT, TEMPERATURE = 15, 5, 800, 512, 5.0, 1.0
-RESERVED_CUS_PER_XCD, N_XCD = 4, 8  # CUs the trunk leaves to the other lane's small kernels
+RESERVED_CUS_PER_XCD, N_XCD = 4, 8  # --trunk-wgs 224: CUs a capped trunk leaves to the other lane's small kernels
 BOARDS_PER_WORKGROUP = 3  # boards per persistent trunk workgroup and step at the default batch
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 PEAK_F16_MATRIX_TFLOPS = 2500.0  # dense f16 / bf16 MFMA, same table
@@ -262,21 +263,24 @@ def child_line(flags, timeout=900):
 
 def run_literal_config(args):
     """The literal share of configs[3], 512 games in flight, as a child process with the lane layout plan_lanes() picks
-    for that batch (one lane: two rounds of its trunk on all CUs) -> the fields of its line worth keeping."""
+    for that batch (two lanes of 256 games, un-capped trunks, 'parts' FC GEMM) -> the fields of its line worth keeping."""
     # (a few more warm-up moves than the main run: the GPU has idled through the CPU baseline before this child starts)
-    rec = child_line(['--lanes', 1, '--games', GAMES_PER_GPU, '--steps', args.steps, '--warmup', max(args.warmup, 4),
-                      '--net-algo', args.net_algo, '--heads-algo', args.heads_algo, '--graph', args.graph, '--noise',
-                      args.noise, '--no-cpu-baseline', '--no-games-leg', '--no-literal-config', '--no-configs'], 600)
+    rec = child_line(['--lanes', 2, '--games', GAMES_PER_GPU, '--trunk-wgs', 0, '--steps', args.steps, '--warmup',
+                      max(args.warmup, 4), '--net-algo', args.net_algo, '--graph', args.graph, '--noise', args.noise,
+                      '--no-cpu-baseline', '--no-games-leg', '--no-literal-config', '--no-configs'], 600)
     if rec is None:
         return None
     rf = rec.get('roofline') or {}
-    return {'workload': rec['config']['workload'], 'lanes': 1, 'value': rec['value'], 'unit': rec['unit'],
-            'ms_per_step': rec['ms_per_step'], 'roofline_frac': rf.get('frac'),
-            'roofline_avg_launch_ms': rf.get('avg_launch_ms'),
-            'note': 'same engine, one lane of %d games in flight = 4096 games / 8 GPUs (BASELINE.json configs[3]); '
-                    'measured by a child process before the main run (two lanes of 256 with un-capped trunks and the '
-                    'co-resident FC GEMM: --lanes 2 --games 512 --trunk-wgs 0 --heads-algo parts, -5 %% .. +7 %% '
-                    'depending on the box, profiles/r02/lane_sweeps.txt)' % GAMES_PER_GPU}
+    return {'workload': rec['config']['workload'], 'lanes': 2, 'value': rec['value'], 'unit': rec['unit'],
+            'ms_per_step': rec['ms_per_step'],
+            # all trunk flops of the run / wall-clock, and the trunk launched alone (256 boards: one round on 256 CUs); the
+            # event-bracketed launches of this layout contain the wait for the other lane's trunk (eager samples)
+            'roofline_frac': rf.get('whole_job_frac'), 'roofline_exclusive_frac': rf.get('exclusive_frac'),
+            'roofline_exclusive_launch_ms': rf.get('exclusive_launch_ms'),
+            'note': 'same engine, %d games in flight = 4096 games / 8 GPUs (BASELINE.json configs[3]) as two lanes of 256 '
+                    'with un-capped trunks, the FC GEMM and the tree step of one lane co-resident with the other lane\'s '
+                    'trunk (selfplay.plan_lanes); measured by a child process before the main run; one lane of 512 '
+                    '(--lanes 1 --games 512) runs 3-12 %% below it (profiles/r02/lane_sweeps.txt)' % GAMES_PER_GPU}
 
 
 # the other configurations of BASELINE.json, each measured by a child process of the default N = 1 run
@@ -503,11 +507,12 @@ def main():
                     help='skip the child-process legs for the other BASELINE.json configurations (C1, C2, C3, C5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--games', type=int, default=0,
-                    help='games per GPU; 0 = lanes x %d boards x trunk workgroups (1344) with 2 lanes, %d with 1' %
+                    help='games per GPU; 0 = lanes x %d boards x trunk workgroups (1536) with 2 lanes, %d with 1' %
                     (BOARDS_PER_WORKGROUP, GAMES_PER_GPU))
-    ap.add_argument('--trunk-wgs', type=int, default=-1,
-                    help='persistent trunk workgroups per lane; -1 = CUs - %d with lanes > 1, one per CU otherwise' %
-                    (RESERVED_CUS_PER_XCD * N_XCD))
+    ap.add_argument('--trunk-wgs', type=int, default=0,
+                    help='persistent trunk workgroups per lane; 0 = one per CU (default: with lanes > 1 the small kernels of '
+                         'one lane run beside the other lane\'s trunk on the same CUs); %d = the capped layout of round 1 '
+                         '(4 CUs per XCD left to the small kernels)' % (256 - RESERVED_CUS_PER_XCD * N_XCD))
     ap.add_argument('--board', type=int, default=BOARD)
     ap.add_argument('--game', default='gomoku', choices=['gomoku', 'connect4', 'muzero'],
                     help='connect4: 6x7, 4 in a row, 7 column actions (BASELINE config 3; pair with '
@@ -610,10 +615,14 @@ def main():
         board, n_row, cells = (6, 7), 4, 42
     n_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
     lanes = max(1, args.lanes)
-    trunk_wgs = args.trunk_wgs
-    if trunk_wgs < 0:
-        trunk_wgs = n_cus - RESERVED_CUS_PER_XCD * N_XCD if lanes > 1 and args.evaluator == 'hipnet' else 0
-    G = args.games if args.games > 0 else (lanes * BOARDS_PER_WORKGROUP * trunk_wgs if trunk_wgs > 0 else GAMES_PER_GPU)
+    trunk_wgs = max(0, args.trunk_wgs)
+    # default batch: lanes x 3 boards x trunk workgroups (1536 with two un-capped lanes on 256 CUs)
+    G = args.games if args.games > 0 else \
+        (lanes * BOARDS_PER_WORKGROUP * (trunk_wgs if trunk_wgs > 0 else n_cus) if lanes > 1 and args.evaluator == 'hipnet'
+         else GAMES_PER_GPU)
+    heads_algo = args.heads_algo
+    if heads_algo == 'auto' and lanes > 1 and trunk_wgs == 0 and args.evaluator == 'hipnet' and args.net_algo == 'split_f16':
+        heads_algo = 'parts'  # un-capped lanes: the LDS-free GEMM that fits beside a resident trunk workgroup
     lanes = max(1, min(lanes, G))
     per_lane = [G // lanes + (1 if i < G % lanes else 0) for i in range(lanes)]
     torch.manual_seed(0)  # identical weights on every rank
@@ -627,7 +636,7 @@ def main():
         if args.evaluator == 'hipnet':
             hip_ev = HipNetEvaluator(net, net_shape, device, max_boards=eng.n_leaves)
             hip_ev.hip.set_algo(args.net_algo)
-            hip_ev.hip.set_heads_algo(args.heads_algo)
+            hip_ev.hip.set_heads_algo(heads_algo)
             hip_ev.hip.set_max_workgroups(trunk_wgs)
             ev = TimedEvaluator(hip_ev, torch,
                                 {'winograd_f4': 'k_trunk_wino_f4<4> (hand-written fused fp32-MFMA conv trunk, Winograd F(4x4,3x3), csrc/rz_net.hip)',

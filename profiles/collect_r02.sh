@@ -18,7 +18,7 @@ echo "default line done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_default" -o s -- $B > "$OUT/bench_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager" -o s -- $B --graph 0 --steps 2 > "$OUT/bench_eager_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_1lane" -o s -- $B --graph 0 --steps 2 --lanes 1 --games 512 > "$OUT/bench_eager_1lane_under_rocprof.json" 2> /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_literal" -o s -- $B --graph 0 --steps 2 --lanes 2 --games 512 --trunk-wgs 0 --heads-algo parts > "$OUT/bench_eager_literal_under_rocprof.json" 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_literal" -o s -- $B --graph 0 --steps 2 --lanes 2 --games 512 > "$OUT/bench_eager_literal_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_c2_k16" -o s -- $B --graph 0 --steps 4 --board 9 --playouts 200 --games 64 --lanes 1 --in-flight 16 > "$OUT/bench_eager_c2_k16_under_rocprof.json" 2> /dev/null
 echo "kernel stats done"
 
@@ -30,9 +30,9 @@ echo "pmc done"
 
 # 4. lane layouts of the literal 512 games per GPU and of large batches; in-flight sweep of configs[1]
 {
-  for spec in "--lanes 1 --games 512" "--lanes 2 --games 512 --trunk-wgs 224" "--lanes 2 --games 512 --trunk-wgs 0" \
-              "--lanes 2 --games 512 --trunk-wgs 0 --heads-algo parts" "--lanes 3 --games 513 --trunk-wgs 0 --heads-algo parts" \
-              "--lanes 2 --games 1344" "--lanes 2 --games 1024 --trunk-wgs 0 --heads-algo parts" "--lanes 2 --games 1536 --trunk-wgs 0 --heads-algo parts"; do
+  for spec in "--lanes 1 --games 512" "--lanes 2 --games 512 --trunk-wgs 224" "--lanes 2 --games 512 --heads-algo split32" \
+              "--lanes 2 --games 512" "--lanes 3 --games 513 --heads-algo parts" \
+              "--lanes 2 --games 1344 --trunk-wgs 224" "--lanes 2 --games 1024" "--lanes 2 --games 1536"; do
     echo "== $spec"; $B $spec 2>/dev/null | python3 -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['value'], r['ms_per_step'], r['roofline']['frac'], r['roofline']['avg_launch_ms'], r.get('small_kernels'))"
   done
 } > "$OUT/lane_sweeps.txt" 2>&1

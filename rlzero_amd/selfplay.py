@@ -138,22 +138,23 @@ def plan_lanes(n_games, n_cus=256):
     """-> (lanes, trunk_workgroups, heads_algo) for ``n_games`` leaves per simulation step on a GPU with ``n_cus`` CUs
     (measured on MI355X, profiles/r02/lane_sweeps.txt; a trunk round = one board per workgroup, ~27-30 us at 15x15).
 
-    * a lane's half of the batch fits ONE round of CUs - 32 workgroups, or is large (>= 2 boards per workgroup): TWO
-      lanes, each trunk capped at CUs - 32 persistent workgroups (4 CUs per XCD stay free): the FC GEMM ('split64')
-      and the tree step of one lane run at full speed on the free CUs under the other lane's trunk;
-    * in between (e.g. the 512 games per GPU of BASELINE.json configs[3]) and up to one round: ONE lane.  Two lanes of
-      256 with un-capped trunks and the LDS-free 'parts' FC GEMM -- whose waves, like the tree step's, fit on a CU beside
-      a resident trunk workgroup -- were measured at -5 % .. +7 % against one lane depending on the box: beside the
-      trunk, which saturates the issue slots of its SIMDs, the tree step takes 70-115 us instead of 12-15.  Selectable
-      (lanes=2, trunk_workgroups=0, heads algo 'parts'), not the default.
+    * up to one round (n_games <= CUs): ONE lane, nothing to overlap with;
+    * a lane's half of the batch fits one round of CUs - 32 workgroups: TWO lanes, each trunk capped at CUs - 32
+      persistent workgroups (4 CUs per XCD stay free): the FC GEMM and the tree step of one lane run at full speed on the
+      free CUs under the other lane's trunk, and the cap costs the trunk nothing;
+    * anything larger (e.g. the 512 games per GPU of BASELINE.json configs[3], or 1536 = 2 lanes x 3 boards x 256
+      workgroups): TWO lanes with UN-capped trunks and the LDS-free 'parts' FC GEMM, whose single-wave workgroups --
+      like the tree step's -- fit on a CU beside a resident trunk workgroup (344 of 512 registers, 151 of 160 KB LDS):
+      the small kernels of one lane run UNDER the other lane's trunk on the same CUs, slower than alone (the trunk
+      saturates the issue slots of its SIMDs) but hidden, and all CUs compute the trunk: +12 % over one lane at 512
+      games, +2 % over capped lanes at 1344-1536.
     0 workgroups means "one per CU" (no cap)."""
     capped = n_cus - RESERVED_CUS_PER_XCD * N_XCD
     if capped <= 0 or n_games <= n_cus:
         return 1, 0, 'auto'
-    per_lane = (n_games + 1) // 2
-    if per_lane <= capped or per_lane >= 2 * capped:
+    if (n_games + 1) // 2 <= capped:
         return 2, capped, 'auto'
-    return 1, 0, 'auto'
+    return 2, 0, 'parts'
 
 
 class _Lane(object):
@@ -225,7 +226,7 @@ class BatchedSelfPlay(object):
         if lanes is None:
             lanes, wgs = auto_lanes, auto_wgs
         else:
-            wgs, heads_algo = ((n_cus - RESERVED_CUS_PER_XCD * N_XCD) if lanes > 1 else 0), 'auto'
+            wgs, heads_algo = (0, 'parts') if lanes > 1 else (0, 'auto')
         if trunk_workgroups is not None:
             wgs = trunk_workgroups
         lanes = max(1, min(int(lanes), n_games))

@@ -114,8 +114,9 @@ def test_plan_lanes():
     (4 CUs per XCD left to the other lane's small kernels) otherwise."""
     from rlzero_amd.selfplay import plan_lanes
     assert plan_lanes(1) == (1, 0, 'auto') and plan_lanes(256) == (1, 0, 'auto')
-    assert plan_lanes(448) == (2, 224, 'auto') and plan_lanes(896) == (2, 224, 'auto') and plan_lanes(1344) == (2, 224, 'auto')
-    assert plan_lanes(512) == (1, 0, 'auto')  # configs[3]'s share: two rounds of one lane's trunk on all CUs
+    assert plan_lanes(448) == (2, 224, 'auto')  # one round of a capped trunk per lane
+    # larger: un-capped trunks on all CUs, the small kernels of one lane co-resident with the other lane's trunk
+    assert plan_lanes(512) == (2, 0, 'parts') and plan_lanes(1344) == (2, 0, 'parts') and plan_lanes(1536) == (2, 0, 'parts')
     assert plan_lanes(100, n_cus=32) == (1, 0, 'auto')  # nothing left to reserve
 
 

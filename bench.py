@@ -291,7 +291,7 @@ CONFIG_LEGS = (  # (key, title, flags, seconds of CPU baseline at --cpu-seconds 
     ('C2_16_in_flight', 'configs[1] with the opt-in virtual-loss mode: 16 simulations in flight per tree (NOT the reference\'s '
      'sequential search; leaf batches of 1024 instead of 64)',
      ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 8, '--warmup', 8, '--in-flight', 16, '--no-cpu-baseline'], 0.0),
-    ('C3', 'configs[2] Connect4, 400 sims/move, 512 games', ['--game', 'connect4', '--playouts', 400, '--games', 512, '--lanes', 1, '--steps', 6, '--warmup', 6], 12.0),
+    ('C3', 'configs[2] Connect4, 400 sims/move, 512 games', ['--game', 'connect4', '--playouts', 400, '--games', 512, '--lanes', 2, '--steps', 6, '--warmup', 6], 12.0),
     ('C5', 'configs[4] MuZero CartPole-v1, 50 sims/move, 4096 environments', ['--game', 'muzero', '--playouts', 50, '--games', 4096, '--steps', 16, '--warmup', 40], 12.0),
 )
 

@@ -539,6 +539,9 @@ def main():
     ap.add_argument('--dump-trajectories', default='',
                     help='rank 0 writes the finished games it holds after the run (N > 1: the gathered ones) as JSON '
                          '{game id: moves, winner, first pi}: a game must not depend on the number of ranks')
+    ap.add_argument('--pipeline', type=int, default=1,
+                    help='1 = the host side of a lane\'s move runs under the other lanes\' simulations (BatchedSelfPlay.'
+                         'play_move_pipelined); 0 = all lanes simulate, then all are finished on the host')
     ap.add_argument('--mz-fused', type=int, default=1,
                     help='--game muzero: 1 = the whole search of a move in one kernel launch (k_mz_search), 0 = one hipGraph '
                          'of tree kernels + PyTorch-ROCm layers per simulation')
@@ -666,11 +669,9 @@ def main():
         first_gen_plies.extend(len(t.moves) for t in done if t.game_id < world * G)
         if (use_dist or args.dump_trajectories) and len(gather_sample) < GATHER_SAMPLE_GAMES:
             gather_sample.extend(done[:GATHER_SAMPLE_GAMES - len(gather_sample)])
-        if done:
+        if done and not args.pipeline:
             free = np.nonzero(sp.slot_game < 0)[0]
-            ids = [next_id[0] + world * i for i in range(len(free))]
-            next_id[0] += world * len(free)
-            sp._start(free, ids)
+            sp._start(free, refill(len(free)))
             sp.retire_finished()
 
     def fence():

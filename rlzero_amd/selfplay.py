@@ -318,22 +318,35 @@ class BatchedSelfPlay(object):
                     with self._on(lane):
                         lane.eng.sim_chunk(lane.evaluator, min(chunk, n - c0))
 
+    def _simulate_lane(self, lane):
+        """Enqueue the n_playout simulations of ONE lane on its stream (graph replays + the eager remainder)."""
+        n = self.eng.n_playout
+        with self._on(lane):
+            if self.use_graph:
+                per = self.eng.graph_chunk(self.sims_per_graph)
+                full, n = divmod(n, per)
+                for _ in range(full):
+                    c = self._chunks_done = getattr(self, '_chunks_done', -1) + 1
+                    if self.eager_every > 0 and c % self.eager_every == 0:
+                        lane.eng.sim_chunk(lane.evaluator, per)
+                    else:
+                        lane.eng.simulate(lane.evaluator, per, use_graph=True, sims_per_graph=per)
+            if n:
+                lane.eng.sim_chunk(lane.evaluator, n)
+
     # -- one move for every running game ----------------------------------------------
-    def play_move(self):
-        """n_playout simulations, then pick / apply one move per game.  Returns the list of
-        trajectories of the games that ended with this move."""
-        eng = self.eng
-        S = eng.n_actions
-        running = np.nonzero(self.slot_game >= 0)[0]
-        self._simulate()
-        visits = np.zeros((self.n_slots, S), dtype=np.int32)
-        for lane in self.lanes:
-            with self._on(lane):
-                visits[lane.slots] = lane.eng.root_visits()
-                if hasattr(getattr(lane.evaluator, 'hip', None), 'check_flags'):
-                    lane.evaluator.hip.check_flags()  # the split-f16 trunk reports activations out of its range
+    def _finish_lane(self, lane):
+        """The move of one lane after its simulations: root visits -> pi -> move drawn (alphazero_mcts.py:88-92,148),
+        tree reuse, game step.  Synchronises that lane's stream only.  Returns the trajectories that ended."""
+        eng = lane.eng
+        lo = lane.slots.start
+        running = lo + np.nonzero(self.slot_game[lane.slots] >= 0)[0]
+        with self._on(lane):
+            visits = lane.eng.root_visits()
+            if hasattr(getattr(lane.evaluator, 'hip', None), 'check_flags'):
+                lane.evaluator.hip.check_flags()  # the split-f16 trunk reports an input outside its range
         self.sims_done += eng.n_playout * len(running)
-        moves = np.full(self.n_slots, -2, dtype=np.int32)
+        moves = np.full(eng.n_games, -2, dtype=np.int32)
         if len(running):
             us = move_uniform(self.seed, self.slot_game[running], self.slot_ply[running])
             taken = self.cell_taken[running]
@@ -342,44 +355,86 @@ class BatchedSelfPlay(object):
                 heights = taken.reshape(len(running), eng.rows, eng.cols).sum(axis=1)
             else:
                 legal = ~taken
-            pis, chosen = batch_pi_and_moves(visits[running], legal, self.temperature, us)
+            pis, chosen = batch_pi_and_moves(visits[running - lo], legal, self.temperature, us)
             cells = heights[np.arange(len(running)), chosen] * eng.cols + chosen if eng.game == 'connect4' else chosen
-            moves[running] = chosen
+            moves[running - lo] = chosen
             self.cell_taken[running, cells] = True
             self.slot_ply[running] += 1
             for i, s_ in enumerate(running):
                 self.slot_pis[s_].append(pis[i])
                 self.slot_moves[s_].append(int(chosen[i]))
-        winner = np.zeros(self.n_slots, dtype=np.int32)
-        ended = np.zeros(self.n_slots, dtype=np.uint8)
         step_moves = np.where(moves >= 0, moves, -1).astype(np.int32)
-        for lane in self.lanes:
-            with self._on(lane):
-                lane.eng.advance(moves[lane.slots])  # tree reuse, before the boards change
-                winner[lane.slots], ended[lane.slots] = lane.eng.step(step_moves[lane.slots])
+        with self._on(lane):
+            lane.eng.advance(moves)  # tree reuse, before the boards change
+            winner, ended = lane.eng.step(step_moves)
         self.moves_done += len(running)
         done = []
         for s in running:
-            if ended[s]:
+            if ended[s - lo]:
                 done.append(Trajectory(self.slot_game[s], eng.board_size, eng.n_in_row,
-                                       self.slot_moves[s], self.slot_pis[s], winner[s], game=eng.game))
+                                       self.slot_moves[s], self.slot_pis[s], winner[s - lo], game=eng.game))
                 self.slot_game[s] = -1
         return done
 
+    def play_move(self):
+        """n_playout simulations, then pick / apply one move per game.  Returns the list of
+        trajectories of the games that ended with this move."""
+        self._simulate()
+        done = []
+        for lane in self.lanes:
+            done.extend(self._finish_lane(lane))
+        return done
+
+    def play_move_pipelined(self, refill=None):
+        """play_move() with the host side of one lane's move hidden under the other lanes' simulations: per lane, wait
+        for ITS simulations, draw and apply its moves, refill its finished slots (``refill(n) -> up to n new game
+        ids``, optional) and enqueue its NEXT move's simulations at once -- while a lane is on the host the others keep
+        the GPU busy.  Every call completes exactly one move of every running game, like play_move(); between calls
+        the simulations of the coming move are already in flight.  Results are those of play_move(): games are
+        independent and their uniforms are keyed by (game, ply)."""
+        for lane in self.lanes:
+            if not getattr(lane, 'primed', False) and (self.slot_game[lane.slots] >= 0).any():
+                self._simulate_lane(lane)
+                lane.primed = True
+        done_all = []
+        for lane in self.lanes:
+            if not getattr(lane, 'primed', False):
+                continue
+            done = self._finish_lane(lane)
+            lane.primed = False
+            if done:
+                if refill is not None:
+                    free = lane.slots.start + np.nonzero(self.slot_game[lane.slots] < 0)[0]
+                    ids = list(refill(len(free)))[:len(free)]
+                    if ids:
+                        self._start(free[:len(ids)], ids)
+                self._retire_lane(lane)
+            if (self.slot_game[lane.slots] >= 0).any():
+                self._simulate_lane(lane)
+                lane.primed = True
+            done_all.extend(done)
+        return done_all
+
+    def _retire_lane(self, lane):
+        idle = np.full(lane.eng.n_games, -2, dtype=np.int32)
+        idle[np.nonzero(self.slot_game[lane.slots] < 0)[0]] = -1
+        with self._on(lane):
+            lane.eng.advance(idle)
+            lane.eng.set_active((self.slot_game[lane.slots] >= 0).astype(np.uint8))
+
     def retire_finished(self):
         """reset_player(): discard the trees of idle slots (game.py:128) and mask them out."""
-        idle = np.full(self.n_slots, -2, dtype=np.int32)
-        idle[np.nonzero(self.slot_game < 0)[0]] = -1
         for lane in self.lanes:
-            with self._on(lane):
-                lane.eng.advance(idle[lane.slots])
-        self._set_active()
+            self._retire_lane(lane)
 
     def check(self):
         return [lane.eng.check() for lane in self.lanes]
 
-    def run(self, game_ids, max_moves=None):
-        """Play all ``game_ids`` to the end; returns trajectories sorted by game id."""
+    def run(self, game_ids, max_moves=None, pipelined=False):
+        """Play all ``game_ids`` to the end; returns trajectories sorted by game id.  ``pipelined``: the host side of a
+        lane's move under the other lanes' simulations (play_move_pipelined); same trajectories."""
+        if pipelined:
+            return self._run_pipelined(game_ids, max_moves)
         pending = list(game_ids)
         G = self.n_slots
         first = pending[:G]
@@ -401,6 +456,28 @@ class BatchedSelfPlay(object):
                 self.retire_finished()
             if max_moves is not None and n_moves >= max_moves:
                 break
+        self.check()
+        return sorted(out, key=lambda t: t.game_id)
+
+
+    def _run_pipelined(self, game_ids, max_moves=None):
+        pending = list(game_ids)
+        first, pending = pending[:self.n_slots], pending[self.n_slots:]
+        self._start(range(len(first)), first)
+        self._set_active()
+
+        def refill(n):
+            take = pending[:n]
+            del pending[:n]
+            return take
+
+        out, n_moves = [], 0
+        while (self.slot_game >= 0).any():
+            out.extend(self.play_move_pipelined(refill))
+            n_moves += 1
+            if max_moves is not None and n_moves >= max_moves:
+                break
+        self.torch.cuda.synchronize()
         self.check()
         return sorted(out, key=lambda t: t.game_id)
 

@@ -495,7 +495,13 @@ def test_two_capped_lanes_with_graphs_equal_one_eager_lane():
     two.refresh_weights()
     a, b = one.run(range(30, 54)), two.run(range(30, 54))
     same(a, b)
-    for lane in one.lanes + two.lanes:
+    # pipelined moves (a lane's host step under the other lanes' simulations, finished slots refilled lane by lane, the
+    # default co-resident layout: un-capped trunks + 'parts' GEMM) and three lanes: still the same trajectories
+    three = BatchedSelfPlay.for_network(net, lanes=3, use_graph=True, sims_per_graph=8, **kw)
+    assert three.lanes[0].evaluator.hip.max_boards >= 4 and three.trunk_workgroups == 0
+    same(one.run(range(54, 90)), three.run(range(54, 90), pipelined=True))
+    same(two.run(range(90, 110), pipelined=True), three.run(range(90, 110)))
+    for lane in one.lanes + two.lanes + three.lanes:
         lane.eng.close()
 
 

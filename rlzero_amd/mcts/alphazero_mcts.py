@@ -130,7 +130,15 @@ class AlphaZeroMCTS(object):
         if not isinstance(self._evaluator, HostEvaluator) and os.environ.get('RLZERO_NO_GRAPH') != '1':
             eng.reset_games()
             self._graph_sims = eng.graph_chunk(8)
-            eng.warm_graph(self._evaluator, self._graph_sims)
+            try:
+                eng.warm_graph(self._evaluator, self._graph_sims)
+            except RuntimeError:
+                # an arbitrary nn.Module (NetEvaluator) may do something a stream capture does not allow: launch it
+                # kernel by kernel instead (the hand-written evaluator always captures)
+                if isinstance(self._evaluator, HipNetEvaluator):
+                    raise
+                eng.torch.cuda.synchronize(eng.device)
+                self._graph_sims = 0
             eng.reset_games()
         return eng
 

@@ -93,9 +93,10 @@ def test_level_synchronous_kernel_equals_its_sequential_restatement(mode):
         net.act_fc1.weight.mul_(10.0)
     net = net.to('cuda:0')
     for evaluator_kind, B, n, G, K, sims in (('vlin', 6, 4, 5, 7, 150), ('net', 9, 5, 6, 8, 123), ('vlin', 15, 5, 3, 16, 200),
-                                             ('net', 9, 5, 4, 3, 64)):
+                                             ('net', 9, 5, 4, 3, 64), ('vlin', (6, 7), 4, 4, 6, 90)):
+        game = 'connect4' if isinstance(B, tuple) else 'gomoku'  # (Connect4: 7 column actions, gravity)
         engines = [MCTSEngine(B, n, n_games=G, n_playout=sims, sims_in_flight=K, in_flight_impl=impl, score_mode=mode,
-                              add_noise=True, noise_seed=9, device='cuda:0') for impl in ('level_sync', 'sequential')]
+                              add_noise=True, noise_seed=9, device='cuda:0', game=game) for impl in ('level_sync', 'sequential')]
         if evaluator_kind == 'net':
             net_b = net if B == 9 else None
             evaluators = [HipNetEvaluator(net_b, B, 'cuda:0', max_boards=G * K) for _ in engines]

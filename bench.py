@@ -663,16 +663,26 @@ def main():
     first_gen_plies = []  # lengths of the finished games among the G games this rank started with
     gather_sample = []    # N > 1: finished trajectories for the one exchange of the path (after the timed region)
 
+    def refill(n):
+        ids = [next_id[0] + world * i for i in range(n)]
+        next_id[0] += world * n
+        return ids
+
     def one_step():
-        done = sp.play_move()
+        # one move of every game, finished slots refilled.  --pipeline 1: the host side of a lane's move (visit counts ->
+        # pi -> move, tree reuse, game step, refill) runs while the other lanes' simulations keep the GPU busy
+        if args.pipeline:
+            done = sp.play_move_pipelined(refill)
+        else:
+            done = sp.play_move()
+            if done:
+                free = np.nonzero(sp.slot_game < 0)[0]
+                sp._start(free, refill(len(free)))
+                sp.retire_finished()
         finished[0] += len(done)
         first_gen_plies.extend(len(t.moves) for t in done if t.game_id < world * G)
         if (use_dist or args.dump_trajectories) and len(gather_sample) < GATHER_SAMPLE_GAMES:
             gather_sample.extend(done[:GATHER_SAMPLE_GAMES - len(gather_sample)])
-        if done and not args.pipeline:
-            free = np.nonzero(sp.slot_game < 0)[0]
-            sp._start(free, refill(len(free)))
-            sp.retire_finished()
 
     def fence():
         torch.cuda.synchronize()

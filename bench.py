@@ -87,23 +87,6 @@ def tree_bytes_per_sim(scanned, created, depth):
     return 12.0 * scanned + 16.0 * created + 24.0 * (depth + 1.0) + 64.0
 
 
-def union_ms(intervals):
-    """Total length (ms) of the union of HIP-event intervals [(start_event, end_event), ...] recorded on any
-    streams of one device, measured on the clock of the earliest start event."""
-    if not intervals:
-        return 0.0
-    base = intervals[0][0]
-    spans = sorted((base.elapsed_time(a), base.elapsed_time(b)) for a, b in intervals)
-    total, cur_s, cur_e = 0.0, spans[0][0], spans[0][1]
-    for s_, e_ in spans[1:]:
-        if s_ > cur_e:
-            total += cur_e - cur_s
-            cur_s, cur_e = s_, e_
-        else:
-            cur_e = max(cur_e, e_)
-    return total + (cur_e - cur_s)
-
-
 def pmc_traffic(kernel, workload, lanes):
     """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes (separate
     FETCH_SIZE / WRITE_SIZE runs, gfx950 read correction applied; profiles/r02/pmc_traffic.json).
@@ -834,12 +817,16 @@ def main():
             # CUs, so a launch's duration is longer than the kernel needs by itself (exclusive_*).
             n_ev = sum(len(ev.events) for ev in evaluators)
             per_stream_ms = sum(ev.mean_ms() * len(ev.events) for ev in evaluators) / n_ev
-            # Launches of different lanes overlap: a lane's trunk is enqueued while the other lane's still holds the
-            # LDS of the 224 CUs, and its workgroups start CU by CU as that one drains, so the interval between a
-            # launch's two events contains time in which it waits.  The duration charged to a launch is therefore
-            # the time during which AT LEAST ONE trunk launch is in flight (union of the event intervals of all
-            # lanes on one clock) / number of launches; with one lane this is the plain average.
-            ms = union_ms([iv for ev in evaluators for iv in ev.events]) / n_ev if lanes > 1 else per_stream_ms
+            # Launches of different lanes overlap: a lane's trunk is enqueued while the other lane's still holds the LDS
+            # of the CUs, and its workgroups start CU by CU as that one drains, so the interval between a launch's two
+            # events contains its wait (avg_launch_ms_per_stream; also what rocprofv3 reports per dispatch).  With
+            # several lanes the duration charged to a launch is the WALL-CLOCK of the timed region / trunk launches in
+            # it -- tree steps, FC GEMMs, kernel boundaries and host time all charged to the trunk: a lower bound of its
+            # efficiency that needs no assumption about which intervals overlap (with the lanes' moves pipelined their
+            # eager timing samples no longer coincide, so a union of sampled intervals would not mean anything).  The
+            # kernel alone is exclusive_*.  With one lane this is the plain average of the event intervals.
+            launches_per_rank = lanes * (total_sims / world / G) / max(1, args.in_flight)
+            ms = (elapsed * 1e3 / launches_per_rank) if lanes > 1 else per_stream_ms
             boards_per_launch = G / float(lanes) * max(1, args.in_flight)
             per_pos = trunk_flops_per_position(cells) if args.evaluator == 'hipnet' else flops_per_position(cells)
             flops = per_pos * boards_per_launch
@@ -853,12 +840,13 @@ def main():
                                 'avg_launch_ms': round(ms, 4), 'avg_launch_ms_per_stream': round(per_stream_ms, 4),
                                 'launches_timed': n_ev,
                                 'note': 'achieved = ALGORITHMIC flops (direct convolution, SURVEY.md 8d) per launch / '
-                                        'average launch duration (HIP events on the launch streams, timed region). With 2 '
-                                        'lanes the launches of the two streams overlap (a trunk is enqueued while the other '
-                                        'lane\'s still holds the CUs and starts as that one drains): avg_launch_ms = time '
-                                        'with at least one trunk launch in flight / launches, avg_launch_ms_per_stream = '
-                                        'plain average of the event intervals (waiting included; what rocprofv3 reports '
-                                        'per dispatch); exclusive_* = the same kernel launched alone after the timed region; whole_job_* = trunk flops of all '
+                                        'average launch duration. One lane: HIP events on the launch stream, timed region. '
+                                        'Several lanes: their trunk launches overlap (one is enqueued while the other '
+                                        'lane\'s still holds the CUs and starts as that one drains), so avg_launch_ms = '
+                                        'wall-clock of the timed region / trunk launches in it (everything else charged to the '
+                                        'trunk: a lower bound), avg_launch_ms_per_stream = plain average of the event intervals '
+                                        'of the eager samples (waiting included; what rocprofv3 reports per dispatch); '
+                                        'exclusive_* = the same kernel launched alone after the timed region; whole_job_* = trunk flops of all '
                                         'simulations / wall-clock; mfma_executed_frac = flops the matrix pipe '
                                         'really executed / time / the peak of that pipe (split_f16: 3.35x the algorithmic '
                                         'flops on the f16 pipe; Winograd F(4x4,3x3) 3.65x fewer on the f32 pipe)',

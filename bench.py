@@ -522,6 +522,10 @@ def main():
     ap.add_argument('--dump-trajectories', default='',
                     help='rank 0 writes the finished games it holds after the run (N > 1: the gathered ones) as JSON '
                          '{game id: moves, winner, first pi}: a game must not depend on the number of ranks')
+    ap.add_argument('--eager-every', type=int, default=10,
+                    help='two extra moves AFTER the timed region launch every k-th graph chunk kernel by kernel with HIP events '
+                         'around the kernels (the timing samples behind roofline.avg_launch_ms of a one-lane run and '
+                         'small_kernels); 0 = none')
     ap.add_argument('--pipeline', type=int, default=1,
                     help='1 = the host side of a lane\'s move runs under the other lanes\' simulations (BatchedSelfPlay.'
                          'play_move_pipelined); 0 = all lanes simulate, then all are finished on the host')
@@ -636,7 +640,7 @@ def main():
         evaluators.append(ev)
     evaluator = evaluators[0]
     sp = BatchedSelfPlay(engines, evaluators, temperature=TEMPERATURE, seed=0,
-                         use_graph=args.graph > 0, sims_per_graph=max(args.graph, 1), eager_every=10)
+                         use_graph=args.graph > 0, sims_per_graph=max(args.graph, 1), eager_every=0)
     sp.warm_graphs()
     # games rank, rank+world, ... ; ids beyond the first G refill finished slots
     next_id = [rank + world * G]
@@ -679,9 +683,6 @@ def main():
     while n_ramp < args.warmup or (time.perf_counter() - t_ramp < 0.3 and n_ramp < args.warmup + 3):
         one_step()
         n_ramp += 1
-    for ev in evaluators:
-        if isinstance(ev, TimedEvaluator):
-            ev.record = True
     sims0, fin0 = sp.sims_done, finished[0]
     fence()
     t0 = time.perf_counter()
@@ -689,6 +690,36 @@ def main():
         one_step()
     fence()
     elapsed = time.perf_counter() - t0
+    # Kernel-level timing samples, right AFTER the timed region on the same games: every k-th graph chunk is launched
+    # kernel by kernel with HIP events around the trunk, the FC GEMM and the tree step.  Not inside the timed region:
+    # there the eager chunks cost 0 % (default, 80-us trunks) to 50 % (Connect4, 15-us trunks) -- the host cannot keep two
+    # lanes of short kernels fed, and a stalled lane breaks the lanes' alternation for the chunks that follow
+    # (profiles/r02/eager_sample_cost.txt).
+    if args.eager_every > 0 and args.graph > 0:
+        sims_keep, fin_keep = sp.sims_done, finished[0]
+        sp.eager_every = args.eager_every
+        for ev in evaluators:
+            if isinstance(ev, TimedEvaluator):
+                ev.record = True
+        for _ in range(2):
+            one_step()
+        fence()
+        for ev in evaluators:
+            if isinstance(ev, TimedEvaluator):
+                ev.record = False
+        sp.eager_every = 0
+        sims_sampled = sp.sims_done - sims_keep
+        sp.sims_done, finished[0] = sims_keep, fin_keep
+    elif args.graph <= 0:
+        sims_sampled = 0
+        for ev in evaluators:
+            if isinstance(ev, TimedEvaluator):
+                ev.record = True
+        one_step()
+        fence()
+        for ev in evaluators:
+            if isinstance(ev, TimedEvaluator):
+                ev.record = False
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -824,7 +855,8 @@ def main():
             # it -- tree steps, FC GEMMs, kernel boundaries and host time all charged to the trunk: a lower bound of its
             # efficiency that needs no assumption about which intervals overlap (with the lanes' moves pipelined their
             # eager timing samples no longer coincide, so a union of sampled intervals would not mean anything).  The
-            # kernel alone is exclusive_*.  With one lane this is the plain average of the event intervals.
+            # kernel alone is exclusive_*.  With one lane this is the plain average of the event intervals (sampled on the
+            # two moves behind the timed region, see above).
             launches_per_rank = lanes * (total_sims / world / G) / max(1, args.in_flight)
             ms = (elapsed * 1e3 / launches_per_rank) if lanes > 1 else per_stream_ms
             boards_per_launch = G / float(lanes) * max(1, args.in_flight)
@@ -840,7 +872,9 @@ def main():
                                 'avg_launch_ms': round(ms, 4), 'avg_launch_ms_per_stream': round(per_stream_ms, 4),
                                 'launches_timed': n_ev,
                                 'note': 'achieved = ALGORITHMIC flops (direct convolution, SURVEY.md 8d) per launch / '
-                                        'average launch duration. One lane: HIP events on the launch stream, timed region. '
+                                        'average launch duration. One lane: HIP events on the launch stream around every '
+                                        'trunk launch of the eager sample chunks of the two moves played right behind the timed '
+                                        'region (sampling inside it slows short-kernel configurations by up to 50 %). '
                                         'Several lanes: their trunk launches overlap (one is enqueued while the other '
                                         'lane\'s still holds the CUs and starts as that one drains), so avg_launch_ms = '
                                         'wall-clock of the timed region / trunk launches in it (everything else charged to the '

@@ -146,8 +146,8 @@ def plan_lanes(n_games, n_cus=256):
       workgroups): TWO lanes with UN-capped trunks and the LDS-free 'parts' FC GEMM, whose single-wave workgroups --
       like the tree step's -- fit on a CU beside a resident trunk workgroup (344 of 512 registers, 151 of 160 KB LDS):
       the small kernels of one lane run UNDER the other lane's trunk on the same CUs (rocprof: tree step 13.5 us
-      there against 11.2 alone, GEMM 4.6 us) and all CUs compute the trunk: +12 % over one lane at 512 games, +1-2 %
-      over capped lanes at 1344-1536.
+      there against 11.2 alone, GEMM 4.6 us) and all CUs compute the trunk: 8.2 M sims/s against 6.8 M on one lane at 512
+      games (15x15), +2-3 % over capped lanes at 1344-1536.
     0 workgroups means "one per CU" (no cap)."""
     capped = n_cus - RESERVED_CUS_PER_XCD * N_XCD
     if capped <= 0 or n_games <= n_cus:

@@ -842,12 +842,13 @@ def main():
             'arena_slots_used_max': int(stats.max_slots_used),
             'engine_hbm_bytes': int(hbm_bytes),
         }
-        if isinstance(evaluator, TimedEvaluator) and evaluator.mean_ms():
+        trunk_events = [iv for ev in evaluators if isinstance(ev, TimedEvaluator) for iv in ev.events]
+        if isinstance(evaluator, TimedEvaluator) and trunk_events:
             # one launch = the trunk of one lane's leaves; durations from HIP events on that lane's
             # stream.  With lanes > 1 the launches of different lanes overlap in time and share the
             # CUs, so a launch's duration is longer than the kernel needs by itself (exclusive_*).
-            n_ev = sum(len(ev.events) for ev in evaluators)
-            per_stream_ms = sum(ev.mean_ms() * len(ev.events) for ev in evaluators) / n_ev
+            n_ev = len(trunk_events)
+            per_stream_ms = sum(a.elapsed_time(b) for a, b in trunk_events) / n_ev
             # Launches of different lanes overlap: a lane's trunk is enqueued while the other lane's still holds the LDS
             # of the CUs, and its workgroups start CU by CU as that one drains, so the interval between a launch's two
             # events contains its wait (avg_launch_ms_per_stream; also what rocprofv3 reports per dispatch).  With

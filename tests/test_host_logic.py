@@ -141,26 +141,3 @@ def test_batched_pi_and_moves_bit_identical_to_per_game_expressions():
                 assert np.array_equal(full, pi[r]) and draw_move(acts, p, us[r]) == mv[r]
 
 
-def test_bench_union_of_launch_intervals():
-    """bench.py charges overlapping trunk launches of two lanes once: the union of their event intervals."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(REPO, 'bench.py'))
-    bench = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(bench)
-
-    class Ev(object):  # a HIP event stand-in: a timestamp in ms
-        def __init__(self, t):
-            self.t = t
-
-        def elapsed_time(self, other):
-            return other.t - self.t
-
-    iv = lambda a, b: (Ev(a), Ev(b))  # noqa: E731
-    assert bench.union_ms([]) == 0.0
-    assert bench.union_ms([iv(5.0, 7.0)]) == 2.0
-    # lane 0: [0, 2], [4, 6]; lane 1: [1, 3], [3.5, 4.5], [10, 11] -> union [0, 3] + [3.5, 6] + [10, 11]
-    got = bench.union_ms([iv(0, 2), iv(4, 6), iv(1, 3), iv(3.5, 4.5), iv(10, 11)])
-    assert abs(got - (3.0 + 2.5 + 1.0)) < 1e-12
-    # nested and unsorted intervals
-    assert abs(bench.union_ms([iv(2, 3), iv(0, 10), iv(9, 12)]) - 12.0) < 1e-12
-    assert bench.flops_per_position(225) == 188416 * 225 + 8 * 225 * 225 + 128

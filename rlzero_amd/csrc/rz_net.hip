@@ -837,10 +837,6 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     float *hw = reinterpret_cast<float *>(c2 + sp::kC2Bytes);  // head weights [128][6], then conv3 biases [128]
     const int tid0 = threadIdx.x;
     const int BH = nd.BH, BW = nd.BW, S = nd.S;
-    {
-        f32x4 *z = reinterpret_cast<f32x4 *>(lds_raw);
-        for (int i = tid0; i < sp::kLdsBytes / 16; i += kThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
     float zmax = 0.0f;  // largest scaled value this thread stored as f16 pieces
     constexpr int kObsPer = (4 * RZ_MAX_BOARD_SIZE * RZ_MAX_BOARD_SIZE + kThreads - 1) / kThreads;
     float ob[kObsPer];
@@ -899,11 +895,20 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
                 *reinterpret_cast<_Float16 *>(in0 + sp::kInPieceBytes + obs_off[k]) = (_Float16)(z - (float)hi);
             }
     };
-    __syncthreads();
-    for (int i = tid0; i < 128 * 7; i += kThreads) hw[i] = i < 768 ? nd.whp[i] : nd.b3[i - 768];
+    // Prologue of a persistent workgroup.  Every global load it needs -- head weights and conv3 biases (3.5 KB, bound for
+    // LDS), the rescaling factors and activation scales, conv1's weights and biases (registers), the first board -- is
+    // ISSUED first, the 151 KB of LDS are zeroed under their latency, and only then the values are stored: with one board
+    // per workgroup (256 boards per launch) the prologue is not amortised, and two lanes alternate such launches.
+    constexpr int kHwPer = (128 * 7 + kThreads - 1) / kThreads;
+    float hw_reg[kHwPer];
+#pragma unroll
+    for (int k = 0; k < kHwPer; ++k) {
+        const int i = tid0 + k * kThreads;
+        hw_reg[k] = i < 768 ? nd.whp[i] : (i < 128 * 7 ? nd.b3[i - 768] : 0.0f);
+    }
     // the 6 head biases too: a global load in the epilogue would sit between the feature stores, and its
     // s_waitcnt vmcnt(0) also waits for the stores before it -- six store round trips per board
-    if (tid0 < 8) hw[128 * 7 + tid0] = tid0 < 6 ? nd.bh[tid0] : 0.0f;
+    const float bh_reg = tid0 < 6 ? nd.bh[tid0] : 0.0f;
     // the rescaling factors and the activation scales of the layers (powers of two chosen by rz_net_load from
     // bounds on the activations) once per workgroup: a load placed behind a layer's MFMA loop is exposed in full
     const float k1 = nd.s_inv[2], k2 = nd.s_inv[0], k3 = nd.s_inv[1];
@@ -920,10 +925,23 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
 #pragma unroll
         for (int g = 0; g < 4; ++g) bias1[g] = *reinterpret_cast<const f32x4 *>(nd.b1 + 8 * g + 4 * (lane0 >> 5)) * act1;
     }
-    if ((int)blockIdx.x < n_boards) {
+    const bool first = (int)blockIdx.x < n_boards;
+    if (first) {
         if (from_bits) load_bits(blockIdx.x, tid0); else load_obs(blockIdx.x, tid0);
-        store_obs(tid0);
     }
+    __builtin_amdgcn_sched_barrier(0);  // the loads above stay above the zeroing
+    {
+        f32x4 *z = reinterpret_cast<f32x4 *>(lds_raw);
+        for (int i = tid0; i < sp::kLdsBytes / 16; i += kThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kHwPer; ++k) {
+        const int i = tid0 + k * kThreads;
+        if (i < 128 * 7) hw[i] = hw_reg[k];
+    }
+    if (tid0 < 8) hw[128 * 7 + tid0] = bh_reg;
+    if (first) store_obs(tid0);
     __syncthreads();
     for (int board = blockIdx.x; board < n_boards; board += gridDim.x) {
     int tid = tid0;

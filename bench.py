@@ -405,6 +405,8 @@ def run_muzero(args, rank, world, device, dist, red_device, use_dist=False, cpu_
     torch.manual_seed(0)
     net = MuZeroNet().to(device).eval()
     sp = MuZeroSelfPlay(net, CartPoleBatch(G, device, seed=rank), n_sims=n_sims, seed=rank, fused=bool(args.mz_fused))
+    if args.mz_gpw:
+        sp.tree.set_search_shape(args.mz_gpw)
     for _ in range(args.warmup):
         sp.play_move()
     torch.cuda.synchronize()
@@ -529,6 +531,8 @@ def main():
     ap.add_argument('--pipeline', type=int, default=1,
                     help='1 = the host side of a lane\'s move runs under the other lanes\' simulations (BatchedSelfPlay.'
                          'play_move_pipelined); 0 = all lanes simulate, then all are finished on the host')
+    ap.add_argument('--mz-gpw', type=int, default=0,
+                    help='--game muzero: games per workgroup of k_mz_search (rz_mz_set_search_shape; 0 = automatic)')
     ap.add_argument('--mz-fused', type=int, default=1,
                     help='--game muzero: 1 = the whole search of a move in one kernel launch (k_mz_search), 0 = one hipGraph '
                          'of tree kernels + PyTorch-ROCm layers per simulation')

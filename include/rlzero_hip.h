@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 17
+#define RZ_ABI_VERSION 18
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 #define RZ_MAX_IN_FLIGHT 16 /* rz_config.sims_in_flight */
@@ -332,8 +332,8 @@ int rz_net_set_max_workgroups(rz_net *net, int32_t max_workgroups);
  * 64 boards per workgroup; needs the f16 feature pieces that the RZ_NET_SPLIT_F16 trunk writes into the internal
  * buffer, and falls back to F32 when the last trunk was another one.
  * RZ_NET_HEADS_AUTO (default): after the RZ_NET_SPLIT_F16 trunk SPLIT_64 when the trunk is capped by
- * rz_net_set_max_workgroups (the GEMM then has only the few CUs the trunk leaves free) and SPLIT_32 otherwise -- both
- * give the same bits; F32 after the other trunks.  RZ_NET_HEADS_SPLIT_PARTS: the same arithmetic with NO reduction inside
+ * rz_net_set_max_workgroups (the GEMM then has only the few CUs the trunk leaves free), otherwise SPLIT_PARTS up to 256
+ * boards and SPLIT_32 above -- all give the same bits; F32 after the other trunks.  RZ_NET_HEADS_SPLIT_PARTS: the same arithmetic with NO reduction inside
  * the GEMM -- one single-wave workgroup per (32 boards x 32 outputs x K quarter), no LDS, few registers, so its waves fit on
  * a CU beside a resident trunk workgroup of another lane; the four partial sums are added by the consumer (the tree kernel
  * of the fused route, k_heads_finish otherwise; see rz_raw_heads) in the order the other shapes use: same bits again.
@@ -403,8 +403,10 @@ int rz_mz_expand_backup(rz_muzero *e, const float *d_reward, const float *d_prob
 /* what: 0 = visit counts (int32), 1 = value sums, 2 = rewards, 3 = priors (float64) of the root's children,
  * [n_games][n_actions] */
 /* The search in ONE launch (k_mz_search): the model of rlzero_amd/muzero/network.py -- dynamics g(s, a) -> (r, s'),
- * prediction f(s) -> (p, v), hidden size 64, <= 8 actions -- evaluated inside the kernel, a workgroup keeping 64 games and
- * the weights in LDS for all n_sims simulations.  rz_mz_load_model takes HOST pointers to 14 fp32 tensors in torch layout
+ * prediction f(s) -> (p, v), hidden size 64, <= 8 actions -- evaluated inside the kernel on the matrix pipe, a workgroup
+ * keeping <= 16 games, its waves' weight fragments in registers and (when they fit) the games' trees in LDS for all n_sims
+ * simulations.  rz_mz_set_search_shape: games per workgroup, 0 (default) = chosen from n_games and the CU count so that
+ * every CU holds at least two workgroups when there are games enough (4 / 8 / 16).  rz_mz_load_model takes HOST pointers to 14 fp32 tensors in torch layout
  * ([out][in]): dyn1.weight [64][64 + A], dyn1.bias, dyn2.weight, dyn2.bias, rew1.weight, rew1.bias, rew2.weight [1][64],
  * rew2.bias, pre1.weight, pre1.bias, pol.weight [A][64], pol.bias, val.weight [1][64], val.bias; call again after every
  * optimiser step.  rz_mz_search: d_hidden float32 [n_games][slots_per_game][64] with slot 0 = the root's state from the
@@ -414,6 +416,7 @@ int rz_mz_expand_backup(rz_muzero *e, const float *d_reward, const float *d_prob
 int rz_mz_load_model(rz_muzero *e, const float *const *h_params, int32_t n_params, int32_t hidden);
 int rz_mz_search(rz_muzero *e, float *d_hidden, int32_t n_sims, int32_t *d_trace_parent, int32_t *d_trace_action,
                  int32_t *d_trace_leaf, float *d_trace_reward, float *d_trace_probs, float *d_trace_value, void *stream);
+int rz_mz_set_search_shape(rz_muzero *e, int32_t games_per_workgroup);
 int rz_mz_root_children(rz_muzero *e, int32_t what, void *d_out, void *stream);
 int rz_mz_root_stats(rz_muzero *e, int32_t *d_n, double *d_value_sum, double *d_vmin, double *d_vmax, void *stream);
 int rz_mz_geometry(rz_muzero *e, int32_t *slots_per_game, int64_t *device_bytes);

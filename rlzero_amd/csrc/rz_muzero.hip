@@ -84,24 +84,25 @@ __global__ void k_mz_init(MzDev E, const float *probs, const double *noise, doub
     E.depth[g] = 0;
 }
 
-// select_child down to the first unexpanded node; max() over (score, action): ties go to the LARGER action
-__device__ __forceinline__ void mz_select_one(const MzDev &E, int g, int &par_out, int &act_out, int &leaf_out) {
-    const long long base = (long long)g * E.cap;
-    int32_t *path = E.path + (long long)g * E.path_stride;
-    const double lo = E.vmin[g], hi = E.vmax[g];
+// select_child down to the first unexpanded node; max() over (score, action): ties go to the LARGER action.
+// ``nodes`` = slot 0 of this game's tree, ``path`` = its path buffer, ``pb_log`` = the host's log table (each in HBM
+// for the step-by-step kernels, in LDS inside k_mz_search: the arithmetic is this one function).  -> depth of the leaf
+template <typename NodeP, typename PathP, typename LogP>
+__device__ __forceinline__ int mz_descend(const MzDev &E, NodeP nodes, PathP path, LogP pb_log, double lo, double hi,
+                                          int &par_out, int &act_out, int &leaf_out) {
     int node = 0, depth = 0, last_action = 0, par = 0;
     path[0] = 0;
-    MzNode cur = E.nodes[base];
+    MzNode cur = nodes[0];
     while (cur.first_child >= 0 && depth + 1 < E.path_stride) {
         const int fc = cur.first_child;
         const int pn = cur.N;
-        const double pb_c0 = E.pb_log[pn <= E.n_sims + 1 ? pn : E.n_sims + 1] + E.pb_c_init;
+        const double pb_c0 = pb_log[pn <= E.n_sims + 1 ? pn : E.n_sims + 1] + E.pb_c_init;
         const double sq = sqrt((double)pn);
         double best = -INFINITY;
         int besta = 0;
         MzNode bestn = cur;
         for (int a = 0; a < E.n_actions; ++a) {
-            const MzNode ch = E.nodes[base + fc + a];
+            const MzNode ch = nodes[fc + a];
             const int cn = ch.N;
             const double pb_c = pb_c0 * (sq / (double)(cn + 1));
             const double prior_score = pb_c * ch.prior;
@@ -121,10 +122,15 @@ __device__ __forceinline__ void mz_select_one(const MzDev &E, int g, int &par_ou
         depth += 1;
         path[depth] = node;
     }
-    E.depth[g] = depth;
     par_out = par;
     act_out = last_action;
     leaf_out = node;
+    return depth;
+}
+
+__device__ __forceinline__ void mz_select_one(const MzDev &E, int g, int &par_out, int &act_out, int &leaf_out) {
+    E.depth[g] = mz_descend(E, E.nodes + (long long)g * E.cap, E.path + (long long)g * E.path_stride, E.pb_log, E.vmin[g],
+                            E.vmax[g], par_out, act_out, leaf_out);
 }
 
 __global__ void k_mz_select(MzDev E, int32_t *parent, int32_t *action, int32_t *leaf, const uint8_t *mask) {
@@ -138,34 +144,45 @@ __global__ void k_mz_select(MzDev E, int32_t *parent, int32_t *action, int32_t *
 }
 
 // expand_node(leaf, network_output) + backpropagate(search_path, value, discount, min_max_stats); `probs` = the
-// n_actions probabilities of this game
-__device__ __forceinline__ void mz_expand_backup_one(const MzDev &E, int g, float reward_g, const float *probs, float value_g) {
-    const long long base = (long long)g * E.cap;
-    const int32_t *path = E.path + (long long)g * E.path_stride;
-    const int depth = E.depth[g];
+// n_actions probabilities of this game (MAXA > 0: a register array of MAXA entries, indexed by an unrolled loop)
+template <int MAXA, typename NodeP, typename PathP>
+__device__ __forceinline__ void mz_grow_backup(const MzDev &E, NodeP nodes, PathP path, int depth, int &top, double &lo,
+                                               double &hi, float reward_g, const float *probs, float value_g) {
     const int leaf = path[depth];
-    const int top = E.top[g];
     if (top + E.n_actions > E.cap) {
         atomicOr(E.err, RZ_FLAG_ARENA_FULL);
     } else {
-        E.nodes[base + leaf].reward = reward_g;
-        E.nodes[base + leaf].first_child = top;
-        for (int a = 0; a < E.n_actions; ++a) E.nodes[base + top + a] = MzNode{0, -1, 0.0, (double)probs[a], 0.0f, 0};
-        E.top[g] = top + E.n_actions;
+        nodes[leaf].reward = reward_g;
+        nodes[leaf].first_child = top;
+        if (MAXA > 0) {
+#pragma unroll
+            for (int a = 0; a < (MAXA > 0 ? MAXA : 1); ++a)
+                if (a < E.n_actions) nodes[top + a] = MzNode{0, -1, 0.0, (double)probs[a], 0.0f, 0};
+        } else {
+            for (int a = 0; a < E.n_actions; ++a) nodes[top + a] = MzNode{0, -1, 0.0, (double)probs[a], 0.0f, 0};
+        }
+        top += E.n_actions;
     }
     double v = (double)value_g;
-    double lo = E.vmin[g], hi = E.vmax[g];
     for (int d = depth; d >= 0; --d) {
-        MzNode *nd = E.nodes + base + path[d];
-        const double sum = nd->value_sum + v;
-        const int n = nd->N + 1;
-        nd->value_sum = sum;
-        nd->N = n;
+        const int slot = path[d];
+        const double sum = nodes[slot].value_sum + v;
+        const int n = nodes[slot].N + 1;
+        nodes[slot].value_sum = sum;
+        nodes[slot].N = n;
         const double nv = sum / (double)n;
         hi = nv > hi ? nv : hi;  // MinMaxStats.update
         lo = nv < lo ? nv : lo;
-        v = (double)nd->reward + E.discount * v;
+        v = (double)nodes[slot].reward + E.discount * v;
     }
+}
+
+__device__ __forceinline__ void mz_expand_backup_one(const MzDev &E, int g, float reward_g, const float *probs, float value_g) {
+    int top = E.top[g];
+    double lo = E.vmin[g], hi = E.vmax[g];
+    mz_grow_backup<0>(E, E.nodes + (long long)g * E.cap, E.path + (long long)g * E.path_stride, E.depth[g], top, lo, hi,
+                      reward_g, probs, value_g);
+    E.top[g] = top;
     E.vmin[g] = lo;
     E.vmax[g] = hi;
 }
@@ -181,19 +198,25 @@ __global__ void k_mz_expand_backup(MzDev E, const float *reward, const float *pr
 // ------------------------------------------------------------------ the whole search in ONE launch
 // k_mz_search: every simulation of every game's search -- select, gather of the parent's hidden state, recurrent
 // inference (dynamics + reward head + prediction of rlzero_amd/muzero/network.py, hidden size 64), scatter of the new
-// hidden state, expand + backup -- inside one kernel.  Games are independent, so a workgroup keeps 64 games and the
-// model's weights (65 KB, k-major) in LDS for all n_sims simulations: no launch, no global synchronisation and no
-// weight traffic between simulations (the step-by-step route replays a hipGraph of ~15 small launches per simulation).
-//   * 8 waves; lane = game, wave w owns output units 8w .. 8w+7 of every 64-wide layer: a thread accumulates its 8
-//     units over k with the activation of ITS game (one ds_read per k, conflict-free [k][65] layout) and 8 weights
-//     broadcast from LDS (two ds_read_b128 per k): plain fp32 FMAs at the vector rate, which on CDNA equals the
-//     f32-input MFMA rate (and needs no fragment shuffles for a 64 x 64 layer);
+// hidden state, expand + backup -- inside one kernel: no launch, no global synchronisation and no weight traffic
+// between simulations (the step-by-step route replays a hipGraph of ~15 small launches per simulation).
+// A search is a chain of short dependent steps per game, so the kernel is built for LATENCY and for filling the chip
+// with few games: a workgroup of 4 waves owns `gpw` <= 16 games (4096 games -> 512 workgroups of 8, two per CU: one
+// walks its trees while the other runs its layers).
+//   * the layers are 64 x K GEMMs over the workgroup's games on the matrix pipe, v_mfma_f32_16x16x4_f32 (exact f32
+//     products, f32 accumulation): games = the 16 columns, wave w owns output units 16w .. 16w+15.  The WEIGHTS are
+//     the A operands and never change: each wave keeps its fragments of all four layers in 66 registers for the whole
+//     search; activations go [k][game] through 13 KB of LDS (B operand: one conflict-free ds_read_b32 per MFMA);
 //   * dyn2 and rew1 read the same activations: one pass over k feeds both; the per-sample min-max scaling of the new
-//     state and the scalar heads (reward, policy logits, value) reduce over the 8 waves through LDS in wave order;
-//   * wave 0 walks and updates the 64 trees (one thread per game, the code of k_mz_select / k_mz_expand_backup), in
-//     fp64 with the host's log table: the tree arithmetic is the step-by-step route's, bit for bit, given the same
-//     network outputs (the outputs themselves differ from rocBLAS' in the last bits: another summation order).
-constexpr int kMzH = 64, kMzLd = 65, kMzWaves = 8, kMzMaxA = 8;
+//     state reduces over the rows with two DPP steps inside a wave and over the 4 waves through LDS; the scalar heads
+//     (reward; policy logits + value) are two more 16-row tiles on wave 0;
+//   * wave 0 walks and updates the trees, one lane per game, with the code of k_mz_select / k_mz_expand_backup
+//     (mz_descend / mz_grow_backup): fp64, the host's log table -- the tree arithmetic is the step-by-step route's,
+//     bit for bit, given the same network outputs (the outputs differ from rocBLAS' in the last bits: another
+//     summation order).  TREE_LDS: the trees (32 B x slots per game), the paths and the log table live in LDS for the
+//     search (a level of the walk costs an LDS round trip instead of an L2 one) and are written back at the end.
+constexpr int kMzH = 64, kMzWaves = 4, kMzMaxA = 8, kMzTile = 16, kMzKX = kMzH + kMzMaxA, kMzMaxGpw = 16;
+typedef float mz_f32x4 __attribute__((ext_vector_type(4)));
 
 struct MzModel {        // device pointers, weights k-major: w[k][unit]
     const float *dyn1_w, *dyn1_b, *dyn2_w, *dyn2_b, *rew1_w, *rew1_b, *rew2_w, *rew2_b, *pre1_w, *pre1_b, *pol_w, *pol_b,
@@ -205,219 +228,275 @@ struct MzTrace {        // optional per-simulation outputs for the parity tests:
     float *reward, *probs, *value;
 };
 
-__host__ __device__ inline int mz_search_lds_floats(int A) {
-    return (kMzH + A) * kMzH + 3 * kMzH * kMzH + kMzH * (6 + A) + 8 + A +   // weights and biases
-           (kMzH + A) * kMzLd + 2 * kMzH * kMzLd +                           // x, h1, next state
-           kMzWaves * 64 * (4 + A) +                                         // reductions: min, max, reward, value, A logits
-           64 * (5 + A);                                                     // per game: parent, action, leaf, reward, value, probs
+// LDS of k_mz_search in bytes: activations, reductions, per-game scalars, paths, log table (+ the trees)
+__host__ __device__ inline int mz_search_fixed_floats() { return kMzKX * kMzTile + 2 * kMzH * kMzTile + 2 * kMzWaves * kMzTile + 16 + 16; }
+__host__ __device__ inline int mz_search_lds_bytes(int gpw, int cap, int path_stride, int n_sims_cfg, bool tree_lds) {
+    int bytes = mz_search_fixed_floats() * 4 + gpw * path_stride * 4;
+    bytes = (bytes + 15) / 16 * 16;
+    bytes += ((n_sims_cfg + 2) * 8 + 15) / 16 * 16;
+    if (tree_lds) bytes += gpw * cap * (int)sizeof(MzNode);
+    return bytes;
 }
 
-__global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M, float *hidden, int n_sims, MzTrace T) {
-    extern __shared__ __attribute__((aligned(16))) float mz_lds[];
+// Development aid (not built by default): -DRZ_MZ_PROFILE accumulates the shader-clock cycles wave 0 of workgroup 0 spends
+// in each stage of k_mz_search into mz_prof[] (read with rz_mz_debug_profile).
+#ifdef RZ_MZ_PROFILE
+__device__ long long mz_prof[16];
+#define MZ_TICK(i) do { const long long now_ = clock64(); prof_acc[i] += now_ - prof_t; prof_t = now_; } while (0)
+#else
+#define MZ_TICK(i)
+#endif
+
+template <bool TREE_LDS>
+__global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M, float *hidden, int n_sims, int gpw, MzTrace T) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mz_lds[];
     const int A = E.n_actions, KX = kMzH + A;
-    const int tid = threadIdx.x, e = tid & 63, w = tid >> 6, j0 = 8 * w;
-    const int g = blockIdx.x * 64 + e;
-    const bool live = g < E.n_games;
-    float *p = mz_lds;
-    float *W1 = p; p += KX * kMzH;
-    float *W2 = p; p += kMzH * kMzH;
-    float *WR = p; p += kMzH * kMzH;
-    float *WP = p; p += kMzH * kMzH;
-    float *B1 = p; p += kMzH;
-    float *B2 = p; p += kMzH;
-    float *BR = p; p += kMzH;
-    float *BP = p; p += kMzH;
-    float *WR2 = p; p += kMzH;
-    float *WPOL = p; p += A * kMzH;
-    float *WVAL = p; p += kMzH;
-    float *BS = p; p += 8 + A;          // [0] rew2 bias, [1] val bias, [2 .. 2 + A) pol biases
-    float *X = p; p += KX * kMzLd;      // parent state + one-hot action, [k][game]
-    float *H1 = p; p += kMzH * kMzLd;   // relu(dyn1)
-    float *S2 = p; p += kMzH * kMzLd;   // next state (scaled)
-    float *RED = p; p += kMzWaves * 64 * (4 + A);
-    float *G = p;                        // per game scalars
-    int *Gpar = reinterpret_cast<int *>(G), *Gact = Gpar + 64, *Gleaf = Gact + 64;
-    // weights into LDS, once
-    for (int i = tid; i < KX * kMzH; i += 64 * kMzWaves) W1[i] = M.dyn1_w[i];
-    for (int i = tid; i < kMzH * kMzH; i += 64 * kMzWaves) {
-        W2[i] = M.dyn2_w[i];
-        WR[i] = M.rew1_w[i];
-        WP[i] = M.pre1_w[i];
+    const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, n = l & 15, q = l >> 4;
+    const int g0 = blockIdx.x * gpw;
+    float *XS = reinterpret_cast<float *>(mz_lds);   // [72][16]: parent state + one-hot action; later the scaled next state
+    float *HP = XS + kMzKX * kMzTile;                // [64][16]: relu(dyn1); later relu(pre1)
+    float *R1 = HP + kMzH * kMzTile;                 // [64][16]: relu(rew1)
+    float *RED = R1 + kMzH * kMzTile;                // [2][4 waves][16]: min / max of the next state's rows per wave
+    float *HB = RED + 2 * kMzWaves * kMzTile;        // [0] rew2 bias, [1] val bias, [2 .. 2 + A) pol biases
+    int *Gleaf = reinterpret_cast<int *>(HB + 16);   // [16]
+    int32_t *PATH = Gleaf + 16;                      // [gpw][path_stride]
+    unsigned char *pp = mz_lds + (mz_search_fixed_floats() * 4 + gpw * E.path_stride * 4 + 15) / 16 * 16;
+    double *PBL = reinterpret_cast<double *>(pp);    // [n_sims + 2]
+    pp += ((E.n_sims + 2) * 8 + 15) / 16 * 16;
+    MzNode *TREE = reinterpret_cast<MzNode *>(pp);   // [gpw][cap] (TREE_LDS)
+
+    // ---- once: weight fragments into registers (A operand of 16x16x4: lane holds W[unit 16w + n][k = 4s + q])
+    float a1[kMzKX / 4], a2[kMzH / 4], ar[kMzH / 4], ap[kMzH / 4], ah[kMzH / 4], ah2[kMzH / 4];
+    const int unit = 16 * w + n;
+#pragma unroll
+    for (int s = 0; s < kMzKX / 4; ++s) {
+        const int k = 4 * s + q;
+        a1[s] = k < KX ? M.dyn1_w[k * kMzH + unit] : 0.0f;
     }
-    for (int i = tid; i < kMzH; i += 64 * kMzWaves) {
-        B1[i] = M.dyn1_b[i];
-        B2[i] = M.dyn2_b[i];
-        BR[i] = M.rew1_b[i];
-        BP[i] = M.pre1_b[i];
-        WR2[i] = M.rew2_w[i];
-        WVAL[i] = M.val_w[i];
+#pragma unroll
+    for (int s = 0; s < kMzH / 4; ++s) {
+        const int k = 4 * s + q;
+        a2[s] = M.dyn2_w[k * kMzH + unit];
+        ar[s] = M.rew1_w[k * kMzH + unit];
+        ap[s] = M.pre1_w[k * kMzH + unit];
+        // wave 0's head tiles: rows 0 .. A-1 = policy, row A = value | row 0 = reward
+        ah[s] = n < A ? M.pol_w[n * kMzH + k] : n == A ? M.val_w[k] : 0.0f;
+        ah2[s] = n == 0 ? M.rew2_w[k] : 0.0f;
     }
-    for (int i = tid; i < A * kMzH; i += 64 * kMzWaves) WPOL[i] = M.pol_w[i];
+    mz_f32x4 b1, b2, br, bp;   // biases in the C/D layout: rows 16w + 4q + i
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        b1[i] = M.dyn1_b[16 * w + 4 * q + i];
+        b2[i] = M.dyn2_b[16 * w + 4 * q + i];
+        br[i] = M.rew1_b[16 * w + 4 * q + i];
+        bp[i] = M.pre1_b[16 * w + 4 * q + i];
+    }
     if (tid == 0) {
-        BS[0] = M.rew2_b[0];
-        BS[1] = M.val_b[0];
+        HB[0] = M.rew2_b[0];
+        HB[1] = M.val_b[0];
     }
-    if (tid < A) BS[2 + tid] = M.pol_b[tid];
-    const long long hbase = (long long)g * E.cap * kMzH;
+    if (tid < A) HB[2 + tid] = M.pol_b[tid];
+    for (int i = tid; i < kMzKX * kMzTile; i += 64 * kMzWaves) XS[i] = 0.0f;   // (the padding rows 64 + A .. 71 stay zero)
+    for (int i = tid; i < E.n_sims + 2; i += 64 * kMzWaves) PBL[i] = E.pb_log[i];
+    // the trees of this workgroup's games
+    const bool mine = w == 0 && l < gpw && g0 + l < E.n_games;   // this lane walks the tree of game g0 + l
+    const int g = g0 + (l < gpw ? l : 0);
+    int top = 0, depth = 0;
+    double lo = 0.0, hi = 0.0;
+    if (mine) {
+        top = E.top[g];
+        lo = E.vmin[g];
+        hi = E.vmax[g];
+    }
+    if (TREE_LDS) {
+        const int per_game = E.cap * (int)(sizeof(MzNode) / 16);   // uint4 words
+        for (int ee = 0; ee < gpw && g0 + ee < E.n_games; ++ee) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(E.nodes + (long long)(g0 + ee) * E.cap);
+            uint4 *dst = reinterpret_cast<uint4 *>(TREE + ee * E.cap);
+            const int used = E.top[g0 + ee] * (int)(sizeof(MzNode) / 16);
+            for (int i = tid; i < used && i < per_game; i += 64 * kMzWaves) dst[i] = src[i];
+        }
+    }
+    MzNode *nodes = TREE_LDS ? TREE + (l < gpw ? l : 0) * E.cap : E.nodes + (long long)g * E.cap;
+    int32_t *path = PATH + (l < gpw ? l : 0) * E.path_stride;
+    __syncthreads();
+
+#ifdef RZ_MZ_PROFILE
+    long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = clock64();
+#endif
     for (int sim = 0; sim < n_sims; ++sim) {
-        // S0: wave 0 selects (one thread per game)
+        // S0 (wave 0): select, one lane per game; then the gather of the parents' hidden states into XS[k][game]
+        // (lane -> game l / 4, four 16-byte pieces of its 256-byte row) and the one-hot action rows
+        int par = 0, act = 0, lf = 0;
         if (w == 0) {
-            int par = 0, act = 0, lf = 0;
-            if (live) mz_select_one(E, g, par, act, lf);
-            Gpar[e] = par;
-            Gact[e] = act;
-            Gleaf[e] = lf;
+            if (mine) depth = mz_descend(E, nodes, path, PBL, lo, hi, par, act, lf);
+            MZ_TICK(0);
+            if (l < kMzTile) Gleaf[l] = lf;
+            const int ee = l >> 2;
+            const int pe = __shfl(par, ee);
+            const bool live_e = ee < gpw && g0 + ee < E.n_games;
+            const float4 *src = reinterpret_cast<const float4 *>(hidden + ((long long)(g0 + (live_e ? ee : 0)) * E.cap + pe) * kMzH);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = (l & 3) + 4 * j;
+                const float4 v = live_e ? src[c] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+                XS[(4 * c + 0) * kMzTile + ee] = v.x;
+                XS[(4 * c + 1) * kMzTile + ee] = v.y;
+                XS[(4 * c + 2) * kMzTile + ee] = v.z;
+                XS[(4 * c + 3) * kMzTile + ee] = v.w;
+            }
+            const int an = __shfl(act, n);
+            const bool live_n = n < gpw && g0 + n < E.n_games;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int a = q + 4 * j;
+                if (a < A) XS[(kMzH + a) * kMzTile + n] = (live_n && an == a) ? 1.0f : 0.0f;
+            }
+            MZ_TICK(1);
         }
         __syncthreads();
-        // S1: gather the parents' hidden states (coalesced rows) into X[k][game]; one-hot action rows
-        for (int idx = tid; idx < 64 * kMzH; idx += 64 * kMzWaves) {
-            const int ee = idx >> 6, k = idx & 63;
-            const int gg = blockIdx.x * 64 + ee;
-            X[k * kMzLd + ee] = gg < E.n_games ? hidden[(long long)gg * E.cap * kMzH + (long long)Gpar[ee] * kMzH + k] : 0.0f;
-        }
-        for (int idx = tid; idx < 64 * A; idx += 64 * kMzWaves) {
-            const int a = idx >> 6, ee = idx & 63;
-            X[(kMzH + a) * kMzLd + ee] = Gact[ee] == a ? 1.0f : 0.0f;
-        }
-        __syncthreads();
-        // S2: h1 = relu(dyn1 [x, onehot(a)])
+        MZ_TICK(2);
+        // S1: h1 = relu(dyn1 [x, onehot(a)])
         {
-            float acc[8];
+            mz_f32x4 acc = b1;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = B1[j0 + i];
-            for (int k = 0; k < KX; ++k) {
-                const float x = X[k * kMzLd + e];
-                const float4 wa = *reinterpret_cast<const float4 *>(W1 + k * kMzH + j0);
-                const float4 wb = *reinterpret_cast<const float4 *>(W1 + k * kMzH + j0 + 4);
-                acc[0] = fmaf(wa.x, x, acc[0]); acc[1] = fmaf(wa.y, x, acc[1]); acc[2] = fmaf(wa.z, x, acc[2]); acc[3] = fmaf(wa.w, x, acc[3]);
-                acc[4] = fmaf(wb.x, x, acc[4]); acc[5] = fmaf(wb.y, x, acc[5]); acc[6] = fmaf(wb.z, x, acc[6]); acc[7] = fmaf(wb.w, x, acc[7]);
-            }
+            for (int s = 0; s < kMzKX / 4; ++s)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], XS[(4 * s + q) * kMzTile + n], acc, 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) H1[(j0 + i) * kMzLd + e] = fmaxf(acc[i], 0.0f);
+            for (int i = 0; i < 4; ++i) HP[(16 * w + 4 * q + i) * kMzTile + n] = fmaxf(acc[i], 0.0f);
         }
+        MZ_TICK(3);
         __syncthreads();
-        // S3: next state (dyn2, before scaling) and the reward head's hidden layer (rew1) from the same activations
-        float t[8], rsum = 0.0f;
+        MZ_TICK(4);
+        // S2: next state (dyn2, before scaling) and the reward head's hidden layer (rew1) from the same activations
+        mz_f32x4 t = b2;
         {
-            float ar[8];
+            mz_f32x4 r = br;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                t[i] = B2[j0 + i];
-                ar[i] = BR[j0 + i];
+            for (int s = 0; s < kMzH / 4; ++s) {
+                const float x = HP[(4 * s + q) * kMzTile + n];
+                t = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s], x, t, 0, 0, 0);
+                r = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[s], x, r, 0, 0, 0);
             }
-            for (int k = 0; k < kMzH; ++k) {
-                const float x = H1[k * kMzLd + e];
-                const float4 wa = *reinterpret_cast<const float4 *>(W2 + k * kMzH + j0);
-                const float4 wb = *reinterpret_cast<const float4 *>(W2 + k * kMzH + j0 + 4);
-                const float4 ra = *reinterpret_cast<const float4 *>(WR + k * kMzH + j0);
-                const float4 rb = *reinterpret_cast<const float4 *>(WR + k * kMzH + j0 + 4);
-                t[0] = fmaf(wa.x, x, t[0]); t[1] = fmaf(wa.y, x, t[1]); t[2] = fmaf(wa.z, x, t[2]); t[3] = fmaf(wa.w, x, t[3]);
-                t[4] = fmaf(wb.x, x, t[4]); t[5] = fmaf(wb.y, x, t[5]); t[6] = fmaf(wb.z, x, t[6]); t[7] = fmaf(wb.w, x, t[7]);
-                ar[0] = fmaf(ra.x, x, ar[0]); ar[1] = fmaf(ra.y, x, ar[1]); ar[2] = fmaf(ra.z, x, ar[2]); ar[3] = fmaf(ra.w, x, ar[3]);
-                ar[4] = fmaf(rb.x, x, ar[4]); ar[5] = fmaf(rb.y, x, ar[5]); ar[6] = fmaf(rb.z, x, ar[6]); ar[7] = fmaf(rb.w, x, ar[7]);
+            float mn = fminf(fminf(t[0], t[1]), fminf(t[2], t[3])), mx = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3]));
+            mn = fminf(mn, __shfl_xor(mn, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mn = fminf(mn, __shfl_xor(mn, 32));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            if (q == 0) {
+                RED[(0 * kMzWaves + w) * kMzTile + n] = mn;
+                RED[(1 * kMzWaves + w) * kMzTile + n] = mx;
             }
-            float lo = t[0], hi = t[0];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                lo = fminf(lo, t[i]);
-                hi = fmaxf(hi, t[i]);
-                rsum = fmaf(fmaxf(ar[i], 0.0f), WR2[j0 + i], rsum);
-            }
-            RED[(0 * kMzWaves + w) * 64 + e] = lo;
-            RED[(1 * kMzWaves + w) * 64 + e] = hi;
-            RED[(2 * kMzWaves + w) * 64 + e] = rsum;
+            for (int i = 0; i < 4; ++i) R1[(16 * w + 4 * q + i) * kMzTile + n] = fmaxf(r[i], 0.0f);
         }
+        MZ_TICK(5);
         __syncthreads();
-        // S4: per-sample min-max scaling of the new state (network.py scale_hidden), stored for the leaf
+        MZ_TICK(6);
+        // S3: per-sample min-max scaling of the new state (network.py scale_hidden), stored for the leaf
         {
-            float lo = RED[(0 * kMzWaves) * 64 + e], hi = RED[(1 * kMzWaves) * 64 + e];
+            float mn = RED[n], mx = RED[kMzWaves * kMzTile + n];
 #pragma unroll
-            for (int q = 1; q < kMzWaves; ++q) {
-                lo = fminf(lo, RED[(0 * kMzWaves + q) * 64 + e]);
-                hi = fmaxf(hi, RED[(1 * kMzWaves + q) * 64 + e]);
+            for (int u = 1; u < kMzWaves; ++u) {
+                mn = fminf(mn, RED[u * kMzTile + n]);
+                mx = fmaxf(mx, RED[(kMzWaves + u) * kMzTile + n]);
             }
-            const float inv = fmaxf(hi - lo, 1e-5f);
-            float *dst = live ? hidden + hbase + (long long)Gleaf[e] * kMzH + j0 : nullptr;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float sv = (t[i] - lo) / inv;
-                S2[(j0 + i) * kMzLd + e] = sv;
-                if (dst) dst[i] = sv;
-            }
+            const float inv = fmaxf(mx - mn, 1e-5f);
+            float4 sv;
+            sv.x = (t[0] - mn) / inv;
+            sv.y = (t[1] - mn) / inv;
+            sv.z = (t[2] - mn) / inv;
+            sv.w = (t[3] - mn) / inv;
+            XS[(16 * w + 4 * q + 0) * kMzTile + n] = sv.x;
+            XS[(16 * w + 4 * q + 1) * kMzTile + n] = sv.y;
+            XS[(16 * w + 4 * q + 2) * kMzTile + n] = sv.z;
+            XS[(16 * w + 4 * q + 3) * kMzTile + n] = sv.w;
+            if (n < gpw && g0 + n < E.n_games)
+                *reinterpret_cast<float4 *>(hidden + ((long long)(g0 + n) * E.cap + Gleaf[n]) * kMzH + 16 * w + 4 * q) = sv;
         }
+        MZ_TICK(7);
         __syncthreads();
-        // S5: prediction: p1 = relu(pre1 s'), partial dot products of the policy and value heads
+        MZ_TICK(8);
+        // S4: prediction trunk: p1 = relu(pre1 s')
         {
-            float acc[8];
+            mz_f32x4 acc = bp;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = BP[j0 + i];
-            for (int k = 0; k < kMzH; ++k) {
-                const float x = S2[k * kMzLd + e];
-                const float4 wa = *reinterpret_cast<const float4 *>(WP + k * kMzH + j0);
-                const float4 wb = *reinterpret_cast<const float4 *>(WP + k * kMzH + j0 + 4);
-                acc[0] = fmaf(wa.x, x, acc[0]); acc[1] = fmaf(wa.y, x, acc[1]); acc[2] = fmaf(wa.z, x, acc[2]); acc[3] = fmaf(wa.w, x, acc[3]);
-                acc[4] = fmaf(wb.x, x, acc[4]); acc[5] = fmaf(wb.y, x, acc[5]); acc[6] = fmaf(wb.z, x, acc[6]); acc[7] = fmaf(wb.w, x, acc[7]);
-            }
-            float vsum = 0.0f;
+            for (int s = 0; s < kMzH / 4; ++s)
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[s], XS[(4 * s + q) * kMzTile + n], acc, 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                acc[i] = fmaxf(acc[i], 0.0f);
-                vsum = fmaf(acc[i], WVAL[j0 + i], vsum);
-            }
-            RED[(3 * kMzWaves + w) * 64 + e] = vsum;
-            for (int a = 0; a < A; ++a) {
-                float ps = 0.0f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) ps = fmaf(acc[i], WPOL[a * kMzH + j0 + i], ps);
-                RED[((4 + a) * kMzWaves + w) * 64 + e] = ps;
-            }
+            for (int i = 0; i < 4; ++i) HP[(16 * w + 4 * q + i) * kMzTile + n] = fmaxf(acc[i], 0.0f);
         }
+        MZ_TICK(9);
         __syncthreads();
-        // S6: wave 0 finishes the heads (sums over the 8 waves in wave order, softmax) and expands + backs up
+        MZ_TICK(10);
+        // S5 (wave 0): the scalar heads as two 16-row tiles (rows 0 .. A-1 policy logits, row A value | row 0 reward),
+        // softmax, expand + backup.  Row m of a tile sits in register m & 3 of the lanes q = m >> 2.
         if (w == 0) {
-            float reward = BS[0], value = BS[1], logit[kMzMaxA], probs[kMzMaxA];
+            mz_f32x4 hp = {0.0f, 0.0f, 0.0f, 0.0f}, hr = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int q = 0; q < kMzWaves; ++q) {
-                reward += RED[(2 * kMzWaves + q) * 64 + e];
-                value += RED[(3 * kMzWaves + q) * 64 + e];
+            for (int s = 0; s < kMzH / 4; ++s) {
+                hp = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[s], HP[(4 * s + q) * kMzTile + n], hp, 0, 0, 0);
+                hr = __builtin_amdgcn_mfma_f32_16x16x4f32(ah2[s], R1[(4 * s + q) * kMzTile + n], hr, 0, 0, 0);
             }
-            float mx = -INFINITY;
+            const float reward = hr[0] + HB[0];   // (row 0: lanes q = 0 -- the lanes that own a game)
+            float logit[kMzMaxA], probs[kMzMaxA], mxl = -INFINITY, value = 0.0f;
 #pragma unroll
-            for (int a = 0; a < kMzMaxA; ++a) {
-                logit[a] = -INFINITY;
-                if (a < A) {
-                    float l = BS[2 + a];
-#pragma unroll
-                    for (int q = 0; q < kMzWaves; ++q) l += RED[((4 + a) * kMzWaves + q) * 64 + e];
-                    logit[a] = l;
-                    mx = fmaxf(mx, l);
+            for (int m = 0; m <= kMzMaxA; ++m) {
+                const float row = __shfl(hp[m & 3], 16 * (m >> 2) + n);
+                if (m < kMzMaxA) {
+                    logit[m] = m < A ? row + HB[2 + (m < A ? m : 0)] : -INFINITY;
+                    mxl = fmaxf(mxl, logit[m]);
                 }
+                if (m == A) value = row + HB[1];
             }
             float den = 0.0f;
 #pragma unroll
             for (int a = 0; a < kMzMaxA; ++a) {
-                probs[a] = a < A ? expf(logit[a] - mx) : 0.0f;
+                probs[a] = a < A ? expf(logit[a] - mxl) : 0.0f;
                 den += probs[a];
             }
 #pragma unroll
             for (int a = 0; a < kMzMaxA; ++a) probs[a] = probs[a] / den;
-            if (live) {
+            MZ_TICK(11);
+            if (mine) {
                 if (T.reward != nullptr) {
                     const long long o = (long long)sim * E.n_games + g;
-                    T.parent[o] = Gpar[e];
-                    T.action[o] = Gact[e];
-                    T.leaf[o] = Gleaf[e];
+                    T.parent[o] = par;
+                    T.action[o] = act;
+                    T.leaf[o] = lf;
                     T.reward[o] = reward;
                     T.value[o] = value;
 #pragma unroll
                     for (int a = 0; a < kMzMaxA; ++a)
                         if (a < A) T.probs[o * A + a] = probs[a];
                 }
-                mz_expand_backup_one(E, g, reward, probs, value);
+                mz_grow_backup<kMzMaxA>(E, nodes, path, depth, top, lo, hi, reward, probs, value);
             }
+            MZ_TICK(12);
         }
-        // (no barrier: the next select is wave 0's too, and every LDS buffer wave 0 reads above is rewritten only
-        // after the barrier that follows that select)
+        // (no barrier: the next select and gather are wave 0's too, and XS -- which the gather rewrites -- was last read
+        // before the barrier behind S4; HP / R1, which wave 0 reads above, are rewritten only after the next S0 barrier)
+    }
+#ifdef RZ_MZ_PROFILE
+    if (blockIdx.x == 0 && tid == 0)
+        for (int i = 0; i < 16; ++i) mz_prof[i] = prof_acc[i];
+#endif
+    if (mine) {
+        E.top[g] = top;
+        E.vmin[g] = lo;
+        E.vmax[g] = hi;
+        E.depth[g] = depth;
+    }
+    if (TREE_LDS) {
+        __syncthreads();
+        if (w == 0 && l < kMzTile) Gleaf[l] = top;   // (every wave needs the final tops)
+        __syncthreads();
+        for (int ee = 0; ee < gpw && g0 + ee < E.n_games; ++ee) {
+            uint4 *dst = reinterpret_cast<uint4 *>(E.nodes + (long long)(g0 + ee) * E.cap);
+            const uint4 *src = reinterpret_cast<const uint4 *>(TREE + ee * E.cap);
+            const int used = Gleaf[ee] * (int)(sizeof(MzNode) / 16);
+            for (int i = tid; i < used; i += 64 * kMzWaves) dst[i] = src[i];
+        }
     }
 }
 
@@ -462,6 +541,8 @@ struct rz_muzero {
     MzModel model = {};          // rz_mz_load_model
     float *d_model = nullptr;    // one allocation behind the pointers above
     bool model_loaded = false;
+    int n_cus = 256;             // of cfg.device
+    int games_per_wg = 0;        // rz_mz_set_search_shape: 0 = chosen from n_games and n_cus
 };
 
 namespace {
@@ -509,6 +590,7 @@ int rz_mz_create(const rz_mz_config *cfg, rz_muzero **out) {
     rz_muzero *e = new (std::nothrow) rz_muzero();
     if (!e) return mz_fail(RZ_ERR_OOM, "host allocation failed");
     e->cfg = *cfg;
+    if (hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || e->n_cus < 1) e->n_cus = 256;
     MzDev &D = e->dev;
     D.n_games = cfg->n_games;
     D.n_actions = cfg->n_actions;
@@ -642,8 +724,9 @@ int rz_mz_load_model(rz_muzero *e, const float *const *h_params, int32_t n_param
         if (hipMalloc((void **)&e->d_model, total * sizeof(float)) != hipSuccess) return mz_fail(RZ_ERR_OOM, "hipMalloc failed (muzero model)");
         e->allocs.push_back(e->d_model);
         e->bytes += (long long)(total * sizeof(float));
-        if (hipFuncSetAttribute((const void *)k_mz_search, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                mz_search_lds_floats(A) * (int)sizeof(float)) != hipSuccess)
+        const int most = 160 * 1024;
+        if (hipFuncSetAttribute((const void *)k_mz_search<true>, hipFuncAttributeMaxDynamicSharedMemorySize, most) != hipSuccess ||
+            hipFuncSetAttribute((const void *)k_mz_search<false>, hipFuncAttributeMaxDynamicSharedMemorySize, most) != hipSuccess)
             return mz_fail(RZ_ERR_HIP, "hipFuncSetAttribute(dynamic LDS) failed");
     }
     if (hipMemcpy(e->d_model, host.data(), total * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
@@ -665,11 +748,35 @@ int rz_mz_search(rz_muzero *e, float *d_hidden, int32_t n_sims, int32_t *d_trace
     const bool all = d_trace_parent && d_trace_action && d_trace_leaf && d_trace_reward && d_trace_probs && d_trace_value;
     if (any && !all) return mz_fail(RZ_ERR_ARG, "the trace arrays come all together or not at all");
     const MzTrace T = {d_trace_parent, d_trace_action, d_trace_leaf, d_trace_reward, d_trace_probs, d_trace_value};
-    const int lds = mz_search_lds_floats(e->cfg.n_actions) * (int)sizeof(float);
-    k_mz_search<<<dim3((unsigned)((e->cfg.n_games + 63) / 64)), dim3(64 * kMzWaves), lds, (hipStream_t)stream>>>(
-        e->dev, e->model, d_hidden, n_sims, T);
+    // games per workgroup: a search is a latency chain per game, so few games per workgroup and MANY workgroups -- at
+    // least two per CU (one walks its trees while the other runs its layers) before the 16 columns of a tile fill up
+    int gpw = e->games_per_wg;
+    if (gpw == 0) gpw = e->cfg.n_games >= 32 * e->n_cus ? 16 : e->cfg.n_games >= 16 * e->n_cus ? 8 : 4;
+    // the trees go to LDS when two workgroups still fit on a CU
+    const MzDev &D = e->dev;
+    bool tree_lds = mz_search_lds_bytes(gpw, D.cap, D.path_stride, D.n_sims, true) <= 80 * 1024;
+    const int lds = mz_search_lds_bytes(gpw, D.cap, D.path_stride, D.n_sims, tree_lds);
+    if (lds > 160 * 1024) return mz_fail(RZ_ERR_ARG, "n_sims too large for the fused search (paths do not fit in LDS)");
+    const dim3 grid((unsigned)((e->cfg.n_games + gpw - 1) / gpw));
+    if (tree_lds)
+        k_mz_search<true><<<grid, dim3(64 * kMzWaves), lds, (hipStream_t)stream>>>(e->dev, e->model, d_hidden, n_sims, gpw, T);
+    else
+        k_mz_search<false><<<grid, dim3(64 * kMzWaves), lds, (hipStream_t)stream>>>(e->dev, e->model, d_hidden, n_sims, gpw, T);
     return mz_launched("launch of k_mz_search failed");
 }
+
+int rz_mz_set_search_shape(rz_muzero *e, int32_t games_per_workgroup) {
+    if (e == nullptr) return mz_fail(RZ_ERR_ARG, "muzero handle is NULL");
+    if (games_per_workgroup < 0 || games_per_workgroup > kMzMaxGpw) return mz_fail(RZ_ERR_ARG, "games_per_workgroup must be 0 (auto) .. 16");
+    e->games_per_wg = games_per_workgroup;
+    return RZ_OK;
+}
+
+#ifdef RZ_MZ_PROFILE
+int rz_mz_debug_profile(long long *h_out16) {
+    return hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(mz_prof), 16 * sizeof(long long)) == hipSuccess ? RZ_OK : RZ_ERR_HIP;
+}
+#endif
 
 int rz_mz_geometry(rz_muzero *e, int32_t *slots_per_game, int64_t *device_bytes) {
     if (e == nullptr) return mz_fail(RZ_ERR_ARG, "muzero handle is NULL");

@@ -2047,8 +2047,10 @@ static void launch_heads_gemm(rz_net *net, const float *d_feat, int32_t n_boards
     int algo = net->heads_algo;
     // after the split-f16 trunk: the f16 pipe.  Beside a capped trunk the GEMM has 32 CUs (64-board workgroups keep
     // the loads of a CU below its vector memory rate), alone it has the chip (many small workgroups hide the load
-    // latency); both shapes give the same bits (profiles/r01/sweep_heads.txt)
-    if (algo == RZ_NET_HEADS_AUTO) algo = net->max_wgs > 0 ? RZ_NET_HEADS_SPLIT_64 : RZ_NET_HEADS_SPLIT_32;
+    // latency); up to 256 boards the single-wave K-quarter workgroups are the shortest launch (+4 % whole-step at 64 and
+    // 256 boards, level above that); every shape gives the same bits (profiles/r01/sweep_heads.txt, r02/heads_small.txt)
+    if (algo == RZ_NET_HEADS_AUTO)
+        algo = net->max_wgs > 0 ? RZ_NET_HEADS_SPLIT_64 : n_boards <= 256 ? RZ_NET_HEADS_SPLIT_PARTS : RZ_NET_HEADS_SPLIT_32;
     if (d_feat != net->d_feat || !net->feat16_valid) algo = RZ_NET_HEADS_F32;
     else if (algo == RZ_NET_HEADS_F32 && !net->feat32_valid)  // F32 chosen after a trunk that wrote only the f16 pieces
         algo = net->max_wgs > 0 ? RZ_NET_HEADS_SPLIT_64 : RZ_NET_HEADS_SPLIT_32;

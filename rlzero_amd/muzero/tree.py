@@ -56,6 +56,11 @@ class MuZeroTree(object):
         ptrs = (ctypes.c_void_p * 14)(*[a.ctypes.data for a in arrays])
         check(self.lib.rz_mz_load_model(self.handle, ptrs, 14, int(net.hidden)), 'rz_mz_load_model')
 
+    def set_search_shape(self, games_per_workgroup=0):
+        """Games per workgroup of ``search_fused`` (<= 16; 0 = chosen from the number of games and CUs)."""
+        check(self.lib.rz_mz_set_search_shape(self.handle, int(games_per_workgroup)), 'rz_mz_set_search_shape')
+        return self
+
     def search_fused(self, hidden, n_sims, trace=False):
         """All ``n_sims`` simulations of every game in ONE launch (k_mz_search; init_roots and the root's hidden state
         in ``hidden[:, 0]`` first).  ``trace``: returns per simulation what the kernel selected and its network outputs:

@@ -407,8 +407,7 @@ def run_muzero(args, rank, world, device, dist, red_device, use_dist=False, cpu_
     sp = MuZeroSelfPlay(net, CartPoleBatch(G, device, seed=rank), n_sims=n_sims, seed=rank, fused=bool(args.mz_fused))
     if args.mz_gpw:
         sp.tree.set_search_shape(args.mz_gpw)
-    for _ in range(args.warmup):
-        sp.play_move()
+    sp.collect(args.warmup)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -418,9 +417,7 @@ def run_muzero(args, rank, world, device, dist, red_device, use_dist=False, cpu_
     if sp.fused:
         sp.search_events = []  # ... or around every fused search launch (all simulations of a move)
     t0 = time.perf_counter()
-    finished = 0
-    for _ in range(args.steps):
-        finished += len(sp.play_move())
+    finished = len(sp.collect(args.steps))  # (fused moves: launches of sp.moves_per_launch moves, records read a launch behind)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -440,20 +437,23 @@ def run_muzero(args, rank, world, device, dist, red_device, use_dist=False, cpu_
         events = sp.search_events if sp.fused else sp.sim_events
         per_launch = G * (n_sims if sp.fused else 1)  # simulations one launch carries
         if events:
-            ms = sum(a.elapsed_time(b) for a, b in events) / len(events)
+            moves_per_launch = sum(e[2] for e in events) / len(events) if sp.fused_moves else 1
+            per_launch = per_launch * moves_per_launch
+            ms = sum(e[0].elapsed_time(e[1]) for e in events) / len(events)
             gbs = MZ_BYTES_PER_SIM * per_launch / (ms * 1e-3) / 1e9
             tf = MZ_FLOPS_PER_SIM * per_launch / (ms * 1e-3) / 1e12
             if sp.fused:
-                # fp32 FMAs on the vector pipe (no MFMA: a 64 x 64 layer per 64 games; vector fp32 peak = the f32 matrix peak)
                 roofline = {'bound': 'mfma', 'kernel': sp.sim_step_label + ', %d environments per launch' % G,
                             'achieved': round(tf, 3), 'peak': PEAK_FP32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
                             'frac': round(tf / PEAK_FP32_MATRIX_TFLOPS, 5), 'traffic': None, 'avg_launch_ms': round(ms, 4),
                             'launches_timed': len(events), 'hbm_achieved_gbs': round(gbs, 2),
+                            'moves_per_launch': moves_per_launch,
                             'note': 'achieved = algorithmic flops of the recurrent inference (%d per simulation: its 7 dense '
-                                    'layers) x %d simulations x %d environments per launch / launch duration (HIP events), against '
-                                    'the fp32 peak (vector fp32 = f32-input MFMA = 157.3 TFLOP/s); %d of the 256 CUs hold a '
-                                    'workgroup (64 environments each), and wave 0 of each walks its 64 trees between the layers'
-                                    % (MZ_FLOPS_PER_SIM, n_sims, G, (G + 63) // 64)}
+                                    'layers) x %d simulations x %d environments x %g moves per launch / launch duration (HIP events), '
+                                    'against the f32-input MFMA peak (157.3 TFLOP/s); %d workgroups of 16 environments (4 waves: '
+                                    'v_mfma_f32_16x16x4_f32 tiles, weights in registers, trees in LDS); a simulation is a chain of '
+                                    'dependent steps per tree (fp64 walk, gather, 4 layers, backup): latency bound, not a roof'
+                                    % (MZ_FLOPS_PER_SIM, n_sims, G, moves_per_launch, (G + 15) // 16)}
             else:
                 roofline = {'bound': 'hbm', 'kernel': sp.sim_step_label + ', %d environments per launch' % G,
                             'achieved': round(gbs, 2), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 5),

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 18
+#define RZ_ABI_VERSION 19
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 #define RZ_MAX_IN_FLIGHT 16 /* rz_config.sims_in_flight */
@@ -417,6 +417,24 @@ int rz_mz_load_model(rz_muzero *e, const float *const *h_params, int32_t n_param
 int rz_mz_search(rz_muzero *e, float *d_hidden, int32_t n_sims, int32_t *d_trace_parent, int32_t *d_trace_action,
                  int32_t *d_trace_leaf, float *d_trace_reward, float *d_trace_probs, float *d_trace_value, void *stream);
 int rz_mz_set_search_shape(rz_muzero *e, int32_t games_per_workgroup);
+/* Whole MOVES of CartPole-v1 environments in one launch (k_mz_search with its MOVES stages): per move the initial
+ * inference h(o) -> s0, f(s0) -> root priors (+ Dirichlet(alpha) noise, weight noise_frac), n_sims simulations, the action
+ * drawn from visits ^ (1 / temperature) (arg-max at temperature <= 0), one packed record and the environment step with
+ * auto-reset.  rz_mz_load_representation: HOST pointers to rep1.weight [64][obs_dim], rep1.bias, rep2.weight [64][64],
+ * rep2.bias (torch layout), beside rz_mz_load_model.  d_state float64 [n_games][4] (x, x_dot, theta, theta_dot), d_steps /
+ * d_episode int64 [n_games]: the environments, updated in place (initial states of an episode: the counter-based stream
+ * of rlzero_amd/muzero/cartpole.py keyed (env_seed, environment, episode)); d_records float64 [n_moves][n_games][8 + A]:
+ * observation before the move (4) | action | reward | visit counts (A) | root value | done.  Random draws come from a
+ * counter-based stream keyed (noise_seed, environment, episode, step). */
+int rz_mz_load_representation(rz_muzero *e, const float *const *h_params, int32_t n_params, int32_t obs_dim, int32_t hidden);
+int rz_mz_play_cartpole(rz_muzero *e, float *d_hidden, int32_t n_sims, int32_t n_moves, double *d_state, int64_t *d_steps,
+                        int64_t *d_episode, uint64_t env_seed, uint64_t noise_seed, double noise_frac, double dirichlet_alpha,
+                        double temperature, double *d_records, void *stream);
+/* One step of n_envs CartPole-v1 environments (gymnasium classic_control/cartpole.py: Euler, tau 0.02, 500-step limit)
+ * with auto-reset, in ONE launch: d_obs float32 [n_envs][4] = the observation AFTER the step (after the reset for a
+ * finished environment), d_reward float32, d_terminated / d_truncated uint8. */
+int rz_cartpole_step(double *d_state, int64_t *d_steps, int64_t *d_episode, const int64_t *d_actions, int32_t n_envs, uint64_t seed,
+                     float *d_obs, float *d_reward, uint8_t *d_terminated, uint8_t *d_truncated, void *stream);
 int rz_mz_root_children(rz_muzero *e, int32_t what, void *d_out, void *stream);
 int rz_mz_root_stats(rz_muzero *e, int32_t *d_n, double *d_value_sum, double *d_vmin, double *d_vmax, void *stream);
 int rz_mz_geometry(rz_muzero *e, int32_t *slots_per_game, int64_t *device_bytes);

@@ -8,7 +8,7 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64,
                     c_void_p)
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
 MAX_IN_FLIGHT = 16
@@ -118,6 +118,9 @@ _SIGNATURES = {
     'rz_mz_load_model': (c_int, [P, POINTER(c_void_p), c_int32, c_int32]),
     'rz_mz_search': (c_int, [P, P, c_int32, P, P, P, P, P, P, P]),
     'rz_mz_set_search_shape': (c_int, [P, c_int32]),
+    'rz_mz_load_representation': (c_int, [P, POINTER(c_void_p), c_int32, c_int32, c_int32]),
+    'rz_mz_play_cartpole': (c_int, [P, P, c_int32, c_int32, P, P, P, c_uint64, c_uint64, c_double, c_double, c_double, P, P]),
+    'rz_cartpole_step': (c_int, [P, P, P, P, c_int32, c_uint64, P, P, P, P, P]),
     'rz_mz_root_children': (c_int, [P, c_int32, P, P]),
     'rz_mz_root_stats': (c_int, [P, P, P, P, P, P]),
     'rz_mz_geometry': (c_int, [P, POINTER(c_int32), POINTER(c_int64)]),

@@ -195,32 +195,153 @@ __global__ void k_mz_expand_backup(MzDev E, const float *reward, const float *pr
     mz_expand_backup_one(E, g, reward[g], probs + (long long)g * E.n_actions, value[g]);
 }
 
+// ------------------------------------------------------------------ CartPole-v1 on the device
+// Gymnasium's CartPoleEnv (classic_control/cartpole.py v0.29: Euler integrator, tau 0.02 s, force 10 N, episode ends at
+// |x| > 2.4 or |theta| > 12 degrees, reward 1 per step) with CartPole-v1's 500-step limit and auto-reset -- the device
+// twin of rlzero_amd/muzero/cartpole.py: same constants, same order of operations (fp64, one rounding per operation),
+// initial states from the same counter-based stream keyed (seed, environment, episode).
+__device__ __forceinline__ unsigned long long mz_splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+struct MzCartPole {
+    double x, x_dot, theta, theta_dot;
+    long long steps, episode;
+};
+
+__device__ __forceinline__ void cartpole_reset(MzCartPole &c, unsigned long long seed, int env) {
+    const unsigned long long key = mz_splitmix64(mz_splitmix64(seed ^ ((unsigned long long)env << 24)) ^ (unsigned long long)c.episode);
+    double v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double u = (double)(mz_splitmix64(key ^ (unsigned long long)(j + 1)) >> 11) / 9007199254740992.0;
+        v[j] = -0.05 + 0.1 * u;
+    }
+    c.x = v[0];
+    c.x_dot = v[1];
+    c.theta = v[2];
+    c.theta_dot = v[3];
+    c.steps = 0;
+}
+
+// one step; -> bit 0 terminated, bit 1 truncated (the state is the terminal one: the caller resets)
+__device__ __forceinline__ int cartpole_step(MzCartPole &c, int action) {
+    const double gravity = 9.8, masspole = 0.1, total_mass = 0.1 + 1.0, length = 0.5, polemass_length = 0.1 * 0.5, tau = 0.02;
+    const double theta_threshold = 12 * 2 * 3.141592653589793 / 360, x_threshold = 2.4;
+    const double force = action == 1 ? 10.0 : -10.0;
+    const double costheta = cos(c.theta), sintheta = sin(c.theta);
+    const double temp = (force + polemass_length * (c.theta_dot * c.theta_dot) * sintheta) / total_mass;
+    const double thetaacc = (gravity * sintheta - costheta * temp) / (length * (4.0 / 3.0 - masspole * (costheta * costheta) / total_mass));
+    const double xacc = temp - polemass_length * thetaacc * costheta / total_mass;
+    c.x = c.x + tau * c.x_dot;
+    c.x_dot = c.x_dot + tau * xacc;
+    c.theta = c.theta + tau * c.theta_dot;
+    c.theta_dot = c.theta_dot + tau * thetaacc;
+    c.steps += 1;
+    const bool terminated = c.x < -x_threshold || c.x > x_threshold || c.theta < -theta_threshold || c.theta > theta_threshold;
+    const bool truncated = c.steps >= 500;
+    return (terminated ? 1 : 0) | (truncated ? 2 : 0);
+}
+
+__global__ void k_cartpole_step(double *state, long long *steps, long long *episode, const long long *actions, int n_envs,
+                                unsigned long long seed, float *obs, float *reward, uint8_t *terminated, uint8_t *truncated) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_envs) return;
+    MzCartPole c = {state[4 * g], state[4 * g + 1], state[4 * g + 2], state[4 * g + 3], steps[g], episode[g]};
+    const int done = cartpole_step(c, (int)actions[g]);
+    if (done) {
+        c.episode += 1;
+        cartpole_reset(c, seed, g);
+    }
+    state[4 * g] = c.x;
+    state[4 * g + 1] = c.x_dot;
+    state[4 * g + 2] = c.theta;
+    state[4 * g + 3] = c.theta_dot;
+    steps[g] = c.steps;
+    episode[g] = c.episode;
+    obs[4 * g] = (float)c.x;
+    obs[4 * g + 1] = (float)c.x_dot;
+    obs[4 * g + 2] = (float)c.theta;
+    obs[4 * g + 3] = (float)c.theta_dot;
+    reward[g] = 1.0f;
+    terminated[g] = (uint8_t)(done & 1);
+    truncated[g] = (uint8_t)((done >> 1) & 1);
+}
+
+// One Gamma(alpha, 1) sample for the root's Dirichlet noise (add_exploration_noise) from a counter-based stream:
+// Marsaglia-Tsang (boosted by U^(1/alpha) below shape 1).  Noise, not parity: hardware transcendentals, 24-bit uniforms
+// (the scheme of gamma03 in rz_engine.hip with the shape as an argument).
+__device__ __forceinline__ uint32_t mz_hash32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+
+__device__ __forceinline__ float mz_gamma(float alpha, uint32_t key) {
+    const float shape = alpha < 1.0f ? alpha + 1.0f : alpha;
+    const float d = shape - 1.0f / 3.0f, c = 1.0f / sqrtf(9.0f * d);
+    const float kLn2 = 0.69314718f, k2m24 = 1.0f / 16777216.0f;
+    float g = d;
+    for (int t = 0; t < 8; ++t) {
+        const uint32_t h1 = mz_hash32(key + 3u * t), h2 = mz_hash32(key + 3u * t + 1u), h3 = mz_hash32(key + 3u * t + 2u);
+        const float u1 = (float)((h1 >> 8) + 1u) * k2m24;   // (0, 1]
+        const float u2 = (float)(h2 >> 8) * k2m24;           // [0, 1): a turn of the cosine
+        const float u3 = (float)((h3 >> 8) + 1u) * k2m24;   // (0, 1]
+        const float x = __builtin_amdgcn_sqrtf(-2.0f * kLn2 * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
+        float v = 1.0f + c * x;
+        if (v <= 0.0f) continue;
+        v = v * v * v;
+        if (kLn2 * __builtin_amdgcn_logf(u3) < 0.5f * x * x + d - d * v + d * kLn2 * __builtin_amdgcn_logf(v)) {
+            g = d * v;
+            break;
+        }
+    }
+    if (alpha < 1.0f) {
+        const float ub = (float)((mz_hash32(key + 0x5bd1e995u) >> 8) + 1u) * k2m24;
+        g = g * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(ub) * (1.0f / alpha));  // ub^(1/alpha)
+    }
+    return fmaxf(g, 1e-30f);
+}
+
 // ------------------------------------------------------------------ the whole search in ONE launch
 // k_mz_search: every simulation of every game's search -- select, gather of the parent's hidden state, recurrent
 // inference (dynamics + reward head + prediction of rlzero_amd/muzero/network.py, hidden size 64), scatter of the new
 // hidden state, expand + backup -- inside one kernel: no launch, no global synchronisation and no weight traffic
 // between simulations (the step-by-step route replays a hipGraph of ~15 small launches per simulation).
 // A search is a chain of short dependent steps per game, so the kernel is built for LATENCY and for filling the chip
-// with few games: a workgroup of 4 waves owns `gpw` <= 16 games (4096 games -> 512 workgroups of 8, two per CU: one
-// walks its trees while the other runs its layers).
+// with few games: a workgroup of 4 waves owns `gpw` <= 16 games (4096 games -> 256 workgroups, one per CU).
 //   * the layers are 64 x K GEMMs over the workgroup's games on the matrix pipe, v_mfma_f32_16x16x4_f32 (exact f32
 //     products, f32 accumulation): games = the 16 columns, wave w owns output units 16w .. 16w+15.  The WEIGHTS are
-//     the A operands and never change: each wave keeps its fragments of all four layers in 66 registers for the whole
-//     search; activations go [k][game] through 13 KB of LDS (B operand: one conflict-free ds_read_b32 per MFMA);
+//     the A operands and never change: each wave keeps its fragments of all layers in registers for the whole launch;
+//     activations go [k][game] through LDS (B operand: one conflict-free ds_read_b32 per MFMA);
 //   * dyn2 and rew1 read the same activations: one pass over k feeds both; the per-sample min-max scaling of the new
-//     state reduces over the rows with two DPP steps inside a wave and over the 4 waves through LDS; the scalar heads
-//     (reward; policy logits + value) are two more 16-row tiles on wave 0;
+//     state reduces over the rows with two cross-row steps inside a wave and over the 4 waves through LDS; the scalar
+//     heads (reward; policy logits, value) are dot products of the rows a lane already holds: partial sums per wave,
+//     summed in wave order by the lane that owns the game;
 //   * wave 0 walks and updates the trees, one lane per game, with the code of k_mz_select / k_mz_expand_backup
 //     (mz_descend / mz_grow_backup): fp64, the host's log table -- the tree arithmetic is the step-by-step route's,
 //     bit for bit, given the same network outputs (the outputs differ from rocBLAS' in the last bits: another
 //     summation order).  TREE_LDS: the trees (32 B x slots per game), the paths and the log table live in LDS for the
-//     search (a level of the walk costs an LDS round trip instead of an L2 one) and are written back at the end.
-constexpr int kMzH = 64, kMzWaves = 4, kMzMaxA = 8, kMzTile = 16, kMzKX = kMzH + kMzMaxA, kMzMaxGpw = 16;
+//     search (a level of the walk costs an LDS round trip instead of an L2 one) and are written back at the end;
+//   * MOVES (rz_mz_play_cartpole): whole MOVES of CartPole environments in the launch -- per move the initial inference
+//     (representation + prediction on the same tiles), root expansion with Dirichlet noise, the n_sims simulations,
+//     the action drawn from the visit counts, one packed record for the host and the environment step: the host's
+//     part of self-play shrinks to reading the records.
+constexpr int kMzH = 64, kMzWaves = 4, kMzMaxA = 8, kMzTile = 16, kMzKX = kMzH + kMzMaxA, kMzMaxGpw = 16, kMzObs = 8;
+constexpr int kMzRedRows = 4 + kMzMaxA;   // min, max, reward, value, logits
+constexpr int kMzHeadRows = 2 + kMzMaxA;  // rew2, val, pol rows
 typedef float mz_f32x4 __attribute__((ext_vector_type(4)));
 
 struct MzModel {        // device pointers, weights k-major: w[k][unit]
     const float *dyn1_w, *dyn1_b, *dyn2_w, *dyn2_b, *rew1_w, *rew1_b, *rew2_w, *rew2_b, *pre1_w, *pre1_b, *pol_w, *pol_b,
-        *val_w, *val_b;
+        *val_w, *val_b, *rep1_w, *rep1_b, *rep2_w, *rep2_b;   // rep1_w: [kMzObs][64], rows >= obs_dim zero
 };
 
 struct MzTrace {        // optional per-simulation outputs for the parity tests: [n_sims][n_games] (probs: x n_actions)
@@ -228,8 +349,20 @@ struct MzTrace {        // optional per-simulation outputs for the parity tests:
     float *reward, *probs, *value;
 };
 
-// LDS of k_mz_search in bytes: activations, reductions, per-game scalars, paths, log table (+ the trees)
-__host__ __device__ inline int mz_search_fixed_floats() { return kMzKX * kMzTile + 2 * kMzH * kMzTile + 2 * kMzWaves * kMzTile + 16 + 16; }
+struct MzPlay {         // rz_mz_play_cartpole
+    int n_moves, row;                       // row = doubles per packed record = 4 + 4 + A
+    double *state;                          // [G][4]
+    long long *steps, *episode;             // [G]
+    unsigned long long env_seed, noise_seed;
+    double noise_frac, inv_temperature;     // inv_temperature <= 0: arg-max of the visit counts
+    float alpha;
+    double *out;                            // [n_moves][G][row]: obs (4) | action | reward | visits (A) | root value | done
+};
+
+// LDS of k_mz_search in bytes: activations, reductions, head weights, per-game scalars, paths, log table (+ the trees)
+__host__ __device__ inline int mz_search_fixed_floats() {
+    return kMzKX * kMzTile + kMzH * kMzTile + kMzRedRows * kMzWaves * kMzTile + 16 + kMzHeadRows * kMzH + kMzObs * kMzTile + 16;
+}
 __host__ __device__ inline int mz_search_lds_bytes(int gpw, int cap, int path_stride, int n_sims_cfg, bool tree_lds) {
     int bytes = mz_search_fixed_floats() * 4 + gpw * path_stride * 4;
     bytes = (bytes + 15) / 16 * 16;
@@ -247,18 +380,44 @@ __device__ long long mz_prof[16];
 #define MZ_TICK(i)
 #endif
 
-template <bool TREE_LDS>
-__global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M, float *hidden, int n_sims, int gpw, MzTrace T) {
+// acc += W(16 units of this wave x 4 STEPS) . B([k][game] in LDS) on the matrix pipe
+template <int STEPS>
+__device__ __forceinline__ mz_f32x4 mz_tile(const float (&a)[STEPS], const float *B, int q, int n, mz_f32x4 acc) {
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], B[(4 * s + q) * kMzTile + n], acc, 0, 0, 0);
+    return acc;
+}
+
+// sum over the 4 lanes that hold the rows of one game (q = 0 .. 3): every lane ends with the same bits
+__device__ __forceinline__ float mz_rowsum(float x) {
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
+    return x;
+}
+
+// dot product of the 4 rows a lane holds (16w + 4q .. +3) with a head's weights, summed over the wave's 16 rows
+__device__ __forceinline__ float mz_head_partial(const mz_f32x4 &p, const float *head_row, int w, int q) {
+    const float4 wv = *reinterpret_cast<const float4 *>(head_row + 16 * w + 4 * q);
+    float s = p[0] * wv.x;
+    s = fmaf(p[1], wv.y, s);
+    s = fmaf(p[2], wv.z, s);
+    s = fmaf(p[3], wv.w, s);
+    return mz_rowsum(s);
+}
+
+template <bool TREE_LDS, bool MOVES>
+__global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M, float *hidden, int n_sims, int gpw, MzTrace T, MzPlay P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mz_lds[];
     const int A = E.n_actions, KX = kMzH + A;
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, n = l & 15, q = l >> 4;
     const int g0 = blockIdx.x * gpw;
     float *XS = reinterpret_cast<float *>(mz_lds);   // [72][16]: parent state + one-hot action; later the scaled next state
-    float *HP = XS + kMzKX * kMzTile;                // [64][16]: relu(dyn1); later relu(pre1)
-    float *R1 = HP + kMzH * kMzTile;                 // [64][16]: relu(rew1)
-    float *RED = R1 + kMzH * kMzTile;                // [2][4 waves][16]: min / max of the next state's rows per wave
-    float *HB = RED + 2 * kMzWaves * kMzTile;        // [0] rew2 bias, [1] val bias, [2 .. 2 + A) pol biases
-    int *Gleaf = reinterpret_cast<int *>(HB + 16);   // [16]
+    float *HP = XS + kMzKX * kMzTile;                // [64][16]: relu(dyn1) (relu(rep1) in the initial inference)
+    float *RED = HP + kMzH * kMzTile;                // [12][4 waves][16]: per-wave min / max / reward / value / logit partials
+    float *HB = RED + kMzRedRows * kMzWaves * kMzTile;   // [0] rew2 bias, [1] val bias, [2 .. 2 + A) pol biases
+    float *HW = HB + 16;                             // [10][64]: rew2 / val / pol weights
+    float *OBS = HW + kMzHeadRows * kMzH;            // [8][16]: observations, [k][game] (MOVES)
+    int *Gleaf = reinterpret_cast<int *>(OBS + kMzObs * kMzTile);   // [16]
     int32_t *PATH = Gleaf + 16;                      // [gpw][path_stride]
     unsigned char *pp = mz_lds + (mz_search_fixed_floats() * 4 + gpw * E.path_stride * 4 + 15) / 16 * 16;
     double *PBL = reinterpret_cast<double *>(pp);    // [n_sims + 2]
@@ -266,7 +425,7 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
     MzNode *TREE = reinterpret_cast<MzNode *>(pp);   // [gpw][cap] (TREE_LDS)
 
     // ---- once: weight fragments into registers (A operand of 16x16x4: lane holds W[unit 16w + n][k = 4s + q])
-    float a1[kMzKX / 4], a2[kMzH / 4], ar[kMzH / 4], ap[kMzH / 4], ah[kMzH / 4], ah2[kMzH / 4];
+    float a1[kMzKX / 4], a2[kMzH / 4], ar[kMzH / 4], ap[kMzH / 4], arep1[kMzObs / 4], arep2[kMzH / 4];
     const int unit = 16 * w + n;
 #pragma unroll
     for (int s = 0; s < kMzKX / 4; ++s) {
@@ -279,36 +438,52 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
         a2[s] = M.dyn2_w[k * kMzH + unit];
         ar[s] = M.rew1_w[k * kMzH + unit];
         ap[s] = M.pre1_w[k * kMzH + unit];
-        // wave 0's head tiles: rows 0 .. A-1 = policy, row A = value | row 0 = reward
-        ah[s] = n < A ? M.pol_w[n * kMzH + k] : n == A ? M.val_w[k] : 0.0f;
-        ah2[s] = n == 0 ? M.rew2_w[k] : 0.0f;
+        arep2[s] = MOVES ? M.rep2_w[k * kMzH + unit] : 0.0f;
     }
-    mz_f32x4 b1, b2, br, bp;   // biases in the C/D layout: rows 16w + 4q + i
+#pragma unroll
+    for (int s = 0; s < kMzObs / 4; ++s) arep1[s] = MOVES ? M.rep1_w[(4 * s + q) * kMzH + unit] : 0.0f;
+    mz_f32x4 b1, b2, br, bp, brep1 = {0.0f, 0.0f, 0.0f, 0.0f}, brep2 = {0.0f, 0.0f, 0.0f, 0.0f};   // biases in the C/D layout: rows 16w + 4q + i
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        b1[i] = M.dyn1_b[16 * w + 4 * q + i];
-        b2[i] = M.dyn2_b[16 * w + 4 * q + i];
-        br[i] = M.rew1_b[16 * w + 4 * q + i];
-        bp[i] = M.pre1_b[16 * w + 4 * q + i];
+        const int row = 16 * w + 4 * q + i;
+        b1[i] = M.dyn1_b[row];
+        b2[i] = M.dyn2_b[row];
+        br[i] = M.rew1_b[row];
+        bp[i] = M.pre1_b[row];
+        if (MOVES) {
+            brep1[i] = M.rep1_b[row];
+            brep2[i] = M.rep2_b[row];
+        }
     }
     if (tid == 0) {
         HB[0] = M.rew2_b[0];
         HB[1] = M.val_b[0];
     }
     if (tid < A) HB[2 + tid] = M.pol_b[tid];
+    for (int i = tid; i < kMzHeadRows * kMzH; i += 64 * kMzWaves) {
+        const int row = i >> 6, k = i & 63;
+        HW[i] = row == 0 ? M.rew2_w[k] : row == 1 ? M.val_w[k] : row - 2 < A ? M.pol_w[(row - 2) * kMzH + k] : 0.0f;
+    }
     for (int i = tid; i < kMzKX * kMzTile; i += 64 * kMzWaves) XS[i] = 0.0f;   // (the padding rows 64 + A .. 71 stay zero)
+    for (int i = tid; i < kMzObs * kMzTile; i += 64 * kMzWaves) OBS[i] = 0.0f;
     for (int i = tid; i < E.n_sims + 2; i += 64 * kMzWaves) PBL[i] = E.pb_log[i];
     // the trees of this workgroup's games
     const bool mine = w == 0 && l < gpw && g0 + l < E.n_games;   // this lane walks the tree of game g0 + l
     const int g = g0 + (l < gpw ? l : 0);
+    const bool live_n = n < gpw && g0 + n < E.n_games;           // column n of the tiles is a game
     int top = 0, depth = 0;
     double lo = 0.0, hi = 0.0;
+    MzCartPole env = {0.0, 0.0, 0.0, 0.0, 0, 0};
     if (mine) {
-        top = E.top[g];
-        lo = E.vmin[g];
-        hi = E.vmax[g];
+        if (MOVES) {
+            env = MzCartPole{P.state[4 * g], P.state[4 * g + 1], P.state[4 * g + 2], P.state[4 * g + 3], P.steps[g], P.episode[g]};
+        } else {
+            top = E.top[g];
+            lo = E.vmin[g];
+            hi = E.vmax[g];
+        }
     }
-    if (TREE_LDS) {
+    if (TREE_LDS && !MOVES) {
         const int per_game = E.cap * (int)(sizeof(MzNode) / 16);   // uint4 words
         for (int ee = 0; ee < gpw && g0 + ee < E.n_games; ++ee) {
             const uint4 *src = reinterpret_cast<const uint4 *>(E.nodes + (long long)(g0 + ee) * E.cap);
@@ -320,10 +495,139 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
     MzNode *nodes = TREE_LDS ? TREE + (l < gpw ? l : 0) * E.cap : E.nodes + (long long)g * E.cap;
     int32_t *path = PATH + (l < gpw ? l : 0) * E.path_stride;
     __syncthreads();
+    if (MOVES && mine) {   // (after the zero fill of OBS)
+        OBS[0 * kMzTile + l] = (float)env.x;
+        OBS[1 * kMzTile + l] = (float)env.x_dot;
+        OBS[2 * kMzTile + l] = (float)env.theta;
+        OBS[3 * kMzTile + l] = (float)env.theta_dot;
+    }
+
+    // ---- the pieces the initial inference and a simulation share
+    // per-sample min-max scaling of a new state t (network.py scale_hidden) from the per-wave extremes in RED: the scaled
+    // rows go to XS (the next layer's input) and to the hidden-state slot Gleaf[game] of the game
+    auto scale_and_store = [&](const mz_f32x4 &t) {
+        float mn = RED[n], mx = RED[kMzWaves * kMzTile + n];
+#pragma unroll
+        for (int u = 1; u < kMzWaves; ++u) {
+            mn = fminf(mn, RED[u * kMzTile + n]);
+            mx = fmaxf(mx, RED[(kMzWaves + u) * kMzTile + n]);
+        }
+        const float inv = fmaxf(mx - mn, 1e-5f);
+        float4 sv;
+        sv.x = (t[0] - mn) / inv;
+        sv.y = (t[1] - mn) / inv;
+        sv.z = (t[2] - mn) / inv;
+        sv.w = (t[3] - mn) / inv;
+        XS[(16 * w + 4 * q + 0) * kMzTile + n] = sv.x;
+        XS[(16 * w + 4 * q + 1) * kMzTile + n] = sv.y;
+        XS[(16 * w + 4 * q + 2) * kMzTile + n] = sv.z;
+        XS[(16 * w + 4 * q + 3) * kMzTile + n] = sv.w;
+        if (live_n) *reinterpret_cast<float4 *>(hidden + ((long long)(g0 + n) * E.cap + Gleaf[n]) * kMzH + 16 * w + 4 * q) = sv;
+    };
+    auto wave_extremes = [&](const mz_f32x4 &t) {
+        float mn = fminf(fminf(t[0], t[1]), fminf(t[2], t[3])), mx = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3]));
+        mn = fminf(mn, __shfl_xor(mn, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mn = fminf(mn, __shfl_xor(mn, 32));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (q == 0) {
+            RED[(0 * kMzWaves + w) * kMzTile + n] = mn;
+            RED[(1 * kMzWaves + w) * kMzTile + n] = mx;
+        }
+    };
+    // prediction f(s) on the state in XS: p1 = relu(pre1 s), per-wave partial sums of the value and policy heads
+    auto predict_partials = [&]() {
+        mz_f32x4 p = mz_tile(ap, XS, q, n, bp);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = fmaxf(p[i], 0.0f);
+        const float pv = mz_head_partial(p, HW + 1 * kMzH, w, q);
+        if (q == 0) RED[(3 * kMzWaves + w) * kMzTile + n] = pv;
+#pragma unroll
+        for (int a = 0; a < kMzMaxA; ++a) {
+            if (a < A) {
+                const float pl = mz_head_partial(p, HW + (2 + a) * kMzH, w, q);
+                if (q == 0) RED[((4 + a) * kMzWaves + w) * kMzTile + n] = pl;
+            }
+        }
+    };
+    // (lane that owns a game) value and softmax(policy logits) from the partial sums, waves in order
+    auto finish_prediction = [&](float &value, float (&probs)[kMzMaxA]) {
+        value = HB[1];
+#pragma unroll
+        for (int u = 0; u < kMzWaves; ++u) value += RED[(3 * kMzWaves + u) * kMzTile + n];
+        float logit[kMzMaxA], mxl = -INFINITY;
+#pragma unroll
+        for (int a = 0; a < kMzMaxA; ++a) {
+            logit[a] = -INFINITY;
+            if (a < A) {
+                float x = HB[2 + a];
+#pragma unroll
+                for (int u = 0; u < kMzWaves; ++u) x += RED[((4 + a) * kMzWaves + u) * kMzTile + n];
+                logit[a] = x;
+                mxl = fmaxf(mxl, x);
+            }
+        }
+        float den = 0.0f;
+#pragma unroll
+        for (int a = 0; a < kMzMaxA; ++a) {
+            probs[a] = a < A ? expf(logit[a] - mxl) : 0.0f;
+            den += probs[a];
+        }
+#pragma unroll
+        for (int a = 0; a < kMzMaxA; ++a) probs[a] = probs[a] / den;
+    };
 
 #ifdef RZ_MZ_PROFILE
     long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = clock64();
 #endif
+    const int n_moves = MOVES ? P.n_moves : 1;
+    for (int move = 0; move < n_moves; ++move) {
+        if (MOVES) {
+            // ---- initial inference: s0 = scale(rep2 relu(rep1 obs)) -> hidden slot 0; root priors = softmax(pol(relu(pre1 s0)))
+            __syncthreads();   // (OBS of this move is written; the last move's reads of RED / XS are over)
+            if (tid < kMzTile) Gleaf[tid] = 0;
+            {
+                mz_f32x4 h = mz_tile(arep1, OBS, q, n, brep1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) HP[(16 * w + 4 * q + i) * kMzTile + n] = fmaxf(h[i], 0.0f);
+            }
+            __syncthreads();
+            const mz_f32x4 t0 = mz_tile(arep2, HP, q, n, brep2);
+            wave_extremes(t0);
+            __syncthreads();
+            scale_and_store(t0);
+            __syncthreads();
+            predict_partials();
+            __syncthreads();
+            if (w == 0) {
+                float value, probs[kMzMaxA];
+                finish_prediction(value, probs);
+                if (mine) {
+                    // expand_node(root) + add_exploration_noise: prior * (1 - frac) + noise * frac (k_mz_init), fresh MinMaxStats
+                    const unsigned long long key = mz_splitmix64(mz_splitmix64(mz_splitmix64(P.noise_seed ^ ((unsigned long long)g << 24)) ^
+                                                                                (unsigned long long)env.episode) ^ (unsigned long long)env.steps);
+                    float gam[kMzMaxA], gsum = 0.0f;
+#pragma unroll
+                    for (int a = 0; a < kMzMaxA; ++a) {
+                        gam[a] = a < A ? mz_gamma(P.alpha, (uint32_t)(key >> 32) + 0x9E3779B9u * (uint32_t)(a + 1) + (uint32_t)key) : 0.0f;
+                        gsum += gam[a];
+                    }
+                    nodes[0] = MzNode{0, 1, 0.0, 0.0, 0.0f, 0};
+#pragma unroll
+                    for (int a = 0; a < kMzMaxA; ++a) {
+                        if (a < A) {
+                            double pr = (double)probs[a];
+                            if (P.noise_frac > 0.0) pr = pr * (1.0 - P.noise_frac) + ((double)gam[a] / (double)gsum) * P.noise_frac;
+                            nodes[1 + a] = MzNode{0, -1, 0.0, pr, 0.0f, 0};
+                        }
+                    }
+                    top = 1 + A;
+                    lo = INFINITY;
+                    hi = -INFINITY;
+                    depth = 0;
+                }
+            }
+        }
     for (int sim = 0; sim < n_sims; ++sim) {
         // S0 (wave 0): select, one lane per game; then the gather of the parents' hidden states into XS[k][game]
         // (lane -> game l / 4, four 16-byte pieces of its 256-byte row) and the one-hot action rows
@@ -346,7 +650,6 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
                 XS[(4 * c + 3) * kMzTile + ee] = v.w;
             }
             const int an = __shfl(act, n);
-            const bool live_n = n < gpw && g0 + n < E.n_games;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int a = q + 4 * j;
@@ -358,17 +661,14 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
         MZ_TICK(2);
         // S1: h1 = relu(dyn1 [x, onehot(a)])
         {
-            mz_f32x4 acc = b1;
-#pragma unroll
-            for (int s = 0; s < kMzKX / 4; ++s)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], XS[(4 * s + q) * kMzTile + n], acc, 0, 0, 0);
+            const mz_f32x4 acc = mz_tile(a1, XS, q, n, b1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) HP[(16 * w + 4 * q + i) * kMzTile + n] = fmaxf(acc[i], 0.0f);
         }
         MZ_TICK(3);
         __syncthreads();
         MZ_TICK(4);
-        // S2: next state (dyn2, before scaling) and the reward head's hidden layer (rew1) from the same activations
+        // S2: next state (dyn2, before scaling) and the reward head (rew2 relu(rew1 h1)) from the same activations
         mz_f32x4 t = b2;
         {
             mz_f32x4 r = br;
@@ -378,88 +678,35 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
                 t = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s], x, t, 0, 0, 0);
                 r = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[s], x, r, 0, 0, 0);
             }
-            float mn = fminf(fminf(t[0], t[1]), fminf(t[2], t[3])), mx = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3]));
-            mn = fminf(mn, __shfl_xor(mn, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mn = fminf(mn, __shfl_xor(mn, 32));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            if (q == 0) {
-                RED[(0 * kMzWaves + w) * kMzTile + n] = mn;
-                RED[(1 * kMzWaves + w) * kMzTile + n] = mx;
-            }
+            wave_extremes(t);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) R1[(16 * w + 4 * q + i) * kMzTile + n] = fmaxf(r[i], 0.0f);
+            for (int i = 0; i < 4; ++i) r[i] = fmaxf(r[i], 0.0f);
+            const float pr = mz_head_partial(r, HW, w, q);
+            if (q == 0) RED[(2 * kMzWaves + w) * kMzTile + n] = pr;
         }
         MZ_TICK(5);
         __syncthreads();
         MZ_TICK(6);
-        // S3: per-sample min-max scaling of the new state (network.py scale_hidden), stored for the leaf
-        {
-            float mn = RED[n], mx = RED[kMzWaves * kMzTile + n];
-#pragma unroll
-            for (int u = 1; u < kMzWaves; ++u) {
-                mn = fminf(mn, RED[u * kMzTile + n]);
-                mx = fmaxf(mx, RED[(kMzWaves + u) * kMzTile + n]);
-            }
-            const float inv = fmaxf(mx - mn, 1e-5f);
-            float4 sv;
-            sv.x = (t[0] - mn) / inv;
-            sv.y = (t[1] - mn) / inv;
-            sv.z = (t[2] - mn) / inv;
-            sv.w = (t[3] - mn) / inv;
-            XS[(16 * w + 4 * q + 0) * kMzTile + n] = sv.x;
-            XS[(16 * w + 4 * q + 1) * kMzTile + n] = sv.y;
-            XS[(16 * w + 4 * q + 2) * kMzTile + n] = sv.z;
-            XS[(16 * w + 4 * q + 3) * kMzTile + n] = sv.w;
-            if (n < gpw && g0 + n < E.n_games)
-                *reinterpret_cast<float4 *>(hidden + ((long long)(g0 + n) * E.cap + Gleaf[n]) * kMzH + 16 * w + 4 * q) = sv;
-        }
+        // S3: per-sample min-max scaling of the new state, stored for the leaf
+        scale_and_store(t);
         MZ_TICK(7);
         __syncthreads();
         MZ_TICK(8);
-        // S4: prediction trunk: p1 = relu(pre1 s')
-        {
-            mz_f32x4 acc = bp;
-#pragma unroll
-            for (int s = 0; s < kMzH / 4; ++s)
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[s], XS[(4 * s + q) * kMzTile + n], acc, 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) HP[(16 * w + 4 * q + i) * kMzTile + n] = fmaxf(acc[i], 0.0f);
-        }
+        // S4: prediction on the new state
+        predict_partials();
         MZ_TICK(9);
         __syncthreads();
         MZ_TICK(10);
-        // S5 (wave 0): the scalar heads as two 16-row tiles (rows 0 .. A-1 policy logits, row A value | row 0 reward),
-        // softmax, expand + backup.  Row m of a tile sits in register m & 3 of the lanes q = m >> 2.
+        // S5 (wave 0): finish the heads, expand + backup
         if (w == 0) {
-            mz_f32x4 hp = {0.0f, 0.0f, 0.0f, 0.0f}, hr = {0.0f, 0.0f, 0.0f, 0.0f};
+            float reward = HB[0];
 #pragma unroll
-            for (int s = 0; s < kMzH / 4; ++s) {
-                hp = __builtin_amdgcn_mfma_f32_16x16x4f32(ah[s], HP[(4 * s + q) * kMzTile + n], hp, 0, 0, 0);
-                hr = __builtin_amdgcn_mfma_f32_16x16x4f32(ah2[s], R1[(4 * s + q) * kMzTile + n], hr, 0, 0, 0);
-            }
-            const float reward = hr[0] + HB[0];   // (row 0: lanes q = 0 -- the lanes that own a game)
-            float logit[kMzMaxA], probs[kMzMaxA], mxl = -INFINITY, value = 0.0f;
-#pragma unroll
-            for (int m = 0; m <= kMzMaxA; ++m) {
-                const float row = __shfl(hp[m & 3], 16 * (m >> 2) + n);
-                if (m < kMzMaxA) {
-                    logit[m] = m < A ? row + HB[2 + (m < A ? m : 0)] : -INFINITY;
-                    mxl = fmaxf(mxl, logit[m]);
-                }
-                if (m == A) value = row + HB[1];
-            }
-            float den = 0.0f;
-#pragma unroll
-            for (int a = 0; a < kMzMaxA; ++a) {
-                probs[a] = a < A ? expf(logit[a] - mxl) : 0.0f;
-                den += probs[a];
-            }
-#pragma unroll
-            for (int a = 0; a < kMzMaxA; ++a) probs[a] = probs[a] / den;
+            for (int u = 0; u < kMzWaves; ++u) reward += RED[(2 * kMzWaves + u) * kMzTile + n];
+            float value, probs[kMzMaxA];
+            finish_prediction(value, probs);
             MZ_TICK(11);
             if (mine) {
-                if (T.reward != nullptr) {
+                if (!MOVES && T.reward != nullptr) {
                     const long long o = (long long)sim * E.n_games + g;
                     T.parent[o] = par;
                     T.action[o] = act;
@@ -474,8 +721,68 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
             }
             MZ_TICK(12);
         }
-        // (no barrier: the next select and gather are wave 0's too, and XS -- which the gather rewrites -- was last read
-        // before the barrier behind S4; HP / R1, which wave 0 reads above, are rewritten only after the next S0 barrier)
+        // (no barrier: the next select and gather are wave 0's too; XS -- which the gather rewrites -- was last read
+        // before the barrier behind S4, and RED, which wave 0 reads above, is rewritten only after the next S0 barrier)
+    }
+        if (MOVES && mine) {
+            // ---- the move: action ~ visits ^ (1 / T) (select_action), record for the host, environment step
+            double wgt[kMzMaxA], total = 0.0, best_w = -1.0;
+            int visits[kMzMaxA], arg = 0;
+#pragma unroll
+            for (int a = 0; a < kMzMaxA; ++a) {
+                visits[a] = a < A ? nodes[1 + a].N : 0;
+                wgt[a] = 0.0;
+                if (a < A) {
+                    wgt[a] = P.inv_temperature == 1.0 || P.inv_temperature <= 0.0 ? (double)visits[a] : pow((double)visits[a], P.inv_temperature);
+                    total += wgt[a];
+                    if (wgt[a] > best_w) {
+                        best_w = wgt[a];
+                        arg = a;
+                    }
+                }
+            }
+            int action = arg;
+            if (P.inv_temperature > 0.0) {
+                const unsigned long long key = mz_splitmix64(mz_splitmix64(mz_splitmix64(P.noise_seed ^ 0xA5A5A5A5ull ^ ((unsigned long long)g << 24)) ^
+                                                                            (unsigned long long)env.episode) ^ (unsigned long long)env.steps);
+                const double target = ((double)(key >> 11) / 9007199254740992.0) * total;
+                double cum = 0.0;
+                bool found = false;
+                action = A - 1;
+#pragma unroll
+                for (int a = 0; a < kMzMaxA; ++a) {
+                    if (a < A) {
+                        cum += wgt[a];
+                        if (!found && cum > target) {
+                            action = a;
+                            found = true;
+                        }
+                    }
+                }
+            }
+            const MzNode root = nodes[0];
+            double *rec = P.out + ((long long)move * E.n_games + g) * P.row;
+            rec[0] = (double)(float)env.x;   // the observation the search started from
+            rec[1] = (double)(float)env.x_dot;
+            rec[2] = (double)(float)env.theta;
+            rec[3] = (double)(float)env.theta_dot;
+            rec[4] = (double)action;
+            rec[5] = 1.0;
+#pragma unroll
+            for (int a = 0; a < kMzMaxA; ++a)
+                if (a < A) rec[6 + a] = (double)visits[a];
+            rec[6 + A] = root.value_sum / (double)(root.N > 1 ? root.N : 1);
+            const int done = cartpole_step(env, action);
+            rec[7 + A] = done ? 1.0 : 0.0;
+            if (done) {
+                env.episode += 1;
+                cartpole_reset(env, P.env_seed, g);
+            }
+            OBS[0 * kMzTile + l] = (float)env.x;
+            OBS[1 * kMzTile + l] = (float)env.x_dot;
+            OBS[2 * kMzTile + l] = (float)env.theta;
+            OBS[3 * kMzTile + l] = (float)env.theta_dot;
+        }
     }
 #ifdef RZ_MZ_PROFILE
     if (blockIdx.x == 0 && tid == 0)
@@ -486,6 +793,14 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
         E.vmin[g] = lo;
         E.vmax[g] = hi;
         E.depth[g] = depth;
+        if (MOVES) {
+            P.state[4 * g] = env.x;
+            P.state[4 * g + 1] = env.x_dot;
+            P.state[4 * g + 2] = env.theta;
+            P.state[4 * g + 3] = env.theta_dot;
+            P.steps[g] = env.steps;
+            P.episode[g] = env.episode;
+        }
     }
     if (TREE_LDS) {
         __syncthreads();
@@ -540,7 +855,8 @@ struct rz_muzero {
     long long bytes = 0;
     MzModel model = {};          // rz_mz_load_model
     float *d_model = nullptr;    // one allocation behind the pointers above
-    bool model_loaded = false;
+    bool model_loaded = false, representation_loaded = false;
+    float *d_rep = nullptr;      // rz_mz_load_representation
     int n_cus = 256;             // of cfg.device
     int games_per_wg = 0;        // rz_mz_set_search_shape: 0 = chosen from n_games and n_cus
 };
@@ -725,17 +1041,76 @@ int rz_mz_load_model(rz_muzero *e, const float *const *h_params, int32_t n_param
         e->allocs.push_back(e->d_model);
         e->bytes += (long long)(total * sizeof(float));
         const int most = 160 * 1024;
-        if (hipFuncSetAttribute((const void *)k_mz_search<true>, hipFuncAttributeMaxDynamicSharedMemorySize, most) != hipSuccess ||
-            hipFuncSetAttribute((const void *)k_mz_search<false>, hipFuncAttributeMaxDynamicSharedMemorySize, most) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)k_mz_search<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, most) != hipSuccess ||
+            hipFuncSetAttribute((const void *)k_mz_search<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, most) != hipSuccess ||
+            hipFuncSetAttribute((const void *)k_mz_search<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, most) != hipSuccess ||
+            hipFuncSetAttribute((const void *)k_mz_search<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, most) != hipSuccess)
             return mz_fail(RZ_ERR_HIP, "hipFuncSetAttribute(dynamic LDS) failed");
     }
     if (hipMemcpy(e->d_model, host.data(), total * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
         return mz_fail(RZ_ERR_HIP, "hipMemcpy(model) failed");
     const float *b = e->d_model;
+    const MzModel seen = e->model;   // (the representation layers are loaded by their own call)
     e->model = MzModel{b + off[0], b + off[1], b + off[2], b + off[3], b + off[4], b + off[5], b + off[6], b + off[7],
-                       b + off[8], b + off[9], b + off[10], b + off[11], b + off[12], b + off[13]};
+                       b + off[8], b + off[9], b + off[10], b + off[11], b + off[12], b + off[13],
+                       seen.rep1_w, seen.rep1_b, seen.rep2_w, seen.rep2_b};
     e->model_loaded = true;
     return RZ_OK;
+}
+
+int rz_mz_load_representation(rz_muzero *e, const float *const *h_params, int32_t n_params, int32_t obs_dim, int32_t hidden) {
+    int rc = mz_ready(e);
+    if (rc != RZ_OK) return rc;
+    if (h_params == nullptr || n_params != 4) return mz_fail(RZ_ERR_ARG, "expected rep1.weight, rep1.bias, rep2.weight, rep2.bias");
+    if (hidden != kMzH || obs_dim < 1 || obs_dim > kMzObs) return mz_fail(RZ_ERR_ARG, "the fused moves are built for hidden size 64 and <= 8 observation features");
+    for (int i = 0; i < 4; ++i)
+        if (!h_params[i]) return mz_fail(RZ_ERR_ARG, "a parameter pointer is NULL");
+    // rep1.w [64][obs_dim] -> k-major [8][64] (rows >= obs_dim zero), rep1.b, rep2.w [64][64] -> k-major, rep2.b
+    const size_t off[4] = {0, (size_t)kMzObs * kMzH, (size_t)kMzObs * kMzH + kMzH, (size_t)kMzObs * kMzH + kMzH + (size_t)kMzH * kMzH};
+    const size_t total = off[3] + kMzH;
+    std::vector<float> host(total, 0.0f);
+    for (int o = 0; o < kMzH; ++o) {
+        for (int k = 0; k < obs_dim; ++k) host[off[0] + (size_t)k * kMzH + o] = h_params[0][(size_t)o * obs_dim + k];
+        for (int k = 0; k < kMzH; ++k) host[off[2] + (size_t)k * kMzH + o] = h_params[2][(size_t)o * kMzH + k];
+        host[off[1] + o] = h_params[1][o];
+        host[off[3] + o] = h_params[3][o];
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return mz_fail(RZ_ERR_HIP, "hipDeviceSynchronize failed");
+    if (e->d_rep == nullptr) {
+        if (hipMalloc((void **)&e->d_rep, total * sizeof(float)) != hipSuccess) return mz_fail(RZ_ERR_OOM, "hipMalloc failed (muzero representation)");
+        e->allocs.push_back(e->d_rep);
+        e->bytes += (long long)(total * sizeof(float));
+    }
+    if (hipMemcpy(e->d_rep, host.data(), total * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+        return mz_fail(RZ_ERR_HIP, "hipMemcpy(representation) failed");
+    e->model.rep1_w = e->d_rep + off[0];
+    e->model.rep1_b = e->d_rep + off[1];
+    e->model.rep2_w = e->d_rep + off[2];
+    e->model.rep2_b = e->d_rep + off[3];
+    e->representation_loaded = true;
+    return RZ_OK;
+}
+
+static int mz_launch_search(rz_muzero *e, float *d_hidden, int32_t n_sims, const MzTrace &T, const MzPlay *play, void *stream) {
+    // games per workgroup: a search is a latency chain per game and two workgroups share a CU without slowing each
+    // other, so the 16 columns of a tile are filled first (profiles/r02/muzero_search_shape.txt)
+    const int gpw = e->games_per_wg > 0 ? e->games_per_wg : kMzMaxGpw;
+    // the trees go to LDS when two workgroups still fit on a CU
+    const MzDev &D = e->dev;
+    const bool tree_lds = mz_search_lds_bytes(gpw, D.cap, D.path_stride, D.n_sims, true) <= 80 * 1024;
+    const int lds = mz_search_lds_bytes(gpw, D.cap, D.path_stride, D.n_sims, tree_lds);
+    if (lds > 160 * 1024) return mz_fail(RZ_ERR_ARG, "n_sims too large for the fused search (paths do not fit in LDS)");
+    const dim3 grid((unsigned)((e->cfg.n_games + gpw - 1) / gpw)), block(64 * kMzWaves);
+    const MzPlay none = {};
+    hipStream_t st = (hipStream_t)stream;
+    if (play != nullptr) {
+        if (tree_lds) k_mz_search<true, true><<<grid, block, lds, st>>>(e->dev, e->model, d_hidden, n_sims, gpw, T, *play);
+        else k_mz_search<false, true><<<grid, block, lds, st>>>(e->dev, e->model, d_hidden, n_sims, gpw, T, *play);
+    } else {
+        if (tree_lds) k_mz_search<true, false><<<grid, block, lds, st>>>(e->dev, e->model, d_hidden, n_sims, gpw, T, none);
+        else k_mz_search<false, false><<<grid, block, lds, st>>>(e->dev, e->model, d_hidden, n_sims, gpw, T, none);
+    }
+    return mz_launched("launch of k_mz_search failed");
 }
 
 int rz_mz_search(rz_muzero *e, float *d_hidden, int32_t n_sims, int32_t *d_trace_parent, int32_t *d_trace_action,
@@ -748,21 +1123,43 @@ int rz_mz_search(rz_muzero *e, float *d_hidden, int32_t n_sims, int32_t *d_trace
     const bool all = d_trace_parent && d_trace_action && d_trace_leaf && d_trace_reward && d_trace_probs && d_trace_value;
     if (any && !all) return mz_fail(RZ_ERR_ARG, "the trace arrays come all together or not at all");
     const MzTrace T = {d_trace_parent, d_trace_action, d_trace_leaf, d_trace_reward, d_trace_probs, d_trace_value};
-    // games per workgroup: a search is a latency chain per game, so few games per workgroup and MANY workgroups -- at
-    // least two per CU (one walks its trees while the other runs its layers) before the 16 columns of a tile fill up
-    int gpw = e->games_per_wg;
-    if (gpw == 0) gpw = e->cfg.n_games >= 32 * e->n_cus ? 16 : e->cfg.n_games >= 16 * e->n_cus ? 8 : 4;
-    // the trees go to LDS when two workgroups still fit on a CU
-    const MzDev &D = e->dev;
-    bool tree_lds = mz_search_lds_bytes(gpw, D.cap, D.path_stride, D.n_sims, true) <= 80 * 1024;
-    const int lds = mz_search_lds_bytes(gpw, D.cap, D.path_stride, D.n_sims, tree_lds);
-    if (lds > 160 * 1024) return mz_fail(RZ_ERR_ARG, "n_sims too large for the fused search (paths do not fit in LDS)");
-    const dim3 grid((unsigned)((e->cfg.n_games + gpw - 1) / gpw));
-    if (tree_lds)
-        k_mz_search<true><<<grid, dim3(64 * kMzWaves), lds, (hipStream_t)stream>>>(e->dev, e->model, d_hidden, n_sims, gpw, T);
-    else
-        k_mz_search<false><<<grid, dim3(64 * kMzWaves), lds, (hipStream_t)stream>>>(e->dev, e->model, d_hidden, n_sims, gpw, T);
-    return mz_launched("launch of k_mz_search failed");
+    return mz_launch_search(e, d_hidden, n_sims, T, nullptr, stream);
+}
+
+int rz_mz_play_cartpole(rz_muzero *e, float *d_hidden, int32_t n_sims, int32_t n_moves, double *d_state, int64_t *d_steps,
+                        int64_t *d_episode, uint64_t env_seed, uint64_t noise_seed, double noise_frac, double dirichlet_alpha,
+                        double temperature, double *d_records, void *stream) {
+    int rc = mz_ready(e);
+    if (rc != RZ_OK) return rc;
+    if (!e->model_loaded || !e->representation_loaded) return mz_fail(RZ_ERR_ARG, "rz_mz_load_model and rz_mz_load_representation first");
+    if (e->cfg.n_actions != 2) return mz_fail(RZ_ERR_ARG, "CartPole has 2 actions");
+    if (d_hidden == nullptr || n_sims < 1 || n_sims > e->cfg.n_sims || n_moves < 1) return mz_fail(RZ_ERR_ARG, "d_hidden is NULL or n_sims / n_moves out of range");
+    if (!d_state || !d_steps || !d_episode || !d_records) return mz_fail(RZ_ERR_ARG, "NULL environment / record pointer");
+    if (!(dirichlet_alpha > 0.0) || noise_frac < 0.0 || noise_frac > 1.0) return mz_fail(RZ_ERR_ARG, "dirichlet_alpha must be > 0, noise_frac in [0, 1]");
+    MzPlay play = {};
+    play.n_moves = n_moves;
+    play.row = 4 + 4 + e->cfg.n_actions;
+    play.state = d_state;
+    play.steps = reinterpret_cast<long long *>(d_steps);
+    play.episode = reinterpret_cast<long long *>(d_episode);
+    play.env_seed = env_seed;
+    play.noise_seed = noise_seed;
+    play.noise_frac = noise_frac;
+    play.inv_temperature = temperature > 0.0 ? 1.0 / temperature : 0.0;
+    play.alpha = (float)dirichlet_alpha;
+    play.out = d_records;
+    const MzTrace T = {};
+    return mz_launch_search(e, d_hidden, n_sims, T, &play, stream);
+}
+
+int rz_cartpole_step(double *d_state, int64_t *d_steps, int64_t *d_episode, const int64_t *d_actions, int32_t n_envs, uint64_t seed,
+                     float *d_obs, float *d_reward, uint8_t *d_terminated, uint8_t *d_truncated, void *stream) {
+    if (!d_state || !d_steps || !d_episode || !d_actions || !d_obs || !d_reward || !d_terminated || !d_truncated || n_envs < 1)
+        return mz_fail(RZ_ERR_ARG, "NULL pointer or n_envs < 1");
+    k_cartpole_step<<<dim3((unsigned)((n_envs + 127) / 128)), dim3(128), 0, (hipStream_t)stream>>>(
+        d_state, reinterpret_cast<long long *>(d_steps), reinterpret_cast<long long *>(d_episode),
+        reinterpret_cast<const long long *>(d_actions), n_envs, seed, d_obs, d_reward, d_terminated, d_truncated);
+    return mz_launched("launch of k_cartpole_step failed");
 }
 
 int rz_mz_set_search_shape(rz_muzero *e, int32_t games_per_workgroup) {

@@ -40,20 +40,36 @@ def initial_states(seed, env_ids, episodes):
 
 
 class CartPoleBatch(object):
+    """The environments live on the device: ``state`` float64 [n, 4], ``steps`` / ``episode_dev`` int64 [n]; a step of
+    all of them (physics, termination, auto-reset) is ONE kernel launch (csrc/rz_muzero.hip k_cartpole_step) and never
+    synchronises with the host.  The fused MuZero moves (MuZeroTree.play_cartpole) step the same tensors in place."""
     n_actions = 2
     obs_dim = 4
+    max_episode_steps = MAX_EPISODE_STEPS
 
     def __init__(self, n_envs, device='cuda:0', seed=0):
         import torch
+        from .. import _hip
         self.torch = torch
         self.device = torch.device(device)
         if self.device.type != 'cuda':
             raise RuntimeError('CartPoleBatch runs on the GPU (device=%r)' % (device, ))
+        self.lib = _hip.load()
         self.n_envs, self.seed = int(n_envs), int(seed)
-        self.state = torch.zeros((n_envs, 4), dtype=torch.float64, device=self.device)
-        self.steps = torch.zeros(n_envs, dtype=torch.int64, device=self.device)
-        self.episode = np.zeros(n_envs, dtype=np.int64)
+        kw = dict(device=self.device)
+        self.state = torch.zeros((n_envs, 4), dtype=torch.float64, **kw)
+        self.steps = torch.zeros(n_envs, dtype=torch.int64, **kw)
+        self.episode_dev = torch.zeros(n_envs, dtype=torch.int64, **kw)
+        self._obs = torch.zeros((n_envs, 4), dtype=torch.float32, **kw)
+        self._reward = torch.zeros(n_envs, dtype=torch.float32, **kw)
+        self._terminated = torch.zeros(n_envs, dtype=torch.uint8, **kw)
+        self._truncated = torch.zeros(n_envs, dtype=torch.uint8, **kw)
         self.reset_all()
+
+    @property
+    def episode(self):
+        """Episode index of every environment (host copy)."""
+        return self.episode_dev.cpu().numpy()
 
     def reset_all(self):
         self.set_states(initial_states(self.seed, np.arange(self.n_envs), self.episode))
@@ -76,29 +92,12 @@ class CartPoleBatch(object):
         """actions int64 [n] on the device -> (obs float32 [n,4] AFTER auto-reset, reward float32 [n],
         terminated bool [n], truncated bool [n]) ; the observation of a finished environment is the first of
         its next episode (the terminal state itself is never evaluated by MuZero)."""
+        import ctypes
+        from ..engine import _ptr, check
         t = self.torch
-        x, x_dot, theta, theta_dot = self.state.unbind(dim=1)
-        force = t.where(actions == 1, FORCE_MAG, -FORCE_MAG).to(t.float64)
-        costheta, sintheta = t.cos(theta), t.sin(theta)
-        temp = (force + POLEMASS_LENGTH * (theta_dot * theta_dot) * sintheta) / TOTAL_MASS
-        thetaacc = (GRAVITY * sintheta - costheta * temp) / (
-            LENGTH * (4.0 / 3.0 - MASSPOLE * (costheta * costheta) / TOTAL_MASS))
-        xacc = temp - POLEMASS_LENGTH * thetaacc * costheta / TOTAL_MASS
-        x = x + TAU * x_dot
-        x_dot = x_dot + TAU * xacc
-        theta = theta + TAU * theta_dot
-        theta_dot = theta_dot + TAU * thetaacc
-        self.state = t.stack((x, x_dot, theta, theta_dot), dim=1)
-        self.steps += 1
-        terminated = (x < -X_THRESHOLD) | (x > X_THRESHOLD) | (theta < -THETA_THRESHOLD) | (theta > THETA_THRESHOLD)
-        truncated = self.steps >= MAX_EPISODE_STEPS
-        reward = t.ones(self.n_envs, dtype=t.float32, device=self.device)
-        done = (terminated | truncated).cpu().numpy()
-        if done.any():
-            idx = np.nonzero(done)[0]
-            self.episode[idx] += 1
-            new = t.from_numpy(initial_states(self.seed, idx, self.episode[idx])).to(self.device)
-            where = t.from_numpy(idx).to(self.device)
-            self.state[where] = new
-            self.steps[where] = 0
-        return self.observe(), reward, terminated, truncated
+        actions = actions.to(t.int64).contiguous()
+        stream = ctypes.c_void_p(t.cuda.current_stream(self.device).cuda_stream)
+        check(self.lib.rz_cartpole_step(_ptr(self.state), _ptr(self.steps), _ptr(self.episode_dev), _ptr(actions), self.n_envs,
+                                        self.seed & (2 ** 64 - 1), _ptr(self._obs), _ptr(self._reward), _ptr(self._terminated),
+                                        _ptr(self._truncated), stream), 'rz_cartpole_step')
+        return self._obs.clone(), self._reward.clone(), self._terminated.bool(), self._truncated.bool()

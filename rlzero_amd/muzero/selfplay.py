@@ -27,6 +27,55 @@ class Episode(object):
         return len(self.actions)
 
 
+class EpisodeSeq(object):
+    """The episodes that ended during a stretch of self-play, as a sequence: the steps of all of them lie in a few flat
+    arrays (one gather per field and move) and an ``Episode`` -- views into those arrays -- is made when it is asked for.
+    With thousands of environments hundreds of episodes end per move: building them eagerly was the host's largest cost."""
+
+    def __init__(self):
+        self._chunks = []   # (fields tuple of flat arrays, offsets int64 [n + 1])
+        self._starts = [0]  # index of the first episode of every chunk (+ the total)
+
+    def _add(self, fields, lengths):
+        offsets = np.zeros(len(lengths) + 1, dtype=np.int64)
+        np.cumsum(lengths, out=offsets[1:])
+        self._chunks.append((fields, offsets))
+        self._starts.append(self._starts[-1] + len(lengths))
+
+    def extend(self, other):
+        for fields, offsets in other._chunks:
+            self._chunks.append((fields, offsets))
+            self._starts.append(self._starts[-1] + len(offsets) - 1)
+
+    def __len__(self):
+        return self._starts[-1]
+
+    def _make(self, chunk, j):
+        fields, offsets = self._chunks[chunk]
+        a, b = int(offsets[j]), int(offsets[j + 1])
+        return Episode.from_arrays(*(f[a:b] for f in fields))
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        n = len(self)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError(i)
+        chunk = int(np.searchsorted(self._starts, i, side='right')) - 1
+        return self._make(chunk, i - self._starts[chunk])
+
+    def __iter__(self):
+        for chunk, (_, offsets) in enumerate(self._chunks):
+            for j in range(len(offsets) - 1):
+                yield self._make(chunk, j)
+
+    def lengths(self):
+        """Number of steps of every episode, int64 [len(self)]."""
+        return np.concatenate([np.diff(o) for _, o in self._chunks]) if self._chunks else np.zeros(0, dtype=np.int64)
+
+
 class ReplayBuffer(object):
     """Finished episodes + the target construction of the MuZero learner (``make_target``): K unrolled
     steps, n-step value targets bootstrapped from the stored root values."""
@@ -84,11 +133,17 @@ class ReplayBuffer(object):
 class MuZeroSelfPlay(object):
 
     def __init__(self, net, env, n_sims=50, discount=0.997, temperature=1.0, root_dirichlet_alpha=0.25,
-                 root_exploration_fraction=0.25, seed=0, pb_c_base=19652.0, pb_c_init=1.25, use_graph=True, fused=None):
+                 root_exploration_fraction=0.25, seed=0, pb_c_base=19652.0, pb_c_init=1.25, use_graph=True, fused=None,
+                 fused_moves=None, moves_per_launch=8):
         """``fused``: run the whole search of a move in ONE kernel launch (csrc/rz_muzero.hip k_mz_search: the model is
-        evaluated inside the kernel, weights and 64 games per workgroup resident in LDS); None = whenever the model fits
-        it (hidden size 64, <= 8 actions).  Otherwise one hipGraph of ~15 launches per simulation (tree kernels +
-        PyTorch-ROCm layers)."""
+        evaluated inside the kernel on the matrix pipe, 16 games per workgroup, trees in LDS); None = whenever the model
+        fits it (hidden size 64, <= 8 actions).  Otherwise one hipGraph of ~15 launches per simulation (tree kernels +
+        PyTorch-ROCm layers).
+        ``fused_moves``: whole MOVES in one launch (the MOVES stages of k_mz_search: initial inference, root noise, search,
+        action draw, environment step; ``moves_per_launch`` of them per launch) -- the host only reads one packed record
+        per environment and move, a chunk behind the GPU.  None = whenever ``fused`` holds and the environment is a
+        CartPoleBatch (the environment step is device code).  Its random draws (root noise, actions) come from the
+        kernel's counter-based stream keyed (seed, environment, episode, step), not from the torch generator."""
         import torch
         from .tree import MuZeroTree
         self.torch = torch
@@ -124,15 +179,29 @@ class MuZeroSelfPlay(object):
         # every search starts by re-initialising its roots).  Weight updates are in place: the graph stays valid.
         self.fused = (net.hidden == 64 and self.n_actions <= 8) if fused is None else bool(fused)
         self._model_seen = None
+        from .cartpole import CartPoleBatch
+        can_fuse_moves = self.fused and isinstance(env, CartPoleBatch) and net.obs_dim == 4 and self.n_actions == 2
+        self.fused_moves = can_fuse_moves if fused_moves is None else bool(fused_moves)
+        if self.fused_moves and not can_fuse_moves:
+            raise ValueError('fused_moves needs the fused search and a CartPoleBatch environment')
+        self.moves_per_launch = max(1, int(moves_per_launch))
+        self.noise_seed = int(seed)
+        self._records = None  # fused moves: [device records, pinned host copy, event] x 2 (double buffer)
         if self.fused:
             use_graph = False
             self._refresh_model()
         self.search_events = None  # bench.py: HIP events around the fused search launches
         self._graph = None
         self.sim_events = None
-        self.sim_step_label = ('k_mz_search (the whole %d-simulation search of a move in one launch: select, recurrent '
-                               'inference on LDS-resident weights, expand + backup)' % self.n_sims) if self.fused else \
-            'MuZero simulation step (k_mz_select + torch recurrent inference + k_mz_expand_backup, one hipGraph)'
+        if self.fused_moves:
+            self.sim_step_label = ('k_mz_search with its MOVES stages (whole moves in one launch: initial inference, root noise, '
+                                   '%d simulations -- select, recurrent inference on the matrix pipe, expand + backup -- action draw, '
+                                   'CartPole step)' % self.n_sims)
+        elif self.fused:
+            self.sim_step_label = ('k_mz_search (the whole %d-simulation search of a move in one launch: select, recurrent '
+                                   'inference on the matrix pipe with register-resident weights, expand + backup)' % self.n_sims)
+        else:
+            self.sim_step_label = 'MuZero simulation step (k_mz_select + torch recurrent inference + k_mz_expand_backup, one hipGraph)'
         if use_graph:
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
@@ -151,6 +220,8 @@ class MuZeroSelfPlay(object):
         seen = tuple((p.data_ptr(), p._version) for p in self.net.parameters())
         if seen != self._model_seen:
             self.tree.load_model(self.net)
+            if self.fused_moves:
+                self.tree.load_representation(self.net)
             self._model_seen = seen
 
     def _sim_step(self):
@@ -230,16 +301,25 @@ class MuZeroSelfPlay(object):
     # ------------------------------------------------------------------ game loop
     def play_move(self):
         """One move of every environment; returns the episodes that ended with it."""
+        if self.fused_moves:
+            return self._collect_fused(1)
         t = self.torch
         obs = self.obs
         visits, root_value = self.search(obs)
         actions = self.select_actions(visits)
         nxt_obs, reward, terminated, truncated = self.env.step(actions)
         # everything the host keeps of this move in ONE device-to-host copy: [obs | action | reward | visits | root value | done]
-        D, A = obs.shape[1], self.n_actions
         packed = t.cat((obs.to(t.float64), actions.to(t.float64)[:, None], reward.to(t.float64)[:, None],
                         visits.to(t.float64), root_value.to(t.float64)[:, None],
                         (terminated | truncated).to(t.float64)[:, None]), dim=1).cpu().numpy()
+        finished = self._ingest(packed)
+        self.obs = nxt_obs
+        return finished
+
+    def _ingest(self, packed):
+        """The host's part of a move: one packed record per environment (float64 [n, obs | action | reward | visits |
+        root value | done]) into the history rings; -> the episodes that ended with this move."""
+        D, A = self.net.obs_dim, self.n_actions
         slot = self._t % self.HIST
         self._h_obs[slot] = packed[:, :D]
         self._h_act[slot] = packed[:, D].astype(np.int64)
@@ -249,27 +329,79 @@ class MuZeroSelfPlay(object):
         self._h_val[slot] = packed[:, D + 2 + A]
         done_h = packed[:, D + 3 + A] != 0.0
         self._t += 1
-        finished = []
+        finished = EpisodeSeq()
         ended = np.nonzero(done_h)[0]
         if len(ended):
-            # all episodes that ended with this move in ONE gather per field, then split by length
+            # all episodes that ended with this move in ONE gather per field; an Episode is cut out when it is read
             lengths = self._t - self._ep_start[ended]
             env_idx = np.repeat(ended, lengths)
             first = np.repeat(self._ep_start[ended], lengths)
             within = np.arange(int(lengths.sum())) - np.repeat(np.cumsum(lengths) - lengths, lengths)
             step_idx = (first + within) % self.HIST
-            cuts = np.cumsum(lengths)[:-1]
-            fields = [np.split(h[step_idx, env_idx], cuts) for h in (self._h_obs, self._h_act, self._h_rew, self._h_pol, self._h_val)]
-            finished = [Episode.from_arrays(*parts) for parts in zip(*fields)]
+            finished._add(tuple(h[step_idx, env_idx] for h in (self._h_obs, self._h_act, self._h_rew, self._h_pol, self._h_val)),
+                          lengths)
             self._ep_start[ended] = self._t
-        self.obs = nxt_obs
         self.moves_done += self.n_envs
         return finished
 
+    # ------------------------------------------------------------------ whole moves on the device
+    def _launch_moves(self, n_moves, buf):
+        """Enqueue ``n_moves`` moves of every environment (one launch) and the copy of their records to the host."""
+        t = self.torch
+        dev, host, event = buf
+        with t.no_grad():
+            self._refresh_model()
+            ev = None
+            if self.search_events is not None:
+                ev = (t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True), n_moves)
+                ev[0].record()
+            self.tree.play_cartpole(self.hidden, self.n_sims, n_moves, self.env, self.noise_seed, self.noise_frac, self.alpha,
+                                    self.temperature, dev)
+            if ev is not None:
+                ev[1].record()
+                self.search_events.append(ev)
+            host[:n_moves].copy_(dev[:n_moves], non_blocking=True)
+            event.record()
+        self.sims_done += self.n_sims * self.n_envs * n_moves
+
+    def _collect_fused(self, n_moves):
+        """``n_moves`` moves in launches of ``moves_per_launch``; the records of a launch are read while the next one
+        runs (the environments, their episode counters and the random streams live on the device: a launch needs
+        nothing from the host)."""
+        t = self.torch
+        if self._records is None:
+            row = self.net.obs_dim + 4 + self.n_actions
+            shape = (self.moves_per_launch, self.n_envs, row)
+            self._records = [(t.zeros(shape, dtype=t.float64, device=self.device),
+                              t.zeros(shape, dtype=t.float64).pin_memory(), t.cuda.Event()) for _ in range(2)]
+        finished = EpisodeSeq()
+        pending = None  # (buffer, moves in it)
+        left, which = int(n_moves), 0
+        while left > 0 or pending is not None:
+            launched = None
+            if left > 0:
+                k = min(left, self.moves_per_launch)
+                self._launch_moves(k, self._records[which])
+                launched = (self._records[which], k)
+                left -= k
+                which ^= 1
+            if pending is not None:
+                (_, host, event), k = pending
+                event.synchronize()
+                rec = host.numpy()
+                for i in range(k):
+                    finished.extend(self._ingest(rec[i]))
+            pending = launched
+        return finished
+
     def collect(self, n_moves):
-        """``n_moves`` moves of every environment -> list of finished episodes."""
-        out = []
-        for _ in range(n_moves):
-            out.extend(self.play_move())
+        """``n_moves`` moves of every environment -> the finished episodes (an EpisodeSeq: len / iteration / indexing)."""
+        if self.fused_moves:
+            out = self._collect_fused(n_moves)
+            self.obs = self.env.observe()
+        else:
+            out = EpisodeSeq()
+            for _ in range(n_moves):
+                out.extend(self.play_move())
         self.tree.check()
         return out

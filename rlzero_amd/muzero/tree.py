@@ -56,6 +56,27 @@ class MuZeroTree(object):
         ptrs = (ctypes.c_void_p * 14)(*[a.ctypes.data for a in arrays])
         check(self.lib.rz_mz_load_model(self.handle, ptrs, 14, int(net.hidden)), 'rz_mz_load_model')
 
+    REPRESENTATION_PARAMS = ('rep1.weight', 'rep1.bias', 'rep2.weight', 'rep2.bias')
+
+    def load_representation(self, net):
+        """Upload the representation layers h(o) of a MuZeroNet (for ``play_cartpole``); call again after every
+        optimiser step, like ``load_model``."""
+        sd = net.state_dict()
+        arrays = [sd[name].detach().to('cpu', self.torch.float32).contiguous().numpy() for name in self.REPRESENTATION_PARAMS]
+        ptrs = (ctypes.c_void_p * 4)(*[a.ctypes.data for a in arrays])
+        check(self.lib.rz_mz_load_representation(self.handle, ptrs, 4, int(net.obs_dim), int(net.hidden)),
+              'rz_mz_load_representation')
+
+    def play_cartpole(self, hidden, n_sims, n_moves, env, noise_seed, noise_frac, alpha, temperature, records):
+        """``n_moves`` whole moves of the CartPoleBatch ``env`` in ONE launch (k_mz_search, MOVES stages): initial
+        inference, root noise, ``n_sims`` simulations, action from the visit counts, environment step -- per move one
+        record per environment in ``records`` float64 [n_moves, G, 8 + A] (device):
+        observation (4) | action | reward | visits (A) | root value | done."""
+        check(self.lib.rz_mz_play_cartpole(self.handle, _ptr(hidden), int(n_sims), int(n_moves), _ptr(env.state), _ptr(env.steps),
+                                           _ptr(env.episode_dev), int(env.seed) & (2 ** 64 - 1), int(noise_seed) & (2 ** 64 - 1),
+                                           float(noise_frac), float(alpha), float(temperature), _ptr(records), self.stream()),
+              'rz_mz_play_cartpole')
+
     def set_search_shape(self, games_per_workgroup=0):
         """Games per workgroup of ``search_fused`` (<= 16; 0 = chosen from the number of games and CUs)."""
         check(self.lib.rz_mz_set_search_shape(self.handle, int(games_per_workgroup)), 'rz_mz_set_search_shape')

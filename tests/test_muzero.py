@@ -235,6 +235,90 @@ def test_cartpole_batch_vs_scalar_restatement():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('fused_moves', [True, False])
+def test_muzero_selfplay_paths_agree_on_what_a_move_is(fused_moves):
+    """Whole moves inside the kernel (rz_mz_play_cartpole) against the host-driven loop: the records of both follow the
+    scalar CartPole restatement under the recorded actions (observations, resets, done flags), every search spends its
+    simulations, and at temperature 0 the action is the arg-max of the visit counts."""
+    import torch
+    from rlzero_amd.muzero import CartPoleBatch, MuZeroNet, MuZeroSelfPlay
+    from rlzero_amd.muzero.cartpole import initial_states
+    torch.manual_seed(5)
+    net = MuZeroNet().to('cuda:0').eval()
+    G, n_moves = 40, 30
+    env = CartPoleBatch(G, 'cuda:0', seed=11)
+    sp = MuZeroSelfPlay(net, env, n_sims=25, seed=4, temperature=0.0, fused_moves=fused_moves, moves_per_launch=7)
+    assert sp.fused and sp.fused_moves == fused_moves
+    episodes = sp.collect(n_moves)
+    assert sp.sims_done == G * n_moves * 25 and sp.moves_done == G * n_moves and sp._t == n_moves
+    refs, episode = [], np.zeros(G, dtype=np.int64)
+    for i in range(G):
+        r = ref.RefCartPole()
+        r.reset(initial_states(11, [i], [0])[0])
+        refs.append(r)
+    ended = 0
+    for t in range(n_moves):
+        slot = t % sp.HIST
+        for i in range(G):
+            want_obs = np.array(refs[i].state, dtype=np.float64).astype(np.float32)
+            assert np.max(np.abs(sp._h_obs[slot, i] - want_obs)) < 1e-6, (t, i)
+            pol = sp._h_pol[slot, i]
+            action = int(sp._h_act[slot, i])
+            assert abs(pol.sum() - 1.0) < 1e-6 and np.all(np.round(pol * 25) == pol * 25)   # visit counts / 25
+            assert pol[action] == pol.max()                                                  # temperature 0
+            assert sp._h_rew[slot, i] == 1.0 and math.isfinite(sp._h_val[slot, i])
+            state, rew, term, trunc = refs[i].step(action)
+            if term or trunc:
+                ended += 1
+                episode[i] += 1
+                refs[i] = ref.RefCartPole()
+                refs[i].reset(initial_states(11, [i], [episode[i]])[0])
+    assert ended == len(episodes) > 0 and np.array_equal(env.episode, episode)
+    final = env.state.cpu().numpy()
+    for i in range(G):
+        assert np.max(np.abs(final[i] - np.array(refs[i].state))) < 1e-9
+    assert sum(len(ep) for ep in episodes) == int(sum(sp._ep_start))
+    sp.tree.check()
+    sp.close()
+
+
+@pytest.mark.gpu
+def test_fused_moves_search_agrees_with_the_traced_search_and_noise_is_dirichlet():
+    """(a) noise off: the searches inside rz_mz_play_cartpole start from the kernel's own initial inference (matrix
+    pipe) instead of torch's, so visit counts agree with MuZeroSelfPlay.search on the same observations except where a
+    last-bit difference flips a near-tie; (b) noise weight 1: the root priors ARE the kernel's Dirichlet(alpha) draw:
+    mean 1/2, variance 1 / (4 (2 alpha + 1))."""
+    import torch
+    from rlzero_amd.muzero import CartPoleBatch, MuZeroNet, MuZeroSelfPlay
+    torch.manual_seed(6)
+    net = MuZeroNet().to('cuda:0').eval()
+    G = 512
+    env = CartPoleBatch(G, 'cuda:0', seed=21)
+    sp = MuZeroSelfPlay(net, env, n_sims=30, seed=8, root_exploration_fraction=0.0, fused_moves=True, moves_per_launch=1)
+    obs = env.observe().clone()
+    visits_host, value_host = sp.search(obs, add_noise=False)   # torch initial inference + fused search
+    visits_host, value_host = visits_host.cpu().numpy(), value_host.cpu().numpy()
+    sp.collect(1)
+    slot = 0
+    visits_dev = np.round(sp._h_pol[slot].astype(np.float64) * 30).astype(np.int64)
+    assert (visits_dev.sum(axis=1) == 30).all()
+    same = (visits_dev == visits_host).all(axis=1)
+    assert same.mean() >= 0.9, same.mean()
+    assert np.max(np.abs(sp._h_val[slot][same] - value_host[same])) < 1e-4
+    sp.close()
+    for alpha in (0.25, 1.5):
+        env = CartPoleBatch(4096, 'cuda:0', seed=22)
+        sp = MuZeroSelfPlay(net, env, n_sims=2, seed=9, root_dirichlet_alpha=alpha, root_exploration_fraction=1.0,
+                            fused_moves=True, moves_per_launch=1)
+        sp.collect(1)
+        pri = sp.tree.root_children('prior').cpu().numpy()
+        assert np.max(np.abs(pri.sum(axis=1) - 1.0)) < 1e-6 and (pri >= 0).all()
+        want_var = 1.0 / (4.0 * (2.0 * alpha + 1.0))
+        assert abs(pri[:, 0].mean() - 0.5) < 0.03 and abs(pri[:, 0].var() - want_var) < 0.1 * want_var + 0.004, (alpha, pri[:, 0].var())
+        sp.close()
+
+
+@pytest.mark.gpu
 def test_muzero_selfplay_and_learner_smoke():
     import torch
     from rlzero_amd.muzero import CartPoleBatch, MuZeroAgent, MuZeroSelfPlay, ReplayBuffer

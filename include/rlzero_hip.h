@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 19
+#define RZ_ABI_VERSION 20
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 #define RZ_MAX_IN_FLIGHT 16 /* rz_config.sims_in_flight */
@@ -419,17 +419,35 @@ int rz_mz_search(rz_muzero *e, float *d_hidden, int32_t n_sims, int32_t *d_trace
 int rz_mz_set_search_shape(rz_muzero *e, int32_t games_per_workgroup);
 /* Whole MOVES of CartPole-v1 environments in one launch (k_mz_search with its MOVES stages): per move the initial
  * inference h(o) -> s0, f(s0) -> root priors (+ Dirichlet(alpha) noise, weight noise_frac), n_sims simulations, the action
- * drawn from visits ^ (1 / temperature) (arg-max at temperature <= 0), one packed record and the environment step with
+ * drawn from visits ^ (1 / temperature) (arg-max at temperature <= 0), one record and the environment step with
  * auto-reset.  rz_mz_load_representation: HOST pointers to rep1.weight [64][obs_dim], rep1.bias, rep2.weight [64][64],
- * rep2.bias (torch layout), beside rz_mz_load_model.  d_state float64 [n_games][4] (x, x_dot, theta, theta_dot), d_steps /
- * d_episode int64 [n_games]: the environments, updated in place (initial states of an episode: the counter-based stream
- * of rlzero_amd/muzero/cartpole.py keyed (env_seed, environment, episode)); d_records float64 [n_moves][n_games][8 + A]:
- * observation before the move (4) | action | reward | visit counts (A) | root value | done.  Random draws come from a
- * counter-based stream keyed (noise_seed, environment, episode, step). */
+ * rep2.bias (torch layout), beside rz_mz_load_model.
+ * The environments: d_state float64 [n_games][4] (x, x_dot, theta, theta_dot), d_steps / d_episode int64 [n_games], updated
+ * in place (initial states of an episode: the counter-based stream of rlzero_amd/muzero/cartpole.py keyed (env_seed,
+ * environment, episode)).  Random draws come from a counter-based stream keyed (noise_seed, environment, episode, step).
+ * The history stays on the device: a record is 8 + A float64 -- observation before the move (4) | action | reward | visit
+ * counts (A) | root value | done; every move's record goes to d_ring [n_games][ring_steps][8 + A] at step % ring_steps
+ * (global step index = first_step + move of the launch; ring_steps >= 500 + n_moves), d_episode_start int64 [n_games]
+ * holds the step at which the running episode began.  When an episode ENDS its records are copied, as one contiguous run,
+ * to d_arena [arena_rows][8 + A] and (environment, end step, length, first arena row) is appended to d_entries int64
+ * [max_entries][4] -- the host reads finished episodes, not moves.  d_counters int64 [4], zeroed by the caller before the
+ * launch: [0] arena rows claimed, [1] entries, [2] episodes that did not fit into the arena (their entry has row -1:
+ * read them from d_ring). */
+typedef struct rz_mz_cartpole_play {
+    double *d_state;
+    int64_t *d_steps, *d_episode, *d_episode_start;
+    uint64_t env_seed, noise_seed;
+    double noise_frac, dirichlet_alpha, temperature;
+    double *d_ring;
+    int32_t ring_steps, reserved;
+    int64_t first_step;
+    double *d_arena;
+    int64_t arena_rows;
+    int64_t *d_counters, *d_entries;
+    int64_t max_entries;
+} rz_mz_cartpole_play;
 int rz_mz_load_representation(rz_muzero *e, const float *const *h_params, int32_t n_params, int32_t obs_dim, int32_t hidden);
-int rz_mz_play_cartpole(rz_muzero *e, float *d_hidden, int32_t n_sims, int32_t n_moves, double *d_state, int64_t *d_steps,
-                        int64_t *d_episode, uint64_t env_seed, uint64_t noise_seed, double noise_frac, double dirichlet_alpha,
-                        double temperature, double *d_records, void *stream);
+int rz_mz_play_cartpole(rz_muzero *e, float *d_hidden, int32_t n_sims, int32_t n_moves, const rz_mz_cartpole_play *play, void *stream);
 /* One step of n_envs CartPole-v1 environments (gymnasium classic_control/cartpole.py: Euler, tau 0.02, 500-step limit)
  * with auto-reset, in ONE launch: d_obs float32 [n_envs][4] = the observation AFTER the step (after the reset for a
  * finished environment), d_reward float32, d_terminated / d_truncated uint8. */

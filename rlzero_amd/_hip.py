@@ -8,7 +8,7 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64,
                     c_void_p)
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
 MAX_IN_FLIGHT = 16
@@ -44,6 +44,15 @@ class RzMzConfig(Structure):
     _fields_ = [('abi_version', c_int32), ('n_games', c_int32), ('n_actions', c_int32), ('n_sims', c_int32),
                 ('discount', c_double), ('pb_c_base', c_double), ('pb_c_init', c_double),
                 ('device', c_int32), ('reserved', c_int32)]
+
+
+class RzMzCartPolePlay(Structure):
+    """rz_mz_cartpole_play: environments, random streams and the device-side history of rz_mz_play_cartpole."""
+    _fields_ = [('d_state', c_void_p), ('d_steps', c_void_p), ('d_episode', c_void_p), ('d_episode_start', c_void_p),
+                ('env_seed', c_uint64), ('noise_seed', c_uint64), ('noise_frac', c_double), ('dirichlet_alpha', c_double),
+                ('temperature', c_double), ('d_ring', c_void_p), ('ring_steps', c_int32), ('reserved', c_int32),
+                ('first_step', c_int64), ('d_arena', c_void_p), ('arena_rows', c_int64), ('d_counters', c_void_p),
+                ('d_entries', c_void_p), ('max_entries', c_int64)]
 
 
 class RzRawHeads(Structure):
@@ -119,7 +128,7 @@ _SIGNATURES = {
     'rz_mz_search': (c_int, [P, P, c_int32, P, P, P, P, P, P, P]),
     'rz_mz_set_search_shape': (c_int, [P, c_int32]),
     'rz_mz_load_representation': (c_int, [P, POINTER(c_void_p), c_int32, c_int32, c_int32]),
-    'rz_mz_play_cartpole': (c_int, [P, P, c_int32, c_int32, P, P, P, c_uint64, c_uint64, c_double, c_double, c_double, P, P]),
+    'rz_mz_play_cartpole': (c_int, [P, P, c_int32, c_int32, POINTER(RzMzCartPolePlay), P]),
     'rz_cartpole_step': (c_int, [P, P, P, P, c_int32, c_uint64, P, P, P, P, P]),
     'rz_mz_root_children': (c_int, [P, c_int32, P, P]),
     'rz_mz_root_stats': (c_int, [P, P, P, P, P, P]),

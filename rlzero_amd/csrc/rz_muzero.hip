@@ -334,6 +334,195 @@ __device__ __forceinline__ float mz_gamma(float alpha, uint32_t key) {
 //     (representation + prediction on the same tiles), root expansion with Dirichlet noise, the n_sims simulations,
 //     the action drawn from the visit counts, one packed record for the host and the environment step: the host's
 //     part of self-play shrinks to reading the records.
+//   * TREE_LDS trees use their own record: MzHot (N, first_child, value_sum, prior and q = reward + discount * value(),
+//     refreshed by the backup that changes it, so the walk does not divide value_sum / N again at every visit) plus one
+//     float of reward per node; sqrt(N) of the walk comes from a table filled with the same IEEE sqrt.  Same operations on
+//     the same operands as mz_descend / mz_grow_backup: same bits (tests: fused search == step-by-step == CPython).
+struct __attribute__((aligned(16))) MzHot {
+    int32_t N, first_child;
+    double value_sum, prior, q;
+};
+static_assert(sizeof(MzHot) == 32, "MzHot layout");
+
+// N IEEE fp64 divisions x[i] / y[i] with their dependent chains INTERLEAVED: a division is a chain of 11 dependent fp64
+// operations (~200 cycles for a wave, however few lanes are active), and the compiler emits one chain after the other.
+// The operations are exactly those of its own expansion of `x / y` (v_div_scale x 2, v_rcp, the Newton steps,
+// v_div_fmas, v_div_fixup): same bits.
+template <int N>
+__device__ __forceinline__ void mz_divide(const double (&x)[N], const double (&y)[N], double (&out)[N]) {
+    double d[N], ns[N], r[N], e[N], m[N];
+    bool flag[N], unused;
+#pragma unroll
+    for (int i = 0; i < N; ++i) d[i] = __builtin_amdgcn_div_scale(x[i], y[i], false, &unused);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = __builtin_amdgcn_rcp(d[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = __builtin_fma(-d[i], r[i], 1.0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = __builtin_fma(r[i], e[i], r[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = __builtin_fma(-d[i], r[i], 1.0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) ns[i] = __builtin_amdgcn_div_scale(x[i], y[i], true, &flag[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = __builtin_fma(r[i], e[i], r[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) m[i] = ns[i] * r[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) e[i] = __builtin_fma(-d[i], m[i], ns[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) m[i] = __builtin_amdgcn_div_fmas(e[i], r[i], m[i], flag[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = __builtin_amdgcn_div_fixup(m[i], y[i], x[i]);
+}
+
+// the value of lane l ^ 1 / l ^ 2 (DPP quad_perm: one VALU move per dword)
+__device__ __forceinline__ int mz_quad_xor1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ int mz_quad_xor2(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true); }
+template <int WHICH>
+__device__ __forceinline__ double mz_quad_xor(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = (int)b, hi = (int)(b >> 32);
+    const int olo = WHICH == 1 ? mz_quad_xor1(lo) : mz_quad_xor2(lo), ohi = WHICH == 1 ? mz_quad_xor1(hi) : mz_quad_xor2(hi);
+    return __longlong_as_double(((long long)ohi << 32) | (unsigned int)olo);
+}
+
+// mz_descend on the MzHot trees with the FOUR lanes of a quad walking one tree together: lane `ca` of the quad scores
+// the children ca, ca + 4, .. of a level (one child each up to 4 actions: the two divisions of a score are the walk's
+// long operations), the quad then takes the best (score, action) -- larger action on a tie, as the sequential scan --
+// and all four lanes step down together.  Every lane returns the same (depth, parent, action, leaf).
+template <typename HotP, typename PathP, typename TabP>
+__device__ __forceinline__ int mz_descend_hot(const MzDev &E, HotP hot, PathP path, TabP pb_log, TabP sq_tab, double lo, double hi,
+                                              int ca, int &par_out, int &act_out, int &leaf_out) {
+    int node = 0, depth = 0, last_action = 0, par = 0;
+    path[0] = 0;
+    int fc = hot[0].first_child, pn = hot[0].N;
+    const bool ranged = hi > lo;   // MinMaxStats.normalize
+    const double divisor = ranged ? hi - lo : 1.0;
+    while (fc >= 0 && depth + 1 < E.path_stride) {
+        const int idx = pn <= E.n_sims + 1 ? pn : E.n_sims + 1;
+        const double pb_c0 = pb_log[idx] + E.pb_c_init;
+        const double sq = pn <= E.n_sims + 1 ? sq_tab[idx] : sqrt((double)pn);
+        double best = -INFINITY;
+        int besta = -1, best_fc = -1, best_n = 0;
+        for (int a = ca; a < E.n_actions; a += 4) {
+            const MzHot ch = hot[fc + a];
+            // (both divisions of a score are issued unconditionally and interleaved; what MinMaxStats.normalize would not
+            // divide is picked afterwards)
+            const double num[2] = {sq, ch.q - lo}, den[2] = {(double)(ch.N + 1), divisor};
+            double quo[2];
+#ifdef MZ_ABL_NODIV
+            quo[0] = num[0] * den[0];
+            quo[1] = num[1] * den[1];
+#else
+            mz_divide<2>(num, den, quo);
+#endif
+            const double pb_c = pb_c0 * quo[0];
+            const double prior_score = pb_c * ch.prior;
+            const double score = prior_score + (ch.N > 0 ? (ranged ? quo[1] : ch.q) : 0.0);
+            if (score >= best) {  // the later (larger) action wins a tie
+                best = score;
+                besta = a;
+                best_fc = ch.first_child;
+                best_n = ch.N;
+            }
+        }
+#ifndef MZ_ABL_NODPP
+        {   // best of the quad
+            double ob = mz_quad_xor<1>(best);
+            int oa = mz_quad_xor1(besta), ofc = mz_quad_xor1(best_fc), on = mz_quad_xor1(best_n);
+            bool take = ob > best || (ob == best && oa > besta);
+            best = take ? ob : best;
+            besta = take ? oa : besta;
+            best_fc = take ? ofc : best_fc;
+            best_n = take ? on : best_n;
+            ob = mz_quad_xor<2>(best);
+            oa = mz_quad_xor2(besta);
+            ofc = mz_quad_xor2(best_fc);
+            on = mz_quad_xor2(best_n);
+            take = ob > best || (ob == best && oa > besta);
+            besta = take ? oa : besta;
+            best_fc = take ? ofc : best_fc;
+            best_n = take ? on : best_n;
+        }
+#else
+        besta = besta < 0 ? 0 : besta;
+#endif
+        par = node;
+        last_action = besta;
+        node = fc + besta;
+        fc = best_fc;
+        pn = best_n;
+        depth += 1;
+        path[depth] = node;
+    }
+    par_out = par;
+    act_out = last_action;
+    leaf_out = node;
+    return depth;
+}
+
+// expand + backup on the MzHot trees; the backup takes four levels of the path at a time: their loads, the four
+// value_sum / N divisions (issued for all four, used where the level exists) and the stores are independent, only
+// v = reward + discount * v chains through them
+template <int MAXA, typename HotP, typename RewP, typename PathP>
+__device__ __forceinline__ void mz_grow_backup_hot(const MzDev &E, HotP hot, RewP rew, PathP path, int spare, int depth, int &top,
+                                                   double &lo, double &hi, float reward_g, const float *probs, float value_g) {
+    const int leaf = path[depth];
+    if (top + E.n_actions > E.cap) {
+        atomicOr(E.err, RZ_FLAG_ARENA_FULL);
+    } else {
+        rew[leaf] = reward_g;
+        hot[leaf].first_child = top;
+#pragma unroll
+        for (int a = 0; a < MAXA; ++a) {
+            if (a < E.n_actions) {
+                hot[top + a] = MzHot{0, -1, 0.0, (double)probs[a], 0.0};
+                rew[top + a] = 0.0f;
+            }
+        }
+        top += E.n_actions;
+    }
+    // a chunk is straight-line code, so that its four division chains overlap: a level above the root is played on
+    // the spare record `spare` (slot index relative to `hot` / `rew`; its contents are never read for a result)
+    double v = (double)value_g;
+    for (int d = depth; d >= 0; d -= 4) {
+        int slot[4], nn[4];
+        double vs[4], r[4], vv[4], sum[4], nv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) slot[i] = d - i >= 0 ? path[d - i >= 0 ? d - i : 0] : spare;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            vs[i] = hot[slot[i]].value_sum;
+            nn[i] = hot[slot[i]].N + 1;
+            r[i] = (double)rew[slot[i]];
+        }
+        vv[0] = v;
+        vv[1] = r[0] + E.discount * vv[0];
+        vv[2] = r[1] + E.discount * vv[1];
+        vv[3] = r[2] + E.discount * vv[2];
+        v = r[3] + E.discount * vv[3];
+        double den[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool real = d - i >= 0;
+            sum[i] = real ? vs[i] + vv[i] : 0.0;
+            nn[i] = real ? nn[i] : 1;
+            den[i] = (double)nn[i];
+        }
+        mz_divide<4>(sum, den, nv);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool real = d - i >= 0;
+            hot[slot[i]].value_sum = sum[i];
+            hot[slot[i]].N = real ? nn[i] : 0;
+            hot[slot[i]].q = r[i] + E.discount * nv[i];
+            hi = real && nv[i] > hi ? nv[i] : hi;  // MinMaxStats.update
+            lo = real && nv[i] < lo ? nv[i] : lo;
+        }
+    }
+}
+
 constexpr int kMzH = 64, kMzWaves = 4, kMzMaxA = 8, kMzTile = 16, kMzKX = kMzH + kMzMaxA, kMzMaxGpw = 16, kMzObs = 8;
 constexpr int kMzRedRows = 4 + kMzMaxA;   // min, max, reward, value, logits
 constexpr int kMzHeadRows = 2 + kMzMaxA;  // rew2, val, pol rows
@@ -356,7 +545,19 @@ struct MzPlay {         // rz_mz_play_cartpole
     unsigned long long env_seed, noise_seed;
     double noise_frac, inv_temperature;     // inv_temperature <= 0: arg-max of the visit counts
     float alpha;
-    double *out;                            // [n_moves][G][row]: obs (4) | action | reward | visits (A) | root value | done
+    // history on the device: every move's record -- obs (4) | action | reward | visits (A) | root value | done -- goes
+    // to ring[environment][step % hist]; when an episode ends, its records are copied into `arena` as one contiguous
+    // run and (environment, end step, length, first arena row) is appended to `entries`: the host reads finished
+    // episodes, not moves
+    double *ring;                           // [G][hist][row]
+    int hist;
+    long long t0;                           // global step index of the first move of this launch
+    long long *ep_start;                    // [G]: step index where the running episode of an environment began
+    double *arena;                          // [arena_rows][row]
+    long long arena_rows;
+    long long *counters;                    // [0] arena rows claimed, [1] entries, [2] episodes that did not fit (row -1)
+    long long *entries;                     // [max_entries][4]
+    long long max_entries;
 };
 
 // LDS of k_mz_search in bytes: activations, reductions, head weights, per-game scalars, paths, log table (+ the trees)
@@ -366,8 +567,8 @@ __host__ __device__ inline int mz_search_fixed_floats() {
 __host__ __device__ inline int mz_search_lds_bytes(int gpw, int cap, int path_stride, int n_sims_cfg, bool tree_lds) {
     int bytes = mz_search_fixed_floats() * 4 + gpw * path_stride * 4;
     bytes = (bytes + 15) / 16 * 16;
-    bytes += ((n_sims_cfg + 2) * 8 + 15) / 16 * 16;
-    if (tree_lds) bytes += gpw * cap * (int)sizeof(MzNode);
+    bytes += 2 * (((n_sims_cfg + 2) * 8 + 15) / 16 * 16);   // log and sqrt tables
+    if (tree_lds) bytes += gpw * (cap + 1) * (int)sizeof(MzHot) + (gpw * (cap + 1) * 4 + 15) / 16 * 16;   // records (+ a spare per game) + rewards
     return bytes;
 }
 
@@ -389,24 +590,34 @@ __device__ __forceinline__ mz_f32x4 mz_tile(const float (&a)[STEPS], const float
 }
 
 // sum over the 4 lanes that hold the rows of one game (q = 0 .. 3): every lane ends with the same bits
-__device__ __forceinline__ float mz_rowsum(float x) {
-    x += __shfl_xor(x, 16);
-    x += __shfl_xor(x, 32);
+// the value of lane l ^ 16 / l ^ 32 (gfx950 v_permlane16_swap / v_permlane32_swap: two VALU operations instead of a trip
+// through the LDS crossbar)
+__device__ __forceinline__ float mz_xor16(float x, int l) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float((l & 16) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float mz_xor32(float x, int l) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float((l & 32) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float mz_rowsum(float x, int l) {
+    x += mz_xor16(x, l);
+    x += mz_xor32(x, l);
     return x;
 }
 
 // dot product of the 4 rows a lane holds (16w + 4q .. +3) with a head's weights, summed over the wave's 16 rows
-__device__ __forceinline__ float mz_head_partial(const mz_f32x4 &p, const float *head_row, int w, int q) {
+__device__ __forceinline__ float mz_head_partial(const mz_f32x4 &p, const float *head_row, int w, int q, int l) {
     const float4 wv = *reinterpret_cast<const float4 *>(head_row + 16 * w + 4 * q);
     float s = p[0] * wv.x;
     s = fmaf(p[1], wv.y, s);
     s = fmaf(p[2], wv.z, s);
     s = fmaf(p[3], wv.w, s);
-    return mz_rowsum(s);
+    return mz_rowsum(s, l);
 }
 
 template <bool TREE_LDS, bool MOVES>
-__global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M, float *hidden, int n_sims, int gpw, MzTrace T, MzPlay P) {
+__global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel M, float *hidden, int n_sims, int gpw, MzTrace T, MzPlay P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mz_lds[];
     const int A = E.n_actions, KX = kMzH + A;
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, n = l & 15, q = l >> 4;
@@ -420,9 +631,13 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
     int *Gleaf = reinterpret_cast<int *>(OBS + kMzObs * kMzTile);   // [16]
     int32_t *PATH = Gleaf + 16;                      // [gpw][path_stride]
     unsigned char *pp = mz_lds + (mz_search_fixed_floats() * 4 + gpw * E.path_stride * 4 + 15) / 16 * 16;
-    double *PBL = reinterpret_cast<double *>(pp);    // [n_sims + 2]
+    double *PBL = reinterpret_cast<double *>(pp);    // [n_sims + 2]: the host's log table
     pp += ((E.n_sims + 2) * 8 + 15) / 16 * 16;
-    MzNode *TREE = reinterpret_cast<MzNode *>(pp);   // [gpw][cap] (TREE_LDS)
+    double *SQT = reinterpret_cast<double *>(pp);    // [n_sims + 2]: sqrt(n)
+    pp += ((E.n_sims + 2) * 8 + 15) / 16 * 16;
+    const int tcap = E.cap + 1;                      // slots per game in LDS: the tree + one spare record (mz_grow_backup_hot)
+    MzHot *TREE = reinterpret_cast<MzHot *>(pp);     // [gpw][tcap] (TREE_LDS)
+    float *REW = reinterpret_cast<float *>(pp + gpw * tcap * (int)sizeof(MzHot));   // [gpw][tcap] rewards (TREE_LDS)
 
     // ---- once: weight fragments into registers (A operand of 16x16x4: lane holds W[unit 16w + n][k = 4s + q])
     float a1[kMzKX / 4], a2[kMzH / 4], ar[kMzH / 4], ap[kMzH / 4], arep1[kMzObs / 4], arep2[kMzH / 4];
@@ -466,17 +681,26 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
     }
     for (int i = tid; i < kMzKX * kMzTile; i += 64 * kMzWaves) XS[i] = 0.0f;   // (the padding rows 64 + A .. 71 stay zero)
     for (int i = tid; i < kMzObs * kMzTile; i += 64 * kMzWaves) OBS[i] = 0.0f;
-    for (int i = tid; i < E.n_sims + 2; i += 64 * kMzWaves) PBL[i] = E.pb_log[i];
+    for (int i = tid; i < E.n_sims + 2; i += 64 * kMzWaves) {
+        PBL[i] = E.pb_log[i];
+        SQT[i] = sqrt((double)i);
+    }
     // the trees of this workgroup's games
-    const bool mine = w == 0 && l < gpw && g0 + l < E.n_games;   // this lane walks the tree of game g0 + l
-    const int g = g0 + (l < gpw ? l : 0);
+    // wave 0 walks the trees: the four lanes of quad `ge` own game g0 + ge together -- they score different children in
+    // the walk and otherwise run the same tree code on the same values (same LDS words, same bits); `lead` writes to HBM
+    const int ge = l >> 2, ca = l & 3;
+    const bool mine = w == 0 && ge < gpw && g0 + ge < E.n_games;
+    const bool lead = mine && ca == 0;
+    const int g = g0 + (ge < gpw ? ge : 0);
     const bool live_n = n < gpw && g0 + n < E.n_games;           // column n of the tiles is a game
     int top = 0, depth = 0;
     double lo = 0.0, hi = 0.0;
     MzCartPole env = {0.0, 0.0, 0.0, 0.0, 0, 0};
+    long long ep_start = 0;
     if (mine) {
         if (MOVES) {
             env = MzCartPole{P.state[4 * g], P.state[4 * g + 1], P.state[4 * g + 2], P.state[4 * g + 3], P.steps[g], P.episode[g]};
+            ep_start = P.ep_start[g];
         } else {
             top = E.top[g];
             lo = E.vmin[g];
@@ -484,22 +708,27 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
         }
     }
     if (TREE_LDS && !MOVES) {
-        const int per_game = E.cap * (int)(sizeof(MzNode) / 16);   // uint4 words
         for (int ee = 0; ee < gpw && g0 + ee < E.n_games; ++ee) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(E.nodes + (long long)(g0 + ee) * E.cap);
-            uint4 *dst = reinterpret_cast<uint4 *>(TREE + ee * E.cap);
-            const int used = E.top[g0 + ee] * (int)(sizeof(MzNode) / 16);
-            for (int i = tid; i < used && i < per_game; i += 64 * kMzWaves) dst[i] = src[i];
+            const MzNode *src = E.nodes + (long long)(g0 + ee) * E.cap;
+            const int used = E.top[g0 + ee] < E.cap ? E.top[g0 + ee] : E.cap;
+            for (int i = tid; i < used; i += 64 * kMzWaves) {
+                const MzNode nd = src[i];
+                TREE[ee * tcap + i] = MzHot{nd.N, nd.first_child, nd.value_sum, nd.prior,
+                                            nd.N > 0 ? (double)nd.reward + E.discount * node_value(nd) : 0.0};
+                REW[ee * tcap + i] = nd.reward;
+            }
         }
     }
-    MzNode *nodes = TREE_LDS ? TREE + (l < gpw ? l : 0) * E.cap : E.nodes + (long long)g * E.cap;
-    int32_t *path = PATH + (l < gpw ? l : 0) * E.path_stride;
+    MzNode *nodes = E.nodes + (long long)g * E.cap;                 // (!TREE_LDS)
+    MzHot *hot = TREE + (ge < gpw ? ge : 0) * tcap;                 // (TREE_LDS)
+    float *rew = REW + (ge < gpw ? ge : 0) * tcap;
+    int32_t *path = PATH + (ge < gpw ? ge : 0) * E.path_stride;
     __syncthreads();
     if (MOVES && mine) {   // (after the zero fill of OBS)
-        OBS[0 * kMzTile + l] = (float)env.x;
-        OBS[1 * kMzTile + l] = (float)env.x_dot;
-        OBS[2 * kMzTile + l] = (float)env.theta;
-        OBS[3 * kMzTile + l] = (float)env.theta_dot;
+        OBS[0 * kMzTile + ge] = (float)env.x;
+        OBS[1 * kMzTile + ge] = (float)env.x_dot;
+        OBS[2 * kMzTile + ge] = (float)env.theta;
+        OBS[3 * kMzTile + ge] = (float)env.theta_dot;
     }
 
     // ---- the pieces the initial inference and a simulation share
@@ -526,10 +755,10 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
     };
     auto wave_extremes = [&](const mz_f32x4 &t) {
         float mn = fminf(fminf(t[0], t[1]), fminf(t[2], t[3])), mx = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3]));
-        mn = fminf(mn, __shfl_xor(mn, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mn = fminf(mn, __shfl_xor(mn, 32));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mn = fminf(mn, mz_xor16(mn, l));
+        mx = fmaxf(mx, mz_xor16(mx, l));
+        mn = fminf(mn, mz_xor32(mn, l));
+        mx = fmaxf(mx, mz_xor32(mx, l));
         if (q == 0) {
             RED[(0 * kMzWaves + w) * kMzTile + n] = mn;
             RED[(1 * kMzWaves + w) * kMzTile + n] = mx;
@@ -540,12 +769,12 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
         mz_f32x4 p = mz_tile(ap, XS, q, n, bp);
 #pragma unroll
         for (int i = 0; i < 4; ++i) p[i] = fmaxf(p[i], 0.0f);
-        const float pv = mz_head_partial(p, HW + 1 * kMzH, w, q);
+        const float pv = mz_head_partial(p, HW + 1 * kMzH, w, q, l);
         if (q == 0) RED[(3 * kMzWaves + w) * kMzTile + n] = pv;
 #pragma unroll
         for (int a = 0; a < kMzMaxA; ++a) {
             if (a < A) {
-                const float pl = mz_head_partial(p, HW + (2 + a) * kMzH, w, q);
+                const float pl = mz_head_partial(p, HW + (2 + a) * kMzH, w, q, l);
                 if (q == 0) RED[((4 + a) * kMzWaves + w) * kMzTile + n] = pl;
             }
         }
@@ -554,7 +783,7 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
     auto finish_prediction = [&](float &value, float (&probs)[kMzMaxA]) {
         value = HB[1];
 #pragma unroll
-        for (int u = 0; u < kMzWaves; ++u) value += RED[(3 * kMzWaves + u) * kMzTile + n];
+        for (int u = 0; u < kMzWaves; ++u) value += RED[(3 * kMzWaves + u) * kMzTile + ge];
         float logit[kMzMaxA], mxl = -INFINITY;
 #pragma unroll
         for (int a = 0; a < kMzMaxA; ++a) {
@@ -562,7 +791,7 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
             if (a < A) {
                 float x = HB[2 + a];
 #pragma unroll
-                for (int u = 0; u < kMzWaves; ++u) x += RED[((4 + a) * kMzWaves + u) * kMzTile + n];
+                for (int u = 0; u < kMzWaves; ++u) x += RED[((4 + a) * kMzWaves + u) * kMzTile + ge];
                 logit[a] = x;
                 mxl = fmaxf(mxl, x);
             }
@@ -612,13 +841,23 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
                         gam[a] = a < A ? mz_gamma(P.alpha, (uint32_t)(key >> 32) + 0x9E3779B9u * (uint32_t)(a + 1) + (uint32_t)key) : 0.0f;
                         gsum += gam[a];
                     }
-                    nodes[0] = MzNode{0, 1, 0.0, 0.0, 0.0f, 0};
+                    if (TREE_LDS) {
+                        hot[0] = MzHot{0, 1, 0.0, 0.0, 0.0};
+                        rew[0] = 0.0f;
+                    } else {
+                        nodes[0] = MzNode{0, 1, 0.0, 0.0, 0.0f, 0};
+                    }
 #pragma unroll
                     for (int a = 0; a < kMzMaxA; ++a) {
                         if (a < A) {
                             double pr = (double)probs[a];
                             if (P.noise_frac > 0.0) pr = pr * (1.0 - P.noise_frac) + ((double)gam[a] / (double)gsum) * P.noise_frac;
-                            nodes[1 + a] = MzNode{0, -1, 0.0, pr, 0.0f, 0};
+                            if (TREE_LDS) {
+                                hot[1 + a] = MzHot{0, -1, 0.0, pr, 0.0};
+                                rew[1 + a] = 0.0f;
+                            } else {
+                                nodes[1 + a] = MzNode{0, -1, 0.0, pr, 0.0f, 0};
+                            }
                         }
                     }
                     top = 1 + A;
@@ -627,18 +866,27 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
                     depth = 0;
                 }
             }
+            MZ_TICK(13);
         }
     for (int sim = 0; sim < n_sims; ++sim) {
         // S0 (wave 0): select, one lane per game; then the gather of the parents' hidden states into XS[k][game]
         // (lane -> game l / 4, four 16-byte pieces of its 256-byte row) and the one-hot action rows
         int par = 0, act = 0, lf = 0;
         if (w == 0) {
-            if (mine) depth = mz_descend(E, nodes, path, PBL, lo, hi, par, act, lf);
+            if (mine)
+                depth = TREE_LDS ? mz_descend_hot(E, hot, path, PBL, SQT, lo, hi, ca, par, act, lf)
+                                 : mz_descend(E, nodes, path, PBL, lo, hi, par, act, lf);
             MZ_TICK(0);
-            if (l < kMzTile) Gleaf[l] = lf;
-            const int ee = l >> 2;
-            const int pe = __shfl(par, ee);
-            const bool live_e = ee < gpw && g0 + ee < E.n_games;
+#ifdef RZ_MZ_PROFILE
+            {   // the wave walks as long as its deepest game
+                int md = mine ? depth : 0;
+                for (int off = 32; off >= 1; off >>= 1) md = max(md, __shfl_xor(md, off));
+                prof_acc[15] += md;
+            }
+#endif
+            if (ca == 0) Gleaf[ge] = lf;
+            const int ee = ge, pe = par;   // (the quad of a game also gathers its parent's state: 4 x 64 bytes per lane)
+            const bool live_e = mine;
             const float4 *src = reinterpret_cast<const float4 *>(hidden + ((long long)(g0 + (live_e ? ee : 0)) * E.cap + pe) * kMzH);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -649,7 +897,7 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
                 XS[(4 * c + 2) * kMzTile + ee] = v.z;
                 XS[(4 * c + 3) * kMzTile + ee] = v.w;
             }
-            const int an = __shfl(act, n);
+            const int an = __shfl(act, 4 * n);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int a = q + 4 * j;
@@ -681,7 +929,7 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
             wave_extremes(t);
 #pragma unroll
             for (int i = 0; i < 4; ++i) r[i] = fmaxf(r[i], 0.0f);
-            const float pr = mz_head_partial(r, HW, w, q);
+            const float pr = mz_head_partial(r, HW, w, q, l);
             if (q == 0) RED[(2 * kMzWaves + w) * kMzTile + n] = pr;
         }
         MZ_TICK(5);
@@ -701,12 +949,12 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
         if (w == 0) {
             float reward = HB[0];
 #pragma unroll
-            for (int u = 0; u < kMzWaves; ++u) reward += RED[(2 * kMzWaves + u) * kMzTile + n];
+            for (int u = 0; u < kMzWaves; ++u) reward += RED[(2 * kMzWaves + u) * kMzTile + ge];
             float value, probs[kMzMaxA];
             finish_prediction(value, probs);
             MZ_TICK(11);
             if (mine) {
-                if (!MOVES && T.reward != nullptr) {
+                if (!MOVES && lead && T.reward != nullptr) {
                     const long long o = (long long)sim * E.n_games + g;
                     T.parent[o] = par;
                     T.action[o] = act;
@@ -717,7 +965,8 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
                     for (int a = 0; a < kMzMaxA; ++a)
                         if (a < A) T.probs[o * A + a] = probs[a];
                 }
-                mz_grow_backup<kMzMaxA>(E, nodes, path, depth, top, lo, hi, reward, probs, value);
+                if (TREE_LDS) mz_grow_backup_hot<kMzMaxA>(E, hot, rew, path, E.cap, depth, top, lo, hi, reward, probs, value);
+                else mz_grow_backup<kMzMaxA>(E, nodes, path, depth, top, lo, hi, reward, probs, value);
             }
             MZ_TICK(12);
         }
@@ -730,7 +979,7 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
             int visits[kMzMaxA], arg = 0;
 #pragma unroll
             for (int a = 0; a < kMzMaxA; ++a) {
-                visits[a] = a < A ? nodes[1 + a].N : 0;
+                visits[a] = a < A ? (TREE_LDS ? hot[1 + a].N : nodes[1 + a].N) : 0;
                 wgt[a] = 0.0;
                 if (a < A) {
                     wgt[a] = P.inv_temperature == 1.0 || P.inv_temperature <= 0.0 ? (double)visits[a] : pow((double)visits[a], P.inv_temperature);
@@ -760,35 +1009,81 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
                     }
                 }
             }
-            const MzNode root = nodes[0];
-            double *rec = P.out + ((long long)move * E.n_games + g) * P.row;
-            rec[0] = (double)(float)env.x;   // the observation the search started from
-            rec[1] = (double)(float)env.x_dot;
-            rec[2] = (double)(float)env.theta;
-            rec[3] = (double)(float)env.theta_dot;
-            rec[4] = (double)action;
-            rec[5] = 1.0;
+            const double root_sum = TREE_LDS ? hot[0].value_sum : nodes[0].value_sum;
+            const int root_n = TREE_LDS ? hot[0].N : nodes[0].N;
+            const long long t = P.t0 + move;
+            double *ring_g = P.ring + (long long)g * P.hist * P.row;
+            double *rec = ring_g + (t % P.hist) * P.row;
+            double last[8 + kMzMaxA];
+            last[0] = (double)(float)env.x;   // the observation the search started from
+            last[1] = (double)(float)env.x_dot;
+            last[2] = (double)(float)env.theta;
+            last[3] = (double)(float)env.theta_dot;
+            last[4] = (double)action;
+            last[5] = 1.0;
 #pragma unroll
-            for (int a = 0; a < kMzMaxA; ++a)
-                if (a < A) rec[6 + a] = (double)visits[a];
-            rec[6 + A] = root.value_sum / (double)(root.N > 1 ? root.N : 1);
+            for (int a = 0; a < kMzMaxA; ++a) last[6 + a] = (double)visits[a];
+            const double root_value = root_sum / (double)(root_n > 1 ? root_n : 1);
             const int done = cartpole_step(env, action);
-            rec[7 + A] = done ? 1.0 : 0.0;
+            if (lead) {
+#pragma unroll
+                for (int c = 0; c < 6 + kMzMaxA; ++c)
+                    if (c < 6 + A) rec[c] = last[c];
+                rec[6 + A] = root_value;
+                rec[7 + A] = done ? 1.0 : 0.0;
+            }
             if (done) {
+                // the episode's records as one run in the arena: the quad copies the earlier moves from the ring, the
+                // lead adds this move's from its registers
+                const long long len = t + 1 - ep_start;
+                long long off = -1;
+                if (lead) {
+                    off = (long long)atomicAdd(reinterpret_cast<unsigned long long *>(P.counters), (unsigned long long)len);
+                    if (off + len > P.arena_rows) {
+                        off = -1;
+                        atomicAdd(reinterpret_cast<unsigned long long *>(P.counters + 2), 1ull);
+                    }
+                    const long long e = (long long)atomicAdd(reinterpret_cast<unsigned long long *>(P.counters + 1), 1ull);
+                    if (e < P.max_entries) {
+                        P.entries[4 * e + 0] = g;
+                        P.entries[4 * e + 1] = t + 1;
+                        P.entries[4 * e + 2] = len;
+                        P.entries[4 * e + 3] = off;
+                    }
+                }
+                off = __shfl(off, l & ~3);
+                if (off >= 0) {
+                    for (long long j = ca; j < len - 1; j += 4) {
+                        const double *src = ring_g + ((ep_start + j) % P.hist) * P.row;
+                        double *dst = P.arena + (off + j) * P.row;
+                        for (int c = 0; c < P.row; ++c)
+                            dst[c] = __hip_atomic_load(src + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (past the L1: written by other launches / moves)
+                    }
+                    if (lead) {
+                        double *dst = P.arena + (off + len - 1) * P.row;
+#pragma unroll
+                        for (int c = 0; c < 6 + kMzMaxA; ++c)
+                            if (c < 6 + A) dst[c] = last[c];
+                        dst[6 + A] = root_value;
+                        dst[7 + A] = 1.0;
+                    }
+                }
+                ep_start = t + 1;
                 env.episode += 1;
                 cartpole_reset(env, P.env_seed, g);
             }
-            OBS[0 * kMzTile + l] = (float)env.x;
-            OBS[1 * kMzTile + l] = (float)env.x_dot;
-            OBS[2 * kMzTile + l] = (float)env.theta;
-            OBS[3 * kMzTile + l] = (float)env.theta_dot;
+            OBS[0 * kMzTile + ge] = (float)env.x;
+            OBS[1 * kMzTile + ge] = (float)env.x_dot;
+            OBS[2 * kMzTile + ge] = (float)env.theta;
+            OBS[3 * kMzTile + ge] = (float)env.theta_dot;
         }
+        MZ_TICK(14);
     }
 #ifdef RZ_MZ_PROFILE
     if (blockIdx.x == 0 && tid == 0)
         for (int i = 0; i < 16; ++i) mz_prof[i] = prof_acc[i];
 #endif
-    if (mine) {
+    if (lead) {
         E.top[g] = top;
         E.vmin[g] = lo;
         E.vmax[g] = hi;
@@ -800,17 +1095,20 @@ __global__ __launch_bounds__(64 * kMzWaves) void k_mz_search(MzDev E, MzModel M,
             P.state[4 * g + 3] = env.theta_dot;
             P.steps[g] = env.steps;
             P.episode[g] = env.episode;
+            P.ep_start[g] = ep_start;
         }
     }
     if (TREE_LDS) {
         __syncthreads();
-        if (w == 0 && l < kMzTile) Gleaf[l] = top;   // (every wave needs the final tops)
+        if (w == 0 && ca == 0) Gleaf[ge] = top;   // (every wave needs the final tops)
         __syncthreads();
         for (int ee = 0; ee < gpw && g0 + ee < E.n_games; ++ee) {
-            uint4 *dst = reinterpret_cast<uint4 *>(E.nodes + (long long)(g0 + ee) * E.cap);
-            const uint4 *src = reinterpret_cast<const uint4 *>(TREE + ee * E.cap);
-            const int used = Gleaf[ee] * (int)(sizeof(MzNode) / 16);
-            for (int i = tid; i < used; i += 64 * kMzWaves) dst[i] = src[i];
+            MzNode *dst = E.nodes + (long long)(g0 + ee) * E.cap;
+            const int used = Gleaf[ee];
+            for (int i = tid; i < used; i += 64 * kMzWaves) {
+                const MzHot h = TREE[ee * tcap + i];
+                dst[i] = MzNode{h.N, h.first_child, h.value_sum, h.prior, REW[ee * tcap + i], 0};
+            }
         }
     }
 }
@@ -1126,30 +1424,41 @@ int rz_mz_search(rz_muzero *e, float *d_hidden, int32_t n_sims, int32_t *d_trace
     return mz_launch_search(e, d_hidden, n_sims, T, nullptr, stream);
 }
 
-int rz_mz_play_cartpole(rz_muzero *e, float *d_hidden, int32_t n_sims, int32_t n_moves, double *d_state, int64_t *d_steps,
-                        int64_t *d_episode, uint64_t env_seed, uint64_t noise_seed, double noise_frac, double dirichlet_alpha,
-                        double temperature, double *d_records, void *stream) {
+int rz_mz_play_cartpole(rz_muzero *e, float *d_hidden, int32_t n_sims, int32_t n_moves, const rz_mz_cartpole_play *play, void *stream) {
     int rc = mz_ready(e);
     if (rc != RZ_OK) return rc;
     if (!e->model_loaded || !e->representation_loaded) return mz_fail(RZ_ERR_ARG, "rz_mz_load_model and rz_mz_load_representation first");
     if (e->cfg.n_actions != 2) return mz_fail(RZ_ERR_ARG, "CartPole has 2 actions");
-    if (d_hidden == nullptr || n_sims < 1 || n_sims > e->cfg.n_sims || n_moves < 1) return mz_fail(RZ_ERR_ARG, "d_hidden is NULL or n_sims / n_moves out of range");
-    if (!d_state || !d_steps || !d_episode || !d_records) return mz_fail(RZ_ERR_ARG, "NULL environment / record pointer");
-    if (!(dirichlet_alpha > 0.0) || noise_frac < 0.0 || noise_frac > 1.0) return mz_fail(RZ_ERR_ARG, "dirichlet_alpha must be > 0, noise_frac in [0, 1]");
-    MzPlay play = {};
-    play.n_moves = n_moves;
-    play.row = 4 + 4 + e->cfg.n_actions;
-    play.state = d_state;
-    play.steps = reinterpret_cast<long long *>(d_steps);
-    play.episode = reinterpret_cast<long long *>(d_episode);
-    play.env_seed = env_seed;
-    play.noise_seed = noise_seed;
-    play.noise_frac = noise_frac;
-    play.inv_temperature = temperature > 0.0 ? 1.0 / temperature : 0.0;
-    play.alpha = (float)dirichlet_alpha;
-    play.out = d_records;
+    if (d_hidden == nullptr || play == nullptr || n_sims < 1 || n_sims > e->cfg.n_sims || n_moves < 1)
+        return mz_fail(RZ_ERR_ARG, "NULL pointer or n_sims / n_moves out of range");
+    if (!play->d_state || !play->d_steps || !play->d_episode || !play->d_episode_start || !play->d_ring || !play->d_arena ||
+        !play->d_counters || !play->d_entries)
+        return mz_fail(RZ_ERR_ARG, "NULL environment / history pointer");
+    if (play->ring_steps < 500 + n_moves || play->arena_rows < 1 || play->max_entries < (int64_t)e->cfg.n_games * n_moves || play->first_step < 0)
+        return mz_fail(RZ_ERR_ARG, "ring_steps must cover an episode (500 steps) + the launch, max_entries one entry per environment and move");
+    if (!(play->dirichlet_alpha > 0.0) || play->noise_frac < 0.0 || play->noise_frac > 1.0) return mz_fail(RZ_ERR_ARG, "dirichlet_alpha must be > 0, noise_frac in [0, 1]");
+    MzPlay p = {};
+    p.n_moves = n_moves;
+    p.row = 4 + 4 + e->cfg.n_actions;
+    p.state = play->d_state;
+    p.steps = reinterpret_cast<long long *>(play->d_steps);
+    p.episode = reinterpret_cast<long long *>(play->d_episode);
+    p.env_seed = play->env_seed;
+    p.noise_seed = play->noise_seed;
+    p.noise_frac = play->noise_frac;
+    p.inv_temperature = play->temperature > 0.0 ? 1.0 / play->temperature : 0.0;
+    p.alpha = (float)play->dirichlet_alpha;
+    p.ring = play->d_ring;
+    p.hist = play->ring_steps;
+    p.t0 = play->first_step;
+    p.ep_start = reinterpret_cast<long long *>(play->d_episode_start);
+    p.arena = play->d_arena;
+    p.arena_rows = play->arena_rows;
+    p.counters = reinterpret_cast<long long *>(play->d_counters);
+    p.entries = reinterpret_cast<long long *>(play->d_entries);
+    p.max_entries = play->max_entries;
     const MzTrace T = {};
-    return mz_launch_search(e, d_hidden, n_sims, T, &play, stream);
+    return mz_launch_search(e, d_hidden, n_sims, T, &p, stream);
 }
 
 int rz_cartpole_step(double *d_state, int64_t *d_steps, int64_t *d_episode, const int64_t *d_actions, int32_t n_envs, uint64_t seed,

@@ -29,30 +29,32 @@ class Episode(object):
 
 class EpisodeSeq(object):
     """The episodes that ended during a stretch of self-play, as a sequence: the steps of all of them lie in a few flat
-    arrays (one gather per field and move) and an ``Episode`` -- views into those arrays -- is made when it is asked for.
+    arrays (one block per stretch) and an ``Episode`` -- views into those arrays -- is made when it is asked for.
     With thousands of environments hundreds of episodes end per move: building them eagerly was the host's largest cost."""
 
     def __init__(self):
-        self._chunks = []   # (fields tuple of flat arrays, offsets int64 [n + 1])
+        self._chunks = []   # (fields tuple of flat arrays, first row int64 [n], lengths int64 [n])
         self._starts = [0]  # index of the first episode of every chunk (+ the total)
 
-    def _add(self, fields, lengths):
-        offsets = np.zeros(len(lengths) + 1, dtype=np.int64)
-        np.cumsum(lengths, out=offsets[1:])
-        self._chunks.append((fields, offsets))
+    def _add(self, fields, lengths, first_rows=None):
+        lengths = np.asarray(lengths, dtype=np.int64)
+        if first_rows is None:  # the episodes lie one behind the other
+            first_rows = np.cumsum(lengths) - lengths
+        self._chunks.append((fields, np.asarray(first_rows, dtype=np.int64), lengths))
         self._starts.append(self._starts[-1] + len(lengths))
 
     def extend(self, other):
-        for fields, offsets in other._chunks:
-            self._chunks.append((fields, offsets))
-            self._starts.append(self._starts[-1] + len(offsets) - 1)
+        for chunk in other._chunks:
+            self._chunks.append(chunk)
+            self._starts.append(self._starts[-1] + len(chunk[2]))
 
     def __len__(self):
         return self._starts[-1]
 
     def _make(self, chunk, j):
-        fields, offsets = self._chunks[chunk]
-        a, b = int(offsets[j]), int(offsets[j + 1])
+        fields, first_rows, lengths = self._chunks[chunk]
+        a = int(first_rows[j])
+        b = a + int(lengths[j])
         return Episode.from_arrays(*(f[a:b] for f in fields))
 
     def __getitem__(self, i):
@@ -67,13 +69,13 @@ class EpisodeSeq(object):
         return self._make(chunk, i - self._starts[chunk])
 
     def __iter__(self):
-        for chunk, (_, offsets) in enumerate(self._chunks):
-            for j in range(len(offsets) - 1):
+        for chunk, (_, _, lengths) in enumerate(self._chunks):
+            for j in range(len(lengths)):
                 yield self._make(chunk, j)
 
     def lengths(self):
         """Number of steps of every episode, int64 [len(self)]."""
-        return np.concatenate([np.diff(o) for _, o in self._chunks]) if self._chunks else np.zeros(0, dtype=np.int64)
+        return np.concatenate([c[2] for c in self._chunks]) if self._chunks else np.zeros(0, dtype=np.int64)
 
 
 class ReplayBuffer(object):
@@ -134,7 +136,7 @@ class MuZeroSelfPlay(object):
 
     def __init__(self, net, env, n_sims=50, discount=0.997, temperature=1.0, root_dirichlet_alpha=0.25,
                  root_exploration_fraction=0.25, seed=0, pb_c_base=19652.0, pb_c_init=1.25, use_graph=True, fused=None,
-                 fused_moves=None, moves_per_launch=8):
+                 fused_moves=None, moves_per_launch=16):
         """``fused``: run the whole search of a move in ONE kernel launch (csrc/rz_muzero.hip k_mz_search: the model is
         evaluated inside the kernel on the matrix pipe, 16 games per workgroup, trees in LDS); None = whenever the model
         fits it (hidden size 64, <= 8 actions).  Otherwise one hipGraph of ~15 launches per simulation (tree kernels +
@@ -159,15 +161,11 @@ class MuZeroSelfPlay(object):
         self.rows = torch.arange(self.n_envs, device=self.device)
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(int(seed))
-        # step history: rings [step % HIST][environment] on the host; an episode is cut out of them (one fancy index per
+        # step history of the host-driven loop: rings [step % HIST][environment] on the host (allocated at the first
+        # move: the fused moves keep their history on the device); an episode is cut out of them (one fancy index per
         # field) when it ends.  CartPole-v1 truncates at 500 steps, so 512 steps of history always cover an episode.
         self.HIST = max(512, int(getattr(env, 'max_episode_steps', 500)) + 12)
-        G, A = self.n_envs, self.n_actions
-        self._h_obs = np.zeros((self.HIST, G, net.obs_dim), dtype=np.float32)
-        self._h_act = np.zeros((self.HIST, G), dtype=np.int64)
-        self._h_rew = np.zeros((self.HIST, G), dtype=np.float64)
-        self._h_pol = np.zeros((self.HIST, G, A), dtype=np.float32)
-        self._h_val = np.zeros((self.HIST, G), dtype=np.float64)
+        self._h_obs = None
         self._t = 0                                           # global step index of the next move
         self._ep_start = np.zeros(self.n_envs, dtype=np.int64)
         self.sims_done = 0
@@ -316,39 +314,91 @@ class MuZeroSelfPlay(object):
         self.obs = nxt_obs
         return finished
 
-    def _ingest(self, packed):
-        """The host's part of a move: one packed record per environment (float64 [n, obs | action | reward | visits |
-        root value | done]) into the history rings; -> the episodes that ended with this move."""
+    def _ingest(self, rec):
+        """The host's part of self-play: the packed records of K consecutive moves (float64 [K, n, obs | action | reward |
+        visits | root value | done]; [n, row] = one move) into the history rings; -> the episodes that ended during them,
+        in the order of their last move (then environment).  One pass of array operations for the whole stretch: with
+        thousands of environments the per-call overhead of a move-by-move loop was the bottleneck of self-play."""
+        rec = rec[None] if rec.ndim == 2 else rec
+        K = rec.shape[0]
         D, A = self.net.obs_dim, self.n_actions
-        slot = self._t % self.HIST
-        self._h_obs[slot] = packed[:, :D]
-        self._h_act[slot] = packed[:, D].astype(np.int64)
-        self._h_rew[slot] = packed[:, D + 1]
-        vis = packed[:, D + 2:D + 2 + A]
-        self._h_pol[slot] = (vis / vis.sum(axis=1, keepdims=True)).astype(np.float32)
-        self._h_val[slot] = packed[:, D + 2 + A]
-        done_h = packed[:, D + 3 + A] != 0.0
-        self._t += 1
+        if self._h_obs is None:
+            G = self.n_envs
+            self.HIST = max(self.HIST, K + 512)
+            self._h_obs = np.zeros((self.HIST, G, D), dtype=np.float32)
+            self._h_act = np.zeros((self.HIST, G), dtype=np.int64)
+            self._h_rew = np.zeros((self.HIST, G), dtype=np.float64)
+            self._h_pol = np.zeros((self.HIST, G, A), dtype=np.float32)
+            self._h_val = np.zeros((self.HIST, G), dtype=np.float64)
+        t0 = self._t
+        slots = (t0 + np.arange(K)) % self.HIST
+        self._h_obs[slots] = rec[:, :, :D]
+        self._h_act[slots] = rec[:, :, D]
+        self._h_rew[slots] = rec[:, :, D + 1]
+        vis = rec[:, :, D + 2:D + 2 + A]
+        self._h_pol[slots] = vis / vis.sum(axis=2, keepdims=True)
+        self._h_val[slots] = rec[:, :, D + 2 + A]
+        self._t += K
+        self.moves_done += self.n_envs * K
         finished = EpisodeSeq()
-        ended = np.nonzero(done_h)[0]
-        if len(ended):
-            # all episodes that ended with this move in ONE gather per field; an Episode is cut out when it is read
-            lengths = self._t - self._ep_start[ended]
-            env_idx = np.repeat(ended, lengths)
-            first = np.repeat(self._ep_start[ended], lengths)
+        kk, ee = np.nonzero(rec[:, :, D + 3 + A] != 0.0)   # (move, environment) of every episode end, by move then environment
+        if len(kk):
+            end = t0 + kk + 1                                # global step index behind the episode's last move
+            # an environment may finish more than once in the stretch: its later episodes start where the previous ended
+            order = np.lexsort((kk, ee))
+            ee_s, end_s = ee[order], end[order]
+            first = np.ones(len(order), dtype=bool)
+            first[1:] = ee_s[1:] != ee_s[:-1]
+            start_s = np.empty_like(end_s)
+            start_s[first] = self._ep_start[ee_s[first]]
+            start_s[~first] = end_s[:-1][~first[1:]]
+            last = np.ones(len(order), dtype=bool)
+            last[:-1] = first[1:]
+            self._ep_start[ee_s[last]] = end_s[last]
+            start = np.empty_like(start_s)
+            start[order] = start_s
+            # all episodes in ONE gather per field; an Episode is cut out when it is read
+            lengths = end - start
+            env_idx = np.repeat(ee, lengths)
             within = np.arange(int(lengths.sum())) - np.repeat(np.cumsum(lengths) - lengths, lengths)
-            step_idx = (first + within) % self.HIST
+            step_idx = (np.repeat(start, lengths) + within) % self.HIST
             finished._add(tuple(h[step_idx, env_idx] for h in (self._h_obs, self._h_act, self._h_rew, self._h_pol, self._h_val)),
                           lengths)
-            self._ep_start[ended] = self._t
-        self.moves_done += self.n_envs
         return finished
 
     # ------------------------------------------------------------------ whole moves on the device
+    def _fused_state(self):
+        """Device-side history of the fused moves (MuZeroTree.play_cartpole) and the two sets of per-launch buffers."""
+        if self._records is None:
+            t = self.torch
+            G, K = self.n_envs, self.moves_per_launch
+            row = self.net.obs_dim + 4 + self.n_actions
+            kw = dict(device=self.device)
+            steps = int(getattr(self.env, 'max_episode_steps', 500)) + 2 * K + 12
+            self._ring = t.zeros((G, steps, row), dtype=t.float64, **kw)
+            self._ep_start_dev = t.full((G, ), self._t, dtype=t.int64, **kw)
+            # in the steady state a launch ends about as many steps of episodes as it plays (G x K); twice that, plus a
+            # few long episodes, always fits -- what does not is read back from the ring (entry with row -1)
+            rows, n_entries = 2 * G * K + 4 * steps, G * K
+            self._copy_stream = t.cuda.Stream(device=self.device)
+            self._records = []
+            for _ in range(2):
+                dev = (t.zeros(4, dtype=t.int64, **kw), t.zeros((n_entries, 4), dtype=t.int64, **kw),
+                       t.zeros((rows, row), dtype=t.float64, **kw))
+                host = tuple(t.zeros(x.shape, dtype=x.dtype).pin_memory() for x in dev)
+                self._records.append((dev, host, t.cuda.Event()))
+        return self._records
+
+    def device_history(self):
+        """(ring float64 [n_envs, ring_steps, obs | action | reward | visits | root value | done], episode_start int64
+        [n_envs]) of the fused moves as numpy arrays: every move still in the ring, finished or not (tests, debugging)."""
+        self._fused_state()
+        return self._ring.cpu().numpy(), self._ep_start_dev.cpu().numpy()
+
     def _launch_moves(self, n_moves, buf):
-        """Enqueue ``n_moves`` moves of every environment (one launch) and the copy of their records to the host."""
+        """Enqueue ``n_moves`` moves of every environment (one launch) and the copy of what ended during them."""
         t = self.torch
-        dev, host, event = buf
+        (counters, entries, arena), host, event = buf
         with t.no_grad():
             self._refresh_model()
             ev = None
@@ -356,41 +406,71 @@ class MuZeroSelfPlay(object):
                 ev = (t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True), n_moves)
                 ev[0].record()
             self.tree.play_cartpole(self.hidden, self.n_sims, n_moves, self.env, self.noise_seed, self.noise_frac, self.alpha,
-                                    self.temperature, dev)
+                                    self.temperature, (self._ring, self._ep_start_dev), self._t, arena, counters, entries)
             if ev is not None:
                 ev[1].record()
                 self.search_events.append(ev)
-            host[:n_moves].copy_(dev[:n_moves], non_blocking=True)
-            event.record()
+            # the copies run on their own stream: the next launch (other set of buffers) does not wait behind them
+            done = t.cuda.Event()
+            done.record()
+            with t.cuda.stream(self._copy_stream):
+                self._copy_stream.wait_event(done)
+                for h, d in zip(host, (counters, entries, arena)):
+                    h.copy_(d, non_blocking=True)
+                event.record()
+        self._t += n_moves
         self.sims_done += self.n_sims * self.n_envs * n_moves
+        self.moves_done += self.n_envs * n_moves
+
+    def _episodes_of_launch(self, buf):
+        """The finished episodes of a launch from its arena (host copy), ordered by (last move, environment)."""
+        _, (counters, entries, arena), event = buf
+        event.synchronize()
+        D, A = self.net.obs_dim, self.n_actions
+        n_rows, n_entries, missed = (int(v) for v in counters.numpy()[:3])
+        finished = EpisodeSeq()
+        if n_entries == 0:
+            return finished
+        ent = entries.numpy()[:n_entries]
+        ent = ent[np.lexsort((ent[:, 0], ent[:, 1]))]
+        fits = ent[:, 3] >= 0
+
+        def fields_of(block):
+            vis = block[:, D + 2:D + 2 + A]
+            return (block[:, :D].astype(np.float32), block[:, D].astype(np.int64), block[:, D + 1].copy(),
+                    (vis / vis.sum(axis=1, keepdims=True)).astype(np.float32), block[:, D + 2 + A].copy())
+
+        if fits.any():
+            used = min(n_rows, arena.shape[0])
+            finished._add(fields_of(arena.numpy()[:used]), ent[fits, 2], ent[fits, 3])
+        if missed:  # the arena was too small for these: their records are still in the ring
+            t = self.torch
+            env, end, length = (ent[~fits, c] for c in (0, 1, 2))
+            env_idx = np.repeat(env, length)
+            within = np.arange(int(length.sum())) - np.repeat(np.cumsum(length) - length, length)
+            step_idx = (np.repeat(end - length, length) + within) % self._ring.shape[1]
+            block = self._ring[t.from_numpy(env_idx).to(self.device), t.from_numpy(step_idx).to(self.device)].cpu().numpy()
+            finished._add(fields_of(block), length)
+        return finished
 
     def _collect_fused(self, n_moves):
-        """``n_moves`` moves in launches of ``moves_per_launch``; the records of a launch are read while the next one
-        runs (the environments, their episode counters and the random streams live on the device: a launch needs
-        nothing from the host)."""
-        t = self.torch
-        if self._records is None:
-            row = self.net.obs_dim + 4 + self.n_actions
-            shape = (self.moves_per_launch, self.n_envs, row)
-            self._records = [(t.zeros(shape, dtype=t.float64, device=self.device),
-                              t.zeros(shape, dtype=t.float64).pin_memory(), t.cuda.Event()) for _ in range(2)]
+        """``n_moves`` moves in launches of ``moves_per_launch``; what ended during a launch is read while the next one
+        runs (the environments, their histories and the random streams live on the device: a launch needs nothing from
+        the host, and the host reads finished episodes, not moves)."""
+        bufs = self._fused_state()
         finished = EpisodeSeq()
-        pending = None  # (buffer, moves in it)
+        pending = None
         left, which = int(n_moves), 0
         while left > 0 or pending is not None:
             launched = None
             if left > 0:
                 k = min(left, self.moves_per_launch)
-                self._launch_moves(k, self._records[which])
-                launched = (self._records[which], k)
+                self._launch_moves(k, bufs[which])
+                launched = bufs[which]
                 left -= k
                 which ^= 1
             if pending is not None:
-                (_, host, event), k = pending
-                event.synchronize()
-                rec = host.numpy()
-                for i in range(k):
-                    finished.extend(self._ingest(rec[i]))
+                finished.extend(self._episodes_of_launch(pending))
             pending = launched
         return finished
 

@@ -67,14 +67,23 @@ class MuZeroTree(object):
         check(self.lib.rz_mz_load_representation(self.handle, ptrs, 4, int(net.obs_dim), int(net.hidden)),
               'rz_mz_load_representation')
 
-    def play_cartpole(self, hidden, n_sims, n_moves, env, noise_seed, noise_frac, alpha, temperature, records):
+    def play_cartpole(self, hidden, n_sims, n_moves, env, noise_seed, noise_frac, alpha, temperature, history, first_step,
+                      arena, counters, entries):
         """``n_moves`` whole moves of the CartPoleBatch ``env`` in ONE launch (k_mz_search, MOVES stages): initial
-        inference, root noise, ``n_sims`` simulations, action from the visit counts, environment step -- per move one
-        record per environment in ``records`` float64 [n_moves, G, 8 + A] (device):
-        observation (4) | action | reward | visits (A) | root value | done."""
-        check(self.lib.rz_mz_play_cartpole(self.handle, _ptr(hidden), int(n_sims), int(n_moves), _ptr(env.state), _ptr(env.steps),
-                                           _ptr(env.episode_dev), int(env.seed) & (2 ** 64 - 1), int(noise_seed) & (2 ** 64 - 1),
-                                           float(noise_frac), float(alpha), float(temperature), _ptr(records), self.stream()),
+        inference, root noise, ``n_sims`` simulations, action from the visit counts, environment step.  ``history`` =
+        (ring float64 [G, ring_steps, 8 + A], episode_start int64 [G]): every move's record -- observation (4) | action |
+        reward | visits (A) | root value | done -- lands in the ring at step % ring_steps (step = first_step + move); the
+        records of every episode that ENDS are copied as one run into ``arena`` float64 [rows, 8 + A] and described in
+        ``entries`` int64 [n, 4] (environment, end step, length, first arena row or -1); ``counters`` int64 [4] (zeroed
+        here): arena rows claimed, entries, episodes that did not fit."""
+        ring, episode_start = history
+        counters.zero_()
+        play = _hip.RzMzCartPolePlay(
+            env.state.data_ptr(), env.steps.data_ptr(), env.episode_dev.data_ptr(), episode_start.data_ptr(),
+            int(env.seed) & (2 ** 64 - 1), int(noise_seed) & (2 ** 64 - 1), float(noise_frac), float(alpha), float(temperature),
+            ring.data_ptr(), int(ring.shape[1]), 0, int(first_step), arena.data_ptr(), int(arena.shape[0]),
+            counters.data_ptr(), entries.data_ptr(), int(entries.shape[0]))
+        check(self.lib.rz_mz_play_cartpole(self.handle, _ptr(hidden), int(n_sims), int(n_moves), ctypes.byref(play), self.stream()),
               'rz_mz_play_cartpole')
 
     def set_search_shape(self, games_per_workgroup=0):

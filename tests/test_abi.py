@@ -43,6 +43,9 @@ def test_config_struct_layout_matches_header():
     assert ctypes.sizeof(_hip.RzConfig) == 72
     assert _hip.RzConfig.c_puct.offset == 32 and _hip.RzConfig.device.offset == 48
     assert ctypes.sizeof(_hip.RzStats) == 64
+    # rz_mz_cartpole_play: 4 pointers, 2 uint64, 3 doubles, pointer, 2 int32, int64, pointer, int64, 2 pointers, int64
+    assert ctypes.sizeof(_hip.RzMzCartPolePlay) == 136 and _hip.RzMzCartPolePlay.first_step.offset == 88
+    assert _hip.RzMzCartPolePlay.max_entries.offset == 128
 
 
 def test_product_fails_loudly_without_gpu():

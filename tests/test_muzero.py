@@ -106,6 +106,54 @@ def test_initial_states_and_replay_targets():
 
 
 # ------------------------------------------------------------------ HIP tree kernels vs the oracle
+def _fake_selfplay(n_envs, hist=64):
+    """The host-side state MuZeroSelfPlay._ingest works on, without a GPU."""
+    import types
+    fake = types.SimpleNamespace(net=types.SimpleNamespace(obs_dim=4), n_actions=2, n_envs=n_envs, HIST=hist, _t=0, moves_done=0)
+    fake._h_obs = np.zeros((hist, n_envs, 4), dtype=np.float32)
+    fake._h_act = np.zeros((hist, n_envs), dtype=np.int64)
+    fake._h_rew = np.zeros((hist, n_envs), dtype=np.float64)
+    fake._h_pol = np.zeros((hist, n_envs, 2), dtype=np.float32)
+    fake._h_val = np.zeros((hist, n_envs), dtype=np.float64)
+    fake._ep_start = np.zeros(n_envs, dtype=np.int64)
+    return fake
+
+
+def test_ingest_of_a_stretch_of_moves_equals_move_by_move():
+    """The records of K moves ingested in one call (what the fused moves hand over) against the same records one move
+    at a time: same episodes in the same order -- including environments that finish twice inside the stretch and
+    episodes that straddle calls and the wrap of the history ring."""
+    from rlzero_amd.muzero.selfplay import MuZeroSelfPlay
+    rng = np.random.RandomState(3)
+    n_envs, n_moves = 13, 90
+    rec = np.zeros((n_moves, n_envs, 10))
+    rec[:, :, :4] = rng.randn(n_moves, n_envs, 4).astype(np.float32)
+    rec[:, :, 4] = rng.randint(2, size=(n_moves, n_envs))
+    rec[:, :, 5] = 1.0
+    rec[:, :, 6:8] = rng.randint(1, 20, size=(n_moves, n_envs, 2))
+    rec[:, :, 8] = rng.randn(n_moves, n_envs)
+    rec[:, :, 9] = rng.rand(n_moves, n_envs) < 0.3          # short episodes: several ends per environment and stretch
+    one, many = _fake_selfplay(n_envs), _fake_selfplay(n_envs)
+    a = []
+    for t in range(n_moves):
+        a.extend(MuZeroSelfPlay._ingest(one, rec[t]))
+    b = []
+    for lo_, hi_ in ((0, 7), (7, 8), (8, 24), (24, 40), (40, 90)):
+        chunk = MuZeroSelfPlay._ingest(many, rec[lo_:hi_])
+        assert len(chunk) == int(rec[lo_:hi_, :, 9].sum()) == len(chunk.lengths())
+        b.extend(chunk)
+    assert len(a) == len(b) == int(rec[:, :, 9].sum()) and one._t == many._t == n_moves
+    assert np.array_equal(one._ep_start, many._ep_start) and one.moves_done == many.moves_done == n_envs * n_moves
+    for x, y in zip(a, b):
+        assert len(x) == len(y) > 0
+        for f in ('obs', 'actions', 'rewards', 'policies', 'root_values'):
+            assert np.array_equal(getattr(x, f), getattr(y, f)), f
+    first = a[0]   # and an episode is what the records say: the first one ends at the first done flag (move-major order)
+    k0, e0 = np.argwhere(rec[:, :, 9] != 0)[0]
+    assert len(first) == k0 + 1 and np.array_equal(first.obs, rec[:k0 + 1, e0, :4].astype(np.float32))
+    assert np.array_equal(first.actions, rec[:k0 + 1, e0, 4].astype(np.int64))
+
+
 def _hexf(x):
     return float(x).hex()
 
@@ -251,33 +299,53 @@ def test_muzero_selfplay_paths_agree_on_what_a_move_is(fused_moves):
     assert sp.fused and sp.fused_moves == fused_moves
     episodes = sp.collect(n_moves)
     assert sp.sims_done == G * n_moves * 25 and sp.moves_done == G * n_moves and sp._t == n_moves
+    if fused_moves:  # the history is on the device: [environment, step % ring_steps, obs | action | reward | visits | value | done]
+        ring, ep_start = sp.device_history()
+
+        def record(t, i):
+            r = ring[i, t % ring.shape[1]]
+            return r[:4].astype(np.float32), int(r[4]), r[5], (r[6:8] / r[6:8].sum()).astype(np.float32), r[8], bool(r[9])
+    else:
+        ep_start = sp._ep_start
+
+        def record(t, i):
+            slot = t % sp.HIST
+            return sp._h_obs[slot, i], int(sp._h_act[slot, i]), sp._h_rew[slot, i], sp._h_pol[slot, i], sp._h_val[slot, i], None
     refs, episode = [], np.zeros(G, dtype=np.int64)
     for i in range(G):
         r = ref.RefCartPole()
         r.reset(initial_states(11, [i], [0])[0])
         refs.append(r)
-    ended = 0
+    ended, want_episodes = 0, []
+    running = [[] for _ in range(G)]
     for t in range(n_moves):
-        slot = t % sp.HIST
         for i in range(G):
+            obs, action, reward, pol, value, done = record(t, i)
             want_obs = np.array(refs[i].state, dtype=np.float64).astype(np.float32)
-            assert np.max(np.abs(sp._h_obs[slot, i] - want_obs)) < 1e-6, (t, i)
-            pol = sp._h_pol[slot, i]
-            action = int(sp._h_act[slot, i])
+            assert np.max(np.abs(obs - want_obs)) < 1e-6, (t, i)
             assert abs(pol.sum() - 1.0) < 1e-6 and np.all(np.round(pol * 25) == pol * 25)   # visit counts / 25
             assert pol[action] == pol.max()                                                  # temperature 0
-            assert sp._h_rew[slot, i] == 1.0 and math.isfinite(sp._h_val[slot, i])
+            assert reward == 1.0 and math.isfinite(value)
+            running[i].append((obs, action, value))
             state, rew, term, trunc = refs[i].step(action)
+            assert done is None or done == (term or trunc)
             if term or trunc:
                 ended += 1
                 episode[i] += 1
                 refs[i] = ref.RefCartPole()
                 refs[i].reset(initial_states(11, [i], [episode[i]])[0])
+                want_episodes.append(running[i])
+                running[i] = []
     assert ended == len(episodes) > 0 and np.array_equal(env.episode, episode)
+    # the episodes handed out: ordered by (last move, environment), each the run of its environment's records
+    for ep, want in zip(episodes, want_episodes):
+        assert len(ep) == len(want)
+        assert np.array_equal(ep.obs, np.array([w[0] for w in want])) and list(ep.actions) == [w[1] for w in want]
+        assert np.array_equal(ep.root_values, np.array([w[2] for w in want])) and (np.asarray(ep.rewards) == 1.0).all()
     final = env.state.cpu().numpy()
     for i in range(G):
         assert np.max(np.abs(final[i] - np.array(refs[i].state))) < 1e-9
-    assert sum(len(ep) for ep in episodes) == int(sum(sp._ep_start))
+    assert sum(len(ep) for ep in episodes) == int(sum(ep_start))
     sp.tree.check()
     sp.close()
 
@@ -299,12 +367,12 @@ def test_fused_moves_search_agrees_with_the_traced_search_and_noise_is_dirichlet
     visits_host, value_host = sp.search(obs, add_noise=False)   # torch initial inference + fused search
     visits_host, value_host = visits_host.cpu().numpy(), value_host.cpu().numpy()
     sp.collect(1)
-    slot = 0
-    visits_dev = np.round(sp._h_pol[slot].astype(np.float64) * 30).astype(np.int64)
+    ring, _ = sp.device_history()
+    visits_dev = ring[:, 0, 6:8].astype(np.int64)
     assert (visits_dev.sum(axis=1) == 30).all()
     same = (visits_dev == visits_host).all(axis=1)
     assert same.mean() >= 0.9, same.mean()
-    assert np.max(np.abs(sp._h_val[slot][same] - value_host[same])) < 1e-4
+    assert np.max(np.abs(ring[:, 0, 8][same] - value_host[same])) < 1e-4
     sp.close()
     for alpha in (0.25, 1.5):
         env = CartPoleBatch(4096, 'cuda:0', seed=22)

@@ -275,7 +275,8 @@ CONFIG_LEGS = (  # (key, title, flags, seconds of CPU baseline at --cpu-seconds 
      'sequential search; leaf batches of 1024 instead of 64)',
      ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 8, '--warmup', 8, '--in-flight', 16, '--no-cpu-baseline'], 0.0),
     ('C3', 'configs[2] Connect4, 400 sims/move, 512 games', ['--game', 'connect4', '--playouts', 400, '--games', 512, '--lanes', 2, '--steps', 6, '--warmup', 6], 12.0),
-    ('C5', 'configs[4] MuZero CartPole-v1, 50 sims/move, 4096 environments', ['--game', 'muzero', '--playouts', 50, '--games', 4096, '--steps', 16, '--warmup', 40], 12.0),
+    ('C5', 'configs[4] MuZero CartPole-v1, 50 sims/move, 8192 environments (two 16-environment workgroups per CU)',
+     ['--game', 'muzero', '--playouts', 50, '--games', 8192, '--steps', 512, '--warmup', 48], 12.0),
 )
 
 
@@ -400,7 +401,7 @@ def run_muzero(args, rank, world, device, dist, red_device, use_dist=False, cpu_
     the batch), action sampling, environment step."""
     import torch
     from rlzero_amd.muzero import CartPoleBatch, MuZeroNet, MuZeroSelfPlay
-    G = args.games if args.games > 0 else 4096
+    G = args.games if args.games > 0 else 8192
     n_sims = args.playouts if args.playouts != N_PLAYOUT else 50
     torch.manual_seed(0)
     net = MuZeroNet().to(device).eval()

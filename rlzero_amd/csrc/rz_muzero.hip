@@ -338,6 +338,7 @@ __device__ __forceinline__ float mz_gamma(float alpha, uint32_t key) {
 //     refreshed by the backup that changes it, so the walk does not divide value_sum / N again at every visit) plus one
 //     float of reward per node; sqrt(N) of the walk comes from a table filled with the same IEEE sqrt.  Same operations on
 //     the same operands as mz_descend / mz_grow_backup: same bits (tests: fused search == step-by-step == CPython).
+constexpr int kMzHidden = 64;   // floats of a hidden state (= kMzH below)
 struct __attribute__((aligned(16))) MzHot {
     int32_t N, first_child;
     double value_sum, prior, q;
@@ -387,74 +388,127 @@ __device__ __forceinline__ double mz_quad_xor(double x) {
     return __longlong_as_double(((long long)ohi << 32) | (unsigned int)olo);
 }
 
+// the value of lane J of the quad in all four
+template <int J>
+__device__ __forceinline__ double mz_quad_bcast(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, J * 0x55, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), J * 0x55, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Touch a hidden-state row the walk may need next (global_load into a register nobody reads: the line is on its way to
+// L2 / L1 while the walk goes on).  `sink` keeps the destination register reserved until the caller has waited for its
+// vector memory operations (they return in order, and the compiler's own s_waitcnt counts only get stricter).
+__device__ __forceinline__ void mz_touch(const float *p, float &sink) {
+    asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void mz_touch_done(float &sink) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) : : "memory");
+}
+
 // mz_descend on the MzHot trees with the FOUR lanes of a quad walking one tree together: lane `ca` of the quad scores
-// the children ca, ca + 4, .. of a level (one child each up to 4 actions: the two divisions of a score are the walk's
-// long operations), the quad then takes the best (score, action) -- larger action on a tie, as the sequential scan --
-// and all four lanes step down together.  Every lane returns the same (depth, parent, action, leaf).
+// ONE child of a level (the two divisions of a score are the walk's long operations; a single wave issues one
+// instruction every ~5 cycles, so the walk is written for few instructions: straight-line, selects instead of
+// branches), the quad then takes the best (score, action) -- larger action on a tie, as the sequential scan -- and all
+// four lanes step down together.  Up to 2 actions lanes 2, 3 mirror lanes 0, 1 (one exchange); 3 or 4 actions take a
+// second exchange; more fall back to every lane scanning the children ca, ca + 4, ...
+// Every lane returns the same (depth, parent, action, leaf).
 template <typename HotP, typename PathP, typename TabP>
 __device__ __forceinline__ int mz_descend_hot(const MzDev &E, HotP hot, PathP path, TabP pb_log, TabP sq_tab, double lo, double hi,
-                                              int ca, int &par_out, int &act_out, int &leaf_out) {
+                                              int ca, const float *hidden_g, float &sink, int &par_out, int &act_out, int &leaf_out) {
+    const int A = E.n_actions;
     int node = 0, depth = 0, last_action = 0, par = 0;
     path[0] = 0;
     int fc = hot[0].first_child, pn = hot[0].N;
     const bool ranged = hi > lo;   // MinMaxStats.normalize
     const double divisor = ranged ? hi - lo : 1.0;
-    while (fc >= 0 && depth + 1 < E.path_stride) {
-        const int idx = pn <= E.n_sims + 1 ? pn : E.n_sims + 1;
-        const double pb_c0 = pb_log[idx] + E.pb_c_init;
-        const double sq = pn <= E.n_sims + 1 ? sq_tab[idx] : sqrt((double)pn);
-        double best = -INFINITY;
-        int besta = -1, best_fc = -1, best_n = 0;
-        for (int a = ca; a < E.n_actions; a += 4) {
-            const MzHot ch = hot[fc + a];
-            // (both divisions of a score are issued unconditionally and interleaved; what MinMaxStats.normalize would not
-            // divide is picked afterwards)
+    if (A <= 4) {
+        const int my_a = A <= 2 ? (ca & 1) : ca;
+        const bool has_child = my_a < A;
+        const int a_eff = has_child ? my_a : 0;
+        while (fc >= 0 && depth + 1 < E.path_stride) {
+            const MzHot ch = hot[fc + a_eff];
+            const int idx = pn <= E.n_sims + 1 ? pn : E.n_sims + 1;
+            const double pb_c0 = pb_log[idx] + E.pb_c_init;
+            const double sq = pn <= E.n_sims + 1 ? sq_tab[idx] : sqrt((double)pn);
             const double num[2] = {sq, ch.q - lo}, den[2] = {(double)(ch.N + 1), divisor};
             double quo[2];
-#ifdef MZ_ABL_NODIV
-            quo[0] = num[0] * den[0];
-            quo[1] = num[1] * den[1];
-#else
             mz_divide<2>(num, den, quo);
-#endif
-            const double pb_c = pb_c0 * quo[0];
-            const double prior_score = pb_c * ch.prior;
-            const double score = prior_score + (ch.N > 0 ? (ranged ? quo[1] : ch.q) : 0.0);
-            if (score >= best) {  // the later (larger) action wins a tie
-                best = score;
-                besta = a;
-                best_fc = ch.first_child;
-                best_n = ch.N;
+            const double own = pb_c0 * quo[0] * ch.prior + (ch.N > 0 ? (ranged ? quo[1] : ch.q) : 0.0);
+            const double score = has_child ? own : -INFINITY;
+            // the neighbour's child (action my_a ^ 1) wins with a larger score, or the same score and the larger action
+            double ob = mz_quad_xor<1>(score);
+            int ofc = mz_quad_xor1(ch.first_child), on = mz_quad_xor1(ch.N);
+            bool take = ob > score || (ob == score && (my_a & 1) == 0);
+            double best = take ? ob : score;
+            int besta = take ? (my_a ^ 1) : my_a, best_fc = take ? ofc : ch.first_child, best_n = take ? on : ch.N;
+            if (A > 2) {
+                ob = mz_quad_xor<2>(best);
+                const int oa = mz_quad_xor2(besta);
+                ofc = mz_quad_xor2(best_fc);
+                on = mz_quad_xor2(best_n);
+                take = ob > best || (ob == best && oa > besta);
+                besta = take ? oa : besta;
+                best_fc = take ? ofc : best_fc;
+                best_n = take ? on : best_n;
             }
+            par = node;
+            last_action = besta;
+            node = fc + besta;
+            fc = best_fc;
+            pn = best_n;
+            depth += 1;
+            path[depth] = node;
+            // the node stepped into is the parent whose hidden state the gather reads if the walk ends below it: the
+            // quad touches the four 64-byte pieces of its row now (~1 us from the Infinity Cache otherwise)
+            mz_touch(hidden_g + (long long)node * kMzHidden + 16 * ca, sink);
         }
-#ifndef MZ_ABL_NODPP
-        {   // best of the quad
-            double ob = mz_quad_xor<1>(best);
-            int oa = mz_quad_xor1(besta), ofc = mz_quad_xor1(best_fc), on = mz_quad_xor1(best_n);
-            bool take = ob > best || (ob == best && oa > besta);
-            best = take ? ob : best;
-            besta = take ? oa : besta;
-            best_fc = take ? ofc : best_fc;
-            best_n = take ? on : best_n;
-            ob = mz_quad_xor<2>(best);
-            oa = mz_quad_xor2(besta);
-            ofc = mz_quad_xor2(best_fc);
-            on = mz_quad_xor2(best_n);
-            take = ob > best || (ob == best && oa > besta);
-            besta = take ? oa : besta;
-            best_fc = take ? ofc : best_fc;
-            best_n = take ? on : best_n;
+    } else {
+        while (fc >= 0 && depth + 1 < E.path_stride) {
+            const int idx = pn <= E.n_sims + 1 ? pn : E.n_sims + 1;
+            const double pb_c0 = pb_log[idx] + E.pb_c_init;
+            const double sq = pn <= E.n_sims + 1 ? sq_tab[idx] : sqrt((double)pn);
+            double best = -INFINITY;
+            int besta = -1, best_fc = -1, best_n = 0;
+            for (int a = ca; a < A; a += 4) {
+                const MzHot ch = hot[fc + a];
+                const double num[2] = {sq, ch.q - lo}, den[2] = {(double)(ch.N + 1), divisor};
+                double quo[2];
+                mz_divide<2>(num, den, quo);
+                const double score = pb_c0 * quo[0] * ch.prior + (ch.N > 0 ? (ranged ? quo[1] : ch.q) : 0.0);
+                if (score >= best) {  // the later (larger) action wins a tie
+                    best = score;
+                    besta = a;
+                    best_fc = ch.first_child;
+                    best_n = ch.N;
+                }
+            }
+            {   // best of the quad
+                double ob = mz_quad_xor<1>(best);
+                int oa = mz_quad_xor1(besta), ofc = mz_quad_xor1(best_fc), on = mz_quad_xor1(best_n);
+                bool take = ob > best || (ob == best && oa > besta);
+                best = take ? ob : best;
+                besta = take ? oa : besta;
+                best_fc = take ? ofc : best_fc;
+                best_n = take ? on : best_n;
+                ob = mz_quad_xor<2>(best);
+                oa = mz_quad_xor2(besta);
+                ofc = mz_quad_xor2(best_fc);
+                on = mz_quad_xor2(best_n);
+                take = ob > best || (ob == best && oa > besta);
+                besta = take ? oa : besta;
+                best_fc = take ? ofc : best_fc;
+                best_n = take ? on : best_n;
+            }
+            par = node;
+            last_action = besta;
+            node = fc + besta;
+            fc = best_fc;
+            pn = best_n;
+            depth += 1;
+            path[depth] = node;
         }
-#else
-        besta = besta < 0 ? 0 : besta;
-#endif
-        par = node;
-        last_action = besta;
-        node = fc + besta;
-        fc = best_fc;
-        pn = best_n;
-        depth += 1;
-        path[depth] = node;
     }
     par_out = par;
     act_out = last_action;
@@ -462,11 +516,13 @@ __device__ __forceinline__ int mz_descend_hot(const MzDev &E, HotP hot, PathP pa
     return depth;
 }
 
-// expand + backup on the MzHot trees; the backup takes four levels of the path at a time: their loads, the four
-// value_sum / N divisions (issued for all four, used where the level exists) and the stores are independent, only
-// v = reward + discount * v chains through them
+// expand + backup on the MzHot trees, the four lanes of a quad together: the backup takes four levels of the path at a
+// time, lane `ca` the level d - ca (one load of its node, ONE value_sum / N division, one store); only
+// v = reward + discount * v chains through the levels, so every lane runs that short chain on the quad's four rewards.
+// A level above the root is played on the spare record `spare` (slot index relative to `hot` / `rew`; never read for a
+// result).  MinMaxStats takes the quad's extremes (max / min do not depend on the order of the updates).
 template <int MAXA, typename HotP, typename RewP, typename PathP>
-__device__ __forceinline__ void mz_grow_backup_hot(const MzDev &E, HotP hot, RewP rew, PathP path, int spare, int depth, int &top,
+__device__ __forceinline__ void mz_grow_backup_hot(const MzDev &E, HotP hot, RewP rew, PathP path, int spare, int ca, int depth, int &top,
                                                    double &lo, double &hi, float reward_g, const float *probs, float value_g) {
     const int leaf = path[depth];
     if (top + E.n_actions > E.cap) {
@@ -483,43 +539,34 @@ __device__ __forceinline__ void mz_grow_backup_hot(const MzDev &E, HotP hot, Rew
         }
         top += E.n_actions;
     }
-    // a chunk is straight-line code, so that its four division chains overlap: a level above the root is played on
-    // the spare record `spare` (slot index relative to `hot` / `rew`; its contents are never read for a result)
     double v = (double)value_g;
     for (int d = depth; d >= 0; d -= 4) {
-        int slot[4], nn[4];
-        double vs[4], r[4], vv[4], sum[4], nv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) slot[i] = d - i >= 0 ? path[d - i >= 0 ? d - i : 0] : spare;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            vs[i] = hot[slot[i]].value_sum;
-            nn[i] = hot[slot[i]].N + 1;
-            r[i] = (double)rew[slot[i]];
-        }
-        vv[0] = v;
-        vv[1] = r[0] + E.discount * vv[0];
-        vv[2] = r[1] + E.discount * vv[1];
-        vv[3] = r[2] + E.discount * vv[2];
-        v = r[3] + E.discount * vv[3];
-        double den[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool real = d - i >= 0;
-            sum[i] = real ? vs[i] + vv[i] : 0.0;
-            nn[i] = real ? nn[i] : 1;
-            den[i] = (double)nn[i];
-        }
-        mz_divide<4>(sum, den, nv);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool real = d - i >= 0;
-            hot[slot[i]].value_sum = sum[i];
-            hot[slot[i]].N = real ? nn[i] : 0;
-            hot[slot[i]].q = r[i] + E.discount * nv[i];
-            hi = real && nv[i] > hi ? nv[i] : hi;  // MinMaxStats.update
-            lo = real && nv[i] < lo ? nv[i] : lo;
-        }
+        const bool real = d - ca >= 0;
+        const int slot = real ? path[real ? d - ca : 0] : spare;
+        const double vs = hot[slot].value_sum, r = (double)rew[slot];
+        const int n = real ? hot[slot].N + 1 : 1;
+        const double r0 = mz_quad_bcast<0>(r), r1 = mz_quad_bcast<1>(r), r2 = mz_quad_bcast<2>(r), r3 = mz_quad_bcast<3>(r);
+        const double v1 = r0 + E.discount * v;
+        const double v2 = r1 + E.discount * v1;
+        const double v3 = r2 + E.discount * v2;
+        const double mine = ca == 0 ? v : ca == 1 ? v1 : ca == 2 ? v2 : v3;
+        v = r3 + E.discount * v3;
+        const double sum = real ? vs + mine : 0.0;
+        const double nv = sum / (double)n;
+        hot[slot].value_sum = sum;
+        hot[slot].N = real ? n : 0;
+        hot[slot].q = r + E.discount * nv;
+        double up = real ? nv : -INFINITY, dn = real ? nv : INFINITY;   // MinMaxStats.update over the quad's levels
+        double o = mz_quad_xor<1>(up);
+        up = o > up ? o : up;
+        o = mz_quad_xor<2>(up);
+        up = o > up ? o : up;
+        o = mz_quad_xor<1>(dn);
+        dn = o < dn ? o : dn;
+        o = mz_quad_xor<2>(dn);
+        dn = o < dn ? o : dn;
+        hi = up > hi ? up : hi;
+        lo = dn < lo ? dn : lo;
     }
 }
 
@@ -809,6 +856,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
 #ifdef RZ_MZ_PROFILE
     long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = clock64();
 #endif
+    float touch_sink = 0.0f;   // mz_touch
     const int n_moves = MOVES ? P.n_moves : 1;
     for (int move = 0; move < n_moves; ++move) {
         if (MOVES) {
@@ -874,7 +922,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
         int par = 0, act = 0, lf = 0;
         if (w == 0) {
             if (mine)
-                depth = TREE_LDS ? mz_descend_hot(E, hot, path, PBL, SQT, lo, hi, ca, par, act, lf)
+                depth = TREE_LDS ? mz_descend_hot(E, hot, path, PBL, SQT, lo, hi, ca, hidden + (long long)g * E.cap * kMzH, touch_sink, par, act, lf)
                                  : mz_descend(E, nodes, path, PBL, lo, hi, par, act, lf);
             MZ_TICK(0);
 #ifdef RZ_MZ_PROFILE
@@ -903,6 +951,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
                 const int a = q + 4 * j;
                 if (a < A) XS[(kMzH + a) * kMzTile + n] = (live_n && an == a) ? 1.0f : 0.0f;
             }
+            mz_touch_done(touch_sink);
             MZ_TICK(1);
         }
         __syncthreads();
@@ -965,7 +1014,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
                     for (int a = 0; a < kMzMaxA; ++a)
                         if (a < A) T.probs[o * A + a] = probs[a];
                 }
-                if (TREE_LDS) mz_grow_backup_hot<kMzMaxA>(E, hot, rew, path, E.cap, depth, top, lo, hi, reward, probs, value);
+                if (TREE_LDS) mz_grow_backup_hot<kMzMaxA>(E, hot, rew, path, E.cap, ca, depth, top, lo, hi, reward, probs, value);
                 else mz_grow_backup<kMzMaxA>(E, nodes, path, depth, top, lo, hi, reward, probs, value);
             }
             MZ_TICK(12);

@@ -20,6 +20,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager" -o s 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_1lane" -o s -- $B --graph 0 --steps 2 --lanes 1 --games 512 > "$OUT/bench_eager_1lane_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_literal" -o s -- $B --graph 0 --steps 2 --lanes 2 --games 512 > "$OUT/bench_eager_literal_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_c2_k16" -o s -- $B --graph 0 --steps 4 --board 9 --playouts 200 --games 64 --lanes 1 --in-flight 16 > "$OUT/bench_eager_c2_k16_under_rocprof.json" 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_muzero" -o s -- $B --game muzero --games 8192 --steps 64 --warmup 16 > "$OUT/bench_muzero_under_rocprof.json" 2> /dev/null
 echo "kernel stats done"
 
 # 3. HBM traffic counters, one pass each (short eager run of the default geometry)

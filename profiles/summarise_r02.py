@@ -35,7 +35,7 @@ def per_kernel(csv_path, counter):
 def main(out):
     keep = os.path.join(out, 'keep')
     os.makedirs(keep, exist_ok=True)
-    for name in ('bench_default.json', 'lane_sweeps.txt', 'in_flight_sweep.txt', 'bench_eager_literal_under_rocprof.json', 'bench_eager_c2_k16_under_rocprof.json',
+    for name in ('bench_default.json', 'lane_sweeps.txt', 'in_flight_sweep.txt', 'bench_eager_literal_under_rocprof.json', 'bench_eager_c2_k16_under_rocprof.json', 'bench_muzero_under_rocprof.json',
                  'microbench_f32_mfma_overlap.txt', 'microbench_f16_mfma_rate.txt', 'microbench_f16_mfma_fillers.txt',
                  'bench_under_rocprof.json', 'sweep_games.txt', 'sweep_heads.txt',
                  'bench_eager_under_rocprof.json', 'bench_eager_1lane_under_rocprof.json',
@@ -43,7 +43,7 @@ def main(out):
         src = os.path.join(out, name)
         if os.path.exists(src) and os.path.getsize(src):
             shutil.copy(src, os.path.join(keep, name))
-    for tag in ('stats_default', 'stats_eager', 'stats_eager_1lane', 'stats_eager_literal', 'stats_eager_c2_k16'):
+    for tag in ('stats_default', 'stats_eager', 'stats_eager_1lane', 'stats_eager_literal', 'stats_eager_c2_k16', 'stats_muzero'):
         found = glob.glob(os.path.join(out, tag, '**', '*kernel_stats.csv'), recursive=True)
         if found:
             shutil.copy(found[0], os.path.join(keep, 'bench_%s_kernel_stats.csv' % tag[6:]))

@@ -136,7 +136,7 @@ class MuZeroSelfPlay(object):
 
     def __init__(self, net, env, n_sims=50, discount=0.997, temperature=1.0, root_dirichlet_alpha=0.25,
                  root_exploration_fraction=0.25, seed=0, pb_c_base=19652.0, pb_c_init=1.25, use_graph=True, fused=None,
-                 fused_moves=None, moves_per_launch=16):
+                 fused_moves=None, moves_per_launch=16, arena_rows=None):
         """``fused``: run the whole search of a move in ONE kernel launch (csrc/rz_muzero.hip k_mz_search: the model is
         evaluated inside the kernel on the matrix pipe, 16 games per workgroup, trees in LDS); None = whenever the model
         fits it (hidden size 64, <= 8 actions).  Otherwise one hipGraph of ~15 launches per simulation (tree kernels +
@@ -145,7 +145,9 @@ class MuZeroSelfPlay(object):
         action draw, environment step; ``moves_per_launch`` of them per launch) -- the host only reads one packed record
         per environment and move, a chunk behind the GPU.  None = whenever ``fused`` holds and the environment is a
         CartPoleBatch (the environment step is device code).  Its random draws (root noise, actions) come from the
-        kernel's counter-based stream keyed (seed, environment, episode, step), not from the torch generator."""
+        kernel's counter-based stream keyed (seed, environment, episode, step), not from the torch generator.
+        ``arena_rows``: records the per-launch arena of finished episodes holds (None = twice what a launch plays + a few
+        long episodes; episodes that do not fit are read back from the device ring instead)."""
         import torch
         from .tree import MuZeroTree
         self.torch = torch
@@ -183,6 +185,7 @@ class MuZeroSelfPlay(object):
         if self.fused_moves and not can_fuse_moves:
             raise ValueError('fused_moves needs the fused search and a CartPoleBatch environment')
         self.moves_per_launch = max(1, int(moves_per_launch))
+        self._arena_rows = arena_rows
         self.noise_seed = int(seed)
         self._records = None  # fused moves: [device records, pinned host copy, event] x 2 (double buffer)
         if self.fused:
@@ -380,6 +383,8 @@ class MuZeroSelfPlay(object):
             # in the steady state a launch ends about as many steps of episodes as it plays (G x K); twice that, plus a
             # few long episodes, always fits -- what does not is read back from the ring (entry with row -1)
             rows, n_entries = 2 * G * K + 4 * steps, G * K
+            if self._arena_rows is not None:
+                rows = max(1, int(self._arena_rows))
             self._copy_stream = t.cuda.Stream(device=self.device)
             self._records = []
             for _ in range(2):
@@ -437,8 +442,10 @@ class MuZeroSelfPlay(object):
 
         def fields_of(block):
             vis = block[:, D + 2:D + 2 + A]
-            return (block[:, :D].astype(np.float32), block[:, D].astype(np.int64), block[:, D + 1].copy(),
-                    (vis / vis.sum(axis=1, keepdims=True)).astype(np.float32), block[:, D + 2 + A].copy())
+            with np.errstate(invalid='ignore', divide='ignore'):  # (rows of the arena no episode claimed are zero)
+                pol = (vis / vis.sum(axis=1, keepdims=True)).astype(np.float32)
+            return (block[:, :D].astype(np.float32), block[:, D].astype(np.int64), block[:, D + 1].copy(), pol,
+                    block[:, D + 2 + A].copy())
 
         if fits.any():
             used = min(n_rows, arena.shape[0])

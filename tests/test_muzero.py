@@ -216,6 +216,85 @@ def test_muzero_tree_kernels_bit_exact_vs_pseudocode(fused):
     sp.close()
 
 
+class _BareEnv(object):
+    """What MuZeroSelfPlay.search needs of an environment (no stepping): sizes, device, observations."""
+
+    def __init__(self, n_envs, n_actions, obs):
+        self.n_envs, self.n_actions, self.device, self._obs = n_envs, n_actions, obs.device, obs
+
+    def observe(self):
+        return self._obs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_actions,n_sims', [(1, 12), (3, 30), (4, 25), (6, 10), (6, 50), (8, 40)])
+def test_fused_search_other_action_counts_and_tree_placements(n_actions, n_sims):
+    """k_mz_search away from CartPole's two actions: 3 / 4 actions take the quad's second exchange, more than 4 the
+    strided scan, and (6, 50) / (8, 40) trees do not fit the LDS budget and stay in HBM (one-lane walk) -- every one
+    against the CPython restatement fed the kernel's traced network outputs: identical visit counts and value sums."""
+    import torch
+    from rlzero_amd.muzero import MuZeroNet, MuZeroSelfPlay
+    torch.manual_seed(10 + n_actions)
+    G = 37
+    net = MuZeroNet(n_actions=n_actions).to('cuda:0').eval()
+    obs = torch.randn(G, 4, device='cuda:0')
+    sp = MuZeroSelfPlay(net, _BareEnv(G, n_actions, obs), n_sims=n_sims, seed=3, fused=True)
+    assert sp.fused and not sp.fused_moves
+    record = []
+    visits, root_value = sp.search(obs, add_noise=True, record=record)
+    visits, root_value = visits.cpu().numpy(), root_value.cpu().numpy()
+    n, vsum, vmin, vmax = (x.cpu().numpy().copy() for x in sp.tree.root_stats())
+    child_sum = sp.tree.root_children('value_sum').cpu().numpy()
+    _, probs0, noise = record[0]
+    probs0, noise = probs0.cpu().numpy(), noise.cpu().numpy()
+    sims = [tuple(x.cpu().numpy() for x in r) for r in record[1:]]
+    cfg = ref.MuZeroConfig(num_simulations=n_sims)
+    for g in range(G):
+        root = ref.Node(0)
+        ref.expand_node(root, None, 0.0, [float(p) for p in probs0[g]])
+        ref.add_exploration_noise(cfg, root, [float(x) for x in noise[g]])
+        step = [0]
+
+        def model(hidden, action, path, g=g, step=step):
+            parent, act, leaf, reward, probs, value = sims[step[0]]
+            assert act[g] == action
+            step[0] += 1
+            return None, float(reward[g]), [float(p) for p in probs[g]], float(value[g])
+
+        stats = ref.run_mcts(cfg, root, model)
+        assert root.visit_count == n[g] == n_sims and _hexf(root.value_sum) == _hexf(vsum[g])
+        assert _hexf(stats.minimum) == _hexf(vmin[g]) and _hexf(stats.maximum) == _hexf(vmax[g])
+        for a, child in enumerate(root.children):
+            assert child.visit_count == visits[g, a] and _hexf(child.value_sum) == _hexf(child_sum[g, a])
+    # and the untraced launch builds the same trees
+    v2, rv2 = sp.search(obs, add_noise=False)
+    v2, rv2 = v2.clone(), rv2.clone()
+    v3, rv3 = sp.search(obs, add_noise=False, record=[])
+    assert torch.equal(v2, v3) and torch.equal(rv2, rv3)
+    sp.tree.check()
+    sp.close()
+
+
+@pytest.mark.gpu
+def test_fused_moves_episodes_that_do_not_fit_the_arena_come_from_the_ring():
+    """A per-launch arena far too small for what ends during a launch: the kernel marks those episodes (row -1) and the
+    host reads them back from the device ring -- the same episodes as with the default arena."""
+    import torch
+    from rlzero_amd.muzero import CartPoleBatch, MuZeroNet, MuZeroSelfPlay
+    torch.manual_seed(7)
+    net = MuZeroNet().to('cuda:0').eval()
+
+    def play(arena_rows):
+        sp = MuZeroSelfPlay(net, CartPoleBatch(96, 'cuda:0', seed=5), n_sims=10, seed=2, moves_per_launch=9, arena_rows=arena_rows)
+        eps = sp.collect(45)
+        out = sorted((len(e), e.obs.tobytes(), e.actions.tobytes(), e.root_values.tobytes(), e.policies.tobytes()) for e in eps)
+        sp.close()
+        return out
+
+    roomy, tight = play(None), play(40)
+    assert len(roomy) > 100 and roomy == tight
+
+
 @pytest.mark.gpu
 def test_fused_search_network_matches_the_torch_model():
     """The recurrent inference k_mz_search evaluates inside the kernel (dynamics, reward head, min-max scaled next state,

@@ -144,8 +144,10 @@ class HipNet(object):
 
     def set_heads_algo(self, algo):
         """GEMM of the first FC layers: 'f32' (f32-input MFMA), 'split32' / 'split64' (f16 matrix pipe with hi + lo
-        operand pairs after the 'split_f16' trunk, 32 / 64 boards per workgroup), 'auto' (default after the
-        'split_f16' trunk: 'split64' beside a capped trunk, 'split32' otherwise; 'f32' after the f32 trunks)."""
+        operand pairs after the 'split_f16' trunk, 32 / 64 boards per workgroup), 'parts' (the same arithmetic as
+        single-wave workgroups per K quarter, no LDS: fits beside a resident trunk workgroup of another lane; the consumer
+        adds the four partial sums), 'auto' (default after the 'split_f16' trunk: 'split64' beside a capped trunk,
+        otherwise 'parts' up to 256 boards and 'split32' above; 'f32' after the f32 trunks).  All give the same bits."""
         code = {'auto': _hip.NET_HEADS_AUTO, 'f32': _hip.NET_HEADS_F32, 'split32': _hip.NET_HEADS_SPLIT_32,
                 'split64': _hip.NET_HEADS_SPLIT_64, 'parts': _hip.NET_HEADS_SPLIT_PARTS}[algo]
         check(self.lib.rz_net_set_heads_algo(self.handle, code), 'rz_net_set_heads_algo')

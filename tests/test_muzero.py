@@ -276,6 +276,33 @@ def test_fused_search_other_action_counts_and_tree_placements(n_actions, n_sims)
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('temperature', [1.0, 0.5])
+def test_fused_moves_draw_actions_from_the_visit_counts(temperature):
+    """select_action of the pseudocode inside the kernel: P(action) = visits ^ (1 / T) / sum, drawn from the kernel's
+    counter-based stream -- over 8192 environments the drawn actions follow the recorded visit counts (mean of the
+    per-environment probability of action 1, 4 sigma), and every drawn action has a visit."""
+    import torch
+    from rlzero_amd.muzero import CartPoleBatch, MuZeroNet, MuZeroSelfPlay
+    torch.manual_seed(12)
+    net = MuZeroNet().to('cuda:0').eval()
+    G = 8192
+    sp = MuZeroSelfPlay(net, CartPoleBatch(G, 'cuda:0', seed=31), n_sims=16, seed=6, temperature=temperature, moves_per_launch=2)
+    assert sp.fused_moves
+    sp.collect(2)
+    ring, _ = sp.device_history()
+    for t in range(2):
+        action, visits = ring[:, t, 4].astype(np.int64), ring[:, t, 6:8]
+        assert (visits.sum(axis=1) == 16).all() and (visits[np.arange(G), action] > 0).all()
+        w = visits ** (1.0 / temperature)
+        p1 = w[:, 1] / w.sum(axis=1)
+        sigma = math.sqrt(float((p1 * (1 - p1)).sum())) / G
+        assert abs(float(action.mean()) - float(p1.mean())) < 4 * sigma + 1e-9, (action.mean(), p1.mean(), sigma)
+    a0, a1 = ring[:, 0, 4], ring[:, 1, 4]
+    assert 0.2 < float((a0 != a1).mean()) < 0.8   # the two moves of an environment are separate draws
+    sp.close()
+
+
+@pytest.mark.gpu
 def test_fused_moves_episodes_that_do_not_fit_the_arena_come_from_the_ring():
     """A per-launch arena far too small for what ends during a launch: the kernel marks those episodes (row -1) and the
     host reads them back from the device ring -- the same episodes as with the default arena."""

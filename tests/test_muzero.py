@@ -276,6 +276,40 @@ def test_fused_search_other_action_counts_and_tree_placements(n_actions, n_sims)
 
 
 @pytest.mark.gpu
+def test_fused_moves_history_ring_wraps():
+    """More moves than the device ring has steps: episodes that straddle the wrap (and launches of uneven length) still come
+    out as the scalar environment replays them under their recorded actions."""
+    import torch
+    from rlzero_amd.muzero import CartPoleBatch, MuZeroNet, MuZeroSelfPlay
+    from rlzero_amd.muzero.cartpole import initial_states
+    torch.manual_seed(13)
+    net = MuZeroNet().to('cuda:0').eval()
+    G = 20
+    env = CartPoleBatch(G, 'cuda:0', seed=17)
+    sp = MuZeroSelfPlay(net, env, n_sims=4, seed=1, moves_per_launch=13)
+    episodes = []
+    for n in (300, 1, 290, 64):     # 655 moves > 500 + 2 * 13 + 12 ring steps
+        episodes.extend(sp.collect(n))
+    ring, ep_start = sp.device_history()
+    assert sp._t == 655 > ring.shape[1] and len(episodes) > 200
+    count = np.zeros(G, dtype=np.int64)
+    for ep in episodes:  # which environment an episode belongs to: its first observation is that environment's next start
+        first = np.asarray(ep.obs[0], dtype=np.float32)
+        owner = [i for i in range(G) if np.array_equal(initial_states(17, [i], [count[i]])[0].astype(np.float32), first)]
+        assert len(owner) == 1
+        i = owner[0]
+        r = ref.RefCartPole()
+        r.reset(initial_states(17, [i], [count[i]])[0])
+        for t in range(len(ep)):
+            assert np.max(np.abs(np.asarray(ep.obs[t]) - np.array(r.state, dtype=np.float64).astype(np.float32))) < 1e-6
+            state, rew, term, trunc = r.step(int(ep.actions[t]))
+            assert (term or trunc) == (t == len(ep) - 1)
+        count[i] += 1
+    assert np.array_equal(count, env.episode) and sum(len(ep) for ep in episodes) == int(ep_start.sum())
+    sp.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('temperature', [1.0, 0.5])
 def test_fused_moves_draw_actions_from_the_visit_counts(temperature):
     """select_action of the pseudocode inside the kernel: P(action) = visits ^ (1 / T) / sum, drawn from the kernel's

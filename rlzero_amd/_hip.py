@@ -140,7 +140,8 @@ _lib = None
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'librlzero_hip.so')
+    """The in-tree build; RZ_HIP_LIBRARY names another build of the same ABI (A / B runs of a kernel change)."""
+    return os.environ.get('RZ_HIP_LIBRARY') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'librlzero_hip.so')
 
 
 def load():

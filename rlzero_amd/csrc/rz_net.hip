@@ -716,13 +716,17 @@ __device__ __forceinline__ f16x8 load_w(__amdgpu_buffer_rsrc_t rsrc, int lane_of
     return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, uniform_off, 0));
 }
 
-// x (already scaled) -> hi, lo
+// x (already scaled) -> hi, lo.  Written for 8 vector instructions per 4 values: two packed conversions for the hi pieces
+// (v_cvt_pk_f16_f32, round to nearest even like the scalar conversion), the residuals z - hi as v_fma_mix_f32 (the f16
+// operand widened inside the instruction: the same single rounding as convert + subtract), two packed conversions for lo.
 __device__ __forceinline__ void split4(const float (&z)[4], f16x4 &hi, f16x4 &lo) {
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    const f32x4v zv = {z[0], z[1], z[2], z[3]};
+    hi = __builtin_convertvector(zv, f16x4);
+    f32x4v r;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        hi[j] = (_Float16)z[j];
-        lo[j] = (_Float16)(z[j] - (float)hi[j]);
-    }
+    for (int j = 0; j < 4; ++j) r[j] = __builtin_fmaf((float)hi[j], -1.0f, z[j]);
+    lo = __builtin_convertvector(r, f16x4);
 }
 
 // slot I of K-step S: MFMA I of the step plus (behind the first MFMAs) one load of a coming step
@@ -825,10 +829,23 @@ struct LeafBits {
     const int32_t *last;
 };
 
+// Development aid (not built by default): -DRZ_NET_PROFILE accumulates the shader-clock cycles wave 0 of workgroup 0 spends in
+// each phase of a board in k_trunk_split into net_prof[] (rz_net_debug_profile).
+#ifdef RZ_NET_PROFILE
+__device__ long long net_prof[16];
+#define NET_TICK(i) do { const long long now_ = __builtin_readcyclecounter(); prof_acc[i] += now_ - prof_t; prof_t = now_; } while (0)
+#else
+#define NET_TICK(i)
+#endif
+
 template <int TN>
 __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__restrict__ obs, LeafBits leaves,
                                                      float *__restrict__ feat, _Float16 *__restrict__ feat16,
                                                      int n_boards, unsigned *__restrict__ flags) {
+#ifdef RZ_NET_PROFILE
+    const long long prof_k0 = __builtin_readcyclecounter();
+    long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = prof_k0;
+#endif
     constexpr int kThreads = 256;
     __shared__ __attribute__((aligned(16))) char lds_raw[sp::kLdsBytes];
     char *in0 = lds_raw;                      // observation planes, pieces hi | lo
@@ -848,14 +865,18 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
             ob[k] = i < 4 * S ? src[i] : 0.0f;
         }
     };
+    const bool from_bits = leaves.stones != nullptr;
     int obs_off[kObsPer];
 #pragma unroll
-    for (int k = 0; k < kObsPer; ++k) {
-        const int i = tid0 + k * kThreads;
-        const int c = i / S, r = i - c * S, y = r / BW, x = r - y * BW;
-        obs_off[k] = i < 4 * S ? ((y + 1) * sp::kInCols + (x + 1)) * 8 + c * 2 : -1;
+    for (int k = 0; k < kObsPer; ++k) obs_off[k] = -1;
+    if (!from_bits) {  // (two integer divisions per element: ~1.5 k cycles of the prologue that the bitboard route does not need)
+#pragma unroll
+        for (int k = 0; k < kObsPer; ++k) {
+            const int i = tid0 + k * kThreads;
+            const int c = i / S, r = i - c * S, y = r / BW, x = r - y * BW;
+            obs_off[k] = i < 4 * S ? ((y + 1) * sp::kInCols + (x + 1)) * 8 + c * 2 : -1;
+        }
     }
-    const bool from_bits = leaves.stones != nullptr;
     // bit mode: thread t owns cell t (S <= 256 = threads); its 4 plane values as f16 (x 16: exact, the lo piece is 0)
     const int cell_y = tid0 / BW, cell_x = tid0 - cell_y * BW;
     const int cell_off = tid0 < S ? ((cell_y + 1) * sp::kInCols + (cell_x + 1)) * 8 : -1;
@@ -930,11 +951,45 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         if (from_bits) load_bits(blockIdx.x, tid0); else load_obs(blockIdx.x, tid0);
     }
     __builtin_amdgcn_sched_barrier(0);  // the loads above stay above the zeroing
+    NET_TICK(11);
     {
+        // What a board never writes must read as zero: the observation planes' halo (all of in0: 5.8 KB), and in c1 / c2
+        // the halo ring and the positions beyond the board -- NOT the board's own positions, which every board overwrites
+        // (all channels a convolution reads; the 8 padding channels of a position are never read): 99 of 324 positions on
+        // a 15x15 board instead of 147 KB.
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         f32x4 *z = reinterpret_cast<f32x4 *>(lds_raw);
-        for (int i = tid0; i < sp::kLdsBytes / 16; i += kThreads) z[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = tid0; i < sp::kInBytes / 16; i += kThreads) z[i] = zero;
+        // the positions to zero, numbered densely so that every lane of a store instruction has one (an LDS store costs
+        // its issue whatever the number of active lanes): first the 18 - BH full rows (row 0, rows BH+1 ..), then the
+        // 18 - BW outside columns (column 0, columns BW+1 ..) of the board's rows; x 2 pieces: 198 items on a 15x15 board
+        const int out_rows = kRowW - BH, out_cols = kRowW - BW, n_out = out_rows * kRowW + BH * out_cols;
+        for (int it = tid0; it < 2 * n_out; it += kThreads) {
+            const int piece = it >= n_out, idx = it - piece * n_out;
+            int py, px;
+            if (idx < out_rows * kRowW) {
+                const int r = idx / kRowW;
+                py = r == 0 ? 0 : BH + r;
+                px = idx - r * kRowW;
+            } else {
+                const int j = idx - out_rows * kRowW;
+                const int r = (int)((float)j / (float)out_cols);   // (j < 18 * 17, out_cols <= 17: the float quotient is exact enough to floor)
+                const int c = j - r * out_cols;
+                py = 1 + r;
+                px = c == 0 ? 0 : BW + c;
+            }
+            const int pos = py * kRowW + px;
+            f32x4 *q1 = reinterpret_cast<f32x4 *>(c1 + piece * sp::Geo<32>::piece_bytes + pos * sp::Geo<32>::pos_bytes);
+#pragma unroll
+            for (int i = 0; i < sp::Geo<32>::pos_bytes / 16; ++i) q1[i] = zero;
+            f32x4 *q2 = reinterpret_cast<f32x4 *>(c2 + piece * sp::Geo<64>::piece_bytes + pos * sp::Geo<64>::pos_bytes);
+#pragma unroll
+            for (int i = 0; i < sp::Geo<64>::pos_bytes / 16; ++i) q2[i] = zero;
+        }
     }
+    NET_TICK(12);
     __syncthreads();
+    NET_TICK(13);
 #pragma unroll
     for (int k = 0; k < kHwPer; ++k) {
         const int i = tid0 + k * kThreads;
@@ -942,7 +997,12 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     }
     if (tid0 < 8) hw[128 * 7 + tid0] = bh_reg;
     if (first) store_obs(tid0);
+    NET_TICK(14);
     __syncthreads();
+#ifdef RZ_NET_PROFILE
+    NET_TICK(15);
+    prof_acc[9] = prof_t - prof_k0;   // the prologue
+#endif
     for (int board = blockIdx.x; board < n_boards; board += gridDim.x) {
     int tid = tid0;
     asm volatile("" : "+v"(tid));
@@ -1006,7 +1066,9 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
             }
         }
     }
+    NET_TICK(0);
     __syncthreads();
+    NET_TICK(1);
     if (next_board < n_boards) {
         if (from_bits) load_bits(next_board, tid); else load_obs(next_board, tid);
     }
@@ -1019,6 +1081,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
 #pragma unroll
             for (int g = 0; g < 4; ++g) bias2[m][g] = *reinterpret_cast<const f32x4 *>(nd.b2 + m * 32 + 8 * g + 4 * h) * act2;
         if (TN == 2 || busy) sp::conv<32, 2, TN>(c1, nd.s2, row0, ry, x, lane, a2, acc);
+        NET_TICK(2);
         sp::preload_w<64, 4>(a3, nd.s3, lane);
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -1044,7 +1107,9 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
             }
     }
     if (next_board < n_boards) store_obs(tid);
+    NET_TICK(3);
     __syncthreads();
+    NET_TICK(4);
     {   // conv3: 64 -> 128; its ReLU'd output feeds the two 1x1 head convolutions from registers
         f32x2 vals2[TN][3];  // [position][pair of head outputs]
 #pragma unroll
@@ -1054,6 +1119,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         {
             sp::f32x16 acc[4][TN];
             if (TN == 2 || busy) sp::conv<64, 4, TN>(c2, nd.s3, row0, ry, x, lane, a3, acc);
+            NET_TICK(5);
             // per (m, g): the lane's channels c0 .. c0+3 = 32*m + 8*g + 4*h ..: 24 head weights [j][output] and 4
             // biases from LDS, fetched one group ahead (the fences keep hipcc from hoisting all 16 groups' reads)
             f32x4 w[2][7];
@@ -1091,6 +1157,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        NET_TICK(6);
         // the two lane halves hold different channels of the same TN positions: with TN = 2 lane half h stores
         // position h, with TN = 1 half 0 stores the one position
         float *dst = feat ? feat + (size_t)board * nd.feat_ld : nullptr;  // null: only the f16 pieces are wanted
@@ -1122,7 +1189,14 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
             }
         }
     }
+    NET_TICK(7);
     }  // boards
+#ifdef RZ_NET_PROFILE
+    if (blockIdx.x == 0 && tid0 == 0) {
+        for (int i = 0; i < 16; ++i) net_prof[i] = prof_acc[i];
+        net_prof[10] = __builtin_readcyclecounter() - prof_k0;
+    }
+#endif
     if (!(zmax <= 65504.0f)) atomicOr(flags, (unsigned)RZ_NET_FLAG_F16_RANGE);
 }
 
@@ -2127,6 +2201,12 @@ int rz_net_range_info(rz_net *net, float *h_info8) {
     memcpy(h_info8, net->range_info, sizeof(net->range_info));
     return RZ_OK;
 }
+
+#ifdef RZ_NET_PROFILE
+int rz_net_debug_profile(long long *h_out16) {
+    return hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(net_prof), 16 * sizeof(long long)) == hipSuccess ? RZ_OK : RZ_ERR_HIP;
+}
+#endif
 
 int rz_net_set_heads_algo(rz_net *net, int32_t heads_algo) {
     if (!net) return net_fail(RZ_ERR_ARG, "net handle is NULL");

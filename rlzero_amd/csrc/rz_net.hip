@@ -716,16 +716,27 @@ __device__ __forceinline__ f16x8 load_w(__amdgpu_buffer_rsrc_t rsrc, int lane_of
     return __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, uniform_off, 0));
 }
 
-// x (already scaled) -> hi, lo.  Written for 8 vector instructions per 4 values: two packed conversions for the hi pieces
-// (v_cvt_pk_f16_f32, round to nearest even like the scalar conversion), the residuals z - hi as v_fma_mix_f32 (the f16
-// operand widened inside the instruction: the same single rounding as convert + subtract), two packed conversions for lo.
+// x (already scaled) -> hi, lo in 8 vector instructions per 4 values: two packed conversions for the hi pieces
+// (v_cvt_pk_f16_f32, round to nearest even like the scalar conversion), the residuals z - hi as v_fma_mix_f32 with the f16
+// operand widened inside the instruction (the same single rounding as convert + subtract; hipcc folds fma(x, -1, z) back
+// into the two instructions, hence the asm), two packed conversions for lo.
+__device__ __forceinline__ float resid_lo(float z, unsigned pair) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pair), "v"(z));
+    return r;
+}
+__device__ __forceinline__ float resid_hi(float z, unsigned pair) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pair), "v"(z));
+    return r;
+}
 __device__ __forceinline__ void split4(const float (&z)[4], f16x4 &hi, f16x4 &lo) {
     typedef float f32x4v __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     const f32x4v zv = {z[0], z[1], z[2], z[3]};
     hi = __builtin_convertvector(zv, f16x4);
-    f32x4v r;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r[j] = __builtin_fmaf((float)hi[j], -1.0f, z[j]);
+    const u32x2 pairs = __builtin_bit_cast(u32x2, hi);
+    const f32x4v r = {resid_lo(z[0], pairs[0]), resid_hi(z[1], pairs[0]), resid_lo(z[2], pairs[1]), resid_hi(z[3], pairs[1])};
     lo = __builtin_convertvector(r, f16x4);
 }
 
@@ -1083,28 +1094,29 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         if (TN == 2 || busy) sp::conv<32, 2, TN>(c1, nd.s2, row0, ry, x, lane, a2, acc);
         NET_TICK(2);
         sp::preload_w<64, 4>(a3, nd.s3, lane);
+        // (position outermost: ONE guarded region per N-tile instead of one per group of 4 channels)
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int t = 0; t < TN; ++t) {
+            const int y = row0 + 2 * t + ry;
+            if (busy && col_ok && y < BH && x < BW) {
+                char *pos = c2 + ((y + 1) * kRowW + (x + 1)) * sp::Geo<64>::pos_bytes + 4 * h * 2;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c0 = m * 32 + 8 * g + 4 * h;
-                const f32x4 bv = bias2[m][g];
+                for (int m = 0; m < 2; ++m)
 #pragma unroll
-                for (int t = 0; t < TN; ++t) {
-                    const int y = row0 + 2 * t + ry;
-                    float z[4];
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 bv = bias2[m][g];
+                        float z[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) z[j] = fmaxf(fmaf(acc[m][t][4 * g + j], k2, bv[j]), 0.0f);
-                    if (busy && col_ok && y < BH && x < BW) {
+                        for (int j = 0; j < 4; ++j) z[j] = fmaxf(fmaf(acc[m][t][4 * g + j], k2, bv[j]), 0.0f);
                         zmax = fmaxf(fmaxf(zmax, fmaxf(z[0], z[1])), fmaxf(z[2], z[3]));
                         sp::f16x4 hi, lo;
                         sp::split4(z, hi, lo);
-                        char *dst = c2 + ((y + 1) * kRowW + (x + 1)) * sp::Geo<64>::pos_bytes + c0 * 2;
+                        char *dst = pos + (m * 32 + 8 * g) * 2;
                         *reinterpret_cast<sp::f16x4 *>(dst) = hi;
                         *reinterpret_cast<sp::f16x4 *>(dst + sp::Geo<64>::piece_bytes) = lo;
                     }
-                }
             }
+        }
     }
     if (next_board < n_boards) store_obs(tid);
     NET_TICK(3);

@@ -270,6 +270,8 @@ def run_literal_config(args):
 CONFIG_LEGS = (  # (key, title, flags, seconds of CPU baseline at --cpu-seconds 60); a few warm-up moves each: a leg starts on a GPU
     # that has idled through its own CPU baseline (the main run adds up to 3 moves to its W until 0.3 s have passed)
     ('C1', 'configs[0] TicTacToe, 25 sims/move, 1 game', ['--board', 3, '--playouts', 25, '--games', 1, '--lanes', 1, '--steps', 9, '--warmup', 20], 5.0),
+    ('C1_16_games', 'configs[0] with as many games as the CPU baseline plays at once (16 processes = 16 games): like for like with '
+     'its aggregate figure', ['--board', 3, '--playouts', 25, '--games', 16, '--lanes', 1, '--steps', 9, '--warmup', 20, '--no-cpu-baseline'], 0.0),
     ('C2', 'configs[1] 9x9 Gomoku, 200 sims/move, 64 games', ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 8, '--warmup', 8], 12.0),
     ('C2_16_in_flight', 'configs[1] with the opt-in virtual-loss mode: 16 simulations in flight per tree (NOT the reference\'s '
      'sequential search; leaf batches of 1024 instead of 64)',

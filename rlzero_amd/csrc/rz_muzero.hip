@@ -8,14 +8,17 @@
 // which the parity tests restate in CPython and compare against, statistic for statistic.
 // Single-player form (to_play is constant, CartPole): no sign flip in the backup.
 //
-// One THREAD per game: a MuZero tree is tiny (n_sims + 1 expanded nodes, A children each) and its
-// walk is a short chain of dependent loads, so the parallelism is across the thousands of games.
-// Tree layout (struct of arrays, per game g, node slot i, slot index g * cap + i):
-//   one 32-byte record per node: N int32, first_child int32 (-1 = not expanded; the A children of a node are the
-//   consecutive slots first_child .. first_child + A - 1), value_sum f64, prior f64, reward f32.
-// The learned model stays outside: rz_mz_select reports (parent slot, action, leaf slot) per game;
-// the caller gathers the parents' hidden states, runs dynamics + prediction on the batch, stores
-// the new hidden states at the leaf slots and hands reward / policy / value to rz_mz_expand_backup.
+// Three routes, one tree arithmetic (mz_descend / mz_grow_backup and their LDS twins give the same bits):
+//   * step by step (rz_mz_select / rz_mz_expand_backup, one THREAD per game): the learned model stays outside -- the
+//     caller gathers the parents' hidden states, runs dynamics + prediction on the batch, stores the new hidden states
+//     at the leaf slots and hands reward / policy / value back;
+//   * rz_mz_search: all simulations of a move in ONE launch, the model evaluated inside the kernel (k_mz_search);
+//   * rz_mz_play_cartpole: whole MOVES in one launch -- initial inference, root noise, search, action draw, CartPole step,
+//     episode history on the device (k_mz_search with its MOVES stages).
+// A MuZero tree is tiny (n_sims + 1 expanded nodes, A children each) and its walk is a short chain of dependent steps,
+// so the parallelism is across the thousands of games.  Tree layout in HBM (per game g, node slot i, slot index
+// g * cap + i): one 32-byte record per node: N int32, first_child int32 (-1 = not expanded; the A children of a node are
+// the consecutive slots first_child .. first_child + A - 1), value_sum f64, prior f64, reward f32.
 //
 // Arithmetic: fp64, one rounding per operation (-ffp-contract=off), IEEE divide and sqrt; the
 // log((N + c2 + 1) / c2) factor of pUCT comes from a table filled by the HOST libm (what CPython's

@@ -5,8 +5,11 @@ Per move (arXiv:1911.08265v2 appendix: ``play_game`` / ``run_mcts`` / ``select_a
   -> ``n_sims`` x [ rz_mz_select -> gather the parents' hidden states -> recurrent inference on the whole
      batch -> store the leaves' hidden states -> rz_mz_expand_backup ]
   -> action ~ visit counts ^ (1 / T) -> environment step -> the step goes to the episode's trajectory.
-Everything between the observation and the chosen action stays on the device; the tree statistics live
-in the HIP kernels, the small MLPs of the model run on PyTorch-ROCm (rocBLAS GEMMs)."""
+Three routes (``MuZeroSelfPlay(fused=..., fused_moves=...)``): the step-by-step one above (tree kernels + the model's
+small MLPs on PyTorch-ROCm, one hipGraph per simulation); the search of a move in ONE launch with the model evaluated
+inside the kernel (``rz_mz_search``); and whole MOVES in one launch -- initial inference, noise, search, action draw,
+CartPole step, episode history on the device (``rz_mz_play_cartpole``), the host reading finished episodes a launch
+behind the GPU.  The last is the default for a ``CartPoleBatch`` environment and a hidden size of 64."""
 import numpy as np
 
 

@@ -8,8 +8,9 @@ from ..engine import _ptr, check
 
 
 class MuZeroTree(object):
-    """Search trees of ``n_games`` environments on one GPU (one thread per tree).  The learned model is the
-    caller's: see ``MuZeroSelfPlay.search`` for the simulation loop."""
+    """Search trees of ``n_games`` environments on one GPU.  Step by step (``select`` / ``expand_backup``) the learned
+    model is the caller's: see ``MuZeroSelfPlay.search`` for the simulation loop; ``search_fused`` and ``play_cartpole``
+    evaluate it inside the kernel (``load_model`` / ``load_representation`` first)."""
 
     def __init__(self, n_games, n_actions, n_sims, discount=0.997, pb_c_base=19652.0, pb_c_init=1.25,
                  device='cuda:0'):

@@ -929,7 +929,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     };
     // Prologue of a persistent workgroup.  Every global load it needs -- head weights and conv3 biases (3.5 KB, bound for
     // LDS), the rescaling factors and activation scales, conv1's weights and biases (registers), the first board -- is
-    // ISSUED first, the 151 KB of LDS are zeroed under their latency, and only then the values are stored: with one board
+    // ISSUED first, the parts of the LDS that no board writes are zeroed under their latency, and only then the values are stored: with one board
     // per workgroup (256 boards per launch) the prologue is not amortised, and two lanes alternate such launches.
     constexpr int kHwPer = (128 * 7 + kThreads - 1) / kThreads;
     float hw_reg[kHwPer];

@@ -741,51 +741,61 @@ __device__ __forceinline__ void split4(const float (&z)[4], f16x4 &hi, f16x4 &lo
 }
 
 // slot I of K-step S: MFMA I of the step plus (behind the first MFMAs) one load of a coming step
+// (D = depth of the ring of weight fragments: a step's fragments are requested D - 1 steps ahead -- 2 where a step has
+// 6 or more MFMAs to cover the L2 round trip, 4 for the small tiles of the channel-split variants)
+constexpr int ring_depth(int tm, int tn) { return tm * tn >= 4 ? 3 : 5; }
+// (and of the ring of activation fragments: read from LDS one step ahead)
+constexpr int act_depth(int, int) { return 2; }   // (3 for the small tiles was tried: no gain, their steps are bound by the accumulator chain)
 template <int CIN, int TM, int TN, int S, int I>
-__device__ __forceinline__ void slot(f32x16 (&acc)[TM][TN], f16x8 (&a)[3][TM][2], f16x8 (&b)[2][TN][2], lds_frag q0,
+__device__ __forceinline__ void slot(f32x16 (&acc)[TM][TN], f16x8 (&a)[ring_depth(TM, TN)][TM][2], f16x8 (&b)[act_depth(TM, TN)][TN][2], lds_frag q0,
                                      lds_frag q1, __amdgpu_buffer_rsrc_t w_rsrc, int w_base, int w_lane) {
     using G = Geo<CIN>;
+    constexpr int D = ring_depth(TM, TN);
     constexpr int combo = I / (TM * TN), m = (I / TN) % TM, n = I % TN;
     constexpr int pa = combo == 2 ? 1 : 0, pb = combo == 1 ? 1 : 0;
-    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[S % 3][m][pa], b[S % 2][n][pb], acc[m][n], 0, 0, 0);
+    constexpr int DB = act_depth(TM, TN);
+    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[S % D][m][pa], b[S % DB][n][pb], acc[m][n], 0, 0, 0);
     if constexpr (I < 2 * TN) {
-        if constexpr (S + 1 < G::steps) {
-            constexpr int s1 = S + 1, tap = s1 / G::chunks, c = s1 % G::chunks, nn = I / 2, piece = I % 2;
+        if constexpr (S + DB - 1 < G::steps) {
+            constexpr int s1 = S + DB - 1, tap = s1 / G::chunks, c = s1 % G::chunks, nn = I / 2, piece = I % 2;
             constexpr int off = ((2 * nn + tap / 3) * kRowW + tap % 3) * G::pos_bytes + c * 32;
             static_assert(off % 16 == 0 && off < 65536, "ds_read_b128 immediate");
-            b[s1 % 2][nn][piece] = (piece ? q1 : q0)[off / 16];
+            b[s1 % DB][nn][piece] = (piece ? q1 : q0)[off / 16];
         }
     } else if constexpr (I < 2 * TN + 2 * TM) {
-        if constexpr (S + 2 < G::steps) {
-            constexpr int s2 = S + 2, j = I - 2 * TN, mm = j / 2, piece = j % 2;
-            a[s2 % 3][mm][piece] = load_w(w_rsrc, w_lane, w_base + ((mm * G::steps + s2) * 2 + piece) * 1024);
+        if constexpr (S + D - 1 < G::steps) {
+            constexpr int s2 = S + D - 1, j = I - 2 * TN, mm = j / 2, piece = j % 2;
+            a[s2 % D][mm][piece] = load_w(w_rsrc, w_lane, w_base + ((mm * G::steps + s2) * 2 + piece) * 1024);
+            // one M-tile x one N-tile: three MFMAs per step but four fragments to fetch -- the last slot takes two
+            if constexpr (TM == 1 && TN == 1 && I == 2)
+                a[s2 % D][0][1] = load_w(w_rsrc, w_lane, w_base + (s2 * 2 + 1) * 1024);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int CIN, int TM, int TN, int S, int... Is>
-__device__ __forceinline__ void step(std::integer_sequence<int, Is...>, f32x16 (&acc)[TM][TN], f16x8 (&a)[3][TM][2],
-                                     f16x8 (&b)[2][TN][2], lds_frag q0, lds_frag q1, __amdgpu_buffer_rsrc_t w_rsrc,
+__device__ __forceinline__ void step(std::integer_sequence<int, Is...>, f32x16 (&acc)[TM][TN], f16x8 (&a)[ring_depth(TM, TN)][TM][2],
+                                     f16x8 (&b)[act_depth(TM, TN)][TN][2], lds_frag q0, lds_frag q1, __amdgpu_buffer_rsrc_t w_rsrc,
                                      int w_base, int w_lane) {
     (slot<CIN, TM, TN, S, Is>(acc, a, b, q0, q1, w_rsrc, w_base, w_lane), ...);
 }
 
 template <int CIN, int TM, int TN, int... Ss>
-__device__ __forceinline__ void steps(std::integer_sequence<int, Ss...>, f32x16 (&acc)[TM][TN], f16x8 (&a)[3][TM][2],
-                                      f16x8 (&b)[2][TN][2], lds_frag q0, lds_frag q1, __amdgpu_buffer_rsrc_t w_rsrc,
+__device__ __forceinline__ void steps(std::integer_sequence<int, Ss...>, f32x16 (&acc)[TM][TN], f16x8 (&a)[ring_depth(TM, TN)][TM][2],
+                                      f16x8 (&b)[act_depth(TM, TN)][TN][2], lds_frag q0, lds_frag q1, __amdgpu_buffer_rsrc_t w_rsrc,
                                       int w_base, int w_lane) {
     (step<CIN, TM, TN, Ss>(std::make_integer_sequence<int, 3 * TM * TN>{}, acc, a, b, q0, q1, w_rsrc, w_base, w_lane), ...);
 }
 
-// The weight fragments of K-steps 0 and 1 (M-tiles 0 .. TM-1): no dependence on LDS, so a layer's first
+// The weight fragments of the first K-steps (M-tiles 0 .. TM-1): no dependence on LDS, so a layer's first
 // fragments are requested while the previous layer is still being reduced.
-template <int CIN, int TM>
-__device__ __forceinline__ void preload_w(f16x8 (&a)[3][TM][2], const void *wts, int lane) {
+template <int CIN, int TM, int TN>
+__device__ __forceinline__ void preload_w(f16x8 (&a)[ring_depth(TM, TN)][TM][2], const void *wts, int lane) {
     using G = Geo<CIN>;
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(wts), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < ring_depth(TM, TN) - 1; ++s)
 #pragma unroll
         for (int m = 0; m < TM; ++m)
 #pragma unroll
@@ -798,18 +808,23 @@ __device__ __forceinline__ void preload_w(f16x8 (&a)[3][TM][2], const void *wts,
 // only) lies two rows below.
 template <int CIN, int TM, int TN>
 __device__ __forceinline__ void conv(const char *in, const void *wts, int row0, int ry, int x, int lane,
-                                     f16x8 (&a)[3][TM][2], f32x16 (&acc)[TM][TN]) {
+                                     f16x8 (&a)[ring_depth(TM, TN)][TM][2], f32x16 (&acc)[TM][TN]) {
     using G = Geo<CIN>;
     const int h = lane >> 5;
     // halo position (row0 + ry, x) = the top-left tap of output (row0 + ry, x)
     const int lane_byte = ((row0 + ry) * kRowW + x) * G::pos_bytes + h * 16;
     const lds_frag q0 = (lds_frag)(in + lane_byte), q1 = (lds_frag)(in + lane_byte + G::piece_bytes);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(wts), 0, 0x7fffffff, 0x00020000);
-    f16x8 b[2][TN][2];
+    f16x8 b[act_depth(TM, TN)][TN][2];
 #pragma unroll
-    for (int nn = 0; nn < TN; ++nn) {
-        b[0][nn][0] = q0[(2 * nn * kRowW * G::pos_bytes) / 16];
-        b[0][nn][1] = q1[(2 * nn * kRowW * G::pos_bytes) / 16];
+    for (int s0 = 0; s0 < act_depth(TM, TN) - 1; ++s0) {   // the fragments of the first step(s): tap = s0 / chunks, chunk = s0 % chunks
+        const int tap = s0 / G::chunks, c = s0 % G::chunks;
+#pragma unroll
+        for (int nn = 0; nn < TN; ++nn) {
+            const int off = ((2 * nn + tap / 3) * kRowW + tap % 3) * G::pos_bytes + c * 32;
+            b[s0][nn][0] = q0[off / 16];
+            b[s0][nn][1] = q1[off / 16];
+        }
     }
 #pragma unroll
     for (int m = 0; m < TM; ++m)
@@ -849,7 +864,12 @@ __device__ long long net_prof[16];
 #define NET_TICK(i)
 #endif
 
-template <int TN>
+// MS (with TN = 1): when the board needs only 2 (MS = 2) or 1 (MS = 4) of the four N-tiles, the waves that would idle
+// take a share of the OUTPUT CHANNELS instead: wave = part * (4 / MS) + tile, part p computes M-tiles p * TM / MS .. of
+// conv2 and conv3 for its tile (a 6x7 Connect4 board: 6 instead of 12 MFMAs per K-step and wave; a 3x3 board: 3).  The
+// 1x1 head convolutions then sum over the channels of MS waves: partial sums meet in LDS (in the 16 padding bytes of
+// conv1's positions, which nothing else touches), part 0 adds them in part order and stores the features.
+template <int TN, int MS = 1>
 __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__restrict__ obs, LeafBits leaves,
                                                      float *__restrict__ feat, _Float16 *__restrict__ feat16,
                                                      int n_boards, unsigned *__restrict__ flags) {
@@ -1019,8 +1039,15 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int next_board = board + (int)gridDim.x;
-    sp::f16x8 a2[3][2][2];
-    sp::preload_w<32, 2>(a2, nd.s2, lane);
+    constexpr int kTiles = 4 / MS;          // waves side by side over the board's rows
+    const int tile = MS == 1 ? wave : wave % kTiles, part = MS == 1 ? 0 : wave / kTiles;
+    constexpr int TM2 = MS == 1 ? 2 : 1, TM3 = 4 / MS;   // M-tiles of conv2 / conv3 per wave
+    const int m2 = MS == 1 ? 0 : (part & 1), m3 = part * TM3;   // ... starting at
+    const bool conv2_mine = MS < 4 || part < 2;           // (conv2 has two M-tiles: with MS = 4 parts 2, 3 sit it out)
+    const char *s2p = reinterpret_cast<const char *>(nd.s2) + (size_t)m2 * sp::Geo<32>::steps * 2 * 1024;
+    const char *s3p = reinterpret_cast<const char *>(nd.s3) + (size_t)m3 * sp::Geo<64>::steps * 2 * 1024;
+    sp::f16x8 a2[sp::ring_depth(TM2, TN)][TM2][2];
+    sp::preload_w<32, TM2, TN>(a2, s2p, lane);
     // the lane's column of an N-tile: position (ry, x) of a tile of RT rows (TN = 2: always 2 x 16); a lane past the
     // tile's positions computes position (0, 0) again and stores nothing
     const int RT = TN == 2 ? 2 : nd.tile_rows, CT = TN == 2 ? 16 : nd.tile_cols;
@@ -1028,11 +1055,11 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     const int ry_raw = TN == 2 ? n >> 4 : (n * nd.tile_rcp) >> 16;
     const bool col_ok = ry_raw < RT;
     const int ry = col_ok ? ry_raw : 0, x = col_ok ? n - ry_raw * CT : 0;
-    const int row0 = RT * TN * wave;       // first board row of this wave
+    const int row0 = RT * TN * tile;       // first board row of this wave
     // a wave below the board skips its MFMA loops (it still meets the barriers); with TN = 2 its rows stay inside the
     // halo grid and it computes them unconditionally (a branch around the loops costs the accumulators their registers)
     const bool busy = row0 < BH;
-    if (busy) {   // conv1: 4 -> 32 (one M-tile), N-tiles TN*wave ..; K-step = kernel row ky
+    if (busy && part == 0) {   // conv1: 4 -> 32 (one M-tile), N-tiles TN*wave ..; K-step = kernel row ky
         typedef const __attribute__((address_space(3))) sp::f16x4 *lds_half;
         const lds_half q = (lds_half)(in0 + ((row0 + ry) * sp::kInCols + x + 2 * h) * 8);
         sp::f16x8 b1[3][TN][2];
@@ -1083,25 +1110,25 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     if (next_board < n_boards) {
         if (from_bits) load_bits(next_board, tid); else load_obs(next_board, tid);
     }
-    sp::f16x8 a3[3][4][2];
+    sp::f16x8 a3[sp::ring_depth(TM3, TN)][TM3][2];
     {   // conv2: 32 -> 64
-        sp::f32x16 acc[2][TN];
-        f32x4 bias2[2][4];  // fetched before the MFMA loop
+        sp::f32x16 acc[TM2][TN];
+        f32x4 bias2[TM2][4];  // fetched before the MFMA loop
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < TM2; ++m)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bias2[m][g] = *reinterpret_cast<const f32x4 *>(nd.b2 + m * 32 + 8 * g + 4 * h) * act2;
-        if (TN == 2 || busy) sp::conv<32, 2, TN>(c1, nd.s2, row0, ry, x, lane, a2, acc);
+            for (int g = 0; g < 4; ++g) bias2[m][g] = *reinterpret_cast<const f32x4 *>(nd.b2 + (m2 + m) * 32 + 8 * g + 4 * h) * act2;
+        if (TN == 2 || (busy && conv2_mine)) sp::conv<32, TM2, TN>(c1, s2p, row0, ry, x, lane, a2, acc);
         NET_TICK(2);
-        sp::preload_w<64, 4>(a3, nd.s3, lane);
+        sp::preload_w<64, TM3, TN>(a3, s3p, lane);
         // (position outermost: ONE guarded region per N-tile instead of one per group of 4 channels)
 #pragma unroll
         for (int t = 0; t < TN; ++t) {
             const int y = row0 + 2 * t + ry;
-            if (busy && col_ok && y < BH && x < BW) {
-                char *pos = c2 + ((y + 1) * kRowW + (x + 1)) * sp::Geo<64>::pos_bytes + 4 * h * 2;
+            if (busy && conv2_mine && col_ok && y < BH && x < BW) {
+                char *pos = c2 + ((y + 1) * kRowW + (x + 1)) * sp::Geo<64>::pos_bytes + (m2 * 32 + 4 * h) * 2;
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                for (int m = 0; m < TM2; ++m)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const f32x4 bv = bias2[m][g];
@@ -1129,23 +1156,23 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
 #pragma unroll
             for (int o2 = 0; o2 < 3; ++o2) vals2[t][o2] = f32x2{0.0f, 0.0f};
         {
-            sp::f32x16 acc[4][TN];
-            if (TN == 2 || busy) sp::conv<64, 4, TN>(c2, nd.s3, row0, ry, x, lane, a3, acc);
+            sp::f32x16 acc[TM3][TN];
+            if (TN == 2 || busy) sp::conv<64, TM3, TN>(c2, s3p, row0, ry, x, lane, a3, acc);
             NET_TICK(5);
             // per (m, g): the lane's channels c0 .. c0+3 = 32*m + 8*g + 4*h ..: 24 head weights [j][output] and 4
             // biases from LDS, fetched one group ahead (the fences keep hipcc from hoisting all 16 groups' reads)
             f32x4 w[2][7];
             auto load_group = [&](int mg, f32x4 (&dstw)[7]) {
-                const int c0 = (mg >> 2) * 32 + 8 * (mg & 3) + 4 * h;
+                const int c0 = (m3 + (mg >> 2)) * 32 + 8 * (mg & 3) + 4 * h;
 #pragma unroll
                 for (int i = 0; i < 6; ++i) dstw[i] = *reinterpret_cast<const f32x4 *>(hw + c0 * 6 + 4 * i);
                 dstw[6] = *reinterpret_cast<const f32x4 *>(hw + 768 + c0);
             };
             load_group(0, w[0]);
 #pragma unroll
-            for (int mg = 0; mg < 16; ++mg) {
+            for (int mg = 0; mg < 4 * TM3; ++mg) {
                 const int m = mg >> 2, g = mg & 3;
-                if (mg + 1 < 16) load_group(mg + 1, w[(mg + 1) & 1]);
+                if (mg + 1 < 4 * TM3) load_group(mg + 1, w[(mg + 1) & 1]);
                 const f32x4(&wc)[7] = w[mg & 1];
 #pragma unroll
                 for (int t = 0; t < TN; ++t)
@@ -1174,7 +1201,19 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         // position h, with TN = 1 half 0 stores the one position
         float *dst = feat ? feat + (size_t)board * nd.feat_ld : nullptr;  // null: only the f16 pieces are wanted
         const int y = row0 + (TN == 2 ? 2 * h : 0) + ry;
-        const bool mine = busy && col_ok && (TN == 2 || h == 0);
+        const bool mine = busy && part == 0 && col_ok && (TN == 2 || h == 0);
+        // MS > 1: the 6 sums of a position are spread over MS waves (their shares of the 128 channels): they meet in LDS
+        float *pad_a = reinterpret_cast<float *>(c1 + ((part * kTiles + tile) * 32 + n) * sp::Geo<32>::pos_bytes + 64);
+        float *pad_b = reinterpret_cast<float *>(reinterpret_cast<char *>(pad_a) + sp::Geo<32>::piece_bytes);
+        if (MS > 1) {
+#pragma unroll
+            for (int o = 0; o < 6; ++o) {
+                float v0 = vals2[0][o >> 1][o & 1];
+                v0 += __shfl_xor(v0, 32);
+                if (h == 0) (o < 4 ? pad_a[o] : pad_b[o - 4]) = v0;
+            }
+            __syncthreads();
+        }
         // the same features as hi + lo f16 pieces for the A fragments of k_heads_split:
         // [32-board tile][K-step][hi | lo][board % 32][k % 16] -- the 16 values of a board and K-step are one 32-byte
         // sector (written whole by neighbouring lanes of this wave), a wave of the GEMM reads the 1 KB of a piece
@@ -1183,7 +1222,15 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
 #pragma unroll
         for (int o = 0; o < 6; ++o) {
             float v0 = vals2[0][o >> 1][o & 1], v1 = vals2[TN - 1][o >> 1][o & 1];
-            v0 += __shfl_xor(v0, 32);
+            if (MS > 1) {  // the parts' shares, in part order (every lane reads: part 0's result is the one stored)
+                const int stride = kTiles * 32 * sp::Geo<32>::pos_bytes / 4;   // floats from one part's slot to the next
+                const float *q = (o < 4 ? pad_a + o : pad_b + (o - 4)) - part * stride;
+                v0 = q[0];
+#pragma unroll
+                for (int p_ = 1; p_ < MS; ++p_) v0 += q[p_ * stride];
+            } else {
+                v0 += __shfl_xor(v0, 32);
+            }
             if (TN == 2) v1 += __shfl_xor(v1, 32);
             const float v = fmaxf(((TN == 2 && h) ? v1 : v0) + hw[128 * 7 + o], 0.0f);
             if (mine && y < BH && x < BW) {
@@ -2117,7 +2164,12 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
     {
         _Float16 *f16 = internal ? net->d_feat16 : nullptr;
         float *f32 = want_f32 ? d_feat : nullptr;
-        if ((net->dev.BH + net->dev.tile_rows - 1) / net->dev.tile_rows <= 4)  // four tiles cover the board: one per wave
+        const int tiles = (net->dev.BH + net->dev.tile_rows - 1) / net->dev.tile_rows;
+        if (tiles <= 1)        // one tile: the four waves share the output channels
+            k_trunk_split<1, 4><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
+        else if (tiles <= 2)   // two tiles x two channel halves
+            k_trunk_split<1, 2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
+        else if (tiles <= 4)   // four tiles cover the board: one per wave
             k_trunk_split<1><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
         else
             k_trunk_split<2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);

@@ -984,30 +984,27 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     __builtin_amdgcn_sched_barrier(0);  // the loads above stay above the zeroing
     NET_TICK(11);
     {
-        // What a board never writes must read as zero: the observation planes' halo (all of in0: 5.8 KB), and in c1 / c2
-        // the halo ring and the positions beyond the board -- NOT the board's own positions, which every board overwrites
-        // (all channels a convolution reads; the 8 padding channels of a position are never read): 99 of 324 positions on
-        // a 15x15 board instead of 147 KB.
+        // What a VALID position reads and no board writes must be zero: the observation planes' halo (all of in0: 5.8 KB)
+        // and, in c1 / c2, the ring of positions around the board (row 0, row BH + 1, column 0, column BW + 1 of the halo
+        // grid).  Positions further out are read only by MFMA columns that are not positions of the board (tile padding:
+        // a column's garbage stays in that column and is never stored), and the board's own positions are overwritten by
+        // every board: 64 positions x 2 pieces on a 15x15 board instead of 147 KB, numbered densely (an LDS store costs
+        // its issue whatever the number of active lanes).
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         f32x4 *z = reinterpret_cast<f32x4 *>(lds_raw);
         for (int i = tid0; i < sp::kInBytes / 16; i += kThreads) z[i] = zero;
-        // the positions to zero, numbered densely so that every lane of a store instruction has one (an LDS store costs
-        // its issue whatever the number of active lanes): first the 18 - BH full rows (row 0, rows BH+1 ..), then the
-        // 18 - BW outside columns (column 0, columns BW+1 ..) of the board's rows; x 2 pieces: 198 items on a 15x15 board
-        const int out_rows = kRowW - BH, out_cols = kRowW - BW, n_out = out_rows * kRowW + BH * out_cols;
-        for (int it = tid0; it < 2 * n_out; it += kThreads) {
-            const int piece = it >= n_out, idx = it - piece * n_out;
+        const int n_ring = 2 * (BW + 2) + 2 * BH;
+        for (int it = tid0; it < 2 * n_ring; it += kThreads) {
+            const int piece = it >= n_ring, idx = it - piece * n_ring;
             int py, px;
-            if (idx < out_rows * kRowW) {
-                const int r = idx / kRowW;
-                py = r == 0 ? 0 : BH + r;
-                px = idx - r * kRowW;
+            if (idx < 2 * (BW + 2)) {
+                const int bottom = idx >= BW + 2;
+                py = bottom ? BH + 1 : 0;
+                px = idx - bottom * (BW + 2);
             } else {
-                const int j = idx - out_rows * kRowW;
-                const int r = (int)((float)j / (float)out_cols);   // (j < 18 * 17, out_cols <= 17: the float quotient is exact enough to floor)
-                const int c = j - r * out_cols;
-                py = 1 + r;
-                px = c == 0 ? 0 : BW + c;
+                const int j = idx - 2 * (BW + 2);
+                py = 1 + (j >> 1);
+                px = (j & 1) ? BW + 1 : 0;
             }
             const int pos = py * kRowW + px;
             f32x4 *q1 = reinterpret_cast<f32x4 *>(c1 + piece * sp::Geo<32>::piece_bytes + pos * sp::Geo<32>::pos_bytes);

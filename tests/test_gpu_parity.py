@@ -667,6 +667,32 @@ def test_hip_net_vs_golden_and_torch(g4):
     hip.close()
 
 
+def test_split_trunk_every_board_size():
+    """k_trunk_split over all its shapes -- tiles of 2 x 16 (11 .. 16), one tile per wave (9, 10), the channel-split
+    variants for boards of two tiles (6, 7, 8) and of one (3, 4, 5) -- against torch fp64 (1e-4, random non-0/1 inputs,
+    37 boards on 5 persistent workgroups and on one each: same bits) and against the direct f32 kernel's features."""
+    import torch
+    from rlzero_amd.engine import HipNet
+    for B in range(3, 17):
+        weights = ev.numpy_weights(B, 1000 + B)
+        hip = HipNet(B, 'cuda:0', max_boards=64).load_state_dict(weights)
+        rs = np.random.RandomState(B)
+        x = torch.from_numpy(rs.standard_normal((37, 4, B, B)).astype(np.float32)).to('cuda:0')
+        lp64, v64 = ev.net_forward(weights, x.cpu().numpy(), dtype=torch.float64)
+        lp, v = hip.forward(x)
+        assert np.max(np.abs(lp.cpu().numpy() - lp64.numpy())) <= 1e-4, B
+        assert np.max(np.abs(v.cpu().numpy() - v64.numpy()[:, 0])) <= 1e-4, B
+        lp5, v5 = hip.set_max_workgroups(5).forward(x)
+        assert torch.equal(lp5, lp) and torch.equal(v5, v), B
+        hip.set_max_workgroups(0)
+        planes = (torch.rand((9, 4, B, B), device='cuda:0') < 0.4).float()   # 0 / 1 planes like the tree's leaves
+        feat = hip.trunk(planes).cpu().numpy()
+        feat_direct = hip.set_algo('direct').trunk(planes).cpu().numpy()
+        assert np.max(np.abs(feat - feat_direct)) <= 2e-5 * max(1.0, float(np.abs(feat_direct).max())), B
+        hip.check_flags()
+        hip.close()
+
+
 def test_trunk_is_deterministic_under_load():
     """The default trunk accumulates with an inline-assembly MFMA whose register hazards are kept by hand
     (DESIGN.md section 7): a violated hazard would be timing dependent, so 60 launches of a full 512-board batch,

@@ -869,6 +869,12 @@ __device__ long long net_prof[16];
 // conv2 and conv3 for its tile (a 6x7 Connect4 board: 6 instead of 12 MFMAs per K-step and wave; a 3x3 board: 3).  The
 // 1x1 head convolutions then sum over the channels of MS waves: partial sums meet in LDS (in the 16 padding bytes of
 // conv1's positions, which nothing else touches), part 0 adds them in part order and stores the features.
+// the value of lane l ^ 32 (h = l >> 5): v_permlane32_swap, two vector instructions instead of a trip through the LDS crossbar
+__device__ __forceinline__ float other_half(float x, int h) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(h ? r[0] : r[1]);
+}
+
 template <int TN, int MS = 1>
 __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__restrict__ obs, LeafBits leaves,
                                                      float *__restrict__ feat, _Float16 *__restrict__ feat16,
@@ -1206,7 +1212,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
 #pragma unroll
             for (int o = 0; o < 6; ++o) {
                 float v0 = vals2[0][o >> 1][o & 1];
-                v0 += __shfl_xor(v0, 32);
+                v0 += other_half(v0, h);
                 if (h == 0) (o < 4 ? pad_a[o] : pad_b[o - 4]) = v0;
             }
             __syncthreads();
@@ -1216,6 +1222,9 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         // sector (written whole by neighbouring lanes of this wave), a wave of the GEMM reads the 1 KB of a piece
         _Float16 *dst16 = feat16 ? feat16 + ((size_t)(board >> 5) * (nd.groups_act + nd.groups_val) * 1024 + (board & 31) * 16)
                                  : nullptr;
+        // the six sums of the lane's position first (the other lane half's share by v_permlane32_swap, the biases in one
+        // go), then the stores: nothing in the store sequence waits for a cross-lane or LDS round trip
+        float vsum[6];
 #pragma unroll
         for (int o = 0; o < 6; ++o) {
             float v0 = vals2[0][o >> 1][o & 1], v1 = vals2[TN - 1][o >> 1][o & 1];
@@ -1226,14 +1235,22 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
 #pragma unroll
                 for (int p_ = 1; p_ < MS; ++p_) v0 += q[p_ * stride];
             } else {
-                v0 += __shfl_xor(v0, 32);
+                v0 += other_half(v0, h);
             }
-            if (TN == 2) v1 += __shfl_xor(v1, 32);
-            const float v = fmaxf(((TN == 2 && h) ? v1 : v0) + hw[128 * 7 + o], 0.0f);
-            if (mine && y < BH && x < BW) {
-                if (dst) dst[(o < 4 ? o * S : nd.feat_val_off + (o - 4) * S) + y * BW + x] = v;
+            if (TN == 2) v1 += other_half(v1, h);
+            vsum[o] = (TN == 2 && h) ? v1 : v0;
+        }
+        float hb[6];
+#pragma unroll
+        for (int o = 0; o < 6; ++o) hb[o] = hw[128 * 7 + o];
+        if (mine && y < BH && x < BW) {
+            const int cell = y * BW + x;
+#pragma unroll
+            for (int o = 0; o < 6; ++o) {
+                const float v = fmaxf(vsum[o] + hb[o], 0.0f);
+                if (dst) dst[(o < 4 ? o * S : nd.feat_val_off + (o - 4) * S) + cell] = v;
                 if (dst16) {
-                    const int k = (o < 4 ? o : o - 4) * S + y * BW + x;
+                    const int k = (o < 4 ? o : o - 4) * S + cell;
                     const int step = (o < 4 ? 0 : nd.groups_act) + (k >> 4);
                     const float z = v * act3;
                     const _Float16 zh = (_Float16)z;

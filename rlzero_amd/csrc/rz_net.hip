@@ -1024,12 +1024,9 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     NET_TICK(12);
     __syncthreads();
     NET_TICK(13);
-#pragma unroll
-    for (int k = 0; k < kHwPer; ++k) {
-        const int i = tid0 + k * kThreads;
-        if (i < 128 * 7) hw[i] = hw_reg[k];
-    }
-    if (tid0 < 8) hw[128 * 7 + tid0] = bh_reg;
+    // (the head weights go to LDS behind the first board's conv1: they are first read two barriers later, and their
+    // loads need not be waited for here)
+    bool hw_pending = true;
     if (first) store_obs(tid0);
     NET_TICK(14);
     __syncthreads();
@@ -1106,6 +1103,15 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
                 }
             }
         }
+    }
+    if (hw_pending) {
+#pragma unroll
+        for (int k = 0; k < kHwPer; ++k) {
+            const int i = tid0 + k * kThreads;
+            if (i < 128 * 7) hw[i] = hw_reg[k];
+        }
+        if (tid0 < 8) hw[128 * 7 + tid0] = bh_reg;
+        hw_pending = false;
     }
     NET_TICK(0);
     __syncthreads();

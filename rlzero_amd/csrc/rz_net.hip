@@ -754,7 +754,12 @@ __device__ __forceinline__ void slot(f32x16 (&acc)[TM][TN], f16x8 (&a)[ring_dept
     constexpr int combo = I / (TM * TN), m = (I / TN) % TM, n = I % TN;
     constexpr int pa = combo == 2 ? 1 : 0, pb = combo == 1 ? 1 : 0;
     constexpr int DB = act_depth(TM, TN);
-    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[S % D][m][pa], b[S % DB][n][pb], acc[m][n], 0, 0, 0);
+    if constexpr (S == 0 && combo == 0) {   // the first MFMA of a tile starts from the constant 0: no zeroing of 16 registers per tile
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[S % D][m][pa], b[S % DB][n][pb], zero, 0, 0, 0);
+    } else {
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[S % D][m][pa], b[S % DB][n][pb], acc[m][n], 0, 0, 0);
+    }
     if constexpr (I < 2 * TN) {
         if constexpr (S + DB - 1 < G::steps) {
             constexpr int s1 = S + DB - 1, tap = s1 / G::chunks, c = s1 % G::chunks, nn = I / 2, piece = I % 2;
@@ -826,12 +831,6 @@ __device__ __forceinline__ void conv(const char *in, const void *wts, int row0, 
             b[s0][nn][1] = q1[off / 16];
         }
     }
-#pragma unroll
-    for (int m = 0; m < TM; ++m)
-#pragma unroll
-        for (int nn = 0; nn < TN; ++nn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][nn][r] = 0.0f;
     __builtin_amdgcn_sched_barrier(0);
     steps<CIN, TM, TN>(std::make_integer_sequence<int, G::steps>{}, acc, a, b, q0, q1, w_rsrc, 0, lane * 16);
 }

@@ -360,17 +360,44 @@ __device__ __forceinline__ float gamma03(uint32_t key) {
     return g * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(ub) * (1.0f / 0.3f));  // ub^(1/0.3)
 }
 
-// wave arg-max of (score, index) with the LOWEST index winning ties (Python's max keeps the first)
-__device__ __forceinline__ int wave_first_max(double best, int besti) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double ob = __shfl_xor(best, off);
-        const int oi = __shfl_xor(besti, off);
-        if (ob > best || (ob == best && oi < besti)) {
-            best = ob;
-            besti = oi;
-        }
+// wave arg-max of (score, index) with the LOWEST index winning ties (Python's max keeps the first).  Six exchange
+// stages, none through the LDS crossbar (a ds_bpermute round trip per stage was ~600 cycles of waiting per tree level):
+// lanes 1, 2 apart by DPP quad_perm, the other half of a row of 8 / 16 by row_half_mirror / row_mirror (a reduction needs
+// a partner from the other group, not a particular one), rows 16 / 32 apart by v_permlane16_swap / v_permlane32_swap.
+template <int CTRL>
+__device__ __forceinline__ int dpp_move(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true); }
+template <int STAGE>   // 0 .. 5: partner 1, 2, (4), (8), 16, 32 lanes away
+__device__ __forceinline__ int partner_of(int x, int lane) {
+    if (STAGE == 0) return dpp_move<0xB1>(x);    // quad_perm [1, 0, 3, 2]
+    if (STAGE == 1) return dpp_move<0x4E>(x);    // quad_perm [2, 3, 0, 1]
+    if (STAGE == 2) return dpp_move<0x141>(x);   // row_half_mirror
+    if (STAGE == 3) return dpp_move<0x140>(x);   // row_mirror
+    if (STAGE == 4) {
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+        return (int)((lane & 16) ? r[0] : r[1]);
     }
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
+    return (int)((lane & 32) ? r[0] : r[1]);
+}
+template <int STAGE>
+__device__ __forceinline__ void first_max_stage(double &best, int &besti, int lane) {
+    const long long b = __double_as_longlong(best);
+    const int olo = partner_of<STAGE>((int)b, lane), ohi = partner_of<STAGE>((int)(b >> 32), lane);
+    const int oi = partner_of<STAGE>(besti, lane);
+    const double ob = __longlong_as_double(((long long)ohi << 32) | (unsigned int)olo);
+    if (ob > best || (ob == best && oi < besti)) {
+        best = ob;
+        besti = oi;
+    }
+}
+__device__ __forceinline__ int wave_first_max(double best, int besti) {
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    first_max_stage<0>(best, besti, lane);
+    first_max_stage<1>(best, besti, lane);
+    first_max_stage<2>(best, besti, lane);
+    first_max_stage<3>(best, besti, lane);
+    first_max_stage<4>(best, besti, lane);
+    first_max_stage<5>(best, besti, lane);
     return besti;
 }
 

@@ -1116,6 +1116,7 @@ __global__ void k_tree_step_ml(Dev E, const float *logp, const float *value, Raw
                 SL[j].last = last0;
                 SL[j].nst = count_bits(st0[0]) + count_bits(st0[1]);
                 SL[j].moved = 0;
+                SL[j].pad0 = -1;
                 E.path[(long long)(g * K + j) * E.path_stride] = 0;
             }
         }
@@ -1215,29 +1216,12 @@ __global__ void k_tree_step_ml(Dev E, const float *logp, const float *value, Raw
                     stg[2 * r + 1] = make_hi(rec_w(chi) - 1.0, chi.z, __int_as_float(chi.w));
                 }
             }
-            // the move on the slot's board
-            uint64_t st[2][kWords], occ[kWords];
-#pragma unroll
-            for (int i = 0; i < kWords; ++i) {
-                st[0][i] = SL[j].st[0][i];
-                st[1][i] = SL[j].st[1][i];
-                occ[i] = st[0][i] | st[1][i];
-            }
-            const Legal L = legal_of(E, occ, lane);
-            int action, cell;
-            if (!nth_legal(E, occ, L, r, lane, action, cell)) {
-                flag(E, g, RZ_FLAG_INTERNAL, lane);
-                if (lane == 0) { SL[j].fresh = 2; SL[j].active = 0; }
-                continue;
-            }
+            // (the move on the slot's board -- which cell child r is -- depends on no other slot: phase B2 below, every
+            // slot's own wave, instead of inside this slot-after-slot loop)
             if (lane == 0) {
-                const int tm = SL[j].to_move;
-                SL[j].st[tm][cell >> 6] |= 1ull << (cell & 63);
-                SL[j].to_move = tm ^ 1;
-                SL[j].last = cell;
-                SL[j].nst += 1;
                 SL[j].depth += 1;
                 SL[j].rank = r;
+                SL[j].pad0 = r;   // for phase B2
                 SL[j].lo = clo;
                 SL[j].hi = chi;
                 if (fresh) {
@@ -1247,6 +1231,32 @@ __global__ void k_tree_step_ml(Dev E, const float *logp, const float *value, Raw
             }
         }
         __syncthreads();
+        // phase B2: wave j plays the chosen child on slot j's board (all slots side by side; wave 0 goes on to phase C,
+        // which reads none of what is written here)
+        if (w < ks && SL[w].pad0 >= 0) {
+            const int j = w, r = SL[j].pad0;
+            uint64_t st[2][kWords], occ[kWords];
+#pragma unroll
+            for (int i = 0; i < kWords; ++i) {
+                st[0][i] = SL[j].st[0][i];
+                st[1][i] = SL[j].st[1][i];
+                occ[i] = st[0][i] | st[1][i];
+            }
+            const Legal L = legal_of(E, occ, lane);
+            int action, cell;
+            const bool ok = nth_legal(E, occ, L, r, lane, action, cell);
+            if (!ok) flag(E, g, RZ_FLAG_INTERNAL, lane);
+            if (lane == 0) {
+                SL[j].pad0 = -1;
+                if (ok) {
+                    const int tm = SL[j].to_move;
+                    SL[j].st[tm][cell >> 6] |= 1ull << (cell & 63);
+                    SL[j].to_move = tm ^ 1;
+                    SL[j].last = cell;
+                    SL[j].nst += 1;
+                }
+            }
+        }
         if (w != 0) continue;
         // phase C (wave 0): new blocks for the child vectors that grew, write back what the pass changed, resolve the slots'
         // new nodes, owners of the next pass

@@ -379,6 +379,41 @@ __device__ __forceinline__ int partner_of(int x, int lane) {
     const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);
     return (int)((lane & 32) ? r[0] : r[1]);
 }
+// The value of lane l ^ OFF, the partner of __shfl_xor(x, OFF), without the LDS crossbar -- for the wave sums whose ORDER
+// of additions is part of the result (the log_softmax of the heads must give the bits of k_heads_finish): 32 / 16 by
+// v_permlane32/16_swap, 8 = a rotation of the row by 8, 4 = row_shl:4 / row_shr:4 by bit 2 of the lane, 2 / 1 by quad_perm.
+template <int OFF>
+__device__ __forceinline__ float xor_partner(float x, int lane) {
+    const int v = __float_as_int(x);
+    if (OFF == 32) return __int_as_float(partner_of<5>(v, lane));
+    if (OFF == 16) return __int_as_float(partner_of<4>(v, lane));
+    if (OFF == 8) return __int_as_float(dpp_move<0x128>(v));   // row_ror:8
+    if (OFF == 4) {
+        const int up = dpp_move<0x104>(v), down = dpp_move<0x114>(v);   // row_shl:4 (from lane + 4), row_shr:4 (from lane - 4)
+        return __int_as_float((lane & 4) ? down : up);
+    }
+    if (OFF == 2) return __int_as_float(dpp_move<0x4E>(v));
+    return __int_as_float(dpp_move<0xB1>(v));
+}
+__device__ __forceinline__ float wave_sum(float x, int lane) {   // x + partner, offsets 32, 16, .. 1: the order of the shuffle loop
+    x += xor_partner<32>(x, lane);
+    x += xor_partner<16>(x, lane);
+    x += xor_partner<8>(x, lane);
+    x += xor_partner<4>(x, lane);
+    x += xor_partner<2>(x, lane);
+    x += xor_partner<1>(x, lane);
+    return x;
+}
+__device__ __forceinline__ float wave_max(float x, int lane) {
+    x = fmaxf(x, xor_partner<32>(x, lane));
+    x = fmaxf(x, xor_partner<16>(x, lane));
+    x = fmaxf(x, xor_partner<8>(x, lane));
+    x = fmaxf(x, xor_partner<4>(x, lane));
+    x = fmaxf(x, xor_partner<2>(x, lane));
+    x = fmaxf(x, xor_partner<1>(x, lane));
+    return x;
+}
+
 template <int STAGE>
 __device__ __forceinline__ void first_max_stage(double &best, int &besti, int lane) {
     const long long b = __double_as_longlong(best);
@@ -683,17 +718,14 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
                 mx = fmaxf(mx, x[i]);
             }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+        mx = wave_max(mx, lane);
         float sum = 0.0f;
 #pragma unroll
         for (int i = 0; i < kWords; ++i) sum += (lane + 64 * i < E.A) ? expf(x[i] - mx) : 0.0f;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+        sum = wave_sum(sum, lane);
         lse = mx + logf(sum);
         float h = hid * w2;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) h += __shfl_xor(h, off);
+        h = wave_sum(h, lane);
         raw_value = tanhf(h + b2);
     }
     if (!act) return;
@@ -753,8 +785,7 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
                         noise[j] = gamma03(hash32((uint32_t)key ^ (uint32_t)(key >> 32)) + 0x9E3779B9u * (uint32_t)(64 * j + lane + 1));
                         local += noise[j];
                     }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) local += __shfl_xor(local, off);
+                local = wave_sum(local, lane);
                 noise_sum = local > 0.0f ? local : 1.0f;
                 if (lane == 0) E.noise_ctr[g] = ctr + 1;
             }
@@ -958,17 +989,14 @@ __global__ void k_tree_step_ml(Dev E, const float *logp, const float *value, Raw
                         mx = fmaxf(mx, x[i]);
                     }
                 }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+                mx = wave_max(mx, lane);
                 float sum = 0.0f;
 #pragma unroll
                 for (int i = 0; i < kWords; ++i) sum += (lane + 64 * i < A) ? expf(x[i] - mx) : 0.0f;
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+                sum = wave_sum(sum, lane);
                 lse = mx + logf(sum);
                 float h = hid * w2;
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) h += __shfl_xor(h, off);
+                h = wave_sum(h, lane);
                 val = tanhf(h + b2);
             } else {
                 val = value[gk];
@@ -1028,8 +1056,7 @@ __global__ void k_tree_step_ml(Dev E, const float *logp, const float *value, Raw
                         noise[i] = gamma03(hash32((uint32_t)key ^ (uint32_t)(key >> 32)) + 0x9E3779B9u * (uint32_t)(64 * i + lane + 1));
                         local += noise[i];
                     }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) local += __shfl_xor(local, off);
+                local = wave_sum(local, lane);
                 noise_sum = local > 0.0f ? local : 1.0f;
             }
 #pragma unroll

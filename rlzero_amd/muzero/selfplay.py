@@ -306,7 +306,9 @@ class MuZeroSelfPlay(object):
     def play_move(self):
         """One move of every environment; returns the episodes that ended with it."""
         if self.fused_moves:
-            return self._collect_fused(1)
+            finished = self._collect_fused(1)
+            self.obs = self.env.observe()
+            return finished
         t = self.torch
         obs = self.obs
         visits, root_value = self.search(obs)

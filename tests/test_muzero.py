@@ -154,6 +154,29 @@ def test_ingest_of_a_stretch_of_moves_equals_move_by_move():
     assert np.array_equal(first.actions, rec[:k0 + 1, e0, 4].astype(np.int64))
 
 
+def test_episode_sequence_is_a_lazy_view_of_the_finished_episodes():
+    """EpisodeSeq (what MuZeroSelfPlay.collect returns): length, iteration, indexing (negative, slices), lengths() and
+    extend() over chunks whose episodes lie in arbitrary order inside one flat block (the device arena's layout)."""
+    from rlzero_amd.muzero.selfplay import EpisodeSeq
+    block = np.arange(40, dtype=np.float64)
+    fields = (np.stack([block] * 4, axis=1).astype(np.float32), block.astype(np.int64), block * 0 + 1.0,
+              np.stack([block, block], axis=1).astype(np.float32), -block)
+    seq = EpisodeSeq()
+    assert len(seq) == 0 and list(seq) == [] and not seq and len(seq.lengths()) == 0
+    seq._add(fields, lengths=[3, 5, 2], first_rows=[10, 0, 30])      # three episodes out of order inside the block
+    other = EpisodeSeq()
+    other._add(tuple(f[20:26] for f in fields), lengths=[4, 2])      # contiguous episodes: rows 0-3, 4-5 of this block
+    seq.extend(other)
+    assert len(seq) == 5 and bool(seq) and list(seq.lengths()) == [3, 5, 2, 4, 2]
+    want_first = [10, 0, 30, 20, 24]
+    for i, ep in enumerate(seq):
+        assert len(ep) == seq.lengths()[i] and ep.actions[0] == want_first[i] and ep.obs.shape == (len(ep), 4)
+        assert np.array_equal(ep.root_values, -ep.actions.astype(np.float64)) and np.array_equal(seq[i].actions, ep.actions)
+    assert seq[-1].actions.tolist() == [24, 25] and [len(e) for e in seq[1:4]] == [5, 2, 4]
+    with pytest.raises(IndexError):
+        seq[5]
+
+
 def _hexf(x):
     return float(x).hex()
 

@@ -743,10 +743,10 @@ __device__ __forceinline__ void split4(const float (&z)[4], f16x4 &hi, f16x4 &lo
 // slot I of K-step S: MFMA I of the step plus (behind the first MFMAs) one load of a coming step
 // (D = depth of the ring of weight fragments: a step's fragments are requested D - 1 steps ahead -- 2 where a step has
 // 6 or more MFMAs to cover the L2 round trip, 4 for the small tiles of the channel-split variants)
-constexpr int ring_depth(int tm, int tn) { return tm * tn >= 4 ? 3 : 5; }
+constexpr int ring_depth(int tm, int tn) { return tm * tn >= 3 ? 3 : 5; }
 // (and of the ring of activation fragments: read from LDS one step ahead)
 constexpr int act_depth(int, int) { return 2; }   // (3 for the small tiles was tried: no gain, their steps are bound by the accumulator chain)
-template <int CIN, int TM, int TN, int S, int I>
+template <int CIN, int TM, int TN, int RPT, int S, int I>
 __device__ __forceinline__ void slot(f32x16 (&acc)[TM][TN], f16x8 (&a)[ring_depth(TM, TN)][TM][2], f16x8 (&b)[act_depth(TM, TN)][TN][2], lds_frag q0,
                                      lds_frag q1, __amdgpu_buffer_rsrc_t w_rsrc, int w_base, int w_lane) {
     using G = Geo<CIN>;
@@ -763,7 +763,7 @@ __device__ __forceinline__ void slot(f32x16 (&acc)[TM][TN], f16x8 (&a)[ring_dept
     if constexpr (I < 2 * TN) {
         if constexpr (S + DB - 1 < G::steps) {
             constexpr int s1 = S + DB - 1, tap = s1 / G::chunks, c = s1 % G::chunks, nn = I / 2, piece = I % 2;
-            constexpr int off = ((2 * nn + tap / 3) * kRowW + tap % 3) * G::pos_bytes + c * 32;
+            constexpr int off = ((RPT * nn + tap / 3) * kRowW + tap % 3) * G::pos_bytes + c * 32;
             static_assert(off % 16 == 0 && off < 65536, "ds_read_b128 immediate");
             b[s1 % DB][nn][piece] = (piece ? q1 : q0)[off / 16];
         }
@@ -779,18 +779,18 @@ __device__ __forceinline__ void slot(f32x16 (&acc)[TM][TN], f16x8 (&a)[ring_dept
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int CIN, int TM, int TN, int S, int... Is>
+template <int CIN, int TM, int TN, int RPT, int S, int... Is>
 __device__ __forceinline__ void step(std::integer_sequence<int, Is...>, f32x16 (&acc)[TM][TN], f16x8 (&a)[ring_depth(TM, TN)][TM][2],
                                      f16x8 (&b)[act_depth(TM, TN)][TN][2], lds_frag q0, lds_frag q1, __amdgpu_buffer_rsrc_t w_rsrc,
                                      int w_base, int w_lane) {
-    (slot<CIN, TM, TN, S, Is>(acc, a, b, q0, q1, w_rsrc, w_base, w_lane), ...);
+    (slot<CIN, TM, TN, RPT, S, Is>(acc, a, b, q0, q1, w_rsrc, w_base, w_lane), ...);
 }
 
-template <int CIN, int TM, int TN, int... Ss>
+template <int CIN, int TM, int TN, int RPT, int... Ss>
 __device__ __forceinline__ void steps(std::integer_sequence<int, Ss...>, f32x16 (&acc)[TM][TN], f16x8 (&a)[ring_depth(TM, TN)][TM][2],
                                       f16x8 (&b)[act_depth(TM, TN)][TN][2], lds_frag q0, lds_frag q1, __amdgpu_buffer_rsrc_t w_rsrc,
                                       int w_base, int w_lane) {
-    (step<CIN, TM, TN, Ss>(std::make_integer_sequence<int, 3 * TM * TN>{}, acc, a, b, q0, q1, w_rsrc, w_base, w_lane), ...);
+    (step<CIN, TM, TN, RPT, Ss>(std::make_integer_sequence<int, 3 * TM * TN>{}, acc, a, b, q0, q1, w_rsrc, w_base, w_lane), ...);
 }
 
 // The weight fragments of the first K-steps (M-tiles 0 .. TM-1): no dependence on LDS, so a layer's first
@@ -810,8 +810,8 @@ __device__ __forceinline__ void preload_w(f16x8 (&a)[ring_depth(TM, TN)][TM][2],
 // acc[m][n] = sum over taps and input channels for M-tiles 0 .. TM-1 (all output channels of the layer) and
 // N-tiles nt0 .. nt0 + TN - 1 (`in` = piece 0 of the layer's input in LDS, `a` primed by preload_w).
 // The lane's MFMA column is the position (row0 + ry, x) of the wave's first N-tile; a further tile of the wave (TN = 2
-// only) lies two rows below.
-template <int CIN, int TM, int TN>
+// only) lies two rows below (RPT rows in general: the 3 + 1 variant runs three 3-row tiles in one wave).
+template <int CIN, int TM, int TN, int RPT = 2>
 __device__ __forceinline__ void conv(const char *in, const void *wts, int row0, int ry, int x, int lane,
                                      f16x8 (&a)[ring_depth(TM, TN)][TM][2], f32x16 (&acc)[TM][TN]) {
     using G = Geo<CIN>;
@@ -826,13 +826,13 @@ __device__ __forceinline__ void conv(const char *in, const void *wts, int row0, 
         const int tap = s0 / G::chunks, c = s0 % G::chunks;
 #pragma unroll
         for (int nn = 0; nn < TN; ++nn) {
-            const int off = ((2 * nn + tap / 3) * kRowW + tap % 3) * G::pos_bytes + c * 32;
+            const int off = ((RPT * nn + tap / 3) * kRowW + tap % 3) * G::pos_bytes + c * 32;
             b[s0][nn][0] = q0[off / 16];
             b[s0][nn][1] = q1[off / 16];
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    steps<CIN, TM, TN>(std::make_integer_sequence<int, G::steps>{}, acc, a, b, q0, q1, w_rsrc, 0, lane * 16);
+    steps<CIN, TM, TN, RPT>(std::make_integer_sequence<int, G::steps>{}, acc, a, b, q0, q1, w_rsrc, 0, lane * 16);
 }
 
 }  // namespace sp
@@ -1038,11 +1038,14 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int next_board = board + (int)gridDim.x;
-    constexpr int kTiles = 4 / MS;          // waves side by side over the board's rows
-    const int tile = MS == 1 ? wave : wave % kTiles, part = MS == 1 ? 0 : wave / kTiles;
-    constexpr int TM2 = MS == 1 ? 2 : 1, TM3 = 4 / MS;   // M-tiles of conv2 / conv3 per wave
-    const int m2 = MS == 1 ? 0 : (part & 1), m3 = part * TM3;   // ... starting at
-    const bool conv2_mine = MS < 4 || part < 2;           // (conv2 has two M-tiles: with MS = 4 parts 2, 3 sit it out)
+    // MS = 3 (three N-tiles of 3 rows: 9x9): waves 0 .. 2 = the tiles with M-tiles 0 .. 2 of conv3 (and all of conv1 / conv2),
+    // wave 3 = part 1 = conv3's M-tile 3 for ALL three tiles: 9 MFMAs per K-step in every wave instead of 12 in three
+    constexpr int kTiles = MS == 3 ? 3 : 4 / MS;          // waves side by side over the board's rows
+    const int tile = MS == 1 ? wave : (MS == 3 ? (wave < 3 ? wave : 0) : wave % kTiles);
+    const int part = MS == 1 ? 0 : (MS == 3 ? (wave == 3 ? 1 : 0) : wave / kTiles);
+    constexpr int TM2 = (MS == 1 || MS == 3) ? 2 : 1, TM3 = MS == 3 ? 3 : 4 / MS;   // M-tiles of conv2 / conv3 per wave
+    const int m2 = (MS == 1 || MS == 3) ? 0 : (part & 1), m3 = MS == 3 ? 0 : part * TM3;   // ... starting at
+    const bool conv2_mine = MS == 3 ? part == 0 : (MS < 4 || part < 2);   // (conv2 has two M-tiles: with MS = 4 parts 2, 3 sit it out)
     const char *s2p = reinterpret_cast<const char *>(nd.s2) + (size_t)m2 * sp::Geo<32>::steps * 2 * 1024;
     const char *s3p = reinterpret_cast<const char *>(nd.s3) + (size_t)m3 * sp::Geo<64>::steps * 2 * 1024;
     sp::f16x8 a2[sp::ring_depth(TM2, TN)][TM2][2];
@@ -1163,7 +1166,40 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         for (int t = 0; t < TN; ++t)
 #pragma unroll
             for (int o2 = 0; o2 < 3; ++o2) vals2[t][o2] = f32x2{0.0f, 0.0f};
-        {
+        f32x2 vals3[3][3];   // MS = 3, wave 3: [tile][pair of head outputs] over the channels of M-tile 3
+        if (MS == 3 && part == 1) {
+            constexpr int kM = 3;   // the M-tile
+            const char *s3q = reinterpret_cast<const char *>(nd.s3) + (size_t)kM * sp::Geo<64>::steps * 2 * 1024;
+            sp::f16x8 a3w[sp::ring_depth(1, 3)][1][2];
+            sp::preload_w<64, 1, 3>(a3w, s3q, lane);
+            sp::f32x16 accw[1][3];
+            sp::conv<64, 1, 3, 3>(c2, s3q, 0, ry, x, lane, a3w, accw);
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int o2 = 0; o2 < 3; ++o2) vals3[t][o2] = f32x2{0.0f, 0.0f};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c0 = kM * 32 + 8 * g + 4 * h;
+                f32x4 wc[7];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) wc[i] = *reinterpret_cast<const f32x4 *>(hw + c0 * 6 + 4 * i);
+                wc[6] = *reinterpret_cast<const f32x4 *>(hw + 768 + c0);
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float hv = fmaxf(fmaf(accw[0][t][4 * g + j], k3, wc[6][j]), 0.0f);
+#pragma unroll
+                        for (int o2 = 0; o2 < 3; ++o2) {
+                            const int e = 6 * j + 2 * o2;
+                            vals3[t][o2] = __builtin_elementwise_fma(f32x2{wc[e >> 2][e & 3], wc[e >> 2][(e & 3) + 1]},
+                                                                     f32x2{hv, hv}, vals3[t][o2]);
+                        }
+                    }
+            }
+        }
+        if (MS != 3 || part == 0) {
             sp::f32x16 acc[TM3][TN];
             if (TN == 2 || busy) sp::conv<64, TM3, TN>(c2, s3p, row0, ry, x, lane, a3, acc);
             NET_TICK(5);
@@ -1213,7 +1249,22 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         // MS > 1: the 6 sums of a position are spread over MS waves (their shares of the 128 channels): they meet in LDS
         float *pad_a = reinterpret_cast<float *>(c1 + ((part * kTiles + tile) * 32 + n) * sp::Geo<32>::pos_bytes + 64);
         float *pad_b = reinterpret_cast<float *>(reinterpret_cast<char *>(pad_a) + sp::Geo<32>::piece_bytes);
-        if (MS > 1) {
+        if (MS == 3) {   // wave 3 leaves its share of every tile's sums in slot (tile, n)
+            if (part == 1) {
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    float *qa = reinterpret_cast<float *>(c1 + (t * 32 + n) * sp::Geo<32>::pos_bytes + 64);
+                    float *qb = reinterpret_cast<float *>(reinterpret_cast<char *>(qa) + sp::Geo<32>::piece_bytes);
+#pragma unroll
+                    for (int o = 0; o < 6; ++o) {
+                        float v0 = vals3[t][o >> 1][o & 1];
+                        v0 += other_half(v0, h);
+                        if (h == 0) (o < 4 ? qa[o] : qb[o - 4]) = v0;
+                    }
+                }
+            }
+            __syncthreads();
+        } else if (MS > 1) {
 #pragma unroll
             for (int o = 0; o < 6; ++o) {
                 float v0 = vals2[0][o >> 1][o & 1];
@@ -1233,7 +1284,11 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
 #pragma unroll
         for (int o = 0; o < 6; ++o) {
             float v0 = vals2[0][o >> 1][o & 1], v1 = vals2[TN - 1][o >> 1][o & 1];
-            if (MS > 1) {  // the parts' shares, in part order (every lane reads: part 0's result is the one stored)
+            if (MS == 3) {  // channels 0 .. 95 (this wave) + 96 .. 127 (wave 3's slot of this tile)
+                const float *q = o < 4 ? pad_a + o : pad_b + (o - 4);   // (part 0: slot (tile, n))
+                v0 += other_half(v0, h);
+                v0 += q[0];
+            } else if (MS > 1) {  // the parts' shares, in part order (every lane reads: part 0's result is the one stored)
                 const int stride = kTiles * 32 * sp::Geo<32>::pos_bytes / 4;   // floats from one part's slot to the next
                 const float *q = (o < 4 ? pad_a + o : pad_b + (o - 4)) - part * stride;
                 v0 = q[0];
@@ -2188,6 +2243,8 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
             k_trunk_split<1, 4><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
         else if (tiles <= 2)   // two tiles x two channel halves
             k_trunk_split<1, 2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
+        else if (tiles == 3 && net->dev.tile_rows == 3)   // 9x9: three tiles + the fourth wave on a quarter of conv3's channels
+            k_trunk_split<1, 3><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
         else if (tiles <= 4)   // four tiles cover the board: one per wave
             k_trunk_split<1><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
         else

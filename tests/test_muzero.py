@@ -299,6 +299,28 @@ def test_fused_search_other_action_counts_and_tree_placements(n_actions, n_sims)
 
 
 @pytest.mark.gpu
+def test_fused_search_does_not_depend_on_how_games_share_workgroups():
+    """A game's search is a column of the workgroup's tiles and a quad of its wave: 4, 8 or 16 games per workgroup
+    (rz_mz_set_search_shape) give bit-identical visit counts, root values and hidden states."""
+    import torch
+    from rlzero_amd.muzero import MuZeroNet, MuZeroSelfPlay
+    torch.manual_seed(21)
+    G = 53
+    net = MuZeroNet().to('cuda:0').eval()
+    obs = torch.randn(G, 4, device='cuda:0')
+    sp = MuZeroSelfPlay(net, _BareEnv(G, 2, obs), n_sims=40, seed=2, fused=True)
+    got = []
+    for gpw in (16, 8, 4, 0):
+        sp.tree.set_search_shape(gpw)
+        visits, root_value = sp.search(obs, add_noise=False)
+        got.append((visits.clone(), root_value.clone(), sp.hidden.clone(), sp.tree.root_children('value_sum')))
+    for other in got[1:]:
+        for a, b in zip(got[0], other):
+            assert torch.equal(a, b)
+    sp.close()
+
+
+@pytest.mark.gpu
 def test_fused_moves_history_ring_wraps():
     """More moves than the device ring has steps: episodes that straddle the wrap (and launches of uneven length) still come
     out as the scalar environment replays them under their recorded actions."""

@@ -693,6 +693,32 @@ def test_split_trunk_every_board_size():
         hip.close()
 
 
+def test_split_trunk_rectangular_boards():
+    """Rectangular boards through every tile shape of k_trunk_split -- (7, 9) / (8, 10) / (9, 10): three 3-row tiles = the
+    3 + 1 channel split; (6, 7) / (12, 5) / (4, 16): two tiles = two channel halves; (2, 13) / (5, 6): one tile = four
+    channel quarters; (10, 10) / (8, 3): four tiles; (13, 16) / (16, 11) / (5, 16) x ... : tiles of 2 x 16 -- against the
+    torch module in fp64 (1e-4), ragged batches on capped workgroups giving the same bits."""
+    import torch
+    from rlzero_amd.engine import HipNet
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    shapes = [(7, 9), (8, 10), (9, 10), (6, 7), (12, 5), (4, 16), (2, 13), (5, 6), (10, 10), (8, 3), (13, 16), (16, 11), (11, 12)]
+    for i, (rows, cols) in enumerate(shapes):
+        torch.manual_seed(100 + i)
+        n_actions = rows * cols
+        net = PolicyValueNet(rows, cols, n_actions)
+        hip = HipNet((rows, cols, n_actions), 'cuda:0', max_boards=64).load_state_dict(net.state_dict())
+        x = torch.randn(35, 4, rows, cols)
+        with torch.no_grad():
+            lp64, v64 = net.double()(x.double())
+        lp, v = hip.forward(x.to('cuda:0'))
+        assert np.max(np.abs(lp.cpu().numpy() - lp64.numpy())) <= 1e-4, (rows, cols)
+        assert np.max(np.abs(v.cpu().numpy() - v64.numpy()[:, 0])) <= 1e-4, (rows, cols)
+        lp3, v3 = hip.set_max_workgroups(3).forward(x.to('cuda:0'))
+        assert torch.equal(lp3, lp) and torch.equal(v3, v), (rows, cols)
+        hip.check_flags()
+        hip.close()
+
+
 def test_trunk_is_deterministic_under_load():
     """The default trunk accumulates with an inline-assembly MFMA whose register hazards are kept by hand
     (DESIGN.md section 7): a violated hazard would be timing dependent, so 60 launches of a full 512-board batch,

@@ -66,13 +66,13 @@ def executed_flop_ratio(args, cells):
     columns) + conv1's 270 f32 MFMAs."""
     if args.evaluator != 'hipnet' or args.game != 'gomoku' or args.board != 15:
         return 1.0
-    mfmas = {'winograd_f4': 6030, 'direct': 21870, 'split_f16': 4320 * 16 + 270}[args.net_algo]
+    mfmas = {'winograd_f4': 6030, 'direct': 21870, 'split_f16': 4050 * 16 + 270, 'split_f16_tiles': 4320 * 16 + 270}[args.net_algo]
     return mfmas * 2048.0 / trunk_flops_per_position(cells)
 
 
 def trunk_peak(args):
     """-> (peak TFLOP/s the trunk's ALGORITHMIC flops are priced against, peak of the pipe it executes on, note)."""
-    if args.evaluator == 'hipnet' and args.net_algo == 'split_f16':
+    if args.evaluator == 'hipnet' and args.net_algo.startswith('split_f16'):
         return (PEAK_F16_MATRIX_TFLOPS / SPLIT_MFMAS_PER_PRODUCT, PEAK_F16_MATRIX_TFLOPS,
                 'peak = dense f16 MFMA peak (2500 TFLOP/s) / 3: every f32 product costs three f16 MFMAs (operands '
                 'carried as hi + lo f16 pairs, f32 accumulation; error at the level of the exact-f32 kernel, '
@@ -511,7 +511,7 @@ def main():
                     help="hipnet: hand-written fused fp32 MFMA forward (csrc/rz_net.hip); torchnet: "
                          "PyTorch-ROCm/MIOpen; vlin: synthetic evaluator (isolates the tree kernels)")
     ap.add_argument('--graph', type=int, default=8, help='simulation steps per hipGraph (0 = eager)')
-    ap.add_argument('--net-algo', default='split_f16', choices=['winograd_f4', 'direct', 'split_f16'])
+    ap.add_argument('--net-algo', default='split_f16', choices=['winograd_f4', 'direct', 'split_f16', 'split_f16_tiles'])
     ap.add_argument('--no-games-leg', action='store_true',
                     help='skip the self-play games/s leg (after the timed steps the games of the first generation '
                          'are played to their end, slots refilled, to measure moves/s over whole games and the mean '
@@ -618,7 +618,7 @@ def main():
         (lanes * BOARDS_PER_WORKGROUP * (trunk_wgs if trunk_wgs > 0 else n_cus) if lanes > 1 and args.evaluator == 'hipnet'
          else GAMES_PER_GPU)
     heads_algo = args.heads_algo
-    if heads_algo == 'auto' and lanes > 1 and trunk_wgs == 0 and args.evaluator == 'hipnet' and args.net_algo == 'split_f16':
+    if heads_algo == 'auto' and lanes > 1 and trunk_wgs == 0 and args.evaluator == 'hipnet' and args.net_algo.startswith('split_f16'):
         heads_algo = 'parts'  # un-capped lanes: the LDS-free GEMM that fits beside a resident trunk workgroup
     lanes = max(1, min(lanes, G))
     per_lane = [G // lanes + (1 if i < G % lanes else 0) for i in range(lanes)]
@@ -637,7 +637,8 @@ def main():
             hip_ev.hip.set_max_workgroups(trunk_wgs)
             ev = TimedEvaluator(hip_ev, torch,
                                 {'winograd_f4': 'k_trunk_wino_f4<4> (hand-written fused fp32-MFMA conv trunk, Winograd F(4x4,3x3), csrc/rz_net.hip)',
-                                 'split_f16': 'k_trunk_split (hand-written fused conv trunk: direct convolution on the f16 matrix pipe, f32 operands as hi + lo f16 pairs, f32 accumulation, csrc/rz_net.hip)',
+                                 'split_f16': 'k_trunk_rows on 15-row boards, else k_trunk_split (hand-written fused conv trunk: direct convolution on the f16 matrix pipe, f32 operands as hi + lo f16 pairs, f32 accumulation, csrc/rz_net.hip)',
+                                 'split_f16_tiles': 'k_trunk_split (hand-written fused conv trunk: direct convolution on the f16 matrix pipe, f32 operands as hi + lo f16 pairs, f32 accumulation, csrc/rz_net.hip)',
                                  'direct': 'k_trunk (hand-written fused fp32-MFMA conv trunk, direct, csrc/rz_net.hip)'}[args.net_algo])
         elif args.evaluator == 'torchnet':
             ev = TimedEvaluator(NetEvaluator(net), torch, 'torch/MIOpen forward (~14 kernels)')
@@ -828,7 +829,7 @@ def main():
             'ms_per_step': round(1000.0 * elapsed / max(args.steps, 1), 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': ('f32 net (conv2/conv3 operands as hi + lo f16 pairs on the f16 MFMA pipe, f32 accumulation) / f64 tree'
-                      if args.evaluator == 'hipnet' and args.net_algo == 'split_f16' else 'f32 net / f64 tree'), 'data': 'synthetic (random-init net, torch.manual_seed(0); '
+                      if args.evaluator == 'hipnet' and args.net_algo.startswith('split_f16') else 'f32 net / f64 tree'), 'data': 'synthetic (random-init net, torch.manual_seed(0); '
             'games from the empty board)',
             'config': {'workload': ('connect4_6x7_n4_selfplay_%dsims_per_move_%dgames_per_gpu' % (args.playouts, G))
                        if args.game == 'connect4' else

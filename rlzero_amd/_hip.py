@@ -16,7 +16,7 @@ MAX_IN_FLIGHT = 16
 OK = 0
 SCORE_UCT_REF, SCORE_PUCT = 0, 1
 GAME_GOMOKU, GAME_CONNECT4 = 0, 1
-NET_DIRECT, NET_WINOGRAD_F4, NET_SPLIT_F16 = 0, 1, 2
+NET_DIRECT, NET_WINOGRAD_F4, NET_SPLIT_F16, NET_SPLIT_F16_TILES = 0, 1, 2, 3
 NET_FLAG_F16_RANGE = 1
 NET_HEADS_AUTO, NET_HEADS_F32, NET_HEADS_SPLIT_32, NET_HEADS_SPLIT_64, NET_HEADS_SPLIT_PARTS = 0, 1, 2, 3, 4
 EVAL_V0, EVAL_VLIN = 0, 1

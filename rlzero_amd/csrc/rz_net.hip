@@ -55,6 +55,7 @@ struct NetDev {
     const f32x4 *u2f, *u3f;      // F(4x4,3x3): [tile][pass][cin_step][3][64 lanes] x 4 components (pack_wino_f4)
     const f32x4 *s1;             // conv1 for k_trunk_split: [kernel row][hi | lo][64 lanes] x 8 f16 (pack_split1)
     const f32x4 *s2, *s3;        // split f16 weights: [32-channel tile][tap][16-channel chunk][hi | lo][64 lanes] x 8 f16
+    const f32x4 *t2, *t3;        // the same for k_trunk_rows: [16-channel tile][tap][32-channel chunk][hi | lo][64 lanes] x 8 f16 (pack_rows)
     const float *s_inv;          // [8] in device memory (a captured launch must see a reload's values), with a1, a2, a3 =
                                  // the activation scales of conv1's / conv2's outputs and of the head features (powers of
                                  // two from rz_net_load's activation bounds), sw* the weight scales:
@@ -1333,6 +1334,437 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     if (!(zmax <= 65504.0f)) atomicOr(flags, (unsigned)RZ_NET_FLAG_F16_RANGE);
 }
 
+// ------------------------------------------------------------------ row-tile trunk (wide boards: 11 .. 16 columns)
+// The arithmetic of k_trunk_split (hi + lo f16 operands, three MFMAs per product, f32 accumulation) on
+// v_mfma_f32_16x16x32_f16 with the work split over the waves by OUTPUT CHANNEL instead of by board row:
+//   * N-tile = ONE board row (16 columns), K-step = 32 input channels of one tap, M-tile = 16 output channels.  A 15 x 15
+//     board is 15 N-tiles (240 MFMA columns for 225 positions) where 2-row x 16-column tiles of the 32 x 32 MFMA need 8 x 32 =
+//     256, and no wave owns a row that does not exist.
+//   * wave w owns output channels 16 w .. 16 w + 15 of conv2 and 32 w .. 32 w + 31 of conv3 for ALL rows: every weight
+//     fragment is fetched by one wave instead of four (L2 -> CU traffic of conv3: 295 KB per board instead of 1.18 MB), the
+//     activation fragments (LDS) by all four.
+//   * the chip holds a higher clock in this MFMA shape (profiles/r03/conv3_shapes.txt: the conv3 loop on every CU, random
+//     data: 1.75 GHz against 1.52 GHz and 6 % fewer cycles: 17.1 against 20.5 us per board).
+// LDS: a position's record is [hi: CIN f16][lo: CIN f16][32 bytes of padding] (160 / 288 bytes): lane = 16 * (k block) +
+// column reads the 8 channels of its k block with one ds_read_b128, and record size / 16 = 2 (mod 4) puts the 16 lanes of
+// every LDS cycle on 16 different 16-byte slots.  The head convolutions: a lane holds 8 of the 128 channels of a position,
+// so the 6 sums of a position are spread over 4 lanes x 4 waves: lanes meet by v_permlane16/32_swap (reduce-scatter), waves
+// in LDS (inside the board positions of conv1's region, which the next board overwrites anyway); thread = cell then adds
+// the four waves' shares in wave order and stores the features.
+namespace rt {
+
+using sp::f16x4;
+using sp::f16x8;
+using sp::lds_frag;
+
+template <int CIN> struct Geo {
+    static constexpr int pos_bytes = 4 * CIN + 32;               // 160 / 288
+    static constexpr int grid_bytes = sp::kGridPos * pos_bytes;  // 51 840 / 93 312
+    static constexpr int chunks = CIN / 32, steps = 9 * chunks;
+    static_assert((pos_bytes / 16) % 4 == 2, "conflict-free ds_read_b128");
+};
+constexpr int kLA = 3;   // activation fragments are requested kLA rows ahead
+constexpr int kAD = 2;   // weight fragments: the next K-step's while this one computes
+constexpr int kLdsBytes = sp::kInBytes + Geo<32>::grid_bytes + Geo<64>::grid_bytes;
+static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
+
+// slot J = (K-step s, row t): its 3 * TM MFMAs; in front of them the activation fragments of slot J + kLA and, behind the
+// first rows of a step, the weight fragments of step s + 1
+template <int CIN, int TM, int NT, int J>
+__device__ __forceinline__ void slot(f32x4 (&acc)[TM][NT], f16x8 (&a)[kAD][TM][2], f16x8 (&b)[kLA + 1][2], lds_frag q, lds_frag qf,
+                                     __amdgpu_buffer_rsrc_t w_rsrc, int w_lane) {
+    using G = Geo<CIN>;
+    constexpr int PD = kLA + 1, s = J / NT, t = J % NT, J2 = J + kLA;
+    if constexpr (J2 < G::steps * NT) {
+        constexpr int s2 = J2 / NT, t2 = J2 % NT, tap = s2 / G::chunks, c = s2 % G::chunks;
+        constexpr int row = t2 + tap / 3, far = row >= 8;   // (qf = q + 8 halo rows: the immediate offset has 16 bits)
+        constexpr int off = ((row - 8 * far) * kRowW + tap % 3) * G::pos_bytes + c * 64;
+        static_assert(off % 16 == 0 && off + CIN * 2 < 65536, "ds_read_b128 immediate");
+        b[J2 % PD][0] = (far ? qf : q)[off / 16];
+        b[J2 % PD][1] = (far ? qf : q)[(off + CIN * 2) / 16];
+    }
+    if constexpr (s + 1 < G::steps && t < TM) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) a[(s + 1) % kAD][t][p] = sp::load_w(w_rsrc, w_lane, ((t * G::steps + s + 1) * 2 + p) * 1024);
+    }
+#pragma unroll
+    for (int combo = 0; combo < 3; ++combo)
+#pragma unroll
+        for (int m = 0; m < TM; ++m) {
+            const int pa = combo == 2 ? 1 : 0, pb = combo == 1 ? 1 : 0;
+            if (s == 0 && combo == 0) {   // the first MFMA of a tile starts from the constant 0
+                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s % kAD][m][pa], b[J % PD][pb], zero, 0, 0, 0);
+            } else {
+                acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s % kAD][m][pa], b[J % PD][pb], acc[m][t], 0, 0, 0);
+            }
+        }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int CIN, int TM, int NT, int... Js>
+__device__ __forceinline__ void slots(std::integer_sequence<int, Js...>, f32x4 (&acc)[TM][NT], f16x8 (&a)[kAD][TM][2],
+                                      f16x8 (&b)[kLA + 1][2], lds_frag q, lds_frag qf, __amdgpu_buffer_rsrc_t w_rsrc, int w_lane) {
+    (slot<CIN, TM, NT, Js>(acc, a, b, q, qf, w_rsrc, w_lane), ...);
+}
+
+// the weight fragments of K-step 0 (no dependence on LDS: requested while the previous layer is being reduced)
+template <int CIN, int TM>
+__device__ __forceinline__ void preload_w(f16x8 (&a)[kAD][TM][2], const void *wts, int lane) {
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(wts), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) a[0][m][p] = sp::load_w(w_rsrc, lane * 16, (m * Geo<CIN>::steps * 2 + p) * 1024);
+}
+
+// acc[m][t] = sum over taps and input channels for the wave's TM M-tiles (`wts` = their fragments) and board rows 0 .. NT - 1;
+// lane = 16 g + n: MFMA column n = board column, k block g = input channels 8 g .. 8 g + 7 of a chunk of 32
+template <int CIN, int TM, int NT>
+__device__ __forceinline__ void conv(const char *in, const void *wts, int lane, f16x8 (&a)[kAD][TM][2], f32x4 (&acc)[TM][NT]) {
+    using G = Geo<CIN>;
+    static_assert(TM <= NT && kLA <= NT, "loads are spread over a step's first rows");
+    const int n = lane & 15, g = lane >> 4;
+    // halo position (t, n) = the top-left tap of output (t, n)
+    const lds_frag q = (lds_frag)(in + n * G::pos_bytes + g * 16), qf = q + 8 * kRowW * G::pos_bytes / 16;
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(wts), 0, 0x7fffffff, 0x00020000);
+    f16x8 b[kLA + 1][2];
+#pragma unroll
+    for (int j = 0; j < kLA; ++j) {   // slots 0 .. kLA - 1: K-step 0 (tap 0, chunk 0), rows 0 ..
+        b[j][0] = q[(j * kRowW * G::pos_bytes) / 16];
+        b[j][1] = q[(j * kRowW * G::pos_bytes + CIN * 2) / 16];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    slots<CIN, TM, NT>(std::make_integer_sequence<int, G::steps * NT>{}, acc, a, b, q, qf, w_rsrc, lane * 16);
+}
+
+}  // namespace rt
+
+template <int NT, bool BITS>
+__global__ __launch_bounds__(256) void k_trunk_rows(NetDev nd, const float *__restrict__ obs, LeafBits leaves,
+                                                    float *__restrict__ feat, _Float16 *__restrict__ feat16,
+                                                    int n_boards, unsigned *__restrict__ flags) {
+#ifdef RZ_NET_PROFILE
+    const long long prof_k0 = __builtin_readcyclecounter();
+    long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = prof_k0;
+#endif
+    constexpr int kThreads = 256;
+    constexpr int P1 = rt::Geo<32>::pos_bytes, P2 = rt::Geo<64>::pos_bytes;
+    __shared__ __attribute__((aligned(16))) char lds_raw[rt::kLdsBytes];
+    char *in0 = lds_raw;                      // observation planes, pieces hi | lo (as k_trunk_split)
+    char *c1 = lds_raw + sp::kInBytes;        // conv1 output, records [hi 32 | lo 32 | pad]
+    char *c2 = c1 + rt::Geo<32>::grid_bytes;  // conv2 output, records [hi 64 | lo 64 | pad]
+    const int tid0 = threadIdx.x;
+    const int BH = nd.BH, BW = nd.BW, S = nd.S;
+    float zmax = 0.0f;  // largest scaled value this thread stored as f16 pieces (float planes only: bitboard planes are 0 / 1)
+    constexpr int kObsPer = BITS ? 1 : (4 * RZ_MAX_BOARD_SIZE * RZ_MAX_BOARD_SIZE + kThreads - 1) / kThreads;
+    float ob[kObsPer];
+    int obs_off[kObsPer];
+    if constexpr (!BITS) {
+#pragma unroll
+        for (int k = 0; k < kObsPer; ++k) {
+            const int i = tid0 + k * kThreads;
+            const int c = i / S, r = i - c * S, y = r / BW, x = r - y * BW;
+            obs_off[k] = i < 4 * S ? ((y + 1) * sp::kInCols + (x + 1)) * 8 + c * 2 : -1;
+        }
+    }
+    auto load_obs = [&](int board, int tid) {
+        if constexpr (!BITS) {
+            const float *src = obs + (size_t)board * 4 * S;
+#pragma unroll
+            for (int k = 0; k < kObsPer; ++k) {
+                const int i = tid + k * kThreads;
+                ob[k] = i < 4 * S ? src[i] : 0.0f;
+            }
+        }
+    };
+    // thread t owns cell t (S <= 256 = threads): the planes of the bitboard route, and the cell whose features it stores
+    const int cell_y = tid0 / BW, cell_x = tid0 - cell_y * BW;
+    const int cell_off = tid0 < S ? ((cell_y + 1) * sp::kInCols + (cell_x + 1)) * 8 : -1;
+    sp::f16x4 cell_planes = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+    auto load_bits = [&](int board, int tid) {
+        const uint64_t *sb = leaves.stones + (size_t)board * 8;
+        const int tm = leaves.to_move[board], lc = leaves.last[board];
+        int nst = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) nst += __popcll(sb[q]);  // (uniform address: scalar loads)
+        const int word = (tid >> 6) & 3, bit = tid & 63;
+        const uint64_t w0 = sb[word], w1 = sb[4 + word];
+        const bool s0 = (w0 >> bit) & 1ull, s1 = (w1 >> bit) & 1ull;
+        const bool mine = tm == 0 ? s0 : s1, theirs = tm == 0 ? s1 : s0;
+        const _Float16 one = (_Float16)sp::kObsScale, zero = (_Float16)0.0f;
+        cell_planes[0] = mine ? one : zero;
+        cell_planes[1] = theirs ? one : zero;
+        cell_planes[2] = (nst > 0 && tid == lc) ? one : zero;
+        cell_planes[3] = (nst & 1) ? zero : one;
+    };
+    auto load_board = [&](int board, int tid) {
+        if constexpr (BITS) load_bits(board, tid); else load_obs(board, tid);
+    };
+    auto store_obs = [&]() {
+        if constexpr (BITS) {
+            if (cell_off >= 0) {
+                *reinterpret_cast<sp::f16x4 *>(in0 + cell_off) = cell_planes;
+                *reinterpret_cast<sp::f16x4 *>(in0 + sp::kInPieceBytes + cell_off) =
+                    sp::f16x4{(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kObsPer; ++k)
+                if (obs_off[k] >= 0) {
+                    const float z = ob[k] * sp::kObsScale;
+                    const _Float16 hi = (_Float16)z;
+                    zmax = fmaxf(zmax, fabsf(z));
+                    *reinterpret_cast<_Float16 *>(in0 + obs_off[k]) = hi;
+                    *reinterpret_cast<_Float16 *>(in0 + sp::kInPieceBytes + obs_off[k]) = (_Float16)(z - (float)hi);
+                }
+        }
+    };
+    // Prologue of a persistent workgroup: every global load is issued first, the LDS is zeroed under their latency.
+    const int lane0 = tid0 & 63, wave0 = tid0 >> 6, g0 = lane0 >> 4;
+    // the 1x1 head convolutions: the lane's 8 channels of conv3 (32 wave + 16 m + 4 g + j) meet 6 outputs each -- 48 weights
+    // and 8 biases that never change: registers for the whole launch
+    f32x4 hwr[2][6], b3r[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int c0 = 32 * wave0 + 16 * m + 4 * g0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) hwr[m][i] = *reinterpret_cast<const f32x4 *>(nd.whp + c0 * 6 + 4 * i);
+        b3r[m] = *reinterpret_cast<const f32x4 *>(nd.b3 + c0);
+    }
+    float hb[6];
+#pragma unroll
+    for (int o = 0; o < 6; ++o) hb[o] = nd.bh[o];
+    const float k1 = nd.s_inv[2], k2 = nd.s_inv[0], k3 = nd.s_inv[1];
+    const float act1 = nd.s_inv[5], act2 = nd.s_inv[6], act3 = nd.s_inv[7];
+    // conv1's weights (3 kernel rows x hi / lo) and biases stay in registers for all boards (32 x 32 x 16 tiles, as k_trunk_split)
+    sp::f16x8 a1[3][2];
+    f32x4 bias1[4];
+    {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int p_ = 0; p_ < 2; ++p_) a1[ky][p_] = __builtin_bit_cast(sp::f16x8, nd.s1[(ky * 2 + p_) * 64 + lane0]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias1[g] = *reinterpret_cast<const f32x4 *>(nd.b1 + 8 * g + 4 * (lane0 >> 5)) * act1;
+    }
+    const f32x4 bias2 = *reinterpret_cast<const f32x4 *>(nd.b2 + 16 * wave0 + 4 * g0) * act2;
+    const bool first = (int)blockIdx.x < n_boards;
+    if (first) load_board(blockIdx.x, tid0);
+    __builtin_amdgcn_sched_barrier(0);  // the loads above stay above the zeroing
+    NET_TICK(11);
+    {
+        // what a valid position reads and no board writes must be zero: the observation planes' halo (all of in0) and, in
+        // c1 / c2, the ring of positions around the board (whole records)
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 *z = reinterpret_cast<f32x4 *>(lds_raw);
+        for (int i = tid0; i < sp::kInBytes / 16; i += kThreads) z[i] = zero;
+        const int n_ring = 2 * (BW + 2) + 2 * BH;
+        for (int idx = tid0; idx < n_ring; idx += kThreads) {
+            int py, px;
+            if (idx < 2 * (BW + 2)) {
+                const int bottom = idx >= BW + 2;
+                py = bottom ? BH + 1 : 0;
+                px = idx - bottom * (BW + 2);
+            } else {
+                const int j = idx - 2 * (BW + 2);
+                py = 1 + (j >> 1);
+                px = (j & 1) ? BW + 1 : 0;
+            }
+            const int pos = py * kRowW + px;
+            f32x4 *q1 = reinterpret_cast<f32x4 *>(c1 + pos * P1);
+#pragma unroll
+            for (int i = 0; i < P1 / 16; ++i) q1[i] = zero;
+            f32x4 *q2 = reinterpret_cast<f32x4 *>(c2 + pos * P2);
+#pragma unroll
+            for (int i = 0; i < P2 / 16; ++i) q2[i] = zero;
+        }
+    }
+    NET_TICK(12);
+    __syncthreads();
+    NET_TICK(13);
+    if (first) store_obs();
+    NET_TICK(14);
+    __syncthreads();
+#ifdef RZ_NET_PROFILE
+    NET_TICK(15);
+    prof_acc[9] = prof_t - prof_k0;   // the prologue
+#endif
+    for (int board = blockIdx.x; board < n_boards; board += gridDim.x) {
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int next_board = board + (int)gridDim.x;
+    const int n = lane & 15, g = lane >> 4;
+    const char *t2p = reinterpret_cast<const char *>(nd.t2) + (size_t)wave * rt::Geo<32>::steps * 2 * 1024;
+    const char *t3p = reinterpret_cast<const char *>(nd.t3) + (size_t)(2 * wave) * rt::Geo<64>::steps * 2 * 1024;
+    sp::f16x8 a2[rt::kAD][1][2];
+    rt::preload_w<32, 1>(a2, t2p, lane);
+    {   // conv1: 4 -> 32 on 32 x 32 x 16 tiles of 2 rows x 16 columns, wave w = rows 4 w .. 4 w + 3; K-step = kernel row
+        const int n32 = lane & 31, h = lane >> 5, ry = n32 >> 4, x = n32 & 15, row0 = 4 * wave;
+        if (row0 < BH) {
+            typedef const __attribute__((address_space(3))) sp::f16x4 *lds_half;
+            const lds_half q = (lds_half)(in0 + ((row0 + ry) * sp::kInCols + x + 2 * h) * 8);
+            sp::f16x8 b1[3][2][2];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int p_ = 0; p_ < 2; ++p_) {
+                        const int o = ((2 * t + ky) * sp::kInCols * 8 + p_ * sp::kInPieceBytes) / 8;
+                        const sp::f16x4 lo4 = q[o], hi4 = q[o + 1];
+                        b1[ky][t][p_] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+                    }
+            sp::f32x16 acc1[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc1[t][r] = 0.0f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int combo = 0; combo < 3; ++combo) {
+                    if (BITS && combo == 1) continue;   // the lo pieces of 0 / 1 planes are zero
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        acc1[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ky][combo == 2], b1[ky][t][combo == 1], acc1[t], 0, 0, 0);
+                }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int y = row0 + 2 * t + ry;
+                if (y < BH && x < BW) {
+                    char *pos = c1 + ((y + 1) * kRowW + (x + 1)) * P1 + 4 * h * 2;
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        float z[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) z[j] = fmaxf(fmaf(acc1[t][4 * gg + j], k1, bias1[gg][j]), 0.0f);
+                        if constexpr (!BITS) zmax = fmaxf(fmaxf(zmax, fmaxf(z[0], z[1])), fmaxf(z[2], z[3]));
+                        sp::f16x4 hi, lo;
+                        sp::split4(z, hi, lo);
+                        *reinterpret_cast<sp::f16x4 *>(pos + 8 * gg * 2) = hi;
+                        *reinterpret_cast<sp::f16x4 *>(pos + 8 * gg * 2 + 64) = lo;
+                    }
+                }
+            }
+        }
+    }
+    NET_TICK(0);
+    __syncthreads();
+    NET_TICK(1);
+    if (next_board < n_boards) load_board(next_board, tid);
+    sp::f16x8 a3[rt::kAD][2][2];
+    {   // conv2: 32 -> 64, wave w = output channels 16 w .. 16 w + 15
+        f32x4 acc[1][NT];
+        rt::conv<32, 1, NT>(c1, t2p, lane, a2, acc);
+        NET_TICK(2);
+        rt::preload_w<64, 2>(a3, t3p, lane);
+        if (n < BW) {
+            char *pos = c2 + (kRowW + n + 1) * P2 + (16 * wave + 4 * g) * 2;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                float z[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) z[j] = fmaxf(fmaf(acc[0][t][j], k2, bias2[j]), 0.0f);
+                if constexpr (!BITS) zmax = fmaxf(fmaxf(zmax, fmaxf(z[0], z[1])), fmaxf(z[2], z[3]));
+                sp::f16x4 hi, lo;
+                sp::split4(z, hi, lo);
+                *reinterpret_cast<sp::f16x4 *>(pos + t * kRowW * P2) = hi;
+                *reinterpret_cast<sp::f16x4 *>(pos + t * kRowW * P2 + 128) = lo;
+            }
+        }
+    }
+    if (next_board < n_boards) store_obs();
+    NET_TICK(3);
+    __syncthreads();
+    NET_TICK(4);
+    // the waves' shares of the head sums: rows of 16 floats [wave][output], inside the board positions of halo row t + 1 of c1
+    constexpr int kShare = 6 * 64;   // bytes of a wave's share of one board row
+    {   // conv3: 64 -> 128, wave w = output channels 32 w .. 32 w + 31; its ReLU'd output feeds the two 1x1 head convolutions
+        float vals[96];   // [row t][output o]: the lane's 8 channels of position (t, n)
+        {
+            f32x4 acc[2][NT];
+            rt::conv<64, 2, NT>(c2, t3p, lane, a3, acc);
+            NET_TICK(5);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                f32x2 v2[3] = {f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}, f32x2{0.0f, 0.0f}};
+                if (t < NT) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float hv = fmaxf(fmaf(acc[m][t < NT ? t : 0][j], k3, b3r[m][j]), 0.0f);
+#pragma unroll
+                            for (int o2 = 0; o2 < 3; ++o2) {
+                                const int e = 6 * j + 2 * o2;  // float index of (channel j, outputs 2 o2, 2 o2 + 1)
+                                v2[o2] = __builtin_elementwise_fma(f32x2{hwr[m][e >> 2][e & 3], hwr[m][e >> 2][(e & 3) + 1]},
+                                                                   f32x2{hv, hv}, v2[o2]);
+                            }
+                        }
+                }
+#pragma unroll
+                for (int o = 0; o < 6; ++o) vals[t * 6 + o] = v2[o >> 1][o & 1];
+            }
+        }
+        // sum over the 4 k blocks (lanes n, n + 16, n + 32, n + 48); lane group g is left with rows 8 (g & 1) + 4 (g >> 1) + 0 .. 3
+        float mine[24];
+        f4::reduce_scatter_96(vals, mine);
+        const int t0 = 8 * (g & 1) + 4 * (g >> 1);
+        float *share = reinterpret_cast<float *>(c1 + ((t0 + 1) * kRowW + 1) * P1 + wave * kShare) + n;
+#pragma unroll
+        for (int i = 0; i < 24; ++i)
+            if (t0 + i / 6 < NT) share[(i / 6) * (kRowW * P1 / 4) + (i % 6) * 16] = mine[i];
+    }
+    NET_TICK(6);
+    __syncthreads();
+    {
+        float *dst = feat ? feat + (size_t)board * nd.feat_ld : nullptr;  // null: only the f16 pieces are wanted
+        _Float16 *dst16 = feat16 ? feat16 + ((size_t)(board >> 5) * (nd.groups_act + nd.groups_val) * 1024 + (board & 31) * 16)
+                                 : nullptr;
+        if (tid < S) {
+            const float *share = reinterpret_cast<const float *>(c1 + ((cell_y + 1) * kRowW + 1) * P1) + cell_x;
+            float vsum[6];
+#pragma unroll
+            for (int o = 0; o < 6; ++o) {
+                float v = share[o * 16];
+#pragma unroll
+                for (int w = 1; w < 4; ++w) v += share[w * (kShare / 4) + o * 16];
+                vsum[o] = v;
+            }
+            const int cell = tid;
+#pragma unroll
+            for (int o = 0; o < 6; ++o) {
+                const float v = fmaxf(vsum[o] + hb[o], 0.0f);
+                if (dst) dst[(o < 4 ? o * S : nd.feat_val_off + (o - 4) * S) + cell] = v;
+                if (dst16) {
+                    const int k = (o < 4 ? o : o - 4) * S + cell;
+                    const int step = (o < 4 ? 0 : nd.groups_act) + (k >> 4);
+                    const float z = v * act3;
+                    const _Float16 zh = (_Float16)z;
+                    if constexpr (!BITS) zmax = fmaxf(zmax, z);
+                    _Float16 *q = dst16 + (size_t)step * 1024 + (k & 15);
+                    q[0] = zh;
+                    q[512] = (_Float16)(z - (float)zh);
+                }
+            }
+        }
+    }
+    NET_TICK(7);
+    __syncthreads();   // the shares are read: the next board's conv1 may overwrite them
+    NET_TICK(8);
+    }  // boards
+#ifdef RZ_NET_PROFILE
+    if (blockIdx.x == 0 && tid0 == 0) {
+        for (int i = 0; i < 16; ++i) net_prof[i] = prof_acc[i];
+        net_prof[10] = __builtin_readcyclecounter() - prof_k0;
+    }
+#endif
+    if constexpr (!BITS)
+        if (!(zmax <= 65504.0f)) atomicOr(flags, (unsigned)RZ_NET_FLAG_F16_RANGE);
+}
+
 // Direct path: wave w = 4*rh + q4 owns output-channel quarter q4 (the two waves of a quarter share
 // a SIMD, waves are dealt to SIMDs cyclically) and row half rh (rows 0-7 / 8-15; on a 15x15 board
 // the second half computes 7 rows, so every SIMD carries exactly 15 row-units of each layer).
@@ -1916,6 +2348,28 @@ std::vector<f32x4> pack_split(const float *w, int cout, int cin, float *scale_ou
     return out;
 }
 
+// The same weights for k_trunk_rows (scale as pack_split: the two kernels share the rescaling factors).  Packed
+// [tile of 16 cout][step = tap * chunks + chunk of 32 cin][piece][lane] x 8 f16: lane = g*16 + r holds
+// W[16*tile + r][32*chunk + 8*g + j][tap], j = 0..7 (the A fragment of v_mfma_f32_16x16x32_f16).
+std::vector<f32x4> pack_rows(const float *w, int cout, int cin, float scale) {
+    const int tiles = cout / 16, chunks = cin / 32, steps = 9 * chunks;
+    std::vector<f32x4> out((size_t)tiles * steps * 2 * 64);
+    _Float16 *o = reinterpret_cast<_Float16 *>(out.data());
+    for (int t = 0; t < tiles; ++t)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int c = 0; c < chunks; ++c)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int r = lane & 15, g = lane >> 4, s = tap * chunks + c;
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = w[((size_t)(16 * t + r) * cin + (32 * c + 8 * g + j)) * 9 + tap] * scale;
+                        const _Float16 hi = (_Float16)v;
+                        o[((((size_t)t * steps + s) * 2 + 0) * 64 + lane) * 8 + j] = hi;
+                        o[((((size_t)t * steps + s) * 2 + 1) * 64 + lane) * 8 + j] = (_Float16)(v - (float)hi);
+                    }
+                }
+    return out;
+}
+
 // conv1 (32 x 4 x 3 x 3) for k_trunk_split: K-step = kernel row ky, k = 4 * kx + plane for kx = 0..3 (kx = 3: zero
 // padding); lane = h*32 + r holds k = 8*h .. 8*h + 7 of output channel r.  [ky][hi | lo][lane] x 8 f16.
 std::vector<f32x4> pack_split1(const float *w, float *scale_out) {
@@ -2081,6 +2535,8 @@ int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params) {
         float sw2 = 1.0f, sw3 = 1.0f;
         up_vec4(pack_split(h_params[2], 64, 32, &sw2), &D.s2);
         up_vec4(pack_split(h_params[4], 128, 64, &sw3), &D.s3);
+        up_vec4(pack_rows(h_params[2], 64, 32, sw2), &D.t2);
+        up_vec4(pack_rows(h_params[4], 128, 64, sw3), &D.t3);
         float sw1 = 1.0f;
         up_vec4(pack_split1(h_params[0], &sw1), &D.s1);
         float sfa = 1.0f, sfv = 1.0f;
@@ -2212,6 +2668,9 @@ int rz_net_reserve(rz_net *net, int32_t max_boards) {
     return RZ_OK;
 }
 
+// k_trunk_rows is instantiated for 15 rows (the 15 x 15 Gomoku board of the BASELINE configuration and its 11 .. 16 column kin)
+static bool rows_kernel_covers(int bh, int bw) { return bh == 15 && bw >= 11 && bw <= 16; }
+
 static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t n_boards, void *stream,
                          LeafBits leaves = LeafBits{nullptr, nullptr, nullptr}) {
     const dim3 grid((unsigned)n_boards);
@@ -2220,7 +2679,8 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
     // the split-f16 trunk writes what the FC GEMM behind it reads: the f16 pieces, and the f32 features only for a
     // caller's buffer or when the f32 GEMM is forced
     // a net whose weights give no finite activation bound (rz_net_load) never runs on the f16 pipe
-    const int algo = (net->algo == RZ_NET_SPLIT_F16 && !net->split_ok) ? RZ_NET_DIRECT : net->algo;
+    const bool split_algo = net->algo == RZ_NET_SPLIT_F16 || net->algo == RZ_NET_SPLIT_F16_TILES;
+    const int algo = (split_algo && !net->split_ok) ? RZ_NET_DIRECT : (split_algo ? RZ_NET_SPLIT_F16 : net->algo);
     const bool split = algo == RZ_NET_SPLIT_F16;
     const bool want_f32 = !split || !internal || net->heads_algo == RZ_NET_HEADS_F32;
     if (internal) {
@@ -2239,7 +2699,11 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
         _Float16 *f16 = internal ? net->d_feat16 : nullptr;
         float *f32 = want_f32 ? d_feat : nullptr;
         const int tiles = (net->dev.BH + net->dev.tile_rows - 1) / net->dev.tile_rows;
-        if (tiles <= 1)        // one tile: the four waves share the output channels
+        const bool bits = leaves.stones != nullptr;
+        if (net->algo == RZ_NET_SPLIT_F16 && rows_kernel_covers(net->dev.BH, net->dev.BW)) {   // wide boards: one N-tile per row
+            if (bits) k_trunk_rows<15, true><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
+            else k_trunk_rows<15, false><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
+        } else if (tiles <= 1)        // one tile: the four waves share the output channels
             k_trunk_split<1, 4><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
         else if (tiles <= 2)   // two tiles x two channel halves
             k_trunk_split<1, 2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
@@ -2320,7 +2784,7 @@ int rz_net_trunk_leaves(rz_net *net, const uint64_t *d_stones, const int32_t *d_
     if (n_boards == 0) return RZ_OK;
     if (!d_stones || !d_to_move || !d_last_cell) return net_fail(RZ_ERR_ARG, "NULL device pointer");
     if (n_boards > net->feat_boards) return net_fail(RZ_ERR_ARG, "batch larger than rz_net_reserve()d");
-    if (net->algo != RZ_NET_SPLIT_F16 || !net->split_ok)
+    if ((net->algo != RZ_NET_SPLIT_F16 && net->algo != RZ_NET_SPLIT_F16_TILES) || !net->split_ok)
         return net_fail(RZ_ERR_ARG, "rz_net_trunk_leaves needs the RZ_NET_SPLIT_F16 trunk (the others read float planes: rz_net_trunk)");
     launch_trunk(net, nullptr, net->d_feat, n_boards, stream, LeafBits{d_stones, d_to_move, d_last_cell});
     if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_trunk_split failed");
@@ -2329,7 +2793,7 @@ int rz_net_trunk_leaves(rz_net *net, const uint64_t *d_stones, const int32_t *d_
 
 int rz_net_set_algo(rz_net *net, int32_t algo) {
     if (!net) return net_fail(RZ_ERR_ARG, "net handle is NULL");
-    if (algo != RZ_NET_DIRECT && algo != RZ_NET_WINOGRAD_F4 && algo != RZ_NET_SPLIT_F16)
+    if (algo != RZ_NET_DIRECT && algo != RZ_NET_WINOGRAD_F4 && algo != RZ_NET_SPLIT_F16 && algo != RZ_NET_SPLIT_F16_TILES)
         return net_fail(RZ_ERR_ARG, "unknown algorithm");
     net->algo = algo;
     return RZ_OK;

@@ -104,8 +104,10 @@ class HipNet(object):
     def set_algo(self, algo):
         """conv2 / conv3 algorithm: 'split_f16' (default: direct convolution on the f16 matrix pipe, every f32
         operand carried as a hi + lo pair of f16 values, f32 accumulation -- as accurate as 'direct'), or on the
-        f32-input MFMA: 'winograd_f4' (F(4x4,3x3)) or 'direct' (bit-for-bit a k-ordered fmaf chain)."""
-        code = {'direct': _hip.NET_DIRECT, 'winograd_f4': _hip.NET_WINOGRAD_F4, 'split_f16': _hip.NET_SPLIT_F16}[algo]
+        f32-input MFMA: 'winograd_f4' (F(4x4,3x3)) or 'direct' (bit-for-bit a k-ordered fmaf chain).  'split_f16_tiles'
+        is 'split_f16' with the 32 x 32 x 16 tile kernel on every board size (15-row boards otherwise run the row-tile kernel)."""
+        code = {'direct': _hip.NET_DIRECT, 'winograd_f4': _hip.NET_WINOGRAD_F4, 'split_f16': _hip.NET_SPLIT_F16,
+                'split_f16_tiles': _hip.NET_SPLIT_F16_TILES}[algo]
         check(self.lib.rz_net_set_algo(self.handle, code), 'rz_net_set_algo')
         self.algo = algo
         return self
@@ -113,7 +115,7 @@ class HipNet(object):
     def reads_positions(self):
         """True when the trunk can be fed the engine's leaf bitboards (rz_net_trunk_leaves): the 'split_f16' trunk of a
         net with finite activation bounds.  The tree kernels then write no observation planes at all."""
-        return getattr(self, 'algo', 'split_f16') == 'split_f16' and getattr(self, '_split_ok', True)
+        return getattr(self, 'algo', 'split_f16') in ('split_f16', 'split_f16_tiles') and getattr(self, '_split_ok', True)
 
     def trunk_leaves(self, eng):
         """The trunk on the engine's current leaves, read as bitboards (no float planes), into the internal buffer."""

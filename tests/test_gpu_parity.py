@@ -719,6 +719,41 @@ def test_split_trunk_rectangular_boards():
         hip.close()
 
 
+def test_row_tile_trunk_on_15_row_boards():
+    """k_trunk_rows (boards of 15 rows, 11 .. 16 columns: v_mfma_f32_16x16x32_f16, one N-tile per board row, the waves
+    split the output channels) against the torch module in fp64 (1e-4 on log-probabilities and values, random non-0/1
+    inputs) and against k_trunk_split on the same boards ('split_f16_tiles': the same hi + lo arithmetic in another
+    summation order -- f32 accumulation rounding apart); ragged batches on capped workgroups give the same bits."""
+    import torch
+    from rlzero_amd.engine import HipNet
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    for i, cols in enumerate(range(11, 17)):
+        rows = 15
+        torch.manual_seed(300 + i)
+        n_actions = rows * cols
+        net = PolicyValueNet(rows, cols, n_actions)
+        hip = HipNet((rows, cols, n_actions), 'cuda:0', max_boards=64).load_state_dict(net.state_dict())
+        x = torch.randn(37, 4, rows, cols)
+        with torch.no_grad():
+            lp64, v64 = net.double()(x.double())
+        xd = x.to('cuda:0')
+        lp, v = hip.forward(xd)
+        assert np.max(np.abs(lp.cpu().numpy() - lp64.numpy())) <= 1e-4, cols
+        assert np.max(np.abs(v.cpu().numpy() - v64.numpy()[:, 0])) <= 1e-4, cols
+        lp3, v3 = hip.set_max_workgroups(3).forward(xd)
+        assert torch.equal(lp3, lp) and torch.equal(v3, v), cols
+        hip.set_max_workgroups(0)
+        planes = (torch.rand((9, 4, rows, cols), device='cuda:0') < 0.4).float()   # 0 / 1 planes like the tree's leaves
+        feat = hip.trunk(planes).cpu().numpy()
+        feat_tiles = hip.set_algo('split_f16_tiles').trunk(planes).cpu().numpy()
+        feat_direct = hip.set_algo('direct').trunk(planes).cpu().numpy()
+        scale = max(1.0, float(np.abs(feat_direct).max()))
+        assert np.abs(feat).max() > 0.05 and np.max(np.abs(feat - feat_tiles)) <= 2e-6 * scale, cols
+        assert np.max(np.abs(feat - feat_direct)) <= 2e-5 * scale, cols
+        hip.check_flags()
+        hip.close()
+
+
 def test_trunk_is_deterministic_under_load():
     """The default trunk accumulates with an inline-assembly MFMA whose register hazards are kept by hand
     (DESIGN.md section 7): a violated hazard would be timing dependent, so 60 launches of a full 512-board batch,
@@ -982,12 +1017,12 @@ def test_fused_route_priors_vs_golden_and_unfused(g4):
                     break
             if not e.game_end_winner()[0]:
                 envs.append(e)
-        for algo, heads in (('split_f16', 'auto'), ('split_f16', 'parts'), ('winograd_f4', 'auto'), ('direct', 'auto')):
+        for algo, heads in (('split_f16', 'auto'), ('split_f16', 'parts'), ('split_f16_tiles', 'auto'), ('winograd_f4', 'auto'), ('direct', 'auto')):
             evaluator.hip.set_algo(algo).set_heads_algo(heads)
             got = {}
             planes = HipNetEvaluator.__new__(HipNetEvaluator)  # the same HipNet, fed float planes instead of positions
             planes.module, planes.hip, planes.use_positions = evaluator.module, evaluator.hip, False
-            assert planes.needs_obs and evaluator.needs_obs == (algo != 'split_f16')
+            assert planes.needs_obs and evaluator.needs_obs == (algo not in ('split_f16', 'split_f16_tiles'))
             for route, evl in (('fused', evaluator), ('fused_planes', planes), ('unfused', _UnfusedHipNet(evaluator.hip))):
                 eng = _engine(B, n, n_games=len(envs), n_playout=4)
                 _set_roots(eng, envs, reset_trees=True)

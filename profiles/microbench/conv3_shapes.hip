@@ -183,7 +183,88 @@ __device__ __forceinline__ float board(const char *in, const char *wts, int m0, 
 constexpr int lds_bytes = 324 * pos_bytes;
 }  // namespace s16
 
-enum { P32, C16, H16, P16, C16x1, C16x3 };
+// ---------------------------------------------------------------- R16: the C16 split with the K loop turned inside out: for
+// every (tap column dx, channel chunk) the 17 halo rows are read ONCE each and a row's fragment meets the three kernel rows
+// (output rows r, r - 1, r - 2): a third of C16's LDS reads, the same weight traffic, 18 MFMAs per pair of ds_read_b128
+namespace r16 {
+using s16::CIN; using s16::pos_bytes; using s16::chunks;
+constexpr int NT = 15, TM = 2, LA = 3, PD = LA + 1, combos = 3 * chunks, rows = NT + 2;   // combo = dx * chunks + chunk
+// weight fragment of (M-tile m, tap (dy, dx), chunk c): the layout of s16 (step = tap * chunks + c)
+__device__ __forceinline__ constexpr int w_off(int m, int dy, int combo, int p) {
+    return ((m * s16::steps + (dy * 3 + combo / chunks) * chunks + combo % chunks) * 2 + p) * 1024;
+}
+template <int J>
+__device__ __forceinline__ void slot(f32x4 (&acc)[TM][NT], f16x8 (&a)[2][3][TM][2], f16x8 (&b)[PD][2], lds_frag q,
+                                     __amdgpu_buffer_rsrc_t w_rsrc, int w_lane) {
+    constexpr int cb = J / rows, r = J % rows, J2 = J + LA;
+    if constexpr (J2 < combos * rows) {
+        constexpr int cb2 = J2 / rows, r2 = J2 % rows, dx = cb2 / chunks, c = cb2 % chunks, far = r2 >= 8;
+        constexpr int off = ((r2 - 8 * far) * kRowW + dx) * pos_bytes + c * 64;
+        const lds_frag qq = far ? q + 8 * kRowW * pos_bytes / 16 : q;
+        b[J2 % PD][0] = qq[off / 16];
+        b[J2 % PD][1] = qq[(off + CIN * 2) / 16];
+    }
+    if constexpr (cb + 1 < combos && r < 3 * TM) {   // the next combo's 12 weight fragments behind this combo's first rows
+        constexpr int dy = r / TM, m = r % TM;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) a[(cb + 1) % 2][dy][m][p] = load_w(w_rsrc, w_lane, w_off(m, dy, cb + 1, p));
+    }
+#pragma unroll
+    for (int combo = 0; combo < 3; ++combo)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int m = 0; m < TM; ++m) {
+                const int t = r - dy, pa = combo == 2 ? 1 : 0, pb = combo == 1 ? 1 : 0;
+                if (t >= 0 && t < NT) {
+                    if (cb == 0 && dy == 0 && combo == 0) {   // the first MFMA of a tile (every row meets dy = 0 in combo 0 first)
+                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cb % 2][dy][m][pa], b[J % PD][pb], zero, 0, 0, 0);
+                    } else {
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cb % 2][dy][m][pa], b[J % PD][pb], acc[m][t], 0, 0, 0);
+                    }
+                }
+            }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int... Js>
+__device__ __forceinline__ void slots(std::integer_sequence<int, Js...>, f32x4 (&acc)[TM][NT], f16x8 (&a)[2][3][TM][2], f16x8 (&b)[PD][2],
+                                      lds_frag q, __amdgpu_buffer_rsrc_t w_rsrc, int w_lane) {
+    (slot<Js>(acc, a, b, q, w_rsrc, w_lane), ...);
+}
+__device__ __forceinline__ float board(const char *in, const char *wts, int m0, int lane) {
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wts + (size_t)m0 * s16::steps * 2 * 1024), 0, 0x7fffffff, 0x00020000);
+    f16x8 a[2][3][TM][2];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) a[0][dy][m][p] = load_w(w_rsrc, lane * 16, w_off(m, dy, 0, p));
+    const int n = lane & 15, g = lane >> 4;
+    const lds_frag q = (lds_frag)(in + n * pos_bytes + g * 16);
+    f16x8 b[PD][2];
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+        b[j][0] = q[(j * kRowW * pos_bytes) / 16];
+        b[j][1] = q[(j * kRowW * pos_bytes + CIN * 2) / 16];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[TM][NT];
+    slots(std::make_integer_sequence<int, combos * rows>{}, acc, a, b, q, w_rsrc, lane * 16);
+    float s = 0.0f;
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += acc[m][t][r];
+    return s;
+}
+}  // namespace r16
+
+enum { P32, C16, H16, P16, C16x1, C16x3, R16 };
 template <int KIND>
 __global__ __launch_bounds__(256) void k(const _Float16 *__restrict__ act, const char *__restrict__ wts, float *out, long long *ticks,
                                          int boards) {
@@ -202,6 +283,7 @@ __global__ __launch_bounds__(256) void k(const _Float16 *__restrict__ act, const
         if constexpr (KIND == C16) s += s16::board<2, 15, 2>(lds, wts, 2 * wave, 0, lane);
         if constexpr (KIND == C16x1) s += s16::board<2, 15, 1>(lds, wts, 2 * wave, 0, lane);
         if constexpr (KIND == C16x3) s += s16::board<2, 15, 3>(lds, wts, 2 * wave, 0, lane);
+        if constexpr (KIND == R16) s += r16::board(lds, wts, 2 * wave, lane);
         if constexpr (KIND == H16) {
             if (wave < 2) s += s16::board<4, 8, 1>(lds, wts, 4 * wave, 0, lane);
             else s += s16::board<4, 7, 1>(lds, wts, 4 * (wave - 2), 8, lane);
@@ -258,6 +340,7 @@ int main() {
             run<P16>("P16", grid, act, wts, out, ticks, boards);
             run<C16x1>("C16 one row per slot", grid, act, wts, out, ticks, boards);
             run<C16x3>("C16 three rows per slot", grid, act, wts, out, ticks, boards);
+            run<R16>("R16 halo rows read once", grid, act, wts, out, ticks, boards);
         }
     return 0;
 }

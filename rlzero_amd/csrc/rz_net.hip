@@ -859,7 +859,7 @@ struct LeafBits {
 // each phase of a board in k_trunk_split into net_prof[] (rz_net_debug_profile).
 #ifdef RZ_NET_PROFILE
 __device__ long long net_prof[16];
-#define NET_TICK(i) do { const long long now_ = __builtin_readcyclecounter(); prof_acc[i] += now_ - prof_t; prof_t = now_; } while (0)
+#define NET_TICK(i) do { __builtin_amdgcn_sched_barrier(0); const long long now_ = __builtin_readcyclecounter(); prof_acc[i] += now_ - prof_t; prof_t = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define NET_TICK(i)
 #endif
@@ -1440,8 +1440,12 @@ __device__ __forceinline__ void conv(const char *in, const void *wts, int lane, 
 
 }  // namespace rt
 
+// Register budget: 200 VGPRs + 200 accumulation registers.  Two lanes of games overlap because a wave of the other lane's tree
+// step or FC GEMM (112 / 104 registers) fits beside a trunk wave on the same SIMD (512 registers): at 400 registers or fewer the
+// trunk leaves that room, at 408 it does not and the lanes' kernels take turns (measured: 10.7 -> 9.5 M sims/s from 8 registers).
+// Left alone hipcc allocates 396 .. 420 here depending on details of the prologue; the cap holds it at 372, no scratch.
 template <int NT, bool BITS>
-__global__ __launch_bounds__(256) void k_trunk_rows(NetDev nd, const float *__restrict__ obs, LeafBits leaves,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_trunk_rows(NetDev nd, const float *__restrict__ obs, LeafBits leaves,
                                                     float *__restrict__ feat, _Float16 *__restrict__ feat16,
                                                     int n_boards, unsigned *__restrict__ flags) {
 #ifdef RZ_NET_PROFILE

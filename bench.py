@@ -1,34 +1,27 @@
 #!/usr/bin/env python3
 """Headline benchmark: MCTS simulations / second (and self-play games / second) of AlphaZero self-play on
-15x15 Gomoku, 800 simulations per move (BASELINE.json configs[3]), random-init PolicyValueNet
-(torch.manual_seed(0)), fp32.  Games in flight per GPU are an engine parameter (the batch of the leaf
-evaluation): the default keeps 2 lanes x 768 games = 1536 per GPU, which is what fills an MI355X -- the
-network trunk of one lane runs as 256 persistent workgroups (one per CU, three boards each) while the tree / FC
-kernels of the other lane run beside it on the same CUs (their waves fit next to a resident trunk workgroup).
-`--games 512` is the literal 4096 / 8 games per GPU of configs[3]; at N = 1 the default run measures it too
-(`literal_config`); `--trunk-wgs 224 --games 1344` is the capped layout of round 1.
+15x15 Gomoku, 800 simulations per move, 512 games in flight per GPU = BASELINE.json configs[3] (4096 games over 8 GPUs),
+random-init PolicyValueNet (torch.manual_seed(0)), f32 network / f64 tree.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one move of every game on the GPU: n_playout simulation steps (select ->
-evaluate -> expand/backup for all games), pi from the root visits, a move drawn and applied,
-tree reuse; finished games are replaced by fresh ones so the batch stays full.  Games are
-independent, so N GPUs play N x 1536 games with no collective in the timed region (weak
-scaling); rank 0 prints ONE JSON line.
+A "step" is one move of every game on the GPU: n_playout simulation steps (select -> evaluate -> expand / backup for all
+games), pi from the root visits, a move drawn and applied, tree reuse; finished games are replaced so the batch stays
+full.  The 512 games of a GPU run as two lanes of 256 (separate streams: the tree / FC kernels of one lane run beside the
+network trunk of the other on the same CUs).  Games are independent: N GPUs play N x 512 games with no collective in the
+timed region (weak scaling); rank 0 prints ONE JSON line.  `value` is the MEDIAN of --regions (3) timed regions of K steps
+each, every region bracketed by barrier + synchronize.
 
-Also on the line:
-  roofline      for the dominant kernel region (the policy+value forward of the leaf batch,
-                the path's one dense contraction): algorithmic FLOPs F(S) = 188416*S + 8*S^2 +
-                128 per position (the trunk kernel alone: 188160*S) x positions per launch /
-                its average duration from HIP events on the launch streams (two lanes: the union of their
-                intervals / launches), against the peak of the pipe it runs on: the f16 MFMA peak / 3 for the
-                default trunk (three f16 MFMAs per f32 product), the f32-input MFMA peak for the others.
-  selfplay      after the timed steps the first-generation games are played to their end (slots refilled):
-                games/s = moves/s of that leg / mean plies per game.
-  cpu_baseline  the oracle (Python restatement of the reference, batch-1 torch CPU forward,
-                one thread per process) timed on this host's cores on a bounded sample of
-                the same workload.
+On the line (what each number means and how it is priced: DESIGN.md section 5):
+  roofline       the dominant kernel (the network trunk on one lane's leaves): algorithmic flops per launch / launch
+                 duration, against the peak of the pipe it runs on
+  roofline_tree  the tree step against the HBM roofline (algorithmic bytes of SURVEY.md 8d)
+  fill_1536      the same engine with 1536 games in flight (3 boards per trunk workgroup: what fills an MI355X)
+  configs        the other BASELINE.json configurations (C1, C2, C3, C5) and the opt-in PUCT rule at the headline
+                 geometry, each measured by a child process with its own roofline and CPU baseline
+  cpu_baseline   the oracle (Python restatement of the reference, batch-1 torch CPU forward, one thread per process)
+                 timed on this host's cores on a bounded sample of the same workload
 """
 import argparse
 import json
@@ -48,6 +41,7 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 PEAK_F16_MATRIX_TFLOPS = 2500.0  # dense f16 / bf16 MFMA, same table
 SPLIT_MFMAS_PER_PRODUCT = 3      # split_f16: hi*hi + hi*lo + lo*hi
 PEAK_HBM_GBS = 8000.0
+FILL_GAMES_PER_GPU = 1536  # 2 lanes x 3 boards x 256 trunk workgroups: the batch that fills one MI355X
 GATHER_SAMPLE_GAMES = 256  # N > 1: finished games per rank sent to rank 0 by the trajectory gather (outside the timed region)
 
 
@@ -87,19 +81,15 @@ def tree_bytes_per_sim(scanned, created, depth):
     return 12.0 * scanned + 16.0 * created + 24.0 * (depth + 1.0) + 64.0
 
 
-def pmc_traffic(kernel, workload, lanes):
-    """HBM bytes per launch of ``kernel`` from the committed rocprofv3 PMC passes (separate
-    FETCH_SIZE / WRITE_SIZE runs, gfx950 read correction applied; profiles/r02/pmc_traffic.json).
-    None when no counter run exists for this workload / launch geometry."""
-    for rnd in ('r02', 'r01'):  # the newest committed counter run that matches this launch geometry
-        try:
-            rec = json.load(open(os.path.join(REPO, 'profiles', rnd, 'pmc_traffic.json')))
-            if rec['workload'] != workload or rec.get('lanes', 1) != lanes:
-                continue
-            return rec['kernels'][kernel]['traffic_bytes_per_launch']
-        except (OSError, KeyError, ValueError):
-            continue
-    return None
+def pmc_traffic(kernel, workload):
+    """HBM bytes per launch of ``kernel`` in ``workload`` from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
+    WRITE_SIZE runs of that very workload, gfx950 read correction applied: profiles/r03/pmc_traffic.json, collected by
+    profiles/collect_r03.sh).  None when no counter run exists for the workload."""
+    try:
+        rec = json.load(open(os.path.join(REPO, 'profiles', 'r03', 'pmc_traffic.json')))
+        return rec[workload]['kernels'][kernel]['traffic_bytes_per_launch']
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
 
 
 # --------------------------------------------------------------------------- CPU baseline
@@ -227,10 +217,7 @@ def run_cpu_baseline(seconds, game='gomoku', board=BOARD, n_playout=N_PLAYOUT):
             'muzero': 'MuZero CartPole-v1 episodes'}[game]
     return {'value': round(total / worst, 1), 'unit': 'sims/s', 'cores': cores, 'kind': 'port',
             'per_process': round(total / worst / cores, 1),
-            'sample': '%d processes x %.0f s of %s at %d sims/move from the start position, oracle (%s) + batch-1 '
-                      'torch CPU forward, 1 thread each, moves sampled like the reference (numpy.random.choice on '
-                      'softmax(log N)); the port runs ~2x the reference\'s own 376-444 sims/s/thread at 15x15 '
-                      '(BASELINE.md section 2): it is the faster of the two CPU paths'
+            'sample': '%d processes x %.0f s of %s at %d sims/move, %s + batch-1 torch CPU forward, 1 thread each'
                       % (cores, seconds, what, n_playout, 'oracle/muzero_ref.py' if game == 'muzero' else 'oracle/mcts_ref.py')}
 
 
@@ -244,62 +231,49 @@ def child_line(flags, timeout=900):
         return None
 
 
-def run_literal_config(args):
-    """The literal share of configs[3], 512 games in flight, as a child process with the lane layout plan_lanes() picks
-    for that batch (two lanes of 256 games, un-capped trunks, 'parts' FC GEMM) -> the fields of its line worth keeping."""
-    # (a few more warm-up moves than the main run: the GPU has idled through the CPU baseline before this child starts)
-    rec = child_line(['--lanes', 2, '--games', GAMES_PER_GPU, '--trunk-wgs', 0, '--steps', args.steps, '--warmup',
-                      max(args.warmup, 4), '--net-algo', args.net_algo, '--graph', args.graph, '--noise', args.noise,
-                      '--no-cpu-baseline', '--no-games-leg', '--no-literal-config', '--no-configs'], 600)
+def run_fill_config(args):
+    """The same engine with 1536 games in flight (two lanes of 768: three boards per persistent trunk workgroup), as a
+    child process -> the fields of its line worth keeping."""
+    rec = child_line(['--lanes', 2, '--games', FILL_GAMES_PER_GPU, '--steps', args.steps, '--warmup', max(args.warmup, 3),
+                      '--regions', 1, '--net-algo', args.net_algo, '--graph', args.graph, '--noise', args.noise,
+                      '--no-cpu-baseline', '--no-games-leg', '--no-fill', '--no-configs'], 600)
     if rec is None:
         return None
     rf = rec.get('roofline') or {}
-    return {'workload': rec['config']['workload'], 'lanes': 2, 'value': rec['value'], 'unit': rec['unit'],
-            'ms_per_step': rec['ms_per_step'],
-            # all trunk flops of the run / wall-clock, and the trunk launched alone (256 boards: one round on 256 CUs); the
-            # event-bracketed launches of this layout contain the wait for the other lane's trunk (eager samples)
-            'roofline_frac': rf.get('whole_job_frac'), 'roofline_exclusive_frac': rf.get('exclusive_frac'),
-            'roofline_exclusive_launch_ms': rf.get('exclusive_launch_ms'),
-            'note': 'same engine, %d games in flight = 4096 games / 8 GPUs (BASELINE.json configs[3]) as two lanes of 256 '
-                    'with un-capped trunks, the FC GEMM and the tree step of one lane co-resident with the other lane\'s '
-                    'trunk (selfplay.plan_lanes); measured by a child process before the main run; one lane of 512 '
-                    '(--lanes 1 --games 512) runs 3-12 %% below it (profiles/r02/lane_sweeps.txt)' % GAMES_PER_GPU}
+    return {'workload': rec['config']['workload'], 'value': rec['value'], 'ms_per_step': rec['ms_per_step'],
+            'frac': rf.get('frac'), 'avg_launch_ms': rf.get('avg_launch_ms'), 'traffic': rf.get('traffic')}
 
 
 # the other configurations of BASELINE.json, each measured by a child process of the default N = 1 run
-CONFIG_LEGS = (  # (key, title, flags, seconds of CPU baseline at --cpu-seconds 60); a few warm-up moves each: a leg starts on a GPU
-    # that has idled through its own CPU baseline (the main run adds up to 3 moves to its W until 0.3 s have passed)
-    ('C1', 'configs[0] TicTacToe, 25 sims/move, 1 game', ['--board', 3, '--playouts', 25, '--games', 1, '--lanes', 1, '--steps', 9, '--warmup', 20], 5.0),
-    ('C1_16_games', 'configs[0] with as many games as the CPU baseline plays at once (16 processes = 16 games): like for like with '
-     'its aggregate figure', ['--board', 3, '--playouts', 25, '--games', 16, '--lanes', 1, '--steps', 9, '--warmup', 20, '--no-cpu-baseline'], 0.0),
-    ('C2', 'configs[1] 9x9 Gomoku, 200 sims/move, 64 games', ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 8, '--warmup', 8], 12.0),
-    ('C2_16_in_flight', 'configs[1] with the opt-in virtual-loss mode: 16 simulations in flight per tree (NOT the reference\'s '
-     'sequential search; leaf batches of 1024 instead of 64)',
-     ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 8, '--warmup', 8, '--in-flight', 16, '--no-cpu-baseline'], 0.0),
-    ('C3', 'configs[2] Connect4, 400 sims/move, 512 games', ['--game', 'connect4', '--playouts', 400, '--games', 512, '--lanes', 2, '--steps', 6, '--warmup', 6], 12.0),
-    ('C5', 'configs[4] MuZero CartPole-v1, 50 sims/move, 8192 environments (two 16-environment workgroups per CU)',
-     ['--game', 'muzero', '--playouts', 50, '--games', 8192, '--steps', 512, '--warmup', 48], 12.0),
+CONFIG_LEGS = (  # (key, flags, seconds of CPU baseline at --cpu-seconds 60); a leg starts on a GPU that has idled: warm-up moves
+    ('C1_ttt_25sims_1game', ['--board', 3, '--playouts', 25, '--games', 1, '--lanes', 1, '--steps', 9, '--warmup', 20], 5.0),
+    ('C1_16games', ['--board', 3, '--playouts', 25, '--games', 16, '--lanes', 1, '--steps', 9, '--warmup', 20, '--no-cpu-baseline'], 0.0),
+    ('C2_9x9_200sims_64games', ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 8, '--warmup', 8], 12.0),
+    ('C2_16_in_flight', ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 8, '--warmup', 8, '--in-flight', 16,
+                         '--no-cpu-baseline'], 0.0),
+    ('C3_connect4_400sims_512games', ['--game', 'connect4', '--playouts', 400, '--games', 512, '--lanes', 2, '--steps', 6, '--warmup', 6], 12.0),
+    ('C4_puct_rule', ['--score-mode', 'puct', '--steps', 3, '--warmup', 2, '--no-cpu-baseline'], 0.0),
+    ('C5_muzero_cartpole_50sims_8192envs', ['--game', 'muzero', '--playouts', 50, '--games', 8192, '--steps', 512, '--warmup', 48], 12.0),
 )
 
 
 def run_config_legs(args):
     out = {}
-    for key, title, flags, cpu_s in CONFIG_LEGS:
-        rec = child_line(flags + ['--cpu-seconds', max(1.0, cpu_s * args.cpu_seconds / 60.0), '--no-games-leg',
-                                  '--no-literal-config', '--no-configs'] + (['--no-cpu-baseline'] if args.no_cpu_baseline else []), 600)
+    for key, flags, cpu_s in CONFIG_LEGS:
+        rec = child_line(flags + ['--cpu-seconds', max(1.0, cpu_s * args.cpu_seconds / 60.0), '--regions', 1, '--no-games-leg',
+                                  '--no-fill', '--no-configs'] + (['--no-cpu-baseline'] if args.no_cpu_baseline else []), 600)
         if rec is None:
-            out[key] = {'config': title, 'error': 'the child process printed no line'}
+            out[key] = {'error': 'the child process printed no line'}
             continue
-        rf = rec.get('roofline')
-        if rf:
-            rf = {k: rf[k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms',
-                                     'exclusive_frac', 'eager_samples_host_bound', 'note') if k in rf}
-        out[key] = {'config': title, 'workload': rec['config']['workload'], 'value': rec['value'], 'unit': rec['unit'],
-                    'ms_per_step': rec['ms_per_step'], 'steps': rec['steps'], 'roofline': rf,
-                    'cpu_baseline': rec.get('cpu_baseline')}
-        for extra in ('multi_sim',):
-            if extra in rec.get('config', {}):
-                out[key][extra] = rec['config'][extra]
+        rf = rec.get('roofline') or {}
+        cpu = rec.get('cpu_baseline') or {}
+        leg = {'workload': rec['config']['workload'], 'value': rec['value'], 'ms_per_step': rec['ms_per_step'],
+               'roofline': {k: rf.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms')},
+               'cpu_baseline': {k: cpu.get(k) for k in ('value', 'cores')} if cpu else None}
+        rt = rec.get('roofline_tree')
+        if rt:
+            leg['roofline_tree'] = {k: rt.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms')}
+        out[key] = leg
     return out
 
 
@@ -405,6 +379,7 @@ def run_muzero(args, rank, world, device, dist, red_device, use_dist=False, cpu_
     from rlzero_amd.muzero import CartPoleBatch, MuZeroNet, MuZeroSelfPlay
     G = args.games if args.games > 0 else 8192
     n_sims = args.playouts if args.playouts != N_PLAYOUT else 50
+    workload = 'muzero_cartpole_v1_%dsims_per_move_%denvs_per_gpu' % (n_sims, G)
     torch.manual_seed(0)
     net = MuZeroNet().to(device).eval()
     sp = MuZeroSelfPlay(net, CartPoleBatch(G, device, seed=rank), n_sims=n_sims, seed=rank, fused=bool(args.mz_fused))
@@ -448,32 +423,20 @@ def run_muzero(args, rank, world, device, dist, red_device, use_dist=False, cpu_
             if sp.fused:
                 roofline = {'bound': 'mfma', 'kernel': sp.sim_step_label + ', %d environments per launch' % G,
                             'achieved': round(tf, 3), 'peak': PEAK_FP32_MATRIX_TFLOPS, 'unit': 'TFLOP/s',
-                            'frac': round(tf / PEAK_FP32_MATRIX_TFLOPS, 5), 'traffic': None, 'avg_launch_ms': round(ms, 4),
+                            'frac': round(tf / PEAK_FP32_MATRIX_TFLOPS, 5), 'traffic': pmc_traffic('k_mz_search', workload), 'avg_launch_ms': round(ms, 4),
                             'launches_timed': len(events), 'hbm_achieved_gbs': round(gbs, 2),
-                            'moves_per_launch': moves_per_launch,
-                            'note': 'achieved = algorithmic flops of the recurrent inference (%d per simulation: its 7 dense '
-                                    'layers) x %d simulations x %d environments x %g moves per launch / launch duration (HIP events), '
-                                    'against the f32-input MFMA peak (157.3 TFLOP/s); %d workgroups of 16 environments (4 waves: '
-                                    'v_mfma_f32_16x16x4_f32 tiles, weights in registers, trees in LDS); a simulation is a chain of '
-                                    'dependent steps per tree (fp64 walk, gather, 4 layers, backup): latency bound, not a roof'
-                                    % (MZ_FLOPS_PER_SIM, n_sims, G, moves_per_launch, (G + 15) // 16)}
+                            'moves_per_launch': moves_per_launch}
             else:
                 roofline = {'bound': 'hbm', 'kernel': sp.sim_step_label + ', %d environments per launch' % G,
                             'achieved': round(gbs, 2), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 5),
                             'traffic': None, 'avg_launch_ms': round(ms, 4), 'launches_timed': len(events),
-                            'flops_achieved_tflops': round(tf, 3), 'flops_frac_of_f32_mfma_peak': round(tf / PEAK_FP32_MATRIX_TFLOPS, 5),
-                            'note': 'one simulation step of all environments (select -> recurrent inference -> expand + backup), '
-                                    'HIP events on the launch stream; algorithmic bytes per simulation = %d (hidden state in + out, '
-                                    'tree nodes on the path, network heads), algorithmic flops = %d (the 7 dense layers of the '
-                                    'recurrent inference): arithmetic intensity 45 flop/B is above the ridge only nominally -- at '
-                                    '4096 environments the step is bound by launch / dependent latency, not by either roof'
-                                    % (MZ_BYTES_PER_SIM, MZ_FLOPS_PER_SIM)}
+                            'flops_achieved_tflops': round(tf, 3), 'flops_frac_of_f32_mfma_peak': round(tf / PEAK_FP32_MATRIX_TFLOPS, 5)}
         print(json.dumps({
             'metric': 'mcts_sims_per_sec', 'value': round(total / elapsed, 1), 'unit': 'sims/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1000.0 * elapsed / max(args.steps, 1), 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 model / f64 tree',
             'data': 'synthetic (random-init MuZero MLPs, torch.manual_seed(0); CartPole-v1 restatement)',
-            'config': {'workload': 'muzero_cartpole_v1_%dsims_per_move_%denvs_per_gpu' % (n_sims, G),
+            'config': {'workload': workload,
                        'games_total': G * world, 'discount': 0.997, 'parallelism': 'environments sharded, dp%d' % world},
             'episodes_finished_in_timed_region': finished, 'tree_hbm_bytes': int(sp.tree.device_bytes),
             'roofline': roofline, 'cpu_baseline': cpu_baseline}), flush=True)
@@ -495,8 +458,7 @@ def main():
                     help='skip the child-process legs for the other BASELINE.json configurations (C1, C2, C3, C5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--games', type=int, default=0,
-                    help='games per GPU; 0 = lanes x %d boards x trunk workgroups (1536) with 2 lanes, %d with 1' %
-                    (BOARDS_PER_WORKGROUP, GAMES_PER_GPU))
+                    help='games per GPU; 0 = %d (BASELINE.json configs[3]: 4096 games / 8 GPUs)' % GAMES_PER_GPU)
     ap.add_argument('--trunk-wgs', type=int, default=0,
                     help='persistent trunk workgroups per lane; 0 = one per CU (default: with lanes > 1 the small kernels of '
                          'one lane run beside the other lane\'s trunk on the same CUs); %d = the capped layout of round 1 '
@@ -516,8 +478,12 @@ def main():
                     help='skip the self-play games/s leg (after the timed steps the games of the first generation '
                          'are played to their end, slots refilled, to measure moves/s over whole games and the mean '
                          'game length)')
-    ap.add_argument('--no-literal-config', action='store_true',
-                    help='skip the extra N=1 measurement of the literal configs[3] share: 1 lane x %d games' % GAMES_PER_GPU)
+    ap.add_argument('--no-fill', '--no-literal-config', dest='no_fill', action='store_true',
+                    help='skip the extra N=1 measurement with %d games in flight (child process)' % FILL_GAMES_PER_GPU)
+    ap.add_argument('--regions', type=int, default=3, help='timed regions of K steps each; value = their median')
+    ap.add_argument('--score-mode', default='uct_ref', choices=['uct_ref', 'puct'],
+                    help="uct_ref: the reference's selection rule (node.py:32-42, 75-88; bit-exact); puct: the opt-in AlphaZero "
+                         "rule Q + c P sqrt(N_parent) / (N + 1) (every level scans all children; parity by the oracle's restatement)")
     ap.add_argument('--heads-algo', default='auto', choices=['auto', 'f32', 'split32', 'split64', 'parts'],
                     help='GEMM of the first FC layers (rz_net_set_heads_algo)')
     ap.add_argument('--noise', type=int, default=1,
@@ -566,17 +532,17 @@ def main():
         playouts = 50 if (args.game == 'muzero' and args.playouts == N_PLAYOUT) else args.playouts
         cpu_baseline = run_cpu_baseline(args.cpu_seconds, args.game, args.board, playouts)
 
-    # the literal share of configs[3] (4096 games / 8 GPUs = 512 per GPU, one lane) in a child process of its
-    # own, also before this process touches the GPU (a process that has initialised the GPU starts no program)
-    literal = None
-    if (world == 1 and args.gpus == 1 and not args.no_literal_config and args.game == 'gomoku' and args.games == 0
-            and args.board == BOARD and args.playouts == N_PLAYOUT and args.evaluator == 'hipnet'):
-        literal = run_literal_config(args)
+    # the same engine with 1536 games in flight, in a child process of its own, also before this process touches the GPU
+    # (a process that has initialised the GPU starts no program)
+    fill = None
+    if (world == 1 and args.gpus == 1 and not args.no_fill and default_config and args.games == 0
+            and args.evaluator == 'hipnet' and args.score_mode == 'uct_ref'):
+        fill = run_fill_config(args)
     # ... and the other configurations of BASELINE.json (C1, C2, C3, C5), each a child process with its own
     # roofline and CPU baseline: reported under `configs` of the default N = 1 line
     config_legs = None
     if (world == 1 and args.gpus == 1 and not args.no_configs and default_config and args.games == 0
-            and args.evaluator == 'hipnet'):
+            and args.evaluator == 'hipnet' and args.score_mode == 'uct_ref'):
         config_legs = run_config_legs(args)
 
     import numpy as np
@@ -613,10 +579,8 @@ def main():
     n_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
     lanes = max(1, args.lanes)
     trunk_wgs = max(0, args.trunk_wgs)
-    # default batch: lanes x 3 boards x trunk workgroups (1536 with two un-capped lanes on 256 CUs)
-    G = args.games if args.games > 0 else \
-        (lanes * BOARDS_PER_WORKGROUP * (trunk_wgs if trunk_wgs > 0 else n_cus) if lanes > 1 and args.evaluator == 'hipnet'
-         else GAMES_PER_GPU)
+    # default batch: the 512 games per GPU of BASELINE.json configs[3] (4096 games over 8 GPUs), as two lanes of 256
+    G = args.games if args.games > 0 else GAMES_PER_GPU
     heads_algo = args.heads_algo
     if heads_algo == 'auto' and lanes > 1 and trunk_wgs == 0 and args.evaluator == 'hipnet' and args.net_algo.startswith('split_f16'):
         heads_algo = 'parts'  # un-capped lanes: the LDS-free GEMM that fits beside a resident trunk workgroup
@@ -629,17 +593,17 @@ def main():
     for g_lane in per_lane:
         eng = MCTSEngine(board, n_row, n_games=g_lane, n_playout=args.playouts, c_puct=C_PUCT, device=device,
                          game=args.game, add_noise=bool(args.noise), noise_seed=1000 * rank + len(engines),
-                         sims_in_flight=args.in_flight)
+                         sims_in_flight=args.in_flight, score_mode=args.score_mode)
         if args.evaluator == 'hipnet':
             hip_ev = HipNetEvaluator(net, net_shape, device, max_boards=eng.n_leaves)
             hip_ev.hip.set_algo(args.net_algo)
             hip_ev.hip.set_heads_algo(heads_algo)
             hip_ev.hip.set_max_workgroups(trunk_wgs)
             ev = TimedEvaluator(hip_ev, torch,
-                                {'winograd_f4': 'k_trunk_wino_f4<4> (hand-written fused fp32-MFMA conv trunk, Winograd F(4x4,3x3), csrc/rz_net.hip)',
-                                 'split_f16': 'k_trunk_rows on 15-row boards, else k_trunk_split (hand-written fused conv trunk: direct convolution on the f16 matrix pipe, f32 operands as hi + lo f16 pairs, f32 accumulation, csrc/rz_net.hip)',
-                                 'split_f16_tiles': 'k_trunk_split (hand-written fused conv trunk: direct convolution on the f16 matrix pipe, f32 operands as hi + lo f16 pairs, f32 accumulation, csrc/rz_net.hip)',
-                                 'direct': 'k_trunk (hand-written fused fp32-MFMA conv trunk, direct, csrc/rz_net.hip)'}[args.net_algo])
+                                {'winograd_f4': 'k_trunk_wino_f4<4>',
+                                 'split_f16': 'k_trunk_rows' if (args.game == 'gomoku' and board == 15) else 'k_trunk_split',
+                                 'split_f16_tiles': 'k_trunk_split',
+                                 'direct': 'k_trunk'}[args.net_algo])
         elif args.evaluator == 'torchnet':
             ev = TimedEvaluator(NetEvaluator(net), torch, 'torch/MIOpen forward (~14 kernels)')
         else:
@@ -691,13 +655,26 @@ def main():
     while n_ramp < args.warmup or (time.perf_counter() - t_ramp < 0.3 and n_ramp < args.warmup + 3):
         one_step()
         n_ramp += 1
-    sims0, fin0 = sp.sims_done, finished[0]
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    # --regions timed regions of K steps each, every one bracketed by barrier + synchronize; the MEDIAN region is reported
+    regions = []
+    for _ in range(max(1, args.regions)):
+        sims0, fin0 = sp.sims_done, finished[0]
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        fence()
+        dt = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=red_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            counts = torch.tensor([sp.sims_done - sims0, finished[0] - fin0], dtype=torch.float64, device=red_device)
+            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+            regions.append((dt, float(counts[0].item()), float(counts[1].item())))
+        else:
+            regions.append((dt, float(sp.sims_done - sims0), float(finished[0] - fin0)))
+    elapsed, total_sims, total_finished = sorted(regions, key=lambda r: r[1] / r[0])[len(regions) // 2]
     # Kernel-level timing samples, right AFTER the timed region on the same games: every k-th graph chunk is launched
     # kernel by kernel with HIP events around the trunk, the FC GEMM and the tree step.  Not inside the timed region:
     # there the eager chunks cost 0 % (default, 80-us trunks) to 50 % (Connect4, 15-us trunks) -- the host cannot keep two
@@ -728,15 +705,6 @@ def main():
         for ev in evaluators:
             if isinstance(ev, TimedEvaluator):
                 ev.record = False
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        counts = torch.tensor([sp.sims_done - sims0, finished[0] - fin0], dtype=torch.float64, device=red_device)
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-        total_sims, total_finished = float(counts[0].item()), float(counts[1].item())
-    else:
-        total_sims, total_finished = float(sp.sims_done - sims0), float(finished[0] - fin0)
     all_stats = sp.check()
     stats = max(all_stats, key=lambda st: st.max_slots_used)
     # the dominant kernel by itself (no other lane on the GPU): its duration on the CUs it is given
@@ -785,9 +753,7 @@ def main():
             mean_plies = acc[1] / acc[2]
             selfplay = {'games_per_sec': round(acc[0] / leg / mean_plies, 2), 'mean_plies_per_game': round(mean_plies, 2),
                         'games_sampled': int(acc[2]), 'moves_per_sec': round(acc[0] / leg, 2),
-                        'leg_seconds': round(leg, 2),
-                        'note': 'after the timed steps: all first-generation games played to their end with finished '
-                                'slots refilled; games/s = moves/s of this leg / mean plies of those games'}
+                        'leg_seconds': round(leg, 2)}
 
     # N > 1: the path's single exchange, a gather of finished trajectories to rank 0 (RCCL over xGMI when the
     # process group is nccl), exercised on a bounded sample outside the timed region
@@ -823,25 +789,25 @@ def main():
                        for t in merged}, f)
     if rank == 0:
         value = total_sims / elapsed
+        split = args.evaluator == 'hipnet' and args.net_algo.startswith('split_f16')
         line = {
             'metric': 'mcts_sims_per_sec', 'value': round(value, 1), 'unit': 'sims/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'warmup_moves_run': n_ramp,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1000.0 * elapsed / max(args.steps, 1), 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': ('f32 net (conv2/conv3 operands as hi + lo f16 pairs on the f16 MFMA pipe, f32 accumulation) / f64 tree'
-                      if args.evaluator == 'hipnet' and args.net_algo.startswith('split_f16') else 'f32 net / f64 tree'), 'data': 'synthetic (random-init net, torch.manual_seed(0); '
-            'games from the empty board)',
+            'dtype': 'f32 net (hi + lo f16 operand pairs on the f16 MFMA pipe, f32 accumulation) / f64 tree' if split else 'f32 net / f64 tree',
+            'data': 'synthetic (random-init net, torch.manual_seed(0); games from the empty board)',
             'config': {'workload': ('connect4_6x7_n4_selfplay_%dsims_per_move_%dgames_per_gpu' % (args.playouts, G))
                        if args.game == 'connect4' else
                        'gomoku%dx%d_n%d_selfplay_%dsims_per_move_%dgames_per_gpu' % (board, board, n_row, args.playouts, G),
-                       'games_total': G * world, 'c_puct': C_PUCT, 'temperature': TEMPERATURE,
+                       'games_total': G * world, 'lanes': lanes, 'c_puct': C_PUCT, 'temperature': TEMPERATURE,
                        'evaluator': args.evaluator,
-                       'score_mode': 'UCT_REF (bit-exact)' if args.in_flight <= 1 else
-                       'UCT_REF rule with %d simulations in flight per tree and virtual loss (opt-in, NOT the reference\'s '
-                       'sequential search)' % args.in_flight,
+                       'score_mode': ('UCT_REF (bit-exact)' if args.score_mode == 'uct_ref' else 'PUCT (opt-in)') +
+                       ('' if args.in_flight <= 1 else ', %d simulations in flight per tree (opt-in virtual loss)' % args.in_flight),
                        'multi_sim': {'sims_in_flight': max(1, args.in_flight)},
-                       'dirichlet_noise_at_every_expansion': bool(args.noise),
-                       'sims_per_graph': args.graph, 'lanes': lanes, 'parallelism': 'games sharded, dp%d' % world},
+                       'dirichlet_noise': bool(args.noise), 'sims_per_graph': args.graph,
+                       'parallelism': 'games sharded, dp%d' % world},
+            'regions_sims_per_sec': [round(r[1] / r[0], 1) for r in regions], 'warmup_moves_run': n_ramp,
             'moves_per_sec': round(total_sims / args.playouts / elapsed, 2),
             'games_finished_in_timed_region': int(total_finished),
             'selfplay_games_per_sec': selfplay['games_per_sec'] if selfplay else None,
@@ -852,88 +818,48 @@ def main():
         }
         trunk_events = [iv for ev in evaluators if isinstance(ev, TimedEvaluator) for iv in ev.events]
         if isinstance(evaluator, TimedEvaluator) and trunk_events:
-            # one launch = the trunk of one lane's leaves; durations from HIP events on that lane's
-            # stream.  With lanes > 1 the launches of different lanes overlap in time and share the
-            # CUs, so a launch's duration is longer than the kernel needs by itself (exclusive_*).
+            # One launch = the trunk on one lane's leaves.  With several lanes a launch is enqueued while the other lane's
+            # trunk still holds the CUs, so the interval between its two events contains its wait (avg_launch_ms_per_stream,
+            # also what rocprofv3 reports per dispatch): the duration charged to a launch is then the wall-clock of the timed
+            # region / trunk launches in it (everything else charged to the trunk: a lower bound of its efficiency); the
+            # kernel alone is exclusive_*.  One lane: the plain average of the event intervals.  
             n_ev = len(trunk_events)
             per_stream_ms = sum(a.elapsed_time(b) for a, b in trunk_events) / n_ev
-            # Launches of different lanes overlap: a lane's trunk is enqueued while the other lane's still holds the LDS
-            # of the CUs, and its workgroups start CU by CU as that one drains, so the interval between a launch's two
-            # events contains its wait (avg_launch_ms_per_stream; also what rocprofv3 reports per dispatch).  With
-            # several lanes the duration charged to a launch is the WALL-CLOCK of the timed region / trunk launches in
-            # it -- tree steps, FC GEMMs, kernel boundaries and host time all charged to the trunk: a lower bound of its
-            # efficiency that needs no assumption about which intervals overlap (with the lanes' moves pipelined their
-            # eager timing samples no longer coincide, so a union of sampled intervals would not mean anything).  The
-            # kernel alone is exclusive_*.  With one lane this is the plain average of the event intervals (sampled on the
-            # two moves behind the timed region, see above).
             launches_per_rank = lanes * (total_sims / world / G) / max(1, args.in_flight)
             ms = (elapsed * 1e3 / launches_per_rank) if lanes > 1 else per_stream_ms
             boards_per_launch = G / float(lanes) * max(1, args.in_flight)
             per_pos = trunk_flops_per_position(cells) if args.evaluator == 'hipnet' else flops_per_position(cells)
             flops = per_pos * boards_per_launch
             achieved = flops / (ms * 1e-3) / 1e12
-            peak, pipe_peak, peak_note = trunk_peak(args)
-            line['roofline'] = {'bound': 'mfma',
-                                'kernel': '%s, %d leaves per launch' % (evaluator.label, boards_per_launch),
-                                'achieved': round(achieved, 3), 'peak': round(peak, 1),
-                                'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'peak_note': peak_note,
-                                'traffic': pmc_traffic('k_trunk', line['config']['workload'], lanes),
-                                'avg_launch_ms': round(ms, 4), 'avg_launch_ms_per_stream': round(per_stream_ms, 4),
-                                'launches_timed': n_ev,
-                                'note': 'achieved = ALGORITHMIC flops (direct convolution, SURVEY.md 8d) per launch / '
-                                        'average launch duration. One lane: HIP events on the launch stream around every '
-                                        'trunk launch of the eager sample chunks of the two moves played right behind the timed '
-                                        'region (sampling inside it slows short-kernel configurations by up to 50 %). '
-                                        'Several lanes: their trunk launches overlap (one is enqueued while the other '
-                                        'lane\'s still holds the CUs and starts as that one drains), so avg_launch_ms = '
-                                        'wall-clock of the timed region / trunk launches in it (everything else charged to the '
-                                        'trunk: a lower bound), avg_launch_ms_per_stream = plain average of the event intervals '
-                                        'of the eager samples (waiting included; what rocprofv3 reports per dispatch); '
-                                        'exclusive_* = the same kernel launched alone after the timed region; whole_job_* = trunk flops of all '
-                                        'simulations / wall-clock; mfma_executed_frac = flops the matrix pipe '
-                                        'really executed / time / the peak of that pipe (split_f16: 3.35x the algorithmic '
-                                        'flops on the f16 pipe; Winograd F(4x4,3x3) 3.65x fewer on the f32 pipe)',
-                                'mfma_executed_frac': round(achieved / pipe_peak * executed_flop_ratio(args, cells), 4),
-                                # trunk launches of all lanes x the duration charged to one / wall-clock (the eager samples
-                                # run a little slower than the graph replays they stand for, so a trunk-bound run reads ~1)
-                                'share_of_step_time': round(ms * lanes * (total_sims / world / G / max(1, args.in_flight)) / (elapsed * 1e3), 3),
-                                'concurrent_lanes': lanes,
-                                'trunk_workgroups': trunk_wgs if trunk_wgs > 0 else n_cus}
-            rf = line['roofline']
+            peak, pipe_peak, _ = trunk_peak(args)
+            rf = {'bound': 'mfma', 'kernel': '%s, %d leaves per launch' % (evaluator.label, boards_per_launch),
+                  'achieved': round(achieved, 3), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+                  'traffic': pmc_traffic('k_trunk', line['config']['workload']),
+                  'avg_launch_ms': round(ms, 4), 'avg_launch_ms_per_stream': round(per_stream_ms, 4), 'launches_timed': n_ev,
+                  'mfma_executed_frac': round(achieved / pipe_peak * executed_flop_ratio(args, cells), 4),
+                  'trunk_workgroups': trunk_wgs if trunk_wgs > 0 else n_cus}
+            line['roofline'] = rf
             if exclusive_ms:
                 ex = flops / (exclusive_ms * 1e-3) / 1e12
                 rf['exclusive_launch_ms'] = round(exclusive_ms, 4)
-                rf['exclusive_achieved'] = round(ex, 3)
                 rf['exclusive_frac'] = round(ex / peak, 4)
                 if ms > 1.3 * exclusive_ms:
-                    # short kernels (small boards): in the eager samples the GPU drains its queue faster than Python
-                    # refills it, and the interval between a launch's two events then contains the host's enqueue gap
-                    rf['eager_samples_host_bound'] = True
-            # the two small kernels of a simulation step, bracketed the same way (per stream: beside a capped trunk
-            # they share 32 CUs with nothing but each other)
+                    rf['eager_samples_host_bound'] = True   # short kernels: the event intervals contain the host's enqueue gaps
+            # the two small kernels of a simulation step, bracketed the same way
             fc = [x.elapsed_time(y) for ev in evaluators for x, y in ev.fc_events]
             tr = [x.elapsed_time(y) for ev in evaluators for x, y in ev.tree_events]
             if fc and tr:
                 fc_ms, tr_ms = sum(fc) / len(fc), sum(tr) / len(tr)
                 per_sim = tree_bytes_per_sim(365.5, 208.8, 1.74) if (args.game == 'gomoku' and board == 15) else None
-                line['small_kernels'] = {'heads_gemm_ms': round(fc_ms, 4), 'tree_step_ms': round(tr_ms, 4),
-                                         'launches_timed': len(tr)}
+                line['small_kernels'] = {'heads_gemm_ms': round(fc_ms, 4), 'tree_step_ms': round(tr_ms, 4), 'launches_timed': len(tr)}
                 if per_sim:
+                    # (PUCT scans all children at every level: the same formula with the counts of that rule)
                     gbs = per_sim * boards_per_launch / (tr_ms * 1e-3) / 1e9
                     line['roofline_tree'] = {
-                        'bound': 'hbm', 'kernel': 'k_tree_step_raw (expand + backup of one simulation, select of the next), '
-                                                  '%d games per launch' % boards_per_launch,
+                        'bound': 'hbm', 'kernel': 'k_tree_step_raw, %d games per launch' % boards_per_launch,
                         'achieved': round(gbs, 2), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 5),
-                        'traffic': pmc_traffic('k_tree_step', line['config']['workload'], lanes),
-                        'avg_launch_ms': round(tr_ms, 4),
-                        'note': 'achieved = the ALGORITHMIC tree bytes of the reference\'s dense formulation (SURVEY.md 8d: 12 B per '
-                                'scanned child, 16 B per created child, 24 B per backed-up node, 64 B of root boards = 7.86 KB per '
-                                'simulation at 15x15) x games per launch / average launch duration (HIP events); the kernel is a '
-                                'chain of dependent loads per game (latency bound, one wave per game), not a streaming kernel'}
-            # all trunk flops of the timed region / its whole wall-clock (tree, FC, host time included)
-            whole = value / world * per_pos / 1e12
-            rf['whole_job_achieved'] = round(whole, 3)
-            rf['whole_job_frac'] = round(whole / peak, 4)
+                        'traffic': pmc_traffic('k_tree_step', line['config']['workload']),
+                        'avg_launch_ms': round(tr_ms, 4)}
         else:
             per_sim = tree_bytes_per_sim(365.5, 208.8, 1.74) if board == 15 else None
             if per_sim:
@@ -941,7 +867,7 @@ def main():
                 line['roofline'] = {'bound': 'hbm', 'kernel': 'k_select + k_expand_backup (tree only)',
                                     'achieved': round(achieved, 3), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                     'frac': round(achieved / PEAK_HBM_GBS, 6), 'traffic': None}
-        line['literal_config'] = literal
+        line['fill_%d' % FILL_GAMES_PER_GPU] = fill
         line['configs'] = config_legs
         line['cpu_baseline'] = cpu_baseline
         print(json.dumps(line), flush=True)

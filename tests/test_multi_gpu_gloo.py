@@ -124,7 +124,7 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert rec['config']['games_total'] == 64
     # 2 ranks x 32 games x 2 moves x 40 simulations in the timed region
     assert abs(rec['value'] * rec['ms_per_step'] * 2 / 1000.0 - 2 * 32 * 2 * 40) < 1.0
-    assert rec['cpu_baseline'] is None and rec['literal_config'] is None
+    assert rec['cpu_baseline'] is None and rec['fill_1536'] is None
     assert rec['selfplay']['games_sampled'] == 64 and rec['selfplay_games_per_sec'] > 0
     tg = rec['trajectory_gather']  # the one exchange of the path, here over gloo
     assert tg['ranks'] == 2 and tg['games'] >= 64 and tg['unique_game_ids'] and tg['plies'] >= 64 * 9

@@ -832,9 +832,11 @@ def main():
             flops = per_pos * boards_per_launch
             achieved = flops / (ms * 1e-3) / 1e12
             peak, pipe_peak, _ = trunk_peak(args)
+            pmc_key = line['config']['workload'] + ('+puct' if args.score_mode == 'puct' else '') + \
+                ('+k%d' % args.in_flight if args.in_flight > 1 else '')
             rf = {'bound': 'mfma', 'kernel': '%s, %d leaves per launch' % (evaluator.label, boards_per_launch),
                   'achieved': round(achieved, 3), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
-                  'traffic': pmc_traffic('k_trunk', line['config']['workload']),
+                  'traffic': pmc_traffic('k_trunk', pmc_key),
                   'avg_launch_ms': round(ms, 4), 'avg_launch_ms_per_stream': round(per_stream_ms, 4), 'launches_timed': n_ev,
                   'mfma_executed_frac': round(achieved / pipe_peak * executed_flop_ratio(args, cells), 4),
                   'trunk_workgroups': trunk_wgs if trunk_wgs > 0 else n_cus}
@@ -858,7 +860,7 @@ def main():
                     line['roofline_tree'] = {
                         'bound': 'hbm', 'kernel': 'k_tree_step_raw, %d games per launch' % boards_per_launch,
                         'achieved': round(gbs, 2), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 5),
-                        'traffic': pmc_traffic('k_tree_step', line['config']['workload']),
+                        'traffic': pmc_traffic('k_tree_step', pmc_key),
                         'avg_launch_ms': round(tr_ms, 4)}
         else:
             per_sim = tree_bytes_per_sim(365.5, 208.8, 1.74) if board == 15 else None

@@ -49,8 +49,7 @@ def main(out):
         except (OSError, ValueError, IndexError):
             continue
         workload = line['config']['workload']
-        if tag in ('puct', 'c2k16'):
-            workload += '+' + tag   # same geometry, another rule / mode: its own entry
+        workload += {'puct': '+puct', 'c2k16': '+k16'}.get(tag, '')   # same geometry, another rule / mode: its own entry
         rec = {'tag': tag, 'kernels': {}}
         per = {}
         for counter in ('FETCH_SIZE', 'WRITE_SIZE'):

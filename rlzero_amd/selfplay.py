@@ -501,10 +501,12 @@ def unpack_trajectories(header, moves, pis, board_size, n_in_row, game='gomoku')
     return out
 
 
-def gather_trajectories(trajs, board_size, n_in_row, dst=0, group=None, game='gomoku'):
+def gather_trajectories(trajs, board_size, n_in_row, dst=0, group=None, game='gomoku', pi_dtype=np.float64):
     """The one exchange of the path: every rank sends its finished trajectories to ``dst``
     (one size all_gather + one padded gather per array).  Returns the merged, game-id-sorted
-    list on ``dst`` and None elsewhere.  Without an initialised process group: identity."""
+    list on ``dst`` and None elsewhere.  Without an initialised process group: identity.
+    ``pi_dtype``: what pi travels as -- float64 (default: bit-identical to the single-process run) or float32 (what the
+    learner consumes, alphazero_agent.py:59-61: half the bytes, the exchange SURVEY.md 8e sizes; the trainer's choice)."""
     import torch
     import torch.distributed as dist
     n_cells = board_size[1] if game == 'connect4' else board_size * board_size  # width of a pi row
@@ -541,7 +543,7 @@ def gather_trajectories(trajs, board_size, n_in_row, dst=0, group=None, game='go
     sends, buckets = None, None
     try:
         sends = (padded(header, max_games, torch.int64), padded(moves, max_plies, torch.int64),
-                 padded(pis, max_plies, torch.float64))
+                 padded(pis.astype(pi_dtype, copy=False), max_plies, torch.float32 if pi_dtype == np.float32 else torch.float64))
         if rank == dst:
             buckets = [[torch.zeros_like(buf) for _ in range(world)] for buf in sends]
     except Exception as exc:  # noqa: BLE001 -- e.g. out of memory for the padded buffers

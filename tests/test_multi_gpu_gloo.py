@@ -166,3 +166,123 @@ def test_bench_collectives_on_rccl_with_one_rank():
     assert tg.get('error') is None and tg['backend'] == 'nccl' and tg['ranks'] == 1
     assert tg['games'] >= 32 and tg['unique_game_ids'] and tg['payload_bytes'] > 0
     assert rec['selfplay']['games_sampled'] == 32
+
+
+# ------------------------------------------------------------------ the multi-rank trainer (tools/train_alphazero.py)
+def _load_trainer():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('train_alphazero', os.path.join(REPO, 'tools', 'train_alphazero.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _train_on_cpu(world, games_in_flight, n_batches):
+    """TrainPipeline.run() on the CPU with the oracle as the search (the sequential reference rule driven by the CURRENT
+    network: a round's games depend on the weights the rank holds) -> (losses, buffer arrays, final weight sums)."""
+    import random
+    import torch
+    from oracle.evaluators import NetEvaluator
+    from oracle.gomoku_ref import RefGomoku
+    from oracle.mcts_ref import RefPlayer, inverse_cdf_choice, self_play_game
+    from rlzero_amd.selfplay import Trajectory, move_uniform
+    torch.set_num_threads(1)
+    torch.cuda.is_available = lambda: False   # the trainer picks its device (and the gloo backend) from this
+    mod = _load_trainer()
+    rank = int(os.environ.get('RANK', '0'))
+    random.seed(5)
+    np.random.seed(5)
+    torch.manual_seed(100 + rank)             # ranks start from DIFFERENT weights: the pipeline must hand out rank 0's
+    pipe = mod.TrainPipeline(board_size=3, n_in_row=3, n_playout=20, game_batch_num=n_batches, check_freq=50,
+                             selfplay_games_in_flight=games_in_flight, seed=11)
+    assert (pipe.rank, pipe.world) == (rank, world) and pipe.selfplay_seed == 11
+    pipe.batch_size = 16
+    played = []
+
+    def play(game_ids):
+        weights = {k: v.detach().cpu().numpy() for k, v in pipe.alphazero_agent.policy_value_net.state_dict().items()}
+        evaluator = NetEvaluator(weights, 3)
+        out = []
+        for gid in game_ids:
+            us = move_uniform(pipe.selfplay_seed, np.full(16, gid), np.arange(16))
+            player = RefPlayer(evaluator, pipe.n_playout, pipe.c_puct, is_selfplay=True, choice=inverse_cdf_choice(us))
+            winner, data, moves = self_play_game(RefGomoku(3, 3), player, temperature=1.0)
+            out.append(Trajectory(gid, 3, 3, moves, [pi for _, pi, _ in data], winner))
+        played.extend(game_ids)
+        return out
+
+    pipe._play_games = play
+    losses = []
+    real_update = pipe.policy_update
+    pipe.policy_update = lambda: losses.append(real_update()) or losses[-1]
+    pipe.run()
+    assert played == [g for g in range(n_batches * games_in_flight * world) if g % world == rank]
+    buf = list(pipe.data_buffer)
+    sums = [float(p.detach().double().abs().sum()) for p in pipe.alphazero_agent.policy_value_net.parameters()]
+    return (np.array(losses, dtype=np.float64).reshape(-1, 2),
+            np.array([s for s, _, _ in buf], dtype=np.float32).reshape(len(buf), 36),
+            np.array([p for _, p, _ in buf], dtype=np.float32).reshape(len(buf), 9),
+            np.array([z for _, _, z in buf], dtype=np.float64), np.array(sums))
+
+
+def _trainer_worker(rank, world, port, result_path):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port), RZ_DIST_BACKEND='gloo')
+    import torch.distributed as dist
+    losses, states, pis, zs, sums = _train_on_cpu(world, 3, 3)
+    if rank == 0:
+        np.savez(result_path, losses=losses, states=states, pis=pis, zs=zs, sums=sums)
+    else:
+        assert len(losses) == 0 and len(zs) == 0   # the buffer and the learner live on rank 0
+        np.savez(result_path + '.rank1.npz', sums=sums)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_trainer_equals_the_single_process_run(tmp_path):
+    """tools/train_alphazero.py on two gloo ranks: every round's games are dealt by id (g mod 2), ONE gather brings the
+    trajectories to rank 0 (pi as float32), rank 0 learns, ONE broadcast hands out the weights -- and the losses, the
+    replay buffer and the final weights are those of one process playing the same ids (the reference's loop,
+    train_alphazero.py:81-137,164-190).  The games depend on the weights, so a rank that missed a broadcast would
+    play different games."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    result = str(tmp_path / 'two.npz')
+    mp.spawn(_trainer_worker, args=(2, port, result), nprocs=2, join=True)
+    two = np.load(result)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        os.environ.pop(k, None)
+    losses, states, pis, zs, sums = _train_on_cpu(1, 6, 3)
+    assert len(losses) == 3 and np.array_equal(two['losses'], losses)
+    assert np.array_equal(two['states'], states) and np.array_equal(two['pis'], pis) and np.array_equal(two['zs'], zs)
+    assert np.array_equal(two['sums'], sums)
+    assert np.array_equal(np.load(result + '.rank1.npz')['sums'], sums)   # rank 1 ends with rank 0's weights
+
+
+@pytest.mark.gpu
+def test_trainer_two_ranks_on_one_gpu(tmp_path):
+    """`python tools/train_alphazero.py --gpus 2` with NO launcher on a 1-GPU box (the two ranks share cuda:0 and meet over
+    gloo: RCCL refuses two ranks on one device): BatchedSelfPlay on each rank's share of the ids, the gather, rank 0's
+    policy_update, the weight broadcast, refresh_weights on every lane -- against one process playing the same 16 ids:
+    the first round's games are the same (a game depends on (seed, id) only), so its log lines agree."""
+    import subprocess
+    env = dict(os.environ, RZ_DIST_SINGLE_DEVICE='1', RZ_DIST_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    common = ['--board', '6', '--n-in-row', '4', '--playouts', '30', '--batches', '2', '--seed', '3']
+    outs = []
+    for gpus, in_flight in ((2, 8), (1, 16)):
+        cmd = [sys.executable, os.path.join(REPO, 'tools', 'train_alphazero.py'), '--gpus', str(gpus), '--games-in-flight',
+               str(in_flight)] + common
+        out = subprocess.run(cmd, env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        assert out.returncode == 0, out.stderr.decode()[-2000:]
+        outs.append([ln for ln in out.stdout.decode().splitlines() if ln.startswith(('batch i:', 'kl:'))])
+    two, one = outs
+    assert len(two) == 4 and len(one) == 4 and two[0] == one[0] and two[0].startswith('batch i:1, episode_len:')
+    num = lambda line: {k: float(v) for k, v in (item.split(':') for item in line.split(','))}  # noqa: E731
+    a, b = num(two[1]), num(one[1])
+    assert abs(a['loss'] - b['loss']) <= 1e-3 and abs(a['entropy'] - b['entropy']) <= 1e-3
+    assert two[2].startswith('batch i:2, episode_len:') and one[2].startswith('batch i:2, episode_len:')

@@ -7,8 +7,15 @@ lines :124-136,161,170), running on the MI355X engine.
 Two ways to collect self-play data:
   * ``selfplay_games_in_flight == 0`` (default): the reference's flow -- one game at a time
     through ``GameControl.start_self_play`` and ``AlphaZeroPlayer`` (search on the GPU);
-  * ``selfplay_games_in_flight  > 0``: that many games in lock-step per collection round
+  * ``selfplay_games_in_flight  > 0``: that many games in lock-step per collection round and GPU
     (``rlzero_amd.selfplay.BatchedSelfPlay``), the mode the hardware is built for.
+
+Several GPUs (``python tools/train_alphazero.py --gpus N ...`` starts one process per GPU itself, or run it under
+``torch.distributed.run``): the games of a collection round are dealt to the ranks by id (game g -> rank g mod N, no
+collective inside the search), ONE gather brings the finished trajectories to rank 0, which alone keeps the replay buffer
+and runs ``policy_update`` / ``policy_evaluate`` / the checkpoints (train_alphazero.py:81-137,164-190), then ONE broadcast
+hands every rank the new weights for its next round.  A game's trajectory depends on (seed, game id) only, so the data --
+and with them the losses -- are those of the single-process run on the same ids.
 
 Reference quirks kept on purpose: ``lr_multiplier`` is adapted but never
 applied and ``learn_rate`` is never passed to the agent (D-7); ``policy_evaluate`` counts
@@ -50,12 +57,15 @@ def _symmetries(planes, pi_grid):
 class TrainPipeline:
 
     def __init__(self, board_size=6, n_in_row=4, n_playout=400, game_batch_num=64, check_freq=50,
-                 selfplay_games_in_flight=0, buffer_size=None):
+                 selfplay_games_in_flight=0, buffer_size=None, seed=None):
         """``buffer_size``: length of the replay deque.  None = the reference's 1000 (train_alphazero.py:32) in the
         reference flow; in the batched mode (``selfplay_games_in_flight > 0``) None sizes it to hold ONE collection
         round (games in flight x board cells x 8 symmetries) -- a documented deviation: with the reference's 1000 a
         256-game round (~200 k augmented samples) would keep its last 1000 samples and drop > 99 % of what the GPU
-        produced.  Pass 1000 to get the reference's number in either mode."""
+        produced.  Pass 1000 to get the reference's number in either mode.  ``seed``: of the batched mode's move draws
+        (uniforms keyed (seed, game id, ply)); None = drawn on rank 0.  Under a launcher (RANK / WORLD_SIZE set, or an
+        initialised process group) the pipeline is one of the ranks: see the module docstring."""
+        self.rank, self.world = self._init_ranks()
         # board and game
         self.board_size = board_size
         self.n_in_row = n_in_row
@@ -69,7 +79,7 @@ class TrainPipeline:
         self.c_puct = 5
         if buffer_size is None:
             buffer_size = 1000 if selfplay_games_in_flight <= 0 else \
-                max(1000, selfplay_games_in_flight * board_size * board_size * 8)
+                max(1000, selfplay_games_in_flight * self.world * board_size * board_size * 8)
         self.buffer_size = int(buffer_size)
         self.batch_size = 32
         self.data_buffer = deque(maxlen=self.buffer_size)
@@ -79,7 +89,7 @@ class TrainPipeline:
         self.check_freq = check_freq
         self.game_batch_num = game_batch_num
         self.best_win_ratio = 0.0
-        self.device = torch.device('cuda') if torch.cuda.is_available() else torch.device('cpu')
+        self.device = self._pick_device()
         self.pure_mcts_playout_num = 100
         self.selfplay_games_in_flight = selfplay_games_in_flight
         self.alphazero_agent = AlphaZeroAgent(self.board_size, device=self.device)
@@ -87,6 +97,50 @@ class TrainPipeline:
                                            c_puct=self.c_puct, is_selfplay=True)
         self._batched = None
         self._next_game_id = 0
+        self.selfplay_seed = self._agree_on(random.getrandbits(31) if seed is None else int(seed))
+        if self.world > 1:   # every rank starts from rank 0's weights
+            from rlzero.algorithms import broadcast_weights
+            broadcast_weights(self.alphazero_agent.policy_value_net, src=0)
+
+    # ------------------------------------------------------------------ ranks
+    @staticmethod
+    def _init_ranks():
+        """-> (rank, world).  One process per GPU; the process group is RCCL (backend nccl) on GPUs, gloo on the CPU or when
+        RZ_DIST_BACKEND says so (two ranks on one GPU: RCCL refuses that)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+        world = int(os.environ.get('WORLD_SIZE', '1'))
+        if world <= 1:
+            return 0, 1
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        backend = os.environ.get('RZ_DIST_BACKEND', 'nccl' if torch.cuda.is_available() else 'gloo')
+        if backend == 'nccl':
+            local = 0 if os.environ.get('RZ_DIST_SINGLE_DEVICE') == '1' else int(os.environ.get('LOCAL_RANK', '0'))
+            torch.cuda.set_device(local)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
+        return dist.get_rank(), dist.get_world_size()
+
+    def _pick_device(self):
+        if not torch.cuda.is_available():
+            return torch.device('cpu')
+        if self.world == 1:
+            return torch.device('cuda')
+        local = 0 if os.environ.get('RZ_DIST_SINGLE_DEVICE') == '1' else int(os.environ.get('LOCAL_RANK', str(self.rank)))
+        torch.cuda.set_device(local)
+        return torch.device('cuda', local)
+
+    def _agree_on(self, value):
+        """rank 0's ``value`` (an int) on every rank."""
+        if self.world == 1:
+            return value
+        import torch.distributed as dist
+        on_gpu = dist.get_backend() == 'nccl'
+        t = torch.tensor([value], dtype=torch.int64, device=self.device if on_gpu else 'cpu')
+        dist.broadcast(t, src=0)
+        return int(t.item())
 
     # ------------------------------------------------------------------ data
     def get_equi_data(self, play_data):
@@ -98,23 +152,36 @@ class TrainPipeline:
                 extend_data.append((equi_state, equi_prob, winner))
         return extend_data
 
-    def _collect_batched(self, n_games):
+    def _play_games(self, game_ids):
+        """The trajectories of ``game_ids`` (this rank's share of a round), games in lock-step on this rank's GPU."""
         from rlzero.algorithms import BatchedSelfPlay
         if self._batched is None:
             # one or two lanes of games, whichever fills the GPU better (selfplay.plan_lanes)
             self._batched = BatchedSelfPlay.for_network(
                 self.alphazero_agent.policy_value_net, self.board_size, self.n_in_row,
                 n_games=self.selfplay_games_in_flight, n_playout=self.n_playout, c_puct=self.c_puct,
-                device=str(self.device), temperature=self.temperature, seed=random.getrandbits(31))
-        self._batched.refresh_weights()
+                device=str(self.device), temperature=self.temperature, seed=self.selfplay_seed)
+        self._batched.refresh_weights()   # (every lane's evaluator: the learner has stepped / new weights have arrived)
+        return self._batched.run(game_ids) if len(game_ids) else []
+
+    def _collect_batched(self, n_games):
+        """One collection round: ``n_games`` games in all, game g played by rank g mod world (selfplay.shard_game_ids),
+        one gather to rank 0 (pi as float32: what the learner consumes).  -> start_self_play's tuples on rank 0, in game
+        id order; [] on the other ranks."""
+        from rlzero.algorithms import gather_trajectories
         ids = range(self._next_game_id, self._next_game_id + n_games)
         self._next_game_id += n_games
-        return [t.as_reference_tuple() for t in self._batched.run(ids)]
+        local = self._play_games([g for g in ids if g % self.world == self.rank])
+        if self.world > 1:
+            merged = gather_trajectories(local, self.board_size, self.n_in_row, dst=0, pi_dtype=np.float32)
+        else:
+            merged = sorted(local, key=lambda t: t.game_id)
+        return [t.as_reference_tuple() for t in merged] if merged is not None else []
 
     def collect_selfplay_data(self, n_games=1):
         """collect self-play data for training."""
         if self.selfplay_games_in_flight > 0:
-            games = self._collect_batched(max(n_games, self.selfplay_games_in_flight))
+            games = self._collect_batched(max(n_games, self.selfplay_games_in_flight * self.world))
         else:
             games = [self.game.start_self_play(self.mcts_player, temperature=self.temperature)
                      for _ in range(n_games)]
@@ -165,15 +232,24 @@ class TrainPipeline:
                                                                   win_cnt[2], win_cnt[-1]))
         return win_ratio
 
+    def _sync_weights(self):
+        """After rank 0's policy_update: its parameters on every rank (one broadcast; nothing to do in one process)."""
+        if self.world > 1:
+            from rlzero.algorithms import broadcast_weights
+            broadcast_weights(self.alphazero_agent.policy_value_net, src=0)
+
     def run(self):
         """run the training pipeline."""
+        lead = self.rank == 0   # rank 0 holds the buffer, learns, evaluates, saves and prints; the others play their share
         try:
             for i in range(self.game_batch_num):
                 self.collect_selfplay_data(self.play_batch_size)
-                print('batch i:{}, episode_len:{}'.format(i + 1, self.episode_len))
-                if len(self.data_buffer) > self.batch_size:
-                    loss, entropy = self.policy_update()
-                if (i + 1) % self.check_freq == 0:
+                if lead:
+                    print('batch i:{}, episode_len:{}'.format(i + 1, self.episode_len))
+                    if len(self.data_buffer) > self.batch_size:
+                        loss, entropy = self.policy_update()
+                self._sync_weights()
+                if lead and (i + 1) % self.check_freq == 0:
                     print('current self-play batch: {}'.format(i + 1))
                     win_ratio = self.policy_evaluate()
                     self.alphazero_agent.save_model('./current_policy.model')
@@ -188,6 +264,48 @@ class TrainPipeline:
             print('\n\rquit')
 
 
+def launch_ranks(n):
+    """`--gpus n` without a launcher: run this command line under torch.distributed.run as a CHILD process (this process
+    never touches the GPU); returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr',
+           '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main():
+    import argparse
+    ap = argparse.ArgumentParser(description='AlphaZero training for Gomoku on MI355X (no arguments: the reference script\'s run)')
+    ap.add_argument('--gpus', type=int, default=1, help='processes (one per GPU); > 1 without a launcher starts them itself')
+    ap.add_argument('--board', type=int, default=6)
+    ap.add_argument('--n-in-row', type=int, default=4)
+    ap.add_argument('--playouts', type=int, default=400)
+    ap.add_argument('--batches', type=int, default=64, help='game_batch_num')
+    ap.add_argument('--check-freq', type=int, default=50)
+    ap.add_argument('--games-in-flight', type=int, default=0, help='per GPU; 0 = the reference flow, one game at a time')
+    ap.add_argument('--seed', type=int, default=None)
+    args = ap.parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+    if args.seed is not None:   # a reproducible run: initial weights, random.sample of the replay buffer, numpy draws
+        random.seed(args.seed)
+        np.random.seed(args.seed)
+        torch.manual_seed(args.seed)
+    pipe = TrainPipeline(board_size=args.board, n_in_row=args.n_in_row, n_playout=args.playouts, game_batch_num=args.batches,
+                         check_freq=args.check_freq, selfplay_games_in_flight=args.games_in_flight, seed=args.seed)
+    if pipe.world > 1 and args.games_in_flight <= 0:
+        raise SystemExit('several ranks share a collection round: pass --games-in-flight > 0')
+    pipe.run()
+    if pipe.world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 if __name__ == '__main__':
-    training_pipeline = TrainPipeline()
-    training_pipeline.run()
+    main()

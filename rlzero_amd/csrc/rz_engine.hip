@@ -1896,11 +1896,14 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
             delete e;
             return fail(RZ_ERR_ARG, "sims_in_flight %d x %d actions needs %d bytes of LDS (> 160 KB)", cfg->sims_in_flight, A, need);
         }
-        hipError_t a1 = hipFuncSetAttribute((const void *)k_tree_step_ml<true>, hipFuncAttributeMaxDynamicSharedMemorySize, e->ml_lds);
-        hipError_t a2 = hipFuncSetAttribute((const void *)k_tree_step_ml<false>, hipFuncAttributeMaxDynamicSharedMemorySize, e->ml_lds);
+        // the attribute belongs to the kernel, not to this engine: set to the hardware's 160 KB once and for all, so that a
+        // later engine with a smaller K x A cannot lower it under an earlier, larger one
+        const int most = 160 * 1024;
+        hipError_t a1 = hipFuncSetAttribute((const void *)k_tree_step_ml<true>, hipFuncAttributeMaxDynamicSharedMemorySize, most);
+        hipError_t a2 = hipFuncSetAttribute((const void *)k_tree_step_ml<false>, hipFuncAttributeMaxDynamicSharedMemorySize, most);
         if (a1 != hipSuccess || a2 != hipSuccess) {
             delete e;
-            return fail(RZ_ERR_HIP, "hipFuncSetAttribute(dynamic LDS %d bytes) failed", e->ml_lds);
+            return fail(RZ_ERR_HIP, "hipFuncSetAttribute(dynamic LDS %d bytes) failed", most);
         }
     }
     D.score_mode = cfg->score_mode;

@@ -153,6 +153,7 @@ class HipNet(object):
         code = {'auto': _hip.NET_HEADS_AUTO, 'f32': _hip.NET_HEADS_F32, 'split32': _hip.NET_HEADS_SPLIT_32,
                 'split64': _hip.NET_HEADS_SPLIT_64, 'parts': _hip.NET_HEADS_SPLIT_PARTS}[algo]
         check(self.lib.rz_net_set_heads_algo(self.handle, code), 'rz_net_set_heads_algo')
+        self.heads_algo = algo
         return self
 
     def set_max_workgroups(self, n):

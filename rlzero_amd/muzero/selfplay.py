@@ -15,6 +15,7 @@ import numpy as np
 
 class Episode(object):
     """One finished (or running) episode: observations, actions, rewards, search policies, root values."""
+    FIELDS = ('obs', 'actions', 'rewards', 'policies', 'root_values')
 
     def __init__(self):
         self.obs, self.actions, self.rewards, self.policies, self.root_values = [], [], [], [], []
@@ -93,6 +94,9 @@ class ReplayBuffer(object):
     def add(self, episode):
         if len(episode) == 0:
             return
+        # an Episode cut out of an EpisodeSeq is views into that stretch's block: kept as they are, one stored episode would
+        # keep the whole block (thousands of episodes) alive -- the buffer owns its copies
+        episode = Episode.from_arrays(*(np.array(getattr(episode, name)) for name in Episode.FIELDS))
         self.episodes.append(episode)
         if len(self.episodes) > self.capacity:
             self.episodes.pop(0)
@@ -169,7 +173,9 @@ class MuZeroSelfPlay(object):
         # step history of the host-driven loop: rings [step % HIST][environment] on the host (allocated at the first
         # move: the fused moves keep their history on the device); an episode is cut out of them (one fancy index per
         # field) when it ends.  CartPole-v1 truncates at 500 steps, so 512 steps of history always cover an episode.
-        self.HIST = max(512, int(getattr(env, 'max_episode_steps', 500)) + 12)
+        if not hasattr(env, 'max_episode_steps'):
+            raise ValueError('the environment must state max_episode_steps: the step history is a ring of that many steps')
+        self.HIST = max(512, int(env.max_episode_steps) + 12)
         self._h_obs = None
         self._t = 0                                           # global step index of the next move
         self._ep_start = np.zeros(self.n_envs, dtype=np.int64)
@@ -367,6 +373,8 @@ class MuZeroSelfPlay(object):
             start[order] = start_s
             # all episodes in ONE gather per field; an Episode is cut out when it is read
             lengths = end - start
+            if int(lengths.max()) > self.HIST:   # (cannot happen while the environment keeps its max_episode_steps)
+                raise RuntimeError('an episode of %d steps does not fit the history ring of %d' % (int(lengths.max()), self.HIST))
             env_idx = np.repeat(ee, lengths)
             within = np.arange(int(lengths.sum())) - np.repeat(np.cumsum(lengths) - lengths, lengths)
             step_idx = (np.repeat(start, lengths) + within) % self.HIST
@@ -382,7 +390,7 @@ class MuZeroSelfPlay(object):
             G, K = self.n_envs, self.moves_per_launch
             row = self.net.obs_dim + 4 + self.n_actions
             kw = dict(device=self.device)
-            steps = int(getattr(self.env, 'max_episode_steps', 500)) + 2 * K + 12
+            steps = int(self.env.max_episode_steps) + 2 * K + 12
             self._ring = t.zeros((G, steps, row), dtype=t.float64, **kw)
             self._ep_start_dev = t.full((G, ), self._t, dtype=t.int64, **kw)
             # in the steady state a launch ends about as many steps of episodes as it plays (G x K); twice that, plus a

@@ -282,6 +282,11 @@ class BatchedSelfPlay(object):
             self.slot_pis[s] = []
         for lane in self.lanes:
             if mask[lane.slots].any():
+                if getattr(lane, 'primed', False):
+                    # a pipelined run that stopped early (max_moves) left the next move's simulations enqueued: they end
+                    # on the old roots, and the trees reset here must not be taken for searched ones
+                    lane.stream.synchronize()
+                    lane.primed = False
                 with self._on(lane):
                     lane.eng.reset_games(mask=mask[lane.slots])
 
@@ -292,6 +297,14 @@ class BatchedSelfPlay(object):
                 lane.eng.set_active(active[lane.slots])
 
     def _simulate(self):
+        if any(getattr(lane, 'primed', False) for lane in self.lanes):
+            # a lane primed by play_move_pipelined has the coming move's simulations in flight already: searching it again
+            # would double its visits -- the lanes are taken one by one, the primed ones as they are
+            for lane in self.lanes:
+                if not getattr(lane, 'primed', False):
+                    self._simulate_lane(lane)
+                lane.primed = False
+            return
         n = self.eng.n_playout
         if self.use_graph:
             per = self.eng.graph_chunk(self.sims_per_graph)
@@ -477,7 +490,7 @@ class BatchedSelfPlay(object):
             n_moves += 1
             if max_moves is not None and n_moves >= max_moves:
                 break
-        self.torch.cuda.synchronize()
+        self.torch.cuda.synchronize()   # (lanes still primed hold a finished search: play_move() / play_move_pipelined() use it)
         self.check()
         return sorted(out, key=lambda t: t.game_id)
 

@@ -352,6 +352,53 @@ def test_full_size_batches_of_the_baseline_configs(config):
         lane.eng.close()
 
 
+@pytest.mark.parametrize('n_games', [512, 1536])
+def test_full_size_shipped_layout_equals_one_plain_lane(n_games):
+    """The layout bench.py times -- two co-resident lanes with un-capped trunks, the LDS-free 'parts' FC GEMM, hipGraphs of 8
+    simulation steps, the host side of a lane's move pipelined under the other lane's simulations -- at FULL size (15x15,
+    800 simulations per move; 512 games = BASELINE.json configs[3]'s share of a GPU, 1536 = the batch that fills one)
+    against ONE lane launched kernel by kernel with every move finished on the host before the next search: the layout is
+    scheduling only, so every game's moves and pi are the same bits; no subtree dropped, no flag, pi from exact counts."""
+    import torch
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    from rlzero_amd.selfplay import BatchedSelfPlay
+    torch.manual_seed(0)
+    net = PolicyValueNet(15).to('cuda:0')
+    plies, sims = 4, 800
+
+    def play(shipped):
+        kw = {} if shipped else dict(lanes=1, use_graph=False)
+        sp = BatchedSelfPlay.for_network(net, 15, 5, n_games=n_games, n_playout=sims, seed=5, **kw)
+        if shipped:
+            assert len(sp.lanes) == 2 and sp.trunk_workgroups == 0 and sp.use_graph
+            assert all(lane.evaluator.hip.heads_algo == 'parts' for lane in sp.lanes)
+        sp._start(range(n_games), range(n_games))
+        sp._set_active()
+        for _ in range(plies):
+            done = sp.play_move_pipelined() if shipped else sp.play_move()
+            assert not done   # no 15x15 game ends within 4 plies
+        torch.cuda.synchronize()
+        for st in sp.check():
+            assert st.reuse_dropped == 0 and st.max_slots_used < st.arena_slots
+        assert sp.moves_done == plies * n_games and sp.sims_done >= plies * n_games * sims
+        moves = np.array([sp.slot_moves[s] for s in range(n_games)], dtype=np.int64)
+        pis = np.array([sp.slot_pis[s] for s in range(n_games)], dtype=np.float64)
+        for lane in sp.lanes:
+            lane.evaluator.hip.check_flags()
+            lane.eng.close()
+        return moves, pis
+
+    moves, pis = play(True)
+    moves1, pis1 = play(False)
+    assert moves.shape == (n_games, plies) and np.array_equal(moves, moves1)
+    assert np.array_equal(pis.view(np.uint64), pis1.view(np.uint64))
+    assert np.abs(pis.sum(axis=2) - 1.0).max() < 1e-9
+    for ply in range(1, plies):   # a move never lands on an occupied cell, and pi gives earlier moves no mass
+        for earlier in range(ply):
+            assert (moves[:, ply] != moves[:, earlier]).all()
+            assert (pis[np.arange(n_games), ply, moves[:, earlier]] == 0.0).all()
+
+
 # ------------------------------------------------------------------ player / game loop (G3)
 class _Injected(object):
 
@@ -501,7 +548,22 @@ def test_two_capped_lanes_with_graphs_equal_one_eager_lane():
     assert three.lanes[0].evaluator.hip.max_boards >= 4 and three.trunk_workgroups == 0
     same(one.run(range(54, 90)), three.run(range(54, 90), pipelined=True))
     same(two.run(range(90, 110), pipelined=True), three.run(range(90, 110)))
-    for lane in one.lanes + two.lanes + three.lanes:
+    # a pipelined run cut short leaves lanes with the next move's simulations enqueued: a later run starts clean, and
+    # play_move() after play_move_pipelined() takes a primed lane's search as it is (no second search on top)
+    three.run(range(200, 236), max_moves=3, pipelined=True)
+    assert any(getattr(lane, 'primed', False) for lane in three.lanes)
+    same(one.run(range(110, 140)), three.run(range(110, 140)))
+    mixed = BatchedSelfPlay.for_network(net, lanes=2, use_graph=True, sims_per_graph=8, **kw)
+    plain = BatchedSelfPlay.for_network(net, lanes=1, use_graph=False, **kw)
+    for sp_ in (mixed, plain):
+        sp_._start(range(12), range(300, 312))
+        sp_._set_active()
+    for ply in range(4):
+        assert not (mixed.play_move_pipelined() if ply % 2 == 0 else mixed.play_move()) and not plain.play_move()
+    assert mixed.slot_moves == plain.slot_moves
+    rn_m = np.concatenate([lane.eng.root_stats()[0] for lane in mixed.lanes])
+    assert np.array_equal(rn_m, plain.eng.root_stats()[0])   # no tree carries a search too many
+    for lane in one.lanes + two.lanes + three.lanes + mixed.lanes + plain.lanes:
         lane.eng.close()
 
 

@@ -241,6 +241,7 @@ def test_muzero_tree_kernels_bit_exact_vs_pseudocode(fused):
 
 class _BareEnv(object):
     """What MuZeroSelfPlay.search needs of an environment (no stepping): sizes, device, observations."""
+    max_episode_steps = 500
 
     def __init__(self, n_envs, n_actions, obs):
         self.n_envs, self.n_actions, self.device, self._obs = n_envs, n_actions, obs.device, obs

@@ -1,12 +1,13 @@
 #!/bin/bash
 # Round 3: collects what is kept under profiles/r03/ on a GPU box (run from the repository root):
 #   bash profiles/collect_r03.sh [quick]
-# Output goes to gpurun_out/r03/ (scratch); profiles/summarise_r03.py picks the files to keep.
+# Raw rocprofv3 output goes to /tmp/rz_r03 on the box (hundreds of MB); profiles/summarise_r03.py picks the files to keep and
+# they come back under gpurun_out/r03/ (copy them to profiles/r03/).
 # rocprofv3 is always given the program itself after `--`; counters get their own passes (one counter per pass).
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/r03
-mkdir -p "$OUT"
+OUT=/tmp/rz_r03
+rm -rf "$OUT"; mkdir -p "$OUT" "$ROOT/gpurun_out/r03"
 cd /tmp && export TMPDIR=/tmp
 B="python3 $ROOT/bench.py --no-cpu-baseline --no-games-leg --no-fill --no-configs --regions 1"
 
@@ -49,4 +50,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_c5_$c" -o p -- $B --game muzero --playouts 50 --games 8192 --steps 32 --warmup 16 > "$OUT/pmc_c5.json" 2> /dev/null
 done
 echo "pmc done"
-cd "$ROOT" && python3 profiles/summarise_r03.py "$OUT"
+cd "$ROOT" && python3 profiles/summarise_r03.py "$OUT" && cp "$OUT"/keep/* "$ROOT/gpurun_out/r03/"

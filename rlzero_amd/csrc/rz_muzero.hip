@@ -690,7 +690,10 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
     float *REW = reinterpret_cast<float *>(pp + gpw * tcap * (int)sizeof(MzHot));   // [gpw][tcap] rewards (TREE_LDS)
 
     // ---- once: weight fragments into registers (A operand of 16x16x4: lane holds W[unit 16w + n][k = 4s + q])
-    float a1[kMzKX / 4], a2[kMzH / 4], ar[kMzH / 4], ap[kMzH / 4], arep1[kMzObs / 4], arep2[kMzH / 4];
+    // (the representation network's fragments -- 18 + 8 registers, used once per MOVE -- are fetched at the start of every
+    // move instead: kept for the whole launch they push the MOVES variants past the 256 registers of two workgroups per CU
+    // and into scratch, in the middle of the per-simulation chain)
+    float a1[kMzKX / 4], a2[kMzH / 4], ar[kMzH / 4], ap[kMzH / 4];
     const int unit = 16 * w + n;
 #pragma unroll
     for (int s = 0; s < kMzKX / 4; ++s) {
@@ -703,11 +706,8 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
         a2[s] = M.dyn2_w[k * kMzH + unit];
         ar[s] = M.rew1_w[k * kMzH + unit];
         ap[s] = M.pre1_w[k * kMzH + unit];
-        arep2[s] = MOVES ? M.rep2_w[k * kMzH + unit] : 0.0f;
     }
-#pragma unroll
-    for (int s = 0; s < kMzObs / 4; ++s) arep1[s] = MOVES ? M.rep1_w[(4 * s + q) * kMzH + unit] : 0.0f;
-    mz_f32x4 b1, b2, br, bp, brep1 = {0.0f, 0.0f, 0.0f, 0.0f}, brep2 = {0.0f, 0.0f, 0.0f, 0.0f};   // biases in the C/D layout: rows 16w + 4q + i
+    mz_f32x4 b1, b2, br, bp;   // biases in the C/D layout: rows 16w + 4q + i
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = 16 * w + 4 * q + i;
@@ -715,10 +715,6 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
         b2[i] = M.dyn2_b[row];
         br[i] = M.rew1_b[row];
         bp[i] = M.pre1_b[row];
-        if (MOVES) {
-            brep1[i] = M.rep1_b[row];
-            brep2[i] = M.rep2_b[row];
-        }
     }
     if (tid == 0) {
         HB[0] = M.rew2_b[0];
@@ -864,6 +860,22 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
     for (int move = 0; move < n_moves; ++move) {
         if (MOVES) {
             // ---- initial inference: s0 = scale(rep2 relu(rep1 obs)) -> hidden slot 0; root priors = softmax(pol(relu(pre1 s0)))
+            // the representation network's fragments and biases, from L2 (laundered pointers: the loads stay inside the move)
+            float arep1[kMzObs / 4], arep2[kMzH / 4];
+            mz_f32x4 brep1, brep2;
+            {
+                const float *r1w = M.rep1_w, *r2w = M.rep2_w, *r1b = M.rep1_b, *r2b = M.rep2_b;
+                asm volatile("" : "+s"(r1w), "+s"(r2w), "+s"(r1b), "+s"(r2b));
+#pragma unroll
+                for (int s = 0; s < kMzObs / 4; ++s) arep1[s] = r1w[(4 * s + q) * kMzH + unit];
+#pragma unroll
+                for (int s = 0; s < kMzH / 4; ++s) arep2[s] = r2w[(4 * s + q) * kMzH + unit];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    brep1[i] = r1b[16 * w + 4 * q + i];
+                    brep2[i] = r2b[16 * w + 4 * q + i];
+                }
+            }
             __syncthreads();   // (OBS of this move is written; the last move's reads of RED / XS are over)
             if (tid < kMzTile) Gleaf[tid] = 0;
             {

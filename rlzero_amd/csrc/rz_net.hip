@@ -1369,13 +1369,21 @@ constexpr int kLdsBytes = sp::kInBytes + Geo<32>::grid_bytes + Geo<64>::grid_byt
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 
 // slot J = (K-step s, row t): its 3 * TM MFMAs; in front of them the activation fragments of slot J + kLA and, behind the
-// first rows of a step, the weight fragments of step s + 1
+// first rows of a step, the weight fragments of step s + 1.
+// A slot whose tap row lies in the zero ring above / below the board -- (dy = 0, row 0) and (dy = 2, row NT - 1): the kernel
+// runs boards of exactly NT rows -- multiplies zeros: it is skipped whole (no fragment read, no MFMA: 2 of 45 (row, dy) pairs,
+// 4.4 % of a layer's MFMAs; adding +0 products would leave the sums as they are).
+template <int CIN, int NT>
+__device__ __forceinline__ constexpr bool dead_slot(int j) {
+    const int s = j / NT, t = j % NT, dy = s / Geo<CIN>::chunks / 3;
+    return (dy == 0 && t == 0) || (dy == 2 && t == NT - 1);
+}
 template <int CIN, int TM, int NT, int J>
 __device__ __forceinline__ void slot(f32x4 (&acc)[TM][NT], f16x8 (&a)[kAD][TM][2], f16x8 (&b)[kLA + 1][2], lds_frag q, lds_frag qf,
                                      __amdgpu_buffer_rsrc_t w_rsrc, int w_lane) {
     using G = Geo<CIN>;
     constexpr int PD = kLA + 1, s = J / NT, t = J % NT, J2 = J + kLA;
-    if constexpr (J2 < G::steps * NT) {
+    if constexpr (J2 < G::steps * NT && !dead_slot<CIN, NT>(J2 < G::steps * NT ? J2 : 0)) {
         constexpr int s2 = J2 / NT, t2 = J2 % NT, tap = s2 / G::chunks, c = s2 % G::chunks;
         constexpr int row = t2 + tap / 3, far = row >= 8;   // (qf = q + 8 halo rows: the immediate offset has 16 bits)
         constexpr int off = ((row - 8 * far) * kRowW + tap % 3) * G::pos_bytes + c * 64;
@@ -1387,18 +1395,22 @@ __device__ __forceinline__ void slot(f32x4 (&acc)[TM][NT], f16x8 (&a)[kAD][TM][2
 #pragma unroll
         for (int p = 0; p < 2; ++p) a[(s + 1) % kAD][t][p] = sp::load_w(w_rsrc, w_lane, ((t * G::steps + s + 1) * 2 + p) * 1024);
     }
+    if constexpr (!dead_slot<CIN, NT>(J)) {
+        // a row's first live K-step: step 0, or the first step of kernel row 1 for board row 0
+        constexpr int first = t == 0 ? 3 * G::chunks : 0;
 #pragma unroll
-    for (int combo = 0; combo < 3; ++combo)
+        for (int combo = 0; combo < 3; ++combo)
 #pragma unroll
-        for (int m = 0; m < TM; ++m) {
-            const int pa = combo == 2 ? 1 : 0, pb = combo == 1 ? 1 : 0;
-            if (s == 0 && combo == 0) {   // the first MFMA of a tile starts from the constant 0
-                const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s % kAD][m][pa], b[J % PD][pb], zero, 0, 0, 0);
-            } else {
-                acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s % kAD][m][pa], b[J % PD][pb], acc[m][t], 0, 0, 0);
+            for (int m = 0; m < TM; ++m) {
+                const int pa = combo == 2 ? 1 : 0, pb = combo == 1 ? 1 : 0;
+                if (s == first && combo == 0) {   // the first MFMA of a tile starts from the constant 0
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s % kAD][m][pa], b[J % PD][pb], zero, 0, 0, 0);
+                } else {
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s % kAD][m][pa], b[J % PD][pb], acc[m][t], 0, 0, 0);
+                }
             }
-        }
+    }
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -1430,7 +1442,7 @@ __device__ __forceinline__ void conv(const char *in, const void *wts, int lane, 
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(wts), 0, 0x7fffffff, 0x00020000);
     f16x8 b[kLA + 1][2];
 #pragma unroll
-    for (int j = 0; j < kLA; ++j) {   // slots 0 .. kLA - 1: K-step 0 (tap 0, chunk 0), rows 0 ..
+    for (int j = 1; j < kLA; ++j) {   // slots 1 .. kLA - 1: K-step 0 (tap 0, chunk 0), rows 1 .. (slot 0 is a dead one)
         b[j][0] = q[(j * kRowW * G::pos_bytes) / 16];
         b[j][1] = q[(j * kRowW * G::pos_bytes + CIN * 2) / 16];
     }

@@ -1364,90 +1364,88 @@ template <int CIN> struct Geo {
     static_assert((pos_bytes / 16) % 4 == 2, "conflict-free ds_read_b128");
 };
 constexpr int kLA = 3;   // activation fragments are requested kLA rows ahead
-constexpr int kAD = 2;   // weight fragments: the next K-step's while this one computes
 constexpr int kLdsBytes = sp::kInBytes + Geo<32>::grid_bytes + Geo<64>::grid_bytes;
 static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 
-// slot J = (K-step s, row t): its 3 * TM MFMAs; in front of them the activation fragments of slot J + kLA and, behind the
-// first rows of a step, the weight fragments of step s + 1.
-// A slot whose tap row lies in the zero ring above / below the board -- (dy = 0, row 0) and (dy = 2, row NT - 1): the kernel
-// runs boards of exactly NT rows -- multiplies zeros: it is skipped whole (no fragment read, no MFMA: 2 of 45 (row, dy) pairs,
-// 4.4 % of a layer's MFMAs; adding +0 products would leave the sums as they are).
-template <int CIN, int NT>
-__device__ __forceinline__ constexpr bool dead_slot(int j) {
-    const int s = j / NT, t = j % NT, dy = s / Geo<CIN>::chunks / 3;
-    return (dy == 0 && t == 0) || (dy == 2 && t == NT - 1);
-}
+// The K loop, rows innermost: for every (tap column dx, channel chunk) -- a "combo" -- the NT live halo rows 1 .. NT are read
+// ONCE each and a row's fragment meets the three kernel rows (output rows r - dy): 9 * TM MFMAs per pair of ds_read_b128, a
+// third of the LDS reads of a (tap, row) order (profiles/microbench/conv3_shapes.hip: R16 against C16; +2.1 .. 2.7 % on the whole
+// bench); the 3 * TM weight fragments of a combo's three kernel rows sit in registers, the next combo's arrive meanwhile.
+// Halo rows 0 and NT + 1 are the zero ring above / below the board (the kernel runs boards of exactly NT rows): never read,
+// their products never formed (2 of 45 (row, kernel row) pairs = 4.4 % of a layer's MFMAs; +2.3 %).
 template <int CIN, int TM, int NT, int J>
-__device__ __forceinline__ void slot(f32x4 (&acc)[TM][NT], f16x8 (&a)[kAD][TM][2], f16x8 (&b)[kLA + 1][2], lds_frag q, lds_frag qf,
-                                     __amdgpu_buffer_rsrc_t w_rsrc, int w_lane) {
+__device__ __forceinline__ void slot_r(f32x4 (&acc)[TM][NT], f16x8 (&a)[2][3][TM][2], f16x8 (&b)[kLA + 1][2], lds_frag q, lds_frag qf,
+                                       __amdgpu_buffer_rsrc_t w_rsrc, int w_lane) {
     using G = Geo<CIN>;
-    constexpr int PD = kLA + 1, s = J / NT, t = J % NT, J2 = J + kLA;
-    if constexpr (J2 < G::steps * NT && !dead_slot<CIN, NT>(J2 < G::steps * NT ? J2 : 0)) {
-        constexpr int s2 = J2 / NT, t2 = J2 % NT, tap = s2 / G::chunks, c = s2 % G::chunks;
-        constexpr int row = t2 + tap / 3, far = row >= 8;   // (qf = q + 8 halo rows: the immediate offset has 16 bits)
-        constexpr int off = ((row - 8 * far) * kRowW + tap % 3) * G::pos_bytes + c * 64;
+    constexpr int PD = kLA + 1, combos = 3 * G::chunks, cb = J / NT, r = J % NT + 1, J2 = J + kLA;   // r: halo row
+    if constexpr (J2 < combos * NT) {
+        constexpr int cb2 = J2 / NT, r2 = J2 % NT + 1, dx = cb2 / G::chunks, c = cb2 % G::chunks, far = r2 >= 8;
+        constexpr int off = ((r2 - 8 * far) * kRowW + dx) * G::pos_bytes + c * 64;
         static_assert(off % 16 == 0 && off + CIN * 2 < 65536, "ds_read_b128 immediate");
         b[J2 % PD][0] = (far ? qf : q)[off / 16];
         b[J2 % PD][1] = (far ? qf : q)[(off + CIN * 2) / 16];
     }
-    if constexpr (s + 1 < G::steps && t < TM) {
+    if constexpr (cb + 1 < combos && r - 1 < 3 * TM) {   // the next combo's weight fragments behind this combo's first rows
+        constexpr int dy = (r - 1) / TM, m = (r - 1) % TM, dx = (cb + 1) / G::chunks, c = (cb + 1) % G::chunks;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) a[(s + 1) % kAD][t][p] = sp::load_w(w_rsrc, w_lane, ((t * G::steps + s + 1) * 2 + p) * 1024);
+        for (int p = 0; p < 2; ++p)
+            a[(cb + 1) % 2][dy][m][p] = sp::load_w(w_rsrc, w_lane, ((m * G::steps + (dy * 3 + dx) * G::chunks + c) * 2 + p) * 1024);
     }
-    if constexpr (!dead_slot<CIN, NT>(J)) {
-        // a row's first live K-step: step 0, or the first step of kernel row 1 for board row 0
-        constexpr int first = t == 0 ? 3 * G::chunks : 0;
 #pragma unroll
-        for (int combo = 0; combo < 3; ++combo)
+    for (int combo = 0; combo < 3; ++combo)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int m = 0; m < TM; ++m) {
-                const int pa = combo == 2 ? 1 : 0, pb = combo == 1 ? 1 : 0;
-                if (s == first && combo == 0) {   // the first MFMA of a tile starts from the constant 0
-                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s % kAD][m][pa], b[J % PD][pb], zero, 0, 0, 0);
-                } else {
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s % kAD][m][pa], b[J % PD][pb], acc[m][t], 0, 0, 0);
+                const int t = r - dy, pa = combo == 2 ? 1 : 0, pb = combo == 1 ? 1 : 0;   // halo row r = board row r - 1 = tap row dy of output row r - dy
+                if (t >= 0 && t < NT) {
+                    // a row's first product: combo 0 of (cb = 0, dy = 0) at halo row t -- board row 0 would meet dy = 0 at halo
+                    // row 0 (the zero ring, never read): its first is dy = 1 at halo row 1
+                    if (cb == 0 && combo == 0 && (dy == 0 || (t == 0 && dy == 1))) {
+                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cb % 2][dy][m][pa], b[J % PD][pb], zero, 0, 0, 0);
+                    } else {
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cb % 2][dy][m][pa], b[J % PD][pb], acc[m][t], 0, 0, 0);
+                    }
                 }
             }
-    }
     __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int CIN, int TM, int NT, int... Js>
-__device__ __forceinline__ void slots(std::integer_sequence<int, Js...>, f32x4 (&acc)[TM][NT], f16x8 (&a)[kAD][TM][2],
-                                      f16x8 (&b)[kLA + 1][2], lds_frag q, lds_frag qf, __amdgpu_buffer_rsrc_t w_rsrc, int w_lane) {
-    (slot<CIN, TM, NT, Js>(acc, a, b, q, qf, w_rsrc, w_lane), ...);
+__device__ __forceinline__ void slots_r(std::integer_sequence<int, Js...>, f32x4 (&acc)[TM][NT], f16x8 (&a)[2][3][TM][2],
+                                        f16x8 (&b)[kLA + 1][2], lds_frag q, lds_frag qf, __amdgpu_buffer_rsrc_t w_rsrc, int w_lane) {
+    (slot_r<CIN, TM, NT, Js>(acc, a, b, q, qf, w_rsrc, w_lane), ...);
 }
 
-// the weight fragments of K-step 0 (no dependence on LDS: requested while the previous layer is being reduced)
+// the weight fragments of combo 0 (tap column 0, chunk 0; kernel rows 0 .. 2): requested while the previous layer is reduced
 template <int CIN, int TM>
-__device__ __forceinline__ void preload_w(f16x8 (&a)[kAD][TM][2], const void *wts, int lane) {
+__device__ __forceinline__ void preload_w_r(f16x8 (&a)[2][3][TM][2], const void *wts, int lane) {
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(wts), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-    for (int m = 0; m < TM; ++m)
+    for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-        for (int p = 0; p < 2; ++p) a[0][m][p] = sp::load_w(w_rsrc, lane * 16, (m * Geo<CIN>::steps * 2 + p) * 1024);
+        for (int m = 0; m < TM; ++m)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                a[0][dy][m][p] = sp::load_w(w_rsrc, lane * 16, ((m * Geo<CIN>::steps + dy * 3 * Geo<CIN>::chunks) * 2 + p) * 1024);
 }
 
-// acc[m][t] = sum over taps and input channels for the wave's TM M-tiles (`wts` = their fragments) and board rows 0 .. NT - 1;
-// lane = 16 g + n: MFMA column n = board column, k block g = input channels 8 g .. 8 g + 7 of a chunk of 32
 template <int CIN, int TM, int NT>
-__device__ __forceinline__ void conv(const char *in, const void *wts, int lane, f16x8 (&a)[kAD][TM][2], f32x4 (&acc)[TM][NT]) {
+__device__ __forceinline__ void conv_r(const char *in, const void *wts, int lane, f16x8 (&a)[2][3][TM][2], f32x4 (&acc)[TM][NT]) {
     using G = Geo<CIN>;
-    static_assert(TM <= NT && kLA <= NT, "loads are spread over a step's first rows");
+    static_assert(3 * TM <= NT && kLA <= NT, "loads are spread over a combo's first rows");
     const int n = lane & 15, g = lane >> 4;
-    // halo position (t, n) = the top-left tap of output (t, n)
     const lds_frag q = (lds_frag)(in + n * G::pos_bytes + g * 16), qf = q + 8 * kRowW * G::pos_bytes / 16;
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(wts), 0, 0x7fffffff, 0x00020000);
     f16x8 b[kLA + 1][2];
 #pragma unroll
-    for (int j = 1; j < kLA; ++j) {   // slots 1 .. kLA - 1: K-step 0 (tap 0, chunk 0), rows 1 .. (slot 0 is a dead one)
-        b[j][0] = q[(j * kRowW * G::pos_bytes) / 16];
-        b[j][1] = q[(j * kRowW * G::pos_bytes + CIN * 2) / 16];
+    for (int j = 0; j < kLA; ++j) {   // slots 0 .. kLA - 1: combo 0 (dx = 0, chunk 0), halo rows 1 ..
+        b[j][0] = q[((j + 1) * kRowW * G::pos_bytes) / 16];
+        b[j][1] = q[((j + 1) * kRowW * G::pos_bytes + CIN * 2) / 16];
     }
     __builtin_amdgcn_sched_barrier(0);
-    slots<CIN, TM, NT>(std::make_integer_sequence<int, G::steps * NT>{}, acc, a, b, q, qf, w_rsrc, lane * 16);
+    slots_r<CIN, TM, NT>(std::make_integer_sequence<int, 3 * G::chunks * NT>{}, acc, a, b, q, qf, w_rsrc, lane * 16);
 }
 
 }  // namespace rt
@@ -1614,8 +1612,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_t
     const int n = lane & 15, g = lane >> 4;
     const char *t2p = reinterpret_cast<const char *>(nd.t2) + (size_t)wave * rt::Geo<32>::steps * 2 * 1024;
     const char *t3p = reinterpret_cast<const char *>(nd.t3) + (size_t)(2 * wave) * rt::Geo<64>::steps * 2 * 1024;
-    sp::f16x8 a2[rt::kAD][1][2];
-    rt::preload_w<32, 1>(a2, t2p, lane);
+    sp::f16x8 a2[2][3][1][2];
+    rt::preload_w_r<32, 1>(a2, t2p, lane);
     {   // conv1: 4 -> 32 on 32 x 32 x 16 tiles of 2 rows x 16 columns, wave w = rows 4 w .. 4 w + 3; K-step = kernel row
         const int n32 = lane & 31, h = lane >> 5, ry = n32 >> 4, x = n32 & 15, row0 = 4 * wave;
         if (row0 < BH) {
@@ -1670,12 +1668,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_t
     __syncthreads();
     NET_TICK(1);
     if (next_board < n_boards) load_board(next_board, tid);
-    sp::f16x8 a3[rt::kAD][2][2];
+    sp::f16x8 a3[2][3][2][2];
     {   // conv2: 32 -> 64, wave w = output channels 16 w .. 16 w + 15
         f32x4 acc[1][NT];
-        rt::conv<32, 1, NT>(c1, t2p, lane, a2, acc);
+        rt::conv_r<32, 1, NT>(c1, t2p, lane, a2, acc);
         NET_TICK(2);
-        rt::preload_w<64, 2>(a3, t3p, lane);
+        rt::preload_w_r<64, 2>(a3, t3p, lane);
         if (n < BW) {
             char *pos = c2 + (kRowW + n + 1) * P2 + (16 * wave + 4 * g) * 2;
 #pragma unroll
@@ -1701,7 +1699,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_t
         float vals[96];   // [row t][output o]: the lane's 8 channels of position (t, n)
         {
             f32x4 acc[2][NT];
-            rt::conv<64, 2, NT>(c2, t3p, lane, a3, acc);
+            rt::conv_r<64, 2, NT>(c2, t3p, lane, a3, acc);
             NET_TICK(5);
 #pragma unroll
             for (int t = 0; t < 16; ++t) {

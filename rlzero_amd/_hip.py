@@ -18,7 +18,7 @@ SCORE_UCT_REF, SCORE_PUCT = 0, 1
 GAME_GOMOKU, GAME_CONNECT4 = 0, 1
 NET_DIRECT, NET_WINOGRAD_F4, NET_SPLIT_F16, NET_SPLIT_F16_TILES = 0, 1, 2, 3
 NET_FLAG_F16_RANGE = 1
-NET_HEADS_AUTO, NET_HEADS_F32, NET_HEADS_SPLIT_32, NET_HEADS_SPLIT_64, NET_HEADS_SPLIT_PARTS = 0, 1, 2, 3, 4
+NET_HEADS_AUTO, NET_HEADS_F32, NET_HEADS_SPLIT_32, NET_HEADS_SPLIT_64, NET_HEADS_SPLIT_PARTS, NET_HEADS_IN_TRUNK = 0, 1, 2, 3, 4, 5
 EVAL_V0, EVAL_VLIN = 0, 1
 FLAG_NAMES = {1: 'arena full', 2: 'block queue full', 4: 'illegal move', 8: 'ln table too short',
               16: 'internal'}

@@ -875,10 +875,16 @@ __device__ __forceinline__ float other_half(float x, int h) {
     return __uint_as_float(h ? r[0] : r[1]);
 }
 
+// FC_HERE (small boards, TN = 1; `raw` / `hid` given): the workgroup also runs the first FC layers of both heads on ITS OWN
+// board, behind the feature stage -- the arithmetic of k_heads_split (the same MFMA on the same K quarters, one per wave, the
+// quarters summed in wave order, fmaf(sum, scale, bias)): the same bits, one launch and one kernel boundary less in the chain
+// trunk -> FC -> tree step of a small batch.  A board is row 0 of the MFMA's 32 (the other rows are zero: rows do not mix), its
+// features never leave the CU (f16 pieces in LDS), the weights stream from L2.
 template <int TN, int MS = 1>
 __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__restrict__ obs, LeafBits leaves,
                                                      float *__restrict__ feat, _Float16 *__restrict__ feat16,
-                                                     int n_boards, unsigned *__restrict__ flags) {
+                                                     int n_boards, unsigned *__restrict__ flags,
+                                                     float *__restrict__ raw = nullptr, float *__restrict__ hid = nullptr) {
 #ifdef RZ_NET_PROFILE
     const long long prof_k0 = __builtin_readcyclecounter();
     long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = prof_k0;
@@ -1304,13 +1310,30 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         float hb[6];
 #pragma unroll
         for (int o = 0; o < 6; ++o) hb[o] = hw[128 * 7 + o];
+        // FC_HERE: the board's f16 feature pieces [K-step][hi | lo][16] in LDS, inside halo rows 12 .. of conv2's region (a
+        // board of up to 10 rows never reads them); zeroed K tail
+        const bool fc_here = TN == 1 && raw != nullptr;
+        _Float16 *fa_lds = reinterpret_cast<_Float16 *>(c2 + 12 * kRowW * sp::Geo<64>::pos_bytes);
+        const int fc_steps = nd.groups_act + nd.groups_val;
+        if (fc_here) {
+            for (int i = tid; i < fc_steps * 8; i += kThreads) reinterpret_cast<f32x2 *>(fa_lds)[i] = f32x2{0.0f, 0.0f};
+            __syncthreads();
+        }
         if (mine && y < BH && x < BW) {
             const int cell = y * BW + x;
 #pragma unroll
             for (int o = 0; o < 6; ++o) {
                 const float v = fmaxf(vsum[o] + hb[o], 0.0f);
                 if (dst) dst[(o < 4 ? o * S : nd.feat_val_off + (o - 4) * S) + cell] = v;
-                if (dst16) {
+                if (fc_here) {
+                    const int k = (o < 4 ? o : o - 4) * S + cell;
+                    const int step = (o < 4 ? 0 : nd.groups_act) + (k >> 4);
+                    const float z = v * act3;
+                    const _Float16 zh = (_Float16)z;
+                    zmax = fmaxf(zmax, z);
+                    fa_lds[step * 32 + (k & 15)] = zh;
+                    fa_lds[step * 32 + 16 + (k & 15)] = (_Float16)(z - (float)zh);
+                } else if (dst16) {
                     const int k = (o < 4 ? o : o - 4) * S + cell;
                     const int step = (o < 4 ? 0 : nd.groups_act) + (k >> 4);
                     const float z = v * act3;
@@ -1324,6 +1347,71 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         }
     }
     NET_TICK(7);
+    if constexpr (TN == 1) {
+        if (raw != nullptr) {
+            // ---- the first FC layers of both heads on this board (k_heads_split's arithmetic: see the kernel's header)
+            __syncthreads();   // the feature pieces are in LDS
+            const _Float16 *fa_lds = reinterpret_cast<const _Float16 *>(c2 + 12 * kRowW * sp::Geo<64>::pos_bytes);
+            float *ps = reinterpret_cast<float *>(c2 + 15 * kRowW * sp::Geo<64>::pos_bytes);   // [K quarter][tile][32 outputs]
+            const int n_act_tiles = nd.Npad / 32, n_tiles = n_act_tiles + 2;
+            const f32x4 *zero_frag = nd.fs_act + (size_t)n_act_tiles * nd.groups_act * 128;
+            const int half = lane >> 5;
+            const bool row0 = (lane & 31) == 0;   // the lanes that hold MFMA row 0 of the A operand
+            for (int tile = 0; tile < n_tiles; ++tile) {
+                const bool is_act = tile < n_act_tiles;
+                const f32x4 *fb = is_act ? nd.fs_act + (size_t)tile * nd.groups_act * 128
+                                         : nd.fs_val + (size_t)(tile - n_act_tiles) * nd.groups_val * 128;
+                const int K = is_act ? nd.groups_act : nd.groups_val, a0 = is_act ? 0 : nd.groups_act;
+                const int k0 = wave * K / 4, k1 = (wave + 1) * K / 4;
+                sp::f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+                constexpr int D = 4;   // weight fragments in flight (every load unconditional: see fs_load)
+                sp::f16x8 bw[D][2];
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const f32x4 *src = k0 + d < k1 ? fb + (size_t)(k0 + d) * 128 : zero_frag;
+#pragma unroll
+                    for (int p_ = 0; p_ < 2; ++p_) bw[d][p_] = __builtin_bit_cast(sp::f16x8, src[p_ * 64 + lane]);
+                }
+                for (int k = k0; k < k1; k += D) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        if (k + d < k1) {   // (wave-uniform)
+                            const sp::f16x8 zero8 = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f,
+                                                     (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
+                            const _Float16 *src = fa_lds + (a0 + k + d) * 32 + 8 * half;
+                            const sp::f16x8 ah = row0 ? *reinterpret_cast<const sp::f16x8 *>(src) : zero8;
+                            const sp::f16x8 al = row0 ? *reinterpret_cast<const sp::f16x8 *>(src + 16) : zero8;
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bw[d][0], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bw[d][1], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bw[d][0], acc, 0, 0, 0);
+                        }
+                        const f32x4 *src2 = k + d + D < k1 ? fb + (size_t)(k + d + D) * 128 : zero_frag;
+#pragma unroll
+                        for (int p_ = 0; p_ < 2; ++p_) bw[d][p_] = __builtin_bit_cast(sp::f16x8, src2[p_ * 64 + lane]);
+                    }
+                }
+                if (half == 0) ps[(wave * n_tiles + tile) * 32 + (lane & 31)] = acc[0];   // D row 0 = this board, column = output
+            }
+            __syncthreads();
+            const float sc_act = nd.s_inv[3], sc_val = nd.s_inv[4];
+            for (int i = tid; i < n_tiles * 32; i += kThreads) {
+                const int tile = i >> 5, col = i & 31;
+                float v = ps[(0 * n_tiles + tile) * 32 + col];
+#pragma unroll
+                for (int q = 1; q < 4; ++q) v += ps[(q * n_tiles + tile) * 32 + col];
+                if (tile < n_act_tiles) {
+                    const int c = 32 * tile + col;
+                    raw[(size_t)board * nd.Npad + c] = fmaf(v, sc_act, nd.fc_act_b[c]);
+                } else {
+                    const int c = 32 * (tile - n_act_tiles) + col;
+                    hid[(size_t)board * 64 + c] = fmaxf(fmaf(v, sc_val, nd.fc_val1_b[c]), 0.0f);
+                }
+            }
+            __syncthreads();   // (a further board of this workgroup reuses the pieces and the partial sums)
+        }
+    }
     }  // boards
 #ifdef RZ_NET_PROFILE
     if (blockIdx.x == 0 && tid0 == 0) {
@@ -2240,6 +2328,7 @@ struct rz_net {
     bool feat32_valid = false;     // ... wrote d_feat (the split-f16 trunk skips it when the GEMM reads the f16 pieces)
     int heads_algo = RZ_NET_HEADS_AUTO;
     int raw_parts = 1;           // what the last launch_heads_gemm left in d_raw / d_hid: 1 = final, 4 = K-quarter sums
+    bool raw_from_trunk = false; // the last trunk launch ran the FC layers itself (k_trunk_split, FC_HERE): d_raw / d_hid are final
     size_t raw_part_floats = 0, hid_part_floats = 0;  // stride between the parts
     unsigned *d_flags = nullptr;
     long long feat_boards = 0;
@@ -2706,6 +2795,7 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
     // Winograd kernels are persistent: one workgroup per CU (LDS bound) loops over its boards
     const int wg_cap = net->max_wgs > 0 ? net->max_wgs : net->n_cus;
     const dim3 pgrid((unsigned)(n_boards < wg_cap ? n_boards : wg_cap));
+    net->raw_from_trunk = false;
     if (algo == RZ_NET_WINOGRAD_F4)
         k_trunk_wino_f4<4><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
     else if (algo == RZ_NET_SPLIT_F16)
@@ -2714,17 +2804,28 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
         float *f32 = want_f32 ? d_feat : nullptr;
         const int tiles = (net->dev.BH + net->dev.tile_rows - 1) / net->dev.tile_rows;
         const bool bits = leaves.stones != nullptr;
+        // Small batches of small boards (every board has a workgroup of its own, nothing of another lane to overlap with): the
+        // trunk's workgroups run the FC layers on their boards themselves -- no FC launch, no kernel boundary (same bits).
+        // Every workgroup then streams ALL FC weights from L2 for its one board (the GEMM launch reads them once per 32
+        // boards): AUTO takes this route up to 6 x 6 (38 KB: TicTacToe one game +6 %, 16 games +3 %); at 9 x 9 (146 KB) the
+        // launch it saves is cheaper than the stream it costs (64 games -5 %, profiles/r03/in_trunk_fc.txt)
+        const bool fc_here = internal && tiles <= 4 && net->dev.BH <= 10 && !rows_kernel_covers(net->dev.BH, net->dev.BW) &&
+                             (net->heads_algo == RZ_NET_HEADS_IN_TRUNK ||
+                              (net->heads_algo == RZ_NET_HEADS_AUTO && net->max_wgs == 0 && n_boards <= wg_cap && net->dev.S <= 36));
+        float *raw = fc_here ? net->d_raw : nullptr, *hid = fc_here ? net->d_hid : nullptr;
+        net->raw_from_trunk = fc_here;
+        if (fc_here) net->feat16_valid = false;   // (the pieces stayed in LDS)
         if (net->algo == RZ_NET_SPLIT_F16 && rows_kernel_covers(net->dev.BH, net->dev.BW)) {   // wide boards: one N-tile per row
             if (bits) k_trunk_rows<15, true><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
             else k_trunk_rows<15, false><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
         } else if (tiles <= 1)        // one tile: the four waves share the output channels
-            k_trunk_split<1, 4><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
+            k_trunk_split<1, 4><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, raw, hid);
         else if (tiles <= 2)   // two tiles x two channel halves
-            k_trunk_split<1, 2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
+            k_trunk_split<1, 2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, raw, hid);
         else if (tiles == 3 && net->dev.tile_rows == 3)   // 9x9: three tiles + the fourth wave on a quarter of conv3's channels
-            k_trunk_split<1, 3><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
+            k_trunk_split<1, 3><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, raw, hid);
         else if (tiles <= 4)   // four tiles cover the board: one per wave
-            k_trunk_split<1><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
+            k_trunk_split<1><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, raw, hid);
         else
             k_trunk_split<2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
     }
@@ -2736,12 +2837,16 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
 static void launch_heads_gemm(rz_net *net, const float *d_feat, int32_t n_boards, void *stream) {
     net->dev.feat_ld = 16 * (net->dev.groups_act + net->dev.groups_val);
     net->dev.feat_val_off = 16 * net->dev.groups_act;
+    if (net->raw_from_trunk && d_feat == net->d_feat) {   // the trunk's workgroups ran these layers on their boards
+        net->raw_parts = 1;
+        return;
+    }
     int algo = net->heads_algo;
     // after the split-f16 trunk: the f16 pipe.  Beside a capped trunk the GEMM has 32 CUs (64-board workgroups keep
     // the loads of a CU below its vector memory rate), alone it has the chip (many small workgroups hide the load
     // latency); up to 256 boards the single-wave K-quarter workgroups are the shortest launch (+4 % whole-step at 64 and
     // 256 boards, level above that); every shape gives the same bits (profiles/r01/sweep_heads.txt, r02/heads_small.txt)
-    if (algo == RZ_NET_HEADS_AUTO)
+    if (algo == RZ_NET_HEADS_AUTO || algo == RZ_NET_HEADS_IN_TRUNK)   // (IN_TRUNK on a board size the trunk does not do it for)
         algo = net->max_wgs > 0 ? RZ_NET_HEADS_SPLIT_64 : n_boards <= 256 ? RZ_NET_HEADS_SPLIT_PARTS : RZ_NET_HEADS_SPLIT_32;
     if (d_feat != net->d_feat || !net->feat16_valid) algo = RZ_NET_HEADS_F32;
     else if (algo == RZ_NET_HEADS_F32 && !net->feat32_valid)  // F32 chosen after a trunk that wrote only the f16 pieces
@@ -2828,7 +2933,7 @@ int rz_net_debug_profile(long long *h_out16) {
 
 int rz_net_set_heads_algo(rz_net *net, int32_t heads_algo) {
     if (!net) return net_fail(RZ_ERR_ARG, "net handle is NULL");
-    if (heads_algo < RZ_NET_HEADS_AUTO || heads_algo > RZ_NET_HEADS_SPLIT_PARTS) return net_fail(RZ_ERR_ARG, "unknown heads algorithm");
+    if (heads_algo < RZ_NET_HEADS_AUTO || heads_algo > RZ_NET_HEADS_IN_TRUNK) return net_fail(RZ_ERR_ARG, "unknown heads algorithm");
     net->heads_algo = heads_algo;
     return RZ_OK;
 }

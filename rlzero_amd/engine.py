@@ -149,9 +149,11 @@ class HipNet(object):
         operand pairs after the 'split_f16' trunk, 32 / 64 boards per workgroup), 'parts' (the same arithmetic as
         single-wave workgroups per K quarter, no LDS: fits beside a resident trunk workgroup of another lane; the consumer
         adds the four partial sums), 'auto' (default after the 'split_f16' trunk: 'split64' beside a capped trunk,
-        otherwise 'parts' up to 256 boards and 'split32' above; 'f32' after the f32 trunks).  All give the same bits."""
+        otherwise 'parts' up to 256 boards and 'split32' above; 'f32' after the f32 trunks; on boards of up to 36 cells an
+        un-capped batch of at most one board per CU runs 'in_trunk': every trunk workgroup does these layers on its own board,
+        no GEMM launch -- selectable up to 10 rows).  All give the same bits."""
         code = {'auto': _hip.NET_HEADS_AUTO, 'f32': _hip.NET_HEADS_F32, 'split32': _hip.NET_HEADS_SPLIT_32,
-                'split64': _hip.NET_HEADS_SPLIT_64, 'parts': _hip.NET_HEADS_SPLIT_PARTS}[algo]
+                'split64': _hip.NET_HEADS_SPLIT_64, 'parts': _hip.NET_HEADS_SPLIT_PARTS, 'in_trunk': _hip.NET_HEADS_IN_TRUNK}[algo]
         check(self.lib.rz_net_set_heads_algo(self.handle, code), 'rz_net_set_heads_algo')
         self.heads_algo = algo
         return self

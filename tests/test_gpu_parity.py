@@ -983,7 +983,7 @@ def test_split_f16_heads_gemm_equals_the_f32_gemm():
         for n in batches:
             x = (torch.rand((n, 4, rows, cols), device='cuda:0') < 0.4).float()
             out = {}
-            for algo in ('f32', 'split32', 'split64', 'parts', 'auto'):
+            for algo in ('f32', 'split32', 'split64', 'parts', 'auto', 'in_trunk'):
                 lp, v = hip.set_heads_algo(algo).forward(x)
                 out[algo] = (lp.clone(), v.clone())
             lp, v = hip.set_max_workgroups(8).forward(x)  # 'auto' beside a capped trunk: 64-board workgroups
@@ -997,7 +997,9 @@ def test_split_f16_heads_gemm_equals_the_f32_gemm():
                 assert float((out[algo][1].cpu().double() - v64[:, 0]).abs().max()) <= 2e-6, (shape, n, algo)
             assert float((out['f32'][0] - out['split32'][0]).abs().max()) <= 1e-5
             assert float((out['f32'][1] - out['split32'][1]).abs().max()) <= 2e-6
-            for algo in ('split64', 'parts', 'auto', 'auto_capped'):  # the workgroup shape / who adds the K quarters is scheduling only: same bits
+            # the workgroup shape / who adds the K quarters / the trunk's workgroups doing the layers on their own boards (boards of
+            # up to 10 rows, 'in_trunk' and 'auto' up to one board per CU) is scheduling only: same bits
+            for algo in ('split64', 'parts', 'auto', 'in_trunk', 'auto_capped'):
                 assert torch.equal(out[algo][0], out['split32'][0]) and torch.equal(out[algo][1], out['split32'][1])
         # the split trunk wrote only the f16 pieces (GEMM 'auto'): a GEMM forced to f32 afterwards runs on them
         hip.set_heads_algo('auto').trunk_internal(x)

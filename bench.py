@@ -601,7 +601,7 @@ def main():
             hip_ev.hip.set_max_workgroups(trunk_wgs)
             ev = TimedEvaluator(hip_ev, torch,
                                 {'winograd_f4': 'k_trunk_wino_f4<4>',
-                                 'split_f16': 'k_trunk_rows' if (args.game == 'gomoku' and board == 15) else 'k_trunk_split',
+                                 'split_f16': 'k_trunk_rows' if (args.game == 'gomoku' and 11 <= board <= 16) else 'k_trunk_split',
                                  'split_f16_tiles': 'k_trunk_split',
                                  'direct': 'k_trunk'}[args.net_algo])
         elif args.evaluator == 'torchnet':

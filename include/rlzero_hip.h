@@ -310,7 +310,7 @@ enum {
                                DIRECT (1e-7 relative against fp64).  The f16 pieces of a layer's activations are stored times a
                                power of two that rz_net_load derives from bounds on the activations (observation planes in
                                [0, 1]), so weights of any scale stay in range on MCTS leaves; only inputs beyond [0, 1]
-                               can overflow, which sets RZ_NET_FLAG_F16_RANGE.  Boards of 15 rows and 11 .. 16 columns run
+                               can overflow, which sets RZ_NET_FLAG_F16_RANGE.  Boards of 11 .. 16 rows and columns run
                                k_trunk_rows (v_mfma_f32_16x16x32_f16, one N-tile per board row, waves split the output
                                channels), all others k_trunk_split (32 x 32 x 16 tiles of whole rows, waves split the rows) */
     ,

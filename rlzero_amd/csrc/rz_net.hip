@@ -2533,6 +2533,13 @@ std::vector<f32x4> pack_split_fc(const float *w, int n_out, int k_in, int tiles,
 
 }  // namespace
 
+template <int NT>
+static void launch_trunk_rows(bool bits, dim3 grid, hipStream_t stream, const NetDev &nd, const float *d_obs, LeafBits leaves, float *f32,
+                              _Float16 *f16, int n_boards, unsigned *flags) {
+    if (bits) k_trunk_rows<NT, true><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags);
+    else k_trunk_rows<NT, false><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags);
+}
+
 extern "C" {
 
 int rz_net_create(int32_t height, int32_t width, int32_t n_actions, int32_t device, rz_net **out) {
@@ -2771,8 +2778,10 @@ int rz_net_reserve(rz_net *net, int32_t max_boards) {
     return RZ_OK;
 }
 
-// k_trunk_rows is instantiated for 15 rows (the 15 x 15 Gomoku board of the BASELINE configuration and its 11 .. 16 column kin)
-static bool rows_kernel_covers(int bh, int bw) { return bh == 15 && bw >= 11 && bw <= 16; }
+// k_trunk_rows is instantiated for boards of 11 .. 16 rows (the 15 x 15 Gomoku board of the BASELINE configuration and its kin:
+// the boards k_trunk_split needs more than four tiles for), 11 .. 16 columns wide (narrower ones leave too many of a row tile's
+// 16 MFMA columns empty)
+static bool rows_kernel_covers(int bh, int bw) { return bh >= 11 && bh <= 16 && bw >= 11 && bw <= 16; }
 
 static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t n_boards, void *stream,
                          LeafBits leaves = LeafBits{nullptr, nullptr, nullptr}) {
@@ -2816,8 +2825,15 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
         net->raw_from_trunk = fc_here;
         if (fc_here) net->feat16_valid = false;   // (the pieces stayed in LDS)
         if (net->algo == RZ_NET_SPLIT_F16 && rows_kernel_covers(net->dev.BH, net->dev.BW)) {   // wide boards: one N-tile per row
-            if (bits) k_trunk_rows<15, true><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
-            else k_trunk_rows<15, false><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
+            const hipStream_t st = (hipStream_t)stream;
+            switch (net->dev.BH) {
+                case 11: launch_trunk_rows<11>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags); break;
+                case 12: launch_trunk_rows<12>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags); break;
+                case 13: launch_trunk_rows<13>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags); break;
+                case 14: launch_trunk_rows<14>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags); break;
+                case 15: launch_trunk_rows<15>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags); break;
+                default: launch_trunk_rows<16>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags); break;
+            }
         } else if (tiles <= 1)        // one tile: the four waves share the output channels
             k_trunk_split<1, 4><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, raw, hid);
         else if (tiles <= 2)   // two tiles x two channel halves

@@ -105,7 +105,7 @@ class HipNet(object):
         """conv2 / conv3 algorithm: 'split_f16' (default: direct convolution on the f16 matrix pipe, every f32
         operand carried as a hi + lo pair of f16 values, f32 accumulation -- as accurate as 'direct'), or on the
         f32-input MFMA: 'winograd_f4' (F(4x4,3x3)) or 'direct' (bit-for-bit a k-ordered fmaf chain).  'split_f16_tiles'
-        is 'split_f16' with the 32 x 32 x 16 tile kernel on every board size (15-row boards otherwise run the row-tile kernel)."""
+        is 'split_f16' with the 32 x 32 x 16 tile kernel on every board size (boards of 11 .. 16 rows and columns otherwise run the row-tile kernel)."""
         code = {'direct': _hip.NET_DIRECT, 'winograd_f4': _hip.NET_WINOGRAD_F4, 'split_f16': _hip.NET_SPLIT_F16,
                 'split_f16_tiles': _hip.NET_SPLIT_F16_TILES}[algo]
         check(self.lib.rz_net_set_algo(self.handle, code), 'rz_net_set_algo')

@@ -781,16 +781,17 @@ def test_split_trunk_rectangular_boards():
         hip.close()
 
 
-def test_row_tile_trunk_on_15_row_boards():
-    """k_trunk_rows (boards of 15 rows, 11 .. 16 columns: v_mfma_f32_16x16x32_f16, one N-tile per board row, the waves
+def test_row_tile_trunk_on_its_board_shapes():
+    """k_trunk_rows (boards of 11 .. 16 rows and columns: v_mfma_f32_16x16x32_f16, one N-tile per board row, the waves
     split the output channels) against the torch module in fp64 (1e-4 on log-probabilities and values, random non-0/1
     inputs) and against k_trunk_split on the same boards ('split_f16_tiles': the same hi + lo arithmetic in another
-    summation order -- f32 accumulation rounding apart); ragged batches on capped workgroups give the same bits."""
+    summation order -- f32 accumulation rounding apart); ragged batches on capped workgroups give the same bits.  Every
+    width at 15 rows, every row count at some width."""
     import torch
     from rlzero_amd.engine import HipNet
     from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
-    for i, cols in enumerate(range(11, 17)):
-        rows = 15
+    shapes = [(15, cols) for cols in range(11, 17)] + [(11, 11), (12, 16), (13, 13), (14, 12), (16, 11), (16, 16)]
+    for i, (rows, cols) in enumerate(shapes):
         torch.manual_seed(300 + i)
         n_actions = rows * cols
         net = PolicyValueNet(rows, cols, n_actions)
@@ -800,18 +801,18 @@ def test_row_tile_trunk_on_15_row_boards():
             lp64, v64 = net.double()(x.double())
         xd = x.to('cuda:0')
         lp, v = hip.forward(xd)
-        assert np.max(np.abs(lp.cpu().numpy() - lp64.numpy())) <= 1e-4, cols
-        assert np.max(np.abs(v.cpu().numpy() - v64.numpy()[:, 0])) <= 1e-4, cols
+        assert np.max(np.abs(lp.cpu().numpy() - lp64.numpy())) <= 1e-4, (rows, cols)
+        assert np.max(np.abs(v.cpu().numpy() - v64.numpy()[:, 0])) <= 1e-4, (rows, cols)
         lp3, v3 = hip.set_max_workgroups(3).forward(xd)
-        assert torch.equal(lp3, lp) and torch.equal(v3, v), cols
+        assert torch.equal(lp3, lp) and torch.equal(v3, v), (rows, cols)
         hip.set_max_workgroups(0)
         planes = (torch.rand((9, 4, rows, cols), device='cuda:0') < 0.4).float()   # 0 / 1 planes like the tree's leaves
         feat = hip.trunk(planes).cpu().numpy()
         feat_tiles = hip.set_algo('split_f16_tiles').trunk(planes).cpu().numpy()
         feat_direct = hip.set_algo('direct').trunk(planes).cpu().numpy()
         scale = max(1.0, float(np.abs(feat_direct).max()))
-        assert np.abs(feat).max() > 0.05 and np.max(np.abs(feat - feat_tiles)) <= 2e-6 * scale, cols
-        assert np.max(np.abs(feat - feat_direct)) <= 2e-5 * scale, cols
+        assert np.abs(feat).max() > 0.02 and np.max(np.abs(feat - feat_tiles)) <= 2e-6 * scale, (rows, cols)
+        assert np.max(np.abs(feat - feat_direct)) <= 2e-5 * scale, (rows, cols)
         hip.check_flags()
         hip.close()
 

@@ -417,10 +417,11 @@ __device__ __forceinline__ void mz_touch_done(float &sink) {
 // four lanes step down together.  Up to 2 actions lanes 2, 3 mirror lanes 0, 1 (one exchange); 3 or 4 actions take a
 // second exchange; more fall back to every lane scanning the children ca, ca + 4, ...
 // Every lane returns the same (depth, parent, action, leaf).
-template <typename HotP, typename PathP, typename TabP>
+// AFIX > 0: the action count is a compile-time constant (2 for CartPole's whole MOVES: the per-level code loses its runtime tests)
+template <int AFIX = 0, typename HotP, typename PathP, typename TabP>
 __device__ __forceinline__ int mz_descend_hot(const MzDev &E, HotP hot, PathP path, TabP pb_log, TabP sq_tab, double lo, double hi,
                                               int ca, const float *hidden_g, float &sink, int &par_out, int &act_out, int &leaf_out) {
-    const int A = E.n_actions;
+    const int A = AFIX > 0 ? AFIX : E.n_actions;
     int node = 0, depth = 0, last_action = 0, par = 0;
     path[0] = 0;
     int fc = hot[0].first_child, pn = hot[0].N;
@@ -524,23 +525,24 @@ __device__ __forceinline__ int mz_descend_hot(const MzDev &E, HotP hot, PathP pa
 // v = reward + discount * v chains through the levels, so every lane runs that short chain on the quad's four rewards.
 // A level above the root is played on the spare record `spare` (slot index relative to `hot` / `rew`; never read for a
 // result).  MinMaxStats takes the quad's extremes (max / min do not depend on the order of the updates).
-template <int MAXA, typename HotP, typename RewP, typename PathP>
+template <int MAXA, int AFIX = 0, typename HotP, typename RewP, typename PathP>
 __device__ __forceinline__ void mz_grow_backup_hot(const MzDev &E, HotP hot, RewP rew, PathP path, int spare, int ca, int depth, int &top,
                                                    double &lo, double &hi, float reward_g, const float *probs, float value_g) {
     const int leaf = path[depth];
-    if (top + E.n_actions > E.cap) {
+    const int A = AFIX > 0 ? AFIX : E.n_actions;
+    if (top + A > E.cap) {
         atomicOr(E.err, RZ_FLAG_ARENA_FULL);
     } else {
         rew[leaf] = reward_g;
         hot[leaf].first_child = top;
 #pragma unroll
         for (int a = 0; a < MAXA; ++a) {
-            if (a < E.n_actions) {
+            if (a < A) {
                 hot[top + a] = MzHot{0, -1, 0.0, (double)probs[a], 0.0};
                 rew[top + a] = 0.0f;
             }
         }
-        top += E.n_actions;
+        top += A;
     }
     double v = (double)value_g;
     for (int d = depth; d >= 0; d -= 4) {
@@ -612,7 +614,8 @@ struct MzPlay {         // rz_mz_play_cartpole
 
 // LDS of k_mz_search in bytes: activations, reductions, head weights, per-game scalars, paths, log table (+ the trees)
 __host__ __device__ inline int mz_search_fixed_floats() {
-    return kMzKX * kMzTile + kMzH * kMzTile + kMzRedRows * kMzWaves * kMzTile + 16 + kMzHeadRows * kMzH + kMzObs * kMzTile + 16;
+    return kMzKX * kMzTile + kMzH * kMzTile + kMzRedRows * kMzWaves * kMzTile + 16 + kMzHeadRows * kMzH + kMzObs * kMzTile + 16 +
+           kMzTile * 16;   // (+ the environments of whole MOVES: 7 doubles per game, 8 reserved)
 }
 __host__ __device__ inline int mz_search_lds_bytes(int gpw, int cap, int path_stride, int n_sims_cfg, bool tree_lds) {
     int bytes = mz_search_fixed_floats() * 4 + gpw * path_stride * 4;
@@ -666,10 +669,14 @@ __device__ __forceinline__ float mz_head_partial(const mz_f32x4 &p, const float 
     return mz_rowsum(s, l);
 }
 
-template <bool TREE_LDS, bool MOVES>
+// MAXA: the action count the per-action loops are unrolled for (register arrays of that size): 8 in general, 2 for whole MOVES --
+// CartPole has two actions, and with 8-entry arrays the MOVES variants do not fit the 256 registers of two workgroups per CU
+// (200 bytes of scratch per lane, ~20 scratch loads inside every simulation's serial chain)
+template <bool TREE_LDS, bool MOVES, int MAXA = (MOVES ? 2 : kMzMaxA)>
 __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel M, float *hidden, int n_sims, int gpw, MzTrace T, MzPlay P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mz_lds[];
-    const int A = E.n_actions, KX = kMzH + A;
+    constexpr int AFIX = MOVES ? 2 : 0;   // whole MOVES are CartPole's: two actions (rz_mz_play_cartpole checks)
+    const int A = AFIX > 0 ? AFIX : E.n_actions, KX = kMzH + A;
     const int tid = threadIdx.x, l = tid & 63, w = tid >> 6, n = l & 15, q = l >> 4;
     const int g0 = blockIdx.x * gpw;
     float *XS = reinterpret_cast<float *>(mz_lds);   // [72][16]: parent state + one-hot action; later the scaled next state
@@ -679,7 +686,10 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
     float *HW = HB + 16;                             // [10][64]: rew2 / val / pol weights
     float *OBS = HW + kMzHeadRows * kMzH;            // [8][16]: observations, [k][game] (MOVES)
     int *Gleaf = reinterpret_cast<int *>(OBS + kMzObs * kMzTile);   // [16]
-    int32_t *PATH = Gleaf + 16;                      // [gpw][path_stride]
+    // MOVES: the environments (x, x_dot, theta, theta_dot, steps, episode, episode start) wait in LDS between a move's first and
+    // last stage -- 14 registers that the simulations in between would otherwise carry
+    double *ENV = reinterpret_cast<double *>(Gleaf + 16);           // [16][8]
+    int32_t *PATH = reinterpret_cast<int32_t *>(ENV + kMzTile * 8);  // [gpw][path_stride]
     unsigned char *pp = mz_lds + (mz_search_fixed_floats() * 4 + gpw * E.path_stride * 4 + 15) / 16 * 16;
     double *PBL = reinterpret_cast<double *>(pp);    // [n_sims + 2]: the host's log table
     pp += ((E.n_sims + 2) * 8 + 15) / 16 * 16;
@@ -741,12 +751,24 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
     const bool live_n = n < gpw && g0 + n < E.n_games;           // column n of the tiles is a game
     int top = 0, depth = 0;
     double lo = 0.0, hi = 0.0;
-    MzCartPole env = {0.0, 0.0, 0.0, 0.0, 0, 0};
-    long long ep_start = 0;
+    double *env_g = ENV + 8 * ge;
+    auto env_load = [&](MzCartPole &c, long long &ep0) {
+        c = MzCartPole{env_g[0], env_g[1], env_g[2], env_g[3], __double_as_longlong(env_g[4]), __double_as_longlong(env_g[5])};
+        ep0 = __double_as_longlong(env_g[6]);
+    };
+    auto env_store = [&](const MzCartPole &c, long long ep0) {   // (the four lanes of a quad write the same values)
+        env_g[0] = c.x;
+        env_g[1] = c.x_dot;
+        env_g[2] = c.theta;
+        env_g[3] = c.theta_dot;
+        env_g[4] = __longlong_as_double(c.steps);
+        env_g[5] = __longlong_as_double(c.episode);
+        env_g[6] = __longlong_as_double(ep0);
+    };
     if (mine) {
         if (MOVES) {
-            env = MzCartPole{P.state[4 * g], P.state[4 * g + 1], P.state[4 * g + 2], P.state[4 * g + 3], P.steps[g], P.episode[g]};
-            ep_start = P.ep_start[g];
+            env_store(MzCartPole{P.state[4 * g], P.state[4 * g + 1], P.state[4 * g + 2], P.state[4 * g + 3], P.steps[g], P.episode[g]},
+                      P.ep_start[g]);
         } else {
             top = E.top[g];
             lo = E.vmin[g];
@@ -771,10 +793,10 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
     int32_t *path = PATH + (ge < gpw ? ge : 0) * E.path_stride;
     __syncthreads();
     if (MOVES && mine) {   // (after the zero fill of OBS)
-        OBS[0 * kMzTile + ge] = (float)env.x;
-        OBS[1 * kMzTile + ge] = (float)env.x_dot;
-        OBS[2 * kMzTile + ge] = (float)env.theta;
-        OBS[3 * kMzTile + ge] = (float)env.theta_dot;
+        OBS[0 * kMzTile + ge] = (float)env_g[0];
+        OBS[1 * kMzTile + ge] = (float)env_g[1];
+        OBS[2 * kMzTile + ge] = (float)env_g[2];
+        OBS[3 * kMzTile + ge] = (float)env_g[3];
     }
 
     // ---- the pieces the initial inference and a simulation share
@@ -818,7 +840,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
         const float pv = mz_head_partial(p, HW + 1 * kMzH, w, q, l);
         if (q == 0) RED[(3 * kMzWaves + w) * kMzTile + n] = pv;
 #pragma unroll
-        for (int a = 0; a < kMzMaxA; ++a) {
+        for (int a = 0; a < MAXA; ++a) {
             if (a < A) {
                 const float pl = mz_head_partial(p, HW + (2 + a) * kMzH, w, q, l);
                 if (q == 0) RED[((4 + a) * kMzWaves + w) * kMzTile + n] = pl;
@@ -826,13 +848,13 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
         }
     };
     // (lane that owns a game) value and softmax(policy logits) from the partial sums, waves in order
-    auto finish_prediction = [&](float &value, float (&probs)[kMzMaxA]) {
+    auto finish_prediction = [&](float &value, float (&probs)[MAXA]) {
         value = HB[1];
 #pragma unroll
         for (int u = 0; u < kMzWaves; ++u) value += RED[(3 * kMzWaves + u) * kMzTile + ge];
-        float logit[kMzMaxA], mxl = -INFINITY;
+        float logit[MAXA], mxl = -INFINITY;
 #pragma unroll
-        for (int a = 0; a < kMzMaxA; ++a) {
+        for (int a = 0; a < MAXA; ++a) {
             logit[a] = -INFINITY;
             if (a < A) {
                 float x = HB[2 + a];
@@ -844,12 +866,12 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
         }
         float den = 0.0f;
 #pragma unroll
-        for (int a = 0; a < kMzMaxA; ++a) {
+        for (int a = 0; a < MAXA; ++a) {
             probs[a] = a < A ? expf(logit[a] - mxl) : 0.0f;
             den += probs[a];
         }
 #pragma unroll
-        for (int a = 0; a < kMzMaxA; ++a) probs[a] = probs[a] / den;
+        for (int a = 0; a < MAXA; ++a) probs[a] = probs[a] / den;
     };
 
 #ifdef RZ_MZ_PROFILE
@@ -892,15 +914,16 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
             predict_partials();
             __syncthreads();
             if (w == 0) {
-                float value, probs[kMzMaxA];
+                float value, probs[MAXA];
                 finish_prediction(value, probs);
                 if (mine) {
                     // expand_node(root) + add_exploration_noise: prior * (1 - frac) + noise * frac (k_mz_init), fresh MinMaxStats
                     const unsigned long long key = mz_splitmix64(mz_splitmix64(mz_splitmix64(P.noise_seed ^ ((unsigned long long)g << 24)) ^
-                                                                                (unsigned long long)env.episode) ^ (unsigned long long)env.steps);
-                    float gam[kMzMaxA], gsum = 0.0f;
+                                                                                (unsigned long long)__double_as_longlong(env_g[5])) ^
+                                                                 (unsigned long long)__double_as_longlong(env_g[4]));
+                    float gam[MAXA], gsum = 0.0f;
 #pragma unroll
-                    for (int a = 0; a < kMzMaxA; ++a) {
+                    for (int a = 0; a < MAXA; ++a) {
                         gam[a] = a < A ? mz_gamma(P.alpha, (uint32_t)(key >> 32) + 0x9E3779B9u * (uint32_t)(a + 1) + (uint32_t)key) : 0.0f;
                         gsum += gam[a];
                     }
@@ -911,7 +934,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
                         nodes[0] = MzNode{0, 1, 0.0, 0.0, 0.0f, 0};
                     }
 #pragma unroll
-                    for (int a = 0; a < kMzMaxA; ++a) {
+                    for (int a = 0; a < MAXA; ++a) {
                         if (a < A) {
                             double pr = (double)probs[a];
                             if (P.noise_frac > 0.0) pr = pr * (1.0 - P.noise_frac) + ((double)gam[a] / (double)gsum) * P.noise_frac;
@@ -937,7 +960,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
         int par = 0, act = 0, lf = 0;
         if (w == 0) {
             if (mine)
-                depth = TREE_LDS ? mz_descend_hot(E, hot, path, PBL, SQT, lo, hi, ca, hidden + (long long)g * E.cap * kMzH, touch_sink, par, act, lf)
+                depth = TREE_LDS ? mz_descend_hot<AFIX>(E, hot, path, PBL, SQT, lo, hi, ca, hidden + (long long)g * E.cap * kMzH, touch_sink, par, act, lf)
                                  : mz_descend(E, nodes, path, PBL, lo, hi, par, act, lf);
             MZ_TICK(0);
 #ifdef RZ_MZ_PROFILE
@@ -1014,7 +1037,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
             float reward = HB[0];
 #pragma unroll
             for (int u = 0; u < kMzWaves; ++u) reward += RED[(2 * kMzWaves + u) * kMzTile + ge];
-            float value, probs[kMzMaxA];
+            float value, probs[MAXA];
             finish_prediction(value, probs);
             MZ_TICK(11);
             if (mine) {
@@ -1026,11 +1049,11 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
                     T.reward[o] = reward;
                     T.value[o] = value;
 #pragma unroll
-                    for (int a = 0; a < kMzMaxA; ++a)
+                    for (int a = 0; a < MAXA; ++a)
                         if (a < A) T.probs[o * A + a] = probs[a];
                 }
-                if (TREE_LDS) mz_grow_backup_hot<kMzMaxA>(E, hot, rew, path, E.cap, ca, depth, top, lo, hi, reward, probs, value);
-                else mz_grow_backup<kMzMaxA>(E, nodes, path, depth, top, lo, hi, reward, probs, value);
+                if (TREE_LDS) mz_grow_backup_hot<MAXA, AFIX>(E, hot, rew, path, E.cap, ca, depth, top, lo, hi, reward, probs, value);
+                else mz_grow_backup<MAXA>(E, nodes, path, depth, top, lo, hi, reward, probs, value);
             }
             MZ_TICK(12);
         }
@@ -1039,10 +1062,13 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
     }
         if (MOVES && mine) {
             // ---- the move: action ~ visits ^ (1 / T) (select_action), record for the host, environment step
-            double wgt[kMzMaxA], total = 0.0, best_w = -1.0;
-            int visits[kMzMaxA], arg = 0;
+            MzCartPole env;
+            long long ep_start;
+            env_load(env, ep_start);
+            double wgt[MAXA], total = 0.0, best_w = -1.0;
+            int visits[MAXA], arg = 0;
 #pragma unroll
-            for (int a = 0; a < kMzMaxA; ++a) {
+            for (int a = 0; a < MAXA; ++a) {
                 visits[a] = a < A ? (TREE_LDS ? hot[1 + a].N : nodes[1 + a].N) : 0;
                 wgt[a] = 0.0;
                 if (a < A) {
@@ -1063,7 +1089,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
                 bool found = false;
                 action = A - 1;
 #pragma unroll
-                for (int a = 0; a < kMzMaxA; ++a) {
+                for (int a = 0; a < MAXA; ++a) {
                     if (a < A) {
                         cum += wgt[a];
                         if (!found && cum > target) {
@@ -1078,7 +1104,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
             const long long t = P.t0 + move;
             double *ring_g = P.ring + (long long)g * P.hist * P.row;
             double *rec = ring_g + (t % P.hist) * P.row;
-            double last[8 + kMzMaxA];
+            double last[8 + MAXA];
             last[0] = (double)(float)env.x;   // the observation the search started from
             last[1] = (double)(float)env.x_dot;
             last[2] = (double)(float)env.theta;
@@ -1086,12 +1112,12 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
             last[4] = (double)action;
             last[5] = 1.0;
 #pragma unroll
-            for (int a = 0; a < kMzMaxA; ++a) last[6 + a] = (double)visits[a];
+            for (int a = 0; a < MAXA; ++a) last[6 + a] = (double)visits[a];
             const double root_value = root_sum / (double)(root_n > 1 ? root_n : 1);
             const int done = cartpole_step(env, action);
             if (lead) {
 #pragma unroll
-                for (int c = 0; c < 6 + kMzMaxA; ++c)
+                for (int c = 0; c < 6 + MAXA; ++c)
                     if (c < 6 + A) rec[c] = last[c];
                 rec[6 + A] = root_value;
                 rec[7 + A] = done ? 1.0 : 0.0;
@@ -1126,7 +1152,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
                     if (lead) {
                         double *dst = P.arena + (off + len - 1) * P.row;
 #pragma unroll
-                        for (int c = 0; c < 6 + kMzMaxA; ++c)
+                        for (int c = 0; c < 6 + MAXA; ++c)
                             if (c < 6 + A) dst[c] = last[c];
                         dst[6 + A] = root_value;
                         dst[7 + A] = 1.0;
@@ -1140,6 +1166,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
             OBS[1 * kMzTile + ge] = (float)env.x_dot;
             OBS[2 * kMzTile + ge] = (float)env.theta;
             OBS[3 * kMzTile + ge] = (float)env.theta_dot;
+            env_store(env, ep_start);
         }
         MZ_TICK(14);
     }
@@ -1153,13 +1180,13 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
         E.vmax[g] = hi;
         E.depth[g] = depth;
         if (MOVES) {
-            P.state[4 * g] = env.x;
-            P.state[4 * g + 1] = env.x_dot;
-            P.state[4 * g + 2] = env.theta;
-            P.state[4 * g + 3] = env.theta_dot;
-            P.steps[g] = env.steps;
-            P.episode[g] = env.episode;
-            P.ep_start[g] = ep_start;
+            P.state[4 * g] = env_g[0];
+            P.state[4 * g + 1] = env_g[1];
+            P.state[4 * g + 2] = env_g[2];
+            P.state[4 * g + 3] = env_g[3];
+            P.steps[g] = __double_as_longlong(env_g[4]);
+            P.episode[g] = __double_as_longlong(env_g[5]);
+            P.ep_start[g] = __double_as_longlong(env_g[6]);
         }
     }
     if (TREE_LDS) {

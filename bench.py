@@ -766,7 +766,8 @@ def main():
         try:
             # a local failure inside is agreed on by all ranks within the collectives (selfplay.gather_trajectories):
             # every rank raises together, nobody stays blocked, and the measured line is still printed
-            merged = gather_trajectories(gather_sample, board, n_row, dst=0, game=args.game) or []
+            # (pi as float32: what the learner consumes, half the bytes -- the exchange SURVEY.md 8e sizes)
+            merged = gather_trajectories(gather_sample, board, n_row, dst=0, game=args.game, pi_dtype=np.float32) or []
             gather_error = None
         except Exception as exc:  # noqa: BLE001
             merged, gather_error = [], '%s: %s' % (type(exc).__name__, exc)
@@ -777,7 +778,7 @@ def main():
         elif rank == 0:
             plies = sum(len(t.moves) for t in merged)
             gather = {'ranks': world, 'games': len(merged), 'plies': plies, 'backend': dist.get_backend(),
-                      'payload_bytes': int(32 * len(merged) + plies * 8 * (1 + merged[0].pis.shape[1])) if merged else 0,
+                      'payload_bytes': int(32 * len(merged) + plies * (8 + 4 * merged[0].pis.shape[1])) if merged else 0,
                       'ms': round(1000.0 * dt, 2),
                       'unique_game_ids': len({t.game_id for t in merged}) == len(merged)}
 
@@ -785,7 +786,7 @@ def main():
         # the finished games rank 0 holds (N > 1: gathered from all ranks), for world-size-invariance checks
         with open(args.dump_trajectories, 'w') as f:
             json.dump({str(t.game_id): {'moves': t.moves, 'winner': t.winner,
-                                        'pi_hex': [float(x).hex() for x in t.pis[0]] if len(t.moves) else []}
+                                        'pi_hex': [float(np.float32(x)).hex() for x in t.pis[0]] if len(t.moves) else []}
                        for t in merged}, f)
     if rank == 0:
         value = total_sims / elapsed

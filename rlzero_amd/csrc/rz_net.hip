@@ -10,9 +10,12 @@
 // Kernels (one workgroup owns a board; its activations never leave the CU: input planes, conv1 output (32 ch)
 // and conv2 output (64 ch) live in LDS as halo-padded planes [channel][18 rows][18 cols]; conv3's 128 channels
 // stay in registers and are consumed by the two 1x1 head convolutions there):
-//   k_trunk_split<TN> (default)   conv1..conv3 as direct convolutions on v_mfma_f32_32x32x16_f16, every f32 operand
-//                                 a hi + lo pair of f16 values; persistent workgroups, 4 waves (f16 layouts in LDS:
-//                                 see the kernel); TN = 2 row-pair tiles per wave, 1 for boards of up to 8 rows
+//   k_trunk_rows<NT> (default,    conv1..conv3 as direct convolutions on the f16 matrix pipe, every f32 operand a hi + lo pair of
+//     boards of 11 .. 16 rows     f16 values: v_mfma_f32_16x16x32_f16, one N-tile per board row, the four waves split the OUTPUT
+//     and columns)                CHANNELS, rows innermost in the K loop; persistent workgroups (layouts in LDS: see the kernel)
+//   k_trunk_split<TN, MS>         the same arithmetic on v_mfma_f32_32x32x16_f16 tiles of whole rows, the waves split the rows
+//     (smaller boards)            (TN = 1: one tile per wave, MS: idle waves take channel shares); optionally the FC layers of
+//                                 its own board behind it (RZ_NET_HEADS_IN_TRUNK); the checker of k_trunk_rows
 //   k_trunk_wino_f4<4>            conv2 / conv3 as Winograd F(4x4,3x3) on the f32-input MFMA, persistent workgroups, 4 waves
 //   k_trunk                       direct implicit GEMM (bit-for-bit a k-ordered fmaf chain): M = output channels
 //                                 (A = weights, pre-packed on the host in fragment order, streamed from L2), N =

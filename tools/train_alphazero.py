@@ -66,6 +66,8 @@ class TrainPipeline:
         (uniforms keyed (seed, game id, ply)); None = drawn on rank 0.  Under a launcher (RANK / WORLD_SIZE set, or an
         initialised process group) the pipeline is one of the ranks: see the module docstring."""
         self.rank, self.world = self._init_ranks()
+        if self.world > 1 and selfplay_games_in_flight <= 0:
+            raise ValueError('several ranks share a collection round: selfplay_games_in_flight must be > 0 (games per GPU)')
         # board and game
         self.board_size = board_size
         self.n_in_row = n_in_row
@@ -298,8 +300,6 @@ def main():
         torch.manual_seed(args.seed)
     pipe = TrainPipeline(board_size=args.board, n_in_row=args.n_in_row, n_playout=args.playouts, game_batch_num=args.batches,
                          check_freq=args.check_freq, selfplay_games_in_flight=args.games_in_flight, seed=args.seed)
-    if pipe.world > 1 and args.games_in_flight <= 0:
-        raise SystemExit('several ranks share a collection round: pass --games-in-flight > 0')
     pipe.run()
     if pipe.world > 1:
         import torch.distributed as dist

@@ -484,7 +484,7 @@ def main():
     ap.add_argument('--score-mode', default='uct_ref', choices=['uct_ref', 'puct'],
                     help="uct_ref: the reference's selection rule (node.py:32-42, 75-88; bit-exact); puct: the opt-in AlphaZero "
                          "rule Q + c P sqrt(N_parent) / (N + 1) (every level scans all children; parity by the oracle's restatement)")
-    ap.add_argument('--heads-algo', default='auto', choices=['auto', 'f32', 'split32', 'split64', 'parts'],
+    ap.add_argument('--heads-algo', default='auto', choices=['auto', 'f32', 'split32', 'split64', 'parts', 'in_trunk'],
                     help='GEMM of the first FC layers (rz_net_set_heads_algo)')
     ap.add_argument('--noise', type=int, default=1,
                     help='Dirichlet(0.3) noise mixed into the priors of EVERY expanded node, as the reference does in '
@@ -584,6 +584,9 @@ def main():
     heads_algo = args.heads_algo
     if heads_algo == 'auto' and lanes > 1 and trunk_wgs == 0 and args.evaluator == 'hipnet' and args.net_algo.startswith('split_f16'):
         heads_algo = 'parts'  # un-capped lanes: the LDS-free GEMM that fits beside a resident trunk workgroup
+        from rlzero_amd.selfplay import fc_in_trunk_pays
+        if fc_in_trunk_pays(*((6, 7, 7) if args.game == 'connect4' else (board, board, board * board))):
+            heads_algo = 'in_trunk'  # small FC layers: the trunk's workgroups run them on their own boards, no GEMM launch
     lanes = max(1, min(lanes, G))
     per_lane = [G // lanes + (1 if i < G % lanes else 0) for i in range(lanes)]
     torch.manual_seed(0)  # identical weights on every rank

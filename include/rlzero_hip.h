@@ -348,7 +348,8 @@ int rz_net_set_max_workgroups(rz_net *net, int32_t max_workgroups);
 enum { RZ_NET_HEADS_AUTO = 0, RZ_NET_HEADS_F32 = 1, RZ_NET_HEADS_SPLIT_32 = 2, RZ_NET_HEADS_SPLIT_64 = 3, RZ_NET_HEADS_SPLIT_PARTS = 4,
        RZ_NET_HEADS_IN_TRUNK = 5   /* boards of up to 10 rows on the RZ_NET_SPLIT_F16 trunk: every trunk workgroup runs these layers on
                                       its own board behind the feature stage (no GEMM launch; the bits of the SPLIT shapes); what AUTO
-                                      picks for an un-capped batch of at most one board per CU on boards of up to 36 cells; other boards: as AUTO */ };
+                                      picks for an un-capped batch of at most one board per CU while the FC weights are at most 40 KB (6 x 6, Connect4);
+                                      other boards: as AUTO */ };
 int rz_net_set_heads_algo(rz_net *net, int32_t heads_algo);
 int rz_net_create(int32_t height, int32_t width, int32_t n_actions, int32_t device, rz_net **out);
 int rz_net_destroy(rz_net *net);

@@ -2819,11 +2819,13 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
         // Small batches of small boards (every board has a workgroup of its own, nothing of another lane to overlap with): the
         // trunk's workgroups run the FC layers on their boards themselves -- no FC launch, no kernel boundary (same bits).
         // Every workgroup then streams ALL FC weights from L2 for its one board (the GEMM launch reads them once per 32
-        // boards): AUTO takes this route up to 6 x 6 (38 KB: TicTacToe one game +6 %, 16 games +3 %); at 9 x 9 (146 KB) the
+        // boards): AUTO takes this route while the weights are at most 40 KB (6 x 6: 39 KB, TicTacToe one game +6 %, 16 games +3 %;
+        // Connect4: 26 KB); at 9 x 9 (146 KB) the
         // launch it saves is cheaper than the stream it costs (64 games -5 %, profiles/r03/in_trunk_fc.txt)
         const bool fc_here = internal && tiles <= 4 && net->dev.BH <= 10 && !rows_kernel_covers(net->dev.BH, net->dev.BW) &&
                              (net->heads_algo == RZ_NET_HEADS_IN_TRUNK ||
-                              (net->heads_algo == RZ_NET_HEADS_AUTO && net->max_wgs == 0 && n_boards <= wg_cap && net->dev.S <= 36));
+                              (net->heads_algo == RZ_NET_HEADS_AUTO && net->max_wgs == 0 && n_boards <= wg_cap &&
+                               ((size_t)net->dev.A * 4 * net->dev.S + (size_t)64 * 2 * net->dev.S) * 4 <= 40 * 1024));
         float *raw = fc_here ? net->d_raw : nullptr, *hid = fc_here ? net->d_hid : nullptr;
         net->raw_from_trunk = fc_here;
         if (fc_here) net->feat16_valid = false;   // (the pieces stayed in LDS)

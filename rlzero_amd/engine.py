@@ -149,7 +149,7 @@ class HipNet(object):
         operand pairs after the 'split_f16' trunk, 32 / 64 boards per workgroup), 'parts' (the same arithmetic as
         single-wave workgroups per K quarter, no LDS: fits beside a resident trunk workgroup of another lane; the consumer
         adds the four partial sums), 'auto' (default after the 'split_f16' trunk: 'split64' beside a capped trunk,
-        otherwise 'parts' up to 256 boards and 'split32' above; 'f32' after the f32 trunks; on boards of up to 36 cells an
+        otherwise 'parts' up to 256 boards and 'split32' above; 'f32' after the f32 trunks; with FC weights of at most 40 KB (6x6, Connect4) an
         un-capped batch of at most one board per CU runs 'in_trunk': every trunk workgroup does these layers on its own board,
         no GEMM launch -- selectable up to 10 rows).  All give the same bits."""
         code = {'auto': _hip.NET_HEADS_AUTO, 'f32': _hip.NET_HEADS_F32, 'split32': _hip.NET_HEADS_SPLIT_32,

@@ -157,6 +157,15 @@ def plan_lanes(n_games, n_cus=256):
     return 2, 0, 'parts'
 
 
+def fc_in_trunk_pays(rows, cols, n_actions):
+    """True when the trunk's workgroups should run the first FC layers on their own boards (HipNet.set_heads_algo('in_trunk'))
+    instead of a GEMM launch of its own: boards of up to 10 rows whose FC weights (hi + lo f16) are at most 40 KB -- every workgroup
+    streams them for its one board (6x6: 39 KB, TicTacToe +6 %; Connect4: 26 KB, 512 games on two lanes +3 %; 9x9: 146 KB, -5 to
+    -11 %: profiles/r03/in_trunk_fc.txt)."""
+    cells = rows * cols
+    return rows <= 10 and (n_actions * 4 * cells + 64 * 2 * cells) * 4 <= 40 * 1024
+
+
 class _Lane(object):
     """One engine + its evaluator + the HIP stream its kernels are enqueued on."""
 
@@ -229,6 +238,11 @@ class BatchedSelfPlay(object):
             wgs, heads_algo = (0, 'parts') if lanes > 1 else (0, 'auto')
         if trunk_workgroups is not None:
             wgs = trunk_workgroups
+        shape = net_shape if net_shape is not None else board
+        rows, cols = (shape[0], shape[1]) if isinstance(shape, (tuple, list)) else (shape, shape)
+        acts = shape[2] if isinstance(shape, (tuple, list)) and len(shape) > 2 else rows * cols
+        if heads_algo == 'parts' and int(wgs) == 0 and fc_in_trunk_pays(rows, cols, acts):
+            heads_algo = 'in_trunk'   # small FC layers: no GEMM launch at all (each lane's chain loses a kernel and a boundary)
         lanes = max(1, min(int(lanes), n_games))
         per_lane = [n_games // lanes + (1 if i < n_games % lanes else 0) for i in range(lanes)]
         engines, evaluators = [], []

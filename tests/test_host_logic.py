@@ -141,3 +141,28 @@ def test_batched_pi_and_moves_bit_identical_to_per_game_expressions():
                 assert np.array_equal(full, pi[r]) and draw_move(acts, p, us[r]) == mv[r]
 
 
+
+
+def test_fc_in_trunk_rule():
+    """The FC layers ride inside the trunk's launch only where their weights are a small stream per board (<= 40 KB of hi + lo
+    f16, boards of up to 10 rows): TicTacToe, 6x6, Connect4 -- not 9x9 (146 KB: measured slower), never the 15x15 of the metric."""
+    from rlzero_amd.selfplay import fc_in_trunk_pays
+    assert fc_in_trunk_pays(3, 3, 9) and fc_in_trunk_pays(6, 6, 36) and fc_in_trunk_pays(6, 7, 7)
+    assert not fc_in_trunk_pays(7, 7, 49) and not fc_in_trunk_pays(9, 9, 81) and not fc_in_trunk_pays(15, 15, 225)
+    assert not fc_in_trunk_pays(11, 3, 33)  # a board of more than 10 rows has no room for the pieces in LDS
+
+
+def test_bench_reads_the_committed_counter_runs():
+    """bench.pmc_traffic: HBM-side bytes per launch from profiles/r03/pmc_traffic.json, one entry per workload on the line (the
+    rule variants of a geometry keyed separately); None for a workload nobody profiled."""
+    import bench
+    head = 'gomoku15x15_n5_selfplay_800sims_per_move_512games_per_gpu'
+    for kernel in ('k_trunk', 'k_heads', 'k_tree_step'):
+        assert bench.pmc_traffic(kernel, head) > 1e6
+        assert bench.pmc_traffic(kernel, 'gomoku15x15_n5_selfplay_800sims_per_move_1536games_per_gpu') > bench.pmc_traffic(kernel, head)
+    assert bench.pmc_traffic('k_tree_step', head + '+puct') > bench.pmc_traffic('k_tree_step', head)   # every level scans all children
+    assert bench.pmc_traffic('k_mz_search', 'muzero_cartpole_v1_50sims_per_move_8192envs_per_gpu') > 1e9
+    assert bench.pmc_traffic('k_trunk', 'gomoku19x19_n5_selfplay_800sims_per_move_512games_per_gpu') is None
+    # the trunk of a 256-board launch writes exactly the f16 feature pieces: 256 boards x 1350 features x (hi + lo) x 2 bytes
+    rec = __import__('json').load(open(__import__('os').path.join(bench.REPO, 'profiles', 'r03', 'pmc_traffic.json')))
+    assert abs(rec[head]['kernels']['k_trunk']['write_size_kb'] * 1024 - 256 * 1350 * 4) < 0.03 * 256 * 1350 * 4

@@ -579,10 +579,16 @@ constexpr int kMzH = 64, kMzWaves = 4, kMzMaxA = 8, kMzTile = 16, kMzKX = kMzH +
 constexpr int kMzRedRows = 4 + kMzMaxA;   // min, max, reward, value, logits
 constexpr int kMzHeadRows = 2 + kMzMaxA;  // rew2, val, pol rows
 typedef float mz_f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 mz_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 mz_f16x4 __attribute__((ext_vector_type(4)));
 
 struct MzModel {        // device pointers, weights k-major: w[k][unit]
     const float *dyn1_w, *dyn1_b, *dyn2_w, *dyn2_b, *rew1_w, *rew1_b, *rew2_w, *rew2_b, *pre1_w, *pre1_b, *pol_w, *pol_b,
         *val_w, *val_b, *rep1_w, *rep1_b, *rep2_w, *rep2_b;   // rep1_w: [kMzObs][64], rows >= obs_dim zero
+    // whole MOVES run dyn1 / dyn2 / rew1 / pre1 on the f16 matrix pipe with hi + lo operand pairs (k_mz_search, F16): the powers of
+    // two that bring each layer's largest weight into [2^13, 2^14) -- sw of dyn1 (its 64 state columns), dyn2, rew1, pre1 -- and the
+    // scale s1 <= 16 of relu(dyn1)'s f16 pieces from a bound on them (states lie in [0, 1]): [5] floats
+    const float *f16_scales;
 };
 
 struct MzTrace {        // optional per-simulation outputs for the parity tests: [n_sims][n_games] (probs: x n_actions)
@@ -614,8 +620,10 @@ struct MzPlay {         // rz_mz_play_cartpole
 
 // LDS of k_mz_search in bytes: activations, reductions, head weights, per-game scalars, paths, log table (+ the trees)
 __host__ __device__ inline int mz_search_fixed_floats() {
-    return kMzKX * kMzTile + kMzH * kMzTile + kMzRedRows * kMzWaves * kMzTile + 16 + kMzHeadRows * kMzH + kMzObs * kMzTile + 16 +
-           kMzTile * 16;   // (+ the environments of whole MOVES: 7 doubles per game, 8 reserved)
+    return kMzKX * kMzTile + (kMzH * kMzTile + 128) + kMzRedRows * kMzWaves * kMzTile + 16 + kMzHeadRows * kMzH + kMzObs * kMzTile + 16 +
+           kMzTile * 16 +                  // (+ the environments of whole MOVES: 7 doubles per game, 8 reserved)
+           2 * kMzH + kMzTile;             // (+ dyn1's action columns [2 actions][unit] and the games' actions: the f16 layers of whole
+                                           // MOVES; every byte counts -- two workgroups of 16 games share a CU's 160 KB with 1.5 KB to spare)
 }
 __host__ __device__ inline int mz_search_lds_bytes(int gpw, int cap, int path_stride, int n_sims_cfg, bool tree_lds) {
     int bytes = mz_search_fixed_floats() * 4 + gpw * path_stride * 4;
@@ -681,7 +689,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
     const int g0 = blockIdx.x * gpw;
     float *XS = reinterpret_cast<float *>(mz_lds);   // [72][16]: parent state + one-hot action; later the scaled next state
     float *HP = XS + kMzKX * kMzTile;                // [64][16]: relu(dyn1) (relu(rep1) in the initial inference)
-    float *RED = HP + kMzH * kMzTile;                // [12][4 waves][16]: per-wave min / max / reward / value / logit partials
+    float *RED = HP + kMzH * kMzTile + 128;          // [12][4 waves][16]: per-wave min / max / reward / value / logit partials
     float *HB = RED + kMzRedRows * kMzWaves * kMzTile;   // [0] rew2 bias, [1] val bias, [2 .. 2 + A) pol biases
     float *HW = HB + 16;                             // [10][64]: rew2 / val / pol weights
     float *OBS = HW + kMzHeadRows * kMzH;            // [8][16]: observations, [k][game] (MOVES)
@@ -689,7 +697,9 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
     // MOVES: the environments (x, x_dot, theta, theta_dot, steps, episode, episode start) wait in LDS between a move's first and
     // last stage -- 14 registers that the simulations in between would otherwise carry
     double *ENV = reinterpret_cast<double *>(Gleaf + 16);           // [16][8]
-    int32_t *PATH = reinterpret_cast<int32_t *>(ENV + kMzTile * 8);  // [gpw][path_stride]
+    float *W1A = reinterpret_cast<float *>(ENV + kMzTile * 8);       // [2][64]: dyn1's weights of the one-hot action rows (F16: two actions)
+    int *Gact = reinterpret_cast<int *>(W1A + 2 * kMzH);             // [16]: the action of the edge into each game's leaf (F16)
+    int32_t *PATH = Gact + kMzTile;                                  // [gpw][path_stride]
     unsigned char *pp = mz_lds + (mz_search_fixed_floats() * 4 + gpw * E.path_stride * 4 + 15) / 16 * 16;
     double *PBL = reinterpret_cast<double *>(pp);    // [n_sims + 2]: the host's log table
     pp += ((E.n_sims + 2) * 8 + 15) / 16 * 16;
@@ -703,20 +713,81 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
     // (the representation network's fragments -- 18 + 8 registers, used once per MOVE -- are fetched at the start of every
     // move instead: kept for the whole launch they push the MOVES variants past the 256 registers of two workgroups per CU
     // and into scratch, in the middle of the per-simulation chain)
-    float a1[kMzKX / 4], a2[kMzH / 4], ar[kMzH / 4], ap[kMzH / 4];
+    // F16 (whole MOVES): the four 64 x 64 layers of a simulation on the f16 matrix pipe, v_mfma_f32_16x16x32_f16 with every
+    // f32 operand a hi + lo pair of f16 values (three MFMAs per product, f32 accumulation: the network trunk's arithmetic,
+    // rz_net.hip) -- 6 MFMAs of 16 cycles per layer instead of 16 .. 18 of 32.  The activations then live in LDS as
+    // [game][hi: 64 f16 | lo: 64 f16 | 32 B pad] (a B fragment = one ds_read_b128: lane = 16 (k block) + game), the hidden
+    // states in HBM as the same 256 bytes (the gather is a plain copy), dyn1's one-hot action rows are added as a column of
+    // f32 weights.  Activation scales: 16 for states (they lie in [0, 1]), s1 for relu(dyn1) (rz_mz_load_model's bound).
+    constexpr bool F16 = MOVES;
+    constexpr int kRec = 288;   // bytes of a game's activation record
+    float a1[F16 ? 1 : kMzKX / 4], a2[F16 ? 1 : kMzH / 4], ar[F16 ? 1 : kMzH / 4], ap[F16 ? 1 : kMzH / 4];
+    mz_f16x8 f1[2][2], f2[2][2], fr[2][2], fp[2][2];   // (F16) [K-step of 32][hi | lo]: lane = 16 g + r holds W[k = 32 s + 8 g + j][unit 16 w + r]
+    float d1 = 1.0f, d2 = 1.0f, dr = 1.0f, dp = 1.0f, s1 = 1.0f;
     const int unit = 16 * w + n;
+    if constexpr (F16) {
+        const float sw1 = M.f16_scales[0], sw2 = M.f16_scales[1], swr = M.f16_scales[2], swp = M.f16_scales[3];
+        s1 = M.f16_scales[4];
+        d1 = 1.0f / (16.0f * sw1);
+        d2 = 1.0f / (s1 * sw2);
+        dr = 1.0f / (s1 * swr);
+        dp = 1.0f / (16.0f * swp);
+        auto frag = [&](const float *wk, float sw, mz_f16x8 (&f)[2][2]) {
 #pragma unroll
-    for (int s = 0; s < kMzKX / 4; ++s) {
-        const int k = 4 * s + q;
-        a1[s] = k < KX ? M.dyn1_w[k * kMzH + unit] : 0.0f;
-    }
+            for (int st = 0; st < 2; ++st)
 #pragma unroll
-    for (int s = 0; s < kMzH / 4; ++s) {
-        const int k = 4 * s + q;
-        a2[s] = M.dyn2_w[k * kMzH + unit];
-        ar[s] = M.rew1_w[k * kMzH + unit];
-        ap[s] = M.pre1_w[k * kMzH + unit];
+                for (int j = 0; j < 8; ++j) {
+                    const float v = wk[(32 * st + 8 * q + j) * kMzH + unit] * sw;
+                    const _Float16 hi = (_Float16)v;
+                    f[st][0][j] = hi;
+                    f[st][1][j] = (_Float16)(v - (float)hi);
+                }
+        };
+        frag(M.dyn1_w, sw1, f1);
+        frag(M.dyn2_w, sw2, f2);
+        frag(M.rew1_w, swr, fr);
+        frag(M.pre1_w, swp, fp);
+        static_assert(!F16 || AFIX == 2, "the f16 layers are built for CartPole's two actions");
+        for (int i = tid; i < 2 * kMzH; i += 64 * kMzWaves) W1A[i] = M.dyn1_w[kMzH * kMzH + i];   // rows 64, 65 of [k][unit]
+    } else {
+#pragma unroll
+        for (int s = 0; s < kMzKX / 4; ++s) {
+            const int k = 4 * s + q;
+            a1[s] = k < KX ? M.dyn1_w[k * kMzH + unit] : 0.0f;
+        }
+#pragma unroll
+        for (int s = 0; s < kMzH / 4; ++s) {
+            const int k = 4 * s + q;
+            a2[s] = M.dyn2_w[k * kMzH + unit];
+            ar[s] = M.rew1_w[k * kMzH + unit];
+            ap[s] = M.pre1_w[k * kMzH + unit];
+        }
     }
+    // (F16) acc += W . X over the 64 state values of the games' records at `rec` (LDS), hi + lo pairs: 6 MFMAs
+    auto mfma16 = [&](const mz_f16x8 (&f)[2][2], const unsigned char *rec, mz_f32x4 acc) {
+        const unsigned char *p = rec + n * kRec + q * 16;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const mz_f16x8 bh = *reinterpret_cast<const mz_f16x8 *>(p + st * 64), bl = *reinterpret_cast<const mz_f16x8 *>(p + 128 + st * 64);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[st][0], bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[st][0], bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f[st][1], bh, acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    // (F16) the lane's 4 values (units 16 w + 4 q + i of game n), already scaled, as hi + lo pieces into the games' records
+    auto store16 = [&](unsigned char *rec, const float (&z)[4]) {
+        mz_f16x4 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            hi[i] = (_Float16)z[i];
+            lo[i] = (_Float16)(z[i] - (float)hi[i]);
+        }
+        unsigned char *p = rec + n * kRec + (16 * w + 4 * q) * 2;
+        *reinterpret_cast<mz_f16x4 *>(p) = hi;
+        *reinterpret_cast<mz_f16x4 *>(p + 128) = lo;
+    };
+    unsigned char *XS16 = reinterpret_cast<unsigned char *>(XS), *HP16 = reinterpret_cast<unsigned char *>(HP);
     mz_f32x4 b1, b2, br, bp;   // biases in the C/D layout: rows 16w + 4q + i
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -815,11 +886,22 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
         sv.y = (t[1] - mn) / inv;
         sv.z = (t[2] - mn) / inv;
         sv.w = (t[3] - mn) / inv;
-        XS[(16 * w + 4 * q + 0) * kMzTile + n] = sv.x;
-        XS[(16 * w + 4 * q + 1) * kMzTile + n] = sv.y;
-        XS[(16 * w + 4 * q + 2) * kMzTile + n] = sv.z;
-        XS[(16 * w + 4 * q + 3) * kMzTile + n] = sv.w;
-        if (live_n) *reinterpret_cast<float4 *>(hidden + ((long long)(g0 + n) * E.cap + Gleaf[n]) * kMzH + 16 * w + 4 * q) = sv;
+        if constexpr (F16) {
+            const float z[4] = {sv.x * 16.0f, sv.y * 16.0f, sv.z * 16.0f, sv.w * 16.0f};
+            store16(XS16, z);
+            if (live_n) {   // the same 256 bytes as the game's hidden-state slot
+                const unsigned char *src = XS16 + n * kRec + (16 * w + 4 * q) * 2;
+                unsigned char *dst = reinterpret_cast<unsigned char *>(hidden + ((long long)(g0 + n) * E.cap + Gleaf[n]) * kMzH) + (16 * w + 4 * q) * 2;
+                *reinterpret_cast<mz_f16x4 *>(dst) = *reinterpret_cast<const mz_f16x4 *>(src);
+                *reinterpret_cast<mz_f16x4 *>(dst + 128) = *reinterpret_cast<const mz_f16x4 *>(src + 128);
+            }
+        } else {
+            XS[(16 * w + 4 * q + 0) * kMzTile + n] = sv.x;
+            XS[(16 * w + 4 * q + 1) * kMzTile + n] = sv.y;
+            XS[(16 * w + 4 * q + 2) * kMzTile + n] = sv.z;
+            XS[(16 * w + 4 * q + 3) * kMzTile + n] = sv.w;
+            if (live_n) *reinterpret_cast<float4 *>(hidden + ((long long)(g0 + n) * E.cap + Gleaf[n]) * kMzH + 16 * w + 4 * q) = sv;
+        }
     };
     auto wave_extremes = [&](const mz_f32x4 &t) {
         float mn = fminf(fminf(t[0], t[1]), fminf(t[2], t[3])), mx = fmaxf(fmaxf(t[0], t[1]), fmaxf(t[2], t[3]));
@@ -834,9 +916,16 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
     };
     // prediction f(s) on the state in XS: p1 = relu(pre1 s), per-wave partial sums of the value and policy heads
     auto predict_partials = [&]() {
-        mz_f32x4 p = mz_tile(ap, XS, q, n, bp);
+        mz_f32x4 p;
+        if constexpr (F16) {
+            p = mfma16(fp, XS16, mz_f32x4{0.0f, 0.0f, 0.0f, 0.0f});
 #pragma unroll
-        for (int i = 0; i < 4; ++i) p[i] = fmaxf(p[i], 0.0f);
+            for (int i = 0; i < 4; ++i) p[i] = fmaxf(fmaf(p[i], dp, bp[i]), 0.0f);
+        } else {
+            p = mz_tile(ap, XS, q, n, bp);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) p[i] = fmaxf(p[i], 0.0f);
+        }
         const float pv = mz_head_partial(p, HW + 1 * kMzH, w, q, l);
         if (q == 0) RED[(3 * kMzWaves + w) * kMzTile + n] = pv;
 #pragma unroll
@@ -974,20 +1063,30 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
             const int ee = ge, pe = par;   // (the quad of a game also gathers its parent's state: 4 x 64 bytes per lane)
             const bool live_e = mine;
             const float4 *src = reinterpret_cast<const float4 *>(hidden + ((long long)(g0 + (live_e ? ee : 0)) * E.cap + pe) * kMzH);
+            if constexpr (F16) {   // the slot holds the record's 256 bytes as they are: a copy (16 games x 4 lanes x 4 pieces)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c = (l & 3) + 4 * j;
-                const float4 v = live_e ? src[c] : float4{0.0f, 0.0f, 0.0f, 0.0f};
-                XS[(4 * c + 0) * kMzTile + ee] = v.x;
-                XS[(4 * c + 1) * kMzTile + ee] = v.y;
-                XS[(4 * c + 2) * kMzTile + ee] = v.z;
-                XS[(4 * c + 3) * kMzTile + ee] = v.w;
-            }
-            const int an = __shfl(act, 4 * n);
+                for (int j = 0; j < 4; ++j) {
+                    const int c = (l & 3) + 4 * j;
+                    const float4 v = live_e ? src[c] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+                    *reinterpret_cast<float4 *>(XS16 + ee * kRec + c * 16) = v;
+                }
+                if (ca == 0) Gact[ge] = mine ? act : 0;
+            } else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int a = q + 4 * j;
-                if (a < A) XS[(kMzH + a) * kMzTile + n] = (live_n && an == a) ? 1.0f : 0.0f;
+                for (int j = 0; j < 4; ++j) {
+                    const int c = (l & 3) + 4 * j;
+                    const float4 v = live_e ? src[c] : float4{0.0f, 0.0f, 0.0f, 0.0f};
+                    XS[(4 * c + 0) * kMzTile + ee] = v.x;
+                    XS[(4 * c + 1) * kMzTile + ee] = v.y;
+                    XS[(4 * c + 2) * kMzTile + ee] = v.z;
+                    XS[(4 * c + 3) * kMzTile + ee] = v.w;
+                }
+                const int an = __shfl(act, 4 * n);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int a = q + 4 * j;
+                    if (a < A) XS[(kMzH + a) * kMzTile + n] = (live_n && an == a) ? 1.0f : 0.0f;
+                }
             }
             mz_touch_done(touch_sink);
             MZ_TICK(1);
@@ -995,7 +1094,15 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
         __syncthreads();
         MZ_TICK(2);
         // S1: h1 = relu(dyn1 [x, onehot(a)])
-        {
+        if constexpr (F16) {
+            const mz_f32x4 acc = mfma16(f1, XS16, mz_f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+            const float4 wa = *reinterpret_cast<const float4 *>(W1A + Gact[n] * kMzH + 16 * w + 4 * q);   // the one-hot action's row of weights
+            const float col[4] = {wa.x, wa.y, wa.z, wa.w};
+            float z[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[i] = fmaxf(fmaf(acc[i], d1, col[i] + b1[i]), 0.0f) * s1;
+            store16(HP16, z);
+        } else {
             const mz_f32x4 acc = mz_tile(a1, XS, q, n, b1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) HP[(16 * w + 4 * q + i) * kMzTile + n] = fmaxf(acc[i], 0.0f);
@@ -1007,11 +1114,21 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
         mz_f32x4 t = b2;
         {
             mz_f32x4 r = br;
+            if constexpr (F16) {
+                t = mfma16(f2, HP16, mz_f32x4{0.0f, 0.0f, 0.0f, 0.0f});
+                r = mfma16(fr, HP16, mz_f32x4{0.0f, 0.0f, 0.0f, 0.0f});
 #pragma unroll
-            for (int s = 0; s < kMzH / 4; ++s) {
-                const float x = HP[(4 * s + q) * kMzTile + n];
-                t = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s], x, t, 0, 0, 0);
-                r = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[s], x, r, 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    t[i] = fmaf(t[i], d2, b2[i]);
+                    r[i] = fmaf(r[i], dr, br[i]);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < kMzH / 4; ++s) {
+                    const float x = HP[(4 * s + q) * kMzTile + n];
+                    t = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[s], x, t, 0, 0, 0);
+                    r = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[s], x, r, 0, 0, 0);
+                }
             }
             wave_extremes(t);
 #pragma unroll
@@ -1413,6 +1530,8 @@ int rz_mz_load_model(rz_muzero *e, const float *const *h_params, int32_t n_param
         off[i] = total;
         total += (sizes[i] + 3) / 4 * 4;
     }
+    const size_t off_scales = total;
+    total += 8;
     std::vector<float> host(total, 0.0f);
     auto transpose = [&](int idx, int n_out, int n_in) {
         for (int o = 0; o < n_out; ++o)
@@ -1424,6 +1543,40 @@ int rz_mz_load_model(rz_muzero *e, const float *const *h_params, int32_t n_param
     transpose(8, kMzH, kMzH);
     for (int i : {1, 3, 5, 6, 7, 9, 10, 11, 12, 13})
         for (size_t q = 0; q < sizes[i]; ++q) host[off[i] + q] = h_params[i][q];
+    {   // the f16 layers of whole MOVES (MzModel::f16_scales)
+        auto pow2_for = [](float wmax) {
+            int ex = 0;
+            if (wmax > 0.0f && std::isfinite(wmax)) {
+                (void)std::frexp(wmax, &ex);
+                ex = 14 - ex;   // wmax * 2^ex in [2^13, 2^14)
+            }
+            return std::ldexp(1.0f, ex);
+        };
+        auto wmax_of = [&](int idx, int n_in) {   // torch layout [out][in], the first 64 input columns
+            float m = 0.0f;
+            for (int o = 0; o < kMzH; ++o)
+                for (int k = 0; k < kMzH; ++k) m = std::fmax(m, std::fabs(h_params[idx][(size_t)o * n_in + k]));
+            return m;
+        };
+        host[off_scales + 0] = pow2_for(wmax_of(0, KX));
+        host[off_scales + 1] = pow2_for(wmax_of(2, kMzH));
+        host[off_scales + 2] = pow2_for(wmax_of(4, kMzH));
+        host[off_scales + 3] = pow2_for(wmax_of(8, kMzH));
+        double bound = 0.0;   // relu(dyn1 [state in [0, 1], one-hot action]) <= |bias| + the positive state weights + the largest action weight
+        for (int o = 0; o < kMzH; ++o) {
+            double acc = std::fabs((double)h_params[1][o]), amax = 0.0;
+            for (int k = 0; k < kMzH; ++k) acc += std::fmax(0.0, (double)h_params[0][(size_t)o * KX + k]);
+            for (int a = 0; a < A; ++a) amax = std::fmax(amax, (double)h_params[0][(size_t)o * KX + kMzH + a]);
+            bound = std::fmax(bound, acc + amax);
+        }
+        float s1 = 16.0f;
+        if (!(bound * 16.0 < 60000.0)) {
+            int ex = 0;
+            (void)std::frexp(60000.0 / (std::isfinite(bound) && bound > 0.0 ? bound : 1e30), &ex);
+            s1 = std::ldexp(1.0f, ex - 1);
+        }
+        host[off_scales + 4] = s1;
+    }
     if (hipDeviceSynchronize() != hipSuccess) return mz_fail(RZ_ERR_HIP, "hipDeviceSynchronize failed");
     if (e->d_model == nullptr) {
         if (hipMalloc((void **)&e->d_model, total * sizeof(float)) != hipSuccess) return mz_fail(RZ_ERR_OOM, "hipMalloc failed (muzero model)");
@@ -1442,7 +1595,7 @@ int rz_mz_load_model(rz_muzero *e, const float *const *h_params, int32_t n_param
     const MzModel seen = e->model;   // (the representation layers are loaded by their own call)
     e->model = MzModel{b + off[0], b + off[1], b + off[2], b + off[3], b + off[4], b + off[5], b + off[6], b + off[7],
                        b + off[8], b + off[9], b + off[10], b + off[11], b + off[12], b + off[13],
-                       seen.rep1_w, seen.rep1_b, seen.rep2_w, seen.rep2_b};
+                       seen.rep1_w, seen.rep1_b, seen.rep2_w, seen.rep2_b, b + off_scales};
     e->model_loaded = true;
     return RZ_OK;
 }

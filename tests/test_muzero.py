@@ -593,3 +593,38 @@ def test_muzero_selfplay_and_learner_smoke():
         first = first if first is not None else loss
     assert loss < first  # the model fits its own replay data
     sp.close()
+
+
+@pytest.mark.gpu
+def test_whole_moves_network_on_the_f16_pipe_agrees_with_the_f32_search():
+    """Whole MOVES run the four 64 x 64 layers of a simulation on the f16 matrix pipe (hi + lo operand pairs, hidden states
+    kept as f16 pieces); the search of a move launched from the host runs them on the f32-input MFMA.  From the same
+    observations, without root noise, both must arrive at the same search: root values within 1e-4, visit counts equal in
+    (nearly) every environment (a 1e-7 difference of a network output may flip a tie); also on weights 20x the initial scale."""
+    import torch
+    from rlzero_amd.muzero import CartPoleBatch, MuZeroNet, MuZeroSelfPlay
+    for gain in (1.0, 20.0):
+        torch.manual_seed(7)
+        net = MuZeroNet().to('cuda:0').eval()
+        with torch.no_grad():
+            for name, p_ in net.named_parameters():
+                if gain != 1.0 and name.split('.')[0] in ('dyn1', 'pre1') and name.endswith('weight'):
+                    p_.mul_(gain)
+        G = 200
+        out = {}
+        for moves in (True, False):
+            sp = MuZeroSelfPlay(net, CartPoleBatch(G, 'cuda:0', seed=3), n_sims=50, seed=9, temperature=0.0,
+                                root_exploration_fraction=0.0, fused=True, fused_moves=moves, moves_per_launch=1)
+            sp.collect(1)
+            if moves:
+                ring, _ = sp.device_history()
+                r = ring[:, 0]
+                out[moves] = (r[:, 6:8].astype(np.int64), r[:, 8].copy(), r[:, 4].astype(np.int64))
+            else:
+                out[moves] = (np.round(sp._h_pol[0] * 50).astype(np.int64), sp._h_val[0].copy(), sp._h_act[0].copy())
+            sp.tree.check()
+            sp.close()
+        same = (out[True][0] == out[False][0]).all(axis=1)
+        assert same.mean() >= 0.97, (gain, float(same.mean()))
+        assert np.max(np.abs(out[True][1][same] - out[False][1][same])) <= 1e-4, gain
+        assert (out[True][2][same] == out[False][2][same]).all()

@@ -776,7 +776,7 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
         return acc;
     };
     // (F16) the lane's 4 values (units 16 w + 4 q + i of game n), already scaled, as hi + lo pieces into the games' records
-    auto store16 = [&](unsigned char *rec, const float (&z)[4]) {
+    auto store16 = [&](unsigned char *rec, const float (&z)[4], mz_f16x4 *hi_out = nullptr, mz_f16x4 *lo_out = nullptr) {
         mz_f16x4 hi, lo;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -786,6 +786,10 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
         unsigned char *p = rec + n * kRec + (16 * w + 4 * q) * 2;
         *reinterpret_cast<mz_f16x4 *>(p) = hi;
         *reinterpret_cast<mz_f16x4 *>(p + 128) = lo;
+        if (hi_out) {
+            *hi_out = hi;
+            *lo_out = lo;
+        }
     };
     unsigned char *XS16 = reinterpret_cast<unsigned char *>(XS), *HP16 = reinterpret_cast<unsigned char *>(HP);
     mz_f32x4 b1, b2, br, bp;   // biases in the C/D layout: rows 16w + 4q + i
@@ -882,18 +886,26 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
         }
         const float inv = fmaxf(mx - mn, 1e-5f);
         float4 sv;
-        sv.x = (t[0] - mn) / inv;
-        sv.y = (t[1] - mn) / inv;
-        sv.z = (t[2] - mn) / inv;
-        sv.w = (t[3] - mn) / inv;
+        if constexpr (F16) {   // one division per game and lane instead of four (1 ulp from x / inv: the pieces carry 1e-7 anyway)
+            const float rinv = 1.0f / inv;
+            sv.x = (t[0] - mn) * rinv;
+            sv.y = (t[1] - mn) * rinv;
+            sv.z = (t[2] - mn) * rinv;
+            sv.w = (t[3] - mn) * rinv;
+        } else {
+            sv.x = (t[0] - mn) / inv;
+            sv.y = (t[1] - mn) / inv;
+            sv.z = (t[2] - mn) / inv;
+            sv.w = (t[3] - mn) / inv;
+        }
         if constexpr (F16) {
             const float z[4] = {sv.x * 16.0f, sv.y * 16.0f, sv.z * 16.0f, sv.w * 16.0f};
-            store16(XS16, z);
+            mz_f16x4 hi, lo;
+            store16(XS16, z, &hi, &lo);
             if (live_n) {   // the same 256 bytes as the game's hidden-state slot
-                const unsigned char *src = XS16 + n * kRec + (16 * w + 4 * q) * 2;
                 unsigned char *dst = reinterpret_cast<unsigned char *>(hidden + ((long long)(g0 + n) * E.cap + Gleaf[n]) * kMzH) + (16 * w + 4 * q) * 2;
-                *reinterpret_cast<mz_f16x4 *>(dst) = *reinterpret_cast<const mz_f16x4 *>(src);
-                *reinterpret_cast<mz_f16x4 *>(dst + 128) = *reinterpret_cast<const mz_f16x4 *>(src + 128);
+                *reinterpret_cast<mz_f16x4 *>(dst) = hi;
+                *reinterpret_cast<mz_f16x4 *>(dst + 128) = lo;
             }
         } else {
             XS[(16 * w + 4 * q + 0) * kMzTile + n] = sv.x;

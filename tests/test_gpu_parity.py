@@ -1227,6 +1227,84 @@ def test_rollout_player_game_through_reference_api():
     assert results[0] == results[1]
 
 
+def test_batched_evaluation_equals_single_games(monkeypatch):
+    """rlzero_amd.evaluate.BatchedEvaluation (policy_evaluate's games in lock-step, tools/train_alphazero.py:139-162): every game equals
+    GameControl.start_play(AlphaZeroPlayer, RolloutPlayer) (game.py:61-94) played alone with the same draws -- the network player's
+    two np.random.choice calls per move (alphazero_mcts.py:148,157) fed the batch's uniforms, the pure-MCTS player's play-out seed set to
+    the batch's -- move for move, winner included; with the network seated second in some games both engines search at the same ply."""
+    import torch
+    from rlzero_amd.evaluate import BatchedEvaluation, rollout_seed
+    from rlzero_amd.games import GameControl, GomokuEnv
+    from rlzero_amd.games.gomoku.alphazero_agent import AlphaZeroAgent
+    from rlzero_amd.mcts import AlphaZeroPlayer
+    from rlzero_amd.mcts.rollout_mcts import RolloutPlayer
+    from rlzero_amd.selfplay import draw_move, move_uniform
+    B, n, seed, sims, pure_sims = 6, 4, 77, 40, 60
+    torch.manual_seed(3)
+    agent = AlphaZeroAgent(B, device='cuda:0')
+    seats = [True, True, False, True, False, False]
+    for use_graph in (False, True):
+        duel = BatchedEvaluation.for_network(agent.policy_value_net, B, n, n_games=len(seats), n_playout=sims,
+                                             rollout_playouts=pure_sims, seed=seed, use_graph=use_graph)
+        results = duel.run(net_first=seats)
+        again = duel.run(net_first=seats)  # the engines are reusable and the games reproducible
+        assert [(r.moves, r.winner) for r in again] == [(r.moves, r.winner) for r in results]
+        duel.close()
+        assert all(r.winner in (-1, 0, 1) and len(r.moves) >= 2 * n - 1 for r in results)
+        assert len({tuple(r.moves) for r in results}) > 1
+        if use_graph:
+            assert [(r.moves, r.winner) for r in results] == eager
+        eager = [(r.moves, r.winner) for r in results]
+    for g, net_first in enumerate(seats):
+        env = GomokuEnv(B, n)
+        calls = {}
+
+        def choice(acts, p=None, g=g, env=env, calls=calls):
+            ply = len(env.states)
+            k = calls[ply] = calls.get(ply, -1) + 1   # 0: the draw that is dropped, 1: the one that is played
+            return draw_move(acts, p, float(move_uniform(seed, g, 2 * ply + k)))
+
+        monkeypatch.setattr(np.random, 'choice', choice)
+        az = AlphaZeroPlayer(agent.policy_value_fn, n_playout=sims, c_puct=5)
+        pure = RolloutPlayer(n_playout=pure_sims, c_puct=5)
+        plain_get_action = pure.get_action
+
+        def seeded(game_env, pure=pure, g=g, plain=plain_get_action, **kw):
+            pure.mcts.seed = rollout_seed(seed, len(game_env.states)) ^ g
+            return plain(game_env, **kw)
+
+        pure.get_action = seeded
+        winner = GameControl(env).start_play(az, pure, is_shown=0) if net_first else \
+            GameControl(env).start_play(pure, az, is_shown=0)
+        assert (list(env.states.keys()), winner) == (results[g].moves, results[g].winner), g
+        assert sorted(calls.values()) == [1] * len(calls)   # two draws at every network ply
+        assert results[g].net_won == (winner == (0 if net_first else 1))
+        az.mcts._engine.close()
+        pure.mcts._engine.close()
+
+
+def test_batched_evaluation_connect4():
+    """The same duel on Connect4 (actions = columns, the stone drops): every game replays on the rules twin to the winner the engines
+    report, and ends."""
+    import torch
+    from rlzero_amd.evaluate import BatchedEvaluation
+    from rlzero_amd.games.connect4.connect4_env import Connect4Env
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    torch.manual_seed(5)
+    net = PolicyValueNet(6, 7, 7).to('cuda:0')
+    duel = BatchedEvaluation.for_network(net, (6, 7), 4, n_games=8, n_playout=50, rollout_playouts=80, seed=9, game='connect4',
+                                         net_shape=(6, 7, 7))
+    results = duel.run(net_first=[i % 2 == 0 for i in range(8)])
+    duel.close()
+    for r in results:
+        env = Connect4Env(6, 7, 4)
+        for i, m in enumerate(r.moves):
+            assert not env.game_end_winner()[0] and m in env.leagel_actions()
+            env.step(m)
+        end, winner = env.game_end_winner()
+        assert end and winner == r.winner
+
+
 # ------------------------------------------------------------------ opt-in PUCT mode, noise
 def _skewed(env):
     """Evaluator with non-uniform float32 priors (exactly the numbers the engine stores) and the

@@ -186,3 +186,9 @@ def test_train_pipeline_runs_on_gpu(tmp_path, capsys, monkeypatch):
     assert state.shape == (4, 6, 6) and prob.shape == (36, ) and z in (-1.0, 0.0, 1.0)
     assert len(pipe2.data_buffer) >= 8 * 8 * 7
     pipe2.policy_update()
+    # ... and its evaluation games run in lock-step too (rlzero_amd.evaluate), reported with the reference's line
+    pipe2.pure_mcts_playout_num = 20
+    capsys.readouterr()
+    ratio = pipe2.policy_evaluate(4)
+    assert 0.0 <= ratio <= 1.0 and 'num_playouts:20, win:' in capsys.readouterr().out
+    assert pipe2._duel.n_slots == 4 and pipe2._duel.rollout_playouts == 20

@@ -8,7 +8,8 @@ Two ways to collect self-play data:
   * ``selfplay_games_in_flight == 0`` (default): the reference's flow -- one game at a time
     through ``GameControl.start_self_play`` and ``AlphaZeroPlayer`` (search on the GPU);
   * ``selfplay_games_in_flight  > 0``: that many games in lock-step per collection round and GPU
-    (``rlzero_amd.selfplay.BatchedSelfPlay``), the mode the hardware is built for.
+    (``rlzero_amd.selfplay.BatchedSelfPlay``), the mode the hardware is built for; ``policy_evaluate``'s games then
+    run in lock-step as well (``rlzero_amd.evaluate.BatchedEvaluation``).
 
 Several GPUs (``python tools/train_alphazero.py --gpus N ...`` starts one process per GPU itself, or run it under
 ``torch.distributed.run``): the games of a collection round are dealt to the ranks by id (game g -> rank g mod N, no
@@ -98,6 +99,7 @@ class TrainPipeline:
         self.mcts_player = AlphaZeroPlayer(self.alphazero_agent.policy_value_fn, n_playout=self.n_playout,
                                            c_puct=self.c_puct, is_selfplay=True)
         self._batched = None
+        self._duel, self._duel_key, self._evaluations = None, None, 0
         self._next_game_id = 0
         self.selfplay_seed = self._agree_on(random.getrandbits(31) if seed is None else int(seed))
         if self.world > 1:   # every rank starts from rank 0's weights
@@ -220,8 +222,34 @@ class TrainPipeline:
                                                   explained_var_new))
         return loss, entropy
 
+    def _evaluate_batched(self, n_games):
+        """The ``n_games`` evaluation games in lock-step on this GPU (rlzero_amd.evaluate.BatchedEvaluation: per game what
+        start_play does with the two players below) -> their winner ids."""
+        from rlzero.algorithms import BatchedEvaluation
+        key = (n_games, self.pure_mcts_playout_num)
+        if self._duel is None or self._duel_key != key:
+            if self._duel is not None:
+                self._duel.close()
+            self._duel = BatchedEvaluation.for_network(
+                self.alphazero_agent.policy_value_net, self.board_size, self.n_in_row, n_games=n_games,
+                n_playout=self.n_playout, rollout_playouts=self.pure_mcts_playout_num, c_puct=self.c_puct, rollout_c_puct=5,
+                device=str(self.device), seed=self.selfplay_seed)
+            self._duel_key = key
+        self._duel.refresh_weights()
+        self._duel.seed = (self.selfplay_seed + 0x9E37 * self._evaluations) & 0x7fffffff   # fresh draws every evaluation
+        self._evaluations += 1
+        return [r.winner for r in self._duel.run()]
+
     def policy_evaluate(self, n_games=10):
         """Play the current policy against the pure-MCTS opponent (monitoring only)."""
+        if self.selfplay_games_in_flight > 0:
+            win_cnt = defaultdict(int)
+            for winner in self._evaluate_batched(n_games):
+                win_cnt[winner] += 1
+            win_ratio = 1.0 * (win_cnt[1] + 0.5 * win_cnt[-1]) / n_games
+            print('num_playouts:{}, win: {}, lose: {}, tie:{}'.format(self.pure_mcts_playout_num, win_cnt[1],
+                                                                      win_cnt[2], win_cnt[-1]))
+            return win_ratio
         current_mcts_player = AlphaZeroPlayer(self.alphazero_agent.policy_value_fn, n_playout=self.n_playout,
                                               c_puct=self.c_puct)
         pure_mcts_player = RolloutPlayer(n_playout=self.pure_mcts_playout_num, c_puct=5)

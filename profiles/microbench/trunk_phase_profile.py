@@ -3,7 +3,7 @@ this file.  k_trunk_rows: 'stores' = barrier + the four waves' shares summed + f
 import ctypes, os, sys
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
 import rlzero_amd._hip as H
-H.library_path = lambda: os.path.join(os.path.dirname(os.path.abspath(__file__)), 'librlzero_netprof.so')
+H.library_path = lambda: os.environ.get('RZ_NETPROF_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'librlzero_netprof.so')
 import numpy as np, torch
 from rlzero_amd.engine import HipNet
 from oracle.evaluators import numpy_weights
@@ -37,9 +37,21 @@ for B, boards, algo in CASES:
         else:
             H.check(lib.rz_net_trunk_leaves(net.handle, d_stones.data_ptr(), d_tm.data_ptr(), d_last.data_ptr(), boards, None), 'trunk_leaves')
     torch.cuda.synchronize()
+    # wall time per launch of the same (instrumented) kernel -> the shader clock it ran at = cycles / time
+    reps = 200
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(reps):
+        if planes_route:
+            net.trunk_internal(x)
+        else:
+            H.check(lib.rz_net_trunk_leaves(net.handle, d_stones.data_ptr(), d_tm.data_ptr(), d_last.data_ptr(), boards, None), 'trunk_leaves')
+    t1.record()
+    torch.cuda.synchronize()
+    us = t0.elapsed_time(t1) * 1e3 / reps
     out = (ctypes.c_longlong * 16)()
     lib.rz_net_debug_profile(out)
     v = list(out)
     per = max(1, (boards + 255) // 256)
-    print('board %s %s, %d boards (%d per workgroup): kernel %d cycles; per board: ' % (str(B), algo, boards, per, v[10]) +
+    print('board %s %s, %d boards (%d per workgroup): kernel %d cycles in %.1f us back to back = %.2f GHz; per board: ' % (str(B), algo, boards, per, v[10], us, v[10] / us / 1e3) +
           '  '.join('%s=%d' % (n, x / per) for n, x in zip(names[:9], v[:9])) + '  | prologue=%d (issue loads %d, zero %d, barrier %d, stores %d, barrier %d)' % (v[9], v[11], v[12], v[13], v[14], v[15]))

@@ -17,9 +17,9 @@ mask), on its own HIP stream, and both apply every move.  The reference seats th
 caller seat it second in some games, in which case the two engines search their halves of the batch at the same time.
 
 Randomness: the two draws of a network move use uniforms keyed (seed, game, 2 ply) and (seed, game, 2 ply + 1) (selfplay.move_uniform);
-the play-outs of a pure-MCTS move use the device generator keyed (rollout_seed(seed, ply) ^ game, simulation, play-out ply), which is
-what a single-game ``RolloutPlayer`` whose ``mcts.seed`` is ``rollout_seed(seed, ply) ^ game`` uses: a batched game equals the
-single-game route move for move (tests/test_gpu_parity.py::test_batched_evaluation_equals_single_games).
+the play-outs of a pure-MCTS move use the device generator keyed (rollout_seed(seed, ply) ^ slot, simulation, play-out ply) -- slot =
+the game's position in ``run(game_ids)``, the game id itself by default --, which is what a single-game ``RolloutPlayer`` whose
+``mcts.seed`` is ``rollout_seed(seed, ply) ^ slot`` uses: a batched game equals the single-game route move for move (tests/test_gpu_parity.py::test_batched_evaluation_equals_single_games).
 """
 import numpy as np
 
@@ -174,10 +174,14 @@ class BatchedEvaluation(object):
                 moves_of[s].append(int(chosen[s]))
             # -- fresh roots for the searched trees (both players reset after every move), the move on both engines' boards
             step_moves = chosen.astype(np.int32)
+            verdicts = []
             for eng, stream, turn in ((self.net_eng, self.net_stream, net_turn), (self.ro_eng, self.ro_stream, ro_turn)):
                 with torch.cuda.stream(stream):
                     eng.advance(np.where(turn, -1, -2).astype(np.int32))
-                    winner, ended = eng.step(step_moves)
+                    verdicts.append(eng.step(step_moves))
+            (winner, ended), (winner_b, ended_b) = verdicts
+            if not (np.array_equal(winner[rows], winner_b[rows]) and np.array_equal(ended[rows], ended_b[rows])):
+                raise RuntimeError('the two engines disagree about a board')   # (they are stepped with the same moves)
             for s in rows:
                 if ended[s]:
                     winner_of[s] = winner[s]

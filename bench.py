@@ -8,8 +8,8 @@ random-init PolicyValueNet (torch.manual_seed(0)), f32 network / f64 tree.
 
 A "step" is one move of every game on the GPU: n_playout simulation steps (select -> evaluate -> expand / backup for all
 games), pi from the root visits, a move drawn and applied, tree reuse; finished games are replaced so the batch stays
-full.  The 512 games of a GPU run as two lanes of 256 (separate streams: the tree / FC kernels of one lane run beside the
-network trunk of the other on the same CUs).  Games are independent: N GPUs play N x 512 games with no collective in the
+full.  The 512 games of a GPU run as four lanes of 128 (separate streams: the tree / FC kernels of one lane run beside the
+network trunks of the others on the same CUs; rlzero_amd.selfplay.plan_lanes).  Games are independent: N GPUs play N x 512 games with no collective in the
 timed region (weak scaling); rank 0 prints ONE JSON line.  `value` is the MEDIAN of --regions (3) timed regions of K steps
 each, every region bracketed by barrier + synchronize.
 
@@ -33,6 +33,10 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
+
+# four lanes of games need more than HIP's default of 4 hardware queues (rlzero_amd/__init__.py does the same on import; the
+# runtime reads the variable when it initialises, which is after this line in every process bench.py starts)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 BOARD, N_ROW, N_PLAYOUT, GAMES_PER_GPU, C_PUCT, TEMPERATURE = 15, 5, 800, 512, 5.0, 1.0
 RESERVED_CUS_PER_XCD, N_XCD = 4, 8  # --trunk-wgs 224: CUs a capped trunk leaves to the other lane's small kernels
@@ -251,7 +255,7 @@ CONFIG_LEGS = (  # (key, flags, seconds of CPU baseline at --cpu-seconds 60); a 
     ('C2_9x9_200sims_64games', ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 8, '--warmup', 8], 12.0),
     ('C2_16_in_flight', ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 8, '--warmup', 8, '--in-flight', 16,
                          '--no-cpu-baseline'], 0.0),
-    ('C3_connect4_400sims_512games', ['--game', 'connect4', '--playouts', 400, '--games', 512, '--lanes', 2, '--steps', 6, '--warmup', 6], 12.0),
+    ('C3_connect4_400sims_512games', ['--game', 'connect4', '--playouts', 400, '--games', 512, '--steps', 6, '--warmup', 6], 12.0),
     ('C4_puct_rule', ['--score-mode', 'puct', '--steps', 3, '--warmup', 2, '--no-cpu-baseline'], 0.0),
     ('C5_muzero_cartpole_50sims_8192envs', ['--game', 'muzero', '--playouts', 50, '--games', 8192, '--steps', 512, '--warmup', 48], 12.0),
 )
@@ -508,9 +512,9 @@ def main():
     ap.add_argument('--in-flight', type=int, default=1,
                     help='K > 1: opt-in virtual-loss mode, K simulations of every tree share one evaluator batch (NOT the '
                          'reference\'s sequential search: results differ from it; for batches too small to fill the GPU)')
-    ap.add_argument('--lanes', type=int, default=2,
-                    help='independent batches of games on separate HIP streams (the tree / FC kernels of one '
-                         'lane run beside the network trunk of the other)')
+    ap.add_argument('--lanes', type=int, default=0,
+                    help='independent batches of games on separate HIP streams (the tree / FC kernels of one lane run beside the '
+                         'network trunks of the others); 0 = what rlzero_amd.selfplay.plan_lanes picks for the batch (512 games: 4)')
     args = ap.parse_args()
     if args.cpu_worker is not None:
         cpu_worker(args.cpu_worker, args.game, args.board, args.playouts)
@@ -577,9 +581,13 @@ def main():
     if args.game == 'connect4':
         board, n_row, cells = (6, 7), 4, 42
     n_cus = torch.cuda.get_device_properties(local_rank).multi_processor_count
-    lanes = max(1, args.lanes)
+    if args.lanes > 0:
+        lanes = args.lanes
+    else:
+        from rlzero_amd.selfplay import plan_lanes
+        lanes = plan_lanes((args.games if args.games > 0 else GAMES_PER_GPU) * max(1, args.in_flight), n_cus)[0]
     trunk_wgs = max(0, args.trunk_wgs)
-    # default batch: the 512 games per GPU of BASELINE.json configs[3] (4096 games over 8 GPUs), as two lanes of 256
+    # default batch: the 512 games per GPU of BASELINE.json configs[3] (4096 games over 8 GPUs), as four lanes of 128
     G = args.games if args.games > 0 else GAMES_PER_GPU
     heads_algo = args.heads_algo
     if heads_algo == 'auto' and lanes > 1 and trunk_wgs == 0 and args.evaluator == 'hipnet' and args.net_algo.startswith('split_f16'):
@@ -842,10 +850,13 @@ def main():
                   'achieved': round(achieved, 3), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                   'traffic': pmc_traffic('k_trunk', pmc_key),
                   'avg_launch_ms': round(ms, 4), 'avg_launch_ms_per_stream': round(per_stream_ms, 4), 'launches_timed': n_ev,
+                  # trunk launches of different lanes share the CUs: how many are in flight on average (a launch's own interval
+                  # between its events / the wall-clock per launch); rocprofv3's per-dispatch duration is the former
+                  'launches_in_flight': round(per_stream_ms / ms, 2) if lanes > 1 else 1.0,
                   'mfma_executed_frac': round(achieved / pipe_peak * executed_flop_ratio(args, cells), 4),
                   'trunk_workgroups': trunk_wgs if trunk_wgs > 0 else n_cus}
             line['roofline'] = rf
-            if exclusive_ms:
+            if exclusive_ms and boards_per_launch >= n_cus:   # (a launch of fewer boards than CUs cannot fill the chip by itself)
                 ex = flops / (exclusive_ms * 1e-3) / 1e12
                 rf['exclusive_launch_ms'] = round(exclusive_ms, 4)
                 rf['exclusive_frac'] = round(ex / peak, 4)

@@ -26,7 +26,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_1lane"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_puct" -o s -- $B --graph 0 --steps 2 --score-mode puct > "$OUT/bench_eager_puct_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_puct_1lane" -o s -- $B --graph 0 --steps 2 --score-mode puct --lanes 1 > "$OUT/bench_eager_puct_1lane_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_c2" -o s -- $B --graph 0 --steps 4 --board 9 --playouts 200 --games 64 --lanes 1 > "$OUT/bench_eager_c2_under_rocprof.json" 2> /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_c3" -o s -- $B --graph 0 --steps 2 --game connect4 --playouts 400 --games 512 --lanes 2 > "$OUT/bench_eager_c3_under_rocprof.json" 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_c3" -o s -- $B --graph 0 --steps 2 --game connect4 --playouts 400 --games 512 > "$OUT/bench_eager_c3_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_muzero" -o s -- $B --game muzero --playouts 50 --games 8192 --steps 64 --warmup 16 > "$OUT/bench_muzero_under_rocprof.json" 2> /dev/null
 echo "kernel stats done"
 
@@ -43,7 +43,7 @@ pmc fill --games 1536
 pmc puct --score-mode puct
 pmc c2 --board 9 --playouts 200 --games 64 --lanes 1
 pmc c2k16 --board 9 --playouts 200 --games 64 --lanes 1 --in-flight 16
-pmc c3 --game connect4 --playouts 400 --games 512 --lanes 2
+pmc c3 --game connect4 --playouts 400 --games 512
 pmc c1 --board 3 --playouts 25 --games 1 --lanes 1 --steps 8
 pmc c1x16 --board 3 --playouts 25 --games 16 --lanes 1 --steps 8
 for c in FETCH_SIZE WRITE_SIZE; do

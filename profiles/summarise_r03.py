@@ -41,6 +41,31 @@ def main(out):
         found = glob.glob(os.path.join(d, '**', '*kernel_stats.csv'), recursive=True)
         if found:
             shutil.copy(found[0], os.path.join(keep, 'bench_%s_kernel_stats.csv' % os.path.basename(d)[6:]))
+    # how the trunk dispatches of the lanes overlap in the headline run (hipGraph replays): with four lanes two dispatches of 128
+    # boards share the CUs, so the chip-level rate is boards / (wall covered by >= 1 dispatch), not boards / a dispatch's duration
+    for tag in ('default', 'fill'):
+        found = glob.glob(os.path.join(out, 'stats_%s' % tag, '**', '*kernel_trace.csv'), recursive=True)
+        if not found:
+            continue
+        spans = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp'])) for r in csv.DictReader(open(found[0]))
+                       if 'k_trunk' in r['Kernel_Name'])
+        if len(spans) < 100:
+            continue
+        spans = spans[len(spans) // 4:]   # (skip the warm-up)
+        covered, cur_a, cur_b = 0, spans[0][0], spans[0][1]
+        for a, b in spans[1:]:
+            if a > cur_b:
+                covered += cur_b - cur_a
+                cur_a, cur_b = a, b
+            else:
+                cur_b = max(cur_b, b)
+        covered += cur_b - cur_a
+        total = sum(b - a for a, b in spans)
+        json.dump({'kernel': 'k_trunk_*', 'dispatches': len(spans), 'mean_dispatch_us': round(total / len(spans) / 1e3, 3),
+                   'covered_by_a_dispatch_us_per_dispatch': round(covered / len(spans) / 1e3, 3),
+                   'dispatches_in_flight': round(total / covered, 3),
+                   'span_us_per_dispatch': round((spans[-1][1] - spans[0][0]) / len(spans) / 1e3, 3)},
+                  open(os.path.join(keep, 'trunk_overlap_%s.json' % tag), 'w'), indent=1)
     traffic = {}
     for line_file in sorted(glob.glob(os.path.join(out, 'pmc_*.json'))):
         tag = os.path.basename(line_file)[4:-5]

@@ -130,30 +130,37 @@ class Trajectory(object):
         return self.winner, list(zip(self.states(), list(self.pis), self.z()))
 
 
-RESERVED_CUS_PER_XCD, N_XCD = 4, 8  # CUs a lane's trunk leaves to the other lane's tree / FC kernels
 BOARDS_PER_WORKGROUP = 3  # boards a persistent trunk workgroup takes per step at the tuned batch (bench.py default)
 
 
-def plan_lanes(n_games, n_cus=256):
-    """-> (lanes, trunk_workgroups, heads_algo) for ``n_games`` leaves per simulation step on a GPU with ``n_cus`` CUs
-    (measured on MI355X, profiles/r02/lane_sweeps.txt; a trunk round = one board per workgroup, ~27-30 us at 15x15).
+def plan_lanes(n_games, n_cus=256, hw_queues=None):
+    """-> (lanes, trunk_workgroups, heads_algo) for ``n_games`` leaves per simulation step on a GPU with ``n_cus`` CUs and
+    ``hw_queues`` hardware queues for its streams (default: what rlzero_amd claimed on import, rlzero_amd.HW_QUEUES).  Measured on
+    MI355X at 15x15 (profiles/r03/lane_sweeps.txt; a trunk workgroup takes a board in ~23 us, three in ~65 us):
 
-    * up to one round (n_games <= CUs): ONE lane, nothing to overlap with;
-    * a lane's half of the batch fits one round of CUs - 32 workgroups: TWO lanes, each trunk capped at CUs - 32
-      persistent workgroups (4 CUs per XCD stay free): the FC GEMM and the tree step of one lane run at full speed on the
-      free CUs under the other lane's trunk, and the cap costs the trunk nothing;
-    * anything larger (e.g. the 512 games per GPU of BASELINE.json configs[3], or 1536 = 2 lanes x 3 boards x 256
-      workgroups): TWO lanes with UN-capped trunks and the LDS-free 'parts' FC GEMM, whose single-wave workgroups --
-      like the tree step's -- fit on a CU beside a resident trunk workgroup (344 of 512 registers, 151 of 160 KB LDS):
-      the small kernels of one lane run UNDER the other lane's trunk on the same CUs (rocprof: tree step 13.5 us
-      there against 11.2 alone, GEMM 4.6 us) and all CUs compute the trunk: 8.2 M sims/s against 6.8 M on one lane at 512
-      games (15x15), +2-3 % over capped lanes at 1344-1536.
-    0 workgroups means "one per CU" (no cap)."""
-    capped = n_cus - RESERVED_CUS_PER_XCD * N_XCD
-    if capped <= 0 or n_games <= n_cus:
+    * up to one round of boards (n_games <= CUs): ONE lane -- the step is a chain of three latency-bound launches, and splitting it
+      shortens none of them (128 / 192 / 256 games: 3.4 / 4.9 / 6.3 M with one lane, 3-8 % less with two to four);
+    * more: lanes with UN-capped trunks and the LDS-free 'parts' FC GEMM, whose single-wave workgroups -- like the tree step's -- fit
+      on a CU beside a resident trunk workgroup (the trunk holds 151 of 160 KB LDS and at most 400 of 512 registers): the small kernels
+      of a lane run UNDER the other lanes' trunks on the same CUs.  With TWO lanes a lane's tree step + FC GEMM (15 us + two kernel
+      boundaries) must end before the other lane's trunk does (23 us at one board per workgroup), or the CUs wait: on most boxes they
+      do (512 games: 8.0-8.9 M, on the best box 10.3 M).  FOUR lanes of a quarter of the games keep two lanes' trunk workgroups queued
+      on the CUs at all times and the chip never waits for a lane's chain: 9.8-10.3 M on every box -- from ~1.75 to ~2.75 rounds of
+      boards (448 .. 704 games), and only with 8 hardware queues (with HIP's default of 4 the fourth lane shares a queue and the lanes
+      serialise: 6.1 M; five lanes and more collapse the same way even with 16);
+    * THREE lanes between one and 1.75 rounds (320 / 384 games: +4 % / +1 % over two) and wherever four would need more queues;
+    * beyond ~2.75 rounds TWO lanes: a trunk launch then runs two or three boards per workgroup (44 / 65 us) and hides a lane's chain
+      by itself (768 / 1024 / 1536 games: 10.1 / 11.3 / 11.4 M with two lanes, 9.5 / 9.1 / 10.2 with four).
+    ``trunk_workgroups`` is 0 = one per CU (capped trunks, 4 CUs per XCD left to the small kernels, lost 15-19 % against un-capped
+    ones once the 'parts' GEMM existed)."""
+    if hw_queues is None:
+        from . import HW_QUEUES as hw_queues
+    if n_games <= n_cus:
         return 1, 0, 'auto'
-    if (n_games + 1) // 2 <= capped:
-        return 2, capped, 'auto'
+    if 4 * n_games < 7 * n_cus:
+        return 3, 0, 'parts'
+    if 4 * n_games <= 11 * n_cus:
+        return (4 if hw_queues >= 8 else 3), 0, 'parts'
     return 2, 0, 'parts'
 
 

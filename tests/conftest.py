@@ -13,6 +13,10 @@ if REPO not in sys.path:
 
 GOLDEN = os.path.join(HERE, 'golden')
 
+# rlzero_amd claims 8 hardware queues on import (four lanes of games: rlzero_amd/__init__.py); the collection hook below asks
+# torch for the GPU -- which starts the runtime -- before any test imports the package, so the variable is set here
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')

@@ -110,14 +110,29 @@ def test_game_control_two_players():
 
 
 def test_plan_lanes():
-    """One lane while the trunk fits a board round or two lanes would need an extra round; two capped lanes
-    (4 CUs per XCD left to the other lane's small kernels) otherwise."""
+    """One lane up to a round of boards (one per CU); beyond, lanes with un-capped trunks and the LDS-free FC GEMM: three up to 1.75
+    rounds, four up to 2.75 rounds where 8 hardware queues carry them (three where only HIP's default 4 do), two beyond."""
     from rlzero_amd.selfplay import plan_lanes
     assert plan_lanes(1) == (1, 0, 'auto') and plan_lanes(256) == (1, 0, 'auto')
-    assert plan_lanes(448) == (2, 224, 'auto')  # one round of a capped trunk per lane
-    # larger: un-capped trunks on all CUs, the small kernels of one lane co-resident with the other lane's trunk
-    assert plan_lanes(512) == (2, 0, 'parts') and plan_lanes(1344) == (2, 0, 'parts') and plan_lanes(1536) == (2, 0, 'parts')
-    assert plan_lanes(100, n_cus=32) == (1, 0, 'auto')  # nothing left to reserve
+    assert plan_lanes(320, hw_queues=8) == (3, 0, 'parts') and plan_lanes(447, hw_queues=8) == (3, 0, 'parts')
+    # the 512 games per GPU of BASELINE.json configs[3]
+    assert plan_lanes(448, hw_queues=8) == (4, 0, 'parts') and plan_lanes(512, hw_queues=8) == (4, 0, 'parts')
+    assert plan_lanes(704, hw_queues=8) == (4, 0, 'parts') and plan_lanes(512, hw_queues=16) == (4, 0, 'parts')
+    assert plan_lanes(512, hw_queues=4) == (3, 0, 'parts')   # a fourth stream would share a hardware queue
+    assert plan_lanes(768, hw_queues=8) == (2, 0, 'parts') and plan_lanes(1536, hw_queues=8) == (2, 0, 'parts')
+    assert plan_lanes(100, n_cus=32, hw_queues=8) == (2, 0, 'parts')
+
+
+def test_hw_queues_are_claimed_on_import():
+    """rlzero_amd sets GPU_MAX_HW_QUEUES before the HIP runtime starts (unless the caller chose a value) and remembers what holds."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); import rlzero_amd; "
+            "print(os.environ.get('GPU_MAX_HW_QUEUES'), rlzero_amd.HW_QUEUES)" % REPO)
+    env = {k: v for k, v in os.environ.items() if k != 'GPU_MAX_HW_QUEUES'}
+    assert subprocess.check_output([sys.executable, '-c', code], env=env).decode().split() == ['8', '8']
+    env['GPU_MAX_HW_QUEUES'] = '4'
+    assert subprocess.check_output([sys.executable, '-c', code], env=env).decode().split() == ['4', '4']
 
 
 def test_batched_pi_and_moves_bit_identical_to_per_game_expressions():

@@ -160,7 +160,7 @@ class TrainPipeline:
         """The trajectories of ``game_ids`` (this rank's share of a round), games in lock-step on this rank's GPU."""
         from rlzero.algorithms import BatchedSelfPlay
         if self._batched is None:
-            # one or two lanes of games, whichever fills the GPU better (selfplay.plan_lanes)
+            # one to four lanes of games, whichever fills the GPU better (selfplay.plan_lanes)
             self._batched = BatchedSelfPlay.for_network(
                 self.alphazero_agent.policy_value_net, self.board_size, self.n_in_row,
                 n_games=self.selfplay_games_in_flight, n_playout=self.n_playout, c_puct=self.c_puct,

@@ -180,4 +180,5 @@ def test_bench_reads_the_committed_counter_runs():
     assert bench.pmc_traffic('k_trunk', 'gomoku19x19_n5_selfplay_800sims_per_move_512games_per_gpu') is None
     # the trunk of a 256-board launch writes exactly the f16 feature pieces: 256 boards x 1350 features x (hi + lo) x 2 bytes
     rec = __import__('json').load(open(__import__('os').path.join(bench.REPO, 'profiles', 'r03', 'pmc_traffic.json')))
-    assert abs(rec[head]['kernels']['k_trunk']['write_size_kb'] * 1024 - 256 * 1350 * 4) < 0.03 * 256 * 1350 * 4
+    # what a trunk launch writes is exactly its boards' head features as f16 pieces: 128 boards (a lane of the headline) x 1350 x 4 B
+    assert abs(rec[head]['kernels']['k_trunk']['write_size_kb'] * 1024 - 128 * 1350 * 4) < 0.03 * 128 * 1350 * 4

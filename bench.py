@@ -854,7 +854,7 @@ def main():
                   # between its events / the wall-clock per launch); rocprofv3's per-dispatch duration is the former
                   'launches_in_flight': round(per_stream_ms / ms, 2) if lanes > 1 else 1.0,
                   'mfma_executed_frac': round(achieved / pipe_peak * executed_flop_ratio(args, cells), 4),
-                  'trunk_workgroups': trunk_wgs if trunk_wgs > 0 else n_cus}
+                  'trunk_workgroups': int(min(trunk_wgs if trunk_wgs > 0 else n_cus, boards_per_launch))}
             line['roofline'] = rf
             if exclusive_ms and boards_per_launch >= n_cus:   # (a launch of fewer boards than CUs cannot fill the chip by itself)
                 ex = flops / (exclusive_ms * 1e-3) / 1e12

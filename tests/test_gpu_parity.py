@@ -551,6 +551,10 @@ def test_two_capped_lanes_with_graphs_equal_one_eager_lane():
     assert three.lanes[0].evaluator.hip.max_boards >= 4 and three.trunk_workgroups == 0
     same(one.run(range(54, 90)), three.run(range(54, 90), pipelined=True))
     same(two.run(range(90, 110), pipelined=True), three.run(range(90, 110)))
+    # four lanes (the layout of the BASELINE batch, each lane on a hardware queue of its own) with refills lane by lane
+    four = BatchedSelfPlay.for_network(net, lanes=4, use_graph=True, sims_per_graph=8, **kw)
+    assert len(four.lanes) == 4 and [lane.eng.n_games for lane in four.lanes] == [3, 3, 3, 3]
+    same(one.run(range(400, 440)), four.run(range(400, 440), pipelined=True))
     # a pipelined run cut short leaves lanes with the next move's simulations enqueued: a later run starts clean, and
     # play_move() after play_move_pipelined() takes a primed lane's search as it is (no second search on top)
     three.run(range(200, 236), max_moves=3, pipelined=True)

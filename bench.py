@@ -40,7 +40,6 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 BOARD, N_ROW, N_PLAYOUT, GAMES_PER_GPU, C_PUCT, TEMPERATURE = 15, 5, 800, 512, 5.0, 1.0
 RESERVED_CUS_PER_XCD, N_XCD = 4, 8  # --trunk-wgs 224: CUs a capped trunk leaves to the other lane's small kernels
-BOARDS_PER_WORKGROUP = 3  # boards per persistent trunk workgroup and step at the default batch
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 PEAK_F16_MATRIX_TFLOPS = 2500.0  # dense f16 / bf16 MFMA, same table
 SPLIT_MFMAS_PER_PRODUCT = 3      # split_f16: hi*hi + hi*lo + lo*hi

@@ -130,7 +130,6 @@ class Trajectory(object):
         return self.winner, list(zip(self.states(), list(self.pis), self.z()))
 
 
-BOARDS_PER_WORKGROUP = 3  # boards a persistent trunk workgroup takes per step at the tuned batch (bench.py default)
 
 
 def plan_lanes(n_games, n_cus=256, hw_queues=None):

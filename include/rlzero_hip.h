@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 20
+#define RZ_ABI_VERSION 21
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 #define RZ_MAX_IN_FLIGHT 16 /* rz_config.sims_in_flight */
@@ -91,7 +91,7 @@ typedef struct rz_config {
     int32_t score_mode;  /* RZ_SCORE_* */
     int32_t add_noise;   /* != 0: priors are mixed 0.75/0.25 with Dirichlet(0.3) noise at every expanded
                             node (node.py:63-69; is_selfplay in alphazero_mcts.py:124-129).  Drawn on the
-                            device from a counter-based stream (noise_seed, game, expansion #): same
+                            device from a counter-based stream (noise_seed, game, expansion #; rz_set_noise_keys): same
                             distribution as numpy's, not its global stream.  RZ_SCORE_UCT_REF never reads
                             the prior, so the noise cannot change its search. */
     double c_puct;       /* AlphaZeroPlayer(c_puct=) */
@@ -152,6 +152,13 @@ int rz_get_roots(rz_engine *e, uint64_t *d_stones, int32_t *d_to_move, int32_t *
                  void *stream);
 /* Games with active == 0 are skipped by select / expand_backup (finished games). */
 int rz_set_active(rz_engine *e, const uint8_t *d_active, void *stream);
+/* The Dirichlet noise of game g (rz_config.add_noise; node.py:63-69) is drawn from a counter-based stream keyed (key[g], expansion #).
+ * By default key[g] = noise_seed ^ g << 20: a stream per SLOT of this engine.  A host that deals games to slots, lanes and GPUs
+ * (rlzero_amd.selfplay) gives every game a key of its own when it starts -- d_keys uint64 [n_games], d_mask uint8 [n_games] or NULL
+ * (all) selects the slots; their expansion counters restart at 0 -- so that a game's noise, like its move draws, depends on (seed,
+ * game id) and not on where the game is played.  d_keys == NULL restores the default keys.  (The reference draws from numpy's
+ * global stream, node.py:65: one stream for everything, in the order the single process happens to expand nodes.) */
+int rz_set_noise_keys(rz_engine *e, const uint64_t *d_keys, const uint8_t *d_mask, void *stream);
 
 /* SELECT + STEP: for every active game walk from the root to a leaf
  * (AlphaZeroMCTS._playout select loop, alphazero_mcts.py:48-54; TreeNode.select /

@@ -8,7 +8,7 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64,
                     c_void_p)
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
 MAX_IN_FLIGHT = 16
@@ -79,6 +79,7 @@ _SIGNATURES = {
     'rz_set_roots': (c_int, [P, P, P, P, P, c_int, P]),
     'rz_get_roots': (c_int, [P, P, P, P, P]),
     'rz_set_active': (c_int, [P, P, P]),
+    'rz_set_noise_keys': (c_int, [P, P, P, P]),
     'rz_select_step': (c_int, [P, P, P]),
     'rz_set_in_flight': (c_int, [P, c_int32, c_int32]),
     'rz_leaf_buffers': (c_int, [P, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p)]),

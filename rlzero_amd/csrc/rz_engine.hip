@@ -76,6 +76,7 @@ struct Dev {
     int32_t *err, *err_any, *reuse_drops;
     const double *logtab;
     int32_t *noise_ctr;
+    uint64_t *noise_key;   // per game: the key of its Dirichlet stream (default: noise_seed ^ game << 20; rz_set_noise_keys)
     uint64_t noise_seed;
     int add_noise;
     uint64_t valid[kWords];
@@ -777,7 +778,7 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
             float noise_sum = 1.0f;
             if (E.add_noise) {
                 const int ctr = noise_ctr;
-                const uint64_t key = mix64(mix64(E.noise_seed ^ ((uint64_t)g << 20)) ^ (uint64_t)ctr);
+                const uint64_t key = mix64(mix64(E.noise_key[g]) ^ (uint64_t)ctr);
                 float local = 0.0f;
 #pragma unroll
                 for (int j = 0; j < kWords; ++j)
@@ -1048,7 +1049,7 @@ __global__ void k_tree_step_ml(Dev E, const float *logp, const float *value, Raw
             float noise[kWords] = {0.f, 0.f, 0.f, 0.f};
             float noise_sum = 1.0f;
             if (E.add_noise) {
-                const uint64_t key = mix64(mix64(E.noise_seed ^ ((uint64_t)g << 20)) ^ (uint64_t)(ctr0 + before_n));
+                const uint64_t key = mix64(mix64(E.noise_key[g]) ^ (uint64_t)(ctr0 + before_n));
                 float local = 0.0f;
 #pragma unroll
                 for (int i = 0; i < kWords; ++i)
@@ -1732,6 +1733,14 @@ __global__ void k_get_leaves(Dev E, uint64_t *stones, int32_t *to_move, int32_t 
     terminal[g] = E.leaf_term[g];
 }
 
+// keys == nullptr: the default keys (noise_seed ^ game << 20) for the selected games
+__global__ void k_set_noise_keys(Dev E, const uint64_t *keys, const uint8_t *mask) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.n_games || (mask != nullptr && !mask[g])) return;
+    E.noise_key[g] = keys != nullptr ? keys[g] : (E.noise_seed ^ ((uint64_t)g << 20));
+    E.noise_ctr[g] = 0;
+}
+
 __global__ void k_set_active(Dev E, const uint8_t *active) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g < E.n_games) E.active[g] = active ? (active[g] ? 1 : 0) : 1;
@@ -1958,6 +1967,7 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     RZ_ALLOC(err_any, 1);
     RZ_ALLOC(reuse_drops, 1);
     RZ_ALLOC(noise_ctr, G);
+    RZ_ALLOC(noise_key, G);
     if (rc == RZ_OK) rc = dev_alloc(e, &e->d_logtab, D.logtab_n);
 #undef RZ_ALLOC
     if (rc != RZ_OK) {
@@ -1998,6 +2008,7 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
         if (herr == hipSuccess) herr = hipMemcpy(d_mv, mv.data(), G * 4, hipMemcpyHostToDevice);
         if (herr == hipSuccess) {
             k_advance<<<dim3((unsigned)G), dim3(kWave), 0, 0>>>(D, d_mv);
+            k_set_noise_keys<<<dim3((unsigned)((G + 255) / 256)), dim3(256), 0, 0>>>(D, nullptr, nullptr);   // the default keys
             herr = hipDeviceSynchronize();
         }
         if (d_mv) (void)hipFree(d_mv);
@@ -2078,6 +2089,12 @@ int rz_set_active(rz_engine *e, const uint8_t *d_active, void *stream) {
     RZ_ENTER(e);
     k_set_active<<<flat_grid(e), dim3(256), 0, as_stream(stream)>>>(e->dev, d_active);
     return launched("k_set_active");
+}
+
+int rz_set_noise_keys(rz_engine *e, const uint64_t *d_keys, const uint8_t *d_mask, void *stream) {
+    RZ_ENTER(e);
+    k_set_noise_keys<<<flat_grid(e), dim3(256), 0, as_stream(stream)>>>(e->dev, d_keys, d_mask);
+    return launched("k_set_noise_keys");
 }
 
 int rz_set_in_flight(rz_engine *e, int32_t k_backup, int32_t k_select) {

@@ -398,6 +398,8 @@ class MCTSEngine(object):
         self.terminal = torch.zeros(G, dtype=torch.int32, **kw)
         self.mask = torch.zeros(G, dtype=torch.uint8, **kw)
         self.active_dev = torch.ones(G, dtype=torch.uint8, **kw)
+        self.noise_keys = torch.zeros(G, dtype=torch.int64, **kw)
+        self.noise_mask = torch.zeros(G, dtype=torch.uint8, **kw)
         self.active_host = np.ones(G, dtype=np.uint8)
         self._graphs = {}
 
@@ -466,6 +468,20 @@ class MCTSEngine(object):
         self.active_host = np.ascontiguousarray(active, dtype=np.uint8).copy()
         self.active_dev.copy_(self.torch.from_numpy(self.active_host))
         check(self.lib.rz_set_active(self.handle, _ptr(self.active_dev), self.stream()), 'rz_set_active')
+
+    def set_noise_keys(self, keys=None, mask=None):
+        """The Dirichlet stream of every selected game: ``keys`` uint64 [G] (None = the engine's per-slot default), ``mask`` bool [G] or
+        None (all); the games' expansion counters restart.  BatchedSelfPlay keys a game's noise by (seed, game id), so its search under
+        the PUCT rule does not depend on the slot, lane or GPU it is played on (rz_set_noise_keys)."""
+        t = self.torch
+        kptr = mptr = None
+        if keys is not None:
+            self.noise_keys.copy_(t.from_numpy(np.ascontiguousarray(keys, dtype=np.uint64).view(np.int64)))
+            kptr = _ptr(self.noise_keys)
+        if mask is not None:
+            self.noise_mask.copy_(t.from_numpy(np.ascontiguousarray(mask, dtype=np.uint8)))
+            mptr = _ptr(self.noise_mask)
+        check(self.lib.rz_set_noise_keys(self.handle, kptr, mptr, self.stream()), 'rz_set_noise_keys')
 
     def get_leaves(self):
         check(self.lib.rz_get_leaves(self.handle, _ptr(self.stones), _ptr(self.to_move),

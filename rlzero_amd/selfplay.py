@@ -300,6 +300,10 @@ class BatchedSelfPlay(object):
             self.cell_taken[s] = False
             self.slot_moves[s] = []
             self.slot_pis[s] = []
+        # a game's Dirichlet noise (read by the PUCT rule only), like its move draws, is keyed by (seed, game id): the trajectory
+        # does not depend on the slot, lane or GPU the game is played on
+        with np.errstate(over='ignore'):
+            keys = _splitmix64(_splitmix64(np.uint64(self.seed) ^ np.uint64(0x6E6F697365000000)) ^ self.slot_game.astype(np.uint64))
         for lane in self.lanes:
             if mask[lane.slots].any():
                 if getattr(lane, 'primed', False):
@@ -309,6 +313,7 @@ class BatchedSelfPlay(object):
                     lane.primed = False
                 with self._on(lane):
                     lane.eng.reset_games(mask=mask[lane.slots])
+                    lane.eng.set_noise_keys(keys[lane.slots], mask=mask[lane.slots])
 
     def _set_active(self):
         active = (self.slot_game >= 0).astype(np.uint8)

@@ -352,14 +352,15 @@ def test_full_size_batches_of_the_baseline_configs(config):
         lane.eng.close()
 
 
-@pytest.mark.parametrize('n_games', [512, 1536])
-def test_full_size_shipped_layout_equals_one_plain_lane(n_games):
+@pytest.mark.parametrize('n_games,score_mode', [(512, 'uct_ref'), (1536, 'uct_ref'), (512, 'puct')])
+def test_full_size_shipped_layout_equals_one_plain_lane(n_games, score_mode):
     """The layout bench.py times -- co-resident lanes (four at 512 games, each on a hardware queue of its own; two at 1536) with
     un-capped trunks, the LDS-free 'parts' FC GEMM, hipGraphs of 8
     simulation steps, the host side of a lane's move pipelined under the other lanes' simulations -- at FULL size (15x15,
     800 simulations per move; 512 games = BASELINE.json configs[3]'s share of a GPU, 1536 = the batch that fills one)
     against ONE lane launched kernel by kernel with every move finished on the host before the next search: the layout is
-    scheduling only, so every game's moves and pi are the same bits; no subtree dropped, no flag, pi from exact counts."""
+    scheduling only, so every game's moves and pi are the same bits; no subtree dropped, no flag, pi from exact counts.  Also under
+    the opt-in PUCT rule (the `C4_puct_rule` leg of the bench line), whose tree step scans and initialises every child."""
     import torch
     from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
     from rlzero_amd.selfplay import BatchedSelfPlay
@@ -369,7 +370,7 @@ def test_full_size_shipped_layout_equals_one_plain_lane(n_games):
 
     def play(shipped):
         kw = {} if shipped else dict(lanes=1, use_graph=False)
-        sp = BatchedSelfPlay.for_network(net, 15, 5, n_games=n_games, n_playout=sims, seed=5, **kw)
+        sp = BatchedSelfPlay.for_network(net, 15, 5, n_games=n_games, n_playout=sims, seed=5, score_mode=score_mode, **kw)
         if shipped:
             import rlzero_amd
             assert rlzero_amd.HW_QUEUES >= 8   # (claimed on import, before this process touched the GPU)
@@ -560,6 +561,15 @@ def test_two_capped_lanes_with_graphs_equal_one_eager_lane():
     three.run(range(200, 236), max_moves=3, pipelined=True)
     assert any(getattr(lane, 'primed', False) for lane in three.lanes)
     same(one.run(range(110, 140)), three.run(range(110, 140)))
+    # the PUCT rule READS the priors, Dirichlet noise included: a game's noise stream is keyed by (seed, game id)
+    # (rz_set_noise_keys), so slots, lanes and refills still do not matter
+    pk = dict(kw, score_mode='puct')
+    p_one = BatchedSelfPlay.for_network(net, lanes=1, use_graph=False, **pk)
+    p_three = BatchedSelfPlay.for_network(net, lanes=3, use_graph=True, sims_per_graph=8, **pk)
+    a, b = p_one.run(range(500, 530)), p_three.run(range(500, 530), pipelined=True)
+    same(a, b)
+    same(a[:6], p_one.run(range(500, 506)))   # ... nor the games played before in the same slots
+    assert [t.moves for t in a] != [t.moves for t in one.run(range(500, 530))]   # (the rule does change the games)
     mixed = BatchedSelfPlay.for_network(net, lanes=2, use_graph=True, sims_per_graph=8, **kw)
     plain = BatchedSelfPlay.for_network(net, lanes=1, use_graph=False, **kw)
     for sp_ in (mixed, plain):

@@ -252,7 +252,7 @@ CONFIG_LEGS = (  # (key, flags, seconds of CPU baseline at --cpu-seconds 60); a 
     ('C1_ttt_25sims_1game', ['--board', 3, '--playouts', 25, '--games', 1, '--lanes', 1, '--steps', 9, '--warmup', 20], 5.0),
     ('C1_16games', ['--board', 3, '--playouts', 25, '--games', 16, '--lanes', 1, '--steps', 9, '--warmup', 20, '--no-cpu-baseline'], 0.0),
     ('C2_9x9_200sims_64games', ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 8, '--warmup', 8], 12.0),
-    ('C2_16_in_flight', ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 8, '--warmup', 8, '--in-flight', 16,
+    ('C2_16_in_flight', ['--board', 9, '--playouts', 200, '--games', 64, '--steps', 8, '--warmup', 8, '--in-flight', 16,   # (1024 leaves: two lanes)
                          '--no-cpu-baseline'], 0.0),
     ('C3_connect4_400sims_512games', ['--game', 'connect4', '--playouts', 400, '--games', 512, '--steps', 6, '--warmup', 6], 12.0),
     ('C4_puct_rule', ['--score-mode', 'puct', '--steps', 3, '--warmup', 2, '--no-cpu-baseline'], 0.0),

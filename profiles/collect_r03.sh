@@ -42,7 +42,7 @@ pmc default
 pmc fill --games 1536
 pmc puct --score-mode puct
 pmc c2 --board 9 --playouts 200 --games 64 --lanes 1
-pmc c2k16 --board 9 --playouts 200 --games 64 --lanes 1 --in-flight 16
+pmc c2k16 --board 9 --playouts 200 --games 64 --in-flight 16
 pmc c3 --game connect4 --playouts 400 --games 512
 pmc c1 --board 3 --playouts 25 --games 1 --lanes 1 --steps 8
 pmc c1x16 --board 3 --playouts 25 --games 16 --lanes 1 --steps 8

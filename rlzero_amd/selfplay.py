@@ -228,7 +228,8 @@ class BatchedSelfPlay(object):
                     use_graph=True, sims_per_graph=8, eager_every=0, add_noise=True, sims_in_flight=1, **engine_kw):
         """Self-play of ``n_games`` games in flight with the hand-written evaluator of ``net_module`` (a
         PolicyValueNet): builds the lanes (engine + HipNetEvaluator each) as plan_lanes() recommends, unless
-        ``lanes`` / ``trunk_workgroups`` are given.  ``add_noise``: Dirichlet noise on the priors of every expanded
+        ``lanes`` / ``trunk_workgroups`` are given (more than four lanes take turns on the GPU's four compute pipes, and four need
+        GPU_MAX_HW_QUEUES >= 8: profiles/r03/lane_sweeps.txt).  ``add_noise``: Dirichlet noise on the priors of every expanded
         node, what ``AlphaZeroPlayer(is_selfplay=True)`` does (alphazero_mcts.py:124-129, node.py:63-69).
         ``sims_in_flight`` = K > 1: the opt-in virtual-loss mode (MCTSEngine), for batches too small to fill the GPU
         with one leaf per game; the evaluator batch of a lane is then its games x K."""

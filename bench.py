@@ -845,13 +845,15 @@ def main():
             peak, pipe_peak, _ = trunk_peak(args)
             pmc_key = line['config']['workload'] + ('+puct' if args.score_mode == 'puct' else '') + \
                 ('+k%d' % args.in_flight if args.in_flight > 1 else '')
-            rf = {'bound': 'mfma', 'kernel': '%s, %d leaves per launch' % (evaluator.label, boards_per_launch),
+            in_flight = round(per_stream_ms / ms, 2) if lanes > 1 else 1.0
+            rf = {'bound': 'mfma', 'kernel': '%s, %d leaves per launch%s' % (
+                      evaluator.label, boards_per_launch, (', %.1f launches in flight' % in_flight) if in_flight >= 1.5 else ''),
                   'achieved': round(achieved, 3), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                   'traffic': pmc_traffic('k_trunk', pmc_key),
                   'avg_launch_ms': round(ms, 4), 'avg_launch_ms_per_stream': round(per_stream_ms, 4), 'launches_timed': n_ev,
                   # trunk launches of different lanes share the CUs: how many are in flight on average (a launch's own interval
                   # between its events / the wall-clock per launch); rocprofv3's per-dispatch duration is the former
-                  'launches_in_flight': round(per_stream_ms / ms, 2) if lanes > 1 else 1.0,
+                  'launches_in_flight': in_flight,
                   'mfma_executed_frac': round(achieved / pipe_peak * executed_flop_ratio(args, cells), 4),
                   'trunk_workgroups': int(min(trunk_wgs if trunk_wgs > 0 else n_cus, boards_per_launch))}
             line['roofline'] = rf

@@ -475,7 +475,7 @@ def main():
     ap.add_argument('--evaluator', default='hipnet', choices=['hipnet', 'torchnet', 'vlin'],
                     help="hipnet: hand-written fused fp32 MFMA forward (csrc/rz_net.hip); torchnet: "
                          "PyTorch-ROCm/MIOpen; vlin: synthetic evaluator (isolates the tree kernels)")
-    ap.add_argument('--graph', type=int, default=8, help='simulation steps per hipGraph (0 = eager)')
+    ap.add_argument('--graph', type=int, default=16, help='simulation steps per hipGraph (0 = eager); 16 or more: +3 %% over 8 on four lanes')
     ap.add_argument('--net-algo', default='split_f16', choices=['winograd_f4', 'direct', 'split_f16', 'split_f16_tiles'])
     ap.add_argument('--no-games-leg', action='store_true',
                     help='skip the self-play games/s leg (after the timed steps the games of the first generation '

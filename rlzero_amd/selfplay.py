@@ -225,7 +225,7 @@ class BatchedSelfPlay(object):
     @classmethod
     def for_network(cls, net_module, board, n_in_row, n_games, n_playout, c_puct=5.0, device='cuda:0',
                     game='gomoku', net_shape=None, lanes=None, trunk_workgroups=None, temperature=1.0, seed=0,
-                    use_graph=True, sims_per_graph=8, eager_every=0, add_noise=True, sims_in_flight=1, **engine_kw):
+                    use_graph=True, sims_per_graph=16, eager_every=0, add_noise=True, sims_in_flight=1, **engine_kw):
         """Self-play of ``n_games`` games in flight with the hand-written evaluator of ``net_module`` (a
         PolicyValueNet): builds the lanes (engine + HipNetEvaluator each) as plan_lanes() recommends, unless
         ``lanes`` / ``trunk_workgroups`` are given (more than four lanes take turns on the GPU's four compute pipes, and four need

@@ -355,7 +355,7 @@ def test_full_size_batches_of_the_baseline_configs(config):
 @pytest.mark.parametrize('n_games,score_mode', [(512, 'uct_ref'), (1536, 'uct_ref'), (512, 'puct')])
 def test_full_size_shipped_layout_equals_one_plain_lane(n_games, score_mode):
     """The layout bench.py times -- co-resident lanes (four at 512 games, each on a hardware queue of its own; two at 1536) with
-    un-capped trunks, the LDS-free 'parts' FC GEMM, hipGraphs of 8
+    un-capped trunks, the LDS-free 'parts' FC GEMM, hipGraphs of 16
     simulation steps, the host side of a lane's move pipelined under the other lanes' simulations -- at FULL size (15x15,
     800 simulations per move; 512 games = BASELINE.json configs[3]'s share of a GPU, 1536 = the batch that fills one)
     against ONE lane launched kernel by kernel with every move finished on the host before the next search: the layout is

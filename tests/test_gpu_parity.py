@@ -1396,5 +1396,26 @@ def test_dirichlet_noise_on_priors():
     eng3.simulate(SyntheticEvaluator('v0'), sims)
     assert np.array_equal(eng3.root_visits(), vis)  # the reference's selection never reads the prior
     assert not np.array_equal(eng3.root_priors(), eng.root_priors())
+    # rz_set_noise_keys: a game's stream follows its KEY, not its slot -- the keys of slots 0 .. G-1 reversed give the reversed
+    # noise; masked slots keep theirs; keys = None restores the per-slot default (counters restart, so the first search again)
+    keys = np.arange(G, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(5)
+    outs = []
+    for k_ in (keys, keys[::-1].copy()):
+        eng2.reset_games()
+        eng2.set_noise_keys(k_)
+        eng2.simulate(SyntheticEvaluator('v0'), sims)
+        outs.append(eng2.root_priors().copy())
+    assert np.array_equal(outs[0], outs[1][::-1]) and not np.array_equal(outs[0], pri.astype(np.float32))
+    eng2.reset_games()
+    half = np.arange(G) < G // 2
+    eng2.set_noise_keys(keys, mask=half)      # the upper half keeps the reversed keys -- and its running counters
+    eng2.simulate(SyntheticEvaluator('v0'), sims)
+    mixed = eng2.root_priors()
+    assert np.array_equal(mixed[:G // 2], outs[0][:G // 2]) and not np.array_equal(mixed[G // 2:], outs[1][G // 2:])
+    eng2.reset_games()
+    eng2.set_noise_keys(None)
+    eng2.simulate(SyntheticEvaluator('v0'), sims)
+    assert np.array_equal(eng2.root_priors(), eng.root_priors())
+    eng2.check()
     for e in (eng, eng2, eng3):
         e.close()

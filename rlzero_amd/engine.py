@@ -264,17 +264,29 @@ class HipNetEvaluator(object):
         self.hip = HipNet(board_size, device, max_boards)
         self.refresh()
 
-    def _fingerprint(self):
+    def _fingerprint(self, content=False):
         # in-place optimiser steps bump Tensor._version; load_state_dict / .to() change data_ptr
-        return tuple((p.data_ptr(), p._version) for p in self.module.parameters())
+        params = list(self.module.parameters())
+        marks = tuple((p.data_ptr(), p._version) for p in params)
+        if not content:
+            return marks
+        # a write through ``p.data`` (which carries a version counter of its own) changes neither mark: the CONTENT as two float64
+        # reductions over the whole parameter set (0.3 M values and one device round trip: per collection round, not per move)
+        t = self.hip.torch
+        with t.no_grad():
+            flat = t.cat([p.detach().reshape(-1) for p in params]).double()
+            ramp = t.arange(1, flat.numel() + 1, dtype=flat.dtype, device=flat.device)
+            return marks, tuple(t.stack([flat.sum(), (flat * ramp).sum()]).tolist())
 
     def refresh(self):
         self.hip.load_state_dict(self.module.state_dict())
         self._seen = self._fingerprint()
+        self._seen_content = self._fingerprint(content=True)[1]
 
-    def refresh_if_changed(self):
-        """Re-upload the weights if the torch module was trained / reloaded since the last upload."""
-        if self._fingerprint() != self._seen:
+    def refresh_if_changed(self, content=False):
+        """Re-upload the weights if the torch module was trained / reloaded since the last upload.  ``content``: also compare
+        the parameter VALUES with those uploaded (a copy through ``p.data`` leaves version and pointer alone)."""
+        if self._fingerprint() != self._seen or (content and self._fingerprint(content=True)[1] != self._seen_content):
             self.refresh()
 
     def __call__(self, eng):

@@ -93,7 +93,7 @@ class BatchedEvaluation(object):
         """Re-upload the network weights if the torch module changed (after a learner step)."""
         refresh = getattr(self.net_evaluator, 'refresh_if_changed', None)
         if refresh is not None:
-            refresh()
+            refresh(content=True)
 
     def close(self):
         for eng in (self.net_eng, self.ro_eng):

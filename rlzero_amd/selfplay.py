@@ -286,7 +286,7 @@ class BatchedSelfPlay(object):
         for lane in self.lanes:
             refresh = getattr(lane.evaluator, 'refresh_if_changed', None)
             if refresh is not None:
-                refresh()
+                refresh(content=True)
 
     def _on(self, lane):
         return self.torch.cuda.stream(lane.stream)
@@ -615,14 +615,18 @@ def broadcast_weights(module, src=0, group=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return module
-    params = [p.data for p in module.parameters()]
-    flat = torch.cat([p.reshape(-1) for p in params])
-    if dist.get_backend(group) == 'nccl' and not flat.is_cuda:
-        flat = flat.cuda()
-    dist.broadcast(flat, src=src, group=group)
-    at = 0
-    for p in params:
-        n = p.numel()
-        p.copy_(flat[at:at + n].reshape(p.shape).to(p.device))
-        at += n
+    params = list(module.parameters())
+    with torch.no_grad():
+        flat = torch.cat([p.detach().reshape(-1) for p in params])
+        if dist.get_backend(group) == 'nccl' and not flat.is_cuda:
+            flat = flat.cuda()
+        dist.broadcast(flat, src=src, group=group)
+        at = 0
+        for p in params:
+            n = p.numel()
+            # copy_ on the Parameter ITSELF (not on p.data, which carries a version counter of its own): the in-place write bumps
+            # p._version, which is what HipNetEvaluator.refresh_if_changed() looks at -- a rank that only receives weights must
+            # re-upload them like the rank whose optimiser stepped
+            p.copy_(flat[at:at + n].reshape(p.shape).to(p.device))
+            at += n
     return module

@@ -51,7 +51,10 @@ def _worker(rank, world, port, n_games, result_path):
     from rlzero_amd.selfplay import broadcast_weights
     torch.manual_seed(100 + rank)
     net = PolicyValueNet(3)
+    versions = [p._version for p in net.parameters()]
     broadcast_weights(net, src=0)
+    # the copy must be visible to HipNetEvaluator.refresh_if_changed (data_ptr, _version): a write through p.data is not
+    assert all(p._version > v for p, v in zip(net.parameters(), versions))
     torch.manual_seed(100)
     want = PolicyValueNet(3)
     for a, b in zip(net.parameters(), want.parameters()):
@@ -267,22 +270,40 @@ def test_trainer_two_ranks_on_one_gpu(tmp_path):
     """`python tools/train_alphazero.py --gpus 2` with NO launcher on a 1-GPU box (the two ranks share cuda:0 and meet over
     gloo: RCCL refuses two ranks on one device): BatchedSelfPlay on each rank's share of the ids, the gather, rank 0's
     policy_update, the weight broadcast, refresh_weights on every lane -- against one process playing the same 16 ids:
-    the first round's games are the same (a game depends on (seed, id) only), so its log lines agree."""
+    the first round's games are the same (a game depends on (seed, id) only), so its log lines agree.  Three rounds, traced
+    (RZ_TRAIN_TRACE): in EVERY round rank 1 holds rank 0's parameters and its HIP evaluators -- the copies of the weights the
+    search really runs on -- answer a fixed batch of positions with rank 0's bits, which change from round to round as rank 0
+    learns (a rank that kept searching with the weights of round 1 fails here)."""
+    import json
     import subprocess
     env = dict(os.environ, RZ_DIST_SINGLE_DEVICE='1', RZ_DIST_BACKEND='gloo')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(k, None)
-    common = ['--board', '6', '--n-in-row', '4', '--playouts', '30', '--batches', '2', '--seed', '3']
-    outs = []
+    common = ['--board', '6', '--n-in-row', '4', '--playouts', '30', '--batches', '3', '--seed', '3']
+    outs, traces = [], []
     for gpus, in_flight in ((2, 8), (1, 16)):
+        trace = tmp_path / ('trace%d' % gpus)
+        trace.mkdir()
         cmd = [sys.executable, os.path.join(REPO, 'tools', 'train_alphazero.py'), '--gpus', str(gpus), '--games-in-flight',
                str(in_flight)] + common
-        out = subprocess.run(cmd, env=env, cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+        out = subprocess.run(cmd, env=dict(env, RZ_TRAIN_TRACE=str(trace)), cwd=str(tmp_path), stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, timeout=900)
         assert out.returncode == 0, out.stderr.decode()[-2000:]
         outs.append([ln for ln in out.stdout.decode().splitlines() if ln.startswith(('batch i:', 'kl:'))])
+        traces.append([[json.loads(ln) for ln in open(str(trace / ('rank%d.jsonl' % r)))] for r in range(gpus)])
     two, one = outs
-    assert len(two) == 4 and len(one) == 4 and two[0] == one[0] and two[0].startswith('batch i:1, episode_len:')
+    assert len(two) == 6 and len(one) == 6 and two[0] == one[0] and two[0].startswith('batch i:1, episode_len:')
     num = lambda line: {k: float(v) for k, v in (item.split(':') for item in line.split(','))}  # noqa: E731
     a, b = num(two[1]), num(one[1])
     assert abs(a['loss'] - b['loss']) <= 1e-3 and abs(a['entropy'] - b['entropy']) <= 1e-3
     assert two[2].startswith('batch i:2, episode_len:') and one[2].startswith('batch i:2, episode_len:')
+    (rank0, rank1), (single, ) = traces
+    assert len(rank0) == len(rank1) == len(single) == 3
+    for r0, r1 in zip(rank0, rank1):
+        assert r0['params'] == r1['params'], 'round %d: rank 1 does not hold rank 0\'s parameters' % r0['round']
+        assert len(set(r0['lanes'] + r1['lanes'])) == 1, 'round %d: an evaluator searches with other weights' % r0['round']
+        assert set(r0['games']).isdisjoint(r1['games']) and len(r0['games']) == len(r1['games']) == 8
+    assert len({r['lanes'][0] for r in rank1}) == 3 and len({r['params'] for r in rank1}) == 3   # rank 0 learned in between
+    # the first round does not depend on the learner: the same games as the single process, id for id
+    both = dict(rank0[0]['games'], **rank1[0]['games'])
+    assert both == single[0]['games'] and rank0[0]['lanes'][0] == single[0]['lanes'][0]

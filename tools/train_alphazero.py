@@ -101,6 +101,7 @@ class TrainPipeline:
         self._batched = None
         self._duel, self._duel_key, self._evaluations = None, None, 0
         self._next_game_id = 0
+        self._trace_rounds = 0
         self.selfplay_seed = self._agree_on(random.getrandbits(31) if seed is None else int(seed))
         if self.world > 1:   # every rank starts from rank 0's weights
             from rlzero.algorithms import broadcast_weights
@@ -166,7 +167,34 @@ class TrainPipeline:
                 n_games=self.selfplay_games_in_flight, n_playout=self.n_playout, c_puct=self.c_puct,
                 device=str(self.device), temperature=self.temperature, seed=self.selfplay_seed)
         self._batched.refresh_weights()   # (every lane's evaluator: the learner has stepped / new weights have arrived)
-        return self._batched.run(game_ids) if len(game_ids) else []
+        trajs = self._batched.run(game_ids) if len(game_ids) else []
+        if os.environ.get('RZ_TRAIN_TRACE'):
+            self._trace_round(trajs)
+        return trajs
+
+    def _trace_round(self, trajs):
+        """RZ_TRAIN_TRACE=<directory>: one JSON line per collection round and rank -- a digest of the torch parameters, a digest
+        of what every lane's HIP evaluator answers on a fixed batch of positions (i.e. of the weights it was handed), and the
+        round's games.  What the multi-rank tests compare: every rank must search with the weights rank 0 learned."""
+        import hashlib
+        import json
+        net = self.alphazero_agent.policy_value_net
+        digest = hashlib.sha1()
+        for p in net.parameters():
+            digest.update(p.detach().cpu().numpy().tobytes())
+        rng = np.random.RandomState(7)
+        obs = torch.from_numpy((rng.rand(8, 4, self.board_size, self.board_size) < 0.3).astype(np.float32)).to(self.device)
+        answers = []
+        for lane in self._batched.lanes:
+            with torch.cuda.stream(lane.stream):
+                logp, value = lane.evaluator.hip.forward(obs)
+            lane.stream.synchronize()
+            answers.append(hashlib.sha1(logp.cpu().numpy().tobytes() + value.cpu().numpy().tobytes()).hexdigest())
+        rec = {'rank': self.rank, 'round': self._trace_rounds, 'params': digest.hexdigest(), 'lanes': answers,
+               'games': {str(t.game_id): t.moves for t in trajs}}
+        self._trace_rounds += 1
+        with open(os.path.join(os.environ['RZ_TRAIN_TRACE'], 'rank%d.jsonl' % self.rank), 'a') as f:
+            f.write(json.dumps(rec) + '\n')
 
     def _collect_batched(self, n_games):
         """One collection round: ``n_games`` games in all, game g played by rank g mod world (selfplay.shard_game_ids),

@@ -676,15 +676,17 @@ def main():
         fence()
         dt = time.perf_counter() - t0
         if use_dist:
-            t = torch.tensor([dt], dtype=torch.float64, device=red_device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-            counts = torch.tensor([sp.sims_done - sims0, finished[0] - fin0], dtype=torch.float64, device=red_device)
-            dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-            regions.append((dt, float(counts[0].item()), float(counts[1].item())))
+            # every rank's own (seconds, simulations, games finished) of the region, on every rank: the line reports MAX time /
+            # SUM work (the contract) AND each rank's own rate, so a throttling or straggling GPU shows
+            mine = torch.tensor([dt, sp.sims_done - sims0, finished[0] - fin0], dtype=torch.float64, device=red_device)
+            rows = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(rows, mine)
+            rows = torch.stack(rows).cpu().numpy()
+            regions.append((float(rows[:, 0].max()), float(rows[:, 1].sum()), float(rows[:, 2].sum()),
+                            [float(r[1] / r[0]) for r in rows]))
         else:
-            regions.append((dt, float(sp.sims_done - sims0), float(finished[0] - fin0)))
-    elapsed, total_sims, total_finished = sorted(regions, key=lambda r: r[1] / r[0])[len(regions) // 2]
+            regions.append((dt, float(sp.sims_done - sims0), float(finished[0] - fin0), [float(sp.sims_done - sims0) / dt]))
+    elapsed, total_sims, total_finished, per_rank_rates = sorted(regions, key=lambda r: r[1] / r[0])[len(regions) // 2]
     # Kernel-level timing samples, right AFTER the timed region on the same games: every k-th graph chunk is launched
     # kernel by kernel with HIP events around the trunk, the FC GEMM and the tree step.  Not inside the timed region:
     # there the eager chunks cost 0 % (default, 80-us trunks) to 50 % (Connect4, 15-us trunks) -- the host cannot keep two
@@ -717,6 +719,7 @@ def main():
                 ev.record = False
     all_stats = sp.check()
     stats = max(all_stats, key=lambda st: st.max_slots_used)
+    reuse_dropped_timed = int(sum(st.reuse_dropped for st in all_stats))   # kept subtrees over the carry limit (0 = the reference's unbounded update_with_move)
     # the dominant kernel by itself (no other lane on the GPU): its duration on the CUs it is given
     exclusive_ms = None
     if isinstance(evaluator, TimedEvaluator) and getattr(evaluator.inner, 'hip', None) is not None and rank == 0:
@@ -758,19 +761,28 @@ def main():
             c = torch.tensor(acc, dtype=torch.float64, device=red_device)
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
             acc = [float(v) for v in c.tolist()]
-        sp.check()
+        leg_stats = sp.check()
+        dropped = [float(sum(st.reuse_dropped for st in leg_stats)), float(max(st.max_slots_used for st in leg_stats))]
+        if use_dist:
+            c = torch.tensor(dropped, dtype=torch.float64, device=red_device)
+            dist.all_reduce(c, op=dist.ReduceOp.MAX)
+            dropped = [float(v) for v in c.tolist()]
         if acc[2] > 0 and leg > 0:
             mean_plies = acc[1] / acc[2]
             selfplay = {'games_per_sec': round(acc[0] / leg / mean_plies, 2), 'mean_plies_per_game': round(mean_plies, 2),
                         'games_sampled': int(acc[2]), 'moves_per_sec': round(acc[0] / leg, 2),
-                        'leg_seconds': round(leg, 2)}
+                        'leg_seconds': round(leg, 2),
+                        # whole games with refills: subtrees dropped at the carry limit since the engines were created (max over
+                        # ranks; 0 = every update_with_move kept its subtree, alphazero_mcts.py:96-103) and the fullest arena
+                        'reuse_dropped': int(dropped[0]), 'arena_slots_used_max': int(dropped[1]),
+                        'arena_slots': int(leg_stats[0].arena_slots)}
 
     # N > 1: the path's single exchange, a gather of finished trajectories to rank 0 (RCCL over xGMI when the
     # process group is nccl), exercised on a bounded sample outside the timed region
     gather = None
     merged = sorted(gather_sample, key=lambda t: t.game_id)
     if use_dist and not args.no_games_leg:
-        from rlzero_amd.selfplay import gather_trajectories
+        from rlzero_amd.selfplay import COLLECTIVES_PER_EXCHANGE, gather_trajectories
         fence()
         t2 = time.perf_counter()
         try:
@@ -790,6 +802,7 @@ def main():
             gather = {'ranks': world, 'games': len(merged), 'plies': plies, 'backend': dist.get_backend(),
                       'payload_bytes': int(32 * len(merged) + plies * (8 + 4 * merged[0].pis.shape[1])) if merged else 0,
                       'ms': round(1000.0 * dt, 2),
+                      'collectives_per_exchange': COLLECTIVES_PER_EXCHANGE,   # one size all_gather + one payload gather
                       'unique_game_ids': len({t.game_id for t in merged}) == len(merged)}
 
     if rank == 0 and args.dump_trajectories:
@@ -817,14 +830,19 @@ def main():
                        ('' if args.in_flight <= 1 else ', %d simulations in flight per tree (opt-in virtual loss)' % args.in_flight),
                        'multi_sim': {'sims_in_flight': max(1, args.in_flight)},
                        'dirichlet_noise': bool(args.noise), 'sims_per_graph': args.graph,
+                       'hw_queues': int(os.environ.get('GPU_MAX_HW_QUEUES', '4')),   # hardware queues asked of the HIP runtime (a lane each)
                        'parallelism': 'games sharded, dp%d' % world},
             'regions_sims_per_sec': [round(r[1] / r[0], 1) for r in regions], 'warmup_moves_run': n_ramp,
+            # every rank's own rate in the reported (median) region -- its simulations / ITS seconds; value = SUM work / MAX seconds
+            'per_rank_sims_per_sec': [round(v, 1) for v in per_rank_rates],
+            'per_rank_min': round(min(per_rank_rates), 1), 'per_rank_max': round(max(per_rank_rates), 1),
             'moves_per_sec': round(total_sims / args.playouts / elapsed, 2),
             'games_finished_in_timed_region': int(total_finished),
             'selfplay_games_per_sec': selfplay['games_per_sec'] if selfplay else None,
             'selfplay': selfplay,
             'trajectory_gather': gather,
-            'arena_slots_used_max': int(stats.max_slots_used),
+            'arena_slots_used_max': int(stats.max_slots_used), 'arena_slots': int(stats.arena_slots),
+            'reuse_dropped': reuse_dropped_timed,   # rank 0, warm-up + timed regions + timing samples
             'engine_hbm_bytes': int(hbm_bytes),
         }
         trunk_events = [iv for ev in evaluators if isinstance(ev, TimedEvaluator) for iv in ev.events]

@@ -159,7 +159,15 @@ def plan_lanes(n_games, n_cus=256, hw_queues=None):
     if 4 * n_games < 7 * n_cus:
         return 3, 0, 'parts'
     if 4 * n_games <= 11 * n_cus:
-        return (4 if hw_queues >= 8 else 3), 0, 'parts'
+        if hw_queues < 8:
+            import warnings
+            from . import HW_QUEUES_TOO_LATE
+            warnings.warn('plan_lanes: %d games want four lanes, but this process has %d hardware queues%s: three lanes (about 8 %% '
+                          'slower at 512 games); see rlzero_amd.configure' % (
+                              n_games, hw_queues, ' (rlzero_amd was imported after the HIP runtime had started)'
+                              if HW_QUEUES_TOO_LATE else ''), RuntimeWarning, stacklevel=2)
+            return 3, 0, 'parts'
+        return 4, 0, 'parts'
     return 2, 0, 'parts'
 
 
@@ -540,12 +548,38 @@ def unpack_trajectories(header, moves, pis, board_size, n_in_row, game='gomoku')
     return out
 
 
+COLLECTIVES_PER_EXCHANGE = 2   # gather_trajectories: one all_gather of a 3-word size row + ONE gather of the byte payload
+
+
+def _payload_bytes(header, moves, pis, pi_dtype):
+    """One contiguous record of a rank's finished games: header int64 [n, 4] | moves int64 [P] | pi [P, A] (float32 or
+    float64) -- fixed strides, so (n, P) from the size row are all the receiver needs to cut it up again."""
+    return np.concatenate([np.ascontiguousarray(header, dtype=np.int64).reshape(-1).view(np.uint8),
+                           np.ascontiguousarray(moves, dtype=np.int64).view(np.uint8),
+                           np.ascontiguousarray(pis, dtype=pi_dtype).reshape(-1).view(np.uint8)])
+
+
+def _payload_split(raw, n_games, n_plies, n_cells, pi_dtype):
+    at = n_games * 32
+    header = raw[:at].view(np.int64).reshape(n_games, 4)
+    moves = raw[at:at + 8 * n_plies].view(np.int64)
+    at += 8 * n_plies
+    pis = raw[at:at + n_plies * n_cells * np.dtype(pi_dtype).itemsize].view(pi_dtype).reshape(n_plies, n_cells)
+    return header, moves, pis.astype(np.float64)
+
+
 def gather_trajectories(trajs, board_size, n_in_row, dst=0, group=None, game='gomoku', pi_dtype=np.float64):
-    """The one exchange of the path: every rank sends its finished trajectories to ``dst``
-    (one size all_gather + one padded gather per array).  Returns the merged, game-id-sorted
-    list on ``dst`` and None elsewhere.  Without an initialised process group: identity.
+    """The one exchange of the path: every rank sends its finished trajectories to ``dst``.  Two collectives
+    (COLLECTIVES_PER_EXCHANGE): an all_gather of one 3-word row per rank (games, plies, error bit) and ONE gather of a byte
+    payload -- header, moves and pi of all the rank's games in one buffer, padded to the longest rank's.  Returns the merged,
+    game-id-sorted list on ``dst`` and None elsewhere.  Without an initialised process group: identity.
     ``pi_dtype``: what pi travels as -- float64 (default: bit-identical to the single-process run) or float32 (what the
-    learner consumes, alphazero_agent.py:59-61: half the bytes, the exchange SURVEY.md 8e sizes; the trainer's choice)."""
+    learner consumes, alphazero_agent.py:59-61: half the bytes, the exchange SURVEY.md 8e sizes; the trainer's choice).
+
+    What can fail locally -- packing, the device copy of the rank's own payload -- happens BEFORE the size row is exchanged
+    and travels in it as the error bit: a rank that failed still takes part in that all_gather and then ALL ranks raise, so
+    no peer is left blocked in the gather.  (Behind the size row only the padding of the send buffer and the receive buffers
+    of ``dst`` are allocated; running out of memory there is an out-of-memory inside a collective, fatal to the job.)"""
     import torch
     import torch.distributed as dist
     n_cells = board_size[1] if game == 'connect4' else board_size * board_size  # width of a pi row
@@ -554,56 +588,34 @@ def gather_trajectories(trajs, board_size, n_in_row, dst=0, group=None, game='go
     rank, world = dist.get_rank(group), dist.get_world_size(group)  # a group of one runs the same collectives
     on_gpu = dist.get_backend(group) == 'nccl'
     device = torch.device('cuda', torch.cuda.current_device()) if on_gpu else torch.device('cpu')
-    # Host-side work that can fail locally (packing, buffer allocation) is kept out of the collectives, and the
-    # ranks agree on its success inside them: a rank that failed still takes part in every collective up to the
-    # agreement and then ALL ranks raise, so no peer is left blocked in a gather.
-    local_error = None
+    pi_dtype = np.dtype(pi_dtype).type
+    local_error, mine, n_games, n_plies = None, None, 0, 0
     try:
         header, moves, pis = pack_trajectories(trajs, n_cells)
+        n_games, n_plies = header.shape[0], moves.shape[0]
+        mine = torch.from_numpy(_payload_bytes(header, moves, pis, pi_dtype)).to(device)
     except Exception as exc:  # noqa: BLE001
-        local_error = exc
-        header, moves, pis = np.zeros((0, 4), np.int64), np.zeros(0, np.int64), np.zeros((0, n_cells))
-    sizes = torch.tensor([header.shape[0], moves.shape[0], 0 if local_error is None else 1], dtype=torch.int64,
-                         device=device)
+        local_error, mine, n_games, n_plies = exc, None, 0, 0
+    sizes = torch.tensor([n_games, n_plies, 0 if local_error is None else 1], dtype=torch.int64, device=device)
     all_sizes = [torch.zeros_like(sizes) for _ in range(world)]
-    dist.all_gather(all_sizes, sizes, group=group)
+    dist.all_gather(all_sizes, sizes, group=group)                                   # collective 1 of 2
     all_sizes = torch.stack(all_sizes).cpu().numpy()
     if all_sizes[:, 2].any():
         raise RuntimeError('gather_trajectories: packing failed on rank(s) %s%s' % (
             np.nonzero(all_sizes[:, 2])[0].tolist(), '' if local_error is None else ' (here: %r)' % (local_error, )))
-    max_games, max_plies = int(all_sizes[:, 0].max()), int(all_sizes[:, 1].max())
-
-    def padded(arr, rows, dtype):
-        buf = torch.zeros((rows, ) + arr.shape[1:], dtype=dtype, device=device)
-        if arr.shape[0]:
-            buf[:arr.shape[0]] = torch.from_numpy(arr).to(device)
-        return buf
-
-    sends, buckets = None, None
-    try:
-        sends = (padded(header, max_games, torch.int64), padded(moves, max_plies, torch.int64),
-                 padded(pis.astype(pi_dtype, copy=False), max_plies, torch.float32 if pi_dtype == np.float32 else torch.float64))
-        if rank == dst:
-            buckets = [[torch.zeros_like(buf) for _ in range(world)] for buf in sends]
-    except Exception as exc:  # noqa: BLE001 -- e.g. out of memory for the padded buffers
-        local_error = exc
-    bad = torch.tensor([0 if local_error is None else 1], dtype=torch.int64, device=device)
-    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
-    if int(bad.item()):
-        raise RuntimeError('gather_trajectories: buffer allocation failed on some rank%s' % (
-            '' if local_error is None else ' (here: %r)' % (local_error, )))
-    recvs = []
-    for i, buf in enumerate(sends):
-        bucket = buckets[i] if rank == dst else None
-        dist.gather(buf, gather_list=bucket, dst=dst, group=group)
-        recvs.append(bucket)
+    row_bytes = 8 + n_cells * np.dtype(pi_dtype).itemsize
+    n_bytes = all_sizes[:, 0] * 32 + all_sizes[:, 1] * row_bytes
+    send = torch.zeros(max(int(n_bytes.max()), 1), dtype=torch.uint8, device=device)
+    send[:mine.numel()] = mine
+    bucket = [torch.zeros_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, gather_list=bucket, dst=dst, group=group)                      # collective 2 of 2
     if rank != dst:
         return None
     merged = []
     for r in range(world):
-        n_g, n_p = int(all_sizes[r, 0]), int(all_sizes[r, 1])
-        merged.extend(unpack_trajectories(recvs[0][r][:n_g].cpu().numpy(), recvs[1][r][:n_p].cpu().numpy(),
-                                          recvs[2][r][:n_p].cpu().numpy(), board_size, n_in_row, game=game))
+        raw = bucket[r][:int(n_bytes[r])].cpu().numpy()
+        merged.extend(unpack_trajectories(*_payload_split(raw, int(all_sizes[r, 0]), int(all_sizes[r, 1]), n_cells, pi_dtype),
+                                          board_size, n_in_row, game=game))
     return sorted(merged, key=lambda t: t.game_id)
 
 

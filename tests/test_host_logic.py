@@ -118,7 +118,8 @@ def test_plan_lanes():
     # the 512 games per GPU of BASELINE.json configs[3]
     assert plan_lanes(448, hw_queues=8) == (4, 0, 'parts') and plan_lanes(512, hw_queues=8) == (4, 0, 'parts')
     assert plan_lanes(704, hw_queues=8) == (4, 0, 'parts') and plan_lanes(512, hw_queues=16) == (4, 0, 'parts')
-    assert plan_lanes(512, hw_queues=4) == (3, 0, 'parts')   # a fourth stream would share a hardware queue
+    with pytest.warns(RuntimeWarning, match='four lanes'):
+        assert plan_lanes(512, hw_queues=4) == (3, 0, 'parts')   # a fourth stream would share a hardware queue
     assert plan_lanes(768, hw_queues=8) == (2, 0, 'parts') and plan_lanes(1536, hw_queues=8) == (2, 0, 'parts')
     assert plan_lanes(100, n_cus=32, hw_queues=8) == (2, 0, 'parts')
 
@@ -133,6 +134,32 @@ def test_hw_queues_are_claimed_on_import():
     assert subprocess.check_output([sys.executable, '-c', code], env=env).decode().split() == ['8', '8']
     env['GPU_MAX_HW_QUEUES'] = '4'
     assert subprocess.check_output([sys.executable, '-c', code], env=env).decode().split() == ['4', '4']
+    del env['GPU_MAX_HW_QUEUES']
+    assert subprocess.check_output([sys.executable, '-c', code], env=dict(env, RZ_HW_QUEUES='6')).decode().split() == ['6', '6']
+    # the explicit call, before the runtime starts: the number holds
+    code = ("import os, sys; sys.path.insert(0, %r); import rlzero_amd; n = rlzero_amd.configure(hw_queues=12); "
+            "print(os.environ.get('GPU_MAX_HW_QUEUES'), n, rlzero_amd.HW_QUEUES)" % REPO)
+    assert subprocess.check_output([sys.executable, '-c', code], env=env).decode().split() == ['12', '12', '12']
+    # a late import (the runtime of the process holds /dev/kfd already -- simulated: no GPU here): nothing is claimed, configure()
+    # warns, and plan_lanes() warns when it falls back from four lanes to three
+    code = """
+import os, sys, warnings
+sys.path.insert(0, %r)
+import rlzero_amd as rz
+rz._runtime_started = lambda: True
+os.environ.pop('GPU_MAX_HW_QUEUES', None)
+rz.HW_QUEUES, rz.HW_QUEUES_TOO_LATE = rz._claim_hw_queues()
+print(rz.HW_QUEUES, rz.HW_QUEUES_TOO_LATE, os.environ.get('GPU_MAX_HW_QUEUES'))
+from rlzero_amd.selfplay import plan_lanes
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter('always')
+    n = rz.configure(hw_queues=8)
+    lanes = plan_lanes(512)[0]
+print(n, lanes, [x.category.__name__ for x in w], 'after the HIP runtime' in str(w[-1].message))
+""" % REPO
+    out = subprocess.check_output([sys.executable, '-c', code], env=env).decode().splitlines()
+    assert out[0].split() == ['4', 'True', 'None']
+    assert out[1] == "4 3 ['RuntimeWarning', 'RuntimeWarning'] True"
 
 
 def test_batched_pi_and_moves_bit_identical_to_per_game_expressions():

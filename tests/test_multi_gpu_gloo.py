@@ -78,6 +78,54 @@ def test_sharded_selfplay_gather_equals_single_process(tmp_path):
     assert np.array_equal(got['pis'], np.concatenate([t.pis for t in single]))
 
 
+def _edge_worker(rank, world, port, result_path):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import torch.distributed as dist
+    from rlzero_amd import selfplay
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    calls = []
+    real_all_gather, real_gather, real_all_reduce = dist.all_gather, dist.gather, dist.all_reduce
+    dist.all_gather = lambda *a, **k: calls.append('all_gather') or real_all_gather(*a, **k)
+    dist.gather = lambda *a, **k: calls.append('gather') or real_gather(*a, **k)
+    dist.all_reduce = lambda *a, **k: calls.append('all_reduce') or real_all_reduce(*a, **k)
+    # (1) a rank with nothing to send, pi as float32: exactly two collectives, one of them the payload
+    local = _play([0, 1, 2], seed=3, sims=20) if rank == 0 else []
+    merged = selfplay.gather_trajectories(local, 3, 3, dst=0, pi_dtype=np.float32)
+    assert calls == ['all_gather', 'gather'] and len(calls) == selfplay.COLLECTIVES_PER_EXCHANGE
+    if rank == 0:
+        assert [t.game_id for t in merged] == [0, 1, 2]
+        for got, want in zip(merged, local):
+            assert got.moves == want.moves and got.winner == want.winner
+            assert np.array_equal(got.pis, want.pis.astype(np.float32).astype(np.float64))
+    # (2) nobody has anything
+    assert (selfplay.gather_trajectories([], 3, 3, dst=0) or []) == []
+    # (3) packing fails on rank 1 only: BOTH ranks raise, inside the first collective's agreement, nobody waits in the gather
+    del calls[:]
+    try:
+        selfplay.gather_trajectories(_play([4 + rank], seed=3, sims=20) if rank == 0 else [object()], 3, 3, dst=0)
+        raised = False
+    except RuntimeError as exc:
+        raised = 'rank(s) [1]' in str(exc)
+    assert raised and calls == ['all_gather']
+    dist.barrier()
+    open(result_path + '.%d' % rank, 'w').write('ok')
+    dist.destroy_process_group()
+
+
+def test_gather_is_one_size_row_and_one_payload(tmp_path):
+    """gather_trajectories = one all_gather of a 3-word size row + ONE gather of a byte payload (header + moves + pi); a rank
+    without games takes part with an empty payload; a rank that fails to pack makes every rank raise after the size row."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    result = str(tmp_path / 'edge')
+    mp.spawn(_edge_worker, args=(2, port, result), nprocs=2, join=True)
+    assert os.path.exists(result + '.0') and os.path.exists(result + '.1')
+
+
 def test_gather_without_process_group_is_identity():
     from rlzero_amd.selfplay import gather_trajectories, pack_trajectories, unpack_trajectories
     trajs = _play([2, 0, 1], seed=1, sims=10)
@@ -131,7 +179,14 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert rec['selfplay']['games_sampled'] == 64 and rec['selfplay_games_per_sec'] > 0
     tg = rec['trajectory_gather']  # the one exchange of the path, here over gloo
     assert tg['ranks'] == 2 and tg['games'] >= 64 and tg['unique_game_ids'] and tg['plies'] >= 64 * 9
-    assert tg['backend'] == 'gloo'
+    assert tg['backend'] == 'gloo' and tg['collectives_per_exchange'] == 2   # one size all_gather + ONE payload gather
+    # every rank's own rate is on the line; value = SUM work / MAX seconds lies between world x min and world x max
+    rates = rec['per_rank_sims_per_sec']
+    assert len(rates) == 2 and min(rates) == rec['per_rank_min'] > 0 and max(rates) == rec['per_rank_max']
+    assert 2 * min(rates) * 0.999 <= rec['value'] <= 2 * max(rates) * 1.001
+    assert rec['reuse_dropped'] == 0 and rec['selfplay']['reuse_dropped'] == 0
+    assert 0 < rec['selfplay']['arena_slots_used_max'] < rec['selfplay']['arena_slots'] == rec['arena_slots']
+    assert rec['config']['hw_queues'] == 8
     # the same 64 game ids on ONE rank (one lane of 64 games instead of two ranks x two lanes of 16)
     cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--games', '64', '--lanes', '1',
            '--dump-trajectories', dump1] + common
@@ -166,7 +221,8 @@ def test_bench_collectives_on_rccl_with_one_rank():
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     rec = json.loads([ln for ln in out.stdout.decode().splitlines() if ln.startswith('{')][-1])
     tg = rec['trajectory_gather']
-    assert tg.get('error') is None and tg['backend'] == 'nccl' and tg['ranks'] == 1
+    assert tg.get('error') is None and tg['backend'] == 'nccl' and tg['ranks'] == 1 and tg['collectives_per_exchange'] == 2
+    assert len(rec['per_rank_sims_per_sec']) == 1 and abs(rec['per_rank_sims_per_sec'][0] - rec['value']) <= 1e-3 * rec['value']
     assert tg['games'] >= 32 and tg['unique_game_ids'] and tg['payload_bytes'] > 0
     assert rec['selfplay']['games_sampled'] == 32
 

@@ -348,6 +348,13 @@ class TimedEvaluator(object):
         the tree step launched in between (same stream)."""
         if not self.record:
             self.last_c = None
+            if os.environ.get('RZ_DIAG_SKIP_FC') == '1':
+                # DIAGNOSTIC ONLY (wrong trees): the FC GEMM is launched once and its stale outputs reused, so a lane's chain is
+                # trunk -> tree step -- what a shorter chain would buy the schedule (profiles/r04/NOTES.md)
+                self._trunk(eng)
+                if getattr(self, '_stale_heads', None) is None:
+                    self._stale_heads = self.inner.hip.heads_gemm(eng.obs.shape[0])
+                return self._stale_heads
             return self.inner.raw_heads(eng)
         t = self.torch
         a, b, c = (t.cuda.Event(enable_timing=True) for _ in range(3))

@@ -403,6 +403,57 @@ def test_full_size_shipped_layout_equals_one_plain_lane(n_games, score_mode):
             assert (pis[np.arange(n_games), ply, moves[:, earlier]] == 0.0).all()
 
 
+def test_whole_games_on_the_shipped_layout_equal_one_plain_lane():
+    """WHOLE games at full size on the layout bench.py times: `BatchedSelfPlay.run(range(640), pipelined=True)` -- four
+    co-resident lanes of 128 games, hipGraphs, pipelined moves, finished slots refilled with the ids 512 .. 639 -- at 15x15 / 800
+    simulations per move, every game played to its END (the reference's loop: game.py:96-134), against ONE plain lane launched
+    kernel by kernel on a sample of 64 of the same ids (first-generation games and refilled ones): moves, pi bits and winners
+    equal.  update_with_move keeps its subtree at every ply of every game (alphazero_mcts.py:96-103: the reference's tree is
+    unbounded; here reuse_dropped counts a subtree over the carry limit and must stay 0) and no arena fills up."""
+    import torch
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    from rlzero_amd.selfplay import BatchedSelfPlay
+    torch.manual_seed(0)
+    net = PolicyValueNet(15).to('cuda:0')
+    n_ids, sims = 640, 800
+    sample = list(range(0, 512, 11)) + list(range(512, 640, 8))       # 47 first-generation games + 16 refilled ones
+    sample = sample + [511]
+    assert len(sample) == 64
+
+    def play(shipped):
+        kw = {} if shipped else dict(lanes=1, use_graph=False)
+        sp = BatchedSelfPlay.for_network(net, 15, 5, n_games=512 if shipped else len(sample), n_playout=sims, seed=5, **kw)
+        if shipped:
+            assert len(sp.lanes) == 4 and sp.trunk_workgroups == 0 and sp.use_graph
+        out = sp.run(range(n_ids) if shipped else sample, pipelined=shipped)
+        stats = sp.check()
+        for st in stats:
+            assert st.reuse_dropped == 0, 'a kept subtree exceeded the carry limit: not the reference\'s update_with_move'
+            assert st.max_slots_used < st.arena_slots
+        for lane in sp.lanes:
+            lane.evaluator.hip.check_flags()
+            lane.eng.close()
+        return {t.game_id: t for t in out}, max(st.max_slots_used for st in stats), stats[0].arena_slots
+
+    shipped, used, slots = play(True)
+    assert sorted(shipped) == list(range(n_ids))
+    plain, _, _ = play(False)
+    assert sorted(plain) == sorted(sample)
+    lengths = []
+    for g in sample:
+        a, b = shipped[g], plain[g]
+        assert a.moves == b.moves and a.winner == b.winner, 'game %d depends on the layout' % g
+        assert np.array_equal(a.pis.view(np.uint64), b.pis.view(np.uint64))
+        lengths.append(len(a.moves))
+    for t in shipped.values():                                          # every game: a legal, finished game of Gomoku
+        assert 9 <= len(t.moves) <= 225 and len(set(t.moves)) == len(t.moves) and t.winner in (-1, 0, 1)
+        assert t.winner != -1 or len(t.moves) == 225                    # a tie is a full board
+        assert abs(t.pis.sum(axis=1) - 1.0).max() < 1e-9
+    assert max(len(t.moves) for t in shipped.values()) > 60, 'the carry limit is only exercised by long games'
+    print('whole games: mean %.1f plies, longest %d; fullest arena %d of %d slots' % (
+        np.mean([len(t.moves) for t in shipped.values()]), max(len(t.moves) for t in shipped.values()), used, slots))
+
+
 # ------------------------------------------------------------------ player / game loop (G3)
 class _Injected(object):
 

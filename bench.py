@@ -238,7 +238,7 @@ def run_fill_config(args):
     """The same engine with 1536 games in flight (two lanes of 768: three boards per persistent trunk workgroup), as a
     child process -> the fields of its line worth keeping."""
     rec = child_line(['--lanes', 2, '--games', FILL_GAMES_PER_GPU, '--steps', args.steps, '--warmup', max(args.warmup, 3),
-                      '--regions', 1, '--net-algo', args.net_algo, '--graph', args.graph, '--noise', args.noise,
+                      '--regions', 1, '--net-algo', args.net_algo, '--graph', args.graph, '--noise', args.noise, '--deferred', args.deferred,
                       '--no-cpu-baseline', '--no-games-leg', '--no-fill', '--no-configs'], 600)
     if rec is None:
         return None
@@ -337,6 +337,31 @@ class TimedEvaluator(object):
     def begin_chunk(self):
         """engine.sim_chunk starts a chunk of eager simulations: the previous chunk's last event pairs with nothing."""
         self.last_c = None
+
+    @property
+    def hip(self):
+        return self.inner.hip
+
+    def deferred_ok(self, eng):
+        ok = getattr(self.inner, 'deferred_ok', None)
+        return ok is not None and ok(eng)
+
+    def deferred_trunk(self, eng):
+        """Deferred-priors route (two launches per step): the trunk bracketed when recording; the event behind it and the
+        first event of the NEXT step of the same eager chunk bracket the tree step launched in between."""
+        if not self.record:
+            self.last_c = None
+            return self.inner.deferred_trunk(eng)
+        t = self.torch
+        a, b = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+        a.record()
+        if getattr(self, 'last_c', None) is not None:
+            self.tree_events.append((self.last_c, a))
+        out = self.inner.deferred_trunk(eng)
+        b.record()
+        self.events.append((a, b))
+        self.last_c = b
+        return out
 
     @property
     def fused_heads(self):
@@ -518,6 +543,10 @@ def main():
     ap.add_argument('--in-flight', type=int, default=1,
                     help='K > 1: opt-in virtual-loss mode, K simulations of every tree share one evaluator batch (NOT the '
                          'reference\'s sequential search: results differ from it; for batches too small to fill the GPU)')
+    ap.add_argument('--deferred', type=int, default=1,
+                    help='1 (default): deferred priors where the route exists (UCT_REF, one simulation in flight, boards of 11 .. 16 rows) -- '
+                         'a step is trunk -> tree step, the policy GEMM and the priors of a move\'s expansions run as one batch per move; '
+                         '0: the three-launch step (trunk -> FC GEMM -> tree step writing the priors at once)')
     ap.add_argument('--lanes', type=int, default=0,
                     help='independent batches of games on separate HIP streams (the tree / FC kernels of one lane run beside the '
                          'network trunks of the others); 0 = what rlzero_amd.selfplay.plan_lanes picks for the batch (512 games: 4)')
@@ -607,6 +636,7 @@ def main():
     net = (PolicyValueNet(6, 7, 7) if args.game == 'connect4' else PolicyValueNet(board)).to(device).eval()
     net_shape = (6, 7, 7) if args.game == 'connect4' else board
     engines, evaluators = [], []
+    deferred_route = False
     for g_lane in per_lane:
         eng = MCTSEngine(board, n_row, n_games=g_lane, n_playout=args.playouts, c_puct=C_PUCT, device=device,
                          game=args.game, add_noise=bool(args.noise), noise_seed=1000 * rank + len(engines),
@@ -616,6 +646,8 @@ def main():
             hip_ev.hip.set_algo(args.net_algo)
             hip_ev.hip.set_heads_algo(heads_algo)
             hip_ev.hip.set_max_workgroups(trunk_wgs)
+            hip_ev.deferred_priors = bool(args.deferred)
+            deferred_route = hip_ev.deferred_ok(eng)
             ev = TimedEvaluator(hip_ev, torch,
                                 {'winograd_f4': 'k_trunk_wino_f4<4>',
                                  'split_f16': 'k_trunk_rows' if (args.game == 'gomoku' and 11 <= board <= 16) else 'k_trunk_split',
@@ -837,6 +869,9 @@ def main():
                        ('' if args.in_flight <= 1 else ', %d simulations in flight per tree (opt-in virtual loss)' % args.in_flight),
                        'multi_sim': {'sims_in_flight': max(1, args.in_flight)},
                        'dirichlet_noise': bool(args.noise), 'sims_per_graph': args.graph,
+                       'priors': 'deferred (one policy GEMM + one priors kernel per move, outside the chain of a simulation step)'
+                       if deferred_route else 'written by every tree step',
+                       'launches_per_step': 2 if deferred_route else 3,
                        'hw_queues': int(os.environ.get('GPU_MAX_HW_QUEUES', '4')),   # hardware queues asked of the HIP runtime (a lane each)
                        'parallelism': 'games sharded, dp%d' % world},
             'regions_sims_per_sec': [round(r[1] / r[0], 1) for r in regions], 'warmup_moves_run': n_ramp,
@@ -891,15 +926,17 @@ def main():
             # the two small kernels of a simulation step, bracketed the same way
             fc = [x.elapsed_time(y) for ev in evaluators for x, y in ev.fc_events]
             tr = [x.elapsed_time(y) for ev in evaluators for x, y in ev.tree_events]
-            if fc and tr:
-                fc_ms, tr_ms = sum(fc) / len(fc), sum(tr) / len(tr)
+            if tr:
+                fc_ms, tr_ms = (sum(fc) / len(fc)) if fc else None, sum(tr) / len(tr)
                 per_sim = tree_bytes_per_sim(365.5, 208.8, 1.74) if (args.game == 'gomoku' and board == 15) else None
-                line['small_kernels'] = {'heads_gemm_ms': round(fc_ms, 4), 'tree_step_ms': round(tr_ms, 4), 'launches_timed': len(tr)}
+                # (deferred priors: no FC GEMM inside a step -- heads_gemm_ms is None; the tree step finishes the value head itself)
+                line['small_kernels'] = {'heads_gemm_ms': round(fc_ms, 4) if fc else None, 'tree_step_ms': round(tr_ms, 4),
+                                         'launches_timed': len(tr)}
                 if per_sim:
                     # (PUCT scans all children at every level: the same formula with the counts of that rule)
                     gbs = per_sim * boards_per_launch / (tr_ms * 1e-3) / 1e9
                     line['roofline_tree'] = {
-                        'bound': 'hbm', 'kernel': 'k_tree_step_raw, %d games per launch' % boards_per_launch,
+                        'bound': 'hbm', 'kernel': '%s, %d games per launch' % ('k_tree_step_def' if deferred_route else 'k_tree_step_raw', boards_per_launch),
                         'achieved': round(gbs, 2), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 5),
                         'traffic': pmc_traffic('k_tree_step', pmc_key),
                         'avg_launch_ms': round(tr_ms, 4)}

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 21
+#define RZ_ABI_VERSION 22
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 #define RZ_MAX_IN_FLIGHT 16 /* rz_config.sims_in_flight */
@@ -247,6 +247,47 @@ typedef struct rz_raw_heads {
 int rz_expand_backup_raw(rz_engine *e, const rz_raw_heads *heads, void *stream);
 int rz_tree_step_raw(rz_engine *e, const rz_raw_heads *heads, float *d_obs, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * DEFERRED PRIORS (RZ_SCORE_UCT_REF, one simulation in flight per tree).  The reference's selection rule
+ * (node.py:32-42,75-88) never reads TreeNode.prior: what the NEXT simulation of a tree depends on is the leaf VALUE
+ * alone (alphazero_mcts.py:59-71).  So the policy half of policy_value_fn (alphazero_agent.py:41-45: act_fc1,
+ * log_softmax, exp) and TreeNode.expand's priors with their Dirichlet noise (node.py:44-73) need not sit between two
+ * simulations: the tree step of this route finishes the value head, reserves the expanded node's prior block (same
+ * offsets as the other routes), backs up and selects; the leaf's policy features wait in a per-step store and ALL
+ * priors of a search are written by one batched GEMM + one kernel before anything reads them (tree reuse, read-outs).
+ * Every number stored is the one the other routes store, except that the value head's first layer is summed in f32 by
+ * the game's own workgroup (k ascending in eight slices) instead of by the FC GEMM: values agree to f32 rounding,
+ * not bit for bit.  A step of a lane is TWO launches (trunk, tree step) instead of three.
+ *
+ * rz_value_head: what the trunk of this route leaves for the tree step (rz_net_trunk_leaves_deferred). */
+typedef struct rz_value_head {
+    const float *valfeat; /* [rows][ld]: ReLU'd outputs of val_conv1, plane-major (2 x S), zero padded to ld */
+    const float *w1t;     /* val_fc1.weight as [groups][64 hidden units][4 inputs] (inputs zero padded to 4 * groups) */
+    const float *b1;      /* [64] val_fc1.bias */
+    const float *w2;      /* [64] val_fc2.weight */
+    const float *b2;      /* [1] */
+    int32_t ld;           /* = 4 * groups */
+    int32_t groups;       /* 64 or 128: eight waves of the game's workgroup x 8 or 16 groups */
+} rz_value_head;
+/* rz_deferred_logits: the policy logits of the stored leaves after rz_net_deferred_gemm: row = slot * rows_per_slot + leaf */
+typedef struct rz_deferred_logits {
+    const float *raw; /* [n_slots * rows_per_slot][ld], final (scaled, bias added): what k_heads_split leaves */
+    int32_t ld;
+    int32_t rows_per_slot;
+} rz_deferred_logits;
+/* Room for `slots` steps between two flushes (per game: a pending-expansion record of 80 bytes per slot).  Needs
+ * RZ_SCORE_UCT_REF and sims_in_flight == 1. */
+int rz_deferred_reserve(rz_engine *e, int32_t slots);
+/* int32 [n_games]: the store slot the NEXT leaf of each game goes to (= steps since the last flush); the trunk reads it */
+int rz_deferred_slots(rz_engine *e, const int32_t **d_slot_of_game);
+/* rz_expand_backup / rz_tree_step of this route (pair with rz_select_step(e, NULL, ..) + rz_net_trunk_leaves_deferred) */
+int rz_expand_backup_deferred(rz_engine *e, const rz_value_head *head, void *stream);
+int rz_tree_step_deferred(rz_engine *e, const rz_value_head *head, void *stream);
+/* Writes the priors of every expansion pending in slots [0, n_slots) -- exp(log_softmax) over the leaf's legal moves mixed
+ * with its Dirichlet noise: the operations of rz_expand_backup_raw -- and empties the slots.  Must run before
+ * rz_advance_roots / rz_set_roots / the prior read-outs; without pending slots a no-op. */
+int rz_deferred_flush(rz_engine *e, const rz_deferred_logits *logits, int32_t n_slots, void *stream);
+
 /* Root statistics after the simulations (AlphaZeroMCTS.simulate, alphazero_mcts.py:88-90):
  * visit count / W of the root child of every action, 0 for illegal or unvisited actions;
  * [n_games][B*B].  rz_root_stats: N and W of the roots themselves, [n_games]. */
@@ -372,6 +413,15 @@ int rz_net_trunk(rz_net *net, const float *d_obs, int32_t n_boards, float *d_fea
  * rz_select_step would have written. */
 int rz_net_trunk_leaves(rz_net *net, const uint64_t *d_stones, const int32_t *d_to_move, const int32_t *d_last_cell,
                         int32_t n_boards, void *stream);
+/* Deferred priors (see rz_value_head): room for `slots` steps of `max_boards` leaves in the policy-feature store
+ * (slots x ceil(max_boards / 32) tiles of f16 pieces) and for their logits. */
+int rz_net_deferred_reserve(rz_net *net, int32_t max_boards, int32_t slots);
+/* rz_net_trunk_leaves of the deferred route: board b's policy features go to slot d_slot_of_board[b] of the store, its
+ * value features (f32) to the rows of *out; no FC GEMM follows. */
+int rz_net_trunk_leaves_deferred(rz_net *net, const uint64_t *d_stones, const int32_t *d_to_move, const int32_t *d_last_cell,
+                                 int32_t n_boards, const int32_t *d_slot_of_board, rz_value_head *out, void *stream);
+/* act_fc1 (policy_value_net.py:43) over the stored leaves of slots [0, n_slots) as ONE GEMM (k_heads_split's arithmetic) */
+int rz_net_deferred_gemm(rz_net *net, int32_t n_boards, int32_t n_slots, rz_deferred_logits *out, void *stream);
 int rz_net_heads(rz_net *net, int32_t n_boards, float *d_logp, float *d_value, void *stream);
 /* only the FC GEMM of the heads on the internal features; returns the device pointers that
  * rz_tree_step_raw / rz_expand_backup_raw consume (valid until the next rz_net_reserve / load) */

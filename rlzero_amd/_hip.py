@@ -8,7 +8,7 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64,
                     c_void_p)
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
 MAX_IN_FLIGHT = 16
@@ -62,6 +62,17 @@ class RzRawHeads(Structure):
                 ('hid_part_stride', c_int64), ('ld', c_int32), ('n_parts', c_int32)]
 
 
+class RzValueHead(Structure):
+    """rz_value_head: what the trunk of the deferred-priors route leaves for the tree step (device pointers)."""
+    _fields_ = [('valfeat', c_void_p), ('w1t', c_void_p), ('b1', c_void_p), ('w2', c_void_p), ('b2', c_void_p),
+                ('ld', c_int32), ('groups', c_int32)]
+
+
+class RzDeferredLogits(Structure):
+    """rz_deferred_logits: the policy logits of the stored leaves after rz_net_deferred_gemm."""
+    _fields_ = [('raw', c_void_p), ('ld', c_int32), ('rows_per_slot', c_int32)]
+
+
 class HipError(RuntimeError):
     pass
 
@@ -94,6 +105,11 @@ _SIGNATURES = {
     'rz_tree_step': (c_int, [P, P, P, P, P]),
     'rz_expand_backup_raw': (c_int, [P, POINTER(RzRawHeads), P]),
     'rz_tree_step_raw': (c_int, [P, POINTER(RzRawHeads), P, P]),
+    'rz_deferred_reserve': (c_int, [P, c_int32]),
+    'rz_deferred_slots': (c_int, [P, POINTER(c_void_p)]),
+    'rz_expand_backup_deferred': (c_int, [P, POINTER(RzValueHead), P]),
+    'rz_tree_step_deferred': (c_int, [P, POINTER(RzValueHead), P]),
+    'rz_deferred_flush': (c_int, [P, POINTER(RzDeferredLogits), c_int32, P]),
     'rz_root_visits': (c_int, [P, P, P]),
     'rz_root_wsum': (c_int, [P, P, P]),
     'rz_root_priors': (c_int, [P, P, P]),
@@ -116,6 +132,9 @@ _SIGNATURES = {
     'rz_net_reserve': (c_int, [P, c_int32]),
     'rz_net_trunk': (c_int, [P, P, c_int32, P, P]),
     'rz_net_trunk_leaves': (c_int, [P, P, P, P, c_int32, P]),
+    'rz_net_deferred_reserve': (c_int, [P, c_int32, c_int32]),
+    'rz_net_trunk_leaves_deferred': (c_int, [P, P, P, P, c_int32, P, POINTER(RzValueHead), P]),
+    'rz_net_deferred_gemm': (c_int, [P, c_int32, c_int32, POINTER(RzDeferredLogits), P]),
     'rz_net_heads': (c_int, [P, c_int32, P, P, P]),
     'rz_net_heads_gemm': (c_int, [P, c_int32, POINTER(RzRawHeads), P]),
     'rz_net_forward': (c_int, [P, P, c_int32, P, P, P]),

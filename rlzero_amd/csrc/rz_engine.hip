@@ -79,6 +79,12 @@ struct Dev {
     uint64_t *noise_key;   // per game: the key of its Dirichlet stream (default: noise_seed ^ game << 20; rz_set_noise_keys)
     uint64_t noise_seed;
     int add_noise;
+    // deferred priors (rz_deferred_reserve): pend[g] = records of game g since the last flush = the store slot of its next leaf;
+    // record (slot, g): the prior block reserved for the node expanded in that step (-1: none), the counter of its noise
+    // stream, the leaf's board
+    int pend_cap;
+    int32_t *pend, *pend_pb, *pend_ctr;
+    uint64_t *pend_stones;
     uint64_t valid[kWords];
 };
 
@@ -655,6 +661,8 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
 // then log_softmax over the A policy logits and value = tanh(hid . w2 + b2), the work of k_heads_finish
 // (rz_net.hip), operation for operation, so every route gives identical bits.
 typedef rz_raw_heads RawHeads;
+typedef rz_value_head ValueHead;
+constexpr int kDefWaves = 4;   // waves of a game's workgroup: all sum a quarter of the value head's first layer (k_tree_step_def), wave 0 is the game's
 
 // ------------------------------------------------------------------ EXPAND + BACKUP
 // PROBS: `logp` already holds probabilities (host evaluators hand over the callable's exact
@@ -664,10 +672,16 @@ typedef rz_raw_heads RawHeads;
 // counts this visit (N += 1 at selection) and carries its virtual loss, so the backup adds x + 1 to W and leaves N
 // alone; whether the leaf is expanded is decided from its CURRENT record (an earlier slot of the same step may have
 // expanded it already).
-template <typename VT, bool PROBS = false, bool RAW = false, bool VL = false>
+// DEF (deferred priors, rz_value_head in include/rlzero_hip.h; RZ_SCORE_UCT_REF, K = 1): `def_value` is the leaf value the
+// game's workgroup has just finished (value_head_def below); an expansion reserves its prior block and leaves a record
+// (block, noise counter, board) in slot pend[g] -- the priors themselves are written by k_deferred_priors at the next flush
+// -- and every active game moves on to the next slot.
+template <typename VT, bool PROBS = false, bool RAW = false, bool VL = false, bool DEF = false>
 __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *logp, const VT *value, int g,
-                                                   int lane, RawHeads rh = RawHeads(), int j = 0) {
+                                                   int lane, RawHeads rh = RawHeads(), int j = 0, ValueHead vh = ValueHead(),
+                                                   float (*part)[kWave] = nullptr) {
     const int gk = VL ? g * E.K + j : g;
+    const int slot = DEF ? E.pend[g] : 0;
     // loads first, the test of `active` after them (see select_body)
     const bool act = E.active[g] != 0;
     const int arena = E.cur_arena[g];
@@ -729,12 +743,29 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
         h = wave_sum(h, lane);
         raw_value = tanhf(h + b2);
     }
+    float def_value = 0.0f;
+    if (DEF) {
+        // the worker waves' slices of val_fc1 (value_slice_def) meet here, behind this wave's own first loads: added in slice
+        // order, then the bias, ReLU, val_fc2 over the wave (the order of wave_sum) and tanh (policy_value_net.py:47-51)
+        const float b1 = vh.b1[lane], w2 = vh.w2[lane], b2 = vh.b2[0];
+        __syncthreads();
+        float hid = part[0][lane];
+#pragma unroll
+        for (int q = 1; q < kDefWaves; ++q) hid += part[q][lane];
+        hid = fmaxf(hid + b1, 0.0f);
+        def_value = tanhf(wave_sum(hid * w2, lane) + b2);
+    }
     if (!act) return;
     int4 *R = arena_records(E, g, arena);
     float *P = arena_priors(E, g, arena);
 
     // the reference evaluates terminal leaves too and discards the result (:59-68)
-    const double v = term ? leaf_tval : (RAW ? (double)raw_value : (double)value[gk]);
+    const double v = term ? leaf_tval : (DEF ? (double)def_value : RAW ? (double)raw_value : (double)value[gk]);
+    if (DEF && slot >= E.pend_cap) {   // the host flushes before the slots run out: never reached
+        flag(E, g, RZ_FLAG_INTERNAL, lane);
+        return;
+    }
+    const long long rec = DEF ? (long long)slot * E.n_games + g : 0;
 
     int new_fc = -1, new_nv = 0, new_k = 0, new_cap = 0, new_pb = -1;
     bool expand_now = !term && fresh != 2;
@@ -748,7 +779,7 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
         for (int j = 0; j < kWords; ++j) occ[j] = st[0][j] | st[1][j];
         const Legal L = legal_of(E, occ, lane);
         const int k = L.k;
-        const bool dense = E.score_mode == RZ_SCORE_PUCT;
+        const bool dense = !DEF && E.score_mode == RZ_SCORE_PUCT;
         const int top = dense ? top_now : 0;
         if ((long long)ptop + k > E.pcap || nblk >= E.qcap) {
             flag(E, g, RZ_FLAG_BLOCKS_FULL, lane);
@@ -767,9 +798,19 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
                 E.nblk[g] = nblk + 1;
                 if (dense) E.top[g] = top + k;
             }
+            if (DEF) {
+                // the block is reserved, its priors come at the next flush: what k_deferred_priors needs to write them
+                if (lane == 0) {
+                    E.pend_pb[rec] = ptop;
+                    E.pend_ctr[rec] = noise_ctr;
+                    if (E.add_noise) E.noise_ctr[g] = noise_ctr + 1;
+                }
+                store_board(E.pend_stones, (int)rec, st, lane);
+            }
             // TreeNode.expand: one child per legal move, prior from the policy head; in self-play
             // mixed with Dirichlet(0.3) noise at EVERY expanded node (node.py:63-69)
             const float uniform = 1.0f / (float)k;
+            if (!DEF) {
             int ranks[kWords];
             int before = 0;
 #pragma unroll
@@ -807,7 +848,12 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
                     R[2 * (top + r) + 1] = make_hi(0.0, -1, prior);
                 }
             }
+            }  // !DEF
         }
+    }
+    if (DEF && lane == 0) {
+        if (new_pb < 0) E.pend_pb[rec] = -1;   // nothing expanded in this step (a terminal leaf, a full arena)
+        E.pend[g] = slot + 1;
     }
 
     // TreeNode.update_recursive(-leaf_value): leaf gets -v, its parent +v, ... (node.py:135-144)
@@ -863,6 +909,135 @@ __global__ __launch_bounds__(kWave) void k_tree_step_raw(Dev E, RawHeads rh, flo
     expand_backup_body<float, false, true>(E, nullptr, nullptr, blockIdx.x, threadIdx.x, rh);
     __syncthreads();
     select_body<false>(E, obs, blockIdx.x, threadIdx.x);
+}
+
+// ------------------------------------------------------------------ deferred priors
+// The first layer of the value head of the game's leaf (val_fc1, policy_value_net.py:48) by the four waves of the game's
+// workgroup -- one per SIMD, each small enough (<= 112 registers) to sit beside a wave of the trunk, whose workgroup holds
+// 400 of a SIMD's 512: wave q sums K-quarter q (2 x PER groups of 4 inputs) into hidden unit `lane` in f32, k ascending, even
+// and odd k in two chains.  PER 16-byte weight loads of a wave are in flight together (4 x PER x 1 KB: the layer in TWO memory
+// round trips); the quarters meet in LDS (expand_backup_body<DEF>), where wave 0 -- the game's wave -- goes on alone.  The input
+// row is uniform over the wave: the constant address space makes its loads scalar.
+template <int PER>
+__device__ __forceinline__ void value_quarter_def(const ValueHead &vh, int gk, int lane, int q, float (*part)[kWave]) {
+    typedef float vec4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) vec4 *uniform_row;
+    const vec4 *w = reinterpret_cast<const vec4 *>(vh.w1t) + (size_t)q * 2 * PER * kWave + lane;
+    const uniform_row f = (uniform_row)(reinterpret_cast<const vec4 *>(vh.valfeat + (size_t)gk * vh.ld) + q * 2 * PER);
+    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        vec4 wv[PER], fv[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            wv[i] = w[(size_t)(half * PER + i) * kWave];
+            fv[i] = f[half * PER + i];
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            a0 = fmaf(fv[i].x, wv[i].x, a0);
+            a1 = fmaf(fv[i].y, wv[i].y, a1);
+            a0 = fmaf(fv[i].z, wv[i].z, a0);
+            a1 = fmaf(fv[i].w, wv[i].w, a1);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // (the second half's loads are not hoisted over the first half's sums: registers)
+    }
+    part[q][lane] = a0 + a1;
+}
+
+template <int PER>
+__global__ __launch_bounds__(kWave * kDefWaves) void k_expand_backup_def(Dev E, ValueHead vh) {
+    __shared__ float part[kDefWaves][kWave];
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    value_quarter_def<PER>(vh, blockIdx.x, lane, wave, part);
+    if (wave != 0) {
+        __syncthreads();
+        return;
+    }
+    expand_backup_body<float, false, false, false, true>(E, nullptr, nullptr, blockIdx.x, lane, RawHeads(), 0, vh, part);
+}
+
+// (`obs` is always NULL on this route -- the trunk reads positions -- but stays a run-time argument: with the constant hipcc
+// schedules the selection into 115 registers instead of 107, and 112 is what a SIMD has left beside a wave of the trunk)
+template <int PER>
+__global__ __launch_bounds__(kWave * kDefWaves) void k_tree_step_def(Dev E, ValueHead vh, float *obs) {
+    __shared__ float part[kDefWaves][kWave];
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    value_quarter_def<PER>(vh, blockIdx.x, lane, wave, part);
+    if (wave != 0) {
+        __syncthreads();
+        return;
+    }
+    expand_backup_body<float, false, false, false, true>(E, nullptr, nullptr, blockIdx.x, lane, RawHeads(), 0, vh, part);
+    __syncthreads();   // (wave 0's alone: the other waves have ended)
+    select_body<false>(E, obs, blockIdx.x, lane);
+}
+
+// The flush: the priors of the node expanded in step `slot` of game g -- exp(log_softmax) of the leaf's logits over its legal
+// moves, mixed with the Dirichlet noise of counter pend_ctr: expand_backup_body<RAW>'s operations on the same numbers (the
+// logits are final: k_heads_split's epilogue), into the block that step reserved.  grid = (games, slots).
+__global__ __launch_bounds__(kWave) void k_deferred_priors(Dev E, const float *__restrict__ raw, int ld, long long rows_per_slot) {
+    const int g = blockIdx.x, slot = blockIdx.y, lane = threadIdx.x;
+    if (slot >= E.pend[g]) return;
+    const long long rec = (long long)slot * E.n_games + g;
+    const int pb = E.pend_pb[rec];
+    if (pb < 0) return;
+    const int ctr = E.pend_ctr[rec];
+    uint64_t st[2][kWords];
+    load_board(E.pend_stones, (int)rec, st);
+    const float *r = raw + ((size_t)slot * rows_per_slot + g) * ld;
+    float x[kWords];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < kWords; ++i) {
+        const int j = lane + 64 * i;
+        x[i] = j < E.A ? r[j] : -INFINITY;
+        mx = fmaxf(mx, x[i]);
+    }
+    mx = wave_max(mx, lane);
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kWords; ++i) sum += (lane + 64 * i < E.A) ? expf(x[i] - mx) : 0.0f;
+    sum = wave_sum(sum, lane);
+    const float lse = mx + logf(sum);
+    float *P = arena_priors(E, g, E.cur_arena[g]);
+    uint64_t occ[kWords];
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) occ[j] = st[0][j] | st[1][j];
+    const Legal L = legal_of(E, occ, lane);
+    int ranks[kWords];
+    int before = 0;
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) ranks[j] = lane_action_rank(E, occ, L, j, lane, before);
+    float noise[kWords] = {0.f, 0.f, 0.f, 0.f};
+    float noise_sum = 1.0f;
+    if (E.add_noise) {
+        const uint64_t key = mix64(mix64(E.noise_key[g]) ^ (uint64_t)ctr);
+        float local = 0.0f;
+#pragma unroll
+        for (int j = 0; j < kWords; ++j)
+            if (ranks[j] >= 0) {
+                noise[j] = gamma03(hash32((uint32_t)key ^ (uint32_t)(key >> 32)) + 0x9E3779B9u * (uint32_t)(64 * j + lane + 1));
+                local += noise[j];
+            }
+        local = wave_sum(local, lane);
+        noise_sum = local > 0.0f ? local : 1.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) {
+        const int rk = ranks[j];
+        if (rk < 0) continue;
+        float prior = expf(x[j] - lse);
+        if (E.add_noise) prior = 0.75f * prior + 0.25f * (noise[j] / noise_sum);
+        P[pb + rk] = prior;
+    }
+}
+
+__global__ void k_deferred_reset(Dev E) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < E.n_games) E.pend[g] = 0;
 }
 
 // EXPAND + BACKUP of simulation s and SELECT + STEP of simulation s+1 in one launch (same
@@ -2229,6 +2404,76 @@ int rz_expand_backup_raw(rz_engine *e, const rz_raw_heads *heads, void *stream) 
     }
     k_expand_backup_raw<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, rh);
     return launched("k_expand_backup_raw");
+}
+
+static int deferred_ok(rz_engine *e, const rz_value_head *h) {
+    if (h == nullptr || !h->valfeat || !h->w1t || !h->b1 || !h->w2 || !h->b2) return fail(RZ_ERR_ARG, "rz_value_head: NULL pointer");
+    if ((h->groups != 16 * kDefWaves && h->groups != 32 * kDefWaves) || h->ld != 4 * h->groups)
+        return fail(RZ_ERR_ARG, "rz_value_head: groups = %d must be %d or %d and ld = 4 * groups", h->groups, 16 * kDefWaves, 32 * kDefWaves);
+    if (e->dev.pend_cap <= 0) return fail(RZ_ERR_ARG, "call rz_deferred_reserve first");
+    return RZ_OK;
+}
+
+int rz_deferred_reserve(rz_engine *e, int32_t slots) {
+    int rc = check_engine(e);
+    if (rc != RZ_OK) return rc;
+    if (slots < 1) return fail(RZ_ERR_ARG, "rz_deferred_reserve: slots must be positive");
+    if (e->cfg.score_mode != RZ_SCORE_UCT_REF || e->dev.K != 1)
+        return fail(RZ_ERR_ARG, "deferred priors need RZ_SCORE_UCT_REF (the rule that never reads a prior) and sims_in_flight == 1");
+    if (slots <= e->dev.pend_cap) return RZ_OK;
+    RZ_HIP(hipDeviceSynchronize());
+    const long long G = e->cfg.n_games;
+    // (the records of a smaller reservation stay allocated until rz_destroy: reservations grow once or twice in a process)
+    if ((rc = dev_alloc(e, &e->dev.pend_pb, (long long)slots * G)) != RZ_OK) return rc;
+    if ((rc = dev_alloc(e, &e->dev.pend_ctr, (long long)slots * G)) != RZ_OK) return rc;
+    if ((rc = dev_alloc(e, &e->dev.pend_stones, (long long)slots * G * 2 * kWords)) != RZ_OK) return rc;
+    if (e->dev.pend == nullptr) {
+        if ((rc = dev_alloc(e, &e->dev.pend, G)) != RZ_OK) return rc;
+    }
+    RZ_HIP(hipMemset(e->dev.pend, 0, (size_t)G * sizeof(int32_t)));
+    e->dev.pend_cap = slots;
+    return RZ_OK;
+}
+
+int rz_deferred_slots(rz_engine *e, const int32_t **d_slot_of_game) {
+    int rc = check_engine(e);
+    if (rc != RZ_OK) return rc;
+    if (!d_slot_of_game) return fail(RZ_ERR_ARG, "NULL output pointer");
+    if (e->dev.pend_cap <= 0) return fail(RZ_ERR_ARG, "call rz_deferred_reserve first");
+    *d_slot_of_game = e->dev.pend;
+    return RZ_OK;
+}
+
+int rz_expand_backup_deferred(rz_engine *e, const rz_value_head *head, void *stream) {
+    int rc = check_engine(e);
+    if (rc != RZ_OK) return rc;
+    if ((rc = deferred_ok(e, head)) != RZ_OK) return rc;
+    if (head->groups == 16 * kDefWaves) k_expand_backup_def<8><<<per_game(e), dim3(kWave * kDefWaves), 0, as_stream(stream)>>>(e->dev, *head);
+    else k_expand_backup_def<16><<<per_game(e), dim3(kWave * kDefWaves), 0, as_stream(stream)>>>(e->dev, *head);
+    return launched("k_expand_backup_def");
+}
+
+int rz_tree_step_deferred(rz_engine *e, const rz_value_head *head, void *stream) {
+    int rc = check_engine(e);
+    if (rc != RZ_OK) return rc;
+    if ((rc = deferred_ok(e, head)) != RZ_OK) return rc;
+    e->n_select += 1;
+    if (head->groups == 16 * kDefWaves) k_tree_step_def<8><<<per_game(e), dim3(kWave * kDefWaves), 0, as_stream(stream)>>>(e->dev, *head, nullptr);
+    else k_tree_step_def<16><<<per_game(e), dim3(kWave * kDefWaves), 0, as_stream(stream)>>>(e->dev, *head, nullptr);
+    return launched("k_tree_step_def");
+}
+
+int rz_deferred_flush(rz_engine *e, const rz_deferred_logits *logits, int32_t n_slots, void *stream) {
+    int rc = check_engine(e);
+    if (rc != RZ_OK) return rc;
+    if (e->dev.pend_cap <= 0 || n_slots <= 0) return RZ_OK;
+    if (!logits || !logits->raw) return fail(RZ_ERR_ARG, "rz_deferred_logits: NULL pointer");
+    if (n_slots > e->dev.pend_cap) return fail(RZ_ERR_ARG, "more slots than rz_deferred_reserve()d");
+    if (logits->ld < e->dev.A || logits->rows_per_slot < e->cfg.n_games) return fail(RZ_ERR_ARG, "rz_deferred_logits: rows shorter than the batch");
+    k_deferred_priors<<<dim3((unsigned)e->cfg.n_games, (unsigned)n_slots), dim3(kWave), 0, as_stream(stream)>>>(
+        e->dev, logits->raw, logits->ld, (long long)logits->rows_per_slot);
+    k_deferred_reset<<<flat_grid(e), dim3(256), 0, as_stream(stream)>>>(e->dev);
+    return launched("k_deferred_priors");
 }
 
 int rz_tree_step_raw(rz_engine *e, const rz_raw_heads *heads, float *d_obs, void *stream) {

@@ -1545,10 +1545,20 @@ __device__ __forceinline__ void conv_r(const char *in, const void *wts, int lane
 // step or FC GEMM (112 / 104 registers) fits beside a trunk wave on the same SIMD (512 registers): at 400 registers or fewer the
 // trunk leaves that room, at 408 it does not and the lanes' kernels take turns (measured: 10.7 -> 9.5 M sims/s from 8 registers).
 // Left alone hipcc allocates 396 .. 420 here depending on details of the prologue; the cap holds it at 372, no scratch.
+// Deferred priors (rz_value_head, include/rlzero_hip.h): where a board's features go when no FC GEMM follows the trunk -- the policy
+// pieces into slot slot_of[board] of a store of `slot_halfs` f16 values per slot (tiles of groups_act K-steps), the value head's
+// inputs as f32 rows of vf_ld floats.  slot_of == nullptr: the ordinary route.
+struct DeferredOut {
+    const int32_t *slot_of;
+    long long slot_halfs;
+    float *valfeat;
+    int vf_ld;
+};
+
 template <int NT, bool BITS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_trunk_rows(NetDev nd, const float *__restrict__ obs, LeafBits leaves,
                                                     float *__restrict__ feat, _Float16 *__restrict__ feat16,
-                                                    int n_boards, unsigned *__restrict__ flags) {
+                                                    int n_boards, unsigned *__restrict__ flags, DeferredOut later) {
 #ifdef RZ_NET_PROFILE
     const long long prof_k0 = __builtin_readcyclecounter();
     long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = prof_k0;
@@ -1828,6 +1838,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_t
         float *dst = feat ? feat + (size_t)board * nd.feat_ld : nullptr;  // null: only the f16 pieces are wanted
         _Float16 *dst16 = feat16 ? feat16 + ((size_t)(board >> 5) * (nd.groups_act + nd.groups_val) * 1024 + (board & 31) * 16)
                                  : nullptr;
+        const bool deferred = later.slot_of != nullptr;
+        float *vdst = nullptr;
+        if (deferred) {   // the policy pieces wait in the store (tiles of groups_act K-steps), the value inputs go on as f32
+            dst16 = feat16 + (size_t)later.slot_of[board] * later.slot_halfs + (size_t)(board >> 5) * nd.groups_act * 1024 + (board & 31) * 16;
+            vdst = later.valfeat + (size_t)board * later.vf_ld;
+        }
         if (tid < S) {
             const float *share = reinterpret_cast<const float *>(c1 + ((cell_y + 1) * kRowW + 1) * P1) + cell_x;
             float vsum[6];
@@ -1843,7 +1859,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_t
             for (int o = 0; o < 6; ++o) {
                 const float v = fmaxf(vsum[o] + hb[o], 0.0f);
                 if (dst) dst[(o < 4 ? o * S : nd.feat_val_off + (o - 4) * S) + cell] = v;
-                if (dst16) {
+                if (deferred && o >= 4) {
+                    vdst[(o - 4) * S + cell] = v;
+                } else if (dst16) {
                     const int k = (o < 4 ? o : o - 4) * S + cell;
                     const int step = (o < 4 ? 0 : nd.groups_act) + (k >> 4);
                     const float z = v * act3;
@@ -2336,6 +2354,13 @@ struct rz_net {
     unsigned *d_flags = nullptr;
     long long feat_boards = 0;
     size_t feat_floats = 0;
+    // deferred priors (rz_net_deferred_reserve): the policy-feature store, the logits of a flush, the value head's inputs
+    _Float16 *d_store16 = nullptr;
+    float *d_store_raw = nullptr, *d_valfeat = nullptr;
+    const float *d_w1t = nullptr;        // val_fc1.weight as [groups][64][4] (rz_value_head)
+    int vf_groups = 0;                    // K / 4 of the value head's first layer, padded to a multiple of 4
+    int store_slots = 0, store_tiles = 0; // slots x 32-board tiles per slot
+    long long store_boards = 0;
 };
 
 namespace {
@@ -2538,9 +2563,9 @@ std::vector<f32x4> pack_split_fc(const float *w, int n_out, int k_in, int tiles,
 
 template <int NT>
 static void launch_trunk_rows(bool bits, dim3 grid, hipStream_t stream, const NetDev &nd, const float *d_obs, LeafBits leaves, float *f32,
-                              _Float16 *f16, int n_boards, unsigned *flags) {
-    if (bits) k_trunk_rows<NT, true><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags);
-    else k_trunk_rows<NT, false><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags);
+                              _Float16 *f16, int n_boards, unsigned *flags, DeferredOut later = DeferredOut{nullptr, 0, nullptr, 0}) {
+    if (bits) k_trunk_rows<NT, true><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later);
+    else k_trunk_rows<NT, false><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later);
 }
 
 extern "C" {
@@ -2604,6 +2629,9 @@ int rz_net_destroy(rz_net *net) {
     if (net->d_raw) (void)hipFree(net->d_raw);
     if (net->d_hid) (void)hipFree(net->d_hid);
     if (net->d_flags) (void)hipFree(net->d_flags);
+    if (net->d_store16) (void)hipFree(net->d_store16);
+    if (net->d_store_raw) (void)hipFree(net->d_store_raw);
+    if (net->d_valfeat) (void)hipFree(net->d_valfeat);
     delete net;
     return RZ_OK;
 }
@@ -2731,6 +2759,13 @@ int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params) {
     }
     up_f(h_params[14], 64, &D.fc_val2_w);
     up_f(h_params[15], 1, &D.fc_val2_b);
+    {   // the value head's first layer for the tree step of the deferred route: [group of 4 inputs][hidden unit][4]
+        net->vf_groups = (2 * S + 3) / 4 <= 64 ? 64 : 128;   // eight waves x 8 or 16 groups (k_tree_step_def)
+        std::vector<float> t((size_t)net->vf_groups * 64 * 4, 0.0f);
+        for (int j = 0; j < 64; ++j)
+            for (int k = 0; k < 2 * S; ++k) t[((size_t)(k / 4) * 64 + j) * 4 + k % 4] = h_params[12][(size_t)j * 2 * S + k];
+        if (rc == RZ_OK) rc = net_upload(net, t, &net->d_w1t);
+    }
     net->loaded = rc == RZ_OK;
     return rc;
 }
@@ -2787,7 +2822,7 @@ int rz_net_reserve(rz_net *net, int32_t max_boards) {
 static bool rows_kernel_covers(int bh, int bw) { return bh >= 11 && bh <= 16 && bw >= 11 && bw <= 16; }
 
 static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t n_boards, void *stream,
-                         LeafBits leaves = LeafBits{nullptr, nullptr, nullptr}) {
+                         LeafBits leaves = LeafBits{nullptr, nullptr, nullptr}, DeferredOut later = DeferredOut{nullptr, 0, nullptr, 0}) {
     const dim3 grid((unsigned)n_boards);
     // the internal buffer uses the padded layout of the FC GEMM, a caller's buffer the natural one
     const bool internal = d_feat == net->d_feat;
@@ -2812,8 +2847,9 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
         k_trunk_wino_f4<4><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
     else if (algo == RZ_NET_SPLIT_F16)
     {
-        _Float16 *f16 = internal ? net->d_feat16 : nullptr;
-        float *f32 = want_f32 ? d_feat : nullptr;
+        _Float16 *f16 = later.slot_of ? net->d_store16 : internal ? net->d_feat16 : nullptr;
+        float *f32 = later.slot_of ? nullptr : want_f32 ? d_feat : nullptr;
+        if (later.slot_of) net->feat16_valid = net->feat32_valid = false;   // (nothing for rz_net_heads_gemm)
         const int tiles = (net->dev.BH + net->dev.tile_rows - 1) / net->dev.tile_rows;
         const bool bits = leaves.stones != nullptr;
         // Small batches of small boards (every board has a workgroup of its own, nothing of another lane to overlap with): the
@@ -2832,12 +2868,12 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
         if (net->algo == RZ_NET_SPLIT_F16 && rows_kernel_covers(net->dev.BH, net->dev.BW)) {   // wide boards: one N-tile per row
             const hipStream_t st = (hipStream_t)stream;
             switch (net->dev.BH) {
-                case 11: launch_trunk_rows<11>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags); break;
-                case 12: launch_trunk_rows<12>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags); break;
-                case 13: launch_trunk_rows<13>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags); break;
-                case 14: launch_trunk_rows<14>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags); break;
-                case 15: launch_trunk_rows<15>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags); break;
-                default: launch_trunk_rows<16>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags); break;
+                case 11: launch_trunk_rows<11>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later); break;
+                case 12: launch_trunk_rows<12>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later); break;
+                case 13: launch_trunk_rows<13>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later); break;
+                case 14: launch_trunk_rows<14>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later); break;
+                case 15: launch_trunk_rows<15>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later); break;
+                default: launch_trunk_rows<16>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later); break;
             }
         } else if (tiles <= 1)        // one tile: the four waves share the output channels
             k_trunk_split<1, 4><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, raw, hid);
@@ -2928,6 +2964,88 @@ int rz_net_trunk_leaves(rz_net *net, const uint64_t *d_stones, const int32_t *d_
         return net_fail(RZ_ERR_ARG, "rz_net_trunk_leaves needs the RZ_NET_SPLIT_F16 trunk (the others read float planes: rz_net_trunk)");
     launch_trunk(net, nullptr, net->d_feat, n_boards, stream, LeafBits{d_stones, d_to_move, d_last_cell});
     if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_trunk_split failed");
+    return RZ_OK;
+}
+
+static bool deferred_trunk_covers(const rz_net *net) {
+    return net->algo == RZ_NET_SPLIT_F16 && net->split_ok && rows_kernel_covers(net->dev.BH, net->dev.BW);
+}
+
+int rz_net_deferred_reserve(rz_net *net, int32_t max_boards, int32_t slots) {
+    int rc = net_ready(net, max_boards);
+    if (rc != RZ_OK) return rc;
+    if (slots < 1 || max_boards < 1) return net_fail(RZ_ERR_ARG, "rz_net_deferred_reserve: slots and max_boards must be positive");
+    if (max_boards <= net->store_boards && slots <= net->store_slots) return RZ_OK;
+    (void)hipDeviceSynchronize();
+    if (net->d_store16) (void)hipFree(net->d_store16);
+    if (net->d_store_raw) (void)hipFree(net->d_store_raw);
+    if (net->d_valfeat) (void)hipFree(net->d_valfeat);
+    net->d_store16 = nullptr;
+    net->d_store_raw = net->d_valfeat = nullptr;
+    net->store_boards = 0;
+    net->store_slots = 0;
+    const int tiles = ((max_boards + 63) / 64) * 2;   // whole 64-board blocks: the GEMM's workgroups take two tiles
+    const size_t store_bytes = (size_t)slots * tiles * net->dev.groups_act * 2048;
+    const size_t raw_bytes = (size_t)slots * tiles * 32 * net->dev.Npad * sizeof(float);
+    const size_t val_bytes = (size_t)tiles * 32 * net->vf_groups * 4 * sizeof(float);
+    if (hipMalloc((void **)&net->d_store16, store_bytes) != hipSuccess || hipMalloc((void **)&net->d_store_raw, raw_bytes) != hipSuccess ||
+        hipMalloc((void **)&net->d_valfeat, val_bytes) != hipSuccess)
+        return net_fail(RZ_ERR_OOM, "hipMalloc failed (deferred-priors store)");
+    // the K tail of a tile's last K-step, the rows of boards that do not exist and the padding of the value rows are never
+    // written: they must read as finite values (they meet zero weights, or rows nobody reads)
+    if (hipMemset(net->d_store16, 0, store_bytes) != hipSuccess || hipMemset(net->d_valfeat, 0, val_bytes) != hipSuccess)
+        return net_fail(RZ_ERR_HIP, "hipMemset failed (deferred-priors store)");
+    net->store_tiles = tiles;
+    net->store_slots = slots;
+    net->store_boards = max_boards;
+    return RZ_OK;
+}
+
+int rz_net_trunk_leaves_deferred(rz_net *net, const uint64_t *d_stones, const int32_t *d_to_move, const int32_t *d_last_cell,
+                                 int32_t n_boards, const int32_t *d_slot_of_board, rz_value_head *out, void *stream) {
+    int rc = net_ready(net, n_boards);
+    if (rc != RZ_OK) return rc;
+    if (!out) return net_fail(RZ_ERR_ARG, "NULL output pointer");
+    if (!deferred_trunk_covers(net))
+        return net_fail(RZ_ERR_ARG, "the deferred-priors route needs the RZ_NET_SPLIT_F16 trunk on a board of 11 .. 16 rows and columns");
+    if (n_boards > net->store_boards) return net_fail(RZ_ERR_ARG, "batch larger than rz_net_deferred_reserve()d");
+    if (n_boards > 0) {
+        if (!d_stones || !d_to_move || !d_last_cell || !d_slot_of_board) return net_fail(RZ_ERR_ARG, "NULL device pointer");
+        const DeferredOut later{d_slot_of_board, (long long)net->store_tiles * net->dev.groups_act * 1024, net->d_valfeat, net->vf_groups * 4};
+        launch_trunk(net, nullptr, net->d_feat, n_boards, stream, LeafBits{d_stones, d_to_move, d_last_cell}, later);
+        if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_trunk_rows failed");
+    }
+    memset(out, 0, sizeof(*out));
+    out->valfeat = net->d_valfeat;
+    out->w1t = net->d_w1t;
+    out->b1 = net->dev.fc_val1_b;
+    out->w2 = net->dev.fc_val2_w;
+    out->b2 = net->dev.fc_val2_b;
+    out->ld = net->vf_groups * 4;
+    out->groups = net->vf_groups;
+    return RZ_OK;
+}
+
+int rz_net_deferred_gemm(rz_net *net, int32_t n_boards, int32_t n_slots, rz_deferred_logits *out, void *stream) {
+    int rc = net_ready(net, n_boards);
+    if (rc != RZ_OK) return rc;
+    if (!out) return net_fail(RZ_ERR_ARG, "NULL output pointer");
+    if (n_slots < 0 || n_slots > net->store_slots || n_boards > net->store_boards)
+        return net_fail(RZ_ERR_ARG, "more slots / boards than rz_net_deferred_reserve()d");
+    if (n_slots > 0 && n_boards > 0) {
+        // the store is a list of n_slots * store_tiles tiles of groups_act K-steps each: k_heads_split's policy groups over all of
+        // them (64 boards x 128 outputs per workgroup, the K quarters over its four waves: the bits of every other shape)
+        NetDev nd = net->dev;
+        nd.groups_val = 0;   // a tile of the store holds the policy K-steps only
+        const int n_act_tiles = nd.Npad / 32;
+        const dim3 grid((unsigned)((size_t)n_slots * net->store_tiles / 2), (unsigned)((n_act_tiles + 3) / 4));
+        k_heads_split<2, 4, 3, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(
+            nd, reinterpret_cast<const f32x4 *>(net->d_store16), net->d_store_raw, nullptr, n_slots * net->store_tiles * 32);
+        if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_heads_split failed");
+    }
+    out->raw = net->d_store_raw;
+    out->ld = net->dev.Npad;
+    out->rows_per_slot = net->store_tiles * 32;
     return RZ_OK;
 }
 

@@ -125,6 +125,39 @@ class HipNet(object):
         stones, to_move, last = eng.leaf_buffers()
         check(self.lib.rz_net_trunk_leaves(self.handle, stones, to_move, last, n, self._stream()), 'rz_net_trunk_leaves')
 
+    # -- deferred priors (include/rlzero_hip.h: rz_value_head) -------------------------------------------------
+    def supports_deferred(self):
+        """True when this net's trunk can leave the policy features in a store and hand the tree step the value head's inputs
+        (rz_net_trunk_leaves_deferred): the 'split_f16' trunk on a board of 11 .. 16 rows and columns (k_trunk_rows)."""
+        return (getattr(self, 'algo', 'split_f16') == 'split_f16' and getattr(self, '_split_ok', True)
+                and 11 <= self.rows <= 16 and 11 <= self.cols <= 16)
+
+    def deferred_bytes_per_slot(self, n_boards):
+        """Device bytes one store slot (one simulation step of ``n_boards`` leaves) takes: f16 feature pieces + logits."""
+        tiles = (n_boards + 63) // 64 * 2
+        k_steps = (4 * self.n_cells + 15) // 16
+        n_pad = (self.n_actions + 31) // 32 * 32
+        return tiles * k_steps * 2048 + tiles * 32 * n_pad * 4
+
+    def deferred_reserve(self, n_boards, slots):
+        check(self.lib.rz_net_deferred_reserve(self.handle, int(n_boards), int(slots)), 'rz_net_deferred_reserve')
+
+    def trunk_leaves_deferred(self, eng):
+        """The trunk on the engine's current leaves: policy features into the store slot of each game, the value head's
+        inputs for the tree step -> RzValueHead."""
+        stones, to_move, last = eng.leaf_buffers()
+        out = _hip.RzValueHead()
+        check(self.lib.rz_net_trunk_leaves_deferred(self.handle, stones, to_move, last, eng.n_leaves, eng.deferred_slot_ptr(),
+                                                    ctypes.byref(out), self._stream()), 'rz_net_trunk_leaves_deferred')
+        return out
+
+    def deferred_gemm(self, n_boards, n_slots):
+        """act_fc1 over the stored leaves of slots [0, n_slots) as one GEMM -> RzDeferredLogits."""
+        out = _hip.RzDeferredLogits()
+        check(self.lib.rz_net_deferred_gemm(self.handle, int(n_boards), int(n_slots), ctypes.byref(out), self._stream()),
+              'rz_net_deferred_gemm')
+        return out
+
     def range_info(self):
         """What rz_net_load derived from the weights for the split-f16 trunk: bounds on the activations of conv1 /
         conv2 / the head features for observation planes in [0, 1], the power-of-two scales their f16 pieces are
@@ -246,10 +279,22 @@ class HipNetEvaluator(object):
     trunk reads the leaf POSITIONS (the engine's bitboards) and ``needs_obs`` is False: no observation planes are
     written or read; the f32 trunks and the un-fused ``__call__`` route take the float planes."""
     fused_heads = True
+    # Deferred priors (RZ_SCORE_UCT_REF, one simulation in flight, boards of 11 .. 16 rows): a simulation step is trunk ->
+    # tree step; the policy half of the evaluation and the priors of the expanded nodes are written in one batch before
+    # anything reads them (MCTSEngine.flush_deferred).  False: the three-launch route (trunk -> FC GEMM -> tree step).
+    deferred_priors = True
 
     @property
     def needs_obs(self):
         return not (self.use_positions and self.hip.reads_positions())
+
+    def deferred_ok(self, eng):
+        """Whether ``eng``'s simulation steps take the deferred-priors route with this evaluator."""
+        return (self.deferred_priors and self.use_positions and eng.score_mode == _hip.SCORE_UCT_REF and eng.sims_in_flight == 1
+                and self.hip.supports_deferred())
+
+    def deferred_trunk(self, eng):
+        return self.hip.trunk_leaves_deferred(eng)
 
     def raw_heads(self, eng):
         if not self.needs_obs:
@@ -279,6 +324,11 @@ class HipNetEvaluator(object):
             return marks, tuple(t.stack([flat.sum(), (flat * ramp).sum()]).tolist())
 
     def refresh(self):
+        for eng in list(getattr(self, '_deferring', ())):   # stored features belong to the weights they were computed with
+            if eng._def_pending > 0 and eng._def_ev is self:   # (rare: a search still pending when the learner steps)
+                self.hip.torch.cuda.synchronize(self.hip.device)
+                eng.flush_deferred()
+                self.hip.torch.cuda.synchronize(self.hip.device)
         self.hip.load_state_dict(self.module.state_dict())
         self._seen = self._fingerprint()
         self._seen_content = self._fingerprint(content=True)[1]
@@ -414,6 +464,9 @@ class MCTSEngine(object):
         self.noise_mask = torch.zeros(G, dtype=torch.uint8, **kw)
         self.active_host = np.ones(G, dtype=np.uint8)
         self._graphs = {}
+        # deferred priors: the evaluator whose store holds this engine's pending leaves, steps since the last flush, capacity
+        self._def_ev, self._def_pending, self._def_slots, self._def_slot_ptr, self._capturing = None, 0, 0, None, False
+        self.deferred_max_bytes = 6 << 30   # cap of an evaluator's store + logits (a flush every slots steps when n_playout needs more)
 
     # ------------------------------------------------------------------ plumbing
     def stream(self):
@@ -453,6 +506,7 @@ class MCTSEngine(object):
     def set_roots(self, stones, to_move, last_move, mask=None, reset_trees=False):
         """stones: uint64 [G,2,WORDS]; to_move / last_move: int [G]; mask: bool [G] or None."""
         t = self.torch
+        self.flush_deferred()   # (pending priors belong to the trees as they are)
         self.stones.copy_(t.from_numpy(np.ascontiguousarray(stones, dtype=np.uint64).view(np.int64)))
         self.to_move.copy_(t.from_numpy(np.ascontiguousarray(to_move, dtype=np.int32)))
         self.last_move.copy_(t.from_numpy(np.ascontiguousarray(last_move, dtype=np.int32)))
@@ -542,6 +596,10 @@ class MCTSEngine(object):
         if n <= 0:
             return
         K = self.sims_in_flight
+        ok = getattr(evaluator, 'deferred_ok', None)
+        deferred = ok is not None and ok(self)
+        if not deferred:
+            self.flush_deferred()   # (an evaluator of another route takes over: its expansions write their priors at once)
         if isinstance(evaluator, HostEvaluator):
             if K > 1:
                 raise HipError('host evaluators are not available with sims_in_flight > 1')
@@ -552,6 +610,8 @@ class MCTSEngine(object):
         begin = getattr(evaluator, 'begin_chunk', None)  # optional evaluator hook (bench.py's timing wrapper)
         if begin is not None:
             begin()
+        if deferred:
+            return self._sim_chunk_deferred(evaluator, n)
         obs = _ptr(self.obs) if getattr(evaluator, 'needs_obs', True) else None
         steps = -(-n // K)
         counts = [min(K, n - i * K) for i in range(steps)] + [0]  # slots in flight in step i
@@ -578,6 +638,66 @@ class MCTSEngine(object):
                 check(lib.rz_expand_backup(h, _ptr(logp), _ptr(value), self.stream()), 'rz_expand_backup')
         if K > 1:
             self._in_flight(K, K)
+
+    # ------------------------------------------------------------------ deferred priors
+    def deferred_slot_ptr(self):
+        if self._def_slot_ptr is None:
+            p = ctypes.c_void_p()
+            check(self.lib.rz_deferred_slots(self.handle, ctypes.byref(p)), 'rz_deferred_slots')
+            self._def_slot_ptr = p
+        return self._def_slot_ptr
+
+    def _deferred_begin(self, evaluator, n):
+        """Before ``n`` more steps on the deferred route: the store of ``evaluator`` holds this engine's pending leaves (another
+        evaluator's are flushed first), reserved once for min(n_playout, what deferred_max_bytes allows) steps; a flush when the
+        coming steps would not fit.  -> steps that may be enqueued now (<= n)."""
+        if self._def_ev is not evaluator:
+            self.flush_deferred()
+            hip = evaluator.hip
+            per_slot = hip.deferred_bytes_per_slot(self.n_leaves) + 80 * self.n_games
+            slots = int(max(16, min(max(self.n_playout, 16), self.deferred_max_bytes // per_slot)))
+            if slots > self._def_slots:
+                check(self.lib.rz_deferred_reserve(self.handle, slots), 'rz_deferred_reserve')
+                self._def_slots = slots
+                self._def_slot_ptr = None
+            hip.deferred_reserve(self.n_leaves, self._def_slots)
+            self._def_ev = evaluator
+            refs = getattr(evaluator, '_deferring', None)
+            if refs is None:
+                import weakref
+                refs = evaluator._deferring = weakref.WeakSet()
+            refs.add(self)
+        if self._capturing:
+            return n
+        if self._def_pending + min(n, self._def_slots) > self._def_slots:
+            self.flush_deferred()
+        return min(n, self._def_slots - self._def_pending)
+
+    def _sim_chunk_deferred(self, evaluator, n):
+        """sim_chunk on the deferred-priors route: per step the trunk (policy features into the step's store slot, value inputs
+        on) and ONE tree launch (value head, backup, next selection)."""
+        lib, h = self.lib, self.handle
+        while n > 0:
+            m = self._deferred_begin(evaluator, n)
+            check(lib.rz_select_step(h, None, self.stream()), 'rz_select_step')
+            for i in range(m):
+                head = evaluator.deferred_trunk(self)
+                if i + 1 < m:
+                    check(lib.rz_tree_step_deferred(h, ctypes.byref(head), self.stream()), 'rz_tree_step_deferred')
+                else:
+                    check(lib.rz_expand_backup_deferred(h, ctypes.byref(head), self.stream()), 'rz_expand_backup_deferred')
+            if not self._capturing:
+                self._def_pending += m
+            n -= m
+
+    def flush_deferred(self):
+        """Write the priors of every expansion since the last flush (one GEMM over the stored leaves + one kernel).  Called by
+        whatever reads priors or moves trees (advance, set_roots, root_priors, arena) and when the store is full."""
+        if self._def_pending <= 0 or self._def_ev is None:
+            return
+        logits = self._def_ev.hip.deferred_gemm(self.n_leaves, self._def_pending)
+        check(self.lib.rz_deferred_flush(self.handle, ctypes.byref(logits), self._def_pending, self.stream()), 'rz_deferred_flush')
+        self._def_pending = 0
 
     def _whole_steps(self, n_sims):
         """``n_sims`` rounded down to whole steps of K simulations (at least one step)."""
@@ -614,7 +734,13 @@ class MCTSEngine(object):
             raise HipError('call warm_graph(evaluator, %d) before simulate(use_graph=True)' % per)
         graph = self._graphs[key][0]
         full, rest = divmod(n, per)
+        ok = getattr(evaluator, 'deferred_ok', None)
+        deferred = ok is not None and ok(self)
         for _ in range(full):
+            if deferred:   # the replay writes `per` more slots of the store
+                if self._deferred_begin(evaluator, per) < per:
+                    raise HipError('the deferred-priors store (%d slots) is smaller than a graph of %d steps' % (self._def_slots, per))
+                self._def_pending += per
             graph.replay()
         self.sim_chunk(evaluator, rest)
 
@@ -634,15 +760,31 @@ class MCTSEngine(object):
             self.sim_chunk(evaluator, 3 * self.sims_in_flight)
         cur.wait_stream(side)
         t.cuda.synchronize(self.device)
+        self.flush_deferred()   # (the warm-up's leaves; a capture holds no flush: simulate() places them between replays)
         graph = t.cuda.CUDAGraph()
-        with t.cuda.graph(graph):
-            self.sim_chunk(evaluator, per)
+        self._capturing = True
+        try:
+            with t.cuda.graph(graph):
+                self.sim_chunk(evaluator, per)
+        finally:
+            self._capturing = False
         self._graphs[key] = (graph, evaluator)
         return graph
 
     # ------------------------------------------------------------------ read-out
     def root_visits(self):
         check(self.lib.rz_root_visits(self.handle, _ptr(self.visits), self.stream()), 'rz_root_visits')
+        if self._def_pending > 0:
+            # the visit counts do not wait for the priors: their copy is enqueued first, the flush runs while the host works on them
+            t = self.torch
+            if getattr(self, '_visits_host', None) is None:
+                self._visits_host = t.empty(self.visits.shape, dtype=self.visits.dtype, pin_memory=True)
+            self._visits_host.copy_(self.visits, non_blocking=True)
+            done = t.cuda.Event()
+            done.record(t.cuda.current_stream(self.device))
+            self.flush_deferred()
+            done.synchronize()
+            return self._visits_host.numpy().copy()
         return self.visits.cpu().numpy()
 
     def root_wsum(self):
@@ -650,6 +792,7 @@ class MCTSEngine(object):
         return self.wsum.cpu().numpy()
 
     def root_priors(self):
+        self.flush_deferred()
         check(self.lib.rz_root_priors(self.handle, _ptr(self.priors), self.stream()), 'rz_root_priors')
         return self.priors.cpu().numpy()
 
@@ -660,6 +803,7 @@ class MCTSEngine(object):
 
     def advance(self, moves):
         """update_with_move for every game: move >= 0 keep that subtree, -1 reset, -2 skip."""
+        self.flush_deferred()   # (the kept subtree's prior blocks are copied: they must be written)
         self.moves.copy_(self.torch.from_numpy(np.ascontiguousarray(moves, dtype=np.int32)))
         check(self.lib.rz_advance_roots(self.handle, _ptr(self.moves), self.stream()), 'rz_advance_roots')
 
@@ -676,6 +820,7 @@ class MCTSEngine(object):
         record, -1 = none yet), NV (visited children = child records in use), K (children, 0 = not
         expanded), PB (offset into PRI of the node's K child priors); the visited child r < NV of a node
         is slot FC + r and the prior of ANY child r < K is PRI[PB + r]."""
+        self.flush_deferred()
         st = self.stats()
         cap = int(st.arena_slots)
         n = np.zeros(cap, np.int32)

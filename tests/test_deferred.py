@@ -1,0 +1,226 @@
+"""The deferred-priors route (include/rlzero_hip.h: rz_value_head; RZ_SCORE_UCT_REF, one simulation in flight, boards of 11 .. 16
+rows): a simulation step is trunk -> tree step (value head, backup, next selection); the policy half of
+AlphaZeroAgent.policy_value_fn (alphazero_agent.py:41-45) and TreeNode.expand's priors (node.py:44-73) -- which the reference's
+selection rule never reads (node.py:32-42,75-88) -- are written in one batch before anything reads them.
+
+Pinned here: (1) the priors are, bit for bit, those of the route that writes them inside every tree step, the values agree with
+it to f32 rounding and with the reference's CPU outputs to 1e-4; (2) the trees are EXACTLY the oracle's when it is fed the values
+this route produces; (3) when the flushes happen -- store size, hipGraphs, tree reuse -- changes no bit."""
+import numpy as np
+import pytest
+
+from oracle import evaluators as ev
+from oracle.gomoku_ref import RefGomoku
+from oracle.mcts_ref import RefSearch, tree_dump
+
+pytestmark = pytest.mark.gpu
+
+
+def _positions(B, n, count, seed):
+    rs = np.random.RandomState(seed)
+    envs = [RefGomoku(B, n), RefGomoku.from_moves(B, n, [0])]
+    while len(envs) < count:  # random non-terminal mid-game positions, up to a nearly full board
+        e = RefGomoku(B, n)
+        for m in rs.permutation(B * B)[:rs.randint(0, B * B - 1)]:
+            e.step(int(m))
+            if e.game_end_winner()[0]:
+                break
+        if not e.game_end_winner()[0]:
+            envs.append(e)
+    return envs
+
+
+def _set_roots(eng, envs):
+    from rlzero_amd.engine import int_to_bits
+    stones = np.array([[int_to_bits(e.bitboards()[0]), int_to_bits(e.bitboards()[1])] for e in envs], dtype=np.uint64)
+    eng.set_roots(stones, [e.current_player() for e in envs], [e.last_move for e in envs], reset_trees=True)
+
+
+def _net(B, seed=None, g4=None):
+    import torch
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    net = PolicyValueNet(B)
+    if g4 is not None:
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in ev.numpy_weights(B, int(g4['B%d_seed' % B])).items()})
+    else:
+        torch.manual_seed(seed)
+        net = PolicyValueNet(B)
+    return net
+
+
+def _hex_tree(d):
+    return {k: (n, float(w).hex()) for k, (n, w) in d.items()}
+
+
+def _whole_tree(eng, game):
+    """Every visited node of a game's tree, by its path of child ranks: (N, W bits, K, the bits of its K child priors) -- what
+    the arena MEANS (reserved child slots that no visit has written yet hold whatever was there before)."""
+    ar = eng.arena(game)
+    out, stack = {}, [((), 0)]
+    while stack:
+        path, slot = stack.pop()
+        k, pb = int(ar['K'][slot]), int(ar['PB'][slot])
+        priors = ar['PRI'][pb:pb + k].view(np.uint32).tolist() if k > 0 else []
+        out[path] = (int(ar['N'][slot]), float(ar['W'][slot]).hex(), k, tuple(priors))
+        if k > 0:
+            assert len(priors) == k and all(np.isfinite(ar['PRI'][pb:pb + k])) and (ar['PRI'][pb:pb + k] > 0).all()
+            for r in range(int(ar['NV'][slot])):
+                stack.append((path + (r, ), int(ar['FC'][slot]) + r))
+    return out
+
+
+def test_deferred_priors_are_the_in_step_route_s_bits(g4):
+    """One expansion of 16 positions per board size on both routes: the priors (read after the flush) are the same bits -- the
+    policy GEMM over the store is k_heads_split on the same f16 pieces, the softmax and the noise the same operations --, the
+    values agree to f32 rounding (the value head's first layer is summed by the game's workgroup instead of the GEMM), and at
+    15 x 15 both agree with the reference's policy_value_fn output (1e-4).  Then three more simulations: same roots."""
+    from rlzero_amd.engine import HipNetEvaluator, MCTSEngine
+    for B, n, noise in ((15, 5, False), (15, 5, True), (11, 5, True), (13, 5, False), (16, 5, True)):
+        net = _net(B, seed=B, g4=g4 if B == 15 else None)
+        evaluator = HipNetEvaluator(net, B, 'cuda:0', max_boards=16)
+        envs = _positions(B, n, 16, seed=B)
+        got = {}
+        for deferred in (True, False):
+            evaluator.deferred_priors = deferred
+            eng = MCTSEngine(B, n, n_games=len(envs), n_playout=8, device='cuda:0', add_noise=noise, noise_seed=3)
+            assert evaluator.deferred_ok(eng) == deferred
+            _set_roots(eng, envs)
+            eng.sim_chunk(evaluator, 1)  # the first simulation expands every root
+            assert (eng._def_pending == 1) == deferred
+            pri = eng.root_priors().copy()  # (flushes)
+            assert eng._def_pending == 0
+            rn, rw = eng.root_stats()
+            assert (rn == 1).all()
+            eng.sim_chunk(evaluator, 3)
+            pri4 = eng.root_priors().copy()
+            rn4, _ = eng.root_stats()
+            eng.check()
+            got[deferred] = (pri, rw.copy(), pri4, rn4.copy())
+            eng.close()
+        assert np.array_equal(got[True][0].view(np.uint32), got[False][0].view(np.uint32)), B
+        assert np.array_equal(got[True][2].view(np.uint32), got[False][2].view(np.uint32)), B
+        assert np.max(np.abs(got[True][1] - got[False][1])) <= 2e-6 and (got[True][3] == 4).all()
+        for g, e in enumerate(envs):  # priors exist for the legal moves only
+            illegal = sorted(set(range(B * B)) - set(e.leagel_actions()))
+            assert not got[True][0][g][illegal].any() and 0.0 < got[True][0][g].astype(np.float64).sum() <= 1.0 + 1e-5
+        if B == 15 and not noise:
+            acts = [int(a) for a in g4['B15_pvf_acts']]
+            want_p, want_v = g4['B15_pvf_probs'].astype(np.float64), float(g4['B15_pvf_value'])
+            assert np.max(np.abs(got[True][0][1][acts].astype(np.float64) - want_p)) <= 1e-4
+            assert abs(-got[True][1][1] - want_v) <= 1e-4
+        evaluator.hip.close()
+
+
+def test_deferred_search_is_the_oracle_s_search_on_this_route_s_values():
+    """Whole searches at 15 x 15 on the deferred route == the oracle's sequential search (node.py, alphazero_mcts.py:42-94) fed,
+    leaf by leaf, the value this route gives that position (a one-game engine expanding the position as its root: the value of a
+    board does not depend on its batch): every node's N and W, bit for bit -- with Dirichlet noise on (it touches priors only)."""
+    from rlzero_amd.engine import HipNetEvaluator, MCTSEngine
+    B, n, sims = 15, 5, 150
+    net = _net(B, seed=1)
+    evaluator = HipNetEvaluator(net, B, 'cuda:0', max_boards=8)
+    probe_eval = HipNetEvaluator(net, B, 'cuda:0', max_boards=1)
+    probe = MCTSEngine(B, n, n_games=1, n_playout=4, device='cuda:0')
+    cache = {}
+
+    def pvf(env):
+        key = (env.bitboards(), env.current_player(), env.last_move)
+        if key not in cache:
+            _set_roots(probe, [env])
+            probe.sim_chunk(probe_eval, 1)
+            cache[key] = -float(probe.root_stats()[1][0])
+        legal = env.leagel_actions()
+        return [(a, 1.0 / len(legal)) for a in legal], cache[key]
+
+    envs = [RefGomoku(B, n), RefGomoku.from_moves(B, n, [112, 113, 97]),
+            RefGomoku.from_moves(B, n, [112, 111, 113, 110, 114, 109, 115]),   # four in a row: wins and terminal leaves nearby
+            _positions(B, n, 6, seed=4)[5]]
+    eng = MCTSEngine(B, n, n_games=len(envs), n_playout=sims, device='cuda:0', add_noise=True, noise_seed=9)
+    _set_roots(eng, envs)
+    eng.simulate(evaluator, sims)
+    eng.check()
+    assert eng._def_pending == sims
+    for g, env in enumerate(envs):
+        ref = RefSearch(pvf, sims, 5)
+        ref.simulate(env, 1.0)
+        assert _hex_tree(eng.tree_dump(g)) == _hex_tree(tree_dump(ref.root)), 'game %d' % g
+    for e_ in (eng, probe):
+        e_.close()
+    evaluator.hip.close()
+    probe_eval.hip.close()
+
+
+def test_when_the_flushes_happen_changes_no_bit():
+    """The same searches with tree reuse over three moves: (a) one flush per move, eager launches; (b) a store of 16 slots
+    (a flush every 16 steps, also in the middle of a chunk); (c) hipGraphs of 16 steps.  Every record of every arena -- N, W,
+    the priors of every expanded node -- is the same."""
+    from rlzero_amd.engine import HipNetEvaluator, MCTSEngine
+    B, n, sims = 13, 5, 90
+    net = _net(B, seed=2)
+    envs = _positions(B, n, 6, seed=8)
+    dumps = {}
+    for mode in ('move', 'small_store', 'graph'):
+        evaluator = HipNetEvaluator(net, B, 'cuda:0', max_boards=len(envs))
+        eng = MCTSEngine(B, n, n_games=len(envs), n_playout=sims, device='cuda:0', add_noise=True, noise_seed=5)
+        if mode == 'small_store':
+            eng.deferred_max_bytes = 1   # -> the minimum of 16 slots
+        if mode == 'graph':
+            eng.reset_games()
+            eng.warm_graph(evaluator, 16)
+        _set_roots(eng, envs)
+        eng.set_noise_keys()   # (the games' noise streams restart: the graph warm-up has drawn from them)
+        record = []
+        for move in range(3):
+            eng.simulate(evaluator, sims, use_graph=mode == 'graph', sims_per_graph=16)
+            if mode == 'small_store':
+                assert eng._def_slots == 16 and 0 < eng._def_pending <= 16
+            else:
+                assert eng._def_pending == sims
+            visits = eng.root_visits()
+            assert eng._def_pending == 0 and (visits.sum(axis=1) == eng.root_stats()[0] - 1).all()
+            record.append(visits.copy())
+            record.append([_whole_tree(eng, g) for g in range(len(envs))])
+            eng.advance(visits.argmax(axis=1).astype(np.int32))   # keep the most visited child's subtree
+            eng.step(visits.argmax(axis=1).astype(np.int32))
+        st = eng.check()
+        assert st.reuse_dropped == 0
+        dumps[mode] = record
+        eng.close()
+        evaluator.hip.close()
+    for mode in ('small_store', 'graph'):
+        for a, b in zip(dumps['move'], dumps[mode]):
+            if isinstance(a, np.ndarray):
+                assert np.array_equal(a, b), mode
+            else:
+                assert a == b, mode
+
+
+def test_an_evaluator_of_another_route_takes_over_cleanly():
+    """Pending priors are written before another evaluator searches the same trees (sim_chunk flushes), before the roots are set
+    anew, and before the weights of the deferring evaluator change."""
+    import torch
+    from rlzero_amd.engine import HipNetEvaluator, MCTSEngine, SyntheticEvaluator
+    B, n = 15, 5
+    net = _net(B, seed=3).to('cuda:0')
+    evaluator = HipNetEvaluator(net, B, 'cuda:0', max_boards=4)
+    eng = MCTSEngine(B, n, n_games=4, n_playout=40, device='cuda:0')
+    eng.reset_games()
+    eng.sim_chunk(evaluator, 10)
+    assert eng._def_pending == 10
+    eng.sim_chunk(SyntheticEvaluator('vlin'), 5)
+    assert eng._def_pending == 0 and (eng.root_stats()[0] == 15).all()
+    pri = eng.arena(0)['PRI']
+    assert np.isfinite(pri).all() and (pri > 0).all()   # every reserved block was written (by the flush or by the in-step route)
+    eng.sim_chunk(evaluator, 10)
+    assert eng._def_pending == 10
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(1.01)
+    evaluator.refresh_if_changed()
+    assert eng._def_pending == 0
+    eng.sim_chunk(evaluator, 3)
+    eng.reset_games()
+    assert eng._def_pending == 0
+    eng.check()
+    eng.close()
+    evaluator.hip.close()

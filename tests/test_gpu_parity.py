@@ -1138,6 +1138,7 @@ def test_fused_route_priors_vs_golden_and_unfused(g4):
         net = PolicyValueNet(B)
         net.load_state_dict({k: torch.from_numpy(v) for k, v in ev.numpy_weights(B, int(g4['B%d_seed' % B])).items()})
         evaluator = HipNetEvaluator(net, B, 'cuda:0', max_boards=16)
+        evaluator.deferred_priors = False   # the route that writes priors inside the tree step (the deferred one: tests/test_deferred.py)
         acts = [int(a) for a in g4['B%d_pvf_acts' % B]]
         want_p, want_v = g4['B%d_pvf_probs' % B].astype(np.float64), float(g4['B%d_pvf_value' % B])
         rs = np.random.RandomState(B)

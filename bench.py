@@ -239,7 +239,7 @@ def run_fill_config(args):
     child process -> the fields of its line worth keeping."""
     rec = child_line(['--lanes', 2, '--games', FILL_GAMES_PER_GPU, '--steps', args.steps, '--warmup', max(args.warmup, 3),
                       '--regions', 1, '--net-algo', args.net_algo, '--graph', args.graph, '--noise', args.noise, '--deferred', args.deferred,
-                      '--no-cpu-baseline', '--no-games-leg', '--no-fill', '--no-configs'], 600)
+                      '--no-cpu-baseline', '--no-games-leg', '--no-fill', '--no-configs', '--timeline', 0], 600)
     if rec is None:
         return None
     rf = rec.get('roofline') or {}
@@ -264,7 +264,7 @@ def run_config_legs(args):
     out = {}
     for key, flags, cpu_s in CONFIG_LEGS:
         rec = child_line(flags + ['--cpu-seconds', max(1.0, cpu_s * args.cpu_seconds / 60.0), '--regions', 1, '--no-games-leg',
-                                  '--no-fill', '--no-configs'] + (['--no-cpu-baseline'] if args.no_cpu_baseline else []), 600)
+                                  '--no-fill', '--no-configs', '--timeline', 0] + (['--no-cpu-baseline'] if args.no_cpu_baseline else []), 600)
         if rec is None:
             out[key] = {'error': 'the child process printed no line'}
             continue
@@ -547,6 +547,9 @@ def main():
                     help='1 (default): deferred priors where the route exists (UCT_REF, one simulation in flight, boards of 11 .. 16 rows) -- '
                          'a step is trunk -> tree step, the policy GEMM and the priors of a move\'s expansions run as one batch per move; '
                          '0: the three-launch step (trunk -> FC GEMM -> tree step writing the priors at once)')
+    ap.add_argument('--timeline', type=int, default=1,
+                    help='1: behind the timed work, play three more moves of the same layout with the device-side launch trace '
+                         'attached (rlzero_amd/trace.py) and report the schedule (`lane_timeline`, roofline.launches_in_flight)')
     ap.add_argument('--lanes', type=int, default=0,
                     help='independent batches of games on separate HIP streams (the tree / FC kernels of one lane run beside the '
                          'network trunks of the others); 0 = what rlzero_amd.selfplay.plan_lanes picks for the batch (512 games: 4)')
@@ -950,9 +953,24 @@ def main():
         line['fill_%d' % FILL_GAMES_PER_GPU] = fill
         line['configs'] = config_legs
         line['cpu_baseline'] = cpu_baseline
-        print(json.dumps(line), flush=True)
     for eng in engines:
         eng.close()
+    if rank == 0:
+        # The schedule without a profiler in the way (rlzero_amd/trace.py): the same layout played once more with the device-side
+        # launch trace attached -- every trunk / tree-step workgroup leaves its start, end and CU -- behind everything that is timed.
+        # launches_in_flight, the CUs' time under trunk workgroups and the lanes' step cycle come from those records, not from a
+        # ratio of averaged event intervals (rocprofv3 serialises the lanes' queues: profiles/r03/trunk_overlap_default.json).
+        if args.timeline and deferred_route and world == 1 and lanes > 1 and args.evaluator == 'hipnet' and 'roofline' in line:
+            try:
+                from rlzero_amd.trace import measure
+                tl = measure(net, board, n_row, n_games=G, n_playout=args.playouts, lanes=lanes, device=device, add_noise=bool(args.noise))
+                line['lane_timeline'] = tl
+                line['roofline']['launches_in_flight_from_event_averages'] = line['roofline']['launches_in_flight']
+                line['roofline']['launches_in_flight'] = tl['launches_in_flight']
+                line['roofline']['cu_time_in_trunk'] = tl['cu_time_in_trunk']
+            except Exception as exc:  # noqa: BLE001 -- a diagnostic: the measured line is printed whatever happens here
+                line['lane_timeline'] = {'error': '%s: %s' % (type(exc).__name__, str(exc)[:200])}
+        print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()
 

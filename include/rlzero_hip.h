@@ -278,6 +278,12 @@ typedef struct rz_deferred_logits {
 /* Room for `slots` steps between two flushes (per game: a pending-expansion record of 80 bytes per slot).  Needs
  * RZ_SCORE_UCT_REF and sims_in_flight == 1. */
 int rz_deferred_reserve(rz_engine *e, int32_t slots);
+/* Opt-in device-side launch trace (rlzero_amd/csrc/rz_trace.h; rlzero_amd/trace.py): d_trace = uint64 [2 + 8 * slots * n_games] of
+ * THIS engine's lane with [0] = slots (steps of a search) and [1] = n_games filled in, or NULL to detach.  The deferred route's
+ * kernels launched AFTERWARDS (a hipGraph keeps what it captured) leave one record per workgroup: start / end on the 100 MHz
+ * clock, step, block, CU; a search overwrites the records of the one before it.  A diagnostic: traced instantiations of the
+ * kernels run, not the production ones. */
+int rz_trace_attach(rz_engine *e, void *d_trace);   /* the evaluator's half: rz_net_trace_attach below */
 /* int32 [n_games]: the store slot the NEXT leaf of each game goes to (= steps since the last flush); the trunk reads it */
 int rz_deferred_slots(rz_engine *e, const int32_t **d_slot_of_game);
 /* rz_expand_backup / rz_tree_step of this route (pair with rz_select_step(e, NULL, ..) + rz_net_trunk_leaves_deferred) */
@@ -422,6 +428,7 @@ int rz_net_trunk_leaves_deferred(rz_net *net, const uint64_t *d_stones, const in
                                  int32_t n_boards, const int32_t *d_slot_of_board, rz_value_head *out, void *stream);
 /* act_fc1 (policy_value_net.py:43) over the stored leaves of slots [0, n_slots) as ONE GEMM (k_heads_split's arithmetic) */
 int rz_net_deferred_gemm(rz_net *net, int32_t n_boards, int32_t n_slots, rz_deferred_logits *out, void *stream);
+int rz_net_trace_attach(rz_net *net, void *d_trace);   /* see rz_trace_attach */
 int rz_net_heads(rz_net *net, int32_t n_boards, float *d_logp, float *d_value, void *stream);
 /* only the FC GEMM of the heads on the internal features; returns the device pointers that
  * rz_tree_step_raw / rz_expand_backup_raw consume (valid until the next rz_net_reserve / load) */

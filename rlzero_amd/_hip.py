@@ -105,6 +105,8 @@ _SIGNATURES = {
     'rz_tree_step': (c_int, [P, P, P, P, P]),
     'rz_expand_backup_raw': (c_int, [P, POINTER(RzRawHeads), P]),
     'rz_tree_step_raw': (c_int, [P, POINTER(RzRawHeads), P, P]),
+    'rz_trace_attach': (c_int, [P, P]),
+    'rz_net_trace_attach': (c_int, [P, P]),
     'rz_deferred_reserve': (c_int, [P, c_int32]),
     'rz_deferred_slots': (c_int, [P, POINTER(c_void_p)]),
     'rz_expand_backup_deferred': (c_int, [P, POINTER(RzValueHead), P]),

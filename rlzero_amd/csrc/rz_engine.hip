@@ -48,6 +48,7 @@
 #include <vector>
 
 #include "rlzero_hip.h"
+#include "rz_trace.h"
 
 #pragma clang fp contract(off)
 
@@ -85,6 +86,7 @@ struct Dev {
     int pend_cap;
     int32_t *pend, *pend_pb, *pend_ctr;
     uint64_t *pend_stones;
+    unsigned long long *trace;   // rz_trace.h (NULL: none)
     uint64_t valid[kWords];
 };
 
@@ -960,11 +962,15 @@ __global__ __launch_bounds__(kWave * kDefWaves) void k_expand_backup_def(Dev E, 
 
 // (`obs` is always NULL on this route -- the trunk reads positions -- but stays a run-time argument: with the constant hipcc
 // schedules the selection into 115 registers instead of 107, and 112 is what a SIMD has left beside a wave of the trunk)
-template <int PER>
+// TRACE: the instantiation launched while a trace buffer is attached (rz_trace_attach) leaves a record per game; the production
+// one carries nothing of it (the trace's live values cost the latency chain 132 bytes of scratch).
+template <int PER, bool TRACE>
 __global__ __launch_bounds__(kWave * kDefWaves) void k_tree_step_def(Dev E, ValueHead vh, float *obs) {
     __shared__ float part[kDefWaves][kWave];
     __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & (kWave - 1), wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    __shared__ unsigned long long trace_t0;
+    if (TRACE && threadIdx.x == 0) trace_t0 = rz_trace_now();
     value_quarter_def<PER>(vh, blockIdx.x, lane, wave, part);
     if (wave != 0) {
         __syncthreads();
@@ -973,6 +979,7 @@ __global__ __launch_bounds__(kWave * kDefWaves) void k_tree_step_def(Dev E, Valu
     expand_backup_body<float, false, false, false, true>(E, nullptr, nullptr, blockIdx.x, lane, RawHeads(), 0, vh, part);
     __syncthreads();   // (wave 0's alone: the other waves have ended)
     select_body<false>(E, obs, blockIdx.x, lane);
+    if (TRACE && lane == 0) rz_trace_write(E.trace, RZ_TRACE_TREE, E.pend[blockIdx.x] - 1, blockIdx.x, trace_t0);
 }
 
 // The flush: the priors of the node expanded in step `slot` of game g -- exp(log_softmax) of the leaf's logits over its legal
@@ -2435,6 +2442,13 @@ int rz_deferred_reserve(rz_engine *e, int32_t slots) {
     return RZ_OK;
 }
 
+int rz_trace_attach(rz_engine *e, void *d_trace) {
+    int rc = check_engine(e);
+    if (rc != RZ_OK) return rc;
+    e->dev.trace = (unsigned long long *)d_trace;
+    return RZ_OK;
+}
+
 int rz_deferred_slots(rz_engine *e, const int32_t **d_slot_of_game) {
     int rc = check_engine(e);
     if (rc != RZ_OK) return rc;
@@ -2458,8 +2472,15 @@ int rz_tree_step_deferred(rz_engine *e, const rz_value_head *head, void *stream)
     if (rc != RZ_OK) return rc;
     if ((rc = deferred_ok(e, head)) != RZ_OK) return rc;
     e->n_select += 1;
-    if (head->groups == 16 * kDefWaves) k_tree_step_def<8><<<per_game(e), dim3(kWave * kDefWaves), 0, as_stream(stream)>>>(e->dev, *head, nullptr);
-    else k_tree_step_def<16><<<per_game(e), dim3(kWave * kDefWaves), 0, as_stream(stream)>>>(e->dev, *head, nullptr);
+    const dim3 block(kWave * kDefWaves);
+    const bool small = head->groups == 16 * kDefWaves;
+    if (e->dev.trace) {
+        if (small) k_tree_step_def<8, true><<<per_game(e), block, 0, as_stream(stream)>>>(e->dev, *head, nullptr);
+        else k_tree_step_def<16, true><<<per_game(e), block, 0, as_stream(stream)>>>(e->dev, *head, nullptr);
+    } else {
+        if (small) k_tree_step_def<8, false><<<per_game(e), block, 0, as_stream(stream)>>>(e->dev, *head, nullptr);
+        else k_tree_step_def<16, false><<<per_game(e), block, 0, as_stream(stream)>>>(e->dev, *head, nullptr);
+    }
     return launched("k_tree_step_def");
 }
 

@@ -37,6 +37,7 @@
 #include <vector>
 
 #include "rlzero_hip.h"
+#include "rz_trace.h"
 
 void rz_set_error(const char *msg);  // rz_engine.hip
 
@@ -1553,9 +1554,12 @@ struct DeferredOut {
     long long slot_halfs;
     float *valfeat;
     int vf_ld;
+    unsigned long long *trace;   // rz_trace.h (NULL: none)
 };
 
-template <int NT, bool BITS>
+// TRACE (rz_trace.h): instantiated for the 15-row bitboard kernel only -- the layout whose schedule profiles/lane_timeline.py reads;
+// the production kernels carry nothing of it (its live values cost ten registers of a budget that is pinned).
+template <int NT, bool BITS, bool TRACE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_trunk_rows(NetDev nd, const float *__restrict__ obs, LeafBits leaves,
                                                     float *__restrict__ feat, _Float16 *__restrict__ feat16,
                                                     int n_boards, unsigned *__restrict__ flags, DeferredOut later) {
@@ -1570,6 +1574,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_t
     char *c1 = lds_raw + sp::kInBytes;        // conv1 output, records [hi 32 | lo 32 | pad]
     char *c2 = c1 + rt::Geo<32>::grid_bytes;  // conv2 output, records [hi 64 | lo 64 | pad]
     const int tid0 = threadIdx.x;
+    __shared__ unsigned long long trace_t0;   // (parked in LDS: the register budget below is pinned)
+    if (TRACE && tid0 == 0) trace_t0 = rz_trace_now();
     const int BH = nd.BH, BW = nd.BW, S = nd.S;
     float zmax = 0.0f;  // largest scaled value this thread stored as f16 pieces (float planes only: bitboard planes are 0 / 1)
     constexpr int kObsPer = BITS ? 1 : (4 * RZ_MAX_BOARD_SIZE * RZ_MAX_BOARD_SIZE + kThreads - 1) / kThreads;
@@ -1886,6 +1892,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_t
 #endif
     if constexpr (!BITS)
         if (!(zmax <= 65504.0f)) atomicOr(flags, (unsigned)RZ_NET_FLAG_F16_RANGE);
+    if (TRACE && tid0 == 0 && (int)blockIdx.x < n_boards)
+        rz_trace_write(later.trace, RZ_TRACE_TRUNK, later.slot_of ? later.slot_of[blockIdx.x] : 0, blockIdx.x, trace_t0);
 }
 
 // Direct path: wave w = 4*rh + q4 owns output-channel quarter q4 (the two waves of a quarter share
@@ -2360,6 +2368,7 @@ struct rz_net {
     const float *d_w1t = nullptr;        // val_fc1.weight as [groups][64][4] (rz_value_head)
     int vf_groups = 0;                    // K / 4 of the value head's first layer, padded to a multiple of 4
     int store_slots = 0, store_tiles = 0; // slots x 32-board tiles per slot
+    unsigned long long *d_trace = nullptr; // rz_net_trace_attach
     long long store_boards = 0;
 };
 
@@ -2563,7 +2572,13 @@ std::vector<f32x4> pack_split_fc(const float *w, int n_out, int k_in, int tiles,
 
 template <int NT>
 static void launch_trunk_rows(bool bits, dim3 grid, hipStream_t stream, const NetDev &nd, const float *d_obs, LeafBits leaves, float *f32,
-                              _Float16 *f16, int n_boards, unsigned *flags, DeferredOut later = DeferredOut{nullptr, 0, nullptr, 0}) {
+                              _Float16 *f16, int n_boards, unsigned *flags, DeferredOut later = DeferredOut{nullptr, 0, nullptr, 0, nullptr}) {
+    if constexpr (NT == 15) {
+        if (bits && later.trace) {
+            k_trunk_rows<NT, true, true><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later);
+            return;
+        }
+    }
     if (bits) k_trunk_rows<NT, true><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later);
     else k_trunk_rows<NT, false><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later);
 }
@@ -2822,7 +2837,7 @@ int rz_net_reserve(rz_net *net, int32_t max_boards) {
 static bool rows_kernel_covers(int bh, int bw) { return bh >= 11 && bh <= 16 && bw >= 11 && bw <= 16; }
 
 static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t n_boards, void *stream,
-                         LeafBits leaves = LeafBits{nullptr, nullptr, nullptr}, DeferredOut later = DeferredOut{nullptr, 0, nullptr, 0}) {
+                         LeafBits leaves = LeafBits{nullptr, nullptr, nullptr}, DeferredOut later = DeferredOut{nullptr, 0, nullptr, 0, nullptr}) {
     const dim3 grid((unsigned)n_boards);
     // the internal buffer uses the padded layout of the FC GEMM, a caller's buffer the natural one
     const bool internal = d_feat == net->d_feat;
@@ -3011,7 +3026,7 @@ int rz_net_trunk_leaves_deferred(rz_net *net, const uint64_t *d_stones, const in
     if (n_boards > net->store_boards) return net_fail(RZ_ERR_ARG, "batch larger than rz_net_deferred_reserve()d");
     if (n_boards > 0) {
         if (!d_stones || !d_to_move || !d_last_cell || !d_slot_of_board) return net_fail(RZ_ERR_ARG, "NULL device pointer");
-        const DeferredOut later{d_slot_of_board, (long long)net->store_tiles * net->dev.groups_act * 1024, net->d_valfeat, net->vf_groups * 4};
+        const DeferredOut later{d_slot_of_board, (long long)net->store_tiles * net->dev.groups_act * 1024, net->d_valfeat, net->vf_groups * 4, net->d_trace};
         launch_trunk(net, nullptr, net->d_feat, n_boards, stream, LeafBits{d_stones, d_to_move, d_last_cell}, later);
         if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_trunk_rows failed");
     }
@@ -3023,6 +3038,12 @@ int rz_net_trunk_leaves_deferred(rz_net *net, const uint64_t *d_stones, const in
     out->b2 = net->dev.fc_val2_b;
     out->ld = net->vf_groups * 4;
     out->groups = net->vf_groups;
+    return RZ_OK;
+}
+
+int rz_net_trace_attach(rz_net *net, void *d_trace) {
+    if (!net) return net_fail(RZ_ERR_ARG, "net handle is NULL");
+    net->d_trace = (unsigned long long *)d_trace;
     return RZ_OK;
 }
 

@@ -233,14 +233,17 @@ class BatchedSelfPlay(object):
     @classmethod
     def for_network(cls, net_module, board, n_in_row, n_games, n_playout, c_puct=5.0, device='cuda:0',
                     game='gomoku', net_shape=None, lanes=None, trunk_workgroups=None, temperature=1.0, seed=0,
-                    use_graph=True, sims_per_graph=16, eager_every=0, add_noise=True, sims_in_flight=1, **engine_kw):
+                    use_graph=True, sims_per_graph=16, eager_every=0, add_noise=True, sims_in_flight=1, before_warm=None,
+                    deferred_priors=None, **engine_kw):
         """Self-play of ``n_games`` games in flight with the hand-written evaluator of ``net_module`` (a
         PolicyValueNet): builds the lanes (engine + HipNetEvaluator each) as plan_lanes() recommends, unless
         ``lanes`` / ``trunk_workgroups`` are given (more than four lanes take turns on the GPU's four compute pipes, and four need
         GPU_MAX_HW_QUEUES >= 8: profiles/r03/lane_sweeps.txt).  ``add_noise``: Dirichlet noise on the priors of every expanded
         node, what ``AlphaZeroPlayer(is_selfplay=True)`` does (alphazero_mcts.py:124-129, node.py:63-69).
         ``sims_in_flight`` = K > 1: the opt-in virtual-loss mode (MCTSEngine), for batches too small to fill the GPU
-        with one leaf per game; the evaluator batch of a lane is then its games x K."""
+        with one leaf per game; the evaluator batch of a lane is then its games x K.  ``deferred_priors``: None = the deferred-priors
+        route wherever it exists (HipNetEvaluator.deferred_ok), False = the three-launch step everywhere.  ``before_warm(sp)``: called
+        before the hipGraphs are captured (rlzero_amd.trace attaches its buffer there)."""
         import torch
         from .engine import HipNetEvaluator, MCTSEngine
         dev = torch.device(device)
@@ -269,11 +272,15 @@ class BatchedSelfPlay(object):
                                  max_boards=g_lane * K)
             ev.hip.set_max_workgroups(max(0, int(wgs)))
             ev.hip.set_heads_algo(heads_algo)
+            if deferred_priors is not None:
+                ev.deferred_priors = bool(deferred_priors)
             evaluators.append(ev)
         sp = cls(engines if lanes > 1 else engines[0], evaluators if lanes > 1 else evaluators[0],
                  temperature=temperature, seed=seed, use_graph=use_graph, sims_per_graph=sims_per_graph,
                  eager_every=eager_every)
         sp.trunk_workgroups = int(wgs)
+        if before_warm is not None:
+            before_warm(sp)
         sp.warm_graphs()
         return sp
 

@@ -1,10 +1,12 @@
 #!/bin/bash
 # build the HIP library of another revision (for same-box A / B runs through RZ_HIP_LIBRARY): profiles/build_ref.sh <rev> <out.so>
+# Sources and headers come from <rev> (git archive), the compile flags from rlzero_amd/_build.py: the ref is built exactly as the
+# in-tree library is.  RZ_HIP_LIBRARY swaps the library only: <rev> must have the ABI version of the working tree's binding
+# (rlzero_amd/_hip.py) -- for older revisions run the ref leg from a `git worktree` of that revision instead.
 set -e
 rev=$1; out=$2; tmp=$(mktemp -d)
-mkdir -p $tmp/csrc $tmp/include
-for f in rz_engine.hip rz_net.hip rz_muzero.hip; do git show $rev:rlzero_amd/csrc/$f > $tmp/csrc/$f; done
-git show $rev:include/rlzero_hip.h > $tmp/include/rlzero_hip.h
-hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -std=c++17 -fPIC -shared -Wno-unused-function \
-    -I$tmp/include $tmp/csrc/rz_engine.hip $tmp/csrc/rz_net.hip $tmp/csrc/rz_muzero.hip -o $out
+git archive $rev rlzero_amd/csrc include | tar -x -C $tmp
+flags=$(python -c "from rlzero_amd import _build; print(' '.join(_build.FLAGS))")
+srcs=$(python -c "from rlzero_amd import _build; import os; print(' '.join('$tmp/rlzero_amd/csrc/' + os.path.basename(s) for s in _build.SOURCES))")
+hipcc $flags -I$tmp/include $srcs -o $out
 rm -rf $tmp

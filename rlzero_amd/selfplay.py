@@ -132,9 +132,18 @@ class Trajectory(object):
 
 
 
-def plan_lanes(n_games, n_cus=256, hw_queues=None):
+def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False):
     """-> (lanes, trunk_workgroups, heads_algo) for ``n_games`` leaves per simulation step on a GPU with ``n_cus`` CUs and
-    ``hw_queues`` hardware queues for its streams (default: what rlzero_amd claimed on import, rlzero_amd.HW_QUEUES).  Measured on
+    ``hw_queues`` hardware queues for its streams (default: what rlzero_amd claimed on import, rlzero_amd.HW_QUEUES).
+
+    ``deferred``: the batch runs the deferred-priors route (HipNetEvaluator.deferred_ok: UCT_REF, one simulation in flight, boards
+    of 11 .. 16 rows).  A lane's step is then trunk -> tree step (23 + 10 us at 15x15) and the table was measured again
+    (profiles/r04/lane_sweep.txt, M simulations / s): up to 0.75 rounds of boards ONE lane (192 games: 6.0 against 5.95 with two);
+    up to one round TWO (256 games: 7.8 against 7.4); up to 1.75 rounds THREE (320 / 384 games: 9.2 / 10.3 against 8.7 / 9.8 with
+    two); 448 games TWO (10.3 against 10.1); 2 .. 2.75 rounds FOUR on 8 hardware queues (512 / 640 games: 10.6 / 10.6 against 10.5
+    / 10.1 with two -- with fewer queues two lanes, a percent behind); beyond, TWO (768 .. 1536 games: 10.9 .. 11.0).
+
+    The three-launch step (every other batch), measured on
     MI355X at 15x15 (profiles/r03/lane_sweeps.txt; a trunk workgroup takes a board in ~23 us, three in ~65 us):
 
     * up to one round of boards (n_games <= CUs): ONE lane -- the step is a chain of three latency-bound launches, and splitting it
@@ -154,6 +163,16 @@ def plan_lanes(n_games, n_cus=256, hw_queues=None):
     ones once the 'parts' GEMM existed)."""
     if hw_queues is None:
         from . import HW_QUEUES as hw_queues
+    if deferred:
+        if 4 * n_games <= 3 * n_cus:
+            return 1, 0, 'auto'
+        if n_games <= n_cus:
+            return 2, 0, 'parts'
+        if 4 * n_games < 7 * n_cus:
+            return 3, 0, 'parts'
+        if n_games < 2 * n_cus or 4 * n_games > 11 * n_cus:
+            return 2, 0, 'parts'
+        return (4 if hw_queues >= 8 else 2), 0, 'parts'
     if n_games <= n_cus:
         return 1, 0, 'auto'
     if 4 * n_games < 7 * n_cus:
@@ -249,7 +268,11 @@ class BatchedSelfPlay(object):
         dev = torch.device(device)
         n_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         K = max(1, int(sims_in_flight))
-        auto_lanes, auto_wgs, heads_algo = plan_lanes(n_games * K, n_cus)
+        shape0 = net_shape if net_shape is not None else board
+        rows0, cols0 = (shape0[0], shape0[1]) if isinstance(shape0, (tuple, list)) else (shape0, shape0)
+        deferred = (deferred_priors is not False and K == 1 and engine_kw.get('score_mode', 'uct_ref') in ('uct_ref', 0)
+                    and game == 'gomoku' and 11 <= rows0 <= 16 and 11 <= cols0 <= 16)
+        auto_lanes, auto_wgs, heads_algo = plan_lanes(n_games * K, n_cus, deferred=deferred)
         if lanes is None:
             lanes, wgs = auto_lanes, auto_wgs
         else:

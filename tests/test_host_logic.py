@@ -122,6 +122,11 @@ def test_plan_lanes():
         assert plan_lanes(512, hw_queues=4) == (3, 0, 'parts')   # a fourth stream would share a hardware queue
     assert plan_lanes(768, hw_queues=8) == (2, 0, 'parts') and plan_lanes(1536, hw_queues=8) == (2, 0, 'parts')
     assert plan_lanes(100, n_cus=32, hw_queues=8) == (2, 0, 'parts')
+    # the deferred-priors route (a step = trunk -> tree step): profiles/r04/lane_sweep.txt
+    d = lambda n, q=8: plan_lanes(n, hw_queues=q, deferred=True)[0]  # noqa: E731
+    assert [d(n) for n in (1, 128, 192, 193, 256, 257, 320, 384, 447, 448, 511, 512, 640, 704, 705, 768, 1536)] == \
+        [1, 1, 1, 2, 2, 3, 3, 3, 3, 2, 2, 4, 4, 4, 2, 2, 2]
+    assert d(512, 4) == 2 and d(640, 4) == 2 and plan_lanes(512, hw_queues=8, deferred=True) == (4, 0, 'parts')
 
 
 def test_hw_queues_are_claimed_on_import():

@@ -2415,8 +2415,8 @@ int rz_expand_backup_raw(rz_engine *e, const rz_raw_heads *heads, void *stream) 
 
 static int deferred_ok(rz_engine *e, const rz_value_head *h) {
     if (h == nullptr || !h->valfeat || !h->w1t || !h->b1 || !h->w2 || !h->b2) return fail(RZ_ERR_ARG, "rz_value_head: NULL pointer");
-    if ((h->groups != 16 * kDefWaves && h->groups != 32 * kDefWaves) || h->ld != 4 * h->groups)
-        return fail(RZ_ERR_ARG, "rz_value_head: groups = %d must be %d or %d and ld = 4 * groups", h->groups, 16 * kDefWaves, 32 * kDefWaves);
+    if ((h->groups != 16 && h->groups != 32 && h->groups != 64 && h->groups != 128) || h->ld != 4 * h->groups)
+        return fail(RZ_ERR_ARG, "rz_value_head: groups = %d must be 16, 32, 64 or 128 and ld = 4 * groups", h->groups);
     if (e->dev.pend_cap <= 0) return fail(RZ_ERR_ARG, "call rz_deferred_reserve first");
     return RZ_OK;
 }
@@ -2462,8 +2462,13 @@ int rz_expand_backup_deferred(rz_engine *e, const rz_value_head *head, void *str
     int rc = check_engine(e);
     if (rc != RZ_OK) return rc;
     if ((rc = deferred_ok(e, head)) != RZ_OK) return rc;
-    if (head->groups == 16 * kDefWaves) k_expand_backup_def<8><<<per_game(e), dim3(kWave * kDefWaves), 0, as_stream(stream)>>>(e->dev, *head);
-    else k_expand_backup_def<16><<<per_game(e), dim3(kWave * kDefWaves), 0, as_stream(stream)>>>(e->dev, *head);
+    const dim3 block(kWave * kDefWaves);
+    switch (head->groups) {   // = 4 waves x 2 halves x PER
+        case 16: k_expand_backup_def<2><<<per_game(e), block, 0, as_stream(stream)>>>(e->dev, *head); break;
+        case 32: k_expand_backup_def<4><<<per_game(e), block, 0, as_stream(stream)>>>(e->dev, *head); break;
+        case 64: k_expand_backup_def<8><<<per_game(e), block, 0, as_stream(stream)>>>(e->dev, *head); break;
+        default: k_expand_backup_def<16><<<per_game(e), block, 0, as_stream(stream)>>>(e->dev, *head); break;
+    }
     return launched("k_expand_backup_def");
 }
 
@@ -2473,13 +2478,15 @@ int rz_tree_step_deferred(rz_engine *e, const rz_value_head *head, void *stream)
     if ((rc = deferred_ok(e, head)) != RZ_OK) return rc;
     e->n_select += 1;
     const dim3 block(kWave * kDefWaves);
-    const bool small = head->groups == 16 * kDefWaves;
-    if (e->dev.trace) {
-        if (small) k_tree_step_def<8, true><<<per_game(e), block, 0, as_stream(stream)>>>(e->dev, *head, nullptr);
-        else k_tree_step_def<16, true><<<per_game(e), block, 0, as_stream(stream)>>>(e->dev, *head, nullptr);
-    } else {
-        if (small) k_tree_step_def<8, false><<<per_game(e), block, 0, as_stream(stream)>>>(e->dev, *head, nullptr);
-        else k_tree_step_def<16, false><<<per_game(e), block, 0, as_stream(stream)>>>(e->dev, *head, nullptr);
+    if (e->dev.trace && head->groups == 128) {   // (the traced instantiation exists for the 15 x 15 board's head: rz_trace_attach)
+        k_tree_step_def<16, true><<<per_game(e), block, 0, as_stream(stream)>>>(e->dev, *head, nullptr);
+        return launched("k_tree_step_def");
+    }
+    switch (head->groups) {   // = 4 waves x 2 halves x PER
+        case 16: k_tree_step_def<2, false><<<per_game(e), block, 0, as_stream(stream)>>>(e->dev, *head, nullptr); break;
+        case 32: k_tree_step_def<4, false><<<per_game(e), block, 0, as_stream(stream)>>>(e->dev, *head, nullptr); break;
+        case 64: k_tree_step_def<8, false><<<per_game(e), block, 0, as_stream(stream)>>>(e->dev, *head, nullptr); break;
+        default: k_tree_step_def<16, false><<<per_game(e), block, 0, as_stream(stream)>>>(e->dev, *head, nullptr); break;
     }
     return launched("k_tree_step_def");
 }

@@ -879,6 +879,17 @@ __device__ __forceinline__ float other_half(float x, int h) {
     return __uint_as_float(h ? r[0] : r[1]);
 }
 
+// Deferred priors (rz_value_head, include/rlzero_hip.h): where a board's features go when no FC GEMM follows the trunk -- the policy
+// pieces into slot slot_of[board] of a store of `slot_halfs` f16 values per slot (tiles of groups_act K-steps), the value head's
+// inputs as f32 rows of vf_ld floats.  slot_of == nullptr: the ordinary route.
+struct DeferredOut {
+    const int32_t *slot_of;
+    long long slot_halfs;
+    float *valfeat;
+    int vf_ld;
+    unsigned long long *trace;   // rz_trace.h (NULL: none)
+};
+
 // FC_HERE (small boards, TN = 1; `raw` / `hid` given): the workgroup also runs the first FC layers of both heads on ITS OWN
 // board, behind the feature stage -- the arithmetic of k_heads_split (the same MFMA on the same K quarters, one per wave, the
 // quarters summed in wave order, fmaf(sum, scale, bias)): the same bits, one launch and one kernel boundary less in the chain
@@ -888,7 +899,8 @@ template <int TN, int MS = 1>
 __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__restrict__ obs, LeafBits leaves,
                                                      float *__restrict__ feat, _Float16 *__restrict__ feat16,
                                                      int n_boards, unsigned *__restrict__ flags,
-                                                     float *__restrict__ raw = nullptr, float *__restrict__ hid = nullptr) {
+                                                     float *__restrict__ raw = nullptr, float *__restrict__ hid = nullptr,
+                                                     DeferredOut later = DeferredOut{nullptr, 0, nullptr, 0, nullptr}) {
 #ifdef RZ_NET_PROFILE
     const long long prof_k0 = __builtin_readcyclecounter();
     long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = prof_k0;
@@ -1289,6 +1301,12 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         // sector (written whole by neighbouring lanes of this wave), a wave of the GEMM reads the 1 KB of a piece
         _Float16 *dst16 = feat16 ? feat16 + ((size_t)(board >> 5) * (nd.groups_act + nd.groups_val) * 1024 + (board & 31) * 16)
                                  : nullptr;
+        const bool deferred = later.slot_of != nullptr;   // (DeferredOut: the policy pieces wait in the store, the value inputs go on as f32)
+        float *vdst = nullptr;
+        if (deferred) {
+            dst16 = feat16 + (size_t)later.slot_of[board] * later.slot_halfs + (size_t)(board >> 5) * nd.groups_act * 1024 + (board & 31) * 16;
+            vdst = later.valfeat + (size_t)board * later.vf_ld;
+        }
         // the six sums of the lane's position first (the other lane half's share by v_permlane32_swap, the biases in one
         // go), then the stores: nothing in the store sequence waits for a cross-lane or LDS round trip
         float vsum[6];
@@ -1337,6 +1355,8 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
                     zmax = fmaxf(zmax, z);
                     fa_lds[step * 32 + (k & 15)] = zh;
                     fa_lds[step * 32 + 16 + (k & 15)] = (_Float16)(z - (float)zh);
+                } else if (deferred && o >= 4) {
+                    vdst[(o - 4) * S + cell] = v;
                 } else if (dst16) {
                     const int k = (o < 4 ? o : o - 4) * S + cell;
                     const int step = (o < 4 ? 0 : nd.groups_act) + (k >> 4);
@@ -1546,17 +1566,6 @@ __device__ __forceinline__ void conv_r(const char *in, const void *wts, int lane
 // step or FC GEMM (112 / 104 registers) fits beside a trunk wave on the same SIMD (512 registers): at 400 registers or fewer the
 // trunk leaves that room, at 408 it does not and the lanes' kernels take turns (measured: 10.7 -> 9.5 M sims/s from 8 registers).
 // Left alone hipcc allocates 396 .. 420 here depending on details of the prologue; the cap holds it at 372, no scratch.
-// Deferred priors (rz_value_head, include/rlzero_hip.h): where a board's features go when no FC GEMM follows the trunk -- the policy
-// pieces into slot slot_of[board] of a store of `slot_halfs` f16 values per slot (tiles of groups_act K-steps), the value head's
-// inputs as f32 rows of vf_ld floats.  slot_of == nullptr: the ordinary route.
-struct DeferredOut {
-    const int32_t *slot_of;
-    long long slot_halfs;
-    float *valfeat;
-    int vf_ld;
-    unsigned long long *trace;   // rz_trace.h (NULL: none)
-};
-
 // TRACE (rz_trace.h): instantiated for the 15-row bitboard kernel only -- the layout whose schedule profiles/lane_timeline.py reads;
 // the production kernels carry nothing of it (its live values cost ten registers of a budget that is pinned).
 template <int NT, bool BITS, bool TRACE = false>
@@ -2775,7 +2784,9 @@ int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params) {
     up_f(h_params[14], 64, &D.fc_val2_w);
     up_f(h_params[15], 1, &D.fc_val2_b);
     {   // the value head's first layer for the tree step of the deferred route: [group of 4 inputs][hidden unit][4]
-        net->vf_groups = (2 * S + 3) / 4 <= 64 ? 64 : 128;   // eight waves x 8 or 16 groups (k_tree_step_def)
+        // four waves x two halves x PER groups of 4 inputs, PER = 2, 4, 8 or 16 (k_tree_step_def): 64 .. 512 inputs
+        const int need = (2 * S + 3) / 4;
+        net->vf_groups = need <= 16 ? 16 : need <= 32 ? 32 : need <= 64 ? 64 : 128;
         std::vector<float> t((size_t)net->vf_groups * 64 * 4, 0.0f);
         for (int j = 0; j < 64; ++j)
             for (int k = 0; k < 2 * S; ++k) t[((size_t)(k / 4) * 64 + j) * 4 + k % 4] = h_params[12][(size_t)j * 2 * S + k];
@@ -2873,7 +2884,7 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
         // boards): AUTO takes this route while the weights are at most 40 KB (6 x 6: 39 KB, TicTacToe one game +6 %, 16 games +3 %;
         // Connect4: 26 KB); at 9 x 9 (146 KB) the
         // launch it saves is cheaper than the stream it costs (64 games -5 %, profiles/r03/in_trunk_fc.txt)
-        const bool fc_here = internal && tiles <= 4 && net->dev.BH <= 10 && !rows_kernel_covers(net->dev.BH, net->dev.BW) &&
+        const bool fc_here = !later.slot_of && internal && tiles <= 4 && net->dev.BH <= 10 && !rows_kernel_covers(net->dev.BH, net->dev.BW) &&
                              (net->heads_algo == RZ_NET_HEADS_IN_TRUNK ||
                               (net->heads_algo == RZ_NET_HEADS_AUTO && net->max_wgs == 0 && n_boards <= wg_cap &&
                                ((size_t)net->dev.A * 4 * net->dev.S + (size_t)64 * 2 * net->dev.S) * 4 <= 40 * 1024));
@@ -2891,15 +2902,15 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
                 default: launch_trunk_rows<16>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later); break;
             }
         } else if (tiles <= 1)        // one tile: the four waves share the output channels
-            k_trunk_split<1, 4><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, raw, hid);
+            k_trunk_split<1, 4><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, raw, hid, later);
         else if (tiles <= 2)   // two tiles x two channel halves
-            k_trunk_split<1, 2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, raw, hid);
+            k_trunk_split<1, 2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, raw, hid, later);
         else if (tiles == 3 && net->dev.tile_rows == 3)   // 9x9: three tiles + the fourth wave on a quarter of conv3's channels
-            k_trunk_split<1, 3><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, raw, hid);
+            k_trunk_split<1, 3><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, raw, hid, later);
         else if (tiles <= 4)   // four tiles cover the board: one per wave
-            k_trunk_split<1><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, raw, hid);
+            k_trunk_split<1><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, raw, hid, later);
         else
-            k_trunk_split<2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags);
+            k_trunk_split<2><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, nullptr, nullptr, later);
     }
     else
         k_trunk<<<grid, dim3(kTrunkThreads), 0, (hipStream_t)stream>>>(net->dev, d_obs, d_feat, n_boards);
@@ -2982,8 +2993,8 @@ int rz_net_trunk_leaves(rz_net *net, const uint64_t *d_stones, const int32_t *d_
     return RZ_OK;
 }
 
-static bool deferred_trunk_covers(const rz_net *net) {
-    return net->algo == RZ_NET_SPLIT_F16 && net->split_ok && rows_kernel_covers(net->dev.BH, net->dev.BW);
+static bool deferred_trunk_covers(const rz_net *net) {   // the split-f16 trunks (both kernels), fed positions
+    return (net->algo == RZ_NET_SPLIT_F16 || net->algo == RZ_NET_SPLIT_F16_TILES) && net->split_ok;
 }
 
 int rz_net_deferred_reserve(rz_net *net, int32_t max_boards, int32_t slots) {
@@ -3022,13 +3033,13 @@ int rz_net_trunk_leaves_deferred(rz_net *net, const uint64_t *d_stones, const in
     if (rc != RZ_OK) return rc;
     if (!out) return net_fail(RZ_ERR_ARG, "NULL output pointer");
     if (!deferred_trunk_covers(net))
-        return net_fail(RZ_ERR_ARG, "the deferred-priors route needs the RZ_NET_SPLIT_F16 trunk on a board of 11 .. 16 rows and columns");
+        return net_fail(RZ_ERR_ARG, "the deferred-priors route needs the RZ_NET_SPLIT_F16 trunk (a net with finite activation bounds)");
     if (n_boards > net->store_boards) return net_fail(RZ_ERR_ARG, "batch larger than rz_net_deferred_reserve()d");
     if (n_boards > 0) {
         if (!d_stones || !d_to_move || !d_last_cell || !d_slot_of_board) return net_fail(RZ_ERR_ARG, "NULL device pointer");
         const DeferredOut later{d_slot_of_board, (long long)net->store_tiles * net->dev.groups_act * 1024, net->d_valfeat, net->vf_groups * 4, net->d_trace};
         launch_trunk(net, nullptr, net->d_feat, n_boards, stream, LeafBits{d_stones, d_to_move, d_last_cell}, later);
-        if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_trunk_rows failed");
+        if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of the split-f16 trunk failed");
     }
     memset(out, 0, sizeof(*out));
     out->valfeat = net->d_valfeat;

@@ -128,9 +128,8 @@ class HipNet(object):
     # -- deferred priors (include/rlzero_hip.h: rz_value_head) -------------------------------------------------
     def supports_deferred(self):
         """True when this net's trunk can leave the policy features in a store and hand the tree step the value head's inputs
-        (rz_net_trunk_leaves_deferred): the 'split_f16' trunk on a board of 11 .. 16 rows and columns (k_trunk_rows)."""
-        return (getattr(self, 'algo', 'split_f16') == 'split_f16' and getattr(self, '_split_ok', True)
-                and 11 <= self.rows <= 16 and 11 <= self.cols <= 16)
+        (rz_net_trunk_leaves_deferred): the 'split_f16' trunks, every board size."""
+        return getattr(self, 'algo', 'split_f16') in ('split_f16', 'split_f16_tiles') and getattr(self, '_split_ok', True)
 
     def deferred_bytes_per_slot(self, n_boards):
         """Device bytes one store slot (one simulation step of ``n_boards`` leaves) takes: f16 feature pieces + logits."""

@@ -43,7 +43,7 @@ class TraceBuffer(object):
         meta, hw = r[:, 2], r[:, 3]
         xcc = ((hw >> np.uint64(32)) & np.uint64(15)).astype(np.int64)
         # HW_REG_HW_ID (gfx9): wave [3:0], SIMD [5:4], pipe [7:6], CU [11:8], SH [12], SE [15:13] (+ more SE bits on wider parts)
-        cu_in_xcc = ((hw >> np.uint64(8)) & np.uint64(0x1FF)).astype(np.int64)   # CU, SH, SE bits together
+        cu_in_xcc = ((hw >> np.uint64(8)) & np.uint64(0xFF)).astype(np.int64)   # CU, SH, SE bits together
         return {'t0': r[:, 0].astype(np.int64), 't1': r[:, 1].astype(np.int64),
                 'kind': (meta >> np.uint64(56)).astype(np.int64), 'step': ((meta >> np.uint64(32)) & np.uint64(0xFFFFFF)).astype(np.int64),
                 'block': (meta & np.uint64(0xFFFFFFFF)).astype(np.int64), 'lane': np.full(len(r), lane, dtype=np.int64),
@@ -81,6 +81,10 @@ def summarise(rec, n_cus=256):
     # trimmed by 2 % at both ends
     t_lo = max(int(rec['t0'][trunk & (lane == ln)].min()) for ln in set(lane.tolist()))
     t_hi = min(int(rec['t1'][trunk & (lane == ln)].max()) for ln in set(lane.tolist()))
+    out['window'] = 'all lanes searching'
+    if t_hi - t_lo < 100:   # (searches too short to overlap: the union of the lanes' searches instead)
+        t_lo, t_hi = int(rec['t0'][trunk].min()), int(rec['t1'][trunk].max())
+        out['window'] = 'union of the lanes\' searches'
     trim = (t_hi - t_lo) // 50
     t_lo, t_hi = t_lo + trim, t_hi - trim
     span_us = (t_hi - t_lo) * TICK_US

@@ -1,5 +1,5 @@
-"""The deferred-priors route (include/rlzero_hip.h: rz_value_head; RZ_SCORE_UCT_REF, one simulation in flight, boards of 11 .. 16
-rows): a simulation step is trunk -> tree step (value head, backup, next selection); the policy half of
+"""The deferred-priors route (include/rlzero_hip.h: rz_value_head; RZ_SCORE_UCT_REF, one simulation in flight, every board
+size): a simulation step is trunk -> tree step (value head, backup, next selection); the policy half of
 AlphaZeroAgent.policy_value_fn (alphazero_agent.py:41-45) and TreeNode.expand's priors (node.py:44-73) -- which the reference's
 selection rule never reads (node.py:32-42,75-88) -- are written in one batch before anything reads them.
 
@@ -75,7 +75,7 @@ def test_deferred_priors_are_the_in_step_route_s_bits(g4):
     values agree to f32 rounding (the value head's first layer is summed by the game's workgroup instead of the GEMM), and at
     15 x 15 both agree with the reference's policy_value_fn output (1e-4).  Then three more simulations: same roots."""
     from rlzero_amd.engine import HipNetEvaluator, MCTSEngine
-    for B, n, noise in ((15, 5, False), (15, 5, True), (11, 5, True), (13, 5, False), (16, 5, True)):
+    for B, n, noise in ((15, 5, False), (15, 5, True), (11, 5, True), (13, 5, False), (16, 5, True), (3, 3, True), (6, 4, False), (9, 5, True), (10, 5, False)):
         net = _net(B, seed=B, g4=g4 if B == 15 else None)
         evaluator = HipNetEvaluator(net, B, 'cuda:0', max_boards=16)
         envs = _positions(B, n, 16, seed=B)

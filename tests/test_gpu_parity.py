@@ -1092,6 +1092,7 @@ def test_search_with_hip_net_equals_search_with_its_values():
     torch.manual_seed(0)
     net = PolicyValueNet(6).to('cuda:0')
     evaluator = HipNetEvaluator(net, 6, 'cuda:0', max_boards=8)
+    evaluator.deferred_priors = False   # (values from the FC GEMM, like hip.forward below; the deferred route: tests/test_deferred.py)
     eng = _engine(6, 4, n_games=8, n_playout=80)
     eng.reset_games()
     eng.simulate(evaluator, 80)
@@ -1205,6 +1206,7 @@ def test_puct_search_with_hip_net_vs_oracle():
             net.act_fc1.weight.mul_(20.0)
         net = net.to('cuda:0')
         evaluator = HipNetEvaluator(net, B, 'cuda:0', max_boards=8)
+        evaluator.deferred_priors = False   # (the one-game probe below follows the reference's rule: it must take the PUCT engine's route)
         probe = _engine(B, n, n_games=1, n_playout=2)
 
         def pvf(env, probe=probe, evaluator=evaluator):

@@ -38,19 +38,20 @@ def test_coverage_counts_overlaps():
 
 @pytest.mark.gpu
 def test_trace_of_the_four_lane_layout():
-    """The shipped layout (512 games, four lanes, hipGraphs, pipelined moves) with the trace attached, 48 simulations per move:
-    every lane's last search is there in full -- 48 trunk launches of 128 workgroups and as many tree steps --, the CUs are mostly
+    """The shipped layout (512 games, four lanes, hipGraphs, pipelined moves) with the trace attached, 160 simulations per move:
+    every lane's last search is there in full -- 160 trunk launches of 128 workgroups and 150 tree steps --, the CUs are mostly
     under trunk workgroups, and more than one lane's trunk is on the chip at a time."""
     import torch
     from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
     from rlzero_amd.trace import measure
     torch.manual_seed(0)
     net = PolicyValueNet(15).to('cuda:0').eval()
-    out = measure(net, 15, 5, n_games=512, n_playout=48, warm_moves=2)
-    assert out['lanes_in_layout'] == 4 and out['records'] == 4 * 48 * 128 * 2
+    out = measure(net, 15, 5, n_games=512, n_playout=160, warm_moves=2)
+    # (the last step of a graph chunk of 16 is backup only -- the next chunk opens with its own selection -- and is not traced: 150 tree steps)
+    assert out['lanes_in_layout'] == 4 and out['records'] == 4 * 128 * (160 + 150)
     for ln in '0123':
         lane = out['lanes'][ln]
-        assert lane['trunk_launches'] == 48 and lane['workgroups_per_trunk_launch'] == 128.0
+        assert lane['trunk_launches'] == 160 and lane['workgroups_per_trunk_launch'] == 128.0
         assert 5.0 < lane['tree_launch_us'] < 60.0 and 15.0 < lane['trunk_launch_us'] < 120.0
-    assert 0.5 < out['cu_time_in_trunk'] <= 1.0 and out['launches_in_flight'] > 1.3 and out['cus_seen'] >= 200
+    assert 0.5 < out['cu_time_in_trunk'] <= 1.0 and out['launches_in_flight'] > 1.3 and 200 <= out['cus_seen'] <= 256 and out['window'] == 'all lanes searching'
     assert 15.0 < out['trunk_workgroup_us']['mean'] < 40.0 and out['sims_per_sec_in_window'] > 3e6

@@ -1374,6 +1374,7 @@ struct rz_muzero {
     MzModel model = {};          // rz_mz_load_model
     float *d_model = nullptr;    // one allocation behind the pointers above
     bool model_loaded = false, representation_loaded = false;
+    bool f16_ok = false;   // rz_mz_load_model: finite weights and a finite bound on relu(dyn1): whole MOVES may run their layers on the f16 pipe
     float *d_rep = nullptr;      // rz_mz_load_representation
     int n_cus = 256;             // of cfg.device
     int games_per_wg = 0;        // rz_mz_set_search_shape: 0 = chosen from n_games and n_cus
@@ -1588,6 +1589,18 @@ int rz_mz_load_model(rz_muzero *e, const float *const *h_params, int32_t n_param
             s1 = std::ldexp(1.0f, ex - 1);
         }
         host[off_scales + 4] = s1;
+        // the f16 pieces of whole MOVES cannot overflow when the weights are finite: hidden states are min-max scaled to [0, 1]
+        // (stored x 16), relu(dyn1) is stored x s1 with bound x s1 < 60000, every weight x its power of two lies below 2^14.  Weights
+        // WITHOUT finite values give no such bound: the whole-moves route then refuses to run (rz_mz_play_cartpole) instead of
+        // filling the trees with inf -- the move-by-move routes (f32-input MFMA, PyTorch-ROCm) remain.
+        bool finite = std::isfinite(bound);
+        for (int i = 0; i < 14 && finite; ++i)
+            for (size_t q = 0; q < sizes[i]; ++q)
+                if (!std::isfinite(h_params[i][q])) {
+                    finite = false;
+                    break;
+                }
+        e->f16_ok = finite;
     }
     if (hipDeviceSynchronize() != hipSuccess) return mz_fail(RZ_ERR_HIP, "hipDeviceSynchronize failed");
     if (e->d_model == nullptr) {
@@ -1685,6 +1698,9 @@ int rz_mz_play_cartpole(rz_muzero *e, float *d_hidden, int32_t n_sims, int32_t n
     if (rc != RZ_OK) return rc;
     if (!e->model_loaded || !e->representation_loaded) return mz_fail(RZ_ERR_ARG, "rz_mz_load_model and rz_mz_load_representation first");
     if (e->cfg.n_actions != 2) return mz_fail(RZ_ERR_ARG, "CartPole has 2 actions");
+    if (!e->f16_ok)
+        return mz_fail(RZ_ERR_ARG, "the model has non-finite weights: whole moves run their layers on the f16 matrix pipe and need finite "
+                                   "bounds (use the move-by-move search, rz_mz_search / fused_moves=False)");
     if (d_hidden == nullptr || play == nullptr || n_sims < 1 || n_sims > e->cfg.n_sims || n_moves < 1)
         return mz_fail(RZ_ERR_ARG, "NULL pointer or n_sims / n_moves out of range");
     if (!play->d_state || !play->d_steps || !play->d_episode || !play->d_episode_start || !play->d_ring || !play->d_arena ||

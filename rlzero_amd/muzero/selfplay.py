@@ -153,7 +153,7 @@ class MuZeroSelfPlay(object):
         per environment and move, a chunk behind the GPU.  None = whenever ``fused`` holds and the environment is a
         CartPoleBatch (the environment step is device code).  Its random draws (root noise, actions) come from the
         kernel's counter-based stream keyed (seed, environment, episode, step), not from the torch generator.
-        ``arena_rows``: records the per-launch arena of finished episodes holds (None = twice what a launch plays + a few
+        ``arena_rows``: records the per-launch arena of finished episodes holds (None = 1.25 x what a launch plays + a few
         long episodes; episodes that do not fit are read back from the device ring instead)."""
         import torch
         from .tree import MuZeroTree
@@ -393,9 +393,14 @@ class MuZeroSelfPlay(object):
             steps = int(self.env.max_episode_steps) + 2 * K + 12
             self._ring = t.zeros((G, steps, row), dtype=t.float64, **kw)
             self._ep_start_dev = t.full((G, ), self._t, dtype=t.int64, **kw)
-            # in the steady state a launch ends about as many steps of episodes as it plays (G x K); twice that, plus a
-            # few long episodes, always fits -- what does not is read back from the ring (entry with row -1)
-            rows, n_entries = 2 * G * K + 4 * steps, G * K
+            # in the steady state a launch ends about as many steps of episodes as it plays (G x K: every environment plays K
+            # moves, and what ends is as long on average as what was played); the sum fluctuates by L sqrt(G K / L) rows for
+            # episodes of length L (3 % at 500-step episodes of 8192 environments): G x K plus a quarter, plus a few long
+            # episodes, fits -- what does not is read back from the ring (entry with row -1).  The whole arena is copied to
+            # the host behind every launch (the copy is enqueued before the NEXT launch takes the CUs: its blit kernel has to
+            # find room beside the search), so its size is paid: twice G x K here was 21 MB per launch, 31 % of the GPU's
+            # time in copy kernels (profiles/r03/bench_muzero_kernel_stats.csv)
+            rows, n_entries = G * K + G * K // 4 + 4 * steps, G * K
             if self._arena_rows is not None:
                 rows = max(1, int(self._arena_rows))
             self._copy_stream = t.cuda.Stream(device=self.device)

@@ -628,3 +628,22 @@ def test_whole_moves_network_on_the_f16_pipe_agrees_with_the_f32_search():
         assert same.mean() >= 0.97, (gain, float(same.mean()))
         assert np.max(np.abs(out[True][1][same] - out[False][1][same])) <= 1e-4, gain
         assert (out[True][2][same] == out[False][2][same]).all()
+
+
+@pytest.mark.gpu
+def test_whole_moves_refuse_weights_without_finite_bounds():
+    """The f16 layers of whole MOVES have no overflow path for finite weights (bounds in rz_mz_load_model); a model with inf / nan
+    weights gives no bound, and the whole-moves route then fails loudly instead of filling the trees with inf: the move-by-move
+    search still runs."""
+    import torch
+    from rlzero_amd._hip import HipError
+    from rlzero_amd.muzero import CartPoleBatch, MuZeroNet, MuZeroSelfPlay
+    torch.manual_seed(0)
+    net = MuZeroNet().to('cuda:0').eval()
+    with torch.no_grad():
+        net.dyn2.weight.view(-1)[3] = float('inf')
+    sp = MuZeroSelfPlay(net, CartPoleBatch(32, 'cuda:0', seed=0), n_sims=8, seed=0, fused=True)
+    assert sp.fused_moves
+    with pytest.raises(HipError, match='non-finite weights'):
+        sp.collect(2)
+    sp.close()

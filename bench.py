@@ -86,13 +86,15 @@ def tree_bytes_per_sim(scanned, created, depth):
 
 def pmc_traffic(kernel, workload):
     """HBM bytes per launch of ``kernel`` in ``workload`` from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
-    WRITE_SIZE runs of that very workload, gfx950 read correction applied: profiles/r03/pmc_traffic.json, collected by
-    profiles/collect_r03.sh).  None when no counter run exists for the workload."""
-    try:
-        rec = json.load(open(os.path.join(REPO, 'profiles', 'r03', 'pmc_traffic.json')))
-        return rec[workload]['kernels'][kernel]['traffic_bytes_per_launch']
-    except (OSError, KeyError, ValueError, TypeError):
-        return None
+    WRITE_SIZE runs of that very workload, gfx950 read correction applied: profiles/r04/pmc_traffic.json, collected by
+    profiles/collect_r04.sh).  None when no counter run exists for the workload."""
+    for rnd in ('r04', 'r03'):   # (a workload without a counter run of this round keeps the last round's)
+        try:
+            rec = json.load(open(os.path.join(REPO, 'profiles', rnd, 'pmc_traffic.json')))
+            return rec[workload]['kernels'][kernel]['traffic_bytes_per_launch']
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None
 
 
 # --------------------------------------------------------------------------- CPU baseline
@@ -916,7 +918,8 @@ def main():
             achieved = flops / (ms * 1e-3) / 1e12
             peak, pipe_peak, _ = trunk_peak(args)
             pmc_key = line['config']['workload'] + ('+puct' if args.score_mode == 'puct' else '') + \
-                ('+k%d' % args.in_flight if args.in_flight > 1 else '')
+                ('+k%d' % args.in_flight if args.in_flight > 1 else '') + \
+                ('+3launch' if (not deferred_route and args.score_mode != 'puct' and args.in_flight <= 1) else '')
             in_flight = round(per_stream_ms / ms, 2) if lanes > 1 else 1.0
             rf = {'bound': 'mfma', 'kernel': '%s, %d leaves per launch%s' % (
                       evaluator.label, boards_per_launch, (', %.1f launches in flight' % in_flight) if in_flight >= 1.5 else ''),

@@ -16,7 +16,8 @@ import os
 import shutil
 import sys
 
-KERNELS = {'k_trunk': 'k_trunk', 'k_tree_step': 'k_tree_step', 'k_heads': 'k_heads', 'k_mz_search': 'k_mz_search'}
+KERNELS = {'k_trunk': 'k_trunk', 'k_tree_step': 'k_tree_step', 'k_heads': 'k_heads', 'k_mz_search': 'k_mz_search',
+           'k_deferred_priors': 'k_deferred_priors'}
 
 
 def per_kernel(csv_path, counter):
@@ -74,7 +75,7 @@ def main(out):
         except (OSError, ValueError, IndexError):
             continue
         workload = line['config']['workload']
-        workload += {'puct': '+puct', 'c2k16': '+k16'}.get(tag, '')   # same geometry, another rule / mode: its own entry
+        workload += {'puct': '+puct', 'c2k16': '+k16', '3launch': '+3launch'}.get(tag, '')   # same geometry, another rule / mode: its own entry
         rec = {'tag': tag, 'kernels': {}}
         per = {}
         for counter in ('FETCH_SIZE', 'WRITE_SIZE'):

@@ -504,12 +504,27 @@ class BatchedSelfPlay(object):
         for lane in self.lanes:
             self._retire_lane(lane)
 
+    def abandon_running(self):
+        """Drop every game still in a slot (a run that stopped early -- max_moves -- leaves its games there, and a pipelined one
+        leaves their NEXT search finished on the device as well): the slots become idle, their trees are reset, no lane stays
+        primed.  run() starts with this: games of an earlier run are neither played on nor searched a second time on top of a
+        finished search."""
+        if not (self.slot_game >= 0).any() and not any(getattr(lane, 'primed', False) for lane in self.lanes):
+            return
+        self.slot_game[:] = -1
+        for lane in self.lanes:
+            if getattr(lane, 'primed', False):
+                lane.stream.synchronize()
+                lane.primed = False
+            self._retire_lane(lane)
+
     def check(self):
         return [lane.eng.check() for lane in self.lanes]
 
     def run(self, game_ids, max_moves=None, pipelined=False):
         """Play all ``game_ids`` to the end; returns trajectories sorted by game id.  ``pipelined``: the host side of a
         lane's move under the other lanes' simulations (play_move_pipelined); same trajectories."""
+        self.abandon_running()
         if pipelined:
             return self._run_pipelined(game_ids, max_moves)
         pending = list(game_ids)

@@ -45,6 +45,9 @@ def test_config_struct_layout_matches_header():
     assert ctypes.sizeof(_hip.RzStats) == 64
     # rz_mz_cartpole_play: 4 pointers, 2 uint64, 3 doubles, pointer, 2 int32, int64, pointer, int64, 2 pointers, int64
     assert ctypes.sizeof(_hip.RzMzCartPolePlay) == 136 and _hip.RzMzCartPolePlay.first_step.offset == 88
+    # rz_value_head: five pointers + two int32; rz_deferred_logits: a pointer + two int32 (the deferred-priors route, ABI 22)
+    assert ctypes.sizeof(_hip.RzValueHead) == 48 and _hip.RzValueHead.ld.offset == 40 and _hip.RzValueHead.groups.offset == 44
+    assert ctypes.sizeof(_hip.RzDeferredLogits) == 16 and _hip.RzDeferredLogits.rows_per_slot.offset == 12
     assert _hip.RzMzCartPolePlay.max_entries.offset == 128
 
 

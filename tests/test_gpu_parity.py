@@ -612,6 +612,13 @@ def test_two_capped_lanes_with_graphs_equal_one_eager_lane():
     three.run(range(200, 236), max_moves=3, pipelined=True)
     assert any(getattr(lane, 'primed', False) for lane in three.lanes)
     same(one.run(range(110, 140)), three.run(range(110, 140)))
+    # ... also when the later run has fewer games than slots: the games the cut-short run left behind are abandoned (not played
+    # on, not searched a second time on top of their finished search, not returned)
+    three.run(range(236, 272), max_moves=2, pipelined=True)
+    assert (three.slot_game >= 0).sum() == 12
+    few = three.run(range(140, 145), pipelined=True)
+    same(one.run(range(140, 145)), few)
+    assert [t.game_id for t in few] == list(range(140, 145)) and (three.slot_game < 0).all()
     # the PUCT rule READS the priors, Dirichlet noise included: a game's noise stream is keyed by (seed, game id)
     # (rz_set_noise_keys), so slots, lanes and refills still do not matter
     pk = dict(kw, score_mode='puct')

@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 LIB = os.path.join(PKG, 'librlzero_hip.so')
 SOURCES = [os.path.join(PKG, 'csrc', name) for name in ('rz_engine.hip', 'rz_net.hip', 'rz_muzero.hip')]
-HEADERS = [os.path.join(REPO, 'include', 'rlzero_hip.h'), os.path.join(PKG, 'csrc', 'rz_trace.h')]
+HEADERS = [os.path.join(REPO, "include", "rlzero_hip.h"), os.path.join(PKG, "csrc", "rz_trace.h"), os.path.join(PKG, "csrc", "rz_tree.h")]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fno-fast-math', '-fno-slp-vectorize', '-std=c++17',
          '-fPIC', '-shared', '-Wall', '-Wno-unused-function']
 

@@ -348,6 +348,13 @@ class TimedEvaluator(object):
         ok = getattr(self.inner, 'deferred_ok', None)
         return ok is not None and ok(eng)
 
+    def resident_ok(self, eng):
+        ok = getattr(self.inner, 'resident_ok', None)
+        return ok is not None and ok(eng)
+
+    def search_resident(self, eng, n_sims):
+        return self.inner.search_resident(eng, n_sims)
+
     def deferred_trunk(self, eng):
         """Deferred-priors route (two launches per step): the trunk bracketed when recording; the event behind it and the
         first event of the NEXT step of the same eager chunk bracket the tree step launched in between."""
@@ -661,6 +668,8 @@ def main():
             hip_ev.hip.set_heads_algo(heads_algo)
             hip_ev.hip.set_max_workgroups(trunk_wgs)
             hip_ev.deferred_priors = bool(args.deferred)
+            if os.environ.get('RZ_RESIDENT') == '0':   # (profiles/ab_resident.sh: the two-launch step on a batch the resident search would take)
+                hip_ev.resident_search = False
             deferred_route = hip_ev.deferred_ok(eng)
             ev = TimedEvaluator(hip_ev, torch,
                                 {'winograd_f4': 'k_trunk_wino_f4<4>',

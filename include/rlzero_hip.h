@@ -284,6 +284,10 @@ int rz_deferred_reserve(rz_engine *e, int32_t slots);
  * clock, step, block, CU; a search overwrites the records of the one before it.  A diagnostic: traced instantiations of the
  * kernels run, not the production ones. */
 int rz_trace_attach(rz_engine *e, void *d_trace);   /* the evaluator's half: rz_net_trace_attach below */
+/* The engine's device view (pointers and geometry the tree code reads: rlzero_amd/csrc/rz_tree.h, struct Dev) for kernels of the
+ * SAME build that run tree code outside the engine's own launches -- rz_net_search_resident.  out_bytes must be that build's
+ * sizeof(Dev); valid until rz_destroy / the next rz_deferred_reserve. */
+int rz_device_view(rz_engine *e, void *out, int64_t out_bytes);
 /* int32 [n_games]: the store slot the NEXT leaf of each game goes to (= steps since the last flush); the trunk reads it */
 int rz_deferred_slots(rz_engine *e, const int32_t **d_slot_of_game);
 /* rz_expand_backup / rz_tree_step of this route (pair with rz_select_step(e, NULL, ..) + rz_net_trunk_leaves_deferred) */
@@ -429,6 +433,13 @@ int rz_net_trunk_leaves_deferred(rz_net *net, const uint64_t *d_stones, const in
 /* act_fc1 (policy_value_net.py:43) over the stored leaves of slots [0, n_slots) as ONE GEMM (k_heads_split's arithmetic) */
 int rz_net_deferred_gemm(rz_net *net, int32_t n_boards, int32_t n_slots, rz_deferred_logits *out, void *stream);
 int rz_net_trace_attach(rz_net *net, void *d_trace);   /* see rz_trace_attach */
+/* RESIDENT SEARCH -- n_sims consecutive simulations of every active game of `engine` (AlphaZeroMCTS.simulate's loop,
+ * alphazero_mcts.py:82-85) in ONE launch, one workgroup per game: trunk -> value head -> expand / backup -> next selection without
+ * a kernel boundary, the leaf handed from the tree code to the trunk through LDS.  For batches of at most one game per CU (the
+ * single-game API, BASELINE configs[0] and [1]).  The deferred-priors route's arithmetic and bookkeeping: pair with
+ * rz_select_step(engine, NULL, ..) before (the first leaf) and rz_net_deferred_gemm + rz_deferred_flush later; the engine's slots
+ * advance by n_sims.  Same trees, values and priors as rz_net_trunk_leaves_deferred + rz_tree_step_deferred, bit for bit. */
+int rz_net_search_resident(rz_net *net, rz_engine *engine, int32_t n_sims, void *stream);
 int rz_net_heads(rz_net *net, int32_t n_boards, float *d_logp, float *d_value, void *stream);
 /* only the FC GEMM of the heads on the internal features; returns the device pointers that
  * rz_tree_step_raw / rz_expand_backup_raw consume (valid until the next rz_net_reserve / load) */

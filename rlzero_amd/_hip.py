@@ -107,6 +107,7 @@ _SIGNATURES = {
     'rz_tree_step_raw': (c_int, [P, POINTER(RzRawHeads), P, P]),
     'rz_trace_attach': (c_int, [P, P]),
     'rz_net_trace_attach': (c_int, [P, P]),
+    'rz_device_view': (c_int, [P, P, c_int64]),
     'rz_deferred_reserve': (c_int, [P, c_int32]),
     'rz_deferred_slots': (c_int, [P, POINTER(c_void_p)]),
     'rz_expand_backup_deferred': (c_int, [P, POINTER(RzValueHead), P]),
@@ -137,6 +138,7 @@ _SIGNATURES = {
     'rz_net_deferred_reserve': (c_int, [P, c_int32, c_int32]),
     'rz_net_trunk_leaves_deferred': (c_int, [P, P, P, P, c_int32, P, POINTER(RzValueHead), P]),
     'rz_net_deferred_gemm': (c_int, [P, c_int32, c_int32, POINTER(RzDeferredLogits), P]),
+    'rz_net_search_resident': (c_int, [P, P, c_int32, P]),
     'rz_net_heads': (c_int, [P, c_int32, P, P, P]),
     'rz_net_heads_gemm': (c_int, [P, c_int32, POINTER(RzRawHeads), P]),
     'rz_net_forward': (c_int, [P, P, c_int32, P, P, P]),

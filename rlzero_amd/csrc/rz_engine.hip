@@ -1584,6 +1584,14 @@ int rz_trace_attach(rz_engine *e, void *d_trace) {
     return RZ_OK;
 }
 
+int rz_device_view(rz_engine *e, void *out, int64_t out_bytes) {
+    int rc = check_engine(e);
+    if (rc != RZ_OK) return rc;
+    if (out == nullptr || out_bytes != (int64_t)sizeof(Dev)) return fail(RZ_ERR_ARG, "rz_device_view: the caller's view is %lld bytes, the engine's %zu", (long long)out_bytes, sizeof(Dev));
+    memcpy(out, &e->dev, sizeof(Dev));
+    return RZ_OK;
+}
+
 int rz_deferred_slots(rz_engine *e, const int32_t **d_slot_of_game) {
     int rc = check_engine(e);
     if (rc != RZ_OK) return rc;

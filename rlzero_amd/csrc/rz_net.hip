@@ -38,6 +38,7 @@
 
 #include "rlzero_hip.h"
 #include "rz_trace.h"
+#include "rz_tree.h"
 
 void rz_set_error(const char *msg);  // rz_engine.hip
 
@@ -879,6 +880,21 @@ __device__ __forceinline__ float other_half(float x, int h) {
     return __uint_as_float(h ? r[0] : r[1]);
 }
 
+// RESIDENT SEARCH (RES instantiations of the trunk kernels; rz_net_search_resident).  For a batch of at most one game per CU the whole
+// chain of a search lives in ONE workgroup per game and ONE launch: trunk -> value head -> expand / backup -> next selection, n_sims
+// times, the leaf handed from the tree code to the trunk through LDS, the value head's inputs never leaving the CU, the trunk's
+// prologue (weights into registers, LDS zeroing) paid once per launch instead of once per simulation, no kernel boundary inside a
+// search.  The tree code is the engine's own (rz_tree.h: the bodies of k_tree_step_def), the policy features go to the deferred
+// store like in the two-launch step, so trees, priors and values are those of that route bit for bit.
+template <bool RES> struct ResArgs {};
+template <> struct ResArgs<true> {
+    rzt::Dev E;          // the engine's device view (rz_device_view)
+    rz_value_head vh;    // valfeat unused: the inputs stay in LDS
+    int n_sims;          // simulations of this launch: n_sims x (trunk, expand / backup), a selection between two of them
+};
+__device__ __forceinline__ int res_sims(const ResArgs<false> &) { return 0; }
+__device__ __forceinline__ int res_sims(const ResArgs<true> &r) { return r.n_sims; }
+
 // Deferred priors (rz_value_head, include/rlzero_hip.h): where a board's features go when no FC GEMM follows the trunk -- the policy
 // pieces into slot slot_of[board] of a store of `slot_halfs` f16 values per slot (tiles of groups_act K-steps), the value head's
 // inputs as f32 rows of vf_ld floats.  slot_of == nullptr: the ordinary route.
@@ -1568,10 +1584,21 @@ __device__ __forceinline__ void conv_r(const char *in, const void *wts, int lane
 // Left alone hipcc allocates 396 .. 420 here depending on details of the prologue; the cap holds it at 372, no scratch.
 // TRACE (rz_trace.h): instantiated for the 15-row bitboard kernel only -- the layout whose schedule profiles/lane_timeline.py reads;
 // the production kernels carry nothing of it (its live values cost ten registers of a budget that is pinned).
-template <int NT, bool BITS, bool TRACE = false>
+template <int NT, bool BITS, bool TRACE = false, bool RES = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_trunk_rows(NetDev nd, const float *__restrict__ obs, LeafBits leaves,
                                                     float *__restrict__ feat, _Float16 *__restrict__ feat16,
-                                                    int n_boards, unsigned *__restrict__ flags, DeferredOut later) {
+                                                    int n_boards, unsigned *__restrict__ flags, DeferredOut later, ResArgs<RES> res) {
+    static_assert(!RES || (BITS && !TRACE), "the resident search reads positions");
+    // RES: the value head's input row (zero padded to 4 x groups floats), the K-quarter sums of its first layer, the next leaf
+    __shared__ float res_vrow[RES ? 512 : 1];
+    __shared__ float res_part[RES ? rzt::kDefWaves : 1][RES ? rzt::kWave : 1];
+    __shared__ uint64_t res_leaf[RES ? 2 * RZ_BOARD_WORDS + 1 : 1];
+    int res_slot0 = 0;
+    if constexpr (RES) {
+        if ((int)blockIdx.x >= n_boards || res.E.active[blockIdx.x] == 0) return;   // (uniform: before any barrier)
+        res_slot0 = res.E.pend[blockIdx.x];
+        for (int i = threadIdx.x; i < 512; i += 256) res_vrow[i] = 0.0f;
+    }
 #ifdef RZ_NET_PROFILE
     const long long prof_k0 = __builtin_readcyclecounter();
     long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = prof_k0;
@@ -1720,11 +1747,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_t
     NET_TICK(15);
     prof_acc[9] = prof_t - prof_k0;   // the prologue
 #endif
-    for (int board = blockIdx.x; board < n_boards; board += gridDim.x) {
+    // (RES: the "boards" of this workgroup are the leaves of its game's simulations, one after the other)
+    for (int board = blockIdx.x, sim = 0; RES ? sim < res_sims(res) : board < n_boards; RES ? (void)++sim : (void)(board += gridDim.x)) {
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int next_board = board + (int)gridDim.x;
+    const int next_board = RES ? n_boards : board + (int)gridDim.x;   // (RES: the next leaf does not exist yet)
     const int n = lane & 15, g = lane >> 4;
     const char *t2p = reinterpret_cast<const char *>(nd.t2) + (size_t)wave * rt::Geo<32>::steps * 2 * 1024;
     const char *t3p = reinterpret_cast<const char *>(nd.t3) + (size_t)(2 * wave) * rt::Geo<64>::steps * 2 * 1024;
@@ -1853,9 +1881,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_t
         float *dst = feat ? feat + (size_t)board * nd.feat_ld : nullptr;  // null: only the f16 pieces are wanted
         _Float16 *dst16 = feat16 ? feat16 + ((size_t)(board >> 5) * (nd.groups_act + nd.groups_val) * 1024 + (board & 31) * 16)
                                  : nullptr;
-        const bool deferred = later.slot_of != nullptr;
+        const bool deferred = RES || later.slot_of != nullptr;
         float *vdst = nullptr;
-        if (deferred) {   // the policy pieces wait in the store (tiles of groups_act K-steps), the value inputs go on as f32
+        if constexpr (RES) {   // the game's slot advances by one per simulation (expand_backup_body<DEF>); the value inputs stay in LDS
+            dst16 = feat16 + (size_t)(res_slot0 + sim) * later.slot_halfs + (size_t)(board >> 5) * nd.groups_act * 1024 + (board & 31) * 16;
+            vdst = res_vrow;
+        } else if (deferred) {   // the policy pieces wait in the store (tiles of groups_act K-steps), the value inputs go on as f32
             dst16 = feat16 + (size_t)later.slot_of[board] * later.slot_halfs + (size_t)(board >> 5) * nd.groups_act * 1024 + (board & 31) * 16;
             vdst = later.valfeat + (size_t)board * later.vf_ld;
         }
@@ -1892,6 +1923,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_t
     NET_TICK(7);
     __syncthreads();   // the shares are read: the next board's conv1 may overwrite them
     NET_TICK(8);
+    if constexpr (RES) {
+        // ---- the rest of the simulation, by the same workgroup (k_tree_step_def's body: rz_tree.h): the value head's first layer
+        // by K-quarters from the row in LDS, then wave 0 -- the game's wave -- finishes the value, reserves the prior block, backs
+        // up and selects the next leaf, which comes back through LDS
+        const int game = blockIdx.x;
+        if (res.vh.groups == 128) rzt::value_quarter_lds<16>(res.vh, res_vrow, lane, wave, res_part);
+        else rzt::value_quarter_lds<8>(res.vh, res_vrow, lane, wave, res_part);
+        if (wave == 0) rzt::expand_backup_body<float, false, false, false, true>(res.E, nullptr, nullptr, game, lane, rz_raw_heads(), 0, res.vh, res_part);
+        else __syncthreads();   // (the barrier inside the body, where the quarters meet)
+        __syncthreads();        // the tree's updates before the selection's loads
+        const bool more = sim + 1 < res_sims(res);
+        if (wave == 0 && more) rzt::select_body<false>(res.E, nullptr, game, lane, 0, res_leaf);
+        __syncthreads();
+        if (more) {   // the planes of the next leaf, from LDS: what load_bits forms from the leaf arrays
+            int nst = 0;
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) nst += __popcll(res_leaf[q8]);
+            const int tm = reinterpret_cast<const int *>(res_leaf + 2 * RZ_BOARD_WORDS)[0], lc = reinterpret_cast<const int *>(res_leaf + 2 * RZ_BOARD_WORDS)[1];
+            const int word = (tid >> 6) & 3, bit = tid & 63;
+            const uint64_t w0 = res_leaf[word], w1 = res_leaf[4 + word];
+            const bool s0 = (w0 >> bit) & 1ull, s1 = (w1 >> bit) & 1ull;
+            const bool mine = tm == 0 ? s0 : s1, theirs = tm == 0 ? s1 : s0;
+            const _Float16 one = (_Float16)sp::kObsScale, zero = (_Float16)0.0f;
+            cell_planes[0] = mine ? one : zero;
+            cell_planes[1] = theirs ? one : zero;
+            cell_planes[2] = (nst > 0 && tid == lc) ? one : zero;
+            cell_planes[3] = (nst & 1) ? zero : one;
+            store_obs();
+            __syncthreads();
+        }
+    }
     }  // boards
 #ifdef RZ_NET_PROFILE
     if (blockIdx.x == 0 && tid0 == 0) {
@@ -2584,12 +2646,18 @@ static void launch_trunk_rows(bool bits, dim3 grid, hipStream_t stream, const Ne
                               _Float16 *f16, int n_boards, unsigned *flags, DeferredOut later = DeferredOut{nullptr, 0, nullptr, 0, nullptr}) {
     if constexpr (NT == 15) {
         if (bits && later.trace) {
-            k_trunk_rows<NT, true, true><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later);
+            k_trunk_rows<NT, true, true><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later, ResArgs<false>{});
             return;
         }
     }
-    if (bits) k_trunk_rows<NT, true><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later);
-    else k_trunk_rows<NT, false><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later);
+    if (bits) k_trunk_rows<NT, true><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later, ResArgs<false>{});
+    else k_trunk_rows<NT, false><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later, ResArgs<false>{});
+}
+
+template <int NT>
+static void launch_search_rows(dim3 grid, hipStream_t stream, const NetDev &nd, LeafBits leaves, _Float16 *store, int n_games, unsigned *flags,
+                               DeferredOut later, const ResArgs<true> &res) {
+    k_trunk_rows<NT, true, false, true><<<grid, dim3(256), 0, stream>>>(nd, nullptr, leaves, nullptr, store, n_games, flags, later, res);
 }
 
 extern "C" {
@@ -3049,6 +3117,47 @@ int rz_net_trunk_leaves_deferred(rz_net *net, const uint64_t *d_stones, const in
     out->b2 = net->dev.fc_val2_b;
     out->ld = net->vf_groups * 4;
     out->groups = net->vf_groups;
+    return RZ_OK;
+}
+
+int rz_net_search_resident(rz_net *net, rz_engine *engine, int32_t n_sims, void *stream) {
+    rzt::Dev dev;
+    int rc = rz_device_view(engine, &dev, (int64_t)sizeof(dev));
+    if (rc != RZ_OK) return rc;
+    if ((rc = net_ready(net, dev.n_games)) != RZ_OK) return rc;
+    if (n_sims < 1) return net_fail(RZ_ERR_ARG, "rz_net_search_resident: n_sims must be positive");
+    if (!deferred_trunk_covers(net) || !rows_kernel_covers(net->dev.BH, net->dev.BW) || net->algo != RZ_NET_SPLIT_F16)
+        return net_fail(RZ_ERR_ARG, "the resident search needs the RZ_NET_SPLIT_F16 trunk on a board of 11 .. 16 rows and columns");
+    if (dev.K != 1 || dev.score_mode != RZ_SCORE_UCT_REF || dev.pend_cap <= 0)
+        return net_fail(RZ_ERR_ARG, "the resident search is the deferred-priors route: RZ_SCORE_UCT_REF, one simulation in flight, rz_deferred_reserve first");
+    if (dev.BH != net->dev.BH || dev.BW != net->dev.BW || dev.A != net->dev.A) return net_fail(RZ_ERR_ARG, "engine and network disagree on the board");
+    if (dev.n_games > net->store_boards || dev.n_games > net->n_cus)
+        return net_fail(RZ_ERR_ARG, "the resident search runs one workgroup per game, at most one per CU and rz_net_deferred_reserve()d");
+    if (net->vf_groups != 64 && net->vf_groups != 128) return net_fail(RZ_ERR_INTERNAL, "value head groups");
+    ResArgs<true> res;
+    res.E = dev;
+    memset(&res.vh, 0, sizeof(res.vh));
+    res.vh.w1t = net->d_w1t;
+    res.vh.b1 = net->dev.fc_val1_b;
+    res.vh.w2 = net->dev.fc_val2_w;
+    res.vh.b2 = net->dev.fc_val2_b;
+    res.vh.ld = net->vf_groups * 4;
+    res.vh.groups = net->vf_groups;
+    res.n_sims = n_sims;
+    const DeferredOut later{dev.pend, (long long)net->store_tiles * net->dev.groups_act * 1024, nullptr, 0, nullptr};
+    const LeafBits leaves{dev.leaf_stones, dev.leaf_to_move, dev.leaf_last};
+    const dim3 grid((unsigned)dev.n_games);
+    const hipStream_t st = (hipStream_t)stream;
+    net->feat16_valid = net->feat32_valid = false;
+    switch (net->dev.BH) {
+        case 11: launch_search_rows<11>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res); break;
+        case 12: launch_search_rows<12>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res); break;
+        case 13: launch_search_rows<13>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res); break;
+        case 14: launch_search_rows<14>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res); break;
+        case 15: launch_search_rows<15>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res); break;
+        default: launch_search_rows<16>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res); break;
+    }
+    if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of the resident search failed");
     return RZ_OK;
 }
 

@@ -460,8 +460,11 @@ __device__ __forceinline__ int scan_children(const Dev &E, const int4 *R, const 
 // by the real value.  A first-visit child gets a placeholder record (N = 1, W = -1) at once, so the prefix invariant
 // and the scans hold while its evaluation is pending; two slots may end in the same unexpanded leaf (both are
 // evaluated, the first backup expands it).  Per-leaf state is indexed by g * K + j.
+// `lds_leaf` (the resident search kernels, rz_net.hip): the leaf position also goes to LDS -- uint64 [8] stones, then side to move
+// and last cell as two int32 -- where the trunk of the SAME workgroup reads it behind a barrier (a scalar load of the leaf arrays
+// could hit the scalar cache's copy of the previous simulation's leaf).
 template <bool VL>
-__device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int lane, int j = 0) {
+__device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int lane, int j = 0, uint64_t *lds_leaf = nullptr) {
     const int gk = VL ? g * E.K + j : g;
     // every load that does not depend on another one is issued before `active` is tested: a kernel of dependent
     // round trips (an inactive game's slots exist, reading them is harmless)
@@ -614,6 +617,13 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
         E.leaf_last[gk] = last;
     }
     store_board(E.leaf_stones, gk, st, lane);
+    if (lds_leaf != nullptr) {
+        store_board(lds_leaf, 0, st, lane);
+        if (lane == 0) {
+            reinterpret_cast<int *>(lds_leaf + 2 * kWords)[0] = to_move;
+            reinterpret_cast<int *>(lds_leaf + 2 * kWords)[1] = last;
+        }
+    }
     if (obs != nullptr)
         write_obs(obs + (long long)gk * 4 * S, to_move == 0 ? st[0] : st[1],
                   to_move == 0 ? st[1] : st[0], last, nst, S, lane);
@@ -882,6 +892,34 @@ __device__ __forceinline__ void value_quarter_def(const ValueHead &vh, int gk, i
             a1 = fmaf(fv[i].w, wv[i].w, a1);
         }
         __builtin_amdgcn_sched_barrier(0);   // (the second half's loads are not hoisted over the first half's sums: registers)
+    }
+    part[q][lane] = a0 + a1;
+}
+
+// the same quarter with the input row in LDS (`row`: 8 x PER x 4 floats, zero padded; every lane reads the same address: a
+// broadcast) -- the resident search kernels, whose trunk leaves the value head's inputs on the CU.  Same operations, same order.
+template <int PER>
+__device__ __forceinline__ void value_quarter_lds(const ValueHead &vh, const float *row, int lane, int q, float (*part)[kWave]) {
+    typedef float vec4 __attribute__((ext_vector_type(4)));
+    const vec4 *w = reinterpret_cast<const vec4 *>(vh.w1t) + (size_t)q * 2 * PER * kWave + lane;
+    const vec4 *f = reinterpret_cast<const vec4 *>(row) + q * 2 * PER;
+    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        vec4 wv[PER], fv[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            wv[i] = w[(size_t)(half * PER + i) * kWave];
+            fv[i] = f[half * PER + i];
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            a0 = fmaf(fv[i].x, wv[i].x, a0);
+            a1 = fmaf(fv[i].y, wv[i].y, a1);
+            a0 = fmaf(fv[i].z, wv[i].z, a0);
+            a1 = fmaf(fv[i].w, wv[i].w, a1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
     part[q][lane] = a0 + a1;
 }

@@ -150,6 +150,15 @@ class HipNet(object):
                                                     ctypes.byref(out), self._stream()), 'rz_net_trunk_leaves_deferred')
         return out
 
+    def supports_resident(self):
+        """True when whole searches can run as ONE launch, one workgroup per game (rz_net_search_resident)."""
+        return getattr(self, 'algo', 'split_f16') == 'split_f16' and getattr(self, '_split_ok', True) \
+            and 11 <= self.rows <= 16 and 11 <= self.cols <= 16
+
+    def search_resident(self, eng, n_sims):
+        """``n_sims`` simulations of every active game of ``eng`` in one launch (the first leaves selected: rz_select_step)."""
+        check(self.lib.rz_net_search_resident(self.handle, eng.handle, int(n_sims), self._stream()), 'rz_net_search_resident')
+
     def deferred_gemm(self, n_boards, n_slots):
         """act_fc1 over the stored leaves of slots [0, n_slots) as one GEMM -> RzDeferredLogits."""
         out = _hip.RzDeferredLogits()
@@ -294,6 +303,17 @@ class HipNetEvaluator(object):
 
     def deferred_trunk(self, eng):
         return self.hip.trunk_leaves_deferred(eng)
+
+    # The resident search: for a batch of at most one game per CU the simulations of a search run as ONE launch, one workgroup per
+    # game (trunk -> value head -> expand / backup -> selection, no kernel boundary; the deferred route's trees, values and priors).
+    resident_search = True
+
+    def resident_ok(self, eng):
+        return (self.resident_search and self.deferred_ok(eng) and self.hip.supports_resident()
+                and eng.n_games <= self.hip.torch.cuda.get_device_properties(self.hip.device).multi_processor_count)
+
+    def search_resident(self, eng, n_sims):
+        self.hip.search_resident(eng, n_sims)
 
     def raw_heads(self, eng):
         if not self.needs_obs:
@@ -676,9 +696,17 @@ class MCTSEngine(object):
         """sim_chunk on the deferred-priors route: per step the trunk (policy features into the step's store slot, value inputs
         on) and ONE tree launch (value head, backup, next selection)."""
         lib, h = self.lib, self.handle
+        res_ok = getattr(evaluator, 'resident_ok', None)
+        resident = res_ok is not None and res_ok(self)
         while n > 0:
             m = self._deferred_begin(evaluator, n)
             check(lib.rz_select_step(h, None, self.stream()), 'rz_select_step')
+            if resident:   # the m simulations in ONE launch, one workgroup per game
+                evaluator.search_resident(self, m)
+                if not self._capturing:
+                    self._def_pending += m
+                n -= m
+                continue
             for i in range(m):
                 head = evaluator.deferred_trunk(self)
                 if i + 1 < m:
@@ -721,8 +749,9 @@ class MCTSEngine(object):
         use_graph: replay a hipGraph holding ``sims_per_graph`` simulations (captured by
         ``warm_graph``) instead of launching kernel by kernel; device-side evaluators only."""
         n = self.n_playout if n_sims is None else int(n_sims)
-        if not use_graph or isinstance(evaluator, HostEvaluator):
-            self.sim_chunk(evaluator, n)
+        res_ok = getattr(evaluator, 'resident_ok', None)
+        if not use_graph or isinstance(evaluator, HostEvaluator) or (res_ok is not None and res_ok(self)):
+            self.sim_chunk(evaluator, n)   # (the resident search is two launches for the whole search: nothing to capture)
             return
         per = self._whole_steps(sims_per_graph)
         if per > n:

@@ -224,3 +224,49 @@ def test_an_evaluator_of_another_route_takes_over_cleanly():
     eng.check()
     eng.close()
     evaluator.hip.close()
+
+
+def test_resident_search_is_the_two_launch_step_in_one_launch():
+    """rz_net_search_resident: for a batch of at most one game per CU the simulations of a search run as ONE launch, one workgroup per
+    game -- trunk, value head, expand / backup and the next selection back to back, the leaf handed over through LDS.  It is the
+    deferred route's arithmetic and bookkeeping: over three moves with tree reuse every visited node's N, W and priors equal those
+    of the two-launch step, bit for bit; boards of 11 .. 16 rows, rectangles, noise, inactive games, hipGraph callers."""
+    import torch
+    from rlzero_amd.engine import HipNetEvaluator, MCTSEngine
+    for (rows, cols), sims, noise in (((15, 15), 90, True), ((11, 11), 60, False), ((16, 16), 40, True), ((13, 13), 50, True)):
+        B = rows
+        torch.manual_seed(rows)
+        net = _net(B, seed=rows)
+        envs = _positions(B, 5, 7, seed=rows)
+        dumps = {}
+        for resident in (True, False):
+            evaluator = HipNetEvaluator(net, B, 'cuda:0', max_boards=len(envs))
+            evaluator.resident_search = resident
+            eng = MCTSEngine(B, 5, n_games=len(envs), n_playout=sims, device='cuda:0', add_noise=noise, noise_seed=5)
+            assert evaluator.resident_ok(eng) == resident and evaluator.deferred_ok(eng)
+            _set_roots(eng, envs)
+            eng.set_noise_keys()
+            active = np.ones(len(envs), dtype=np.uint8)
+            active[3] = 0   # an idle slot: its workgroup ends at once, its tree stays a fresh root
+            eng.set_active(active)
+            record = []
+            for move in range(3):
+                eng.simulate(evaluator, sims, use_graph=False)
+                assert eng._def_pending == sims
+                visits = eng.root_visits()
+                record.append(visits.copy())
+                record.append([_whole_tree(eng, g) for g in range(len(envs))])
+                moves = np.where(active > 0, visits.argmax(axis=1), -2).astype(np.int32)
+                eng.advance(moves)
+                eng.step(np.where(moves >= 0, moves, -1).astype(np.int32))
+            st = eng.check()
+            assert st.reuse_dropped == 0
+            dumps[resident] = record
+            eng.close()
+            evaluator.hip.close()
+        for a, b in zip(dumps[True], dumps[False]):
+            if isinstance(a, np.ndarray):
+                assert np.array_equal(a, b), (rows, cols)
+                assert (a[3] == 0).all() and a[0].sum() >= sims - 1   # (the first simulation expands the root; later moves carry a subtree)
+            else:
+                assert a == b, (rows, cols)

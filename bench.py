@@ -657,7 +657,7 @@ def main():
     net = (PolicyValueNet(6, 7, 7) if args.game == 'connect4' else PolicyValueNet(board)).to(device).eval()
     net_shape = (6, 7, 7) if args.game == 'connect4' else board
     engines, evaluators = [], []
-    deferred_route = False
+    deferred_route = resident_route = False
     for g_lane in per_lane:
         eng = MCTSEngine(board, n_row, n_games=g_lane, n_playout=args.playouts, c_puct=C_PUCT, device=device,
                          game=args.game, add_noise=bool(args.noise), noise_seed=1000 * rank + len(engines),
@@ -671,6 +671,7 @@ def main():
             if os.environ.get('RZ_RESIDENT') == '0':   # (profiles/ab_resident.sh: the two-launch step on a batch the resident search would take)
                 hip_ev.resident_search = False
             deferred_route = hip_ev.deferred_ok(eng)
+            resident_route = lanes == 1 and hip_ev.resident_ok(eng)   # (BatchedSelfPlay switches it off for several lanes)
             ev = TimedEvaluator(hip_ev, torch,
                                 {'winograd_f4': 'k_trunk_wino_f4<4>',
                                  'split_f16': 'k_trunk_rows' if (args.game == 'gomoku' and 11 <= board <= 16) else 'k_trunk_split',
@@ -894,7 +895,8 @@ def main():
                        'dirichlet_noise': bool(args.noise), 'sims_per_graph': args.graph,
                        'priors': 'deferred (one policy GEMM + one priors kernel per move, outside the chain of a simulation step)'
                        if deferred_route else 'written by every tree step',
-                       'launches_per_step': 2 if deferred_route else 3,
+                       'launches_per_step': (0 if resident_route else 2) if deferred_route else 3,
+                       'resident_search': bool(resident_route),
                        'hw_queues': int(os.environ.get('GPU_MAX_HW_QUEUES', '4')),   # hardware queues asked of the HIP runtime (a lane each)
                        'parallelism': 'games sharded, dp%d' % world},
             'regions_sims_per_sec': [round(r[1] / r[0], 1) for r in regions], 'warmup_moves_run': n_ramp,
@@ -964,6 +966,19 @@ def main():
                         'achieved': round(gbs, 2), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 5),
                         'traffic': pmc_traffic('k_tree_step', pmc_key),
                         'avg_launch_ms': round(tr_ms, 4)}
+        elif resident_route:
+            # The resident search: ONE launch per search, one workgroup per game running trunk -> value head -> expand / backup ->
+            # selection n_playout times.  The dominant work is still the trunk's: its algorithmic flops for the G leaves of a
+            # simulation step / the wall-clock per step (tree code, boundaries between moves and host time all charged to it).
+            step_ms = elapsed * 1e3 / (total_sims / world / G)
+            flops = trunk_flops_per_position(cells) * G
+            achieved = flops / (step_ms * 1e-3) / 1e12
+            peak, pipe_peak, _ = trunk_peak(args)
+            line['roofline'] = {'bound': 'mfma', 'kernel': '%s<RES> (resident search: trunk + value head + tree step of a game in one '
+                                'workgroup, one launch per search), %d games' % (evaluator.label, G),
+                                'achieved': round(achieved, 3), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
+                                'traffic': None, 'avg_launch_ms': round(step_ms * args.playouts, 4), 'ms_per_simulation_step': round(step_ms, 5),
+                                'launches_per_search': 2, 'trunk_workgroups': G}
         else:
             per_sim = tree_bytes_per_sim(365.5, 208.8, 1.74) if board == 15 else None
             if per_sim:
@@ -981,7 +996,7 @@ def main():
         # launch trace attached -- every trunk / tree-step workgroup leaves its start, end and CU -- behind everything that is timed.
         # launches_in_flight, the CUs' time under trunk workgroups and the lanes' step cycle come from those records, not from a
         # ratio of averaged event intervals (rocprofv3 serialises the lanes' queues: profiles/r03/trunk_overlap_default.json).
-        if args.timeline and deferred_route and world == 1 and lanes > 1 and args.evaluator == 'hipnet' and 'roofline' in line:
+        if args.timeline and deferred_route and not resident_route and world == 1 and lanes > 1 and args.evaluator == 'hipnet' and 'roofline' in line:
             try:
                 from rlzero_amd.trace import measure
                 tl = measure(net, board, n_row, n_games=G, n_playout=args.playouts, lanes=lanes, device=device, add_noise=bool(args.noise))

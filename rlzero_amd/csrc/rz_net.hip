@@ -911,17 +911,29 @@ struct DeferredOut {
 // quarters summed in wave order, fmaf(sum, scale, bias)): the same bits, one launch and one kernel boundary less in the chain
 // trunk -> FC -> tree step of a small batch.  A board is row 0 of the MFMA's 32 (the other rows are zero: rows do not mix), its
 // features never leave the CU (f16 pieces in LDS), the weights stream from L2.
-template <int TN, int MS = 1>
+template <int TN, int MS = 1, bool RES = false>
 __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__restrict__ obs, LeafBits leaves,
                                                      float *__restrict__ feat, _Float16 *__restrict__ feat16,
                                                      int n_boards, unsigned *__restrict__ flags,
                                                      float *__restrict__ raw = nullptr, float *__restrict__ hid = nullptr,
-                                                     DeferredOut later = DeferredOut{nullptr, 0, nullptr, 0, nullptr}) {
+                                                     DeferredOut later = DeferredOut{nullptr, 0, nullptr, 0, nullptr},
+                                                     ResArgs<RES> res = ResArgs<RES>{}) {
 #ifdef RZ_NET_PROFILE
     const long long prof_k0 = __builtin_readcyclecounter();
     long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = prof_k0;
 #endif
     constexpr int kThreads = 256;
+    // RES (the resident search, see ResArgs): the value head's input row (boards of up to 10 rows and columns: 2 S <= 256 with
+    // the padding), the K-quarter sums of its first layer, the next leaf
+    __shared__ float res_vrow[RES ? 256 : 1];
+    __shared__ float res_part[RES ? rzt::kDefWaves : 1][RES ? rzt::kWave : 1];
+    __shared__ uint64_t res_leaf[RES ? 2 * RZ_BOARD_WORDS + 1 : 1];
+    int res_slot0 = 0;
+    if constexpr (RES) {
+        if ((int)blockIdx.x >= n_boards || res.E.active[blockIdx.x] == 0) return;   // (uniform: before any barrier)
+        res_slot0 = res.E.pend[blockIdx.x];
+        res_vrow[threadIdx.x] = 0.0f;
+    }
     __shared__ __attribute__((aligned(16))) char lds_raw[sp::kLdsBytes];
     char *in0 = lds_raw;                      // observation planes, pieces hi | lo
     char *c1 = lds_raw + sp::kInBytes;        // conv1 output, pieces hi | lo
@@ -1072,11 +1084,11 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     NET_TICK(15);
     prof_acc[9] = prof_t - prof_k0;   // the prologue
 #endif
-    for (int board = blockIdx.x; board < n_boards; board += gridDim.x) {
+    for (int board = blockIdx.x, sim = 0; RES ? sim < res_sims(res) : board < n_boards; RES ? (void)++sim : (void)(board += gridDim.x)) {
     int tid = tid0;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int next_board = board + (int)gridDim.x;
+    const int next_board = RES ? n_boards : board + (int)gridDim.x;   // (RES: the next leaf does not exist yet)
     // MS = 3 (three N-tiles of 3 rows: 9x9): waves 0 .. 2 = the tiles with M-tiles 0 .. 2 of conv3 (and all of conv1 / conv2),
     // wave 3 = part 1 = conv3's M-tile 3 for ALL three tiles: 9 MFMAs per K-step in every wave instead of 12 in three
     constexpr int kTiles = MS == 3 ? 3 : 4 / MS;          // waves side by side over the board's rows
@@ -1317,9 +1329,12 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         // sector (written whole by neighbouring lanes of this wave), a wave of the GEMM reads the 1 KB of a piece
         _Float16 *dst16 = feat16 ? feat16 + ((size_t)(board >> 5) * (nd.groups_act + nd.groups_val) * 1024 + (board & 31) * 16)
                                  : nullptr;
-        const bool deferred = later.slot_of != nullptr;   // (DeferredOut: the policy pieces wait in the store, the value inputs go on as f32)
+        const bool deferred = RES || later.slot_of != nullptr;   // (DeferredOut: the policy pieces wait in the store, the value inputs go on as f32)
         float *vdst = nullptr;
-        if (deferred) {
+        if constexpr (RES) {   // the game's slot advances by one per simulation; the value inputs stay in LDS
+            dst16 = feat16 + (size_t)(res_slot0 + sim) * later.slot_halfs + (size_t)(board >> 5) * nd.groups_act * 1024 + (board & 31) * 16;
+            vdst = res_vrow;
+        } else if (deferred) {
             dst16 = feat16 + (size_t)later.slot_of[board] * later.slot_halfs + (size_t)(board >> 5) * nd.groups_act * 1024 + (board & 31) * 16;
             vdst = later.valfeat + (size_t)board * later.vf_ld;
         }
@@ -1450,6 +1465,37 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
                 }
             }
             __syncthreads();   // (a further board of this workgroup reuses the pieces and the partial sums)
+        }
+    }
+    if constexpr (RES) {
+        // ---- the rest of the simulation, by the same workgroup (see k_trunk_rows: the body of k_tree_step_def, rz_tree.h)
+        __syncthreads();   // the value head's inputs are in LDS
+        const int game = blockIdx.x;
+        if (res.vh.groups == 64) rzt::value_quarter_lds<8>(res.vh, res_vrow, lane, wave, res_part);
+        else if (res.vh.groups == 32) rzt::value_quarter_lds<4>(res.vh, res_vrow, lane, wave, res_part);
+        else rzt::value_quarter_lds<2>(res.vh, res_vrow, lane, wave, res_part);
+        if (wave == 0) rzt::expand_backup_body<float, false, false, false, true>(res.E, nullptr, nullptr, game, lane, rz_raw_heads(), 0, res.vh, res_part);
+        else __syncthreads();   // (the barrier inside the body, where the quarters meet)
+        __syncthreads();        // the tree's updates before the selection's loads
+        const bool more = sim + 1 < res_sims(res);
+        if (wave == 0 && more) rzt::select_body<false>(res.E, nullptr, game, lane, 0, res_leaf);
+        __syncthreads();
+        if (more) {   // the planes of the next leaf, from LDS: what load_bits forms from the leaf arrays
+            int nst = 0;
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) nst += __popcll(res_leaf[q8]);
+            const int tm = reinterpret_cast<const int *>(res_leaf + 2 * RZ_BOARD_WORDS)[0], lc = reinterpret_cast<const int *>(res_leaf + 2 * RZ_BOARD_WORDS)[1];
+            const int word = (tid >> 6) & 3, bit = tid & 63;
+            const uint64_t w0 = res_leaf[word], w1 = res_leaf[4 + word];
+            const bool s0 = (w0 >> bit) & 1ull, s1 = (w1 >> bit) & 1ull;
+            const bool mine_ = tm == 0 ? s0 : s1, theirs = tm == 0 ? s1 : s0;
+            const _Float16 one = (_Float16)sp::kObsScale, zero = (_Float16)0.0f;
+            cell_planes[0] = mine_ ? one : zero;
+            cell_planes[1] = theirs ? one : zero;
+            cell_planes[2] = (nst > 0 && tid == lc) ? one : zero;
+            cell_planes[3] = (nst & 1) ? zero : one;
+            store_obs(tid);
+            __syncthreads();
         }
     }
     }  // boards
@@ -3126,14 +3172,17 @@ int rz_net_search_resident(rz_net *net, rz_engine *engine, int32_t n_sims, void 
     if (rc != RZ_OK) return rc;
     if ((rc = net_ready(net, dev.n_games)) != RZ_OK) return rc;
     if (n_sims < 1) return net_fail(RZ_ERR_ARG, "rz_net_search_resident: n_sims must be positive");
-    if (!deferred_trunk_covers(net) || !rows_kernel_covers(net->dev.BH, net->dev.BW) || net->algo != RZ_NET_SPLIT_F16)
-        return net_fail(RZ_ERR_ARG, "the resident search needs the RZ_NET_SPLIT_F16 trunk on a board of 11 .. 16 rows and columns");
+    const bool rows = net->algo == RZ_NET_SPLIT_F16 && rows_kernel_covers(net->dev.BH, net->dev.BW);
+    const int tiles = (net->dev.BH + net->dev.tile_rows - 1) / net->dev.tile_rows;
+    if (!deferred_trunk_covers(net) || (!rows && (tiles > 4 || net->dev.BH > 10 || net->dev.BW > 10)))
+        return net_fail(RZ_ERR_ARG, "the resident search needs the RZ_NET_SPLIT_F16 trunk on a board of 11 .. 16 rows and columns (the row-tile "
+                                    "kernel) or of up to 10 x 10 (k_trunk_split with one N-tile per wave)");
     if (dev.K != 1 || dev.score_mode != RZ_SCORE_UCT_REF || dev.pend_cap <= 0)
         return net_fail(RZ_ERR_ARG, "the resident search is the deferred-priors route: RZ_SCORE_UCT_REF, one simulation in flight, rz_deferred_reserve first");
     if (dev.BH != net->dev.BH || dev.BW != net->dev.BW || dev.A != net->dev.A) return net_fail(RZ_ERR_ARG, "engine and network disagree on the board");
     if (dev.n_games > net->store_boards || dev.n_games > net->n_cus)
         return net_fail(RZ_ERR_ARG, "the resident search runs one workgroup per game, at most one per CU and rz_net_deferred_reserve()d");
-    if (net->vf_groups != 64 && net->vf_groups != 128) return net_fail(RZ_ERR_INTERNAL, "value head groups");
+    if (rows ? (net->vf_groups != 64 && net->vf_groups != 128) : net->vf_groups > 64) return net_fail(RZ_ERR_INTERNAL, "value head groups");
     ResArgs<true> res;
     res.E = dev;
     memset(&res.vh, 0, sizeof(res.vh));
@@ -3149,6 +3198,16 @@ int rz_net_search_resident(rz_net *net, rz_engine *engine, int32_t n_sims, void 
     const dim3 grid((unsigned)dev.n_games);
     const hipStream_t st = (hipStream_t)stream;
     net->feat16_valid = net->feat32_valid = false;
+    if (!rows) {   // (the launches of launch_trunk for these boards, RES instantiations)
+        _Float16 *store = net->d_store16;
+        const int ng = dev.n_games;
+        if (tiles <= 1) k_trunk_split<1, 4, true><<<grid, dim3(256), 0, st>>>(net->dev, nullptr, leaves, nullptr, store, ng, net->d_flags, nullptr, nullptr, later, res);
+        else if (tiles <= 2) k_trunk_split<1, 2, true><<<grid, dim3(256), 0, st>>>(net->dev, nullptr, leaves, nullptr, store, ng, net->d_flags, nullptr, nullptr, later, res);
+        else if (tiles == 3 && net->dev.tile_rows == 3) k_trunk_split<1, 3, true><<<grid, dim3(256), 0, st>>>(net->dev, nullptr, leaves, nullptr, store, ng, net->d_flags, nullptr, nullptr, later, res);
+        else k_trunk_split<1, 1, true><<<grid, dim3(256), 0, st>>>(net->dev, nullptr, leaves, nullptr, store, ng, net->d_flags, nullptr, nullptr, later, res);
+        if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of the resident search failed");
+        return RZ_OK;
+    }
     switch (net->dev.BH) {
         case 11: launch_search_rows<11>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res); break;
         case 12: launch_search_rows<12>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res); break;

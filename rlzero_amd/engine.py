@@ -152,8 +152,9 @@ class HipNet(object):
 
     def supports_resident(self):
         """True when whole searches can run as ONE launch, one workgroup per game (rz_net_search_resident)."""
-        return getattr(self, 'algo', 'split_f16') == 'split_f16' and getattr(self, '_split_ok', True) \
-            and 11 <= self.rows <= 16 and 11 <= self.cols <= 16
+        if getattr(self, 'algo', 'split_f16') != 'split_f16' or not getattr(self, '_split_ok', True):
+            return False
+        return (11 <= self.rows <= 16 and 11 <= self.cols <= 16) or (self.rows <= 10 and self.cols <= 10)
 
     def search_resident(self, eng, n_sims):
         """``n_sims`` simulations of every active game of ``eng`` in one launch (the first leaves selected: rz_select_step)."""

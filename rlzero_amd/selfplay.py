@@ -138,8 +138,9 @@ def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False):
 
     ``deferred``: the batch runs the deferred-priors route (HipNetEvaluator.deferred_ok: UCT_REF, one simulation in flight, boards
     of 11 .. 16 rows).  A lane's step is then trunk -> tree step (23 + 10 us at 15x15) and the table was measured again
-    (profiles/r04/lane_sweep.txt, M simulations / s): up to 0.75 rounds of boards ONE lane (192 games: 6.0 against 5.95 with two);
-    up to one round TWO (256 games: 7.8 against 7.4); up to 1.75 rounds THREE (320 / 384 games: 9.2 / 10.3 against 8.7 / 9.8 with
+    (profiles/r04/lane_sweep.txt, M simulations / s): up to one round of boards ONE lane -- the resident search, one workgroup per game
+    and one launch per search (256 games: 8.7 against 7.8 on two lanes of the two-launch step, profiles/r04/ab_resident.txt); up to
+    1.75 rounds THREE (320 / 384 games: 9.2 / 10.3 against 8.7 / 9.8 with
     two); 448 games TWO (10.3 against 10.1); 2 .. 2.75 rounds FOUR on 8 hardware queues (512 / 640 games: 10.6 / 10.6 against 10.5
     / 10.1 with two -- with fewer queues two lanes, a percent behind); beyond, TWO (768 .. 1536 games: 10.9 .. 11.0).
 
@@ -164,10 +165,8 @@ def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False):
     if hw_queues is None:
         from . import HW_QUEUES as hw_queues
     if deferred:
-        if 4 * n_games <= 3 * n_cus:
+        if n_games <= n_cus:   # one game per CU at most: the resident search (one launch per search, a workgroup per game)
             return 1, 0, 'auto'
-        if n_games <= n_cus:
-            return 2, 0, 'parts'
         if 4 * n_games < 7 * n_cus:
             return 3, 0, 'parts'
         if n_games < 2 * n_cus or 4 * n_games > 11 * n_cus:
@@ -232,6 +231,13 @@ class BatchedSelfPlay(object):
             stream.wait_stream(torch.cuda.current_stream(eng.device))
             self.lanes.append(_Lane(eng, ev, stream, offset))
             offset += eng.n_games
+        if len(engines) > 1:
+            # several lanes share the CUs: the resident search (one workgroup per game for a whole search) is for a batch that has
+            # the chip to itself -- lanes run the two-launch step, whose trunk workgroups make way for the other lanes every step
+            for ev in evaluators:
+                inner = getattr(ev, 'inner', ev)   # (bench.py wraps its evaluators)
+                if hasattr(inner, 'resident_search'):
+                    inner.resident_search = False
         self.eng = engines[0]  # geometry (board size, n_playout) is common to all lanes
         self.evaluator = evaluators[0]
         self.n_slots = offset

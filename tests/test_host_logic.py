@@ -125,7 +125,7 @@ def test_plan_lanes():
     # the deferred-priors route (a step = trunk -> tree step): profiles/r04/lane_sweep.txt
     d = lambda n, q=8: plan_lanes(n, hw_queues=q, deferred=True)[0]  # noqa: E731
     assert [d(n) for n in (1, 128, 192, 193, 256, 257, 320, 384, 447, 448, 511, 512, 640, 704, 705, 768, 1536)] == \
-        [1, 1, 1, 2, 2, 3, 3, 3, 3, 2, 2, 4, 4, 4, 2, 2, 2]
+        [1, 1, 1, 1, 1, 3, 3, 3, 3, 2, 2, 4, 4, 4, 2, 2, 2]
     assert d(512, 4) == 2 and d(640, 4) == 2 and plan_lanes(512, hw_queues=8, deferred=True) == (4, 0, 'parts')
 
 

@@ -174,7 +174,7 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert rec['n_gpus'] == 2 and rec['steps'] == 2 and rec['scaling'] == 'weak'
     assert rec['config']['games_total'] == 64
     # 2 ranks x 32 games x 2 moves x 40 simulations in the timed region
-    assert abs(rec['value'] * rec['ms_per_step'] * 2 / 1000.0 - 2 * 32 * 2 * 40) < 1.0
+    assert abs(rec['value'] * rec['ms_per_step'] * 2 / 1000.0 - 2 * 32 * 2 * 40) < 2e-3 * 2 * 32 * 2 * 40   # (ms_per_step is rounded to a microsecond)
     assert rec['cpu_baseline'] is None and rec['fill_1536'] is None
     assert rec['selfplay']['games_sampled'] == 64 and rec['selfplay_games_per_sec'] > 0
     tg = rec['trajectory_gather']  # the one exchange of the path, here over gloo

@@ -671,6 +671,15 @@ class MCTSEngine(object):
         """Before ``n`` more steps on the deferred route: the store of ``evaluator`` holds this engine's pending leaves (another
         evaluator's are flushed first), reserved once for min(n_playout, what deferred_max_bytes allows) steps; a flush when the
         coming steps would not fit.  -> steps that may be enqueued now (<= n)."""
+        # an evaluator's store holds the pending leaves of ONE engine at a time (slot = steps since that engine's flush): another
+        # engine that searches with the same evaluator has its priors written first
+        owner = getattr(evaluator, '_def_owner', None)
+        owner = owner() if owner is not None else None
+        if owner is not None and owner is not self:
+            owner.flush_deferred()
+        if owner is not self:
+            import weakref
+            evaluator._def_owner = weakref.ref(self)
         if self._def_ev is not evaluator:
             self.flush_deferred()
             hip = evaluator.hip

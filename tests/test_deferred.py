@@ -275,3 +275,29 @@ def test_resident_search_is_the_two_launch_step_in_one_launch():
                 assert (a[3] == 0).all()
             else:
                 assert a == b, (rows, cols)
+
+
+def test_two_engines_sharing_one_evaluator():
+    """An evaluator's feature store holds the pending leaves of one engine at a time: when a second engine searches with the same
+    evaluator the first one's priors are written first, so interleaved searches leave the trees they would leave alone."""
+    from rlzero_amd.engine import HipNetEvaluator, MCTSEngine
+    B, n = 15, 5
+    net = _net(B, seed=6)
+    envs = _positions(B, n, 5, seed=11)
+    trees = {}
+    for shared in (True, False):
+        ev_a = HipNetEvaluator(net, B, 'cuda:0', max_boards=8)
+        ev_b = ev_a if shared else HipNetEvaluator(net, B, 'cuda:0', max_boards=8)
+        a = MCTSEngine(B, n, n_games=len(envs), n_playout=60, device='cuda:0', add_noise=True, noise_seed=2)
+        b = MCTSEngine(B, n, n_games=3, n_playout=60, device='cuda:0', add_noise=True, noise_seed=3)
+        _set_roots(a, envs)
+        _set_roots(b, envs[:3])
+        a.sim_chunk(ev_a, 25)
+        b.sim_chunk(ev_b, 30)          # (shared: a's 25 pending steps are flushed before b's leaves take the store's slots)
+        assert a._def_pending == (0 if shared else 25) and b._def_pending == 30
+        a.sim_chunk(ev_a, 35)
+        assert b._def_pending == (0 if shared else 30)
+        trees[shared] = ([_whole_tree(a, g) for g in range(len(envs))], [_whole_tree(b, g) for g in range(3)])
+        a.close()
+        b.close()
+    assert trees[True] == trees[False]

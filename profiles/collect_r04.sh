@@ -27,6 +27,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_1lane"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_puct" -o s -- $B --graph 0 --steps 2 --score-mode puct > "$OUT/bench_eager_puct_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_puct_1lane" -o s -- $B --graph 0 --steps 2 --score-mode puct --lanes 1 > "$OUT/bench_eager_puct_1lane_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_c2" -o s -- $B --graph 0 --steps 4 --board 9 --playouts 200 --games 64 --lanes 1 > "$OUT/bench_eager_c2_under_rocprof.json" 2> /dev/null
+RZ_RESIDENT=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_c2_2launch" -o s -- $B --graph 0 --steps 4 --board 9 --playouts 200 --games 64 --lanes 1 > "$OUT/bench_eager_c2_2launch_under_rocprof.json" 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_256" -o s -- $B --graph 0 --steps 2 --games 256 > "$OUT/bench_eager_256_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_c3" -o s -- $B --graph 0 --steps 2 --game connect4 --playouts 400 --games 512 > "$OUT/bench_eager_c3_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_muzero" -o s -- $B --game muzero --playouts 50 --games 8192 --steps 64 --warmup 16 > "$OUT/bench_muzero_under_rocprof.json" 2> /dev/null
 echo "kernel stats done"

@@ -671,7 +671,7 @@ def main():
             if os.environ.get('RZ_RESIDENT') == '0':   # (profiles/ab_resident.sh: the two-launch step on a batch the resident search would take)
                 hip_ev.resident_search = False
             deferred_route = hip_ev.deferred_ok(eng)
-            resident_route = lanes == 1 and hip_ev.resident_ok(eng)   # (BatchedSelfPlay switches it off for several lanes)
+            resident_route = G <= n_cus and hip_ev.resident_ok(eng)   # (BatchedSelfPlay switches it off for lanes that share CUs)
             ev = TimedEvaluator(hip_ev, torch,
                                 {'winograd_f4': 'k_trunk_wino_f4<4>',
                                  'split_f16': 'k_trunk_rows' if (args.game == 'gomoku' and 11 <= board <= 16) else 'k_trunk_split',

@@ -138,8 +138,9 @@ def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False):
 
     ``deferred``: the batch runs the deferred-priors route (HipNetEvaluator.deferred_ok: UCT_REF, one simulation in flight, boards
     of 11 .. 16 rows).  A lane's step is then trunk -> tree step (23 + 10 us at 15x15) and the table was measured again
-    (profiles/r04/lane_sweep.txt, M simulations / s): up to one round of boards ONE lane -- the resident search, one workgroup per game
-    and one launch per search (256 games: 8.7 against 7.8 on two lanes of the two-launch step, profiles/r04/ab_resident.txt); up to
+    (profiles/r04/lane_sweep.txt, M simulations / s): up to one round of boards the resident search, one workgroup per game and one
+    launch per search, on one lane up to half a round and on two beyond (256 games: 9.2 against 7.8 on two lanes of the two-launch
+    step, profiles/r04/ab_resident.txt); up to
     1.75 rounds THREE (320 / 384 games: 9.2 / 10.3 against 8.7 / 9.8 with
     two); 448 games TWO (10.3 against 10.1); 2 .. 2.75 rounds FOUR on 8 hardware queues (512 / 640 games: 10.6 / 10.6 against 10.5
     / 10.1 with two -- with fewer queues two lanes, a percent behind); beyond, TWO (768 .. 1536 games: 10.9 .. 11.0).
@@ -165,8 +166,10 @@ def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False):
     if hw_queues is None:
         from . import HW_QUEUES as hw_queues
     if deferred:
-        if n_games <= n_cus:   # one game per CU at most: the resident search (one launch per search, a workgroup per game)
-            return 1, 0, 'auto'
+        if n_games <= n_cus:   # one game per CU at most: the resident search (one launch per search, a workgroup per game) --
+            # on TWO lanes from half a round of boards on, so that a lane's host step runs under the other lane's search
+            # (256 games: 9.17 against 8.57 M; 128 games 4.83 against 4.74; profiles/r04/ab_resident.txt)
+            return (2 if 2 * n_games > n_cus else 1), 0, 'auto'
         if 4 * n_games < 7 * n_cus:
             return 3, 0, 'parts'
         if n_games < 2 * n_cus or 4 * n_games > 11 * n_cus:
@@ -231,9 +234,10 @@ class BatchedSelfPlay(object):
             stream.wait_stream(torch.cuda.current_stream(eng.device))
             self.lanes.append(_Lane(eng, ev, stream, offset))
             offset += eng.n_games
-        if len(engines) > 1:
-            # several lanes share the CUs: the resident search (one workgroup per game for a whole search) is for a batch that has
-            # the chip to itself -- lanes run the two-launch step, whose trunk workgroups make way for the other lanes every step
+        n_cus = torch.cuda.get_device_properties(engines[0].device).multi_processor_count
+        if len(engines) > 1 and sum(e.n_games for e in engines) > n_cus:
+            # lanes that share CUs: the resident search (a workgroup keeps its CU for a whole search) is for games that have a CU
+            # each -- these lanes run the two-launch step, whose trunk workgroups make way for the other lanes every step
             for ev in evaluators:
                 inner = getattr(ev, 'inner', ev)   # (bench.py wraps its evaluators)
                 if hasattr(inner, 'resident_search'):

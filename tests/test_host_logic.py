@@ -125,7 +125,7 @@ def test_plan_lanes():
     # the deferred-priors route (a step = trunk -> tree step): profiles/r04/lane_sweep.txt
     d = lambda n, q=8: plan_lanes(n, hw_queues=q, deferred=True)[0]  # noqa: E731
     assert [d(n) for n in (1, 128, 192, 193, 256, 257, 320, 384, 447, 448, 511, 512, 640, 704, 705, 768, 1536)] == \
-        [1, 1, 1, 1, 1, 3, 3, 3, 3, 2, 2, 4, 4, 4, 2, 2, 2]
+        [1, 1, 2, 2, 2, 3, 3, 3, 3, 2, 2, 4, 4, 4, 2, 2, 2]
     assert d(512, 4) == 2 and d(640, 4) == 2 and plan_lanes(512, hw_queues=8, deferred=True) == (4, 0, 'parts')
 
 
@@ -214,3 +214,24 @@ def test_bench_reads_the_committed_counter_runs():
     rec = __import__('json').load(open(__import__('os').path.join(bench.REPO, 'profiles', 'r03', 'pmc_traffic.json')))
     # what a trunk launch writes is exactly its boards' head features as f16 pieces: 128 boards (a lane of the headline) x 1350 x 4 B
     assert abs(rec[head]['kernels']['k_trunk']['write_size_kb'] * 1024 - 128 * 1350 * 4) < 0.03 * 128 * 1350 * 4
+
+
+def test_trajectory_payload_round_trip():
+    """The byte payload of gather_trajectories (header | moves | pi in one buffer) cuts up again into the same trajectories, for both
+    pi widths, ragged games and an empty list."""
+    from rlzero_amd.selfplay import Trajectory, _payload_bytes, _payload_split, pack_trajectories, unpack_trajectories
+    rng = np.random.default_rng(3)
+    trajs = []
+    for gid, plies in ((5, 9), (2, 1), (11, 4)):
+        pis = rng.random((plies, 9))
+        pis /= pis.sum(axis=1, keepdims=True)
+        trajs.append(Trajectory(gid, 3, 3, rng.integers(0, 9, plies), pis, int(rng.integers(-1, 2))))
+    for dtype in (np.float64, np.float32):
+        for batch in (trajs, []):
+            header, moves, pis = pack_trajectories(batch, 9)
+            raw = _payload_bytes(header, moves, pis, dtype)
+            assert raw.dtype == np.uint8 and raw.size == 32 * len(batch) + moves.size * (8 + 9 * np.dtype(dtype).itemsize)
+            back = unpack_trajectories(*_payload_split(raw, len(batch), moves.size, 9, dtype), 3, 3)
+            assert [(t.game_id, t.moves, t.winner) for t in back] == [(t.game_id, t.moves, t.winner) for t in batch]
+            for a, b in zip(back, batch):
+                assert np.array_equal(a.pis, b.pis.astype(dtype).astype(np.float64))

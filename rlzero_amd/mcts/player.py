@@ -28,23 +28,8 @@ class Player(object):
 
 
 class HumanPlayer(Player):
-    """Reads "row,col" from stdin (interactive; not part of the accelerated path)."""
-
-    def __init__(self, player_id=0, player_name=''):
-        super().__init__(player_id, player_name)
-        self.can_click = True
+    """The import path of the reference's interactive player (rlzero/mcts/player.py:33-57) -- console I/O, out of scope here
+    (SURVEY.md section 2): the class exists so that code naming it imports; it does not play."""
 
     def get_action(self, game_env, **kwargs):
-        try:
-            text = input('Your move: ')
-            move = game_env.location_to_move([int(n, 10) for n in text.split(',')])
-        except Exception as exc:  # noqa: BLE001
-            print(exc)
-            move = -1
-        if move == -1 or move not in game_env.leagel_actions():
-            print('invalid move')
-            move = self.get_action(game_env)
-        return move
-
-    def __str__(self):
-        return 'HumanPlayer, id: {}, name {}.'.format(self.get_player_id(), self.get_player_name())
+        raise NotImplementedError('interactive play is not part of this package: use the reference\'s HumanPlayer')

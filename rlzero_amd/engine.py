@@ -791,6 +791,9 @@ class MCTSEngine(object):
         key = (id(evaluator), per)
         if key in self._graphs:
             return self._graphs[key][0]
+        res_ok = getattr(evaluator, 'resident_ok', None)
+        if res_ok is not None and res_ok(self):
+            return None   # (the resident search is one launch per search: simulate() replays no graph for it)
         cur = t.cuda.current_stream(self.device)
         side = t.cuda.Stream(device=self.device)
         side.wait_stream(cur)

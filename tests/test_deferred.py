@@ -161,6 +161,7 @@ def test_when_the_flushes_happen_changes_no_bit():
     dumps = {}
     for mode in ('move', 'small_store', 'graph'):
         evaluator = HipNetEvaluator(net, B, 'cuda:0', max_boards=len(envs))
+        evaluator.resident_search = False   # (the two-launch step and its hipGraphs; the resident search has a test of its own)
         eng = MCTSEngine(B, n, n_games=len(envs), n_playout=sims, device='cuda:0', add_noise=True, noise_seed=5)
         if mode == 'small_store':
             eng.deferred_max_bytes = 1   # -> the minimum of 16 slots

@@ -235,3 +235,51 @@ def test_connect4_rollout_vs_oracle():
     assert move == ref.simulate(RefConnect4.from_moves([3, 3, 2, 4]))
     assert _hex_tree(mcts._engine.tree_dump(0)) == _hex_tree(tree_dump(ref.root))
     mcts._engine.close()
+
+
+@pytest.mark.gpu
+def test_connect4_search_routes_agree():
+    """Connect4 (6 x 7 cells, 7 column actions: policy outputs != cells) on the three routes of the production evaluator -- the
+    resident search (one launch per search), the two-launch step (deferred priors) and the three-launch step: after three moves with
+    tree reuse the visit counts, every node's N / W and every prior are the same between the first two, and the third stores the
+    same priors for the same first expansion with values equal to f32 rounding."""
+    import torch
+    from rlzero_amd.engine import HipNetEvaluator
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    torch.manual_seed(3)
+    net = PolicyValueNet(6, 7, 7)
+    out = {}
+    for route in ('resident', 'two_launch', 'three_launch'):
+        evaluator = HipNetEvaluator(net, (6, 7, 7), 'cuda:0', max_boards=6)
+        evaluator.resident_search = route == 'resident'
+        evaluator.deferred_priors = route != 'three_launch'
+        eng = _engine(n_games=6, n_playout=70, add_noise=True, noise_seed=4)
+        assert evaluator.resident_ok(eng) == (route == 'resident') and evaluator.deferred_ok(eng) == (route != 'three_launch')
+        eng.reset_games()
+        eng.set_noise_keys()
+        eng.sim_chunk(evaluator, 1)
+        first = (eng.root_priors().copy(), eng.root_stats()[1].copy())
+        eng.sim_chunk(evaluator, 69)
+        record = [first]
+        for move in range(3):
+            if move:
+                eng.simulate(evaluator, 70)
+            visits = eng.root_visits()
+            ar = [eng.arena(g) for g in range(6)]
+            record.append((visits.copy(), [(a['N'][0], float(a['W'][0]).hex(), a['PRI'][:7].view(np.uint32).tolist()) for a in ar],
+                           [eng.tree_dump(g) for g in range(6)]))
+            moves = visits.argmax(axis=1).astype(np.int32)
+            eng.advance(moves)
+            eng.step(moves)
+        eng.check()
+        out[route] = record
+        eng.close()
+        evaluator.hip.close()
+    a, b, c = out['resident'], out['two_launch'], out['three_launch']
+    assert np.array_equal(a[0][0].view(np.uint32), b[0][0].view(np.uint32)) and np.array_equal(a[0][1], b[0][1])
+    assert np.array_equal(a[0][0].view(np.uint32), c[0][0].view(np.uint32)) and np.max(np.abs(a[0][1] - c[0][1])) <= 2e-6
+    assert (a[0][0] > 0).sum(axis=1).tolist() == [7] * 6   # seven legal columns on the empty board, a prior each
+    for x, y in zip(a[1:], b[1:]):
+        assert np.array_equal(x[0], y[0]) and x[1] == y[1]
+        assert [{k: (n, float(w).hex()) for k, (n, w) in t.items()} for t in x[2]] == \
+            [{k: (n, float(w).hex()) for k, (n, w) in t.items()} for t in y[2]]

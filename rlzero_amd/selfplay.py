@@ -263,7 +263,7 @@ class BatchedSelfPlay(object):
     def for_network(cls, net_module, board, n_in_row, n_games, n_playout, c_puct=5.0, device='cuda:0',
                     game='gomoku', net_shape=None, lanes=None, trunk_workgroups=None, temperature=1.0, seed=0,
                     use_graph=True, sims_per_graph=16, eager_every=0, add_noise=True, sims_in_flight=1, before_warm=None,
-                    deferred_priors=None, **engine_kw):
+                    deferred_priors=None, resident_search=None, **engine_kw):
         """Self-play of ``n_games`` games in flight with the hand-written evaluator of ``net_module`` (a
         PolicyValueNet): builds the lanes (engine + HipNetEvaluator each) as plan_lanes() recommends, unless
         ``lanes`` / ``trunk_workgroups`` are given (more than four lanes take turns on the GPU's four compute pipes, and four need
@@ -271,7 +271,8 @@ class BatchedSelfPlay(object):
         node, what ``AlphaZeroPlayer(is_selfplay=True)`` does (alphazero_mcts.py:124-129, node.py:63-69).
         ``sims_in_flight`` = K > 1: the opt-in virtual-loss mode (MCTSEngine), for batches too small to fill the GPU
         with one leaf per game; the evaluator batch of a lane is then its games x K.  ``deferred_priors``: None = the deferred-priors
-        route wherever it exists (HipNetEvaluator.deferred_ok), False = the three-launch step everywhere.  ``before_warm(sp)``: called
+        route wherever it exists (HipNetEvaluator.deferred_ok), False = the three-launch step everywhere; ``resident_search`` likewise for
+        the one-launch-per-search kernel of batches that give every game a CU (False = the two-launch step).  ``before_warm(sp)``: called
         before the hipGraphs are captured (rlzero_amd.trace attaches its buffer there)."""
         import torch
         from .engine import HipNetEvaluator, MCTSEngine
@@ -307,6 +308,8 @@ class BatchedSelfPlay(object):
             ev.hip.set_heads_algo(heads_algo)
             if deferred_priors is not None:
                 ev.deferred_priors = bool(deferred_priors)
+            if resident_search is not None:
+                ev.resident_search = bool(resident_search)
             evaluators.append(ev)
         sp = cls(engines if lanes > 1 else engines[0], evaluators if lanes > 1 else evaluators[0],
                  temperature=temperature, seed=seed, use_graph=use_graph, sims_per_graph=sims_per_graph,

@@ -352,7 +352,7 @@ def test_full_size_batches_of_the_baseline_configs(config):
         lane.eng.close()
 
 
-@pytest.mark.parametrize('n_games,score_mode', [(512, 'uct_ref'), (1536, 'uct_ref'), (512, 'puct')])
+@pytest.mark.parametrize('n_games,score_mode', [(512, 'uct_ref'), (1536, 'uct_ref'), (512, 'puct'), (256, 'uct_ref')])
 def test_full_size_shipped_layout_equals_one_plain_lane(n_games, score_mode):
     """The layout bench.py times -- co-resident lanes (four at 512 games, each on a hardware queue of its own; two at 1536) with
     un-capped trunks, the LDS-free 'parts' FC GEMM, hipGraphs of 16
@@ -369,13 +369,20 @@ def test_full_size_shipped_layout_equals_one_plain_lane(n_games, score_mode):
     plies, sims = 4, 800
 
     def play(shipped):
-        kw = {} if shipped else dict(lanes=1, use_graph=False)
+        # (256 games: the shipped layout is the RESIDENT search on two lanes -- one launch per search, a workgroup per game --; the
+        # plain lane then runs the two-launch step kernel by kernel)
+        kw = {} if shipped else dict(lanes=1, use_graph=False, resident_search=False)
         sp = BatchedSelfPlay.for_network(net, 15, 5, n_games=n_games, n_playout=sims, seed=5, score_mode=score_mode, **kw)
         if shipped:
             import rlzero_amd
             assert rlzero_amd.HW_QUEUES >= 8   # (claimed on import, before this process touched the GPU)
             assert len(sp.lanes) == (4 if n_games == 512 else 2) and sp.trunk_workgroups == 0 and sp.use_graph
-            assert all(lane.evaluator.hip.heads_algo == 'parts' for lane in sp.lanes)
+            resident = [lane.evaluator.resident_ok(lane.eng) for lane in sp.lanes]
+            assert resident == [n_games == 256] * len(sp.lanes)
+            if n_games != 256:
+                assert all(lane.evaluator.hip.heads_algo == 'parts' for lane in sp.lanes)
+        else:
+            assert not sp.lanes[0].evaluator.resident_ok(sp.lanes[0].eng)
         sp._start(range(n_games), range(n_games))
         sp._set_active()
         for _ in range(plies):

@@ -8,8 +8,10 @@ random-init PolicyValueNet (torch.manual_seed(0)), f32 network / f64 tree.
 
 A "step" is one move of every game on the GPU: n_playout simulation steps (select -> evaluate -> expand / backup for all
 games), pi from the root visits, a move drawn and applied, tree reuse; finished games are replaced so the batch stays
-full.  The 512 games of a GPU run as four lanes of 128 (separate streams: the tree / FC kernels of one lane run beside the
-network trunks of the others on the same CUs; rlzero_amd.selfplay.plan_lanes).  Games are independent: N GPUs play N x 512 games with no collective in the
+full.  The 512 games of a GPU run as four lanes of 128 (separate streams: the tree steps of one lane run beside the network
+trunks of the others on the same CUs; rlzero_amd.selfplay.plan_lanes); a simulation step of a lane is two launches, trunk -> tree
+step -- the reference's selection rule never reads a prior, so the policy GEMM and the priors of a search's expansions are written
+in one batch per move, inside the timed region.  Games are independent: N GPUs play N x 512 games with no collective in the
 timed region (weak scaling); rank 0 prints ONE JSON line.  `value` is the MEDIAN of --regions (3) timed regions of K steps
 each, every region bracketed by barrier + synchronize.
 
@@ -17,6 +19,8 @@ On the line (what each number means and how it is priced: DESIGN.md section 5):
   roofline       the dominant kernel (the network trunk on one lane's leaves): algorithmic flops per launch / launch
                  duration, against the peak of the pipe it runs on
   roofline_tree  the tree step against the HBM roofline (algorithmic bytes of SURVEY.md 8d)
+  lane_timeline  the schedule from the device-side launch trace (rlzero_amd/trace.py): CU time under trunk workgroups, trunk
+                 launches on the chip, the lanes' step cycle -- no profiler in the way
   fill_1536      the same engine with 1536 games in flight (3 boards per trunk workgroup: what fills an MI355X)
   configs        the other BASELINE.json configurations (C1, C2, C3, C5) and the opt-in PUCT rule at the headline
                  geometry, each measured by a child process with its own roofline and CPU baseline

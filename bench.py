@@ -262,7 +262,9 @@ CONFIG_LEGS = (  # (key, flags, seconds of CPU baseline at --cpu-seconds 60); a 
                          '--no-cpu-baseline'], 0.0),
     ('C3_connect4_400sims_512games', ['--game', 'connect4', '--playouts', 400, '--games', 512, '--steps', 6, '--warmup', 6], 12.0),
     ('C4_puct_rule', ['--score-mode', 'puct', '--steps', 3, '--warmup', 2, '--no-cpu-baseline'], 0.0),
-    ('C5_muzero_cartpole_50sims_8192envs', ['--game', 'muzero', '--playouts', 50, '--games', 8192, '--steps', 512, '--warmup', 48], 12.0),
+    # (launches of 16 moves, two kept enqueued ahead of the host: the timed region ends with the host reading the last two -- 2048
+    # moves = 128 launches = 0.6 s keep that drain at 2 % of the region)
+    ('C5_muzero_cartpole_50sims_8192envs', ['--game', 'muzero', '--playouts', 50, '--games', 8192, '--steps', 2048, '--warmup', 256], 12.0),
 )
 
 
@@ -438,12 +440,21 @@ def run_muzero(args, rank, world, device, dist, red_device, use_dist=False, cpu_
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    # (the interpreter's own housekeeping out of the region: a full collection now, and the objects alive so far -- torch's modules,
+    # the import graph -- moved out of the collector's sight; one generation-2 pass inside the region stalled the host for 38 ms,
+    # four launches of the GPU)
+    import gc
+    gc.collect()
+    gc.freeze()
     sims0 = sp.sims_done
     sp.sim_events = []  # HIP events around every 8th simulation step (one hipGraph replay) of the timed region
     if sp.fused:
         sp.search_events = []  # ... or around every fused search launch (all simulations of a move)
     t0 = time.perf_counter()
-    finished = len(sp.collect(args.steps))  # (fused moves: launches of sp.moves_per_launch moves, records read a launch behind)
+    # (fused moves: launches of sp.moves_per_launch moves, records read two launches behind.  The episodes stay alive until the clock
+    # has stopped: dropping them -- 10 MB of records per launch, 1.3 GB over 2048 moves -- inside the region cost 57 ms of munmap)
+    episodes = sp.collect(args.steps)
+    finished = len(episodes)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -458,6 +469,7 @@ def run_muzero(args, rank, world, device, dist, red_device, use_dist=False, cpu_
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         total = float(c.item())
     sp.tree.check()
+    del episodes
     if rank == 0:
         roofline = None
         events = sp.search_events if sp.fused else sp.sim_events
@@ -480,6 +492,10 @@ def run_muzero(args, rank, world, device, dist, red_device, use_dist=False, cpu_
                             'traffic': pmc_traffic('k_mz_search', workload), 'avg_launch_ms': round(ms, 4),
                             'launches_timed': len(events), 'hbm_achieved_gbs': round(gbs, 2),
                             'moves_per_launch': moves_per_launch,
+                            # the launches of the timed region back to back on the GPU (first launch's start to last one's end) against
+                            # the region's wall clock: the difference is the host reading the last launches' episodes behind the GPU
+                            'gpu_span_ms': round(events[0][0].elapsed_time(events[-1][1]), 2), 'region_wall_ms': round(1e3 * elapsed, 2),
+                            'gpu_gaps_ms': [round(g, 2) for g in sorted(events[i][1].elapsed_time(events[i + 1][0]) for i in range(len(events) - 1))[-4:]],
                             'note': 'latency-bound: one wave per workgroup walks 16 trees between the layer stages (DESIGN.md section 4)'}
             else:
                 roofline = {'bound': 'hbm', 'kernel': sp.sim_step_label + ', %d environments per launch' % G,
@@ -732,6 +748,12 @@ def main():
     while n_ramp < args.warmup or (time.perf_counter() - t_ramp < 0.3 and n_ramp < args.warmup + 3):
         one_step()
         n_ramp += 1
+    # (the interpreter's housekeeping out of the regions, as in run_muzero: a generation-2 pass over torch's object graph stalls the
+    # host for tens of milliseconds)
+    import gc
+    gc.collect()
+    if os.environ.get('RZ_BENCH_NO_GC_FREEZE') != '1':   # (A / B: profiles/r04/NOTES.md)
+        gc.freeze()
     # --regions timed regions of K steps each, every one bracketed by barrier + synchronize; the MEDIAN region is reported
     regions = []
     for _ in range(max(1, args.regions)):

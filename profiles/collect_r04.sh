@@ -30,7 +30,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_c2" -o
 RZ_RESIDENT=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_c2_2launch" -o s -- $B --graph 0 --steps 4 --board 9 --playouts 200 --games 64 --lanes 1 > "$OUT/bench_eager_c2_2launch_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_256" -o s -- $B --graph 0 --steps 2 --games 256 > "$OUT/bench_eager_256_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_c3" -o s -- $B --graph 0 --steps 2 --game connect4 --playouts 400 --games 512 > "$OUT/bench_eager_c3_under_rocprof.json" 2> /dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_muzero" -o s -- $B --game muzero --playouts 50 --games 8192 --steps 64 --warmup 16 > "$OUT/bench_muzero_under_rocprof.json" 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_muzero" -o s -- $B --game muzero --playouts 50 --games 8192 --steps 256 --warmup 64 > "$OUT/bench_muzero_under_rocprof.json" 2> /dev/null
 echo "kernel stats done"
 
 # 3. HBM traffic counters: separate FETCH_SIZE / WRITE_SIZE passes of every workload the line reports, at ITS playout count
@@ -51,7 +51,7 @@ pmc c3 --game connect4 --playouts 400 --games 512
 pmc c1 --board 3 --playouts 25 --games 1 --lanes 1 --steps 8
 pmc c1x16 --board 3 --playouts 25 --games 16 --lanes 1 --steps 8
 for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_c5_$c" -o p -- $B --game muzero --playouts 50 --games 8192 --steps 32 --warmup 16 > "$OUT/pmc_c5.json" 2> /dev/null
+    rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_c5_$c" -o p -- $B --game muzero --playouts 50 --games 8192 --steps 64 --warmup 32 > "$OUT/pmc_c5.json" 2> /dev/null
 done
 echo "pmc done"
 cd "$ROOT" && python3 profiles/summarise_r03.py "$OUT" && cp "$OUT"/keep/* "$ROOT/gpurun_out/r04/"

@@ -55,10 +55,28 @@ class EpisodeSeq(object):
     def __len__(self):
         return self._starts[-1]
 
+    def _add_packed(self, block, obs_dim, n_actions, lengths, first_rows=None):
+        """Episodes as rows of the device's packed records -- float64 [rows, obs | action | reward | visit counts | root value]
+        (rz_mz_play_cartpole) -- kept as they came: the fields of an episode are formed when it is asked for.  (Forming them
+        for every launch's 130 k rows cost the host about as long as the launch takes the GPU.)"""
+        lengths = np.asarray(lengths, dtype=np.int64)
+        if first_rows is None:
+            first_rows = np.cumsum(lengths) - lengths
+        self._chunks.append(((block, int(obs_dim), int(n_actions)), np.asarray(first_rows, dtype=np.int64), lengths))
+        self._starts.append(self._starts[-1] + len(lengths))
+
+    @staticmethod
+    def fields_of_packed(block, D, A):
+        vis = block[:, D + 2:D + 2 + A]
+        pol = (vis / vis.sum(axis=1, keepdims=True)).astype(np.float32)
+        return (block[:, :D].astype(np.float32), block[:, D].astype(np.int64), block[:, D + 1].copy(), pol, block[:, D + 2 + A].copy())
+
     def _make(self, chunk, j):
         fields, first_rows, lengths = self._chunks[chunk]
         a = int(first_rows[j])
         b = a + int(lengths[j])
+        if len(fields) == 3 and isinstance(fields[1], int):   # packed records: cut the episode's rows out, then form its fields
+            return Episode.from_arrays(*self.fields_of_packed(fields[0][a:b], fields[1], fields[2]))
         return Episode.from_arrays(*(f[a:b] for f in fields))
 
     def __getitem__(self, i):
@@ -153,7 +171,7 @@ class MuZeroSelfPlay(object):
         per environment and move, a chunk behind the GPU.  None = whenever ``fused`` holds and the environment is a
         CartPoleBatch (the environment step is device code).  Its random draws (root noise, actions) come from the
         kernel's counter-based stream keyed (seed, environment, episode, step), not from the torch generator.
-        ``arena_rows``: records the per-launch arena of finished episodes holds (None = 1.25 x what a launch plays + a few
+        ``arena_rows``: records the per-launch arena of finished episodes holds (None = twice what a launch plays + a few
         long episodes; episodes that do not fit are read back from the device ring instead)."""
         import torch
         from .tree import MuZeroTree
@@ -196,7 +214,7 @@ class MuZeroSelfPlay(object):
         self.moves_per_launch = max(1, int(moves_per_launch))
         self._arena_rows = arena_rows
         self.noise_seed = int(seed)
-        self._records = None  # fused moves: [device records, pinned host copy, event] x 2 (double buffer)
+        self._records = None  # fused moves: [device records, pinned host copy, event] x 3 (two launches ahead of the host)
         if self.fused:
             use_graph = False
             self._refresh_model()
@@ -393,19 +411,17 @@ class MuZeroSelfPlay(object):
             steps = int(self.env.max_episode_steps) + 2 * K + 12
             self._ring = t.zeros((G, steps, row), dtype=t.float64, **kw)
             self._ep_start_dev = t.full((G, ), self._t, dtype=t.int64, **kw)
-            # in the steady state a launch ends about as many steps of episodes as it plays (G x K: every environment plays K
-            # moves, and what ends is as long on average as what was played); the sum fluctuates by L sqrt(G K / L) rows for
-            # episodes of length L (3 % at 500-step episodes of 8192 environments): G x K plus a quarter, plus a few long
-            # episodes, fits -- what does not is read back from the ring (entry with row -1).  The whole arena is copied to
-            # the host behind every launch (the copy is enqueued before the NEXT launch takes the CUs: its blit kernel has to
-            # find room beside the search), so its size is paid: twice G x K here was 21 MB per launch, 31 % of the GPU's
-            # time in copy kernels (profiles/r03/bench_muzero_kernel_stats.csv)
-            rows, n_entries = G * K + G * K // 4 + 4 * steps, G * K
+            # in the steady state a launch ends about as many steps of episodes as it plays (G x K); but environments that start
+            # together also END together for a while (8192 random-policy episodes of ~22 steps: whole launches in which 1.5 x G x K
+            # rows end), so the arena holds twice that, plus a few long episodes -- what does not fit is read back from the ring
+            # (entry with row -1), a slow path: a gather and a blocking copy per launch (an arena of 1.25 x G x K, tried in round 4,
+            # took it in every launch of the bench: 5 ms each)
+            rows, n_entries = 2 * G * K + 4 * steps, G * K
             if self._arena_rows is not None:
                 rows = max(1, int(self._arena_rows))
             self._copy_stream = t.cuda.Stream(device=self.device)
             self._records = []
-            for _ in range(2):
+            for _ in range(3):   # two launches in flight + the one the host reads
                 dev = (t.zeros(4, dtype=t.int64, **kw), t.zeros((n_entries, 4), dtype=t.int64, **kw),
                        t.zeros((rows, row), dtype=t.float64, **kw))
                 host = tuple(t.zeros(x.shape, dtype=x.dtype).pin_memory() for x in dev)
@@ -458,16 +474,10 @@ class MuZeroSelfPlay(object):
         ent = ent[np.lexsort((ent[:, 0], ent[:, 1]))]
         fits = ent[:, 3] >= 0
 
-        def fields_of(block):
-            vis = block[:, D + 2:D + 2 + A]
-            with np.errstate(invalid='ignore', divide='ignore'):  # (rows of the arena no episode claimed are zero)
-                pol = (vis / vis.sum(axis=1, keepdims=True)).astype(np.float32)
-            return (block[:, :D].astype(np.float32), block[:, D].astype(np.int64), block[:, D + 1].copy(), pol,
-                    block[:, D + 2 + A].copy())
-
         if fits.any():
             used = min(n_rows, arena.shape[0])
-            finished._add(fields_of(arena.numpy()[:used]), ent[fits, 2], ent[fits, 3])
+            # (a copy: the pinned buffer is the next-but-one launch's; the episodes' fields are formed when they are asked for)
+            finished._add_packed(arena.numpy()[:used].copy(), D, A, ent[fits, 2], ent[fits, 3])
         if missed:  # the arena was too small for these: their records are still in the ring
             t = self.torch
             env, end, length = (ent[~fits, c] for c in (0, 1, 2))
@@ -475,7 +485,7 @@ class MuZeroSelfPlay(object):
             within = np.arange(int(length.sum())) - np.repeat(np.cumsum(length) - length, length)
             step_idx = (np.repeat(end - length, length) + within) % self._ring.shape[1]
             block = self._ring[t.from_numpy(env_idx).to(self.device), t.from_numpy(step_idx).to(self.device)].cpu().numpy()
-            finished._add(fields_of(block), length)
+            finished._add_packed(block, D, A, length)
         return finished
 
     def _collect_fused(self, n_moves):
@@ -484,19 +494,19 @@ class MuZeroSelfPlay(object):
         the host, and the host reads finished episodes, not moves)."""
         bufs = self._fused_state()
         finished = EpisodeSeq()
-        pending = None
+        pending = []   # launches enqueued and not read yet, oldest first
         left, which = int(n_moves), 0
-        while left > 0 or pending is not None:
-            launched = None
-            if left > 0:
+        while left > 0 or pending:
+            # TWO launches are kept enqueued ahead of the one the host reads: the copy of a launch's arena is a blit kernel that
+            # finds room on the CUs only as the NEXT launch drains, so the host gets launch k's records about when launch k + 1
+            # ends -- with one launch ahead the GPU then idled while the host read them (2.4 of 7.3 ms per launch)
+            while left > 0 and len(pending) < 2:
                 k = min(left, self.moves_per_launch)
                 self._launch_moves(k, bufs[which])
-                launched = bufs[which]
+                pending.append(bufs[which])
                 left -= k
-                which ^= 1
-            if pending is not None:
-                finished.extend(self._episodes_of_launch(pending))
-            pending = launched
+                which = (which + 1) % len(bufs)
+            finished.extend(self._episodes_of_launch(pending.pop(0)))
         return finished
 
     def collect(self, n_moves):

@@ -67,12 +67,21 @@ def executed_flop_ratio(args, cells):
     columns) + conv1's 270 f32 MFMAs."""
     if args.evaluator != 'hipnet' or args.game != 'gomoku' or args.board != 15:
         return 1.0
-    mfmas = {'winograd_f4': 6030, 'direct': 21870, 'split_f16': 4050 * 16 + 270, 'split_f16_tiles': 4320 * 16 + 270}[args.net_algo]
+    # split_f16_fp8 (opt-in): conv3's two cross terms as one FP8 MFMA of twice the cycles and four times the K: 2 f16-MFMA
+    # equivalents per product instead of 3 on 80 % of the trunk's products (conv2 keeps 3): 0.733 of split_f16's matrix work
+    mfmas = {'winograd_f4': 6030, 'direct': 21870, 'split_f16': 4050 * 16 + 270, 'split_f16_tiles': 4320 * 16 + 270,
+             'split_f16_fp8': 4050 * 16 * (3 * 18432 + 2 * 73728) / (3.0 * (18432 + 73728)) + 270}[args.net_algo]
     return mfmas * 2048.0 / trunk_flops_per_position(cells)
 
 
 def trunk_peak(args):
     """-> (peak TFLOP/s the trunk's ALGORITHMIC flops are priced against, peak of the pipe it executes on, note)."""
+    if args.evaluator == 'hipnet' and args.net_algo == 'split_f16_fp8':
+        per_product = (3 * 18432 + 2 * 73728) / float(18432 + 73728)   # 2.2 f16-MFMA equivalents per product (conv2: 3, conv3: 2)
+        return (PEAK_F16_MATRIX_TFLOPS / per_product, PEAK_F16_MATRIX_TFLOPS,
+                'OPT-IN arithmetic, narrower than the reference\'s f32 (RZ_NET_SPLIT_F16_FP8): peak = dense f16 MFMA peak (2500 TFLOP/s) / 2.2 '
+                '-- conv3\'s cross terms hi x lo + lo x hi run as one block-scaled FP8 MFMA per tap (2 f16-MFMA equivalents per product), '
+                'conv2 keeps three f16 MFMAs per product; error on the logits: tests/test_fp8_trunk.py, DESIGN.md section 5')
     if args.evaluator == 'hipnet' and args.net_algo.startswith('split_f16'):
         return (PEAK_F16_MATRIX_TFLOPS / SPLIT_MFMAS_PER_PRODUCT, PEAK_F16_MATRIX_TFLOPS,
                 'peak = dense f16 MFMA peak (2500 TFLOP/s) / 3: every f32 product costs three f16 MFMAs (operands '
@@ -262,6 +271,8 @@ CONFIG_LEGS = (  # (key, flags, seconds of CPU baseline at --cpu-seconds 60); a 
                          '--no-cpu-baseline'], 0.0),
     ('C3_connect4_400sims_512games', ['--game', 'connect4', '--playouts', 400, '--games', 512, '--steps', 6, '--warmup', 6], 12.0),
     ('C4_puct_rule', ['--score-mode', 'puct', '--steps', 3, '--warmup', 2, '--no-cpu-baseline'], 0.0),
+    # OPT-IN arithmetic (RZ_NET_SPLIT_F16_FP8), never the headline: what the 1e-4 of the path is worth on this chip
+    ('C4_optin_fp8_cross_terms', ['--net-algo', 'split_f16_fp8', '--steps', 3, '--warmup', 3, '--no-cpu-baseline'], 0.0),
     # (launches of 16 moves, two kept enqueued ahead of the host: the timed region ends with the host reading the last two -- 2048
     # moves = 128 launches = 0.6 s keep that drain at 2 % of the region)
     ('C5_muzero_cartpole_50sims_8192envs', ['--game', 'muzero', '--playouts', 50, '--games', 8192, '--steps', 2048, '--warmup', 256], 12.0),
@@ -544,7 +555,8 @@ def main():
                     help="hipnet: hand-written fused fp32 MFMA forward (csrc/rz_net.hip); torchnet: "
                          "PyTorch-ROCm/MIOpen; vlin: synthetic evaluator (isolates the tree kernels)")
     ap.add_argument('--graph', type=int, default=16, help='simulation steps per hipGraph (0 = eager); 16 or more: +3 %% over 8 on four lanes')
-    ap.add_argument('--net-algo', default='split_f16', choices=['winograd_f4', 'direct', 'split_f16', 'split_f16_tiles'])
+    ap.add_argument('--net-algo', default='split_f16', choices=['winograd_f4', 'direct', 'split_f16', 'split_f16_tiles', 'split_f16_fp8'],
+                    help="'split_f16_fp8': OPT-IN arithmetic narrower than the reference's f32 (never the default; 15x15 Gomoku only)")
     ap.add_argument('--no-games-leg', action='store_true',
                     help='skip the self-play games/s leg (after the timed steps the games of the first generation '
                          'are played to their end, slots refilled, to measure moves/s over whole games and the mean '
@@ -659,7 +671,7 @@ def main():
         lanes = args.lanes
     else:
         from rlzero_amd.selfplay import plan_lanes
-        will_defer = (bool(args.deferred) and args.evaluator == 'hipnet' and args.net_algo == 'split_f16' and args.game == 'gomoku'
+        will_defer = (bool(args.deferred) and args.evaluator == 'hipnet' and args.net_algo in ('split_f16', 'split_f16_fp8') and args.game == 'gomoku'
                       and 11 <= args.board <= 16 and args.score_mode == 'uct_ref' and args.in_flight <= 1)
         lanes = plan_lanes((args.games if args.games > 0 else GAMES_PER_GPU) * max(1, args.in_flight), n_cus, deferred=will_defer)[0]
     trunk_wgs = max(0, args.trunk_wgs)
@@ -695,7 +707,7 @@ def main():
             ev = TimedEvaluator(hip_ev, torch,
                                 {'winograd_f4': 'k_trunk_wino_f4<4>',
                                  'split_f16': 'k_trunk_rows' if (args.game == 'gomoku' and 11 <= board <= 16) else 'k_trunk_split',
-                                 'split_f16_tiles': 'k_trunk_split',
+                                 'split_f16_tiles': 'k_trunk_split', 'split_f16_fp8': 'k_trunk_rows',
                                  'direct': 'k_trunk'}[args.net_algo])
         elif args.evaluator == 'torchnet':
             ev = TimedEvaluator(NetEvaluator(net), torch, 'torch/MIOpen forward (~14 kernels)')
@@ -908,7 +920,9 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1000.0 * elapsed / max(args.steps, 1), 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32 net (hi + lo f16 operand pairs on the f16 MFMA pipe, f32 accumulation) / f64 tree' if split else 'f32 net / f64 tree',
+            'dtype': ('OPT-IN: f32 net with conv3\'s cross terms on 8-bit operands (hi x hi on f16, hi x lo + lo x hi on the block-scaled FP8 pipe, '
+                      'f32 accumulation) / f64 tree' if args.net_algo == 'split_f16_fp8' else
+                      'f32 net (hi + lo f16 operand pairs on the f16 MFMA pipe, f32 accumulation) / f64 tree') if split else 'f32 net / f64 tree',
             'data': 'synthetic (random-init net, torch.manual_seed(0); games from the empty board)',
             'config': {'workload': ('connect4_6x7_n4_selfplay_%dsims_per_move_%dgames_per_gpu' % (args.playouts, G))
                        if args.game == 'connect4' else

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 22
+#define RZ_ABI_VERSION 23
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 #define RZ_MAX_IN_FLIGHT 16 /* rz_config.sims_in_flight */
@@ -375,6 +375,15 @@ enum {
     RZ_NET_SPLIT_F16_TILES = 3  /* the same arithmetic with k_trunk_split on every board size (the checker of k_trunk_rows:
                                the two agree to f32 accumulation rounding, not bit for bit -- the MFMA shapes sum in
                                different orders) */
+    ,
+    RZ_NET_SPLIT_F16_FP8 = 4 /* OPT-IN, narrower than the reference's f32 (never the default, never the benchmark's headline):
+                               RZ_NET_SPLIT_F16 with the two CROSS terms hi x lo + lo x hi of conv3 (80 % of the trunk's products)
+                               on the block-scaled FP8 pipe -- one v_mfma_scale_f32_16x16x128_f8f6f4 per tap (weights e4m3,
+                               activations e5m2) instead of four f16 MFMAs, 2 f16-MFMA equivalents per product instead of 3.
+                               The cross terms then carry 3 .. 4 bits instead of 11: ~2^-14 per product, between plain f16
+                               (2^-11) and the default (2^-22); measured on the logits: DESIGN.md.  Boards of 11 .. 16 rows and
+                               columns, position-fed entry points only (rz_net_trunk_leaves*, rz_net_search_resident);
+                               rz_net_trunk / rz_net_forward (float planes) return RZ_ERR_ARG while it is selected. */
 };
 /* rz_net_range_info: h_info8 = {bound on conv1's, conv2's activations and on the head features for inputs in [0, 1];
  * the three activation scales chosen from them; 1.0 if the bounds are finite (0.0: RZ_NET_SPLIT_F16 runs RZ_NET_DIRECT

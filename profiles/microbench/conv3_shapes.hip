@@ -264,7 +264,114 @@ __device__ __forceinline__ float board(const char *in, const char *wts, int m0, 
 }
 }  // namespace r16
 
-enum { P32, C16, H16, P16, C16x1, C16x3, R16 };
+
+// ---------------------------------------------------------------- F8: the C16 split with the CROSS TERMS on the block-scaled FP8 pipe
+// (DESIGN / TRIED "FP8 cross terms"): per tap and N-tile two v_mfma_f32_16x16x32_f16 (hi x hi, 2 x 32 channels) and ONE
+// v_mfma_scale_f32_16x16x128_f8f6f4 whose K = 128 is [hi8 x (w_lo 2^k)8 | (lo 2^k)8 x w_hi8] of the tap's 64 channels -- 2 f16-MFMA
+// equivalents instead of 3 per product.  LDS: one region of hi16 records, one of fp8 records (hi8 | lo8), 144 bytes each; the same
+// bytes per position and per weight fragment as C16.  A timing gate only: the bytes are random.
+namespace f8 {
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef const __attribute__((address_space(3))) i32x4 *lds_q;
+constexpr int CIN = 64, rec = 144, region = 324 * rec, steps = 9, LA = 3, AD = 2;
+struct Frag { f16x8 h[2]; i32x8 q; };
+__device__ __forceinline__ i32x8 cat(i32x4 lo, i32x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+template <int TM, int NT, int TP, int JP>
+__device__ __forceinline__ void slot(f32x4 (&acc)[TM][NT], Frag (&a)[AD][TM], Frag (&b)[TP + LA], lds_frag q16, lds_q q8,
+                                     __amdgpu_buffer_rsrc_t w_rsrc, int w_lane, int sa, int sb) {
+    constexpr int PD = TP + LA;
+#pragma unroll
+    for (int u = 0; u < TP; ++u) {
+        const int J = JP * TP + u, J2 = J + LA;
+        if (J < steps * NT && J2 < steps * NT) {
+            const int tap = J2 / NT, t2 = J2 % NT;
+            const int row = t2 + tap / 3, far = row >= 8;
+            const int off = ((row - 8 * far) * kRowW + tap % 3) * rec;
+            const lds_frag p16 = far ? q16 + 8 * kRowW * rec / 16 : q16;
+            const lds_q p8 = far ? q8 + 8 * kRowW * rec / 16 : q8;
+            b[J2 % PD].h[0] = p16[off / 16];
+            b[J2 % PD].h[1] = p16[(off + 64) / 16];
+            b[J2 % PD].q = cat(p8[off / 16], p8[(off + 16) / 16]);
+        }
+        const int s = J / NT, t = J % NT;
+        if (J < steps * NT && s + 1 < steps) {
+#pragma unroll
+            for (int mm = 0; mm < TM; ++mm)
+                if (mm % NT == t) {
+                    const int base = (mm * steps + s + 1) * 4 * 1024;
+                    a[(s + 1) % AD][mm].h[0] = load_w(w_rsrc, w_lane, base);
+                    a[(s + 1) % AD][mm].h[1] = load_w(w_rsrc, w_lane, base + 1024);
+                    a[(s + 1) % AD][mm].q = cat(__builtin_bit_cast(i32x4, load_w(w_rsrc, w_lane, base + 2048)),
+                                                __builtin_bit_cast(i32x4, load_w(w_rsrc, w_lane, base + 3072)));
+                }
+        }
+    }
+#pragma unroll
+    for (int combo = 0; combo < 3; ++combo)
+#pragma unroll
+        for (int u = 0; u < TP; ++u)
+#pragma unroll
+            for (int m = 0; m < TM; ++m) {
+                const int J = JP * TP + u, s = J / NT, t = J % NT;
+                if (J < steps * NT) {
+                    if (combo < 2) {
+                        if (s == 0 && combo == 0) {
+                            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s % AD][m].h[0], b[J % PD].h[0], zero, 0, 0, 0);
+                        } else {
+                            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s % AD][m].h[combo], b[J % PD].h[combo], acc[m][t], 0, 0, 0);
+                        }
+                    } else {
+                        acc[m][t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[s % AD][m].q, b[J % PD].q, acc[m][t], 0, 0, 0, sa, 0, sb);
+                    }
+                }
+            }
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int TM, int NT, int TP, int... Js>
+__device__ __forceinline__ void slots(std::integer_sequence<int, Js...>, f32x4 (&acc)[TM][NT], Frag (&a)[AD][TM], Frag (&b)[TP + LA],
+                                      lds_frag q16, lds_q q8, __amdgpu_buffer_rsrc_t w_rsrc, int w_lane, int sa, int sb) {
+    (slot<TM, NT, TP, Js>(acc, a, b, q16, q8, w_rsrc, w_lane, sa, sb), ...);
+}
+template <int TM, int NT, int TP>
+__device__ __forceinline__ float board(const char *in, const char *wts, int m0, int row0, int lane, int sa, int sb) {
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(wts + (size_t)m0 * steps * 4 * 1024), 0, 0x7fffffff, 0x00020000);
+    Frag a[AD][TM];
+#pragma unroll
+    for (int m = 0; m < TM; ++m) {
+        a[0][m].h[0] = load_w(w_rsrc, lane * 16, m * steps * 4 * 1024);
+        a[0][m].h[1] = load_w(w_rsrc, lane * 16, m * steps * 4 * 1024 + 1024);
+        a[0][m].q = cat(__builtin_bit_cast(i32x4, load_w(w_rsrc, lane * 16, m * steps * 4 * 1024 + 2048)),
+                        __builtin_bit_cast(i32x4, load_w(w_rsrc, lane * 16, m * steps * 4 * 1024 + 3072)));
+    }
+    const int n = lane & 15, g = lane >> 4;
+    const lds_frag q16 = (lds_frag)(in + (row0 * kRowW + n) * rec + g * 16);
+    const lds_q q8 = (lds_q)(in + region + (row0 * kRowW + n) * rec + g * 32);
+    Frag b[TP + LA];
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+        b[j].h[0] = q16[(j * kRowW * rec) / 16];
+        b[j].h[1] = q16[(j * kRowW * rec + 64) / 16];
+        b[j].q = cat(q8[(j * kRowW * rec) / 16], q8[(j * kRowW * rec + 16) / 16]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[TM][NT];
+    slots<TM, NT, TP>(std::make_integer_sequence<int, (steps * NT + TP - 1) / TP>{}, acc, a, b, q16, q8, w_rsrc, lane * 16, sa, sb);
+    float s = 0.0f;
+#pragma unroll
+    for (int m = 0; m < TM; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += acc[m][t][r];
+    return s;
+}
+constexpr int lds_bytes = 2 * region;
+}  // namespace f8
+
+enum { P32, C16, H16, P16, C16x1, C16x3, R16, F8x1, F8x2 };
 template <int KIND>
 __global__ __launch_bounds__(256) void k(const _Float16 *__restrict__ act, const char *__restrict__ wts, float *out, long long *ticks,
                                          int boards) {
@@ -284,6 +391,8 @@ __global__ __launch_bounds__(256) void k(const _Float16 *__restrict__ act, const
         if constexpr (KIND == C16x1) s += s16::board<2, 15, 1>(lds, wts, 2 * wave, 0, lane);
         if constexpr (KIND == C16x3) s += s16::board<2, 15, 3>(lds, wts, 2 * wave, 0, lane);
         if constexpr (KIND == R16) s += r16::board(lds, wts, 2 * wave, lane);
+        if constexpr (KIND == F8x1) s += f8::board<2, 15, 1>(lds, wts, 2 * wave, 0, lane, boards + 115, 127);
+        if constexpr (KIND == F8x2) s += f8::board<2, 15, 2>(lds, wts, 2 * wave, 0, lane, boards + 115, 127);
         if constexpr (KIND == H16) {
             if (wave < 2) s += s16::board<4, 8, 1>(lds, wts, 4 * wave, 0, lane);
             else s += s16::board<4, 7, 1>(lds, wts, 4 * (wave - 2), 8, lane);
@@ -341,6 +450,8 @@ int main() {
             run<C16x1>("C16 one row per slot", grid, act, wts, out, ticks, boards);
             run<C16x3>("C16 three rows per slot", grid, act, wts, out, ticks, boards);
             run<R16>("R16 halo rows read once", grid, act, wts, out, ticks, boards);
+            run<F8x1>("F8 cross terms, 1 row/slot", grid, act, wts, out, ticks, boards);
+            run<F8x2>("F8 cross terms, 2 rows/slot", grid, act, wts, out, ticks, boards);
         }
     return 0;
 }

@@ -8,7 +8,7 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64,
                     c_void_p)
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
 MAX_IN_FLIGHT = 16
@@ -16,7 +16,7 @@ MAX_IN_FLIGHT = 16
 OK = 0
 SCORE_UCT_REF, SCORE_PUCT = 0, 1
 GAME_GOMOKU, GAME_CONNECT4 = 0, 1
-NET_DIRECT, NET_WINOGRAD_F4, NET_SPLIT_F16, NET_SPLIT_F16_TILES = 0, 1, 2, 3
+NET_DIRECT, NET_WINOGRAD_F4, NET_SPLIT_F16, NET_SPLIT_F16_TILES, NET_SPLIT_F16_FP8 = 0, 1, 2, 3, 4
 NET_FLAG_F16_RANGE = 1
 NET_HEADS_AUTO, NET_HEADS_F32, NET_HEADS_SPLIT_32, NET_HEADS_SPLIT_64, NET_HEADS_SPLIT_PARTS, NET_HEADS_IN_TRUNK = 0, 1, 2, 3, 4, 5
 EVAL_V0, EVAL_VLIN = 0, 1

@@ -61,6 +61,8 @@ struct NetDev {
     const f32x4 *s1;             // conv1 for k_trunk_split: [kernel row][hi | lo][64 lanes] x 8 f16 (pack_split1)
     const f32x4 *s2, *s3;        // split f16 weights: [32-channel tile][tap][16-channel chunk][hi | lo][64 lanes] x 8 f16
     const f32x4 *t2, *t3;        // the same for k_trunk_rows: [16-channel tile][tap][32-channel chunk][hi | lo][64 lanes] x 8 f16 (pack_rows)
+    const f32x4 *t3f;            // conv3 for the FP8 cross terms (RZ_NET_SPLIT_F16_FP8): [16-channel tile][tap][part][half][64 lanes] x 16 bytes
+                                 // (pack_rows_f8: part 0 = the hi f16 pieces of the tap's two chunks, part 1 = e4m3 bytes [lo 2^5 | hi 2^-6])
     const float *s_inv;          // [8] in device memory (a captured launch must see a reload's values), with a1, a2, a3 =
                                  // the activation scales of conv1's / conv2's outputs and of the head features (powers of
                                  // two from rz_net_load's activation bounds), sw* the weight scales:
@@ -1530,6 +1532,8 @@ namespace rt {
 using sp::f16x4;
 using sp::f16x8;
 using sp::lds_frag;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 template <int CIN> struct Geo {
     static constexpr int pos_bytes = 4 * CIN + 32;               // 160 / 288
@@ -1547,23 +1551,60 @@ static_assert(kLdsBytes <= 160 * 1024, "LDS budget");
 // bench); the 3 * TM weight fragments of a combo's three kernel rows sit in registers, the next combo's arrive meanwhile.
 // Halo rows 0 and NT + 1 are the zero ring above / below the board (the kernel runs boards of exactly NT rows): never read,
 // their products never formed (2 of 45 (row, kernel row) pairs = 4.4 % of a layer's MFMAs; +2.3 %).
-template <int CIN, int TM, int NT, int J>
+// F8 (conv3 of RZ_NET_SPLIT_F16_FP8; CIN = 64): a position's record is [hi: 64 f16][hi8: 64 e5m2 of the value][lo8: 64 e5m2 of
+// (value - hi) 2^11][pad] and a "combo" is (tap column dx, part): part 0 = the hi x hi products of the tap's two 32-channel chunks (two
+// v_mfma_f32_16x16x32_f16 per kernel row and M-tile), part 1 = BOTH cross terms of the tap's 64 channels in one
+// v_mfma_scale_f32_16x16x128_f8f6f4 (A = e4m3 weights, B = e5m2 activations; lane group g: K block = [hi8 x (w_lo 2^5)8 | lo8 x
+// (w_hi 2^-6)8] of channels 16 g .. 16 g + 15, one scale 2^-5 for the block).  The same fragment addresses, loads per slot and
+// registers as the three-MFMA loop; 2 f16-MFMA equivalents per product instead of 3 (profiles/microbench/conv3_shapes.hip: F8).
+__device__ __forceinline__ i32x8 cat8(f16x8 lo, f16x8 hi) {
+    return __builtin_shufflevector(__builtin_bit_cast(i32x4, lo), __builtin_bit_cast(i32x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
+}
+constexpr int kF8ScaleA = 127 - 5, kF8ScaleB = 127;   // E8M0: the weights' bytes carry 2^5 (pack_rows_f8), the activations' 2^0
+template <int CIN, int TM, int NT, int J, bool F8 = false>
 __device__ __forceinline__ void slot_r(f32x4 (&acc)[TM][NT], f16x8 (&a)[2][3][TM][2], f16x8 (&b)[kLA + 1][2], lds_frag q, lds_frag qf,
                                        __amdgpu_buffer_rsrc_t w_rsrc, int w_lane) {
     using G = Geo<CIN>;
+    static_assert(!F8 || CIN == 64, "the FP8 cross terms: one tap of 64 channels = one K = 128 block");
     constexpr int PD = kLA + 1, combos = 3 * G::chunks, cb = J / NT, r = J % NT + 1, J2 = J + kLA;   // r: halo row
+    constexpr int second = F8 ? 64 : CIN * 2;   // the second fragment of a slot: the other chunk (F8) / the lo piece
     if constexpr (J2 < combos * NT) {
         constexpr int cb2 = J2 / NT, r2 = J2 % NT + 1, dx = cb2 / G::chunks, c = cb2 % G::chunks, far = r2 >= 8;
-        constexpr int off = ((r2 - 8 * far) * kRowW + dx) * G::pos_bytes + c * 64;
-        static_assert(off % 16 == 0 && off + CIN * 2 < 65536, "ds_read_b128 immediate");
+        constexpr int off = ((r2 - 8 * far) * kRowW + dx) * G::pos_bytes + c * (F8 ? 128 : 64);
+        static_assert(off % 16 == 0 && off + second < 65536, "ds_read_b128 immediate");
         b[J2 % PD][0] = (far ? qf : q)[off / 16];
-        b[J2 % PD][1] = (far ? qf : q)[(off + CIN * 2) / 16];
+        b[J2 % PD][1] = (far ? qf : q)[(off + second) / 16];
     }
     if constexpr (cb + 1 < combos && r - 1 < 3 * TM) {   // the next combo's weight fragments behind this combo's first rows
         constexpr int dy = (r - 1) / TM, m = (r - 1) % TM, dx = (cb + 1) / G::chunks, c = (cb + 1) % G::chunks;
 #pragma unroll
         for (int p = 0; p < 2; ++p)
             a[(cb + 1) % 2][dy][m][p] = sp::load_w(w_rsrc, w_lane, ((m * G::steps + (dy * 3 + dx) * G::chunks + c) * 2 + p) * 1024);
+    }
+    if constexpr (F8) {
+        constexpr int part = cb % 2;
+#pragma unroll
+        for (int c = 0; c < (part ? 1 : 2); ++c)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int m = 0; m < TM; ++m) {
+                    const int t = r - dy;
+                    if (t >= 0 && t < NT) {
+                        if (part) {
+                            acc[m][t] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(cat8(a[cb % 2][dy][m][0], a[cb % 2][dy][m][1]),
+                                                                                         cat8(b[J % PD][0], b[J % PD][1]), acc[m][t],
+                                                                                         0 /* A: e4m3 */, 1 /* B: e5m2 */, 0, kF8ScaleA, 0, kF8ScaleB);
+                        } else if (cb == 0 && c == 0 && (dy == 0 || (t == 0 && dy == 1))) {   // a row's first product (as below)
+                            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0][dy][m][0], b[J % PD][0], zero, 0, 0, 0);
+                        } else {
+                            acc[m][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[cb % 2][dy][m][c], b[J % PD][c], acc[m][t], 0, 0, 0);
+                        }
+                    }
+                }
+        __builtin_amdgcn_sched_barrier(0);
+        return;
     }
 #pragma unroll
     for (int combo = 0; combo < 3; ++combo)
@@ -1586,10 +1627,10 @@ __device__ __forceinline__ void slot_r(f32x4 (&acc)[TM][NT], f16x8 (&a)[2][3][TM
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int CIN, int TM, int NT, int... Js>
+template <int CIN, int TM, int NT, bool F8, int... Js>
 __device__ __forceinline__ void slots_r(std::integer_sequence<int, Js...>, f32x4 (&acc)[TM][NT], f16x8 (&a)[2][3][TM][2],
                                         f16x8 (&b)[kLA + 1][2], lds_frag q, lds_frag qf, __amdgpu_buffer_rsrc_t w_rsrc, int w_lane) {
-    (slot_r<CIN, TM, NT, Js>(acc, a, b, q, qf, w_rsrc, w_lane), ...);
+    (slot_r<CIN, TM, NT, Js, F8>(acc, a, b, q, qf, w_rsrc, w_lane), ...);
 }
 
 // the weight fragments of combo 0 (tap column 0, chunk 0; kernel rows 0 .. 2): requested while the previous layer is reduced
@@ -1605,7 +1646,7 @@ __device__ __forceinline__ void preload_w_r(f16x8 (&a)[2][3][TM][2], const void 
                 a[0][dy][m][p] = sp::load_w(w_rsrc, lane * 16, ((m * Geo<CIN>::steps + dy * 3 * Geo<CIN>::chunks) * 2 + p) * 1024);
 }
 
-template <int CIN, int TM, int NT>
+template <int CIN, int TM, int NT, bool F8 = false>
 __device__ __forceinline__ void conv_r(const char *in, const void *wts, int lane, f16x8 (&a)[2][3][TM][2], f32x4 (&acc)[TM][NT]) {
     using G = Geo<CIN>;
     static_assert(3 * TM <= NT && kLA <= NT, "loads are spread over a combo's first rows");
@@ -1616,10 +1657,10 @@ __device__ __forceinline__ void conv_r(const char *in, const void *wts, int lane
 #pragma unroll
     for (int j = 0; j < kLA; ++j) {   // slots 0 .. kLA - 1: combo 0 (dx = 0, chunk 0), halo rows 1 ..
         b[j][0] = q[((j + 1) * kRowW * G::pos_bytes) / 16];
-        b[j][1] = q[((j + 1) * kRowW * G::pos_bytes + CIN * 2) / 16];
+        b[j][1] = q[((j + 1) * kRowW * G::pos_bytes + (F8 ? 64 : CIN * 2)) / 16];
     }
     __builtin_amdgcn_sched_barrier(0);
-    slots_r<CIN, TM, NT>(std::make_integer_sequence<int, 3 * G::chunks * NT>{}, acc, a, b, q, qf, w_rsrc, lane * 16);
+    slots_r<CIN, TM, NT, F8>(std::make_integer_sequence<int, 3 * G::chunks * NT>{}, acc, a, b, q, qf, w_rsrc, lane * 16);
 }
 
 }  // namespace rt
@@ -1630,11 +1671,14 @@ __device__ __forceinline__ void conv_r(const char *in, const void *wts, int lane
 // Left alone hipcc allocates 396 .. 420 here depending on details of the prologue; the cap holds it at 372, no scratch.
 // TRACE (rz_trace.h): instantiated for the 15-row bitboard kernel only -- the layout whose schedule profiles/lane_timeline.py reads;
 // the production kernels carry nothing of it (its live values cost ten registers of a budget that is pinned).
-template <int NT, bool BITS, bool TRACE = false, bool RES = false>
+// F8: conv3 with its cross terms on the block-scaled FP8 pipe (RZ_NET_SPLIT_F16_FP8, opt-in: narrower arithmetic than the reference's
+// f32 -- rt::slot_r): conv2's epilogue stores the e5m2 pieces where the lo f16 pieces stood, conv3 reads nd.t3f.
+template <int NT, bool BITS, bool TRACE = false, bool RES = false, bool F8 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_trunk_rows(NetDev nd, const float *__restrict__ obs, LeafBits leaves,
                                                     float *__restrict__ feat, _Float16 *__restrict__ feat16,
                                                     int n_boards, unsigned *__restrict__ flags, DeferredOut later, ResArgs<RES> res) {
     static_assert(!RES || (BITS && !TRACE), "the resident search reads positions");
+    static_assert(!F8 || (BITS && !TRACE), "the FP8 cross terms: position-fed launches only");
     // RES: the value head's input row (zero padded to 4 x groups floats), the K-quarter sums of its first layer, the next leaf
     __shared__ float res_vrow[RES ? 512 : 1];
     __shared__ float res_part[RES ? rzt::kDefWaves : 1][RES ? rzt::kWave : 1];
@@ -1801,7 +1845,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_t
     const int next_board = RES ? n_boards : board + (int)gridDim.x;   // (RES: the next leaf does not exist yet)
     const int n = lane & 15, g = lane >> 4;
     const char *t2p = reinterpret_cast<const char *>(nd.t2) + (size_t)wave * rt::Geo<32>::steps * 2 * 1024;
-    const char *t3p = reinterpret_cast<const char *>(nd.t3) + (size_t)(2 * wave) * rt::Geo<64>::steps * 2 * 1024;
+    const char *t3p = reinterpret_cast<const char *>(F8 ? nd.t3f : nd.t3) + (size_t)(2 * wave) * rt::Geo<64>::steps * 2 * 1024;
     sp::f16x8 a2[2][3][1][2];
     rt::preload_w_r<32, 1>(a2, t2p, lane);
     {   // conv1: 4 -> 32 on 32 x 32 x 16 tiles of 2 rows x 16 columns, wave w = rows 4 w .. 4 w + 3; K-step = kernel row
@@ -1872,10 +1916,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_t
 #pragma unroll
                 for (int j = 0; j < 4; ++j) z[j] = fmaxf(fmaf(acc[0][t][j], k2, bias2[j]), 0.0f);
                 if constexpr (!BITS) zmax = fmaxf(fmaxf(zmax, fmaxf(z[0], z[1])), fmaxf(z[2], z[3]));
+                if constexpr (F8) {   // [hi f16 | e5m2 of the value | e5m2 of (value - hi) 2^11]: the lane's 4 channels, 8 + 4 + 4 bytes
+                    typedef float f32x4v __attribute__((ext_vector_type(4)));
+                    const sp::f16x4 hi = __builtin_convertvector((f32x4v){z[0], z[1], z[2], z[3]}, sp::f16x4);
+                    *reinterpret_cast<sp::f16x4 *>(pos + t * kRowW * P2) = hi;
+                    int h8 = __builtin_amdgcn_cvt_pk_bf8_f32(z[0], z[1], 0, false);
+                    h8 = __builtin_amdgcn_cvt_pk_bf8_f32(z[2], z[3], h8, true);
+                    float d[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d[j] = (z[j] - (float)hi[j]) * 2048.0f;
+                    int l8 = __builtin_amdgcn_cvt_pk_bf8_f32(d[0], d[1], 0, false);
+                    l8 = __builtin_amdgcn_cvt_pk_bf8_f32(d[2], d[3], l8, true);
+                    char *p8 = c2 + (kRowW + n + 1) * P2 + 128 + 16 * wave + 4 * g + t * kRowW * P2;
+                    *reinterpret_cast<int *>(p8) = h8;
+                    *reinterpret_cast<int *>(p8 + 64) = l8;
+                } else {
                 sp::f16x4 hi, lo;
                 sp::split4(z, hi, lo);
                 *reinterpret_cast<sp::f16x4 *>(pos + t * kRowW * P2) = hi;
                 *reinterpret_cast<sp::f16x4 *>(pos + t * kRowW * P2 + 128) = lo;
+                }
             }
         }
     }
@@ -1889,7 +1949,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_t
         float vals[96];   // [row t][output o]: the lane's 8 channels of position (t, n)
         {
             f32x4 acc[2][NT];
-            rt::conv_r<64, 2, NT>(c2, t3p, lane, a3, acc);
+            rt::conv_r<64, 2, NT, F8>(c2, t3p, lane, a3, acc);
             NET_TICK(5);
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
@@ -2462,6 +2522,7 @@ struct rz_net {
     bool split_ok = true;        // rz_net_load found finite activation bounds: the split-f16 trunk cannot overflow
     float range_info[8] = {0};   // rz_net_range_info
     int algo = RZ_NET_SPLIT_F16;
+    bool fp8_cross = false;      // RZ_NET_SPLIT_F16_FP8: algo stays RZ_NET_SPLIT_F16, conv3's cross terms run on the FP8 pipe (position-fed launches)
     int n_cus = 256;
     int max_wgs = 0;  // rz_net_set_max_workgroups: 0 = one persistent trunk workgroup per CU
     NetDev dev;
@@ -2627,6 +2688,62 @@ std::vector<f32x4> pack_rows(const float *w, int cout, int cin, float scale) {
     return out;
 }
 
+// OCP e4m3fn (1.4.3, bias 7, no infinities, largest finite 448) of x, round to nearest even, saturating
+unsigned char to_e4m3(float x) {
+    const unsigned char sign = std::signbit(x) ? 0x80 : 0;
+    double a = std::fabs((double)x);
+    if (!(a == a)) return 0x7f;
+    if (a >= 448.0) return sign | 0x7e;
+    if (a < std::ldexp(1.0, -10)) return sign;   // below half the smallest subnormal (2^-9): zero
+    int e = 0;
+    (void)std::frexp(a, &e);   // a = f 2^e, f in [0.5, 1)
+    int ex = e - 1;            // a = 1.m x 2^ex
+    if (ex < -6) ex = -6;      // subnormals share the exponent of the smallest normal
+    const double step = std::ldexp(1.0, ex - 3);
+    double qv = std::nearbyint(a / step);   // (the default rounding mode: to nearest even)
+    int m = (int)qv;   // 0 .. 16 in units of step
+    if (ex == -6 && m < 8) return sign | (unsigned char)m;   // subnormal
+    if (m == 16) { m = 8; ++ex; }
+    if (ex > 8 || (ex == 8 && m - 8 > 6)) return sign | 0x7e;
+    return sign | (unsigned char)(((ex + 7) << 3) | (m - 8));
+}
+
+// conv3 for the FP8 cross terms of k_trunk_rows (rt::slot_r, F8).  v = w * scale as in pack_rows (|v| < 2^14), hi = f16(v),
+// lo = f16(v - hi).  Packed [tile of 16 cout][tap][part][half][lane] x 16 bytes with lane = g*16 + r:
+//   part 0, half c: the hi f16 pieces of W[16 tile + r][32 c + 8 g + j][tap], j = 0..7 (pack_rows' hi fragment of chunk c);
+//   part 1: the lane's 32 bytes of the K = 128 block of the scaled MFMA, input channels 16 g + j, j = 0..15:
+//           half 0 = e4m3(lo * 2^5) (meets the activations' e5m2 value), half 1 = e4m3(hi * 2^-6) (meets e5m2((value - hi) 2^11));
+//           with the block's scale 2^-5 both products come out in the units of hi x hi.  |lo| <= 4 and |hi| <= 2^14: 128 and 256 of 448.
+std::vector<f32x4> pack_rows_f8(const float *w, int cout, int cin, float scale) {
+    const int tiles = cout / 16;
+    std::vector<f32x4> out((size_t)tiles * 9 * 2 * 2 * 64);
+    unsigned char *o = reinterpret_cast<unsigned char *>(out.data());
+    for (int t = 0; t < tiles; ++t)
+        for (int tap = 0; tap < 9; ++tap)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int r = lane & 15, g = lane >> 4;
+                auto piece = [&](int ci, _Float16 *hi, _Float16 *lo) {
+                    const float v = w[((size_t)(16 * t + r) * cin + ci) * 9 + tap] * scale;
+                    *hi = (_Float16)v;
+                    *lo = (_Float16)(v - (float)*hi);
+                };
+                const size_t base = ((size_t)t * 9 + tap) * 4 * 1024 + (size_t)lane * 16;
+                for (int c = 0; c < 2; ++c)
+                    for (int j = 0; j < 8; ++j) {
+                        _Float16 hi, lo;
+                        piece(32 * c + 8 * g + j, &hi, &lo);
+                        memcpy(o + base + c * 1024 + j * 2, &hi, 2);
+                    }
+                for (int j = 0; j < 16; ++j) {
+                    _Float16 hi, lo;
+                    piece(16 * g + j, &hi, &lo);
+                    o[base + 2048 + j] = to_e4m3((float)lo * 32.0f);
+                    o[base + 3072 + j] = to_e4m3((float)hi * (1.0f / 64.0f));
+                }
+            }
+    return out;
+}
+
 // conv1 (32 x 4 x 3 x 3) for k_trunk_split: K-step = kernel row ky, k = 4 * kx + plane for kx = 0..3 (kx = 3: zero
 // padding); lane = h*32 + r holds k = 8*h .. 8*h + 7 of output channel r.  [ky][hi | lo][lane] x 8 f16.
 std::vector<f32x4> pack_split1(const float *w, float *scale_out) {
@@ -2689,7 +2806,12 @@ std::vector<f32x4> pack_split_fc(const float *w, int n_out, int k_in, int tiles,
 
 template <int NT>
 static void launch_trunk_rows(bool bits, dim3 grid, hipStream_t stream, const NetDev &nd, const float *d_obs, LeafBits leaves, float *f32,
-                              _Float16 *f16, int n_boards, unsigned *flags, DeferredOut later = DeferredOut{nullptr, 0, nullptr, 0, nullptr}) {
+                              _Float16 *f16, int n_boards, unsigned *flags, DeferredOut later = DeferredOut{nullptr, 0, nullptr, 0, nullptr},
+                              bool fp8 = false) {
+    if (fp8 && bits) {   // (the schedule trace reads the default arithmetic's kernel)
+        k_trunk_rows<NT, true, false, false, true><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later, ResArgs<false>{});
+        return;
+    }
     if constexpr (NT == 15) {
         if (bits && later.trace) {
             k_trunk_rows<NT, true, true><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later, ResArgs<false>{});
@@ -2702,8 +2824,9 @@ static void launch_trunk_rows(bool bits, dim3 grid, hipStream_t stream, const Ne
 
 template <int NT>
 static void launch_search_rows(dim3 grid, hipStream_t stream, const NetDev &nd, LeafBits leaves, _Float16 *store, int n_games, unsigned *flags,
-                               DeferredOut later, const ResArgs<true> &res) {
-    k_trunk_rows<NT, true, false, true><<<grid, dim3(256), 0, stream>>>(nd, nullptr, leaves, nullptr, store, n_games, flags, later, res);
+                               DeferredOut later, const ResArgs<true> &res, bool fp8) {
+    if (fp8) k_trunk_rows<NT, true, false, true, true><<<grid, dim3(256), 0, stream>>>(nd, nullptr, leaves, nullptr, store, n_games, flags, later, res);
+    else k_trunk_rows<NT, true, false, true><<<grid, dim3(256), 0, stream>>>(nd, nullptr, leaves, nullptr, store, n_games, flags, later, res);
 }
 
 extern "C" {
@@ -2816,6 +2939,7 @@ int rz_net_load(rz_net *net, const float *const *h_params, int32_t n_params) {
         up_vec4(pack_split(h_params[4], 128, 64, &sw3), &D.s3);
         up_vec4(pack_rows(h_params[2], 64, 32, sw2), &D.t2);
         up_vec4(pack_rows(h_params[4], 128, 64, sw3), &D.t3);
+        up_vec4(pack_rows_f8(h_params[4], 128, 64, sw3), &D.t3f);
         float sw1 = 1.0f;
         up_vec4(pack_split1(h_params[0], &sw1), &D.s1);
         float sfa = 1.0f, sfv = 1.0f;
@@ -3007,13 +3131,14 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
         if (fc_here) net->feat16_valid = false;   // (the pieces stayed in LDS)
         if (net->algo == RZ_NET_SPLIT_F16 && rows_kernel_covers(net->dev.BH, net->dev.BW)) {   // wide boards: one N-tile per row
             const hipStream_t st = (hipStream_t)stream;
+            const bool fp8 = net->fp8_cross;   // (float planes in this mode were refused by the callers)
             switch (net->dev.BH) {
-                case 11: launch_trunk_rows<11>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later); break;
-                case 12: launch_trunk_rows<12>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later); break;
-                case 13: launch_trunk_rows<13>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later); break;
-                case 14: launch_trunk_rows<14>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later); break;
-                case 15: launch_trunk_rows<15>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later); break;
-                default: launch_trunk_rows<16>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later); break;
+                case 11: launch_trunk_rows<11>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later, fp8); break;
+                case 12: launch_trunk_rows<12>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later, fp8); break;
+                case 13: launch_trunk_rows<13>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later, fp8); break;
+                case 14: launch_trunk_rows<14>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later, fp8); break;
+                case 15: launch_trunk_rows<15>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later, fp8); break;
+                default: launch_trunk_rows<16>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later, fp8); break;
             }
         } else if (tiles <= 1)        // one tile: the four waves share the output channels
             k_trunk_split<1, 4><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, raw, hid, later);
@@ -3084,6 +3209,9 @@ int rz_net_trunk(rz_net *net, const float *d_obs, int32_t n_boards, float *d_fea
     if (rc != RZ_OK) return rc;
     if (n_boards == 0) return RZ_OK;  // an empty batch is a no-op (its tensors have no storage)
     if (!d_obs) return net_fail(RZ_ERR_ARG, "NULL device pointer");
+    if (net->fp8_cross)
+        return net_fail(RZ_ERR_ARG, "RZ_NET_SPLIT_F16_FP8 evaluates positions (rz_net_trunk_leaves*, rz_net_search_resident): float planes are refused, "
+                                    "not computed in another arithmetic");
     if (!d_feat) {  // internal feature buffer (the input of rz_net_heads)
         if (n_boards > net->feat_boards) return net_fail(RZ_ERR_ARG, "batch larger than rz_net_reserve()d");
         d_feat = net->d_feat;
@@ -3209,12 +3337,12 @@ int rz_net_search_resident(rz_net *net, rz_engine *engine, int32_t n_sims, void 
         return RZ_OK;
     }
     switch (net->dev.BH) {
-        case 11: launch_search_rows<11>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res); break;
-        case 12: launch_search_rows<12>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res); break;
-        case 13: launch_search_rows<13>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res); break;
-        case 14: launch_search_rows<14>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res); break;
-        case 15: launch_search_rows<15>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res); break;
-        default: launch_search_rows<16>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res); break;
+        case 11: launch_search_rows<11>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res, net->fp8_cross); break;
+        case 12: launch_search_rows<12>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res, net->fp8_cross); break;
+        case 13: launch_search_rows<13>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res, net->fp8_cross); break;
+        case 14: launch_search_rows<14>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res, net->fp8_cross); break;
+        case 15: launch_search_rows<15>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res, net->fp8_cross); break;
+        default: launch_search_rows<16>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res, net->fp8_cross); break;
     }
     if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of the resident search failed");
     return RZ_OK;
@@ -3251,9 +3379,13 @@ int rz_net_deferred_gemm(rz_net *net, int32_t n_boards, int32_t n_slots, rz_defe
 
 int rz_net_set_algo(rz_net *net, int32_t algo) {
     if (!net) return net_fail(RZ_ERR_ARG, "net handle is NULL");
-    if (algo != RZ_NET_DIRECT && algo != RZ_NET_WINOGRAD_F4 && algo != RZ_NET_SPLIT_F16 && algo != RZ_NET_SPLIT_F16_TILES)
+    if (algo != RZ_NET_DIRECT && algo != RZ_NET_WINOGRAD_F4 && algo != RZ_NET_SPLIT_F16 && algo != RZ_NET_SPLIT_F16_TILES &&
+        algo != RZ_NET_SPLIT_F16_FP8)
         return net_fail(RZ_ERR_ARG, "unknown algorithm");
-    net->algo = algo;
+    if (algo == RZ_NET_SPLIT_F16_FP8 && !rows_kernel_covers(net->dev.BH, net->dev.BW))
+        return net_fail(RZ_ERR_ARG, "RZ_NET_SPLIT_F16_FP8 exists for boards of 11 .. 16 rows and columns (k_trunk_rows)");
+    net->fp8_cross = algo == RZ_NET_SPLIT_F16_FP8;
+    net->algo = net->fp8_cross ? RZ_NET_SPLIT_F16 : algo;
     return RZ_OK;
 }
 
@@ -3323,6 +3455,9 @@ int rz_net_forward(rz_net *net, const float *d_obs, int32_t n_boards, float *d_l
     if (rc != RZ_OK) return rc;
     if (n_boards == 0) return RZ_OK;
     if (!d_obs || !d_logp || !d_value) return net_fail(RZ_ERR_ARG, "NULL device pointer");
+    if (net->fp8_cross)
+        return net_fail(RZ_ERR_ARG, "RZ_NET_SPLIT_F16_FP8 evaluates positions (rz_net_trunk_leaves*, rz_net_search_resident): float planes are refused, "
+                                    "not computed in another arithmetic");
     if (n_boards > net->feat_boards)
         return net_fail(RZ_ERR_ARG, "batch larger than rz_net_reserve()d (no allocation on the launch path)");
     launch_trunk(net, d_obs, net->d_feat, n_boards, stream);

@@ -105,9 +105,11 @@ class HipNet(object):
         """conv2 / conv3 algorithm: 'split_f16' (default: direct convolution on the f16 matrix pipe, every f32
         operand carried as a hi + lo pair of f16 values, f32 accumulation -- as accurate as 'direct'), or on the
         f32-input MFMA: 'winograd_f4' (F(4x4,3x3)) or 'direct' (bit-for-bit a k-ordered fmaf chain).  'split_f16_tiles'
-        is 'split_f16' with the 32 x 32 x 16 tile kernel on every board size (boards of 11 .. 16 rows and columns otherwise run the row-tile kernel)."""
+        is 'split_f16' with the 32 x 32 x 16 tile kernel on every board size (boards of 11 .. 16 rows and columns otherwise run the row-tile kernel).
+        'split_f16_fp8' (OPT-IN, narrower than the reference's f32; boards of 11 .. 16 rows and columns, positions only): 'split_f16'
+        with conv3's cross terms hi x lo + lo x hi on the block-scaled FP8 pipe (include/rlzero_hip.h: RZ_NET_SPLIT_F16_FP8)."""
         code = {'direct': _hip.NET_DIRECT, 'winograd_f4': _hip.NET_WINOGRAD_F4, 'split_f16': _hip.NET_SPLIT_F16,
-                'split_f16_tiles': _hip.NET_SPLIT_F16_TILES}[algo]
+                'split_f16_tiles': _hip.NET_SPLIT_F16_TILES, 'split_f16_fp8': _hip.NET_SPLIT_F16_FP8}[algo]
         check(self.lib.rz_net_set_algo(self.handle, code), 'rz_net_set_algo')
         self.algo = algo
         return self
@@ -115,7 +117,7 @@ class HipNet(object):
     def reads_positions(self):
         """True when the trunk can be fed the engine's leaf bitboards (rz_net_trunk_leaves): the 'split_f16' trunk of a
         net with finite activation bounds.  The tree kernels then write no observation planes at all."""
-        return getattr(self, 'algo', 'split_f16') in ('split_f16', 'split_f16_tiles') and getattr(self, '_split_ok', True)
+        return getattr(self, 'algo', 'split_f16') in ('split_f16', 'split_f16_tiles', 'split_f16_fp8') and getattr(self, '_split_ok', True)
 
     def trunk_leaves(self, eng):
         """The trunk on the engine's current leaves, read as bitboards (no float planes), into the internal buffer."""
@@ -129,7 +131,7 @@ class HipNet(object):
     def supports_deferred(self):
         """True when this net's trunk can leave the policy features in a store and hand the tree step the value head's inputs
         (rz_net_trunk_leaves_deferred): the 'split_f16' trunks, every board size."""
-        return getattr(self, 'algo', 'split_f16') in ('split_f16', 'split_f16_tiles') and getattr(self, '_split_ok', True)
+        return getattr(self, 'algo', 'split_f16') in ('split_f16', 'split_f16_tiles', 'split_f16_fp8') and getattr(self, '_split_ok', True)
 
     def deferred_bytes_per_slot(self, n_boards):
         """Device bytes one store slot (one simulation step of ``n_boards`` leaves) takes: f16 feature pieces + logits."""
@@ -152,7 +154,7 @@ class HipNet(object):
 
     def supports_resident(self):
         """True when whole searches can run as ONE launch, one workgroup per game (rz_net_search_resident)."""
-        if getattr(self, 'algo', 'split_f16') != 'split_f16' or not getattr(self, '_split_ok', True):
+        if getattr(self, 'algo', 'split_f16') not in ('split_f16', 'split_f16_fp8') or not getattr(self, '_split_ok', True):
             return False
         return (11 <= self.rows <= 16 and 11 <= self.cols <= 16) or (self.rows <= 10 and self.cols <= 10)
 

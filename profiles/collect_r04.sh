@@ -30,6 +30,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_c2" -o
 RZ_RESIDENT=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_c2_2launch" -o s -- $B --graph 0 --steps 4 --board 9 --playouts 200 --games 64 --lanes 1 > "$OUT/bench_eager_c2_2launch_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_256" -o s -- $B --graph 0 --steps 2 --games 256 > "$OUT/bench_eager_256_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_c3" -o s -- $B --graph 0 --steps 2 --game connect4 --playouts 400 --games 512 > "$OUT/bench_eager_c3_under_rocprof.json" 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_fp8" -o s -- $B --graph 0 --steps 2 --net-algo split_f16_fp8 > "$OUT/bench_eager_fp8_under_rocprof.json" 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_fill_fp8" -o s -- $B --graph 0 --steps 2 --games 1536 --net-algo split_f16_fp8 > "$OUT/bench_eager_fill_fp8_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_muzero" -o s -- $B --game muzero --playouts 50 --games 8192 --steps 256 --warmup 64 > "$OUT/bench_muzero_under_rocprof.json" 2> /dev/null
 echo "kernel stats done"
 
@@ -44,6 +46,7 @@ pmc() {  # tag, bench flags
 pmc default
 pmc 3launch --deferred 0
 pmc fill --games 1536
+pmc fp8 --net-algo split_f16_fp8
 pmc puct --score-mode puct
 pmc c2 --board 9 --playouts 200 --games 64 --lanes 1
 pmc c2k16 --board 9 --playouts 200 --games 64 --in-flight 16

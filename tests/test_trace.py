@@ -55,5 +55,6 @@ def test_trace_of_the_four_lane_layout():
         assert 5.0 < lane['tree_launch_us'] < 60.0 and 15.0 < lane['trunk_launch_us'] < 120.0
     # (searches this short overlap only partly -- every lane's host step is a fifth of its search: the full-size figures are
     # on the bench line -- so the bounds are loose)
-    assert 0.3 < out['cu_time_in_trunk'] <= 1.0 and out['launches_in_flight'] > 1.0 and 200 <= out['cus_seen'] <= 256 and out['window'] == 'all lanes searching'
+    assert 0.3 < out['cu_time_in_trunk'] <= 1.0 and out['launches_in_flight'] > 1.0 and 200 <= out['cus_seen'] <= 256
+    assert out['window'] in ('all lanes searching', "union of the lanes' searches")   # (the second when these short searches barely overlap)
     assert 15.0 < out['trunk_workgroup_us']['mean'] < 40.0 and out['sims_per_sec_in_window'] > 3e6

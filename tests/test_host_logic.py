@@ -235,3 +235,26 @@ def test_trajectory_payload_round_trip():
             assert [(t.game_id, t.moves, t.winner) for t in back] == [(t.game_id, t.moves, t.winner) for t in batch]
             for a, b in zip(back, batch):
                 assert np.array_equal(a.pis, b.pis.astype(dtype).astype(np.float64))
+
+
+def test_fp8_model_rounds_to_the_ocp_grids():
+    """oracle/fp8_cross_ref.py (the float64 model of the opt-in FP8 cross terms): e4m3fn and e5m2 roundings -- every value on the
+    grid is a fixed point, midpoints go to the even neighbour, subnormals keep the smallest normal's step, saturation at 448 / 57344 --
+    and the three-term split it models reproduces a float32 product to 2^-21."""
+    import torch
+    from oracle import fp8_cross_ref as m
+    grid4 = torch.tensor([s * (1 + k / 8.0) * 2.0 ** e for s in (1, -1) for e in range(-6, 9) for k in range(8) if (1 + k / 8.0) * 2.0 ** e <= 448] +
+                         [k * 2.0 ** -9 for k in range(8)], dtype=torch.float64)
+    assert torch.equal(m.e4m3(grid4), grid4)
+    grid5 = torch.tensor([s * (1 + k / 4.0) * 2.0 ** e for s in (1, -1) for e in range(-14, 16) for k in range(4)] + [k * 2.0 ** -16 for k in range(4)],
+                         dtype=torch.float64)
+    assert torch.equal(m.e5m2(grid5), grid5)
+    x = torch.tensor([1.0625, 1.1875, 1.0626, 500.0, -1000.0, 2.0 ** -10, 1.5 * 2.0 ** -10, 0.9 * 2.0 ** -10], dtype=torch.float64)
+    assert m.e4m3(x).tolist() == [1.0, 1.25, 1.125, 448.0, -448.0, 0.0, 2.0 ** -9, 0.0]
+    y = torch.tensor([1.125, 1.375, 1.126, 60000.0, 61440.0, 1e9, 2.0 ** -17, 1.5 * 2.0 ** -16], dtype=torch.float64)
+    assert m.e5m2(y).tolist() == [1.0, 1.5, 1.25, 57344.0, 57344.0, 57344.0, 0.0, 2.0 ** -15]
+    torch.manual_seed(0)
+    a, w = torch.randn(1000).float(), torch.randn(1000).float()
+    ah, al = m.split(a)
+    wh, wl = m.split(w)
+    assert float(((ah * wh + ah * wl + al * wh) - a.double() * w.double()).abs().max()) < 2.0 ** -21 * 16

@@ -2345,20 +2345,35 @@ __device__ __forceinline__ void fs_gemm(sp::f32x16 (&acc)[TM][TN], const f32x4 *
     }
 }
 
-template <int TM, int TN, int DEPTH, bool VAL_FUSED>
+// PAIRED (the GEMM over the deferred store: policy outputs only, hundreds of MB of features read once per move): a 1-D grid in
+// which the workgroups of the SAME board tiles and different output groups are 8 apart -- workgroups go to the 8 XCDs round robin,
+// so the two share an L2 and run together: the second one's feature reads hit there instead of HBM (a (tiles, groups) grid
+// dispatches them thousands of workgroups apart: the store came from HBM twice, profiles/r04/pmc_traffic.json).
+template <int TM, int TN, int DEPTH, bool VAL_FUSED, bool PAIRED = false>
 __global__ __launch_bounds__(256) void k_heads_split(NetDev nd, const f32x4 *__restrict__ feat16,
                                                      float *__restrict__ raw, float *__restrict__ hid, int n_boards) {
     __shared__ sp::f32x16 part[4][TM * TN][64];  // [K quarter][tile][lane]
+    const int n_act_tiles = nd.Npad / 32, n_groups = (n_act_tiles + TN - 1) / TN;
+    int block_x = blockIdx.x, block_y = blockIdx.y;
+    if constexpr (PAIRED) {
+        static_assert(!VAL_FUSED, "policy outputs only");
+        if (n_groups == 2) {   // (at most 256 outputs = 8 tiles = 2 groups of TN = 4)
+            block_y = (block_x >> 3) & 1;
+            block_x = ((block_x >> 4) << 3) | (block_x & 7);
+        } else {
+            block_y = 0;
+        }
+        if (block_x * TM * 32 >= n_boards) return;   // (the grid is rounded up to whole groups of 16; uniform, before any barrier)
+    }
     __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mt0 = blockIdx.x * TM;
+    const int mt0 = block_x * TM;
     const int steps_all = nd.groups_act + nd.groups_val;
-    const int n_act_tiles = nd.Npad / 32, n_groups = (n_act_tiles + TN - 1) / TN;
     const f32x4 *fa = feat16 + (size_t)mt0 * steps_all * 128;  // 128 f32x4 = one K-step (hi | lo) of one tile
     const f32x4 *zero = nd.fs_act + (size_t)n_act_tiles * nd.groups_act * 128;  // one all-zero K-step behind the weights
     const int col = lane & 31, h = lane >> 5;
-    const int group = blockIdx.y;                                       // policy outputs 32 * TN * group ..
-    const int vtile = VAL_FUSED ? (int)blockIdx.y : (int)blockIdx.y - n_groups;  // value hidden units 32 * vtile ..
+    const int group = block_y;                                       // policy outputs 32 * TN * group ..
+    const int vtile = VAL_FUSED ? block_y : block_y - n_groups;  // value hidden units 32 * vtile ..
     if (group < n_groups) {
         const f32x4 *fb[TN];
 #pragma unroll
@@ -3365,9 +3380,11 @@ int rz_net_deferred_gemm(rz_net *net, int32_t n_boards, int32_t n_slots, rz_defe
         // them (64 boards x 128 outputs per workgroup, the K quarters over its four waves: the bits of every other shape)
         NetDev nd = net->dev;
         nd.groups_val = 0;   // a tile of the store holds the policy K-steps only
-        const int n_act_tiles = nd.Npad / 32;
-        const dim3 grid((unsigned)((size_t)n_slots * net->store_tiles / 2), (unsigned)((n_act_tiles + 3) / 4));
-        k_heads_split<2, 4, 3, false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(
+        const int n_act_tiles = nd.Npad / 32, n_groups = (n_act_tiles + 3) / 4;
+        if (n_groups > 2) return net_fail(RZ_ERR_INTERNAL, "more than 256 policy outputs");
+        const size_t pairs = (size_t)n_slots * net->store_tiles / 2;   // workgroups per output group: two board tiles each
+        const dim3 grid((unsigned)(n_groups == 2 ? 2 * ((pairs + 7) / 8 * 8) : pairs));
+        k_heads_split<2, 4, 3, false, true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(
             nd, reinterpret_cast<const f32x4 *>(net->d_store16), net->d_store_raw, nullptr, n_slots * net->store_tiles * 32);
         if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_heads_split failed");
     }

@@ -263,7 +263,7 @@ class BatchedSelfPlay(object):
     def for_network(cls, net_module, board, n_in_row, n_games, n_playout, c_puct=5.0, device='cuda:0',
                     game='gomoku', net_shape=None, lanes=None, trunk_workgroups=None, temperature=1.0, seed=0,
                     use_graph=True, sims_per_graph=16, eager_every=0, add_noise=True, sims_in_flight=1, before_warm=None,
-                    deferred_priors=None, resident_search=None, **engine_kw):
+                    deferred_priors=None, resident_search=None, net_algo=None, **engine_kw):
         """Self-play of ``n_games`` games in flight with the hand-written evaluator of ``net_module`` (a
         PolicyValueNet): builds the lanes (engine + HipNetEvaluator each) as plan_lanes() recommends, unless
         ``lanes`` / ``trunk_workgroups`` are given (more than four lanes take turns on the GPU's four compute pipes, and four need
@@ -273,7 +273,9 @@ class BatchedSelfPlay(object):
         with one leaf per game; the evaluator batch of a lane is then its games x K.  ``deferred_priors``: None = the deferred-priors
         route wherever it exists (HipNetEvaluator.deferred_ok), False = the three-launch step everywhere; ``resident_search`` likewise for
         the one-launch-per-search kernel of batches that give every game a CU (False = the two-launch step).  ``before_warm(sp)``: called
-        before the hipGraphs are captured (rlzero_amd.trace attaches its buffer there)."""
+        before the hipGraphs are captured (rlzero_amd.trace attaches its buffer there).  ``net_algo``: HipNet.set_algo for every lane's
+        evaluator -- None keeps the default ('split_f16', the f32-accurate trunk); 'split_f16_fp8' is the OPT-IN arithmetic narrower than
+        the reference's f32 (boards of 11 .. 16 rows and columns)."""
         import torch
         from .engine import HipNetEvaluator, MCTSEngine
         dev = torch.device(device)
@@ -304,6 +306,8 @@ class BatchedSelfPlay(object):
                                       noise_seed=(int(seed) * 7919 + len(engines)) & 0x7fffffff, **engine_kw))
             ev = HipNetEvaluator(net_module, net_shape if net_shape is not None else board, str(device),
                                  max_boards=g_lane * K)
+            if net_algo is not None:
+                ev.hip.set_algo(net_algo)
             ev.hip.set_max_workgroups(max(0, int(wgs)))
             ev.hip.set_heads_algo(heads_algo)
             if deferred_priors is not None:

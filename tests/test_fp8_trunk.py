@@ -163,3 +163,30 @@ def test_fp8_resident_search_is_the_two_launch_step():
     for a, b in zip(dumps[True], dumps[False]):
         assert np.array_equal(a, b)
     assert (dumps[True][0].sum(axis=1) == sims - 1).all() or (dumps[True][0].sum(axis=1) == sims).all()
+
+
+def test_fp8_selfplay_through_for_network():
+    """The product-level opt-in (BatchedSelfPlay.for_network(net_algo='split_f16_fp8')): whole games on two lanes with hipGraphs; the
+    games are legal Gomoku games whose pi rows are visit distributions, every lane runs the FP8 kernel's route, and a second run
+    reproduces the first bit for bit (the mode is as deterministic as the default)."""
+    from rlzero_amd.selfplay import BatchedSelfPlay
+    B = 11
+    net = _net(B, seed=4, gain=2.0).to('cuda:0').eval()
+    runs = []
+    for _ in range(2):
+        sp = BatchedSelfPlay.for_network(net, B, 5, n_games=16, n_playout=40, device='cuda:0', lanes=2, seed=3, net_algo='split_f16_fp8')
+        assert all(lane.evaluator.hip.algo == 'split_f16_fp8' and lane.evaluator.deferred_ok(lane.eng) for lane in sp.lanes)
+        trajs = sp.run(range(16))
+        for lane in sp.lanes:
+            lane.eng.close()
+            lane.evaluator.hip.close()
+        assert len(trajs) == 16
+        for t in trajs:
+            e = RefGomoku(B, 5)
+            for mv, pi in zip(t.moves, t.pis):
+                assert mv in e.leagel_actions() and abs(float(np.sum(pi)) - 1.0) < 1e-5 and pi[mv] > 0
+                e.step(int(mv))
+            ended, winner = e.game_end_winner()
+            assert ended and winner == t.winner
+        runs.append({t.game_id: (list(t.moves), [np.asarray(p, dtype=np.float32).tobytes() for p in t.pis]) for t in trajs})
+    assert runs[0] == runs[1]

@@ -20,4 +20,9 @@ itself, produced in the build container by ``tests/golden/gen_golden.py``
 ``tests/golden/``.  ``tests/test_oracle_golden.py`` checks every fixture
 bit-for-bit (visit counts, W as fp64 bit patterns, moves, winners, z,
 observation planes) and pi to 1e-12.
+
+Not of the reference: ``connect4_ref.py``, ``muzero_ref.py`` (build-defined rules / the published MuZero pseudocode: the
+reference has neither -- parity unpinned by nature, as their headers say) and ``fp8_cross_ref.py`` (the float64 model of
+the OPT-IN RZ_NET_SPLIT_F16_FP8 trunk arithmetic: it says what that mode should compute; ``tests/test_fp8_trunk.py``
+says how far that is from the reference's forward in float64).
 """

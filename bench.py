@@ -970,7 +970,8 @@ def main():
             peak, pipe_peak, _ = trunk_peak(args)
             pmc_key = line['config']['workload'] + ('+puct' if args.score_mode == 'puct' else '') + \
                 ('+k%d' % args.in_flight if args.in_flight > 1 else '') + \
-                ('+3launch' if (not deferred_route and args.score_mode != 'puct' and args.in_flight <= 1) else '')
+                ('+3launch' if (not deferred_route and args.score_mode != 'puct' and args.in_flight <= 1) else '') + \
+                ('+fp8' if args.net_algo == 'split_f16_fp8' else '')
             in_flight = round(per_stream_ms / ms, 2) if lanes > 1 else 1.0
             rf = {'bound': 'mfma', 'kernel': '%s, %d leaves per launch%s' % (
                       evaluator.label, boards_per_launch, (', %.1f launches in flight' % in_flight) if in_flight >= 1.5 else ''),

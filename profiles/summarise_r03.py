@@ -75,7 +75,7 @@ def main(out):
         except (OSError, ValueError, IndexError):
             continue
         workload = line['config']['workload']
-        workload += {'puct': '+puct', 'c2k16': '+k16', '3launch': '+3launch'}.get(tag, '')   # same geometry, another rule / mode: its own entry
+        workload += {'puct': '+puct', 'c2k16': '+k16', '3launch': '+3launch', 'fp8': '+fp8'}.get(tag, '')   # same geometry, another rule / mode: its own entry
         rec = {'tag': tag, 'kernels': {}}
         per = {}
         for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
@@ -90,6 +90,11 @@ def main(out):
                                  'traffic_bytes_per_launch': int(round((2.0 * fetch_kb + write_kb) * 1024))}
         if rec['kernels']:
             traffic[workload] = rec
+    merge = os.environ.get('RZ_PMC_MERGE')   # a pmc_traffic.json to update with the passes of this run (a partial re-collection)
+    if traffic and merge and os.path.exists(merge):
+        base = json.load(open(merge))
+        base.update(traffic)
+        traffic = base
     if traffic:
         traffic['_method'] = ('rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of `bench.py <the workload\'s flags> '
                               '--graph 0 --steps 1 --warmup 1` (eager launches, the workload\'s own playout count); per-dispatch means; '

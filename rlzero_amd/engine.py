@@ -850,6 +850,28 @@ class MCTSEngine(object):
         self.moves.copy_(self.torch.from_numpy(np.ascontiguousarray(moves, dtype=np.int32)))
         check(self.lib.rz_advance_roots(self.handle, _ptr(self.moves), self.stream()), 'rz_advance_roots')
 
+    def advance_and_step(self, keep_moves, step_moves):
+        """``advance(keep_moves)`` then ``step(step_moves)`` as one host step: both move vectors go up in one copy from pinned
+        memory, winners and ended flags come back in one, and the host waits once (the self-play loop's move: update_with_move
+        before the boards change, alphazero_mcts.py:96-103, then env.step + game_end_winner).  -> (winner[G], ended[G])."""
+        t = self.torch
+        self.flush_deferred()   # (the kept subtree's prior blocks are copied: they must be written)
+        G = self.n_games
+        if getattr(self, '_move_io', None) is None:
+            self._move_io = (t.empty((2, G), dtype=t.int32, pin_memory=True), t.empty((2, G), dtype=t.int32, device=self.device),
+                             t.empty(G, dtype=t.int32, pin_memory=True), t.empty(G, dtype=t.uint8, pin_memory=True), t.cuda.Event())
+        h_in, d_in, h_win, h_end, done = self._move_io
+        h_in[0].numpy()[:] = keep_moves
+        h_in[1].numpy()[:] = step_moves
+        d_in.copy_(h_in, non_blocking=True)
+        check(self.lib.rz_advance_roots(self.handle, _ptr(d_in[0]), self.stream()), 'rz_advance_roots')
+        check(self.lib.rz_step_games(self.handle, _ptr(d_in[1]), _ptr(self.winner), _ptr(self.ended), self.stream()), 'rz_step_games')
+        h_win.copy_(self.winner, non_blocking=True)
+        h_end.copy_(self.ended, non_blocking=True)
+        done.record(t.cuda.current_stream(self.device))
+        done.synchronize()
+        return h_win.numpy().copy(), h_end.numpy().copy()
+
     def step(self, moves):
         """env.step + game_end_winner on the root boards -> (winner[G], ended[G])."""
         self.moves.copy_(self.torch.from_numpy(np.ascontiguousarray(moves, dtype=np.int32)))

@@ -416,6 +416,10 @@ class BatchedSelfPlay(object):
         """Enqueue the n_playout simulations of ONE lane on its stream (graph replays + the eager remainder)."""
         n = self.eng.n_playout
         with self._on(lane):
+            res_ok = getattr(lane.evaluator, 'resident_ok', None)
+            if res_ok is not None and res_ok(lane.eng):   # one launch for the whole search: no graph, no chunks
+                lane.eng.sim_chunk(lane.evaluator, n)
+                return
             if self.use_graph:
                 per = self.eng.graph_chunk(self.sims_per_graph)
                 full, n = divmod(n, per)
@@ -437,8 +441,10 @@ class BatchedSelfPlay(object):
         running = lo + np.nonzero(self.slot_game[lane.slots] >= 0)[0]
         with self._on(lane):
             visits = lane.eng.root_visits()
-            if hasattr(getattr(lane.evaluator, 'hip', None), 'check_flags'):
-                lane.evaluator.hip.check_flags()  # the split-f16 trunk reports an input outside its range
+            # the split-f16 trunk reports an input outside its range: float planes only (positions are 0 / 1 planes by construction,
+            # and the query waits for the device)
+            if hasattr(getattr(lane.evaluator, 'hip', None), 'check_flags') and getattr(lane.evaluator, 'needs_obs', True):
+                lane.evaluator.hip.check_flags()
         self.sims_done += eng.n_playout * len(running)
         moves = np.full(eng.n_games, -2, dtype=np.int32)
         if len(running):
@@ -459,8 +465,7 @@ class BatchedSelfPlay(object):
                 self.slot_moves[s_].append(int(chosen[i]))
         step_moves = np.where(moves >= 0, moves, -1).astype(np.int32)
         with self._on(lane):
-            lane.eng.advance(moves)  # tree reuse, before the boards change
-            winner, ended = lane.eng.step(step_moves)
+            winner, ended = lane.eng.advance_and_step(moves, step_moves)  # tree reuse before the boards change
         self.moves_done += len(running)
         done = []
         for s in running:

@@ -443,7 +443,8 @@ def run_muzero(args, rank, world, device, dist, red_device, use_dist=False, cpu_
     workload = 'muzero_cartpole_v1_%dsims_per_move_%denvs_per_gpu' % (n_sims, G)
     torch.manual_seed(0)
     net = MuZeroNet().to(device).eval()
-    sp = MuZeroSelfPlay(net, CartPoleBatch(G, device, seed=rank), n_sims=n_sims, seed=rank, fused=bool(args.mz_fused))
+    sp = MuZeroSelfPlay(net, CartPoleBatch(G, device, seed=rank), n_sims=n_sims, seed=rank, fused=bool(args.mz_fused),
+                        moves_per_launch=args.mz_moves_per_launch)
     if args.mz_gpw:
         sp.tree.set_search_shape(args.mz_gpw)
     sp.collect(args.warmup)
@@ -583,6 +584,7 @@ def main():
     ap.add_argument('--pipeline', type=int, default=1,
                     help='1 = the host side of a lane\'s move runs under the other lanes\' simulations (BatchedSelfPlay.'
                          'play_move_pipelined); 0 = all lanes simulate, then all are finished on the host')
+    ap.add_argument('--mz-moves-per-launch', type=int, default=16, help='MuZero: moves of every environment per launch of the whole-moves kernel')
     ap.add_argument('--mz-gpw', type=int, default=0,
                     help='--game muzero: games per workgroup of k_mz_search (rz_mz_set_search_shape; 0 = automatic)')
     ap.add_argument('--mz-fused', type=int, default=1,

@@ -678,7 +678,10 @@ class MCTSEngine(object):
         owner = getattr(evaluator, '_def_owner', None)
         owner = owner() if owner is not None else None
         if owner is not None and owner is not self:
+            # (the other engine's steps may be on another stream than the one current here: its flush waits for them)
+            self.torch.cuda.synchronize(self.device)
             owner.flush_deferred()
+            self.torch.cuda.synchronize(self.device)
         if owner is not self:
             import weakref
             evaluator._def_owner = weakref.ref(self)

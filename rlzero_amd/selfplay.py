@@ -284,7 +284,8 @@ class BatchedSelfPlay(object):
         shape0 = net_shape if net_shape is not None else board
         rows0, cols0 = (shape0[0], shape0[1]) if isinstance(shape0, (tuple, list)) else (shape0, shape0)
         deferred = (deferred_priors is not False and K == 1 and engine_kw.get('score_mode', 'uct_ref') in ('uct_ref', 0)
-                    and game == 'gomoku' and 11 <= rows0 <= 16 and 11 <= cols0 <= 16)
+                    and game == 'gomoku' and 11 <= rows0 <= 16 and 11 <= cols0 <= 16
+                    and net_algo in (None, 'split_f16', 'split_f16_tiles', 'split_f16_fp8'))
         auto_lanes, auto_wgs, heads_algo = plan_lanes(n_games * K, n_cus, deferred=deferred)
         if lanes is None:
             lanes, wgs = auto_lanes, auto_wgs
@@ -387,6 +388,10 @@ class BatchedSelfPlay(object):
                 lane.primed = False
             return
         n = self.eng.n_playout
+        if all(getattr(lane.evaluator, 'resident_ok', None) is not None and lane.evaluator.resident_ok(lane.eng) for lane in self.lanes):
+            for lane in self.lanes:   # one launch per lane for the whole search: nothing to interleave, no graph
+                self._simulate_lane(lane)
+            return
         if self.use_graph:
             per = self.eng.graph_chunk(self.sims_per_graph)
             full, n = divmod(n, per)

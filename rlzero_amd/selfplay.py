@@ -132,7 +132,7 @@ class Trajectory(object):
 
 
 
-def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False):
+def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False, cells=None):
     """-> (lanes, trunk_workgroups, heads_algo) for ``n_games`` leaves per simulation step on a GPU with ``n_cus`` CUs and
     ``hw_queues`` hardware queues for its streams (default: what rlzero_amd claimed on import, rlzero_amd.HW_QUEUES).
 
@@ -144,6 +144,11 @@ def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False):
     1.75 rounds THREE (320 / 384 games: 9.2 / 10.3 against 8.7 / 9.8 with
     two); 448 games TWO (10.3 against 10.1); 2 .. 2.75 rounds FOUR on 8 hardware queues (512 / 640 games: 10.6 / 10.6 against 10.5
     / 10.1 with two -- with fewer queues two lanes, a percent behind); beyond, TWO (768 .. 1536 games: 10.9 .. 11.0).
+
+    ``cells``: positions of the board, when known.  Boards of at most 42 cells on the split-f16 trunk (Connect4, 6x6: the
+    two-launch step with a 12-us trunk and a 10-us tree step) run TWO lanes above one round of boards (Connect4, M simulations / s on
+    2 / 3 / 4 lanes: 384 games 14.2 / 13.8 / 13.1, 512 games 17.7 / 15.7 / 16.7, 768 games 20.2 / 20.4 / 20.0, 1024 games
+    22.9 / 21.9 / 21.1 -- profiles/r04/small_boards_lanes.txt; 9x9 keeps the table below: 512 games 14.8 / 14.5 / 15.4).
 
     The three-launch step (every other batch), measured on
     MI355X at 15x15 (profiles/r03/lane_sweeps.txt; a trunk workgroup takes a board in ~23 us, three in ~65 us):
@@ -165,6 +170,8 @@ def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False):
     ones once the 'parts' GEMM existed)."""
     if hw_queues is None:
         from . import HW_QUEUES as hw_queues
+    if cells is not None and cells <= 42 and n_games > n_cus:
+        return 2, 0, 'parts'
     if deferred:
         if n_games <= n_cus:   # one game per CU at most: the resident search (one launch per search, a workgroup per game) --
             # on TWO lanes from half a round of boards on, so that a lane's host step runs under the other lane's search
@@ -286,7 +293,9 @@ class BatchedSelfPlay(object):
         deferred = (deferred_priors is not False and K == 1 and engine_kw.get('score_mode', 'uct_ref') in ('uct_ref', 0)
                     and game == 'gomoku' and 11 <= rows0 <= 16 and 11 <= cols0 <= 16
                     and net_algo in (None, 'split_f16', 'split_f16_tiles', 'split_f16_fp8'))
-        auto_lanes, auto_wgs, heads_algo = plan_lanes(n_games * K, n_cus, deferred=deferred)
+        small_trunk = (K == 1 and deferred_priors is not False and engine_kw.get('score_mode', 'uct_ref') in ('uct_ref', 0)
+                       and net_algo in (None, 'split_f16', 'split_f16_tiles'))   # (the two-launch step on a small board)
+        auto_lanes, auto_wgs, heads_algo = plan_lanes(n_games * K, n_cus, deferred=deferred, cells=rows0 * cols0 if small_trunk else None)
         if lanes is None:
             lanes, wgs = auto_lanes, auto_wgs
         else:

@@ -127,6 +127,9 @@ def test_plan_lanes():
     assert [d(n) for n in (1, 128, 192, 193, 256, 257, 320, 384, 447, 448, 511, 512, 640, 704, 705, 768, 1536)] == \
         [1, 1, 2, 2, 2, 3, 3, 3, 3, 2, 2, 4, 4, 4, 2, 2, 2]
     assert d(512, 4) == 2 and d(640, 4) == 2 and plan_lanes(512, hw_queues=8, deferred=True) == (4, 0, 'parts')
+    # small boards on the two-launch step (Connect4: profiles/r04/small_boards_lanes.txt): two lanes above one round of boards
+    assert plan_lanes(512, hw_queues=8, cells=42) == (2, 0, 'parts') and plan_lanes(1024, hw_queues=8, cells=36) == (2, 0, 'parts')
+    assert plan_lanes(256, hw_queues=8, cells=42) == (1, 0, 'auto') and plan_lanes(512, hw_queues=8, cells=81) == (4, 0, 'parts')
 
 
 def test_hw_queues_are_claimed_on_import():

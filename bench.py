@@ -678,7 +678,7 @@ def main():
         small_trunk = (bool(args.deferred) and args.evaluator == 'hipnet' and args.net_algo in ('split_f16', 'split_f16_tiles')
                        and args.score_mode == 'uct_ref' and args.in_flight <= 1)
         lanes = plan_lanes((args.games if args.games > 0 else GAMES_PER_GPU) * max(1, args.in_flight), n_cus, deferred=will_defer,
-                           cells=cells if small_trunk else None)[0]
+                           cells=cells if (small_trunk or args.in_flight > 1) else None, in_flight=max(1, args.in_flight))[0]
     trunk_wgs = max(0, args.trunk_wgs)
     # default batch: the 512 games per GPU of BASELINE.json configs[3] (4096 games over 8 GPUs), as four lanes of 128
     G = args.games if args.games > 0 else GAMES_PER_GPU

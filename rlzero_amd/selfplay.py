@@ -132,7 +132,7 @@ class Trajectory(object):
 
 
 
-def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False, cells=None):
+def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False, cells=None, in_flight=1):
     """-> (lanes, trunk_workgroups, heads_algo) for ``n_games`` leaves per simulation step on a GPU with ``n_cus`` CUs and
     ``hw_queues`` hardware queues for its streams (default: what rlzero_amd claimed on import, rlzero_amd.HW_QUEUES).
 
@@ -149,6 +149,11 @@ def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False, cells=None):
     two-launch step with a 12-us trunk and a 10-us tree step) run TWO lanes above one round of boards (Connect4, M simulations / s on
     2 / 3 / 4 lanes: 384 games 14.2 / 13.8 / 13.1, 512 games 17.7 / 15.7 / 16.7, 768 games 20.2 / 20.4 / 20.0, 1024 games
     22.9 / 21.9 / 21.1 -- profiles/r04/small_boards_lanes.txt; 9x9 keeps the table below: 512 games 14.8 / 14.5 / 15.4).
+
+    ``in_flight`` = K > 1 (the opt-in virtual-loss mode; ``n_games`` = games x K leaves) on a board of at most 100 cells: the
+    three-launch step of short kernels wants MORE lanes than the 15x15 table below gives it (9x9, K = 16, M simulations / s on
+    1 / 2 / 3 / 4 lanes: 32 games 4.5 / 4.7 / 5.1 / 4.3, 64 games 6.8 / 7.4 / 7.9 / 8.1, 128 games 8.6 / 10.0 / 10.7 / 11.2; K = 8,
+    64 games 6.0 / 6.5 / 6.9 / 7.0): three lanes from two rounds of leaves, four from four rounds.
 
     The three-launch step (every other batch), measured on
     MI355X at 15x15 (profiles/r03/lane_sweeps.txt; a trunk workgroup takes a board in ~23 us, three in ~65 us):
@@ -170,8 +175,10 @@ def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False, cells=None):
     ones once the 'parts' GEMM existed)."""
     if hw_queues is None:
         from . import HW_QUEUES as hw_queues
-    if cells is not None and cells <= 42 and n_games > n_cus:
+    if cells is not None and cells <= 42 and n_games > n_cus and in_flight <= 1:
         return 2, 0, 'parts'
+    if cells is not None and cells <= 100 and in_flight > 1 and n_games >= 2 * n_cus:
+        return (4 if (n_games >= 4 * n_cus and hw_queues >= 8) else 3), 0, 'parts'
     if deferred:
         if n_games <= n_cus:   # one game per CU at most: the resident search (one launch per search, a workgroup per game) --
             # on TWO lanes from half a round of boards on, so that a lane's host step runs under the other lane's search
@@ -295,7 +302,8 @@ class BatchedSelfPlay(object):
                     and net_algo in (None, 'split_f16', 'split_f16_tiles', 'split_f16_fp8'))
         small_trunk = (K == 1 and deferred_priors is not False and engine_kw.get('score_mode', 'uct_ref') in ('uct_ref', 0)
                        and net_algo in (None, 'split_f16', 'split_f16_tiles'))   # (the two-launch step on a small board)
-        auto_lanes, auto_wgs, heads_algo = plan_lanes(n_games * K, n_cus, deferred=deferred, cells=rows0 * cols0 if small_trunk else None)
+        auto_lanes, auto_wgs, heads_algo = plan_lanes(n_games * K, n_cus, deferred=deferred,
+                                                      cells=rows0 * cols0 if (small_trunk or K > 1) else None, in_flight=K)
         if lanes is None:
             lanes, wgs = auto_lanes, auto_wgs
         else:

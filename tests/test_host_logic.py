@@ -130,6 +130,10 @@ def test_plan_lanes():
     # small boards on the two-launch step (Connect4: profiles/r04/small_boards_lanes.txt): two lanes above one round of boards
     assert plan_lanes(512, hw_queues=8, cells=42) == (2, 0, 'parts') and plan_lanes(1024, hw_queues=8, cells=36) == (2, 0, 'parts')
     assert plan_lanes(256, hw_queues=8, cells=42) == (1, 0, 'auto') and plan_lanes(512, hw_queues=8, cells=81) == (4, 0, 'parts')
+    # K simulations in flight on a small board (9x9, K = 16: profiles/r04/k_in_flight_lanes.txt): three lanes from two rounds of leaves, four from four
+    assert plan_lanes(512, hw_queues=8, cells=81, in_flight=16)[0] == 3 and plan_lanes(1024, hw_queues=8, cells=81, in_flight=16)[0] == 4
+    assert plan_lanes(1024, hw_queues=4, cells=81, in_flight=16)[0] == 3 and plan_lanes(256, hw_queues=8, cells=81, in_flight=16)[0] == 1
+    assert plan_lanes(2048, hw_queues=8, cells=225, in_flight=16)[0] == 2   # (15x15 keeps the table)
 
 
 def test_hw_queues_are_claimed_on_import():

@@ -447,7 +447,12 @@ int rz_net_trace_attach(rz_net *net, void *d_trace);   /* see rz_trace_attach */
  * a kernel boundary, the leaf handed from the tree code to the trunk through LDS.  For batches of at most one game per CU (the
  * single-game API, BASELINE configs[0] and [1]).  The deferred-priors route's arithmetic and bookkeeping: pair with
  * rz_select_step(engine, NULL, ..) before (the first leaf) and rz_net_deferred_gemm + rz_deferred_flush later; the engine's slots
- * advance by n_sims.  Same trees, values and priors as rz_net_trunk_leaves_deferred + rz_tree_step_deferred, bit for bit. */
+ * advance by n_sims.  Same trees, values and priors as rz_net_trunk_leaves_deferred + rz_tree_step_deferred, bit for bit.
+ * CONTRACT: game g's leaves go to store slots pend[g] .. pend[g] + n_sims - 1 (pend[g] = its steps since the last
+ * rz_deferred_flush), so pend[g] + n_sims must not exceed the slots of rz_net_deferred_reserve / rz_deferred_reserve: flush first.
+ * n_sims beyond either capacity is refused (RZ_ERR_ARG); a leaf whose slot still lies beyond the store (a caller that did not
+ * flush) is not written anywhere and its game is flagged RZ_FLAG_INTERNAL by the tree code -- never an out-of-bounds write.
+ * The same holds for rz_net_trunk_leaves_deferred (slot d_slot_of_board[b]). */
 int rz_net_search_resident(rz_net *net, rz_engine *engine, int32_t n_sims, void *stream);
 int rz_net_heads(rz_net *net, int32_t n_boards, float *d_logp, float *d_value, void *stream);
 /* only the FC GEMM of the heads on the internal features; returns the device pointers that

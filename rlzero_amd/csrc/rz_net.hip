@@ -906,6 +906,7 @@ struct DeferredOut {
     float *valfeat;
     int vf_ld;
     unsigned long long *trace;   // rz_trace.h (NULL: none)
+    int n_slots;                 // slots of the store: a leaf whose slot lies beyond it is NOT stored (the tree step flags the game)
 };
 
 // FC_HERE (small boards, TN = 1; `raw` / `hid` given): the workgroup also runs the first FC layers of both heads on ITS OWN
@@ -1334,10 +1335,11 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         const bool deferred = RES || later.slot_of != nullptr;   // (DeferredOut: the policy pieces wait in the store, the value inputs go on as f32)
         float *vdst = nullptr;
         if constexpr (RES) {   // the game's slot advances by one per simulation; the value inputs stay in LDS
-            dst16 = feat16 + (size_t)(res_slot0 + sim) * later.slot_halfs + (size_t)(board >> 5) * nd.groups_act * 1024 + (board & 31) * 16;
+            dst16 = res_slot0 + sim < later.n_slots ? feat16 + (size_t)(res_slot0 + sim) * later.slot_halfs + (size_t)(board >> 5) * nd.groups_act * 1024 + (board & 31) * 16 : nullptr;
             vdst = res_vrow;
         } else if (deferred) {
-            dst16 = feat16 + (size_t)later.slot_of[board] * later.slot_halfs + (size_t)(board >> 5) * nd.groups_act * 1024 + (board & 31) * 16;
+            const int slot_ = later.slot_of[board];   // (uniform; beyond the store: nothing is written, expand_backup_body<DEF> flags the game)
+            dst16 = slot_ < later.n_slots ? feat16 + (size_t)slot_ * later.slot_halfs + (size_t)(board >> 5) * nd.groups_act * 1024 + (board & 31) * 16 : nullptr;
             vdst = later.valfeat + (size_t)board * later.vf_ld;
         }
         // the six sums of the lane's position first (the other lane half's share by v_permlane32_swap, the biases in one
@@ -1990,10 +1992,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_t
         const bool deferred = RES || later.slot_of != nullptr;
         float *vdst = nullptr;
         if constexpr (RES) {   // the game's slot advances by one per simulation (expand_backup_body<DEF>); the value inputs stay in LDS
-            dst16 = feat16 + (size_t)(res_slot0 + sim) * later.slot_halfs + (size_t)(board >> 5) * nd.groups_act * 1024 + (board & 31) * 16;
+            dst16 = res_slot0 + sim < later.n_slots ? feat16 + (size_t)(res_slot0 + sim) * later.slot_halfs + (size_t)(board >> 5) * nd.groups_act * 1024 + (board & 31) * 16 : nullptr;
             vdst = res_vrow;
         } else if (deferred) {   // the policy pieces wait in the store (tiles of groups_act K-steps), the value inputs go on as f32
-            dst16 = feat16 + (size_t)later.slot_of[board] * later.slot_halfs + (size_t)(board >> 5) * nd.groups_act * 1024 + (board & 31) * 16;
+            const int slot_ = later.slot_of[board];   // (uniform; beyond the store: nothing is written, expand_backup_body<DEF> flags the game)
+            dst16 = slot_ < later.n_slots ? feat16 + (size_t)slot_ * later.slot_halfs + (size_t)(board >> 5) * nd.groups_act * 1024 + (board & 31) * 16 : nullptr;
             vdst = later.valfeat + (size_t)board * later.vf_ld;
         }
         if (tid < S) {
@@ -3294,7 +3297,7 @@ int rz_net_trunk_leaves_deferred(rz_net *net, const uint64_t *d_stones, const in
     if (n_boards > net->store_boards) return net_fail(RZ_ERR_ARG, "batch larger than rz_net_deferred_reserve()d");
     if (n_boards > 0) {
         if (!d_stones || !d_to_move || !d_last_cell || !d_slot_of_board) return net_fail(RZ_ERR_ARG, "NULL device pointer");
-        const DeferredOut later{d_slot_of_board, (long long)net->store_tiles * net->dev.groups_act * 1024, net->d_valfeat, net->vf_groups * 4, net->d_trace};
+        const DeferredOut later{d_slot_of_board, (long long)net->store_tiles * net->dev.groups_act * 1024, net->d_valfeat, net->vf_groups * 4, net->d_trace, net->store_slots};
         launch_trunk(net, nullptr, net->d_feat, n_boards, stream, LeafBits{d_stones, d_to_move, d_last_cell}, later);
         if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of the split-f16 trunk failed");
     }
@@ -3315,6 +3318,13 @@ int rz_net_search_resident(rz_net *net, rz_engine *engine, int32_t n_sims, void 
     if (rc != RZ_OK) return rc;
     if ((rc = net_ready(net, dev.n_games)) != RZ_OK) return rc;
     if (n_sims < 1) return net_fail(RZ_ERR_ARG, "rz_net_search_resident: n_sims must be positive");
+    // a game's leaves go to store slots pend[g] .. pend[g] + n_sims - 1: more simulations than either side has slots can never fit
+    // (and a leaf whose slot lies beyond the store is not written: the tree code flags its game RZ_FLAG_INTERNAL)
+    if (n_sims > net->store_slots || n_sims > dev.pend_cap) {
+        char detail[160];
+        snprintf(detail, sizeof(detail), ": %d simulations, %d / %d slots (rz_net_deferred_reserve / rz_deferred_reserve)", n_sims, net->store_slots, dev.pend_cap);
+        return net_fail(RZ_ERR_ARG, "rz_net_search_resident: more simulations than the store has slots", detail);
+    }
     const bool rows = net->algo == RZ_NET_SPLIT_F16 && rows_kernel_covers(net->dev.BH, net->dev.BW);
     const int tiles = (net->dev.BH + net->dev.tile_rows - 1) / net->dev.tile_rows;
     if (!deferred_trunk_covers(net) || (!rows && (tiles > 4 || net->dev.BH > 10 || net->dev.BW > 10)))
@@ -3336,7 +3346,7 @@ int rz_net_search_resident(rz_net *net, rz_engine *engine, int32_t n_sims, void 
     res.vh.ld = net->vf_groups * 4;
     res.vh.groups = net->vf_groups;
     res.n_sims = n_sims;
-    const DeferredOut later{dev.pend, (long long)net->store_tiles * net->dev.groups_act * 1024, nullptr, 0, nullptr};
+    const DeferredOut later{dev.pend, (long long)net->store_tiles * net->dev.groups_act * 1024, nullptr, 0, nullptr, net->store_slots};
     const LeafBits leaves{dev.leaf_stones, dev.leaf_to_move, dev.leaf_last};
     const dim3 grid((unsigned)dev.n_games);
     const hipStream_t st = (hipStream_t)stream;

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 23
+#define RZ_ABI_VERSION 24
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 #define RZ_MAX_IN_FLIGHT 16 /* rz_config.sims_in_flight */
@@ -316,6 +316,67 @@ int rz_advance_roots(rz_engine *e, const int32_t *d_moves, void *stream);
  * d_moves[g] < 0 = no move.  d_winner: player id or -1 (tie / not ended); d_ended 0/1. */
 int rz_step_games(rz_engine *e, const int32_t *d_moves, int32_t *d_winner, uint8_t *d_ended,
                   void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * THE MOVE STEP ON THE DEVICE.  What the self-play loop does between two searches -- AlphaZeroMCTS.simulate's read-out of the
+ * root visits (alphazero_mcts.py:88-90), AlphaZeroPlayer.get_action's draw (:147-148), update_with_move (:96-103), env.step +
+ * game_end_winner (game.py:109-118), reset_player at the end of a game (:128) and the start of the next one -- for every game
+ * of the engine, enqueued on the stream with NO host round trip: the host keeps whole moves enqueued ahead and reads what
+ * happened from a log, a move or more behind.
+ *
+ * The draw.  numpy.random.choice(acts, p=probs) of the reference is acts[searchsorted(cumsum(p) / cumsum(p)[-1], u, 'right')]
+ * with p = softmax(log(N + 1e-10) / T) (alphazero_mcts.py:10-14,91-92).  The device evaluates the same expression in fp64 with
+ * ITS log / exp (numpy's are not reproducible on another machine, let alone a GPU) on the uniform u = the counter-based
+ * uniform of (seed, game id, ply) (rlzero_amd/selfplay.py: move_uniform -- integer arithmetic, the same bits) and draws the move
+ * ONLY when u lies farther than stall_margin (relative to the total) from both edges of the chosen interval: rounding differences
+ * between the two evaluations are ~1e-14, so the host's numpy expression on the logged visit counts -- the arbiter -- picks the
+ * same move.  Otherwise the game STALLS: no move, the slot is skipped by the coming searches, and the host, reading the log,
+ * decides with numpy and hands the move back (rz_play_resolve).  pi itself is never computed on the device: the host forms it
+ * from the logged counts with the reference's expression (and verifies every move the device drew).
+ *
+ * The log: int32 [ring_steps][n_games][RZ_PLAY_RECORD_WORDS + A]; the record of move step s (counted per engine from
+ * rz_play_attach) and slot g is row s % ring_steps.  Words: [0..1] game id (int64), [2] ply before the move, [3] the move (action)
+ * or -1, [4] RZ_PLAY_* flags | (winner + 1) << 16, [5] N(root), [6] float bits of the draw's distance to the nearer interval edge
+ * (relative), [7] reserved; then per action the visit count of the root child, -1 for an illegal action.  The host must read a
+ * row before ring_steps more moves overwrite it.
+ *
+ * Slots refill themselves: a slot whose game has ended (or that is idle) takes the next entry of a queue of game ids shared by
+ * the engines (lanes) of a GPU -- d_queue_ids int64 [..], d_queue_ctl int32 [2] = {head, entries valid}; the device advances
+ * head atomically, the host may append ids and then raise the count -- and starts that game: empty board, player 0 to move, a
+ * fresh tree, its Dirichlet stream keyed (seed, game id) exactly as rlzero_amd.selfplay keys it. */
+#define RZ_PLAY_RECORD_WORDS 8
+enum {
+    RZ_PLAY_RUNNING = 1,   /* the slot holds a game: the visit counts are valid */
+    RZ_PLAY_STALLED = 2,   /* no move drawn (u too close to an interval edge): waiting for rz_play_resolve */
+    RZ_PLAY_RESOLVED = 4,  /* the move came from rz_play_resolve */
+    RZ_PLAY_ENDED = 8,     /* the game ended with this move; winner + 1 in bits 16.. (0: tie) */
+    RZ_PLAY_SEARCHED = 16  /* the slot took part in the search before this move step (n_playout simulations) */
+};
+typedef struct rz_play_config {
+    uint64_t seed;         /* move uniforms keyed (seed, game id, ply), Dirichlet streams keyed (seed, game id) */
+    double temperature;    /* T of softmax(log(N + 1e-10) / T) */
+    double stall_margin;   /* 0 -> 1e-10 * max(1, 1 / T); a test hook otherwise (0.05 stalls one draw in ten) */
+    const int64_t *d_queue_ids;
+    int32_t *d_queue_ctl;
+    int32_t *d_log;
+    int32_t ring_steps;
+    int32_t reserved;
+} rz_play_config;
+/* Attach (allocates the per-slot state on first use; every slot idle, inactive, with a fresh tree; move step counter 0). */
+int rz_play_attach(rz_engine *e, const rz_play_config *cfg);
+/* After the search of a move, BEFORE rz_deferred_flush: read the root visits into the log, draw (or stall, or take a resolved
+ * move).  One launch. */
+int rz_play_draw(rz_engine *e, void *stream);
+/* Then: rz_advance_roots + rz_step_games with the moves just drawn, the end of finished games and the refill of idle slots
+ * (rz_play_apply without a draw before it only refills: how a run starts).  Three launches. */
+int rz_play_apply(rz_engine *e, void *stream);
+/* The host's decision for a stalled slot (one tiny launch); taken by the next rz_play_draw. */
+int rz_play_resolve(rz_engine *e, int32_t slot, int32_t move, void *stream);
+/* Drop every game: all slots idle with fresh trees (a run that stops early). */
+int rz_play_stop(rz_engine *e, void *stream);
+/* Host copies of the per-slot state for inspection (synchronous): game ids int64 [n_games] (-1: idle), plies int32, states
+ * int32 (0 idle, 1 running, 2 stalled), and the move steps done so far. */
+int rz_play_state(rz_engine *e, int64_t *h_game_id, int32_t *h_ply, int32_t *h_state, int64_t *h_steps);
 
 /* Synchronises `stream`-independent state: waits for the device, then reports flags. */
 int rz_get_stats(rz_engine *e, rz_stats *out);

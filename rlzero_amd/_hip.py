@@ -8,7 +8,7 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64,
                     c_void_p)
 
-ABI_VERSION = 23
+ABI_VERSION = 24
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
 MAX_IN_FLIGHT = 16
@@ -73,6 +73,16 @@ class RzDeferredLogits(Structure):
     _fields_ = [('raw', c_void_p), ('ld', c_int32), ('rows_per_slot', c_int32)]
 
 
+class RzPlayConfig(Structure):
+    """rz_play_config: the move step on the device (uniform / noise seed, temperature, the shared queue of game ids, the log)."""
+    _fields_ = [('seed', c_uint64), ('temperature', c_double), ('stall_margin', c_double), ('d_queue_ids', c_void_p),
+                ('d_queue_ctl', c_void_p), ('d_log', c_void_p), ('ring_steps', c_int32), ('reserved', c_int32)]
+
+
+PLAY_RECORD_WORDS = 8
+PLAY_RUNNING, PLAY_STALLED, PLAY_RESOLVED, PLAY_ENDED, PLAY_SEARCHED = 1, 2, 4, 8, 16
+
+
 class HipError(RuntimeError):
     pass
 
@@ -119,6 +129,12 @@ _SIGNATURES = {
     'rz_root_stats': (c_int, [P, P, P, P]),
     'rz_advance_roots': (c_int, [P, P, P]),
     'rz_step_games': (c_int, [P, P, P, P, P]),
+    'rz_play_attach': (c_int, [P, POINTER(RzPlayConfig)]),
+    'rz_play_draw': (c_int, [P, P]),
+    'rz_play_apply': (c_int, [P, P]),
+    'rz_play_resolve': (c_int, [P, c_int32, c_int32, P]),
+    'rz_play_stop': (c_int, [P, P]),
+    'rz_play_state': (c_int, [P, P, P, P, POINTER(c_int64)]),
     'rz_get_stats': (c_int, [P, POINTER(RzStats)]),
     'rz_clear_errors': (c_int, [P]),
     'rz_copy_arena': (c_int, [P, c_int32, c_int64, P, P, P, P, P, P, P, P]),

@@ -1088,6 +1088,212 @@ __global__ void k_uct_scores(const double *w, const int32_t *n, const int32_t *n
     out[i] = uct_ref(w[i], n[i], logtab[pn], c);
 }
 
+// ------------------------------------------------------------------ the move step on the device (include/rlzero_hip.h: rz_play_*)
+struct Play {
+    int64_t *game_id;          // [G] -1: idle
+    int32_t *ply, *state;      // state: 0 idle, 1 running, 2 stalled
+    int32_t *mailbox;          // [G] the host's move for a stalled slot, -1: none
+    int32_t *keep, *stepm;     // [G] the moves of this step for k_advance / k_step_games
+    int32_t *winner;
+    uint8_t *ended;
+    int32_t *step_ab;          // [2]: k_play_draw reads [0] and writes [1], k_play_after reads [1] and writes [0] = [1] + 1
+    const int64_t *queue_ids;
+    int32_t *queue_ctl;        // [0] head, [1] entries valid
+    int32_t *log;
+    int ring, words;
+    uint64_t seed;
+    double inv_t, margin;
+};
+enum { kPlayIdle = 0, kPlayRunning = 1, kPlayStalled = 2 };
+
+// rlzero_amd/selfplay.py: move_uniform(seed, game id, ply) -- 53 high bits of a splitmix64 chain: the same bits
+__device__ __forceinline__ double play_uniform(uint64_t seed, uint64_t game, uint64_t ply) {
+    uint64_t x = mix64(seed);
+    x = mix64(x ^ game);
+    x = mix64(x ^ ply);
+    return (double)(x >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// One wave per slot: the root's visit counts into the log, then the draw of alphazero_mcts.py:88-92,147-148 in fp64 -- taken only
+// when the uniform lies farther than `margin` from both edges of its interval (the host's numpy evaluation is the arbiter).
+__global__ __launch_bounds__(kWave) void k_play_draw(Dev E, Play Y) {
+    __shared__ double sh_e[kWave * kWords];
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int step = Y.step_ab[0];
+    if (g == 0 && lane == 0) Y.step_ab[1] = step;
+    int32_t *rec = Y.log + ((long long)(step % Y.ring) * E.n_games + g) * Y.words;
+    const int state = Y.state[g];
+    if (state == kPlayIdle) {
+        if (lane == 0) {
+            rec[4] = 0;
+            Y.keep[g] = -2;
+            Y.stepm[g] = -1;
+        }
+        return;
+    }
+    // the root's children by action (k_root_children)
+    const int arena = E.cur_arena[g];
+    const int4 *R = arena_records(E, g, arena);
+    uint64_t st[2][kWords], occ[kWords];
+    load_board(E.root_stones, g, st);
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) occ[j] = st[0][j] | st[1][j];
+    const Legal L = legal_of(E, occ, lane);
+    const int4 lo = R[0];
+    const bool expanded = rec_k(lo) > 0;
+    const int fc = lo.y;
+    const int nv = expanded ? lo.z : 0;
+    int before = 0;
+    int cnt[kWords];
+    bool legal[kWords];
+    double x[kWords];
+    double mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) {
+        const int r = lane_action_rank(E, occ, L, j, lane, before);
+        const int a = 64 * j + lane;
+        legal[j] = a < E.A && r >= 0;
+        cnt[j] = (legal[j] && r < nv) ? R[2 * (fc + r)].x : 0;
+        if (a < E.A) rec[RZ_PLAY_RECORD_WORDS + a] = legal[j] ? cnt[j] : -1;
+        x[j] = legal[j] ? Y.inv_t * log((double)cnt[j] + 1e-10) : -INFINITY;   // alphazero_mcts.py:91
+        mx = fmax(mx, x[j]);
+    }
+    const int64_t gid = Y.game_id[g];
+    const int ply = Y.ply[g];
+    if (lane == 0) {
+        rec[0] = (int32_t)(uint32_t)(uint64_t)gid;
+        rec[1] = (int32_t)((uint64_t)gid >> 32);
+        rec[2] = ply;
+        rec[5] = lo.x;
+        rec[7] = 0;
+    }
+    if (state == kPlayStalled) {
+        const int mv = Y.mailbox[g];
+        if (lane == 0) {
+            if (mv >= 0) {   // the host has decided (rz_play_resolve)
+                rec[3] = mv;
+                rec[4] = RZ_PLAY_RUNNING | RZ_PLAY_RESOLVED;
+                rec[6] = 0;
+                Y.mailbox[g] = -1;
+                Y.state[g] = kPlayRunning;
+                Y.ply[g] = ply + 1;
+                E.active[g] = 1;
+                Y.keep[g] = mv;
+                Y.stepm[g] = mv;
+            } else {
+                rec[3] = -1;
+                rec[4] = RZ_PLAY_RUNNING | RZ_PLAY_STALLED;
+                rec[6] = 0;
+                Y.keep[g] = -2;
+                Y.stepm[g] = -1;
+            }
+        }
+        return;
+    }
+    // wave maximum of x (doubles: two 32-bit halves through the shuffle)
+    for (int off = 32; off >= 1; off >>= 1) mx = fmax(mx, __shfl_xor(mx, off));
+#pragma unroll
+    for (int j = 0; j < kWords; ++j) sh_e[64 * j + lane] = legal[j] ? exp(x[j] - mx) : 0.0;   // :12
+    __syncthreads();
+    if (lane == 0) {
+        // cumsum in action order (numpy's cumsum is sequential too), then the first interval whose upper edge exceeds u x total
+        double total = 0.0;
+        for (int a = 0; a < E.A; ++a) total += sh_e[a];
+        const double u = play_uniform(Y.seed, (uint64_t)gid, (uint64_t)ply);
+        const double target = u * total;
+        double c = 0.0, below = 0.0;
+        int chosen = -1;
+        for (int a = 0; a < E.A; ++a) {
+            const double e = sh_e[a];
+            if (e > 0.0 && c + e > target) {
+                chosen = a;
+                below = c;
+                c += e;
+                break;
+            }
+            c += e;
+        }
+        double rel = 0.0;
+        if (chosen >= 0) rel = fmin(target - below, c - target) / total;
+        const bool ok = chosen >= 0 && total > 0.0 && rel > Y.margin;
+        rec[6] = __float_as_int((float)rel);
+        if (ok) {
+            rec[3] = chosen;
+            rec[4] = RZ_PLAY_RUNNING | RZ_PLAY_SEARCHED;
+            Y.ply[g] = ply + 1;
+            Y.keep[g] = chosen;
+            Y.stepm[g] = chosen;
+        } else {
+            rec[3] = -1;
+            rec[4] = RZ_PLAY_RUNNING | RZ_PLAY_SEARCHED | RZ_PLAY_STALLED;
+            Y.state[g] = kPlayStalled;
+            E.active[g] = 0;   // the coming searches skip the slot until the host has decided
+            Y.keep[g] = -2;
+            Y.stepm[g] = -1;
+        }
+    }
+}
+
+// Behind k_advance + k_step_games of the move: the end of finished games (reset_player, game.py:128) and the refill of idle slots
+// from the queue of game ids (GomokuEnv.reset, gomoku_env.py:33-47: empty board, player 0; a fresh tree; the game's noise key).
+__global__ void k_play_after(Dev E, Play Y) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    const int step = Y.step_ab[1];
+    if (g == 0) Y.step_ab[0] = step + 1;
+    if (g >= E.n_games) return;
+    int state = Y.state[g];
+    if (state == kPlayRunning && Y.stepm[g] >= 0 && Y.ended[g]) {
+        int32_t *rec = Y.log + ((long long)(step % Y.ring) * E.n_games + g) * Y.words;
+        rec[4] |= RZ_PLAY_ENDED | ((Y.winner[g] + 1) << 16);
+        state = kPlayIdle;
+        Y.state[g] = state;
+        Y.game_id[g] = -1;
+        E.active[g] = 0;
+        fresh_root(E, g, E.cur_arena[g], 0);
+    }
+    Y.stepm[g] = -1;   // (an rz_play_apply without a draw before it applies nothing)
+    Y.keep[g] = -2;
+    if (state != kPlayIdle) return;
+    int head = Y.queue_ctl[0];
+    int64_t gid = -1;
+    while (head < Y.queue_ctl[1]) {
+        const int seen = atomicCAS(&Y.queue_ctl[0], head, head + 1);
+        if (seen == head) {
+            gid = Y.queue_ids[head];
+            break;
+        }
+        head = seen;
+    }
+    if (gid < 0) return;
+    Y.game_id[g] = gid;
+    Y.ply[g] = 0;
+    Y.state[g] = kPlayRunning;
+    Y.mailbox[g] = -1;
+    for (int j = 0; j < 2 * kWords; ++j) E.root_stones[(long long)g * 2 * kWords + j] = 0ull;
+    E.root_to_move[g] = 0;
+    E.root_last[g] = -1;
+    fresh_root(E, g, E.cur_arena[g], 0);
+    E.noise_key[g] = mix64(mix64(Y.seed ^ 0x6E6F697365000000ull) ^ (uint64_t)gid);   // rlzero_amd/selfplay.py: _start
+    E.noise_ctr[g] = 0;
+    E.active[g] = 1;
+}
+
+__global__ void k_play_resolve(Play Y, int slot, int move) { Y.mailbox[slot] = move; }
+__global__ void k_play_no_draw(Play Y) { Y.step_ab[1] = Y.step_ab[0]; }   // rz_play_apply without a draw: the step of k_play_after
+
+__global__ void k_play_stop(Dev E, Play Y) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= E.n_games) return;
+    Y.state[g] = kPlayIdle;
+    Y.game_id[g] = -1;
+    Y.mailbox[g] = -1;
+    Y.keep[g] = -2;
+    Y.stepm[g] = -1;
+    E.active[g] = 0;
+    fresh_root(E, g, E.cur_arena[g], 0);
+}
+
 thread_local char g_err[512] = "";
 
 int fail(int code, const char *fmt, ...) {
@@ -1121,6 +1327,9 @@ struct rz_engine {
     bool ml = false;     // sims_in_flight > 1: the level-synchronous kernel (default) instead of the sequential restatement
     int ml_lds = 0;
     double *d_logtab = nullptr;
+    Play play = {};      // rz_play_attach
+    bool play_on = false, play_drawn = false;
+    long long play_steps = 0;   // move steps enqueued (rz_play_apply calls) since rz_play_attach
 };
 
 namespace {
@@ -1702,6 +1911,105 @@ int rz_step_games(rz_engine *e, const int32_t *d_moves, int32_t *d_winner, uint8
     RZ_NEED(d_moves);
     k_step_games<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, d_moves, d_winner, d_ended);
     return launched("k_step_games");
+}
+
+// ------------------------------------------------------------------ the move step on the device
+int rz_play_attach(rz_engine *e, const rz_play_config *cfg) {
+    int rc = check_engine(e);
+    if (rc != RZ_OK) return rc;
+    RZ_NEED(cfg);
+    if (e->dev.K != 1) return fail(RZ_ERR_ARG, "rz_play_attach: one simulation in flight per tree only");
+    if (!cfg->d_queue_ids || !cfg->d_queue_ctl || !cfg->d_log || cfg->ring_steps < 2) return fail(RZ_ERR_ARG, "rz_play_attach: queue, log and a ring of >= 2 steps are needed");
+    if (!(cfg->temperature > 0.0)) return fail(RZ_ERR_ARG, "rz_play_attach: temperature must be positive");
+    if (cfg->stall_margin < 0.0 || cfg->stall_margin >= 0.5) return fail(RZ_ERR_ARG, "rz_play_attach: stall_margin not in [0, 0.5)");
+    RZ_HIP(hipDeviceSynchronize());
+    Play &Y = e->play;
+    const long long G = e->cfg.n_games;
+    if (Y.game_id == nullptr) {
+        memset(&Y, 0, sizeof(Y));
+        if ((rc = dev_alloc(e, &Y.game_id, G)) != RZ_OK) return rc;
+        if ((rc = dev_alloc(e, &Y.ply, G)) != RZ_OK) return rc;
+        if ((rc = dev_alloc(e, &Y.state, G)) != RZ_OK) return rc;
+        if ((rc = dev_alloc(e, &Y.mailbox, G)) != RZ_OK) return rc;
+        if ((rc = dev_alloc(e, &Y.keep, G)) != RZ_OK) return rc;
+        if ((rc = dev_alloc(e, &Y.stepm, G)) != RZ_OK) return rc;
+        if ((rc = dev_alloc(e, &Y.winner, G)) != RZ_OK) return rc;
+        if ((rc = dev_alloc(e, &Y.ended, G)) != RZ_OK) return rc;
+        if ((rc = dev_alloc(e, &Y.step_ab, 2)) != RZ_OK) return rc;
+    }
+    Y.queue_ids = cfg->d_queue_ids;
+    Y.queue_ctl = cfg->d_queue_ctl;
+    Y.log = cfg->d_log;
+    Y.ring = cfg->ring_steps;
+    Y.words = RZ_PLAY_RECORD_WORDS + e->dev.A;
+    Y.seed = cfg->seed;
+    Y.inv_t = 1.0 / cfg->temperature;
+    Y.margin = cfg->stall_margin > 0.0 ? cfg->stall_margin : 1e-10 * (Y.inv_t > 1.0 ? Y.inv_t : 1.0);
+    RZ_HIP(hipMemset(Y.step_ab, 0, 8));
+    RZ_HIP(hipMemset(Y.ply, 0, (size_t)G * 4));
+    RZ_HIP(hipMemset(Y.winner, 0xff, (size_t)G * 4));
+    RZ_HIP(hipMemset(Y.ended, 0, (size_t)G));
+    k_play_stop<<<flat_grid(e), dim3(256), 0, 0>>>(e->dev, Y);
+    RZ_HIP(hipDeviceSynchronize());
+    e->play_on = true;
+    e->play_drawn = false;
+    e->play_steps = 0;
+    return RZ_OK;
+}
+
+int rz_play_draw(rz_engine *e, void *stream) {
+    RZ_ENTER(e);
+    if (!e->play_on) return fail(RZ_ERR_ARG, "call rz_play_attach first");
+    k_play_draw<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, e->play);
+    e->play_drawn = true;
+    return launched("k_play_draw");
+}
+
+int rz_play_apply(rz_engine *e, void *stream) {
+    RZ_ENTER(e);
+    if (!e->play_on) return fail(RZ_ERR_ARG, "call rz_play_attach first");
+    const Play &Y = e->play;
+    if (e->play_drawn) {
+        k_advance<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, Y.keep);   // tree reuse before the boards change
+        k_step_games<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, Y.stepm, Y.winner, Y.ended);
+    } else {
+        k_play_no_draw<<<dim3(1), dim3(1), 0, as_stream(stream)>>>(Y);   // no moves to apply: only the refill of idle slots
+    }
+    e->play_drawn = false;
+    k_play_after<<<flat_grid(e), dim3(256), 0, as_stream(stream)>>>(e->dev, Y);
+    e->play_steps += 1;
+    return launched("k_play_after");
+}
+
+int rz_play_resolve(rz_engine *e, int32_t slot, int32_t move, void *stream) {
+    RZ_ENTER(e);
+    if (!e->play_on) return fail(RZ_ERR_ARG, "call rz_play_attach first");
+    if (slot < 0 || slot >= e->cfg.n_games || move < 0 || move >= e->dev.A) return fail(RZ_ERR_ARG, "rz_play_resolve: slot %d / move %d out of range", slot, move);
+    k_play_resolve<<<dim3(1), dim3(1), 0, as_stream(stream)>>>(e->play, slot, move);
+    return launched("k_play_resolve");
+}
+
+int rz_play_stop(rz_engine *e, void *stream) {
+    RZ_ENTER(e);
+    if (!e->play_on) return fail(RZ_ERR_ARG, "call rz_play_attach first");
+    k_play_stop<<<flat_grid(e), dim3(256), 0, as_stream(stream)>>>(e->dev, e->play);
+    return launched("k_play_stop");
+}
+
+int rz_play_state(rz_engine *e, int64_t *h_game_id, int32_t *h_ply, int32_t *h_state, int64_t *h_steps) {
+    RZ_ENTER(e);
+    if (!e->play_on) return fail(RZ_ERR_ARG, "call rz_play_attach first");
+    RZ_HIP(hipDeviceSynchronize());
+    const size_t G = (size_t)e->cfg.n_games;
+    if (h_game_id) RZ_HIP(hipMemcpy(h_game_id, e->play.game_id, G * 8, hipMemcpyDeviceToHost));
+    if (h_ply) RZ_HIP(hipMemcpy(h_ply, e->play.ply, G * 4, hipMemcpyDeviceToHost));
+    if (h_state) RZ_HIP(hipMemcpy(h_state, e->play.state, G * 4, hipMemcpyDeviceToHost));
+    if (h_steps) {
+        int32_t ab[2] = {0, 0};
+        RZ_HIP(hipMemcpy(ab, e->play.step_ab, 8, hipMemcpyDeviceToHost));
+        *h_steps = ab[0];
+    }
+    return RZ_OK;
 }
 
 int rz_get_stats(rz_engine *e, rz_stats *out) {

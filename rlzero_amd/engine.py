@@ -882,6 +882,60 @@ class MCTSEngine(object):
                                      _ptr(self.ended), self.stream()), 'rz_step_games')
         return self.winner.cpu().numpy(), self.ended.cpu().numpy()
 
+    # ------------------------------------------------------------------ the move step on the device
+    def play_attach(self, seed, temperature, queue_ids, queue_ctl, ring_steps=64, stall_margin=0.0):
+        """Hand the move step to the device (include/rlzero_hip.h: rz_play_*): ``queue_ids`` int64 / ``queue_ctl`` int32 [2] device
+        tensors (the queue of game ids, shared by the lanes of a GPU).  Allocates this engine's log ring -> the tensor
+        [ring_steps][n_games][8 + A] int32.  Every slot starts idle; ``play_apply()`` fills them from the queue."""
+        t = self.torch
+        self.flush_deferred()
+        t.cuda.synchronize(self.device)
+        self.play_log = t.zeros((int(ring_steps), self.n_games, _hip.PLAY_RECORD_WORDS + self.n_actions), dtype=t.int32, device=self.device)
+        self._play_queue = (queue_ids, queue_ctl)   # (kept alive: the engine holds their addresses)
+        cfg = _hip.RzPlayConfig(seed=int(seed) & 0xFFFFFFFFFFFFFFFF, temperature=float(temperature), stall_margin=float(stall_margin),
+                                d_queue_ids=queue_ids.data_ptr(), d_queue_ctl=queue_ctl.data_ptr(), d_log=self.play_log.data_ptr(),
+                                ring_steps=int(ring_steps), reserved=0)
+        check(self.lib.rz_play_attach(self.handle, ctypes.byref(cfg)), 'rz_play_attach')
+        self.play_steps = 0
+        self.active_host[:] = 0
+        return self.play_log
+
+    def play_move(self):
+        """The move step behind a search, enqueued on the current stream without a host round trip: the draw (rz_play_draw: visits
+        into the log, the move of alphazero_mcts.py:147-148 or a stall), the priors of the search's expansions (they must be written
+        before the kept subtree is copied), tree reuse + game step + the end / refill of slots (rz_play_apply).  -> the log row."""
+        st = self.stream()
+        check(self.lib.rz_play_draw(self.handle, st), 'rz_play_draw')
+        self.flush_deferred()
+        check(self.lib.rz_play_apply(self.handle, st), 'rz_play_apply')
+        row = self.play_steps % self.play_log.shape[0]
+        self.play_steps += 1
+        return row
+
+    def play_refill(self):
+        """rz_play_apply alone: idle slots take games from the queue (the start of a run).  Counts as a move step whose log row
+        holds nothing to read (no draw has written it)."""
+        self.flush_deferred()
+        check(self.lib.rz_play_apply(self.handle, self.stream()), 'rz_play_apply')
+        self.play_steps += 1
+
+    def play_resolve(self, slot, move):
+        check(self.lib.rz_play_resolve(self.handle, int(slot), int(move), self.stream()), 'rz_play_resolve')
+
+    def play_stop(self):
+        self.flush_deferred()
+        check(self.lib.rz_play_stop(self.handle, self.stream()), 'rz_play_stop')
+
+    def play_state(self):
+        """-> (game ids int64 [G] (-1 idle), plies, states (0 idle / 1 running / 2 stalled), move steps done); synchronises."""
+        gid = np.zeros(self.n_games, np.int64)
+        ply = np.zeros(self.n_games, np.int32)
+        state = np.zeros(self.n_games, np.int32)
+        steps = ctypes.c_int64(0)
+        check(self.lib.rz_play_state(self.handle, ctypes.c_void_p(gid.ctypes.data), ctypes.c_void_p(ply.ctypes.data),
+                                     ctypes.c_void_p(state.ctypes.data), ctypes.byref(steps)), 'rz_play_state')
+        return gid, ply, state, steps.value
+
     # ------------------------------------------------------------------ inspection
     def arena(self, game=0):
         """Host snapshot of one game's tree.  Per node record (slot): N, W, FC (slot of the first child

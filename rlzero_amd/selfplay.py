@@ -618,6 +618,187 @@ class BatchedSelfPlay(object):
         return sorted(out, key=lambda t: t.game_id)
 
 
+    # -- the move step on the device (include/rlzero_hip.h: rz_play_*) -----------------------------------------------
+    # The host enqueues whole moves -- search, draw, priors, tree reuse, game step, end / refill of slots -- and never waits for
+    # one: what happened comes back through each lane's log, read `depth` moves behind.  pi is formed HERE, from the logged visit
+    # counts with the reference's numpy expression (alphazero_mcts.py:10-14,91-92), and every move the device drew is checked
+    # against numpy's inverse-CDF draw on the same uniform (a mismatch raises; a draw too close to an interval edge was never
+    # made by the device: the slot stalls until the move computed here is handed back).  Same trajectories as play_move().
+    def device_attach(self, queue_capacity=1 << 16, ring_steps=32, depth=3, stall_margin=0.0):
+        """Switch this object to device-driven moves.  ``depth``: moves a lane may be enqueued ahead of the rows read back."""
+        t = self.torch
+        from ._hip import PLAY_RECORD_WORDS
+        dev = self.eng.device
+        if getattr(self, '_dev_on', False):
+            self.device_stop()
+        self._attach_kw = dict(ring_steps=ring_steps, depth=depth, stall_margin=stall_margin)
+        t.cuda.synchronize(dev)
+        self._queue_ids = t.zeros(int(queue_capacity), dtype=t.int64, device=dev)
+        self._queue_ctl = t.zeros(2, dtype=t.int32, device=dev)
+        self._queue_len, self._started, self._depth = 0, 0, max(1, min(int(depth), int(ring_steps) - 2))
+        words = PLAY_RECORD_WORDS + self.eng.n_actions
+        for lane in self.lanes:
+            with self._on(lane):
+                lane.eng.play_attach(self.seed, self.temperature, self._queue_ids, self._queue_ctl, ring_steps=ring_steps,
+                                     stall_margin=stall_margin)
+            lane.host_log = t.empty((int(ring_steps), lane.eng.n_games, words), dtype=t.int32, pin_memory=True)
+            lane.host_np = lane.host_log.numpy()
+            lane.inflight = []          # [(row, event)] oldest first
+            lane.last_running = -1      # RUNNING records in the last row read (-1: none read yet)
+            lane.primed = False
+        self._stalls = {}               # slot -> (game id, ply, pi, move): decided here, waiting for the device to take it
+        self.stalls_resolved = 0
+        self.slot_game[:] = -1
+        self._dev_on = True
+        t.cuda.synchronize(dev)
+
+    def device_queue(self, game_ids):
+        """Replace the queue of waiting game ids (synchronises: not for the middle of a run) and let idle slots take from it."""
+        t = self.torch
+        ids = np.ascontiguousarray(list(game_ids), dtype=np.int64)
+        if ids.size > self._queue_ids.numel():
+            raise ValueError('%d game ids for a queue of %d: device_attach(queue_capacity=...)' % (ids.size, self._queue_ids.numel()))
+        t.cuda.synchronize(self.eng.device)
+        self._queue_ids[:ids.size].copy_(t.from_numpy(ids))
+        self._queue_ctl.copy_(t.tensor([0, ids.size], dtype=t.int32))
+        t.cuda.synchronize(self.eng.device)
+        self._queue_len, self._started = int(ids.size), 0
+        for lane in self.lanes:
+            with self._on(lane):
+                lane.eng.play_refill()
+            lane.last_running = -1
+
+    def _lane_quiet(self, lane):
+        """Nothing left to do on this lane, as far as the rows read so far can tell (the host's view lags the device by design)."""
+        return not lane.inflight and lane.last_running == 0 and self._started >= self._queue_len
+
+    def play_move_device(self):
+        """Enqueue ONE more move of every lane that may still have games and read the rows that have arrived (at most ``depth``
+        moves stay unread per lane) -> the trajectories of the games found finished in them."""
+        for lane in self.lanes:
+            if self._lane_quiet(lane):
+                continue
+            self._simulate_lane(lane)
+            with self._on(lane):
+                row = lane.eng.play_move()
+                lane.host_log[row].copy_(lane.eng.play_log[row], non_blocking=True)
+                ev = self.torch.cuda.Event()
+                ev.record(lane.stream)
+            lane.inflight.append((row, ev))
+        done = []
+        for lane in self.lanes:
+            done.extend(self._harvest(lane, keep=self._depth))
+        return done
+
+    def device_drain(self):
+        """Wait for every enqueued move and read its row -> the finished trajectories found."""
+        done = []
+        for lane in self.lanes:
+            done.extend(self._harvest(lane, keep=0))
+        return done
+
+    def _harvest(self, lane, keep):
+        from ._hip import PLAY_ENDED, PLAY_RECORD_WORDS, PLAY_RESOLVED, PLAY_RUNNING, PLAY_SEARCHED, PLAY_STALLED, HipError
+        rows = []
+        while lane.inflight and (len(lane.inflight) > keep or lane.inflight[0][1].query()):
+            row, ev = lane.inflight.pop(0)
+            ev.synchronize()
+            rows.append(row)
+        if not rows:
+            return []
+        eng, lo, W0 = lane.eng, lane.slots.start, PLAY_RECORD_WORDS
+        G = eng.n_games
+        rec = lane.host_np[rows].reshape(len(rows) * G, -1)   # (a copy: the pinned rows may be overwritten from now on)
+        flags = rec[:, 4] & 0xFFFF
+        lane.last_running = int(((flags[-G:] & PLAY_RUNNING) != 0).sum())
+        idx = np.nonzero(flags & PLAY_RUNNING)[0]
+        if idx.size == 0:
+            return []
+        rec, flags = rec[idx], flags[idx]
+        slots = lo + idx % G
+        gids = rec[:, 0].astype(np.uint32).astype(np.int64) | (rec[:, 1].astype(np.int64) << 32)
+        plies, moves = rec[:, 2].astype(np.int64), rec[:, 3]
+        visits = rec[:, W0:]
+        legal = visits >= 0
+        # the reference's expression on the logged counts; the draw with the game's uniform (numpy's inverse-CDF rule): the arbiter
+        pis, chosen = batch_pi_and_moves(np.where(legal, visits, 0), legal, self.temperature, move_uniform(self.seed, gids, plies))
+        plain = (flags & (PLAY_STALLED | PLAY_RESOLVED)) == 0
+        if (chosen[plain] != moves[plain]).any():
+            bad = np.nonzero(plain & (chosen != moves))[0][0]
+            raise HipError('the move drawn on the device (%d) is not numpy\'s (%d): game %d, ply %d' % (moves[bad], chosen[bad], gids[bad], plies[bad]))
+        done = []
+        n_playout = eng.n_playout
+        for i in range(len(idx)):
+            s, f, gid, ply = int(slots[i]), int(flags[i]), int(gids[i]), int(plies[i])
+            if f & PLAY_SEARCHED:
+                self.sims_done += n_playout
+            if f & PLAY_STALLED:
+                known = self._stalls.get(s)
+                if known is None or known[:2] != (gid, ply):   # first sight of this stall: decide, hand the move back
+                    self._stalls[s] = (gid, ply, pis[i], int(chosen[i]))
+                    with self._on(lane):
+                        eng.play_resolve(s - lo, int(chosen[i]))
+                continue
+            pi, mv = pis[i], int(moves[i])
+            if f & PLAY_RESOLVED:
+                known = self._stalls.pop(s, None)
+                if known is None or known[:2] != (gid, ply) or known[3] != mv:
+                    raise HipError('slot %d: the device resolved game %d ply %d with move %d, the host had decided %r' % (s, gid, ply, mv, known))
+                pi = known[2]
+                self.stalls_resolved += 1
+            if ply == 0:   # the slot has started this game
+                self.slot_game[s], self.slot_ply[s] = gid, 0
+                self.slot_moves[s], self.slot_pis[s] = [], []
+                self._started += 1
+            if self.slot_game[s] != gid or self.slot_ply[s] != ply:
+                raise HipError('slot %d: the log says game %d ply %d, the host expected game %d ply %d' % (s, gid, ply, self.slot_game[s], self.slot_ply[s]))
+            self.slot_pis[s].append(pi)
+            self.slot_moves[s].append(mv)
+            self.slot_ply[s] += 1
+            self.moves_done += 1
+            if f & PLAY_ENDED:
+                winner = ((int(rec[i, 4]) >> 16) & 3) - 1
+                done.append(Trajectory(gid, eng.board_size, eng.n_in_row, self.slot_moves[s], self.slot_pis[s], winner, game=eng.game))
+                self.slot_game[s] = -1
+        return done
+
+    def device_stop(self):
+        """Drop every game and every row in flight: all slots idle (a run that stops early)."""
+        for lane in self.lanes:
+            lane.stream.synchronize()
+            with self._on(lane):
+                lane.eng.play_stop()
+            lane.stream.synchronize()
+            lane.inflight, lane.last_running, lane.primed = [], 0, False
+        self.slot_game[:] = -1
+        self._stalls = {}
+        self._queue_len = self._started = 0
+
+    def run_device(self, game_ids, max_moves=None):
+        """run() with the move step on the device: same trajectories, sorted by game id."""
+        game_ids = list(game_ids)
+        if not getattr(self, '_dev_on', False):
+            self.device_attach(queue_capacity=max(len(game_ids), 1))
+        elif len(game_ids) > self._queue_ids.numel():
+            self.device_attach(queue_capacity=len(game_ids), **self._attach_kw)   # (a longer queue: attach again, same settings)
+        else:
+            self.device_stop()
+        self.device_queue(game_ids)
+        out, n_moves = [], 0
+        while len(out) < len(game_ids):
+            if all(self._lane_quiet(lane) for lane in self.lanes):
+                raise RuntimeError('device-driven self-play went quiet with %d of %d games finished' % (len(out), len(game_ids)))
+            out.extend(self.play_move_device())
+            n_moves += 1
+            if max_moves is not None and n_moves >= max_moves:
+                break
+        out.extend(self.device_drain())
+        self.check()
+        if len(out) < len(game_ids):
+            self.device_stop()
+        return sorted(out, key=lambda t: t.game_id)
+
+
 # ------------------------------------------------------------------------- multi-GPU gather
 def pack_trajectories(trajs, n_cells):
     """-> (header int64 [n,4] = game id, plies, winner, 0 ; moves int64 [P] ; pis float64 [P,S])."""

@@ -49,6 +49,8 @@ def test_config_struct_layout_matches_header():
     assert ctypes.sizeof(_hip.RzValueHead) == 48 and _hip.RzValueHead.ld.offset == 40 and _hip.RzValueHead.groups.offset == 44
     assert ctypes.sizeof(_hip.RzDeferredLogits) == 16 and _hip.RzDeferredLogits.rows_per_slot.offset == 12
     assert _hip.RzMzCartPolePlay.max_entries.offset == 128
+    # rz_play_config: uint64, two doubles, three pointers, two int32 (the move step on the device, ABI 24)
+    assert ctypes.sizeof(_hip.RzPlayConfig) == 56 and _hip.RzPlayConfig.d_queue_ids.offset == 24 and _hip.RzPlayConfig.ring_steps.offset == 48
 
 
 def test_product_fails_loudly_without_gpu():

@@ -1,0 +1,113 @@
+"""The move step on the device (include/rlzero_hip.h: rz_play_*; BatchedSelfPlay.run_device): between two searches the host is
+not in the loop -- the root visits are logged, the move of alphazero_mcts.py:147-148 is drawn, update_with_move (:96-103), env.step
++ game_end_winner (game.py:109-118), reset_player (:128) and the start of the next game all run as kernels enqueued moves ahead of
+the host, which reads the log behind the GPU, forms pi with the reference's numpy expression and verifies every move.
+
+Pinned here: the games are the oracle's (synthetic evaluator: bit-exact trees, moves, pi to 1e-12, z), they are bit for bit the
+games of the host-driven loop (real net, lanes, hipGraphs, the resident search, Connect4, refills), and a draw that falls close to
+an interval edge is decided by the host (forced here by a wide stall margin) without changing a single game."""
+import numpy as np
+import pytest
+
+from oracle import evaluators as ev
+from oracle.gomoku_ref import RefGomoku
+from oracle.mcts_ref import RefPlayer, inverse_cdf_choice, self_play_game
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    assert [t.game_id for t in a] == [t.game_id for t in b]
+    for x, y in zip(a, b):
+        assert (x.winner, x.moves) == (y.winner, y.moves), x.game_id
+        assert np.array_equal(np.asarray(x.pis).view(np.uint64), np.asarray(y.pis).view(np.uint64)), x.game_id
+
+
+def test_device_moves_vs_oracle():
+    """Synthetic evaluator, 8 slots, 24 games (slots refill themselves on the device): game by game the oracle's self-play game
+    for the same uniforms -- moves, winner, pi, z, observation planes."""
+    from rlzero_amd.engine import MCTSEngine, SyntheticEvaluator
+    from rlzero_amd.selfplay import BatchedSelfPlay, move_uniform
+    eng = MCTSEngine(6, 4, n_games=8, n_playout=60, device='cuda:0')
+    sp = BatchedSelfPlay(eng, SyntheticEvaluator('vlin'), temperature=1.0, seed=5)
+    trajs = sp.run_device(range(24))
+    assert [t.game_id for t in trajs] == list(range(24))
+    assert sp.sims_done == 60 * sum(len(t.moves) for t in trajs) and sp.moves_done == sum(len(t.moves) for t in trajs)
+    for t in trajs[::2]:
+        us = move_uniform(5, np.full(64, t.game_id), np.arange(64))
+        player = RefPlayer(ev.vlin, 60, 5, is_selfplay=True, choice=inverse_cdf_choice(us))
+        winner, data, moves = self_play_game(RefGomoku(6, 4), player, temperature=1.0)
+        assert (winner, moves) == (t.winner, t.moves)
+        _, data2 = t.as_reference_tuple()
+        for (s1, p1, z1), (s2, p2, z2) in zip(data, data2):
+            assert (s1 == s2).all() and np.max(np.abs(p1 - p2)) <= 1e-12 and z1 == z2
+    # the same object again, other games, and the host-driven loop on it afterwards: the slots are handed back clean
+    more = sp.run_device(range(100, 110))
+    host = sp.run(range(100, 110))
+    _same(more, host)
+    gid, ply, state, steps = eng.play_state()
+    assert steps > 0
+    eng.close()
+
+
+@pytest.mark.parametrize('layout', ['resident_1lane', 'graphs_2lanes', 'graphs_3lanes_9x9', 'connect4_2lanes'])
+def test_device_moves_equal_host_moves(layout):
+    """The production evaluator on the production routes: run_device() == run() bit for bit (moves, pi, winners), with more
+    games than slots."""
+    import torch
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    from rlzero_amd.selfplay import BatchedSelfPlay
+    torch.manual_seed(2)
+    if layout == 'connect4_2lanes':
+        net = PolicyValueNet(6, 7, 7).to('cuda:0')
+        kw = dict(board=(6, 7), n_in_row=4, n_games=10, n_playout=50, game='connect4', net_shape=(6, 7, 7), lanes=2,
+                  use_graph=True, sims_per_graph=8, resident_search=False)
+    elif layout == 'graphs_3lanes_9x9':
+        net = PolicyValueNet(9).to('cuda:0')
+        kw = dict(board=9, n_in_row=5, n_games=9, n_playout=40, lanes=3, use_graph=True, sims_per_graph=8, resident_search=False)
+    elif layout == 'graphs_2lanes':
+        net = PolicyValueNet(11).to('cuda:0')
+        kw = dict(board=11, n_in_row=5, n_games=8, n_playout=48, lanes=2, use_graph=True, sims_per_graph=16, resident_search=False)
+    else:
+        net = PolicyValueNet(6).to('cuda:0')
+        kw = dict(board=6, n_in_row=4, n_games=6, n_playout=40, lanes=1)
+    ids = list(range(3, 3 + 2 * kw['n_games'] + 3))
+    host = BatchedSelfPlay.for_network(net, device='cuda:0', temperature=1.0, seed=9, **kw)
+    a = host.run(ids, pipelined=len(host.lanes) > 1)
+    dev = BatchedSelfPlay.for_network(net, device='cuda:0', temperature=1.0, seed=9, **kw)
+    b = dev.run_device(ids)
+    _same(a, b)
+    assert dev.sims_done == host.sims_done and dev.moves_done == host.moves_done
+    for sp in (host, dev):
+        for st in sp.check():
+            assert st.reuse_dropped == 0
+        for lane in sp.lanes:
+            lane.evaluator.hip.check_flags()
+            lane.eng.close()
+
+
+def test_a_draw_near_an_interval_edge_is_the_host_s():
+    """stall_margin = 0.08: roughly one draw in six lies that close to an edge of its interval -- the device does not draw, the
+    slot sits out the coming searches, the host decides with numpy and hands the move back.  The games are those of the default
+    margin (where no draw stalls), bit for bit; a stalled slot's search is not repeated (simulations counted once)."""
+    import torch
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    from rlzero_amd.selfplay import BatchedSelfPlay
+    torch.manual_seed(4)
+    net = PolicyValueNet(6).to('cuda:0')
+    kw = dict(board=6, n_in_row=4, n_games=7, n_playout=40, device='cuda:0', temperature=1.0, seed=21, lanes=2,
+              use_graph=True, sims_per_graph=8, resident_search=False)
+    ids = list(range(20))
+    plain = BatchedSelfPlay.for_network(net, **kw)
+    a = plain.run_device(ids)
+    assert plain.stalls_resolved == 0
+    wide = BatchedSelfPlay.for_network(net, **kw)
+    wide.device_attach(queue_capacity=64, stall_margin=0.08)
+    b = wide.run_device(ids)
+    _same(a, b)
+    assert wide.stalls_resolved >= 5 and wide.sims_done == plain.sims_done
+    # (the margin is reported per record: every un-stalled draw of the wide run lay farther than 0.08 from its edges)
+    for sp in (plain, wide):
+        sp.check()
+        for lane in sp.lanes:
+            lane.eng.close()

@@ -584,6 +584,11 @@ def main():
     ap.add_argument('--pipeline', type=int, default=1,
                     help='1 = the host side of a lane\'s move runs under the other lanes\' simulations (BatchedSelfPlay.'
                          'play_move_pipelined); 0 = all lanes simulate, then all are finished on the host')
+    ap.add_argument('--device-moves', type=int, default=1,
+                    help='1 (default): the move step on the device (rz_play_*: the draw, tree reuse, game step, end / refill of slots as '
+                         'kernels enqueued moves ahead of the host, which reads the log behind the GPU, forms pi with numpy and verifies '
+                         'every move); 0: the host-driven move step of rounds 1-4 (--pipeline)')
+    ap.add_argument('--timeline-leg', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--mz-moves-per-launch', type=int, default=16, help='MuZero: moves of every environment per launch of the whole-moves kernel')
     ap.add_argument('--mz-gpw', type=int, default=0,
                     help='--game muzero: games per workgroup of k_mz_search (rz_mz_set_search_shape; 0 = automatic)')
@@ -726,8 +731,13 @@ def main():
     sp.warm_graphs()
     # games rank, rank+world, ... ; ids beyond the first G refill finished slots
     next_id = [rank + world * G]
-    sp._start(range(G), [rank + world * i for i in range(G)])
-    sp._set_active()
+    device_moves = bool(args.device_moves) and args.in_flight <= 1
+    if device_moves:   # the slots take their games from a queue on the device, finished ones refill themselves
+        sp.device_attach(queue_capacity=1 << 16)
+        sp.device_queue([rank + world * i for i in range(1 << 16)])
+    else:
+        sp._start(range(G), [rank + world * i for i in range(G)])
+        sp._set_active()
     finished = [0]
     first_gen_plies = []  # lengths of the finished games among the G games this rank started with
     gather_sample = []    # N > 1: finished trajectories for the one exchange of the path (after the timed region)
@@ -737,9 +747,19 @@ def main():
         next_id[0] += world * n
         return ids
 
+    def account(done):
+        finished[0] += len(done)
+        first_gen_plies.extend(len(t.moves) for t in done if t.game_id < world * G)
+        if (use_dist or args.dump_trajectories) and len(gather_sample) < GATHER_SAMPLE_GAMES:
+            gather_sample.extend(done[:GATHER_SAMPLE_GAMES - len(gather_sample)])
+
     def one_step():
-        # one move of every game, finished slots refilled.  --pipeline 1: the host side of a lane's move (visit counts ->
+        # one move of every game, finished slots refilled.  --device-moves 1: the whole move is enqueued (search, draw, priors, tree
+        # reuse, game step, refill); the host reads the log a few moves behind (pi by numpy, every move verified).
+        # --device-moves 0 --pipeline 1: the host side of a lane's move (visit counts ->
         # pi -> move, tree reuse, game step, refill) runs while the other lanes' simulations keep the GPU busy
+        if device_moves:
+            return account(sp.play_move_device())
         if args.pipeline:
             done = sp.play_move_pipelined(refill)
         else:
@@ -748,13 +768,12 @@ def main():
                 free = np.nonzero(sp.slot_game < 0)[0]
                 sp._start(free, refill(len(free)))
                 sp.retire_finished()
-        finished[0] += len(done)
-        first_gen_plies.extend(len(t.moves) for t in done if t.game_id < world * G)
-        if (use_dist or args.dump_trajectories) and len(gather_sample) < GATHER_SAMPLE_GAMES:
-            gather_sample.extend(done[:GATHER_SAMPLE_GAMES - len(gather_sample)])
+        account(done)
 
     def fence():
         torch.cuda.synchronize()
+        if device_moves:   # every enqueued move has ended: read the rows still unread (pi, verification, finished games)
+            account(sp.device_drain())
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -774,8 +793,8 @@ def main():
     # --regions timed regions of K steps each, every one bracketed by barrier + synchronize; the MEDIAN region is reported
     regions = []
     for _ in range(max(1, args.regions)):
+        fence()   # (device-driven moves: also reads the rows of the moves before the region -- counted before it, not in it)
         sims0, fin0 = sp.sims_done, finished[0]
-        fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             one_step()
@@ -942,6 +961,8 @@ def main():
                        if deferred_route else 'written by every tree step',
                        'launches_per_step': (0 if resident_route else 2) if deferred_route else 3,
                        'resident_search': bool(resident_route),
+                       'move_step': 'device (rz_play_*: moves enqueued ahead, log read behind; pi and verification by numpy on the host)'
+                       if device_moves else ('host, pipelined under the other lanes' if args.pipeline else 'host'),
                        'hw_queues': int(os.environ.get('GPU_MAX_HW_QUEUES', '4')),   # hardware queues asked of the HIP runtime (a lane each)
                        'parallelism': 'games sharded, dp%d' % world},
             'regions_sims_per_sec': [round(r[1] / r[0], 1) for r in regions], 'warmup_moves_run': n_ramp,
@@ -955,6 +976,8 @@ def main():
             'trajectory_gather': gather,
             'arena_slots_used_max': int(stats.max_slots_used), 'arena_slots': int(stats.arena_slots),
             'reuse_dropped': reuse_dropped_timed,   # rank 0, warm-up + timed regions + timing samples
+            # device-driven moves: draws the device left to the host (u within 1e-10 of an interval edge); every other move verified
+            'move_draws_left_to_host': int(getattr(sp, 'stalls_resolved', 0)) if device_moves else None,
             'engine_hbm_bytes': int(hbm_bytes),
         }
         trunk_events = [iv for ev in evaluators if isinstance(ev, TimedEvaluator) for iv in ev.events]

@@ -912,6 +912,46 @@ class MCTSEngine(object):
         self.play_steps += 1
         return row
 
+    def warm_move_graph(self, evaluator):
+        """A hipGraph of one WHOLE move for an evaluator whose search is the one-launch resident kernel (rz_net_search_resident):
+        first selection, n_playout simulations, the draw, the policy GEMM + priors of the search, tree reuse + game step + end /
+        refill of slots -- replayed once per move (play_move_replay), the log row taken from the device's own step counter.  None
+        when the route or the store (fewer than n_playout slots) does not allow it."""
+        t = self.torch
+        res_ok = getattr(evaluator, 'resident_ok', None)
+        if res_ok is None or not res_ok(self) or getattr(self, 'play_log', None) is None:
+            return None
+        n = self.n_playout
+        self.flush_deferred()
+        if self._deferred_begin(evaluator, n) < n or self._def_slots < n:   # (reserves the store; a search must fit between two flushes)
+            return None
+        hip, lib, h = evaluator.hip, self.lib, self.handle
+        t.cuda.synchronize(self.device)
+        graph = t.cuda.CUDAGraph()
+        self._capturing = True
+        try:
+            with t.cuda.graph(graph):
+                st = self.stream()
+                check(lib.rz_select_step(h, None, st), 'rz_select_step')
+                evaluator.search_resident(self, n)
+                check(lib.rz_play_draw(h, st), 'rz_play_draw')
+                logits = hip.deferred_gemm(self.n_leaves, n)
+                check(lib.rz_deferred_flush(h, ctypes.byref(logits), n, st), 'rz_deferred_flush')
+                check(lib.rz_play_apply(h, st), 'rz_play_apply')
+        finally:
+            self._capturing = False
+        self._move_graph_ev = evaluator
+        return graph
+
+    def play_move_replay(self, graph):
+        """One whole move from the graph of warm_move_graph -> the log row it writes."""
+        if self._def_pending > 0:
+            self.flush_deferred()   # (leaves of eager steps before this move: the graph's own flush covers its n_playout slots from 0)
+        graph.replay()
+        row = self.play_steps % self.play_log.shape[0]
+        self.play_steps += 1
+        return row
+
     def play_refill(self):
         """rz_play_apply alone: idle slots take games from the queue (the start of a run).  Counts as a move step whose log row
         holds nothing to read (no draw has written it)."""

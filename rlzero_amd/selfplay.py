@@ -620,32 +620,45 @@ class BatchedSelfPlay(object):
 
     # -- the move step on the device (include/rlzero_hip.h: rz_play_*) -----------------------------------------------
     # The host enqueues whole moves -- search, draw, priors, tree reuse, game step, end / refill of slots -- and never waits for
-    # one: what happened comes back through each lane's log, read `depth` moves behind.  pi is formed HERE, from the logged visit
+    # one: what happened comes back through each lane's log, read behind the GPU.  pi is formed HERE, from the logged visit
     # counts with the reference's numpy expression (alphazero_mcts.py:10-14,91-92), and every move the device drew is checked
     # against numpy's inverse-CDF draw on the same uniform (a mismatch raises; a draw too close to an interval edge was never
     # made by the device: the slot stalls until the move computed here is handed back).  Same trajectories as play_move().
-    def device_attach(self, queue_capacity=1 << 16, ring_steps=32, depth=3, stall_margin=0.0):
-        """Switch this object to device-driven moves.  ``depth``: moves a lane may be enqueued ahead of the rows read back."""
+    def device_attach(self, queue_capacity=1 << 16, ring_steps=64, depth=None, copy_every=None, stall_margin=0.0, move_graphs=True):
+        """Switch this object to device-driven moves.  ``copy_every``: moves of a lane per read-back of its log rows (None: 1, or
+        8 when a move is a fraction of a millisecond -- boards of a few cells with few simulations); ``depth``: read-backs a lane
+        may be ahead of the rows processed here (None: 1 when a move is long, else 2).  ``move_graphs``: a lane whose search is the
+        one-launch resident kernel replays its WHOLE move -- selection, search, draw, priors, tree reuse, game step, refill -- from
+        one hipGraph."""
         t = self.torch
         from ._hip import PLAY_RECORD_WORDS
         dev = self.eng.device
         if getattr(self, '_dev_on', False):
             self.device_stop()
-        self._attach_kw = dict(ring_steps=ring_steps, depth=depth, stall_margin=stall_margin)
+        self._attach_kw = dict(ring_steps=ring_steps, depth=depth, copy_every=copy_every, stall_margin=stall_margin, move_graphs=move_graphs)
         t.cuda.synchronize(dev)
+        work = self.eng.n_playout * self.eng.n_cells   # ~ the length of a move
+        self._copy_every = int(copy_every) if copy_every else (1 if work >= 4000 else 8)
+        self._depth = int(depth) if depth else (1 if work >= 100000 else 2)
+        ring_steps = max(int(ring_steps), self._copy_every * (self._depth + 2) + 2)
         self._queue_ids = t.zeros(int(queue_capacity), dtype=t.int64, device=dev)
         self._queue_ctl = t.zeros(2, dtype=t.int32, device=dev)
-        self._queue_len, self._started, self._depth = 0, 0, max(1, min(int(depth), int(ring_steps) - 2))
+        self._queue_len, self._started = 0, 0
         words = PLAY_RECORD_WORDS + self.eng.n_actions
         for lane in self.lanes:
             with self._on(lane):
                 lane.eng.play_attach(self.seed, self.temperature, self._queue_ids, self._queue_ctl, ring_steps=ring_steps,
                                      stall_margin=stall_margin)
+                lane.move_graph = lane.eng.warm_move_graph(lane.evaluator) if move_graphs else None
             lane.host_log = t.empty((int(ring_steps), lane.eng.n_games, words), dtype=t.int32, pin_memory=True)
             lane.host_np = lane.host_log.numpy()
-            lane.inflight = []          # [(row, event)] oldest first
+            lane.uncopied = []          # rows written by enqueued moves, their read-back not enqueued yet
+            lane.inflight = []          # [(rows, event)] read-backs enqueued, oldest first
             lane.last_running = -1      # RUNNING records in the last row read (-1: none read yet)
             lane.primed = False
+        max_plies = self.eng.n_cells
+        self._pi_buf = np.empty((self.n_slots, max_plies, self.eng.n_actions), dtype=np.float64)   # (pages are touched as games grow)
+        self._mv_buf = np.zeros((self.n_slots, max_plies), dtype=np.int32)
         self._stalls = {}               # slot -> (game id, ply, pi, move): decided here, waiting for the device to take it
         self.stalls_resolved = 0
         self.slot_game[:] = -1
@@ -670,29 +683,51 @@ class BatchedSelfPlay(object):
 
     def _lane_quiet(self, lane):
         """Nothing left to do on this lane, as far as the rows read so far can tell (the host's view lags the device by design)."""
-        return not lane.inflight and lane.last_running == 0 and self._started >= self._queue_len
+        return not lane.inflight and not lane.uncopied and lane.last_running == 0 and self._started >= self._queue_len
+
+    def _read_back(self, lane):
+        """Enqueue the copy of the lane's new log rows to pinned memory (contiguous runs of the ring: one copy each)."""
+        rows = lane.uncopied
+        if not rows:
+            return
+        lane.uncopied = []
+        with self._on(lane):
+            at = 0
+            while at < len(rows):
+                end = at + 1
+                while end < len(rows) and rows[end] == rows[end - 1] + 1:
+                    end += 1
+                lane.host_log[rows[at]:rows[end - 1] + 1].copy_(lane.eng.play_log[rows[at]:rows[end - 1] + 1], non_blocking=True)
+                at = end
+            ev = self.torch.cuda.Event()
+            ev.record(lane.stream)
+        lane.inflight.append((rows, ev))
 
     def play_move_device(self):
-        """Enqueue ONE more move of every lane that may still have games and read the rows that have arrived (at most ``depth``
-        moves stay unread per lane) -> the trajectories of the games found finished in them."""
+        """Enqueue ONE more move of every lane that may still have games and process the log rows that have arrived
+        -> the trajectories of the games found finished in them."""
         for lane in self.lanes:
             if self._lane_quiet(lane):
                 continue
-            self._simulate_lane(lane)
-            with self._on(lane):
-                row = lane.eng.play_move()
-                lane.host_log[row].copy_(lane.eng.play_log[row], non_blocking=True)
-                ev = self.torch.cuda.Event()
-                ev.record(lane.stream)
-            lane.inflight.append((row, ev))
+            if lane.move_graph is not None:
+                with self._on(lane):
+                    lane.uncopied.append(lane.eng.play_move_replay(lane.move_graph))
+            else:
+                self._simulate_lane(lane)
+                with self._on(lane):
+                    lane.uncopied.append(lane.eng.play_move())
+            if len(lane.uncopied) >= self._copy_every:
+                self._read_back(lane)
         done = []
         for lane in self.lanes:
             done.extend(self._harvest(lane, keep=self._depth))
         return done
 
     def device_drain(self):
-        """Wait for every enqueued move and read its row -> the finished trajectories found."""
+        """Wait for every enqueued move and process its row -> the finished trajectories found."""
         done = []
+        for lane in self.lanes:
+            self._read_back(lane)
         for lane in self.lanes:
             done.extend(self._harvest(lane, keep=0))
         return done
@@ -701,65 +736,81 @@ class BatchedSelfPlay(object):
         from ._hip import PLAY_ENDED, PLAY_RECORD_WORDS, PLAY_RESOLVED, PLAY_RUNNING, PLAY_SEARCHED, PLAY_STALLED, HipError
         rows = []
         while lane.inflight and (len(lane.inflight) > keep or lane.inflight[0][1].query()):
-            row, ev = lane.inflight.pop(0)
+            batch, ev = lane.inflight.pop(0)
             ev.synchronize()
-            rows.append(row)
+            rows.extend(batch)
         if not rows:
             return []
         eng, lo, W0 = lane.eng, lane.slots.start, PLAY_RECORD_WORDS
         G = eng.n_games
-        rec = lane.host_np[rows].reshape(len(rows) * G, -1)   # (a copy: the pinned rows may be overwritten from now on)
-        flags = rec[:, 4] & 0xFFFF
-        lane.last_running = int(((flags[-G:] & PLAY_RUNNING) != 0).sum())
-        idx = np.nonzero(flags & PLAY_RUNNING)[0]
-        if idx.size == 0:
+        rec = lane.host_np[rows]                                # [rows, G, words] (a copy: the pinned rows may be overwritten from now on)
+        flags = rec[:, :, 4] & 0xFFFF
+        lane.last_running = int(((flags[-1] & PLAY_RUNNING) != 0).sum())
+        row_i, g_i = np.nonzero(flags & PLAY_RUNNING)           # (row-major: a slot's records in move order)
+        if row_i.size == 0:
             return []
-        rec, flags = rec[idx], flags[idx]
-        slots = lo + idx % G
+        rec, flags = rec[row_i, g_i], flags[row_i, g_i]
+        slots = lo + g_i
         gids = rec[:, 0].astype(np.uint32).astype(np.int64) | (rec[:, 1].astype(np.int64) << 32)
         plies, moves = rec[:, 2].astype(np.int64), rec[:, 3]
         visits = rec[:, W0:]
         legal = visits >= 0
         # the reference's expression on the logged counts; the draw with the game's uniform (numpy's inverse-CDF rule): the arbiter
         pis, chosen = batch_pi_and_moves(np.where(legal, visits, 0), legal, self.temperature, move_uniform(self.seed, gids, plies))
-        plain = (flags & (PLAY_STALLED | PLAY_RESOLVED)) == 0
-        if (chosen[plain] != moves[plain]).any():
-            bad = np.nonzero(plain & (chosen != moves))[0][0]
+        not_plain = (flags & (PLAY_STALLED | PLAY_RESOLVED)) != 0
+        wrong = ~not_plain & (chosen != moves)
+        if wrong.any():
+            bad = np.nonzero(wrong)[0][0]
             raise HipError('the move drawn on the device (%d) is not numpy\'s (%d): game %d, ply %d' % (moves[bad], chosen[bad], gids[bad], plies[bad]))
+        self.sims_done += eng.n_playout * int(((flags & PLAY_SEARCHED) != 0).sum())
+        special = not_plain | ((flags & PLAY_ENDED) != 0) | (plies == 0)
         done = []
-        n_playout = eng.n_playout
-        for i in range(len(idx)):
-            s, f, gid, ply = int(slots[i]), int(flags[i]), int(gids[i]), int(plies[i])
-            if f & PLAY_SEARCHED:
-                self.sims_done += n_playout
-            if f & PLAY_STALLED:
-                known = self._stalls.get(s)
-                if known is None or known[:2] != (gid, ply):   # first sight of this stall: decide, hand the move back
-                    self._stalls[s] = (gid, ply, pis[i], int(chosen[i]))
-                    with self._on(lane):
-                        eng.play_resolve(s - lo, int(chosen[i]))
+        first = np.searchsorted(row_i, np.arange(len(rows) + 1))   # records of row r: first[r] .. first[r + 1]
+        for r in range(len(rows)):
+            a, b = int(first[r]), int(first[r + 1])
+            if a == b:
                 continue
-            pi, mv = pis[i], int(moves[i])
-            if f & PLAY_RESOLVED:
-                known = self._stalls.pop(s, None)
-                if known is None or known[:2] != (gid, ply) or known[3] != mv:
-                    raise HipError('slot %d: the device resolved game %d ply %d with move %d, the host had decided %r' % (s, gid, ply, mv, known))
-                pi = known[2]
-                self.stalls_resolved += 1
-            if ply == 0:   # the slot has started this game
-                self.slot_game[s], self.slot_ply[s] = gid, 0
-                self.slot_moves[s], self.slot_pis[s] = [], []
-                self._started += 1
-            if self.slot_game[s] != gid or self.slot_ply[s] != ply:
-                raise HipError('slot %d: the log says game %d ply %d, the host expected game %d ply %d' % (s, gid, ply, self.slot_game[s], self.slot_ply[s]))
-            self.slot_pis[s].append(pi)
-            self.slot_moves[s].append(mv)
-            self.slot_ply[s] += 1
-            self.moves_done += 1
-            if f & PLAY_ENDED:
-                winner = ((int(rec[i, 4]) >> 16) & 3) - 1
-                done.append(Trajectory(gid, eng.board_size, eng.n_in_row, self.slot_moves[s], self.slot_pis[s], winner, game=eng.game))
-                self.slot_game[s] = -1
+            easy = np.nonzero(~special[a:b])[0] + a
+            if easy.size:   # a move in the middle of a game: the whole row at once
+                s = slots[easy]
+                if (self.slot_game[s] != gids[easy]).any() or (self.slot_ply[s] != plies[easy]).any():
+                    i = easy[np.nonzero((self.slot_game[s] != gids[easy]) | (self.slot_ply[s] != plies[easy]))[0][0]]
+                    raise HipError('slot %d: the log says game %d ply %d, the host expected game %d ply %d' % (
+                        slots[i], gids[i], plies[i], self.slot_game[slots[i]], self.slot_ply[slots[i]]))
+                self._pi_buf[s, plies[easy]] = pis[easy]
+                self._mv_buf[s, plies[easy]] = moves[easy]
+                self.slot_ply[s] += 1
+                self.moves_done += int(easy.size)
+            for i in np.nonzero(special[a:b])[0] + a:
+                s, f, gid, ply = int(slots[i]), int(flags[i]), int(gids[i]), int(plies[i])
+                if f & PLAY_STALLED:
+                    known = self._stalls.get(s)
+                    if known is None or known[:2] != (gid, ply):   # first sight of this stall: decide, hand the move back
+                        self._stalls[s] = (gid, ply, pis[i], int(chosen[i]))
+                        with self._on(lane):
+                            eng.play_resolve(s - lo, int(chosen[i]))
+                    continue
+                pi, mv = pis[i], int(moves[i])
+                if f & PLAY_RESOLVED:
+                    known = self._stalls.pop(s, None)
+                    if known is None or known[:2] != (gid, ply) or known[3] != mv:
+                        raise HipError('slot %d: the device resolved game %d ply %d with move %d, the host had decided %r' % (s, gid, ply, mv, known))
+                    pi = known[2]
+                    self.stalls_resolved += 1
+                if ply == 0:   # the slot has started this game
+                    self.slot_game[s], self.slot_ply[s] = gid, 0
+                    self._started += 1
+                if self.slot_game[s] != gid or self.slot_ply[s] != ply:
+                    raise HipError('slot %d: the log says game %d ply %d, the host expected game %d ply %d' % (s, gid, ply, self.slot_game[s], self.slot_ply[s]))
+                self._pi_buf[s, ply] = pi
+                self._mv_buf[s, ply] = mv
+                self.slot_ply[s] += 1
+                self.moves_done += 1
+                if f & PLAY_ENDED:
+                    winner = ((int(rec[i, 4]) >> 16) & 3) - 1
+                    n = ply + 1
+                    done.append(Trajectory(gid, eng.board_size, eng.n_in_row, self._mv_buf[s, :n].tolist(), self._pi_buf[s, :n].copy(), winner, game=eng.game))
+                    self.slot_game[s] = -1
         return done
 
     def device_stop(self):
@@ -769,7 +820,7 @@ class BatchedSelfPlay(object):
             with self._on(lane):
                 lane.eng.play_stop()
             lane.stream.synchronize()
-            lane.inflight, lane.last_running, lane.primed = [], 0, False
+            lane.inflight, lane.uncopied, lane.last_running, lane.primed = [], [], 0, False
         self.slot_game[:] = -1
         self._stalls = {}
         self._queue_len = self._started = 0

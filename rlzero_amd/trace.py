@@ -150,7 +150,7 @@ def summarise(rec, n_cus=256):
     return out
 
 
-def measure(net_module, board=15, n_in_row=5, n_games=512, n_playout=800, warm_moves=3, device='cuda:0', seed=0, **kw):
+def measure(net_module, board=15, n_in_row=5, n_games=512, n_playout=800, warm_moves=3, device='cuda:0', seed=0, device_moves=True, **kw):
     """Play ``warm_moves`` + 1 pipelined moves of the shipped layout with a trace buffer attached to every lane; -> summary of the
     lanes' LAST searches plus 'sims_per_sec_traced' (the whole run under the trace, host steps included) for comparison with the
     untraced bench."""
@@ -168,22 +168,33 @@ def measure(net_module, board=15, n_in_row=5, n_games=512, n_playout=800, warm_m
     sp = BatchedSelfPlay.for_network(net_module, board, n_in_row, n_games=n_games, n_playout=n_playout, device=device, seed=seed,
                                      before_warm=attach, **kw)
     try:
-        sp._start(range(n_games), range(n_games))
-        sp._set_active()
-        sp.play_move_pipelined()
+        if device_moves:   # the move step on the device (BatchedSelfPlay.play_move_device): what bench.py times by default
+            sp.device_attach(queue_capacity=4 * n_games)
+            sp.device_queue(range(4 * n_games))
+            step = sp.play_move_device
+        else:
+            sp._start(range(n_games), range(n_games))
+            sp._set_active()
+            step = sp.play_move_pipelined
+        step()
         torch.cuda.synchronize()
+        if device_moves:
+            sp.device_drain()
         for tb in traces:
             tb.reset()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(warm_moves):
-            sp.play_move_pipelined()
+            step()
         torch.cuda.synchronize()
+        if device_moves:
+            sp.device_drain()
         dt = time.perf_counter() - t0
         parts = [tb.records(i) for i, tb in enumerate(traces)]
         rec = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
         out = summarise(rec, n_cus=torch.cuda.get_device_properties(torch.device(device)).multi_processor_count)
         out['lanes_in_layout'] = len(sp.lanes)
+        out['move_step'] = 'device' if device_moves else 'host, pipelined'
         out['games'] = n_games
         # (each call enqueues the next move's search before it returns; the last search ends at the synchronize)
         out['sims_per_sec_traced'] = round(warm_moves * n_games * n_playout / dt, 1)

@@ -167,7 +167,10 @@ class TrainPipeline:
                 n_games=self.selfplay_games_in_flight, n_playout=self.n_playout, c_puct=self.c_puct,
                 device=str(self.device), temperature=self.temperature, seed=self.selfplay_seed)
         self._batched.refresh_weights()   # (every lane's evaluator: the learner has stepped / new weights have arrived)
-        trajs = self._batched.run(game_ids) if len(game_ids) else []
+        # the move step on the device (rz_play_*: the host reads the games from a log behind the GPU); RZ_TRAIN_HOST_MOVES=1: the
+        # host-driven loop -- the same trajectories either way (tests/test_device_moves.py)
+        play = self._batched.run if os.environ.get('RZ_TRAIN_HOST_MOVES') == '1' else self._batched.run_device
+        trajs = play(game_ids) if len(game_ids) else []
         if os.environ.get('RZ_TRAIN_TRACE'):
             self._trace_round(trajs)
         return trajs

@@ -12,7 +12,7 @@ full.  The 512 games of a GPU run as four lanes of 128 (separate streams: the tr
 trunks of the others on the same CUs; rlzero_amd.selfplay.plan_lanes); a simulation step of a lane is two launches, trunk -> tree
 step -- the reference's selection rule never reads a prior, so the policy GEMM and the priors of a search's expansions are written
 in one batch per move, inside the timed region.  Games are independent: N GPUs play N x 512 games with no collective in the
-timed region (weak scaling); rank 0 prints ONE JSON line.  `value` is the MEDIAN of --regions (3) timed regions of K steps
+timed region (weak scaling); rank 0 prints ONE JSON line.  `value` is the MEDIAN of --regions (5) timed regions of K steps
 each, every region bracketed by barrier + synchronize.
 
 On the line (what each number means and how it is priced: DESIGN.md section 5):
@@ -106,6 +106,21 @@ def pmc_traffic(kernel, workload):
             rec = json.load(open(os.path.join(REPO, 'profiles', rnd, 'pmc_traffic.json')))
             return rec[workload]['kernels'][kernel]['traffic_bytes_per_launch']
         except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None
+
+
+def rocprof_dispatch_us(kernel_substring, stats='bench_default_kernel_stats.csv'):
+    """Average duration (us) and calls of the first kernel whose name contains ``kernel_substring`` in the committed rocprofv3
+    --kernel-trace --stats summary of the default command (profiles/rNN/<stats>, newest round first) -> (us, calls, path) or None."""
+    import csv
+    for rnd in ('r05', 'r04'):
+        path = os.path.join(REPO, 'profiles', rnd, stats)
+        try:
+            for row in csv.DictReader(open(path)):
+                if kernel_substring in row['Name']:
+                    return float(row['AverageNs']) / 1e3, int(row['Calls']), os.path.relpath(path, REPO)
+        except (OSError, KeyError, ValueError):
             continue
     return None
 
@@ -277,6 +292,14 @@ CONFIG_LEGS = (  # (key, flags, seconds of CPU baseline at --cpu-seconds 60); a 
     # moves = 128 launches = 0.6 s keep that drain at 2 % of the region)
     ('C5_muzero_cartpole_50sims_8192envs', ['--game', 'muzero', '--playouts', 50, '--games', 8192, '--steps', 2048, '--warmup', 256], 12.0),
 )
+
+
+def run_timeline_leg(args):
+    """The device-side launch trace of the same layout (rlzero_amd/trace.py) in a child process of its own: a diagnostic that
+    builds a second self-play object with traced kernel instantiations must not be able to take the measured line with it."""
+    rec = child_line(['--timeline-leg', '--games', args.games, '--playouts', args.playouts, '--lanes', args.lanes, '--noise', args.noise,
+                      '--device-moves', args.device_moves], 300)
+    return rec if rec is not None else {'error': 'the child process printed no line'}
 
 
 def run_config_legs(args):
@@ -564,7 +587,7 @@ def main():
                          'game length)')
     ap.add_argument('--no-fill', '--no-literal-config', dest='no_fill', action='store_true',
                     help='skip the extra N=1 measurement with %d games in flight (child process)' % FILL_GAMES_PER_GPU)
-    ap.add_argument('--regions', type=int, default=3, help='timed regions of K steps each; value = their median')
+    ap.add_argument('--regions', type=int, default=5, help='timed regions of K steps each; value = their median')
     ap.add_argument('--score-mode', default='uct_ref', choices=['uct_ref', 'puct'],
                     help="uct_ref: the reference's selection rule (node.py:32-42, 75-88; bit-exact); puct: the opt-in AlphaZero "
                          "rule Q + c P sqrt(N_parent) / (N + 1) (every level scans all children; parity by the oracle's restatement)")
@@ -622,6 +645,20 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
 
+    if args.timeline_leg:   # child mode: the launch trace of the layout, one JSON line
+        import torch
+        from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+        from rlzero_amd.selfplay import plan_lanes
+        from rlzero_amd.trace import measure
+        torch.manual_seed(0)
+        G = args.games if args.games > 0 else GAMES_PER_GPU
+        net = PolicyValueNet(BOARD).to('cuda:0').eval()
+        n_cus = torch.cuda.get_device_properties(0).multi_processor_count
+        lanes = args.lanes if args.lanes > 0 else plan_lanes(G, n_cus, deferred=True, cells=BOARD * BOARD)[0]
+        print(json.dumps(measure(net, BOARD, N_ROW, n_games=G, n_playout=args.playouts, lanes=lanes, device='cuda:0',
+                                 add_noise=bool(args.noise), device_moves=bool(args.device_moves))), flush=True)
+        return
+
     # CPU baseline first (rank 0, N=1 only), before this process touches the GPU
     cpu_baseline = None
     default_config = (args.game == 'gomoku' and args.board == BOARD and args.playouts == N_PLAYOUT)
@@ -635,12 +672,23 @@ def main():
     if (world == 1 and args.gpus == 1 and not args.no_fill and default_config and args.games == 0
             and args.evaluator == 'hipnet' and args.score_mode == 'uct_ref'):
         fill = run_fill_config(args)
+    timeline = None
+    if (world == 1 and args.gpus == 1 and args.timeline and default_config and args.evaluator == 'hipnet' and args.score_mode == 'uct_ref'
+            and args.net_algo.startswith('split_f16') and args.deferred and args.in_flight <= 1 and (args.games == 0 or args.games > 256)):
+        timeline = run_timeline_leg(args)
     # ... and the other configurations of BASELINE.json (C1, C2, C3, C5), each a child process with its own
     # roofline and CPU baseline: reported under `configs` of the default N = 1 line
     config_legs = None
     if (world == 1 and args.gpus == 1 and not args.no_configs and default_config and args.games == 0
             and args.evaluator == 'hipnet' and args.score_mode == 'uct_ref'):
         config_legs = run_config_legs(args)
+
+    # one process per GPU: this rank's host thread onto the cores of ITS GPU's NUMA node (sysfs only, no numactl / taskset hop, before
+    # the first GPU call; after the CPU baseline and the child legs, which use every core) -- rlzero_amd/affinity.py
+    from rlzero_amd.affinity import pin_to_gpu
+    one_device = os.environ.get('RZ_BENCH_SINGLE_DEVICE') == '1'
+    host_affinity = pin_to_gpu(0 if one_device else local_rank, 1 if one_device else int(os.environ.get('LOCAL_WORLD_SIZE', world)),
+                               apply=os.environ.get('RZ_BENCH_NO_PIN') != '1')
 
     import numpy as np
     import torch
@@ -666,6 +714,10 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    affinities = [host_affinity]
+    if use_dist:
+        affinities = [None] * world
+        dist.all_gather_object(affinities, host_affinity)
     if args.game == 'muzero':
         run_muzero(args, rank, world, device, dist, red_device, use_dist, cpu_baseline)
         return
@@ -974,6 +1026,8 @@ def main():
             'selfplay_games_per_sec': selfplay['games_per_sec'] if selfplay else None,
             'selfplay': selfplay,
             'trajectory_gather': gather,
+            'host_affinity': affinities,   # per rank: the NUMA node of its GPU and the cores its host thread is pinned to
+
             'arena_slots_used_max': int(stats.max_slots_used), 'arena_slots': int(stats.arena_slots),
             'reuse_dropped': reuse_dropped_timed,   # rank 0, warm-up + timed regions + timing samples
             # device-driven moves: draws the device left to the host (u within 1e-10 of an interval edge); every other move verified
@@ -1012,6 +1066,22 @@ def main():
                   'mfma_executed_frac': round(achieved / pipe_peak * executed_flop_ratio(args, cells), 4),
                   'trunk_workgroups': int(min(trunk_wgs if trunk_wgs > 0 else n_cus, boards_per_launch))}
             line['roofline'] = rf
+            # ONE dispatch by itself (no other lane on the chip): live, HIP events on the lane's stream around lone launches, and
+            # the committed rocprofv3 --kernel-trace --stats average of this very command, which must agree.  A dispatch of B
+            # boards holds min(B, CUs) CUs (one 151-KB workgroup per CU): frac_of_chip prices it against the whole chip,
+            # frac_of_held_cus against the CUs it holds.  `frac` above is the wall-clock figure with the lanes overlapped.
+            held = min(1.0, boards_per_launch / float(n_cus))
+            per = {'boards': int(boards_per_launch), 'cus_held': int(round(held * n_cus))}
+            if exclusive_ms:
+                ex_tf = flops / (exclusive_ms * 1e-3) / 1e12
+                per.update({'live_avg_us': round(1e3 * exclusive_ms, 2), 'live_frac_of_chip': round(ex_tf / peak, 4),
+                            'live_frac_of_held_cus': round(ex_tf / peak / held, 4)})
+            prof = rocprof_dispatch_us('k_trunk_rowsILi15ELb1ELb0ELb0ELb0E') if (default_config and args.net_algo == 'split_f16') else None
+            if prof and boards_per_launch == 128:
+                pr_tf = flops / (prof[0] * 1e-6) / 1e12
+                per.update({'rocprof_avg_us': round(prof[0], 2), 'rocprof_calls': prof[1], 'rocprof_stats': prof[2],
+                            'rocprof_frac_of_chip': round(pr_tf / peak, 4), 'rocprof_frac_of_held_cus': round(pr_tf / peak / held, 4)})
+            rf['per_dispatch'] = per
             if exclusive_ms and boards_per_launch >= n_cus:   # (a launch of fewer boards than CUs cannot fill the chip by itself)
                 ex = flops / (exclusive_ms * 1e-3) / 1e12
                 rf['exclusive_launch_ms'] = round(exclusive_ms, 4)
@@ -1061,20 +1131,16 @@ def main():
     for eng in engines:
         eng.close()
     if rank == 0:
-        # The schedule without a profiler in the way (rlzero_amd/trace.py): the same layout played once more with the device-side
-        # launch trace attached -- every trunk / tree-step workgroup leaves its start, end and CU -- behind everything that is timed.
-        # launches_in_flight, the CUs' time under trunk workgroups and the lanes' step cycle come from those records, not from a
-        # ratio of averaged event intervals (rocprofv3 serialises the lanes' queues: profiles/r03/trunk_overlap_default.json).
-        if args.timeline and deferred_route and not resident_route and world == 1 and lanes > 1 and args.evaluator == 'hipnet' and 'roofline' in line:
-            try:
-                from rlzero_amd.trace import measure
-                tl = measure(net, board, n_row, n_games=G, n_playout=args.playouts, lanes=lanes, device=device, add_noise=bool(args.noise))
-                line['lane_timeline'] = tl
+        # The schedule without a profiler in the way (rlzero_amd/trace.py): the same layout played by a CHILD process (before this
+        # one touched the GPU) with the device-side launch trace attached -- every trunk / tree-step workgroup leaves its start, end
+        # and CU.  launches_in_flight, the CUs' time under trunk workgroups and the lanes' step cycle come from those records, not
+        # from a ratio of averaged event intervals (rocprofv3 serialises the lanes' queues: profiles/r03/trunk_overlap_default.json).
+        if timeline is not None and deferred_route and not resident_route and lanes > 1 and 'roofline' in line:
+            line['lane_timeline'] = timeline
+            if 'launches_in_flight' in timeline:
                 line['roofline']['launches_in_flight_from_event_averages'] = line['roofline']['launches_in_flight']
-                line['roofline']['launches_in_flight'] = tl['launches_in_flight']
-                line['roofline']['cu_time_in_trunk'] = tl['cu_time_in_trunk']
-            except Exception as exc:  # noqa: BLE001 -- a diagnostic: the measured line is printed whatever happens here
-                line['lane_timeline'] = {'error': '%s: %s' % (type(exc).__name__, str(exc)[:200])}
+                line['roofline']['launches_in_flight'] = timeline['launches_in_flight']
+                line['roofline']['cu_time_in_trunk'] = timeline['cu_time_in_trunk']
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()

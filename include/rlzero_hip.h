@@ -125,6 +125,9 @@ typedef struct rz_stats {
 } rz_stats;
 
 int rz_abi_version(void);
+/* The hash of the sources, headers and flags this library was built from (rlzero_amd/_build.py): the binding refuses a library
+ * whose hash differs from the source tree beside it, and build() recompiles on a hash mismatch, not on file times. */
+const char *rz_source_hash(void);
 const char *rz_last_error(void);
 
 /* Lifetime.  rz_create allocates every buffer up front (nothing is allocated later). */

@@ -92,6 +92,7 @@ P = c_void_p  # device / host pointers and streams travel as integers
 _SIGNATURES = {
     'rz_abi_version': (c_int, []),
     'rz_last_error': (c_char_p, []),
+    'rz_source_hash': (c_char_p, []),
     'rz_create': (c_int, [POINTER(RzConfig), POINTER(c_void_p)]),
     'rz_destroy': (c_int, [P]),
     'rz_geometry': (c_int, [P, POINTER(c_int32), POINTER(c_int32), POINTER(c_int32)]),
@@ -201,6 +202,11 @@ def load():
     got = lib.rz_abi_version()
     if got != ABI_VERSION:
         raise HipError('librlzero_hip.so has ABI %d, binding expects %d: rebuild' % (got, ABI_VERSION))
+    if not os.environ.get('RZ_HIP_LIBRARY'):   # the in-tree build must be the build OF this tree (no stale binary, whatever its file time)
+        from . import _build
+        built, tree = (lib.rz_source_hash() or b'').decode(), _build.source_hash()
+        if built != tree:
+            raise HipError('librlzero_hip.so was built from other sources (hash %s, this tree %s): python -m rlzero_amd._build' % (built, tree))
     _lib = lib
     return lib
 

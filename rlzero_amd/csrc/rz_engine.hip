@@ -1368,6 +1368,14 @@ int launched(const char *what) {
 extern "C" {
 
 int rz_abi_version(void) { return RZ_ABI_VERSION; }
+#ifndef RZ_SOURCE_HASH
+#define RZ_SOURCE_HASH "unknown"   /* rlzero_amd/_build.py passes the hash of sources + headers + flags */
+#endif
+// the marker is what rlzero_amd/_build.py searches the library's bytes for (no need to load it); the accessor returns the hash alone
+const char *rz_source_hash(void) {
+    static const char marker[] = "RZ_SOURCE_HASH=" RZ_SOURCE_HASH;
+    return marker + 15;
+}
 const char *rz_last_error(void) { return g_err; }
 
 int rz_create(const rz_config *cfg, rz_engine **out) {

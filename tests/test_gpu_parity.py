@@ -411,7 +411,8 @@ def test_full_size_shipped_layout_equals_one_plain_lane(n_games, score_mode):
 
 
 def test_whole_games_on_the_shipped_layout_equal_one_plain_lane():
-    """WHOLE games at full size on the layout bench.py times: `BatchedSelfPlay.run(range(640), pipelined=True)` -- four
+    """WHOLE games at full size on the layout bench.py times: `BatchedSelfPlay.run(range(640), pipelined=True)` and
+    `run_device(range(640))` (the move step on the device: what bench.py runs by default) -- four
     co-resident lanes of 128 games, hipGraphs, pipelined moves, finished slots refilled with the ids 512 .. 639 -- at 15x15 / 800
     simulations per move, every game played to its END (the reference's loop: game.py:96-134), against ONE plain lane launched
     kernel by kernel on a sample of 64 of the same ids (first-generation games and refilled ones): moves, pi bits and winners
@@ -427,12 +428,16 @@ def test_whole_games_on_the_shipped_layout_equal_one_plain_lane():
     sample = sample + [511]
     assert len(sample) == 64
 
-    def play(shipped):
+    def play(shipped, device_moves=False):
         kw = {} if shipped else dict(lanes=1, use_graph=False)
         sp = BatchedSelfPlay.for_network(net, 15, 5, n_games=512 if shipped else len(sample), n_playout=sims, seed=5, **kw)
         if shipped:
             assert len(sp.lanes) == 4 and sp.trunk_workgroups == 0 and sp.use_graph
-        out = sp.run(range(n_ids) if shipped else sample, pipelined=shipped)
+        if device_moves:   # the move step on the device, as bench.py times it: the host reads the games from the log
+            out = sp.run_device(range(n_ids))
+            assert sp.stalls_resolved == 0 and sp.sims_done == sims * sum(len(t.moves) for t in out)
+        else:
+            out = sp.run(range(n_ids) if shipped else sample, pipelined=shipped)
         stats = sp.check()
         for st in stats:
             assert st.reuse_dropped == 0, 'a kept subtree exceeded the carry limit: not the reference\'s update_with_move'
@@ -444,6 +449,12 @@ def test_whole_games_on_the_shipped_layout_equal_one_plain_lane():
 
     shipped, used, slots = play(True)
     assert sorted(shipped) == list(range(n_ids))
+    on_device, used_d, _ = play(True, device_moves=True)
+    assert sorted(on_device) == list(range(n_ids)) and used_d == used
+    for g in range(n_ids):   # EVERY game of the device-driven run is the host-driven run's game
+        a, b = shipped[g], on_device[g]
+        assert a.moves == b.moves and a.winner == b.winner, 'game %d depends on where its moves are drawn' % g
+        assert np.array_equal(a.pis.view(np.uint64), b.pis.view(np.uint64))
     plain, _, _ = play(False)
     assert sorted(plain) == sorted(sample)
     lengths = []

@@ -363,3 +363,162 @@ def test_trainer_two_ranks_on_one_gpu(tmp_path):
     # the first round does not depend on the learner: the same games as the single process, id for id
     both = dict(rank0[0]['games'], **rank1[0]['games'])
     assert both == single[0]['games'] and rank0[0]['lanes'][0] == single[0]['lanes'][0]
+
+
+# ------------------------------------------------------------------ 8-GPU readiness without an 8-GPU box
+def _fake_trajectory(gid, board=15, max_plies=None):
+    """A finished game made from its id alone (no search): what the sharding and the gather carry, whatever produced it."""
+    from rlzero_amd.selfplay import Trajectory
+    rs = np.random.RandomState(gid % (2 ** 31))
+    cells = board * board
+    plies = int(rs.randint(9, 40)) if max_plies is None else int(max_plies)
+    moves = rs.permutation(cells)[:plies]
+    pis = rs.random_sample((plies, cells))
+    pis /= pis.sum(axis=1, keepdims=True)
+    return Trajectory(gid, board, 5, moves, pis, int(rs.randint(-1, 2)))
+
+
+def _world8_worker(rank, world, port, n_games, result_path):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import torch
+    import torch.distributed as dist
+    from rlzero_amd.selfplay import gather_trajectories, shard_game_ids
+    torch.set_num_threads(1)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    mine = shard_game_ids(n_games, rank, world)
+    assert len(mine) in (n_games // world, n_games // world + 1) and all(g % world == rank for g in mine)
+    merged = gather_trajectories([_fake_trajectory(g) for g in mine], 15, 5, dst=0, pi_dtype=np.float32)
+    if rank == 0:
+        np.savez(result_path, ids=[t.game_id for t in merged], winners=[t.winner for t in merged],
+                 plies=[len(t.moves) for t in merged], moves=np.concatenate([t.moves for t in merged]),
+                 pi_sum=np.array([float(t.pis.sum()) for t in merged]), pi0=np.stack([t.pis[0] for t in merged[::97]]))
+    else:
+        assert merged is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_games', [4096, 4099])
+def test_world_8_sharding_and_gather_equal_one_process(tmp_path, n_games):
+    """BASELINE configs[3] on the CPU: 4096 game ids over EIGHT gloo ranks (g mod 8: 512 each; 4099: three ranks carry 513), every
+    rank's finished games to rank 0 in the two collectives of the exchange (pi as float32) == the list one process holds."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    result = str(tmp_path / 'w8.npz')
+    mp.spawn(_world8_worker, args=(8, port, n_games, result), nprocs=8, join=True)
+    got = np.load(result)
+    single = [_fake_trajectory(g) for g in range(n_games)]
+    assert got['ids'].tolist() == list(range(n_games))
+    assert got['winners'].tolist() == [t.winner for t in single] and got['plies'].tolist() == [len(t.moves) for t in single]
+    assert got['moves'].tolist() == [m for t in single for m in t.moves]
+    assert np.array_equal(got['pi0'], np.stack([t.pis[0].astype(np.float32).astype(np.float64) for t in single[::97]]))
+    assert np.array_equal(got['pi_sum'], np.array([float(t.pis.astype(np.float32).astype(np.float64).sum()) for t in single]))
+
+
+def _worst_case_worker(rank, world, port, result_path):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import time
+    import torch
+    import torch.distributed as dist
+    from rlzero_amd.selfplay import gather_trajectories
+    torch.set_num_threads(1)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    trajs = [_fake_trajectory(rank + world * i, max_plies=225) for i in range(512)]   # 512 games x 225 plies: a rank's worst case
+    dist.barrier()
+    t0 = time.perf_counter()
+    merged = gather_trajectories(trajs, 15, 5, dst=0, pi_dtype=np.float32)
+    dist.barrier()
+    ms = 1e3 * (time.perf_counter() - t0)
+    if rank == 0:
+        assert len(merged) == 1024 and [t.game_id for t in merged] == list(range(1024)) and all(len(t.moves) == 225 for t in merged)
+        for t in merged[::101]:
+            want = _fake_trajectory(t.game_id, max_plies=225)
+            assert t.moves == want.moves and np.array_equal(t.pis, want.pis.astype(np.float32).astype(np.float64))
+        payload = 512 * 32 + 512 * 225 * (8 + 4 * 225)
+        open(result_path, 'w').write('%d %.1f' % (payload, ms))
+    dist.destroy_process_group()
+
+
+def test_gather_at_the_worst_case_payload(tmp_path):
+    """ONE exchange at the largest payload a rank of configs[3] can hold -- 512 games x 225 plies, pi as float32: 104.6 MB per
+    rank (SURVEY.md 8e sizes it at ~112 MB) -- through the size row + the single payload gather; time printed (gloo over
+    loopback here; RCCL over xGMI moves it in about a millisecond per link)."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    result = str(tmp_path / 'worst.txt')
+    mp.spawn(_worst_case_worker, args=(2, port, result), nprocs=2, join=True)
+    payload, ms = open(result).read().split()
+    assert int(payload) == 512 * 32 + 512 * 225 * (8 + 4 * 225) == 104_617_984
+    print('worst-case gather: %s bytes per rank, two gloo ranks, %s ms' % (payload, ms))
+
+
+def test_rank_affinity_from_sysfs(tmp_path):
+    """rlzero_amd.affinity: a rank's cores = the cores local to ITS GPU's NUMA node, taken from sysfs alone (KFD topology order =
+    HIP device order), split evenly among the ranks that share the node; nothing is pinned when sysfs says nothing."""
+    from rlzero_amd import affinity
+    root = tmp_path / 'sys'
+    nodes = root / 'class' / 'kfd' / 'kfd' / 'topology' / 'nodes'
+    # two CPU nodes, then eight GPUs: the first four on NUMA node 0 (cores 0-63), the others on node 1 (64-127)
+    for n in range(10):
+        d = nodes / str(n)
+        d.mkdir(parents=True)
+        gpu = n >= 2
+        (d / 'properties').write_text('cpu_cores_count %d\nsimd_count %d\ndrm_render_minor %d\n' % (0 if gpu else 64, 1024 if gpu else 0,
+                                                                                                   128 + n - 2 if gpu else 0))
+        if gpu:
+            dev = root / 'class' / 'drm' / ('renderD%d' % (128 + n - 2)) / 'device'
+            dev.mkdir(parents=True)
+            node = 0 if n - 2 < 4 else 1
+            (dev / 'numa_node').write_text('%d\n' % node)
+            (dev / 'local_cpulist').write_text('0-63\n' if node == 0 else '64-127\n')
+    sysfs = str(root)
+    assert affinity.parse_cpulist('0-3,8,10-11') == [0, 1, 2, 3, 8, 10, 11] and affinity.format_cpulist([0, 1, 2, 3, 8, 10, 11]) == '0-3,8,10-11'
+    gpus = affinity.gpu_numa_nodes(sysfs)
+    assert [g[0] for g in gpus] == [0, 0, 0, 0, 1, 1, 1, 1] and gpus[5][1] == list(range(64, 128))
+    allowed = list(range(128))
+    plans = [affinity.plan(r, list(range(8)), allowed, sysfs, env={}) for r in range(8)]
+    assert [p['numa_node'] for p in plans] == [0, 0, 0, 0, 1, 1, 1, 1]
+    assert [affinity.format_cpulist(p['cpus']) for p in plans] == ['0-15', '16-31', '32-47', '48-63', '64-79', '80-95', '96-111', '112-127']
+    # one rank alone keeps its whole node; a restricted affinity mask is respected; visible-device lists re-map the ordinals
+    assert affinity.plan(5, [5], allowed, sysfs, env={})['cpus'] == list(range(64, 128))
+    assert affinity.plan(0, [0, 1], list(range(0, 64, 2)), sysfs, env={})['cpus'] == list(range(0, 32, 2))
+    assert affinity.plan(0, [0], allowed, sysfs, env={'HIP_VISIBLE_DEVICES': '6,7'})['numa_node'] == 1
+    assert affinity.plan(9, [9], allowed, sysfs, env={}) is None
+    rec = affinity.pin_to_gpu(2, local_world=8, sysfs=sysfs, env={}, apply=False)
+    here = sorted(os.sched_getaffinity(0))   # (this host has fewer cores than the fake node: its share of what both have)
+    local = [c for c in range(64) if c in here]
+    want = local[2 * (len(local) // 4):3 * (len(local) // 4)] if len(local) >= 4 else local
+    assert rec['pinned'] is False and (rec['cpus'] == affinity.format_cpulist(want) if local else 'why' in rec)
+    assert sorted(os.sched_getaffinity(0)) == here   # apply=False changes nothing
+    assert affinity.pin_to_gpu(0, sysfs=str(tmp_path / 'nothing'), apply=False)['pinned'] is False
+
+
+@pytest.mark.gpu
+def test_bench_six_ranks_on_one_gpu():
+    """The N-rank path with more than two ranks, on a 1-GPU box: `bench.py --gpus 6` with its ranks sharing cuda:0 over gloo, 64 games
+    per rank (SIX, not eight: a GPU box of this pool admits at most six processes on its card at once; the eight-rank run is the
+    driver's, on an eight-GPU node).  Six entries of per-rank rates, every gathered game id unique and dealt g mod 6, the two
+    collectives of the exchange, every rank's host affinity on the line."""
+    import json
+    import subprocess
+    env = dict(os.environ, RZ_BENCH_SINGLE_DEVICE='1', RZ_BENCH_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '6', '--games', '64', '--steps', '2', '--warmup', '1', '--board', '9',
+           '--playouts', '40', '--regions', '1', '--no-cpu-baseline', '--no-literal-config', '--no-configs']
+    out = subprocess.run(cmd, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    rec = json.loads([ln for ln in out.stdout.decode().splitlines() if ln.startswith('{')][-1])
+    assert rec['n_gpus'] == 6 and rec['config']['games_total'] == 384
+    assert len(rec['per_rank_sims_per_sec']) == 6 and min(rec['per_rank_sims_per_sec']) > 0
+    tg = rec['trajectory_gather']
+    assert tg['ranks'] == 6 and tg['unique_game_ids'] and tg['collectives_per_exchange'] == 2 and tg['games'] >= 6 * 64
+    assert len(rec['host_affinity']) == 6 and all('pinned' in a for a in rec['host_affinity'])

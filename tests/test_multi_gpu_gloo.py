@@ -502,23 +502,24 @@ def test_rank_affinity_from_sysfs(tmp_path):
 
 
 @pytest.mark.gpu
-def test_bench_six_ranks_on_one_gpu():
-    """The N-rank path with more than two ranks, on a 1-GPU box: `bench.py --gpus 6` with its ranks sharing cuda:0 over gloo, 64 games
-    per rank (SIX, not eight: a GPU box of this pool admits at most six processes on its card at once; the eight-rank run is the
-    driver's, on an eight-GPU node).  Six entries of per-rank rates, every gathered game id unique and dealt g mod 6, the two
-    collectives of the exchange, every rank's host affinity on the line."""
+def test_bench_four_ranks_on_one_gpu():
+    """The N-rank path with more than two ranks, on a 1-GPU box: `bench.py --gpus 4` with its ranks sharing cuda:0 over gloo, 64 games
+    per rank (FOUR, not eight: a GPU box of this pool admits at most six processes on its card at once, and the test runner itself
+    is one of them -- six ranks were tried and the box's process guard ended the run; the eight-rank run is the driver's, on an
+    eight-GPU node, and the world-8 sharding + gather is covered on the CPU above).  Four entries of per-rank rates, every gathered
+    game id unique, the two collectives of the exchange, every rank's host affinity on the line."""
     import json
     import subprocess
     env = dict(os.environ, RZ_BENCH_SINGLE_DEVICE='1', RZ_BENCH_BACKEND='gloo')
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '6', '--games', '64', '--steps', '2', '--warmup', '1', '--board', '9',
+    cmd = [sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '4', '--games', '64', '--steps', '2', '--warmup', '1', '--board', '9',
            '--playouts', '40', '--regions', '1', '--no-cpu-baseline', '--no-literal-config', '--no-configs']
     out = subprocess.run(cmd, env=env, cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     rec = json.loads([ln for ln in out.stdout.decode().splitlines() if ln.startswith('{')][-1])
-    assert rec['n_gpus'] == 6 and rec['config']['games_total'] == 384
-    assert len(rec['per_rank_sims_per_sec']) == 6 and min(rec['per_rank_sims_per_sec']) > 0
+    assert rec['n_gpus'] == 4 and rec['config']['games_total'] == 256
+    assert len(rec['per_rank_sims_per_sec']) == 4 and min(rec['per_rank_sims_per_sec']) > 0
     tg = rec['trajectory_gather']
-    assert tg['ranks'] == 6 and tg['unique_game_ids'] and tg['collectives_per_exchange'] == 2 and tg['games'] >= 6 * 64
-    assert len(rec['host_affinity']) == 6 and all('pinned' in a for a in rec['host_affinity'])
+    assert tg['ranks'] == 4 and tg['unique_game_ids'] and tg['collectives_per_exchange'] == 2 and tg['games'] >= 4 * 64
+    assert len(rec['host_affinity']) == 4 and all('pinned' in a for a in rec['host_affinity'])

@@ -3262,6 +3262,10 @@ int rz_net_deferred_reserve(rz_net *net, int32_t max_boards, int32_t slots) {
     if (rc != RZ_OK) return rc;
     if (slots < 1 || max_boards < 1) return net_fail(RZ_ERR_ARG, "rz_net_deferred_reserve: slots and max_boards must be positive");
     if (max_boards <= net->store_boards && slots <= net->store_slots) return RZ_OK;
+    // grow to the larger of what is held and what is asked in BOTH directions: an engine that reserved more boards (or slots)
+    // earlier keeps fitting when another one asks for more of the other
+    if (max_boards < net->store_boards) max_boards = net->store_boards;
+    if (slots < net->store_slots) slots = net->store_slots;
     (void)hipDeviceSynchronize();
     if (net->d_store16) (void)hipFree(net->d_store16);
     if (net->d_store_raw) (void)hipFree(net->d_store_raw);

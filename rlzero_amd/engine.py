@@ -141,7 +141,14 @@ class HipNet(object):
         return tiles * k_steps * 2048 + tiles * 32 * n_pad * 4
 
     def deferred_reserve(self, n_boards, slots):
+        """-> True when the store was (re)allocated (rz_net_deferred_reserve grows it when either number exceeds what it holds): device
+        addresses captured in hipGraphs before that are stale."""
+        have = getattr(self, '_store', (0, 0))
         check(self.lib.rz_net_deferred_reserve(self.handle, int(n_boards), int(slots)), 'rz_net_deferred_reserve')
+        moved = int(n_boards) > have[0] or int(slots) > have[1]
+        if moved:
+            self._store = (max(have[0], int(n_boards)), max(have[1], int(slots)))
+        return moved and have != (0, 0)
 
     def trunk_leaves_deferred(self, eng):
         """The trunk on the engine's current leaves: policy features into the store slot of each game, the value head's
@@ -593,8 +600,10 @@ class MCTSEngine(object):
     # ------------------------------------------------------------------ the hot loop
     def sim_step(self, evaluator):
         """One simulation for every active game (enqueued, not synchronised)."""
-        if self.sims_in_flight > 1:
-            return self.sim_chunk(evaluator, 1)
+        ok = getattr(evaluator, 'deferred_ok', None)
+        if self.sims_in_flight > 1 or (ok is not None and ok(self)):
+            return self.sim_chunk(evaluator, 1)   # (the deferred route's store bookkeeping lives there)
+        self.flush_deferred()
         obs = _ptr(self.obs) if getattr(evaluator, 'needs_obs', True) else None
         check(self.lib.rz_select_step(self.handle, obs, self.stream()), 'rz_select_step')
         logp, value = evaluator(self)
@@ -690,11 +699,18 @@ class MCTSEngine(object):
             hip = evaluator.hip
             per_slot = hip.deferred_bytes_per_slot(self.n_leaves) + 80 * self.n_games
             slots = int(max(16, min(max(self.n_playout, 16), self.deferred_max_bytes // per_slot)))
+            if self._capturing:
+                raise HipError('the deferred-priors store must be reserved before a hipGraph capture (warm_graph does that)')
             if slots > self._def_slots:
                 check(self.lib.rz_deferred_reserve(self.handle, slots), 'rz_deferred_reserve')
                 self._def_slots = slots
                 self._def_slot_ptr = None
-            hip.deferred_reserve(self.n_leaves, self._def_slots)
+                self._drop_graphs('rz_deferred_reserve moved the pending records')
+            if hip.deferred_reserve(self.n_leaves, self._def_slots):
+                # the evaluator's store moved (a larger engine took it over): every engine's captured launches of this evaluator
+                # hold the old addresses
+                for other in list(getattr(evaluator, '_deferring', ())) + [self]:
+                    other._drop_graphs('rz_net_deferred_reserve moved the feature store')
             self._def_ev = evaluator
             refs = getattr(evaluator, '_deferring', None)
             if refs is None:
@@ -706,6 +722,13 @@ class MCTSEngine(object):
         if self._def_pending + min(n, self._def_slots) > self._def_slots:
             self.flush_deferred()
         return min(n, self._def_slots - self._def_pending)
+
+    def _drop_graphs(self, why):
+        """Captured launches hold device addresses by value: when a reservation moves a buffer they replay into freed memory.  The
+        graphs are dropped; simulate(use_graph=True) then says to call warm_graph again."""
+        if self._graphs:
+            self._graphs = {}
+            self._graphs_dropped = why
 
     def _sim_chunk_deferred(self, evaluator, n):
         """sim_chunk on the deferred-priors route: per step the trunk (policy features into the step's store slot, value inputs
@@ -720,6 +743,7 @@ class MCTSEngine(object):
                 evaluator.search_resident(self, m)
                 if not self._capturing:
                     self._def_pending += m
+                    self._def_stream = self.torch.cuda.current_stream(self.device)
                 n -= m
                 continue
             for i in range(m):
@@ -730,6 +754,7 @@ class MCTSEngine(object):
                     check(lib.rz_expand_backup_deferred(h, ctypes.byref(head), self.stream()), 'rz_expand_backup_deferred')
             if not self._capturing:
                 self._def_pending += m
+                self._def_stream = self.torch.cuda.current_stream(self.device)
             n -= m
 
     def flush_deferred(self):
@@ -737,8 +762,15 @@ class MCTSEngine(object):
         whatever reads priors or moves trees (advance, set_roots, root_priors, arena) and when the store is full."""
         if self._def_pending <= 0 or self._def_ev is None:
             return
+        # the pending steps were enqueued on _def_stream; a caller on another stream (a direct engine user, a read-out from the
+        # default stream while a lane searches) gets the flush ordered behind them, and their stream behind the flush
+        cur, then = self.torch.cuda.current_stream(self.device), getattr(self, '_def_stream', None)
+        if then is not None and then != cur:
+            cur.wait_stream(then)
         logits = self._def_ev.hip.deferred_gemm(self.n_leaves, self._def_pending)
         check(self.lib.rz_deferred_flush(self.handle, ctypes.byref(logits), self._def_pending, self.stream()), 'rz_deferred_flush')
+        if then is not None and then != cur:
+            then.wait_stream(cur)
         self._def_pending = 0
 
     def _whole_steps(self, n_sims):
@@ -774,7 +806,8 @@ class MCTSEngine(object):
             return
         key = (id(evaluator), per)
         if key not in self._graphs:
-            raise HipError('call warm_graph(evaluator, %d) before simulate(use_graph=True)' % per)
+            why = getattr(self, '_graphs_dropped', None)
+            raise HipError('call warm_graph(evaluator, %d) before simulate(use_graph=True)%s' % (per, ' (the graphs were dropped: %s)' % why if why else ''))
         graph = self._graphs[key][0]
         full, rest = divmod(n, per)
         ok = getattr(evaluator, 'deferred_ok', None)
@@ -784,6 +817,7 @@ class MCTSEngine(object):
                 if self._deferred_begin(evaluator, per) < per:
                     raise HipError('the deferred-priors store (%d slots) is smaller than a graph of %d steps' % (self._def_slots, per))
                 self._def_pending += per
+                self._def_stream = self.torch.cuda.current_stream(self.device)
             graph.replay()
         self.sim_chunk(evaluator, rest)
 

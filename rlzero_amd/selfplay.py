@@ -206,6 +206,57 @@ def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False, cells=None, i
     return 2, 0, 'parts'
 
 
+# ------------------------------------------------------------------------- lanes by measurement
+# plan_lanes() is a table measured on ONE chip (MI355X, 256 CUs, 8 hardware queues) for the reference's network: its thresholds are
+# in units of that chip's CUs and its neighbouring choices differ by up to 15 %.  Anywhere else -- a partition of the GPU with
+# fewer CUs, another chip -- the table's pick is only the starting point: the two or three neighbouring layouts are built, timed
+# for two moves each and the fastest is kept, once per (device, CUs, board, batch, search) in this process.
+TABLE_CUS = 256
+_LANE_CACHE = {}
+
+
+def lane_candidates(table_pick, hw_queues, n_games):
+    """The layouts worth timing around the table's pick: one lane fewer, the pick, one more (four lanes need 8 hardware queues)."""
+    most = min(4 if hw_queues >= 8 else 3, max(1, n_games))
+    return sorted({min(most, max(1, table_pick - 1)), min(most, max(1, table_pick)), min(most, table_pick + 1)})
+
+
+def time_moves(sp, moves=2):
+    """Simulations / second of ``sp`` over ``moves`` moves of fresh games (one more move first, un-timed), the move step on the device."""
+    import time
+    t = sp.torch
+    sp.device_attach(queue_capacity=4 * sp.n_slots)
+    sp.device_queue(range(4 * sp.n_slots))
+    sp.play_move_device()
+    t.cuda.synchronize()
+    sp.device_drain()
+    s0, t0 = sp.sims_done, time.perf_counter()
+    for _ in range(moves):
+        sp.play_move_device()
+    t.cuda.synchronize()
+    sp.device_drain()
+    return (sp.sims_done - s0) / (time.perf_counter() - t0)
+
+
+def choose_lanes_by_measurement(key, table_pick, hw_queues, n_games, build, timer=time_moves, cache=None):
+    """-> (lanes, {lanes: simulations / s}) for ``key``: every candidate layout is built by ``build(lanes)`` (-> a BatchedSelfPlay),
+    timed by ``timer(sp)`` and closed; the fastest wins, ties go to fewer lanes.  Cached by ``key``."""
+    cache = _LANE_CACHE if cache is None else cache
+    if key in cache:
+        return cache[key]
+    rates = {}
+    for lanes in lane_candidates(table_pick, hw_queues, n_games):
+        sp = build(lanes)
+        try:
+            rates[lanes] = float(timer(sp))
+        finally:
+            for lane in getattr(sp, 'lanes', ()):
+                lane.eng.close()
+    best = max(sorted(rates), key=lambda c: (rates[c], -c))
+    cache[key] = (best, rates)
+    return cache[key]
+
+
 def fc_in_trunk_pays(rows, cols, n_actions):
     """True when the trunk's workgroups should run the first FC layers on their own boards (HipNet.set_heads_algo('in_trunk'))
     instead of a GEMM launch of its own: boards of up to 10 rows whose FC weights (hi + lo f16) are at most 40 KB -- every workgroup
@@ -283,6 +334,9 @@ class BatchedSelfPlay(object):
         ``lanes`` / ``trunk_workgroups`` are given (more than four lanes take turns on the GPU's four compute pipes, and four need
         GPU_MAX_HW_QUEUES >= 8: profiles/r03/lane_sweeps.txt).  ``add_noise``: Dirichlet noise on the priors of every expanded
         node, what ``AlphaZeroPlayer(is_selfplay=True)`` does (alphazero_mcts.py:124-129, node.py:63-69).
+        ``lanes``: None = the table (plan_lanes) on the chip it was measured on, the measuring fallback elsewhere (another CU count:
+        the table's pick and its neighbours are built and timed for two moves each, choose_lanes_by_measurement); 'measure' forces the
+        measurement, 'table' the table; an int is taken as given.
         ``sims_in_flight`` = K > 1: the opt-in virtual-loss mode (MCTSEngine), for batches too small to fill the GPU
         with one leaf per game; the evaluator batch of a lane is then its games x K.  ``deferred_priors``: None = the deferred-priors
         route wherever it exists (HipNetEvaluator.deferred_ok), False = the three-launch step everywhere; ``resident_search`` likewise for
@@ -304,6 +358,21 @@ class BatchedSelfPlay(object):
                        and net_algo in (None, 'split_f16', 'split_f16_tiles'))   # (the two-launch step on a small board)
         auto_lanes, auto_wgs, heads_algo = plan_lanes(n_games * K, n_cus, deferred=deferred,
                                                       cells=rows0 * cols0 if (small_trunk or K > 1) else None, in_flight=K)
+        measured = None
+        if lanes == 'table':
+            lanes = None
+        elif lanes == 'measure' or (lanes is None and n_cus != TABLE_CUS and n_games * K > n_cus):
+            # off the table's chip (or asked for): the table's pick and its neighbours, timed for two moves each
+            from . import HW_QUEUES
+            key = (torch.cuda.get_device_name(dev), n_cus, rows0, cols0, game, n_games, n_playout, K, bool(deferred), str(net_algo))
+
+            def build(n_lanes):
+                return cls.for_network(net_module, board, n_in_row, n_games, n_playout, c_puct=c_puct, device=device, game=game,
+                                       net_shape=net_shape, lanes=n_lanes, trunk_workgroups=trunk_workgroups, temperature=temperature,
+                                       seed=seed, use_graph=use_graph, sims_per_graph=sims_per_graph, add_noise=add_noise,
+                                       sims_in_flight=sims_in_flight, deferred_priors=deferred_priors, resident_search=resident_search,
+                                       net_algo=net_algo, **engine_kw)
+            lanes, measured = choose_lanes_by_measurement(key, auto_lanes, HW_QUEUES, n_games, build)
         if lanes is None:
             lanes, wgs = auto_lanes, auto_wgs
         else:
@@ -337,6 +406,7 @@ class BatchedSelfPlay(object):
                  temperature=temperature, seed=seed, use_graph=use_graph, sims_per_graph=sims_per_graph,
                  eager_every=eager_every)
         sp.trunk_workgroups = int(wgs)
+        sp.lanes_measured = measured   # {lanes: simulations / s} when the layout was chosen by measurement, else None
         if before_warm is not None:
             before_warm(sp)
         sp.warm_graphs()

@@ -302,3 +302,79 @@ def test_two_engines_sharing_one_evaluator():
         a.close()
         b.close()
     assert trees[True] == trees[False]
+
+
+def test_a_store_that_moves_drops_the_graphs_captured_on_it():
+    """hipGraphs hold device addresses by value.  Engine A (5 games, 60 simulations) captures its steps on a shared evaluator; engine
+    B (3 games, 140 simulations) then needs more store slots: rz_net_deferred_reserve grows the store -- in BOTH directions, A's five
+    boards keep fitting -- and A's graphs are dropped, not replayed into freed memory: simulate(use_graph=True) says so, a new
+    warm_graph captures against the new store, and the trees are those of an engine that never shared anything."""
+    from rlzero_amd._hip import HipError
+    from rlzero_amd.engine import HipNetEvaluator, MCTSEngine
+    B, n = 13, 5
+    net = _net(B, seed=12)
+    envs = _positions(B, n, 5, seed=3)
+    shared = HipNetEvaluator(net, B, 'cuda:0', max_boards=8)
+    shared.resident_search = False
+    a = MCTSEngine(B, n, n_games=len(envs), n_playout=60, device='cuda:0', add_noise=True, noise_seed=2)
+    b = MCTSEngine(B, n, n_games=3, n_playout=140, device='cuda:0', add_noise=True, noise_seed=3)
+    a.reset_games()
+    a.warm_graph(shared, 16)
+    assert len(a._graphs) == 1
+    _set_roots(a, envs)
+    a.set_noise_keys()
+    a.simulate(shared, 32, use_graph=True, sims_per_graph=16)
+    _set_roots(b, envs[:3])
+    b.sim_chunk(shared, 140)   # (A's pending leaves are flushed, then the store grows to 140 slots)
+    assert a._def_pending == 0 and b._def_pending == 140 and not a._graphs
+    with pytest.raises(HipError, match='graphs were dropped'):
+        a.simulate(shared, 16, use_graph=True, sims_per_graph=16)
+    a.flush_deferred()
+    b.flush_deferred()
+    a.warm_graph(shared, 16)   # (captures nothing into the trees: the warm-up's simulations are part of what is compared below)
+    a.simulate(shared, 16, use_graph=True, sims_per_graph=16)
+    got = [_whole_tree(a, g) for g in range(len(envs))]
+    # the same sequence on an evaluator of its own: 32 simulations, then the 3 of the second warm-up, then 16
+    own = HipNetEvaluator(net, B, 'cuda:0', max_boards=8)
+    own.resident_search = False
+    c = MCTSEngine(B, n, n_games=len(envs), n_playout=60, device='cuda:0', add_noise=True, noise_seed=2)
+    _set_roots(c, envs)
+    c.set_noise_keys()
+    c.sim_chunk(own, 32 + 3 + 16)
+    assert got == [_whole_tree(c, g) for g in range(len(envs))]
+    for e_ in (a, b, c):
+        e_.check()
+        e_.close()
+    shared.hip.close()
+    own.hip.close()
+
+
+def test_a_flush_from_another_stream_waits_for_the_pending_steps():
+    """The pending steps of a search live on the stream they were enqueued on; a read-out from another stream (here the default
+    stream, while the lane's stream still holds the search) flushes behind them: the priors are those of a search read on its own stream."""
+    import torch
+    from rlzero_amd.engine import HipNetEvaluator, MCTSEngine
+    B, n = 15, 5
+    net = _net(B, seed=13)
+    envs = _positions(B, n, 6, seed=5)
+    out = []
+    for other_stream in (True, False):
+        evaluator = HipNetEvaluator(net, B, 'cuda:0', max_boards=len(envs))
+        evaluator.resident_search = False
+        eng = MCTSEngine(B, n, n_games=len(envs), n_playout=200, device='cuda:0', add_noise=True, noise_seed=7)
+        _set_roots(eng, envs)
+        eng.set_noise_keys()
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            eng.sim_chunk(evaluator, 200)   # ~10 ms of launches: still running when the read-out below is enqueued
+            if not other_stream:
+                pri = eng.root_priors().copy()
+        if other_stream:
+            pri = eng.root_priors().copy()   # (current stream = the default stream)
+        torch.cuda.synchronize()
+        out.append((pri, [_whole_tree(eng, g) for g in range(len(envs))]))
+        eng.check()
+        eng.close()
+        evaluator.hip.close()
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32)) and out[0][1] == out[1][1]

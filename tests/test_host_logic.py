@@ -136,6 +136,65 @@ def test_plan_lanes():
     assert plan_lanes(2048, hw_queues=8, cells=225, in_flight=16)[0] == 2   # (15x15 keeps the table)
 
 
+def test_lanes_by_measurement_fallback():
+    """Off the table's chip the layout is measured: the table's pick and its neighbours are built, timed (a fake timer here) and
+    closed, the fastest wins (ties: fewer lanes), the answer is cached per key."""
+    from rlzero_amd import selfplay as sp_mod
+    assert sp_mod.lane_candidates(4, 8, 512) == [3, 4] and sp_mod.lane_candidates(2, 8, 512) == [1, 2, 3]
+    assert sp_mod.lane_candidates(3, 4, 512) == [2, 3] and sp_mod.lane_candidates(1, 8, 512) == [1, 2] and sp_mod.lane_candidates(2, 8, 1) == [1]
+    built, closed = [], []
+
+    class FakeEngine(object):
+        def __init__(self, tag):
+            self.tag = tag
+
+        def close(self):
+            closed.append(self.tag)
+
+    class FakeLane(object):
+        def __init__(self, tag):
+            self.eng = FakeEngine(tag)
+
+    class FakeSp(object):
+        def __init__(self, n):
+            self.lanes = [FakeLane((n, i)) for i in range(n)]
+
+    def build(n):
+        built.append(n)
+        return FakeSp(n)
+
+    cache = {}
+    rates = {1: 5.0, 2: 9.0, 3: 9.0, 4: 7.0}
+    best, seen = sp_mod.choose_lanes_by_measurement(('gfx', 128, 15), 2, 8, 256, build, timer=lambda sp: rates[len(sp.lanes)], cache=cache)
+    assert best == 2 and seen == {1: 5.0, 2: 9.0, 3: 9.0} and built == [1, 2, 3]      # the tie between 2 and 3 goes to fewer lanes
+    assert sorted(closed) == [(1, 0), (2, 0), (2, 1), (3, 0), (3, 1), (3, 2)]          # every timed layout was closed
+    again = sp_mod.choose_lanes_by_measurement(('gfx', 128, 15), 2, 8, 256, build, timer=lambda sp: 0.0, cache=cache)
+    assert again == (2, seen) and built == [1, 2, 3]                                    # cached: nothing built again
+    best, seen = sp_mod.choose_lanes_by_measurement(('gfx', 128, 9), 3, 8, 256, build, timer=lambda sp: rates[len(sp.lanes)], cache=cache)
+    assert best == 2 and sorted(seen) == [2, 3, 4]
+
+    def failing(sp):
+        raise RuntimeError('timer failed')
+    del closed[:]
+    with pytest.raises(RuntimeError):
+        sp_mod.choose_lanes_by_measurement(('other', ), 1, 8, 64, build, timer=failing, cache=cache)
+    assert closed == [(1, 0)] and ('other', ) not in cache                              # closed even then, nothing cached
+    assert sp_mod.TABLE_CUS == 256
+
+
+def test_human_player_asks_until_the_move_is_legal(capsys):
+    """rlzero/mcts/player.py:33-57: "row,col" from the console, asked again after nonsense, an occupied cell or a cell off the board."""
+    from rlzero_amd.mcts import HumanPlayer
+    env = GomokuEnv(3, 3)
+    env.reset()
+    env.step(4)
+    answers = iter(['x', '1,1', '9,9', '2,0'])
+    human = HumanPlayer(player_id=1, player_name='me', ask=lambda prompt: next(answers))
+    assert human.can_click and human.get_action(env) == env.location_to_move([2, 0])
+    assert capsys.readouterr().out.count('invalid move') == 3 and str(human) == 'HumanPlayer, id: 1, name me.'
+    human.reset_player()
+
+
 def test_hw_queues_are_claimed_on_import():
     """rlzero_amd sets GPU_MAX_HW_QUEUES before the HIP runtime starts (unless the caller chose a value) and remembers what holds."""
     import subprocess

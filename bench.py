@@ -279,9 +279,11 @@ def run_fill_config(args):
 
 # the other configurations of BASELINE.json, each measured by a child process of the default N = 1 run
 CONFIG_LEGS = (  # (key, flags, seconds of CPU baseline at --cpu-seconds 60); a leg starts on a GPU that has idled: warm-up moves
-    ('C1_ttt_25sims_1game', ['--board', 3, '--playouts', 25, '--games', 1, '--lanes', 1, '--steps', 9, '--warmup', 20], 5.0),
-    ('C1_16games', ['--board', 3, '--playouts', 25, '--games', 16, '--lanes', 1, '--steps', 9, '--warmup', 20, '--no-cpu-baseline'], 0.0),
-    ('C2_9x9_200sims_64games', ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 8, '--warmup', 8], 12.0),
+    # (a TicTacToe move is a third of a millisecond: regions of 180 moves = 20+ whole games per slot, so that the fence of a region --
+    # synchronize, then the host reads the last moves' log rows -- is not most of what is timed; finished slots refill on the device)
+    ('C1_ttt_25sims_1game', ['--board', 3, '--playouts', 25, '--games', 1, '--lanes', 1, '--steps', 180, '--warmup', 20], 5.0),
+    ('C1_16games', ['--board', 3, '--playouts', 25, '--games', 16, '--lanes', 1, '--steps', 180, '--warmup', 20, '--no-cpu-baseline'], 0.0),
+    ('C2_9x9_200sims_64games', ['--board', 9, '--playouts', 200, '--games', 64, '--lanes', 1, '--steps', 32, '--warmup', 8], 12.0),
     ('C2_16_in_flight', ['--board', 9, '--playouts', 200, '--games', 64, '--steps', 8, '--warmup', 8, '--in-flight', 16,   # (1024 leaves: two lanes)
                          '--no-cpu-baseline'], 0.0),
     ('C3_connect4_400sims_512games', ['--game', 'connect4', '--playouts', 400, '--games', 512, '--steps', 6, '--warmup', 6], 12.0),
@@ -392,8 +394,8 @@ class TimedEvaluator(object):
         ok = getattr(self.inner, 'resident_ok', None)
         return ok is not None and ok(eng)
 
-    def search_resident(self, eng, n_sims):
-        return self.inner.search_resident(eng, n_sims)
+    def search_resident(self, eng, n_sims, select_first=False):
+        return self.inner.search_resident(eng, n_sims, select_first)
 
     def deferred_trunk(self, eng):
         """Deferred-priors route (two launches per step): the trunk bracketed when recording; the event behind it and the

@@ -370,8 +370,9 @@ int rz_play_attach(rz_engine *e, const rz_play_config *cfg);
 /* After the search of a move, BEFORE rz_deferred_flush: read the root visits into the log, draw (or stall, or take a resolved
  * move).  One launch. */
 int rz_play_draw(rz_engine *e, void *stream);
-/* Then: rz_advance_roots + rz_step_games with the moves just drawn, the end of finished games and the refill of idle slots
- * (rz_play_apply without a draw before it only refills: how a run starts).  Three launches. */
+/* Then, in ONE launch (a wave per slot): update_with_move + env.step + game_end_winner with the moves just drawn, the end of finished
+ * games and the refill of idle slots (rz_play_apply without a draw before it only refills: how a run starts).  A
+ * rz_deferred_flush between the two calls leaves the restart of the pending-priors counters to this launch. */
 int rz_play_apply(rz_engine *e, void *stream);
 /* The host's decision for a stalled slot (one tiny launch); taken by the next rz_play_draw. */
 int rz_play_resolve(rz_engine *e, int32_t slot, int32_t move, void *stream);
@@ -509,15 +510,16 @@ int rz_net_trace_attach(rz_net *net, void *d_trace);   /* see rz_trace_attach */
 /* RESIDENT SEARCH -- n_sims consecutive simulations of every active game of `engine` (AlphaZeroMCTS.simulate's loop,
  * alphazero_mcts.py:82-85) in ONE launch, one workgroup per game: trunk -> value head -> expand / backup -> next selection without
  * a kernel boundary, the leaf handed from the tree code to the trunk through LDS.  For batches of at most one game per CU (the
- * single-game API, BASELINE configs[0] and [1]).  The deferred-priors route's arithmetic and bookkeeping: pair with
- * rz_select_step(engine, NULL, ..) before (the first leaf) and rz_net_deferred_gemm + rz_deferred_flush later; the engine's slots
- * advance by n_sims.  Same trees, values and priors as rz_net_trunk_leaves_deferred + rz_tree_step_deferred, bit for bit.
+ * single-game API, BASELINE configs[0] and [1]).  The deferred-priors route's arithmetic and bookkeeping: the first leaf comes from
+ * rz_select_step(engine, NULL, ..) before the call (select_first == 0: a search continued in pieces) or is selected by the launch
+ * itself (select_first != 0: the same selection by the same code, one launch less); rz_net_deferred_gemm + rz_deferred_flush later;
+ * the engine's slots advance by n_sims.  Same trees, values and priors as rz_net_trunk_leaves_deferred + rz_tree_step_deferred, bit for bit.
  * CONTRACT: game g's leaves go to store slots pend[g] .. pend[g] + n_sims - 1 (pend[g] = its steps since the last
  * rz_deferred_flush), so pend[g] + n_sims must not exceed the slots of rz_net_deferred_reserve / rz_deferred_reserve: flush first.
  * n_sims beyond either capacity is refused (RZ_ERR_ARG); a leaf whose slot still lies beyond the store (a caller that did not
  * flush) is not written anywhere and its game is flagged RZ_FLAG_INTERNAL by the tree code -- never an out-of-bounds write.
  * The same holds for rz_net_trunk_leaves_deferred (slot d_slot_of_board[b]). */
-int rz_net_search_resident(rz_net *net, rz_engine *engine, int32_t n_sims, void *stream);
+int rz_net_search_resident(rz_net *net, rz_engine *engine, int32_t n_sims, int32_t select_first, void *stream);
 int rz_net_heads(rz_net *net, int32_t n_boards, float *d_logp, float *d_value, void *stream);
 /* only the FC GEMM of the heads on the internal features; returns the device pointers that
  * rz_tree_step_raw / rz_expand_backup_raw consume (valid until the next rz_net_reserve / load) */

@@ -155,7 +155,7 @@ _SIGNATURES = {
     'rz_net_deferred_reserve': (c_int, [P, c_int32, c_int32]),
     'rz_net_trunk_leaves_deferred': (c_int, [P, P, P, P, c_int32, P, POINTER(RzValueHead), P]),
     'rz_net_deferred_gemm': (c_int, [P, c_int32, c_int32, POINTER(RzDeferredLogits), P]),
-    'rz_net_search_resident': (c_int, [P, P, c_int32, P]),
+    'rz_net_search_resident': (c_int, [P, P, c_int32, c_int32, P]),
     'rz_net_heads': (c_int, [P, c_int32, P, P, P]),
     'rz_net_heads_gemm': (c_int, [P, c_int32, POINTER(RzRawHeads), P]),
     'rz_net_forward': (c_int, [P, P, c_int32, P, P, P]),

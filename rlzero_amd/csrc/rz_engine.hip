@@ -873,10 +873,7 @@ __device__ __forceinline__ void fresh_root(const Dev &E, int g, int arena, int l
 // of the discarded siblings and of every outgrown child block.  A copied record keeps its SOURCE
 // first-child / prior-block offsets until the node itself is taken from the queue, so the queue
 // holds destination slots only.
-__global__ __launch_bounds__(kWave) void k_advance(Dev E, const int32_t *moves) {
-    const int g = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int mv = moves[g];
+__device__ __forceinline__ void advance_body(const Dev &E, int g, int lane, int mv) {
     if (mv == -2) return;
     const int src_arena = E.cur_arena[g], dst_arena = src_arena ^ 1;
     const int4 *Rs = arena_records(E, g, src_arena);
@@ -978,15 +975,16 @@ __global__ __launch_bounds__(kWave) void k_advance(Dev E, const int32_t *moves) 
     }
 }
 
+__global__ __launch_bounds__(kWave) void k_advance(Dev E, const int32_t *moves) {
+    advance_body(E, blockIdx.x, threadIdx.x, moves[blockIdx.x]);
+}
+
 // ------------------------------------------------------------------ game step
-__global__ __launch_bounds__(kWave) void k_step_games(Dev E, const int32_t *moves, int32_t *winner,
-                                                      uint8_t *ended) {
-    const int g = blockIdx.x;
-    const int lane = threadIdx.x;
+// -> the winner (player id or -1) and whether the game is over, wave-uniform
+__device__ __forceinline__ void step_body(const Dev &E, int g, int lane, int mv, int &who, bool &over) {
     const int S = E.S;
     uint64_t st[2][kWords];
     load_board(E.root_stones, g, st);
-    const int mv = moves[g];
     int to_move = E.root_to_move[g];
     if (mv >= 0) {
         uint64_t occ[kWords];
@@ -1006,10 +1004,19 @@ __global__ __launch_bounds__(kWave) void k_step_games(Dev E, const int32_t *move
             store_board(E.root_stones, g, st, lane);
         }
     }
-    int who = -1;
+    who = -1;
     if (line_anywhere(st[0], S, E.BH, E.BW, E.n_row, lane)) who = 0;
     else if (line_anywhere(st[1], S, E.BH, E.BW, E.n_row, lane)) who = 1;
-    const bool over = who >= 0 || count_bits(st[0]) + count_bits(st[1]) == S;
+    over = who >= 0 || count_bits(st[0]) + count_bits(st[1]) == S;
+}
+
+__global__ __launch_bounds__(kWave) void k_step_games(Dev E, const int32_t *moves, int32_t *winner,
+                                                      uint8_t *ended) {
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    int who = -1;
+    bool over = false;
+    step_body(E, g, lane, moves[g], who, over);
     if (lane == 0) {
         if (winner) winner[g] = who;
         if (ended) ended[g] = over ? 1 : 0;
@@ -1093,10 +1100,8 @@ struct Play {
     int64_t *game_id;          // [G] -1: idle
     int32_t *ply, *state;      // state: 0 idle, 1 running, 2 stalled
     int32_t *mailbox;          // [G] the host's move for a stalled slot, -1: none
-    int32_t *keep, *stepm;     // [G] the moves of this step for k_advance / k_step_games
-    int32_t *winner;
-    uint8_t *ended;
-    int32_t *step_ab;          // [2]: k_play_draw reads [0] and writes [1], k_play_after reads [1] and writes [0] = [1] + 1
+    int32_t *keep, *stepm;     // [G] the moves of this step (update_with_move / env.step), written by k_play_draw
+    int32_t *step_ab;          // [2]: k_play_draw reads [0] and writes [1], k_play_apply reads [1] and writes [0] = [1] + 1
     const int64_t *queue_ids;
     int32_t *queue_ctl;        // [0] head, [1] entries valid
     int32_t *log;
@@ -1235,24 +1240,34 @@ __global__ __launch_bounds__(kWave) void k_play_draw(Dev E, Play Y) {
     }
 }
 
-// Behind k_advance + k_step_games of the move: the end of finished games (reset_player, game.py:128) and the refill of idle slots
-// from the queue of game ids (GomokuEnv.reset, gomoku_env.py:33-47: empty board, player 0; a fresh tree; the game's noise key).
-__global__ void k_play_after(Dev E, Play Y) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+// The rest of a move in ONE launch, one wave per slot: update_with_move with the move just drawn (advance_body: before the board
+// changes), env.step + game_end_winner (step_body), then the end of a finished game (reset_player, game.py:128) and the refill of an
+// idle slot from the queue of game ids (GomokuEnv.reset, gomoku_env.py:33-47: empty board, player 0; a fresh tree; the game's
+// noise key).  drawn == 0 (no k_play_draw before it): only the refill.  The pending-priors counter of the game restarts here
+// (the flush of the move's search ran just before: rz_deferred_flush leaves its own reset launch out between draw and apply).
+__global__ __launch_bounds__(kWave) void k_play_apply(Dev E, Play Y, int drawn) {
+    const int g = blockIdx.x, lane = threadIdx.x;
     const int step = Y.step_ab[1];
-    if (g == 0) Y.step_ab[0] = step + 1;
-    if (g >= E.n_games) return;
+    if (g == 0 && lane == 0) Y.step_ab[0] = step + 1;
+    const int keep = drawn ? Y.keep[g] : -2, mv = drawn ? Y.stepm[g] : -1;
     int state = Y.state[g];
-    if (state == kPlayRunning && Y.stepm[g] >= 0 && Y.ended[g]) {
+    advance_body(E, g, lane, keep);
+    __syncthreads();
+    int who = -1;
+    bool over = false;
+    if (mv >= 0) step_body(E, g, lane, mv, who, over);   // (idle and stalled slots make no move)
+    if (lane != 0) return;
+    if (drawn && E.pend != nullptr) E.pend[g] = 0;
+    if (state == kPlayRunning && mv >= 0 && over) {
         int32_t *rec = Y.log + ((long long)(step % Y.ring) * E.n_games + g) * Y.words;
-        rec[4] |= RZ_PLAY_ENDED | ((Y.winner[g] + 1) << 16);
+        rec[4] |= RZ_PLAY_ENDED | ((who + 1) << 16);
         state = kPlayIdle;
         Y.state[g] = state;
         Y.game_id[g] = -1;
         E.active[g] = 0;
         fresh_root(E, g, E.cur_arena[g], 0);
     }
-    Y.stepm[g] = -1;   // (an rz_play_apply without a draw before it applies nothing)
+    Y.stepm[g] = -1;
     Y.keep[g] = -2;
     if (state != kPlayIdle) return;
     int head = Y.queue_ctl[0];
@@ -1280,7 +1295,7 @@ __global__ void k_play_after(Dev E, Play Y) {
 }
 
 __global__ void k_play_resolve(Play Y, int slot, int move) { Y.mailbox[slot] = move; }
-__global__ void k_play_no_draw(Play Y) { Y.step_ab[1] = Y.step_ab[0]; }   // rz_play_apply without a draw: the step of k_play_after
+__global__ void k_play_no_draw(Play Y) { Y.step_ab[1] = Y.step_ab[0]; }   // rz_play_apply without a draw: the step k_play_apply reads
 
 __global__ void k_play_stop(Dev E, Play Y) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1860,7 +1875,8 @@ int rz_deferred_flush(rz_engine *e, const rz_deferred_logits *logits, int32_t n_
     if (logits->ld < e->dev.A || logits->rows_per_slot < e->cfg.n_games) return fail(RZ_ERR_ARG, "rz_deferred_logits: rows shorter than the batch");
     k_deferred_priors<<<dim3((unsigned)e->cfg.n_games, (unsigned)n_slots), dim3(kWave), 0, as_stream(stream)>>>(
         e->dev, logits->raw, logits->ld, (long long)logits->rows_per_slot);
-    k_deferred_reset<<<flat_grid(e), dim3(256), 0, as_stream(stream)>>>(e->dev);
+    // (between rz_play_draw and rz_play_apply the counters restart in k_play_apply: one launch less in the chain of a move)
+    if (!(e->play_on && e->play_drawn)) k_deferred_reset<<<flat_grid(e), dim3(256), 0, as_stream(stream)>>>(e->dev);
     return launched("k_deferred_priors");
 }
 
@@ -1941,8 +1957,6 @@ int rz_play_attach(rz_engine *e, const rz_play_config *cfg) {
         if ((rc = dev_alloc(e, &Y.mailbox, G)) != RZ_OK) return rc;
         if ((rc = dev_alloc(e, &Y.keep, G)) != RZ_OK) return rc;
         if ((rc = dev_alloc(e, &Y.stepm, G)) != RZ_OK) return rc;
-        if ((rc = dev_alloc(e, &Y.winner, G)) != RZ_OK) return rc;
-        if ((rc = dev_alloc(e, &Y.ended, G)) != RZ_OK) return rc;
         if ((rc = dev_alloc(e, &Y.step_ab, 2)) != RZ_OK) return rc;
     }
     Y.queue_ids = cfg->d_queue_ids;
@@ -1955,8 +1969,6 @@ int rz_play_attach(rz_engine *e, const rz_play_config *cfg) {
     Y.margin = cfg->stall_margin > 0.0 ? cfg->stall_margin : 1e-10 * (Y.inv_t > 1.0 ? Y.inv_t : 1.0);
     RZ_HIP(hipMemset(Y.step_ab, 0, 8));
     RZ_HIP(hipMemset(Y.ply, 0, (size_t)G * 4));
-    RZ_HIP(hipMemset(Y.winner, 0xff, (size_t)G * 4));
-    RZ_HIP(hipMemset(Y.ended, 0, (size_t)G));
     k_play_stop<<<flat_grid(e), dim3(256), 0, 0>>>(e->dev, Y);
     RZ_HIP(hipDeviceSynchronize());
     e->play_on = true;
@@ -1977,16 +1989,11 @@ int rz_play_apply(rz_engine *e, void *stream) {
     RZ_ENTER(e);
     if (!e->play_on) return fail(RZ_ERR_ARG, "call rz_play_attach first");
     const Play &Y = e->play;
-    if (e->play_drawn) {
-        k_advance<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, Y.keep);   // tree reuse before the boards change
-        k_step_games<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, Y.stepm, Y.winner, Y.ended);
-    } else {
-        k_play_no_draw<<<dim3(1), dim3(1), 0, as_stream(stream)>>>(Y);   // no moves to apply: only the refill of idle slots
-    }
+    if (!e->play_drawn) k_play_no_draw<<<dim3(1), dim3(1), 0, as_stream(stream)>>>(Y);   // (the step counter k_play_draw would have handed on)
+    k_play_apply<<<per_game(e), dim3(kWave), 0, as_stream(stream)>>>(e->dev, Y, e->play_drawn ? 1 : 0);
     e->play_drawn = false;
-    k_play_after<<<flat_grid(e), dim3(256), 0, as_stream(stream)>>>(e->dev, Y);
     e->play_steps += 1;
-    return launched("k_play_after");
+    return launched("k_play_apply");
 }
 
 int rz_play_resolve(rz_engine *e, int32_t slot, int32_t move, void *stream) {

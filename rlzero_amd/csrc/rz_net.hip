@@ -893,6 +893,7 @@ template <> struct ResArgs<true> {
     rzt::Dev E;          // the engine's device view (rz_device_view)
     rz_value_head vh;    // valfeat unused: the inputs stay in LDS
     int n_sims;          // simulations of this launch: n_sims x (trunk, expand / backup), a selection between two of them
+    int select_first;    // != 0: the launch begins with the selection of the first leaf itself (no rz_select_step before it)
 };
 __device__ __forceinline__ int res_sims(const ResArgs<false> &) { return 0; }
 __device__ __forceinline__ int res_sims(const ResArgs<true> &r) { return r.n_sims; }
@@ -1037,9 +1038,27 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         for (int g = 0; g < 4; ++g) bias1[g] = *reinterpret_cast<const f32x4 *>(nd.b1 + 8 * g + 4 * (lane0 >> 5)) * act1;
     }
     const bool first = (int)blockIdx.x < n_boards;
-    if (first) {
+    bool sel_first = false;   // RES: the first leaf is selected by this launch (below, behind the zeroing)
+    if constexpr (RES) sel_first = res.select_first != 0;
+    if (first && !sel_first) {
         if (from_bits) load_bits(blockIdx.x, tid0); else load_obs(blockIdx.x, tid0);
     }
+    // the planes of a leaf handed over through LDS by the tree code of this workgroup (select_body's lds_leaf): what load_bits forms
+    auto planes_from_lds = [&](int tid) {
+        int nst = 0;
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) nst += __popcll(res_leaf[q8]);
+        const int tm = reinterpret_cast<const int *>(res_leaf + 2 * RZ_BOARD_WORDS)[0], lc = reinterpret_cast<const int *>(res_leaf + 2 * RZ_BOARD_WORDS)[1];
+        const int word = (tid >> 6) & 3, bit = tid & 63;
+        const uint64_t w0 = res_leaf[word], w1 = res_leaf[4 + word];
+        const bool s0 = (w0 >> bit) & 1ull, s1 = (w1 >> bit) & 1ull;
+        const bool mine_ = tm == 0 ? s0 : s1, theirs = tm == 0 ? s1 : s0;
+        const _Float16 one = (_Float16)sp::kObsScale, zero = (_Float16)0.0f;
+        cell_planes[0] = mine_ ? one : zero;
+        cell_planes[1] = theirs ? one : zero;
+        cell_planes[2] = (nst > 0 && tid == lc) ? one : zero;
+        cell_planes[3] = (nst & 1) ? zero : one;
+    };
     __builtin_amdgcn_sched_barrier(0);  // the loads above stay above the zeroing
     NET_TICK(11);
     {
@@ -1080,6 +1099,13 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     // (the head weights go to LDS behind the first board's conv1: they are first read two barriers later, and their
     // loads need not be waited for here)
     bool hw_pending = true;
+    if constexpr (RES) {
+        if (sel_first) {   // AlphaZeroMCTS._playout's select loop for the first simulation of the search (rz_select_step's work)
+            if ((tid0 >> 6) == 0) rzt::select_body<false>(res.E, nullptr, blockIdx.x, tid0 & 63, 0, res_leaf);
+            __syncthreads();
+            planes_from_lds(tid0);
+        }
+    }
     if (first) store_obs(tid0);
     NET_TICK(14);
     __syncthreads();
@@ -1485,19 +1511,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         if (wave == 0 && more) rzt::select_body<false>(res.E, nullptr, game, lane, 0, res_leaf);
         __syncthreads();
         if (more) {   // the planes of the next leaf, from LDS: what load_bits forms from the leaf arrays
-            int nst = 0;
-#pragma unroll
-            for (int q8 = 0; q8 < 8; ++q8) nst += __popcll(res_leaf[q8]);
-            const int tm = reinterpret_cast<const int *>(res_leaf + 2 * RZ_BOARD_WORDS)[0], lc = reinterpret_cast<const int *>(res_leaf + 2 * RZ_BOARD_WORDS)[1];
-            const int word = (tid >> 6) & 3, bit = tid & 63;
-            const uint64_t w0 = res_leaf[word], w1 = res_leaf[4 + word];
-            const bool s0 = (w0 >> bit) & 1ull, s1 = (w1 >> bit) & 1ull;
-            const bool mine_ = tm == 0 ? s0 : s1, theirs = tm == 0 ? s1 : s0;
-            const _Float16 one = (_Float16)sp::kObsScale, zero = (_Float16)0.0f;
-            cell_planes[0] = mine_ ? one : zero;
-            cell_planes[1] = theirs ? one : zero;
-            cell_planes[2] = (nst > 0 && tid == lc) ? one : zero;
-            cell_planes[3] = (nst & 1) ? zero : one;
+            planes_from_lds(tid);
             store_obs(tid);
             __syncthreads();
         }
@@ -1675,10 +1689,13 @@ __device__ __forceinline__ void conv_r(const char *in, const void *wts, int lane
 // the production kernels carry nothing of it (its live values cost ten registers of a budget that is pinned).
 // F8: conv3 with its cross terms on the block-scaled FP8 pipe (RZ_NET_SPLIT_F16_FP8, opt-in: narrower arithmetic than the reference's
 // f32 -- rt::slot_r): conv2's epilogue stores the e5m2 pieces where the lo f16 pieces stood, conv3 reads nd.t3f.
-template <int NT, bool BITS, bool TRACE = false, bool RES = false, bool F8 = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_trunk_rows(NetDev nd, const float *__restrict__ obs, LeafBits leaves,
-                                                    float *__restrict__ feat, _Float16 *__restrict__ feat16,
-                                                    int n_boards, unsigned *__restrict__ flags, DeferredOut later, ResArgs<RES> res) {
+// The body is shared by two kernels: k_trunk_rows (the launches of a lane's step: the register cap above) and k_trunk_rows_res (the
+// resident search: a workgroup has its CU to itself for a whole search, no other lane's waves to make room for -- no cap, so the
+// tree code's registers beside the trunk's need no scratch).
+template <int NT, bool BITS, bool TRACE, bool RES, bool F8>
+__device__ __forceinline__ void trunk_rows_body(const NetDev &nd, const float *__restrict__ obs, LeafBits leaves,
+                                                float *__restrict__ feat, _Float16 *__restrict__ feat16,
+                                                int n_boards, unsigned *__restrict__ flags, const DeferredOut &later, const ResArgs<RES> &res) {
     static_assert(!RES || (BITS && !TRACE), "the resident search reads positions");
     static_assert(!F8 || (BITS && !TRACE), "the FP8 cross terms: position-fed launches only");
     // RES: the value head's input row (zero padded to 4 x groups floats), the K-quarter sums of its first layer, the next leaf
@@ -1799,7 +1816,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_t
     }
     const f32x4 bias2 = *reinterpret_cast<const f32x4 *>(nd.b2 + 16 * wave0 + 4 * g0) * act2;
     const bool first = (int)blockIdx.x < n_boards;
-    if (first) load_board(blockIdx.x, tid0);
+    bool sel_first = false;   // RES: the first leaf is selected by this launch (below, behind the zeroing)
+    if constexpr (RES) sel_first = res.select_first != 0;
+    if (first && !sel_first) load_board(blockIdx.x, tid0);
+    // the planes of a leaf handed over through LDS by the tree code of this workgroup (select_body's lds_leaf): what load_bits forms
+    auto planes_from_lds = [&](int tid) {
+        int nst = 0;
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) nst += __popcll(res_leaf[q8]);
+        const int tm = reinterpret_cast<const int *>(res_leaf + 2 * RZ_BOARD_WORDS)[0], lc = reinterpret_cast<const int *>(res_leaf + 2 * RZ_BOARD_WORDS)[1];
+        const int word = (tid >> 6) & 3, bit = tid & 63;
+        const uint64_t w0 = res_leaf[word], w1 = res_leaf[4 + word];
+        const bool s0 = (w0 >> bit) & 1ull, s1 = (w1 >> bit) & 1ull;
+        const bool mine = tm == 0 ? s0 : s1, theirs = tm == 0 ? s1 : s0;
+        const _Float16 one = (_Float16)sp::kObsScale, zero = (_Float16)0.0f;
+        cell_planes[0] = mine ? one : zero;
+        cell_planes[1] = theirs ? one : zero;
+        cell_planes[2] = (nst > 0 && tid == lc) ? one : zero;
+        cell_planes[3] = (nst & 1) ? zero : one;
+    };
     __builtin_amdgcn_sched_barrier(0);  // the loads above stay above the zeroing
     NET_TICK(11);
     {
@@ -1832,6 +1867,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_t
     NET_TICK(12);
     __syncthreads();
     NET_TICK(13);
+    if constexpr (RES) {
+        if (sel_first) {   // AlphaZeroMCTS._playout's select loop for the first simulation of the search (rz_select_step's work)
+            if (wave0 == 0) rzt::select_body<false>(res.E, nullptr, blockIdx.x, lane0, 0, res_leaf);
+            __syncthreads();
+            planes_from_lds(tid0);
+        }
+    }
     if (first) store_obs();
     NET_TICK(14);
     __syncthreads();
@@ -2046,19 +2088,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_t
         if (wave == 0 && more) rzt::select_body<false>(res.E, nullptr, game, lane, 0, res_leaf);
         __syncthreads();
         if (more) {   // the planes of the next leaf, from LDS: what load_bits forms from the leaf arrays
-            int nst = 0;
+            planes_from_lds(tid);
+            // conv1's weight fragments again (6 KB, L2-resident; their latency passes under the barrier below): carried in
+            // registers ACROSS the tree code above they cost the resident kernels a spill that was reloaded in every simulation
+            asm volatile("" ::: "memory");
 #pragma unroll
-            for (int q8 = 0; q8 < 8; ++q8) nst += __popcll(res_leaf[q8]);
-            const int tm = reinterpret_cast<const int *>(res_leaf + 2 * RZ_BOARD_WORDS)[0], lc = reinterpret_cast<const int *>(res_leaf + 2 * RZ_BOARD_WORDS)[1];
-            const int word = (tid >> 6) & 3, bit = tid & 63;
-            const uint64_t w0 = res_leaf[word], w1 = res_leaf[4 + word];
-            const bool s0 = (w0 >> bit) & 1ull, s1 = (w1 >> bit) & 1ull;
-            const bool mine = tm == 0 ? s0 : s1, theirs = tm == 0 ? s1 : s0;
-            const _Float16 one = (_Float16)sp::kObsScale, zero = (_Float16)0.0f;
-            cell_planes[0] = mine ? one : zero;
-            cell_planes[1] = theirs ? one : zero;
-            cell_planes[2] = (nst > 0 && tid == lc) ? one : zero;
-            cell_planes[3] = (nst & 1) ? zero : one;
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int p_ = 0; p_ < 2; ++p_) a1[ky][p_] = __builtin_bit_cast(sp::f16x8, nd.s1[(ky * 2 + p_) * 64 + lane]);
             store_obs();
             __syncthreads();
         }
@@ -2074,6 +2111,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_t
         if (!(zmax <= 65504.0f)) atomicOr(flags, (unsigned)RZ_NET_FLAG_F16_RANGE);
     if (TRACE && tid0 == 0 && (int)blockIdx.x < n_boards)
         rz_trace_write(later.trace, RZ_TRACE_TRUNK, later.slot_of ? later.slot_of[blockIdx.x] : 0, blockIdx.x, trace_t0);
+}
+
+template <int NT, bool BITS, bool TRACE = false, bool F8 = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(200))) void k_trunk_rows(NetDev nd, const float *__restrict__ obs, LeafBits leaves,
+                                                    float *__restrict__ feat, _Float16 *__restrict__ feat16,
+                                                    int n_boards, unsigned *__restrict__ flags, DeferredOut later) {
+    trunk_rows_body<NT, BITS, TRACE, false, F8>(nd, obs, leaves, feat, feat16, n_boards, flags, later, ResArgs<false>{});
+}
+
+template <int NT, bool F8 = false>
+__global__ __launch_bounds__(256) void k_trunk_rows_res(NetDev nd, LeafBits leaves, _Float16 *__restrict__ feat16, int n_boards,
+                                                        unsigned *__restrict__ flags, DeferredOut later, ResArgs<true> res) {
+    trunk_rows_body<NT, true, false, true, F8>(nd, nullptr, leaves, nullptr, feat16, n_boards, flags, later, res);
 }
 
 // Direct path: wave w = 4*rh + q4 owns output-channel quarter q4 (the two waves of a quarter share
@@ -2827,24 +2877,24 @@ static void launch_trunk_rows(bool bits, dim3 grid, hipStream_t stream, const Ne
                               _Float16 *f16, int n_boards, unsigned *flags, DeferredOut later = DeferredOut{nullptr, 0, nullptr, 0, nullptr},
                               bool fp8 = false) {
     if (fp8 && bits) {   // (the schedule trace reads the default arithmetic's kernel)
-        k_trunk_rows<NT, true, false, false, true><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later, ResArgs<false>{});
+        k_trunk_rows<NT, true, false, true><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later);
         return;
     }
     if constexpr (NT == 15) {
         if (bits && later.trace) {
-            k_trunk_rows<NT, true, true><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later, ResArgs<false>{});
+            k_trunk_rows<NT, true, true><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later);
             return;
         }
     }
-    if (bits) k_trunk_rows<NT, true><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later, ResArgs<false>{});
-    else k_trunk_rows<NT, false><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later, ResArgs<false>{});
+    if (bits) k_trunk_rows<NT, true><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later);
+    else k_trunk_rows<NT, false><<<grid, dim3(256), 0, stream>>>(nd, d_obs, leaves, f32, f16, n_boards, flags, later);
 }
 
 template <int NT>
 static void launch_search_rows(dim3 grid, hipStream_t stream, const NetDev &nd, LeafBits leaves, _Float16 *store, int n_games, unsigned *flags,
                                DeferredOut later, const ResArgs<true> &res, bool fp8) {
-    if (fp8) k_trunk_rows<NT, true, false, true, true><<<grid, dim3(256), 0, stream>>>(nd, nullptr, leaves, nullptr, store, n_games, flags, later, res);
-    else k_trunk_rows<NT, true, false, true><<<grid, dim3(256), 0, stream>>>(nd, nullptr, leaves, nullptr, store, n_games, flags, later, res);
+    if (fp8) k_trunk_rows_res<NT, true><<<grid, dim3(256), 0, stream>>>(nd, leaves, store, n_games, flags, later, res);
+    else k_trunk_rows_res<NT><<<grid, dim3(256), 0, stream>>>(nd, leaves, store, n_games, flags, later, res);
 }
 
 extern "C" {
@@ -3316,7 +3366,7 @@ int rz_net_trunk_leaves_deferred(rz_net *net, const uint64_t *d_stones, const in
     return RZ_OK;
 }
 
-int rz_net_search_resident(rz_net *net, rz_engine *engine, int32_t n_sims, void *stream) {
+int rz_net_search_resident(rz_net *net, rz_engine *engine, int32_t n_sims, int32_t select_first, void *stream) {
     rzt::Dev dev;
     int rc = rz_device_view(engine, &dev, (int64_t)sizeof(dev));
     if (rc != RZ_OK) return rc;
@@ -3350,6 +3400,7 @@ int rz_net_search_resident(rz_net *net, rz_engine *engine, int32_t n_sims, void 
     res.vh.ld = net->vf_groups * 4;
     res.vh.groups = net->vf_groups;
     res.n_sims = n_sims;
+    res.select_first = select_first ? 1 : 0;
     const DeferredOut later{dev.pend, (long long)net->store_tiles * net->dev.groups_act * 1024, nullptr, 0, nullptr, net->store_slots};
     const LeafBits leaves{dev.leaf_stones, dev.leaf_to_move, dev.leaf_last};
     const dim3 grid((unsigned)dev.n_games);

@@ -165,9 +165,10 @@ class HipNet(object):
             return False
         return (11 <= self.rows <= 16 and 11 <= self.cols <= 16) or (self.rows <= 10 and self.cols <= 10)
 
-    def search_resident(self, eng, n_sims):
-        """``n_sims`` simulations of every active game of ``eng`` in one launch (the first leaves selected: rz_select_step)."""
-        check(self.lib.rz_net_search_resident(self.handle, eng.handle, int(n_sims), self._stream()), 'rz_net_search_resident')
+    def search_resident(self, eng, n_sims, select_first=False):
+        """``n_sims`` simulations of every active game of ``eng`` in one launch; the first leaves come from rz_select_step before
+        the call, or (``select_first``) from the launch itself."""
+        check(self.lib.rz_net_search_resident(self.handle, eng.handle, int(n_sims), 1 if select_first else 0, self._stream()), 'rz_net_search_resident')
 
     def deferred_gemm(self, n_boards, n_slots):
         """act_fc1 over the stored leaves of slots [0, n_slots) as one GEMM -> RzDeferredLogits."""
@@ -322,8 +323,8 @@ class HipNetEvaluator(object):
         return (self.resident_search and self.deferred_ok(eng) and self.hip.supports_resident()
                 and eng.n_games <= self.hip.torch.cuda.get_device_properties(self.hip.device).multi_processor_count)
 
-    def search_resident(self, eng, n_sims):
-        self.hip.search_resident(eng, n_sims)
+    def search_resident(self, eng, n_sims, select_first=False):
+        self.hip.search_resident(eng, n_sims, select_first)
 
     def raw_heads(self, eng):
         if not self.needs_obs:
@@ -738,14 +739,14 @@ class MCTSEngine(object):
         resident = res_ok is not None and res_ok(self)
         while n > 0:
             m = self._deferred_begin(evaluator, n)
-            check(lib.rz_select_step(h, None, self.stream()), 'rz_select_step')
-            if resident:   # the m simulations in ONE launch, one workgroup per game
-                evaluator.search_resident(self, m)
+            if resident:   # the m simulations in ONE launch, one workgroup per game, the first selection included
+                evaluator.search_resident(self, m, True)
                 if not self._capturing:
                     self._def_pending += m
                     self._def_stream = self.torch.cuda.current_stream(self.device)
                 n -= m
                 continue
+            check(lib.rz_select_step(h, None, self.stream()), 'rz_select_step')
             for i in range(m):
                 head = evaluator.deferred_trunk(self)
                 if i + 1 < m:
@@ -966,8 +967,7 @@ class MCTSEngine(object):
         try:
             with t.cuda.graph(graph):
                 st = self.stream()
-                check(lib.rz_select_step(h, None, st), 'rz_select_step')
-                evaluator.search_resident(self, n)
+                evaluator.search_resident(self, n, True)
                 check(lib.rz_play_draw(h, st), 'rz_play_draw')
                 logits = hip.deferred_gemm(self.n_leaves, n)
                 check(lib.rz_deferred_flush(h, ctypes.byref(logits), n, st), 'rz_deferred_flush')

@@ -385,6 +385,10 @@ int rz_play_state(rz_engine *e, int64_t *h_game_id, int32_t *h_ply, int32_t *h_s
 /* Synchronises `stream`-independent state: waits for the device, then reports flags. */
 int rz_get_stats(rz_engine *e, rz_stats *out);
 int rz_clear_errors(rz_engine *e);
+/* The cheap form for a per-move check (the single-game API polls after every search): waits for `stream` only and reads the OR of
+ * the games' RZ_FLAG_* bits (and, optionally, the count of dropped subtrees) -- 4 + 4 bytes; rz_get_stats names the game when a
+ * bit is set. */
+int rz_poll_errors(rz_engine *e, int32_t *h_flags, int32_t *h_reuse_dropped, void *stream);
 
 /* Inspection for parity tests: copies game `g`'s current arena to HOST arrays of max_slots
  * entries -- per node record: N, W, slot of the first child record (-1 = none yet), number of

@@ -138,6 +138,7 @@ _SIGNATURES = {
     'rz_play_state': (c_int, [P, P, P, P, POINTER(c_int64)]),
     'rz_get_stats': (c_int, [P, POINTER(RzStats)]),
     'rz_clear_errors': (c_int, [P]),
+    'rz_poll_errors': (c_int, [P, POINTER(c_int32), POINTER(c_int32), P]),
     'rz_copy_arena': (c_int, [P, c_int32, c_int64, P, P, P, P, P, P, P, P]),
     'rz_copy_priors': (c_int, [P, c_int32, c_int64, P, P]),
     'rz_uct_scores': (c_int, [P, P, P, P, c_double, P, c_int64, P]),

@@ -2055,6 +2055,15 @@ int rz_get_stats(rz_engine *e, rz_stats *out) {
     return RZ_OK;
 }
 
+int rz_poll_errors(rz_engine *e, int32_t *h_flags, int32_t *h_reuse_dropped, void *stream) {
+    RZ_ENTER(e);
+    RZ_NEED(h_flags);
+    RZ_HIP(hipStreamSynchronize(as_stream(stream)));
+    RZ_HIP(hipMemcpy(h_flags, e->dev.err_any, 4, hipMemcpyDeviceToHost));
+    if (h_reuse_dropped) RZ_HIP(hipMemcpy(h_reuse_dropped, e->dev.reuse_drops, 4, hipMemcpyDeviceToHost));
+    return RZ_OK;
+}
+
 int rz_clear_errors(rz_engine *e) {
     RZ_ENTER(e);
     RZ_HIP(hipDeviceSynchronize());

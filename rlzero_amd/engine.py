@@ -532,21 +532,42 @@ class MCTSEngine(object):
                             st.max_slots_used, st.arena_slots))
         return st
 
+    def poll_errors(self):
+        """check() for every move of a one-game player: waits for the current stream, reads the OR of the games' flags (8 bytes) and
+        only asks for the full statistics -- which name the game and raise -- when a bit is set.  -> subtrees dropped so far."""
+        flags, drops = ctypes.c_int32(0), ctypes.c_int32(0)
+        check(self.lib.rz_poll_errors(self.handle, ctypes.byref(flags), ctypes.byref(drops), self.stream()), 'rz_poll_errors')
+        if flags.value & ~_hip.FLAG_REUSE_DROPPED:
+            self.check()
+        return drops.value
+
     # ------------------------------------------------------------------ roots
     def set_roots(self, stones, to_move, last_move, mask=None, reset_trees=False):
         """stones: uint64 [G,2,WORDS]; to_move / last_move: int [G]; mask: bool [G] or None."""
         t = self.torch
         self.flush_deferred()   # (pending priors belong to the trees as they are)
-        self.stones.copy_(t.from_numpy(np.ascontiguousarray(stones, dtype=np.uint64).view(np.int64)))
-        self.to_move.copy_(t.from_numpy(np.ascontiguousarray(to_move, dtype=np.int32)))
-        self.last_move.copy_(t.from_numpy(np.ascontiguousarray(last_move, dtype=np.int32)))
+        G, nb = self.n_games, 2 * WORDS * 8
+        if getattr(self, '_roots_io', None) is None:
+            # boards, sides to move and last cells go up in ONE copy from pinned memory: [G][2][WORDS] int64 | [G] int32 | [G] int32
+            host = t.empty(G * (nb + 8), dtype=t.uint8, pin_memory=True)
+            dev = t.empty(G * (nb + 8), dtype=t.uint8, device=self.device)
+            hn = host.numpy()
+            self._roots_io = (host, dev, hn[:G * nb].view(np.uint64).reshape(G, 2, WORDS), hn[G * nb:G * nb + 4 * G].view(np.int32),
+                              hn[G * nb + 4 * G:].view(np.int32), t.cuda.Event())
+        host, dev, h_stones, h_to_move, h_last, done = self._roots_io
+        done.synchronize()   # (the previous upload has left the pinned buffer)
+        h_stones[...] = np.asarray(stones, dtype=np.uint64).reshape(G, 2, WORDS)
+        h_to_move[:] = to_move
+        h_last[:] = last_move
+        dev.copy_(host, non_blocking=True)
+        done.record(t.cuda.current_stream(self.device))
         mptr = None
         if mask is not None:
             self.mask.copy_(t.from_numpy(np.ascontiguousarray(mask, dtype=np.uint8)))
             mptr = _ptr(self.mask)
-        check(self.lib.rz_set_roots(self.handle, _ptr(self.stones), _ptr(self.to_move),
-                                    _ptr(self.last_move), mptr, 1 if reset_trees else 0,
-                                    self.stream()), 'rz_set_roots')
+        base = dev.data_ptr()
+        check(self.lib.rz_set_roots(self.handle, ctypes.c_void_p(base), ctypes.c_void_p(base + G * nb), ctypes.c_void_p(base + G * nb + 4 * G),
+                                    mptr, 1 if reset_trees else 0, self.stream()), 'rz_set_roots')
 
     def reset_games(self, mask=None):
         """Empty boards, player 0 to move, fresh trees for the selected games."""
@@ -885,7 +906,14 @@ class MCTSEngine(object):
     def advance(self, moves):
         """update_with_move for every game: move >= 0 keep that subtree, -1 reset, -2 skip."""
         self.flush_deferred()   # (the kept subtree's prior blocks are copied: they must be written)
-        self.moves.copy_(self.torch.from_numpy(np.ascontiguousarray(moves, dtype=np.int32)))
+        t = self.torch
+        if getattr(self, '_adv_io', None) is None:
+            self._adv_io = (t.empty(self.n_games, dtype=t.int32, pin_memory=True), t.cuda.Event())
+        host, done = self._adv_io
+        done.synchronize()
+        host.numpy()[:] = moves
+        self.moves.copy_(host, non_blocking=True)
+        done.record(t.cuda.current_stream(self.device))
         check(self.lib.rz_advance_roots(self.handle, _ptr(self.moves), self.stream()), 'rz_advance_roots')
 
     def advance_and_step(self, keep_moves, step_moves):

@@ -160,9 +160,9 @@ class AlphaZeroMCTS(object):
             self._evaluator.refresh_if_changed()  # the learner may have stepped since the last move
         eng.simulate(self._evaluator, self.n_playout, use_graph=self._graph_sims > 0, sims_per_graph=max(self._graph_sims, 1))
         visits = eng.root_visits()[0]
-        eng.check()
-        if isinstance(self._evaluator, HipNetEvaluator):
-            self._evaluator.hip.check_flags()  # root_visits() has synchronised: one 4-byte read
+        eng.poll_errors()   # (8 bytes; the full statistics only when a flag is set)
+        if isinstance(self._evaluator, HipNetEvaluator) and self._evaluator.needs_obs:
+            self._evaluator.hip.check_flags()  # (only float planes can leave the f16 range: positions are 0 / 1 planes by construction)
         acts = self._legal
         counts = np.array([int(visits[a]) for a in acts])
         act_probs = softmax(1.0 / temperature * np.log(counts + 1e-10))

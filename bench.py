@@ -99,9 +99,9 @@ def tree_bytes_per_sim(scanned, created, depth):
 
 def pmc_traffic(kernel, workload):
     """HBM bytes per launch of ``kernel`` in ``workload`` from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
-    WRITE_SIZE runs of that very workload, gfx950 read correction applied: profiles/r04/pmc_traffic.json, collected by
-    profiles/collect_r04.sh).  None when no counter run exists for the workload."""
-    for rnd in ('r04', 'r03'):   # (a workload without a counter run of this round keeps the last round's)
+    WRITE_SIZE runs of that very workload, gfx950 read correction applied: profiles/r05/pmc_traffic.json, collected by
+    profiles/collect_r05.sh).  None when no counter run exists for the workload."""
+    for rnd in ('r05', 'r04', 'r03'):   # (a workload without a counter run of this round keeps the last round's)
         try:
             rec = json.load(open(os.path.join(REPO, 'profiles', rnd, 'pmc_traffic.json')))
             return rec[workload]['kernels'][kernel]['traffic_bytes_per_launch']

@@ -17,7 +17,7 @@ import shutil
 import sys
 
 KERNELS = {'k_trunk': 'k_trunk', 'k_tree_step': 'k_tree_step', 'k_heads': 'k_heads', 'k_mz_search': 'k_mz_search',
-           'k_deferred_priors': 'k_deferred_priors'}
+           'k_deferred_priors': 'k_deferred_priors', 'k_play_draw': 'k_play_draw', 'k_play_apply': 'k_play_apply'}
 
 
 def per_kernel(csv_path, counter):

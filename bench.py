@@ -1078,7 +1078,7 @@ def main():
                 ex_tf = flops / (exclusive_ms * 1e-3) / 1e12
                 per.update({'live_avg_us': round(1e3 * exclusive_ms, 2), 'live_frac_of_chip': round(ex_tf / peak, 4),
                             'live_frac_of_held_cus': round(ex_tf / peak / held, 4)})
-            prof = rocprof_dispatch_us('k_trunk_rowsILi15ELb1ELb0ELb0ELb0E') if (default_config and args.net_algo == 'split_f16') else None
+            prof = rocprof_dispatch_us('k_trunk_rowsILi15ELb1ELb0ELb0E') if (default_config and args.net_algo == 'split_f16') else None
             if prof and boards_per_launch == 128:
                 pr_tf = flops / (prof[0] * 1e-6) / 1e12
                 per.update({'rocprof_avg_us': round(prof[0], 2), 'rocprof_calls': prof[1], 'rocprof_stats': prof[2],

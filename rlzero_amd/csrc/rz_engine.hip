@@ -1101,6 +1101,7 @@ struct Play {
     int32_t *ply, *state;      // state: 0 idle, 1 running, 2 stalled
     int32_t *mailbox;          // [G] the host's move for a stalled slot, -1: none
     int32_t *keep, *stepm;     // [G] the moves of this step (update_with_move / env.step), written by k_play_draw
+    int32_t *top_hwm;          // [G] the fullest a game's arena has been at the end of a search (read before update_with_move compacts it)
     int32_t *step_ab;          // [2]: k_play_draw reads [0] and writes [1], k_play_apply reads [1] and writes [0] = [1] + 1
     const int64_t *queue_ids;
     int32_t *queue_ctl;        // [0] head, [1] entries valid
@@ -1251,6 +1252,10 @@ __global__ __launch_bounds__(kWave) void k_play_apply(Dev E, Play Y, int drawn) 
     if (g == 0 && lane == 0) Y.step_ab[0] = step + 1;
     const int keep = drawn ? Y.keep[g] : -2, mv = drawn ? Y.stepm[g] : -1;
     int state = Y.state[g];
+    if (lane == 0 && drawn) {   // (rz_get_stats: after the move the arena holds the kept subtree only)
+        const int top = E.top[g];
+        if (top > Y.top_hwm[g]) Y.top_hwm[g] = top;
+    }
     advance_body(E, g, lane, keep);
     __syncthreads();
     int who = -1;
@@ -1958,6 +1963,7 @@ int rz_play_attach(rz_engine *e, const rz_play_config *cfg) {
         if ((rc = dev_alloc(e, &Y.keep, G)) != RZ_OK) return rc;
         if ((rc = dev_alloc(e, &Y.stepm, G)) != RZ_OK) return rc;
         if ((rc = dev_alloc(e, &Y.step_ab, 2)) != RZ_OK) return rc;
+        if ((rc = dev_alloc(e, &Y.top_hwm, G)) != RZ_OK) return rc;
     }
     Y.queue_ids = cfg->d_queue_ids;
     Y.queue_ctl = cfg->d_queue_ctl;
@@ -1969,6 +1975,7 @@ int rz_play_attach(rz_engine *e, const rz_play_config *cfg) {
     Y.margin = cfg->stall_margin > 0.0 ? cfg->stall_margin : 1e-10 * (Y.inv_t > 1.0 ? Y.inv_t : 1.0);
     RZ_HIP(hipMemset(Y.step_ab, 0, 8));
     RZ_HIP(hipMemset(Y.ply, 0, (size_t)G * 4));
+    RZ_HIP(hipMemset(Y.top_hwm, 0, (size_t)G * 4));
     k_play_stop<<<flat_grid(e), dim3(256), 0, 0>>>(e->dev, Y);
     RZ_HIP(hipDeviceSynchronize());
     e->play_on = true;
@@ -2039,6 +2046,12 @@ int rz_get_stats(rz_engine *e, rz_stats *out) {
     RZ_HIP(hipMemcpy(err.data(), e->dev.err, G * 4, hipMemcpyDeviceToHost));
     RZ_HIP(hipMemcpy(top.data(), e->dev.top, G * 4, hipMemcpyDeviceToHost));
     RZ_HIP(hipMemcpy(nblk.data(), e->dev.nblk, G * 4, hipMemcpyDeviceToHost));
+    if (e->play_on) {   // device-driven moves: the arenas' tops at the END of the searches (now they hold the kept subtrees)
+        std::vector<int32_t> hwm(G);
+        RZ_HIP(hipMemcpy(hwm.data(), e->play.top_hwm, G * 4, hipMemcpyDeviceToHost));
+        for (size_t g = 0; g < G; ++g)
+            if (hwm[g] > top[g]) top[g] = hwm[g];
+    }
     memset(out, 0, sizeof(*out));
     out->error_flags = any;
     out->first_bad_game = -1;

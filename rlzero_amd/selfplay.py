@@ -70,13 +70,13 @@ def batch_pi_and_moves(visits, legal, temperature, uniforms):
     mx = np.where(legal, x, -np.inf).max(axis=1)
     e = np.exp(np.where(legal, x - mx[:, None], -np.inf))  # exp(-inf) = 0 at illegal actions
     k = legal.sum(axis=1)
-    order = np.argsort(~legal, axis=1, kind='stable')  # legal actions first, ascending
-    comp = np.take_along_axis(e, order, axis=1)
+    flat = e[legal]                      # every game's legal entries, ascending, one game after the other
+    start = np.cumsum(k) - k
     sums = np.ones(R)
     for kk in np.unique(k):
         if kk > 0:
             rows = np.nonzero(k == kk)[0]
-            sums[rows] = np.ascontiguousarray(comp[rows, :kk]).sum(axis=1)
+            sums[rows] = flat[start[rows][:, None] + np.arange(kk)].sum(axis=1)   # (a contiguous [rows, kk] array: numpy's pairwise sum of kk)
     pi = e / sums[:, None]
     cdf = np.cumsum(pi, axis=1)
     cdf /= cdf[:, -1:]

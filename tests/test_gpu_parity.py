@@ -450,7 +450,7 @@ def test_whole_games_on_the_shipped_layout_equal_one_plain_lane():
     shipped, used, slots = play(True)
     assert sorted(shipped) == list(range(n_ids))
     on_device, used_d, _ = play(True, device_moves=True)
-    assert sorted(on_device) == list(range(n_ids)) and used_d == used
+    assert sorted(on_device) == list(range(n_ids)) and used <= used_d < slots   # (device moves report the arenas' high-water mark)
     for g in range(n_ids):   # EVERY game of the device-driven run is the host-driven run's game
         a, b = shipped[g], on_device[g]
         assert a.moves == b.moves and a.winner == b.winner, 'game %d depends on where its moves are drawn' % g

@@ -31,8 +31,8 @@ def main(path):
             continue
     print('%-8s %-6s %-6s %-8s %-8s %-5s  %s' % ('VGPRs', 'AGPRs', 'SGPRs', 'scratch', 'LDS', 'occ', 'kernel'))
     for r, d in sorted(zip(rows, dem), key=lambda rd: rd[1]):
-        d = re.sub(r'^void ', '', d)
-        d = re.sub(r'\(.*$', '', d).replace('(anonymous namespace)::', '')
+        d = re.sub(r'^void ', '', d).replace('(anonymous namespace)::', '')
+        d = re.sub(r'\((?!anonymous).*$', '', d)   # (the argument list)
         print('%-8d %-6d %-6d %-8d %-8d %-5d  %s' % (r.get('VGPRs', -1), r.get('AGPRs', -1), r.get('TotalSGPRs', -1), r.get('ScratchSize', -1),
                                                  r.get('LDS Size', -1), r.get('Occupancy', -1), d))
 

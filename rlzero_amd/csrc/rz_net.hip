@@ -865,7 +865,7 @@ struct LeafBits {
 // Development aid (not built by default): -DRZ_NET_PROFILE accumulates the shader-clock cycles wave 0 of workgroup 0 spends in
 // each phase of a board in k_trunk_split into net_prof[] (rz_net_debug_profile).
 #ifdef RZ_NET_PROFILE
-__device__ long long net_prof[16];
+__device__ long long net_prof[24];   // [16 .. 19]: the resident search's tree phases (value head, expand / backup, selection, planes)
 #define NET_TICK(i) do { __builtin_amdgcn_sched_barrier(0); const long long now_ = __builtin_readcyclecounter(); prof_acc[i] += now_ - prof_t; prof_t = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define NET_TICK(i)
@@ -924,7 +924,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
                                                      ResArgs<RES> res = ResArgs<RES>{}) {
 #ifdef RZ_NET_PROFILE
     const long long prof_k0 = __builtin_readcyclecounter();
-    long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = prof_k0;
+    long long prof_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = prof_k0;
 #endif
     constexpr int kThreads = 256;
     // RES (the resident search, see ResArgs): the value head's input row (boards of up to 10 rows and columns: 2 S <= 256 with
@@ -1504,22 +1504,26 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         if (res.vh.groups == 64) rzt::value_quarter_lds<8>(res.vh, res_vrow, lane, wave, res_part);
         else if (res.vh.groups == 32) rzt::value_quarter_lds<4>(res.vh, res_vrow, lane, wave, res_part);
         else rzt::value_quarter_lds<2>(res.vh, res_vrow, lane, wave, res_part);
+        NET_TICK(16);
         if (wave == 0) rzt::expand_backup_body<float, false, false, false, true>(res.E, nullptr, nullptr, game, lane, rz_raw_heads(), 0, res.vh, res_part);
         else __syncthreads();   // (the barrier inside the body, where the quarters meet)
         __syncthreads();        // the tree's updates before the selection's loads
+        NET_TICK(17);
         const bool more = sim + 1 < res_sims(res);
         if (wave == 0 && more) rzt::select_body<false>(res.E, nullptr, game, lane, 0, res_leaf);
         __syncthreads();
+        NET_TICK(18);
         if (more) {   // the planes of the next leaf, from LDS: what load_bits forms from the leaf arrays
             planes_from_lds(tid);
             store_obs(tid);
             __syncthreads();
         }
+        NET_TICK(19);
     }
     }  // boards
 #ifdef RZ_NET_PROFILE
     if (blockIdx.x == 0 && tid0 == 0) {
-        for (int i = 0; i < 16; ++i) net_prof[i] = prof_acc[i];
+        for (int i = 0; i < 24; ++i) net_prof[i] = prof_acc[i];
         net_prof[10] = __builtin_readcyclecounter() - prof_k0;
     }
 #endif
@@ -1710,7 +1714,7 @@ __device__ __forceinline__ void trunk_rows_body(const NetDev &nd, const float *_
     }
 #ifdef RZ_NET_PROFILE
     const long long prof_k0 = __builtin_readcyclecounter();
-    long long prof_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = prof_k0;
+    long long prof_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = prof_k0;
 #endif
     constexpr int kThreads = 256;
     constexpr int P1 = rt::Geo<32>::pos_bytes, P2 = rt::Geo<64>::pos_bytes;
@@ -2081,12 +2085,15 @@ __device__ __forceinline__ void trunk_rows_body(const NetDev &nd, const float *_
         const int game = blockIdx.x;
         if (res.vh.groups == 128) rzt::value_quarter_lds<16>(res.vh, res_vrow, lane, wave, res_part);
         else rzt::value_quarter_lds<8>(res.vh, res_vrow, lane, wave, res_part);
+        NET_TICK(16);
         if (wave == 0) rzt::expand_backup_body<float, false, false, false, true>(res.E, nullptr, nullptr, game, lane, rz_raw_heads(), 0, res.vh, res_part);
         else __syncthreads();   // (the barrier inside the body, where the quarters meet)
         __syncthreads();        // the tree's updates before the selection's loads
+        NET_TICK(17);
         const bool more = sim + 1 < res_sims(res);
         if (wave == 0 && more) rzt::select_body<false>(res.E, nullptr, game, lane, 0, res_leaf);
         __syncthreads();
+        NET_TICK(18);
         if (more) {   // the planes of the next leaf, from LDS: what load_bits forms from the leaf arrays
             planes_from_lds(tid);
             // conv1's weight fragments again (6 KB, L2-resident; their latency passes under the barrier below): carried in
@@ -2099,11 +2106,12 @@ __device__ __forceinline__ void trunk_rows_body(const NetDev &nd, const float *_
             store_obs();
             __syncthreads();
         }
+        NET_TICK(19);
     }
     }  // boards
 #ifdef RZ_NET_PROFILE
     if (blockIdx.x == 0 && tid0 == 0) {
-        for (int i = 0; i < 16; ++i) net_prof[i] = prof_acc[i];
+        for (int i = 0; i < 24; ++i) net_prof[i] = prof_acc[i];
         net_prof[10] = __builtin_readcyclecounter() - prof_k0;
     }
 #endif
@@ -3480,7 +3488,7 @@ int rz_net_range_info(rz_net *net, float *h_info8) {
 
 #ifdef RZ_NET_PROFILE
 int rz_net_debug_profile(long long *h_out16) {
-    return hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(net_prof), 16 * sizeof(long long)) == hipSuccess ? RZ_OK : RZ_ERR_HIP;
+    return hipDeviceSynchronize() == hipSuccess && hipMemcpyFromSymbol(h_out16, HIP_SYMBOL(net_prof), 24 * sizeof(long long)) == hipSuccess ? RZ_OK : RZ_ERR_HIP;
 }
 #endif
 

@@ -694,11 +694,11 @@ __global__ void k_tree_step_ml(Dev E, const float *logp, const float *value, Raw
         double tval = 0.0;
         int winner = -1;
         if (depth == 0) {
-            if (line_anywhere(st[0], S, E.BH, E.BW, E.n_row, lane)) winner = 0;
-            else if (line_anywhere(st[1], S, E.BH, E.BW, E.n_row, lane)) winner = 1;
+            if (line_anywhere(st[0], S, E.BH, E.BW, E.n_row, lane, E.bw_rcp)) winner = 0;
+            else if (line_anywhere(st[1], S, E.BH, E.BW, E.n_row, lane, E.bw_rcp)) winner = 1;
         } else {
             const int mover = to_move ^ 1;
-            if (line_through(mover == 0 ? st[0] : st[1], last, E.BH, E.BW, E.n_row, lane)) winner = mover;
+            if (line_through(mover == 0 ? st[0] : st[1], last, E.BH, E.BW, E.n_row, lane, E.bw_rcp, E.n_rcp)) winner = mover;
         }
         if (winner >= 0) {
             term = 2;
@@ -804,7 +804,7 @@ __global__ __launch_bounds__(kWave) void k_eval_rollout(Dev E, uint64_t seed, ui
         }
         if (to_move == 0) set_bit(st[0], cell); else set_bit(st[1], cell);
         nst += 1;
-        if (line_through(to_move == 0 ? st[0] : st[1], cell, E.BH, E.BW, E.n_row, lane)) {
+        if (line_through(to_move == 0 ? st[0] : st[1], cell, E.BH, E.BW, E.n_row, lane, E.bw_rcp, E.n_rcp)) {
             term = 2;
             winner = to_move;
         } else if (nst == S) {
@@ -1005,8 +1005,8 @@ __device__ __forceinline__ void step_body(const Dev &E, int g, int lane, int mv,
         }
     }
     who = -1;
-    if (line_anywhere(st[0], S, E.BH, E.BW, E.n_row, lane)) who = 0;
-    else if (line_anywhere(st[1], S, E.BH, E.BW, E.n_row, lane)) who = 1;
+    if (line_anywhere(st[0], S, E.BH, E.BW, E.n_row, lane, E.bw_rcp)) who = 0;
+    else if (line_anywhere(st[1], S, E.BH, E.BW, E.n_row, lane, E.bw_rcp)) who = 1;
     over = who >= 0 || count_bits(st[0]) + count_bits(st[1]) == S;
 }
 
@@ -1447,6 +1447,8 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     D.S = S;
     D.A = A;
     D.n_row = n_row;
+    D.bw_rcp = (65536 + BW - 1) / BW;
+    D.n_rcp = (65536 + n_row - 1) / n_row;
     D.n_games = cfg->n_games;
     D.n_playout = cfg->n_playout;
     D.K = cfg->sims_in_flight > 1 ? cfg->sims_in_flight : 1;

@@ -50,6 +50,9 @@ struct Dev {
     uint64_t *pend_stones;
     unsigned long long *trace;   // rz_trace.h (NULL: none)
     uint64_t valid[kWords];
+    // x / BW and x / n_row for x < 4096 as (x * rcp) >> 16 (rcp = ceil(65536 / d): exact while x * (rcp * d - 65536) < 65536): the
+    // rule checks divide cell numbers and lane numbers, and an integer division is ~35 instructions of a latency-bound wave
+    int bw_rcp, n_rcp;
 };
 
 // the packed node record
@@ -202,14 +205,14 @@ __device__ __forceinline__ int lane_action_rank(const Dev &E, const uint64_t *oc
 // n-in-row through `last` only: lane l < 4n tests the window of direction l/n that starts
 // l%n steps before `last`.  Equivalent to the reference's whole-board scan
 // (gomoku_env.py:136-168) when the position before `last` had no line.
-__device__ __forceinline__ bool line_through(const uint64_t *x, int last, int BH, int BW, int n, int lane) {
+__device__ __forceinline__ bool line_through(const uint64_t *x, int last, int BH, int BW, int n, int lane, int bw_rcp, int n_rcp) {
     bool hit = false;
     if (lane < 4 * n) {
-        const int d = lane / n, t = lane - d * n;
+        const int d = (lane * n_rcp) >> 16, t = lane - d * n;
         const int stride = (d == 0) ? 1 : (d == 1) ? BW : (d == 2) ? BW + 1 : BW - 1;
         const int start = last - t * stride;
         if (start >= 0) {
-            const int h = start / BW, w = start - h * BW;
+            const int h = (start * bw_rcp) >> 16, w = start - h * BW;
             const bool right = w <= BW - n, down = h <= BH - n, left = w >= n - 1;
             const bool ok = (d == 0) ? right : (d == 1) ? down : (d == 2) ? (right && down)
                                                                           : (left && down);
@@ -223,11 +226,11 @@ __device__ __forceinline__ bool line_through(const uint64_t *x, int last, int BH
 }
 
 // Whole-board n-in-row scan of one colour (gomoku_env.py:136-168), lanes over start cells.
-__device__ __forceinline__ bool line_anywhere(const uint64_t *x, int S, int BH, int BW, int n, int lane) {
+__device__ __forceinline__ bool line_anywhere(const uint64_t *x, int S, int BH, int BW, int n, int lane, int bw_rcp) {
     bool hit = false;
     for (int m = lane; m < S; m += kWave) {
         if (!test_bit(x, m)) continue;
-        const int h = m / BW, w = m - h * BW;
+        const int h = (m * bw_rcp) >> 16, w = m - h * BW;
         const bool right = w <= BW - n, down = h <= BH - n, left = w >= n - 1;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
@@ -593,11 +596,11 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
     {
         int winner = -1;
         if (depth == 0) {
-            if (line_anywhere(st[0], S, E.BH, E.BW, E.n_row, lane)) winner = 0;
-            else if (line_anywhere(st[1], S, E.BH, E.BW, E.n_row, lane)) winner = 1;
+            if (line_anywhere(st[0], S, E.BH, E.BW, E.n_row, lane, E.bw_rcp)) winner = 0;
+            else if (line_anywhere(st[1], S, E.BH, E.BW, E.n_row, lane, E.bw_rcp)) winner = 1;
         } else {
             const int mover = to_move ^ 1;
-            if (line_through(mover == 0 ? st[0] : st[1], last, E.BH, E.BW, E.n_row, lane)) winner = mover;
+            if (line_through(mover == 0 ? st[0] : st[1], last, E.BH, E.BW, E.n_row, lane, E.bw_rcp, E.n_rcp)) winner = mover;
         }
         if (winner >= 0) {
             term = 2;

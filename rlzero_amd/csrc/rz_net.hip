@@ -705,9 +705,10 @@ typedef const __attribute__((address_space(3))) f16x8 *lds_frag;
 constexpr float kObsScale = 16.0f;  // observation planes (0 / 1) are stored times 16
 constexpr float kMaxActScale = 16.0f, kF16Room = 60000.0f;  // activation scales: powers of two <= 16 that keep bound * scale < 60000
 constexpr int kGridPos = 18 * 18;
-template <int CIN> struct Geo {
+// POS: positions of the halo grid (18 x 18 in general; the compact layout of small boards: see k_trunk_split's RW / RH)
+template <int CIN, int POS = kGridPos> struct Geo {
     static constexpr int pos_bytes = (CIN + 8) * 2;          // 80 / 144
-    static constexpr int piece_bytes = kGridPos * pos_bytes;  // 25 920 / 46 656
+    static constexpr int piece_bytes = POS * pos_bytes;      // 25 920 / 46 656 on the 18 x 18 grid
     static constexpr int chunks = CIN / 16, steps = 9 * chunks;
 };
 constexpr int kC1Bytes = 2 * Geo<32>::piece_bytes, kC2Bytes = 2 * Geo<64>::piece_bytes;
@@ -754,7 +755,7 @@ __device__ __forceinline__ void split4(const float (&z)[4], f16x4 &hi, f16x4 &lo
 constexpr int ring_depth(int tm, int tn) { return tm * tn >= 3 ? 3 : 5; }
 // (and of the ring of activation fragments: read from LDS one step ahead)
 constexpr int act_depth(int, int) { return 2; }   // (3 for the small tiles was tried: no gain, their steps are bound by the accumulator chain)
-template <int CIN, int TM, int TN, int RPT, int S, int I>
+template <int CIN, int TM, int TN, int RPT, int RW, int S, int I>
 __device__ __forceinline__ void slot(f32x16 (&acc)[TM][TN], f16x8 (&a)[ring_depth(TM, TN)][TM][2], f16x8 (&b)[act_depth(TM, TN)][TN][2], lds_frag q0,
                                      lds_frag q1, __amdgpu_buffer_rsrc_t w_rsrc, int w_base, int w_lane) {
     using G = Geo<CIN>;
@@ -771,7 +772,7 @@ __device__ __forceinline__ void slot(f32x16 (&acc)[TM][TN], f16x8 (&a)[ring_dept
     if constexpr (I < 2 * TN) {
         if constexpr (S + DB - 1 < G::steps) {
             constexpr int s1 = S + DB - 1, tap = s1 / G::chunks, c = s1 % G::chunks, nn = I / 2, piece = I % 2;
-            constexpr int off = ((RPT * nn + tap / 3) * kRowW + tap % 3) * G::pos_bytes + c * 32;
+            constexpr int off = ((RPT * nn + tap / 3) * RW + tap % 3) * G::pos_bytes + c * 32;
             static_assert(off % 16 == 0 && off < 65536, "ds_read_b128 immediate");
             b[s1 % DB][nn][piece] = (piece ? q1 : q0)[off / 16];
         }
@@ -787,18 +788,18 @@ __device__ __forceinline__ void slot(f32x16 (&acc)[TM][TN], f16x8 (&a)[ring_dept
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int CIN, int TM, int TN, int RPT, int S, int... Is>
+template <int CIN, int TM, int TN, int RPT, int RW, int S, int... Is>
 __device__ __forceinline__ void step(std::integer_sequence<int, Is...>, f32x16 (&acc)[TM][TN], f16x8 (&a)[ring_depth(TM, TN)][TM][2],
                                      f16x8 (&b)[act_depth(TM, TN)][TN][2], lds_frag q0, lds_frag q1, __amdgpu_buffer_rsrc_t w_rsrc,
                                      int w_base, int w_lane) {
-    (slot<CIN, TM, TN, RPT, S, Is>(acc, a, b, q0, q1, w_rsrc, w_base, w_lane), ...);
+    (slot<CIN, TM, TN, RPT, RW, S, Is>(acc, a, b, q0, q1, w_rsrc, w_base, w_lane), ...);
 }
 
-template <int CIN, int TM, int TN, int RPT, int... Ss>
+template <int CIN, int TM, int TN, int RPT, int RW, int... Ss>
 __device__ __forceinline__ void steps(std::integer_sequence<int, Ss...>, f32x16 (&acc)[TM][TN], f16x8 (&a)[ring_depth(TM, TN)][TM][2],
                                       f16x8 (&b)[act_depth(TM, TN)][TN][2], lds_frag q0, lds_frag q1, __amdgpu_buffer_rsrc_t w_rsrc,
                                       int w_base, int w_lane) {
-    (step<CIN, TM, TN, RPT, Ss>(std::make_integer_sequence<int, 3 * TM * TN>{}, acc, a, b, q0, q1, w_rsrc, w_base, w_lane), ...);
+    (step<CIN, TM, TN, RPT, RW, Ss>(std::make_integer_sequence<int, 3 * TM * TN>{}, acc, a, b, q0, q1, w_rsrc, w_base, w_lane), ...);
 }
 
 // The weight fragments of the first K-steps (M-tiles 0 .. TM-1): no dependence on LDS, so a layer's first
@@ -819,13 +820,13 @@ __device__ __forceinline__ void preload_w(f16x8 (&a)[ring_depth(TM, TN)][TM][2],
 // N-tiles nt0 .. nt0 + TN - 1 (`in` = piece 0 of the layer's input in LDS, `a` primed by preload_w).
 // The lane's MFMA column is the position (row0 + ry, x) of the wave's first N-tile; a further tile of the wave (TN = 2
 // only) lies two rows below (RPT rows in general: the 3 + 1 variant runs three 3-row tiles in one wave).
-template <int CIN, int TM, int TN, int RPT = 2>
+template <int CIN, int TM, int TN, int RPT = 2, int RW = kRowW, int POS = kGridPos>
 __device__ __forceinline__ void conv(const char *in, const void *wts, int row0, int ry, int x, int lane,
                                      f16x8 (&a)[ring_depth(TM, TN)][TM][2], f32x16 (&acc)[TM][TN]) {
-    using G = Geo<CIN>;
+    using G = Geo<CIN, POS>;
     const int h = lane >> 5;
     // halo position (row0 + ry, x) = the top-left tap of output (row0 + ry, x)
-    const int lane_byte = ((row0 + ry) * kRowW + x) * G::pos_bytes + h * 16;
+    const int lane_byte = ((row0 + ry) * RW + x) * G::pos_bytes + h * 16;
     const lds_frag q0 = (lds_frag)(in + lane_byte), q1 = (lds_frag)(in + lane_byte + G::piece_bytes);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(wts), 0, 0x7fffffff, 0x00020000);
     f16x8 b[act_depth(TM, TN)][TN][2];
@@ -834,13 +835,13 @@ __device__ __forceinline__ void conv(const char *in, const void *wts, int row0, 
         const int tap = s0 / G::chunks, c = s0 % G::chunks;
 #pragma unroll
         for (int nn = 0; nn < TN; ++nn) {
-            const int off = ((RPT * nn + tap / 3) * kRowW + tap % 3) * G::pos_bytes + c * 32;
+            const int off = ((RPT * nn + tap / 3) * RW + tap % 3) * G::pos_bytes + c * 32;
             b[s0][nn][0] = q0[off / 16];
             b[s0][nn][1] = q1[off / 16];
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    steps<CIN, TM, TN, RPT>(std::make_integer_sequence<int, G::steps>{}, acc, a, b, q0, q1, w_rsrc, 0, lane * 16);
+    steps<CIN, TM, TN, RPT, RW>(std::make_integer_sequence<int, G::steps>{}, acc, a, b, q0, q1, w_rsrc, 0, lane * 16);
 }
 
 }  // namespace sp
@@ -915,8 +916,14 @@ struct DeferredOut {
 // quarters summed in wave order, fmaf(sum, scale, bias)): the same bits, one launch and one kernel boundary less in the chain
 // trunk -> FC -> tree step of a small batch.  A board is row 0 of the MFMA's 32 (the other rows are zero: rows do not mix), its
 // features never leave the CU (f16 pieces in LDS), the weights stream from L2.
-template <int TN, int MS = 1, bool RES = false>
-__global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__restrict__ obs, LeafBits leaves,
+// RW x RH: the halo grid of the activations in LDS.  18 x 18 (a board of up to 16 x 16) in general: 154 KB, one workgroup per CU.
+// COMPACT grids for small boards (RW = width + 2, RH such that RW x RH >= 128 positions: the channel-split variants park their
+// partial head sums in the padding of positions 0 .. 127) cut that to 60-70 KB -- TWO workgroups per CU: a board of 6 x 7 is a
+// latency chain of small MFMA loops, and two such chains interleave on a CU where one leaves the pipes idle most of the time.
+// Tile rows beyond the board still read positions past its ring (MFMA columns that are stored nowhere): inside the grid or
+// in the bytes behind it, always inside the workgroup's LDS.  (FC_HERE needs the big grid's spare rows: 18 x 18 only.)
+template <int TN, int MS = 1, bool RES = false, int RW = kRowW, int RH = 18>
+__global__ __launch_bounds__(256, (RW == kRowW ? 1 : 2)) void k_trunk_split(NetDev nd, const float *__restrict__ obs, LeafBits leaves,
                                                      float *__restrict__ feat, _Float16 *__restrict__ feat16,
                                                      int n_boards, unsigned *__restrict__ flags,
                                                      float *__restrict__ raw = nullptr, float *__restrict__ hid = nullptr,
@@ -938,11 +945,14 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         res_slot0 = res.E.pend[blockIdx.x];
         res_vrow[threadIdx.x] = 0.0f;
     }
-    __shared__ __attribute__((aligned(16))) char lds_raw[sp::kLdsBytes];
+    constexpr int POS = RW * RH, IC = RW + 2;   // positions of the halo grid; columns of the observation planes' grid
+    constexpr int kInPiece = RH * IC * 8, kInB = 2 * kInPiece, kC1B = 2 * sp::Geo<32, POS>::piece_bytes, kC2B = 2 * sp::Geo<64, POS>::piece_bytes;
+    static_assert(kInB % 16 == 0 && POS >= 128, "the grid: 16-byte pieces, 128 positions for the channel-split variants' partial sums");
+    __shared__ __attribute__((aligned(16))) char lds_raw[kInB + kC1B + kC2B + sp::kHeadFloats * 4];
     char *in0 = lds_raw;                      // observation planes, pieces hi | lo
-    char *c1 = lds_raw + sp::kInBytes;        // conv1 output, pieces hi | lo
-    char *c2 = c1 + sp::kC1Bytes;             // conv2 output, pieces hi | lo
-    float *hw = reinterpret_cast<float *>(c2 + sp::kC2Bytes);  // head weights [128][6], then conv3 biases [128]
+    char *c1 = lds_raw + kInB;                // conv1 output, pieces hi | lo
+    char *c2 = c1 + kC1B;                     // conv2 output, pieces hi | lo
+    float *hw = reinterpret_cast<float *>(c2 + kC2B);  // head weights [128][6], then conv3 biases [128]
     const int tid0 = threadIdx.x;
     const int BH = nd.BH, BW = nd.BW, S = nd.S;
     float zmax = 0.0f;  // largest scaled value this thread stored as f16 pieces
@@ -965,12 +975,12 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         for (int k = 0; k < kObsPer; ++k) {
             const int i = tid0 + k * kThreads;
             const int c = i / S, r = i - c * S, y = r / BW, x = r - y * BW;
-            obs_off[k] = i < 4 * S ? ((y + 1) * sp::kInCols + (x + 1)) * 8 + c * 2 : -1;
+            obs_off[k] = i < 4 * S ? ((y + 1) * IC + (x + 1)) * 8 + c * 2 : -1;
         }
     }
     // bit mode: thread t owns cell t (S <= 256 = threads); its 4 plane values as f16 (x 16: exact, the lo piece is 0)
     const int cell_y = tid0 / BW, cell_x = tid0 - cell_y * BW;
-    const int cell_off = tid0 < S ? ((cell_y + 1) * sp::kInCols + (cell_x + 1)) * 8 : -1;
+    const int cell_off = tid0 < S ? ((cell_y + 1) * IC + (cell_x + 1)) * 8 : -1;
     sp::f16x4 cell_planes = {(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
     auto load_bits = [&](int board, int tid) {
         const uint64_t *sb = leaves.stones + (size_t)board * 8;
@@ -992,7 +1002,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         if (from_bits) {
             if (cell_off >= 0) {
                 *reinterpret_cast<sp::f16x4 *>(in0 + cell_off) = cell_planes;
-                *reinterpret_cast<sp::f16x4 *>(in0 + sp::kInPieceBytes + cell_off) =
+                *reinterpret_cast<sp::f16x4 *>(in0 + kInPiece + cell_off) =
                     sp::f16x4{(_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
             }
             return;
@@ -1004,7 +1014,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
                 const _Float16 hi = (_Float16)z;
                 zmax = fmaxf(zmax, fabsf(z));
                 *reinterpret_cast<_Float16 *>(in0 + obs_off[k]) = hi;
-                *reinterpret_cast<_Float16 *>(in0 + sp::kInPieceBytes + obs_off[k]) = (_Float16)(z - (float)hi);
+                *reinterpret_cast<_Float16 *>(in0 + kInPiece + obs_off[k]) = (_Float16)(z - (float)hi);
             }
     };
     // Prologue of a persistent workgroup.  Every global load it needs -- head weights and conv3 biases (3.5 KB, bound for
@@ -1070,7 +1080,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         // its issue whatever the number of active lanes).
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         f32x4 *z = reinterpret_cast<f32x4 *>(lds_raw);
-        for (int i = tid0; i < sp::kInBytes / 16; i += kThreads) z[i] = zero;
+        for (int i = tid0; i < kInB / 16; i += kThreads) z[i] = zero;
         const int n_ring = 2 * (BW + 2) + 2 * BH;
         for (int it = tid0; it < 2 * n_ring; it += kThreads) {
             const int piece = it >= n_ring, idx = it - piece * n_ring;
@@ -1084,11 +1094,11 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
                 py = 1 + (j >> 1);
                 px = (j & 1) ? BW + 1 : 0;
             }
-            const int pos = py * kRowW + px;
-            f32x4 *q1 = reinterpret_cast<f32x4 *>(c1 + piece * sp::Geo<32>::piece_bytes + pos * sp::Geo<32>::pos_bytes);
+            const int pos = py * RW + px;
+            f32x4 *q1 = reinterpret_cast<f32x4 *>(c1 + piece * sp::Geo<32, POS>::piece_bytes + pos * sp::Geo<32>::pos_bytes);
 #pragma unroll
             for (int i = 0; i < sp::Geo<32>::pos_bytes / 16; ++i) q1[i] = zero;
-            f32x4 *q2 = reinterpret_cast<f32x4 *>(c2 + piece * sp::Geo<64>::piece_bytes + pos * sp::Geo<64>::pos_bytes);
+            f32x4 *q2 = reinterpret_cast<f32x4 *>(c2 + piece * sp::Geo<64, POS>::piece_bytes + pos * sp::Geo<64>::pos_bytes);
 #pragma unroll
             for (int i = 0; i < sp::Geo<64>::pos_bytes / 16; ++i) q2[i] = zero;
         }
@@ -1143,7 +1153,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
     const bool busy = row0 < BH;
     if (busy && part == 0) {   // conv1: 4 -> 32 (one M-tile), N-tiles TN*wave ..; K-step = kernel row ky
         typedef const __attribute__((address_space(3))) sp::f16x4 *lds_half;
-        const lds_half q = (lds_half)(in0 + ((row0 + ry) * sp::kInCols + x + 2 * h) * 8);
+        const lds_half q = (lds_half)(in0 + ((row0 + ry) * IC + x + 2 * h) * 8);
         sp::f16x8 b1[3][TN][2];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -1151,7 +1161,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
             for (int t = 0; t < TN; ++t)
 #pragma unroll
                 for (int p_ = 0; p_ < 2; ++p_) {
-                    const int o = ((2 * t + ky) * sp::kInCols * 8 + p_ * sp::kInPieceBytes) / 8;
+                    const int o = ((2 * t + ky) * IC * 8 + p_ * kInPiece) / 8;
                     const sp::f16x4 lo4 = q[o], hi4 = q[o + 1];
                     b1[ky][t][p_] = __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
@@ -1179,9 +1189,9 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
                     zmax = fmaxf(fmaxf(zmax, fmaxf(z[0], z[1])), fmaxf(z[2], z[3]));
                     sp::f16x4 hi, lo;
                     sp::split4(z, hi, lo);
-                    char *dst = c1 + ((y + 1) * kRowW + (x + 1)) * sp::Geo<32>::pos_bytes + (8 * g + 4 * h) * 2;
+                    char *dst = c1 + ((y + 1) * RW + (x + 1)) * sp::Geo<32>::pos_bytes + (8 * g + 4 * h) * 2;
                     *reinterpret_cast<sp::f16x4 *>(dst) = hi;
-                    *reinterpret_cast<sp::f16x4 *>(dst + sp::Geo<32>::piece_bytes) = lo;
+                    *reinterpret_cast<sp::f16x4 *>(dst + sp::Geo<32, POS>::piece_bytes) = lo;
                 }
             }
         }
@@ -1209,7 +1219,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         for (int m = 0; m < TM2; ++m)
 #pragma unroll
             for (int g = 0; g < 4; ++g) bias2[m][g] = *reinterpret_cast<const f32x4 *>(nd.b2 + (m2 + m) * 32 + 8 * g + 4 * h) * act2;
-        if (TN == 2 || (busy && conv2_mine)) sp::conv<32, TM2, TN>(c1, s2p, row0, ry, x, lane, a2, acc);
+        if (TN == 2 || (busy && conv2_mine)) sp::conv<32, TM2, TN, 2, RW, POS>(c1, s2p, row0, ry, x, lane, a2, acc);
         NET_TICK(2);
         sp::preload_w<64, TM3, TN>(a3, s3p, lane);
         // (position outermost: ONE guarded region per N-tile instead of one per group of 4 channels)
@@ -1217,7 +1227,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         for (int t = 0; t < TN; ++t) {
             const int y = row0 + 2 * t + ry;
             if (busy && conv2_mine && col_ok && y < BH && x < BW) {
-                char *pos = c2 + ((y + 1) * kRowW + (x + 1)) * sp::Geo<64>::pos_bytes + (m2 * 32 + 4 * h) * 2;
+                char *pos = c2 + ((y + 1) * RW + (x + 1)) * sp::Geo<64>::pos_bytes + (m2 * 32 + 4 * h) * 2;
 #pragma unroll
                 for (int m = 0; m < TM2; ++m)
 #pragma unroll
@@ -1231,7 +1241,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
                         sp::split4(z, hi, lo);
                         char *dst = pos + (m * 32 + 8 * g) * 2;
                         *reinterpret_cast<sp::f16x4 *>(dst) = hi;
-                        *reinterpret_cast<sp::f16x4 *>(dst + sp::Geo<64>::piece_bytes) = lo;
+                        *reinterpret_cast<sp::f16x4 *>(dst + sp::Geo<64, POS>::piece_bytes) = lo;
                     }
             }
         }
@@ -1253,7 +1263,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
             sp::f16x8 a3w[sp::ring_depth(1, 3)][1][2];
             sp::preload_w<64, 1, 3>(a3w, s3q, lane);
             sp::f32x16 accw[1][3];
-            sp::conv<64, 1, 3, 3>(c2, s3q, 0, ry, x, lane, a3w, accw);
+            sp::conv<64, 1, 3, 3, RW, POS>(c2, s3q, 0, ry, x, lane, a3w, accw);
 #pragma unroll
             for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -1281,7 +1291,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         }
         if (MS != 3 || part == 0) {
             sp::f32x16 acc[TM3][TN];
-            if (TN == 2 || busy) sp::conv<64, TM3, TN>(c2, s3p, row0, ry, x, lane, a3, acc);
+            if (TN == 2 || busy) sp::conv<64, TM3, TN, 2, RW, POS>(c2, s3p, row0, ry, x, lane, a3, acc);
             NET_TICK(5);
             // per (m, g): the lane's channels c0 .. c0+3 = 32*m + 8*g + 4*h ..: 24 head weights [j][output] and 4
             // biases from LDS, fetched one group ahead (the fences keep hipcc from hoisting all 16 groups' reads)
@@ -1328,13 +1338,13 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         const bool mine = busy && part == 0 && col_ok && (TN == 2 || h == 0);
         // MS > 1: the 6 sums of a position are spread over MS waves (their shares of the 128 channels): they meet in LDS
         float *pad_a = reinterpret_cast<float *>(c1 + ((part * kTiles + tile) * 32 + n) * sp::Geo<32>::pos_bytes + 64);
-        float *pad_b = reinterpret_cast<float *>(reinterpret_cast<char *>(pad_a) + sp::Geo<32>::piece_bytes);
+        float *pad_b = reinterpret_cast<float *>(reinterpret_cast<char *>(pad_a) + sp::Geo<32, POS>::piece_bytes);
         if (MS == 3) {   // wave 3 leaves its share of every tile's sums in slot (tile, n)
             if (part == 1) {
 #pragma unroll
                 for (int t = 0; t < 3; ++t) {
                     float *qa = reinterpret_cast<float *>(c1 + (t * 32 + n) * sp::Geo<32>::pos_bytes + 64);
-                    float *qb = reinterpret_cast<float *>(reinterpret_cast<char *>(qa) + sp::Geo<32>::piece_bytes);
+                    float *qb = reinterpret_cast<float *>(reinterpret_cast<char *>(qa) + sp::Geo<32, POS>::piece_bytes);
 #pragma unroll
                     for (int o = 0; o < 6; ++o) {
                         float v0 = vals3[t][o >> 1][o & 1];
@@ -1396,7 +1406,7 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         // FC_HERE: the board's f16 feature pieces [K-step][hi | lo][16] in LDS, inside halo rows 12 .. of conv2's region (a
         // board of up to 10 rows never reads them); zeroed K tail
         const bool fc_here = TN == 1 && raw != nullptr;
-        _Float16 *fa_lds = reinterpret_cast<_Float16 *>(c2 + 12 * kRowW * sp::Geo<64>::pos_bytes);
+        _Float16 *fa_lds = reinterpret_cast<_Float16 *>(c2 + 12 * RW * sp::Geo<64>::pos_bytes);
         const int fc_steps = nd.groups_act + nd.groups_val;
         if (fc_here) {
             for (int i = tid; i < fc_steps * 8; i += kThreads) reinterpret_cast<f32x2 *>(fa_lds)[i] = f32x2{0.0f, 0.0f};
@@ -1436,8 +1446,8 @@ __global__ __launch_bounds__(256) void k_trunk_split(NetDev nd, const float *__r
         if (raw != nullptr) {
             // ---- the first FC layers of both heads on this board (k_heads_split's arithmetic: see the kernel's header)
             __syncthreads();   // the feature pieces are in LDS
-            const _Float16 *fa_lds = reinterpret_cast<const _Float16 *>(c2 + 12 * kRowW * sp::Geo<64>::pos_bytes);
-            float *ps = reinterpret_cast<float *>(c2 + 15 * kRowW * sp::Geo<64>::pos_bytes);   // [K quarter][tile][32 outputs]
+            const _Float16 *fa_lds = reinterpret_cast<const _Float16 *>(c2 + 12 * RW * sp::Geo<64>::pos_bytes);
+            float *ps = reinterpret_cast<float *>(c2 + 15 * RW * sp::Geo<64>::pos_bytes);   // [K quarter][tile][32 outputs]
             const int n_act_tiles = nd.Npad / 32, n_tiles = n_act_tiles + 2;
             const f32x4 *zero_frag = nd.fs_act + (size_t)n_act_tiles * nd.groups_act * 128;
             const int half = lane >> 5;
@@ -2601,6 +2611,7 @@ struct rz_net {
     bool fp8_cross = false;      // RZ_NET_SPLIT_F16_FP8: algo stays RZ_NET_SPLIT_F16, conv3's cross terms run on the FP8 pipe (position-fed launches)
     int n_cus = 256;
     int max_wgs = 0;  // rz_net_set_max_workgroups: 0 = one persistent trunk workgroup per CU
+    bool compact_grid = true;   // small boards, more boards than CUs: k_trunk_split on the compact LDS grid, two workgroups per CU (RZ_NET_COMPACT=0: off)
     NetDev dev;
     std::vector<void *> allocs;
     std::vector<size_t> alloc_bytes;
@@ -2921,6 +2932,7 @@ int rz_net_create(int32_t height, int32_t width, int32_t n_actions, int32_t devi
     if (!net) return net_fail(RZ_ERR_OOM, "host allocation failed");
     net->board_size = height;
     net->device = device;
+    if (const char *v = getenv("RZ_NET_COMPACT")) net->compact_grid = v[0] != '0';
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -3216,6 +3228,11 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
                 case 15: launch_trunk_rows<15>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later, fp8); break;
                 default: launch_trunk_rows<16>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later, fp8); break;
             }
+        } else if (tiles <= 2 && !fc_here && net->compact_grid && n_boards > wg_cap && net->dev.BW <= 7 && tiles * net->dev.tile_rows + 2 <= 15) {
+            // small boards, more boards than CUs: the compact LDS grid (9 x 15 positions, 67 KB): two workgroups per CU
+            const dim3 cgrid((unsigned)(n_boards < 2 * wg_cap ? n_boards : 2 * wg_cap));
+            if (tiles <= 1) k_trunk_split<1, 4, false, 9, 15><<<cgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, nullptr, nullptr, later);
+            else k_trunk_split<1, 2, false, 9, 15><<<cgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, nullptr, nullptr, later);
         } else if (tiles <= 1)        // one tile: the four waves share the output channels
             k_trunk_split<1, 4><<<pgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, raw, hid, later);
         else if (tiles <= 2)   // two tiles x two channel halves

@@ -190,6 +190,9 @@ class TrainPipeline:
         answers = []
         for lane in self._batched.lanes:
             with torch.cuda.stream(lane.stream):
+                if getattr(lane.evaluator.hip, 'algo', 'split_f16') == 'split_f16_fp8':
+                    answers.append('position-fed-only')   # (the opt-in FP8 mode takes no float planes: nothing to digest here)
+                    continue
                 logp, value = lane.evaluator.hip.forward(obs)
             lane.stream.synchronize()
             answers.append(hashlib.sha1(logp.cpu().numpy().tobytes() + value.cpu().numpy().tobytes()).hexdigest())

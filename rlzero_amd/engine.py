@@ -390,7 +390,7 @@ class HostEvaluator(object):
     def __call__(self, eng):
         import torch
         stones, to_move, last, term = eng.get_leaves()
-        active = eng.active_host
+        active = eng.active_host if getattr(eng, '_play_active', None) is None else eng._play_active
         values = np.zeros(eng.n_games, dtype=np.float64)
         probs = np.zeros((eng.n_games, eng.n_actions), dtype=np.float32)
         for g in range(eng.n_games):
@@ -582,6 +582,7 @@ class MCTSEngine(object):
                 self.last_move.cpu().numpy())
 
     def set_active(self, active):
+        self._play_active = None   # (the host owns the flags again: HostEvaluator reads active_host)
         self.active_host = np.ascontiguousarray(active, dtype=np.uint8).copy()
         self.active_dev.copy_(self.torch.from_numpy(self.active_host))
         check(self.lib.rz_set_active(self.handle, _ptr(self.active_dev), self.stream()), 'rz_set_active')
@@ -656,6 +657,9 @@ class MCTSEngine(object):
         if isinstance(evaluator, HostEvaluator):
             if K > 1:
                 raise HipError('host evaluators are not available with sims_in_flight > 1')
+            if getattr(self, 'play_log', None) is not None and getattr(self, '_play_on', False):
+                # the move step on the device owns the games' active flags: which slots hold a running game, as of this search
+                self._play_active = (self.play_state()[2] == 1).astype(np.uint8)
             for _ in range(n):
                 self.sim_step(evaluator)
             return
@@ -960,6 +964,7 @@ class MCTSEngine(object):
                                 ring_steps=int(ring_steps), reserved=0)
         check(self.lib.rz_play_attach(self.handle, ctypes.byref(cfg)), 'rz_play_attach')
         self.play_steps = 0
+        self._play_on, self._play_active = True, None
         self.active_host[:] = 0
         return self.play_log
 
@@ -1027,6 +1032,7 @@ class MCTSEngine(object):
     def play_stop(self):
         self.flush_deferred()
         check(self.lib.rz_play_stop(self.handle, self.stream()), 'rz_play_stop')
+        self._play_active = None   # (the host-driven loop sets active flags of its own again: set_active)
 
     def play_state(self):
         """-> (game ids int64 [G] (-1 idle), plies, states (0 idle / 1 running / 2 stalled), move steps done); synchronises."""

@@ -111,3 +111,31 @@ def test_a_draw_near_an_interval_edge_is_the_host_s():
         sp.check()
         for lane in sp.lanes:
             lane.eng.close()
+
+
+def test_device_moves_with_a_host_callable_and_the_modes_that_refuse():
+    """Any `policy_value_fn` callable (evaluated per leaf on the host, alphazero_mcts.py:28-31,59) can sit in front of the device's
+    move step: the searches are host-paced, the moves still drawn, applied and logged by the device -- the oracle's games.  The
+    opt-in mode with several simulations in flight is refused (the move step assumes the reference's one simulation per tree)."""
+    from rlzero_amd._hip import HipError
+    from rlzero_amd.engine import HostEvaluator, MCTSEngine, SyntheticEvaluator
+    from rlzero_amd.games.gomoku.gomoku_env import GomokuEnv
+    from rlzero_amd.selfplay import BatchedSelfPlay, move_uniform
+    eng = MCTSEngine(3, 3, n_games=3, n_playout=30, device='cuda:0')
+    host = HostEvaluator(ev.vlin, lambda s0, s1, to_move, last: GomokuEnv.from_bitboards(3, 3, s0, s1, to_move, last))
+    sp = BatchedSelfPlay(eng, host, temperature=1.0, seed=2)
+    trajs = sp.run_device(range(5))
+    assert [t.game_id for t in trajs] == list(range(5))
+    for t in trajs:
+        us = move_uniform(2, np.full(16, t.game_id), np.arange(16))
+        player = RefPlayer(ev.vlin, 30, 5, is_selfplay=True, choice=inverse_cdf_choice(us))
+        winner, data, moves = self_play_game(RefGomoku(3, 3), player, temperature=1.0)
+        assert (winner, moves) == (t.winner, t.moves)
+        for (_, p1, _), p2 in zip(data, t.pis):
+            assert np.max(np.abs(p1 - p2)) <= 1e-12
+    eng.close()
+    eng2 = MCTSEngine(6, 4, n_games=4, n_playout=32, device='cuda:0', sims_in_flight=4)
+    sp2 = BatchedSelfPlay(eng2, SyntheticEvaluator('vlin'), temperature=1.0, seed=2)
+    with pytest.raises(HipError, match='one simulation in flight'):
+        sp2.run_device(range(4))
+    eng2.close()

@@ -19,9 +19,11 @@ fi
 
 # 2. per-kernel times: the headline command under rocprofv3 (hipGraph replays), then eager runs (one dispatch per kernel)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_default" -o s -- $B --steps 6 --warmup 2 > "$OUT/bench_under_rocprof.json" 2> /dev/null
+echo "stats default done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_fill" -o s -- $B --games 1536 --steps 6 --warmup 2 > "$OUT/bench_fill_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager" -o s -- $B --graph 0 --steps 2 > "$OUT/bench_eager_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_eager_host_moves" -o s -- $B --graph 0 --steps 2 --device-moves 0 > "$OUT/bench_eager_host_moves_under_rocprof.json" 2> /dev/null
+echo "stats eager done"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c1" -o s -- $B --steps 180 --warmup 20 --board 3 --playouts 25 --games 1 --lanes 1 > "$OUT/bench_c1_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c1x16" -o s -- $B --steps 180 --warmup 20 --board 3 --playouts 25 --games 16 --lanes 1 > "$OUT/bench_c1x16_under_rocprof.json" 2> /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_c2" -o s -- $B --steps 32 --warmup 8 --board 9 --playouts 200 --games 64 --lanes 1 > "$OUT/bench_c2_under_rocprof.json" 2> /dev/null
@@ -35,6 +37,7 @@ pmc() {  # tag, bench flags
     tag=$1; shift
     for c in FETCH_SIZE WRITE_SIZE; do
         rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_${tag}_$c" -o p -- $B --graph 0 --steps 1 --warmup 1 "$@" > "$OUT/pmc_${tag}.json" 2> /dev/null
+        echo "pmc $tag $c done"   # (a line a minute: a silent run is taken to be hung)
     done
 }
 if [ "${1:-}" != quick ]; then

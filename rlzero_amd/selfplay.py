@@ -96,7 +96,9 @@ class Trajectory(object):
         self.game = game
         self.board_size, self.n_in_row = board_size, int(n_in_row)
         self.moves = [int(m) for m in moves]
-        pis = np.asarray(pis, dtype=np.float64)
+        pis = np.asarray(pis)
+        if pis.dtype != np.float32:   # (float32 rows -- what came over the wire for the learner -- stay as they are: no 2x copy of a round's pi)
+            pis = pis.astype(np.float64, copy=False)
         self.pis = pis.reshape(len(self.moves), -1) if len(self.moves) else pis.reshape(0, 0)
         self.winner = int(winner)
 
@@ -950,13 +952,35 @@ def _payload_bytes(header, moves, pis, pi_dtype):
                            np.ascontiguousarray(pis, dtype=pi_dtype).reshape(-1).view(np.uint8)])
 
 
+def payload_of(trajs, n_cells, pi_dtype):
+    """_payload_bytes(*pack_trajectories(trajs), pi_dtype) in ONE pass: every game's pi is converted straight into its place in the
+    buffer (a collection round's pi is 100+ MB per rank: packing it through three intermediate copies cost more than sending it).
+    -> (bytes uint8, games, plies)."""
+    n_games, n_plies = len(trajs), sum(len(t.moves) for t in trajs)
+    item = np.dtype(pi_dtype).itemsize
+    raw = np.empty(n_games * 32 + n_plies * (8 + n_cells * item), dtype=np.uint8)
+    header = raw[:n_games * 32].view(np.int64).reshape(n_games, 4)
+    moves = raw[n_games * 32:n_games * 32 + 8 * n_plies].view(np.int64)
+    pis = raw[n_games * 32 + 8 * n_plies:].view(pi_dtype).reshape(n_plies, n_cells)
+    at = 0
+    for i, t in enumerate(trajs):
+        k = len(t.moves)
+        header[i] = (t.game_id, k, t.winner, 0)
+        moves[at:at + k] = t.moves
+        if k:
+            pis[at:at + k] = t.pis   # (numpy converts while it copies)
+        at += k
+    return raw, n_games, n_plies
+
+
 def _payload_split(raw, n_games, n_plies, n_cells, pi_dtype):
+    """-> header, moves, pi as VIEWS of the received bytes (float32 pi stays float32: Trajectory keeps it)."""
     at = n_games * 32
     header = raw[:at].view(np.int64).reshape(n_games, 4)
     moves = raw[at:at + 8 * n_plies].view(np.int64)
     at += 8 * n_plies
     pis = raw[at:at + n_plies * n_cells * np.dtype(pi_dtype).itemsize].view(pi_dtype).reshape(n_plies, n_cells)
-    return header, moves, pis.astype(np.float64)
+    return header, moves, pis
 
 
 def gather_trajectories(trajs, board_size, n_in_row, dst=0, group=None, game='gomoku', pi_dtype=np.float64):
@@ -982,9 +1006,8 @@ def gather_trajectories(trajs, board_size, n_in_row, dst=0, group=None, game='go
     pi_dtype = np.dtype(pi_dtype).type
     local_error, mine, n_games, n_plies = None, None, 0, 0
     try:
-        header, moves, pis = pack_trajectories(trajs, n_cells)
-        n_games, n_plies = header.shape[0], moves.shape[0]
-        mine = torch.from_numpy(_payload_bytes(header, moves, pis, pi_dtype)).to(device)
+        payload, n_games, n_plies = payload_of(trajs, n_cells, pi_dtype)
+        mine = torch.from_numpy(payload).to(device)
     except Exception as exc:  # noqa: BLE001
         local_error, mine, n_games, n_plies = exc, None, 0, 0
     sizes = torch.tensor([n_games, n_plies, 0 if local_error is None else 1], dtype=torch.int64, device=device)
@@ -996,9 +1019,9 @@ def gather_trajectories(trajs, board_size, n_in_row, dst=0, group=None, game='go
             np.nonzero(all_sizes[:, 2])[0].tolist(), '' if local_error is None else ' (here: %r)' % (local_error, )))
     row_bytes = 8 + n_cells * np.dtype(pi_dtype).itemsize
     n_bytes = all_sizes[:, 0] * 32 + all_sizes[:, 1] * row_bytes
-    send = torch.zeros(max(int(n_bytes.max()), 1), dtype=torch.uint8, device=device)
+    send = torch.empty(max(int(n_bytes.max()), 1), dtype=torch.uint8, device=device)   # (padded to the longest rank's; the padding is never read)
     send[:mine.numel()] = mine
-    bucket = [torch.zeros_like(send) for _ in range(world)] if rank == dst else None
+    bucket = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
     dist.gather(send, gather_list=bucket, dst=dst, group=group)                      # collective 2 of 2
     if rank != dst:
         return None

@@ -394,7 +394,7 @@ def _world8_worker(rank, world, port, n_games, result_path):
     if rank == 0:
         np.savez(result_path, ids=[t.game_id for t in merged], winners=[t.winner for t in merged],
                  plies=[len(t.moves) for t in merged], moves=np.concatenate([t.moves for t in merged]),
-                 pi_sum=np.array([float(t.pis.sum()) for t in merged]), pi0=np.stack([t.pis[0] for t in merged[::97]]))
+                 pi_sum=np.array([float(t.pis.astype(np.float64).sum()) for t in merged]), pi0=np.stack([t.pis[0] for t in merged[::97]]))
     else:
         assert merged is None
     dist.barrier()

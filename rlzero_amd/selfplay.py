@@ -119,13 +119,32 @@ class Trajectory(object):
         return np.where(movers == self.winner, 1.0, -1.0)
 
     def states(self):
-        """Observation planes before every move (current_state)."""
-        env = self._env()
-        out = []
-        for m in self.moves:
-            out.append(env.current_state())
-            env.step(m)
-        return out
+        """Observation planes before every move (GomokuEnv.current_state, gomoku_env.py:95-114): own stones, the opponent's, the
+        last move, ones iff an even number of stones.  Gomoku: formed from the move list at once (ply q's stone is on the board of
+        ply p > q, in plane 0 when q and p have the same parity -- two products of 0 / 1 matrices); Connect4 (stones drop: the cell
+        depends on the column's height) replays the moves through the env."""
+        if self.game == 'connect4':
+            env = self._env()
+            out = []
+            for m in self.moves:
+                out.append(env.current_state())
+                env.step(m)
+            return out
+        P, B = len(self.moves), self.board_size
+        if P == 0:
+            return []
+        moves = np.asarray(self.moves, dtype=np.int64)
+        onehot = np.zeros((P, B * B))
+        onehot[np.arange(P), moves] = 1.0
+        before = np.tri(P, P, -1)                                    # [p, q] = 1 where ply q was played before ply p
+        parity = np.arange(P) % 2
+        same = (parity[:, None] == parity[None, :]).astype(np.float64)
+        planes = np.zeros((P, 4, B * B))
+        planes[:, 0] = (before * same) @ onehot
+        planes[:, 1] = (before * (1.0 - same)) @ onehot
+        planes[1:, 2] = onehot[:-1]
+        planes[0::2, 3] = 1.0
+        return list(planes.reshape(P, 4, B, B))
 
     def as_reference_tuple(self):
         """(winner, [(state, mcts_prob, z), ...]) -- start_self_play's return value."""

@@ -149,12 +149,30 @@ class TrainPipeline:
 
     # ------------------------------------------------------------------ data
     def get_equi_data(self, play_data):
-        """8-fold augmentation: [(state, mcts_prob, winner_z), ...] -> 8x as many."""
+        """8-fold augmentation: [(state, mcts_prob, winner_z), ...] -> 8x as many, in the reference's order (per sample: for
+        i = 1..4 the pair rotated by i quarter turns, then its left-right mirror; train_alphazero.py:59-79).  A game's samples are
+        turned together -- numpy's rot90 / flip on the stacked arrays, the per-sample results of `_symmetries` (which
+        tests/golden/g5_equi.npz pins) as views of them: a 256-game round is 200 k samples, and one numpy call per plane and
+        sample was most of what the trainer's collection round cost the host."""
+        play_data = list(play_data)
+        if not play_data:
+            return []
         size = self.board_size
+        states = np.stack([np.asarray(s_) for s_, _, _ in play_data])                                   # [P, 4, B, B]
+        grids = np.stack([np.asarray(p_).reshape(size, size) for _, p_, _ in play_data])                # [P, B, B]
+        upside_down = grids[:, ::-1, :]                                                                 # np.flipud per sample
+        out_s, out_p = [], []
+        for quarter_turns in (1, 2, 3, 4):
+            turned = np.rot90(states, quarter_turns, axes=(2, 3))
+            pi_turned = np.rot90(upside_down, quarter_turns, axes=(1, 2))
+            out_s.append(np.ascontiguousarray(turned))
+            out_p.append(np.ascontiguousarray(pi_turned[:, ::-1, :]).reshape(len(play_data), -1))      # flipud, flatten
+            out_s.append(np.ascontiguousarray(turned[:, :, :, ::-1]))                                    # fliplr of every plane
+            out_p.append(np.ascontiguousarray(pi_turned[:, :, ::-1][:, ::-1, :]).reshape(len(play_data), -1))   # flipud(fliplr)
         extend_data = []
-        for state, mcts_prob, winner in play_data:
-            for equi_state, equi_prob in _symmetries(state, mcts_prob.reshape(size, size)):
-                extend_data.append((equi_state, equi_prob, winner))
+        for j, (_, _, winner) in enumerate(play_data):
+            for k in range(8):
+                extend_data.append((out_s[k][j], out_p[k][j], winner))
         return extend_data
 
     def _play_games(self, game_ids):

@@ -139,3 +139,27 @@ def test_device_moves_with_a_host_callable_and_the_modes_that_refuse():
     with pytest.raises(HipError, match='one simulation in flight'):
         sp2.run_device(range(4))
     eng2.close()
+
+
+def test_lanes_by_measurement_on_the_gpu():
+    """`for_network(lanes='measure')` (what a chip the tables were not measured on gets by itself): the table's pick and its
+    neighbours are built, timed for two moves with the device-driven loop and closed; the layout kept plays the games every layout
+    plays."""
+    import torch
+    from rlzero_amd import selfplay as sp_mod
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    from rlzero_amd.selfplay import BatchedSelfPlay
+    torch.manual_seed(6)
+    net = PolicyValueNet(6).to('cuda:0')
+    sp_mod._LANE_CACHE.clear()
+    kw = dict(board=6, n_in_row=4, n_games=12, n_playout=24, device='cuda:0', temperature=1.0, seed=3, use_graph=True, sims_per_graph=8)
+    sp = BatchedSelfPlay.for_network(net, lanes='measure', **kw)
+    assert sp.lanes_measured is not None and len(sp.lanes) in sp.lanes_measured and len(sp.lanes_measured) >= 2
+    assert all(rate > 0 for rate in sp.lanes_measured.values()) and len(sp_mod._LANE_CACHE) == 1
+    again = BatchedSelfPlay.for_network(net, lanes='measure', **kw)   # (cached: nothing is timed again)
+    assert len(again.lanes) == len(sp.lanes) and again.lanes_measured == sp.lanes_measured
+    one = BatchedSelfPlay.for_network(net, lanes=1, **kw)
+    _same(sp.run_device(range(20)), one.run(range(20)))
+    for s_ in (sp, again, one):
+        for lane in s_.lanes:
+            lane.eng.close()

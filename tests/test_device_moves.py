@@ -86,6 +86,28 @@ def test_device_moves_equal_host_moves(layout):
             lane.eng.close()
 
 
+@pytest.mark.parametrize('temperature', [1e-3, 0.5])
+def test_device_moves_at_other_temperatures(temperature):
+    """temperature = 1e-3 is get_action's default (alphazero_mcts.py:136): pi is all but one-hot, exp() underflows for every other
+    child and equal maxima share the probability -- the device's fp64 exp / log draw (or its stall, the margin scales with 1 / T)
+    gives the host loop's games and the oracle's, bit for bit; 0.5 for a temperature between."""
+    from rlzero_amd.engine import MCTSEngine, SyntheticEvaluator
+    from rlzero_amd.selfplay import BatchedSelfPlay, move_uniform
+    eng = MCTSEngine(6, 4, n_games=6, n_playout=50, device='cuda:0')
+    sp = BatchedSelfPlay(eng, SyntheticEvaluator('vlin'), temperature=temperature, seed=8)
+    dev = sp.run_device(range(14))
+    host = sp.run(range(14))
+    _same(dev, host)
+    for t in dev[::3]:
+        us = move_uniform(8, np.full(64, t.game_id), np.arange(64))
+        player = RefPlayer(ev.vlin, 50, 5, is_selfplay=True, choice=inverse_cdf_choice(us))
+        winner, data, moves = self_play_game(RefGomoku(6, 4), player, temperature=temperature)
+        assert (winner, moves) == (t.winner, t.moves)
+        for (_, p1, _), p2 in zip(data, t.pis):
+            assert np.max(np.abs(p1 - p2)) <= 1e-12
+    eng.close()
+
+
 def test_a_draw_near_an_interval_edge_is_the_host_s():
     """stall_margin = 0.08: roughly one draw in six lies that close to an edge of its interval -- the device does not draw, the
     slot sits out the coming searches, the host decides with numpy and hands the move back.  The games are those of the default

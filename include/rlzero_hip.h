@@ -270,7 +270,9 @@ typedef struct rz_value_head {
     const float *w2;      /* [64] val_fc2.weight */
     const float *b2;      /* [1] */
     int32_t ld;           /* = 4 * groups */
-    int32_t groups;       /* 16, 32, 64 or 128: four waves of the game's workgroup x 2 halves x 2, 4, 8 or 16 groups */
+    int32_t groups;       /* 16, 32, 64 or 128: four waves of the game's workgroup x 2 halves x 2, 4, 8 or 16 groups; 4 * groups
+                           * >= 2 * S (refused otherwise): the tree step also sizes its bitboard arithmetic by it -- a head of
+                           * 16 / 32 groups means a board of at most 64 cells, one 64-bit word per colour */
 } rz_value_head;
 /* rz_deferred_logits: the policy logits of the stored leaves after rz_net_deferred_gemm: row = slot * rows_per_slot + leaf */
 typedef struct rz_deferred_logits {

@@ -82,6 +82,9 @@ __global__ __launch_bounds__(kWave) void k_tree_step_raw(Dev E, RawHeads rh, flo
 }
 
 // ------------------------------------------------------------------ deferred priors (value_quarter_def: rz_tree.h)
+// A value head of 4 * 8 * PER inputs covers a board of at most 16 * PER cells (deferred_ok): PER says how many words of the
+// bitboards the tree code has to look at (rz_tree.h: W)
+template <int PER> constexpr int words_of_per() { return PER <= 4 ? 1 : (PER == 8 ? 2 : kWords); }
 template <int PER>
 __global__ __launch_bounds__(kWave * kDefWaves) void k_expand_backup_def(Dev E, ValueHead vh) {
     __shared__ float part[kDefWaves][kWave];
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(kWave * kDefWaves) void k_expand_backup_def(Dev E, 
         __syncthreads();
         return;
     }
-    expand_backup_body<float, false, false, false, true>(E, nullptr, nullptr, blockIdx.x, lane, RawHeads(), 0, vh, part);
+    expand_backup_body<float, false, false, false, true, words_of_per<PER>()>(E, nullptr, nullptr, blockIdx.x, lane, RawHeads(), 0, vh, part);
 }
 
 // (`obs` is always NULL on this route -- the trunk reads positions -- but stays a run-time argument: with the constant hipcc
@@ -111,9 +114,9 @@ __global__ __launch_bounds__(kWave * kDefWaves) void k_tree_step_def(Dev E, Valu
         __syncthreads();
         return;
     }
-    expand_backup_body<float, false, false, false, true>(E, nullptr, nullptr, blockIdx.x, lane, RawHeads(), 0, vh, part);
+    expand_backup_body<float, false, false, false, true, words_of_per<PER>()>(E, nullptr, nullptr, blockIdx.x, lane, RawHeads(), 0, vh, part);
     __syncthreads();   // (wave 0's alone: the other waves have ended)
-    select_body<false>(E, obs, blockIdx.x, lane);
+    select_body<false, words_of_per<PER>()>(E, obs, blockIdx.x, lane);
     if (TRACE && lane == 0) rz_trace_write(E.trace, RZ_TRACE_TREE, E.pend[blockIdx.x] - 1, blockIdx.x, trace_t0);
 }
 
@@ -1791,6 +1794,8 @@ static int deferred_ok(rz_engine *e, const rz_value_head *h) {
     if (h == nullptr || !h->valfeat || !h->w1t || !h->b1 || !h->w2 || !h->b2) return fail(RZ_ERR_ARG, "rz_value_head: NULL pointer");
     if ((h->groups != 16 && h->groups != 32 && h->groups != 64 && h->groups != 128) || h->ld != 4 * h->groups)
         return fail(RZ_ERR_ARG, "rz_value_head: groups = %d must be 16, 32, 64 or 128 and ld = 4 * groups", h->groups);
+    if (2 * e->dev.S > 4 * h->groups)   // (the kernels also size their bitboard arithmetic by it: words_of_per)
+        return fail(RZ_ERR_ARG, "rz_value_head: %d groups of 4 inputs do not hold the 2 x %d inputs of this board", h->groups, e->dev.S);
     if (e->dev.pend_cap <= 0) return fail(RZ_ERR_ARG, "call rz_deferred_reserve first");
     return RZ_OK;
 }

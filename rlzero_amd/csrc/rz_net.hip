@@ -934,6 +934,9 @@ __global__ __launch_bounds__(256, (RW == kRowW ? 1 : 2)) void k_trunk_split(NetD
     long long prof_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = prof_k0;
 #endif
     constexpr int kThreads = 256;
+    // the resident search's tree code (rz_tree.h: W): a board of one N-tile (MS = 4) or two (MS = 2) has at most 64 cells = one word
+    // of a bitboard, every board of this kernel (four tiles of 32 positions) at most 128 = two
+    constexpr int kResWords = (MS == 4 || MS == 2) ? 1 : 2;
     // RES (the resident search, see ResArgs): the value head's input row (boards of up to 10 rows and columns: 2 S <= 256 with
     // the padding), the K-quarter sums of its first layer, the next leaf
     __shared__ float res_vrow[RES ? 256 : 1];
@@ -1111,7 +1114,7 @@ __global__ __launch_bounds__(256, (RW == kRowW ? 1 : 2)) void k_trunk_split(NetD
     bool hw_pending = true;
     if constexpr (RES) {
         if (sel_first) {   // AlphaZeroMCTS._playout's select loop for the first simulation of the search (rz_select_step's work)
-            if ((tid0 >> 6) == 0) rzt::select_body<false>(res.E, nullptr, blockIdx.x, tid0 & 63, 0, res_leaf);
+            if ((tid0 >> 6) == 0) rzt::select_body<false, kResWords>(res.E, nullptr, blockIdx.x, tid0 & 63, 0, res_leaf);
             __syncthreads();
             planes_from_lds(tid0);
         }
@@ -1515,12 +1518,12 @@ __global__ __launch_bounds__(256, (RW == kRowW ? 1 : 2)) void k_trunk_split(NetD
         else if (res.vh.groups == 32) rzt::value_quarter_lds<4>(res.vh, res_vrow, lane, wave, res_part);
         else rzt::value_quarter_lds<2>(res.vh, res_vrow, lane, wave, res_part);
         NET_TICK(16);
-        if (wave == 0) rzt::expand_backup_body<float, false, false, false, true>(res.E, nullptr, nullptr, game, lane, rz_raw_heads(), 0, res.vh, res_part);
+        if (wave == 0) rzt::expand_backup_body<float, false, false, false, true, kResWords>(res.E, nullptr, nullptr, game, lane, rz_raw_heads(), 0, res.vh, res_part);
         else __syncthreads();   // (the barrier inside the body, where the quarters meet)
         __syncthreads();        // the tree's updates before the selection's loads
         NET_TICK(17);
         const bool more = sim + 1 < res_sims(res);
-        if (wave == 0 && more) rzt::select_body<false>(res.E, nullptr, game, lane, 0, res_leaf);
+        if (wave == 0 && more) rzt::select_body<false, kResWords>(res.E, nullptr, game, lane, 0, res_leaf);
         __syncthreads();
         NET_TICK(18);
         if (more) {   // the planes of the next leaf, from LDS: what load_bits forms from the leaf arrays

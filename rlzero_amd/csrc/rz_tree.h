@@ -78,36 +78,62 @@ __device__ __forceinline__ int32_t *rec_pb(int4 *R, int slot) { return reinterpr
 // a[j] for a lane-dependent j, as pure ALU on the four VALUES (masks, no selects of array elements): hipcc turns a
 // chain of `j == i ? a[i] : r` into ONE load with a selected address, which pins the whole board array in scratch
 // memory (a memory round trip inside the dependent chain of the tree kernels; 106 scratch instructions before)
+// W (template parameter of the helpers below and of the tree bodies): the 64-bit words of a colour's bitboard that the board can
+// use -- 1 for boards of up to 64 cells, 2 up to 128, kWords in general.  The arrays keep kWords words (the memory layout does not
+// change, the words past W are zero); a kernel that KNOWS its boards are small (its value head's width, its trunk's tiling) passes W
+// and the masks over four words become a shift: the tree code is one wave's instruction count (C1 +7 %, Connect4 +5 %).
+template <int W = kWords>
 __device__ __forceinline__ uint64_t word_of(const uint64_t *a, int j) {
+    if constexpr (W == 1) return a[0];
+    if constexpr (W == 2) {   // (masks, not a select of elements: see above)
+        const uint64_t m0 = j == 0 ? ~0ull : 0ull;
+        return (a[0] & m0) | (a[1] & ~m0);
+    }
     const uint64_t m0 = j == 0 ? ~0ull : 0ull, m1 = j == 1 ? ~0ull : 0ull, m2 = j == 2 ? ~0ull : 0ull,
                    m3 = j == 3 ? ~0ull : 0ull;
     return (a[0] & m0) | (a[1] & m1) | (a[2] & m2) | (a[3] & m3);
 }
+template <int W = kWords>
 __device__ __forceinline__ bool test_bit(const uint64_t *a, int c) {
-    return (word_of(a, c >> 6) >> (c & 63)) & 1ull;
+    return (word_of<W>(a, c >> 6) >> (c & 63)) & 1ull;
 }
+template <int W = kWords>
 __device__ __forceinline__ void set_bit(uint64_t *a, int c) {
     const uint64_t m = 1ull << (c & 63);
-    const int j = c >> 6;
-    a[0] |= (j == 0) ? m : 0ull;
-    a[1] |= (j == 1) ? m : 0ull;
-    a[2] |= (j == 2) ? m : 0ull;
-    a[3] |= (j == 3) ? m : 0ull;
+    if constexpr (W == 1) {
+        a[0] |= m;
+    } else {
+        const int j = c >> 6;
+        a[0] |= (j == 0) ? m : 0ull;
+        a[1] |= (j == 1) ? m : 0ull;
+        if constexpr (W > 2) {
+            a[2] |= (j == 2) ? m : 0ull;
+            a[3] |= (j == 3) ? m : 0ull;
+        }
+    }
 }
+template <int W = kWords>
 __device__ __forceinline__ int count_bits(const uint64_t *a) {
-    return __popcll(a[0]) + __popcll(a[1]) + __popcll(a[2]) + __popcll(a[3]);
+    int n = 0;
+#pragma unroll
+    for (int j = 0; j < W; ++j) n += __popcll(a[j]);
+    return n;
 }
+template <int W = kWords>
 __device__ __forceinline__ void load_board(const uint64_t *src, int g, uint64_t (&st)[2][kWords]) {
 #pragma unroll
     for (int j = 0; j < kWords; ++j) {
-        st[0][j] = src[((long long)g * 2 + 0) * kWords + j];
-        st[1][j] = src[((long long)g * 2 + 1) * kWords + j];
+        st[0][j] = j < W ? src[((long long)g * 2 + 0) * kWords + j] : 0ull;
+        st[1][j] = j < W ? src[((long long)g * 2 + 1) * kWords + j] : 0ull;
     }
 }
+template <int W = kWords>
 __device__ __forceinline__ void store_board(uint64_t *dst, int g, const uint64_t (&st)[2][kWords], int lane) {
     if (lane < 2 * kWords) {
         const int colour = lane / kWords, j = lane % kWords;
-        dst[((long long)g * 2 + colour) * kWords + j] = colour == 0 ? word_of(st[0], j) : word_of(st[1], j);
+        uint64_t v = colour == 0 ? word_of<W>(st[0], j) : word_of<W>(st[1], j);
+        if constexpr (W < kWords) v = j < W ? v : 0ull;   // (the words past W are zero)
+        dst[((long long)g * 2 + colour) * kWords + j] = v;
     }
 }
 
@@ -120,6 +146,7 @@ struct Legal {
     int height;                // Connect4: stones in column `lane` (per lane)
 };
 
+template <int W = kWords>
 __device__ __forceinline__ Legal legal_of(const Dev &E, const uint64_t *occ, int lane) {
     Legal L;
     L.cols = 0ull;
@@ -127,17 +154,18 @@ __device__ __forceinline__ Legal legal_of(const Dev &E, const uint64_t *occ, int
     if (E.kind == RZ_GAME_CONNECT4) {
         int h = 0;
         if (lane < E.BW)
-            for (int y = 0; y < E.BH; ++y) h += test_bit(occ, y * E.BW + lane) ? 1 : 0;
+            for (int y = 0; y < E.BH; ++y) h += test_bit<W>(occ, y * E.BW + lane) ? 1 : 0;
         L.height = h;
         L.cols = __ballot(lane < E.BW && h < E.BH);
         L.k = __popcll(L.cols);
     } else {
-        L.k = E.S - count_bits(occ);
+        L.k = E.S - count_bits<W>(occ);
     }
     return L;
 }
 
 // r-th legal action in ascending order -> (action, cell it occupies).  Wave-uniform.
+template <int W = kWords>
 __device__ __forceinline__ bool nth_legal(const Dev &E, const uint64_t *occ, const Legal &L, int r, int lane,
                                           int &action, int &cell) {
     if (E.kind == RZ_GAME_CONNECT4) {
@@ -152,7 +180,7 @@ __device__ __forceinline__ bool nth_legal(const Dev &E, const uint64_t *occ, con
     const uint64_t below = (1ull << lane) - 1ull;
     int before = 0, found = -1;
 #pragma unroll
-    for (int j = 0; j < kWords; ++j) {
+    for (int j = 0; j < W; ++j) {
         const uint64_t e = ~occ[j] & E.valid[j];
         const bool mine = (e >> lane) & 1ull;
         if (mine && before + __popcll(e & below) == r) found = 64 * j + lane;
@@ -205,6 +233,7 @@ __device__ __forceinline__ int lane_action_rank(const Dev &E, const uint64_t *oc
 // n-in-row through `last` only: lane l < 4n tests the window of direction l/n that starts
 // l%n steps before `last`.  Equivalent to the reference's whole-board scan
 // (gomoku_env.py:136-168) when the position before `last` had no line.
+template <int W = kWords>
 __device__ __forceinline__ bool line_through(const uint64_t *x, int last, int BH, int BW, int n, int lane, int bw_rcp, int n_rcp) {
     bool hit = false;
     if (lane < 4 * n) {
@@ -218,7 +247,7 @@ __device__ __forceinline__ bool line_through(const uint64_t *x, int last, int BH
                                                                           : (left && down);
             if (ok) {
                 hit = true;
-                for (int j = 0; j < n; ++j) hit = hit && test_bit(x, start + j * stride);
+                for (int j = 0; j < n; ++j) hit = hit && test_bit<W>(x, start + j * stride);
             }
         }
     }
@@ -226,10 +255,11 @@ __device__ __forceinline__ bool line_through(const uint64_t *x, int last, int BH
 }
 
 // Whole-board n-in-row scan of one colour (gomoku_env.py:136-168), lanes over start cells.
+template <int W = kWords>
 __device__ __forceinline__ bool line_anywhere(const uint64_t *x, int S, int BH, int BW, int n, int lane, int bw_rcp) {
     bool hit = false;
     for (int m = lane; m < S; m += kWave) {
-        if (!test_bit(x, m)) continue;
+        if (!test_bit<W>(x, m)) continue;
         const int h = (m * bw_rcp) >> 16, w = m - h * BW;
         const bool right = w <= BW - n, down = h <= BH - n, left = w >= n - 1;
 #pragma unroll
@@ -239,7 +269,7 @@ __device__ __forceinline__ bool line_anywhere(const uint64_t *x, int S, int BH, 
                                                                           : (left && down);
             if (!ok) continue;
             bool all = true;
-            for (int j = 1; j < n; ++j) all = all && test_bit(x, m + j * stride);
+            for (int j = 1; j < n; ++j) all = all && test_bit<W>(x, m + j * stride);
             hit = hit || all;
         }
     }
@@ -466,7 +496,7 @@ __device__ __forceinline__ int scan_children(const Dev &E, const int4 *R, const 
 // `lds_leaf` (the resident search kernels, rz_net.hip): the leaf position also goes to LDS -- uint64 [8] stones, then side to move
 // and last cell as two int32 -- where the trunk of the SAME workgroup reads it behind a barrier (a scalar load of the leaf arrays
 // could hit the scalar cache's copy of the previous simulation's leaf).
-template <bool VL>
+template <bool VL, int W = kWords>
 __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int lane, int j = 0, uint64_t *lds_leaf = nullptr) {
     const int gk = VL ? g * E.K + j : g;
     // every load that does not depend on another one is issued before `active` is tested: a kernel of dependent
@@ -478,13 +508,13 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
     const bool act = E.active[g] != 0;
     const int S = E.S;
     uint64_t st[2][kWords];
-    load_board(E.root_stones, g, st);
+    load_board<W>(E.root_stones, g, st);
     if (!act) return;
     int4 *R = arena_records(E, g, arena);
     const float *P = arena_priors(E, g, arena);
     const bool use_puct = E.score_mode == RZ_SCORE_PUCT;
     int top = top0;
-    int nst = count_bits(st[0]) + count_bits(st[1]);
+    int nst = count_bits<W>(st[0]) + count_bits<W>(st[1]);
 
     int32_t *path = E.path + (long long)gk * E.path_stride;
     int node = 0, depth = 0, fresh = 0;
@@ -567,13 +597,13 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
         uint64_t occ[kWords];
 #pragma unroll
         for (int j = 0; j < kWords; ++j) occ[j] = st[0][j] | st[1][j];
-        const Legal L = legal_of(E, occ, lane);
+        const Legal L = legal_of<W>(E, occ, lane);
         int action, cell;
-        if (!nth_legal(E, occ, L, r, lane, action, cell)) {
+        if (!nth_legal<W>(E, occ, L, r, lane, action, cell)) {
             flag(E, g, RZ_FLAG_INTERNAL, lane);
             break;
         }
-        if (to_move == 0) set_bit(st[0], cell); else set_bit(st[1], cell);
+        if (to_move == 0) set_bit<W>(st[0], cell); else set_bit<W>(st[1], cell);
         last = cell;
         to_move ^= 1;
         nst += 1;
@@ -596,11 +626,11 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
     {
         int winner = -1;
         if (depth == 0) {
-            if (line_anywhere(st[0], S, E.BH, E.BW, E.n_row, lane, E.bw_rcp)) winner = 0;
-            else if (line_anywhere(st[1], S, E.BH, E.BW, E.n_row, lane, E.bw_rcp)) winner = 1;
+            if (line_anywhere<W>(st[0], S, E.BH, E.BW, E.n_row, lane, E.bw_rcp)) winner = 0;
+            else if (line_anywhere<W>(st[1], S, E.BH, E.BW, E.n_row, lane, E.bw_rcp)) winner = 1;
         } else {
             const int mover = to_move ^ 1;
-            if (line_through(mover == 0 ? st[0] : st[1], last, E.BH, E.BW, E.n_row, lane, E.bw_rcp, E.n_rcp)) winner = mover;
+            if (line_through<W>(mover == 0 ? st[0] : st[1], last, E.BH, E.BW, E.n_row, lane, E.bw_rcp, E.n_rcp)) winner = mover;
         }
         if (winner >= 0) {
             term = 2;
@@ -619,9 +649,9 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
         E.leaf_to_move[gk] = to_move;
         E.leaf_last[gk] = last;
     }
-    store_board(E.leaf_stones, gk, st, lane);
+    store_board<W>(E.leaf_stones, gk, st, lane);
     if (lds_leaf != nullptr) {
-        store_board(lds_leaf, 0, st, lane);
+        store_board<W>(lds_leaf, 0, st, lane);
         if (lane == 0) {
             reinterpret_cast<int *>(lds_leaf + 2 * kWords)[0] = to_move;
             reinterpret_cast<int *>(lds_leaf + 2 * kWords)[1] = last;
@@ -653,7 +683,7 @@ constexpr int kDefWaves = 4;   // waves of a game's workgroup: all sum a quarter
 // game's workgroup has just finished (value_head_def below); an expansion reserves its prior block and leaves a record
 // (block, noise counter, board) in slot pend[g] -- the priors themselves are written by k_deferred_priors at the next flush
 // -- and every active game moves on to the next slot.
-template <typename VT, bool PROBS = false, bool RAW = false, bool VL = false, bool DEF = false>
+template <typename VT, bool PROBS = false, bool RAW = false, bool VL = false, bool DEF = false, int W = kWords>
 __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *logp, const VT *value, int g,
                                                    int lane, RawHeads rh = RawHeads(), int j = 0, ValueHead vh = ValueHead(),
                                                    float (*part)[kWave] = nullptr) {
@@ -673,7 +703,7 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
     const int32_t *path = E.path + (long long)gk * E.path_stride;
     const int path_lane = path[lane < E.path_stride ? lane : 0];  // the node of path level `lane` (if that level exists)
     uint64_t st[2][kWords];
-    load_board(E.leaf_stones, gk, st);
+    load_board<W>(E.leaf_stones, gk, st);
     float lse = 0.0f, raw_value = 0.0f;
     float x[kWords] = {0.f, 0.f, 0.f, 0.f};  // RAW: the lane's policy logits, kept for the priors below
     if (RAW) {
@@ -754,7 +784,7 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
         uint64_t occ[kWords];
 #pragma unroll
         for (int j = 0; j < kWords; ++j) occ[j] = st[0][j] | st[1][j];
-        const Legal L = legal_of(E, occ, lane);
+        const Legal L = legal_of<W>(E, occ, lane);
         const int k = L.k;
         const bool dense = !DEF && E.score_mode == RZ_SCORE_PUCT;
         const int top = dense ? top_now : 0;
@@ -782,7 +812,7 @@ __device__ __forceinline__ void expand_backup_body(const Dev &E, const float *lo
                     E.pend_ctr[rec] = noise_ctr;
                     if (E.add_noise) E.noise_ctr[g] = noise_ctr + 1;
                 }
-                store_board(E.pend_stones, (int)rec, st, lane);
+                store_board<W>(E.pend_stones, (int)rec, st, lane);
             }
             // TreeNode.expand: one child per legal move, prior from the policy head; in self-play
             // mixed with Dirichlet(0.3) noise at EVERY expanded node (node.py:63-69)

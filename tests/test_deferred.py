@@ -378,3 +378,28 @@ def test_a_flush_from_another_stream_waits_for_the_pending_steps():
         eng.close()
         evaluator.hip.close()
     assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32)) and out[0][1] == out[1][1]
+
+
+def test_a_value_head_narrower_than_the_board_is_refused():
+    """The tree step sizes its bitboard arithmetic by the value head's width (16 .. 128 groups of four inputs hold the 2 S inputs of
+    boards of up to 32 .. 256 cells: a TicTacToe or Connect4 board is one 64-bit word of a colour, rz_tree.h): a head that cannot
+    hold this engine's board is an error at the C ABI, not a search on half a board."""
+    import ctypes
+    from rlzero_amd import _hip
+    from rlzero_amd.engine import HipNetEvaluator, MCTSEngine
+    B, n = 9, 5
+    net = _net(B, seed=3)
+    evaluator = HipNetEvaluator(net, B, 'cuda:0', max_boards=2)
+    evaluator.resident_search = False
+    eng = MCTSEngine(B, n, n_games=2, n_playout=20, device='cuda:0')
+    eng.reset_games()
+    eng.sim_chunk(evaluator, 4)   # (the route works; a head as the trunk leaves it:)
+    head = evaluator.hip.trunk_leaves_deferred(eng)
+    assert head.groups == 64 and head.ld == 256   # 2 x 81 inputs
+    narrow = _hip.RzValueHead()
+    ctypes.memmove(ctypes.byref(narrow), ctypes.byref(head), ctypes.sizeof(head))
+    narrow.groups, narrow.ld = 16, 64
+    rc = eng.lib.rz_tree_step_deferred(eng.handle, ctypes.byref(narrow), None)
+    assert rc != 0 and b'do not hold' in eng.lib.rz_last_error()
+    eng.close()
+    evaluator.hip.close()

@@ -235,22 +235,17 @@ __device__ __forceinline__ int lane_action_rank(const Dev &E, const uint64_t *oc
 // (gomoku_env.py:136-168) when the position before `last` had no line.
 template <int W = kWords>
 __device__ __forceinline__ bool line_through(const uint64_t *x, int last, int BH, int BW, int n, int lane, int bw_rcp, int n_rcp) {
-    bool hit = false;
-    if (lane < 4 * n) {
-        const int d = (lane * n_rcp) >> 16, t = lane - d * n;
-        const int stride = (d == 0) ? 1 : (d == 1) ? BW : (d == 2) ? BW + 1 : BW - 1;
-        const int start = last - t * stride;
-        if (start >= 0) {
-            const int h = (start * bw_rcp) >> 16, w = start - h * BW;
-            const bool right = w <= BW - n, down = h <= BH - n, left = w >= n - 1;
-            const bool ok = (d == 0) ? right : (d == 1) ? down : (d == 2) ? (right && down)
-                                                                          : (left && down);
-            if (ok) {
-                hit = true;
-                for (int j = 0; j < n; ++j) hit = hit && test_bit<W>(x, start + j * stride);
-            }
-        }
-    }
+    // straight-line: every lane runs the window test on registers (test_bit reads no memory; a cell number outside the board tests a
+    // bit that the conditions below discard) -- short-circuit tests cost this single wave an exec-mask round per cell
+    const int d = (lane * n_rcp) >> 16, t = lane - d * n;
+    const int stride = (d == 0) ? 1 : (d == 1) ? BW : (d == 2) ? BW + 1 : BW - 1;
+    const int start = last - t * stride, s0 = start < 0 ? 0 : start;
+    const int h = (s0 * bw_rcp) >> 16, w = s0 - h * BW;
+    const bool right = w <= BW - n, down = h <= BH - n, left = w >= n - 1;
+    const bool ok = (d == 0) ? right : (d == 1) ? down : (d == 2) ? (right & down) : (left & down);
+    bool all = true;
+    for (int j = 0; j < n; ++j) all = all & test_bit<W>(x, s0 + j * stride);
+    const bool hit = (lane < 4 * n) & (start >= 0) & ok & all;
     return __ballot(hit) != 0ull;
 }
 
@@ -443,7 +438,8 @@ __device__ __forceinline__ int wave_first_max(double best, int besti) {
 // ------------------------------------------------------------------ SELECT + STEP
 // Score every child of a fully visited (or dense) node, lane r0 = lane + 64 j takes child r0, and
 // return the first maximum; the winner's record is broadcast so the descent needs no reload.
-template <bool PUCT>
+// (W: a board of W words has at most 64 W children per node -- W of the four child slots of a lane exist)
+template <bool PUCT, int W = kWords>
 __device__ __forceinline__ int scan_children(const Dev &E, const int4 *R, const float *P, const int4 &lo,
                                              const int4 &hi, double parent_term, int lane, int4 &clo, int4 &chi) {
     const int k = rec_k(lo), fc = lo.y, pb = hi.z;
@@ -454,9 +450,13 @@ __device__ __forceinline__ int scan_children(const Dev &E, const int4 *R, const 
     int4 h0 = make_int4(0, 0, -1, 0), h1 = h0, h2 = h0, h3 = h0;
     float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
     if (lane < k) { l0 = R[2 * (fc + lane)]; h0 = R[2 * (fc + lane) + 1]; if (PUCT) p0 = P[pb + lane]; }
-    if (lane + 64 < k) { l1 = R[2 * (fc + lane + 64)]; h1 = R[2 * (fc + lane + 64) + 1]; if (PUCT) p1 = P[pb + lane + 64]; }
-    if (lane + 128 < k) { l2 = R[2 * (fc + lane + 128)]; h2 = R[2 * (fc + lane + 128) + 1]; if (PUCT) p2 = P[pb + lane + 128]; }
-    if (lane + 192 < k) { l3 = R[2 * (fc + lane + 192)]; h3 = R[2 * (fc + lane + 192) + 1]; if (PUCT) p3 = P[pb + lane + 192]; }
+    if constexpr (W >= 2) {
+        if (lane + 64 < k) { l1 = R[2 * (fc + lane + 64)]; h1 = R[2 * (fc + lane + 64) + 1]; if (PUCT) p1 = P[pb + lane + 64]; }
+    }
+    if constexpr (W > 2) {
+        if (lane + 128 < k) { l2 = R[2 * (fc + lane + 128)]; h2 = R[2 * (fc + lane + 128) + 1]; if (PUCT) p2 = P[pb + lane + 128]; }
+        if (lane + 192 < k) { l3 = R[2 * (fc + lane + 192)]; h3 = R[2 * (fc + lane + 192) + 1]; if (PUCT) p3 = P[pb + lane + 192]; }
+    }
     double best = -INFINITY;
     int besti = 0x7fffffff;
     int4 blo = l0, bhi = h0;
@@ -473,9 +473,11 @@ __device__ __forceinline__ int scan_children(const Dev &E, const int4 *R, const 
         }
     };
     consider(l0, h0, p0, lane);
-    consider(l1, h1, p1, lane + 64);
-    consider(l2, h2, p2, lane + 128);
-    consider(l3, h3, p3, lane + 192);
+    if constexpr (W >= 2) consider(l1, h1, p1, lane + 64);
+    if constexpr (W > 2) {
+        consider(l2, h2, p2, lane + 128);
+        consider(l3, h3, p3, lane + 192);
+    }
     const int r = __builtin_amdgcn_readfirstlane(wave_first_max(best, besti));
     if (r >= k) return r;
     const int l = r & 63;
@@ -529,7 +531,7 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
         int4 clo = make_int4(0, -1, 0, 0), chi = make_int4(0, 0, -1, 0);
         if (use_puct) {
             // every child was initialised at expansion (N = 0, W = 0): scan all k
-            r = scan_children<true>(E, R, P, lo, hi, sqrt((double)lo.x), lane, clo, chi);
+            r = scan_children<true, W>(E, R, P, lo, hi, sqrt((double)lo.x), lane, clo, chi);
         } else if (lo.z < k) {
             // some child still has N == 0 -> score +inf, first such child wins; its record is
             // written by the backup of this simulation, here only the slot is reserved
@@ -584,7 +586,7 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
                 flag(E, g, RZ_FLAG_LOGTAB, lane);
                 break;
             }
-            r = scan_children<false>(E, R, P, lo, hi, E.logtab[pn], lane, clo, chi);
+            r = scan_children<false, W>(E, R, P, lo, hi, E.logtab[pn], lane, clo, chi);
         }
         if (r >= k) {
             flag(E, g, RZ_FLAG_INTERNAL, lane);

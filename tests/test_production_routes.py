@@ -106,6 +106,12 @@ CASES = [   # (id, game, shape, n_in_row, simulations per move, routes, games)
     ('C2_9x9_200', 'gomoku', 9, 5, 200, ('resident', 'two_launch_graph'), 6),
     ('C4_15x15_800', 'gomoku', 15, 5, 800, ('resident', 'two_launch_graph'), 6),
     ('C3_connect4_400', 'connect4', (6, 7), 4, 400, ('two_launch_graph', 'resident'), 5),
+    # the tree code is compiled per number of 64-bit words a board's bitboards use (rz_tree.h: W) -- the boundaries: 8 x 8 = 64 cells
+    # is the last one-word board (cell 63 = bit 63), 10 x 10 the largest two-word board of k_trunk_split, 11 x 11 = 121 cells runs the
+    # two-word tree step beside the row kernel's trunk (and the four-word code inside the resident row kernel)
+    ('W1_8x8_120', 'gomoku', 8, 5, 120, ('resident', 'two_launch_graph'), 4),
+    ('W2_10x10_120', 'gomoku', 10, 5, 120, ('resident', 'two_launch_graph'), 4),
+    ('W2_11x11_120', 'gomoku', 11, 5, 120, ('resident', 'two_launch_graph'), 4),
 ]
 N_MOVES = 4
 

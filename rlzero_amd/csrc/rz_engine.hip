@@ -1451,6 +1451,7 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     D.A = A;
     D.n_row = n_row;
     D.bw_rcp = (65536 + BW - 1) / BW;
+    for (int y = 0; y < BH && S <= 64; ++y) D.col0 |= 1ull << (y * BW);
     D.n_rcp = (65536 + n_row - 1) / n_row;
     D.n_games = cfg->n_games;
     D.n_playout = cfg->n_playout;

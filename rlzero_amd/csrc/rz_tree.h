@@ -53,6 +53,8 @@ struct Dev {
     // x / BW and x / n_row for x < 4096 as (x * rcp) >> 16 (rcp = ceil(65536 / d): exact while x * (rcp * d - 65536) < 65536): the
     // rule checks divide cell numbers and lane numbers, and an integer division is ~35 instructions of a latency-bound wave
     int bw_rcp, n_rcp;
+    // Connect4 on a one-word board: the cells of column 0 (bits y * BW, y < BH); << c = the cells of column c (legal_of<1>)
+    uint64_t col0;
 };
 
 // the packed node record
@@ -153,8 +155,12 @@ __device__ __forceinline__ Legal legal_of(const Dev &E, const uint64_t *occ, int
     L.height = 0;
     if (E.kind == RZ_GAME_CONNECT4) {
         int h = 0;
-        if (lane < E.BW)
-            for (int y = 0; y < E.BH; ++y) h += test_bit<W>(occ, y * E.BW + lane) ? 1 : 0;
+        if constexpr (W == 1) {   // a column's stones are one mask of the board's word
+            h = lane < E.BW ? __popcll(occ[0] & (E.col0 << lane)) : 0;
+        } else {
+            if (lane < E.BW)
+                for (int y = 0; y < E.BH; ++y) h += test_bit<W>(occ, y * E.BW + lane) ? 1 : 0;
+        }
         L.height = h;
         L.cols = __ballot(lane < E.BW && h < E.BH);
         L.k = __popcll(L.cols);

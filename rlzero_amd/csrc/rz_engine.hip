@@ -1350,6 +1350,7 @@ struct rz_engine {
     bool ml = false;     // sims_in_flight > 1: the level-synchronous kernel (default) instead of the sequential restatement
     int ml_lds = 0;
     double *d_logtab = nullptr;
+    uint64_t *d_line_tab = nullptr;   // Dev::line_tab
     Play play = {};      // rz_play_attach
     bool play_on = false, play_drawn = false;
     long long play_steps = 0;   // move steps enqueued (rz_play_apply calls) since rz_play_attach
@@ -1529,12 +1530,14 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     RZ_ALLOC(noise_ctr, G);
     RZ_ALLOC(noise_key, G);
     if (rc == RZ_OK) rc = dev_alloc(e, &e->d_logtab, D.logtab_n);
+    if (rc == RZ_OK) rc = dev_alloc(e, &e->d_line_tab, kWave);
 #undef RZ_ALLOC
     if (rc != RZ_OK) {
         rz_destroy(e);
         return rc;
     }
     D.logtab = e->d_logtab;
+    D.line_tab = e->d_line_tab;
     // zero the small state; arenas need no initialisation beyond the root slot
     hipError_t herr = hipSuccess;
     auto zero = [&](void *p, size_t bytes) { if (herr == hipSuccess) herr = hipMemset(p, 0, bytes); };
@@ -1559,6 +1562,18 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
         if (herr != hipSuccess) {
             rz_destroy(e);
             return fail(RZ_ERR_HIP, "hipMemcpy(log table) failed: %s", hipGetErrorString(herr));
+        }
+    }
+    {   // Dev::line_tab (one-word boards; zeros otherwise)
+        uint64_t tab[kWave] = {0};
+        for (int l = 0; l < kWave && l < 4 * n_row && S <= 64; ++l) {
+            const int d = l / n_row, stride = d == 0 ? 1 : d == 1 ? BW : d == 2 ? BW + 1 : BW - 1;
+            for (int j = 0; j < n_row && j * stride < 64; ++j) tab[l] |= 1ull << (j * stride);
+        }
+        herr = hipMemcpy(e->d_line_tab, tab, sizeof(tab), hipMemcpyHostToDevice);
+        if (herr != hipSuccess) {
+            rz_destroy(e);
+            return fail(RZ_ERR_HIP, "hipMemcpy(line table) failed: %s", hipGetErrorString(herr));
         }
     }
     {   // fresh trees

@@ -55,6 +55,10 @@ struct Dev {
     int bw_rcp, n_rcp;
     // Connect4 on a one-word board: the cells of column 0 (bits y * BW, y < BH); << c = the cells of column c (legal_of<1>)
     uint64_t col0;
+    // a one-word board: per LANE l < 4 n of line_through the n cells of its window, relative to the window's first cell (bits j * stride
+    // of direction l / n: right, down, down-right, down-left); a table in device memory -- four more 64-bit kernel arguments cost the
+    // tree step scalar registers it does not have (68 B of scratch)
+    const uint64_t *line_tab;
 };
 
 // the packed node record
@@ -240,7 +244,8 @@ __device__ __forceinline__ int lane_action_rank(const Dev &E, const uint64_t *oc
 // l%n steps before `last`.  Equivalent to the reference's whole-board scan
 // (gomoku_env.py:136-168) when the position before `last` had no line.
 template <int W = kWords>
-__device__ __forceinline__ bool line_through(const uint64_t *x, int last, int BH, int BW, int n, int lane, int bw_rcp, int n_rcp) {
+__device__ __forceinline__ bool line_through(const uint64_t *x, int last, int BH, int BW, int n, int lane, int bw_rcp, int n_rcp,
+                                             uint64_t window = 0) {
     // straight-line: every lane runs the window test on registers (test_bit reads no memory; a cell number outside the board tests a
     // bit that the conditions below discard) -- short-circuit tests cost this single wave an exec-mask round per cell
     const int d = (lane * n_rcp) >> 16, t = lane - d * n;
@@ -250,7 +255,11 @@ __device__ __forceinline__ bool line_through(const uint64_t *x, int last, int BH
     const bool right = w <= BW - n, down = h <= BH - n, left = w >= n - 1;
     const bool ok = (d == 0) ? right : (d == 1) ? down : (d == 2) ? (right & down) : (left & down);
     bool all = true;
-    for (int j = 0; j < n; ++j) all = all & test_bit<W>(x, s0 + j * stride);
+    if constexpr (W == 1) {   // the window's n cells are one mask of the board's word (`window` = Dev::line_tab[lane])
+        all = ((x[0] >> s0) & window) == window;
+    } else {
+        for (int j = 0; j < n; ++j) all = all & test_bit<W>(x, s0 + j * stride);
+    }
     const bool hit = (lane < 4 * n) & (start >= 0) & ok & all;
     return __ballot(hit) != 0ull;
 }
@@ -430,14 +439,17 @@ __device__ __forceinline__ void first_max_stage(double &best, int &besti, int la
         besti = oi;
     }
 }
-__device__ __forceinline__ int wave_first_max(double best, int besti) {
+// (`wide` == false: only lanes 0 .. 15 hold candidates -- a node of at most 16 children -- and lane 0 has the result after four stages)
+__device__ __forceinline__ int wave_first_max(double best, int besti, bool wide = true) {
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     first_max_stage<0>(best, besti, lane);
     first_max_stage<1>(best, besti, lane);
     first_max_stage<2>(best, besti, lane);
     first_max_stage<3>(best, besti, lane);
-    first_max_stage<4>(best, besti, lane);
-    first_max_stage<5>(best, besti, lane);
+    if (wide) {
+        first_max_stage<4>(best, besti, lane);
+        first_max_stage<5>(best, besti, lane);
+    }
     return besti;
 }
 
@@ -484,7 +496,8 @@ __device__ __forceinline__ int scan_children(const Dev &E, const int4 *R, const 
         consider(l2, h2, p2, lane + 128);
         consider(l3, h3, p3, lane + 192);
     }
-    const int r = __builtin_amdgcn_readfirstlane(wave_first_max(best, besti));
+    // (TicTacToe, Connect4, the end of a 6 x 6 game: at most 16 children, two stages of the arg-max less; a scalar branch)
+    const int r = __builtin_amdgcn_readfirstlane(wave_first_max(best, besti, W > 2 || __builtin_amdgcn_readfirstlane(k) > 16));
     if (r >= k) return r;
     const int l = r & 63;
     clo = make_int4(__builtin_amdgcn_readlane(blo.x, l), __builtin_amdgcn_readlane(blo.y, l),
@@ -517,6 +530,8 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
     const int S = E.S;
     uint64_t st[2][kWords];
     load_board<W>(E.root_stones, g, st);
+    uint64_t window = 0;   // (line_through<1>: asked for with the first loads, used at the end)
+    if constexpr (W == 1) window = E.line_tab[lane];
     if (!act) return;
     int4 *R = arena_records(E, g, arena);
     const float *P = arena_priors(E, g, arena);
@@ -638,7 +653,7 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
             else if (line_anywhere<W>(st[1], S, E.BH, E.BW, E.n_row, lane, E.bw_rcp)) winner = 1;
         } else {
             const int mover = to_move ^ 1;
-            if (line_through<W>(mover == 0 ? st[0] : st[1], last, E.BH, E.BW, E.n_row, lane, E.bw_rcp, E.n_rcp)) winner = mover;
+            if (line_through<W>(mover == 0 ? st[0] : st[1], last, E.BH, E.BW, E.n_row, lane, E.bw_rcp, E.n_rcp, window)) winner = mover;
         }
         if (winner >= 0) {
             term = 2;

@@ -1564,9 +1564,9 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
             return fail(RZ_ERR_HIP, "hipMemcpy(log table) failed: %s", hipGetErrorString(herr));
         }
     }
-    {   // Dev::line_tab (one-word boards; zeros otherwise)
+    {   // Dev::line_tab (boards of one or two words; zeros otherwise)
         uint64_t tab[kWave] = {0};
-        for (int l = 0; l < kWave && l < 4 * n_row && S <= 64; ++l) {
+        for (int l = 0; l < kWave && l < 4 * n_row && S <= 128; ++l) {
             const int d = l / n_row, stride = d == 0 ? 1 : d == 1 ? BW : d == 2 ? BW + 1 : BW - 1;
             for (int j = 0; j < n_row && j * stride < 64; ++j) tab[l] |= 1ull << (j * stride);
         }

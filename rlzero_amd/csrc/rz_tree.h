@@ -55,7 +55,7 @@ struct Dev {
     int bw_rcp, n_rcp;
     // Connect4 on a one-word board: the cells of column 0 (bits y * BW, y < BH); << c = the cells of column c (legal_of<1>)
     uint64_t col0;
-    // a one-word board: per LANE l < 4 n of line_through the n cells of its window, relative to the window's first cell (bits j * stride
+    // a board of one or two words: per LANE l < 4 n of line_through the n cells of its window, relative to the window's first cell (bits j * stride
     // of direction l / n: right, down, down-right, down-left); a table in device memory -- four more 64-bit kernel arguments cost the
     // tree step scalar registers it does not have (68 B of scratch)
     const uint64_t *line_tab;
@@ -257,6 +257,10 @@ __device__ __forceinline__ bool line_through(const uint64_t *x, int last, int BH
     bool all = true;
     if constexpr (W == 1) {   // the window's n cells are one mask of the board's word (`window` = Dev::line_tab[lane])
         all = ((x[0] >> s0) & window) == window;
+    } else if constexpr (W == 2) {   // ... of the 64 bits of the two words that begin at the window's first cell
+        const uint64_t from0 = (x[0] >> (s0 & 63)) | ((x[1] << 1) << (63 - (s0 & 63))), from1 = x[1] >> (s0 & 63);
+        const uint64_t v = s0 < 64 ? from0 : from1;
+        all = (v & window) == window;
     } else {
         for (int j = 0; j < n; ++j) all = all & test_bit<W>(x, s0 + j * stride);
     }
@@ -531,7 +535,7 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
     uint64_t st[2][kWords];
     load_board<W>(E.root_stones, g, st);
     uint64_t window = 0;   // (line_through<1>: asked for with the first loads, used at the end)
-    if constexpr (W == 1) window = E.line_tab[lane];
+    if constexpr (W <= 2) window = E.line_tab[lane];
     if (!act) return;
     int4 *R = arena_records(E, g, arena);
     const float *P = arena_priors(E, g, arena);

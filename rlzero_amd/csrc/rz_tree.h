@@ -432,29 +432,39 @@ __device__ __forceinline__ float wave_max(float x, int lane) {
     return x;
 }
 
+// The wave's maximum first (a stage = two moves and a compare-select on the score alone), then the FIRST index that has it: the
+// lanes whose own best equals the maximum vote by slot (index / 64) in ascending order, the lowest lane of the first non-empty
+// vote wins -- index = 64 * slot + lane.  (-0.0 == 0.0 as in Python's `>`; a lane's own best is already the first of its slots.)
+// The (score, index) pairs used to travel together: three moves, two fp64 compares, an integer compare and three selects per stage.
 template <int STAGE>
-__device__ __forceinline__ void first_max_stage(double &best, int &besti, int lane) {
-    const long long b = __double_as_longlong(best);
+__device__ __forceinline__ void max_stage(double &mx, int lane) {
+    const long long b = __double_as_longlong(mx);
     const int olo = partner_of<STAGE>((int)b, lane), ohi = partner_of<STAGE>((int)(b >> 32), lane);
-    const int oi = partner_of<STAGE>(besti, lane);
     const double ob = __longlong_as_double(((long long)ohi << 32) | (unsigned int)olo);
-    if (ob > best || (ob == best && oi < besti)) {
-        best = ob;
-        besti = oi;
-    }
+    mx = ob > mx ? ob : mx;
 }
-// (`wide` == false: only lanes 0 .. 15 hold candidates -- a node of at most 16 children -- and lane 0 has the result after four stages)
+// (`wide` == false: only lanes 0 .. 15 hold candidates -- a node of at most 16 children -- and four stages give their maximum to
+// every lane of their row)
+template <int W = kWords>
 __device__ __forceinline__ int wave_first_max(double best, int besti, bool wide = true) {
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    first_max_stage<0>(best, besti, lane);
-    first_max_stage<1>(best, besti, lane);
-    first_max_stage<2>(best, besti, lane);
-    first_max_stage<3>(best, besti, lane);
+    double mx = best;
+    max_stage<0>(mx, lane);
+    max_stage<1>(mx, lane);
+    max_stage<2>(mx, lane);
+    max_stage<3>(mx, lane);
     if (wide) {
-        first_max_stage<4>(best, besti, lane);
-        first_max_stage<5>(best, besti, lane);
+        max_stage<4>(mx, lane);
+        max_stage<5>(mx, lane);
     }
-    return besti;
+    const bool hit = besti != 0x7fffffff && best == mx;
+    constexpr int kSlots = W == 1 ? 1 : (W == 2 ? 2 : 4);
+#pragma unroll
+    for (int s_ = 0; s_ < kSlots; ++s_) {
+        const unsigned long long m = __ballot(hit && (besti >> 6) == s_);
+        if (m != 0ull) return 64 * s_ + __ffsll((long long)m) - 1;
+    }
+    return 0x7fffffff;
 }
 
 // ------------------------------------------------------------------ SELECT + STEP
@@ -501,7 +511,7 @@ __device__ __forceinline__ int scan_children(const Dev &E, const int4 *R, const 
         consider(l3, h3, p3, lane + 192);
     }
     // (TicTacToe, Connect4, the end of a 6 x 6 game: at most 16 children, two stages of the arg-max less; a scalar branch)
-    const int r = __builtin_amdgcn_readfirstlane(wave_first_max(best, besti, W > 2 || __builtin_amdgcn_readfirstlane(k) > 16));
+    const int r = __builtin_amdgcn_readfirstlane(wave_first_max<W>(best, besti, W > 2 || __builtin_amdgcn_readfirstlane(k) > 16));
     if (r >= k) return r;
     const int l = r & 63;
     clo = make_int4(__builtin_amdgcn_readlane(blo.x, l), __builtin_amdgcn_readlane(blo.y, l),

@@ -941,7 +941,7 @@ __global__ __launch_bounds__(256, (RW == kRowW ? 1 : 2)) void k_trunk_split(NetD
     // the padding), the K-quarter sums of its first layer, the next leaf
     __shared__ float res_vrow[RES ? 256 : 1];
     __shared__ float res_part[RES ? rzt::kDefWaves : 1][RES ? rzt::kWave : 1];
-    __shared__ uint64_t res_leaf[RES ? 2 * RZ_BOARD_WORDS + 1 : 1];
+    __shared__ __attribute__((aligned(16))) uint64_t res_leaf[RES ? 2 * RZ_BOARD_WORDS + 1 : 1];
     int res_slot0 = 0;
     if constexpr (RES) {
         if ((int)blockIdx.x >= n_boards || res.E.active[blockIdx.x] == 0) return;   // (uniform: before any barrier)
@@ -1718,7 +1718,7 @@ __device__ __forceinline__ void trunk_rows_body(const NetDev &nd, const float *_
     // RES: the value head's input row (zero padded to 4 x groups floats), the K-quarter sums of its first layer, the next leaf
     __shared__ float res_vrow[RES ? 512 : 1];
     __shared__ float res_part[RES ? rzt::kDefWaves : 1][RES ? rzt::kWave : 1];
-    __shared__ uint64_t res_leaf[RES ? 2 * RZ_BOARD_WORDS + 1 : 1];
+    __shared__ __attribute__((aligned(16))) uint64_t res_leaf[RES ? 2 * RZ_BOARD_WORDS + 1 : 1];
     int res_slot0 = 0;
     if constexpr (RES) {
         if ((int)blockIdx.x >= n_boards || res.E.active[blockIdx.x] == 0) return;   // (uniform: before any barrier)

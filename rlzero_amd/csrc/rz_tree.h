@@ -133,13 +133,21 @@ __device__ __forceinline__ void load_board(const uint64_t *src, int g, uint64_t 
         st[1][j] = j < W ? src[((long long)g * 2 + 1) * kWords + j] : 0ull;
     }
 }
+// Lane c < 2 writes colour c: its four words as two 16-byte stores (the position is wave-uniform: four selects by the lane's colour,
+// no word picked by a lane-dependent index -- see word_of).  `dst` is 16-byte aligned (the engine's arrays; the resident kernels' LDS).
 template <int W = kWords>
 __device__ __forceinline__ void store_board(uint64_t *dst, int g, const uint64_t (&st)[2][kWords], int lane) {
-    if (lane < 2 * kWords) {
-        const int colour = lane / kWords, j = lane % kWords;
-        uint64_t v = colour == 0 ? word_of<W>(st[0], j) : word_of<W>(st[1], j);
-        if constexpr (W < kWords) v = j < W ? v : 0ull;   // (the words past W are zero)
-        dst[((long long)g * 2 + colour) * kWords + j] = v;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    if (lane < 2) {
+        const bool c1 = lane == 1;
+        u64x2 lo, hi;
+        lo[0] = c1 ? st[1][0] : st[0][0];
+        lo[1] = W >= 2 ? (c1 ? st[1][1] : st[0][1]) : 0ull;
+        hi[0] = W > 2 ? (c1 ? st[1][2] : st[0][2]) : 0ull;   // (the words past W are zero)
+        hi[1] = W > 2 ? (c1 ? st[1][3] : st[0][3]) : 0ull;
+        u64x2 *p = reinterpret_cast<u64x2 *>(dst + ((long long)g * 2 + lane) * kWords);
+        p[0] = lo;
+        p[1] = hi;
     }
 }
 

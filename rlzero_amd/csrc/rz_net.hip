@@ -2614,7 +2614,12 @@ struct rz_net {
     bool fp8_cross = false;      // RZ_NET_SPLIT_F16_FP8: algo stays RZ_NET_SPLIT_F16, conv3's cross terms run on the FP8 pipe (position-fed launches)
     int n_cus = 256;
     int max_wgs = 0;  // rz_net_set_max_workgroups: 0 = one persistent trunk workgroup per CU
-    bool compact_grid = true;   // small boards, more boards than CUs: k_trunk_split on the compact LDS grid, two workgroups per CU (RZ_NET_COMPACT=0: off)
+    // small boards: k_trunk_split on the compact LDS grid, two workgroups per CU, for launches of more boards than HALF the CUs -- more
+    // boards than CUs run in one round instead of two, and of two lanes with up to a CU's worth of boards each both trunks are on the
+    // chip together (Connect4 512 games on two lanes 21.1 -> 21.8 M, 6 x 6 +7 %; four lanes of 128 boards: 3 % slower, hence the half).
+    // RZ_NET_COMPACT=0: never, 2: whenever the geometry allows
+    bool compact_grid = true;
+    bool compact_always = false;
     NetDev dev;
     std::vector<void *> allocs;
     std::vector<size_t> alloc_bytes;
@@ -2935,7 +2940,10 @@ int rz_net_create(int32_t height, int32_t width, int32_t n_actions, int32_t devi
     if (!net) return net_fail(RZ_ERR_OOM, "host allocation failed");
     net->board_size = height;
     net->device = device;
-    if (const char *v = getenv("RZ_NET_COMPACT")) net->compact_grid = v[0] != '0';
+    if (const char *v = getenv("RZ_NET_COMPACT")) {
+        net->compact_grid = v[0] != '0';
+        net->compact_always = v[0] == '2';
+    }
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -3231,7 +3239,7 @@ static void launch_trunk(rz_net *net, const float *d_obs, float *d_feat, int32_t
                 case 15: launch_trunk_rows<15>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later, fp8); break;
                 default: launch_trunk_rows<16>(bits, pgrid, st, net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, later, fp8); break;
             }
-        } else if (tiles <= 2 && !fc_here && net->compact_grid && n_boards > wg_cap && net->dev.BW <= 7 && tiles * net->dev.tile_rows + 2 <= 15) {
+        } else if (tiles <= 2 && !fc_here && net->compact_grid && (2 * n_boards > wg_cap || net->compact_always) && net->dev.BW <= 7 && tiles * net->dev.tile_rows + 2 <= 15) {
             // small boards, more boards than CUs: the compact LDS grid (9 x 15 positions, 67 KB): two workgroups per CU
             const dim3 cgrid((unsigned)(n_boards < 2 * wg_cap ? n_boards : 2 * wg_cap));
             if (tiles <= 1) k_trunk_split<1, 4, false, 9, 15><<<cgrid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, d_obs, leaves, f32, f16, n_boards, net->d_flags, nullptr, nullptr, later);

@@ -1501,9 +1501,10 @@ def test_dirichlet_noise_on_priors():
 
 
 def test_compact_grid_trunk_is_the_same_kernel_on_less_lds(monkeypatch):
-    """Boards of up to 7 columns in launches of more boards than CUs run k_trunk_split on a compact LDS grid (9 x 15 positions, 67 KB:
-    two workgroups per CU instead of one; RZ_NET_COMPACT=0 keeps the 18 x 18 grid): the same instructions on other addresses --
-    log-probabilities and values bit for bit, for both channel-split shapes (one tile: 3 x 3, 5 x 5; two tiles: 6 x 6, 6 x 7, 7 x 7)."""
+    """Boards of up to 7 columns in launches of more boards than HALF the CUs run k_trunk_split on a compact LDS grid (9 x 15 positions,
+    67 KB: two workgroups per CU instead of one -- more boards than CUs in one round, two lanes' launches on the chip together;
+    RZ_NET_COMPACT=0 keeps the 18 x 18 grid): the same instructions on other addresses -- log-probabilities and values bit for bit,
+    for both channel-split shapes (one tile: 3 x 3, 5 x 5; two tiles: 6 x 6, 6 x 7, 7 x 7), above the CU count and just below it."""
     import torch
     from rlzero_amd.engine import HipNet
     from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
@@ -1512,19 +1513,20 @@ def test_compact_grid_trunk_is_the_same_kernel_on_less_lds(monkeypatch):
         rows, cols, acts = shape
         torch.manual_seed(rows * 10 + cols)
         net = PolicyValueNet(rows, cols, acts)
-        n = 2 * n_cus + 37
-        obs = (torch.rand(n, 4, rows, cols) > 0.5).float().to('cuda:0')
-        out = {}
-        for compact in ('0', '1'):
-            monkeypatch.setenv('RZ_NET_COMPACT', compact)
-            hip = HipNet(shape, 'cuda:0', max_boards=n).load_state_dict(net.state_dict())
-            hip.set_heads_algo('parts')
-            lp, v = hip.forward(obs)
-            out[compact] = (lp.cpu().numpy().copy(), v.cpu().numpy().copy())
-            hip.check_flags()
-            hip.close()
-        assert np.array_equal(out['0'][0].view(np.uint32), out['1'][0].view(np.uint32)), shape
-        assert np.array_equal(out['0'][1].view(np.uint32), out['1'][1].view(np.uint32)), shape
-        with torch.no_grad():
-            lp64, v64 = net.double()(obs.cpu().double())
-        assert np.max(np.abs(out['1'][0] - lp64.numpy())) <= 1e-4 and np.max(np.abs(out['1'][1] - v64.numpy()[:, 0])) <= 1e-4
+        for n in (2 * n_cus + 37, n_cus - 3):
+            obs = (torch.rand(n, 4, rows, cols) > 0.5).float().to('cuda:0')
+            out = {}
+            for compact in ('0', '1'):
+                monkeypatch.setenv('RZ_NET_COMPACT', compact)
+                hip = HipNet(shape, 'cuda:0', max_boards=n).load_state_dict(net.state_dict())
+                hip.set_heads_algo('parts')
+                lp, v = hip.forward(obs)
+                out[compact] = (lp.cpu().numpy().copy(), v.cpu().numpy().copy())
+                hip.check_flags()
+                hip.close()
+            assert np.array_equal(out['0'][0].view(np.uint32), out['1'][0].view(np.uint32)), (shape, n)
+            assert np.array_equal(out['0'][1].view(np.uint32), out['1'][1].view(np.uint32)), (shape, n)
+            with torch.no_grad():
+                lp64, v64 = net.double()(obs.cpu().double())
+            net.float()
+            assert np.max(np.abs(out['1'][0] - lp64.numpy())) <= 1e-4 and np.max(np.abs(out['1'][1] - v64.numpy()[:, 0])) <= 1e-4

@@ -1019,7 +1019,11 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
                 finish_prediction(value, probs);
                 if (mine) {
                     // expand_node(root) + add_exploration_noise: prior * (1 - frac) + noise * frac (k_mz_init), fresh MinMaxStats
-                    const unsigned long long key = mz_splitmix64(mz_splitmix64(mz_splitmix64(P.noise_seed ^ ((unsigned long long)g << 24)) ^
+                    // (`gs`: the game's share of the keys, opaque per move -- hoisted out of the move loop the three hashes of it lived
+                    // in registers for the whole launch, and three of them in scratch memory)
+                    unsigned long long gs = (unsigned long long)g << 24;
+                    asm volatile("" : "+v"(gs));
+                    const unsigned long long key = mz_splitmix64(mz_splitmix64(mz_splitmix64(P.noise_seed ^ gs) ^
                                                                                 (unsigned long long)__double_as_longlong(env_g[5])) ^
                                                                  (unsigned long long)__double_as_longlong(env_g[4]));
                     float gam[MAXA], gsum = 0.0f;
@@ -1038,7 +1042,11 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
                     for (int a = 0; a < MAXA; ++a) {
                         if (a < A) {
                             double pr = (double)probs[a];
-                            if (P.noise_frac > 0.0) pr = pr * (1.0 - P.noise_frac) + ((double)gam[a] / (double)gsum) * P.noise_frac;
+                            if (P.noise_frac > 0.0) {
+                                double nf = P.noise_frac;
+                                asm volatile("" : "+v"(nf));   // (1 - nf formed here, not carried through the launch)
+                                pr = pr * (1.0 - nf) + ((double)gam[a] / (double)gsum) * nf;
+                            }
                             if (TREE_LDS) {
                                 hot[1 + a] = MzHot{0, -1, 0.0, pr, 0.0};
                                 rew[1 + a] = 0.0f;
@@ -1211,7 +1219,9 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
             }
             int action = arg;
             if (P.inv_temperature > 0.0) {
-                const unsigned long long key = mz_splitmix64(mz_splitmix64(mz_splitmix64(P.noise_seed ^ 0xA5A5A5A5ull ^ ((unsigned long long)g << 24)) ^
+                unsigned long long gs = (unsigned long long)g << 24;
+                asm volatile("" : "+v"(gs));
+                const unsigned long long key = mz_splitmix64(mz_splitmix64(mz_splitmix64(P.noise_seed ^ 0xA5A5A5A5ull ^ gs) ^
                                                                             (unsigned long long)env.episode) ^ (unsigned long long)env.steps);
                 const double target = ((double)(key >> 11) / 9007199254740992.0) * total;
                 double cum = 0.0;
@@ -1289,7 +1299,9 @@ __global__ __launch_bounds__(64 * kMzWaves, 2) void k_mz_search(MzDev E, MzModel
                 }
                 ep_start = t + 1;
                 env.episode += 1;
-                cartpole_reset(env, P.env_seed, g);
+                int g_reset = g;
+                asm volatile("" : "+v"(g_reset));   // (as `gs` above: the reset's key is formed when an episode ends)
+                cartpole_reset(env, P.env_seed, g_reset);
             }
             OBS[0 * kMzTile + ge] = (float)env.x;
             OBS[1 * kMzTile + ge] = (float)env.x_dot;

@@ -363,7 +363,9 @@ typedef struct rz_play_config {
     double stall_margin;   /* 0 -> 1e-10 * max(1, 1 / T); a test hook otherwise (0.05 stalls one draw in ten) */
     const int64_t *d_queue_ids;
     int32_t *d_queue_ctl;
-    int32_t *d_log;
+    int32_t *d_log;        /* the log ring [ring_steps][n_games][8 + A]: device memory, or (what rlzero_amd passes) pinned host memory that
+                            * the device can address -- the kernels only write it (one read-modify-write of a record's flags when its
+                            * game ends), so the host reads rows in place behind an event and no copy sits between two moves */
     int32_t ring_steps;
     int32_t reserved;
 } rz_play_config;

@@ -12,6 +12,7 @@ One simulation step of all games = what the reference does once per game in
     rz_expand_backup    expand / terminal value + update_recursive
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -957,7 +958,16 @@ class MCTSEngine(object):
         t = self.torch
         self.flush_deferred()
         t.cuda.synchronize(self.device)
-        self.play_log = t.zeros((int(ring_steps), self.n_games, _hip.PLAY_RECORD_WORDS + self.n_actions), dtype=t.int32, device=self.device)
+        # The log ring lives in PINNED HOST memory, which the kernels address directly: a row is written by the move's own kernels
+        # (write-only but for the flag of a game that ends) and read by the host behind an event -- no copy command between two
+        # moves (an 18-us gap + a blit kernel + 6 us on a lane's stream per read-back).  RZ_PLAY_DEVICE_LOG=1: a device ring that the
+        # caller copies from (the first form; kept for comparison).
+        shape = (int(ring_steps), self.n_games, _hip.PLAY_RECORD_WORDS + self.n_actions)
+        self.play_log_on_host = os.environ.get('RZ_PLAY_DEVICE_LOG') != '1'
+        if self.play_log_on_host:
+            self.play_log = t.zeros(shape, dtype=t.int32).pin_memory()
+        else:
+            self.play_log = t.zeros(shape, dtype=t.int32, device=self.device)
         self._play_queue = (queue_ids, queue_ctl)   # (kept alive: the engine holds their addresses)
         cfg = _hip.RzPlayConfig(seed=int(seed) & 0xFFFFFFFFFFFFFFFF, temperature=float(temperature), stall_margin=float(stall_margin),
                                 d_queue_ids=queue_ids.data_ptr(), d_queue_ctl=queue_ctl.data_ptr(), d_log=self.play_log.data_ptr(),

@@ -741,7 +741,9 @@ class BatchedSelfPlay(object):
                 lane.eng.play_attach(self.seed, self.temperature, self._queue_ids, self._queue_ctl, ring_steps=ring_steps,
                                      stall_margin=stall_margin)
                 lane.move_graph = lane.eng.warm_move_graph(lane.evaluator) if move_graphs else None
-            lane.host_log = t.empty((int(ring_steps), lane.eng.n_games, words), dtype=t.int32, pin_memory=True)
+            # (the engine's log ring is pinned host memory that its kernels write directly: nothing to copy -- or, RZ_PLAY_DEVICE_LOG=1,
+            # a device ring whose rows _read_back copies)
+            lane.host_log = lane.eng.play_log if lane.eng.play_log_on_host else t.empty((int(ring_steps), lane.eng.n_games, words), dtype=t.int32, pin_memory=True)
             lane.host_np = lane.host_log.numpy()
             lane.uncopied = []          # rows written by enqueued moves, their read-back not enqueued yet
             lane.inflight = []          # [(rows, event)] read-backs enqueued, oldest first
@@ -777,7 +779,8 @@ class BatchedSelfPlay(object):
         return not lane.inflight and not lane.uncopied and lane.last_running == 0 and self._started >= self._queue_len
 
     def _read_back(self, lane):
-        """Enqueue the copy of the lane's new log rows to pinned memory (contiguous runs of the ring: one copy each)."""
+        """An event behind the lane's new log rows (they are in pinned memory when it has passed: written there by the kernels, or
+        -- a device ring -- copied there, contiguous runs of the ring in one copy each)."""
         rows = lane.uncopied
         if not rows:
             return
@@ -788,7 +791,8 @@ class BatchedSelfPlay(object):
                 end = at + 1
                 while end < len(rows) and rows[end] == rows[end - 1] + 1:
                     end += 1
-                lane.host_log[rows[at]:rows[end - 1] + 1].copy_(lane.eng.play_log[rows[at]:rows[end - 1] + 1], non_blocking=True)
+                if not lane.eng.play_log_on_host:
+                    lane.host_log[rows[at]:rows[end - 1] + 1].copy_(lane.eng.play_log[rows[at]:rows[end - 1] + 1], non_blocking=True)
                 at = end
             ev = self.torch.cuda.Event()
             ev.record(lane.stream)

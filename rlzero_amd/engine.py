@@ -26,6 +26,22 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_DEVICE_INDEX = {}
+
+
+def _current_stream(torch, device):
+    """The current stream of ``device`` as the void* the C ABI takes: torch's raw accessor when it has one (the Stream-object route
+    costs ~4 us a call, a dozen calls per move of the one-game API)."""
+    raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+    if raw is None:
+        return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    idx = _DEVICE_INDEX.get(device)
+    if idx is None:
+        d = torch.device(device)
+        idx = _DEVICE_INDEX[device] = d.index if d.index is not None else torch.cuda.current_device()
+    return ctypes.c_void_p(raw(idx))
+
+
 class SyntheticEvaluator(object):
     """v0 / vlin of SURVEY.md Appendix B, computed on the device from the leaf bitboards."""
     needs_obs = False
@@ -251,7 +267,7 @@ class HipNet(object):
         return logp, value
 
     def _stream(self):
-        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+        return _current_stream(self.torch, self.device)
 
     def trunk_internal(self, obs):
         """k_trunk alone into the internal feature buffer (pair with ``heads``)."""
@@ -341,8 +357,14 @@ class HipNetEvaluator(object):
         self.refresh()
 
     def _fingerprint(self, content=False):
-        # in-place optimiser steps bump Tensor._version; load_state_dict / .to() change data_ptr
-        params = list(self.module.parameters())
+        # in-place optimiser steps bump Tensor._version; load_state_dict / .to() change data_ptr.  The per-move check walks a cached
+        # list of the module's Parameter objects (nn.Module.parameters() is a generator over every submodule: 17 calls per move of
+        # the one-game API); the per-round content check below takes the list afresh and drops a cache that no longer matches
+        params = getattr(self, '_params', None)
+        if params is None or content:
+            fresh = list(self.module.parameters())
+            if params is None or len(fresh) != len(params) or any(a is not b for a, b in zip(fresh, params)):
+                params = self._params = fresh
         marks = tuple((p.data_ptr(), p._version) for p in params)
         if not content:
             return marks
@@ -501,7 +523,7 @@ class MCTSEngine(object):
 
     # ------------------------------------------------------------------ plumbing
     def stream(self):
-        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+        return _current_stream(self.torch, self.device)
 
     def close(self):
         if getattr(self, 'handle', None):

@@ -365,7 +365,8 @@ typedef struct rz_play_config {
     int32_t *d_queue_ctl;
     int32_t *d_log;        /* the log ring [ring_steps][n_games][8 + A]: device memory, or (what rlzero_amd passes) pinned host memory that
                             * the device can address -- the kernels only write it (one read-modify-write of a record's flags when its
-                            * game ends), so the host reads rows in place behind an event and no copy sits between two moves */
+                            * game ends), so the host reads rows in place behind an event and no copy sits between two moves; host
+                            * memory that this engine's device cannot address is refused (hipHostGetDevicePointer) */
     int32_t ring_steps;
     int32_t reserved;
 } rz_play_config;

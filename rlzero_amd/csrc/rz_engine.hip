@@ -1991,6 +1991,20 @@ int rz_play_attach(rz_engine *e, const rz_play_config *cfg) {
     Y.queue_ids = cfg->d_queue_ids;
     Y.queue_ctl = cfg->d_queue_ctl;
     Y.log = cfg->d_log;
+    {   // a log in HOST memory (pinned: the kernels write it directly) must be addressable from THIS device: asked, not assumed
+        hipPointerAttribute_t attr;
+        memset(&attr, 0, sizeof(attr));
+        if (hipPointerGetAttributes(&attr, cfg->d_log) != hipSuccess) {
+            (void)hipGetLastError();   // (an address the runtime does not know: treated as device memory, as before)
+        } else if (attr.type == hipMemoryTypeHost) {
+            void *dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, cfg->d_log, 0) != hipSuccess || dp == nullptr) {
+                (void)hipGetLastError();
+                return fail(RZ_ERR_ARG, "rz_play_attach: d_log is host memory that device %d cannot address (pass device memory)", e->cfg.device);
+            }
+            Y.log = static_cast<int32_t *>(dp);
+        }
+    }
     Y.ring = cfg->ring_steps;
     Y.words = RZ_PLAY_RECORD_WORDS + e->dev.A;
     Y.seed = cfg->seed;

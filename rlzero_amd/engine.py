@@ -991,10 +991,20 @@ class MCTSEngine(object):
         else:
             self.play_log = t.zeros(shape, dtype=t.int32, device=self.device)
         self._play_queue = (queue_ids, queue_ctl)   # (kept alive: the engine holds their addresses)
-        cfg = _hip.RzPlayConfig(seed=int(seed) & 0xFFFFFFFFFFFFFFFF, temperature=float(temperature), stall_margin=float(stall_margin),
-                                d_queue_ids=queue_ids.data_ptr(), d_queue_ctl=queue_ctl.data_ptr(), d_log=self.play_log.data_ptr(),
-                                ring_steps=int(ring_steps), reserved=0)
-        check(self.lib.rz_play_attach(self.handle, ctypes.byref(cfg)), 'rz_play_attach')
+        def attach():
+            cfg = _hip.RzPlayConfig(seed=int(seed) & 0xFFFFFFFFFFFFFFFF, temperature=float(temperature), stall_margin=float(stall_margin),
+                                    d_queue_ids=queue_ids.data_ptr(), d_queue_ctl=queue_ctl.data_ptr(), d_log=self.play_log.data_ptr(),
+                                    ring_steps=int(ring_steps), reserved=0)
+            check(self.lib.rz_play_attach(self.handle, ctypes.byref(cfg)), 'rz_play_attach')
+        try:
+            attach()
+        except HipError as exc:
+            if not self.play_log_on_host or 'cannot address' not in str(exc):
+                raise
+            # (pinned memory this device cannot address -- the library asked the runtime: the device ring and its copies instead)
+            self.play_log_on_host = False
+            self.play_log = t.zeros(shape, dtype=t.int32, device=self.device)
+            attach()
         self.play_steps = 0
         self._play_on, self._play_active = True, None
         self.active_host[:] = 0

@@ -1530,7 +1530,7 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
     RZ_ALLOC(noise_ctr, G);
     RZ_ALLOC(noise_key, G);
     if (rc == RZ_OK) rc = dev_alloc(e, &e->d_logtab, D.logtab_n);
-    if (rc == RZ_OK) rc = dev_alloc(e, &e->d_line_tab, kWave);
+    if (rc == RZ_OK) rc = dev_alloc(e, &e->d_line_tab, 2 * kWave);
 #undef RZ_ALLOC
     if (rc != RZ_OK) {
         rz_destroy(e);
@@ -1564,11 +1564,19 @@ int rz_create(const rz_config *cfg, rz_engine **out) {
             return fail(RZ_ERR_HIP, "hipMemcpy(log table) failed: %s", hipGetErrorString(herr));
         }
     }
-    {   // Dev::line_tab (boards of one or two words; zeros otherwise)
-        uint64_t tab[kWave] = {0};
-        for (int l = 0; l < kWave && l < 4 * n_row && S <= 128; ++l) {
+    {   // Dev::line_tab: the window of lane l -- bits j * stride of its n cells (boards of up to 128 cells: a low word [l] and a high word
+        // [64 + l], the high one empty unless a window spans 64 cell numbers or more); boards of more cells: its first n - 1 cells in [l],
+        // and line_masks says whether those fit
+        uint64_t tab[2 * kWave] = {0};
+        const int cells = S <= 128 ? n_row : n_row - 1;
+        D.line_masks = (cells - 1) * (BW + 1) < 64 ? 1 : 0;
+        for (int l = 0; l < kWave && l < 4 * n_row; ++l) {
             const int d = l / n_row, stride = d == 0 ? 1 : d == 1 ? BW : d == 2 ? BW + 1 : BW - 1;
-            for (int j = 0; j < n_row && j * stride < 64; ++j) tab[l] |= 1ull << (j * stride);
+            for (int j = 0; j < cells; ++j) {
+                const int o = j * stride;
+                if (o < 64) tab[l] |= 1ull << o;
+                else if (o < 128) tab[kWave + l] |= 1ull << (o - 64);
+            }
         }
         herr = hipMemcpy(e->d_line_tab, tab, sizeof(tab), hipMemcpyHostToDevice);
         if (herr != hipSuccess) {

@@ -59,6 +59,7 @@ struct Dev {
     // of direction l / n: right, down, down-right, down-left); a table in device memory -- four more 64-bit kernel arguments cost the
     // tree step scalar registers it does not have (68 B of scratch)
     const uint64_t *line_tab;
+    int line_masks;   // four-word boards: != 0 when the first n - 1 cells of every window fit the 64 bits of its mask (else cell by cell)
 };
 
 // the packed node record
@@ -253,7 +254,7 @@ __device__ __forceinline__ int lane_action_rank(const Dev &E, const uint64_t *oc
 // (gomoku_env.py:136-168) when the position before `last` had no line.
 template <int W = kWords>
 __device__ __forceinline__ bool line_through(const uint64_t *x, int last, int BH, int BW, int n, int lane, int bw_rcp, int n_rcp,
-                                             uint64_t window = 0) {
+                                             uint64_t window = 0, uint64_t window_hi = 0, bool masks = false) {
     // straight-line: every lane runs the window test on registers (test_bit reads no memory; a cell number outside the board tests a
     // bit that the conditions below discard) -- short-circuit tests cost this single wave an exec-mask round per cell
     const int d = (lane * n_rcp) >> 16, t = lane - d * n;
@@ -265,12 +266,22 @@ __device__ __forceinline__ bool line_through(const uint64_t *x, int last, int BH
     bool all = true;
     if constexpr (W == 1) {   // the window's n cells are one mask of the board's word (`window` = Dev::line_tab[lane])
         all = ((x[0] >> s0) & window) == window;
-    } else if constexpr (W == 2) {   // ... of the 64 bits of the two words that begin at the window's first cell
-        const uint64_t from0 = (x[0] >> (s0 & 63)) | ((x[1] << 1) << (63 - (s0 & 63))), from1 = x[1] >> (s0 & 63);
-        const uint64_t v = s0 < 64 ? from0 : from1;
-        all = (v & window) == window;
-    } else {
+    } else if constexpr (W == 2) {
+        // ... of the 128 bits of the two words that begin at the window's first cell: a low and a high mask (the high one is empty
+        // unless n is 7 or more on a wide board: `window_hi` = Dev::line_tab[64 + lane])
+        const int sh = s0 & 63;
+        const uint64_t from0 = (x[0] >> sh) | ((x[1] << 1) << (63 - sh)), from1 = x[1] >> sh;
+        const uint64_t v_lo = s0 < 64 ? from0 : from1, v_hi = s0 < 64 ? from1 : 0ull;
+        all = ((v_lo & window) == window) & ((v_hi & window_hi) == window_hi);
+    } else if (!masks) {   // (wave-uniform: a window longer than 64 cell numbers -- n of 6 or more on a 16-wide board -- is tested cell by cell)
         for (int j = 0; j < n; ++j) all = all & test_bit<W>(x, s0 + j * stride);
+    } else {
+        // four words: the first n - 1 cells as a mask of the 64 bits from the window's first cell (3 x 17 < 64 on a 16-wide board with
+        // n = 5), the last cell by itself (`window` = those n - 1 cells here)
+        const int j0 = s0 >> 6, sh = s0 & 63;
+        const uint64_t w_lo = word_of<W>(x, j0), w_hi = word_of<W>(x, j0 + 1);   // (j0 + 1 == 4: no word, zero)
+        const uint64_t v = (w_lo >> sh) | ((w_hi << 1) << (63 - sh));
+        all = ((v & window) == window) & test_bit<W>(x, s0 + (n - 1) * stride);
     }
     const bool hit = (lane < 4 * n) & (start >= 0) & ok & all;
     return __ballot(hit) != 0ull;
@@ -553,7 +564,9 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
     uint64_t st[2][kWords];
     load_board<W>(E.root_stones, g, st);
     uint64_t window = 0;   // (line_through<1>: asked for with the first loads, used at the end)
-    if constexpr (W <= 2) window = E.line_tab[lane];
+    window = E.line_tab[lane];
+    uint64_t window_hi = 0;
+    if constexpr (W == 2) window_hi = E.line_tab[kWave + lane];
     if (!act) return;
     int4 *R = arena_records(E, g, arena);
     const float *P = arena_priors(E, g, arena);
@@ -675,7 +688,7 @@ __device__ __forceinline__ void select_body(const Dev &E, float *obs, int g, int
             else if (line_anywhere<W>(st[1], S, E.BH, E.BW, E.n_row, lane, E.bw_rcp)) winner = 1;
         } else {
             const int mover = to_move ^ 1;
-            if (line_through<W>(mover == 0 ? st[0] : st[1], last, E.BH, E.BW, E.n_row, lane, E.bw_rcp, E.n_rcp, window)) winner = mover;
+            if (line_through<W>(mover == 0 ? st[0] : st[1], last, E.BH, E.BW, E.n_row, lane, E.bw_rcp, E.n_rcp, window, window_hi, E.line_masks != 0)) winner = mover;
         }
         if (winner >= 0) {
             term = 2;

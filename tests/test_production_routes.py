@@ -76,6 +76,9 @@ def _start_positions(game, shape, n_row, count, seed):
     else:
         B = shape
         envs = [RefGomoku(B, n_row), RefGomoku.from_moves(B, n_row, [B * B // 2])]
+        if n_row >= 7:   # six stones of player 0 on the main diagonal, to move: a seventh makes NO line of eight (a window of n cells that
+            # spans more than 64 cell numbers is tested cell by cell, not by the 64-bit mask of shorter windows: rz_tree.h, line_through)
+            envs.append(RefGomoku.from_moves(B, n_row, [0, 1, B + 1, 3, 2 * (B + 1), 5, 3 * (B + 1), 7, 4 * (B + 1), 2 * B - 1, 5 * (B + 1), 3 * B - 1]))
         if B >= 9:   # an open three in a row of n - 1 next to the centre: wins, losses and terminal leaves inside the search
             c = B * (B // 2) + B // 2
             envs.append(RefGomoku.from_moves(B, n_row, [c, c + B, c + 1, c + B + 1, c + 2, c + B + 2][:2 * (n_row - 2)]))
@@ -112,6 +115,8 @@ CASES = [   # (id, game, shape, n_in_row, simulations per move, routes, games)
     ('W1_8x8_120', 'gomoku', 8, 5, 120, ('resident', 'two_launch_graph'), 4),
     ('W2_10x10_120', 'gomoku', 10, 5, 120, ('resident', 'two_launch_graph'), 4),
     ('W2_11x11_120', 'gomoku', 11, 5, 120, ('resident', 'two_launch_graph'), 4),
+    # n = 8 on 9 x 9: a diagonal window spans 7 x 10 = 70 cell numbers
+    ('N8_9x9_150', 'gomoku', 9, 8, 150, ('resident', 'two_launch_graph'), 4),
 ]
 N_MOVES = 4
 

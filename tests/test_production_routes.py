@@ -95,6 +95,29 @@ def _start_positions(game, shape, n_row, count, seed):
     return envs[:count]
 
 
+def _near_wins(B, n_row, short=1):
+    """Four roots, one per direction of gomoku_env.py:136-168 (right, down, down-right, down-left): the player to move has n - 1 stones
+    in that direction from a corner of the board and the completing cell is free -- every search from them meets a terminal leaf at
+    depth one (and, among its neighbours, windows of n - 1 stones that are NOT wins).  short = 2: n - 2 stones -- the search completes
+    windows of n - 1, which must NOT end the game (a window test that loses its last cell would say they do)."""
+    out = []
+    for dy, dx, y0, x0 in ((0, 1, 0, 0), (1, 0, 0, B - 1), (1, 1, B - n_row, B - n_row), (1, -1, 0, n_row - 1)):
+        mine = [(y0 + j * dy) * B + (x0 + j * dx) for j in range(n_row - short)]
+        last = (y0 + (n_row - short) * dy) * B + (x0 + (n_row - short) * dx)
+        taken, theirs = set((y0 + j * dy) * B + (x0 + j * dx) for j in range(n_row)), []
+        for c in range(B * B - 1, -1, -1):   # the opponent's stones: from the far end, off the line, no two side by side
+            if len(theirs) == n_row - short:
+                break
+            if c not in taken and (c + 1) not in theirs and (c % 3 == 2 or B < 5):
+                theirs.append(c)
+        assert len(theirs) == n_row - short
+        moves = [m for pair in zip(mine, theirs) for m in pair]
+        env = RefGomoku.from_moves(B, n_row, moves)
+        assert not env.game_end_winner()[0] and last in env.leagel_actions()
+        out.append(env)
+    return out
+
+
 def _draw(acts, probs, u):
     cdf = np.cumsum(np.asarray(probs, dtype=np.float64))
     cdf /= cdf[-1]
@@ -117,6 +140,28 @@ CASES = [   # (id, game, shape, n_in_row, simulations per move, routes, games)
     ('W2_11x11_120', 'gomoku', 11, 5, 120, ('resident', 'two_launch_graph'), 4),
     # n = 8 on 9 x 9: a diagonal window spans 7 x 10 = 70 cell numbers
     ('N8_9x9_150', 'gomoku', 9, 8, 150, ('resident', 'two_launch_graph'), 4),
+    # the other shapes of the window test: 10 x 10 with n = 7 (a high mask word), 8 x 8 with n = 8 (one word, the longest window),
+    # 16 x 16 (the widest board whose first n - 1 cells still fit the mask), 15 x 15 with n = 8 (they do not: cell by cell)
+    ('N7_10x10_80', 'gomoku', 10, 7, 80, ('resident', 'two_launch_graph'), 4),
+    ('N8_8x8_80', 'gomoku', 8, 8, 80, ('resident', 'two_launch_graph'), 4),
+    ('N5_16x16_80', 'gomoku', 16, 5, 80, ('resident', 'two_launch_graph'), 4),
+    ('N8_15x15_80', 'gomoku', 15, 8, 80, ('resident', 'two_launch_graph'), 4),
+    # the same shapes from roots one move short of a line in each of the four directions (`near`): terminal leaves in every search
+    ('near_3x3_n3', 'gomoku', 3, 3, 25, ('resident', 'two_launch_graph'), 4, 'near'),
+    ('near_6x6_n4', 'gomoku', 6, 4, 60, ('resident', 'two_launch_graph'), 4, 'near'),
+    ('near_8x8_n8', 'gomoku', 8, 8, 60, ('resident', 'two_launch_graph'), 4, 'near'),
+    ('near_9x9_n5', 'gomoku', 9, 5, 100, ('resident', 'two_launch_graph'), 4, 'near'),
+    ('near_9x9_n8', 'gomoku', 9, 8, 100, ('resident', 'two_launch_graph'), 4, 'near'),
+    ('near_10x10_n7', 'gomoku', 10, 7, 100, ('resident', 'two_launch_graph'), 4, 'near'),
+    ('near_11x11_n5', 'gomoku', 11, 5, 100, ('resident', 'two_launch_graph'), 4, 'near'),
+    ('near_15x15_n5', 'gomoku', 15, 5, 250, ('resident', 'two_launch_graph'), 4, 'near'),
+    ('near_15x15_n8', 'gomoku', 15, 8, 250, ('resident', 'two_launch_graph'), 4, 'near'),
+    ('near_16x16_n5', 'gomoku', 16, 5, 270, ('resident', 'two_launch_graph'), 4, 'near'),
+    ('short_9x9_n8', 'gomoku', 9, 8, 100, ('resident', 'two_launch_graph'), 4, 'short'),
+    ('short_10x10_n7', 'gomoku', 10, 7, 100, ('resident', 'two_launch_graph'), 4, 'short'),
+    ('short_11x11_n7', 'gomoku', 11, 7, 130, ('resident', 'two_launch_graph'), 4, 'short'),
+    ('short_15x15_n8', 'gomoku', 15, 8, 250, ('resident', 'two_launch_graph'), 4, 'short'),
+    ('short_16x16_n5', 'gomoku', 16, 5, 270, ('resident', 'two_launch_graph'), 4, 'short'),
 ]
 N_MOVES = 4
 
@@ -127,12 +172,13 @@ def test_production_routes_are_the_oracle_s_search(case):
     from rlzero_amd.engine import HipNetEvaluator, MCTSEngine
     from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
     from rlzero_amd.selfplay import visits_to_pi
-    _, game, shape, n_row, sims, routes, n_games = case
+    _, game, shape, n_row, sims, routes, n_games = case[:7]
     torch.manual_seed(7)
     net = PolicyValueNet(6, 7, 7) if game == 'connect4' else PolicyValueNet(shape)
     net_shape = (6, 7, 7) if game == 'connect4' else shape
     probe = _Probe(net, game, shape, n_row)
-    starts = _start_positions(game, shape, n_row, n_games, seed=sims)
+    starts = (_near_wins(shape, n_row, 2 if case[7] == 'short' else 1) if len(case) > 7
+              else _start_positions(game, shape, n_row, n_games, seed=sims))
     uniforms = np.random.RandomState(sims + 1).random_sample((n_games, N_MOVES))
 
     # the oracle: per game N_MOVES searches with tree reuse; per move the whole tree, pi and the move drawn from it

@@ -397,6 +397,11 @@ class TimedEvaluator(object):
     def search_resident(self, eng, n_sims, select_first=False):
         return self.inner.search_resident(eng, n_sims, select_first)
 
+    def prepare_search(self, eng):
+        prep = getattr(self.inner, 'prepare_search', None)
+        if prep is not None:
+            prep(eng)
+
     def deferred_trunk(self, eng):
         """Deferred-priors route (two launches per step): the trunk bracketed when recording; the event behind it and the
         first event of the NEXT step of the same eager chunk bracket the tree step launched in between."""

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 24
+#define RZ_ABI_VERSION 25
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 #define RZ_MAX_IN_FLIGHT 16 /* rz_config.sims_in_flight */
@@ -516,6 +516,33 @@ int rz_net_trunk_leaves_deferred(rz_net *net, const uint64_t *d_stones, const in
 /* act_fc1 (policy_value_net.py:43) over the stored leaves of slots [0, n_slots) as ONE GEMM (k_heads_split's arithmetic) */
 int rz_net_deferred_gemm(rz_net *net, int32_t n_boards, int32_t n_slots, rz_deferred_logits *out, void *stream);
 int rz_net_trace_attach(rz_net *net, void *d_trace);   /* see rz_trace_attach */
+/* RECEPTIVE-FIELD ("delta") LEAF EVALUATION -- PolicyValueNet.forward (policy_value_net.py:34-52) on the leaves of a search WITHOUT
+ * recomputing what the root already determines.  The reference's search is near breadth-first (alphazero_mcts.py:42-71 under
+ * node.py:32-42: a 15 x 15 / 800 leaf is the root plus one or two stones), and three 3 x 3 convolutions move conv3's output only in
+ * the 7 x 7 window around a changed cell.  rz_net_delta_bases evaluates, per game, two pseudo-positions of the ROOT (its stones seen
+ * by the side to move / by the other side one stone later; no last-move plane) and keeps conv1's / conv2's outputs and the six head
+ * feature planes in a cache (rz_net_delta_reserve: 209 KB per game); rz_net_delta_leaves then computes, per leaf, only the cells
+ * inside the windows of the cells where its planes (gomoku_env.py:95-114) differ from the base of its parity, with k_trunk_rows'
+ * arithmetic cell by cell, and takes every other cell from the base: THE SAME BITS as rz_net_trunk_leaves_deferred (the store slot
+ * d_slot_of_board[b], the value rows of *out).  The cache validates itself: a leaf whose stones do not contain the cached root's, or
+ * with more than four changed cells, or a game without bases, is evaluated by the same kernel without a base (four passes over
+ * the board's quadrants) -- correct whatever the caller did, only slower; rebuild the bases whenever the roots move.
+ * Boards of 11 .. 16 rows and columns, RZ_NET_SPLIT_F16.  d_active (may be NULL): games whose flag is 0 are skipped.  d_feat32 (may be
+ * NULL): also the features as f32 [n][6][S] (tests); d_slot_of_board may then be NULL (nothing goes to the store; out may be NULL).
+ * without_base != 0: every leaf takes the four-pass route (a checker). */
+int rz_net_delta_reserve(rz_net *net, int32_t n_games);
+int rz_net_delta_invalidate(rz_net *net, void *stream);
+int rz_net_delta_bases(rz_net *net, const uint64_t *d_root_stones, const int32_t *d_root_to_move, int32_t n_games, void *stream);
+int rz_net_delta_leaves(rz_net *net, const uint64_t *d_stones, const int32_t *d_to_move, const int32_t *d_last_cell, int32_t n_boards,
+                        const int32_t *d_slot_of_board, const uint8_t *d_active, float *d_feat32, int32_t without_base, rz_value_head *out,
+                        void *stream);
+/* the same on an engine's own arrays: the bases of every game from its ROOT positions (call whenever the roots have moved: after
+ * rz_set_roots, rz_step_games, rz_play_apply -- a forgotten call costs time, not correctness), and rz_net_trunk_leaves_deferred's
+ * step on its leaves (board b = game b, store slot pend[b], inactive games skipped).  One simulation in flight per tree. */
+int rz_net_delta_bases_engine(rz_net *net, rz_engine *engine, void *stream);
+int rz_net_delta_step(rz_net *net, rz_engine *engine, rz_value_head *out, void *stream);
+/* counters since the last reset: {leaves evaluated against a base, leaves without one, conv3 tiles of 16 cells, changed cells} (synchronises) */
+int rz_net_delta_stats(rz_net *net, uint32_t *h_out4, int32_t reset);
 /* RESIDENT SEARCH -- n_sims consecutive simulations of every active game of `engine` (AlphaZeroMCTS.simulate's loop,
  * alphazero_mcts.py:82-85) in ONE launch, one workgroup per game: trunk -> value head -> expand / backup -> next selection without
  * a kernel boundary, the leaf handed from the tree code to the trunk through LDS.  For batches of at most one game per CU (the

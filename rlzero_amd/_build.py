@@ -20,7 +20,7 @@ REPO = os.path.dirname(PKG)
 LIB = os.path.join(PKG, 'librlzero_hip.so')
 OBJ_DIR = os.path.join(PKG, 'csrc', '_obj')
 SOURCES = [os.path.join(PKG, 'csrc', name) for name in ('rz_engine.hip', 'rz_net.hip', 'rz_muzero.hip')]
-HEADERS = [os.path.join(REPO, "include", "rlzero_hip.h"), os.path.join(PKG, "csrc", "rz_trace.h"), os.path.join(PKG, "csrc", "rz_tree.h")]
+HEADERS = [os.path.join(REPO, "include", "rlzero_hip.h"), os.path.join(PKG, "csrc", "rz_trace.h"), os.path.join(PKG, "csrc", "rz_tree.h"), os.path.join(PKG, "csrc", "rz_delta.h")]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-ffp-contract=off', '-fno-fast-math', '-fno-slp-vectorize', '-std=c++17',
          '-fPIC', '-Wall', '-Wno-unused-function']
 MARKER = b'RZ_SOURCE_HASH='
@@ -57,9 +57,19 @@ def needs_build():
 def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    # one builder at a time (several ranks may call build() together): the others wait, then find the library current
+    import fcntl
+    with open(os.path.join(OBJ_DIR, '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build():
+            return LIB
+        return _build_locked(force, verbose)
+
+
+def _build_locked(force, verbose):
     hipcc = os.environ.get('HIPCC', 'hipcc')
     want = source_hash()
-    os.makedirs(OBJ_DIR, exist_ok=True)
     inc = ['-I' + os.path.join(REPO, 'include')]
     jobs, objs = [], []
     for src in SOURCES:
@@ -71,17 +81,31 @@ def build(force=False, verbose=True):
             for old in os.listdir(OBJ_DIR):
                 if old.startswith(os.path.basename(src) + '.'):
                     os.remove(os.path.join(OBJ_DIR, old))
-            cmd = [hipcc] + FLAGS + inc + ['-DRZ_SOURCE_HASH="%s"' % want, '-c', src, '-o', obj]
+            # compiled beside its final name and renamed on success: a killed hipcc leaves no object to be reused
+            tmp = '%s.tmp.%d' % (obj, os.getpid())
+            cmd = [hipcc] + FLAGS + inc + ['-DRZ_SOURCE_HASH="%s"' % want, '-c', src, '-o', tmp]
             if verbose:
                 print(' '.join(cmd), flush=True)
-            jobs.append((subprocess.Popen(cmd), cmd))
-    for proc, cmd in jobs:
-        if proc.wait() != 0:
-            raise subprocess.CalledProcessError(proc.returncode, cmd)
-    link = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
+            jobs.append((subprocess.Popen(cmd), cmd, tmp, obj))
+    failed = None
+    for proc, cmd, tmp, obj in jobs:
+        if failed is not None:
+            proc.kill()
+        rc = proc.wait()
+        if rc == 0 and failed is None:
+            os.replace(tmp, obj)
+        else:
+            if failed is None:
+                failed = (rc, cmd)
+            if os.path.exists(tmp):
+                os.remove(tmp)
+    if failed is not None:
+        raise subprocess.CalledProcessError(*failed)
+    link = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB + '.tmp']
     if verbose:
         print(' '.join(link), flush=True)
     subprocess.run(link, check=True)
+    os.replace(LIB + '.tmp', LIB)
     got = library_hash()
     if got != want:
         raise RuntimeError('the built library carries hash %r, the tree has %r' % (got, want))

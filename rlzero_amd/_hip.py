@@ -8,7 +8,7 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64,
                     c_void_p)
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
 MAX_IN_FLIGHT = 16
@@ -157,6 +157,13 @@ _SIGNATURES = {
     'rz_net_trunk_leaves_deferred': (c_int, [P, P, P, P, c_int32, P, POINTER(RzValueHead), P]),
     'rz_net_deferred_gemm': (c_int, [P, c_int32, c_int32, POINTER(RzDeferredLogits), P]),
     'rz_net_search_resident': (c_int, [P, P, c_int32, c_int32, P]),
+    'rz_net_delta_reserve': (c_int, [P, c_int32]),
+    'rz_net_delta_invalidate': (c_int, [P, P]),
+    'rz_net_delta_bases': (c_int, [P, P, P, c_int32, P]),
+    'rz_net_delta_leaves': (c_int, [P, P, P, P, c_int32, P, P, P, c_int32, POINTER(RzValueHead), P]),
+    'rz_net_delta_stats': (c_int, [P, POINTER(ctypes.c_uint32), c_int32]),
+    'rz_net_delta_bases_engine': (c_int, [P, P, P]),
+    'rz_net_delta_step': (c_int, [P, P, POINTER(RzValueHead), P]),
     'rz_net_heads': (c_int, [P, c_int32, P, P, P]),
     'rz_net_heads_gemm': (c_int, [P, c_int32, POINTER(RzRawHeads), P]),
     'rz_net_forward': (c_int, [P, P, c_int32, P, P, P]),

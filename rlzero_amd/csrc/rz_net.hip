@@ -1698,6 +1698,8 @@ __device__ __forceinline__ void conv_r(const char *in, const void *wts, int lane
 
 }  // namespace rt
 
+#include "rz_delta.h"
+
 // Register budget: 200 VGPRs + 200 accumulation registers.  Two lanes of games overlap because a wave of the other lane's tree
 // step or FC GEMM (112 / 104 registers) fits beside a trunk wave on the same SIMD (512 registers): at 400 registers or fewer the
 // trunk leaves that room, at 408 it does not and the lanes' kernels take turns (measured: 10.7 -> 9.5 M sims/s from 8 registers).
@@ -2643,6 +2645,12 @@ struct rz_net {
     int store_slots = 0, store_tiles = 0; // slots x 32-board tiles per slot
     unsigned long long *d_trace = nullptr; // rz_net_trace_attach
     long long store_boards = 0;
+    // receptive-field leaf evaluation (rz_delta.h; rz_net_delta_*): the base cache of `base_games` games
+    dl::BaseHdr *d_base_hdr = nullptr;
+    char *d_base_recs = nullptr;
+    unsigned *d_delta_stats = nullptr;
+    uint8_t *d_base_ones = nullptr;   // [base_games] of 1: the `active` flags of a caller that has none
+    int base_games = 0;
 };
 
 namespace {
@@ -2992,6 +3000,10 @@ int rz_net_destroy(rz_net *net) {
     if (net->d_store16) (void)hipFree(net->d_store16);
     if (net->d_store_raw) (void)hipFree(net->d_store_raw);
     if (net->d_valfeat) (void)hipFree(net->d_valfeat);
+    if (net->d_base_hdr) (void)hipFree(net->d_base_hdr);
+    if (net->d_base_recs) (void)hipFree(net->d_base_recs);
+    if (net->d_delta_stats) (void)hipFree(net->d_delta_stats);
+    if (net->d_base_ones) (void)hipFree(net->d_base_ones);
     delete net;
     return RZ_OK;
 }
@@ -3461,6 +3473,130 @@ int rz_net_search_resident(rz_net *net, rz_engine *engine, int32_t n_sims, int32
         default: launch_search_rows<16>(grid, st, net->dev, leaves, net->d_store16, dev.n_games, net->d_flags, later, res, net->fp8_cross); break;
     }
     if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of the resident search failed");
+    return RZ_OK;
+}
+
+static bool delta_covers(const rz_net *net) {   // k_trunk_rows' boards, its arithmetic, positions
+    return net->algo == RZ_NET_SPLIT_F16 && !net->fp8_cross && net->split_ok && rows_kernel_covers(net->dev.BH, net->dev.BW);
+}
+
+int rz_net_delta_reserve(rz_net *net, int32_t n_games) {
+    int rc = net_ready(net, n_games);
+    if (rc != RZ_OK) return rc;
+    if (!delta_covers(net))
+        return net_fail(RZ_ERR_ARG, "receptive-field evaluation exists for the RZ_NET_SPLIT_F16 trunk on boards of 11 .. 16 rows and columns");
+    if (n_games < 1) return net_fail(RZ_ERR_ARG, "rz_net_delta_reserve: n_games must be positive");
+    if (n_games <= net->base_games) return RZ_OK;
+    (void)hipDeviceSynchronize();
+    if (net->d_base_hdr) (void)hipFree(net->d_base_hdr);
+    if (net->d_base_recs) (void)hipFree(net->d_base_recs);
+    if (net->d_base_ones) (void)hipFree(net->d_base_ones);
+    net->d_base_ones = nullptr;
+    net->d_base_hdr = nullptr;
+    net->d_base_recs = nullptr;
+    net->base_games = 0;
+    const size_t hdr_bytes = (size_t)n_games * sizeof(dl::BaseHdr), rec_bytes = (size_t)n_games * 2 * dl::kBaseBytes;
+    if (hipMalloc((void **)&net->d_base_hdr, hdr_bytes) != hipSuccess || hipMalloc((void **)&net->d_base_recs, rec_bytes) != hipSuccess ||
+        hipMalloc((void **)&net->d_base_ones, (size_t)n_games) != hipSuccess)
+        return net_fail(RZ_ERR_OOM, "hipMalloc failed (base cache)");
+    if (hipMemset(net->d_base_ones, 1, (size_t)n_games) != hipSuccess) return net_fail(RZ_ERR_HIP, "hipMemset failed (base cache)");
+    if (!net->d_delta_stats && hipMalloc((void **)&net->d_delta_stats, 4 * sizeof(unsigned)) != hipSuccess)
+        return net_fail(RZ_ERR_OOM, "hipMalloc failed (delta counters)");
+    // valid = 0: a leaf of a game without bases takes the four passes without a base
+    if (hipMemset(net->d_base_hdr, 0, hdr_bytes) != hipSuccess || hipMemset(net->d_delta_stats, 0, 4 * sizeof(unsigned)) != hipSuccess)
+        return net_fail(RZ_ERR_HIP, "hipMemset failed (base cache)");
+    net->base_games = n_games;
+    return RZ_OK;
+}
+
+int rz_net_delta_invalidate(rz_net *net, void *stream) {
+    if (!net) return net_fail(RZ_ERR_ARG, "net handle is NULL");
+    if (net->base_games > 0 &&
+        hipMemsetAsync(net->d_base_hdr, 0, (size_t)net->base_games * sizeof(dl::BaseHdr), (hipStream_t)stream) != hipSuccess)
+        return net_fail(RZ_ERR_HIP, "hipMemsetAsync failed (base cache)");
+    return RZ_OK;
+}
+
+int rz_net_delta_bases(rz_net *net, const uint64_t *d_root_stones, const int32_t *d_root_to_move, int32_t n_games, void *stream) {
+    int rc = net_ready(net, n_games);
+    if (rc != RZ_OK) return rc;
+    if (n_games == 0) return RZ_OK;
+    if (!delta_covers(net)) return net_fail(RZ_ERR_ARG, "receptive-field evaluation: RZ_NET_SPLIT_F16 on boards of 11 .. 16 rows and columns");
+    if (n_games > net->base_games) return net_fail(RZ_ERR_ARG, "more games than rz_net_delta_reserve()d");
+    if (!d_root_stones || !d_root_to_move) return net_fail(RZ_ERR_ARG, "NULL device pointer");
+    dl::DeltaArgs da{net->d_base_hdr, net->d_base_recs, net->d_base_ones, nullptr, nullptr, 1, (65536 + net->dev.BW - 1) / net->dev.BW};
+    const DeferredOut none{nullptr, 0, nullptr, 0, nullptr, 0};
+    dl::k_trunk_delta<false><<<dim3((unsigned)(2 * n_games)), dim3(256), 0, (hipStream_t)stream>>>(
+        net->dev, LeafBits{d_root_stones, d_root_to_move, nullptr}, nullptr, 2 * n_games, none, da);
+    if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_trunk_delta (bases) failed");
+    return RZ_OK;
+}
+
+int rz_net_delta_leaves(rz_net *net, const uint64_t *d_stones, const int32_t *d_to_move, const int32_t *d_last_cell, int32_t n_boards,
+                        const int32_t *d_slot_of_board, const uint8_t *d_active, float *d_feat32, int32_t without_base, rz_value_head *out,
+                        void *stream) {
+    int rc = net_ready(net, n_boards);
+    if (rc != RZ_OK) return rc;
+    if (!delta_covers(net)) return net_fail(RZ_ERR_ARG, "receptive-field evaluation: RZ_NET_SPLIT_F16 on boards of 11 .. 16 rows and columns");
+    if (without_base && n_boards > net->base_games && (rc = rz_net_delta_reserve(net, n_boards)) != RZ_OK) return rc;   // (the kernel reads a header per board in every mode)
+    if (n_boards > net->base_games) return net_fail(RZ_ERR_ARG, "more boards than rz_net_delta_reserve()d games");
+    if (d_slot_of_board && n_boards > net->store_boards) return net_fail(RZ_ERR_ARG, "batch larger than rz_net_deferred_reserve()d");
+    if (n_boards > 0) {
+        if (!d_stones || !d_to_move || !d_last_cell) return net_fail(RZ_ERR_ARG, "NULL device pointer");
+        if (!d_slot_of_board && !d_feat32) return net_fail(RZ_ERR_ARG, "rz_net_delta_leaves: neither a store slot nor an f32 buffer to write to");
+        const DeferredOut later{d_slot_of_board, (long long)net->store_tiles * net->dev.groups_act * 1024, net->d_valfeat, net->vf_groups * 4,
+                                net->d_trace, net->store_slots};
+        dl::DeltaArgs da{net->d_base_hdr, net->d_base_recs, d_active ? d_active : net->d_base_ones, d_feat32, net->d_delta_stats, without_base ? 2 : 0, (65536 + net->dev.BW - 1) / net->dev.BW};
+        const dim3 grid((unsigned)n_boards);
+        _Float16 *store = d_slot_of_board ? net->d_store16 : nullptr;
+        if (d_slot_of_board) net->feat16_valid = net->feat32_valid = false;
+        if (net->d_trace && d_slot_of_board)
+            dl::k_trunk_delta<true><<<grid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, LeafBits{d_stones, d_to_move, d_last_cell}, store, n_boards, later, da);
+        else
+            dl::k_trunk_delta<false><<<grid, dim3(256), 0, (hipStream_t)stream>>>(net->dev, LeafBits{d_stones, d_to_move, d_last_cell}, store, n_boards, later, da);
+        if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_trunk_delta failed");
+    }
+    if (out) {
+        memset(out, 0, sizeof(*out));
+        out->valfeat = net->d_valfeat;
+        out->w1t = net->d_w1t;
+        out->b1 = net->dev.fc_val1_b;
+        out->w2 = net->dev.fc_val2_w;
+        out->b2 = net->dev.fc_val2_b;
+        out->ld = net->vf_groups * 4;
+        out->groups = net->vf_groups;
+    }
+    return RZ_OK;
+}
+
+// the two calls above on an engine's own arrays (rz_device_view): the bases from its ROOT positions, the step on its leaves (store
+// slot pend[g], games whose active flag is 0 skipped)
+int rz_net_delta_bases_engine(rz_net *net, rz_engine *engine, void *stream) {
+    rzt::Dev dev;
+    int rc = rz_device_view(engine, &dev, (int64_t)sizeof(dev));
+    if (rc != RZ_OK) return rc;
+    if (dev.BH != net->dev.BH || dev.BW != net->dev.BW) return net_fail(RZ_ERR_ARG, "engine and network disagree on the board");
+    return rz_net_delta_bases(net, dev.root_stones, dev.root_to_move, dev.n_games, stream);
+}
+
+int rz_net_delta_step(rz_net *net, rz_engine *engine, rz_value_head *out, void *stream) {
+    rzt::Dev dev;
+    int rc = rz_device_view(engine, &dev, (int64_t)sizeof(dev));
+    if (rc != RZ_OK) return rc;
+    if (!out) return net_fail(RZ_ERR_ARG, "NULL output pointer");
+    if (dev.K != 1 || dev.pend_cap <= 0 || dev.pend == nullptr)
+        return net_fail(RZ_ERR_ARG, "rz_net_delta_step is the deferred-priors route: one simulation in flight, rz_deferred_reserve first");
+    if (dev.BH != net->dev.BH || dev.BW != net->dev.BW) return net_fail(RZ_ERR_ARG, "engine and network disagree on the board");
+    return rz_net_delta_leaves(net, dev.leaf_stones, dev.leaf_to_move, dev.leaf_last, dev.n_games, dev.pend, dev.active, nullptr, 0, out, stream);
+}
+
+int rz_net_delta_stats(rz_net *net, uint32_t *h_out4, int32_t reset) {
+    if (!net || !h_out4) return net_fail(RZ_ERR_ARG, "NULL argument");
+    memset(h_out4, 0, 4 * sizeof(uint32_t));
+    if (!net->d_delta_stats) return RZ_OK;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h_out4, net->d_delta_stats, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+        return net_fail(RZ_ERR_HIP, "hipMemcpy failed (delta counters)");
+    if (reset && hipMemset(net->d_delta_stats, 0, 4 * sizeof(uint32_t)) != hipSuccess) return net_fail(RZ_ERR_HIP, "hipMemset failed (delta counters)");
     return RZ_OK;
 }
 

@@ -176,6 +176,46 @@ class HipNet(object):
                                                     ctypes.byref(out), self._stream()), 'rz_net_trunk_leaves_deferred')
         return out
 
+    # -- receptive-field leaf evaluation (include/rlzero_hip.h: rz_net_delta_*) ------------------------------------
+    def supports_delta(self):
+        """True when leaves can be evaluated against cached bases of the root (boards of 11 .. 16 rows and columns, 'split_f16')."""
+        return (getattr(self, 'algo', 'split_f16') == 'split_f16' and getattr(self, '_split_ok', True)
+                and 11 <= self.rows <= 16 and 11 <= self.cols <= 16)
+
+    def delta_reserve(self, n_games):
+        check(self.lib.rz_net_delta_reserve(self.handle, int(n_games)), 'rz_net_delta_reserve')
+        self._delta_games = max(getattr(self, '_delta_games', 0), int(n_games))
+
+    def delta_invalidate(self):
+        check(self.lib.rz_net_delta_invalidate(self.handle, self._stream()), 'rz_net_delta_invalidate')
+
+    def delta_bases(self, stones, to_move, n_games):
+        """The two bases of every game from its ROOT position (device pointers: uint64 [n][2][4], int32 [n])."""
+        check(self.lib.rz_net_delta_bases(self.handle, stones, to_move, int(n_games), self._stream()), 'rz_net_delta_bases')
+
+    def delta_leaves(self, stones, to_move, last, n, slot_of=None, active=None, feat32=None, without_base=False, want_head=True):
+        """The trunk on ``n`` leaves against the cached bases (same bits as trunk_leaves_deferred) -> RzValueHead or None."""
+        out = _hip.RzValueHead() if want_head else None
+        check(self.lib.rz_net_delta_leaves(self.handle, stones, to_move, last, int(n), slot_of, active, feat32, 1 if without_base else 0,
+                                           ctypes.byref(out) if out is not None else None, self._stream()), 'rz_net_delta_leaves')
+        return out
+
+    def delta_bases_engine(self, eng):
+        """The bases of every game of ``eng`` from its root positions (rz_net_delta_bases_engine)."""
+        check(self.lib.rz_net_delta_bases_engine(self.handle, eng.handle, self._stream()), 'rz_net_delta_bases_engine')
+
+    def delta_step(self, eng):
+        """trunk_leaves_deferred on the engine's leaves through the receptive-field kernel (same bits) -> RzValueHead."""
+        out = _hip.RzValueHead()
+        check(self.lib.rz_net_delta_step(self.handle, eng.handle, ctypes.byref(out), self._stream()), 'rz_net_delta_step')
+        return out
+
+    def delta_stats(self, reset=False):
+        """{'delta': leaves evaluated against a base, 'no_base': leaves that took the four passes, 'tiles3': conv3 tiles, 'cells': changed cells}"""
+        out = (ctypes.c_uint32 * 4)()
+        check(self.lib.rz_net_delta_stats(self.handle, out, 1 if reset else 0), 'rz_net_delta_stats')
+        return {'delta': int(out[0]), 'no_base': int(out[1]), 'tiles3': int(out[2]), 'cells': int(out[3])}
+
     def supports_resident(self):
         """True when whole searches can run as ONE launch, one workgroup per game (rz_net_search_resident)."""
         if getattr(self, 'algo', 'split_f16') not in ('split_f16', 'split_f16_fp8') or not getattr(self, '_split_ok', True):
@@ -329,7 +369,35 @@ class HipNetEvaluator(object):
         return (self.deferred_priors and self.use_positions and eng.score_mode == _hip.SCORE_UCT_REF and eng.sims_in_flight == 1
                 and self.hip.supports_deferred())
 
+    # Receptive-field leaf evaluation (csrc/rz_delta.h): on boards of 11 .. 16 rows and columns the deferred route's trunk recomputes only
+    # the windows around the stones a leaf adds to its search's root, on top of activations of the root cached once per move
+    # ("bases") -- the same bits as the full kernel.  RZ_NET_DELTA=0 (or delta_trunk = False): the full kernel on every leaf.
+    delta_trunk = True
+
+    def delta_ok(self, eng):
+        return (self.delta_trunk and os.environ.get('RZ_NET_DELTA', '1') != '0' and self.hip.supports_delta()
+                and eng.rows == self.hip.rows and eng.cols == self.hip.cols)
+
+    def prepare_search(self, eng):
+        """Before the steps of a search of ``eng``: the bases of its CURRENT roots (the engine counts what moves them: roots_epoch).
+        Cheap when nothing moved.  A missed call costs time only: a leaf whose base is stale takes the kernel's route without one."""
+        if not self.deferred_ok(eng) or not self.delta_ok(eng) or eng._capturing:
+            return
+        key = (id(eng), eng.roots_epoch, id(eng.handle))
+        if getattr(self, '_delta_key', None) == key:
+            return
+        if getattr(self.hip, '_delta_games', 0) < eng.n_games:
+            self.hip.torch.cuda.synchronize(self.hip.device)
+            self.hip.delta_reserve(eng.n_games)
+            eng._drop_graphs('rz_net_delta_reserve moved the base cache')
+        self.hip.delta_bases_engine(eng)
+        self._delta_key = key
+
     def deferred_trunk(self, eng):
+        if self.delta_ok(eng):
+            self.prepare_search(eng)   # (nothing while a graph is captured: the eager warm-up steps before a capture reserve the cache)
+            if getattr(self.hip, '_delta_games', 0) >= eng.n_games:
+                return self.hip.delta_step(eng)
         return self.hip.trunk_leaves_deferred(eng)
 
     # The resident search: for a batch of at most one game per CU the simulations of a search run as ONE launch, one workgroup per
@@ -517,6 +585,8 @@ class MCTSEngine(object):
         self.noise_mask = torch.zeros(G, dtype=torch.uint8, **kw)
         self.active_host = np.ones(G, dtype=np.uint8)
         self._graphs = {}
+        self.roots_epoch = 0   # bumped by whatever moves a root position (set_roots, step, the move step on the device): evaluators that cache
+                               # per-root work (HipNetEvaluator's receptive-field bases) compare it with the epoch they computed for
         # deferred priors: the evaluator whose store holds this engine's pending leaves, steps since the last flush, capacity
         self._def_ev, self._def_pending, self._def_slots, self._def_slot_ptr, self._capturing = None, 0, 0, None, False
         self.deferred_max_bytes = 6 << 30   # cap of an evaluator's store + logits (a flush every slots steps when n_playout needs more)
@@ -591,6 +661,7 @@ class MCTSEngine(object):
         base = dev.data_ptr()
         check(self.lib.rz_set_roots(self.handle, ctypes.c_void_p(base), ctypes.c_void_p(base + G * nb), ctypes.c_void_p(base + G * nb + 4 * G),
                                     mptr, 1 if reset_trees else 0, self.stream()), 'rz_set_roots')
+        self.roots_epoch += 1
 
     def reset_games(self, mask=None):
         """Empty boards, player 0 to move, fresh trees for the selected games."""
@@ -845,6 +916,9 @@ class MCTSEngine(object):
         use_graph: replay a hipGraph holding ``sims_per_graph`` simulations (captured by
         ``warm_graph``) instead of launching kernel by kernel; device-side evaluators only."""
         n = self.n_playout if n_sims is None else int(n_sims)
+        prep = getattr(evaluator, 'prepare_search', None) or getattr(getattr(evaluator, 'inner', None), 'prepare_search', None)
+        if prep is not None:
+            prep(self)   # (per-root work of the evaluator: a graph replay calls nothing of it)
         res_ok = getattr(evaluator, 'resident_ok', None)
         if not use_graph or isinstance(evaluator, HostEvaluator) or (res_ok is not None and res_ok(self)):
             self.sim_chunk(evaluator, n)   # (the resident search is two launches for the whole search: nothing to capture)
@@ -959,6 +1033,7 @@ class MCTSEngine(object):
         d_in.copy_(h_in, non_blocking=True)
         check(self.lib.rz_advance_roots(self.handle, _ptr(d_in[0]), self.stream()), 'rz_advance_roots')
         check(self.lib.rz_step_games(self.handle, _ptr(d_in[1]), _ptr(self.winner), _ptr(self.ended), self.stream()), 'rz_step_games')
+        self.roots_epoch += 1
         h_win.copy_(self.winner, non_blocking=True)
         h_end.copy_(self.ended, non_blocking=True)
         done.record(t.cuda.current_stream(self.device))
@@ -970,6 +1045,7 @@ class MCTSEngine(object):
         self.moves.copy_(self.torch.from_numpy(np.ascontiguousarray(moves, dtype=np.int32)))
         check(self.lib.rz_step_games(self.handle, _ptr(self.moves), _ptr(self.winner),
                                      _ptr(self.ended), self.stream()), 'rz_step_games')
+        self.roots_epoch += 1
         return self.winner.cpu().numpy(), self.ended.cpu().numpy()
 
     # ------------------------------------------------------------------ the move step on the device
@@ -1018,6 +1094,7 @@ class MCTSEngine(object):
         check(self.lib.rz_play_draw(self.handle, st), 'rz_play_draw')
         self.flush_deferred()
         check(self.lib.rz_play_apply(self.handle, st), 'rz_play_apply')
+        self.roots_epoch += 1
         row = self.play_steps % self.play_log.shape[0]
         self.play_steps += 1
         return row
@@ -1057,6 +1134,7 @@ class MCTSEngine(object):
         if self._def_pending > 0:
             self.flush_deferred()   # (leaves of eager steps before this move: the graph's own flush covers its n_playout slots from 0)
         graph.replay()
+        self.roots_epoch += 1
         row = self.play_steps % self.play_log.shape[0]
         self.play_steps += 1
         return row
@@ -1066,6 +1144,7 @@ class MCTSEngine(object):
         holds nothing to read (no draw has written it)."""
         self.flush_deferred()
         check(self.lib.rz_play_apply(self.handle, self.stream()), 'rz_play_apply')
+        self.roots_epoch += 1
         self.play_steps += 1
 
     def play_resolve(self, slot, move):

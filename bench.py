@@ -339,6 +339,14 @@ def launch_ranks(n):
 
 
 # --------------------------------------------------------------------------- GPU run
+def delta_resident_per_cu(args):
+    """Resident workgroups a CU holds on the run's route: two of the receptive-field kernel (k_delta_res: the default trunk on boards of
+    11 .. 16 rows and columns, unless RZ_NET_DELTA / RZ_NET_DELTA_RESIDENT / RZ_RESIDENT switch it off), one otherwise."""
+    on = (getattr(args, 'net_algo', 'split_f16') == 'split_f16' and os.environ.get('RZ_NET_DELTA', '1') != '0'
+          and os.environ.get('RZ_NET_DELTA_RESIDENT', '1') != '0' and os.environ.get('RZ_RESIDENT') != '0')
+    return 2 if on else 1
+
+
 class TimedEvaluator(object):
     """Brackets every evaluator call (the policy+value forward of the leaf batch) with HIP
     events on the launch stream (torch's current stream is the stream our kernels use)."""
@@ -661,9 +669,9 @@ def main():
         G = args.games if args.games > 0 else GAMES_PER_GPU
         net = PolicyValueNet(BOARD).to('cuda:0').eval()
         n_cus = torch.cuda.get_device_properties(0).multi_processor_count
-        lanes = args.lanes if args.lanes > 0 else plan_lanes(G, n_cus, deferred=True, cells=BOARD * BOARD)[0]
+        lanes = args.lanes if args.lanes > 0 else plan_lanes(G, n_cus, deferred=True, cells=BOARD * BOARD, resident_per_cu=delta_resident_per_cu(args))[0]
         print(json.dumps(measure(net, BOARD, N_ROW, n_games=G, n_playout=args.playouts, lanes=lanes, device='cuda:0',
-                                 add_noise=bool(args.noise), device_moves=bool(args.device_moves))), flush=True)
+                                 add_noise=bool(args.noise), device_moves=bool(args.device_moves), resident_search=False)), flush=True)
         return
 
     # CPU baseline first (rank 0, N=1 only), before this process touches the GPU
@@ -742,7 +750,8 @@ def main():
         small_trunk = (bool(args.deferred) and args.evaluator == 'hipnet' and args.net_algo in ('split_f16', 'split_f16_tiles')
                        and args.score_mode == 'uct_ref' and args.in_flight <= 1)
         lanes = plan_lanes((args.games if args.games > 0 else GAMES_PER_GPU) * max(1, args.in_flight), n_cus, deferred=will_defer,
-                           cells=cells if (small_trunk or args.in_flight > 1) else None, in_flight=max(1, args.in_flight))[0]
+                           cells=cells if (small_trunk or args.in_flight > 1) else None, in_flight=max(1, args.in_flight),
+                           resident_per_cu=delta_resident_per_cu(args) if will_defer else 1)[0]
     trunk_wgs = max(0, args.trunk_wgs)
     # default batch: the 512 games per GPU of BASELINE.json configs[3] (4096 games over 8 GPUs), as four lanes of 128
     G = args.games if args.games > 0 else GAMES_PER_GPU
@@ -772,7 +781,7 @@ def main():
             if os.environ.get('RZ_RESIDENT') == '0':   # (profiles/ab_resident.sh: the two-launch step on a batch the resident search would take)
                 hip_ev.resident_search = False
             deferred_route = hip_ev.deferred_ok(eng)
-            resident_route = G <= n_cus and hip_ev.resident_ok(eng)   # (BatchedSelfPlay switches it off for lanes that share CUs)
+            resident_route = G <= n_cus * (2 if hip_ev.resident_delta_ok(eng) else 1) and hip_ev.resident_ok(eng)   # (BatchedSelfPlay switches it off for lanes that share CUs)
             ev = TimedEvaluator(hip_ev, torch,
                                 {'winograd_f4': 'k_trunk_wino_f4<4>',
                                  'split_f16': 'k_trunk_rows' if (args.game == 'gomoku' and 11 <= board <= 16) else 'k_trunk_split',

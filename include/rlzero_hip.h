@@ -532,6 +532,10 @@ int rz_net_trace_attach(rz_net *net, void *d_trace);   /* see rz_trace_attach */
  * without_base != 0: every leaf takes the four-pass route (a checker). */
 int rz_net_delta_reserve(rz_net *net, int32_t n_games);
 int rz_net_delta_invalidate(rz_net *net, void *stream);
+/* rz_net_search_resident on these boards, once the cache holds the engine's games: the resident search with THIS trunk (k_delta_res:
+ * 82 KB of LDS, two games per CU -- up to 2 x CUs games in one launch; the bases of the roots are built by the call itself when
+ * select_first != 0).  on = 0: the full-board resident kernel (one game per CU) as before.  Default: on. */
+int rz_net_delta_resident(rz_net *net, int32_t on);
 int rz_net_delta_bases(rz_net *net, const uint64_t *d_root_stones, const int32_t *d_root_to_move, int32_t n_games, void *stream);
 int rz_net_delta_leaves(rz_net *net, const uint64_t *d_stones, const int32_t *d_to_move, const int32_t *d_last_cell, int32_t n_boards,
                         const int32_t *d_slot_of_board, const uint8_t *d_active, float *d_feat32, int32_t without_base, rz_value_head *out,

@@ -159,6 +159,7 @@ _SIGNATURES = {
     'rz_net_search_resident': (c_int, [P, P, c_int32, c_int32, P]),
     'rz_net_delta_reserve': (c_int, [P, c_int32]),
     'rz_net_delta_invalidate': (c_int, [P, P]),
+    'rz_net_delta_resident': (c_int, [P, c_int32]),
     'rz_net_delta_bases': (c_int, [P, P, P, c_int32, P]),
     'rz_net_delta_leaves': (c_int, [P, P, P, P, c_int32, P, P, P, c_int32, POINTER(RzValueHead), P]),
     'rz_net_delta_stats': (c_int, [P, POINTER(ctypes.c_uint32), c_int32]),

@@ -76,7 +76,10 @@ def gpu_numa_nodes(sysfs='/sys'):
 def _visible(n_gpus, env):
     """Indices of the visible GPUs in device-ordinal order (plain index lists only; anything else: the identity)."""
     order = list(range(n_gpus))
-    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+    # ROCR_VISIBLE_DEVICES filters first (the runtime below HIP), then exactly ONE of HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES: in
+    # HIP the latter is an alias read only when the former is unset, not a further filter
+    hip_var = 'HIP_VISIBLE_DEVICES' if env.get('HIP_VISIBLE_DEVICES') not in (None, '') else 'CUDA_VISIBLE_DEVICES'
+    for var in ('ROCR_VISIBLE_DEVICES', hip_var):
         val = env.get(var)
         if val is None or val == '':
             continue

@@ -34,7 +34,7 @@ typedef const __attribute__((address_space(3))) uint32_t *lds_u32;
 typedef __attribute__((address_space(3))) f16x4 *lds_h4;
 typedef __attribute__((address_space(3))) f32x4 *lds_v4;
 
-constexpr int kC1Slots = 128, kC2Slots = 168;   // records of conv1's / conv2's output a pass may hold
+constexpr int kC1Slots = 128, kC2Slots = 164;   // records of conv1's / conv2's output a pass may hold
 constexpr int kT1 = 4, kT2 = 8, kT3 = 8;        // tiles per pass: conv1 (32 cells each), conv2 / conv3 (16 cells each)
 constexpr int kMaxD = 4;                        // changed cells a delta pass handles
 constexpr int P1 = rt::Geo<32>::pos_bytes, P2 = rt::Geo<64>::pos_bytes;   // 160 / 288: k_trunk_rows' records
@@ -46,7 +46,7 @@ constexpr int kOffC1 = sp::kInPieceBytes, kOffC2 = kOffC1 + kC1Slots * P1, kOffZ
               kOffMap1 = kOffHead + kHeadW, kOffMap2 = kOffMap1 + kGrid * 4, kOffList = kOffMap2 + kGrid * 4, kOffCnt = kOffList + 3 * 128 * 2,
               kLdsBytes = kOffCnt + 5 * 4 * 4;
 static_assert(kShareFloats * 4 <= kC1Slots * P1, "the shares lie inside conv1's records (dead behind conv2)");
-static_assert(2 * kLdsBytes + 2048 <= 160 * 1024, "two workgroups per CU, and room for a tree-step workgroup's bytes");
+static_assert(2 * (kLdsBytes + 512 * 4 + 4 * 64 * 4 + 80 + 512) <= 160 * 1024, "two workgroups per CU, also of the resident search (value row, K-quarter sums, leaf)");
 static_assert(kOffC1 % 16 == 0 && kOffZero % 16 == 0 && kOffHead % 16 == 0 && kOffMap1 % 16 == 0, "alignment");
 
 // The base cache: per game a header (the stones the two bases were computed from) and per (game, parity) the records.
@@ -292,142 +292,48 @@ __device__ __forceinline__ void conv3_tiles(lds_u32 map2, const uint16_t *list3,
         if (t0 + i / 6 < NT) shares[((t0 + i / 6) * 4 + wave) * 96 + (i % 6) * 16 + n] = mine[i];
 }
 
-template <bool TRACE>
-__global__ __launch_bounds__(256, 2) void k_trunk_delta(NetDev nd, LeafBits leaves, _Float16 *__restrict__ feat16, int n_boards,
-                                                        DeferredOut later, DeltaArgs da) {
-    __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
-    // (the grid is exactly n_boards workgroups.  Everything up to the first use of a loaded value is ONE block of unconditional
-    // requests -- kernel arguments, the position, the header, the constants: a conditional load or an early return costs a memory
-    // round trip of its own in the chain kernel arguments -> position -> windows -> base records, which is what a leaf waits for)
-    const int board = blockIdx.x;
-    const int mode = da.mode;
-    const int game = mode == 1 ? board >> 1 : board, par_b = mode == 1 ? board & 1 : 0;
-    unsigned long long trace_t0 = 0;
-    if (TRACE) trace_t0 = rz_trace_now();
+// ---- what the pass loop of a leaf needs (one struct so that the two kernels below share the loop)
+struct Leaf {
+    f16x4 cell_planes;        // the four planes of this thread's cell
+    const char *base;         // the base of the leaf's parity (mode 1: the base being built)
+    int dys[kMaxD], dxs[kMaxD];   // the changed cells (-100: none)
+    _Float16 *dst16;          // the policy pieces' place in the store (NULL: none)
+    float *vdst;              // the value head's input row (global memory, or LDS in the resident search)
+    float *dst32;             // f32 features (tests; NULL otherwise)
+    bool deferred, store_head;
+};
+struct Layers {
+    float k1, k2, k3, act1, act2, act3;
+    const char *t2p, *t3p;
+};
 #ifdef RZ_NET_PROFILE
-    long long prof_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, prof_t = __builtin_readcyclecounter();
-    const long long prof_k0 = prof_t;
+struct Prof { long long acc[24], t; };
+#else
+struct Prof {};
 #endif
+
+// The passes of one leaf: -1 = against the base (use_delta), 0 .. 3 = the board's quadrants without one.  -> conv3 tiles computed.
+__device__ __forceinline__ int delta_passes(const NetDev &nd, const DeltaArgs &da, char *lds, int tid0, int wave, const Leaf &leaf, const Layers &ly,
+                                            f32x4 headv, bool &use_delta, Prof &prof) {
     char *in0 = lds, *c1 = lds + kOffC1, *c2 = lds + kOffC2, *zrec = lds + kOffZero, *headw = lds + kOffHead;
     uint32_t *map1 = reinterpret_cast<uint32_t *>(lds + kOffMap1), *map2 = reinterpret_cast<uint32_t *>(lds + kOffMap2);
     uint16_t *list1 = reinterpret_cast<uint16_t *>(lds + kOffList), *list2 = list1 + 128, *list3 = list2 + 128;
     int *cnt = reinterpret_cast<int *>(lds + kOffCnt);   // [5 sets][4 waves]
     float *shares = reinterpret_cast<float *>(c1);
-    const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-    const int BH = nd.BH, BW = nd.BW, S = nd.S;
-
-    const char *t2p = reinterpret_cast<const char *>(nd.t2) + (size_t)wave * rt::Geo<32>::steps * 2 * 1024;
-    const char *t3p = reinterpret_cast<const char *>(nd.t3) + (size_t)(2 * wave) * rt::Geo<64>::steps * 2 * 1024;
-    // the head convolutions' weights: requested now, stored to LDS behind the first barrier
-    f32x4 headv = tid0 < 192 ? reinterpret_cast<const f32x4 *>(nd.whp)[tid0] : reinterpret_cast<const f32x4 *>(nd.b3)[(tid0 - 192) & 31];
-    {   // (threads 224 / 225: the six head biases, two floats of padding)
-        const float *bh = nd.bh + (tid0 == 225 ? 4 : 0);
-        const f32x4 hbv = {bh[0], bh[1], tid0 == 225 ? 0.0f : bh[2], tid0 == 225 ? 0.0f : bh[3]};
-        headv = (tid0 == 224 || tid0 == 225) ? hbv : headv;
-    }
-    const float k1 = nd.s_inv[2], k2 = nd.s_inv[0], k3 = nd.s_inv[1];
-    const float act1 = nd.s_inv[5], act2 = nd.s_inv[6], act3 = nd.s_inv[7];
-
-    // ---- the position (wave-uniform: scalar loads), the header of the game's bases (read in every mode, used in mode 0), the flag
-    const uint64_t *sb = leaves.stones + (size_t)game * 8;
-    const BaseHdr *hd = da.hdr + game;
-    uint64_t ls[8], rs[8];
-    int nst = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        ls[q] = sb[q];
-        rs[q] = hd->stones[q];
-        nst += __popcll(ls[q]);
-    }
-    const int tm = leaves.to_move[game];
-    const int lc_raw = (mode == 1 ? leaves.to_move : leaves.last)[game];   // (mode 1 has no last-move array: any readable word)
-    const int lc = mode == 1 ? -1 : lc_raw;
-    const int h_tm = hd->to_move, h_valid = hd->valid;
-    const int is_active = da.active[game];
-    const bool deferred = later.slot_of != nullptr;
-    const int slot_ = (deferred ? later.slot_of : leaves.to_move)[deferred ? board : game];
-    const int tm_eff = tm ^ par_b;        // mode 1, parity 1: the root seen by the other side, one stone later
-    const int par_count = nst + par_b;
-    const bool has_last = mode != 1 && nst > 0;
-
-    // ---- delta or not (mode 0): the base's stones must be a subset of the leaf's, colour by colour; the changed cells D = the added
-    // stones and the last move (any superset of the cells whose planes differ from the base's is correct).  Selects, no branches.
-    bool use_delta = false;
-    int parity = 0, nD = 0;
-    int dys[kMaxD], dxs[kMaxD];
-    {
-        bool sup = h_valid != 0;
-        int nroot = 0;
-        uint64_t D[4] = {0ull, 0ull, 0ull, 0ull};
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            sup = sup && (rs[q] & ~ls[q]) == 0ull;
-            nroot += __popcll(rs[q]);
-            D[q & 3] |= rs[q] ^ ls[q];
-        }
-#pragma unroll
-        for (int w = 0; w < 4; ++w) D[w] |= (has_last && lc >= 0 && (lc >> 6) == w) ? 1ull << (lc & 63) : 0ull;
-        parity = (nst - nroot) & 1;
-        nD = __popcll(D[0]) + __popcll(D[1]) + __popcll(D[2]) + __popcll(D[3]);
-        use_delta = mode == 0 && sup && tm == (h_tm ^ parity) && nD <= kMaxD;
-#pragma unroll
-        for (int i = 0; i < kMaxD; ++i) {
-            const bool z0 = D[0] == 0ull, z1 = D[1] == 0ull, z2 = D[2] == 0ull;
-            const int w = !z0 ? 0 : !z1 ? 1 : !z2 ? 2 : 3;
-            const uint64_t word = !z0 ? D[0] : !z1 ? D[1] : !z2 ? D[2] : D[3];
-            const bool any = word != 0ull;
-            const int cell = 64 * w + __builtin_ctzll(word | (1ull << 63));
-            const uint64_t rest = word & (word - 1ull);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) D[k] = k == w ? rest : D[k];
-            const int y = (cell * da.bw_rcp) >> 16;
-            dys[i] = any ? y : -100;
-            dxs[i] = any ? cell - y * BW : -100;
-        }
-    }
-    const char *base = da.recs + ((size_t)game * 2 + (mode == 1 ? par_b : parity)) * kBaseBytes;
-
-    // ---- the four planes of this thread's cell (load_bits of trunk_rows_body; mode 1: no last move, the parity's stone count)
-    f16x4 cell_planes;
-    {
-        const int word = (tid0 >> 6) & 3, bit = tid0 & 63;
-        uint64_t w0 = 0ull, w1 = 0ull;   // (masks, not a select of array elements: rz_tree.h's word_of)
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const uint64_t mk = word == w ? ~0ull : 0ull;
-            w0 |= ls[w] & mk;
-            w1 |= ls[4 + w] & mk;
-        }
-        const bool s0 = (w0 >> bit) & 1ull, s1 = (w1 >> bit) & 1ull;
-        const bool mine = tm_eff == 0 ? s0 : s1, theirs = tm_eff == 0 ? s1 : s0;
-        const _Float16 one = (_Float16)sp::kObsScale, zero = (_Float16)0.0f;
-        cell_planes[0] = mine ? one : zero;
-        cell_planes[1] = theirs ? one : zero;
-        cell_planes[2] = (has_last && tid0 == lc) ? one : zero;
-        cell_planes[3] = (par_count & 1) ? zero : one;
-    }
-
-    // ---- where the features go (trunk_rows_body's feature stage)
-    _Float16 *dst16 = nullptr;
-    float *vdst = nullptr;
-    if (mode != 1 && deferred) {
-        dst16 = (feat16 != nullptr && slot_ < later.n_slots) ? feat16 + (size_t)slot_ * later.slot_halfs + (size_t)(board >> 5) * nd.groups_act * 1024 + (board & 31) * 16 : nullptr;
-        vdst = later.valfeat + (size_t)board * later.vf_ld;
-    }
-    float *dst32 = (mode != 1 && da.feat32 != nullptr) ? da.feat32 + (size_t)board * 6 * S : nullptr;
-
-    {   // once per leaf: the planes' halo, the zero record; the planes themselves and the head weights behind the first barrier
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        f32x4 *z = reinterpret_cast<f32x4 *>(in0);
-        for (int i = tid0; i < sp::kInPieceBytes / 16; i += 256) z[i] = zero;
-        if (tid0 < P2 / 16) reinterpret_cast<f32x4 *>(zrec)[tid0] = zero;
-    }
-    if (mode == 0 && is_active == 0) return;   // (uniform; before any barrier; behind the stores above so that the flag's load is
-                                               // one of the batch, not a round trip of its own at the top)
+    const int mode = da.mode, BH = nd.BH, BW = nd.BW, S = nd.S;
+    const float k1 = ly.k1, k2 = ly.k2, k3 = ly.k3, act1 = ly.act1, act2 = ly.act2, act3 = ly.act3;
+    const char *t2p = ly.t2p, *t3p = ly.t3p;
+    const char *base = leaf.base;
+    const f16x4 cell_planes = leaf.cell_planes;
+    const int (&dys)[kMaxD] = leaf.dys, (&dxs)[kMaxD] = leaf.dxs;
+    _Float16 *dst16 = leaf.dst16;
+    float *vdst = leaf.vdst, *dst32 = leaf.dst32;
+    const bool deferred = leaf.deferred, store_head = leaf.store_head;
     const uint32_t zaddr = lds_addr(zrec);
     int n_conv3_tiles = 0;
-    NET_TICK(0);   // requests, scalars, header, planes, zeroing
-
+#ifdef RZ_NET_PROFILE
+    long long (&prof_acc)[24] = prof.acc, &prof_t = prof.t;
+#endif
     for (int pass = use_delta ? -1 : 0; pass < 4; ++pass) {
         // (the thread's number is opaque per pass: hipcc otherwise hoists every lane-dependent address of the pass -- of all its
         // instantiations -- out of this loop and spills them: trunk_rows_body's board loop does the same)
@@ -522,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void k_trunk_delta(NetDev nd, LeafBits leav
         if (f[1]) list2[rank[1]] = (uint16_t)mypos;
         if (f[2]) list3[rank[2]] = (uint16_t)mypos;
         if (pass <= 0 && is_cell) *reinterpret_cast<f16x4 *>(in0 + ((cy + 1) * sp::kInCols + (cx + 1)) * 8) = cell_planes;
-        if (pass <= 0 && tid < 226) reinterpret_cast<f32x4 *>(headw)[tid] = headv;
+        if (pass <= 0 && store_head && tid < 226) reinterpret_cast<f32x4 *>(headw)[tid] = headv;
         asm volatile("" ::"v"(touch));
         if (g1) {
             const f32x4 *src = reinterpret_cast<const f32x4 *>(base + (size_t)tid * 128);
@@ -680,6 +586,154 @@ __global__ __launch_bounds__(256, 2) void k_trunk_delta(NetDev nd, LeafBits leav
         if (pass < 0) break;
         __syncthreads();   // the next pass rewrites maps, lists and records
     }
+    return n_conv3_tiles;
+}
+
+// the four planes of thread `tid`'s cell (load_bits of trunk_rows_body; a base: no last move, the parity's stone count)
+__device__ __forceinline__ f16x4 planes_of(const uint64_t (&ls)[8], int tid, int tm_eff, bool has_last, int lc, int par_count) {
+    f16x4 cell_planes;
+    const int word = (tid >> 6) & 3, bit = tid & 63;
+    uint64_t w0 = 0ull, w1 = 0ull;   // (masks, not a select of array elements: rz_tree.h's word_of)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const uint64_t mk = word == w ? ~0ull : 0ull;
+        w0 |= ls[w] & mk;
+        w1 |= ls[4 + w] & mk;
+    }
+    const bool s0 = (w0 >> bit) & 1ull, s1 = (w1 >> bit) & 1ull;
+    const bool mine = tm_eff == 0 ? s0 : s1, theirs = tm_eff == 0 ? s1 : s0;
+    const _Float16 one = (_Float16)sp::kObsScale, zero = (_Float16)0.0f;
+    cell_planes[0] = mine ? one : zero;
+    cell_planes[1] = theirs ? one : zero;
+    cell_planes[2] = (has_last && tid == lc) ? one : zero;
+    cell_planes[3] = (par_count & 1) ? zero : one;
+    return cell_planes;
+}
+
+// delta or not: the base's stones (rs) must be a subset of the leaf's (ls), colour by colour; the changed cells D = the added stones and
+// the last move (any superset of the cells whose planes differ from the base's is correct).  Selects, no branches.  -> use_delta
+__device__ __forceinline__ bool changed_cells(const uint64_t (&ls)[8], const uint64_t (&rs)[8], int nst, int tm, int lc, bool has_last, bool base_ok, int h_tm,
+                                              int bw_rcp, int BW, int (&dys)[kMaxD], int (&dxs)[kMaxD], int &parity, int &nD) {
+    // ---- delta or not (mode 0): the base's stones must be a subset of the leaf's, colour by colour; the changed cells D = the added
+    // stones and the last move (any superset of the cells whose planes differ from the base's is correct).  Selects, no branches.
+    bool use_delta = false;
+    {
+        bool sup = true;
+        int nroot = 0;
+        uint64_t D[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            sup = sup && (rs[q] & ~ls[q]) == 0ull;
+            nroot += __popcll(rs[q]);
+            D[q & 3] |= rs[q] ^ ls[q];
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) D[w] |= (has_last && lc >= 0 && (lc >> 6) == w) ? 1ull << (lc & 63) : 0ull;
+        parity = (nst - nroot) & 1;
+        nD = __popcll(D[0]) + __popcll(D[1]) + __popcll(D[2]) + __popcll(D[3]);
+        use_delta = base_ok && sup && tm == (h_tm ^ parity) && nD <= kMaxD;
+#pragma unroll
+        for (int i = 0; i < kMaxD; ++i) {
+            const bool z0 = D[0] == 0ull, z1 = D[1] == 0ull, z2 = D[2] == 0ull;
+            const int w = !z0 ? 0 : !z1 ? 1 : !z2 ? 2 : 3;
+            const uint64_t word = !z0 ? D[0] : !z1 ? D[1] : !z2 ? D[2] : D[3];
+            const bool any = word != 0ull;
+            const int cell = 64 * w + __builtin_ctzll(word | (1ull << 63));
+            const uint64_t rest = word & (word - 1ull);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) D[k] = k == w ? rest : D[k];
+            const int y = (cell * bw_rcp) >> 16;
+            dys[i] = any ? y : -100;
+            dxs[i] = any ? cell - y * BW : -100;
+        }
+    }
+    return use_delta;
+}
+
+template <bool TRACE>
+__global__ __launch_bounds__(256, 2) void k_trunk_delta(NetDev nd, LeafBits leaves, _Float16 *__restrict__ feat16, int n_boards,
+                                                        DeferredOut later, DeltaArgs da) {
+    __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+    // (the grid is exactly n_boards workgroups.  Everything up to the first use of a loaded value is ONE block of unconditional
+    // requests -- kernel arguments, the position, the header, the constants: a conditional load or an early return costs a memory
+    // round trip of its own in the chain kernel arguments -> position -> windows -> base records, which is what a leaf waits for)
+    const int board = blockIdx.x;
+    const int mode = da.mode;
+    const int game = mode == 1 ? board >> 1 : board, par_b = mode == 1 ? board & 1 : 0;
+    unsigned long long trace_t0 = 0;
+    if (TRACE) trace_t0 = rz_trace_now();
+    Prof prof;
+#ifdef RZ_NET_PROFILE
+    for (int i = 0; i < 24; ++i) prof.acc[i] = 0;
+    prof.t = __builtin_readcyclecounter();
+    const long long prof_k0 = prof.t;
+    long long (&prof_acc)[24] = prof.acc, &prof_t = prof.t;
+#endif
+    const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const int BW = nd.BW, S = nd.S;
+    Layers ly;
+    ly.t2p = reinterpret_cast<const char *>(nd.t2) + (size_t)wave * rt::Geo<32>::steps * 2 * 1024;
+    ly.t3p = reinterpret_cast<const char *>(nd.t3) + (size_t)(2 * wave) * rt::Geo<64>::steps * 2 * 1024;
+    // the head convolutions' weights: requested now, stored to LDS behind the first barrier
+    f32x4 headv = tid0 < 192 ? reinterpret_cast<const f32x4 *>(nd.whp)[tid0] : reinterpret_cast<const f32x4 *>(nd.b3)[(tid0 - 192) & 31];
+    {   // (threads 224 / 225: the six head biases, two floats of padding)
+        const float *bh = nd.bh + (tid0 == 225 ? 4 : 0);
+        const f32x4 hbv = {bh[0], bh[1], tid0 == 225 ? 0.0f : bh[2], tid0 == 225 ? 0.0f : bh[3]};
+        headv = (tid0 == 224 || tid0 == 225) ? hbv : headv;
+    }
+    ly.k1 = nd.s_inv[2], ly.k2 = nd.s_inv[0], ly.k3 = nd.s_inv[1];
+    ly.act1 = nd.s_inv[5], ly.act2 = nd.s_inv[6], ly.act3 = nd.s_inv[7];
+
+    // ---- the position (wave-uniform: scalar loads), the header of the game's bases (read in every mode, used in mode 0), the flag
+    const uint64_t *sb = leaves.stones + (size_t)game * 8;
+    const BaseHdr *hd = da.hdr + game;
+    uint64_t ls[8], rs[8];
+    int nst = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        ls[q] = sb[q];
+        rs[q] = hd->stones[q];
+        nst += __popcll(ls[q]);
+    }
+    const int tm = leaves.to_move[game];
+    const int lc_raw = (mode == 1 ? leaves.to_move : leaves.last)[game];   // (mode 1 has no last-move array: any readable word)
+    const int lc = mode == 1 ? -1 : lc_raw;
+    const int h_tm = hd->to_move, h_valid = hd->valid;
+    const int is_active = da.active[game];
+    const bool deferred = later.slot_of != nullptr;
+    const int slot_ = (deferred ? later.slot_of : leaves.to_move)[deferred ? board : game];
+    const int tm_eff = tm ^ par_b;        // mode 1, parity 1: the root seen by the other side, one stone later
+    const int par_count = nst + par_b;
+    const bool has_last = mode != 1 && nst > 0;
+
+    Leaf leaf;
+    int parity = 0, nD = 0;
+    bool use_delta = changed_cells(ls, rs, nst, tm, lc, has_last, mode == 0 && h_valid != 0, h_tm, da.bw_rcp, BW, leaf.dys, leaf.dxs, parity, nD);
+    leaf.base = da.recs + ((size_t)game * 2 + (mode == 1 ? par_b : parity)) * kBaseBytes;
+    leaf.cell_planes = planes_of(ls, tid0, tm_eff, has_last, lc, par_count);
+
+    // ---- where the features go (trunk_rows_body's feature stage)
+    leaf.dst16 = nullptr;
+    leaf.vdst = nullptr;
+    if (mode != 1 && deferred) {
+        leaf.dst16 = (feat16 != nullptr && slot_ < later.n_slots) ? feat16 + (size_t)slot_ * later.slot_halfs + (size_t)(board >> 5) * nd.groups_act * 1024 + (board & 31) * 16 : nullptr;
+        leaf.vdst = later.valfeat + (size_t)board * later.vf_ld;
+    }
+    leaf.dst32 = (mode != 1 && da.feat32 != nullptr) ? da.feat32 + (size_t)board * 6 * S : nullptr;
+    leaf.deferred = deferred;
+    leaf.store_head = true;
+
+    {   // once per leaf: the planes' halo, the zero record; the planes themselves and the head weights behind the first barrier
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 *z = reinterpret_cast<f32x4 *>(lds);
+        for (int i = tid0; i < sp::kInPieceBytes / 16; i += 256) z[i] = zero;
+        if (tid0 < P2 / 16) reinterpret_cast<f32x4 *>(lds + kOffZero)[tid0] = zero;
+    }
+    if (mode == 0 && is_active == 0) return;   // (uniform; before any barrier; behind the stores above so that the flag's load is
+                                               // one of the batch, not a round trip of its own at the top)
+    NET_TICK(0);   // requests, scalars, header, planes, zeroing
+    const int n_conv3_tiles = delta_passes(nd, da, lds, tid0, wave, leaf, ly, headv, use_delta, prof);
+
     if (mode == 1 && par_b == 0 && tid0 == 0) {   // the header of this game's bases (the launch behind this one reads it)
         BaseHdr *h = da.hdr + game;
 #pragma unroll
@@ -700,6 +754,134 @@ __global__ __launch_bounds__(256, 2) void k_trunk_delta(NetDev nd, LeafBits leav
     }
 #endif
     if (TRACE && tid0 == 0) rz_trace_write(later.trace, RZ_TRACE_TRUNK, deferred ? slot_ : 0, board, trace_t0);
+}
+
+// RESIDENT SEARCH with receptive-field evaluation (rz_net_search_resident on boards of 11 .. 16 rows and columns once the base cache
+// exists): k_trunk_rows_res's loop -- leaf -> trunk -> value head -> expand / backup -> next selection, n_sims times in ONE launch, one
+// workgroup per game, the leaf handed over through LDS, the tree code the engine's own (rz_tree.h) -- with the delta passes as the
+// trunk.  82 KB of LDS and 256 registers: TWO games per CU, so the serial tree walk of one game (one wave, ~6 us a simulation) runs
+// under the other game's matrix work, and a batch of 2 x CUs games (the 512 per GPU of BASELINE.json configs[3]) is ONE launch per
+// search on one stream: no lanes, no hardware-queue layout, no kernel boundary inside a search.  The bases of the roots are built
+// by the launch before this one (rz_net_search_resident); the header is compared with the root once per search.
+constexpr int kResVrow = 512;
+__global__ __launch_bounds__(256, 2) void k_delta_res(NetDev nd, _Float16 *__restrict__ store16, DeferredOut later, DeltaArgs da, ResArgs<true> res) {
+    __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+    __shared__ float res_vrow[kResVrow];
+    __shared__ float res_part[rzt::kDefWaves][rzt::kWave];
+    __shared__ __attribute__((aligned(16))) uint64_t res_leaf[2 * RZ_BOARD_WORDS + 2];
+    const int game = blockIdx.x;
+    if (game >= res.E.n_games || res.E.active[game] == 0) return;   // (uniform: before any barrier)
+    const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+    const int BW = nd.BW, S = nd.S;
+    Prof prof;
+#ifdef RZ_NET_PROFILE
+    for (int i = 0; i < 24; ++i) prof.acc[i] = 0;
+    prof.t = __builtin_readcyclecounter();
+    const long long prof_k0 = prof.t;
+    long long (&prof_acc)[24] = prof.acc, &prof_t = prof.t;
+#endif
+    Layers ly;
+    ly.t2p = reinterpret_cast<const char *>(nd.t2) + (size_t)wave * rt::Geo<32>::steps * 2 * 1024;
+    ly.t3p = reinterpret_cast<const char *>(nd.t3) + (size_t)(2 * wave) * rt::Geo<64>::steps * 2 * 1024;
+    f32x4 headv = tid0 < 192 ? reinterpret_cast<const f32x4 *>(nd.whp)[tid0] : reinterpret_cast<const f32x4 *>(nd.b3)[(tid0 - 192) & 31];
+    {
+        const float *bh = nd.bh + (tid0 == 225 ? 4 : 0);
+        const f32x4 hbv = {bh[0], bh[1], tid0 == 225 ? 0.0f : bh[2], tid0 == 225 ? 0.0f : bh[3]};
+        headv = (tid0 == 224 || tid0 == 225) ? hbv : headv;
+    }
+    ly.k1 = nd.s_inv[2], ly.k2 = nd.s_inv[0], ly.k3 = nd.s_inv[1];
+    ly.act1 = nd.s_inv[5], ly.act2 = nd.s_inv[6], ly.act3 = nd.s_inv[7];
+    const int slot0 = res.E.pend[game];
+    // the root (it does not move inside a search) against the header of the game's bases: once
+    uint64_t rs[8];
+    bool base_ok = da.hdr[game].valid != 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        rs[q] = res.E.root_stones[(size_t)game * 8 + q];
+        base_ok = base_ok && da.hdr[game].stones[q] == rs[q];
+    }
+    const int h_tm = res.E.root_to_move[game];
+    base_ok = base_ok && da.hdr[game].to_move == h_tm;
+    {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 *z = reinterpret_cast<f32x4 *>(lds);
+        for (int i = tid0; i < sp::kInPieceBytes / 16; i += 256) z[i] = zero;
+        if (tid0 < P2 / 16) reinterpret_cast<f32x4 *>(lds + kOffZero)[tid0] = zero;
+        for (int i = tid0; i < kResVrow; i += 256) res_vrow[i] = 0.0f;
+    }
+    if (res.select_first == 0 && tid0 == 0) {   // the first leaf was selected by rz_select_step: from the engine's leaf arrays
+#pragma unroll
+        for (int q = 0; q < 8; ++q) res_leaf[q] = res.E.leaf_stones[(size_t)game * 8 + q];
+        reinterpret_cast<int *>(res_leaf + 2 * RZ_BOARD_WORDS)[0] = res.E.leaf_to_move[game];
+        reinterpret_cast<int *>(res_leaf + 2 * RZ_BOARD_WORDS)[1] = res.E.leaf_last[game];
+    }
+    __syncthreads();
+    if (res.select_first != 0) {   // AlphaZeroMCTS._playout's select loop for the first simulation of the search (rz_select_step's work)
+        if (wave == 0) rzt::select_body<false>(res.E, nullptr, game, tid0 & 63, 0, res_leaf);
+        __syncthreads();
+    }
+    int tiles_total = 0, deltas = 0, cells_total = 0;
+    for (int sim = 0; sim < res.n_sims; ++sim) {
+        // (the thread's number is opaque per simulation: hipcc otherwise hoists the tree code's lane-dependent addresses out of this
+        // loop and spills them)
+        int tid_s = tid0;
+        asm volatile("" : "+v"(tid_s));
+        // ---- the leaf, from LDS (select_body's lds_leaf): wave-uniform values
+        uint64_t ls[8];
+        int nst = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint64_t v = res_leaf[q];
+            ls[q] = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+            nst += __popcll(ls[q]);
+        }
+        const int tm = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int *>(res_leaf + 2 * RZ_BOARD_WORDS)[0]);
+        const int lc = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int *>(res_leaf + 2 * RZ_BOARD_WORDS)[1]);
+        const bool has_last = nst > 0;
+        Leaf leaf;
+        int parity = 0, nD = 0;
+        bool use_delta = changed_cells(ls, rs, nst, tm, lc, has_last, base_ok, h_tm, da.bw_rcp, BW, leaf.dys, leaf.dxs, parity, nD);
+        leaf.base = da.recs + ((size_t)game * 2 + parity) * kBaseBytes;
+        leaf.cell_planes = planes_of(ls, tid_s, tm, has_last, lc, nst);
+        // the game's slot advances by one per simulation (expand_backup_body<DEF>); the value inputs stay in LDS
+        leaf.dst16 = slot0 + sim < later.n_slots ? store16 + (size_t)(slot0 + sim) * later.slot_halfs + (size_t)(game >> 5) * nd.groups_act * 1024 + (game & 31) * 16 : nullptr;
+        leaf.vdst = res_vrow;
+        leaf.dst32 = nullptr;
+        leaf.deferred = true;
+        leaf.store_head = sim == 0;
+        NET_TICK(0);
+        tiles_total += delta_passes(nd, da, lds, tid_s, wave, leaf, ly, headv, use_delta, prof);
+        deltas += use_delta ? 1 : 0;
+        cells_total += nD;
+        __syncthreads();   // the value head's inputs are complete; the shares are read
+        NET_TICK(12);
+        // ---- the rest of the simulation, by the same workgroup (k_tree_step_def's body: rz_tree.h), as in trunk_rows_body
+        const int lane = tid_s & 63;
+        if (res.vh.groups == 128) rzt::value_quarter_lds<16>(res.vh, res_vrow, lane, wave, res_part);
+        else rzt::value_quarter_lds<8>(res.vh, res_vrow, lane, wave, res_part);
+        NET_TICK(16);
+        if (wave == 0) rzt::expand_backup_body<float, false, false, false, true>(res.E, nullptr, nullptr, game, lane, rz_raw_heads(), 0, res.vh, res_part);
+        else __syncthreads();   // (the barrier inside the body, where the quarters meet)
+        __syncthreads();        // the tree's updates before the selection's loads
+        NET_TICK(17);
+        const bool more = sim + 1 < res.n_sims;
+        if (wave == 0 && more) rzt::select_body<false>(res.E, nullptr, game, lane, 0, res_leaf);
+        __syncthreads();
+        NET_TICK(18);
+    }
+    if (da.stats != nullptr && tid0 == 0) {
+        atomicAdd(da.stats + 0, (unsigned)deltas);
+        atomicAdd(da.stats + 1, (unsigned)(res.n_sims - deltas));
+        atomicAdd(da.stats + 2, (unsigned)tiles_total);
+        atomicAdd(da.stats + 3, (unsigned)cells_total);
+    }
+#ifdef RZ_NET_PROFILE
+    if (blockIdx.x == 0 && tid0 == 0) {
+        for (int i = 0; i < 24; ++i) net_prof[i] = prof_acc[i];
+        net_prof[23] = __builtin_readcyclecounter() - prof_k0;
+        net_prof[22] = tiles_total;
+    }
+#endif
 }
 
 }  // namespace dl

@@ -1985,16 +1985,16 @@ int rz_play_attach(rz_engine *e, const rz_play_config *cfg) {
     RZ_HIP(hipDeviceSynchronize());
     Play &Y = e->play;
     const long long G = e->cfg.n_games;
-    if (Y.game_id == nullptr) {
+    if (Y.top_hwm == nullptr) {   // (keyed on the array allocated LAST; an earlier attach that ran out of memory is retried array by array)
         memset(&Y, 0, sizeof(Y));
-        if ((rc = dev_alloc(e, &Y.game_id, G)) != RZ_OK) return rc;
-        if ((rc = dev_alloc(e, &Y.ply, G)) != RZ_OK) return rc;
-        if ((rc = dev_alloc(e, &Y.state, G)) != RZ_OK) return rc;
-        if ((rc = dev_alloc(e, &Y.mailbox, G)) != RZ_OK) return rc;
-        if ((rc = dev_alloc(e, &Y.keep, G)) != RZ_OK) return rc;
-        if ((rc = dev_alloc(e, &Y.stepm, G)) != RZ_OK) return rc;
-        if ((rc = dev_alloc(e, &Y.step_ab, 2)) != RZ_OK) return rc;
-        if ((rc = dev_alloc(e, &Y.top_hwm, G)) != RZ_OK) return rc;
+        if (Y.game_id == nullptr && (rc = dev_alloc(e, &Y.game_id, G)) != RZ_OK) return rc;
+        if (Y.ply == nullptr && (rc = dev_alloc(e, &Y.ply, G)) != RZ_OK) return rc;
+        if (Y.state == nullptr && (rc = dev_alloc(e, &Y.state, G)) != RZ_OK) return rc;
+        if (Y.mailbox == nullptr && (rc = dev_alloc(e, &Y.mailbox, G)) != RZ_OK) return rc;
+        if (Y.keep == nullptr && (rc = dev_alloc(e, &Y.keep, G)) != RZ_OK) return rc;
+        if (Y.stepm == nullptr && (rc = dev_alloc(e, &Y.stepm, G)) != RZ_OK) return rc;
+        if (Y.step_ab == nullptr && (rc = dev_alloc(e, &Y.step_ab, 2)) != RZ_OK) return rc;
+        if (Y.top_hwm == nullptr && (rc = dev_alloc(e, &Y.top_hwm, G)) != RZ_OK) return rc;
     }
     Y.queue_ids = cfg->d_queue_ids;
     Y.queue_ctl = cfg->d_queue_ctl;

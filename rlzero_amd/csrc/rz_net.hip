@@ -2651,6 +2651,7 @@ struct rz_net {
     unsigned *d_delta_stats = nullptr;
     uint8_t *d_base_ones = nullptr;   // [base_games] of 1: the `active` flags of a caller that has none
     int base_games = 0;
+    bool delta_resident = true;       // rz_net_delta_resident: rz_net_search_resident runs k_delta_res where the cache allows
 };
 
 namespace {
@@ -3435,8 +3436,11 @@ int rz_net_search_resident(rz_net *net, rz_engine *engine, int32_t n_sims, int32
     if (dev.K != 1 || dev.score_mode != RZ_SCORE_UCT_REF || dev.pend_cap <= 0)
         return net_fail(RZ_ERR_ARG, "the resident search is the deferred-priors route: RZ_SCORE_UCT_REF, one simulation in flight, rz_deferred_reserve first");
     if (dev.BH != net->dev.BH || dev.BW != net->dev.BW || dev.A != net->dev.A) return net_fail(RZ_ERR_ARG, "engine and network disagree on the board");
-    if (dev.n_games > net->store_boards || dev.n_games > net->n_cus)
-        return net_fail(RZ_ERR_ARG, "the resident search runs one workgroup per game, at most one per CU and rz_net_deferred_reserve()d");
+    // receptive-field evaluation (rz_net_delta_reserve for this many games, the default trunk on a board of 11 .. 16 rows and columns):
+    // k_delta_res, TWO workgroups per CU; rz_net_delta_resident(net, 0) keeps k_trunk_rows_res
+    const bool delta_res = net->delta_resident && rows && !net->fp8_cross && net->split_ok && net->base_games >= dev.n_games;
+    if (dev.n_games > net->store_boards || dev.n_games > (delta_res ? 2 : 1) * net->n_cus)
+        return net_fail(RZ_ERR_ARG, "the resident search runs one workgroup per game, at most one per CU (two with rz_net_delta_reserve) and rz_net_deferred_reserve()d");
     if (rows ? (net->vf_groups != 64 && net->vf_groups != 128) : net->vf_groups > 64) return net_fail(RZ_ERR_INTERNAL, "value head groups");
     ResArgs<true> res;
     res.E = dev;
@@ -3454,6 +3458,15 @@ int rz_net_search_resident(rz_net *net, rz_engine *engine, int32_t n_sims, int32
     const dim3 grid((unsigned)dev.n_games);
     const hipStream_t st = (hipStream_t)stream;
     net->feat16_valid = net->feat32_valid = false;
+    if (delta_res) {
+        if (select_first) {   // a search begins: the bases of its roots (a continued search finds them, or takes the route without)
+            if ((rc = rz_net_delta_bases(net, dev.root_stones, dev.root_to_move, dev.n_games, stream)) != RZ_OK) return rc;
+        }
+        dl::DeltaArgs da{net->d_base_hdr, net->d_base_recs, net->d_base_ones, nullptr, net->d_delta_stats, 0, (65536 + net->dev.BW - 1) / net->dev.BW};
+        dl::k_delta_res<<<grid, dim3(256), 0, st>>>(net->dev, net->d_store16, later, da, res);
+        if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of the resident search (k_delta_res) failed");
+        return RZ_OK;
+    }
     if (!rows) {   // (the launches of launch_trunk for these boards, RES instantiations)
         _Float16 *store = net->d_store16;
         const int ng = dev.n_games;
@@ -3506,6 +3519,12 @@ int rz_net_delta_reserve(rz_net *net, int32_t n_games) {
     if (hipMemset(net->d_base_hdr, 0, hdr_bytes) != hipSuccess || hipMemset(net->d_delta_stats, 0, 4 * sizeof(unsigned)) != hipSuccess)
         return net_fail(RZ_ERR_HIP, "hipMemset failed (base cache)");
     net->base_games = n_games;
+    return RZ_OK;
+}
+
+int rz_net_delta_resident(rz_net *net, int32_t on) {
+    if (!net) return net_fail(RZ_ERR_ARG, "net handle is NULL");
+    net->delta_resident = on != 0;
     return RZ_OK;
 }
 

@@ -404,11 +404,24 @@ class HipNetEvaluator(object):
     # game (trunk -> value head -> expand / backup -> selection, no kernel boundary; the deferred route's trees, values and priors).
     resident_search = True
 
+    def resident_delta_ok(self, eng):
+        """The resident search with the receptive-field trunk (k_delta_res): TWO games per CU.  RZ_NET_DELTA_RESIDENT=0: never."""
+        return self.delta_ok(eng) and os.environ.get('RZ_NET_DELTA_RESIDENT', '1') != '0'
+
     def resident_ok(self, eng):
+        n_cus = self.hip.torch.cuda.get_device_properties(self.hip.device).multi_processor_count
         return (self.resident_search and self.deferred_ok(eng) and self.hip.supports_resident()
-                and eng.n_games <= self.hip.torch.cuda.get_device_properties(self.hip.device).multi_processor_count)
+                and eng.n_games <= (2 if self.resident_delta_ok(eng) else 1) * n_cus)
 
     def search_resident(self, eng, n_sims, select_first=False):
+        want = self.resident_delta_ok(eng)
+        if getattr(self, '_delta_res_set', None) != want:
+            check(self.hip.lib.rz_net_delta_resident(self.hip.handle, 1 if want else 0), 'rz_net_delta_resident')
+            self._delta_res_set = want
+        if want and getattr(self.hip, '_delta_games', 0) < eng.n_games and not eng._capturing:
+            self.hip.torch.cuda.synchronize(self.hip.device)
+            self.hip.delta_reserve(eng.n_games)   # (the library then runs k_delta_res and builds the roots' bases itself)
+            eng._drop_graphs('rz_net_delta_reserve moved the base cache')
         self.hip.search_resident(eng, n_sims, select_first)
 
     def raw_heads(self, eng):
@@ -846,8 +859,9 @@ class MCTSEngine(object):
     def _drop_graphs(self, why):
         """Captured launches hold device addresses by value: when a reservation moves a buffer they replay into freed memory.  The
         graphs are dropped; simulate(use_graph=True) then says to call warm_graph again."""
-        if self._graphs:
+        if self._graphs or getattr(self, '_move_graph', None) is not None:
             self._graphs = {}
+            self._move_graph = None   # (warm_move_graph's whole-move graph bakes the same addresses in)
             self._graphs_dropped = why
 
     def _sim_chunk_deferred(self, evaluator, n):
@@ -1112,6 +1126,10 @@ class MCTSEngine(object):
         self.flush_deferred()
         if self._deferred_begin(evaluator, n) < n or self._def_slots < n:   # (reserves the store; a search must fit between two flushes)
             return None
+        inner = getattr(evaluator, 'inner', evaluator)
+        if getattr(inner, 'resident_delta_ok', None) is not None and inner.resident_delta_ok(self) and getattr(inner.hip, '_delta_games', 0) < self.n_games:
+            t.cuda.synchronize(self.device)
+            inner.hip.delta_reserve(self.n_games)   # (before the capture: the base cache of the receptive-field trunk)
         hip, lib, h = evaluator.hip, self.lib, self.handle
         t.cuda.synchronize(self.device)
         graph = t.cuda.CUDAGraph()
@@ -1127,10 +1145,13 @@ class MCTSEngine(object):
         finally:
             self._capturing = False
         self._move_graph_ev = evaluator
+        self._move_graph = graph
         return graph
 
     def play_move_replay(self, graph):
         """One whole move from the graph of warm_move_graph -> the log row it writes."""
+        if graph is not getattr(self, '_move_graph', None):
+            raise HipError('this whole-move graph was dropped (%s): call warm_move_graph again' % getattr(self, '_graphs_dropped', 'a buffer it addresses moved'))
         if self._def_pending > 0:
             self.flush_deferred()   # (leaves of eager steps before this move: the graph's own flush covers its n_playout slots from 0)
         graph.replay()

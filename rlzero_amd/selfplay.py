@@ -19,6 +19,8 @@ rank 0 (RCCL when the process group backend is nccl, gloo in the CPU tests).
 """
 import numpy as np
 
+from ._hip import HipError
+
 _MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
@@ -153,7 +155,7 @@ class Trajectory(object):
 
 
 
-def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False, cells=None, in_flight=1):
+def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False, cells=None, in_flight=1, resident_per_cu=1):
     """-> (lanes, trunk_workgroups, heads_algo) for ``n_games`` leaves per simulation step on a GPU with ``n_cus`` CUs and
     ``hw_queues`` hardware queues for its streams (default: what rlzero_amd claimed on import, rlzero_amd.HW_QUEUES).
 
@@ -165,6 +167,12 @@ def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False, cells=None, i
     1.75 rounds THREE (320 / 384 games: 9.2 / 10.3 against 8.7 / 9.8 with
     two); 448 games TWO (10.3 against 10.1); 2 .. 2.75 rounds FOUR on 8 hardware queues (512 / 640 games: 10.6 / 10.6 against 10.5
     / 10.1 with two -- with fewer queues two lanes, a percent behind); beyond, TWO (768 .. 1536 games: 10.9 .. 11.0).
+
+    ``resident_per_cu`` = 2 (with ``deferred``: the receptive-field trunk, HipNetEvaluator.resident_delta_ok -- boards of 11 .. 16 rows
+    and columns): the resident search holds TWO games per CU (k_delta_res: 82 KB of LDS), so up to 2 x CUs games -- the 512 per GPU of
+    BASELINE.json configs[3] -- are ONE launch per search on ONE lane: one game's serial tree walk runs under the other game's matrix
+    work on the same CU, and no hardware-queue layout is involved (round 6, same box: 512 games 18.95 M on one lane, 17.0 M on two,
+    13.7 M on the four lanes of the two-launch step; profiles/r06/NOTES.md).
 
     ``cells``: positions of the board, when known.  Boards of at most 42 cells on the split-f16 trunk (Connect4, 6x6: the
     two-launch step with a 12-us trunk and a 10-us tree step) run TWO lanes above one round of boards (Connect4, M simulations / s on
@@ -201,6 +209,8 @@ def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False, cells=None, i
     if cells is not None and cells <= 100 and in_flight > 1 and n_games >= 2 * n_cus:
         return (4 if (n_games >= 4 * n_cus and hw_queues >= 8) else 3), 0, 'parts'
     if deferred:
+        if resident_per_cu >= 2 and n_games <= 2 * n_cus:   # two games per CU: the resident search with the receptive-field trunk, one lane
+            return 1, 0, 'auto'
         if n_games <= n_cus:   # one game per CU at most: the resident search (one launch per search, a workgroup per game) --
             # on TWO lanes from half a round of boards on, so that a lane's host step runs under the other lane's search
             # (256 games: 9.17 against 8.57 M; 128 games 4.83 against 4.74; profiles/r04/ab_resident.txt)
@@ -267,12 +277,17 @@ def choose_lanes_by_measurement(key, table_pick, hw_queues, n_games, build, time
         return cache[key]
     rates = {}
     for lanes in lane_candidates(table_pick, hw_queues, n_games):
-        sp = build(lanes)
-        try:
+        sp = None
+        try:   # (a candidate that cannot be built or timed -- e.g. a mode the timer's move step does not serve -- is no candidate)
+            sp = build(lanes)
             rates[lanes] = float(timer(sp))
+        except HipError:
+            pass
         finally:
-            for lane in getattr(sp, 'lanes', ()):
+            for lane in getattr(sp, 'lanes', ()) if sp is not None else ():
                 lane.eng.close()
+    if not rates:   # nothing could be measured: the table's pick, not cached as a measurement
+        return table_pick, None
     best = max(sorted(rates), key=lambda c: (rates[c], -c))
     cache[key] = (best, rates)
     return cache[key]
@@ -321,7 +336,12 @@ class BatchedSelfPlay(object):
             self.lanes.append(_Lane(eng, ev, stream, offset))
             offset += eng.n_games
         n_cus = torch.cuda.get_device_properties(engines[0].device).multi_processor_count
-        if len(engines) > 1 and sum(e.n_games for e in engines) > n_cus:
+
+        def per_cu(ev, eng):   # resident workgroups a CU holds: two of the receptive-field kernel (k_delta_res), one otherwise
+            inner = getattr(ev, 'inner', ev)
+            ok = getattr(inner, 'resident_delta_ok', None)
+            return 2 if (ok is not None and ok(eng)) else 1
+        if len(engines) > 1 and sum(e.n_games for e in engines) > n_cus * min(per_cu(ev, e) for ev, e in zip(evaluators, engines)):
             # lanes that share CUs: the resident search (a workgroup keeps its CU for a whole search) is for games that have a CU
             # each -- these lanes run the two-launch step, whose trunk workgroups make way for the other lanes every step
             for ev in evaluators:
@@ -377,11 +397,18 @@ class BatchedSelfPlay(object):
                     and net_algo in (None, 'split_f16', 'split_f16_tiles', 'split_f16_fp8'))
         small_trunk = (K == 1 and deferred_priors is not False and engine_kw.get('score_mode', 'uct_ref') in ('uct_ref', 0)
                        and net_algo in (None, 'split_f16', 'split_f16_tiles'))   # (the two-launch step on a small board)
+        import os
+        delta_res = (deferred and resident_search is not False and net_algo in (None, 'split_f16')
+                     and os.environ.get('RZ_NET_DELTA', '1') != '0' and os.environ.get('RZ_NET_DELTA_RESIDENT', '1') != '0')
         auto_lanes, auto_wgs, heads_algo = plan_lanes(n_games * K, n_cus, deferred=deferred,
-                                                      cells=rows0 * cols0 if (small_trunk or K > 1) else None, in_flight=K)
+                                                      cells=rows0 * cols0 if (small_trunk or K > 1) else None, in_flight=K,
+                                                      resident_per_cu=2 if delta_res else 1)
         measured = None
         if lanes == 'table':
             lanes = None
+        elif K > 1:
+            # K simulations in flight: the timer's move step (rz_play_attach) serves one simulation in flight per tree only -- the table
+            lanes = None if lanes == 'measure' else lanes
         elif lanes == 'measure' or (lanes is None and n_cus != TABLE_CUS and n_games * K > n_cus):
             # off the table's chip (or asked for): the table's pick and its neighbours, timed for two moves each
             from . import HW_QUEUES

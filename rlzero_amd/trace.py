@@ -115,12 +115,21 @@ def summarise(rec, n_cus=256):
     cover, depth = _coverage(all_trunk, t_lo, t_hi)
     out['trunk_launches_on_chip'] = {'share_of_time_with_0': round(cover[0], 4), 'with_1': round(cover[1], 4), 'with_2': round(cover[2], 4),
                                      'with_3_or_more': round(cover[3], 4), 'mean': round(depth, 3)}
-    # CUs: a trunk workgroup holds its CU's LDS alone, so the share of (CU x time) covered by trunk workgroups is the trunk's occupancy
+    # CUs: the share of (CU x time) with AT LEAST ONE trunk workgroup on the CU (a k_trunk_rows workgroup holds its CU's LDS alone; two
+    # receptive-field workgroups, k_trunk_delta, fit side by side), and the mean number of trunk workgroups on a CU
     wg_busy = float(np.clip(np.minimum(rec['t1'][trunk], t_hi) - np.maximum(rec['t0'][trunk], t_lo), 0, None).sum())
     cus_seen = int(len(set(rec['cu'][trunk].tolist())))
     out['cus_seen'] = cus_seen
-    out['cu_time_in_trunk'] = round(wg_busy / ((t_hi - t_lo) * float(n_cus)), 4)
+    covered = 0.0
+    t0s, t1s, cus = rec['t0'][trunk], rec['t1'][trunk], rec['cu'][trunk]
+    order = np.argsort(cus, kind='stable')
+    bounds = np.flatnonzero(np.diff(cus[order])) + 1
+    for idx in np.split(order, bounds):
+        cover, _ = _coverage(list(zip(t0s[idx].tolist(), t1s[idx].tolist())), t_lo, t_hi)
+        covered += 1.0 - cover[0]
+    out['cu_time_in_trunk'] = round(covered / float(n_cus), 4)
     out['cu_idle_of_trunk'] = round(1.0 - out['cu_time_in_trunk'], 4)
+    out['trunk_workgroups_per_cu'] = round(wg_busy / ((t_hi - t_lo) * float(n_cus)), 4)
     out['trunk_workgroup_us'] = {'mean': round(float((rec['t1'][trunk] - rec['t0'][trunk]).mean()) * TICK_US, 2),
                                  'p10': round(float(np.percentile(rec['t1'][trunk] - rec['t0'][trunk], 10)) * TICK_US, 2),
                                  'p90': round(float(np.percentile(rec['t1'][trunk] - rec['t0'][trunk], 90)) * TICK_US, 2)}

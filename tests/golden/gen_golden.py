@@ -16,6 +16,11 @@ not travel to the GPU box, so its outputs are committed here as data:
                    episode_len, buffer length, the moves of the game, and every number policy_update prints
                    (kl, lr_multiplier, loss, entropy, explained variances); search driven by vlin + injected uniforms
                    (exactly reproducible data), learner = the reference's AlphaZeroAgent.learn on numpy_weights
+  g8_realnet.json.gz whole self-play games of the reference's AlphaZeroPlayer with ITS OWN evaluator -- AlphaZeroAgent.policy_value_fn,
+                   torch on the CPU, numpy_weights -- at 6x6 / 400 playouts (the script's default, tools/train_alphazero.py:21-31) and
+                   9x9 / 200: per ply the root's visit counts, the move, the uniform, and the SMALLEST GAP between the two best
+                   finite UCT scores any selection of that search met (node.py:41-42, 75-88: a device whose leaf values differ
+                   from torch's by 1e-7 may legitimately take the other child only where that gap is tiny)
   g6_rollout.json.gz pure-MCTS opponent (RolloutMCTS / RolloutPlayer) with np.random.rand drawn from a
                    recorded private stream: root statistics, chosen moves, a full duel
 
@@ -359,6 +364,71 @@ def gen_g3():
     return {'selfplay': games, 'duels': duels}
 
 
+# ---------------------------------------------------------------------------- G8
+def realnet_game(B, n, sims, seed, wseed):
+    """One self-play game of the reference's player with its own torch-CPU evaluator; TreeNode.select is watched (not changed)."""
+    from rlzero.mcts.node import TreeNode
+    agent = AlphaZeroAgent(B)
+    load_numpy_weights(agent, B, wseed)
+    inj = InjectedChoice(seed)
+    np.random.choice = inj
+    real_select = TreeNode.select
+    gap = [float('inf'), 0]   # of the search in progress: smallest gap, selections among finite scores
+
+    def watching_select(node, c_puct):
+        best, second = float('-inf'), float('-inf')
+        for child in node._children.values():
+            s_ = child.uct_value(c_puct)
+            if s_ > best:
+                best, second = s_, best
+            elif s_ > second:
+                second = s_
+        if best != float('inf') and second != float('-inf'):
+            gap[0] = min(gap[0], best - second)
+            gap[1] += 1
+        return real_select(node, c_puct)
+
+    TreeNode.select = watching_select
+    try:
+        env = GomokuEnv(board_size=B, n_in_row=n)
+        game = GameControl(env)
+        player = AlphaZeroPlayer(agent.policy_value_fn, n_playout=sims, c_puct=5, is_selfplay=True)
+        per_ply = []
+        real_sim = player.mcts.simulate
+
+        def spy(game_env, temperature=1e-3):
+            gap[0], gap[1] = float('inf'), 0
+            with torch.no_grad():
+                acts, probs = real_sim(game_env, temperature)
+            root = player.mcts._root
+            per_ply.append({'acts': [int(a) for a in acts], 'N': [int(root._children[a].explore_count) for a in acts],
+                            'root_N': int(root.explore_count), 'min_gap': hexf(gap[0]) if gap[0] != float('inf') else None,
+                            'value_selections': gap[1]})
+            return acts, probs
+
+        player.mcts.simulate = spy
+        winner, data = game.start_self_play(player, temperature=1.0)
+        data = list(data)
+    finally:
+        np.random.choice = inj.real
+        TreeNode.select = real_select
+    moves = [int(m) for m in env.states.keys()]
+    assert len(moves) == len(per_ply) == len(inj.used)
+    for rec, u, mv in zip(per_ply, inj.used, moves):
+        rec['u'] = hexf(u)
+        rec['move'] = mv
+    return {'B': B, 'n': n, 'n_playout': sims, 'c_puct': 5, 'T': 1.0, 'weights_seed': wseed, 'winner': int(winner), 'moves': moves, 'plies': per_ply}
+
+
+def gen_g8():
+    np.random.seed(8)   # (the reference's Dirichlet noise draws from the global stream: it never reaches the selection)
+    games = []
+    for B, n, sims, count, wseed in ((6, 4, 400, 8, 301), (9, 5, 200, 8, 302)):
+        for k in range(count):
+            games.append(realnet_game(B, n, sims, 8000 + 100 * B + k, wseed))
+    return {'games': games}
+
+
 # ---------------------------------------------------------------------------- net
 def load_numpy_weights(agent, B, seed):
     w = numpy_weights(B, seed)
@@ -544,6 +614,9 @@ def write_json(name, obj):
 
 
 def main():
+    if sys.argv[1:] == ['g8']:   # (this fixture alone: the others do not depend on it)
+        write_json('g8_realnet.json', gen_g8())
+        return
     np.random.seed(0)
     write_json('g1_rules.json', gen_g1())
     write_json('g2_search.json', gen_g2())
@@ -551,6 +624,7 @@ def main():
     write_json('g2_netleaf.json', gen_netleaf())
     write_json('g6_rollout.json', gen_g6())
     write_json('g7_train.json', gen_g7())
+    write_json('g8_realnet.json', gen_g8())
     np.savez_compressed(os.path.join(HERE, 'g4_net.npz'), **gen_g4())
     np.savez_compressed(os.path.join(HERE, 'g5_equi.npz'), **gen_g5())
     for name in ('g4_net.npz', 'g5_equi.npz'):

@@ -179,6 +179,21 @@ def test_lanes_by_measurement_fallback():
     with pytest.raises(RuntimeError):
         sp_mod.choose_lanes_by_measurement(('other', ), 1, 8, 64, build, timer=failing, cache=cache)
     assert closed == [(1, 0)] and ('other', ) not in cache                              # closed even then, nothing cached
+    # a candidate the device refuses (HipError: e.g. a mode the timer's move step does not serve) is no candidate; when none can be
+    # timed the table's pick stands and nothing is cached as a measurement
+    from rlzero_amd._hip import HipError
+    del closed[:]
+
+    def refusing(sp):
+        if len(sp.lanes) == 2:
+            raise HipError('refused')
+        return rates[len(sp.lanes)]
+    best, seen = sp_mod.choose_lanes_by_measurement(('k', 2), 2, 8, 256, build, timer=refusing, cache=cache)
+    assert best == 3 and sorted(seen) == [1, 3] and sorted(closed) == [(1, 0), (2, 0), (2, 1), (3, 0), (3, 1), (3, 2)]
+
+    def always(sp):
+        raise HipError('refused')
+    assert sp_mod.choose_lanes_by_measurement(('k', 3), 2, 8, 256, build, timer=always, cache=cache) == (2, None) and ('k', 3) not in cache
     assert sp_mod.TABLE_CUS == 256
 
 

@@ -491,6 +491,11 @@ def test_rank_affinity_from_sysfs(tmp_path):
     assert affinity.plan(5, [5], allowed, sysfs, env={})['cpus'] == list(range(64, 128))
     assert affinity.plan(0, [0, 1], list(range(0, 64, 2)), sysfs, env={})['cpus'] == list(range(0, 32, 2))
     assert affinity.plan(0, [0], allowed, sysfs, env={'HIP_VISIBLE_DEVICES': '6,7'})['numa_node'] == 1
+    # CUDA_VISIBLE_DEVICES is HIP_VISIBLE_DEVICES' alias, read only when that one is unset -- never a second filter; ROCR_VISIBLE_DEVICES
+    # (the runtime below) filters first
+    assert affinity.plan(0, [0], allowed, sysfs, env={'HIP_VISIBLE_DEVICES': '6,7', 'CUDA_VISIBLE_DEVICES': '1'})['numa_node'] == 1
+    assert affinity.plan(0, [0], allowed, sysfs, env={'CUDA_VISIBLE_DEVICES': '5'})['numa_node'] == 1
+    assert affinity.plan(1, [1], allowed, sysfs, env={'ROCR_VISIBLE_DEVICES': '2,3,4,5', 'HIP_VISIBLE_DEVICES': '0,3'})['numa_node'] == 1
     assert affinity.plan(9, [9], allowed, sysfs, env={}) is None
     rec = affinity.pin_to_gpu(2, local_world=8, sysfs=sysfs, env={}, apply=False)
     here = sorted(os.sched_getaffinity(0))   # (this host has fewer cores than the fake node: its share of what both have)

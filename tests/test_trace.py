@@ -46,15 +46,17 @@ def test_trace_of_the_four_lane_layout():
     from rlzero_amd.trace import measure
     torch.manual_seed(0)
     net = PolicyValueNet(15).to('cuda:0').eval()
-    out = measure(net, 15, 5, n_games=512, n_playout=160, warm_moves=2)
+    # (512 games are ONE resident lane by default since round 6 -- k_delta_res, two games per CU; the trace reads the lanes of the
+    # two-launch step, the layout of more than 2 x CUs games)
+    out = measure(net, 15, 5, n_games=512, n_playout=160, warm_moves=2, lanes=4, resident_search=False)
     # (the last step of a graph chunk of 16 is backup only -- the next chunk opens with its own selection -- and is not traced: 150 tree steps)
     assert out['lanes_in_layout'] == 4 and out['records'] == 4 * 128 * (160 + 150)
     for ln in '0123':
         lane = out['lanes'][ln]
         assert lane['trunk_launches'] == 160 and lane['workgroups_per_trunk_launch'] == 128.0
-        assert 5.0 < lane['tree_launch_us'] < 60.0 and 15.0 < lane['trunk_launch_us'] < 120.0
+        assert 5.0 < lane['tree_launch_us'] < 60.0 and 10.0 < lane['trunk_launch_us'] < 120.0
     # (searches this short overlap only partly -- every lane's host step is a fifth of its search: the full-size figures are
     # on the bench line -- so the bounds are loose)
     assert 0.3 < out['cu_time_in_trunk'] <= 1.0 and out['launches_in_flight'] > 1.0 and 200 <= out['cus_seen'] <= 256
     assert out['window'] in ('all lanes searching', "union of the lanes' searches")   # (the second when these short searches barely overlap)
-    assert 15.0 < out['trunk_workgroup_us']['mean'] < 40.0 and out['sims_per_sec_in_window'] > 3e6
+    assert 8.0 < out['trunk_workgroup_us']['mean'] < 40.0 and out['sims_per_sec_in_window'] > 3e6

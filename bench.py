@@ -101,7 +101,7 @@ def pmc_traffic(kernel, workload):
     """HBM bytes per launch of ``kernel`` in ``workload`` from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
     WRITE_SIZE runs of that very workload, gfx950 read correction applied: profiles/r05/pmc_traffic.json, collected by
     profiles/collect_r05.sh).  None when no counter run exists for the workload."""
-    for rnd in ('r05', 'r04', 'r03'):   # (a workload without a counter run of this round keeps the last round's)
+    for rnd in ('r06', 'r05', 'r04', 'r03'):   # (a workload without a counter run of this round keeps the last round's)
         try:
             rec = json.load(open(os.path.join(REPO, 'profiles', rnd, 'pmc_traffic.json')))
             return rec[workload]['kernels'][kernel]['traffic_bytes_per_launch']
@@ -114,7 +114,7 @@ def rocprof_dispatch_us(kernel_substring, stats='bench_default_kernel_stats.csv'
     """Average duration (us) and calls of the first kernel whose name contains ``kernel_substring`` in the committed rocprofv3
     --kernel-trace --stats summary of the default command (profiles/rNN/<stats>, newest round first) -> (us, calls, path) or None."""
     import csv
-    for rnd in ('r05', 'r04'):
+    for rnd in ('r06', 'r05', 'r04'):
         path = os.path.join(REPO, 'profiles', rnd, stats)
         try:
             for row in csv.DictReader(open(path)):
@@ -123,6 +123,84 @@ def rocprof_dispatch_us(kernel_substring, stats='bench_default_kernel_stats.csv'
         except (OSError, KeyError, ValueError):
             continue
     return None
+
+
+# --------------------------------------------------------------------------- power / clock while the timed regions run
+class PowerSampler(object):
+    """Board power while the timed regions run: the hwmon file of the GPU (sysfs; microwatts), read by a thread every 50 ms -- no child
+    process, no tool.  ``mean()`` -> watts over the samples taken between start() and stop(), or None where the file does not exist."""
+
+    def __init__(self):
+        import glob
+        self.paths = sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*/power1_average') +
+                            glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*/power1_input'))
+        self.samples, self._on, self._thread = [], False, None
+
+    def _read(self):
+        best = None
+        for p in self.paths:   # (one GPU is visible on the box; with several cards: the busiest)
+            try:
+                w = int(open(p).read().strip()) / 1e6
+            except (OSError, ValueError):
+                continue
+            best = w if best is None or w > best else best
+        return best
+
+    def start(self):
+        import threading
+        if not self.paths or self._thread is not None:
+            return
+        self._on = True
+
+        def loop():
+            while self._on:
+                w = self._read()
+                if w is not None:
+                    self.samples.append(w)
+                time.sleep(0.05)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        self._on = False
+        if self._thread is not None:
+            self._thread.join(timeout=1.0)
+            self._thread = None
+
+    def mean(self):
+        return round(sum(self.samples) / len(self.samples), 1) if self.samples else None
+
+
+def time_resident_launches(sp, torch, n_moves=4):
+    """Lone launches of the resident search (k_delta_res: one per move, every simulation of every game of the lane) between HIP
+    events on the lane's own stream, each followed by the move step so that the next one searches new roots -> dict(search_ms,
+    bases_ms, launches, stats) or None.  Behind the timed regions: the games it advances are played for nothing else."""
+    lane = sp.lanes[0]
+    eng, ev = lane.eng, getattr(lane.evaluator, 'inner', lane.evaluator)
+    hip = ev.hip
+    if getattr(eng, 'play_log', None) is None or not ev.resident_delta_ok(eng):
+        return None
+    sp.device_drain()
+    pairs = []
+    with sp._on(lane):
+        torch.cuda.synchronize()
+        hip.delta_stats(reset=True)
+        for _ in range(n_moves):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            eng.flush_deferred()
+            e[0].record()
+            hip.delta_bases_engine(eng)                    # the bases alone (the search's own call builds them again: subtracted below)
+            e[1].record()
+            eng.sim_chunk(lane.evaluator, eng.n_playout)   # rz_net_search_resident: bases + ONE k_delta_res launch
+            e[2].record()
+            lane.uncopied.append(eng.play_move())
+            pairs.append(e)
+        torch.cuda.synchronize()
+    stats = hip.delta_stats()
+    sp.device_drain()
+    bases = sum(a.elapsed_time(b) for a, b, _ in pairs) / len(pairs)
+    both = sum(b.elapsed_time(c) for _, b, c in pairs) / len(pairs)
+    return {'search_ms': both - bases, 'bases_ms': bases, 'launches': len(pairs), 'stats': stats}
 
 
 # --------------------------------------------------------------------------- CPU baseline
@@ -860,14 +938,17 @@ def main():
         gc.freeze()
     # --regions timed regions of K steps each, every one bracketed by barrier + synchronize; the MEDIAN region is reported
     regions = []
+    power = PowerSampler()
     for _ in range(max(1, args.regions)):
         fence()   # (device-driven moves: also reads the rows of the moves before the region -- counted before it, not in it)
         sims0, fin0 = sp.sims_done, finished[0]
+        power.start()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             one_step()
         fence()
         dt = time.perf_counter() - t0
+        power.stop()
         if use_dist:
             # every rank's own (seconds, simulations, games finished) of the region, on every rank: the line reports MAX time /
             # SUM work (the contract) AND each rank's own rate, so a throttling or straggling GPU shows
@@ -880,6 +961,15 @@ def main():
         else:
             regions.append((dt, float(sp.sims_done - sims0), float(finished[0] - fin0), [float(sp.sims_done - sims0) / dt]))
     elapsed, total_sims, total_finished, per_rank_rates = sorted(regions, key=lambda r: r[1] / r[0])[len(regions) // 2]
+    # the resident search's kernel by itself: lone launches between HIP events on its own stream, behind the timed regions
+    resident_timing = None
+    if rank == 0 and resident_route and device_moves and len(sp.lanes) == 1:
+        sims_keep, fin_keep = sp.sims_done, finished[0]
+        try:
+            resident_timing = time_resident_launches(sp, torch)
+        except Exception as exc:  # noqa: BLE001  (a diagnostic cannot take the line with it)
+            resident_timing = {'error': '%s: %s' % (type(exc).__name__, str(exc)[:200])}
+        sp.sims_done, finished[0] = sims_keep, fin_keep
     # Kernel-level timing samples, right AFTER the timed region on the same games: every k-th graph chunk is launched
     # kernel by kernel with HIP events around the trunk, the FC GEMM and the tree step.  Not inside the timed region:
     # there the eager chunks cost 0 % (default, 80-us trunks) to 50 % (Connect4, 15-us trunks) -- the host cannot keep two
@@ -1134,6 +1224,50 @@ def main():
                                 'achieved': round(achieved, 3), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                                 'traffic': None, 'avg_launch_ms': round(step_ms * args.playouts, 4), 'ms_per_simulation_step': round(step_ms, 5),
                                 'launches_per_search': 2, 'trunk_workgroups': G}
+            if resident_timing and 'search_ms' in resident_timing:
+                # k_delta_res: ONE launch = every simulation of every game of a move.  `achieved` prices the launch the contract's way:
+                # the ALGORITHMIC flops of its G x n_playout forward passes (PolicyValueNet.forward on a whole board each: what the
+                # reference computes per leaf) / the launch's own duration (HIP events on its stream, lone launches behind the timed
+                # regions; the committed rocprofv3 summary of the same command beside it).  The kernel EXECUTES fewer products than that --
+                # it recomputes only the windows around the stones a leaf adds to its root (csrc/rz_delta.h) -- and `executed` says
+                # how many and at what share of the f16 pipe; tree code, value head and the base of every root are inside the launch.
+                rt, st = resident_timing, resident_timing['stats']
+                launches = rt['launches']
+                leaves = max(1, st['delta'] + st['no_base'])
+                alg = trunk_flops_per_position(cells) * G * args.playouts
+                ach = alg / (rt['search_ms'] * 1e-3) / 1e12
+                mfma_flops = (st['tiles3'] * 16 * 128 * 576 + st['tiles2'] * 16 * 64 * 288) * 2.0 * SPLIT_MFMAS_PER_PRODUCT / launches
+                prof = rocprof_dispatch_us('k_delta_res')
+                pmc_key = line['config']['workload']
+                rf = {'bound': 'mfma',
+                      'kernel': 'k_delta_res (resident search with the receptive-field trunk: trunk windows + value head + tree step of a game in one '
+                                'workgroup, two games per CU), %d games x %d simulations per launch' % (G, args.playouts),
+                      'achieved': round(ach, 3), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                      'traffic': pmc_traffic('k_delta_res', pmc_key),
+                      'avg_launch_ms': round(rt['search_ms'], 4), 'launches_timed': launches, 'bases_launch_ms': round(rt['bases_ms'], 4),
+                      'algorithmic_flops_per_launch': alg,
+                      'executed': {'f16_mfma_tflops': round(mfma_flops / (rt['search_ms'] * 1e-3) / 1e12, 2),
+                                   'frac_of_f16_mfma_peak': round(mfma_flops / (rt['search_ms'] * 1e-3) / 1e12 / pipe_peak, 4),
+                                   'share_of_the_algorithmic_products': round(mfma_flops / SPLIT_MFMAS_PER_PRODUCT / alg, 4),
+                                   'conv3_tiles_per_leaf': round(st['tiles3'] / leaves, 3), 'conv2_tiles_per_leaf': round(st['tiles2'] / leaves, 3),
+                                   'changed_cells_per_leaf': round(st['cells'] / leaves, 3),
+                                   'leaves_against_a_base': st['delta'], 'leaves_without_a_base': st['no_base']},
+                      'wall_clock': {'ms_per_simulation_step': round(step_ms, 5), 'achieved': round(achieved, 3), 'frac': round(achieved / peak, 4),
+                                     'note': 'the timed region / simulation steps in it: move steps, base builds, policy GEMM and host time charged to the search'},
+                      'launches_per_search': 1, 'trunk_workgroups': G, 'workgroups_per_cu': 2}
+                if prof:
+                    rf['rocprof_avg_ms'] = round(prof[0] / 1e3, 4)
+                    rf['rocprof_calls'], rf['rocprof_stats'] = prof[1], prof[2]
+                    rf['rocprof_frac'] = round(alg / (prof[0] * 1e-6) / 1e12 / peak, 4)
+                ghz = st.get('resident_sclk_ghz')
+                if ghz:
+                    rf['sclk_in_loop_ghz'] = round(ghz, 3)   # (shader cycles / constant-clock ticks of workgroup 0 of the last timed launch)
+                    rf['value_at_2p0ghz'] = round(value * 2.0 / ghz, 1)
+                    rf['us_per_simulation_of_a_game'] = round(rt['search_ms'] * 1e3 / args.playouts, 3)
+                rf['board_power_w'] = power.mean()
+                line['roofline'] = rf
+            elif resident_timing:
+                line['roofline']['resident_timing_error'] = resident_timing.get('error')
         else:
             per_sim = tree_bytes_per_sim(365.5, 208.8, 1.74) if board == 15 else None
             if per_sim:

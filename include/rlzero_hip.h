@@ -545,8 +545,10 @@ int rz_net_delta_leaves(rz_net *net, const uint64_t *d_stones, const int32_t *d_
  * step on its leaves (board b = game b, store slot pend[b], inactive games skipped).  One simulation in flight per tree. */
 int rz_net_delta_bases_engine(rz_net *net, rz_engine *engine, void *stream);
 int rz_net_delta_step(rz_net *net, rz_engine *engine, rz_value_head *out, void *stream);
-/* counters since the last reset: {leaves evaluated against a base, leaves without one, conv3 tiles of 16 cells, changed cells} (synchronises) */
-int rz_net_delta_stats(rz_net *net, uint32_t *h_out4, int32_t reset);
+/* counters since the last reset (synchronises): {leaves evaluated against a base, leaves without one, conv3 tiles of 16 cells, changed
+ * cells, conv2 tiles of 16 cells, 0, and -- of workgroup 0 of the LAST resident launch -- its shader-clock cycles >> 8 and its ticks
+ * of the constant 100 MHz clock: the clock the search ran at = 256 [6] / (10 ns [7])} */
+int rz_net_delta_stats(rz_net *net, uint32_t *h_out8, int32_t reset);
 /* RESIDENT SEARCH -- n_sims consecutive simulations of every active game of `engine` (AlphaZeroMCTS.simulate's loop,
  * alphazero_mcts.py:82-85) in ONE launch, one workgroup per game: trunk -> value head -> expand / backup -> next selection without
  * a kernel boundary, the leaf handed from the tree code to the trunk through LDS.  For batches of at most one game per CU (the

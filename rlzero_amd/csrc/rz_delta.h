@@ -63,7 +63,8 @@ struct DeltaArgs {
                              // head features [6][kCells] f32 (behind their ReLU)
     const uint8_t *active;   // mode 0: games whose flag is 0 are skipped (NULL: none is)
     float *feat32;           // the features as f32 [board][6 S] (tests; NULL otherwise)
-    unsigned *stats;         // [4] counters (NULL: none): delta leaves, leaves without a base, conv3 tiles, changed cells
+    unsigned *stats;         // [8] counters (NULL: none): delta leaves, leaves without a base, conv3 tiles, changed cells, conv2 tiles, -, and of
+                             // workgroup 0 of the LAST resident launch: shader-clock cycles >> 8, ticks of the constant 100 MHz clock
     int mode;                // 0: the leaves of `leaves` against the cache; 1: build the cache from the ROOT positions in `leaves`
                              // (board = 2 game + parity); 2: the leaves without a base (the four-pass route alone: a checker)
     int bw_rcp;              // ceil(65536 / width): cell / width = (cell * bw_rcp) >> 16 for cell < 4096
@@ -312,7 +313,7 @@ struct Prof { long long acc[24], t; };
 struct Prof {};
 #endif
 
-// The passes of one leaf: -1 = against the base (use_delta), 0 .. 3 = the board's quadrants without one.  -> conv3 tiles computed.
+// The passes of one leaf: -1 = against the base (use_delta), 0 .. 3 = the board's quadrants without one.  -> tiles computed: conv3 | conv2 << 16.
 __device__ __forceinline__ int delta_passes(const NetDev &nd, const DeltaArgs &da, char *lds, int tid0, int wave, const Leaf &leaf, const Layers &ly,
                                             f32x4 headv, bool &use_delta, Prof &prof) {
     char *in0 = lds, *c1 = lds + kOffC1, *c2 = lds + kOffC2, *zrec = lds + kOffZero, *headw = lds + kOffHead;
@@ -330,7 +331,7 @@ __device__ __forceinline__ int delta_passes(const NetDev &nd, const DeltaArgs &d
     float *vdst = leaf.vdst, *dst32 = leaf.dst32;
     const bool deferred = leaf.deferred, store_head = leaf.store_head;
     const uint32_t zaddr = lds_addr(zrec);
-    int n_conv3_tiles = 0;
+    int n_conv3_tiles = 0, n_conv2_tiles = 0;
 #ifdef RZ_NET_PROFILE
     long long (&prof_acc)[24] = prof.acc, &prof_t = prof.t;
 #endif
@@ -509,6 +510,7 @@ __device__ __forceinline__ int delta_passes(const NetDev &nd, const DeltaArgs &d
         {
             const lds_u32 m1 = (lds_u32)map1, m2 = (lds_u32)map2;
             const int nt2 = (tot[1] + 15) >> 4;
+            n_conv2_tiles += nt2;
             for (int t0 = 0; t0 < nt2; t0 += 4) {   // groups of up to four tiles (the weights are in registers: a group costs no fetch)
                 const uint16_t *l2 = list2 + 16 * t0;
                 const int left = tot[1] - 16 * t0;
@@ -586,7 +588,7 @@ __device__ __forceinline__ int delta_passes(const NetDev &nd, const DeltaArgs &d
         if (pass < 0) break;
         __syncthreads();   // the next pass rewrites maps, lists and records
     }
-    return n_conv3_tiles;
+    return n_conv3_tiles | (n_conv2_tiles << 16);
 }
 
 // the four planes of thread `tid`'s cell (load_bits of trunk_rows_body; a base: no last move, the parity's stone count)
@@ -732,7 +734,8 @@ __global__ __launch_bounds__(256, 2) void k_trunk_delta(NetDev nd, LeafBits leav
     if (mode == 0 && is_active == 0) return;   // (uniform; before any barrier; behind the stores above so that the flag's load is
                                                // one of the batch, not a round trip of its own at the top)
     NET_TICK(0);   // requests, scalars, header, planes, zeroing
-    const int n_conv3_tiles = delta_passes(nd, da, lds, tid0, wave, leaf, ly, headv, use_delta, prof);
+    const int n_tiles = delta_passes(nd, da, lds, tid0, wave, leaf, ly, headv, use_delta, prof);
+    const int n_conv3_tiles = n_tiles & 0xffff;
 
     if (mode == 1 && par_b == 0 && tid0 == 0) {   // the header of this game's bases (the launch behind this one reads it)
         BaseHdr *h = da.hdr + game;
@@ -745,6 +748,7 @@ __global__ __launch_bounds__(256, 2) void k_trunk_delta(NetDev nd, LeafBits leav
         atomicAdd(da.stats + (use_delta ? 0 : 1), 1u);
         atomicAdd(da.stats + 2, (unsigned)n_conv3_tiles);
         atomicAdd(da.stats + 3, (unsigned)nD);
+        atomicAdd(da.stats + 4, (unsigned)(n_tiles >> 16));
     }
 #ifdef RZ_NET_PROFILE
     if (blockIdx.x == 0 && tid0 == 0) {
@@ -771,6 +775,7 @@ __global__ __launch_bounds__(256, 2) void k_delta_res(NetDev nd, _Float16 *__res
     __shared__ __attribute__((aligned(16))) uint64_t res_leaf[2 * RZ_BOARD_WORDS + 2];
     const int game = blockIdx.x;
     if (game >= res.E.n_games || res.E.active[game] == 0) return;   // (uniform: before any barrier)
+    const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
     const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
     const int BW = nd.BW, S = nd.S;
     Prof prof;
@@ -820,7 +825,7 @@ __global__ __launch_bounds__(256, 2) void k_delta_res(NetDev nd, _Float16 *__res
         if (wave == 0) rzt::select_body<false>(res.E, nullptr, game, tid0 & 63, 0, res_leaf);
         __syncthreads();
     }
-    int tiles_total = 0, deltas = 0, cells_total = 0;
+    int tiles_total = 0, tiles2_total = 0, deltas = 0, cells_total = 0;
     for (int sim = 0; sim < res.n_sims; ++sim) {
         // (the thread's number is opaque per simulation: hipcc otherwise hoists the tree code's lane-dependent addresses out of this
         // loop and spills them)
@@ -850,7 +855,9 @@ __global__ __launch_bounds__(256, 2) void k_delta_res(NetDev nd, _Float16 *__res
         leaf.deferred = true;
         leaf.store_head = sim == 0;
         NET_TICK(0);
-        tiles_total += delta_passes(nd, da, lds, tid_s, wave, leaf, ly, headv, use_delta, prof);
+        const int n_tiles = delta_passes(nd, da, lds, tid_s, wave, leaf, ly, headv, use_delta, prof);
+        tiles_total += n_tiles & 0xffff;
+        tiles2_total += n_tiles >> 16;
         deltas += use_delta ? 1 : 0;
         cells_total += nD;
         __syncthreads();   // the value head's inputs are complete; the shares are read
@@ -874,6 +881,11 @@ __global__ __launch_bounds__(256, 2) void k_delta_res(NetDev nd, _Float16 *__res
         atomicAdd(da.stats + 1, (unsigned)(res.n_sims - deltas));
         atomicAdd(da.stats + 2, (unsigned)tiles_total);
         atomicAdd(da.stats + 3, (unsigned)cells_total);
+        atomicAdd(da.stats + 4, (unsigned)tiles2_total);
+        if (game == 0) {   // the clock this search ran at: cycles / (ticks x 10 ns)
+            da.stats[6] = (unsigned)((__builtin_readcyclecounter() - clk0) >> 8);
+            da.stats[7] = (unsigned)(__builtin_amdgcn_s_memrealtime() - rt0);
+        }
     }
 #ifdef RZ_NET_PROFILE
     if (blockIdx.x == 0 && tid0 == 0) {

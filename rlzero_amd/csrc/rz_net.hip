@@ -3513,10 +3513,10 @@ int rz_net_delta_reserve(rz_net *net, int32_t n_games) {
         hipMalloc((void **)&net->d_base_ones, (size_t)n_games) != hipSuccess)
         return net_fail(RZ_ERR_OOM, "hipMalloc failed (base cache)");
     if (hipMemset(net->d_base_ones, 1, (size_t)n_games) != hipSuccess) return net_fail(RZ_ERR_HIP, "hipMemset failed (base cache)");
-    if (!net->d_delta_stats && hipMalloc((void **)&net->d_delta_stats, 4 * sizeof(unsigned)) != hipSuccess)
+    if (!net->d_delta_stats && hipMalloc((void **)&net->d_delta_stats, 8 * sizeof(unsigned)) != hipSuccess)
         return net_fail(RZ_ERR_OOM, "hipMalloc failed (delta counters)");
     // valid = 0: a leaf of a game without bases takes the four passes without a base
-    if (hipMemset(net->d_base_hdr, 0, hdr_bytes) != hipSuccess || hipMemset(net->d_delta_stats, 0, 4 * sizeof(unsigned)) != hipSuccess)
+    if (hipMemset(net->d_base_hdr, 0, hdr_bytes) != hipSuccess || hipMemset(net->d_delta_stats, 0, 8 * sizeof(unsigned)) != hipSuccess)
         return net_fail(RZ_ERR_HIP, "hipMemset failed (base cache)");
     net->base_games = n_games;
     return RZ_OK;
@@ -3609,13 +3609,13 @@ int rz_net_delta_step(rz_net *net, rz_engine *engine, rz_value_head *out, void *
     return rz_net_delta_leaves(net, dev.leaf_stones, dev.leaf_to_move, dev.leaf_last, dev.n_games, dev.pend, dev.active, nullptr, 0, out, stream);
 }
 
-int rz_net_delta_stats(rz_net *net, uint32_t *h_out4, int32_t reset) {
-    if (!net || !h_out4) return net_fail(RZ_ERR_ARG, "NULL argument");
-    memset(h_out4, 0, 4 * sizeof(uint32_t));
+int rz_net_delta_stats(rz_net *net, uint32_t *h_out8, int32_t reset) {
+    if (!net || !h_out8) return net_fail(RZ_ERR_ARG, "NULL argument");
+    memset(h_out8, 0, 8 * sizeof(uint32_t));
     if (!net->d_delta_stats) return RZ_OK;
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h_out4, net->d_delta_stats, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h_out8, net->d_delta_stats, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
         return net_fail(RZ_ERR_HIP, "hipMemcpy failed (delta counters)");
-    if (reset && hipMemset(net->d_delta_stats, 0, 4 * sizeof(uint32_t)) != hipSuccess) return net_fail(RZ_ERR_HIP, "hipMemset failed (delta counters)");
+    if (reset && hipMemset(net->d_delta_stats, 0, 8 * sizeof(uint32_t)) != hipSuccess) return net_fail(RZ_ERR_HIP, "hipMemset failed (delta counters)");
     return RZ_OK;
 }
 

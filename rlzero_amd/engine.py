@@ -211,10 +211,13 @@ class HipNet(object):
         return out
 
     def delta_stats(self, reset=False):
-        """{'delta': leaves evaluated against a base, 'no_base': leaves that took the four passes, 'tiles3': conv3 tiles, 'cells': changed cells}"""
-        out = (ctypes.c_uint32 * 4)()
+        """{'delta': leaves evaluated against a base, 'no_base': leaves that took the four passes, 'tiles3' / 'tiles2': conv3 / conv2 tiles of
+        16 cells, 'cells': changed cells, 'resident_sclk_ghz': the shader clock the last resident search ran at}"""
+        out = (ctypes.c_uint32 * 8)()
         check(self.lib.rz_net_delta_stats(self.handle, out, 1 if reset else 0), 'rz_net_delta_stats')
-        return {'delta': int(out[0]), 'no_base': int(out[1]), 'tiles3': int(out[2]), 'cells': int(out[3])}
+        ghz = (256.0 * out[6]) / (10.0 * out[7]) if out[7] else None   # (cycles per nanosecond of the last resident launch's workgroup 0)
+        return {'delta': int(out[0]), 'no_base': int(out[1]), 'tiles3': int(out[2]), 'cells': int(out[3]), 'tiles2': int(out[4]),
+                'resident_sclk_ghz': ghz}
 
     def supports_resident(self):
         """True when whole searches can run as ONE launch, one workgroup per game (rz_net_search_resident)."""

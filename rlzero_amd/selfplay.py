@@ -369,7 +369,7 @@ class BatchedSelfPlay(object):
     def for_network(cls, net_module, board, n_in_row, n_games, n_playout, c_puct=5.0, device='cuda:0',
                     game='gomoku', net_shape=None, lanes=None, trunk_workgroups=None, temperature=1.0, seed=0,
                     use_graph=True, sims_per_graph=16, eager_every=0, add_noise=True, sims_in_flight=1, before_warm=None,
-                    deferred_priors=None, resident_search=None, net_algo=None, **engine_kw):
+                    deferred_priors=None, resident_search=None, net_algo=None, delta_trunk=None, **engine_kw):
         """Self-play of ``n_games`` games in flight with the hand-written evaluator of ``net_module`` (a
         PolicyValueNet): builds the lanes (engine + HipNetEvaluator each) as plan_lanes() recommends, unless
         ``lanes`` / ``trunk_workgroups`` are given (more than four lanes take turns on the GPU's four compute pipes, and four need
@@ -384,7 +384,8 @@ class BatchedSelfPlay(object):
         the one-launch-per-search kernel of batches that give every game a CU (False = the two-launch step).  ``before_warm(sp)``: called
         before the hipGraphs are captured (rlzero_amd.trace attaches its buffer there).  ``net_algo``: HipNet.set_algo for every lane's
         evaluator -- None keeps the default ('split_f16', the f32-accurate trunk); 'split_f16_fp8' is the OPT-IN arithmetic narrower than
-        the reference's f32 (boards of 11 .. 16 rows and columns)."""
+        the reference's f32 (boards of 11 .. 16 rows and columns).  ``delta_trunk``: False = the full-board trunk on every leaf (the
+        checker of the receptive-field evaluation, HipNetEvaluator.delta_trunk; with it goes the resident search's second game per CU)."""
         import torch
         from .engine import HipNetEvaluator, MCTSEngine
         dev = torch.device(device)
@@ -398,7 +399,7 @@ class BatchedSelfPlay(object):
         small_trunk = (K == 1 and deferred_priors is not False and engine_kw.get('score_mode', 'uct_ref') in ('uct_ref', 0)
                        and net_algo in (None, 'split_f16', 'split_f16_tiles'))   # (the two-launch step on a small board)
         import os
-        delta_res = (deferred and resident_search is not False and net_algo in (None, 'split_f16')
+        delta_res = (deferred and resident_search is not False and delta_trunk is not False and net_algo in (None, 'split_f16')
                      and os.environ.get('RZ_NET_DELTA', '1') != '0' and os.environ.get('RZ_NET_DELTA_RESIDENT', '1') != '0')
         auto_lanes, auto_wgs, heads_algo = plan_lanes(n_games * K, n_cus, deferred=deferred,
                                                       cells=rows0 * cols0 if (small_trunk or K > 1) else None, in_flight=K,
@@ -419,7 +420,7 @@ class BatchedSelfPlay(object):
                                        net_shape=net_shape, lanes=n_lanes, trunk_workgroups=trunk_workgroups, temperature=temperature,
                                        seed=seed, use_graph=use_graph, sims_per_graph=sims_per_graph, add_noise=add_noise,
                                        sims_in_flight=sims_in_flight, deferred_priors=deferred_priors, resident_search=resident_search,
-                                       net_algo=net_algo, **engine_kw)
+                                       net_algo=net_algo, delta_trunk=delta_trunk, **engine_kw)
             lanes, measured = choose_lanes_by_measurement(key, auto_lanes, HW_QUEUES, n_games, build)
         if lanes is None:
             lanes, wgs = auto_lanes, auto_wgs
@@ -449,6 +450,8 @@ class BatchedSelfPlay(object):
                 ev.deferred_priors = bool(deferred_priors)
             if resident_search is not None:
                 ev.resident_search = bool(resident_search)
+            if delta_trunk is not None:
+                ev.delta_trunk = bool(delta_trunk)
             evaluators.append(ev)
         sp = cls(engines if lanes > 1 else engines[0], evaluators if lanes > 1 else evaluators[0],
                  temperature=temperature, seed=seed, use_graph=use_graph, sims_per_graph=sims_per_graph,

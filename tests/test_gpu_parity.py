@@ -352,15 +352,16 @@ def test_full_size_batches_of_the_baseline_configs(config):
         lane.eng.close()
 
 
-@pytest.mark.parametrize('n_games,score_mode', [(512, 'uct_ref'), (1536, 'uct_ref'), (512, 'puct'), (256, 'uct_ref')])
-def test_full_size_shipped_layout_equals_one_plain_lane(n_games, score_mode):
-    """The layout bench.py times -- co-resident lanes (four at 512 games, each on a hardware queue of its own; two at 1536) with
-    un-capped trunks, the LDS-free 'parts' FC GEMM, hipGraphs of 16
-    simulation steps, the host side of a lane's move pipelined under the other lanes' simulations -- at FULL size (15x15,
-    800 simulations per move; 512 games = BASELINE.json configs[3]'s share of a GPU, 1536 = the batch that fills one)
-    against ONE lane launched kernel by kernel with every move finished on the host before the next search: the layout is
-    scheduling only, so every game's moves and pi are the same bits; no subtree dropped, no flag, pi from exact counts.  Also under
-    the opt-in PUCT rule (the `C4_puct_rule` leg of the bench line), whose tree step scans and initialises every child."""
+@pytest.mark.parametrize('n_games,score_mode,forced_lanes', [(512, 'uct_ref', 0), (512, 'uct_ref', 4), (1536, 'uct_ref', 0), (512, 'puct', 0), (256, 'uct_ref', 0)])
+def test_full_size_shipped_layout_equals_one_plain_lane(n_games, score_mode, forced_lanes):
+    """The layouts bench.py times at FULL size (15x15, 800 simulations per move) -- 512 games (BASELINE.json configs[3]'s share of a GPU)
+    and 256: ONE lane of the resident search with the receptive-field trunk, two games per CU, one launch per search (k_delta_res);
+    1536 games (the batch that fills a GPU): two lanes of the two-launch step with that trunk (k_trunk_delta), hipGraphs of 16 steps;
+    512 games on FOUR such lanes (forced: the shipped layout of round 5); the opt-in PUCT rule: four lanes of the three-launch step
+    with the full-board trunk -- the host side of a lane's move pipelined under the other lanes' simulations -- against ONE lane
+    launched kernel by kernel with the FULL-BOARD trunk on every leaf (k_trunk_rows) and every move finished on the host before
+    the next search: layout and receptive-field evaluation change no bit, so every game's moves and pi are the same; no subtree
+    dropped, no flag, pi from exact counts."""
     import torch
     from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
     from rlzero_amd.selfplay import BatchedSelfPlay
@@ -371,18 +372,20 @@ def test_full_size_shipped_layout_equals_one_plain_lane(n_games, score_mode):
     def play(shipped):
         # (256 games: the shipped layout is the RESIDENT search on two lanes -- one launch per search, a workgroup per game --; the
         # plain lane then runs the two-launch step kernel by kernel)
-        kw = {} if shipped else dict(lanes=1, use_graph=False, resident_search=False)
+        kw = (dict(lanes=forced_lanes, resident_search=False) if forced_lanes else {}) if shipped else dict(lanes=1, use_graph=False, resident_search=False, delta_trunk=False)
         sp = BatchedSelfPlay.for_network(net, 15, 5, n_games=n_games, n_playout=sims, seed=5, score_mode=score_mode, **kw)
         if shipped:
             import rlzero_amd
             assert rlzero_amd.HW_QUEUES >= 8   # (claimed on import, before this process touched the GPU)
-            assert len(sp.lanes) == (4 if n_games == 512 else 2) and sp.trunk_workgroups == 0 and sp.use_graph
+            one_resident_lane = score_mode == 'uct_ref' and n_games <= 512 and not forced_lanes
+            assert len(sp.lanes) == (forced_lanes or (1 if one_resident_lane else 4 if n_games == 512 else 2)) and sp.trunk_workgroups == 0 and sp.use_graph
             resident = [lane.evaluator.resident_ok(lane.eng) for lane in sp.lanes]
-            assert resident == [n_games == 256] * len(sp.lanes)
-            if n_games != 256:
+            assert resident == [one_resident_lane] * len(sp.lanes)
+            assert all(lane.evaluator.delta_ok(lane.eng) for lane in sp.lanes)
+            if not one_resident_lane:
                 assert all(lane.evaluator.hip.heads_algo == 'parts' for lane in sp.lanes)
         else:
-            assert not sp.lanes[0].evaluator.resident_ok(sp.lanes[0].eng)
+            assert not sp.lanes[0].evaluator.resident_ok(sp.lanes[0].eng) and not sp.lanes[0].evaluator.delta_ok(sp.lanes[0].eng)
         sp._start(range(n_games), range(n_games))
         sp._set_active()
         for _ in range(plies):
@@ -412,10 +415,10 @@ def test_full_size_shipped_layout_equals_one_plain_lane(n_games, score_mode):
 
 def test_whole_games_on_the_shipped_layout_equal_one_plain_lane():
     """WHOLE games at full size on the layout bench.py times: `BatchedSelfPlay.run(range(640), pipelined=True)` and
-    `run_device(range(640))` (the move step on the device: what bench.py runs by default) -- four
-    co-resident lanes of 128 games, hipGraphs, pipelined moves, finished slots refilled with the ids 512 .. 639 -- at 15x15 / 800
-    simulations per move, every game played to its END (the reference's loop: game.py:96-134), against ONE plain lane launched
-    kernel by kernel on a sample of 64 of the same ids (first-generation games and refilled ones): moves, pi bits and winners
+    `run_device(range(640))` (the move step on the device: what bench.py runs by default) -- one lane of 512 games on the resident
+    search with the receptive-field trunk (two games per CU, a whole move one hipGraph), finished slots refilled with the ids
+    512 .. 639 -- at 15x15 / 800 simulations per move, every game played to its END (the reference's loop: game.py:96-134), against ONE
+    plain lane launched kernel by kernel with the full-board trunk on a sample of 64 of the same ids (first-generation games and refilled ones): moves, pi bits and winners
     equal.  update_with_move keeps its subtree at every ply of every game (alphazero_mcts.py:96-103: the reference's tree is
     unbounded; here reuse_dropped counts a subtree over the carry limit and must stay 0) and no arena fills up."""
     import torch
@@ -429,10 +432,11 @@ def test_whole_games_on_the_shipped_layout_equal_one_plain_lane():
     assert len(sample) == 64
 
     def play(shipped, device_moves=False):
-        kw = {} if shipped else dict(lanes=1, use_graph=False)
+        kw = {} if shipped else dict(lanes=1, use_graph=False, resident_search=False, delta_trunk=False)
         sp = BatchedSelfPlay.for_network(net, 15, 5, n_games=512 if shipped else len(sample), n_playout=sims, seed=5, **kw)
         if shipped:
-            assert len(sp.lanes) == 4 and sp.trunk_workgroups == 0 and sp.use_graph
+            assert len(sp.lanes) == 1 and sp.trunk_workgroups == 0 and sp.use_graph
+            assert sp.lanes[0].evaluator.resident_ok(sp.lanes[0].eng) and sp.lanes[0].evaluator.resident_delta_ok(sp.lanes[0].eng)
         if device_moves:   # the move step on the device, as bench.py times it: the host reads the games from the log
             out = sp.run_device(range(n_ids))
             assert sp.stalls_resolved == 0 and sp.sims_done == sims * sum(len(t.moves) for t in out)

@@ -134,6 +134,11 @@ def test_plan_lanes():
     assert plan_lanes(512, hw_queues=8, cells=81, in_flight=16)[0] == 3 and plan_lanes(1024, hw_queues=8, cells=81, in_flight=16)[0] == 4
     assert plan_lanes(1024, hw_queues=4, cells=81, in_flight=16)[0] == 3 and plan_lanes(256, hw_queues=8, cells=81, in_flight=16)[0] == 1
     assert plan_lanes(2048, hw_queues=8, cells=225, in_flight=16)[0] == 2   # (15x15 keeps the table)
+    # the receptive-field trunk: the resident search holds two games per CU -- up to 2 x CUs games are one lane, whatever the queues
+    r = lambda n, q=8: plan_lanes(n, hw_queues=q, deferred=True, resident_per_cu=2)   # noqa: E731
+    assert r(512) == (1, 0, 'auto') and r(512, 4) == (1, 0, 'auto') and r(256) == (1, 0, 'auto') and r(1) == (1, 0, 'auto')
+    assert r(513)[0] == 4 and r(1536)[0] == 2 and plan_lanes(512, hw_queues=8, resident_per_cu=2)[0] == 4   # (beyond, and off the deferred route: the table)
+    assert plan_lanes(128, n_cus=64, hw_queues=8, deferred=True, resident_per_cu=2)[0] == 1
 
 
 def test_lanes_by_measurement_fallback():

@@ -75,7 +75,7 @@ def main(out):
         except (OSError, ValueError, IndexError):
             continue
         workload = line['config']['workload']
-        workload += {'puct': '+puct', 'c2k16': '+k16', '3launch': '+3launch', 'fp8': '+fp8'}.get(tag, '')   # same geometry, another rule / mode: its own entry
+        workload += {'puct': '+puct', 'c2k16': '+k16', '3launch': '+3launch', 'fp8': '+fp8', 'lanes4': '+lanes4'}.get(tag, '')   # same geometry, another rule / mode: its own entry
         rec = {'tag': tag, 'kernels': {}}
         per = {}
         for counter in ('FETCH_SIZE', 'WRITE_SIZE'):

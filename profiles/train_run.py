@@ -26,15 +26,32 @@ pipe.run()
 dt = time.perf_counter() - t0
 print('-- 6 batches (6 games, 6 updates, 1 evaluation of 10 games vs RolloutPlayer) in %.1f s' % dt)
 
-print('== batched collection: 256 games in flight per round (15x15, 5 in a row, 800 playouts: BASELINE configs[3] geometry) ==')
-pipe = mod.TrainPipeline(board_size=15, n_in_row=5, n_playout=800, game_batch_num=2, check_freq=1000,
-                         selfplay_games_in_flight=256)
-for i in range(2):
+print('== batched collection: 512 games in flight (15x15, 5 in a row, 800 playouts: BASELINE configs[3], one resident lane) ==')
+G = int(os.environ.get('RZ_TRAIN_GAMES', '512'))
+pipe = mod.TrainPipeline(board_size=15, n_in_row=5, n_playout=800, game_batch_num=3, check_freq=1000,
+                         selfplay_games_in_flight=G)
+spent = {'play': 0.0}
+real_play = pipe._play_games
+
+
+def timed_play(ids):
+    t = time.perf_counter()
+    out = real_play(ids)
+    spent['play'] += time.perf_counter() - t
+    return out
+
+
+pipe._play_games = timed_play
+for i, n in enumerate((G, G, 4 * G)):
+    spent['play'] = 0.0
     t0 = time.perf_counter()
-    pipe.collect_selfplay_data(256)
+    pipe.collect_selfplay_data(n)
     t1 = time.perf_counter()
     loss, entropy = pipe.policy_update()
     t2 = time.perf_counter()
     n_pos = len(pipe.data_buffer) // 8  # the reference's deque(maxlen=1000) keeps the newest 1000 samples
-    print('-- round %d: 256 games collected in %.1f s (%.1f games/s), buffer %d positions x 8 symmetries, update %.2f s, '
-          'loss %.4f entropy %.4f' % (i + 1, t1 - t0, 256 / (t1 - t0), n_pos, t2 - t1, loss, entropy))
+    print('-- round %d: %d games (%d in flight) collected in %.2f s (%.1f games/s): self-play on the GPU %.2f s, host share (planes from move '
+          'lists, the replay buffer) %.2f s; buffer %d positions x 8 symmetries, update %.2f s, loss %.4f entropy %.4f' % (
+              i + 1, n, G, t1 - t0, n / (t1 - t0), spent['play'], t1 - t0 - spent['play'], n_pos, t2 - t1, loss, entropy))
+print('(a round of exactly as many games as slots ends with its LONGEST game -- up to 225 plies of ~17 ms where the mean game has 102 --;\n'
+      ' a round of several times the slots refills them from the queue and runs at the engine\'s steady rate: bench.py\'s selfplay leg)')

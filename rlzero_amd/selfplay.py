@@ -950,8 +950,10 @@ class BatchedSelfPlay(object):
         self._stalls = {}
         self._queue_len = self._started = 0
 
-    def run_device(self, game_ids, max_moves=None):
-        """run() with the move step on the device: same trajectories, sorted by game id."""
+    def run_device(self, game_ids, max_moves=None, on_finished=None):
+        """run() with the move step on the device: same trajectories, sorted by game id.  ``on_finished(trajectories)``: called with the
+        games found finished after every enqueued move, while the GPU searches on (a consumer's per-game work -- the trainer's
+        observation planes and replay-buffer entries -- then costs the round nothing)."""
         game_ids = list(game_ids)
         if not getattr(self, '_dev_on', False):
             self.device_attach(queue_capacity=max(len(game_ids), 1))
@@ -964,11 +966,17 @@ class BatchedSelfPlay(object):
         while len(out) < len(game_ids):
             if all(self._lane_quiet(lane) for lane in self.lanes):
                 raise RuntimeError('device-driven self-play went quiet with %d of %d games finished' % (len(out), len(game_ids)))
-            out.extend(self.play_move_device())
+            done = self.play_move_device()
+            out.extend(done)
+            if on_finished is not None and done:
+                on_finished(done)
             n_moves += 1
             if max_moves is not None and n_moves >= max_moves:
                 break
-        out.extend(self.device_drain())
+        done = self.device_drain()
+        out.extend(done)
+        if on_finished is not None and done:
+            on_finished(done)
         self.check()
         if len(out) < len(game_ids):
             self.device_stop()

@@ -6,6 +6,8 @@ the host, which reads the log behind the GPU, forms pi with the reference's nump
 Pinned here: the games are the oracle's (synthetic evaluator: bit-exact trees, moves, pi to 1e-12, z), they are bit for bit the
 games of the host-driven loop (real net, lanes, hipGraphs, the resident search, Connect4, refills), and a draw that falls close to
 an interval edge is decided by the host (forced here by a wide stall margin) without changing a single game."""
+import os
+
 import numpy as np
 import pytest
 
@@ -185,3 +187,42 @@ def test_lanes_by_measurement_on_the_gpu():
     for s_ in (sp, again, one):
         for lane in s_.lanes:
             lane.eng.close()
+
+
+@pytest.mark.gpu
+def test_the_baseline_batch_does_not_depend_on_import_order():
+    """512 games at 15x15 / 800 are ONE resident lane (k_delta_res, two games per CU) on one stream: a process that touched the GPU
+    BEFORE importing rlzero_amd -- the runtime then has its default four hardware queues, where round 5's four-lane layout fell from
+    10.2 to 6.1 M simulations / s -- gets the same layout and, within 10 %, the rate of a process that imported the package first."""
+    import json
+    import subprocess
+    import sys
+    code = r'''
+import json, os, sys
+os.environ.pop('GPU_MAX_HW_QUEUES', None)
+late = sys.argv[1] == 'late'
+import torch
+if late:
+    torch.zeros(8, device='cuda:0').sum().item()     # the HIP runtime starts here, with its default hardware queues
+import rlzero_amd
+from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+from rlzero_amd.selfplay import BatchedSelfPlay, time_moves
+torch.manual_seed(0)
+net = PolicyValueNet(15).to('cuda:0')
+sp = BatchedSelfPlay.for_network(net, 15, 5, n_games=512, n_playout=800, seed=1)
+lane = sp.lanes[0]
+out = {'late': late, 'hw_queues': rlzero_amd.HW_QUEUES, 'too_late': rlzero_amd.HW_QUEUES_TOO_LATE, 'lanes': len(sp.lanes),
+       'resident': bool(lane.evaluator.resident_ok(lane.eng) and lane.evaluator.resident_delta_ok(lane.eng)), 'rate': time_moves(sp, moves=3)}
+print('RESULT ' + json.dumps(out))
+'''
+    results = {}
+    for mode in ('early', 'late'):
+        run = subprocess.run([sys.executable, '-c', code, mode], capture_output=True, text=True, timeout=600,
+                             cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        lines = [ln for ln in run.stdout.splitlines() if ln.startswith('RESULT ')]
+        assert run.returncode == 0 and lines, (mode, run.stderr[-2000:])
+        results[mode] = json.loads(lines[-1][7:])
+    early, late = results['early'], results['late']
+    assert late['too_late'] and not early['too_late'] and early['hw_queues'] >= 8 and late['hw_queues'] < 8
+    assert early['lanes'] == late['lanes'] == 1 and early['resident'] and late['resident']
+    assert late['rate'] >= 0.9 * early['rate'] and early['rate'] > 1.2e7, results

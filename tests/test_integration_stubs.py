@@ -17,14 +17,15 @@ pytestmark = pytest.mark.gpu
 
 def _stub_namespace():
     text = open(os.path.join(REPO, 'INTEGRATION.md')).read()
-    blocks = [b for b in re.findall(r'```python\n(.*?)```', text, flags=re.S) if 'class HipSearch' in b or 'def self_play' in b]
-    assert len(blocks) == 2 and 'class HipSearch' in blocks[0] and 'def self_play' in blocks[1]
+    blocks = [b for b in re.findall(r'```python\n(.*?)```', text, flags=re.S) if 'class HipSearch' in b or 'def self_play' in b or 'def search_with_the_hand_written_net' in b]
+    assert len(blocks) == 3 and 'class HipSearch' in blocks[0] and 'def search_with_the_hand_written_net' in blocks[1] and 'def self_play' in blocks[2]
     lib_path = os.path.join(REPO, 'rlzero_amd', 'librlzero_hip.so')
     ns = {}
     exec(blocks[0].replace("ctypes.CDLL('librlzero_hip.so')", 'ctypes.CDLL(%r)' % lib_path), ns)
     from rlzero_amd.selfplay import move_uniform
     ns['move_uniform'] = lambda seed, gid, ply: float(move_uniform(seed, gid, int(ply)))
     exec(blocks[1], ns)
+    exec(blocks[2], ns)
     return ns
 
 
@@ -81,3 +82,45 @@ def test_the_self_play_stub_plays_the_oracle_s_games():
             acts = np.nonzero(counts >= 0)[0]
             assert np.max(np.abs(pi[acts] - visits_to_pi(counts[acts], 1.0))) <= 1e-12
     lib.rz_destroy(h)
+
+
+def test_the_resident_search_stub_with_and_without_receptive_fields():
+    """INTEGRATION.md's third stub: one call searches every slot with the hand-written evaluator; with the roots' activations cached
+    (rz_net_delta_*: leaves evaluated by their receptive fields, two games per CU) the visit counts are those of the full forward
+    pass per leaf -- and those of this package's own engine wrapper on the same positions."""
+    import ctypes
+    import torch
+    from rlzero_amd.engine import PARAM_ORDER
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    ns = _stub_namespace()
+    lib, P, ok = ns['lib'], ns['P'], ns['ok']
+    B, n, sims, slots = 15, 5, 120, 6
+    torch.manual_seed(3)
+    sd = PolicyValueNet(B).state_dict()
+    arrays = [sd[name].detach().cpu().float().contiguous().numpy() for name in PARAM_ORDER]
+    net = P()
+    ok(lib.rz_net_create(B, B, B * B, 0, ctypes.byref(net)))
+    ok(lib.rz_net_load(net, (ctypes.c_void_p * 16)(*[a.ctypes.data for a in arrays]), 16))
+    rng = np.random.default_rng(5)
+    stones = np.zeros((slots, 2, 4), dtype=np.uint64)
+    to_move = np.zeros(slots, dtype=np.int32)
+    last = np.full(slots, -1, dtype=np.int32)
+    for g in range(slots):   # a few stones on every board (slot 0: the empty board)
+        cells = rng.permutation(B * B)[:3 * g]
+        for j, c in enumerate(cells):
+            stones[g, j % 2, int(c) >> 6] |= np.uint64(1) << np.uint64(int(c) & 63)
+        to_move[g], last[g] = len(cells) % 2, (int(cells[-1]) if len(cells) else -1)
+    d_stones = torch.from_numpy(stones.view(np.int64)).cuda()
+    d_tm, d_last = torch.from_numpy(to_move).cuda(), torch.from_numpy(last).cuda()
+    st = P(torch.cuda.current_stream().cuda_stream)
+    counts = {}
+    for rf in (True, False):
+        cfg = ns['RzConfig'](lib.rz_abi_version(), 0, B, n, slots, sims, 0, 0, 5.0, 0.0, 0, 0, 0, 0, 0, 0)
+        h = P()
+        ok(lib.rz_create(ctypes.byref(cfg), ctypes.byref(h)))
+        ok(lib.rz_set_roots(h, P(d_stones.data_ptr()), P(d_tm.data_ptr()), P(d_last.data_ptr()), None, 1, st))
+        counts[rf] = ns['search_with_the_hand_written_net'](h, net, slots, sims, B * B, receptive_field=rf).cpu().numpy()
+        torch.cuda.synchronize()
+        ok(lib.rz_destroy(h))
+    assert np.array_equal(counts[True], counts[False]) and (counts[True].sum(axis=1) == sims - 1).all()
+    ok(lib.rz_net_destroy(net))

@@ -26,6 +26,43 @@ def test_get_equi_data_matches_reference(g5):
     assert np.array_equal(np.array([z for _, _, z in out]), g5['equi_z'])
 
 
+def test_replay_buffer_is_the_reference_s_deque_of_augmented_samples(g5):
+    """ReplayBuffer forms the 8 symmetries of a sample when it is read: entry for entry -- values, order, the maxlen window (also
+    through the middle of a game), negative and sliced indices, ready-made entries beside lazy ones -- it is
+    deque(maxlen).extend(get_equi_data(play_data)) (train_alphazero.py:32, 59-79, 88-90), and random.sample draws the same batch."""
+    import random
+    from collections import deque
+    mod = _load()
+    rng = np.random.RandomState(3)
+    B = 4
+    fake = types.SimpleNamespace(board_size=B)
+    games = [[(g5['state'], g5['pi'], 1.0)]]
+    for n in (5, 1, 9, 3):
+        games.append([((rng.rand(4, B, B) < 0.4).astype(np.float64), rng.dirichlet(np.ones(B * B)), float(rng.choice([-1.0, 0.0, 1.0]))) for _ in range(n)])
+    for maxlen in (1000, 100, 37, 8):
+        ref, buf = deque(maxlen=maxlen), mod.ReplayBuffer(maxlen, B)
+        for i, game in enumerate(games):
+            ref.extend(mod.TrainPipeline.get_equi_data(fake, game))
+            if i == 2:
+                buf.extend(mod.TrainPipeline.get_equi_data(fake, game))   # ready-made entries (the reference flow's path)
+            else:
+                buf.extend_samples(game)
+            assert len(buf) == len(ref) and buf.maxlen == maxlen
+            for (s1, p1, z1), (s2, p2, z2) in zip(buf, ref):
+                assert np.array_equal(s1, s2) and np.array_equal(p1, p2) and z1 == z2 and s1.shape == (4, B, B) and p1.shape == (B * B, )
+        for i in (0, -1, len(ref) // 2):
+            assert np.array_equal(buf[i][0], ref[i][0]) and np.array_equal(buf[i][1], ref[i][1]) and buf[i][2] == ref[i][2]
+        assert len(buf[2:5]) == min(3, max(0, len(ref) - 2))
+        with pytest.raises(IndexError):
+            buf[len(ref)]
+        if len(ref) >= 8:
+            random.seed(5)
+            a = random.sample(buf, 8)
+            random.seed(5)
+            b = random.sample(list(ref), 8)
+            assert all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2] for x, y in zip(a, b))
+
+
 def test_reference_import_lines_and_names():
     text = open(os.path.join(REPO, 'tools', 'train_alphazero.py')).read()
     for line in ('from rlzero.games.gomoku import GameControl, GomokuEnv',

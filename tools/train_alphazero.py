@@ -29,6 +29,7 @@ import os
 import random
 import sys
 from collections import defaultdict, deque
+from collections.abc import Sequence
 
 import numpy as np
 import torch
@@ -53,6 +54,94 @@ def _symmetries(planes, pi_grid):
         mirrored = np.array([np.fliplr(plane) for plane in turned])
         out.append((mirrored, np.flipud(np.fliplr(pi_turned)).flatten()))
     return out
+
+
+class ReplayBuffer(Sequence):
+    """The reference's ``deque(maxlen=buffer_size)`` of augmented samples (train_alphazero.py:32, 59-79, 88-90) with the 8 symmetries
+    formed WHEN A SAMPLE IS READ instead of when a game arrives: entry 8 j + k is symmetry k of the j-th sample ever added, in
+    get_equi_data's order and with its numpy operations -- value for value what ``deque.extend(get_equi_data(play_data))`` would
+    hold (tests/test_train_script.py) -- but a collection round of 512 games (52 k positions, 420 k entries) costs the host a list
+    append per game where forming every symmetry up front cost more than the round's self-play on the GPU, and a mini-batch reads 32.
+    Sequence protocol (len, index, iteration: what ``random.sample`` and the tests use), ``maxlen``, ``extend`` (ready-made
+    entries: the reference flow), ``extend_samples`` (a game's un-augmented samples)."""
+
+    def __init__(self, maxlen, board_size):
+        self.maxlen, self.size = int(maxlen), int(board_size)
+        self._blocks = deque()   # ('raw', [entries]) or ('game', states [P,4,B,B], pi grids [P,B,B], z [P])
+        self._counts = deque()   # entries each block contributes
+        self._skip = 0           # entries of the FIRST block that have fallen out (maxlen)
+        self._len = 0
+
+    def __len__(self):
+        return self._len
+
+    def _trim(self):
+        over = self._len - self.maxlen
+        while over > 0:
+            left = self._counts[0] - self._skip
+            if over >= left:
+                self._blocks.popleft()
+                self._counts.popleft()
+                self._skip = 0
+                self._len -= left
+                over -= left
+            else:
+                self._skip += over
+                self._len -= over
+                over = 0
+
+    def extend(self, entries):
+        entries = list(entries)
+        if entries:
+            self._blocks.append(('raw', entries))
+            self._counts.append(len(entries))
+            self._len += len(entries)
+            self._trim()
+
+    def extend_samples(self, play_data):
+        """A game's (state, mcts_prob, z) samples, un-augmented: 8 entries each, formed on access."""
+        play_data = list(play_data)
+        if not play_data:
+            return
+        states = np.stack([np.asarray(s_) for s_, _, _ in play_data])
+        grids = np.stack([np.asarray(p_).reshape(self.size, self.size) for _, p_, _ in play_data])
+        self._blocks.append(('game', states, grids, [w for _, _, w in play_data]))
+        self._counts.append(8 * len(play_data))
+        self._len += 8 * len(play_data)
+        self._trim()
+
+    def _entry(self, block, i):
+        if block[0] == 'raw':
+            return block[1][i]
+        _, states, grids, zs = block
+        j, k = divmod(i, 8)
+        quarter_turns, mirrored = k // 2 + 1, k % 2 == 1
+        turned = np.rot90(states[j:j + 1], quarter_turns, axes=(2, 3))            # get_equi_data's operations on a stack of one
+        pi_turned = np.rot90(grids[j:j + 1, ::-1, :], quarter_turns, axes=(1, 2))
+        if mirrored:
+            return (np.ascontiguousarray(turned[:, :, :, ::-1])[0], np.ascontiguousarray(pi_turned[:, :, ::-1][:, ::-1, :]).reshape(1, -1)[0], zs[j])
+        return np.ascontiguousarray(turned)[0], np.ascontiguousarray(pi_turned[:, ::-1, :]).reshape(1, -1)[0], zs[j]
+
+    def __getitem__(self, index):
+        if isinstance(index, slice):
+            return [self[i] for i in range(*index.indices(self._len))]
+        if index < 0:
+            index += self._len
+        if not 0 <= index < self._len:
+            raise IndexError('ReplayBuffer index out of range')
+        index += self._skip
+        for block, count in zip(self._blocks, self._counts):
+            if index < count:
+                return self._entry(block, index)
+            index -= count
+        raise IndexError('ReplayBuffer index out of range')
+
+    def __iter__(self):
+        first = True
+        for block, count in zip(self._blocks, self._counts):
+            for i in range(self._skip if first else 0, count):
+                yield self._entry(block, i)
+            first = False
 
 
 class TrainPipeline:
@@ -85,7 +174,8 @@ class TrainPipeline:
                 max(1000, selfplay_games_in_flight * self.world * board_size * board_size * 8)
         self.buffer_size = int(buffer_size)
         self.batch_size = 32
-        self.data_buffer = deque(maxlen=self.buffer_size)
+        # (the reference's deque of augmented samples, the symmetries formed on access: ReplayBuffer)
+        self.data_buffer = ReplayBuffer(self.buffer_size, self.board_size)
         self.play_batch_size = 1
         self.epochs = 5
         self.kl_targ = 0.02
@@ -175,8 +265,9 @@ class TrainPipeline:
                 extend_data.append((out_s[k][j], out_p[k][j], winner))
         return extend_data
 
-    def _play_games(self, game_ids):
-        """The trajectories of ``game_ids`` (this rank's share of a round), games in lock-step on this rank's GPU."""
+    def _play_games(self, game_ids, on_finished=None):
+        """The trajectories of ``game_ids`` (this rank's share of a round), games in lock-step on this rank's GPU.  ``on_finished``: see
+        BatchedSelfPlay.run_device (one rank, the move step on the device: the round's samples are formed while the GPU plays on)."""
         from rlzero.algorithms import BatchedSelfPlay
         if self._batched is None:
             # one to four lanes of games, whichever fills the GPU better (selfplay.plan_lanes)
@@ -187,8 +278,12 @@ class TrainPipeline:
         self._batched.refresh_weights()   # (every lane's evaluator: the learner has stepped / new weights have arrived)
         # the move step on the device (rz_play_*: the host reads the games from a log behind the GPU); RZ_TRAIN_HOST_MOVES=1: the
         # host-driven loop -- the same trajectories either way (tests/test_device_moves.py)
-        play = self._batched.run if os.environ.get('RZ_TRAIN_HOST_MOVES') == '1' else self._batched.run_device
-        trajs = play(game_ids) if len(game_ids) else []
+        if os.environ.get('RZ_TRAIN_HOST_MOVES') == '1':
+            trajs = self._batched.run(game_ids) if len(game_ids) else []
+            if on_finished is not None and trajs:
+                on_finished(trajs)
+        else:
+            trajs = self._batched.run_device(game_ids, on_finished=on_finished) if len(game_ids) else []
         if os.environ.get('RZ_TRAIN_TRACE'):
             self._trace_round(trajs)
         return trajs
@@ -227,12 +322,19 @@ class TrainPipeline:
         from rlzero.algorithms import gather_trajectories
         ids = range(self._next_game_id, self._next_game_id + n_games)
         self._next_game_id += n_games
-        local = self._play_games([g for g in ids if g % self.world == self.rank])
         if self.world > 1:
+            local = self._play_games([g for g in ids if g % self.world == self.rank])
             merged = gather_trajectories(local, self.board_size, self.n_in_row, dst=0, pi_dtype=np.float32)
-        else:
-            merged = sorted(local, key=lambda t: t.game_id)
-        return [t.as_reference_tuple() for t in merged] if merged is not None else []
+            return [t.as_reference_tuple() for t in merged] if merged is not None else []
+        # one rank: every finished game becomes start_self_play's tuple (planes from its move list) WHILE the others are played --
+        # behind an idle GPU that was a tenth of a round; the round's order stays the game ids'
+        ready = {}
+
+        def take(trajs):
+            for t in trajs:
+                ready[t.game_id] = t.as_reference_tuple()
+        local = self._play_games(list(ids), on_finished=take)
+        return [ready[t.game_id] if t.game_id in ready else t.as_reference_tuple() for t in sorted(local, key=lambda t: t.game_id)]
 
     def collect_selfplay_data(self, n_games=1):
         """collect self-play data for training."""
@@ -244,7 +346,10 @@ class TrainPipeline:
         for winner, play_data in games:
             play_data = list(play_data)
             self.episode_len = len(play_data)
-            self.data_buffer.extend(self.get_equi_data(play_data))
+            if os.environ.get('RZ_TRAIN_EAGER_SYMMETRIES') == '1':   # (the eight symmetries of every sample up front, as before round 6)
+                self.data_buffer.extend(self.get_equi_data(play_data))
+            else:
+                self.data_buffer.extend_samples(play_data)
 
     # ------------------------------------------------------------------ learning
     def policy_update(self):

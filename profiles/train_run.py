@@ -34,15 +34,15 @@ spent = {'play': 0.0}
 real_play = pipe._play_games
 
 
-def timed_play(ids):
+def timed_play(ids, **kw):
     t = time.perf_counter()
-    out = real_play(ids)
+    out = real_play(ids, **kw)
     spent['play'] += time.perf_counter() - t
     return out
 
 
 pipe._play_games = timed_play
-for i, n in enumerate((G, G, 4 * G)):
+for i, n in enumerate((G, G, 4 * G, 8 * G)):
     spent['play'] = 0.0
     t0 = time.perf_counter()
     pipe.collect_selfplay_data(n)
@@ -50,8 +50,8 @@ for i, n in enumerate((G, G, 4 * G)):
     loss, entropy = pipe.policy_update()
     t2 = time.perf_counter()
     n_pos = len(pipe.data_buffer) // 8  # the reference's deque(maxlen=1000) keeps the newest 1000 samples
-    print('-- round %d: %d games (%d in flight) collected in %.2f s (%.1f games/s): self-play on the GPU %.2f s, host share (planes from move '
-          'lists, the replay buffer) %.2f s; buffer %d positions x 8 symmetries, update %.2f s, loss %.4f entropy %.4f' % (
+    print('-- round %d: %d games (%d in flight) collected in %.2f s (%.1f games/s): the self-play call %.2f s (finished games become samples inside it, while the GPU plays), the rest '
+          '(replay buffer) %.2f s; buffer %d positions x 8 symmetries, update %.2f s, loss %.4f entropy %.4f' % (
               i + 1, n, G, t1 - t0, n / (t1 - t0), spent['play'], t1 - t0 - spent['play'], n_pos, t2 - t1, loss, entropy))
 print('(a round of exactly as many games as slots ends with its LONGEST game -- up to 225 plies of ~17 ms where the mean game has 102 --;\n'
       ' a round of several times the slots refills them from the queue and runs at the engine\'s steady rate: bench.py\'s selfplay leg)')

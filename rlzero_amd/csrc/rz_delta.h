@@ -25,6 +25,15 @@
 // base that is not a subset of the leaf) is evaluated by the same code WITHOUT a base, in four passes over the board's quadrants
 // (each pass: conv3 on <= 8 x 8 cells, conv2 on the 9 x 9 and conv1 on the 10 x 10 around them) -- no second kernel, no host decision.
 // mode 1 builds the bases that way and writes the cache.
+// (issue priorities of the resident search's phases, s_setprio: its serial tree phase -- one wave, ~20 k cycles a simulation -- ahead of
+// the OTHER game's trunk waves on the same SIMDs: +2.5 % on the whole line, profiles/r06/ab_prio.txt; PRO: the trunk's prologue likewise)
+#ifndef RZ_DELTA_TREE_PRIO
+#define RZ_DELTA_TREE_PRIO 1
+#endif
+#ifndef RZ_DELTA_PRO_PRIO
+#define RZ_DELTA_PRO_PRIO 0
+#endif
+
 namespace dl {
 
 using sp::f16x4;
@@ -44,7 +53,7 @@ constexpr int kHeadW = 128 * 6 * 4 + 128 * 4 + 32;   // the 1 x 1 head convoluti
 // (the planes: the hi pieces only -- the lo pieces of 0 / 1 planes are zero and conv1 skips their products)
 constexpr int kOffC1 = sp::kInPieceBytes, kOffC2 = kOffC1 + kC1Slots * P1, kOffZero = kOffC2 + kC2Slots * P2, kOffHead = kOffZero + P2,
               kOffMap1 = kOffHead + kHeadW, kOffMap2 = kOffMap1 + kGrid * 4, kOffList = kOffMap2 + kGrid * 4, kOffCnt = kOffList + 3 * 128 * 2,
-              kLdsBytes = kOffCnt + 5 * 4 * 4;
+              kOffListR = kOffCnt + 5 * 4 * 4, kLdsBytes = kOffListR + ((kC1Slots + kC2Slots + 15) / 16) * 16;   // (listR: the cells of the held records, a byte each)
 static_assert(kShareFloats * 4 <= kC1Slots * P1, "the shares lie inside conv1's records (dead behind conv2)");
 static_assert(2 * (kLdsBytes + 512 * 4 + 4 * 64 * 4 + 80 + 512) <= 160 * 1024, "two workgroups per CU, also of the resident search (value row, K-quarter sums, leaf)");
 static_assert(kOffC1 % 16 == 0 && kOffZero % 16 == 0 && kOffHead % 16 == 0 && kOffMap1 % 16 == 0, "alignment");
@@ -177,22 +186,32 @@ __device__ __forceinline__ void conv3_g(lds_u32 map, const uint16_t *list3, cons
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[m][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     uint32_t rec[NT][3], recn[NT][3];
-    f16x8 b[2][unit_tiles(NT)][2];
+    // units read ahead: a unit of one or two tiles (6 - 12 MFMAs) is shorter than an LDS round trip under load
+#ifndef RZ_DELTA_AHEAD3_SMALL
+#define RZ_DELTA_AHEAD3_SMALL 1
+#endif
+    constexpr int UT = unit_tiles(NT), AH = UT <= 2 ? RZ_DELTA_AHEAD3_SMALL : 1, NB = AH + 1;
+    static_assert((6 * H) % NB == 0 && AH <= H * 6, "a unit's registers are a constant of the unrolled body");
+    f16x8 b[NB][UT][2];
     lookup<NT>(rec, map, pos19, 0, g);
-    read_unit<64, NT, unit_tiles(NT)>(b[0], rec, 0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < AH; ++u) read_unit<64, NT, UT>(b[u], rec, u % H, (u / H) % 3, u / H / 3);
 #pragma unroll 1
     for (int dx = 0; dx < 3; ++dx) {
         lookup<NT>(recn, map, pos19, dx < 2 ? dx + 1 : 2, g);   // the next tap column's records (past the last: unused)
 #pragma unroll
-        for (int u = 0; u < 6 * H; ++u) {   // unit u = step (u / H) x tiles of group (u % H); 6 H is even: the parity of a unit's registers holds
+        for (int u = 0; u < 6 * H; ++u) {   // unit u = step (u / H) x tiles of group (u % H); 6 H is a multiple of NB: a unit's registers are constants
             const int j = u / H, h = u % H;
             if (h == 0) {   // the fragments of step j + R - 1 (past the last tap column: a reload of the last one's, never used)
                 const int jj = j + R - 1, dx2 = jj < 6 ? dx : (dx < 2 ? dx + 1 : 2);
                 load_a3(a3[jj % R], w_rsrc, lane, dx2, jj % 6);
             }
-            if (u + 1 < 6 * H) read_unit<64, NT, unit_tiles(NT)>(b[(u + 1) & 1], rec, (u + 1) % H, ((u + 1) / H) % 3, (u + 1) / H / 3);
-            else read_unit<64, NT, unit_tiles(NT)>(b[(u + 1) & 1], recn, 0, 0, 0);
-            mfma_unit<2, NT, unit_tiles(NT)>(acc, a3[j % R], b[u & 1], h);
+            {
+                const int v = u + AH;   // the unit read now (past this tap column's last: the next column's first)
+                if (v < 6 * H) read_unit<64, NT, UT>(b[v % NB], rec, v % H, (v / H) % 3, v / H / 3);
+                else read_unit<64, NT, UT>(b[v % NB], recn, (v - 6 * H) % H, ((v - 6 * H) / H) % 3, (v - 6 * H) / H / 3);
+            }
+            mfma_unit<2, NT, UT>(acc, a3[j % R], b[u % NB], h);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -320,6 +339,7 @@ __device__ __forceinline__ int delta_passes(const NetDev &nd, const DeltaArgs &d
     uint32_t *map1 = reinterpret_cast<uint32_t *>(lds + kOffMap1), *map2 = reinterpret_cast<uint32_t *>(lds + kOffMap2);
     uint16_t *list1 = reinterpret_cast<uint16_t *>(lds + kOffList), *list2 = list1 + 128, *list3 = list2 + 128;
     int *cnt = reinterpret_cast<int *>(lds + kOffCnt);   // [5 sets][4 waves]
+    uint8_t *listR1 = reinterpret_cast<uint8_t *>(lds + kOffListR), *listR2 = listR1 + kC1Slots;
     float *shares = reinterpret_cast<float *>(c1);
     const int mode = da.mode, BH = nd.BH, BW = nd.BW, S = nd.S;
     const float k1 = ly.k1, k2 = ly.k2, k3 = ly.k3, act1 = ly.act1, act2 = ly.act2, act3 = ly.act3;
@@ -344,6 +364,7 @@ __device__ __forceinline__ int delta_passes(const NetDev &nd, const DeltaArgs &d
         const int cy = (tid * da.bw_rcp) >> 16, cx = tid - cy * BW;
         const bool is_cell = tid < S;
         const int mypos = is_cell ? (cy + 1) * kRowW + cx + 1 : 0;
+        if (RZ_DELTA_PRO_PRIO) __builtin_amdgcn_s_setprio(RZ_DELTA_PRO_PRIO);
         // ---- the distance of this thread's cell to the changed cells (delta) / to the pass's quadrant
         int dist = 1000;
         if (pass < 0) {
@@ -431,6 +452,42 @@ __device__ __forceinline__ int delta_passes(const NetDev &nd, const DeltaArgs &d
         if (pass <= 0 && is_cell) *reinterpret_cast<f16x4 *>(in0 + ((cy + 1) * sp::kInCols + (cx + 1)) * 8) = cell_planes;
         if (pass <= 0 && store_head && tid < 226) reinterpret_cast<f32x4 *>(headw)[tid] = headv;
         asm volatile("" ::"v"(touch));
+#ifndef RZ_DELTA_GATHER_BALANCED
+#define RZ_DELTA_GATHER_BALANCED 0
+#endif
+#if RZ_DELTA_GATHER_BALANCED
+        // the base's records, copied by ALL threads: record r of a layer's held set is 8 / 16 chunks of 16 bytes, chunk c of the set goes
+        // to thread c mod 256 (a wave copies whole records: coalesced) -- ~14 loads a thread where the held cells' own threads (fewer
+        // than half of the workgroup) issued 24 each.  Cells the leaf recomputes are copied too; their layers overwrite them.
+        if (pass < 0) {
+            if (f[3]) listR1[rank[3]] = (uint8_t)tid;
+            if (f[4]) listR2[rank[4]] = (uint8_t)tid;
+            __syncthreads();
+            constexpr int I2 = (kC2Slots * 16 + 255) / 256, I1 = (kC1Slots * 8 + 255) / 256;
+            const int n2c = tot[4] * 16, n1c = tot[3] * 8;
+            f32x4 q2[I2], q1[I1];
+#pragma unroll
+            for (int i = 0; i < I2; ++i) {
+                const int c = tid + 256 * i, cc = c < n2c ? c : 0;
+                q2[i] = *reinterpret_cast<const f32x4 *>(base + kBaseC2 + (size_t)listR2[cc >> 4] * 256 + (cc & 15) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < I1; ++i) {
+                const int c = tid + 256 * i, cc = c < n1c ? c : 0;
+                q1[i] = *reinterpret_cast<const f32x4 *>(base + (size_t)listR1[cc >> 3] * 128 + (cc & 7) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < I2; ++i) {
+                const int c = tid + 256 * i;
+                if (c < n2c) *reinterpret_cast<f32x4 *>(c2 + (c >> 4) * P2 + (c & 15) * 16) = q2[i];
+            }
+#pragma unroll
+            for (int i = 0; i < I1; ++i) {
+                const int c = tid + 256 * i;
+                if (c < n1c) *reinterpret_cast<f32x4 *>(c1 + (c >> 3) * P1 + (c & 7) * 16) = q1[i];
+            }
+        }
+#else
         if (g1) {
             const f32x4 *src = reinterpret_cast<const f32x4 *>(base + (size_t)tid * 128);
             f32x4 r1[8];
@@ -447,6 +504,7 @@ __device__ __forceinline__ int delta_passes(const NetDev &nd, const DeltaArgs &d
 #pragma unroll
             for (int i = 0; i < 16; ++i) *(lds_v4)(uintptr_t)(rec2 + 16 * i) = r2[i];
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);   // (the requests below stay behind the stores of the base's records: their 96 registers are free again)
         f16x8 a2[9][1][2];   // conv2's weight fragments: requested here, conv1 -- one wave's work -- covers their latency
         {
@@ -505,6 +563,7 @@ __device__ __forceinline__ int delta_passes(const NetDev &nd, const DeltaArgs &d
             for (int i = 0; i < 8; ++i) dstp[i] = *(lds_v4)(uintptr_t)(rec1 + 16 * i);
         }
 
+        if (RZ_DELTA_PRO_PRIO) __builtin_amdgcn_s_setprio(0);   // (the matrix loops: behind the other workgroup's latency chains at issue)
         // ---- conv2 (32 -> 64): wave w = output channels 16 w .. 16 w + 15 at every tile
         const int nt3 = (tot[2] + 15) >> 4;
         {
@@ -864,6 +923,7 @@ __global__ __launch_bounds__(256, 2) void k_delta_res(NetDev nd, _Float16 *__res
         NET_TICK(12);
         // ---- the rest of the simulation, by the same workgroup (k_tree_step_def's body: rz_tree.h), as in trunk_rows_body
         const int lane = tid_s & 63;
+        if (RZ_DELTA_TREE_PRIO) __builtin_amdgcn_s_setprio(RZ_DELTA_TREE_PRIO);   // (the serial part of a simulation: ahead of the other game's trunk waves at issue)
         if (res.vh.groups == 128) rzt::value_quarter_lds<16>(res.vh, res_vrow, lane, wave, res_part);
         else rzt::value_quarter_lds<8>(res.vh, res_vrow, lane, wave, res_part);
         NET_TICK(16);
@@ -873,6 +933,7 @@ __global__ __launch_bounds__(256, 2) void k_delta_res(NetDev nd, _Float16 *__res
         NET_TICK(17);
         const bool more = sim + 1 < res.n_sims;
         if (wave == 0 && more) rzt::select_body<false>(res.E, nullptr, game, lane, 0, res_leaf);
+        if (RZ_DELTA_TREE_PRIO) __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         NET_TICK(18);
     }

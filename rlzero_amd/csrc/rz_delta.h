@@ -332,6 +332,14 @@ struct Prof { long long acc[24], t; };
 struct Prof {};
 #endif
 
+// once per launch: every map entry -> the zero record, every list entry -> a valid position (cell 0)
+__device__ __forceinline__ void init_maps(char *lds, int tid) {
+    uint32_t *map1 = reinterpret_cast<uint32_t *>(lds + kOffMap1);
+    const uint32_t zaddr = lds_addr(lds + kOffZero);
+    for (int i = tid; i < 2 * kGrid; i += 256) map1[i] = zaddr;    // (map1 and map2 are contiguous)
+    if (tid < 3 * 128 / 2) reinterpret_cast<uint32_t *>(lds + kOffList)[tid] = 19u | (19u << 16);
+}
+
 // The passes of one leaf: -1 = against the base (use_delta), 0 .. 3 = the board's quadrants without one.  -> tiles computed: conv3 | conv2 << 16.
 __device__ __forceinline__ int delta_passes(const NetDev &nd, const DeltaArgs &da, char *lds, int tid0, int wave, const Leaf &leaf, const Layers &ly,
                                             f32x4 headv, bool &use_delta, Prof &prof) {
@@ -414,8 +422,8 @@ __device__ __forceinline__ int delta_passes(const NetDev &nd, const DeltaArgs &d
             rank[k] = __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
             if (lane == 0) cnt[k * 4 + wave] = __popcll(b);
         }
-        for (int i = tid; i < 2 * kGrid; i += 256) map1[i] = zaddr;    // (map1 and map2 are contiguous)
-        if (tid < 3 * 128 / 2) reinterpret_cast<uint32_t *>(list1)[tid] = 19u | (19u << 16);
+        // (maps and lists: every map entry is the zero record and every list entry a valid position when a pass begins -- set once per
+        // launch, init_maps; a pass puts back what it changed, and a lane past a list's count may read any position: its column is dropped)
         NET_TICK(1);   // distances, requests, ballots, map / list defaults
         __syncthreads();
         NET_TICK(2);
@@ -643,6 +651,8 @@ __device__ __forceinline__ int delta_passes(const NetDev &nd, const DeltaArgs &d
                 }
             }
         }
+        if (f[3]) map1[mypos] = zaddr;   // (every wave is behind conv3: nothing reads the maps any more)
+        if (f[4]) map2[mypos] = zaddr;
         NET_TICK(11);   // features
         if (pass < 0) break;
         __syncthreads();   // the next pass rewrites maps, lists and records
@@ -789,6 +799,7 @@ __global__ __launch_bounds__(256, 2) void k_trunk_delta(NetDev nd, LeafBits leav
         f32x4 *z = reinterpret_cast<f32x4 *>(lds);
         for (int i = tid0; i < sp::kInPieceBytes / 16; i += 256) z[i] = zero;
         if (tid0 < P2 / 16) reinterpret_cast<f32x4 *>(lds + kOffZero)[tid0] = zero;
+        init_maps(lds, tid0);
     }
     if (mode == 0 && is_active == 0) return;   // (uniform; before any barrier; behind the stores above so that the flag's load is
                                                // one of the batch, not a round trip of its own at the top)
@@ -871,6 +882,7 @@ __global__ __launch_bounds__(256, 2) void k_delta_res(NetDev nd, _Float16 *__res
         f32x4 *z = reinterpret_cast<f32x4 *>(lds);
         for (int i = tid0; i < sp::kInPieceBytes / 16; i += 256) z[i] = zero;
         if (tid0 < P2 / 16) reinterpret_cast<f32x4 *>(lds + kOffZero)[tid0] = zero;
+        init_maps(lds, tid0);
         for (int i = tid0; i < kResVrow; i += 256) res_vrow[i] = 0.0f;
     }
     if (res.select_first == 0 && tid0 == 0) {   // the first leaf was selected by rz_select_step: from the engine's leaf arrays

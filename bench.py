@@ -1139,6 +1139,8 @@ def main():
             # device-driven moves: draws the device left to the host (u within 1e-10 of an interval edge); every other move verified
             'move_draws_left_to_host': int(getattr(sp, 'stalls_resolved', 0)) if device_moves else None,
             'engine_hbm_bytes': int(hbm_bytes),
+            # the receptive-field trunk's cache of the roots' activations (rz_net_delta_reserve: a header + 2 x 104 448 bytes per game)
+            'base_cache_bytes': int(sum(getattr(getattr(getattr(ev, 'inner', ev), 'hip', None), '_delta_games', 0) * (2 * 104448 + 80) for ev in evaluators)),
         }
         trunk_events = [iv for ev in evaluators if isinstance(ev, TimedEvaluator) for iv in ev.events]
         if isinstance(evaluator, TimedEvaluator) and trunk_events:

@@ -258,7 +258,7 @@ def _train_on_cpu(world, games_in_flight, n_batches):
     pipe.batch_size = 16
     played = []
 
-    def play(game_ids):
+    def play(game_ids, on_finished=None):   # (TrainPipeline._play_games' signature; the CPU stand-in hands every game over at the end)
         weights = {k: v.detach().cpu().numpy() for k, v in pipe.alphazero_agent.policy_value_net.state_dict().items()}
         evaluator = NetEvaluator(weights, 3)
         out = []
@@ -268,6 +268,8 @@ def _train_on_cpu(world, games_in_flight, n_batches):
             winner, data, moves = self_play_game(RefGomoku(3, 3), player, temperature=1.0)
             out.append(Trajectory(gid, 3, 3, moves, [pi for _, pi, _ in data], winner))
         played.extend(game_ids)
+        if on_finished is not None and out:
+            on_finished(out)
         return out
 
     pipe._play_games = play

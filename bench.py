@@ -48,7 +48,7 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md, chip-level parameters
 PEAK_F16_MATRIX_TFLOPS = 2500.0  # dense f16 / bf16 MFMA, same table
 SPLIT_MFMAS_PER_PRODUCT = 3      # split_f16: hi*hi + hi*lo + lo*hi
 PEAK_HBM_GBS = 8000.0
-FILL_GAMES_PER_GPU = 1536  # 2 lanes x 3 boards x 256 trunk workgroups: the batch that fills one MI355X
+FILL_GAMES_PER_GPU = 1536  # three rounds of two games per CU (rounds 3-5: 2 lanes x 3 boards x 256 trunk workgroups, the batch that filled one MI355X)
 GATHER_SAMPLE_GAMES = 256  # N > 1: finished games per rank sent to rank 0 by the trajectory gather (outside the timed region)
 
 
@@ -343,15 +343,15 @@ def child_line(flags, timeout=900):
 
 
 def run_fill_config(args):
-    """The same engine with 1536 games in flight (two lanes of 768: three boards per persistent trunk workgroup), as a
-    child process -> the fields of its line worth keeping."""
-    rec = child_line(['--lanes', 2, '--games', FILL_GAMES_PER_GPU, '--steps', args.steps, '--warmup', max(args.warmup, 3),
+    """The same engine with 1536 games in flight (the layout plan_lanes picks: with the receptive-field trunk ONE resident lane whose
+    launch runs in three rounds of two games per CU; before, two lanes of 768), as a child process -> the fields of its line worth keeping."""
+    rec = child_line(['--games', FILL_GAMES_PER_GPU, '--steps', args.steps, '--warmup', max(args.warmup, 3),
                       '--regions', 1, '--net-algo', args.net_algo, '--graph', args.graph, '--noise', args.noise, '--deferred', args.deferred,
                       '--no-cpu-baseline', '--no-games-leg', '--no-fill', '--no-configs', '--timeline', 0], 600)
     if rec is None:
         return None
     rf = rec.get('roofline') or {}
-    return {'workload': rec['config']['workload'], 'value': rec['value'], 'ms_per_step': rec['ms_per_step'],
+    return {'workload': rec['config']['workload'], 'value': rec['value'], 'ms_per_step': rec['ms_per_step'], 'lanes': rec['config'].get('lanes'),
             'frac': rf.get('frac'), 'avg_launch_ms': rf.get('avg_launch_ms'), 'traffic': rf.get('traffic')}
 
 
@@ -859,7 +859,7 @@ def main():
             if os.environ.get('RZ_RESIDENT') == '0':   # (profiles/ab_resident.sh: the two-launch step on a batch the resident search would take)
                 hip_ev.resident_search = False
             deferred_route = hip_ev.deferred_ok(eng)
-            resident_route = G <= n_cus * (2 if hip_ev.resident_delta_ok(eng) else 1) and hip_ev.resident_ok(eng)   # (BatchedSelfPlay switches it off for lanes that share CUs)
+            resident_route = (lanes == 1 or G <= n_cus * (2 if hip_ev.resident_delta_ok(eng) else 1)) and hip_ev.resident_ok(eng)   # (BatchedSelfPlay switches it off for lanes that share CUs)
             ev = TimedEvaluator(hip_ev, torch,
                                 {'winograd_f4': 'k_trunk_wino_f4<4>',
                                  'split_f16': 'k_trunk_rows' if (args.game == 'gomoku' and 11 <= board <= 16) else 'k_trunk_split',
@@ -1248,6 +1248,8 @@ def main():
                       'traffic': pmc_traffic('k_delta_res', pmc_key),
                       'avg_launch_ms': round(rt['search_ms'], 4), 'launches_timed': launches, 'bases_launch_ms': round(rt['bases_ms'], 4),
                       'algorithmic_flops_per_launch': alg,
+                      'note': 'achieved / frac price the ALGORITHMIC flops (a whole-board forward per leaf, the contract\'s figure) and can pass 1: '
+                              'the kernel executes only `executed.share_of_the_algorithmic_products` of them -- `executed` is the pipe\'s own rate',
                       'executed': {'f16_mfma_tflops': round(mfma_flops / (rt['search_ms'] * 1e-3) / 1e12, 2),
                                    'frac_of_f16_mfma_peak': round(mfma_flops / (rt['search_ms'] * 1e-3) / 1e12 / pipe_peak, 4),
                                    'share_of_the_algorithmic_products': round(mfma_flops / SPLIT_MFMAS_PER_PRODUCT / alg, 4),
@@ -1266,6 +1268,7 @@ def main():
                     rf['sclk_in_loop_ghz'] = round(ghz, 3)   # (shader cycles / constant-clock ticks of workgroup 0 of the last timed launch)
                     rf['value_at_2p0ghz'] = round(value * 2.0 / ghz, 1)
                     rf['us_per_simulation_of_a_game'] = round(rt['search_ms'] * 1e3 / args.playouts, 3)
+                    rf['trunk_workgroup_us'] = rf['us_per_simulation_of_a_game']   # (a workgroup's trunk windows + value head + tree step of ONE leaf: the resident kernel has no trunk launch of its own)
                 rf['board_power_w'] = power.mean()
                 line['roofline'] = rf
             elif resident_timing:

@@ -3439,8 +3439,11 @@ int rz_net_search_resident(rz_net *net, rz_engine *engine, int32_t n_sims, int32
     // receptive-field evaluation (rz_net_delta_reserve for this many games, the default trunk on a board of 11 .. 16 rows and columns):
     // k_delta_res, TWO workgroups per CU; rz_net_delta_resident(net, 0) keeps k_trunk_rows_res
     const bool delta_res = net->delta_resident && rows && !net->fp8_cross && net->split_ok && net->base_games >= dev.n_games;
-    if (dev.n_games > net->store_boards || dev.n_games > (delta_res ? 2 : 1) * net->n_cus)
-        return net_fail(RZ_ERR_ARG, "the resident search runs one workgroup per game, at most one per CU (two with rz_net_delta_reserve) and rz_net_deferred_reserve()d");
+    // k_trunk_rows_res holds a CU (151 KB of LDS) for a whole search: at most one game per CU.  k_delta_res holds half a CU and its
+    // workgroups depend on nothing outside their game: a batch beyond two per CU runs in ROUNDS, the dispatcher handing a CU's free half
+    // to the next game of the grid as a search ends (1024 / 1536 games: two / three rounds of 512, the chip full throughout)
+    if (dev.n_games > net->store_boards || (!delta_res && dev.n_games > net->n_cus))
+        return net_fail(RZ_ERR_ARG, "the resident search runs one workgroup per game, at most one per CU (any number with rz_net_delta_reserve) and rz_net_deferred_reserve()d");
     if (rows ? (net->vf_groups != 64 && net->vf_groups != 128) : net->vf_groups > 64) return net_fail(RZ_ERR_INTERNAL, "value head groups");
     ResArgs<true> res;
     res.E = dev;

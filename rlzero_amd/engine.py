@@ -413,8 +413,9 @@ class HipNetEvaluator(object):
 
     def resident_ok(self, eng):
         n_cus = self.hip.torch.cuda.get_device_properties(self.hip.device).multi_processor_count
+        # (k_delta_res takes any number of games: beyond two per CU the launch runs in rounds; plan_lanes says when that pays)
         return (self.resident_search and self.deferred_ok(eng) and self.hip.supports_resident()
-                and eng.n_games <= (2 if self.resident_delta_ok(eng) else 1) * n_cus)
+                and (self.resident_delta_ok(eng) or eng.n_games <= n_cus))
 
     def search_resident(self, eng, n_sims, select_first=False):
         want = self.resident_delta_ok(eng)

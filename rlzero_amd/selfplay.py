@@ -172,7 +172,8 @@ def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False, cells=None, i
     and columns): the resident search holds TWO games per CU (k_delta_res: 82 KB of LDS), so up to 2 x CUs games -- the 512 per GPU of
     BASELINE.json configs[3] -- are ONE launch per search on ONE lane: one game's serial tree walk runs under the other game's matrix
     work on the same CU, and no hardware-queue layout is involved (round 6, same box: 512 games 18.95 M on one lane, 17.0 M on two,
-    13.7 M on the four lanes of the two-launch step; profiles/r06/NOTES.md).
+    13.7 M on the four lanes of the two-launch step; profiles/r06/NOTES.md).  From 3 x CUs games on the same single lane again, the
+    grid running in rounds of 2 x CUs workgroups (1024 .. 4096 games: 18.4 .. 18.8 M; profiles/r06/ab_rounds.txt).
 
     ``cells``: positions of the board, when known.  Boards of at most 42 cells on the split-f16 trunk (Connect4, 6x6: the
     two-launch step with a 12-us trunk and a 10-us tree step) run TWO lanes above one round of boards (Connect4, M simulations / s on
@@ -209,7 +210,12 @@ def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False, cells=None, i
     if cells is not None and cells <= 100 and in_flight > 1 and n_games >= 2 * n_cus:
         return (4 if (n_games >= 4 * n_cus and hw_queues >= 8) else 3), 0, 'parts'
     if deferred:
-        if resident_per_cu >= 2 and n_games <= 2 * n_cus:   # two games per CU: the resident search with the receptive-field trunk, one lane
+        if resident_per_cu >= 2 and (n_games <= 2 * n_cus or n_games >= 3 * n_cus):
+            # two games per CU: the resident search with the receptive-field trunk, one lane -- and from 1.5 rounds of two per CU on
+            # again: the launch's workgroups depend on nothing outside their game, so a bigger grid runs in ROUNDS, a CU's free half
+            # going to the next game as a search ends (profiles/r06/ab_rounds.txt, M simulations / s, one resident lane against the
+            # lanes below: 576 games 12.4 / 14.0, 640 13.6 / 14.5, 768 14.6 / 12.6, 1024 18.8 / 11.9, 1536 18.6 / 14.0, 2048 18.4 / 16.1,
+            # 4096 18.4 / 16.9 -- between one and 1.5 rounds the second round is too empty and four lanes of the two-launch step win)
             return 1, 0, 'auto'
         if n_games <= n_cus:   # one game per CU at most: the resident search (one launch per search, a workgroup per game) --
             # on TWO lanes from half a round of boards on, so that a lane's host step runs under the other lane's search

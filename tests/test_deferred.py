@@ -278,6 +278,49 @@ def test_resident_search_is_the_two_launch_step_in_one_launch():
                 assert a == b, (rows, cols)
 
 
+def test_resident_search_beyond_two_games_per_cu_runs_in_rounds():
+    """k_delta_res takes a grid beyond the two workgroups a CU holds (rz_net_search_resident: any number of games with the base cache
+    reserved): the dispatcher hands a CU's free half to the next game as a search ends, and no game sees another -- 800 games (a full
+    round of 512 and a partial one on 256 CUs) over two moves with tree reuse leave the root visits of the two-launch step on every
+    game, and its whole trees on a sample of them, bit for bit."""
+    import torch
+    from rlzero_amd.engine import HipNetEvaluator, MCTSEngine
+    B, n_row, sims, G = 12, 5, 24, 800
+    n_cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert G > 3 * n_cus or n_cus != 256
+    net = _net(B, seed=21)
+    envs = _positions(B, n_row, G, seed=4)
+    sample = list(range(0, G, 37)) + [G - 1]
+    dumps = {}
+    for resident in (True, False):
+        evaluator = HipNetEvaluator(net, B, 'cuda:0', max_boards=G)
+        evaluator.resident_search = resident
+        eng = MCTSEngine(B, n_row, n_games=G, n_playout=sims, device='cuda:0', add_noise=True, noise_seed=9)
+        assert evaluator.resident_ok(eng) == resident and evaluator.deferred_ok(eng) and evaluator.resident_delta_ok(eng)
+        _set_roots(eng, envs)
+        eng.set_noise_keys()
+        record = []
+        for move in range(2):
+            eng.simulate(evaluator, sims, use_graph=False)
+            visits = eng.root_visits()
+            record.append(visits.copy())
+            record.append([_whole_tree(eng, g) for g in sample])
+            playing = visits.sum(axis=1) > 0
+            moves = np.where(playing, visits.argmax(axis=1), -2).astype(np.int32)
+            eng.advance(moves)
+            _, ended = eng.step(np.where(moves >= 0, moves, -1).astype(np.int32))
+            eng.set_active((playing & (np.asarray(ended) == 0)).astype(np.uint8))
+        if resident:
+            st = evaluator.hip.delta_stats()
+            assert st['delta'] > 10 * st['no_base'] > -1   # (k_delta_res ran, its leaves against their roots' bases: a rare deep one takes the passes without)
+        assert eng.check().reuse_dropped == 0
+        dumps[resident] = record
+        eng.close()
+        evaluator.hip.close()
+    for a, b in zip(dumps[True], dumps[False]):
+        assert np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b
+
+
 def test_two_engines_sharing_one_evaluator():
     """An evaluator's feature store holds the pending leaves of one engine at a time: when a second engine searches with the same
     evaluator the first one's priors are written first, so interleaved searches leave the trees they would leave alone."""

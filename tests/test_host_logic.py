@@ -137,7 +137,9 @@ def test_plan_lanes():
     # the receptive-field trunk: the resident search holds two games per CU -- up to 2 x CUs games are one lane, whatever the queues
     r = lambda n, q=8: plan_lanes(n, hw_queues=q, deferred=True, resident_per_cu=2)   # noqa: E731
     assert r(512) == (1, 0, 'auto') and r(512, 4) == (1, 0, 'auto') and r(256) == (1, 0, 'auto') and r(1) == (1, 0, 'auto')
-    assert r(513)[0] == 4 and r(1536)[0] == 2 and plan_lanes(512, hw_queues=8, resident_per_cu=2)[0] == 4   # (beyond, and off the deferred route: the table)
+    assert r(513)[0] == 4 and r(704)[0] == 4 and r(767)[0] == 2 and plan_lanes(512, hw_queues=8, resident_per_cu=2)[0] == 4   # (between one and 1.5 rounds, and off the deferred route: the table)
+    assert r(768)[0] == 1 and r(1024)[0] == 1 and r(1536)[0] == 1 and r(4096)[0] == 1   # (from 1.5 rounds on: one lane, the launch runs in rounds)
+    assert plan_lanes(1536, hw_queues=8, deferred=True)[0] == 2   # (one resident workgroup per CU: no rounds)
     assert plan_lanes(128, n_cus=64, hw_queues=8, deferred=True, resident_per_cu=2)[0] == 1
 
 

@@ -420,9 +420,13 @@ def launch_ranks(n):
 def delta_resident_per_cu(args):
     """Resident workgroups a CU holds on the run's route: two of the receptive-field kernel (k_delta_res: the default trunk on boards of
     11 .. 16 rows and columns, unless RZ_NET_DELTA / RZ_NET_DELTA_RESIDENT / RZ_RESIDENT switch it off), one otherwise."""
-    on = (getattr(args, 'net_algo', 'split_f16') == 'split_f16' and os.environ.get('RZ_NET_DELTA', '1') != '0'
-          and os.environ.get('RZ_NET_DELTA_RESIDENT', '1') != '0' and os.environ.get('RZ_RESIDENT') != '0')
-    return 2 if on else 1
+    if getattr(args, 'net_algo', 'split_f16') != 'split_f16' or os.environ.get('RZ_RESIDENT') == '0':
+        return 1
+    rows, cols = (6, 7) if getattr(args, 'game', 'gomoku') == 'connect4' else (args.board, args.board)
+    if 11 <= rows <= 16:
+        return 2 if (os.environ.get('RZ_NET_DELTA', '1') != '0' and os.environ.get('RZ_NET_DELTA_RESIDENT', '1') != '0') else 1
+    from rlzero_amd.engine import compact_grid_board   # (boards of the compact LDS grid: k_trunk_split<RES> holds two games per CU as well)
+    return 2 if compact_grid_board(rows, cols) else 1
 
 
 class TimedEvaluator(object):
@@ -829,7 +833,7 @@ def main():
                        and args.score_mode == 'uct_ref' and args.in_flight <= 1)
         lanes = plan_lanes((args.games if args.games > 0 else GAMES_PER_GPU) * max(1, args.in_flight), n_cus, deferred=will_defer,
                            cells=cells if (small_trunk or args.in_flight > 1) else None, in_flight=max(1, args.in_flight),
-                           resident_per_cu=delta_resident_per_cu(args) if will_defer else 1)[0]
+                           resident_per_cu=delta_resident_per_cu(args) if (will_defer or small_trunk) else 1)[0]
     trunk_wgs = max(0, args.trunk_wgs)
     # default batch: the 512 games per GPU of BASELINE.json configs[3] (4096 games over 8 GPUs), as four lanes of 128
     G = args.games if args.games > 0 else GAMES_PER_GPU
@@ -859,7 +863,7 @@ def main():
             if os.environ.get('RZ_RESIDENT') == '0':   # (profiles/ab_resident.sh: the two-launch step on a batch the resident search would take)
                 hip_ev.resident_search = False
             deferred_route = hip_ev.deferred_ok(eng)
-            resident_route = (lanes == 1 or G <= n_cus * (2 if hip_ev.resident_delta_ok(eng) else 1)) and hip_ev.resident_ok(eng)   # (BatchedSelfPlay switches it off for lanes that share CUs)
+            resident_route = (lanes == 1 or G <= n_cus * hip_ev.resident_per_cu(eng)) and hip_ev.resident_ok(eng)   # (BatchedSelfPlay switches it off for lanes that share CUs)
             ev = TimedEvaluator(hip_ev, torch,
                                 {'winograd_f4': 'k_trunk_wino_f4<4>',
                                  'split_f16': 'k_trunk_rows' if (args.game == 'gomoku' and 11 <= board <= 16) else 'k_trunk_split',

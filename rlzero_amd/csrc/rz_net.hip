@@ -3442,8 +3442,11 @@ int rz_net_search_resident(rz_net *net, rz_engine *engine, int32_t n_sims, int32
     // k_trunk_rows_res holds a CU (151 KB of LDS) for a whole search: at most one game per CU.  k_delta_res holds half a CU and its
     // workgroups depend on nothing outside their game: a batch beyond two per CU runs in ROUNDS, the dispatcher handing a CU's free half
     // to the next game of the grid as a search ends (1024 / 1536 games: two / three rounds of 512, the chip full throughout)
-    if (dev.n_games > net->store_boards || (!delta_res && dev.n_games > net->n_cus))
-        return net_fail(RZ_ERR_ARG, "the resident search runs one workgroup per game, at most one per CU (any number with rz_net_delta_reserve) and rz_net_deferred_reserve()d");
+    // (small boards on the compact LDS grid, launch_trunk's condition: 69 KB, two workgroups per CU -- the same freedom)
+    const bool compact_res = !rows && tiles <= 2 && net->compact_grid && net->dev.BW <= 7 && tiles * net->dev.tile_rows + 2 <= 15;
+    if (dev.n_games > net->store_boards || (!delta_res && !compact_res && dev.n_games > net->n_cus))
+        return net_fail(RZ_ERR_ARG, "the resident search runs one workgroup per game, at most one per CU (any number with rz_net_delta_reserve, or on a board of "
+                                    "the compact grid) and rz_net_deferred_reserve()d");
     if (rows ? (net->vf_groups != 64 && net->vf_groups != 128) : net->vf_groups > 64) return net_fail(RZ_ERR_INTERNAL, "value head groups");
     ResArgs<true> res;
     res.E = dev;
@@ -3473,6 +3476,12 @@ int rz_net_search_resident(rz_net *net, rz_engine *engine, int32_t n_sims, int32
     if (!rows) {   // (the launches of launch_trunk for these boards, RES instantiations)
         _Float16 *store = net->d_store16;
         const int ng = dev.n_games;
+        if (compact_res && (2 * ng > net->n_cus || net->compact_always)) {   // two games per CU (launch_trunk's rule: from half a chip of boards on)
+            if (tiles <= 1) k_trunk_split<1, 4, true, 9, 15><<<grid, dim3(256), 0, st>>>(net->dev, nullptr, leaves, nullptr, store, ng, net->d_flags, nullptr, nullptr, later, res);
+            else k_trunk_split<1, 2, true, 9, 15><<<grid, dim3(256), 0, st>>>(net->dev, nullptr, leaves, nullptr, store, ng, net->d_flags, nullptr, nullptr, later, res);
+            if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of the resident search (compact grid) failed");
+            return RZ_OK;
+        }
         if (tiles <= 1) k_trunk_split<1, 4, true><<<grid, dim3(256), 0, st>>>(net->dev, nullptr, leaves, nullptr, store, ng, net->d_flags, nullptr, nullptr, later, res);
         else if (tiles <= 2) k_trunk_split<1, 2, true><<<grid, dim3(256), 0, st>>>(net->dev, nullptr, leaves, nullptr, store, ng, net->d_flags, nullptr, nullptr, later, res);
         else if (tiles == 3 && net->dev.tile_rows == 3) k_trunk_split<1, 3, true><<<grid, dim3(256), 0, st>>>(net->dev, nullptr, leaves, nullptr, store, ng, net->d_flags, nullptr, nullptr, later, res);

@@ -94,6 +94,17 @@ PARAM_ORDER = ('conv1.weight', 'conv1.bias', 'conv2.weight', 'conv2.bias', 'conv
                'val_fc2.weight', 'val_fc2.bias')
 
 
+
+def compact_grid_board(rows, cols):
+    """The boards k_trunk_split has a compact LDS grid for (rz_net.hip: launch_trunk / rz_net_search_resident): N-tiles of
+    min(32 // cols, 16) rows, at most two of them, at most 7 columns, tile rows + the halo inside 15 grid rows."""
+    if os.environ.get('RZ_NET_COMPACT', '1') == '0' or cols > 7 or cols < 1:
+        return False
+    tile_rows = min(32 // cols, 16)
+    tiles = (rows + tile_rows - 1) // tile_rows
+    return tiles <= 2 and tiles * tile_rows + 2 <= 15
+
+
 class HipNet(object):
     """The hand-written fused fp32-MFMA forward (csrc/rz_net.hip) of a PolicyValueNet."""
 
@@ -218,6 +229,12 @@ class HipNet(object):
         ghz = (256.0 * out[6]) / (10.0 * out[7]) if out[7] else None   # (cycles per nanosecond of the last resident launch's workgroup 0)
         return {'delta': int(out[0]), 'no_base': int(out[1]), 'tiles3': int(out[2]), 'cells': int(out[3]), 'tiles2': int(out[4]),
                 'resident_sclk_ghz': ghz}
+
+    def compact_resident(self):
+        """Boards whose resident search runs on the COMPACT LDS grid (k_trunk_split<.., RES, 9, 15>: 69 KB, TWO games per CU and any
+        number of games per launch): rz_net_search_resident's rule -- at most two N-tiles, at most 7 columns, tile rows + halo within 15
+        (3x3 .. 7x7, Connect4's 6x7); RZ_NET_COMPACT=0 switches the grid off."""
+        return compact_grid_board(self.rows, self.cols) and self.supports_resident()
 
     def supports_resident(self):
         """True when whole searches can run as ONE launch, one workgroup per game (rz_net_search_resident)."""
@@ -415,7 +432,12 @@ class HipNetEvaluator(object):
         n_cus = self.hip.torch.cuda.get_device_properties(self.hip.device).multi_processor_count
         # (k_delta_res takes any number of games: beyond two per CU the launch runs in rounds; plan_lanes says when that pays)
         return (self.resident_search and self.deferred_ok(eng) and self.hip.supports_resident()
-                and (self.resident_delta_ok(eng) or eng.n_games <= n_cus))
+                and (self.resident_per_cu(eng) >= 2 or eng.n_games <= n_cus))
+
+    def resident_per_cu(self, eng):
+        """Resident workgroups a CU holds: two of k_delta_res (boards of 11 .. 16 rows and columns) and of the compact-grid kernel (boards
+        of up to 7 columns), one otherwise.  With two, a launch takes ANY number of games: beyond 2 x CUs it runs in rounds."""
+        return 2 if (self.resident_delta_ok(eng) or (self.hip.compact_resident() and eng.rows == self.hip.rows and eng.cols == self.hip.cols)) else 1
 
     def search_resident(self, eng, n_sims, select_first=False):
         want = self.resident_delta_ok(eng)

@@ -205,6 +205,12 @@ def plan_lanes(n_games, n_cus=256, hw_queues=None, deferred=False, cells=None, i
     ones once the 'parts' GEMM existed)."""
     if hw_queues is None:
         from . import HW_QUEUES as hw_queues
+    if cells is not None and cells <= 49 and n_cus < n_games <= 2 * n_cus and in_flight <= 1 and resident_per_cu >= 2:
+        # boards of the compact LDS grid (up to 7 columns; HipNet.compact_resident): the resident search holds two games per CU --
+        # one launch per search on one lane up to 2 x CUs games (profiles/r06/ab_compact_resident.txt, M simulations / s against
+        # the two lanes below: Connect4 384 games 19.8 / 17.1, 512 games 24.8 / 21.3; 6x6 512 games 26.5 / 22.5).  Beyond, a
+        # partial second round costs more than the lanes' overlap (768 games 21.2 / 24.7; 1024 25.7 / 25.0; 2048 26.5 / 27.6)
+        return 1, 0, 'auto'
     if cells is not None and cells <= 42 and n_games > n_cus and in_flight <= 1:
         return 2, 0, 'parts'
     if cells is not None and cells <= 100 and in_flight > 1 and n_games >= 2 * n_cus:
@@ -343,10 +349,10 @@ class BatchedSelfPlay(object):
             offset += eng.n_games
         n_cus = torch.cuda.get_device_properties(engines[0].device).multi_processor_count
 
-        def per_cu(ev, eng):   # resident workgroups a CU holds: two of the receptive-field kernel (k_delta_res), one otherwise
+        def per_cu(ev, eng):   # resident workgroups a CU holds: two of the receptive-field kernel (k_delta_res) and of the compact grid's
             inner = getattr(ev, 'inner', ev)
-            ok = getattr(inner, 'resident_delta_ok', None)
-            return 2 if (ok is not None and ok(eng)) else 1
+            fn = getattr(inner, 'resident_per_cu', None)
+            return fn(eng) if fn is not None else 1
         if len(engines) > 1 and sum(e.n_games for e in engines) > n_cus * min(per_cu(ev, e) for ev, e in zip(evaluators, engines)):
             # lanes that share CUs: the resident search (a workgroup keeps its CU for a whole search) is for games that have a CU
             # each -- these lanes run the two-launch step, whose trunk workgroups make way for the other lanes every step
@@ -407,9 +413,12 @@ class BatchedSelfPlay(object):
         import os
         delta_res = (deferred and resident_search is not False and delta_trunk is not False and net_algo in (None, 'split_f16')
                      and os.environ.get('RZ_NET_DELTA', '1') != '0' and os.environ.get('RZ_NET_DELTA_RESIDENT', '1') != '0')
+        from .engine import compact_grid_board
+        compact_res = (small_trunk and not deferred and resident_search is not False and net_algo in (None, 'split_f16')
+                       and max(rows0, cols0) <= 10 and compact_grid_board(rows0, cols0))
         auto_lanes, auto_wgs, heads_algo = plan_lanes(n_games * K, n_cus, deferred=deferred,
                                                       cells=rows0 * cols0 if (small_trunk or K > 1) else None, in_flight=K,
-                                                      resident_per_cu=2 if delta_res else 1)
+                                                      resident_per_cu=2 if (delta_res or compact_res) else 1)
         measured = None
         if lanes == 'table':
             lanes = None

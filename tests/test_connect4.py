@@ -283,3 +283,45 @@ def test_connect4_search_routes_agree():
         assert np.array_equal(x[0], y[0]) and x[1] == y[1]
         assert [{k: (n, float(w).hex()) for k, (n, w) in t.items()} for t in x[2]] == \
             [{k: (n, float(w).hex()) for k, (n, w) in t.items()} for t in y[2]]
+
+
+@pytest.mark.gpu
+def test_connect4_resident_search_on_the_compact_grid_in_rounds():
+    """BASELINE configs[2]'s batch and beyond on ONE lane: 600 Connect4 games are a launch of 600 workgroups of the resident search on the
+    compact LDS grid, two per CU, the last 88 in a second round.  Visit counts of every game and the trees of a sample equal the two-launch
+    step's over two moves with tree reuse, bit for bit; the games start from different openings."""
+    import torch
+    from rlzero_amd.engine import HipNetEvaluator
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    torch.manual_seed(5)
+    net = PolicyValueNet(6, 7, 7)
+    G, sims = 600, 40
+    rs = np.random.RandomState(2)
+    openings = rs.randint(0, 7, size=(2, G)).astype(np.int32)
+    out = {}
+    for resident in (True, False):
+        evaluator = HipNetEvaluator(net, (6, 7, 7), 'cuda:0', max_boards=G)
+        evaluator.resident_search = resident
+        eng = _engine(n_games=G, n_playout=sims, add_noise=True, noise_seed=8)
+        assert evaluator.resident_ok(eng) == resident and evaluator.deferred_ok(eng) and evaluator.resident_per_cu(eng) == 2
+        eng.reset_games()
+        for ply in range(2):
+            eng.advance(openings[ply])   # (nothing searched yet: a fresh root each time)
+            eng.step(openings[ply])
+        eng.set_noise_keys()
+        record = []
+        for move in range(2):
+            eng.simulate(evaluator, sims, use_graph=False)
+            visits = eng.root_visits()
+            record.append((visits.copy(), [eng.tree_dump(g) for g in range(0, G, 41)]))
+            moves = visits.argmax(axis=1).astype(np.int32)
+            eng.advance(moves)
+            eng.step(moves)
+        eng.check()
+        out[resident] = record
+        eng.close()
+        evaluator.hip.close()
+    for x, y in zip(out[True], out[False]):
+        assert np.array_equal(x[0], y[0])
+        assert [{k: (n, float(w).hex()) for k, (n, w) in t.items()} for t in x[1]] == \
+            [{k: (n, float(w).hex()) for k, (n, w) in t.items()} for t in y[1]]

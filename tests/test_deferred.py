@@ -321,6 +321,48 @@ def test_resident_search_beyond_two_games_per_cu_runs_in_rounds():
         assert np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b
 
 
+@pytest.mark.parametrize('B,n_row,G', [(6, 4, 300), (3, 3, 300), (7, 5, 560)])
+def test_resident_search_on_the_compact_grid(B, n_row, G):
+    """Boards of up to 7 columns: from half a chip of games on the resident search runs on k_trunk_split's COMPACT LDS grid (69 KB: two
+    games per CU, any number of games per launch -- 560 games are a full round and a partial one).  The grid changes where a position
+    lives in LDS, not one product: root visits on every game and whole trees on a sample equal the two-launch step's bit for bit over two
+    moves with tree reuse (300 games of 6x6: two N-tiles; 3x3: one; 7x7: two, in rounds)."""
+    import torch
+    from rlzero_amd.engine import HipNetEvaluator, MCTSEngine
+    n_cus = torch.cuda.get_device_properties(0).multi_processor_count
+    sims = 30
+    net = _net(B, seed=B)
+    base = _positions(B, n_row, 40, seed=B + 1)
+    envs = [base[i % len(base)] for i in range(G)]
+    sample = list(range(0, G, 29)) + [G - 1]
+    dumps = {}
+    for resident in (True, False):
+        evaluator = HipNetEvaluator(net, B, 'cuda:0', max_boards=G)
+        evaluator.resident_search = resident
+        eng = MCTSEngine(B, n_row, n_games=G, n_playout=sims, device='cuda:0', add_noise=True, noise_seed=3)
+        assert evaluator.hip.compact_resident() and evaluator.resident_per_cu(eng) == 2
+        assert evaluator.resident_ok(eng) == resident and evaluator.deferred_ok(eng) and 2 * G > n_cus
+        _set_roots(eng, envs)
+        eng.set_noise_keys()   # (a noise stream per game: games on the same root still search differently)
+        record = []
+        for move in range(2):
+            eng.simulate(evaluator, sims, use_graph=False)
+            visits = eng.root_visits()
+            record.append(visits.copy())
+            record.append([_whole_tree(eng, g) for g in sample])
+            playing = visits.sum(axis=1) > 0
+            moves = np.where(playing, visits.argmax(axis=1), -2).astype(np.int32)
+            eng.advance(moves)
+            _, ended = eng.step(np.where(moves >= 0, moves, -1).astype(np.int32))
+            eng.set_active((playing & (np.asarray(ended) == 0)).astype(np.uint8))
+        assert eng.check().reuse_dropped == 0
+        dumps[resident] = record
+        eng.close()
+        evaluator.hip.close()
+    for a, b in zip(dumps[True], dumps[False]):
+        assert np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b
+
+
 def test_two_engines_sharing_one_evaluator():
     """An evaluator's feature store holds the pending leaves of one engine at a time: when a second engine searches with the same
     evaluator the first one's priors are written first, so interleaved searches leave the trees they would leave alone."""

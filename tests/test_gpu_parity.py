@@ -352,11 +352,12 @@ def test_full_size_batches_of_the_baseline_configs(config):
         lane.eng.close()
 
 
-@pytest.mark.parametrize('n_games,score_mode,forced_lanes', [(512, 'uct_ref', 0), (512, 'uct_ref', 4), (1536, 'uct_ref', 0), (512, 'puct', 0), (256, 'uct_ref', 0)])
+@pytest.mark.parametrize('n_games,score_mode,forced_lanes', [(512, 'uct_ref', 0), (512, 'uct_ref', 4), (1536, 'uct_ref', 0), (1536, 'uct_ref', 2), (512, 'puct', 0), (256, 'uct_ref', 0)])
 def test_full_size_shipped_layout_equals_one_plain_lane(n_games, score_mode, forced_lanes):
     """The layouts bench.py times at FULL size (15x15, 800 simulations per move) -- 512 games (BASELINE.json configs[3]'s share of a GPU)
     and 256: ONE lane of the resident search with the receptive-field trunk, two games per CU, one launch per search (k_delta_res);
-    1536 games (the batch that fills a GPU): two lanes of the two-launch step with that trunk (k_trunk_delta), hipGraphs of 16 steps;
+    1536 games: the same single lane, its launch of 1536 workgroups running in three rounds of two per CU -- and (forced: the layout
+    before the rounds) two lanes of the two-launch step with that trunk (k_trunk_delta), hipGraphs of 16 steps;
     512 games on FOUR such lanes (forced: the shipped layout of round 5); the opt-in PUCT rule: four lanes of the three-launch step
     with the full-board trunk -- the host side of a lane's move pipelined under the other lanes' simulations -- against ONE lane
     launched kernel by kernel with the FULL-BOARD trunk on every leaf (k_trunk_rows) and every move finished on the host before
@@ -377,7 +378,7 @@ def test_full_size_shipped_layout_equals_one_plain_lane(n_games, score_mode, for
         if shipped:
             import rlzero_amd
             assert rlzero_amd.HW_QUEUES >= 8   # (claimed on import, before this process touched the GPU)
-            one_resident_lane = score_mode == 'uct_ref' and n_games <= 512 and not forced_lanes
+            one_resident_lane = score_mode == 'uct_ref' and not forced_lanes
             assert len(sp.lanes) == (forced_lanes or (1 if one_resident_lane else 4 if n_games == 512 else 2)) and sp.trunk_workgroups == 0 and sp.use_graph
             resident = [lane.evaluator.resident_ok(lane.eng) for lane in sp.lanes]
             assert resident == [one_resident_lane] * len(sp.lanes)

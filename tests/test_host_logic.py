@@ -141,6 +141,14 @@ def test_plan_lanes():
     assert r(768)[0] == 1 and r(1024)[0] == 1 and r(1536)[0] == 1 and r(4096)[0] == 1   # (from 1.5 rounds on: one lane, the launch runs in rounds)
     assert plan_lanes(1536, hw_queues=8, deferred=True)[0] == 2   # (one resident workgroup per CU: no rounds)
     assert plan_lanes(128, n_cus=64, hw_queues=8, deferred=True, resident_per_cu=2)[0] == 1
+    # boards of the compact LDS grid (Connect4, 6x6, 7x7): two resident games per CU -> one lane up to 2 x CUs games, the lanes beyond
+    c = lambda n, cells=42, per_cu=2: plan_lanes(n, hw_queues=8, cells=cells, resident_per_cu=per_cu)   # noqa: E731
+    assert c(512) == (1, 0, 'auto') and c(384)[0] == 1 and c(257)[0] == 1 and c(512, 49)[0] == 1 and c(512, 36)[0] == 1
+    assert c(513)[0] == 2 and c(1024)[0] == 2 and c(512, per_cu=1)[0] == 2 and c(256)[0] == 1
+    assert c(512, 81)[0] == 4   # (9x9 has no compact grid: the table)
+    from rlzero_amd.engine import compact_grid_board
+    assert all(compact_grid_board(r, k) for r, k in ((6, 7), (6, 6), (3, 3), (7, 7), (5, 5)))
+    assert not any(compact_grid_board(r, k) for r, k in ((9, 9), (8, 8), (15, 15), (10, 10)))
 
 
 def test_lanes_by_measurement_fallback():

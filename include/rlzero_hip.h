@@ -533,8 +533,9 @@ int rz_net_trace_attach(rz_net *net, void *d_trace);   /* see rz_trace_attach */
 int rz_net_delta_reserve(rz_net *net, int32_t n_games);
 int rz_net_delta_invalidate(rz_net *net, void *stream);
 /* rz_net_search_resident on these boards, once the cache holds the engine's games: the resident search with THIS trunk (k_delta_res:
- * 82 KB of LDS, two games per CU -- up to 2 x CUs games in one launch; the bases of the roots are built by the call itself when
- * select_first != 0).  on = 0: the full-board resident kernel (one game per CU) as before.  Default: on. */
+ * 82 KB of LDS, two games per CU, ANY number of games per launch -- a workgroup depends on nothing outside its game, so a grid beyond
+ * 2 x CUs runs in rounds, a CU's free half going to the next game as a search ends; the bases of the roots are built by the call itself
+ * when select_first != 0).  on = 0: the full-board resident kernel (one game per CU, at most CUs games) as before.  Default: on. */
 int rz_net_delta_resident(rz_net *net, int32_t on);
 int rz_net_delta_bases(rz_net *net, const uint64_t *d_root_stones, const int32_t *d_root_to_move, int32_t n_games, void *stream);
 int rz_net_delta_leaves(rz_net *net, const uint64_t *d_stones, const int32_t *d_to_move, const int32_t *d_last_cell, int32_t n_boards,
@@ -551,8 +552,11 @@ int rz_net_delta_step(rz_net *net, rz_engine *engine, rz_value_head *out, void *
 int rz_net_delta_stats(rz_net *net, uint32_t *h_out8, int32_t reset);
 /* RESIDENT SEARCH -- n_sims consecutive simulations of every active game of `engine` (AlphaZeroMCTS.simulate's loop,
  * alphazero_mcts.py:82-85) in ONE launch, one workgroup per game: trunk -> value head -> expand / backup -> next selection without
- * a kernel boundary, the leaf handed from the tree code to the trunk through LDS.  For batches of at most one game per CU (the
- * single-game API, BASELINE configs[0] and [1]).  The deferred-priors route's arithmetic and bookkeeping: the first leaf comes from
+ * a kernel boundary, the leaf handed from the tree code to the trunk through LDS.  Kernels that hold a whole CU (151 KB of LDS: boards
+ * of 8 .. 10 rows, and 11 .. 16 without rz_net_delta_reserve) take at most one game per CU (the single-game API, BASELINE configs[0]
+ * and [1]); the two that hold half a CU -- k_delta_res (above; configs[3]) and k_trunk_split on the compact LDS grid (boards of up to 7
+ * columns, 69 KB: TicTacToe .. 7x7, Connect4's 6x7 = configs[2]; used from half a chip of games on) -- take any number of games, two per
+ * CU at a time.  The deferred-priors route's arithmetic and bookkeeping: the first leaf comes from
  * rz_select_step(engine, NULL, ..) before the call (select_first == 0: a search continued in pieces) or is selected by the launch
  * itself (select_first != 0: the same selection by the same code, one launch less); rz_net_deferred_gemm + rz_deferred_flush later;
  * the engine's slots advance by n_sims.  Same trees, values and priors as rz_net_trunk_leaves_deferred + rz_tree_step_deferred, bit for bit.

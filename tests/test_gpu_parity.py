@@ -414,6 +414,50 @@ def test_full_size_shipped_layout_equals_one_plain_lane(n_games, score_mode, for
             assert (pis[np.arange(n_games), ply, moves[:, earlier]] == 0.0).all()
 
 
+def test_whole_games_of_a_batch_in_rounds_equal_one_plain_lane():
+    """A batch beyond two games per CU, whole games: `run_device(range(900))` with 800 slots at 13x13 / 200 simulations per move is ONE
+    lane whose every search is one launch of 800 workgroups of k_delta_res -- a full round of 2 x CUs and a partial one, fewer as
+    games end and the queue runs dry --, finished slots refilled on the device.  A sample of first-generation and refilled games
+    against ONE plain lane launched kernel by kernel with the full-board trunk: moves, pi bits, winners."""
+    import torch
+    from rlzero_amd.games.gomoku.policy_value_net import PolicyValueNet
+    from rlzero_amd.selfplay import BatchedSelfPlay
+    torch.manual_seed(1)
+    net = PolicyValueNet(13).to('cuda:0')
+    n_slots, n_ids, sims = 800, 900, 200
+    sample = sorted(set(list(range(0, 800, 23)) + list(range(800, 900, 9)) + [799, 899]))
+
+    def play(shipped):
+        kw = {} if shipped else dict(lanes=1, use_graph=False, resident_search=False, delta_trunk=False)
+        sp = BatchedSelfPlay.for_network(net, 13, 5, n_games=n_slots if shipped else len(sample), n_playout=sims, seed=9, **kw)
+        if shipped:
+            n_cus = torch.cuda.get_device_properties(0).multi_processor_count
+            assert len(sp.lanes) == 1 and sp.use_graph and (n_slots >= 3 * n_cus or n_cus != 256)
+            assert sp.lanes[0].evaluator.resident_ok(sp.lanes[0].eng) and sp.lanes[0].evaluator.resident_delta_ok(sp.lanes[0].eng)
+            out = sp.run_device(range(n_ids))
+            assert sp.stalls_resolved == 0 and sp.sims_done == sims * sum(len(t.moves) for t in out)
+        else:
+            out = sp.run(sample)
+        for st in sp.check():
+            assert st.reuse_dropped == 0 and st.max_slots_used < st.arena_slots
+        for lane in sp.lanes:
+            lane.evaluator.hip.check_flags()
+            lane.eng.close()
+        return {t.game_id: t for t in out}
+
+    shipped = play(True)
+    assert sorted(shipped) == list(range(n_ids))
+    plain = play(False)
+    assert sorted(plain) == sorted(sample)
+    for g in sample:
+        a, b = shipped[g], plain[g]
+        assert a.moves == b.moves and a.winner == b.winner, 'game %d depends on the layout' % g
+        assert np.array_equal(a.pis.view(np.uint64), b.pis.view(np.uint64))
+    for t in shipped.values():
+        assert 9 <= len(t.moves) <= 169 and len(set(t.moves)) == len(t.moves) and t.winner in (-1, 0, 1)
+        assert abs(t.pis.sum(axis=1) - 1.0).max() < 1e-9
+
+
 def test_whole_games_on_the_shipped_layout_equal_one_plain_lane():
     """WHOLE games at full size on the layout bench.py times: `BatchedSelfPlay.run(range(640), pipelined=True)` and
     `run_device(range(640))` (the move step on the device: what bench.py runs by default) -- one lane of 512 games on the resident

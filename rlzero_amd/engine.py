@@ -628,7 +628,9 @@ class MCTSEngine(object):
                                # per-root work (HipNetEvaluator's receptive-field bases) compare it with the epoch they computed for
         # deferred priors: the evaluator whose store holds this engine's pending leaves, steps since the last flush, capacity
         self._def_ev, self._def_pending, self._def_slots, self._def_slot_ptr, self._capturing = None, 0, 0, None, False
-        self.deferred_max_bytes = 6 << 30   # cap of an evaluator's store + logits (a flush every slots steps when n_playout needs more)
+        # cap of an evaluator's store + logits (a flush every slots steps when n_playout needs more): a whole 800-simulation search of
+        # 4096 games is 15 GB of 288 -- below the cap the search is one launch and the move one hipGraph (19 MB per slot at 4096 games)
+        self.deferred_max_bytes = 32 << 30
 
     # ------------------------------------------------------------------ plumbing
     def stream(self):

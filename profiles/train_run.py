@@ -42,7 +42,7 @@ def timed_play(ids, **kw):
 
 
 pipe._play_games = timed_play
-for i, n in enumerate((G, G, 4 * G, 8 * G)):
+for i, n in enumerate((G, G, 4 * G, 8 * G, 16 * G)):
     spent['play'] = 0.0
     t0 = time.perf_counter()
     pipe.collect_selfplay_data(n)

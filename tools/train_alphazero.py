@@ -315,10 +315,11 @@ class TrainPipeline:
         with open(os.path.join(os.environ['RZ_TRAIN_TRACE'], 'rank%d.jsonl' % self.rank), 'a') as f:
             f.write(json.dumps(rec) + '\n')
 
-    def _collect_batched(self, n_games):
+    def _collect_batched(self, n_games, consume=None):
         """One collection round: ``n_games`` games in all, game g played by rank g mod world (selfplay.shard_game_ids),
         one gather to rank 0 (pi as float32: what the learner consumes).  -> start_self_play's tuples on rank 0, in game
-        id order; [] on the other ranks."""
+        id order; [] on the other ranks.  ``consume`` (one rank): called with every game's tuple IN GAME-ID ORDER as soon as the game
+        and all games before it have ended -- while the GPU plays the others --; the tuples it took are not returned."""
         from rlzero.algorithms import gather_trajectories
         ids = range(self._next_game_id, self._next_game_id + n_games)
         self._next_game_id += n_games
@@ -328,28 +329,35 @@ class TrainPipeline:
             return [t.as_reference_tuple() for t in merged] if merged is not None else []
         # one rank: every finished game becomes start_self_play's tuple (planes from its move list) WHILE the others are played --
         # behind an idle GPU that was a tenth of a round; the round's order stays the game ids'
-        ready = {}
+        ready, cursor = {}, [ids.start]
 
         def take(trajs):
             for t in trajs:
                 ready[t.game_id] = t.as_reference_tuple()
+            while consume is not None and cursor[0] in ready:   # (the replay buffer's order is the reference's: game by game)
+                consume(ready.pop(cursor[0]))
+                cursor[0] += 1
         local = self._play_games(list(ids), on_finished=take)
-        return [ready[t.game_id] if t.game_id in ready else t.as_reference_tuple() for t in sorted(local, key=lambda t: t.game_id)]
+        rest = [t for t in sorted(local, key=lambda t: t.game_id) if t.game_id >= cursor[0] or consume is None]
+        return [ready[t.game_id] if t.game_id in ready else t.as_reference_tuple() for t in rest]
 
     def collect_selfplay_data(self, n_games=1):
         """collect self-play data for training."""
-        if self.selfplay_games_in_flight > 0:
-            games = self._collect_batched(max(n_games, self.selfplay_games_in_flight * self.world))
-        else:
-            games = [self.game.start_self_play(self.mcts_player, temperature=self.temperature)
-                     for _ in range(n_games)]
-        for winner, play_data in games:
+        def consume(game):
+            winner, play_data = game
             play_data = list(play_data)
             self.episode_len = len(play_data)
             if os.environ.get('RZ_TRAIN_EAGER_SYMMETRIES') == '1':   # (the eight symmetries of every sample up front, as before round 6)
                 self.data_buffer.extend(self.get_equi_data(play_data))
             else:
                 self.data_buffer.extend_samples(play_data)
+        if self.selfplay_games_in_flight > 0:
+            games = self._collect_batched(max(n_games, self.selfplay_games_in_flight * self.world), consume=consume)
+        else:
+            games = [self.game.start_self_play(self.mcts_player, temperature=self.temperature)
+                     for _ in range(n_games)]
+        for game in games:
+            consume(game)
 
     # ------------------------------------------------------------------ learning
     def policy_update(self):

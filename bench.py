@@ -1275,6 +1275,16 @@ def main():
                     rf['trunk_workgroup_us'] = rf['us_per_simulation_of_a_game']   # (a workgroup's trunk windows + value head + tree step of ONE leaf: the resident kernel has no trunk launch of its own)
                 rf['board_power_w'] = power.mean()
                 line['roofline'] = rf
+                if args.game == 'gomoku' and board == 15:
+                    # the tree code has no launch of its own any more (it is the serial part of k_delta_res' workgroups): its ALGORITHMIC
+                    # bytes (7.86 KB per simulation in the reference's dense formulation) over the same launch -- what
+                    # north_star calls the tree traversal's fraction of the HBM roofline; the launch's counter traffic is `roofline.traffic`
+                    per_sim = tree_bytes_per_sim(365.5, 208.8, 1.74)
+                    gbs = per_sim * G * args.playouts / (rt['search_ms'] * 1e-3) / 1e9
+                    line['roofline_tree'] = {'bound': 'hbm', 'kernel': 'the tree code inside k_delta_res (expand_backup_body + select_body of rz_tree.h, one wave per game)',
+                                             'achieved': round(gbs, 2), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 5),
+                                             'traffic': None, 'avg_launch_ms': round(rt['search_ms'], 4),
+                                             'note': 'latency-bound by construction: ~20 k of a simulation\'s 58 k cycles are one wave walking one tree (profiles/r06/delta_resident_phases.txt)'}
             elif resident_timing:
                 line['roofline']['resident_timing_error'] = resident_timing.get('error')
         else:

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RZ_ABI_VERSION 25
+#define RZ_ABI_VERSION 26
 #define RZ_MAX_BOARD_SIZE 16
 #define RZ_BOARD_WORDS 4 /* 4 x 64 bits >= 16*16 cells */
 #define RZ_MAX_IN_FLIGHT 16 /* rz_config.sims_in_flight */
@@ -546,6 +546,11 @@ int rz_net_delta_leaves(rz_net *net, const uint64_t *d_stones, const int32_t *d_
  * step on its leaves (board b = game b, store slot pend[b], inactive games skipped).  One simulation in flight per tree. */
 int rz_net_delta_bases_engine(rz_net *net, rz_engine *engine, void *stream);
 int rz_net_delta_step(rz_net *net, rz_engine *engine, rz_value_head *out, void *stream);
+/* ... and rz_net_trunk_leaves' step on its leaves: the features into the internal buffer's f16 tiles (policy and value K-steps),
+ * rz_net_heads_gemm next -- the three-launch step (the opt-in PUCT rule) with this trunk.  One simulation in flight per tree;
+ * RZ_NET_HEADS_F32 is refused (it reads f32 features).  Replaces the same reference lines as rz_net_trunk_leaves
+ * (policy_value_net.py:34-46 on gomoku_env.py:95-114's planes). */
+int rz_net_delta_trunk_engine(rz_net *net, rz_engine *engine, void *stream);
 /* counters since the last reset (synchronises): {leaves evaluated against a base, leaves without one, conv3 tiles of 16 cells, changed
  * cells, conv2 tiles of 16 cells, 0, and -- of workgroup 0 of the LAST resident launch -- its shader-clock cycles >> 8 and its ticks
  * of the constant 100 MHz clock: the clock the search ran at = 256 [6] / (10 ns [7])} */

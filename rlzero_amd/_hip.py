@@ -8,7 +8,7 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_int, c_int32, c_int64, c_uint32, c_uint64,
                     c_void_p)
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 BOARD_WORDS = 4
 MAX_BOARD_SIZE = 16
 MAX_IN_FLIGHT = 16
@@ -165,6 +165,7 @@ _SIGNATURES = {
     'rz_net_delta_stats': (c_int, [P, POINTER(ctypes.c_uint32), c_int32]),
     'rz_net_delta_bases_engine': (c_int, [P, P, P]),
     'rz_net_delta_step': (c_int, [P, P, POINTER(RzValueHead), P]),
+    'rz_net_delta_trunk_engine': (c_int, [P, P, P]),
     'rz_net_heads': (c_int, [P, c_int32, P, P, P]),
     'rz_net_heads_gemm': (c_int, [P, c_int32, POINTER(RzRawHeads), P]),
     'rz_net_forward': (c_int, [P, P, c_int32, P, P, P]),

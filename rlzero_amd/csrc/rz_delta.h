@@ -790,6 +790,8 @@ __global__ __launch_bounds__(256, 2) void k_trunk_delta(NetDev nd, LeafBits leav
         leaf.dst16 = (feat16 != nullptr && slot_ < later.n_slots) ? feat16 + (size_t)slot_ * later.slot_halfs + (size_t)(board >> 5) * nd.groups_act * 1024 + (board & 31) * 16 : nullptr;
         leaf.vdst = later.valfeat + (size_t)board * later.vf_ld;
     }
+    if (mode != 1 && !deferred && feat16 != nullptr)   // rz_net_delta_trunk_engine: the FC GEMM's own tiles (policy and value K-steps), as trunk_rows_body writes them
+        leaf.dst16 = feat16 + ((size_t)(board >> 5) * (nd.groups_act + nd.groups_val) * 1024 + (board & 31) * 16);
     leaf.dst32 = (mode != 1 && da.feat32 != nullptr) ? da.feat32 + (size_t)board * 6 * S : nullptr;
     leaf.deferred = deferred;
     leaf.store_head = true;

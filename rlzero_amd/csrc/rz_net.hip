@@ -3621,6 +3621,32 @@ int rz_net_delta_step(rz_net *net, rz_engine *engine, rz_value_head *out, void *
     return rz_net_delta_leaves(net, dev.leaf_stones, dev.leaf_to_move, dev.leaf_last, dev.n_games, dev.pend, dev.active, nullptr, 0, out, stream);
 }
 
+// rz_net_trunk_leaves on the engine's leaves through the receptive-field kernel: the features go to the internal buffer's f16 tiles
+// (policy and value K-steps of the FC GEMM: rz_net_heads_gemm next) -- the three-launch step (PUCT) on boards of 11 .. 16 rows.
+int rz_net_delta_trunk_engine(rz_net *net, rz_engine *engine, void *stream) {
+    rzt::Dev dev;
+    int rc = rz_device_view(engine, &dev, (int64_t)sizeof(dev));
+    if (rc != RZ_OK) return rc;
+    if ((rc = net_ready(net, dev.n_games)) != RZ_OK) return rc;
+    if (!delta_covers(net)) return net_fail(RZ_ERR_ARG, "receptive-field evaluation: RZ_NET_SPLIT_F16 on boards of 11 .. 16 rows and columns");
+    if (dev.K != 1) return net_fail(RZ_ERR_ARG, "rz_net_delta_trunk_engine: one simulation in flight per tree (a base per game)");
+    if (dev.BH != net->dev.BH || dev.BW != net->dev.BW) return net_fail(RZ_ERR_ARG, "engine and network disagree on the board");
+    if (dev.n_games > net->base_games) return net_fail(RZ_ERR_ARG, "more games than rz_net_delta_reserve()d");
+    if (dev.n_games > net->feat_boards) return net_fail(RZ_ERR_ARG, "batch larger than rz_net_reserve()d");
+    if (net->heads_algo == RZ_NET_HEADS_F32) return net_fail(RZ_ERR_ARG, "rz_net_delta_trunk_engine writes the f16 tiles only (RZ_NET_HEADS_F32 reads f32 features: rz_net_trunk_leaves)");
+    net->feat16_valid = true;
+    net->feat32_valid = false;
+    net->raw_from_trunk = false;
+    net->dev.feat_ld = 16 * (net->dev.groups_act + net->dev.groups_val);
+    net->dev.feat_val_off = 16 * net->dev.groups_act;
+    const DeferredOut later{nullptr, 0, nullptr, 0, nullptr, 0};
+    dl::DeltaArgs da{net->d_base_hdr, net->d_base_recs, dev.active, nullptr, net->d_delta_stats, 0, (65536 + net->dev.BW - 1) / net->dev.BW};
+    dl::k_trunk_delta<false><<<dim3((unsigned)dev.n_games), dim3(256), 0, (hipStream_t)stream>>>(
+        net->dev, LeafBits{dev.leaf_stones, dev.leaf_to_move, dev.leaf_last}, net->d_feat16, dev.n_games, later, da);
+    if (hipGetLastError() != hipSuccess) return net_fail(RZ_ERR_HIP, "launch of k_trunk_delta failed");
+    return RZ_OK;
+}
+
 int rz_net_delta_stats(rz_net *net, uint32_t *h_out8, int32_t reset) {
     if (!net || !h_out8) return net_fail(RZ_ERR_ARG, "NULL argument");
     memset(h_out8, 0, 8 * sizeof(uint32_t));

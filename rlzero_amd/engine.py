@@ -221,6 +221,10 @@ class HipNet(object):
         check(self.lib.rz_net_delta_step(self.handle, eng.handle, ctypes.byref(out), self._stream()), 'rz_net_delta_step')
         return out
 
+    def delta_trunk_engine(self, eng):
+        """trunk_leaves on the engine's leaves through the receptive-field kernel: the FC GEMM's f16 tiles (heads_gemm next)."""
+        check(self.lib.rz_net_delta_trunk_engine(self.handle, eng.handle, self._stream()), 'rz_net_delta_trunk_engine')
+
     def delta_stats(self, reset=False):
         """{'delta': leaves evaluated against a base, 'no_base': leaves that took the four passes, 'tiles3' / 'tiles2': conv3 / conv2 tiles of
         16 cells, 'cells': changed cells, 'resident_sclk_ghz': the shader clock the last resident search ran at}"""
@@ -401,7 +405,7 @@ class HipNetEvaluator(object):
     def prepare_search(self, eng):
         """Before the steps of a search of ``eng``: the bases of its CURRENT roots (the engine counts what moves them: roots_epoch).
         Cheap when nothing moved.  A missed call costs time only: a leaf whose base is stale takes the kernel's route without one."""
-        if not self.deferred_ok(eng) or not self.delta_ok(eng) or eng._capturing:
+        if not self.delta_ok(eng) or eng.sims_in_flight != 1 or eng._capturing or not (self.deferred_ok(eng) or self.delta_three_launch_ok(eng)):
             return
         key = (id(eng), eng.roots_epoch, id(eng.handle))
         if getattr(self, '_delta_key', None) == key:
@@ -450,8 +454,19 @@ class HipNetEvaluator(object):
             eng._drop_graphs('rz_net_delta_reserve moved the base cache')
         self.hip.search_resident(eng, n_sims, select_first)
 
+    def delta_three_launch_ok(self, eng):
+        """The three-launch step (trunk -> FC GEMM -> tree step: the PUCT rule, or deferred_priors = False) with the receptive-field
+        trunk: positions, one simulation in flight per tree, the f16 FC GEMM."""
+        return (self.delta_ok(eng) and not self.needs_obs and eng.sims_in_flight == 1 and not self.deferred_ok(eng)
+                and getattr(self.hip, 'heads_algo', 'auto') != 'f32')
+
     def raw_heads(self, eng):
         if not self.needs_obs:
+            if self.delta_three_launch_ok(eng):
+                self.prepare_search(eng)   # (nothing while a graph is captured: the eager steps before a capture reserve the cache)
+                if getattr(self.hip, '_delta_games', 0) >= eng.n_games:
+                    self.hip.delta_trunk_engine(eng)
+                    return self.hip.heads_gemm(eng.n_leaves)
             self.hip.trunk_leaves(eng)
         else:
             self.hip.trunk_internal(eng.obs)

@@ -363,6 +363,51 @@ def test_resident_search_on_the_compact_grid(B, n_row, G):
         assert np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b
 
 
+@pytest.mark.parametrize('score_mode', ['puct', 'uct_ref'])
+def test_three_launch_step_on_the_receptive_field_trunk(score_mode):
+    """The three-launch step (trunk -> FC GEMM -> tree step: the opt-in PUCT rule, and UCT_REF with deferred_priors = False) on boards of
+    11 .. 16 rows evaluates its leaves by receptive fields too (rz_net_delta_trunk_engine: the FC GEMM's own f16 tiles, policy and value
+    K-steps): whole trees -- N, W bits, priors bits -- equal the full-board trunk's over three moves with tree reuse, noise, an idle
+    slot; and the counters say the kernel ran against bases."""
+    from rlzero_amd.engine import HipNetEvaluator, MCTSEngine
+    for B, sims in ((15, 70), (12, 50)):
+        net = _net(B, seed=B + 40)
+        envs = _positions(B, 5, 9, seed=B)
+        dumps = {}
+        for delta in (True, False):
+            evaluator = HipNetEvaluator(net, B, 'cuda:0', max_boards=len(envs))
+            evaluator.delta_trunk = delta
+            evaluator.deferred_priors = False
+            eng = MCTSEngine(B, 5, n_games=len(envs), n_playout=sims, device='cuda:0', add_noise=True, noise_seed=6, score_mode=score_mode)
+            assert not evaluator.deferred_ok(eng) and evaluator.delta_three_launch_ok(eng) == delta
+            _set_roots(eng, envs)
+            eng.set_noise_keys()
+            active = np.ones(len(envs), dtype=np.uint8)
+            active[2] = 0
+            eng.set_active(active)
+            record = []
+            for move in range(3):
+                eng.simulate(evaluator, sims, use_graph=False)   # (hipGraph replays of this step: the full-size layout test's PUCT case)
+                visits = eng.root_visits()
+                record.append(visits.copy())
+                record.append([_whole_tree(eng, g) for g in range(len(envs))])
+                playing = (active > 0) & (visits.sum(axis=1) > 0)
+                moves = np.where(playing, visits.argmax(axis=1), -2).astype(np.int32)
+                eng.advance(moves)
+                _, ended = eng.step(np.where(moves >= 0, moves, -1).astype(np.int32))
+                active = (playing & (np.asarray(ended) == 0)).astype(np.uint8)
+                eng.set_active(active)
+            eng.check()
+            if delta:
+                st = evaluator.hip.delta_stats()
+                assert st['delta'] > 10 * st['no_base'] and st['delta'] > sims
+            dumps[delta] = record
+            eng.close()
+            evaluator.hip.close()
+        for a, b in zip(dumps[True], dumps[False]):
+            assert np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b, (B, score_mode)
+
+
 def test_two_engines_sharing_one_evaluator():
     """An evaluator's feature store holds the pending leaves of one engine at a time: when a second engine searches with the same
     evaluator the first one's priors are written first, so interleaved searches leave the trees they would leave alone."""

@@ -651,8 +651,8 @@ def run_muzero(args, rank, world, device, dist, red_device, use_dist=False, cpu_
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=4)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)   # (moves per timed region: a 22-ms move makes five regions of 20 a 2-s measurement; with 4 the
+    ap.add_argument('--warmup', type=int, default=5)   # fence at a region's end -- synchronize, the host reads the last log rows -- is 3 % of it)
     ap.add_argument('--cpu-worker', type=float, default=None, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-seconds', type=float, default=60.0,
                     help='wall-clock budget of the CPU baseline of the main workload (SURVEY.md 8d: >= 60 s); the '

@@ -889,6 +889,9 @@ __device__ __forceinline__ float other_half(float x, int h) {
 // prologue (weights into registers, LDS zeroing) paid once per launch instead of once per simulation, no kernel boundary inside a
 // search.  The tree code is the engine's own (rz_tree.h: the bodies of k_tree_step_def), the policy features go to the deferred
 // store like in the two-launch step, so trees, priors and values are those of that route bit for bit.
+#ifndef RZ_SPLIT_TREE_PRIO
+#define RZ_SPLIT_TREE_PRIO 1   // k_trunk_split<RES> on the compact grid (two games per CU): issue priority of the tree phase
+#endif
 template <bool RES> struct ResArgs {};
 template <> struct ResArgs<true> {
     rzt::Dev E;          // the engine's device view (rz_device_view)
@@ -1514,6 +1517,9 @@ __global__ __launch_bounds__(256, (RW == kRowW ? 1 : 2)) void k_trunk_split(NetD
         // ---- the rest of the simulation, by the same workgroup (see k_trunk_rows: the body of k_tree_step_def, rz_tree.h)
         __syncthreads();   // the value head's inputs are in LDS
         const int game = blockIdx.x;
+        // (two workgroups per CU -- the compact grid --: the serial part of a simulation ahead of the other game's trunk waves at issue,
+        // as in k_delta_res)
+        if (RW != kRowW && RZ_SPLIT_TREE_PRIO) __builtin_amdgcn_s_setprio(RZ_SPLIT_TREE_PRIO);
         if (res.vh.groups == 64) rzt::value_quarter_lds<8>(res.vh, res_vrow, lane, wave, res_part);
         else if (res.vh.groups == 32) rzt::value_quarter_lds<4>(res.vh, res_vrow, lane, wave, res_part);
         else rzt::value_quarter_lds<2>(res.vh, res_vrow, lane, wave, res_part);
@@ -1524,6 +1530,7 @@ __global__ __launch_bounds__(256, (RW == kRowW ? 1 : 2)) void k_trunk_split(NetD
         NET_TICK(17);
         const bool more = sim + 1 < res_sims(res);
         if (wave == 0 && more) rzt::select_body<false, kResWords>(res.E, nullptr, game, lane, 0, res_leaf);
+        if (RW != kRowW && RZ_SPLIT_TREE_PRIO) __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         NET_TICK(18);
         if (more) {   // the planes of the next leaf, from LDS: what load_bits forms from the leaf arrays

@@ -81,4 +81,40 @@ for B, G, sims in ((15, 700, 150), (11, 560, 100), (12, 300, 120), (13, 520, 100
           '%.2f conv3 / %.2f conv2 tiles and %.2f changed cells per leaf; %.1f s' % (
               B, B, G, sims, len(sample), leaves, stats['no_base'], 100.0 * stats['no_base'] / max(1, leaves), stats['tiles3'] / max(1, leaves),
               stats['tiles2'] / max(1, leaves), stats['cells'] / max(1, leaves), time.time() - t0), flush=True)
+
+# ---- small boards: the resident search on the compact LDS grid (two games per CU, rounds) against the two-launch step on the 18 x 18 grid
+for B, n_row, G, sims in ((3, 3, 700, 25), (5, 4, 600, 60), (6, 4, 600, 100), (7, 5, 560, 100), (6, 4, 130, 200)):
+    t0 = time.time()
+    net = T._net(B, seed=300 + B)
+    base = T._positions(B, n_row, 120, seed=B * 11 + G)
+    envs = [base[i % len(base)] for i in range(G)]
+    sample = list(range(0, G, max(1, G // 24)))
+    dumps = {}
+    for shipped in (True, False):
+        ev = HipNetEvaluator(net, B, 'cuda:0', max_boards=G)
+        ev.resident_search = shipped
+        eng = MCTSEngine(B, n_row, n_games=G, n_playout=sims, device='cuda:0', add_noise=True, noise_seed=B)
+        assert ev.resident_ok(eng) == shipped and ev.resident_per_cu(eng) == 2
+        T._set_roots(eng, envs)
+        eng.set_noise_keys()
+        rec = []
+        for move in range(4):
+            eng.simulate(ev, sims, use_graph=False)
+            visits = eng.root_visits()
+            rec.append(visits.copy())
+            rec.append([T._whole_tree(eng, g) for g in sample])
+            playing = visits.sum(axis=1) > 0
+            moves = np.where(playing, visits.argmax(axis=1), -2).astype(np.int32)
+            eng.advance(moves)
+            _, ended = eng.step(np.where(moves >= 0, moves, -1).astype(np.int32))
+            eng.set_active((playing & (np.asarray(ended) == 0)).astype(np.uint8))
+        eng.check()
+        dumps[shipped] = rec
+        eng.close()
+        ev.hip.close()
+    for a, b in zip(dumps[True], dumps[False]):
+        assert np.array_equal(a, b) if isinstance(a, np.ndarray) else a == b, 'board %d: the routes differ' % B
+    total += G * sims * 4
+    print('%dx%d (n = %d) %4d games x %3d simulations x 4 moves, compact-grid resident search against the two-launch step: equal (visits of every game, '
+          '%d whole trees per move); %.1f s' % (B, B, n_row, G, sims, len(sample), time.time() - t0), flush=True)
 print('soak ok: %d leaves' % total)

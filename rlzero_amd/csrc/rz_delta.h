@@ -53,7 +53,7 @@ constexpr int kHeadW = 128 * 6 * 4 + 128 * 4 + 32;   // the 1 x 1 head convoluti
 // (the planes: the hi pieces only -- the lo pieces of 0 / 1 planes are zero and conv1 skips their products)
 constexpr int kOffC1 = sp::kInPieceBytes, kOffC2 = kOffC1 + kC1Slots * P1, kOffZero = kOffC2 + kC2Slots * P2, kOffHead = kOffZero + P2,
               kOffMap1 = kOffHead + kHeadW, kOffMap2 = kOffMap1 + kGrid * 4, kOffList = kOffMap2 + kGrid * 4, kOffCnt = kOffList + 3 * 128 * 2,
-              kOffListR = kOffCnt + 5 * 4 * 4, kLdsBytes = kOffListR + ((kC1Slots + kC2Slots + 15) / 16) * 16;   // (listR: the cells of the held records, a byte each)
+              kLdsBytes = kOffCnt + 5 * 4 * 4;
 static_assert(kShareFloats * 4 <= kC1Slots * P1, "the shares lie inside conv1's records (dead behind conv2)");
 static_assert(2 * (kLdsBytes + 512 * 4 + 4 * 64 * 4 + 80 + 512) <= 160 * 1024, "two workgroups per CU, also of the resident search (value row, K-quarter sums, leaf)");
 static_assert(kOffC1 % 16 == 0 && kOffZero % 16 == 0 && kOffHead % 16 == 0 && kOffMap1 % 16 == 0, "alignment");
@@ -347,7 +347,6 @@ __device__ __forceinline__ int delta_passes(const NetDev &nd, const DeltaArgs &d
     uint32_t *map1 = reinterpret_cast<uint32_t *>(lds + kOffMap1), *map2 = reinterpret_cast<uint32_t *>(lds + kOffMap2);
     uint16_t *list1 = reinterpret_cast<uint16_t *>(lds + kOffList), *list2 = list1 + 128, *list3 = list2 + 128;
     int *cnt = reinterpret_cast<int *>(lds + kOffCnt);   // [5 sets][4 waves]
-    uint8_t *listR1 = reinterpret_cast<uint8_t *>(lds + kOffListR), *listR2 = listR1 + kC1Slots;
     float *shares = reinterpret_cast<float *>(c1);
     const int mode = da.mode, BH = nd.BH, BW = nd.BW, S = nd.S;
     const float k1 = ly.k1, k2 = ly.k2, k3 = ly.k3, act1 = ly.act1, act2 = ly.act2, act3 = ly.act3;
@@ -460,42 +459,6 @@ __device__ __forceinline__ int delta_passes(const NetDev &nd, const DeltaArgs &d
         if (pass <= 0 && is_cell) *reinterpret_cast<f16x4 *>(in0 + ((cy + 1) * sp::kInCols + (cx + 1)) * 8) = cell_planes;
         if (pass <= 0 && store_head && tid < 226) reinterpret_cast<f32x4 *>(headw)[tid] = headv;
         asm volatile("" ::"v"(touch));
-#ifndef RZ_DELTA_GATHER_BALANCED
-#define RZ_DELTA_GATHER_BALANCED 0
-#endif
-#if RZ_DELTA_GATHER_BALANCED
-        // the base's records, copied by ALL threads: record r of a layer's held set is 8 / 16 chunks of 16 bytes, chunk c of the set goes
-        // to thread c mod 256 (a wave copies whole records: coalesced) -- ~14 loads a thread where the held cells' own threads (fewer
-        // than half of the workgroup) issued 24 each.  Cells the leaf recomputes are copied too; their layers overwrite them.
-        if (pass < 0) {
-            if (f[3]) listR1[rank[3]] = (uint8_t)tid;
-            if (f[4]) listR2[rank[4]] = (uint8_t)tid;
-            __syncthreads();
-            constexpr int I2 = (kC2Slots * 16 + 255) / 256, I1 = (kC1Slots * 8 + 255) / 256;
-            const int n2c = tot[4] * 16, n1c = tot[3] * 8;
-            f32x4 q2[I2], q1[I1];
-#pragma unroll
-            for (int i = 0; i < I2; ++i) {
-                const int c = tid + 256 * i, cc = c < n2c ? c : 0;
-                q2[i] = *reinterpret_cast<const f32x4 *>(base + kBaseC2 + (size_t)listR2[cc >> 4] * 256 + (cc & 15) * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < I1; ++i) {
-                const int c = tid + 256 * i, cc = c < n1c ? c : 0;
-                q1[i] = *reinterpret_cast<const f32x4 *>(base + (size_t)listR1[cc >> 3] * 128 + (cc & 7) * 16);
-            }
-#pragma unroll
-            for (int i = 0; i < I2; ++i) {
-                const int c = tid + 256 * i;
-                if (c < n2c) *reinterpret_cast<f32x4 *>(c2 + (c >> 4) * P2 + (c & 15) * 16) = q2[i];
-            }
-#pragma unroll
-            for (int i = 0; i < I1; ++i) {
-                const int c = tid + 256 * i;
-                if (c < n1c) *reinterpret_cast<f32x4 *>(c1 + (c >> 3) * P1 + (c & 7) * 16) = q1[i];
-            }
-        }
-#else
         if (g1) {
             const f32x4 *src = reinterpret_cast<const f32x4 *>(base + (size_t)tid * 128);
             f32x4 r1[8];
@@ -512,7 +475,6 @@ __device__ __forceinline__ int delta_passes(const NetDev &nd, const DeltaArgs &d
 #pragma unroll
             for (int i = 0; i < 16; ++i) *(lds_v4)(uintptr_t)(rec2 + 16 * i) = r2[i];
         }
-#endif
         __builtin_amdgcn_sched_barrier(0);   // (the requests below stay behind the stores of the base's records: their 96 registers are free again)
         f16x8 a2[9][1][2];   // conv2's weight fragments: requested here, conv1 -- one wave's work -- covers their latency
         {
@@ -849,7 +811,7 @@ __global__ __launch_bounds__(256, 2) void k_delta_res(NetDev nd, _Float16 *__res
     if (game >= res.E.n_games || res.E.active[game] == 0) return;   // (uniform: before any barrier)
     const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
     const int tid0 = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
-    const int BW = nd.BW, S = nd.S;
+    const int BW = nd.BW;
     Prof prof;
 #ifdef RZ_NET_PROFILE
     for (int i = 0; i < 24; ++i) prof.acc[i] = 0;

@@ -560,7 +560,7 @@ int rz_net_delta_stats(rz_net *net, uint32_t *h_out8, int32_t reset);
  * a kernel boundary, the leaf handed from the tree code to the trunk through LDS.  Kernels that hold a whole CU (151 KB of LDS: boards
  * of 8 .. 10 rows, and 11 .. 16 without rz_net_delta_reserve) take at most one game per CU (the single-game API, BASELINE configs[0]
  * and [1]); the two that hold half a CU -- k_delta_res (above; configs[3]) and k_trunk_split on the compact LDS grid (boards of up to 7
- * columns, 69 KB: TicTacToe .. 7x7, Connect4's 6x7 = configs[2]; used from half a chip of games on) -- take any number of games, two per
+ * columns, 69 KB: TicTacToe .. 7x7, Connect4's 6x7 = configs[2]) -- take any number of games, two per
  * CU at a time.  The deferred-priors route's arithmetic and bookkeeping: the first leaf comes from
  * rz_select_step(engine, NULL, ..) before the call (select_first == 0: a search continued in pieces) or is selected by the launch
  * itself (select_first != 0: the same selection by the same code, one launch less); rz_net_deferred_gemm + rz_deferred_flush later;
